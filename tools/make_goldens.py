@@ -1,0 +1,283 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference).
+
+Runs only in the build container (the reference does not exist on the GPU box).
+    python tools/make_goldens.py [--only NAME]
+Inputs and weights come from tdeed_amd.synth (seeded, hash-based), so fixtures hold
+only seeds + expected outputs.  Each fixture carries a json ``meta`` entry.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+import time
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from transformers import RegNetConfig, RegNetModel  # noqa: E402  (before the fake torchvision goes in)
+import ref_stubs  # noqa: E402
+ref_stubs.install()
+import tdeed_amd  # noqa: E402,F401
+from tdeed_amd import synth  # noqa: E402
+
+import model.modules as rmod  # noqa: E402  (reference)
+import model.impl.gsf as rgsf  # noqa: E402
+import model.impl.gsm as rgsm  # noqa: E402
+rgsm.ftens = torch.FloatTensor      # torch.cuda.FloatTensor crashes on CPU
+import model.model as rmodel  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def shapes_of(module):
+    return {k: (tuple(v.shape), "int64" if v.dtype == torch.int64 else "float32")
+            for k, v in module.state_dict().items()}
+
+
+def fill(module, seed, prefix=""):
+    sh = shapes_of(module)
+    st = synth.make_state({prefix + k: v for k, v in sh.items()}, seed)
+    module.load_state_dict({k: torch.from_numpy(st[prefix + k]) for k in sh})
+    return st
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def act(seed, name, shape, scale=1.0):
+    n = int(np.prod(shape))
+    return (synth.normalish(seed, name, n) * scale).reshape(shape).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- full model
+def full_model(name, cfg, B, H, W, seed_w=0, seed_x=1000, augment=False, taps=()):
+    args = types.SimpleNamespace(modality="rgb", temporal_arch="ed_sgp_mixer", pretrain=None, **cfg)
+    t0 = time.time()
+    m = rmodel.TDEEDModel(device="cpu", args=args)
+    fill(m._model, seed_w)
+    m._model.eval()
+    clip = synth.uint8_clip(seed_x, (B, cfg["clip_len"], 3, H, W))
+    x = torch.from_numpy(clip).float()
+    feats = {}
+    hooks = []
+
+    def mk(nm):
+        def hook(mod, inp, out):
+            feats[nm] = out.detach().numpy()
+        return hook
+    hooks.append(m._model._features.register_forward_hook(mk("pooled")))
+    hooks.append(m._model._temp_fine.register_forward_hook(mk("sgp_out")))
+    for tname in taps:
+        mod = m._model
+        for part in tname.split("."):
+            mod = getattr(mod, part)
+        hooks.append(mod.register_forward_hook(mk("tap:" + tname)))
+    pred, _ = m._model(x, inference=True, augment_inference=augment)
+    if isinstance(pred, dict):
+        logits, displ = pred["im_feat"].numpy(), pred["displ_feat"].numpy()
+    else:
+        logits, displ = pred.numpy(), np.zeros((0,), np.float32)
+    # the reference's own predict() post-processing on the same clip
+    cls, scores = m.predict(torch.from_numpy(clip), use_amp=False, augment_inference=augment)
+    for h in hooks:
+        h.remove()
+    Tn = cfg["clip_len"]
+    pooled = feats["pooled"].reshape(B, Tn, -1)
+    arrays = dict(logits=logits, displ=displ, pooled=pooled, sgp_out=feats["sgp_out"],
+                  predict_cls=cls.astype(np.int64), predict_scores=scores)
+    for k, v in feats.items():
+        if k.startswith("tap:"):
+            # taps are (B*T,C,h,w): keep channel means per frame + one full frame
+            arrays[k + ":mean_hw"] = v.mean(axis=(2, 3))
+            arrays[k + ":frame1"] = v[1]
+    meta = dict(kind="full_model", cfg=cfg, B=B, H=H, W=W, seed_w=seed_w, seed_x=seed_x, augment=augment,
+                n_params=int(sum(p.numel() for p in m._model.parameters())),
+                n_state=len(m._model.state_dict()), secs=round(time.time() - t0, 1),
+                layout_sha1=hashlib.sha1("\n".join(f"{k}:{tuple(v.shape)}" for k, v in m._model.state_dict().items())
+                                         .encode()).hexdigest())
+    save(name, meta, **arrays)
+    return m
+
+
+CFG_SMALL = dict(feature_arch="rny002_gsf", clip_len=100, crop_dim=224, n_layers=2, sgp_ks=7, sgp_r=4,
+                 num_classes=4, radi_displacement=2)
+CFG_BIG = dict(feature_arch="rny008_gsf", clip_len=100, crop_dim=224, n_layers=3, sgp_ks=7, sgp_r=4,
+               num_classes=4, radi_displacement=2)
+CFG_SNB = dict(feature_arch="rny008_gsf", clip_len=250, crop_dim=None, n_layers=2, sgp_ks=9, sgp_r=4,
+               num_classes=12, radi_displacement=4)
+
+
+def tiny(arch, T=16, **kw):
+    d = dict(feature_arch=arch, clip_len=T, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2,
+             num_classes=3, radi_displacement=2)
+    d.update(kw)
+    return d
+
+
+# ----------------------------------------------------------------------------- module level
+def mod_sgp_block(name, C, T, B, ks, r, seed=3):
+    blk = rmod.SGPBlock(C, kernel_size=ks, k=r, init_conv_vars=0.1).eval()
+    fill(blk, seed, "blk.")
+    x = act(seed, name + ":x", (B, C, T))
+    y = blk(torch.from_numpy(x)).numpy()
+    save(name, dict(kind="sgp_block", C=C, T=T, B=B, ks=ks, r=r, seed=seed, layout="B,C,T"), y=y)
+
+
+def mod_sgp_mixer(name, C, T_hi, T_lo, B, ks, r, seed=4):
+    mx = rmod.SGPMixer(C, kernel_size=ks, k=r, init_conv_vars=0.1, t_size=T_hi, concat=True).eval()
+    fill(mx, seed, "mix.")
+    z = act(seed, name + ":z", (B, C, T_hi))
+    x = act(seed, name + ":x", (B, C, T_lo))
+    y = mx(x=torch.from_numpy(x), z=torch.from_numpy(z)).numpy()
+    save(name, dict(kind="sgp_mixer", C=C, T_hi=T_hi, T_lo=T_lo, B=B, ks=ks, r=r, seed=seed, layout="B,C,T"), y=y)
+
+
+def mod_pyramid(name, C, L, n, B, ks, r, seed=5):
+    net = rmod.EDSGPMIXERLayers(C, L, num_layers=n, ks=ks, k=r, concat=True).eval()
+    fill(net, seed, "_temp_fine.")
+    x = act(seed, name + ":x", (B, L, C))
+    y = net(torch.from_numpy(x)).numpy()
+    save(name, dict(kind="pyramid", C=C, L=L, n=n, B=B, ks=ks, r=r, seed=seed, layout="B,T,C"), y=y)
+
+
+def mod_misc(name="misc_ops", seed=6):
+    out = {}
+    ln = rmod.LayerNorm(48).eval()
+    fill(ln, seed, "ln.")
+    x = act(seed, "ln:x", (2, 48, 25))
+    out["ln_y"] = ln(torch.from_numpy(x).clone()).numpy()
+    for (L, O) in [(25, 13), (125, 63), (100, 50), (13, 7)]:
+        x = act(seed, f"pool{L}:x", (2, 16, L))
+        out[f"pool_{L}_{O}"] = torch.nn.AdaptiveMaxPool1d(O)(torch.from_numpy(x)).numpy()
+    for (Lo, Hi) in [(13, 25), (25, 50), (63, 125), (50, 100)]:
+        x = act(seed, f"up{Lo}:x", (2, 16, Lo))
+        out[f"up_{Lo}_{Hi}"] = torch.nn.Upsample(size=Hi, mode="linear", align_corners=True)(torch.from_numpy(x)).numpy()
+    save(name, dict(kind="misc", seed=seed, ln_C=48, ln_T=25), **out)
+
+
+def mod_gate_shift(name, mode, F, T, B, h, w, seed=7):
+    cls = rgsf._GSF if mode == "gsf" else rgsm._GSM
+    gs = cls(F, T, 100).eval() if mode == "gsf" else cls(F, T).eval()
+    fill(gs, seed, "gs.")
+    x = act(seed, name + ":x", (B * T, F, h, w))
+    y = gs(torch.from_numpy(x)).numpy()
+    save(name, dict(kind="gate_shift", mode=mode, F=F, T=T, B=B, h=h, w=w, seed=seed, layout="N,C,H,W"), y=y)
+
+
+def mod_loss(name="loss_postproc", seed=8):
+    import torch.nn.functional as Fn
+    B, T, K1 = 3, 20, 5
+    logits = act(seed, "logits", (B, T, K1), 2.0)
+    displ = act(seed, "displ", (B, T), 1.5)
+    lab, labD = synth.labels(seed, B, T, K1 - 1, 2, fg_frac=0.3)
+    w = torch.FloatTensor([1] + [5] * (K1 - 1))
+    lg = torch.from_numpy(logits)
+    hard = Fn.cross_entropy(lg.reshape(-1, K1), torch.from_numpy(lab).flatten(), weight=w)
+    lam = synth.uniform01(seed, "lam", B)
+    lab2, labD2 = synth.labels(seed + 1, B, T, K1 - 1, 2, fg_frac=0.3)
+    soft = np.zeros((B, T, K1), np.float32)
+    for i in range(B):
+        soft[i, np.arange(T), lab[i]] += np.float32(lam[i])
+        soft[i, np.arange(T), lab2[i]] += np.float32(1 - lam[i])
+    softl = Fn.cross_entropy(lg.reshape(-1, K1), torch.from_numpy(soft).view(-1, K1), weight=w)
+    mse = Fn.mse_loss(torch.from_numpy(displ), torch.from_numpy(labD).float(), reduction="none").mean()
+    pp = rmod.process_prediction(lg, torch.from_numpy(displ)).numpy()
+    pdh = rmod.process_double_head(lg, torch.from_numpy(displ), num_classes=3).numpy()
+    pl = rmod.process_labels(torch.from_numpy(lab), torch.from_numpy(labD), num_classes=K1).numpy()
+    # displacement values exactly at .5 exercise round-half-to-even
+    d_half = np.tile(np.array([0.5, 1.5, -0.5, -1.5, 2.5], np.float32), (B, T // 5))
+    pp_half = rmod.process_prediction(lg, torch.from_numpy(d_half)).numpy()
+    save(name, dict(kind="loss", B=B, T=T, K1=K1, seed=seed, fg_weight=5),
+         ce_hard=hard.numpy(), ce_soft=softl.numpy(), mse=mse.numpy(), soft_labels=soft,
+         process_prediction=pp, process_double_head=pdh, process_labels=pl,
+         d_half=d_half, process_prediction_half=pp_half)
+
+
+def hf_regnet_crosscheck(name, arch, seed=9):
+    """Independent structural check of the RegNetY trunk restatement (timm is absent): HuggingFace's
+    RegNetYLayer stack, weights copied from the same synthetic state, same input -> pooled features."""
+    from tdeed_amd.regnet_spec import regnet_spec
+    spec = regnet_spec(arch)
+    cfg = RegNetConfig(num_channels=3, embedding_size=32, hidden_sizes=list(spec.widths), depths=list(spec.depths),
+                       groups_width=spec.gw, layer_type="y", hidden_act="relu")
+    hf = RegNetModel(cfg).eval()
+    ours = ref_stubs.RegNet(arch).eval()
+    st = fill(ours, seed, "_features.")
+    osd = ours.state_dict()
+    hsd = hf.state_dict()
+
+    def cp(dst, src):
+        assert hsd[dst].shape == osd[src].shape, (dst, src)
+        hsd[dst] = osd[src].clone()
+
+    def cbn(dst, src):
+        cp(dst + ".convolution.weight", src + ".conv.weight")
+        for a in ("weight", "bias", "running_mean", "running_var"):
+            cp(dst + ".normalization." + a, src + ".bn." + a)
+    cbn("embedder.embedder", "stem")
+    for b in spec.blocks:
+        d = f"encoder.stages.{b.stage - 1}.layers.{b.index - 1}"
+        s = b.name
+        cbn(d + ".layer.0", s + ".conv1")
+        cbn(d + ".layer.1", s + ".conv2")
+        cp(d + ".layer.2.attention.0.weight", s + ".se.fc1.weight")
+        cp(d + ".layer.2.attention.0.bias", s + ".se.fc1.bias")
+        cp(d + ".layer.2.attention.2.weight", s + ".se.fc2.weight")
+        cp(d + ".layer.2.attention.2.bias", s + ".se.fc2.bias")
+        cbn(d + ".layer.3", s + ".conv3")
+        if b.has_downsample:
+            cbn(d + ".shortcut", s + ".downsample")
+    hf.load_state_dict(hsd)
+    x = act(seed, name + ":x", (2, 3, 64, 64))
+    out = hf(torch.from_numpy(x)).pooler_output.flatten(1).numpy()
+    n_params = sum(p.numel() for p in ours.parameters())
+    save(name, dict(kind="hf_regnet", arch=arch, seed=seed, n_params_with_fc=int(n_params)), pooled=out)
+
+
+CASES = {
+    "misc_ops": lambda: mod_misc(),
+    "loss_postproc": lambda: mod_loss(),
+    "sgp_block_c32_t25": lambda: mod_sgp_block("sgp_block_c32_t25", 32, 25, 2, 5, 2),
+    "sgp_block_c368_t100": lambda: mod_sgp_block("sgp_block_c368_t100", 368, 100, 1, 7, 4),
+    "sgp_block_c48_t13": lambda: mod_sgp_block("sgp_block_c48_t13", 48, 13, 2, 9, 4),
+    "sgp_mixer_c32_t25": lambda: mod_sgp_mixer("sgp_mixer_c32_t25", 32, 25, 13, 2, 5, 2),
+    "sgp_mixer_c368_t100": lambda: mod_sgp_mixer("sgp_mixer_c368_t100", 368, 100, 50, 1, 7, 4),
+    "pyramid_c32_l25_n2": lambda: mod_pyramid("pyramid_c32_l25_n2", 32, 25, 2, 2, 5, 2),
+    "pyramid_c64_l100_n3": lambda: mod_pyramid("pyramid_c64_l100_n3", 64, 100, 3, 2, 7, 4),
+    "pyramid_c48_l250_n2": lambda: mod_pyramid("pyramid_c48_l250_n2", 48, 250, 2, 1, 9, 4),
+    "gsf_f16": lambda: mod_gate_shift("gsf_f16", "gsf", 16, 8, 2, 6, 6),
+    "gsf_f40": lambda: mod_gate_shift("gsf_f40", "gsf", 40, 6, 1, 5, 5),
+    "gsf_f92": lambda: mod_gate_shift("gsf_f92", "gsf", 92, 5, 1, 4, 4),
+    "gsm_f16": lambda: mod_gate_shift("gsm_f16", "gsm", 16, 8, 2, 6, 6),
+    "hf_regnet_rny002": lambda: hf_regnet_crosscheck("hf_regnet_rny002", "rny002"),
+    "hf_regnet_rny008": lambda: hf_regnet_crosscheck("hf_regnet_rny008", "rny008"),
+    "tiny_rny002_gsf": lambda: full_model("tiny_rny002_gsf", tiny("rny002_gsf"), 2, 64, 64,
+                                          taps=("_features.s3.b1", "_features.s4.b2")),
+    "tiny_rny008_gsf": lambda: full_model("tiny_rny008_gsf", tiny("rny008_gsf", n_layers=3, sgp_ks=7, sgp_r=4), 2, 64, 64),
+    "tiny_rny002_gsm": lambda: full_model("tiny_rny002_gsm", tiny("rny002_gsm"), 2, 64, 64),
+    "tiny_rny002_crop_flip": lambda: full_model("tiny_rny002_crop_flip", tiny("rny002_gsf", crop_dim=64, radi_displacement=0),
+                                                1, 72, 80, augment=True),
+    "finediving_small": lambda: full_model("finediving_small", CFG_SMALL, 1, 224, 224),
+    "finediving_big": lambda: full_model("finediving_big", CFG_BIG, 1, 224, 224),
+    "snb_t250": lambda: full_model("snb_t250", CFG_SNB, 1, 160, 160),
+}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    for k, fn in CASES.items():
+        if a.only and k not in a.only:
+            continue
+        print(k)
+        fn()
