@@ -1,0 +1,179 @@
+"""Headline benchmark: clips/s of the T-DEED forward (BASELINE.json configs[1]: RegNetY-200MF + GSF + SGP,
+L=100, 224x224, batch 8 per GPU, bf16 inference) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path (uint8 clips resident in HBM -> per-frame logits) over one batch
+of B synthetic clips per GPU.  Clips shard over ranks with no data-path collective (inference), so
+scaling is weak: value = N * B * K / max-over-ranks(time).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import tdeed_amd  # noqa: E402,F401
+from tdeed_amd import synth, state_layout, ops  # noqa: E402
+from tdeed_amd.engine import ForwardEngine  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[1] -- the configuration the metric is quoted on
+    "rny002_b8": dict(cfg=dict(feature_arch="rny002_gsf", clip_len=100, crop_dim=224, n_layers=2, sgp_ks=7, sgp_r=4,
+                               num_classes=4, radi_displacement=2), B=8, H=224, W=224),
+    "rny008_b16": dict(cfg=dict(feature_arch="rny008_gsf", clip_len=100, crop_dim=224, n_layers=3, sgp_ks=7, sgp_r=4,
+                                num_classes=4, radi_displacement=2), B=16, H=224, W=224),
+    "snb_t250_b4": dict(cfg=dict(feature_arch="rny008_gsf", clip_len=250, crop_dim=None, n_layers=2, sgp_ks=9, sgp_r=4,
+                                 num_classes=12, radi_displacement=4), B=4, H=224, W=224),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = {torch.bfloat16: 2500.0, torch.float32: 157.3}
+
+
+def kernel_profile(eng, plan, reps=3):
+    """Per-kernel-family device time, measured live with HIP events on the launch stream (eager replay
+    of the same launches the graph holds)."""
+    agg = {}
+    st = torch.cuda.current_stream()
+    for r in range(reps + 1):
+        evs = []
+        for s in plan.steps:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            s.fn()
+            b.record(st)
+            evs.append((s, a, b))
+        st.synchronize()
+        if r == 0:
+            continue                      # first pass warms caches / code objects
+        for s, a, b in evs:
+            d = agg.setdefault(s.kernel, dict(ms=0.0, launches=0, bytes=0, flops=0))
+            d["ms"] += a.elapsed_time(b)
+            d["launches"] += 1
+            d["bytes"] += s.bytes
+            d["flops"] += s.flops
+    for d in agg.values():
+        for k in ("ms", "launches", "bytes", "flops"):
+            d[k] = d[k] / reps
+    return agg
+
+
+def cpu_baseline():
+    """The oracle (our CPU port of the reference forward) timed on this host: BASELINE.json configs[0]
+    = FineDiving_small, 1 synthetic clip, fp32, all host cores.  Bounded: 1 warm-up + 3 timed clips."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.regnet_spec import regnet_spec
+    c = CONFIGS["rny002_b8"]["cfg"]
+    sd = O.as_torch_state(synth.make_state(state_layout.model_state_shapes(c), 0))
+    clip = torch.from_numpy(synth.uint8_clip(1000, (1, 100, 3, 224, 224)))
+    spec = regnet_spec(c["feature_arch"])
+    ts = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.perf_counter()
+            O.forward(clip, sd, c, spec)
+            ts.append(time.perf_counter() - t0)
+    best = sorted(ts[1:])[len(ts[1:]) // 2]
+    return dict(value=round(1.0 / best, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                sample="FineDiving_small forward, 1 synthetic clip (100x3x224x224), fp32, median of 3 after 1 warm-up",
+                sec_per_clip=round(best, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rny002_b8", choices=list(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = f"cuda:{local}"
+    wl = CONFIGS[a.workload]
+    cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    sd = synth.make_state(state_layout.model_state_shapes(cfg), 0)       # random-init weights of the architecture
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng = ForwardEngine(cfg, sd, dt, dev, use_graph=not a.no_graph)
+        plan = eng.plan(B, H, W)
+        T = cfg["clip_len"]
+        # synthetic uint8 clips, generated on the device straight into the plan's input buffer
+        plan.frames.copy_(ops.fill_u8_hash((B * T, 3, H, W), 1000 + rank, dev))
+        for _ in range(max(a.warmup, 1)):
+            eng.run_plan(plan)
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.run_plan(plan)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            el = float(tt.item())
+        prof = kernel_profile(eng, plan) if rank == 0 else None
+
+    if rank == 0:
+        ms = el / a.steps * 1e3
+        value = world * B * a.steps / el
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        per_launch_s = d["ms"] / max(d["launches"], 1) * 1e-3
+        gbs = d["bytes"] / max(d["launches"], 1) / per_launch_s / 1e9
+        tfs = d["flops"] / max(d["launches"], 1) / per_launch_s / 1e12
+        # bound: whichever roof the kernel's algorithmic intensity puts it under
+        mfma_bound = name == "gemm" and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
+        roof = dict(kernel=name, bound="mfma" if mfma_bound else "hbm",
+                    achieved=round(tfs if mfma_bound else gbs, 2), peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS,
+                    unit="TFLOP/s" if mfma_bound else "GB/s",
+                    frac=round((tfs / MFMA_PEAK_TF[dt]) if mfma_bound else (gbs / HBM_PEAK_GBS), 4), traffic=None,
+                    launches_per_step=d["launches"], ms_per_step=round(d["ms"], 4),
+                    share_of_step=round(d["ms"] / sum(x["ms"] for x in prof.values()), 3))
+        sgp_steps = [s for s in plan.steps if s.name.startswith("_temp_fine.")]
+        kernels = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
+                           GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0,
+                           TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0)
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        out = dict(metric="clips/sec (L=100, 224^2, bf16) forward, per-frame logits", value=round(value, 2),
+                   unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+                   config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']} "
+                                        f"ks={cfg['sgp_ks']}, L={T}, {H}x{W}, batch {B}/GPU, inference forward, "
+                                        "random-init weights", clips_per_gpu=B, parallelism=f"dp{world} (clip-sharded, no collective)",
+                               hip_graph=not a.no_graph),
+                   roofline=roof, kernels=kernels,
+                   sgp_bytes_per_step=sum(s.bytes for s in sgp_steps),
+                   cpu_baseline=None)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

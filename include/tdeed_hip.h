@@ -1,0 +1,159 @@
+/* tdeed_hip.h -- C ABI of libtdeed_hip.so, the gfx950 (MI355X) kernels of the T-DEED hot path.
+ *
+ * The reference (arturxe2/T-DEED) has no FFI/plugin layer: its "operator interface" for this
+ * path is the set of torch.nn module calls inside TDEEDModel.Impl.forward
+ * (/root/reference/model/model.py:105-149) and the loss in TDEEDModel.epoch (model.py:308-319).
+ * Each entry point below replaces one fused group of those calls; the cited file:line is what
+ * it replaces.  Conventions:
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (hipMalloc /
+ *     torch tensor .data_ptr()); the library allocates nothing and never synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered on it;
+ *   - `dtype` selects the storage type of activations and dense weights: TDEED_F32 (parity
+ *     mode, exact-f32 MFMA / VALU) or TDEED_BF16 (throughput mode, fp32 accumulation);
+ *     parameters documented as `float*` are always fp32;
+ *   - activations are channels-last: images NHWC ([frame][y][x][c]), sequences NTC ([clip][t][c]);
+ *   - return 0 on success, <0 on error; tdeed_last_error() gives the message (thread-local).
+ * Channel counts must be multiples of 8 (true for every RegNetY-200MF/800MF and SGP width).
+ */
+#ifndef TDEED_HIP_H
+#define TDEED_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TDEED_F32 = 0, TDEED_BF16 = 1 };
+enum { TDEED_ACT_NONE = 0, TDEED_ACT_RELU = 1, TDEED_ACT_GELU = 2 };
+enum { TDEED_OK = 0, TDEED_ERR_ARG = -1, TDEED_ERR_LAUNCH = -2, TDEED_ERR_RUNTIME = -3 };
+
+const char* tdeed_last_error(void);
+int tdeed_abi_version(void);
+/* Device sanity: returns 0 and fills name (<=63 chars) / CU count when device `dev` is gfx950. */
+int tdeed_device_info(int dev, char* name64, int* n_cu, int* is_gfx950);
+
+/* ---- pre-proc + stem -------------------------------------------------------------------
+ * normalize /255, crop, optional h-flip, ImageNet standardize (model.py:107-129,151-167) fused
+ * into timm RegNet stem Conv3x3 s2 (3->32) + BN(eval, folded to scale/shift) + ReLU (model.py:133).
+ * frames: uint8 [N][3][H][W] (NCHW as the loader delivers it); out: [N][Ho][Wo][32], Ho=(crop_h+1)/2. */
+int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
+                   int crop_h, int crop_w, int flip, const float* w /*[32][3][3][3]*/,
+                   const float* scale /*[32]*/, const float* shift /*[32]*/, void* out, int dtype,
+                   void* stream);
+
+/* ---- dense 1x1 contraction (MFMA) ---------------------------------------------------------
+ * C[m][n] = act( (sum_k A'[m][k] * W[n][k]) * scale[n] + shift[n] + R[m][n] )
+ * Replaces every 1x1 Conv2d+BN(eval)(+ReLU) of the RegNetY trunk incl. the stride-2 shortcut,
+ * the SE re-scale in front of conv3, the residual add + ReLU (timm Bottleneck, model.py:133),
+ * GatedShift's channel splice (shift.py:89-93) and the SGP mlp / concat_fc Conv1d(k=1)
+ * (modules.py:134-138,186,248-254,308-309,316).
+ *   A   [M][K] row stride lda (elements).  If A0 != NULL, columns [0,k0) are read from A0
+ *       (row stride lda0) instead: the gate-shift output spliced in front of the pass-through
+ *       channels.  If a_scale != NULL: A'[m][k] = A[m][k] * a_scale[(m / a_scale_rows)*K + k]
+ *       (SE gate per frame).  If gather_stride > 1: row m = (f, yo, xo) of an
+ *       [F][gather_ho][gather_wo] grid reads input row (f, yo*s, xo*s) of [F][gather_hi][gather_wi].
+ *   W   [N][K] row stride ldw, same dtype as A.   scale/shift: fp32 [N], either may be NULL.
+ *   R   optional residual [M][N] row stride ldr.   C: [M][N] row stride ldc.
+ * K, N, k0, lda, lda0, ldw, ldr, ldc must be multiples of 8. */
+int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
+                   const float* a_scale, int a_scale_rows, int M, int K, int N, const void* W,
+                   long ldw, const float* scale, const float* shift, const void* R, long ldr,
+                   int act, void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
+                   int gather_ho, int gather_wo, int dtype, void* stream);
+
+/* ---- grouped 3x3 conv + BN + ReLU + SE squeeze ---------------------------------------------
+ * timm Bottleneck.conv2 (groups = C/gw, stride 1|2, pad 1) + BN(eval) + ReLU, and the SE
+ * squeeze mean(H,W) of its output.  x: [N][Hi][Wi][C], w: fp32 [C][gw][3][3],
+ * y: [N][Ho][Wo][C], pooled: fp32 [N][C] (mean over Ho*Wo).  gw in {8,16}. */
+int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
+                       const float* w, const float* scale, const float* shift, void* y,
+                       float* pooled, int dtype, void* stream);
+
+/* ---- SE excitation: gate = sigmoid(W2 relu(W1 pooled + b1) + b2) ---------------------------
+ * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled, gate: fp32 [N][C]; w1 [R][C], w2 [C][R]. */
+int tdeed_se_gate_fwd(const float* pooled, int N, int C, int R, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float* gate, void* stream);
+
+/* ---- Gate-Shift(-Fuse) (model/impl/gsf.py:38-93, model/impl/gsm.py:89-116, eval BN) ------------
+ * x: [B*T][h][w][C] (first F channels are gated).  Three launches:
+ *  gate:   BN3d+ReLU+Conv3d(3x3x3, groups 2)+tanh -> gate fp32 [B*T][h][w][2]; also
+ *          ysum[B*T][F] = sum_hw gate*x, xsum[B*T][F] = sum_hw x (fp32).
+ *  weight: GSF only: fusion weight fw[B][F][T] = sigmoid(Conv2d(2->1,3x3) over the (c,t) plane
+ *          of [mean shifted y ; mean r]) (gsf.py:61-78).
+ *  apply:  out[B*T][h][w][Fp] : channels [0,F) = interleave(shift(y)*fw + r*(1-fw)) (GSM: fw==1
+ *          i.e. shift(y)+r), channels [F,Fp) copied from x (Fp = F rounded up to 8). */
+int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
+                       const float* bn_scale, const float* bn_shift,
+                       const float* w3d /*[2][F/2][3][3][3]*/, const float* b3d /*[2]*/,
+                       float* gate, float* ysum, float* xsum, int dtype, void* stream);
+int tdeed_gsf_weight_fwd(const float* ysum, const float* xsum, int B, int T, int F, int hw,
+                         const float* cw1 /*[2][3][3]*/, const float* cb1, const float* cw2,
+                         const float* cb2, float* fw /*[B][F][T]*/, void* stream);
+int tdeed_gsf_apply_fwd(const void* x, const float* gate, const float* fw /*NULL => GSM*/, int B,
+                        int T, int h, int w, int C, int F, int Fp, void* out, int dtype,
+                        void* stream);
+
+/* ---- global average pool + positional encoding (model.py:133-137) --------------------------
+ * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]). */
+int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
+                             void* feat, int dtype, void* stream);
+
+/* ---- SGP pyramid pieces (model/modules.py:58-363), NTC layout ------------------------------- */
+/* channel LayerNorm of every row (modules.py:320-363): y[r][c] = (x-mu)/sqrt(var+eps)*w[c]+b[c];
+ * rows = B*T, row strides ldx / ldy (elements) so the result can land in a slab of the mixer's
+ * concat buffer. */
+int tdeed_layernorm_fwd(const void* x, long ldx, int rows, int C, const float* w, const float* b,
+                        float eps, void* y, long ldy, int dtype, void* stream);
+/* SGPBlock front half (modules.py:161-184): given o = LN(x):
+ *   y = x + fc(o)*relu(gfc(mean_T o)) + (convw(o)+convkw(o))*psi(o) + o
+ * dw: fp32 packed per channel [C][2*ks+up+2]: psi[ks], convw[ks], convkw[up], fc, global_fc;
+ * db: fp32 [5][C] biases in the order psi, convw, convkw, fc, global_fc. */
+int tdeed_sgp_branch_fwd(const void* o, const void* x, int B, int T, int C, int ks, int up,
+                         const float* dw, const float* db, void* y, int dtype, void* stream);
+/* SGPMixer front half (modules.py:286-308): zn = LN1(z) already sits in slab 4 of cat, xn = LN2(x)
+ * at T_lo.  Upsamples xn (linear, align_corners) and fills slabs 0-3 and 5 of
+ * cat [B][T_hi][6C] = (out1,out2,out3,out4,zn,xu).  dw1/db1, dw2/db2 as in sgp_branch. */
+int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int ks, int up,
+                           const float* dw1, const float* db1, const float* dw2,
+                           const float* db2, void* cat, int dtype, void* stream);
+/* nn.GroupNorm(G, C) over (C/G x T) per clip (modules.py:115,186): x,y [B][T][C]. */
+int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* w, const float* b,
+                        float eps, void* y, int dtype, void* stream);
+/* nn.AdaptiveMaxPool1d over T (modules.py:64,76): [B][T_in][C] -> [B][T_out][C]. */
+int tdeed_maxpool_fwd(const void* x, int B, int T_in, int T_out, int C, void* y, int dtype,
+                      void* stream);
+
+/* ---- heads (modules.py:366-387, model.py:141-146), eval (no dropout) ------------------------
+ * x [rows][C]; w fp32 [n_out][C], b [n_out]; out fp32 [rows][n_out] (class logits and the
+ * displacement column are rows of the same matrix: one read of x). */
+int tdeed_heads_fwd(const void* x, int rows, int C, const float* w, const float* b, int n_out,
+                    float* out, int dtype, void* stream);
+
+/* ---- loss (model.py:208-211, 308-319) -------------------------------------------------------
+ * Weighted CE (hard int64 labels, or soft [rows][K1] when soft!=NULL) + MSE(displ, labelD).
+ * out fp32 [3]: total, ce, mse.  logits fp32 [rows][ld] (first K1 columns), displ = column
+ * `displ_col` of the same matrix (or <0 for none). */
+int tdeed_loss_fwd(const float* logits, int rows, int ld, int K1, const int64_t* hard,
+                   const float* soft, const float* cls_w, int displ_col, const float* labelD,
+                   float* out, void* stream);
+
+/* ---- post-proc (modules.py:406-426): softmax over the first K1 columns then scatter-max of
+ * frame t onto clamp(t - rne(displ), 0, T-1).  scores fp32 [B][T][K1] (zero-initialised inside),
+ * cls int64 [B][T] = argmax. */
+int tdeed_process_prediction(const float* head_out, int B, int T, int ld, int K1, int displ_col,
+                             float* scores, int64_t* cls, void* stream);
+
+/* ---- utility ------------------------------------------------------------------------------- */
+int tdeed_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+int tdeed_fill_u8_hash(uint8_t* dst, long n, uint64_t seed, void* stream); /* synthetic clips */
+
+/* ---- HIP graph capture of a launch sequence (replaces eager op-by-op dispatch) ---------------
+ * begin: hipStreamBeginCapture(stream); end: EndCapture + Instantiate -> handle; launch replays. */
+int tdeed_graph_begin(void* stream);
+int tdeed_graph_end(void* stream, void** graph_exec);
+int tdeed_graph_launch(void* graph_exec, void* stream);
+int tdeed_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of csrc/libtdeed_hip.so (C ABI declared in include/tdeed_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, an exception is
+raised.  ``import torch`` happens first so that the library binds to the same libamdhip64 that
+PyTorch-ROCm already loaded (same SONAME) and streams / device pointers are interchangeable.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_long, c_float, c_void_p, c_char_p, c_uint64, POINTER
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libtdeed_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+P = c_void_p
+_SIGS = {
+    "tdeed_abi_version": ([], c_int),
+    "tdeed_device_info": ([c_int, c_char_p, POINTER(c_int), POINTER(c_int)], c_int),
+    "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
+    "tdeed_gemm_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, c_long, P, P, P, c_long,
+                        c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
+    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_se_gate_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
+    "tdeed_gsf_gate_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_gsf_weight_fwd": ([P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
+    "tdeed_gsf_apply_fwd": ([P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_avgpool_posenc_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_int, P], c_int),
+    "tdeed_layernorm_fwd": ([P, c_long, c_int, c_int, P, P, c_float, P, c_long, c_int, P], c_int),
+    "tdeed_sgp_branch_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_mixer_branch_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_groupnorm_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, c_int, P], c_int),
+    "tdeed_maxpool_fwd": ([P, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_heads_fwd": ([P, c_int, c_int, P, P, c_int, P, c_int, P], c_int),
+    "tdeed_loss_fwd": ([P, c_int, c_int, c_int, P, P, P, c_int, P, P, P], c_int),
+    "tdeed_process_prediction": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P], c_int),
+    "tdeed_cast_f32_to_bf16": ([P, P, c_long, P], c_int),
+    "tdeed_fill_u8_hash": ([P, c_long, c_uint64, P], c_int),
+    "tdeed_graph_begin": ([P], c_int),
+    "tdeed_graph_end": ([P, POINTER(c_void_p)], c_int),
+    "tdeed_graph_launch": ([P, P], c_int),
+    "tdeed_graph_destroy": ([P], c_int),
+}
+EXPORTS = tuple(_SIGS) + ("tdeed_last_error",)
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  tdeed_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    lib.tdeed_last_error.argtypes = []
+    lib.tdeed_last_error.restype = c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HipCallError(f"{name} -> {rc}: {lib.tdeed_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(torch_dtype):
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {torch_dtype}")

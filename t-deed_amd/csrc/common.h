@@ -1,0 +1,110 @@
+// Shared device/host helpers for the T-DEED gfx950 kernels.
+// gfx950 only: wave64, MFMA 16x16x32 bf16 / 16x16x4 f32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tdeed_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// --------------------------------------------------------------------------- host side error plumbing
+void tdeed_set_error(const char* fmt, ...);
+#define TD_CHECK(cond, ...)                                   \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      tdeed_set_error(__VA_ARGS__);                           \
+      return TDEED_ERR_ARG;                                   \
+    }                                                         \
+  } while (0)
+#define TD_LAUNCH_CHECK(name)                                                     \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      tdeed_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return TDEED_ERR_LAUNCH;                                                    \
+    }                                                                             \
+  } while (0)
+
+// --------------------------------------------------------------------------- element access (T = float | bf16_t)
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int PER16 = 4;   // elements in a 16-byte chunk
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int PER16 = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// value as it will be read back after a store in T
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return (float)(bf16_t)v; }
+
+// 16-byte chunk <-> fp32 registers
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+// --------------------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a block of NW waves; every thread gets the result. scratch: >= NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r += scratch[i];
+  return r;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

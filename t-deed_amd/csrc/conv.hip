@@ -1,0 +1,303 @@
+// Non-GEMM pieces of the RegNetY trunk: fused pre-proc + stem, grouped 3x3 conv (+BN+ReLU+SE
+// squeeze), SE excitation, global average pool + positional encoding.
+// All are HBM / VALU bound (group width 8/16 and K=27 are no MFMA shapes); weights are
+// block-uniform so they travel through the scalar cache (s_load) and feed v_fma as SGPR operands.
+#include "common.h"
+
+// =========================================================================== stem
+// 16x16 output pixels per block; the 33x33x3 input patch is normalised once into LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ frames, int H, int W,
+                                                   int top, int left, int ch, int cw, int flip,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, T* __restrict__ out,
+                                                   int Ho, int Wo) {
+  __shared__ float tile[3][33][34];
+  const int n = blockIdx.z;
+  const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+  const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const uint8_t* src = frames + (long)n * 3 * H * W;
+  for (int i = threadIdx.x; i < 3 * 33 * 33; i += 256) {
+    int c = i / (33 * 33);
+    int r = i - c * 33 * 33;
+    int y = r / 33, x = r - y * 33;
+    int iy = iy0 + y, ix = ix0 + x;
+    float v = 0.f;
+    if (iy >= 0 && iy < ch && ix >= 0 && ix < cw) {
+      int sx = flip ? (cw - 1 - ix) : ix;
+      float u = (float)src[((long)c * H + (top + iy)) * W + (left + sx)];
+      v = (u / 255.0f - mean[c]) / stdv[c];
+    }
+    tile[c][y][x] = v;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  float in[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) in[c * 9 + ky * 3 + kx] = tile[c][2 * ty + ky][2 * tx + kx];
+  if (oy >= Ho || ox >= Wo) return;
+  T* dst = out + (((long)n * Ho + oy) * Wo + ox) * 32;
+  constexpr int EPC = Chunk<T>::N;
+#pragma unroll
+  for (int o0 = 0; o0 < 32; o0 += EPC) {
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float* wo = w + (o0 + e) * 27;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 27; ++i) a = fmaf(in[i], wo[i], a);
+      v[e] = fmaxf(a * scale[o0 + e] + shift[o0 + e], 0.f);
+    }
+    Chunk<T>::store(dst + o0, v);
+  }
+}
+
+extern "C" int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
+                              int crop_h, int crop_w, int flip, const float* w, const float* scale,
+                              const float* shift, void* out, int dtype, void* stream) {
+  TD_CHECK(frames && w && scale && shift && out, "stem: null pointer");
+  TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 &&
+               crop_top + crop_h <= H && crop_left + crop_w <= W,
+           "stem: bad geometry N=%d H=%d W=%d crop=(%d,%d,%d,%d)", N, H, W, crop_top, crop_left, crop_h, crop_w);
+  TD_CHECK(N <= 65535, "stem: at most 65535 frames per launch (got %d)", N);
+  const int Ho = (crop_h + 1) / 2, Wo = (crop_w + 1) / 2;
+  dim3 grid(cdiv(Wo, 16), cdiv(Ho, 16), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
+                       crop_w, flip, w, scale, shift, (float*)out, Ho, Wo);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
+                       crop_w, flip, w, scale, shift, (bf16_t*)out, Ho, Wo);
+  else { tdeed_set_error("stem: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("stem");
+  return TDEED_OK;
+}
+
+// =========================================================================== grouped 3x3
+// One block = one (frame, group); lanes walk the output pixels, the group's gw*gw*9 weights are
+// block-uniform (packed [G][9][gw_in][gw_out] so the inner o-loop is one s_load_dwordx8/x16).
+// The SE squeeze (mean over Ho*Wo) is completed inside the block: no atomics, deterministic.
+template <typename T, int GW, int NTHR>
+__global__ __launch_bounds__(NTHR) void gconv3x3_kernel(const T* __restrict__ x, int Hi, int Wi, int C,
+                                                        int stride, const float* __restrict__ wp,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, T* __restrict__ y,
+                                                        float* __restrict__ pooled, int Ho, int Wo) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int NCH = GW / EPC;   // 16-B chunks per pixel per group
+  constexpr int NW = NTHR / 64;
+  __shared__ float red[NW][GW];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const float* wg = wp + (long)g * 9 * GW * GW;
+  const T* xin = x + (long)n * Hi * Wi * C + g * GW;
+  T* yout = y + (long)n * Ho * Wo * C + g * GW;
+  float sc[GW], sh[GW], psum[GW];
+#pragma unroll
+  for (int o = 0; o < GW; ++o) {
+    sc[o] = scale[g * GW + o];
+    sh[o] = shift[g * GW + o];
+    psum[o] = 0.f;
+  }
+  const int npix = Ho * Wo;
+  for (int p = threadIdx.x; p < npix; p += NTHR) {
+    const int oy = p / Wo, ox = p - oy * Wo;
+    float acc[GW];
+#pragma unroll
+    for (int o = 0; o < GW; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * stride - 1 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * stride - 1 + kx;
+        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
+          const T* src = xin + ((long)iy * Wi + ix) * C;
+          float in[GW];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            float v[EPC];
+            Chunk<T>::load(src + c * EPC, v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) in[c * EPC + e] = v[e];
+          }
+          const float* wt = wg + (ky * 3 + kx) * GW * GW;
+#pragma unroll
+          for (int i = 0; i < GW; ++i)
+#pragma unroll
+            for (int o = 0; o < GW; ++o) acc[o] = fmaf(in[i], wt[i * GW + o], acc[o]);
+        }
+      }
+    }
+    float outv[GW];
+#pragma unroll
+    for (int o = 0; o < GW; ++o) {
+      outv[o] = fmaxf(acc[o] * sc[o] + sh[o], 0.f);
+    }
+    T* dst = yout + (long)p * C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float v[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = outv[c * EPC + e];
+      Chunk<T>::store(dst + c * EPC, v);
+      // the squeeze sees what the next layer sees: the stored (rounded) activation
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) psum[c * EPC + e] += round_to<T>(v[e]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 0; o < GW; ++o) {
+    float s = wave_sum(psum[o]);
+    if (lane == 0) red[wv][o] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < GW) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i][threadIdx.x];
+    pooled[(long)n * C + g * GW + threadIdx.x] = s / (float)npix;
+  }
+}
+
+template <typename T, int GW>
+static int launch_gconv(const void* x, int N, int Hi, int Wi, int C, int stride, const float* w,
+                        const float* scale, const float* shift, void* y, float* pooled, hipStream_t st) {
+  const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+  dim3 grid(C / GW, N);
+  if (Ho * Wo <= 64)
+    hipLaunchKernelGGL((gconv3x3_kernel<T, GW, 64>), grid, dim3(64), 0, st, (const T*)x, Hi, Wi, C, stride, w,
+                       scale, shift, (T*)y, pooled, Ho, Wo);
+  else
+    hipLaunchKernelGGL((gconv3x3_kernel<T, GW, 256>), grid, dim3(256), 0, st, (const T*)x, Hi, Wi, C, stride, w,
+                       scale, shift, (T*)y, pooled, Ho, Wo);
+  TD_LAUNCH_CHECK("gconv3x3");
+  return TDEED_OK;
+}
+
+extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
+                                  const float* w, const float* scale, const float* shift, void* y,
+                                  float* pooled, int dtype, void* stream) {
+  TD_CHECK(x && w && scale && shift && y && pooled, "gconv3x3: null pointer");
+  TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "gconv3x3: group width %d / C %d unsupported", gw, C);
+  TD_CHECK(stride == 1 || stride == 2, "gconv3x3: stride %d", stride);
+  TD_CHECK(N > 0 && N <= 65535 && Hi > 0 && Wi > 0, "gconv3x3: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    return gw == 8 ? launch_gconv<float, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
+                   : launch_gconv<float, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
+  if (dtype == TDEED_BF16)
+    return gw == 8 ? launch_gconv<bf16_t, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
+                   : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
+  tdeed_set_error("gconv3x3: bad dtype %d", dtype);
+  return TDEED_ERR_ARG;
+}
+
+// =========================================================================== SE excitation
+// FPB frames per block share every weight read.  w1t: [C][R], w2t: [R][C] (transposed on the host
+// so adjacent threads read adjacent addresses).
+#define SE_FPB 4
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pooled, int N, int C, int R,
+                                                      const float* __restrict__ w1t,
+                                                      const float* __restrict__ b1,
+                                                      const float* __restrict__ w2t,
+                                                      const float* __restrict__ b2, float* __restrict__ gate) {
+  extern __shared__ float sm[];   // [FPB][C] pooled, [FPB][R] hidden
+  float* sp = sm;
+  float* shid = sm + SE_FPB * C;
+  const int f0 = blockIdx.x * SE_FPB;
+  for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
+    int f = i / C;
+    sp[i] = (f0 + f < N) ? pooled[(long)(f0 + f) * C + (i - f * C)] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < R; j += 256) {
+    float a[SE_FPB];
+#pragma unroll
+    for (int f = 0; f < SE_FPB; ++f) a[f] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float wv = w1t[(long)c * R + j];
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f) a[f] = fmaf(sp[f * C + c], wv, a[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < SE_FPB; ++f) shid[f * R + j] = fmaxf(a[f] + b1[j], 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a[SE_FPB];
+#pragma unroll
+    for (int f = 0; f < SE_FPB; ++f) a[f] = 0.f;
+    for (int j = 0; j < R; ++j) {
+      float wv = w2t[(long)j * C + c];
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f) a[f] = fmaf(shid[f * R + j], wv, a[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < SE_FPB; ++f)
+      if (f0 + f < N) gate[(long)(f0 + f) * C + c] = sigmoidf_(a[f] + b2[c]);
+  }
+}
+
+extern "C" int tdeed_se_gate_fwd(const float* pooled, int N, int C, int R, const float* w1t, const float* b1,
+                                 const float* w2t, const float* b2, float* gate, void* stream) {
+  TD_CHECK(pooled && w1t && b1 && w2t && b2 && gate, "se_gate: null pointer");
+  TD_CHECK(N > 0 && C > 0 && R > 0, "se_gate: bad sizes");
+  size_t smem = (size_t)SE_FPB * (C + R) * sizeof(float);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(cdiv(N, SE_FPB)), dim3(256), smem, (hipStream_t)stream, pooled, N, C,
+                     R, w1t, b1, w2t, b2, gate);
+  TD_LAUNCH_CHECK("se_gate");
+  return TDEED_OK;
+}
+
+// =========================================================================== avg-pool + pos-enc
+template <typename T>
+__global__ void avgpool_posenc_kernel(const T* __restrict__ x, int T_len, int hw, int C,
+                                      const float* __restrict__ temp_enc, T* __restrict__ feat) {
+  constexpr int EPC = Chunk<T>::N;
+  const int f = blockIdx.x;            // frame = b*T + t
+  const int t = f % T_len;
+  const int c0 = threadIdx.x * EPC;
+  if (c0 >= C) return;
+  float a[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+  const T* src = x + (long)f * hw * C + c0;
+  for (int p = 0; p < hw; ++p) {
+    float v[EPC];
+    Chunk<T>::load(src + (long)p * C, v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) a[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) a[e] = a[e] / (float)hw + temp_enc[(long)t * C + c0 + e];
+  Chunk<T>::store(feat + (long)f * C + c0, a);
+}
+
+extern "C" int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
+                                        void* feat, int dtype, void* stream) {
+  TD_CHECK(x && temp_enc && feat, "avgpool: null pointer");
+  TD_CHECK(B > 0 && T > 0 && hw > 0 && C > 0 && C % 8 == 0, "avgpool: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    int thr = cdiv(C / 4, 64) * 64;
+    hipLaunchKernelGGL(avgpool_posenc_kernel<float>, dim3(B * T), dim3(thr), 0, st, (const float*)x, T, hw, C,
+                       temp_enc, (float*)feat);
+  } else if (dtype == TDEED_BF16) {
+    int thr = cdiv(C / 8, 64) * 64;
+    hipLaunchKernelGGL(avgpool_posenc_kernel<bf16_t>, dim3(B * T), dim3(thr), 0, st, (const bf16_t*)x, T, hw, C,
+                       temp_enc, (bf16_t*)feat);
+  } else { tdeed_set_error("avgpool: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("avgpool_posenc");
+  return TDEED_OK;
+}

@@ -1,0 +1,435 @@
+// SGP encoder-decoder pieces (reference: /root/reference/model/modules.py:58-363), NTC layout.
+// Everything here is bandwidth / latency bound: channel LayerNorm (wave64 reductions over the
+// contiguous C of one row), the depthwise temporal convs with their +-up/2 window staged in LDS,
+// GroupNorm(16) over a (C/16 x T) slab, adaptive max-pool, linear up-sampling.  The dense
+// C->4C->C / 6C->C contractions run on the MFMA kernel in gemm.hip.
+#include "common.h"
+
+// =========================================================================== channel LayerNorm
+// one wave per row; lane l owns 16-B chunks l, l+64, ... of the row (C <= 4*64*EPC).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx, int rows, int C,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps,
+                                                        T* __restrict__ y, long ldy) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int MAXCH = 4;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C / EPC;
+  float v[MAXCH][EPC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nch) {
+      Chunk<T>::load(x + row * ldx + (long)ck * EPC, v[i]);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s += v[i][e];
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nch) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        v[i][e] -= mu;
+        q += v[i][e] * v[i][e];
+      }
+    }
+  }
+  const float den = sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nch) {
+      float o[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int c = ck * EPC + e;
+        o[e] = v[i][e] / den * w[c] + b[c];
+      }
+      Chunk<T>::store(y + row * ldy + (long)ck * EPC, o);
+    }
+  }
+}
+
+extern "C" int tdeed_layernorm_fwd(const void* x, long ldx, int rows, int C, const float* w, const float* b,
+                                   float eps, void* y, long ldy, int dtype, void* stream) {
+  TD_CHECK(x && w && b && y, "layernorm: null pointer");
+  TD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(rows, 4));
+  if (dtype == TDEED_F32) {
+    TD_CHECK(C <= 4 * 64 * 4, "layernorm: C=%d too wide", C);
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, rows, C, w, b, eps,
+                       (float*)y, ldy);
+  } else if (dtype == TDEED_BF16) {
+    TD_CHECK(C <= 4 * 64 * 8, "layernorm: C=%d too wide", C);
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, C, w, b, eps,
+                       (bf16_t*)y, ldy);
+  } else { tdeed_set_error("layernorm: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("layernorm");
+  return TDEED_OK;
+}
+
+// =========================================================================== depthwise branch helpers
+// A block owns CH=16 channels of one clip: tile[(T + 2*halo)][16] fp32 in LDS with zero halo rows,
+// per-channel weights transposed to wl[tap][16].  Thread (tl = tid>>4, c = tid&15).
+#define SGP_CH 16
+
+// load rows [0,T) x 16 channels (row stride ld) into tile rows [halo, halo+T); zero the halos.
+template <typename T>
+__device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, int T_len, int c0, int C,
+                                          float* tile, int halo) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int CPR = SGP_CH / EPC;
+  for (int i = threadIdx.x; i < 2 * halo * SGP_CH; i += 256) {
+    int r = i / SGP_CH, c = i - r * SGP_CH;
+    int row = r < halo ? r : (T_len + r);
+    tile[row * SGP_CH + c] = 0.f;
+  }
+  for (int i = threadIdx.x; i < T_len * CPR; i += 256) {
+    int t = i / CPR, ck = i - t * CPR;
+    float v[EPC];
+    if (c0 + ck * EPC < C) {
+      Chunk<T>::load(src + (long)t * ld + c0 + ck * EPC, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) tile[(halo + t) * SGP_CH + ck * EPC + e] = v[e];
+  }
+}
+
+// store a [T][16] fp32 LDS tile to dst rows (stride ld), optionally adding `add` (same geometry as dst)
+template <typename T>
+__device__ __forceinline__ void store_tile(const float* res, T* __restrict__ dst, long ld, int T_len, int c0,
+                                           int C, const T* __restrict__ add, long ld_add) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int CPR = SGP_CH / EPC;
+  for (int i = threadIdx.x; i < T_len * CPR; i += 256) {
+    int t = i / CPR, ck = i - t * CPR;
+    if (c0 + ck * EPC >= C) continue;
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = res[t * SGP_CH + ck * EPC + e];
+    if (add) {
+      float a[EPC];
+      Chunk<T>::load(add + (long)t * ld_add + c0 + ck * EPC, a);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] += a[e];
+    }
+    Chunk<T>::store(dst + (long)t * ld + c0 + ck * EPC, v);
+  }
+}
+
+// per-channel weights: dw[c][psi ks | convw ks | convkw up | fc | gfc] -> wl[tap][16]
+__device__ __forceinline__ void load_dw(const float* __restrict__ dw, int wlen, int c0, int C, float* wl) {
+  for (int i = threadIdx.x; i < wlen * SGP_CH; i += 256) {
+    int c = i / wlen, k = i - c * wlen;
+    wl[k * SGP_CH + c] = (c0 + c < C) ? dw[(long)(c0 + c) * wlen + k] : 0.f;
+  }
+}
+
+// mean over T of the tile per channel; result broadcast through red[16]
+__device__ __forceinline__ void tile_mean(const float* tile, int T_len, int halo, float* red /*[17][16]*/) {
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  float s = 0.f;
+  for (int t = tl; t < T_len; t += 16) s += tile[(halo + t) * SGP_CH + c];
+  red[tl * SGP_CH + c] = s;
+  __syncthreads();
+  if (threadIdx.x < SGP_CH) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += red[i * SGP_CH + threadIdx.x];
+    red[16 * SGP_CH + threadIdx.x] = a / (float)T_len;
+  }
+  __syncthreads();
+}
+
+struct BranchOut { float conv_gate; float inst; };   // (convw+convkw)*psi ,  fc*phi
+
+__device__ __forceinline__ BranchOut branch_eval(const float* tile, const float* wl, const float* bias5,
+                                                 long bstride, int cglob, bool cok, int t, int c, int halo,
+                                                 int ks, int up, float mean_c) {
+  // bias5: [5][C] psi, convw, convkw, fc, gfc
+  const float b_psi = cok ? bias5[cglob] : 0.f, b_cw = cok ? bias5[bstride + cglob] : 0.f,
+              b_ckw = cok ? bias5[2 * bstride + cglob] : 0.f, b_fc = cok ? bias5[3 * bstride + cglob] : 0.f,
+              b_g = cok ? bias5[4 * bstride + cglob] : 0.f;
+  const float* col = tile + (halo + t) * SGP_CH + c;
+  float psi = b_psi, cw = b_cw, ckw = b_ckw;
+  const int hk = ks >> 1, hu = up >> 1;
+  for (int k = 0; k < ks; ++k) {
+    const float v = col[(k - hk) * SGP_CH];
+    psi = fmaf(wl[k * SGP_CH + c], v, psi);
+    cw = fmaf(wl[(ks + k) * SGP_CH + c], v, cw);
+  }
+  for (int k = 0; k < up; ++k) ckw = fmaf(wl[(2 * ks + k) * SGP_CH + c], col[(k - hu) * SGP_CH], ckw);
+  const float o = col[0];
+  const float fc = fmaf(wl[(2 * ks + up) * SGP_CH + c], o, b_fc);
+  const float phi = fmaxf(fmaf(wl[(2 * ks + up + 1) * SGP_CH + c], mean_c, b_g), 0.f);
+  BranchOut r;
+  r.conv_gate = (cw + ckw) * psi;
+  r.inst = fc * phi;
+  return r;
+}
+
+// =========================================================================== SGPBlock front half
+template <typename T>
+__global__ __launch_bounds__(256) void sgp_branch_kernel(const T* __restrict__ o, const T* __restrict__ x,
+                                                         int T_len, int C, int ks, int up,
+                                                         const float* __restrict__ dw,
+                                                         const float* __restrict__ db, T* __restrict__ y) {
+  extern __shared__ float sm[];
+  const int halo = up >> 1;
+  const int wlen = 2 * ks + up + 2;
+  float* tile = sm;                                   // [(T+2h)][16]
+  float* res = tile + (T_len + 2 * halo) * SGP_CH;    // [T][16]
+  float* wl = res + T_len * SGP_CH;                   // [wlen][16]
+  float* red = wl + wlen * SGP_CH;                    // [17][16]
+  const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
+  const long base = (long)b * T_len * C;
+  load_tile<T>(o + base, C, T_len, c0, C, tile, halo);
+  load_dw(dw, wlen, c0, C, wl);
+  __syncthreads();
+  tile_mean(tile, T_len, halo, red);
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const bool cok = c0 + c < C;
+  const float mean_c = red[16 * SGP_CH + c];
+  for (int t = tl; t < T_len; t += 16) {
+    BranchOut r = branch_eval(tile, wl, db, C, c0 + c, cok, t, c, halo, ks, up, mean_c);
+    res[t * SGP_CH + c] = r.inst + r.conv_gate + tile[(halo + t) * SGP_CH + c];
+  }
+  __syncthreads();
+  store_tile<T>(res, y + base, C, T_len, c0, C, x + base, C);
+}
+
+static size_t sgp_smem(int T_len, int ks, int up, int ntiles, int nres) {
+  const int halo = up / 2, wlen = 2 * ks + up + 2;
+  return (size_t)(ntiles * (T_len + 2 * halo) * SGP_CH + nres * T_len * SGP_CH + ntiles * wlen * SGP_CH +
+                  17 * SGP_CH) * sizeof(float);
+}
+
+extern "C" int tdeed_sgp_branch_fwd(const void* o, const void* x, int B, int T, int C, int ks, int up,
+                                    const float* dw, const float* db, void* y, int dtype, void* stream) {
+  TD_CHECK(o && x && dw && db && y, "sgp_branch: null pointer");
+  TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_branch: bad sizes");
+  size_t smem = sgp_smem(T, ks, up, 1, 1);
+  TD_CHECK(smem <= 64 * 1024, "sgp_branch: T=%d too long for the LDS window", T);
+  dim3 grid(B, cdiv(C, SGP_CH));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(sgp_branch_kernel<float>, grid, dim3(256), smem, st, (const float*)o, (const float*)x, T, C,
+                       ks, up, dw, db, (float*)y);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(sgp_branch_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)o, (const bf16_t*)x, T,
+                       C, ks, up, dw, db, (bf16_t*)y);
+  else { tdeed_set_error("sgp_branch: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("sgp_branch");
+  return TDEED_OK;
+}
+
+// =========================================================================== SGPMixer front half
+// cat row = [out1 | out2 | out3 | out4 | zn | xu], each C wide.  zn is already in slab 4.
+template <typename T>
+__global__ __launch_bounds__(256) void mixer_branch_kernel(const T* __restrict__ xn, int T_hi, int T_lo, int C,
+                                                           int ks, int up, const float* __restrict__ dw1,
+                                                           const float* __restrict__ db1,
+                                                           const float* __restrict__ dw2,
+                                                           const float* __restrict__ db2, T* __restrict__ cat) {
+  extern __shared__ float sm[];
+  const int halo = up >> 1;
+  const int wlen = 2 * ks + up + 2;
+  const int trows = T_hi + 2 * halo;
+  float* zt = sm;                              // zn tile
+  float* xt = zt + trows * SGP_CH;             // xu tile
+  float* res = xt + trows * SGP_CH;            // [T_hi][16] (also holds xn [T_lo][16] during upsampling)
+  float* wl1 = res + T_hi * SGP_CH;
+  float* wl2 = wl1 + wlen * SGP_CH;
+  float* red = wl2 + wlen * SGP_CH;
+  const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
+  const long ldc = 6L * C;
+  T* crow = cat + (long)b * T_hi * ldc;
+  load_tile<T>(crow + 4L * C, ldc, T_hi, c0, C, zt, halo);
+  // xn at T_lo -> res (no halo), then linear up-sampling (align_corners=True) into xt
+  load_tile<T>(xn + (long)b * T_lo * C, C, T_lo, c0, C, res, 0);
+  load_dw(dw1, wlen, c0, C, wl1);
+  load_dw(dw2, wlen, c0, C, wl2);
+  for (int i = threadIdx.x; i < 2 * halo * SGP_CH; i += 256) {
+    int r = i / SGP_CH, c = i - r * SGP_CH;
+    int row = r < halo ? r : (T_hi + r);
+    xt[row * SGP_CH + c] = 0.f;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  {
+    const float scale = (T_hi > 1) ? (float)(T_lo - 1) / (float)(T_hi - 1) : 0.f;
+    for (int t = tl; t < T_hi; t += 16) {
+      float v;
+      if (T_hi == T_lo) {
+        v = res[t * SGP_CH + c];
+      } else {
+        const float src = scale * (float)t;
+        const int i0 = (int)src;
+        const int i1 = i0 + (i0 < T_lo - 1 ? 1 : 0);
+        const float l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+        const float l0 = 1.f - l1;
+        v = l0 * res[i0 * SGP_CH + c] + l1 * res[i1 * SGP_CH + c];
+      }
+      // the up-sampled sequence is a tensor in the reference: round it like a stored activation
+      xt[(halo + t) * SGP_CH + c] = round_to<T>(v);
+    }
+  }
+  __syncthreads();
+  // slab 5 = xu
+  for (int t = tl; t < T_hi; t += 16) res[t * SGP_CH + c] = xt[(halo + t) * SGP_CH + c];
+  __syncthreads();
+  store_tile<T>(res, crow + 5L * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
+  tile_mean(zt, T_hi, halo, red);
+  const float mz = red[16 * SGP_CH + c];
+  __syncthreads();
+  tile_mean(xt, T_hi, halo, red);
+  const float mx = red[16 * SGP_CH + c];
+  const bool cok = c0 + c < C;
+  // out1 (slab 0) / out3 (slab 2) from z ; out2 (slab 1) / out4 (slab 3) from x
+  for (int pass = 0; pass < 4; ++pass) {
+    const bool fromz = (pass & 1) == 0;
+    const float* tile = fromz ? zt : xt;
+    const float* wl = fromz ? wl1 : wl2;
+    const float* db = fromz ? db1 : db2;
+    const float mean_c = fromz ? mz : mx;
+    __syncthreads();
+    for (int t = tl; t < T_hi; t += 16) {
+      BranchOut r = branch_eval(tile, wl, db, C, c0 + c, cok, t, c, halo, ks, up, mean_c);
+      res[t * SGP_CH + c] = pass < 2 ? r.conv_gate : r.inst;
+    }
+    __syncthreads();
+    const int slab = pass;   // pass 0: out1 (z), 1: out2 (x), 2: out3 (z), 3: out4 (x)
+    store_tile<T>(res, crow + (long)slab * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
+  }
+}
+
+extern "C" int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int ks, int up,
+                                      const float* dw1, const float* db1, const float* dw2, const float* db2,
+                                      void* cat, int dtype, void* stream) {
+  TD_CHECK(xn && dw1 && db1 && dw2 && db2 && cat, "mixer_branch: null pointer");
+  TD_CHECK(B > 0 && T_hi >= T_lo && T_lo > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks,
+           "mixer_branch: bad sizes");
+  size_t smem = sgp_smem(T_hi, ks, up, 2, 1);
+  TD_CHECK(smem <= 64 * 1024, "mixer_branch: T=%d too long for the LDS window", T_hi);
+  dim3 grid(B, cdiv(C, SGP_CH));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(mixer_branch_kernel<float>, grid, dim3(256), smem, st, (const float*)xn, T_hi, T_lo, C, ks,
+                       up, dw1, db1, dw2, db2, (float*)cat);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(mixer_branch_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)xn, T_hi, T_lo, C, ks,
+                       up, dw1, db1, dw2, db2, (bf16_t*)cat);
+  else { tdeed_set_error("mixer_branch: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("mixer_branch");
+  return TDEED_OK;
+}
+
+// =========================================================================== GroupNorm
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_kernel(const T* __restrict__ x, int T_len, int C, int G,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bia, float eps,
+                                                        T* __restrict__ y) {
+  extern __shared__ float sm[];     // [T][cg] cached slab + 4 scratch
+  const int b = blockIdx.x, g = blockIdx.y;
+  const int cg = C / G;
+  const int n = T_len * cg;
+  float* slab = sm;
+  float* scratch = sm + n;
+  const T* xb = x + (long)b * T_len * C + g * cg;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int t = i / cg, cl = i - t * cg;
+    float v = (float)xb[(long)t * C + cl];
+    slab[i] = v;
+    s += v;
+  }
+  const float mean = block_sum<4>(s, scratch) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float d = slab[i] - mean;
+    q += d * d;
+  }
+  const float var = block_sum<4>(q, scratch) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  T* yb = y + (long)b * T_len * C + g * cg;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int t = i / cg, cl = i - t * cg;
+    int c = g * cg + cl;
+    yb[(long)t * C + cl] = (T)((slab[i] - mean) * rstd * w[c] + bia[c]);
+  }
+}
+
+extern "C" int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* w, const float* b,
+                                   float eps, void* y, int dtype, void* stream) {
+  TD_CHECK(x && w && b && y, "groupnorm: null pointer");
+  TD_CHECK(B > 0 && T > 0 && G > 0 && C % G == 0, "groupnorm: bad sizes");
+  size_t smem = ((size_t)T * (C / G) + 8) * sizeof(float);
+  TD_CHECK(smem <= 64 * 1024, "groupnorm: slab too large");
+  dim3 grid(B, G);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(groupnorm_kernel<float>, grid, dim3(256), smem, st, (const float*)x, T, C, G, w, b, eps,
+                       (float*)y);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(groupnorm_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)x, T, C, G, w, b, eps,
+                       (bf16_t*)y);
+  else { tdeed_set_error("groupnorm: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("groupnorm");
+  return TDEED_OK;
+}
+
+// =========================================================================== adaptive max-pool over T
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, int T_in, int T_out, int C, T* __restrict__ y,
+                               long total) {
+  constexpr int EPC = Chunk<T>::N;
+  const int cpr = C / EPC;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ck = (int)(idx % cpr);
+    const long r = idx / cpr;
+    const int i = (int)(r % T_out);
+    const long b = r / T_out;
+    const int lo = (int)(((long)i * T_in) / T_out);
+    const int hi = (int)((((long)(i + 1)) * T_in + T_out - 1) / T_out);
+    float m[EPC];
+    Chunk<T>::load(x + ((long)b * T_in + lo) * C + ck * EPC, m);
+    for (int t = lo + 1; t < hi; ++t) {
+      float v[EPC];
+      Chunk<T>::load(x + ((long)b * T_in + t) * C + ck * EPC, v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+    Chunk<T>::store(y + ((long)b * T_out + i) * C + ck * EPC, m);
+  }
+}
+
+extern "C" int tdeed_maxpool_fwd(const void* x, int B, int T_in, int T_out, int C, void* y, int dtype,
+                                 void* stream) {
+  TD_CHECK(x && y, "maxpool: null pointer");
+  TD_CHECK(B > 0 && T_in > 0 && T_out > 0 && T_out <= T_in && C % 8 == 0, "maxpool: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    long total = (long)B * T_out * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)x, T_in,
+                       T_out, C, (float*)y, total);
+  } else if (dtype == TDEED_BF16) {
+    long total = (long)B * T_out * (C / 8);
+    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)x, T_in,
+                       T_out, C, (bf16_t*)y, total);
+  } else { tdeed_set_error("maxpool: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("maxpool");
+  return TDEED_OK;
+}

@@ -1,0 +1,462 @@
+"""Launch plan of the T-DEED inference forward on one MI355X.
+
+``ForwardEngine`` turns a reference-format state_dict into packed device weights (BN folded
+into per-channel scale/shift epilogues, depthwise weights packed per channel, dense weights in
+the activation dtype) and, per input geometry, a static list of kernel launches over
+pre-allocated buffers.  The list is captured once into a HIP graph and replayed: no tracing
+compiler, no per-op host work in the steady state.
+
+Mirrors ``TDEEDModel.Impl.forward(x, inference=True)`` (/root/reference/model/model.py:105-149).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops, _lib
+from .regnet_spec import regnet_spec, sgp_up_size, pyramid_lengths
+
+BN_EPS = 1e-5
+
+
+def _np(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+class _Pool:
+    """Free-list of device byte buffers so that dead activations are recycled (keeps the working
+    set small enough to live in the 256 MiB Infinity Cache between producer and consumer)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = []
+        self.all = []
+
+    def take(self, shape, dtype):
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        n = (n + 255) // 256 * 256
+        best = None
+        for i, b in enumerate(self.free):
+            if b.numel() >= n and (best is None or b.numel() < self.free[best].numel()):
+                best = i
+        if best is not None and self.free[best].numel() <= 2 * n + (1 << 20):
+            raw = self.free.pop(best)
+        else:
+            raw = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self.all.append(raw)
+        t = raw[:int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
+        t._td_raw = raw
+        return t
+
+    def give(self, t):
+        self.free.append(t._td_raw)
+
+    def total_bytes(self):
+        return sum(b.numel() for b in self.all)
+
+
+def _f32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+def _dense(a, act_dtype, device):
+    return _f32(a, device).to(act_dtype).contiguous()
+
+
+def _dwpack(sd, pre, names, C, device):
+    """per-channel depthwise weights [C][sum of taps] and biases [len(names)][C]"""
+    ws = [_np(sd[f"{pre}.{n}.weight"]).reshape(C, -1) for n in names]
+    bs = [_np(sd[f"{pre}.{n}.bias"]).reshape(C) for n in names]
+    return _f32(np.concatenate(ws, axis=1), device), _f32(np.stack(bs, axis=0), device)
+
+
+def _pack_mlp(sd, pre, C, o, act_dtype, device):
+    o.w_fc1 = _dense(_np(sd[pre + ".mlp.0.weight"]).reshape(4 * C, C), act_dtype, device)
+    o.b_fc1 = _f32(_np(sd[pre + ".mlp.0.bias"]), device)
+    o.w_fc2 = _dense(_np(sd[pre + ".mlp.2.weight"]).reshape(C, 4 * C), act_dtype, device)
+    o.b_fc2 = _f32(_np(sd[pre + ".mlp.2.bias"]), device)
+    o.gn_w, o.gn_b = _f32(_np(sd[pre + ".gn.weight"]), device), _f32(_np(sd[pre + ".gn.bias"]), device)
+
+
+def pack_sgp_block(sd, pre, C, act_dtype, device):
+    """SGPBlock parameters (modules.py:91-145) in kernel layout."""
+    o = SimpleNamespace(C=C)
+    o.ln_w = _f32(_np(sd[pre + ".ln.weight"]).reshape(C), device)
+    o.ln_b = _f32(_np(sd[pre + ".ln.bias"]).reshape(C), device)
+    o.dw, o.db = _dwpack(sd, pre, ["psi", "convw", "convkw", "fc", "global_fc"], C, device)
+    o.ks = _np(sd[pre + ".psi.weight"]).shape[-1]
+    o.up = _np(sd[pre + ".convkw.weight"]).shape[-1]
+    _pack_mlp(sd, pre, C, o, act_dtype, device)
+    return o
+
+
+def pack_sgp_mixer(sd, pre, C, act_dtype, device):
+    """SGPMixer parameters (modules.py:192-254) in kernel layout."""
+    o = SimpleNamespace(C=C)
+    for n in ("ln1", "ln2"):
+        setattr(o, n + "_w", _f32(_np(sd[f"{pre}.{n}.weight"]).reshape(C), device))
+        setattr(o, n + "_b", _f32(_np(sd[f"{pre}.{n}.bias"]).reshape(C), device))
+    o.dw1, o.db1 = _dwpack(sd, pre, ["psi1", "convw1", "convkw1", "fc1", "global_fc1"], C, device)
+    o.dw2, o.db2 = _dwpack(sd, pre, ["psi2", "convw2", "convkw2", "fc2", "global_fc2"], C, device)
+    o.ks = _np(sd[pre + ".psi1.weight"]).shape[-1]
+    o.up = _np(sd[pre + ".convkw1.weight"]).shape[-1]
+    o.w_cat = _dense(_np(sd[pre + ".concat_fc.weight"]).reshape(C, 6 * C), act_dtype, device)
+    o.b_cat = _f32(_np(sd[pre + ".concat_fc.bias"]), device)
+    _pack_mlp(sd, pre, C, o, act_dtype, device)
+    return o
+
+
+class Step:
+    """One kernel launch of a plan with its algorithmic cost (what a perfect kernel must move / compute)."""
+    __slots__ = ("name", "kernel", "fn", "bytes", "flops")
+
+    def __init__(self, name, kernel, fn, nbytes=0, flops=0):
+        self.name, self.kernel, self.fn, self.bytes, self.flops = name, kernel, fn, int(nbytes), int(flops)
+
+
+def _esz(dt):
+    return 2 if dt == torch.bfloat16 else 4
+
+
+def gemm_cost(M, K, N, es, residual=False, extra=0):
+    return (M * K + N * K + M * N * (2 if residual else 1)) * es + extra, 2 * M * K * N
+
+
+class SgpBuilder:
+    """Appends the launches of SGP blocks / mixers / the whole encoder-decoder to a step list."""
+
+    def __init__(self, pool, steps, keep, taps, B, act_dtype):
+        self.pool, self.steps, self.keep, self.taps, self.B, self.dt = pool, steps, keep, taps, B, act_dtype
+
+    def block(self, xin, Tn, o, name):
+        pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        ln = pool.take((B, Tn, C), dt)
+        y = pool.take((B, Tn, C), dt)
+        gn = pool.take((B, Tn, C), dt)
+        hid = pool.take((B, Tn, 4 * C), dt)
+        outb = pool.take((B, Tn, C), dt)
+        es, R = _esz(dt), B * Tn
+        wl = 2 * o.ks + o.up + 2
+        steps.append(Step(name + ".ln", "layernorm", lambda: ops.layernorm(xin, o.ln_w, o.ln_b, out=ln), 2 * R * C * es))
+        steps.append(Step(name + ".branch", "sgp_branch", lambda: ops.sgp_branch(ln, xin, o.ks, o.up, o.dw, o.db, out=y),
+                          3 * R * C * es + C * (wl + 5) * 4, 2 * R * C * (wl + 3)))
+        steps.append(Step(name + ".gn", "groupnorm", lambda: ops.groupnorm(y, 16, o.gn_w, o.gn_b, out=gn), 2 * R * C * es))
+        steps.append(Step(name + ".fc1", "gemm", lambda: ops.gemm(gn, o.w_fc1, None, o.b_fc1, ops.ACT_GELU, out=hid, M=R),
+                          *gemm_cost(R, C, 4 * C, es)))
+        steps.append(Step(name + ".fc2", "gemm", lambda: ops.gemm(hid, o.w_fc2, None, o.b_fc2, ops.ACT_NONE, residual=y,
+                                                                  out=outb, M=R), *gemm_cost(R, 4 * C, C, es, True)))
+        for t_ in (ln, y, gn, hid):
+            pool.give(t_)
+        if name in self.taps:
+            self.keep[name] = outb
+        return outb
+
+    def mixer(self, xlo, T_lo, z, T_hi, o, name):
+        pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        cat = pool.take((B, T_hi, 6 * C), dt)
+        xn = pool.take((B, T_lo, C), dt)
+        mo = pool.take((B, T_hi, C), dt)
+        gn = pool.take((B, T_hi, C), dt)
+        hid = pool.take((B, T_hi, 4 * C), dt)
+        outb = pool.take((B, T_hi, C), dt)
+        zslab = cat.view(-1)[4 * C:]
+        es, R, Rl = _esz(dt), B * T_hi, B * T_lo
+        wl = 2 * o.ks + o.up + 2
+        steps.append(Step(name + ".ln1", "layernorm", lambda: ops.layernorm(z, o.ln1_w, o.ln1_b, out=zslab, ldy=6 * C,
+                                                                            rows=R, C=C), 2 * R * C * es))
+        steps.append(Step(name + ".ln2", "layernorm", lambda: ops.layernorm(xlo, o.ln2_w, o.ln2_b, out=xn), 2 * Rl * C * es))
+        steps.append(Step(name + ".branch", "mixer_branch",
+                          lambda: ops.mixer_branch(xn, cat, T_hi, o.ks, o.up, o.dw1, o.db1, o.dw2, o.db2),
+                          (6 * R + Rl) * C * es + 2 * C * (wl + 5) * 4, 4 * R * C * (wl + 3)))
+        steps.append(Step(name + ".cat", "gemm", lambda: ops.gemm(cat, o.w_cat, None, o.b_cat, ops.ACT_GELU, out=mo, M=R),
+                          *gemm_cost(R, 6 * C, C, es)))
+        steps.append(Step(name + ".gn", "groupnorm", lambda: ops.groupnorm(mo, 16, o.gn_w, o.gn_b, out=gn), 2 * R * C * es))
+        steps.append(Step(name + ".fc1", "gemm", lambda: ops.gemm(gn, o.w_fc1, None, o.b_fc1, ops.ACT_GELU, out=hid, M=R),
+                          *gemm_cost(R, C, 4 * C, es)))
+        steps.append(Step(name + ".fc2", "gemm", lambda: ops.gemm(hid, o.w_fc2, None, o.b_fc2, ops.ACT_NONE, residual=mo,
+                                                                  out=outb, M=R), *gemm_cost(R, 4 * C, C, es, True)))
+        for t_ in (cat, xn, mo, gn, hid):
+            pool.give(t_)
+        if name in self.taps:
+            self.keep[name] = outb
+        return outb
+
+    def pyramid(self, feat, T, n, sgp, mixers, pre="_temp_fine."):
+        """EDSGPMIXERLayers.forward (modules.py:69-87) on an NTC tensor."""
+        pool, steps, B, dt = self.pool, self.steps, self.B, self.dt
+        C = sgp[0].C
+        lens = pyramid_lengths(T, n)
+        cur = feat
+        stash = []
+        for i in range(n):
+            cur = self.block(cur, lens[i], sgp[i], f"{pre}_sgp.{i}")
+            stash.append(cur)
+            pooled = pool.take((B, lens[i + 1], C), dt)
+            steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1]: ops.maxpool(a, L, out=b),
+                              B * (lens[i] + lens[i + 1]) * C * _esz(dt)))
+            cur = pooled
+        cur = self.block(cur, lens[n], sgp[n], f"{pre}_sgp.{n}")
+        for i in range(n):
+            lvl = n - 1 - i
+            cur = self.mixer(cur, lens[lvl + 1], stash[lvl], lens[lvl], mixers[lvl], f"{pre}_sgpMixer.{lvl}")
+            cur = self.block(cur, lens[lvl], sgp[n + 1 + i], f"{pre}_sgp.{n + 1 + i}")
+        return cur
+
+
+class PackedWeights:
+    """Device-side weights in kernel layouts.  ``state``: reference key grammar."""
+
+    def __init__(self, cfg, state, act_dtype, device):
+        g = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+        self.arch = g("feature_arch")
+        self.spec = regnet_spec(self.arch)
+        self.mode = "gsm" if self.arch.endswith("_gsm") else ("gsf" if self.arch.endswith("_gsf") else None)
+        self.clip_len = g("clip_len")
+        self.n_layers = g("n_layers")
+        self.ks = g("sgp_ks")
+        self.up = sgp_up_size(self.ks, g("sgp_r"))
+        self.radi = g("radi_displacement")
+        self.act_dtype = act_dtype
+        self.device = device
+        sd = {k: _np(v) for k, v in state.items()}
+        self.double_head = "_pred_fine._fc1._fc_out.weight" in sd
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)   # noqa: E731
+        dense = lambda a: f32(a).to(act_dtype).contiguous()                                       # noqa: E731
+
+        def bn_fold(pre):
+            w, b = sd[pre + ".weight"].astype(np.float64), sd[pre + ".bias"].astype(np.float64)
+            m, v = sd[pre + ".running_mean"].astype(np.float64), sd[pre + ".running_var"].astype(np.float64)
+            s = w / np.sqrt(v + BN_EPS)
+            return f32(s), f32(b - m * s)
+
+        W = SimpleNamespace()
+        p = "_features."
+        W.stem_w = f32(sd[p + "stem.conv.weight"].reshape(32, 27))
+        W.stem_scale, W.stem_shift = bn_fold(p + "stem.bn")
+        W.blocks = []
+        for blk in self.spec.blocks:
+            bp = p + blk.name
+            bw = SimpleNamespace(spec=blk)
+            c1 = bp + (".conv1.net" if blk.gsf_fold else ".conv1")
+            bw.w1 = dense(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin))
+            bw.s1, bw.h1 = bn_fold(c1 + ".bn")
+            w2 = sd[bp + ".conv2.conv.weight"]                       # [C][gw][3][3]
+            G, gw = blk.groups, blk.gw
+            w2 = w2.reshape(G, gw, gw, 3, 3).transpose(0, 3, 4, 2, 1)  # [G][ky][kx][in][out]
+            bw.w2 = f32(w2.reshape(G, 9, gw, gw))
+            bw.s2, bw.h2 = bn_fold(bp + ".conv2.bn")
+            bw.se_w1t = f32(sd[bp + ".se.fc1.weight"].reshape(blk.se_rd, blk.cout).T)
+            bw.se_b1 = f32(sd[bp + ".se.fc1.bias"])
+            bw.se_w2t = f32(sd[bp + ".se.fc2.weight"].reshape(blk.cout, blk.se_rd).T)
+            bw.se_b2 = f32(sd[bp + ".se.fc2.bias"])
+            bw.w3 = dense(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout))
+            bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
+            if blk.has_downsample:
+                bw.wd = dense(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin))
+                bw.sd, bw.hd = bn_fold(bp + ".downsample.bn")
+            if blk.gsf_fold:
+                gp = bp + ".conv1.gs"
+                F = blk.gsf_fold
+                bw.gs_scale, bw.gs_shift = bn_fold(gp + ".bn")
+                w3d = sd[gp + ".conv3D.weight"]                       # [2][F/2][3][3][3]
+                bw.gs_wq = f32(w3d.reshape(F, 27).T)                  # [27][F], c = g*F/2 + cl
+                bw.gs_b3d = f32(sd[gp + ".conv3D.bias"])
+                if self.mode == "gsf":
+                    bw.gs_cw1 = f32(sd[gp + ".channel_conv1.weight"].reshape(18))
+                    bw.gs_cb1 = f32(sd[gp + ".channel_conv1.bias"])
+                    bw.gs_cw2 = f32(sd[gp + ".channel_conv2.weight"].reshape(18))
+                    bw.gs_cb2 = f32(sd[gp + ".channel_conv2.bias"])
+                else:
+                    bw.gs_cw1 = bw.gs_cb1 = bw.gs_cw2 = bw.gs_cb2 = None
+            W.blocks.append(bw)
+        W.temp_enc = f32(sd["temp_enc"])
+        C = self.spec.feat_dim
+
+        W.sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, act_dtype, device) for i in range(2 * self.n_layers + 1)]
+        W.mixer = [pack_sgp_mixer(sd, f"_temp_fine._sgpMixer.{i}", C, act_dtype, device) for i in range(self.n_layers)]
+        if self.double_head:
+            hw = [sd["_pred_fine._fc1._fc_out.weight"], sd["_pred_fine._fc2._fc_out.weight"]]
+            hb = [sd["_pred_fine._fc1._fc_out.bias"], sd["_pred_fine._fc2._fc_out.bias"]]
+        else:
+            hw, hb = [sd["_pred_fine._fc_out.weight"]], [sd["_pred_fine._fc_out.bias"]]
+        self.n_cls = int(sum(w.shape[0] for w in hw))
+        if self.radi > 0:
+            hw.append(sd["_pred_displ._fc_out.weight"])
+            hb.append(sd["_pred_displ._fc_out.bias"])
+        W.head_w = f32(np.concatenate(hw, axis=0))
+        W.head_b = f32(np.concatenate(hb, axis=0))
+        self.n_out = W.head_w.shape[0]
+        self.displ_col = self.n_cls if self.radi > 0 else -1
+        self.W = W
+
+
+class ForwardEngine:
+    def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", use_graph=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("tdeed_amd.ForwardEngine needs an MI355X (no CPU path)")
+        _lib.load()
+        self.cfg = cfg
+        g = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+        self.crop_dim = g("crop_dim")
+        self.pw = PackedWeights(cfg, state, act_dtype, device)
+        self.act_dtype = act_dtype
+        self.device = device
+        self.use_graph = use_graph
+        self._plans = {}
+
+    # ------------------------------------------------------------------ plan construction
+    def _build(self, B, H, W, flip, taps):
+        pw, Wt = self.pw, self.pw.W
+        T = pw.clip_len
+        N = B * T
+        dt = self.act_dtype
+        dev = self.device
+        pool = _Pool(dev)
+        steps = []
+        keep = {}
+        crop = None
+        ch, cw = H, W
+        if self.crop_dim is not None and self.crop_dim > 0 and (self.crop_dim != H or self.crop_dim != W):
+            ch = cw = self.crop_dim
+            crop = (int(round((H - ch) / 2.0)), int(round((W - cw) / 2.0)), ch, cw)
+        frames = torch.empty((N, 3, H, W), dtype=torch.uint8, device=dev)
+        Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
+        x = pool.take((N, Ho, Wo, 32), dt)
+        es = _esz(dt)
+        steps.append(Step("stem", "stem", lambda x=x: ops.stem(frames, Wt.stem_w, Wt.stem_scale, Wt.stem_shift, dt, crop,
+                                                               flip, out=x),
+                          N * 3 * ch * cw + N * Ho * Wo * 32 * es, 2 * N * Ho * Wo * 32 * 27))
+        h, w = Ho, Wo
+        x_kept = "_features.stem" in taps
+        if x_kept:
+            keep["_features.stem"] = x
+        for bw in Wt.blocks:
+            blk = bw.spec
+            M = N * h * w
+            # conv1 (optionally behind the gate-shift splice)
+            y1 = pool.take((N, h, w, blk.cout), dt)
+            if blk.gsf_fold:
+                F = blk.gsf_fold
+                Fp = (F + 7) // 8 * 8
+                gb = dict(gate=pool.take((N, h, w, 2), torch.float32), ysum=pool.take((N, F), torch.float32),
+                          xsum=pool.take((N, F), torch.float32), out=pool.take((M, Fp), dt))
+                if bw.gs_cw1 is not None:
+                    gb["fw"] = pool.take((B, F, T), torch.float32)
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
+                    x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                steps.append(Step(blk.name + ".conv1", "gemm", lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: ops.gemm(
+                    x, bw.w1, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
+                    *gemm_cost(M, blk.cin, blk.cout, es)))
+                if blk.name and ("_features." + blk.name + ".gs_out") in taps:
+                    keep["_features." + blk.name + ".gs_out"] = gb["out"]
+                gs_bufs = list(gb.values())
+            else:
+                steps.append(Step(blk.name + ".conv1", "gemm", lambda x=x, bw=bw, y1=y1, M=M: ops.gemm(
+                    x, bw.w1, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
+                gs_bufs = []
+            s = blk.stride
+            h2, w2 = (h - 1) // s + 1, (w - 1) // s + 1
+            M2 = N * h2 * w2
+            y2 = pool.take((N, h2, w2, blk.cout), dt)
+            pooled = pool.take((N, blk.cout), torch.float32)
+            gate = pool.take((N, blk.cout), torch.float32)
+            steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
+                y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, out=y2, pooled=pooled),
+                (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
+            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate: ops.se_gate(
+                pooled, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate),
+                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            if blk.has_downsample:
+                sc = pool.take((N, h2, w2, blk.cout), dt)
+                gather = (s, h, w, h2, w2) if s > 1 else None
+                steps.append(Step(blk.name + ".downsample", "gemm", lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: ops.gemm(
+                    x, bw.wd, bw.sd, bw.hd, ops.ACT_NONE, gather=gather, out=sc, M=M2),
+                    *gemm_cost(M2, blk.cin, blk.cout, es)))
+            else:
+                sc = x
+            out = pool.take((N, h2, w2, blk.cout), dt)
+            steps.append(Step(blk.name + ".conv3", "gemm", lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2: ops.gemm(
+                y2, bw.w3, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
+                *gemm_cost(M2, blk.cout, blk.cout, es, True)))
+            # liveness: everything but `out` dies here
+            for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
+                pool.give(t_)
+            if not x_kept:
+                pool.give(x)
+            tapname = "_features." + blk.name
+            x_kept = tapname in taps
+            if x_kept:
+                keep[tapname] = out
+            x, h, w = out, h2, w2
+        C = pw.spec.feat_dim
+        feat = pool.take((B, T, C), dt)
+        steps.append(Step("avgpool", "avgpool_posenc", lambda x=x, feat=feat: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat),
+                          (N * h * w + N) * C * es))
+        keep["feat"] = feat
+        if not x_kept:
+            pool.give(x)
+
+        # ---------------- SGP encoder-decoder
+        sb = SgpBuilder(pool, steps, keep, taps, B, dt)
+        cur = sb.pyramid(feat, T, pw.n_layers, Wt.sgp, Wt.mixer)
+        keep["sgp_out"] = cur
+        head_out = torch.empty((N, pw.n_out), dtype=torch.float32, device=dev)
+        steps.append(Step("heads", "heads", lambda cur=cur: ops.heads(cur, Wt.head_w, Wt.head_b, out=head_out),
+                          N * C * es + N * pw.n_out * 4, 2 * N * C * pw.n_out))
+        return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=head_out, graph=None,
+                               pool_bytes=pool.total_bytes(), B=B, T=T)
+
+    def plan(self, B, H, W, flip=False, taps=()):
+        key = (B, H, W, bool(flip), tuple(sorted(taps)))
+        if key not in self._plans:
+            self._plans[key] = self._build(B, H, W, bool(flip), set(taps))
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ execution
+    def run_plan(self, plan):
+        """Launch the plan on the current stream (eager) or replay its HIP graph."""
+        if not self.use_graph:
+            for s_ in plan.steps:
+                s_.fn()
+            return
+        st = torch.cuda.current_stream()
+        if st.cuda_stream == 0:
+            raise RuntimeError("graph replay needs a non-default stream: wrap the call in torch.cuda.stream(s)")
+        if plan.graph is None:
+            for s_ in plan.steps:          # warm-up launch (module load, validates arguments)
+                s_.fn()
+            st.synchronize()
+            import ctypes
+            _lib.call("tdeed_graph_begin", st.cuda_stream)
+            try:
+                for s_ in plan.steps:
+                    s_.fn()
+            finally:
+                h = ctypes.c_void_p()
+                _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
+            plan.graph = h
+        _lib.call("tdeed_graph_launch", plan.graph, st.cuda_stream)
+
+    def forward(self, frames_u8, augment_inference=False, taps=()):
+        """frames: uint8 (B,T,3,H,W) on the GPU.  Returns head_out fp32 (B*T, n_cls [+1])."""
+        if frames_u8.dtype != torch.uint8:
+            raise TypeError("frames must be uint8 (0..255); callers holding floats convert with .to(torch.uint8)")
+        B, T, Cc, H, W = frames_u8.shape
+        if T != self.pw.clip_len:
+            raise ValueError(f"clip length {T} != clip_len {self.pw.clip_len} (gate-shift needs exact clips)")
+        plan = self.plan(B, H, W, augment_inference, taps)
+        plan.frames.copy_(frames_u8.reshape(B * T, Cc, H, W), non_blocking=True)
+        self.run_plan(plan)
+        return plan.head_out, plan
+
+    def __del__(self):
+        try:
+            for p in self._plans.values():
+                if p.graph is not None:
+                    _lib.call("tdeed_graph_destroy", p.graph)
+        except Exception:
+            pass

@@ -1,0 +1,248 @@
+"""Drop-in counterpart of the reference's ``model/model.py`` API, backed by the HIP engine.
+
+Same constructor arguments, attributes and method signatures as
+``TDEEDModel`` / ``TDEEDModel.Impl`` (/root/reference/model/model.py:21-376) and
+``BaseRGBModel`` (/root/reference/model/modules.py:35-55), so ``train_tdeed.py:142-148``,
+``util/eval.py:301-339`` and ``evaluate_tdeed_challenge.py`` can import this module
+instead.  There is exactly one execution backend (the gfx950 kernels); without the
+built library or without a GPU every compute call raises.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops, synth, state_layout
+from .engine import ForwardEngine
+from .regnet_spec import regnet_spec
+
+
+def _cfg_from_args(args):
+    crop = getattr(args, "crop_dim", None)
+    if crop is not None and crop <= 0:      # train_tdeed.py:110-111
+        crop = None
+    return dict(feature_arch=args.feature_arch, clip_len=args.clip_len, crop_dim=crop,
+                n_layers=args.n_layers, sgp_ks=args.sgp_ks, sgp_r=args.sgp_r,
+                num_classes=args.num_classes, radi_displacement=args.radi_displacement)
+
+
+class TDEEDModel:
+
+    class Impl:
+        """The network.  Holds the fp32 master state in the reference's key grammar."""
+
+        def __init__(self, args=None, seed=0):
+            self._modality = args.modality
+            assert self._modality == "rgb", "Only RGB supported for now"
+            self._temp_arch = args.temporal_arch
+            assert self._temp_arch in ["ed_sgp_mixer"], "Only ed_sgp_mixer supported for now"
+            self._radi_displacement = args.radi_displacement
+            self._feature_arch = args.feature_arch
+            assert "rny" in self._feature_arch, "Only rny supported for now"
+            if not self._feature_arch.startswith(("rny002", "rny008")):
+                raise NotImplementedError(self._feature_arch)
+            self._double_head = False
+            self._cfg = _cfg_from_args(args)
+            self._spec = regnet_spec(self._feature_arch)
+            self._d = self._feat_dim = self._spec.feat_dim
+            self._require_clip_len = args.clip_len if self._feature_arch.endswith(("_gsm", "_gsf")) else -1
+            self.croping = self._cfg["crop_dim"]
+            self._head_classes = None
+            # No network, no pretrained ImageNet weights (model.py:38-41 downloads them): deterministic
+            # synthetic init; real weights arrive through load()/load_state_dict().
+            shapes = state_layout.model_state_shapes(self._cfg)
+            self._state = {k: torch.from_numpy(v) for k, v in synth.make_state(shapes, seed).items()}
+            self._device = "cpu"
+            self.training = False
+            self._engines = {}
+
+        # ---- nn.Module-like surface the reference's callers touch
+        def to(self, device):
+            self._device = str(device)
+            self._state = {k: v.to(device) for k, v in self._state.items()}
+            self._engines = {}
+            return self
+
+        def cuda(self):
+            return self.to("cuda")
+
+        def train(self, mode=True):
+            self.training = mode
+            return self
+
+        def eval(self):
+            return self.train(False)
+
+        def state_dict(self):
+            return dict(self._state)
+
+        def load_state_dict(self, sd, strict=True):
+            missing = [k for k in self._state if k not in sd]
+            extra = [k for k in sd if k not in self._state]
+            if strict and (missing or extra):
+                raise RuntimeError(f"state_dict mismatch: missing {missing[:5]} unexpected {extra[:5]}")
+            for k, v in sd.items():
+                if k in self._state:
+                    v = torch.as_tensor(v)
+                    if tuple(v.shape) != tuple(self._state[k].shape):
+                        raise RuntimeError(f"shape mismatch for {k}: {tuple(v.shape)} vs {tuple(self._state[k].shape)}")
+                    self._state[k] = v.detach().to(self._state[k].dtype).to(self._device).clone()
+            self._engines = {}
+
+        def parameters(self):
+            return [v for k, v in self._state.items() if state_layout.is_parameter(k)]
+
+        def update_pred_head(self, num_classes=[1, 1]):
+            """model.py:169-172: replace the class head by two heads (joint-dataset training)."""
+            C = self._feat_dim
+            for k in [k for k in self._state if k.startswith("_pred_fine.")]:
+                del self._state[k]
+            shapes = {}
+            for i, n in enumerate(num_classes, start=1):
+                shapes[f"_pred_fine._fc{i}._fc_out.weight"] = ((n, C), "float32")
+                shapes[f"_pred_fine._fc{i}._fc_out.bias"] = ((n,), "float32")
+            new = {k: torch.from_numpy(v).to(self._device) for k, v in synth.make_state(shapes, 1).items()}
+            # keep the reference's key order: heads sit before _pred_displ
+            displ = {k: self._state.pop(k) for k in [k for k in self._state if k.startswith("_pred_displ.")]}
+            self._state.update(new)
+            self._state.update(displ)
+            self._double_head = True
+            self._head_classes = list(num_classes)
+            self._engines = {}
+
+        def print_stats(self):
+            def cnt(pfx):
+                return sum(v.numel() for k, v in self._state.items()
+                           if k.startswith(pfx) and state_layout.is_parameter(k))
+            print("Model params:", cnt(""))
+            print("  CNN features:", cnt("_features."))
+            print("  Temporal:", cnt("_temp_fine."))
+            print("  Head:", cnt("_pred_fine."))
+
+        # ---- forward
+        def engine(self, act_dtype):
+            if act_dtype not in self._engines:
+                if not str(self._device).startswith("cuda"):
+                    raise RuntimeError("tdeed_amd runs on the GPU only: construct TDEEDModel(device='cuda')")
+                self._engines[act_dtype] = ForwardEngine(self._cfg, self._state, act_dtype, self._device)
+            return self._engines[act_dtype]
+
+        def forward(self, x, y=None, inference=False, augment_inference=False, act_dtype=torch.bfloat16):
+            """model.py:105-149.  x: (B,T,3,H,W) uint8, or float holding 0..255 integers."""
+            if not inference or self.training:
+                raise NotImplementedError(
+                    "training-mode forward (batch-stat BN, dropout, random crop/augment) lands with the "
+                    "backward kernels; this build serves inference=True in eval() mode")
+            if x.dtype != torch.uint8:
+                x = x.round().clamp_(0, 255).to(torch.uint8)
+            x = x.to(self._device)
+            B, T = x.shape[:2]
+            eng = self.engine(act_dtype)
+            head, _ = eng.forward(x.contiguous(), augment_inference)
+            pw = eng.pw
+            head = head.view(B, T, pw.n_out)
+            im_feat = head[..., :pw.n_cls]
+            if self._radi_displacement > 0:
+                return {"im_feat": im_feat, "displ_feat": head[..., pw.displ_col], "_head_out": head}, y
+            return im_feat, y
+
+        __call__ = forward
+
+    # ----------------------------------------------------------------------------------------
+    def __init__(self, device="cuda", args=None):
+        self.device = device
+        self._model = TDEEDModel.Impl(args=args)
+        self._model.print_stats()
+        self._args = args
+        self._model.to(device)
+        self._num_classes = args.num_classes + 1
+        self._stream = None
+
+    # BaseRGBModel (modules.py:35-55)
+    def get_optimizer(self, opt_args):
+        raise NotImplementedError("optimizer / train step: next milestone (backward kernels + fused AdamW)")
+
+    def _get_params(self):
+        return list(self._model.parameters())
+
+    def state_dict(self):
+        return self._model.state_dict()
+
+    def load(self, state_dict):
+        self._model.load_state_dict(state_dict)
+
+    def _ctx(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        return torch.cuda.stream(self._stream)
+
+    def predict(self, seq, use_amp=True, augment_inference=False):
+        """model.py:334-369 -> (pred_cls (B,T) int64 numpy, scores (B,T,K+1) float32 numpy)."""
+        if not isinstance(seq, torch.Tensor):
+            seq = torch.as_tensor(np.asarray(seq))
+        if seq.dim() == 4:
+            seq = seq.unsqueeze(0)
+        self._model.eval()
+        dt = torch.bfloat16 if use_amp else torch.float32
+        cur = torch.cuda.current_stream()
+        with self._ctx():
+            self._stream.wait_stream(cur)
+            pred, _ = self._model(seq.to(self.device), inference=True, augment_inference=augment_inference,
+                                  act_dtype=dt)
+            B, T = seq.shape[:2]
+            if isinstance(pred, dict):
+                head = pred["_head_out"].reshape(B * T, -1)
+                pw = self._model.engine(dt).pw
+                k1 = (self._args.num_classes + 1) if self._model._double_head else pw.n_cls
+                cls, scores = ops.process_prediction(head, B, T, k1, pw.displ_col)
+            else:
+                head = pred.reshape(B * T, -1).contiguous()
+                cls, scores = ops.process_prediction(head, B, T, head.shape[-1], -1)
+            self._stream.synchronize()
+        return cls.cpu().numpy(), scores.cpu().numpy()
+
+    def epoch(self, loader, optimizer=None, scaler=None, lr_scheduler=None, acc_grad_iter=1, fg_weight=5,
+              valMAP=False):
+        """model.py:193-332.  Validation pass (optimizer None) runs on the HIP path; the training
+        branch needs the backward kernels (next milestone)."""
+        if optimizer is not None:
+            raise NotImplementedError("training epoch: backward kernels + fused AdamW are the next milestone")
+        self._model.eval()
+        K1 = self._num_classes
+        w = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32, device=self.device)
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        map_labels, map_preds = [], []
+        n = 0
+        with self._ctx():
+            for batch in loader:
+                frame = batch["frame"].to(self.device)
+                label = batch["label"].to(self.device)
+                B, T = frame.shape[:2]
+                pred, _ = self._model(frame, y=label, inference=True)
+                labelD = batch["labelD"].to(self.device).float().reshape(-1).contiguous() if "labelD" in batch else None
+                if isinstance(pred, dict):
+                    head = pred["_head_out"].reshape(B * T, -1)
+                    dcol = self._model.engine(torch.bfloat16).pw.displ_col if labelD is not None else -1
+                else:
+                    head, dcol = pred.reshape(B * T, -1).contiguous(), -1
+                out = ops.loss(head, K1, w, hard=label.reshape(-1).contiguous(), displ_col=dcol, labelD=labelD)
+                total += out[0]
+                n += 1
+                if valMAP:
+                    cls, scores = ops.process_prediction(head, B, T, K1, dcol)
+                    map_preds.append(scores.cpu())
+                    from .modules import process_labels
+                    map_labels.append(process_labels(label.cpu(), batch.get("labelD"), num_classes=K1))
+            self._stream.synchronize()
+        avg = float(total.item()) / max(n, 1)       # one device sync per epoch, not per batch
+        if valMAP:
+            return avg, torch.cat(map_labels, 0), torch.cat(map_preds, 0)
+        return avg
+
+
+def update_labels_2heads(labels, datasets, num_classes1=1):
+    """model.py:371-376."""
+    for i in range(len(datasets)):
+        if datasets[i] == 2:
+            labels[i] = labels[i] + num_classes1 + 1
+    return labels

@@ -1,0 +1,212 @@
+"""torch-tensor front ends of the C-ABI entry points (one function per ``tdeed_*_fwd``).
+
+Tensors must live on the GPU ("cuda" is the ROCm device string); activations are
+channels-last (NHWC images, NTC sequences).  Nothing here computes on the host: each
+function validates shapes, allocates the output with torch (device memory plumbing) and
+launches the HIP kernel on the current stream.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr, dtype_code, ACT_NONE, ACT_RELU, ACT_GELU  # noqa: F401
+
+
+def _chk(t, name, dtype=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (tdeed_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None):
+    """frames (N,3,H,W) uint8 -> (N,Ho,Wo,32).  crop = (top,left,h,w) or None."""
+    _chk(frames_u8, "frames", torch.uint8)
+    N, _, H, W = frames_u8.shape
+    top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
+    Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
+    if out is None:
+        out = torch.empty((N, Ho, Wo, 32), dtype=act_dtype, device=frames_u8.device)
+    call("tdeed_stem_fwd", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(w), ptr(scale), ptr(shift),
+         ptr(out), dtype_code(act_dtype), stream_ptr())
+    return out
+
+
+def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
+         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None):
+    """C = act((A' @ W^T) * scale + shift + residual).  A (M,K) / W (N,K) same dtype.
+    gather = (stride, hi, wi, ho, wo) for the stride-2 1x1 shortcut."""
+    _chk(A, "A"); _chk(W, "W", A.dtype)
+    K = W.shape[1]
+    N = W.shape[0]
+    if M is None:
+        M = A.numel() // A.shape[-1]
+        if gather is not None:
+            s, hi, wi, ho, wo = gather
+            M = (M // (hi * wi)) * ho * wo
+    lda = A.shape[-1] if lda is None else lda
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    ldc = N if ldc is None else ldc
+    g = gather if gather is not None else (1, 0, 0, 0, 0)
+    call("tdeed_gemm_fwd", ptr(A), lda, ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0,
+         ptr(a_scale), a_scale_rows, M, K, N, ptr(W), W.shape[1], ptr(scale), ptr(shift),
+         ptr(residual), (residual.shape[-1] if residual is not None else 0), act, ptr(out), ldc,
+         g[0], g[1], g[2], g[3], g[4], dtype_code(A.dtype), stream_ptr())
+    return out
+
+
+def gconv3x3(x, w_packed, scale, shift, gw, stride, out=None, pooled=None):
+    """x (N,Hi,Wi,C) -> y (N,Ho,Wo,C), pooled (N,C) fp32.  w_packed: fp32 [G][9][gw][gw]."""
+    _chk(x, "x")
+    N, Hi, Wi, C = x.shape
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    if pooled is None:
+        pooled = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(scale), ptr(shift), ptr(out),
+         ptr(pooled), dtype_code(x.dtype), stream_ptr())
+    return out, pooled
+
+
+def se_gate(pooled, w1t, b1, w2t, b2, out=None):
+    N, C = pooled.shape
+    R = w1t.shape[1]
+    if out is None:
+        out = torch.empty_like(pooled)
+    call("tdeed_se_gate_fwd", ptr(pooled), N, C, R, ptr(w1t), ptr(b1), ptr(w2t), ptr(b2), ptr(out), stream_ptr())
+    return out
+
+
+def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
+               bufs=None):
+    """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
+    GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out."""
+    _chk(x, "x")
+    N, h, w, C = x.shape
+    dev = x.device
+    bufs = bufs or {}
+    gate = bufs.get("gate")
+    if gate is None:
+        gate = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
+    ysum = bufs.get("ysum")
+    if ysum is None:
+        ysum = torch.empty((N, F), dtype=torch.float32, device=dev)
+    xsum = bufs.get("xsum")
+    if xsum is None:
+        xsum = torch.empty((N, F), dtype=torch.float32, device=dev)
+    out = bufs.get("out")
+    if out is None:
+        out = torch.empty((N * h * w, Fp), dtype=x.dtype, device=dev)
+    dc = dtype_code(x.dtype)
+    call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(b3d),
+         ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+    fw = None
+    if cw1 is not None:
+        fw = bufs.get("fw")
+        if fw is None:
+            fw = torch.empty((B, F, T), dtype=torch.float32, device=dev)
+        call("tdeed_gsf_weight_fwd", ptr(ysum), ptr(xsum), B, T, F, h * w, ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
+             ptr(fw), stream_ptr())
+    call("tdeed_gsf_apply_fwd", ptr(x), ptr(gate), ptr(fw), B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
+    return out
+
+
+def avgpool_posenc(x, B, T, temp_enc, out=None):
+    N, h, w, C = x.shape
+    if out is None:
+        out = torch.empty((B, T, C), dtype=x.dtype, device=x.device)
+    call("tdeed_avgpool_posenc_fwd", ptr(x), B, T, h * w, C, ptr(temp_enc), ptr(out), dtype_code(x.dtype),
+         stream_ptr())
+    return out
+
+
+def layernorm(x, w, b, eps=1e-5, out=None, ldy=None, rows=None, C=None, ldx=None):
+    C = x.shape[-1] if C is None else C
+    rows = x.numel() // x.shape[-1] if rows is None else rows
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_layernorm_fwd", ptr(x), (C if ldx is None else ldx), rows, C, ptr(w), ptr(b), eps, ptr(out),
+         (C if ldy is None else ldy), dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def sgp_branch(o, x, ks, up, dw, db, out=None):
+    B, T, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_sgp_branch_fwd", ptr(o), ptr(x), B, T, C, ks, up, ptr(dw), ptr(db), ptr(out), dtype_code(x.dtype),
+         stream_ptr())
+    return out
+
+
+def mixer_branch(xn, cat, T_hi, ks, up, dw1, db1, dw2, db2):
+    B, T_lo, C = xn.shape
+    call("tdeed_mixer_branch_fwd", ptr(xn), B, T_hi, T_lo, C, ks, up, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
+         ptr(cat), dtype_code(xn.dtype), stream_ptr())
+    return cat
+
+
+def groupnorm(x, G, w, b, eps=1e-5, out=None):
+    B, T, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_groupnorm_fwd", ptr(x), B, T, C, G, ptr(w), ptr(b), eps, ptr(out), dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def maxpool(x, T_out, out=None):
+    B, T_in, C = x.shape
+    if out is None:
+        out = torch.empty((B, T_out, C), dtype=x.dtype, device=x.device)
+    call("tdeed_maxpool_fwd", ptr(x), B, T_in, T_out, C, ptr(out), dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def heads(x, w, b, out=None):
+    rows = x.numel() // x.shape[-1]
+    C = x.shape[-1]
+    n_out = w.shape[0]
+    if out is None:
+        out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    call("tdeed_heads_fwd", ptr(x), rows, C, ptr(w), ptr(b), n_out, ptr(out), dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def loss(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=None, out=None):
+    rows, ld = head_out.shape
+    if out is None:
+        out = torch.empty(3, dtype=torch.float32, device=head_out.device)
+    call("tdeed_loss_fwd", ptr(head_out), rows, ld, K1, ptr(hard), ptr(soft), ptr(cls_w), displ_col, ptr(labelD),
+         ptr(out), stream_ptr())
+    return out
+
+
+def process_prediction(head_out, B, T, K1, displ_col):
+    ld = head_out.shape[-1]
+    scores = torch.empty((B, T, K1), dtype=torch.float32, device=head_out.device)
+    cls = torch.empty((B, T), dtype=torch.int64, device=head_out.device)
+    call("tdeed_process_prediction", ptr(head_out), B, T, ld, K1, displ_col, ptr(scores), ptr(cls), stream_ptr())
+    return cls, scores
+
+
+def cast_bf16(src_f32):
+    out = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
+    call("tdeed_cast_f32_to_bf16", ptr(src_f32), ptr(out), src_f32.numel(), stream_ptr())
+    return out
+
+
+def fill_u8_hash(shape, seed, device="cuda"):
+    """Device-side twin of tdeed_amd.synth.uint8_clip (bit-identical bytes)."""
+    from .synth import fnv1a64
+    n = 1
+    for s in shape:
+        n *= int(s)
+    out = torch.empty(((n + 7) // 8) * 8, dtype=torch.uint8, device=device)
+    base = ((seed * 0x9E3779B97F4A7C15) ^ fnv1a64("clip")) & 0xFFFFFFFFFFFFFFFF
+    call("tdeed_fill_u8_hash", ptr(out), n, base, stream_ptr())
+    return out[:n].view(*shape)

@@ -1,0 +1,135 @@
+"""Whole-forward parity on the MI355X: HIP engine vs (a) logits produced by the reference itself
+(committed golden vectors) and (b) the CPU oracle on the same seeded inputs.  -m gpu only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, model_state, t, max_abs, cfg_ns
+from tdeed_amd import synth, state_layout
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOGIT_TOL_F32 = 1e-3      # BASELINE.json north_star: per-frame logits within 1e-3 in fp32
+
+
+def _engine(cfg, sd, dtype, use_graph=True):
+    from tdeed_amd.engine import ForwardEngine
+    return ForwardEngine(cfg, sd, dtype, DEV, use_graph=use_graph)
+
+
+def _run(eng, clip, flip=False, taps=()):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        head, plan = eng.forward(t(clip).to(DEV), augment_inference=flip, taps=taps)
+        st.synchronize()
+    return head.float().cpu(), plan
+
+
+FULL = ["tiny_rny002_gsf", "tiny_rny008_gsf", "tiny_rny002_gsm", "tiny_rny002_crop_flip", "finediving_small",
+        "finediving_big", "snb_t250"]
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_forward_fp32_matches_reference_golden(name):
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    sd = model_state(cfg, meta["seed_w"])
+    clip = synth.uint8_clip(meta["seed_x"], (meta["B"], cfg["clip_len"], 3, meta["H"], meta["W"]))
+    eng = _engine(cfg, sd, torch.float32)
+    head, plan = _run(eng, clip, flip=meta["augment"])
+    B, T = meta["B"], cfg["clip_len"]
+    head = head.view(B, T, -1)
+    K1 = cfg["num_classes"] + 1
+    pooled = plan.keep["feat"].float().cpu() - t(sd["temp_enc"])[None]
+    assert max_abs(pooled, g["pooled"]) < 1e-3 * max(1.0, float(np.abs(g["pooled"]).max()))
+    assert max_abs(plan.keep["sgp_out"].float().cpu(), g["sgp_out"]) < 1e-3 * max(1.0, float(np.abs(g["sgp_out"]).max()))
+    assert max_abs(head[..., :K1], g["logits"]) < LOGIT_TOL_F32
+    if cfg["radi_displacement"] > 0:
+        assert max_abs(head[..., K1], g["displ"]) < LOGIT_TOL_F32
+
+
+@pytest.mark.parametrize("name", ["tiny_rny002_gsf", "tiny_rny008_gsf"])
+def test_forward_fp32_matches_oracle_with_taps(name):
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.regnet_spec import regnet_spec
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    sd = model_state(cfg, meta["seed_w"] + 1)          # different weights than the golden run
+    clip = synth.uint8_clip(77, (meta["B"], cfg["clip_len"], 3, meta["H"], meta["W"]))
+    spec = regnet_spec(cfg["feature_arch"])
+    taps = {}
+    with torch.no_grad():
+        logits, displ, feat = O.forward(t(clip), sd, cfg, spec, taps=taps)
+    names = ["_features.stem"] + ["_features." + b.name for b in spec.blocks]
+    eng = _engine(cfg, sd, torch.float32, use_graph=False)
+    head, plan = _run(eng, clip, taps=tuple(names))
+    for n in names:
+        ref = taps[n].permute(0, 2, 3, 1)
+        got = plan.keep[n].float().cpu()
+        assert max_abs(got, ref) < 1e-4 * max(1.0, float(ref.abs().max())), n
+    assert max_abs(plan.keep["feat"].float().cpu(), feat) < 1e-4 * max(1.0, float(feat.abs().max()))
+    K1 = cfg["num_classes"] + 1
+    head = head.view(meta["B"], cfg["clip_len"], -1)
+    assert max_abs(head[..., :K1], logits) < LOGIT_TOL_F32
+    assert max_abs(head[..., K1], displ) < LOGIT_TOL_F32
+
+
+@pytest.mark.parametrize("name", ["tiny_rny002_gsf", "finediving_small"])
+def test_forward_bf16_close_to_reference(name):
+    """bf16 is the throughput mode: not held to 1e-3 (the reference's own bf16 autocast is 4.5e-2 off,
+    SURVEY.md section 0) but must track the fp32 logits."""
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    sd = model_state(cfg, meta["seed_w"])
+    clip = synth.uint8_clip(meta["seed_x"], (meta["B"], cfg["clip_len"], 3, meta["H"], meta["W"]))
+    head, _ = _run(_engine(cfg, sd, torch.bfloat16), clip)
+    K1 = cfg["num_classes"] + 1
+    head = head.view(meta["B"], cfg["clip_len"], -1)
+    ref = t(g["logits"])
+    err = (head[..., :K1] - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err < 0.08 * max(1.0, scale), (err, scale)
+    assert (head[..., :K1].argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
+
+
+def test_graph_replay_equals_eager_and_is_deterministic():
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    sd = model_state(cfg, 0)
+    clip = synth.uint8_clip(5, (2, cfg["clip_len"], 3, 64, 64))
+    h_eager, _ = _run(_engine(cfg, sd, torch.bfloat16, use_graph=False), clip)
+    eng = _engine(cfg, sd, torch.bfloat16, use_graph=True)
+    h1, _ = _run(eng, clip)
+    h2, _ = _run(eng, clip)
+    clip2 = synth.uint8_clip(6, (2, cfg["clip_len"], 3, 64, 64))
+    h3, _ = _run(eng, clip2)
+    assert torch.equal(h1, h_eager) and torch.equal(h1, h2)
+    assert not torch.equal(h1, h3)
+
+
+def test_model_api_predict_and_epoch():
+    """TDEEDModel drop-in surface: predict() against the reference's own predict() output, epoch() val loss
+    against the oracle loss, state_dict round trip."""
+    from tdeed_amd.model import TDEEDModel
+    from oracle import tdeed_oracle as O
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    m = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    sd = model_state(cfg, meta["seed_w"])
+    m.load({k: t(v) for k, v in sd.items()})
+    got = m.state_dict()
+    assert list(got.keys()) == list(state_layout.model_state_shapes(cfg).keys())
+    clip = synth.uint8_clip(meta["seed_x"], (meta["B"], cfg["clip_len"], 3, meta["H"], meta["W"]))
+    cls, scores = m.predict(t(clip).float(), use_amp=False)       # callers hand over .float() frames
+    assert max_abs(scores, g["predict_scores"]) < 1e-3
+    assert (cls == g["predict_cls"]).mean() > 0.99
+    cls_b, scores_b = m.predict(t(clip), use_amp=True)
+    assert np.abs(scores_b - g["predict_scores"]).max() < 0.1
+    # validation epoch: loss of the HIP path == oracle loss on the golden logits
+    lab, labD = synth.labels(3, meta["B"], cfg["clip_len"], cfg["num_classes"], cfg["radi_displacement"])
+    loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD))]
+    loss = m.epoch(loader)
+    ref = float(O.loss_fn(t(g["logits"]), t(lab), t(g["displ"]), t(labD)))
+    assert abs(loss - ref) < 0.05 * max(1.0, abs(ref))      # bf16 forward
+    with pytest.raises(NotImplementedError):
+        m.epoch(loader, optimizer=object())

@@ -1,0 +1,316 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle / torch fp32
+references and the reference-generated golden vectors.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden, act, module_state, t, max_abs
+from tdeed_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+F32_TOL = 1e-4          # kernels in TDEED_F32 mode vs fp32 CPU (relative to output magnitude)
+BF16_TOL = 3e-2         # bf16 storage, fp32 accumulation
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tdeed_amd import ops as o, _lib
+    _lib.load()
+    return o
+
+
+def rel_err(a, b):
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    a = a.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def rnd(seed, name, shape, scale=1.0):
+    return t(act(seed, name, shape, scale))
+
+
+# ----------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(300, 32, 24), (257, 24, 56), (1000, 56, 152), (129, 152, 368), (640, 368, 368),
+               (200, 368, 1472), (200, 1472, 368), (75, 2208, 368), (128, 64, 64), (5000, 128, 320)]
+
+
+@pytest.mark.parametrize("M,K,N", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_plain(ops, M, K, N, dtype):
+    A = rnd(1, f"A{M}", (M, K)).to(dtype)
+    W = rnd(2, f"W{N}", (N, K), 1.0 / np.sqrt(K)).to(dtype)
+    sc = rnd(3, "sc", (N,)) * 0.2 + 1.0
+    sh = rnd(4, "sh", (N,))
+    ref = (A.float() @ W.float().T) * sc + sh
+    out = ops.gemm(A.to(DEV), W.to(DEV), sc.to(DEV), sh.to(DEV), ops.ACT_NONE)
+    assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("actn", [0, 1, 2])
+def test_gemm_epilogue(ops, dtype, actn):
+    M, K, N = 333, 152, 152
+    A = rnd(5, "A", (M, K)).to(dtype)
+    W = rnd(6, "W", (N, K), 0.1).to(dtype)
+    R = rnd(7, "R", (M, N)).to(dtype)
+    sh = rnd(8, "sh", (N,))
+    ref = A.float() @ W.float().T + sh + R.float()
+    ref = [ref, torch.relu(ref), F.gelu(ref)][actn]
+    out = ops.gemm(A.to(DEV), W.to(DEV), None, sh.to(DEV), actn, residual=R.to(DEV))
+    assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_se_scale_splice_gather(ops, dtype):
+    # SE gate on A (per frame), gate-shift splice in front, and the stride-2 row gather
+    Fr, hw, K, N = 6, 49, 152, 368
+    M = Fr * hw
+    A = rnd(9, "A", (M, K)).to(dtype)
+    W = rnd(10, "W", (N, K), 0.1).to(dtype)
+    gate = torch.sigmoid(rnd(11, "g", (Fr, K)))
+    ref = (A.float().view(Fr, hw, K) * gate[:, None, :])
+    if dtype == torch.bfloat16:
+        ref = ref.to(torch.bfloat16).float()        # the kernel rounds the scaled operand to bf16
+    ref = ref.view(M, K) @ W.float().T
+    out = ops.gemm(A.to(DEV), W.to(DEV), a_scale=gate.to(DEV), a_scale_rows=hw)
+    assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+    k0 = 48
+    A0 = rnd(12, "A0", (M, k0)).to(dtype)
+    Asp = torch.cat([A0, A[:, k0:]], dim=1)
+    ref = Asp.float() @ W.float().T
+    out = ops.gemm(A.to(DEV), W.to(DEV), A0=A0.to(DEV), k0=k0)
+    assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+    hi, wi, s = 7, 9, 2
+    ho, wo = (hi - 1) // s + 1, (wi - 1) // s + 1
+    X = rnd(13, "X", (3, hi, wi, K)).to(dtype)
+    ref = X.float()[:, ::s, ::s, :].reshape(-1, K) @ W.float().T
+    out = ops.gemm(X.to(DEV), W.to(DEV), gather=(s, hi, wi, ho, wo))
+    assert out.shape[0] == 3 * ho * wo
+    assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+# ----------------------------------------------------------------------------- stem / grouped conv / SE / pool
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(2, 64, 64, None, False), (1, 72, 80, (4, 8, 64, 64), True), (1, 50, 37, None, False)])
+def test_stem(ops, dtype, geom):
+    from oracle import tdeed_oracle as O
+    N, H, W, crop, flip = geom
+    fr = synth.uint8_clip(21, (N, 3, H, W))
+    w = rnd(22, "w", (32, 3, 3, 3), 0.3)
+    sc = rnd(23, "sc", (32,)) * 0.2 + 1.0
+    sh = rnd(24, "sh", (32,)) * 0.1
+    x = t(fr).float() / 255.0
+    if crop:
+        x = x[..., crop[0]:crop[0] + crop[2], crop[1]:crop[1] + crop[3]]
+    if flip:
+        x = x.flip(-1)
+    mean = torch.tensor(O.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(O.IMAGENET_STD).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    ref = torch.relu(F.conv2d(x, w, stride=2, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    out = ops.stem(t(fr).to(DEV), w.reshape(32, 27).contiguous().to(DEV), sc.to(DEV), sh.to(DEV), dtype, crop, flip)
+    assert rel_err(out.float().permute(0, 3, 1, 2), ref) < (F32_TOL if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,gw,stride,H,W", [(24, 8, 2, 20, 22), (56, 8, 1, 9, 7), (64, 16, 2, 16, 16),
+                                             (368, 8, 1, 7, 7), (128, 16, 1, 28, 28)])
+def test_gconv3x3(ops, dtype, C, gw, stride, H, W):
+    N = 3
+    x = rnd(31, "x", (N, C, H, W)).to(dtype)
+    w = rnd(32, "w", (C, gw, 3, 3), 0.2)
+    sc = rnd(33, "sc", (C,)) * 0.2 + 1.0
+    sh = rnd(34, "sh", (C,)) * 0.1
+    ref = torch.relu(F.conv2d(x.float(), w, stride=stride, padding=1, groups=C // gw) * sc.view(1, -1, 1, 1)
+                     + sh.view(1, -1, 1, 1))
+    G = C // gw
+    wp = w.reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1).reshape(G, 9, gw, gw).contiguous()
+    y, pooled = ops.gconv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp.to(DEV), sc.to(DEV), sh.to(DEV), gw, stride)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert rel_err(y.float().permute(0, 3, 1, 2), ref) < tol
+    assert rel_err(pooled, ref.mean(dim=(2, 3))) < tol
+
+
+def test_se_gate(ops):
+    N, C, R = 11, 152, 38
+    p = rnd(41, "p", (N, C)).abs()
+    w1, b1 = rnd(42, "w1", (R, C), 0.1), rnd(43, "b1", (R,), 0.1)
+    w2, b2 = rnd(44, "w2", (C, R), 0.2), rnd(45, "b2", (C,), 0.1)
+    ref = torch.sigmoid(torch.relu(p @ w1.T + b1) @ w2.T + b2)
+    out = ops.se_gate(p.to(DEV), w1.T.contiguous().to(DEV), b1.to(DEV), w2.T.contiguous().to(DEV), b2.to(DEV))
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_avgpool_posenc(ops, dtype):
+    B, T, hw, C = 2, 5, 49, 368
+    x = rnd(51, "x", (B * T, 7, 7, C)).to(dtype)
+    te = rnd(52, "te", (T, C), 0.1)
+    ref = x.float().mean(dim=(1, 2)).view(B, T, C) + te[None]
+    out = ops.avgpool_posenc(x.to(DEV), B, T, te.to(DEV))
+    assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else 1e-2)
+
+
+# ----------------------------------------------------------------------------- gate-shift (golden = reference output)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["gsf_f16", "gsf_f40", "gsf_f92", "gsm_f16"])
+def test_gate_shift_golden(ops, name, dtype):
+    meta, g = load_golden(name)
+    Fd, T, B, h, w, mode = meta["F"], meta["T"], meta["B"], meta["h"], meta["w"], meta["mode"]
+    sd = module_state("gate_shift", "gs", meta["seed"], F=Fd, mode=mode)
+    x = act(meta["seed"], name + ":x", (B * T, Fd, h, w))
+    C = (Fd + 7) // 8 * 8 + 8                      # a few pass-through channels behind the fold
+    xin = np.zeros((B * T, h, w, C), np.float32)
+    xin[..., :Fd] = x.transpose(0, 2, 3, 1)
+    xin[..., Fd:] = act(99, "pad", (B * T, h, w, C - Fd))
+    bnw, bnb = sd["gs.bn.weight"].astype(np.float64), sd["gs.bn.bias"].astype(np.float64)
+    s = bnw / np.sqrt(sd["gs.bn.running_var"].astype(np.float64) + 1e-5)
+    sh = bnb - sd["gs.bn.running_mean"].astype(np.float64) * s
+    dev = lambda a: t(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    kw = {}
+    if mode == "gsf":
+        kw = dict(cw1=dev(sd["gs.channel_conv1.weight"].reshape(18)), cb1=dev(sd["gs.channel_conv1.bias"]),
+                  cw2=dev(sd["gs.channel_conv2.weight"].reshape(18)), cb2=dev(sd["gs.channel_conv2.bias"]))
+    Fp = (Fd + 7) // 8 * 8
+    out = ops.gate_shift(t(xin).to(dtype).to(DEV), B, T, Fd, Fp, dev(s), dev(sh),
+                         dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T), dev(sd["gs.conv3D.bias"]), **kw)
+    out = out.float().cpu().view(B * T, h, w, Fp)
+    ref = t(g["y"]).permute(0, 2, 3, 1)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert max_abs(out[..., :Fd], ref) < tol * max(1.0, float(ref.abs().max()))
+    if Fp > Fd:   # padding columns are copies of x
+        assert max_abs(out[..., Fd:], t(xin)[..., Fd:Fp].to(dtype).float()) == 0.0
+
+
+# ----------------------------------------------------------------------------- SGP pieces
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_pool_golden(ops, dtype):
+    meta, g = load_golden("misc_ops")
+    sd = module_state("ln", "ln", meta["seed"], C=48)
+    x = act(meta["seed"], "ln:x", (2, 48, 25)).transpose(0, 2, 1)          # NTC
+    dev = lambda a: t(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    y = ops.layernorm(dev(x).to(dtype), dev(sd["ln.weight"].reshape(-1)), dev(sd["ln.bias"].reshape(-1)))
+    ref = t(g["ln_y"]).permute(0, 2, 1)
+    assert max_abs(y.float().cpu(), ref) < (2e-5 if dtype == torch.float32 else 3e-2)
+    for (L, o) in [(25, 13), (125, 63), (100, 50), (13, 7)]:
+        xp = act(meta["seed"], f"pool{L}:x", (2, 16, L)).transpose(0, 2, 1)
+        yp = ops.maxpool(dev(xp).to(dtype), o)
+        refp = t(g[f"pool_{L}_{o}"]).permute(0, 2, 1)
+        if dtype == torch.float32:
+            assert torch.equal(yp.cpu(), refp)
+        else:
+            assert torch.equal(yp.cpu(), refp.to(torch.bfloat16))
+
+
+def _run_steps(steps):
+    for s_ in steps:
+        s_.fn()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["sgp_block_c32_t25", "sgp_block_c368_t100", "sgp_block_c48_t13"])
+def test_sgp_block_golden(ops, name, dtype):
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, _Pool
+    meta, g = load_golden(name)
+    B, C, T = meta["B"], meta["C"], meta["T"]
+    sd = module_state("sgp_block", "blk", meta["seed"], **meta)
+    x = t(act(meta["seed"], name + ":x", (B, C, T)).transpose(0, 2, 1).copy()).to(dtype).to(DEV)
+    steps, keep = [], {}
+    sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, dtype)
+    out = sb.block(x, T, pack_sgp_block(sd, "blk", C, dtype, DEV), "blk")
+    _run_steps(steps)
+    ref = t(g["y"]).permute(0, 2, 1)
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["sgp_mixer_c32_t25", "sgp_mixer_c368_t100"])
+def test_sgp_mixer_golden(ops, name, dtype):
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_mixer, _Pool
+    meta, g = load_golden(name)
+    B, C, Th, Tl = meta["B"], meta["C"], meta["T_hi"], meta["T_lo"]
+    sd = module_state("sgp_mixer", "mix", meta["seed"], **meta)
+    z = t(act(meta["seed"], name + ":z", (B, C, Th)).transpose(0, 2, 1).copy()).to(dtype).to(DEV)
+    x = t(act(meta["seed"], name + ":x", (B, C, Tl)).transpose(0, 2, 1).copy()).to(dtype).to(DEV)
+    steps, keep = [], {}
+    sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, dtype)
+    out = sb.mixer(x, Tl, z, Th, pack_sgp_mixer(sd, "mix", C, dtype, DEV), "mix")
+    _run_steps(steps)
+    ref = t(g["y"]).permute(0, 2, 1)
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["pyramid_c32_l25_n2", "pyramid_c64_l100_n3", "pyramid_c48_l250_n2"])
+def test_pyramid_golden(ops, name, dtype):
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, pack_sgp_mixer, _Pool
+    meta, g = load_golden(name)
+    B, C, L, n = meta["B"], meta["C"], meta["L"], meta["n"]
+    sd = module_state("pyramid", "_temp_fine", meta["seed"], **meta)
+    x = t(act(meta["seed"], name + ":x", (B, L, C))).to(dtype).to(DEV)
+    sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, dtype, DEV) for i in range(2 * n + 1)]
+    mix = [pack_sgp_mixer(sd, f"_temp_fine._sgpMixer.{i}", C, dtype, DEV) for i in range(n)]
+    steps, keep = [], {}
+    sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, dtype)
+    out = sb.pyramid(x, L, n, sgp, mix)
+    _run_steps(steps)
+    ref = t(g["y"])
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+
+
+# ----------------------------------------------------------------------------- heads / loss / post-proc
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads(ops, dtype):
+    rows, C, n_out = 37, 368, 6
+    x = rnd(61, "x", (rows, C)).to(dtype)
+    w, b = rnd(62, "w", (n_out, C), 0.05), rnd(63, "b", (n_out,), 0.1)
+    out = ops.heads(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert rel_err(out, x.float() @ w.T + b) < 1e-5
+
+
+def test_loss_and_process_prediction_golden(ops):
+    meta, g = load_golden("loss_postproc")
+    B, T, K1, seed = meta["B"], meta["T"], meta["K1"], meta["seed"]
+    logits = act(seed, "logits", (B, T, K1), 2.0)
+    displ = act(seed, "displ", (B, T), 1.5)
+    lab, labD = synth.labels(seed, B, T, K1 - 1, 2, fg_frac=0.3)
+    head = t(np.concatenate([logits, displ[..., None]], axis=-1).reshape(B * T, K1 + 1)).to(DEV)
+    w = torch.tensor([1.0] + [5.0] * (K1 - 1), device=DEV)
+    out = ops.loss(head, K1, w, hard=t(lab.reshape(-1)).to(DEV), displ_col=K1,
+                   labelD=t(labD.reshape(-1).astype(np.float32)).to(DEV)).cpu()
+    assert abs(float(out[1]) - float(g["ce_hard"])) < 1e-5
+    assert abs(float(out[2]) - float(g["mse"])) < 1e-5
+    assert abs(float(out[0]) - float(g["ce_hard"]) - float(g["mse"])) < 1e-5
+    out = ops.loss(head, K1, w, soft=t(g["soft_labels"].reshape(B * T, K1)).to(DEV)).cpu()
+    assert abs(float(out[1]) - float(g["ce_soft"])) < 1e-5
+    cls, scores = ops.process_prediction(head, B, T, K1, K1)
+    assert max_abs(scores.cpu(), g["process_prediction"]) < 1e-6
+    assert np.array_equal(cls.cpu().numpy(), g["process_prediction"].argmax(-1))
+    head2 = t(np.concatenate([logits, g["d_half"][..., None]], axis=-1).reshape(B * T, K1 + 1)).to(DEV)
+    _, scores = ops.process_prediction(head2, B, T, K1, K1)       # .5 displacements: round-half-even
+    assert max_abs(scores.cpu(), g["process_prediction_half"]) < 1e-6
+    from tdeed_amd import modules
+    s2 = modules.process_double_head(t(logits).to(DEV), t(displ).to(DEV), num_classes=3)
+    assert max_abs(s2.cpu(), g["process_double_head"]) < 1e-6
+
+
+def test_fill_u8_hash_matches_host(ops):
+    for shape in [(2, 3, 3, 8, 8), (1, 5, 3, 7, 9)]:
+        dev = ops.fill_u8_hash(shape, 1000).cpu().numpy()
+        assert np.array_equal(dev, synth.uint8_clip(1000, shape))
+
+
+def test_errors_are_loud(ops):
+    from tdeed_amd._lib import HipCallError
+    with pytest.raises(HipCallError):
+        ops.gemm(torch.zeros(4, 12, device=DEV), torch.zeros(8, 12, device=DEV))      # K % 8 != 0
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))                                # CPU tensors

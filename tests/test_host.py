@@ -1,0 +1,78 @@
+"""Host-side logic that needs no GPU: synthetic generator determinism, state layout, spec tables,
+weight packing, the TDEEDModel API surface."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import model_state, cfg_ns
+from tdeed_amd import synth, state_layout
+from tdeed_amd.regnet_spec import regnet_spec, gsf_fold_dim, sgp_up_size, pyramid_lengths
+
+CFG = dict(feature_arch="rny002_gsf", clip_len=16, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+           radi_displacement=2)
+
+
+def test_synth_is_deterministic_and_well_scaled():
+    a = synth.uint8_clip(7, (2, 3, 5, 11))
+    assert np.array_equal(a, synth.uint8_clip(7, (2, 3, 5, 11))) and not np.array_equal(a, synth.uint8_clip(8, (2, 3, 5, 11)))
+    # known-answer: pins the hash so that fixtures and the device-side twin cannot drift
+    assert synth.hash_u64(0, "clip", 2).tolist() == synth.hash_u64(0, "clip", 3)[:2].tolist()
+    n = synth.normalish(1, "x", 200000)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
+    u = synth.uniform01(1, "x", 200000)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_spec_tables_match_survey():
+    s2, s8 = regnet_spec("rny002_gsf"), regnet_spec("rny008_gsf")
+    assert [b.gsf_fold for b in s2.blocks if b.gsf_fold] == [16, 40, 40, 40, 40] + [92] * 6
+    assert [b.gsf_fold for b in s8.blocks if b.gsf_fold] == [32] + [80] * 8 + [192]
+    assert [b.se_rd for b in s2.blocks][:3] == [8, 6, 14] and s8.feat_dim == 768
+    assert gsf_fold_dim(368) == 92 and sgp_up_size(7, 4) == 33 and sgp_up_size(9, 4) == 41
+    assert pyramid_lengths(100, 3) == [100, 50, 25, 13] and pyramid_lengths(250, 2) == [250, 125, 63]
+    assert all(b.gsf_fold == 0 for b in regnet_spec("rny002").blocks)
+
+
+def test_param_counts_match_reference():
+    for arch, n, total in [("rny002_gsf", 2, 12267634), ("rny008_gsf", 3, 64018958)]:
+        cfg = dict(feature_arch=arch, clip_len=100, crop_dim=224, n_layers=n, sgp_ks=7, sgp_r=4, num_classes=4,
+                   radi_displacement=2)
+        sh = state_layout.model_state_shapes(cfg)
+        assert sum(int(np.prod(s)) for k, (s, _) in sh.items() if state_layout.is_parameter(k)) == total
+
+
+def test_weight_packing_layouts():
+    from tdeed_amd.engine import PackedWeights
+    sd = model_state(CFG)
+    pw = PackedWeights(CFG, sd, torch.bfloat16, "cpu")
+    b = pw.W.blocks[2]                       # s3.b1: gate-shift in front of conv1
+    assert b.spec.gsf_fold == 16 and b.gs_wq.shape == (27, 16) and b.w1.dtype == torch.bfloat16
+    w2 = sd["_features.s3.b1.conv2.conv.weight"]           # [C][gw][3][3]
+    g, o, i, ky, kx = 3, 5, 2, 1, 2
+    assert float(b.w2[g, ky * 3 + kx, i, o]) == float(w2[g * 8 + o, i, ky, kx])
+    s = sd["_features.stem.bn.weight"] / np.sqrt(sd["_features.stem.bn.running_var"] + 1e-5)
+    assert np.allclose(pw.W.stem_scale.numpy(), s, rtol=1e-6)
+    assert pw.n_out == 5 and pw.displ_col == 4
+    o0 = pw.W.sgp[0]
+    assert o0.dw.shape == (368, 2 * 5 + 13 + 2) and o0.db.shape == (5, 368)
+    assert np.array_equal(o0.dw[:, 5:10].numpy(), sd["_temp_fine._sgp.0.convw.weight"].reshape(368, 5))
+
+
+def test_model_api_surface_on_cpu():
+    """Construction, state_dict grammar, double head, loud failure without a GPU."""
+    from tdeed_amd.model import TDEEDModel, update_labels_2heads
+    m = TDEEDModel(device="cpu", args=cfg_ns(CFG))
+    sd = m.state_dict()
+    assert list(sd) == list(state_layout.model_state_shapes(CFG))
+    assert m._num_classes == 4 and not m._model._double_head
+    m.load({k: v.clone() for k, v in sd.items()})
+    with pytest.raises(RuntimeError):
+        m.load({"bogus": torch.zeros(1)})
+    m._model.update_pred_head([4, 18])
+    assert m._model._double_head and "_pred_fine._fc2._fc_out.weight" in m.state_dict()
+    assert list(m.state_dict())[-2:] == ["_pred_displ._fc_out.weight", "_pred_displ._fc_out.bias"]
+    assert len(m._get_params()) == sum(state_layout.is_parameter(k) for k in m.state_dict())
+    lab = torch.zeros(2, 4, dtype=torch.int64)
+    assert update_labels_2heads(lab, [1, 2], 3)[1, 0].item() == 4
+    with pytest.raises(RuntimeError, match="GPU"):
+        m._model(torch.zeros(1, 16, 3, 32, 32, dtype=torch.uint8), inference=True)
