@@ -92,6 +92,10 @@ def _kind(key: str, shape) -> tuple:
         return ("normal", 0.0, 1.0 / shape[0])
     is_norm = re.search(r"(\.bn\.|\.ln\d?\.|\.gn\.)", "." + key) is not None
     if is_norm:
+        if key.endswith("conv3.bn.weight"):
+            # last BN of a residual branch: small gain keeps the synthetic trunk well conditioned
+            # (activations O(1) through 14 blocks) like a trained net; otherwise they grow ~1.3x per block
+            return ("uniform", 0.15, 0.45)
         return ("uniform", 0.5, 1.5) if last == "weight" else ("normal", 0.0, 0.1)
     mod = key.rsplit(".", 2)[-2] if key.count(".") >= 1 else ""
     mod_base = re.sub(r"\d+$", "", mod)

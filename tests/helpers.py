@@ -62,7 +62,8 @@ def module_state(mkind, prefix, mseed, **kw):
 
 
 def t(x):
-    return torch.from_numpy(np.ascontiguousarray(x))
+    x = np.asarray(x)
+    return torch.from_numpy(x.copy() if x.ndim == 0 else np.ascontiguousarray(x))
 
 
 def max_abs(a, b):
