@@ -62,29 +62,39 @@ int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
 
 /* ---- grouped 3x3 conv + BN + ReLU + SE squeeze ---------------------------------------------
  * timm Bottleneck.conv2 (groups = C/gw, stride 1|2, pad 1) + BN(eval) + ReLU, and the SE
- * squeeze mean(H,W) of its output.  x: [N][Hi][Wi][C], w: fp32 [C][gw][3][3],
- * y: [N][Ho][Wo][C], pooled: fp32 [N][C] (mean over Ho*Wo).  gw in {8,16}. */
+ * squeeze (sum over H,W) of its output.  x: [N][Hi][Wi][C], y: [N][Ho][Wo][C], gw in {8,16}.
+ *   w      fp32 [G][9][gw_in][gw_out] (tap-major repack of Conv2d.weight [C][gw][3][3]); used by the
+ *          VALU kernel (TDEED_F32, or bf16 when wfrag is NULL).
+ *   wfrag  bf16 MFMA operand fragments [ceil4(C/16)][5][64][8] (see tdeed_amd.engine.pack_gconv_frags);
+ *          TDEED_BF16 only: implicit GEMM on v_mfma_f32_16x16x32_bf16 from an LDS-staged halo band.
+ *   pooled fp32 [N][parts][C]: per-band partial SUMS of y over pixels, parts =
+ *          tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype) (1 on the VALU path). */
+int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype);
 int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
-                       const float* w, const float* scale, const float* shift, void* y,
-                       float* pooled, int dtype, void* stream);
+                       const float* w, const void* wfrag, const float* scale, const float* shift,
+                       void* y, float* pooled, int dtype, void* stream);
 
-/* ---- SE excitation: gate = sigmoid(W2 relu(W1 pooled + b1) + b2) ---------------------------
- * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled, gate: fp32 [N][C]; w1 [R][C], w2 [C][R]. */
-int tdeed_se_gate_fwd(const float* pooled, int N, int C, int R, const float* w1, const float* b1,
-                      const float* w2, const float* b2, float* gate, void* stream);
+/* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
+ * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled: fp32 [N][n_parts][C] partial sums, mean = inv_cnt *
+ * sum over parts; gate: fp32 [N][C]; w1t [C][R] (fc1.weight transposed), w2t [R][C] (fc2.weight transposed). */
+int tdeed_se_gate_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R,
+                      const float* w1t, const float* b1, const float* w2t, const float* b2,
+                      float* gate, void* stream);
 
 /* ---- Gate-Shift(-Fuse) (model/impl/gsf.py:38-93, model/impl/gsm.py:89-116, eval BN) ------------
  * x: [B*T][h][w][C] (first F channels are gated).  Three launches:
  *  gate:   BN3d+ReLU+Conv3d(3x3x3, groups 2)+tanh -> gate fp32 [B*T][h][w][2]; also
- *          ysum[B*T][F] = sum_hw gate*x, xsum[B*T][F] = sum_hw x (fp32).
+ *          ysum[B*T][F] = sum_hw gate*x, xsum[B*T][F] = sum_hw x (fp32).  Two kernels inside: per-frame
+ *          partial sums Q (each frame read once), then the temporal combine + tanh + spatial sums.
  *  weight: GSF only: fusion weight fw[B][F][T] = sigmoid(Conv2d(2->1,3x3) over the (c,t) plane
  *          of [mean shifted y ; mean r]) (gsf.py:61-78).
  *  apply:  out[B*T][h][w][Fp] : channels [0,F) = interleave(shift(y)*fw + r*(1-fw)) (GSM: fw==1
  *          i.e. shift(y)+r), channels [F,Fp) copied from x (Fp = F rounded up to 8). */
 int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
                        const float* bn_scale, const float* bn_shift,
-                       const float* w3d /*[2][F/2][3][3][3]*/, const float* b3d /*[2]*/,
-                       float* gate, float* ysum, float* xsum, int dtype, void* stream);
+                       const float* wq /*[27][F] tap-major conv3D weight*/, const float* b3d /*[2]*/,
+                       float* Q /*scratch fp32 [B*T][h][w][6]*/, float* gate, float* ysum, float* xsum,
+                       int dtype, void* stream);
 int tdeed_gsf_weight_fwd(const float* ysum, const float* xsum, int B, int T, int F, int hw,
                          const float* cw1 /*[2][3][3]*/, const float* cb1, const float* cw2,
                          const float* cb2, float* fw /*[B][F][T]*/, void* stream);

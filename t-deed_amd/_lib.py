@@ -32,9 +32,10 @@ _SIGS = {
     "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_gemm_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, c_long, P, P, P, c_long,
                         c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
-    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
-    "tdeed_se_gate_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
-    "tdeed_gsf_gate_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_gconv3x3_parts": ([c_int, c_int, c_int, c_int, c_int], c_int),
+    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
+    "tdeed_gsf_gate_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_gsf_weight_fwd": ([P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gsf_apply_fwd": ([P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_avgpool_posenc_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_int, P], c_int),

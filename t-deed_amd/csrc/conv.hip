@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHR) void gconv3x3_kernel(const T* __restrict__ x,
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NW; ++i) s += red[i][threadIdx.x];
-    pooled[(long)n * C + g * GW + threadIdx.x] = s / (float)npix;
+    pooled[(long)n * C + g * GW + threadIdx.x] = s;   // sum; the SE kernel applies 1/(Ho*Wo)
   }
 }
 
@@ -185,63 +185,248 @@ static int launch_gconv(const void* x, int N, int Hi, int Wi, int C, int stride,
   return TDEED_OK;
 }
 
+// --------------------------------------------------------------------------- bf16 MFMA variant
+// Implicit GEMM per "unit" of 16 output channels (two gw=8 groups block-diagonal, or one gw=16
+// group): D[n][pixel] = sum_k Wt[n][k] X[k][pixel], k = (half, tap, in-ch 8) -> 18 slots of 8 = 5
+// k-steps of v_mfma_f32_16x16x32_bf16.  The X fragment of a lane (pixel l&15, slot 4ks+(l>>4)) is
+// exactly one 16-byte chunk of the channels-last input at pixel+tap, so a zero-padded halo band of
+// the input (rows x (Wi+2) x slab of <=64 channels, pixel stride slab*2+16 B => conflict-free
+// ds_read_b128) is the only staging needed.  Weights come pre-packed per (unit, k-step, lane)
+// and stay in registers.  The weights are the MFMA A operand so that each lane ends up with 4
+// consecutive channels of one pixel (8-byte stores) rather than 4 pixels of one channel.
+#define GC_LDS_CAP (64 * 1024)
+struct GcGeom { int band, nbands, CSP, nslabs, PS, rows_in; };
+static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
+  GcGeom g;
+  const int Ho = (Hi - 1) / stride + 1;
+  g.CSP = C >= 64 ? 64 : (C > 16 ? 32 : 16);
+  if (C > 32 && C < 64) g.CSP = 64;
+  g.nslabs = (C + g.CSP - 1) / g.CSP;
+  g.PS = g.CSP * 2 + 16;
+  const long rowb = (long)(Wi + 2) * g.PS;
+  int rows = (int)(GC_LDS_CAP / rowb);
+  int band = rows >= 3 ? (rows - 3) / stride + 1 : 0;
+  if (band > Ho) band = Ho;
+  g.band = band;
+  g.nbands = band > 0 ? (Ho + band - 1) / band : 0;
+  g.rows_in = band > 0 ? (band - 1) * stride + 3 : 0;
+  return g;
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ x, int Hi, int Wi, int C,
+                                                            const bf16x8* __restrict__ wfrag,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            bf16_t* __restrict__ y, float* __restrict__ pooled,
+                                                            int Ho, int Wo, int band, int nbands, int CSP, int PS,
+                                                            int rows_in) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+  __shared__ float red[4][16];
+  const int bnd = blockIdx.x, slab = blockIdx.y, n = blockIdx.z;
+  const int cs0 = slab * CSP;
+  const int oy0 = bnd * band;
+  const int nrows_out = min(band, Ho - oy0);
+  const int WP = Wi + 2;
+  const int iy0 = oy0 * STRIDE - 1;
+  // ---- stage the zero-padded input band: (row, col, chunk) with chunk fastest
+  const int cpp = CSP >> 3;
+  const int nrow_used = (nrows_out - 1) * STRIDE + 3;
+  const bf16_t* xin = x + (long)n * Hi * Wi * C;
+  for (int i = threadIdx.x; i < nrow_used * WP * cpp; i += 256) {
+    const int j = i % cpp;
+    const int pix = i / cpp;
+    const int r = pix / WP, xx = pix - r * WP;
+    const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C)
+      v = *reinterpret_cast<const u32x4*>(xin + ((long)iy * Wi + ix) * C + c);
+    *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = lane >> 4, pl = lane & 15;
+  const int units = CSP >> 4;
+  const int unit = wv % units;
+  const int mstep = 4 / units;
+  // weights of this unit: 5 k-steps
+  bf16x8 wf[5];
+  const long ubase = ((long)(slab * 4 + unit) * 5) * 64 + lane;   // wfrag laid out [slab*4+unit][ks][lane]
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) wf[ks] = wfrag[ubase + ks * 64];
+  int off[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) {
+    const int sidx = 4 * ks + q;
+    const int half = sidx / 9, tap = sidx - half * 9;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    off[ks] = sidx < 18 ? (dy * WP + dx) * PS + half * 16 + unit * 32 : unit * 32;
+  }
+  const int ch0 = cs0 + unit * 16 + q * 4;      // this lane's 4 output channels
+  float sc[4], sh[4], psum[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = ch0 + r < C;
+    sc[r] = ok ? scale[ch0 + r] : 0.f;
+    sh[r] = ok ? shift[ch0 + r] : 0.f;
+    psum[r] = 0.f;
+  }
+  const int npix = nrows_out * Wo;
+  const int ntiles = (npix + 15) >> 4;
+  bf16_t* yout = y + ((long)n * Ho + oy0) * Wo * C;
+  for (int mt = wv / units; mt < ntiles; mt += mstep) {
+    const int p = mt * 16 + pl;
+    const bool pok = p < npix;
+    const int pc = pok ? p : 0;
+    const int oyl = pc / Wo, ox = pc - oyl * Wo;
+    const unsigned char* base = tile + ((long)(oyl * STRIDE) * WP + ox * STRIDE) * PS;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + off[ks]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc, 0, 0, 0);
+    }
+    if (pok && ch0 < C) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaxf(acc[r] * sc[r] + sh[r], 0.f);
+        o[r] = (bf16_t)v;
+        psum[r] += (float)o[r];
+      }
+      *reinterpret_cast<bf16x4*>(yout + (long)pc * C + ch0) = o;
+    }
+  }
+  // ---- SE squeeze partial sums: lanes sharing q, then waves sharing the unit
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = psum[r];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (pl == 0) red[wv][q * 4 + r] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < units * 16) {
+    const int u = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    float sres = 0.f;
+    for (int w2 = u; w2 < 4; w2 += units) sres += red[w2][cc];
+    const int ch = cs0 + u * 16 + cc;
+    if (ch < C) pooled[((long)n * nbands + bnd) * C + ch] = sres;
+  }
+}
+
+extern "C" int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype) {
+  if (dtype != TDEED_BF16) return 1;
+  GcGeom g = gc_geom(Hi, Wi, C, stride);
+  return g.band > 0 ? g.nbands : 1;
+}
+
 extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
-                                  const float* w, const float* scale, const float* shift, void* y,
-                                  float* pooled, int dtype, void* stream) {
-  TD_CHECK(x && w && scale && shift && y && pooled, "gconv3x3: null pointer");
+                                  const float* w, const void* wfrag, const float* scale, const float* shift,
+                                  void* y, float* pooled, int dtype, void* stream) {
+  TD_CHECK(x && scale && shift && y && pooled, "gconv3x3: null pointer");
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "gconv3x3: group width %d / C %d unsupported", gw, C);
   TD_CHECK(stride == 1 || stride == 2, "gconv3x3: stride %d", stride);
   TD_CHECK(N > 0 && N <= 65535 && Hi > 0 && Wi > 0, "gconv3x3: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32)
+  if (dtype == TDEED_F32) {
+    TD_CHECK(w, "gconv3x3: fp32 path needs the packed fp32 weights");
     return gw == 8 ? launch_gconv<float, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
                    : launch_gconv<float, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
-  if (dtype == TDEED_BF16)
-    return gw == 8 ? launch_gconv<bf16_t, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
-                   : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
+  }
+  if (dtype == TDEED_BF16) {
+    GcGeom g = gc_geom(Hi, Wi, C, stride);
+    if (!wfrag || g.band <= 0) {     // no MFMA fragments given (or a row does not fit LDS): VALU kernel
+      TD_CHECK(w, "gconv3x3: no weights");
+      return gw == 8 ? launch_gconv<bf16_t, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
+                     : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
+    }
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    dim3 grid(g.nbands, g.nslabs, N);
+    size_t smem = (size_t)g.rows_in * (Wi + 2) * g.PS;
+    if (stride == 1)
+      hipLaunchKernelGGL(gconv3x3_mfma_kernel<1>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
+                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP,
+                         g.PS, g.rows_in);
+    else
+      hipLaunchKernelGGL(gconv3x3_mfma_kernel<2>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
+                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP,
+                         g.PS, g.rows_in);
+    TD_LAUNCH_CHECK("gconv3x3_mfma");
+    return TDEED_OK;
+  }
   tdeed_set_error("gconv3x3: bad dtype %d", dtype);
   return TDEED_ERR_ARG;
 }
 
 // =========================================================================== SE excitation
-// FPB frames per block share every weight read.  w1t: [C][R], w2t: [R][C] (transposed on the host
-// so adjacent threads read adjacent addresses).
+// FPB frames per block share every weight read.  Both phases are thread-per-output with the weights
+// transposed on the host (w1t [C][R], w2t [R][C]) so adjacent threads read adjacent addresses, and
+// deeply unrolled so every thread keeps >= 8 independent L2 loads in flight (the kernel is pure
+// latency: 270 KB of weights, 800 frames).  Phase 1 additionally splits C over 256/R thread slices.
+// pooled holds SUMS over pixels in n_parts partial rows per frame ([N][n_parts][C]); inv_cnt = 1/(Ho*Wo).
 #define SE_FPB 4
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pooled, int N, int C, int R,
-                                                      const float* __restrict__ w1t,
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pooled, int n_parts, float inv_cnt,
+                                                      int N, int C, int R, const float* __restrict__ w1t,
                                                       const float* __restrict__ b1,
                                                       const float* __restrict__ w2t,
                                                       const float* __restrict__ b2, float* __restrict__ gate) {
-  extern __shared__ float sm[];   // [FPB][C] pooled, [FPB][R] hidden
+  extern __shared__ float sm[];   // [FPB][C] pooled means, [FPB][R] hidden
   float* sp = sm;
   float* shid = sm + SE_FPB * C;
   const int f0 = blockIdx.x * SE_FPB;
   for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
-    int f = i / C;
-    sp[i] = (f0 + f < N) ? pooled[(long)(f0 + f) * C + (i - f * C)] : 0.f;
+    const int f = i / C, c = i - f * C;
+    float v = 0.f;
+    if (f0 + f < N) {
+      const float* src = pooled + ((long)(f0 + f) * n_parts) * C + c;
+      for (int q = 0; q < n_parts; ++q) v += src[(long)q * C];
+    }
+    sp[i] = v * inv_cnt;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < R; j += 256) {
+  // phase 1: thread (j, slice) walks its slice of C with independent coalesced loads of w1t[c][j]
+  {
+    const int RP = R <= 32 ? 32 : (R <= 64 ? 64 : (R <= 128 ? 128 : 256));
+    const int nsl = 256 / RP;                       // C slices handled in parallel
+    const int j = threadIdx.x % RP, sl = threadIdx.x / RP;
     float a[SE_FPB];
 #pragma unroll
     for (int f = 0; f < SE_FPB; ++f) a[f] = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float wv = w1t[(long)c * R + j];
+    if (j < R) {
+      const int cper = (C + nsl - 1) / nsl;
+      const int c0 = sl * cper, c1 = min(C, c0 + cper);
+#pragma unroll 8
+      for (int c = c0; c < c1; ++c) {
+        const float wv_ = w1t[(long)c * R + j];
 #pragma unroll
-      for (int f = 0; f < SE_FPB; ++f) a[f] = fmaf(sp[f * C + c], wv, a[f]);
+        for (int f = 0; f < SE_FPB; ++f) a[f] = fmaf(sp[f * C + c], wv_, a[f]);
+      }
     }
+    float* part = shid + SE_FPB * R;                // [nsl][FPB][R]
+    if (j < R) {
 #pragma unroll
-    for (int f = 0; f < SE_FPB; ++f) shid[f * R + j] = fmaxf(a[f] + b1[j], 0.f);
+      for (int f = 0; f < SE_FPB; ++f) part[(sl * SE_FPB + f) * R + j] = a[f];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SE_FPB * R; i += 256) {
+      float v = 0.f;
+      for (int q = 0; q < nsl; ++q) v += part[q * SE_FPB * R + i];
+      shid[i] = fmaxf(v + b1[i % R], 0.f);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float a[SE_FPB];
 #pragma unroll
     for (int f = 0; f < SE_FPB; ++f) a[f] = 0.f;
+#pragma unroll 8
     for (int j = 0; j < R; ++j) {
-      float wv = w2t[(long)j * C + c];
+      const float wv_ = w2t[(long)j * C + c];
 #pragma unroll
-      for (int f = 0; f < SE_FPB; ++f) a[f] = fmaf(shid[f * R + j], wv, a[f]);
+      for (int f = 0; f < SE_FPB; ++f) a[f] = fmaf(shid[f * R + j], wv_, a[f]);
     }
 #pragma unroll
     for (int f = 0; f < SE_FPB; ++f)
@@ -249,13 +434,15 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   }
 }
 
-extern "C" int tdeed_se_gate_fwd(const float* pooled, int N, int C, int R, const float* w1t, const float* b1,
-                                 const float* w2t, const float* b2, float* gate, void* stream) {
+extern "C" int tdeed_se_gate_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R,
+                                 const float* w1t, const float* b1, const float* w2t, const float* b2, float* gate,
+                                 void* stream) {
   TD_CHECK(pooled && w1t && b1 && w2t && b2 && gate, "se_gate: null pointer");
-  TD_CHECK(N > 0 && C > 0 && R > 0, "se_gate: bad sizes");
-  size_t smem = (size_t)SE_FPB * (C + R) * sizeof(float);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(cdiv(N, SE_FPB)), dim3(256), smem, (hipStream_t)stream, pooled, N, C,
-                     R, w1t, b1, w2t, b2, gate);
+  TD_CHECK(N > 0 && C > 0 && R > 0 && R <= 256 && n_parts > 0, "se_gate: bad sizes");
+  const int RP = R <= 32 ? 32 : (R <= 64 ? 64 : (R <= 128 ? 128 : 256));
+  size_t smem = (size_t)SE_FPB * (C + R + (256 / RP) * R) * sizeof(float);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(cdiv(N, SE_FPB)), dim3(256), smem, (hipStream_t)stream, pooled, n_parts,
+                     inv_cnt, N, C, R, w1t, b1, w2t, b2, gate);
   TD_LAUNCH_CHECK("se_gate");
   return TDEED_OK;
 }

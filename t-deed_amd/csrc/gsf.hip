@@ -25,78 +25,118 @@ template <> struct Pair<bf16_t> {
   }
 };
 
+// ---- launch 1a: per-frame partial gate sums Q
+// conv3d(a)[t] = sum_j conv2d(a[t+j-1], w[:,:,j]), so every frame is read ONCE: its block computes
+// Q[f][p][j][g] = conv2d_3x3(relu(bn(x[f])), w3d[g][:, j]) for the three temporal taps j and both
+// gate groups g.  The BN+ReLU'd frame band (+1 halo row each side) and the 27 x F weights sit in LDS;
+// work items are (pixel, j, g), pixel fastest, so activation reads are conflict-free ds_read_b64
+// (row stride F+2 floats) and weight reads are broadcasts.
 // wq: [27][F] tap-major repack of conv3D.weight ([2][F/2][3][3][3]); channel c = g*F/2 + cl.
 template <typename T>
-__global__ __launch_bounds__(256) void gsf_gate_kernel(const T* __restrict__ x, int T_len, int h, int w, int C,
-                                                       int F, const float* __restrict__ bn_scale,
-                                                       const float* __restrict__ bn_shift,
-                                                       const float* __restrict__ wq,
-                                                       const float* __restrict__ b3d, float* __restrict__ gate,
-                                                       float* __restrict__ ysum, float* __restrict__ xsum) {
+__global__ __launch_bounds__(256) void gsf_q_kernel(const T* __restrict__ x, int h, int w, int C, int F,
+                                                    int band, const float* __restrict__ bn_scale,
+                                                    const float* __restrict__ bn_shift,
+                                                    const float* __restrict__ wq, float* __restrict__ Q) {
+  extern __shared__ float sm[];
+  const int f = blockIdx.x;
+  const int y0 = blockIdx.y * band;
+  const int y1 = min(h, y0 + band);
+  const int rows = y1 - y0 + 2;               // with halo rows y0-1 and y1
+  const int LD = F + 2;
+  float* wl = sm;                              // [27][F]
+  float* a = sm + 27 * F;                      // [rows*w][LD]
+  for (int i = threadIdx.x; i < 27 * F; i += 256) wl[i] = wq[i];
+  const int nq = F >> 1;                       // channel pairs
+  for (int i = threadIdx.x; i < rows * w * nq; i += 256) {
+    const int cp = i % nq;
+    const int pix = i / nq;
+    const int ry = pix / w, px = pix - ry * w;
+    const int yy = y0 - 1 + ry;
+    float v0 = 0.f, v1 = 0.f;
+    if (yy >= 0 && yy < h) {
+      Pair<T>::load(x + ((long)f * h * w + (long)yy * w + px) * C + 2 * cp, v0, v1);
+      v0 = fmaxf(fmaf(v0, bn_scale[2 * cp], bn_shift[2 * cp]), 0.f);
+      v1 = fmaxf(fmaf(v1, bn_scale[2 * cp + 1], bn_shift[2 * cp + 1]), 0.f);
+    }
+    a[pix * LD + 2 * cp] = v0;
+    a[pix * LD + 2 * cp + 1] = v1;
+  }
+  __syncthreads();
+  const int Fh = F >> 1;
+  const int npix = (y1 - y0) * w;
+  for (int it = threadIdx.x; it < 6 * npix; it += 256) {
+    const int jg = it / npix;                 // 0..5 = j*2 + g
+    const int p = it - jg * npix;
+    const int j = jg >> 1, g = jg & 1;
+    const int py = p / w, px = p - py * w;    // py relative to y0
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = px + dx - 1;
+        if (xx < 0 || xx >= w) continue;      // halo rows are zero-filled, columns are bounds-checked
+        const float* ap = a + ((py + dy) * w + xx) * LD + g * Fh;
+        const float* wp = wl + ((j * 3 + dy) * 3 + dx) * F + g * Fh;
+        float a2 = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < Fh; c += 2) {
+          const f32x2 av = *reinterpret_cast<const f32x2*>(ap + c);
+          const f32x2 wv = *reinterpret_cast<const f32x2*>(wp + c);
+          acc = fmaf(av[0], wv[0], acc);
+          a2 = fmaf(av[1], wv[1], a2);
+        }
+        acc += a2;
+      }
+    }
+    Q[((long)f * h * w + (long)(y0 + py) * w + px) * 6 + jg] = acc;
+  }
+}
+
+// ---- launch 1b: gate = tanh(b + Q[t-1][0] + Q[t][1] + Q[t+1][2]) and the spatial sums of gate*x and x
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict__ x, const float* __restrict__ Q,
+                                                            int T_len, int hw, int C, int F,
+                                                            const float* __restrict__ b3d,
+                                                            float* __restrict__ gate, float* __restrict__ ysum,
+                                                            float* __restrict__ xsum) {
   extern __shared__ float sm[];        // gates [hw][2], then partial sums [2][S][F]
   const int f = blockIdx.x;
   const int t = f % T_len;
-  const int hw = h * w;
   const int Fh = F >> 1;
   float* sg = sm;
   float* part = sm + 2 * hw;
-  for (int p = threadIdx.x; p < hw; p += 256) {
-    const int py = p / w, px = p - py * w;
-    float g0 = b3d[0], g1 = b3d[1];
-    for (int dt = 0; dt < 3; ++dt) {
-      const int tt = t + dt - 1;
-      if (tt < 0 || tt >= T_len) continue;
-      const T* xf = x + (long)(f + dt - 1) * hw * C;
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = py + dy - 1;
-        if (yy < 0 || yy >= h) continue;
-        for (int dx = 0; dx < 3; ++dx) {
-          const int xx = px + dx - 1;
-          if (xx < 0 || xx >= w) continue;
-          const T* src = xf + ((long)yy * w + xx) * C;
-          const float* wt = wq + ((dt * 3 + dy) * 3 + dx) * F;
-          float a0 = 0.f, a1 = 0.f;
-          for (int c = 0; c < Fh; c += 2) {
-            float v0, v1;
-            Pair<T>::load(src + c, v0, v1);
-            a0 = fmaf(fmaxf(fmaf(v0, bn_scale[c], bn_shift[c]), 0.f), wt[c], a0);
-            a0 = fmaf(fmaxf(fmaf(v1, bn_scale[c + 1], bn_shift[c + 1]), 0.f), wt[c + 1], a0);
-          }
-          for (int c = Fh; c < F; c += 2) {
-            float v0, v1;
-            Pair<T>::load(src + c, v0, v1);
-            a1 = fmaf(fmaxf(fmaf(v0, bn_scale[c], bn_shift[c]), 0.f), wt[c], a1);
-            a1 = fmaf(fmaxf(fmaf(v1, bn_scale[c + 1], bn_shift[c + 1]), 0.f), wt[c + 1], a1);
-          }
-          g0 += a0;
-          g1 += a1;
-        }
-      }
-    }
-    g0 = tanhf(g0);
-    g1 = tanhf(g1);
-    sg[2 * p] = g0;
-    sg[2 * p + 1] = g1;
-    gate[((long)f * hw + p) * 2] = g0;
-    gate[((long)f * hw + p) * 2 + 1] = g1;
+  for (int i = threadIdx.x; i < 2 * hw; i += 256) {
+    const int p = i >> 1, g = i & 1;
+    float v = b3d[g] + Q[((long)f * hw + p) * 6 + 2 + g];
+    if (t > 0) v += Q[((long)(f - 1) * hw + p) * 6 + g];
+    if (t < T_len - 1) v += Q[((long)(f + 1) * hw + p) * 6 + 4 + g];
+    v = tanhf(v);
+    sg[i] = v;
+    gate[(long)f * hw * 2 + i] = v;
   }
   __syncthreads();
-  // spatial sums of y = gate*x and of x, deterministic: S pixel slices per channel, ordered reduce
-  const int S = 256 / F;               // F <= 256 checked on the host
+  // deterministic spatial sums: channel pairs across lanes (coalesced), S pixel slices, ordered reduce
+  const int nq = F >> 1;
+  const int S = 256 / nq;
   {
-    const int c = threadIdx.x % F;
-    const int s = threadIdx.x / F;
+    const int cp = threadIdx.x % nq;
+    const int s = threadIdx.x / nq;
     if (s < S) {
-      float ys = 0.f, xs = 0.f;
-      const T* xf = x + (long)f * hw * C + c;
-      const int g = c >= Fh;
+      float y0 = 0.f, y1 = 0.f, x0 = 0.f, x1 = 0.f;
+      const T* xf = x + (long)f * hw * C + 2 * cp;
+      const int g = (2 * cp) >= Fh;
       for (int p = s; p < hw; p += S) {
-        float v = (float)xf[(long)p * C];
-        xs += v;
-        ys += v * sg[2 * p + g];
+        float v0, v1;
+        Pair<T>::load(xf + (long)p * C, v0, v1);
+        const float gt = sg[2 * p + g];
+        x0 += v0; x1 += v1;
+        y0 += v0 * gt; y1 += v1 * gt;
       }
-      part[s * F + c] = ys;
-      part[(S + s) * F + c] = xs;
+      part[s * F + 2 * cp] = y0;
+      part[s * F + 2 * cp + 1] = y1;
+      part[(S + s) * F + 2 * cp] = x0;
+      part[(S + s) * F + 2 * cp + 1] = x1;
     }
   }
   __syncthreads();
@@ -113,23 +153,36 @@ __global__ __launch_bounds__(256) void gsf_gate_kernel(const T* __restrict__ x, 
 
 extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
                                   const float* bn_scale, const float* bn_shift, const float* wq,
-                                  const float* b3d, float* gate, float* ysum, float* xsum, int dtype,
+                                  const float* b3d, float* Q, float* gate, float* ysum, float* xsum, int dtype,
                                   void* stream) {
-  TD_CHECK(x && bn_scale && bn_shift && wq && b3d && gate && ysum && xsum, "gsf_gate: null pointer");
+  TD_CHECK(x && bn_scale && bn_shift && wq && b3d && Q && gate && ysum && xsum, "gsf_gate: null pointer");
   TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && F > 0 && F % 4 == 0 && F <= C && F <= 256,
            "gsf_gate: bad sizes B=%d T=%d h=%d w=%d C=%d F=%d", B, T, h, w, C, F);
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_gate: bad dtype %d", dtype);
   const int hw = h * w;
-  const int S = 256 / F;
-  size_t smem = (size_t)(2 * hw + 2 * S * F) * sizeof(float);
-  TD_CHECK(smem <= 64 * 1024, "gsf_gate: frame too large for LDS (%d px)", hw);
+  // rows per band so that weights + (band+2) rows of (F+2) floats fit 60 KB of LDS
+  const long budget = 60 * 1024 / 4 - 27L * F;
+  int band = (int)(budget / ((long)w * (F + 2))) - 2;
+  TD_CHECK(band >= 1, "gsf_gate: row of %d px x %d ch does not fit LDS", w, F);
+  if (band > h) band = h;
+  const int nb = cdiv(h, band);
+  TD_CHECK(nb <= 65535, "gsf_gate: too many bands");
+  size_t smem1 = (size_t)(27 * F + (band + 2) * w * (F + 2)) * sizeof(float);
+  const int S = 256 / (F / 2);
+  size_t smem2 = (size_t)(2 * hw + 2 * S * F) * sizeof(float);
+  TD_CHECK(smem2 <= 64 * 1024, "gsf_gate: frame too large for the gate/sum pass (%d px)", hw);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(gsf_gate_kernel<float>, dim3(B * T), dim3(256), smem, st, (const float*)x, T, h, w, C, F,
-                       bn_scale, bn_shift, wq, b3d, gate, ysum, xsum);
-  else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(gsf_gate_kernel<bf16_t>, dim3(B * T), dim3(256), smem, st, (const bf16_t*)x, T, h, w, C, F,
-                       bn_scale, bn_shift, wq, b3d, gate, ysum, xsum);
-  else { tdeed_set_error("gsf_gate: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  if (dtype == TDEED_F32) {
+    hipLaunchKernelGGL(gsf_q_kernel<float>, dim3(B * T, nb), dim3(256), smem1, st, (const float*)x, h, w, C, F, band,
+                       bn_scale, bn_shift, wq, Q);
+    hipLaunchKernelGGL(gsf_gate_sums_kernel<float>, dim3(B * T), dim3(256), smem2, st, (const float*)x, Q, T, hw, C,
+                       F, b3d, gate, ysum, xsum);
+  } else {
+    hipLaunchKernelGGL(gsf_q_kernel<bf16_t>, dim3(B * T, nb), dim3(256), smem1, st, (const bf16_t*)x, h, w, C, F,
+                       band, bn_scale, bn_shift, wq, Q);
+    hipLaunchKernelGGL(gsf_gate_sums_kernel<bf16_t>, dim3(B * T), dim3(256), smem2, st, (const bf16_t*)x, Q, T, hw,
+                       C, F, b3d, gate, ysum, xsum);
+  }
   TD_LAUNCH_CHECK("gsf_gate");
   return TDEED_OK;
 }
@@ -142,7 +195,7 @@ __global__ void gsf_weight_kernel(const float* __restrict__ ysum, const float* _
                                   float* __restrict__ fw) {
   const int b = blockIdx.x;
   const int Fh = F >> 1;
-  for (int i = threadIdx.x; i < F * T; i += blockDim.x) {
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < F * T; i += gridDim.y * blockDim.x) {
     const int c = i / T, t = i - c * T;
     const int g = c >= Fh;
     const int cl = c - g * Fh;
@@ -177,7 +230,7 @@ extern "C" int tdeed_gsf_weight_fwd(const float* ysum, const float* xsum, int B,
                                     float* fw, void* stream) {
   TD_CHECK(ysum && xsum && cw1 && cb1 && cw2 && cb2 && fw, "gsf_weight: null pointer");
   TD_CHECK(B > 0 && T > 0 && F > 0 && hw > 0, "gsf_weight: bad sizes");
-  hipLaunchKernelGGL(gsf_weight_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ysum, xsum, T, F,
+  hipLaunchKernelGGL(gsf_weight_kernel, dim3(B, cdiv((long)F * T, 256)), dim3(256), 0, (hipStream_t)stream, ysum, xsum, T, F,
                      1.0f / (float)hw, cw1, cb1, cw2, cb2, fw);
   TD_LAUNCH_CHECK("gsf_weight");
   return TDEED_OK;

@@ -249,7 +249,7 @@ extern "C" int tdeed_graph_end(void* stream, void** graph_exec) {
   if (e != hipSuccess || !g) { tdeed_set_error("graph_end: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
   hipGraphExec_t ex = nullptr;
   e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   if (e != hipSuccess) { tdeed_set_error("graph_instantiate: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
   *graph_exec = (void*)ex;
   return TDEED_OK;
@@ -260,6 +260,6 @@ extern "C" int tdeed_graph_launch(void* graph_exec, void* stream) {
   return TDEED_OK;
 }
 extern "C" int tdeed_graph_destroy(void* graph_exec) {
-  if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
   return TDEED_OK;
 }

@@ -81,6 +81,36 @@ def _pack_mlp(sd, pre, C, o, act_dtype, device):
     o.gn_w, o.gn_b = _f32(_np(sd[pre + ".gn.weight"]), device), _f32(_np(sd[pre + ".gn.bias"]), device)
 
 
+def pack_gconv_frags(w, gw, device):
+    """Conv2d.weight [C][gw][3][3] -> bf16 MFMA A-operand fragments [ceil4(C/16)][5][64][8] for
+    gconv3x3_mfma_kernel: unit u = output channels [16u,16u+16); lane l holds Wt[n=l&15][k=8(l>>4)+j];
+    k-slot s = 4*ks + (l>>4) = half*9 + tap; for gw=8 'half' selects which of the unit's two groups
+    the 8 input channels belong to (block-diagonal), for gw=16 which half of the group's 16 inputs."""
+    w = _np(w).astype(np.float32)
+    C = w.shape[0]
+    nu = (C + 15) // 16
+    nu4 = (nu + 3) // 4 * 4
+    fr = np.zeros((nu4, 5, 64, 8), np.float32)
+    for u in range(nu):
+        for ks in range(5):
+            for q in range(4):
+                s_ = 4 * ks + q
+                if s_ >= 18:
+                    continue
+                half, tap = divmod(s_, 9)
+                ky, kx = divmod(tap, 3)
+                for n in range(16):
+                    co = u * 16 + n
+                    if co >= C:
+                        continue
+                    lane = q * 16 + n
+                    if gw == 16:
+                        fr[u, ks, lane, :] = w[co, half * 8:half * 8 + 8, ky, kx]
+                    elif n // 8 == half:
+                        fr[u, ks, lane, :] = w[co, :, ky, kx]
+    return torch.from_numpy(fr).to(device).to(torch.bfloat16).contiguous()
+
+
 def pack_sgp_block(sd, pre, C, act_dtype, device):
     """SGPBlock parameters (modules.py:91-145) in kernel layout."""
     o = SimpleNamespace(C=C)
@@ -248,6 +278,7 @@ class PackedWeights:
             w2 = w2.reshape(G, gw, gw, 3, 3).transpose(0, 3, 4, 2, 1)  # [G][ky][kx][in][out]
             bw.w2 = f32(w2.reshape(G, 9, gw, gw))
             bw.s2, bw.h2 = bn_fold(bp + ".conv2.bn")
+            bw.w2frag = pack_gconv_frags(sd[bp + ".conv2.conv.weight"], gw, device) if act_dtype == torch.bfloat16 else None
             bw.se_w1t = f32(sd[bp + ".se.fc1.weight"].reshape(blk.se_rd, blk.cout).T)
             bw.se_b1 = f32(sd[bp + ".se.fc1.bias"])
             bw.se_w2t = f32(sd[bp + ".se.fc2.weight"].reshape(blk.cout, blk.se_rd).T)
@@ -341,7 +372,8 @@ class ForwardEngine:
             if blk.gsf_fold:
                 F = blk.gsf_fold
                 Fp = (F + 7) // 8 * 8
-                gb = dict(gate=pool.take((N, h, w, 2), torch.float32), ysum=pool.take((N, F), torch.float32),
+                gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
+                          ysum=pool.take((N, F), torch.float32),
                           xsum=pool.take((N, F), torch.float32), out=pool.take((M, Fp), dt))
                 if bw.gs_cw1 is not None:
                     gb["fw"] = pool.take((B, F, T), torch.float32)
@@ -362,13 +394,14 @@ class ForwardEngine:
             h2, w2 = (h - 1) // s + 1, (w - 1) // s + 1
             M2 = N * h2 * w2
             y2 = pool.take((N, h2, w2, blk.cout), dt)
-            pooled = pool.take((N, blk.cout), torch.float32)
+            parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
+            pooled = pool.take((N, parts, blk.cout), torch.float32)
             gate = pool.take((N, blk.cout), torch.float32)
             steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
-                y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, out=y2, pooled=pooled),
+                y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
                 (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
-            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate: ops.se_gate(
-                pooled, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate),
+            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): ops.se_gate(
+                pooled, ic, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate),
                 2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
             if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)

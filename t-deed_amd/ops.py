@@ -59,26 +59,34 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     return out
 
 
-def gconv3x3(x, w_packed, scale, shift, gw, stride, out=None, pooled=None):
-    """x (N,Hi,Wi,C) -> y (N,Ho,Wo,C), pooled (N,C) fp32.  w_packed: fp32 [G][9][gw][gw]."""
+def gconv3x3_parts(Hi, Wi, C, stride, act_dtype):
+    return _lib.load().tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype_code(act_dtype))
+
+
+def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None):
+    """x (N,Hi,Wi,C) -> y (N,Ho,Wo,C), pooled (N,parts,C) fp32 partial sums over pixels.
+    w_packed: fp32 [G][9][gw][gw] (VALU path); wfrag: bf16 MFMA fragments (bf16 path)."""
     _chk(x, "x")
     N, Hi, Wi, C = x.shape
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    parts = gconv3x3_parts(Hi, Wi, C, stride, x.dtype) if wfrag is not None else 1
     if pooled is None:
-        pooled = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(scale), ptr(shift), ptr(out),
-         ptr(pooled), dtype_code(x.dtype), stream_ptr())
+        pooled = torch.empty((N, parts, C), dtype=torch.float32, device=x.device)
+    call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(wfrag), ptr(scale), ptr(shift),
+         ptr(out), ptr(pooled), dtype_code(x.dtype), stream_ptr())
     return out, pooled
 
 
-def se_gate(pooled, w1t, b1, w2t, b2, out=None):
-    N, C = pooled.shape
+def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
+    """pooled (N,parts,C) partial sums -> gate (N,C).  w1t (C,R), w2t (R,C)."""
+    N, parts, C = pooled.shape
     R = w1t.shape[1]
     if out is None:
-        out = torch.empty_like(pooled)
-    call("tdeed_se_gate_fwd", ptr(pooled), N, C, R, ptr(w1t), ptr(b1), ptr(w2t), ptr(b2), ptr(out), stream_ptr())
+        out = torch.empty((N, C), dtype=torch.float32, device=pooled.device)
+    call("tdeed_se_gate_fwd", ptr(pooled), parts, float(inv_cnt), N, C, R, ptr(w1t), ptr(b1), ptr(w2t), ptr(b2),
+         ptr(out), stream_ptr())
     return out
 
 
@@ -102,9 +110,12 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     out = bufs.get("out")
     if out is None:
         out = torch.empty((N * h * w, Fp), dtype=x.dtype, device=dev)
+    q = bufs.get("q")
+    if q is None:
+        q = torch.empty((N, h, w, 6), dtype=torch.float32, device=dev)
     dc = dtype_code(x.dtype)
     call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(b3d),
-         ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+         ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
     fw = None
     if cw1 is not None:
         fw = bufs.get("fw")

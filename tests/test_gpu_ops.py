@@ -119,7 +119,8 @@ def test_stem(ops, dtype, geom):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,gw,stride,H,W", [(24, 8, 2, 20, 22), (56, 8, 1, 9, 7), (64, 16, 2, 16, 16),
-                                             (368, 8, 1, 7, 7), (128, 16, 1, 28, 28)])
+                                             (368, 8, 1, 7, 7), (128, 16, 1, 28, 28), (152, 8, 2, 28, 28),
+                                             (24, 8, 2, 112, 112), (320, 16, 1, 14, 14), (768, 16, 2, 14, 14)])
 def test_gconv3x3(ops, dtype, C, gw, stride, H, W):
     N = 3
     x = rnd(31, "x", (N, C, H, W)).to(dtype)
@@ -130,10 +131,15 @@ def test_gconv3x3(ops, dtype, C, gw, stride, H, W):
                      + sh.view(1, -1, 1, 1))
     G = C // gw
     wp = w.reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1).reshape(G, 9, gw, gw).contiguous()
-    y, pooled = ops.gconv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp.to(DEV), sc.to(DEV), sh.to(DEV), gw, stride)
+    from tdeed_amd.engine import pack_gconv_frags
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     tol = F32_TOL if dtype == torch.float32 else BF16_TOL
-    assert rel_err(y.float().permute(0, 3, 1, 2), ref) < tol
-    assert rel_err(pooled, ref.mean(dim=(2, 3))) < tol
+    variants = [None] if dtype == torch.float32 else [None, pack_gconv_frags(w, gw, DEV)]   # VALU, MFMA
+    for wfrag in variants:
+        y, pooled = ops.gconv3x3(xin, wp.to(DEV), sc.to(DEV), sh.to(DEV), gw, stride, wfrag=wfrag)
+        assert rel_err(y.float().permute(0, 3, 1, 2), ref) < tol
+        npix = y.shape[1] * y.shape[2]
+        assert rel_err(pooled.sum(dim=1) / npix, ref.mean(dim=(2, 3))) < tol
 
 
 def test_se_gate(ops):
@@ -142,7 +148,8 @@ def test_se_gate(ops):
     w1, b1 = rnd(42, "w1", (R, C), 0.1), rnd(43, "b1", (R,), 0.1)
     w2, b2 = rnd(44, "w2", (C, R), 0.2), rnd(45, "b2", (C,), 0.1)
     ref = torch.sigmoid(torch.relu(p @ w1.T + b1) @ w2.T + b2)
-    out = ops.se_gate(p.to(DEV), w1.T.contiguous().to(DEV), b1.to(DEV), w2.T.contiguous().to(DEV), b2.to(DEV))
+    parts = torch.stack([p * 0.25 * 7, p * 0.75 * 7], dim=1).contiguous()      # two partial sums over 7 "pixels"
+    out = ops.se_gate(parts.to(DEV), 1.0 / 7, w1.T.contiguous().to(DEV), b1.to(DEV), w2.T.contiguous().to(DEV), b2.to(DEV))
     assert rel_err(out, ref) < 1e-5
 
 
