@@ -60,6 +60,19 @@ int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
                    int act, void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
                    int gather_ho, int gather_wo, int dtype, void* stream);
 
+/* Weight-stationary variant of the same contraction for narrow layers (whole W in LDS, activations
+ * streamed global->registers in MFMA fragment shape, persistent blocks; see gemm.hip).  Same
+ * semantics and arguments as tdeed_gemm_fwd except that the weights arrive pre-packed:
+ * Wfrag = tdeed_amd.engine.pack_ws_weights(W): [2*ceil(N/32)][ceil(K/(4*epc))][64 lanes][16 B], rows
+ * permuted so that each lane owns 8 consecutive output channels.  tdeed_gemm_ws_fits() tells whether
+ * (K, N, dtype) fits (LDS budget 64 KB). */
+int tdeed_gemm_ws_fits(int K, int N, int dtype);
+int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
+                      const float* a_scale, int a_scale_rows, int M, int K, int N, const void* Wfrag,
+                      const float* scale, const float* shift, const void* R, long ldr, int act,
+                      void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
+                      int gather_ho, int gather_wo, int dtype, void* stream);
+
 /* ---- grouped 3x3 conv + BN + ReLU + SE squeeze ---------------------------------------------
  * timm Bottleneck.conv2 (groups = C/gw, stride 1|2, pad 1) + BN(eval) + ReLU, and the SE
  * squeeze (sum over H,W) of its output.  x: [N][Hi][Wi][C], y: [N][Ho][Wo][C], gw in {8,16}.

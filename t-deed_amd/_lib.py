@@ -32,6 +32,9 @@ _SIGS = {
     "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_gemm_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, c_long, P, P, P, c_long,
                         c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
+    "tdeed_gemm_ws_fits": ([c_int, c_int, c_int], c_int),
+    "tdeed_gemm_ws_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, c_long,
+                           c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gconv3x3_parts": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),

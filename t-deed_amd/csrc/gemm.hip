@@ -281,3 +281,206 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st) : launch_gemm<bf16_t>(p, st);
 }
+
+// =============================================================================================
+// Weight-stationary streaming contraction for the narrow layers (K, N <= ~176: every 1x1 conv of
+// stages s1-s3 of RegNetY-200MF).  These are pure HBM streams (2-8 flop/byte .. 150 flop/byte), so
+// the kernel is built around bytes in flight, not MFMA rate:
+//   * the whole weight matrix sits in LDS, pre-packed on the host in MFMA fragment order
+//     ([n-tile][k-step][lane][16 B]) so a fragment read is one conflict-free 1-KiB ds_read_b128;
+//   * activations go global -> registers directly in fragment shape (lane = pixel l&15, k-chunk
+//     l>>4); no LDS staging, no block barriers in the loop, every wave independent;
+//   * persistent blocks; 3 waves/SIMD x 10 outstanding 16-B loads per lane hide the HBM latency;
+//   * weights are the MFMA A operand, so D[n][pixel] leaves each lane with 4 channels of ONE pixel;
+//     weight rows are permuted on the host so that two n-tiles give 8 consecutive channels:
+//     16-byte residual loads / output stores straight from the accumulators, no LDS transpose.
+// The SE gate, the gate-shift splice and the stride-2 row gather are applied while loading.
+struct GemmWsP {
+  const void* A; long lda;
+  const void* A0; long lda0; int k0;
+  const float* a_scale; int a_scale_rows;
+  int M, K, N;
+  const void* Wf;                 // [NT][KS][64] x 16 B
+  const float* scale; const float* shift;
+  const void* R; long ldr;
+  int act;
+  void* C; long ldc;
+  int g_stride, g_hi, g_wi, g_ho, g_wo;
+  int NT;
+};
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
+  constexpr int EPC = Chunk<T>::N;
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  frag_t* wl = reinterpret_cast<frag_t*>(smem);                       // [NT][KS][64]
+  float* ssc = reinterpret_cast<float*>(smem + (size_t)p.NT * KS * 64 * 16);   // [NT*16] scale (logical order)
+  float* ssh = ssc + p.NT * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  {
+    const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf);
+    for (int i = tid; i < p.NT * KS * 64; i += 256) wl[i] = src[i];
+    for (int i = tid; i < p.NT * 16; i += 256) {
+      ssc[i] = (p.scale && i < p.N) ? p.scale[i] : 1.0f;
+      ssh[i] = (p.shift && i < p.N) ? p.shift[i] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int px = lane & 15, q = lane >> 4;
+  const long nchunks = ((long)p.M + 127) / 128;
+  for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long mbase = chunk * 128 + wv * 32;
+    frag_t xf[2][KS];
+    bool mok[2];
+    long mrow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const long m = mbase + mt * 16 + px;
+      mok[mt] = m < p.M;
+      const long mm = mok[mt] ? m : 0;
+      mrow[mt] = mm;
+      long src = mm;
+      if (p.g_stride > 1) {
+        const long per = (long)p.g_ho * p.g_wo;
+        const long f = mm / per;
+        const int rem = (int)(mm - f * per);
+        const int yo = rem / p.g_wo, xo = rem - yo * p.g_wo;
+        src = (f * p.g_hi + (long)yo * p.g_stride) * p.g_wi + (long)xo * p.g_stride;
+      }
+      const T* arow = reinterpret_cast<const T*>(p.A) + src * p.lda;
+      const T* a0row = p.A0 ? reinterpret_cast<const T*>(p.A0) + src * p.lda0 : nullptr;
+      const float* srow = p.a_scale ? p.a_scale + (mm / p.a_scale_rows) * (long)p.K : nullptr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = (ks * 4 + q) * EPC;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (mok[mt] && k < p.K) {
+          const T* s = (a0row && k < p.k0) ? a0row + k : arow + k;
+          v = *reinterpret_cast<const u32x4*>(s);
+          if (srow) {
+            float f[EPC];
+            Chunk<T>::load(reinterpret_cast<const T*>(&v), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] *= srow[k + e];
+            Chunk<T>::store(reinterpret_cast<T*>(&v), f);
+          }
+        }
+        xf[mt][ks] = *reinterpret_cast<frag_t*>(&v);
+      }
+    }
+    for (int tp = 0; tp < p.NT; tp += 2) {           // 32 output channels per pass
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const frag_t w0 = wl[((tp + 0) * KS + ks) * 64 + lane];
+        const frag_t w1 = wl[((tp + 1) * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[0][mt] = mma<T>(w0, xf[mt][ks], acc[0][mt]);
+          acc[1][mt] = mma<T>(w1, xf[mt][ks], acc[1][mt]);
+        }
+      }
+      const int ch = tp * 16 + q * 8;                 // first of this lane's 8 logical channels
+      if (ch < p.N) {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = ssc[ch + e]; sh[e] = ssh[ch + e]; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (!mok[mt]) continue;
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[0][mt][r] * sc[r] + sh[r];
+            v[4 + r] = acc[1][mt][r] * sc[4 + r] + sh[4 + r];
+          }
+          const long m = mrow[mt];
+          if (p.R) {
+            const T* rp = reinterpret_cast<const T*>(p.R) + m * p.ldr + ch;
+            float rv[EPC];
+#pragma unroll
+            for (int h = 0; h < 8 / EPC; ++h) {
+              Chunk<T>::load(rp + h * EPC, rv);
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) v[h * EPC + e] += rv[e];
+            }
+          }
+          if (p.act == TDEED_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == TDEED_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+          }
+          T* cp = reinterpret_cast<T*>(p.C) + m * p.ldc + ch;
+#pragma unroll
+          for (int h = 0; h < 8 / EPC; ++h) {
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = v[h * EPC + e];
+            Chunk<T>::store(cp + h * EPC, o);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_gemm_ws(const GemmWsP& p, hipStream_t st) {
+  constexpr int EPC = Chunk<T>::N;
+  const int KS = (p.K + 4 * EPC - 1) / (4 * EPC);
+  const size_t smem = (size_t)p.NT * KS * 64 * 16 + (size_t)p.NT * 16 * 2 * sizeof(float);
+  if (smem > 64 * 1024) { tdeed_set_error("gemm_ws: weights (%zu B) do not fit LDS", smem); return TDEED_ERR_ARG; }
+  const long nchunks = ((long)p.M + 127) / 128;
+  const int grid = (int)(nchunks < 1024 ? nchunks : 1024);
+#define WS_CASE(k) case k: hipLaunchKernelGGL((gemm_ws_kernel<T, k>), dim3(grid), dim3(256), smem, st, p); break;
+  switch (KS) {
+    WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10)
+    default: tdeed_set_error("gemm_ws: unsupported K=%d", p.K); return TDEED_ERR_ARG;
+  }
+#undef WS_CASE
+  TD_LAUNCH_CHECK("gemm_ws");
+  return TDEED_OK;
+}
+
+extern "C" int tdeed_gemm_ws_fits(int K, int N, int dtype) {
+  const int epc = dtype == TDEED_F32 ? 4 : 8;
+  const int KS = (K + 4 * epc - 1) / (4 * epc);
+  const int NT = (N + 31) / 32 * 2;
+  const size_t smem = (size_t)NT * KS * 64 * 16 + (size_t)NT * 16 * 2 * sizeof(float);
+  const bool ks_ok = KS == 1 || KS == 2 || KS == 3 || KS == 4 || KS == 5 || KS == 6 || KS == 8 || KS == 10;
+  return (smem <= 64 * 1024 && ks_ok) ? 1 : 0;
+}
+
+extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
+                                 const float* a_scale, int a_scale_rows, int M, int K, int N,
+                                 const void* Wfrag, const float* scale, const float* shift, const void* R,
+                                 long ldr, int act, void* C, long ldc, int gather_stride, int gather_hi,
+                                 int gather_wi, int gather_ho, int gather_wo, int dtype, void* stream) {
+  TD_CHECK(A && Wfrag && C, "gemm_ws: null pointer");
+  TD_CHECK(M > 0 && K > 0 && N > 0, "gemm_ws: bad sizes M=%d K=%d N=%d", M, K, N);
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gemm_ws: bad dtype %d", dtype);
+  TD_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldc % 8 == 0, "gemm_ws: K, N, lda, ldc must be multiples of 8");
+  TD_CHECK(!A0 || (k0 % 8 == 0 && lda0 % 8 == 0 && k0 <= K), "gemm_ws: bad splice");
+  TD_CHECK(!R || ldr % 8 == 0, "gemm_ws: bad ldr");
+  TD_CHECK(act >= 0 && act <= 2, "gemm_ws: bad act %d", act);
+  TD_CHECK(tdeed_gemm_ws_fits(K, N, dtype), "gemm_ws: K=%d N=%d does not fit the weight-stationary kernel", K, N);
+  if (gather_stride > 1)
+    TD_CHECK(gather_hi > 0 && gather_wi > 0 && gather_ho > 0 && gather_wo > 0 && M % (gather_ho * gather_wo) == 0,
+             "gemm_ws: bad gather geometry");
+  GemmWsP p;
+  p.A = A; p.lda = lda; p.A0 = A0; p.lda0 = lda0; p.k0 = A0 ? k0 : 0;
+  p.a_scale = a_scale; p.a_scale_rows = a_scale_rows > 0 ? a_scale_rows : 1;
+  p.M = M; p.K = K; p.N = N; p.Wf = Wfrag; p.scale = scale; p.shift = shift;
+  p.R = R; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
+  p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
+  p.NT = (N + 31) / 32 * 2;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TDEED_F32 ? launch_gemm_ws<float>(p, st) : launch_gemm_ws<bf16_t>(p, st);
+}

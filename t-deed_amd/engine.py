@@ -81,6 +81,43 @@ def _pack_mlp(sd, pre, C, o, act_dtype, device):
     o.gn_w, o.gn_b = _f32(_np(sd[pre + ".gn.weight"]), device), _f32(_np(sd[pre + ".gn.bias"]), device)
 
 
+def pack_ws_weights(W, act_dtype, device):
+    """[N][K] dense weight -> fragments for gemm_ws_kernel: [NT][KS][64][epc] with NT = 2*ceil(N/32),
+    KS = ceil(K/(4*epc)); MFMA row n of tile 2t+h holds logical channel 32t + 8(n//4) + 4h + n%4 so that a
+    lane's accumulators of a tile pair are 8 consecutive output channels."""
+    W = _np(W).astype(np.float32)
+    N, K = W.shape
+    epc = 8 if act_dtype == torch.bfloat16 else 4
+    KS = (K + 4 * epc - 1) // (4 * epc)
+    NT = (N + 31) // 32 * 2
+    Wp = np.zeros((NT * 16, KS * 4 * epc), np.float32)
+    n = np.arange(16)
+    for nt in range(NT):
+        t, h = divmod(nt, 2)
+        L = 32 * t + 8 * (n // 4) + 4 * h + (n % 4)
+        ok = L < N
+        Wp[nt * 16 + n[ok], :K] = W[L[ok]]
+    fr = Wp.reshape(NT, 16, KS, 4, epc).transpose(0, 2, 3, 1, 4)          # [NT][KS][q][n][epc]
+    fr = np.ascontiguousarray(fr).reshape(NT, KS, 64, epc)
+    return torch.from_numpy(fr).to(device).to(act_dtype).contiguous()
+
+
+class DenseW:
+    """A dense [N][K] weight in the layout the chosen contraction kernel wants."""
+
+    def __init__(self, W, act_dtype, device):
+        W = _np(W)
+        self.N, self.K = W.shape
+        self.ws = ops.gemm_ws_fits(self.K, self.N, act_dtype) if str(device) != "cpu" else False
+        self.w = pack_ws_weights(W, act_dtype, device) if self.ws else _dense(W, act_dtype, device)
+        self.kernel = "gemm_ws" if self.ws else "gemm"
+
+    def run(self, A, scale, shift, act, **kw):
+        if self.ws:
+            return ops.gemm_ws(A, self.w, self.K, self.N, scale, shift, act, **kw)
+        return ops.gemm(A, self.w, scale, shift, act, **kw)
+
+
 def pack_gconv_frags(w, gw, device):
     """Conv2d.weight [C][gw][3][3] -> bf16 MFMA A-operand fragments [ceil4(C/16)][5][64][8] for
     gconv3x3_mfma_kernel: unit u = output channels [16u,16u+16); lane l holds Wt[n=l&15][k=8(l>>4)+j];
@@ -271,7 +308,7 @@ class PackedWeights:
             bp = p + blk.name
             bw = SimpleNamespace(spec=blk)
             c1 = bp + (".conv1.net" if blk.gsf_fold else ".conv1")
-            bw.w1 = dense(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin))
+            bw.w1 = DenseW(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
             bw.s1, bw.h1 = bn_fold(c1 + ".bn")
             w2 = sd[bp + ".conv2.conv.weight"]                       # [C][gw][3][3]
             G, gw = blk.groups, blk.gw
@@ -283,10 +320,10 @@ class PackedWeights:
             bw.se_b1 = f32(sd[bp + ".se.fc1.bias"])
             bw.se_w2t = f32(sd[bp + ".se.fc2.weight"].reshape(blk.cout, blk.se_rd).T)
             bw.se_b2 = f32(sd[bp + ".se.fc2.bias"])
-            bw.w3 = dense(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout))
+            bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
             if blk.has_downsample:
-                bw.wd = dense(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin))
+                bw.wd = DenseW(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
                 bw.sd, bw.hd = bn_fold(bp + ".downsample.bn")
             if blk.gsf_fold:
                 gp = bp + ".conv1.gs"
@@ -380,15 +417,15 @@ class ForwardEngine:
                 steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
                     bw.gs_cw2, bw.gs_cb2, bufs=gb), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
-                steps.append(Step(blk.name + ".conv1", "gemm", lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: ops.gemm(
-                    x, bw.w1, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
+                steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
+                    x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
                     *gemm_cost(M, blk.cin, blk.cout, es)))
                 if blk.name and ("_features." + blk.name + ".gs_out") in taps:
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
                 gs_bufs = list(gb.values())
             else:
-                steps.append(Step(blk.name + ".conv1", "gemm", lambda x=x, bw=bw, y1=y1, M=M: ops.gemm(
-                    x, bw.w1, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
+                steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
+                    x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
                 gs_bufs = []
             s = blk.stride
             h2, w2 = (h - 1) // s + 1, (w - 1) // s + 1
@@ -406,14 +443,14 @@ class ForwardEngine:
             if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
                 gather = (s, h, w, h2, w2) if s > 1 else None
-                steps.append(Step(blk.name + ".downsample", "gemm", lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: ops.gemm(
-                    x, bw.wd, bw.sd, bw.hd, ops.ACT_NONE, gather=gather, out=sc, M=M2),
+                steps.append(Step(blk.name + ".downsample", bw.wd.kernel, lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: bw.wd.run(
+                    x, bw.sd, bw.hd, ops.ACT_NONE, gather=gather, out=sc, M=M2),
                     *gemm_cost(M2, blk.cin, blk.cout, es)))
             else:
                 sc = x
             out = pool.take((N, h2, w2, blk.cout), dt)
-            steps.append(Step(blk.name + ".conv3", "gemm", lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2: ops.gemm(
-                y2, bw.w3, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
+            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
+                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
                 *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` dies here
             for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):

@@ -59,6 +59,31 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     return out
 
 
+def gemm_ws_fits(K, N, act_dtype):
+    return bool(_lib.load().tdeed_gemm_ws_fits(K, N, dtype_code(act_dtype)))
+
+
+def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
+            A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None):
+    """Weight-stationary streaming form of gemm(); Wfrag from engine.pack_ws_weights."""
+    _chk(A, "A")
+    if M is None:
+        M = A.numel() // A.shape[-1]
+        if gather is not None:
+            s, hi, wi, ho, wo = gather
+            M = (M // (hi * wi)) * ho * wo
+    lda = A.shape[-1] if lda is None else lda
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    ldc = N if ldc is None else ldc
+    g = gather if gather is not None else (1, 0, 0, 0, 0)
+    call("tdeed_gemm_ws_fwd", ptr(A), lda, ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0,
+         ptr(a_scale), a_scale_rows, M, K, N, ptr(Wfrag), ptr(scale), ptr(shift),
+         ptr(residual), (residual.shape[-1] if residual is not None else 0), act, ptr(out), ldc,
+         g[0], g[1], g[2], g[3], g[4], dtype_code(A.dtype), stream_ptr())
+    return out
+
+
 def gconv3x3_parts(Hi, Wi, C, stride, act_dtype):
     return _lib.load().tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype_code(act_dtype))
 

@@ -94,6 +94,48 @@ def test_gemm_se_scale_splice_gather(ops, dtype):
     assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
 
 
+WS_SHAPES = [(300, 32, 24), (1000, 24, 24), (257, 24, 56), (640, 56, 56), (999, 56, 152), (4097, 152, 152),
+             (500, 64, 128), (130, 128, 128)]
+
+
+@pytest.mark.parametrize("M,K,N", WS_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_ws(ops, M, K, N, dtype):
+    """weight-stationary kernel == tiled kernel semantics (plain, epilogue, SE scale, splice, gather)."""
+    from tdeed_amd.engine import pack_ws_weights
+    if not ops.gemm_ws_fits(K, N, dtype):
+        pytest.skip("does not fit the weight-stationary kernel in this dtype")
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    A = rnd(71, f"A{M}", (M, K)).to(dtype)
+    W = rnd(72, f"W{N}", (N, K), 1.0 / np.sqrt(K)).to(dtype)
+    Wf = pack_ws_weights(W.float().numpy(), dtype, DEV)
+    sc, sh = rnd(73, "sc", (N,)) * 0.2 + 1.0, rnd(74, "sh", (N,))
+    R = rnd(75, "R", (M, N)).to(dtype)
+    base = A.float() @ W.float().T
+    out = ops.gemm_ws(A.to(DEV), Wf, K, N, sc.to(DEV), sh.to(DEV), ops.ACT_NONE)
+    assert rel_err(out.float(), base * sc + sh) < tol
+    for actn, fn in [(1, torch.relu), (2, F.gelu)]:
+        out = ops.gemm_ws(A.to(DEV), Wf, K, N, None, sh.to(DEV), actn, residual=R.to(DEV))
+        assert rel_err(out.float(), fn(base + sh + R.float())) < tol
+    rows = 7
+    Mp = (M // rows) * rows
+    gate = torch.sigmoid(rnd(76, "g", (Mp // rows, K)))
+    ref = A[:Mp].float().view(-1, rows, K) * gate[:, None, :]
+    if dtype == torch.bfloat16:
+        ref = ref.to(torch.bfloat16).float()
+    out = ops.gemm_ws(A[:Mp].contiguous().to(DEV), Wf, K, N, a_scale=gate.to(DEV), a_scale_rows=rows)
+    assert rel_err(out.float(), ref.view(Mp, K) @ W.float().T) < tol
+    if K >= 16:
+        k0 = 8
+        A0 = rnd(77, "A0", (M, k0)).to(dtype)
+        out = ops.gemm_ws(A.to(DEV), Wf, K, N, A0=A0.to(DEV), k0=k0)
+        assert rel_err(out.float(), torch.cat([A0, A[:, k0:]], 1).float() @ W.float().T) < tol
+    hi, wi, s_ = 6, 10, 2
+    X = rnd(78, "X", (3, hi, wi, K)).to(dtype)
+    out = ops.gemm_ws(X.to(DEV), Wf, K, N, gather=(s_, hi, wi, 3, 5))
+    assert rel_err(out.float(), X.float()[:, ::2, ::2, :].reshape(-1, K) @ W.float().T) < tol
+
+
 # ----------------------------------------------------------------------------- stem / grouped conv / SE / pool
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("geom", [(2, 64, 64, None, False), (1, 72, 80, (4, 8, 64, 64), True), (1, 50, 37, None, False)])

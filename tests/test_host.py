@@ -46,7 +46,7 @@ def test_weight_packing_layouts():
     sd = model_state(CFG)
     pw = PackedWeights(CFG, sd, torch.bfloat16, "cpu")
     b = pw.W.blocks[2]                       # s3.b1: gate-shift in front of conv1
-    assert b.spec.gsf_fold == 16 and b.gs_wq.shape == (27, 16) and b.w1.dtype == torch.bfloat16
+    assert b.spec.gsf_fold == 16 and b.gs_wq.shape == (27, 16) and b.w1.w.dtype == torch.bfloat16 and not b.w1.ws
     w2 = sd["_features.s3.b1.conv2.conv.weight"]           # [C][gw][3][3]
     g, o, i, ky, kx = 3, 5, 2, 1, 2
     assert float(b.w2[g, ky * 3 + kx, i, o]) == float(w2[g * 8 + o, i, ky, kx])
