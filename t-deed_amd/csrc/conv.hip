@@ -233,15 +233,32 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   const int cpp = CSP >> 3;
   const int nrow_used = (nrows_out - 1) * STRIDE + 3;
   const bf16_t* xin = x + (long)n * Hi * Wi * C;
-  for (int i = threadIdx.x; i < nrow_used * WP * cpp; i += 256) {
-    const int j = i % cpp;
-    const int pix = i / cpp;
-    const int r = pix / WP, xx = pix - r * WP;
-    const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C)
-      v = *reinterpret_cast<const u32x4*>(xin + ((long)iy * Wi + ix) * C + c);
-    *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = v;
+  // batches of 8 independent 16-B loads per thread before the LDS stores (memory-level parallelism)
+  const int total = nrow_used * WP * cpp;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = i0 + b8 * 256;
+      v[b8] = (u32x4){0u, 0u, 0u, 0u};
+      if (i < total) {
+        const int j = i % cpp;
+        const int pix = i / cpp;
+        const int r = pix / WP, xx = pix - r * WP;
+        const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
+        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C)
+          v[b8] = *reinterpret_cast<const u32x4*>(xin + ((long)iy * Wi + ix) * C + c);
+      }
+    }
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = i0 + b8 * 256;
+      if (i < total) {
+        const int j = i % cpp;
+        const int pix = i / cpp;
+        *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = v[b8];
+      }
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

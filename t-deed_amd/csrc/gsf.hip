@@ -25,6 +25,14 @@ template <> struct Pair<bf16_t> {
   }
 };
 
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) { Chunk<float>::load(p, v); }
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  const u32x2 u = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(u[0] << 16); v[1] = __uint_as_float(u[0] & 0xffff0000u);
+  v[2] = __uint_as_float(u[1] << 16); v[3] = __uint_as_float(u[1] & 0xffff0000u);
+}
+
 // ---- launch 1a: per-frame partial gate sums Q
 // conv3d(a)[t] = sum_j conv2d(a[t+j-1], w[:,:,j]), so every frame is read ONCE: its block computes
 // Q[f][p][j][g] = conv2d_3x3(relu(bn(x[f])), w3d[g][:, j]) for the three temporal taps j and both
@@ -46,20 +54,38 @@ __global__ __launch_bounds__(256) void gsf_q_kernel(const T* __restrict__ x, int
   float* wl = sm;                              // [27][F]
   float* a = sm + 27 * F;                      // [rows*w][LD]
   for (int i = threadIdx.x; i < 27 * F; i += 256) wl[i] = wq[i];
-  const int nq = F >> 1;                       // channel pairs
-  for (int i = threadIdx.x; i < rows * w * nq; i += 256) {
-    const int cp = i % nq;
-    const int pix = i / nq;
-    const int ry = pix / w, px = pix - ry * w;
-    const int yy = y0 - 1 + ry;
-    float v0 = 0.f, v1 = 0.f;
-    if (yy >= 0 && yy < h) {
-      Pair<T>::load(x + ((long)f * h * w + (long)yy * w + px) * C + 2 * cp, v0, v1);
-      v0 = fmaxf(fmaf(v0, bn_scale[2 * cp], bn_shift[2 * cp]), 0.f);
-      v1 = fmaxf(fmaf(v1, bn_scale[2 * cp + 1], bn_shift[2 * cp + 1]), 0.f);
+  const int nq = F >> 2;                       // channel quads (fold % 4 == 0)
+  const int total = rows * w * nq;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 4) {     // 4 independent loads in flight per thread
+    float v[4][4];
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) {
+      const int i = i0 + b4 * 256;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[b4][e] = 0.f;
+      if (i < total) {
+        const int cq = i % nq;
+        const int pix = i / nq;
+        const int ry = pix / w, px = pix - ry * w;
+        const int yy = y0 - 1 + ry;
+        if (yy >= 0 && yy < h) load4<T>(x + ((long)f * h * w + (long)yy * w + px) * C + 4 * cq, v[b4]);
+      }
     }
-    a[pix * LD + 2 * cp] = v0;
-    a[pix * LD + 2 * cp + 1] = v1;
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) {
+      const int i = i0 + b4 * 256;
+      if (i < total) {
+        const int cq = i % nq;
+        const int pix = i / nq;
+        const int yy2 = y0 - 1 + pix / w;
+        const bool outside = yy2 < 0 || yy2 >= h;               // halo rows beyond the image stay exactly zero
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r = fmaxf(fmaf(v[b4][e], bn_scale[4 * cq + e], bn_shift[4 * cq + e]), 0.f);
+          a[pix * LD + 4 * cq + e] = outside ? 0.f : r;
+        }
+      }
+    }
   }
   __syncthreads();
   const int Fh = F >> 1;
