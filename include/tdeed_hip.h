@@ -40,6 +40,18 @@ int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int
                    const float* scale /*[32]*/, const float* shift /*[32]*/, void* out, int dtype,
                    void* stream);
 
+/* ---- fused trunk front (bf16 only): pre-proc + stem + s1.b1.conv1 + s1.b1.conv2 (+SE squeeze) + s1.b1.downsample
+ * uint8 frames [N][3][H][W] -> y2 [N][Ho][Wo][C1] (conv2 output), shortcut [N][Ho][Wo][C1], pooled fp32
+ * [N][parts][C1] partial sums of y2 (parts = tdeed_s1_front_parts(crop_h, crop_w, C1)).  The 112^2 stem and conv1
+ * maps stay in LDS / MFMA accumulators (front.hip).  Weight fragments are pre-packed by
+ * tdeed_amd.engine.pack_front_weights; scale/shift are the folded eval BatchNorms (fp32). */
+int tdeed_s1_front_parts(int crop_h, int crop_w, int C1);
+int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h,
+                       int crop_w, int flip, const void* stem_wf, const float* stem_sc, const float* stem_sh,
+                       int C1, const void* w1f, const float* sc1, const float* sh1, const void* wdf,
+                       const float* scd, const float* shd, const void* w2f, const float* sc2,
+                       const float* sh2, void* y2, void* shortcut, float* pooled, void* stream);
+
 /* ---- dense 1x1 contraction (MFMA) ---------------------------------------------------------
  * C[m][n] = act( (sum_k A'[m][k] * W[n][k]) * scale[n] + shift[n] + R[m][n] )
  * Replaces every 1x1 Conv2d+BN(eval)(+ReLU) of the RegNetY trunk incl. the stride-2 shortcut,
@@ -86,6 +98,20 @@ int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype);
 int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                        const float* w, const void* wfrag, const float* scale, const float* shift,
                        void* y, float* pooled, int dtype, void* stream);
+
+/* ---- whole bottleneck in one launch (bf16, stride 1, identity shortcut, map <= 64 px: s4.b2.. of RegNetY-200MF)
+ * conv1(+gate-shift splice G in front)+BN+ReLU -> grouped 3x3+BN+ReLU -> SE -> conv3+BN+residual+ReLU, one
+ * frame per workgroup, intermediates in LDS/registers (bneck.hip).  x,out [N][h*w][C]; G [N*h*w][Fp] or NULL.
+ * w1f / w3f = engine.pack_rowtile_weights(W1 / W3), w2f = pack_gconv_frags(W2) (bf16);
+ * s1..s3 / h1..h3: folded eval BatchNorm scale / shift; se_w1p bf16 [C][ceil8(R)] (fc1.weight^T, zero padded),
+ * se_w2p bf16 [R][C] (fc2.weight^T); SE biases fp32. */
+int tdeed_bneck_fits(int h, int w, int C, int R);
+/* diagnostic only: device buffer of 8 int64 per frame receiving phase time stamps (NULL switches it off) */
+int tdeed_bneck_set_debug(void* buf);
+int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f,
+                    const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
+                    const void* se_w1p, const float* se_b1, const void* se_w2p, const float* se_b2, int R,
+                    const void* w3f, const float* s3, const float* h3, void* out, void* stream);
 
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
  * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled: fp32 [N][n_parts][C] partial sums, mean = inv_cnt *

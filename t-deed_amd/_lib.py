@@ -30,6 +30,9 @@ _SIGS = {
     "tdeed_abi_version": ([], c_int),
     "tdeed_device_info": ([c_int, c_char_p, POINTER(c_int), POINTER(c_int)], c_int),
     "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
+    "tdeed_s1_front_parts": ([c_int, c_int, c_int], c_int),
+    "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,
+                            P, P, P, P, P, P, P], c_int),
     "tdeed_gemm_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, c_long, P, P, P, c_long,
                         c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gemm_ws_fits": ([c_int, c_int, c_int], c_int),
@@ -37,6 +40,9 @@ _SIGS = {
                            c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gconv3x3_parts": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_bneck_set_debug": ([P], c_int),
+    "tdeed_bneck_fits": ([c_int, c_int, c_int, c_int], c_int),
+    "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P], c_int),
     "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gsf_gate_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_gsf_weight_fwd": ([P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P], c_int),

@@ -194,7 +194,16 @@ static int launch_gconv(const void* x, int N, int Hi, int Wi, int C, int stride,
 // ds_read_b128) is the only staging needed.  Weights come pre-packed per (unit, k-step, lane)
 // and stay in registers.  The weights are the MFMA A operand so that each lane ends up with 4
 // consecutive channels of one pixel (8-byte stores) rather than 4 pixels of one channel.
-#define GC_LDS_CAP (64 * 1024)
+#include <stdlib.h>
+static long gc_cap() {
+  static long cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("TDEED_GCONV_LDS_KB");
+    cap = e ? atol(e) * 1024 : 64 * 1024;
+    if (cap > 64 * 1024) cap = 64 * 1024;
+  }
+  return cap;
+}
 struct GcGeom { int band, nbands, CSP, nslabs, PS, rows_in; };
 static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
   GcGeom g;
@@ -204,7 +213,8 @@ static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
   g.nslabs = (C + g.CSP - 1) / g.CSP;
   g.PS = g.CSP * 2 + 16;
   const long rowb = (long)(Wi + 2) * g.PS;
-  int rows = (int)(GC_LDS_CAP / rowb);
+  int rows = (int)(gc_cap() / rowb);
+  if (rows < 3 && 3 * rowb <= 64 * 1024) rows = 3;
   int band = rows >= 3 ? (rows - 3) / stride + 1 : 0;
   if (band > Ho) band = Ho;
   g.band = band;

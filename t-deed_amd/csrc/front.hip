@@ -1,0 +1,346 @@
+// Fused front of the RegNetY trunk (bf16 throughput mode):
+//   uint8 frame -> /255, crop, flip, standardise -> stem conv3x3 s2 (3->32)+BN+ReLU
+//               -> s1.b1.conv1 1x1 (32->C1)+BN+ReLU -> s1.b1.conv2 grouped 3x3 s2 (+BN+ReLU, SE squeeze)
+//               -> s1.b1.downsample 1x1 s2 (32->C1)+BN        (the block's shortcut)
+// One block = one frame x one band of conv2 output rows.  The 112^2 x 32 stem map and the 112^2 x C1 conv1
+// map (0.64 + 0.48 GB per 8 clips in bf16, written once and read 2.25x by the unfused path) never leave
+// the CU: the normalised input patch and the conv1 band live in LDS, the stem result goes from MFMA
+// accumulators straight into the next MFMA as its B operand (k order permuted consistently in the
+// pre-packed weights).  HBM traffic per step drops from 2.77 GB to 0.36 GB for these four layers.
+//
+// MFMA formulation (v_mfma_f32_16x16x32_bf16, weights = A operand, 16 pixels = B operand columns):
+//   stem : K = (ky, kx 0..3, c 0..3) = 48 of 64: the LDS patch is [row][col][4 bf16] (RGB0), so a lane's 8
+//          k-values (two horizontally adjacent taps) are ONE aligned 16-byte LDS read. 2 k-steps x 2 n-tiles.
+//   conv1/downsample : K = 32 stem channels, taken from the stem accumulators (rows 4q+r of both n-tiles).
+//   conv2: as gconv3x3_mfma_kernel (conv.hip): 5 k-steps per 16-channel unit from the LDS conv1 band.
+#include "common.h"
+#include <stdlib.h>
+
+struct FrontP {
+  const uint8_t* frames; int H, W, top, left, ch, cw, flip;
+  const bf16x8* stem_wf;  const float* stem_sc; const float* stem_sh;     // [2][2][64]
+  const bf16x8* w1f;      const float* sc1;     const float* sh1;         // [C1P/16][64]
+  const bf16x8* wdf;      const float* scd;     const float* shd;
+  const bf16x8* w2f;      const float* sc2;     const float* sh2;         // [ceil4(C1/16)][5][64]
+  bf16_t* y2; bf16_t* shortcut; float* pooled;
+  int C1, CSP, PS, band, nbands, Hs, Ws, Ho, Wo;     // stem map Hs x Ws, block output Ho x Wo
+  int vec16;                                          // rows are 16-byte aligned: vector uint8 loads
+};
+
+template <int NT1>
+__global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[4][16];
+  const int bnd = blockIdx.x, n = blockIdx.y;
+  const int oy0 = bnd * p.band;
+  const int nrows_out = min(p.band, p.Ho - oy0);
+  const int y1r0 = 2 * oy0 - 1;                         // first conv1-map row held (may be -1)
+  const int ny1 = 2 * (nrows_out - 1) + 3;              // conv1 rows held
+  const int in_r0 = 2 * y1r0 - 1;                       // first input row held
+  const int nin = 2 * (ny1 - 1) + 3;
+  const int INW = p.cw + 2;                             // patch columns: input col -1 .. cw (zero padded)
+  const int Y1W = p.Ws + 2;                             // conv1 columns -1 .. Ws
+  bf16_t* inp = reinterpret_cast<bf16_t*>(smem);                       // [nin][INW][4]
+  const int in_bytes = ((2 * (2 * (p.band - 1) + 3 - 1) + 3) * INW * 8 + 15) & ~15;
+  unsigned char* y1t = smem + in_bytes;                                 // [ny1][Y1W][PS]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int px = lane & 15, q = lane >> 4;
+
+  // ---- A. fill the patch: normalised input as bf16 [row][col][RGB0]; zero halo columns / rows outside the
+  //         image; zero the parts of the conv1 band that phase B does not write (halo columns, rows outside the map)
+  {
+    // (u/255 - mean)/std as one fp32 FMA; the result is rounded to bf16 anyway
+    const float na[3] = {1.0f / (255.0f * 0.229f), 1.0f / (255.0f * 0.224f), 1.0f / (255.0f * 0.225f)};
+    const float nb[3] = {-0.485f / 0.229f, -0.456f / 0.224f, -0.406f / 0.225f};
+    const uint8_t* src = p.frames + (long)n * 3 * p.H * p.W;
+    const long plane = (long)p.H * p.W;
+    const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (p.vec16) {
+      // a thread owns 16 pixels of one row: three 16-byte loads (R,G,B planes) in flight, 16 8-byte LDS stores
+      const int nch = p.cw >> 4;
+      const int total = nin * nch;
+      for (int i = tid; i < total; i += 256) {
+        const int k = i % nch, r = i / nch;
+        const int iy = in_r0 + r;
+        bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)r * INW + 16 * k + 1) * 4);
+        if (iy >= 0 && iy < p.ch) {
+          const int scol = p.flip ? (p.cw - 16 - 16 * k) : 16 * k;
+          const uint8_t* s0 = src + (long)(p.top + iy) * p.W + p.left + scol;
+          const u32x4 v0 = *reinterpret_cast<const u32x4*>(s0);
+          const u32x4 v1 = *reinterpret_cast<const u32x4*>(s0 + plane);
+          const u32x4 v2 = *reinterpret_cast<const u32x4*>(s0 + 2 * plane);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const unsigned int sh8 = 8 * (e & 3);
+            bf16x4 o;
+            o[0] = (bf16_t)fmaf((float)((v0[e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
+            o[1] = (bf16_t)fmaf((float)((v1[e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
+            o[2] = (bf16_t)fmaf((float)((v2[e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
+            o[3] = (bf16_t)0.f;
+            dst[p.flip ? (15 - e) : e] = o;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[e] = z4;
+        }
+      }
+    } else {
+      for (int i = tid; i < nin * p.cw; i += 256) {
+        const int r = i / p.cw, ix = i - r * p.cw;
+        const int iy = in_r0 + r;
+        bf16x4 v4 = z4;
+        if (iy >= 0 && iy < p.ch) {
+          const int sx = p.flip ? (p.cw - 1 - ix) : ix;
+          const long o = (long)(p.top + iy) * p.W + (p.left + sx);
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) v4[c3] = (bf16_t)fmaf((float)src[c3 * plane + o], na[c3], nb[c3]);
+        }
+        *reinterpret_cast<bf16x4*>(inp + ((long)r * INW + ix + 1) * 4) = v4;
+      }
+    }
+    for (int i = tid; i < nin * 2; i += 256)          // patch halo columns (input col -1 and cw)
+      *reinterpret_cast<bf16x4*>(inp + ((long)(i >> 1) * INW + ((i & 1) ? (p.cw + 1) : 0)) * 4) = z4;
+    // conv1 band: halo columns of every row, and whole rows that fall outside the stem map
+    const int cpp = p.PS >> 4;                         // 16-byte pieces per pixel (incl. the pad piece)
+    for (int i = tid; i < ny1 * 2 * cpp; i += 256) {
+      const int j = i % cpp, rc = i / cpp;
+      const int rr = rc >> 1, col = (rc & 1) ? (p.Ws + 1) : 0;
+      *reinterpret_cast<u32x4*>(y1t + ((long)rr * Y1W + col) * p.PS + j * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    for (int rr = 0; rr < ny1; ++rr) {
+      const int r = y1r0 + rr;
+      if (r >= 0 && r < p.Hs) continue;
+      for (int i = tid; i < Y1W * cpp; i += 256)
+        *reinterpret_cast<u32x4*>(y1t + (long)rr * Y1W * p.PS + (long)i * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  __syncthreads();
+
+  // ---- B. stem -> conv1 (-> LDS band) and downsample (-> HBM), 16 stem pixels per MFMA tile
+  {
+    bf16x8 swf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) swf[t][ks] = p.stem_wf[(t * 2 + ks) * 64 + lane];
+    float ssc[8], ssh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (e < 4) ? (4 * q + e) : (16 + 4 * q + e - 4);
+      ssc[e] = p.stem_sc[c];
+      ssh[e] = p.stem_sh[c];
+    }
+    // conv1 / downsample weights and their BN affine for this lane's channels stay in registers
+    bf16x8 w1r[NT1], wdr[NT1];
+    float c1s[NT1][4], c1h[NT1][4], cds[NT1][4], cdh[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      w1r[t] = p.w1f[t * 64 + lane];
+      wdr[t] = p.wdf[t * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int chn = t * 16 + 4 * q + e;
+        const bool ok = chn < p.C1;
+        c1s[t][e] = ok ? p.sc1[chn] : 0.f; c1h[t][e] = ok ? p.sh1[chn] : 0.f;
+        cds[t][e] = ok ? p.scd[chn] : 0.f; cdh[t][e] = ok ? p.shd[chn] : 0.f;
+      }
+    }
+    // stem rows to produce: conv1 rows y1r0 .. y1r0+ny1-1 that lie inside the map
+    const int r_lo = max(y1r0, 0), r_hi = min(y1r0 + ny1, p.Hs);
+    const int tiles_per_row = (p.Ws + 15) >> 4;
+    const int ntiles = (r_hi - r_lo) * tiles_per_row;
+    for (int tI = wv; tI < ntiles; tI += 4) {
+      const int r = r_lo + tI / tiles_per_row;
+      const int c0 = (tI % tiles_per_row) * 16;
+      const int c = c0 + px;
+      const bool cok = c < p.Ws;
+      const int cc = cok ? c : (p.Ws - 1);
+      // stem B fragments: slot s = 4ks+q -> (ky = s>>1, half = s&1): 16 B at patch[(2r-1+ky) - in_r0][2c + 2half]
+      f32x4 sa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int s = 4 * ks + q;
+        const int ky = s >> 1, half = s & 1;
+        const int prow = (s < 6) ? (2 * r - 1 + ky - in_r0) : 0;
+        const int pcol = (s < 6) ? (2 * cc + 2 * half) : 0;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(inp + ((long)prow * INW + pcol) * 4);
+        sa[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][ks], xf, sa[0], 0, 0, 0);
+        sa[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][ks], xf, sa[1], 0, 0, 0);
+      }
+      // BN + ReLU -> bf16: this lane's 8 stem channels of pixel (r, c) = k-slot q of the next contraction
+      bf16x8 sf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sf[e] = (bf16_t)fmaxf(sa[0][e] * ssc[e] + ssh[e], 0.f);
+        sf[4 + e] = (bf16_t)fmaxf(sa[1][e] * ssc[4 + e] + ssh[4 + e], 0.f);
+      }
+      unsigned char* y1p = y1t + ((long)(r - y1r0) * Y1W + (cc + 1)) * p.PS;
+      const bool do_ds = ((r & 1) == 0) && (r >> 1) >= oy0 && (r >> 1) < oy0 + nrows_out;
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) {
+        const int ch0 = t * 16 + 4 * q;
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t], sf, a1, 0, 0, 0);
+        if (cok) {          // channels >= C1 get exact zeros (their scale/shift are 0): the band needs no pre-clear
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(a1[e] * c1s[t][e] + c1h[t][e], 0.f);
+          *reinterpret_cast<bf16x4*>(y1p + ch0 * 2) = o;
+        }
+        if (do_ds) {
+          f32x4 ad = {0.f, 0.f, 0.f, 0.f};
+          ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdr[t], sf, ad, 0, 0, 0);
+          if (cok && (c & 1) == 0 && ch0 < p.C1) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(ad[e] * cds[t][e] + cdh[t][e]);
+            *reinterpret_cast<bf16x4*>(p.shortcut + (((long)n * p.Ho + (r >> 1)) * p.Wo + (c >> 1)) * p.C1 + ch0) = o;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- C. grouped 3x3 stride 2 from the LDS conv1 band (same scheme as gconv3x3_mfma_kernel)
+  {
+    const int units = p.CSP >> 4;
+    const int unit = wv % units;
+    const int mstep = 4 / units;
+    bf16x8 wf[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) wf[ks] = p.w2f[(unit * 5 + ks) * 64 + lane];
+    int off[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int sidx = 4 * ks + q;
+      const int half = sidx / 9, tap = sidx - half * 9;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      off[ks] = sidx < 18 ? (dy * Y1W + dx) * p.PS + half * 16 + unit * 32 : unit * 32;
+    }
+    const int ch0 = unit * 16 + q * 4;
+    float sc[4], sh[4], psum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = ch0 + r < p.C1;
+      sc[r] = ok ? p.sc2[ch0 + r] : 0.f;
+      sh[r] = ok ? p.sh2[ch0 + r] : 0.f;
+      psum[r] = 0.f;
+    }
+    const int npix = nrows_out * p.Wo;
+    const int ntl = (npix + 15) >> 4;
+    bf16_t* yout = p.y2 + ((long)n * p.Ho + oy0) * p.Wo * p.C1;
+    for (int mt = wv / units; mt < ntl; mt += mstep) {
+      const int pp = mt * 16 + px;
+      const bool pok = pp < npix;
+      const int pc = pok ? pp : 0;
+      const int oyl = pc / p.Wo, ox = pc - oyl * p.Wo;
+      const unsigned char* base = y1t + ((long)(oyl * 2) * Y1W + ox * 2) * p.PS;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + off[ks]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc, 0, 0, 0);
+      }
+      if (pok && ch0 < p.C1) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (bf16_t)fmaxf(acc[r] * sc[r] + sh[r], 0.f);
+          psum[r] += (float)o[r];
+        }
+        *reinterpret_cast<bf16x4*>(yout + (long)pc * p.C1 + ch0) = o;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = psum[r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (px == 0) red[wv][q * 4 + r] = v;
+    }
+    __syncthreads();
+    if (tid < units * 16) {
+      const int u = tid >> 4, cc = tid & 15;
+      float sres = 0.f;
+      for (int w2 = u; w2 < 4; w2 += units) sres += red[w2][cc];
+      const int chn = u * 16 + cc;
+      if (chn < p.C1) p.pooled[((long)n * p.nbands + bnd) * p.C1 + chn] = sres;
+    }
+  }
+}
+
+#define FRONT_LDS_CAP (80 * 1024)
+static long front_cap() {
+  static long cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("TDEED_FRONT_LDS_KB");
+    cap = e ? atol(e) * 1024 : 48 * 1024;
+    if (cap > FRONT_LDS_CAP) cap = FRONT_LDS_CAP;
+  }
+  return cap;
+}
+static int front_band(int cw, int Ws, int PS, int Ho) {
+  int best = 0;
+  for (int band = 1; band <= Ho && band <= 8; ++band) {
+    const int ny1 = 2 * (band - 1) + 3, nin = 2 * (ny1 - 1) + 3;
+    const long bytes = (((long)nin * (cw + 2) * 8 + 15) & ~15L) + (long)ny1 * (Ws + 2) * PS;
+    if (bytes <= front_cap() || band == 1) best = band;
+  }
+  return best;
+}
+
+extern "C" int tdeed_s1_front_parts(int crop_h, int crop_w, int C1) {
+  const int Hs = (crop_h + 1) / 2, Ws = (crop_w + 1) / 2, Ho = (Hs + 1) / 2;
+  const int CSP = C1 > 32 ? 64 : (C1 > 16 ? 32 : 16);
+  const int band = front_band(crop_w, Ws, CSP * 2 + 16, Ho);
+  return band > 0 ? (Ho + band - 1) / band : 0;
+}
+
+extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
+                                  int crop_h, int crop_w, int flip, const void* stem_wf, const float* stem_sc,
+                                  const float* stem_sh, int C1, const void* w1f, const float* sc1,
+                                  const float* sh1, const void* wdf, const float* scd, const float* shd,
+                                  const void* w2f, const float* sc2, const float* sh2, void* y2, void* shortcut,
+                                  float* pooled, void* stream) {
+  TD_CHECK(frames && stem_wf && stem_sc && stem_sh && w1f && sc1 && sh1 && wdf && scd && shd && w2f && sc2 && sh2 &&
+               y2 && shortcut && pooled, "s1_front: null pointer");
+  TD_CHECK(N > 0 && N <= 65535 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 &&
+               crop_top + crop_h <= H && crop_left + crop_w <= W, "s1_front: bad geometry");
+  TD_CHECK(C1 % 8 == 0 && C1 >= 8 && C1 <= 64, "s1_front: C1=%d unsupported", C1);
+  FrontP p;
+  p.frames = frames; p.H = H; p.W = W; p.top = crop_top; p.left = crop_left; p.ch = crop_h; p.cw = crop_w; p.flip = flip;
+  p.stem_wf = (const bf16x8*)stem_wf; p.stem_sc = stem_sc; p.stem_sh = stem_sh;
+  p.w1f = (const bf16x8*)w1f; p.sc1 = sc1; p.sh1 = sh1;
+  p.wdf = (const bf16x8*)wdf; p.scd = scd; p.shd = shd;
+  p.w2f = (const bf16x8*)w2f; p.sc2 = sc2; p.sh2 = sh2;
+  p.y2 = (bf16_t*)y2; p.shortcut = (bf16_t*)shortcut; p.pooled = pooled;
+  p.C1 = C1;
+  p.CSP = C1 > 32 ? 64 : (C1 > 16 ? 32 : 16);
+  p.PS = p.CSP * 2 + 16;
+  p.Hs = (crop_h + 1) / 2; p.Ws = (crop_w + 1) / 2;
+  p.Ho = (p.Hs + 1) / 2; p.Wo = (p.Ws + 1) / 2;
+  p.band = front_band(crop_w, p.Ws, p.PS, p.Ho);
+  TD_CHECK(p.band > 0, "s1_front: a row band of %d px does not fit LDS", crop_w);
+  p.nbands = (p.Ho + p.band - 1) / p.band;
+  const int ny1 = 2 * (p.band - 1) + 3, nin = 2 * (ny1 - 1) + 3;
+  const size_t smem = (((size_t)nin * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)ny1 * (p.Ws + 2) * p.PS;
+  p.vec16 = (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
+            (((uintptr_t)frames & 15) == 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)s1_front_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e != hipSuccess) { tdeed_set_error("s1_front: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  const int nt1 = p.CSP >> 4;
+  if (nt1 == 1) hipLaunchKernelGGL(s1_front_kernel<1>, dim3(p.nbands, N), dim3(256), smem, (hipStream_t)stream, p);
+  else if (nt1 == 2) hipLaunchKernelGGL(s1_front_kernel<2>, dim3(p.nbands, N), dim3(256), smem, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(s1_front_kernel<4>, dim3(p.nbands, N), dim3(256), smem, (hipStream_t)stream, p);
+  TD_LAUNCH_CHECK("s1_front");
+  return TDEED_OK;
+}

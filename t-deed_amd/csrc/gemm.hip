@@ -9,10 +9,12 @@
 //         so the k permutation is harmless); exact f32 FMA chains -> parity mode.
 // Tile: 128 (M) x BN (N) per 256-thread block, K in slabs of 128 bytes per row (64 bf16 / 32 f32),
 // waves 2x2, each 64 x BN/2.  LDS rows are 128 B, 16-B chunks XOR-swizzled with (row & 7) so the
-// ds_read_b128 fragment reads are conflict-free; double buffered, register-staged global loads
-// (the staging pass is where the SE gate / gate-shift splice / stride-2 row gather are applied).
+// ds_read_b128 fragment reads are conflict-free; one LDS stage + the next K slab prefetched in registers
+// (32 KB of LDS per block => 4-5 resident blocks per CU hide the HBM/L2 latency; the staging pass is
+// where the SE gate / gate-shift splice / stride-2 row gather are applied).
 // Epilogue goes through LDS so that C (and the residual) move as whole 16-B chunks per lane.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmP {
   const void* A; long lda;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   constexpr int A_BYTES = 128 * 128, B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int CS_LD = BN + 4;
-  constexpr int LDS_BYTES = (2 * STAGE > 64 * CS_LD * 4) ? 2 * STAGE : 64 * CS_LD * 4;
+  constexpr int LDS_BYTES = (STAGE > 64 * CS_LD * 4) ? STAGE : 64 * CS_LD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   typedef typename Frag<T>::type frag_t;
 
@@ -101,38 +103,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 
   u32x4 areg[4], breg[BROWS];
+  f32x4 greg[4][EPC / 4];                // SE gate values of the prefetched slab (applied at LDS-store time)
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  // branch-free prefetch: out-of-range chunks read a valid dummy address and are zeroed by a select
   auto gload = [&](int kt) {
     const int k = kt * KT + ch * EPC;
     const bool kok = k < p.K;
+    const int kc = kok ? k : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (kok && aok[i]) {
-        const T* src = (a0row[i] && k < p.k0) ? a0row[i] + k : arow[i] + k;
-        areg[i] = *reinterpret_cast<const u32x4*>(src);
-      } else {
-        areg[i] = zero4;
-      }
+      const T* src = (a0row[i] && kc < p.k0) ? a0row[i] + kc : arow[i] + kc;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+      areg[i] = (kok && aok[i]) ? v : zero4;
     }
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i)
-      breg[i] = (kok && bok[i]) ? *reinterpret_cast<const u32x4*>(brow[i] + k) : zero4;
-    if (p.a_scale && kok) {
+    for (int i = 0; i < BROWS; ++i) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(brow[i] + kc);
+      breg[i] = (kok && bok[i]) ? v : zero4;
+    }
+    if (p.a_scale) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (aok[i]) {
-          float v[EPC];
-          Chunk<T>::load(reinterpret_cast<const T*>(&areg[i]), v);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] *= srow[i][k + e];
-          Chunk<T>::store(reinterpret_cast<T*>(&areg[i]), v);
-        }
-      }
+        for (int h = 0; h < EPC / 4; ++h) greg[i][h] = *reinterpret_cast<const f32x4*>(srow[i] + kc + 4 * h);
     }
   };
   auto lstore = [&](int buf) {
     unsigned char* base = lds + buf * STAGE;
+    if (p.a_scale) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[EPC];
+        Chunk<T>::load(reinterpret_cast<const T*>(&areg[i]), v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] *= greg[i][e >> 2][e & 3];
+        Chunk<T>::store(reinterpret_cast<T*>(&areg[i]), v);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + swz(r0 + 32 * i, ch)) = areg[i];
 #pragma unroll
@@ -150,11 +158,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   gload(0);
   lstore(0);
   __syncthreads();
+  if (nkt > 1) gload(1);                       // tile k+1 sits in registers while tile k is consumed from LDS
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) gload(kt + 1);
-    const unsigned char* abase = lds + cur * STAGE;
+    const unsigned char* abase = lds;
     const unsigned char* bbase = abase + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -170,7 +177,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma<T>(af[mt], bfr[nt], acc[mt][nt]);
     }
-    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __syncthreads();                           // every wave is done reading tile kt
+    if (kt + 1 < nkt) {
+      lstore(0);
+      if (kt + 2 < nkt) gload(kt + 2);
+    }
     __syncthreads();
   }
 
@@ -242,6 +253,9 @@ static int launch_gemm(const GemmP& p, hipStream_t st) {
       if (c < best) { best = c; bn = cand[i]; }
     }
     while (bn > 32 && mb * ((p.N + bn - 1) / bn) < 384) bn >>= 1;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("TDEED_GEMM_BN"); force = e ? atoi(e) : 0; }
+    if (force == 32 || force == 64 || force == 128) bn = force;
   }
   const long nb = (p.N + bn - 1) / bn;
   const long grid = mb * nb;
@@ -309,18 +323,24 @@ struct GemmWsP {
   int NT;
 };
 
-template <typename T, int KS>
+// WLDS = false: the weights do not fit LDS (K = N = 368): fragments are read straight from global memory
+// (1-KiB coalesced wave loads of the pre-packed array; L1/L2 resident, all waves of a CU walk it in step).
+template <typename T, int KS, bool WLDS>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
   constexpr int EPC = Chunk<T>::N;
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  frag_t* wl = reinterpret_cast<frag_t*>(smem);                       // [NT][KS][64]
-  float* ssc = reinterpret_cast<float*>(smem + (size_t)p.NT * KS * 64 * 16);   // [NT*16] scale (logical order)
+  const size_t wbytes = WLDS ? (size_t)p.NT * KS * 64 * 16 : 0;
+  const frag_t* wl = WLDS ? reinterpret_cast<const frag_t*>(smem) : reinterpret_cast<const frag_t*>(p.Wf);
+  float* ssc = reinterpret_cast<float*>(smem + wbytes);               // [NT*16] scale (logical order)
   float* ssh = ssc + p.NT * 16;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   {
-    const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf);
-    for (int i = tid; i < p.NT * KS * 64; i += 256) wl[i] = src[i];
+    if (WLDS) {
+      frag_t* wdst = reinterpret_cast<frag_t*>(smem);
+      const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf);
+      for (int i = tid; i < p.NT * KS * 64; i += 256) wdst[i] = src[i];
+    }
     for (int i = tid; i < p.NT * 16; i += 256) {
       ssc[i] = (p.scale && i < p.N) ? p.scale[i] : 1.0f;
       ssh[i] = (p.shift && i < p.N) ? p.shift[i] : 0.0f;
@@ -362,7 +382,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
             float f[EPC];
             Chunk<T>::load(reinterpret_cast<const T*>(&v), f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] *= srow[k + e];
+            for (int e4 = 0; e4 < EPC; e4 += 4) {
+              const f32x4 g4 = *reinterpret_cast<const f32x4*>(srow + k + e4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) f[e4 + e] *= g4[e];
+            }
             Chunk<T>::store(reinterpret_cast<T*>(&v), f);
           }
         }
@@ -370,6 +394,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
       }
     }
     for (int tp = 0; tp < p.NT; tp += 2) {           // 32 output channels per pass
+      const int chp = tp * 16 + q * 8;
+      u32x4 rpre[2][8 / EPC];
+      if (p.R && chp < p.N) {                          // residual chunks: issued now, consumed after the MFMAs
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int h = 0; h < 8 / EPC; ++h)
+            rpre[mt][h] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + mrow[mt] * p.ldr + chp + h * EPC);
+      }
       f32x4 acc[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -401,11 +434,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
           }
           const long m = mrow[mt];
           if (p.R) {
-            const T* rp = reinterpret_cast<const T*>(p.R) + m * p.ldr + ch;
             float rv[EPC];
 #pragma unroll
             for (int h = 0; h < 8 / EPC; ++h) {
-              Chunk<T>::load(rp + h * EPC, rv);
+              Chunk<T>::load(reinterpret_cast<const T*>(&rpre[mt][h]), rv);
 #pragma unroll
               for (int e = 0; e < EPC; ++e) v[h * EPC + e] += rv[e];
             }
@@ -431,18 +463,33 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
   }
 }
 
+static bool ws_ks_ok(int KS, bool lds) {
+  if (lds) return KS == 1 || KS == 2 || KS == 3 || KS == 4 || KS == 5 || KS == 6 || KS == 8 || KS == 10;
+  return KS == 5 || KS == 10 || KS == 12;       // global-weight mode: the wide s4 layers
+}
+
 template <typename T>
 static int launch_gemm_ws(const GemmWsP& p, hipStream_t st) {
   constexpr int EPC = Chunk<T>::N;
   const int KS = (p.K + 4 * EPC - 1) / (4 * EPC);
-  const size_t smem = (size_t)p.NT * KS * 64 * 16 + (size_t)p.NT * 16 * 2 * sizeof(float);
-  if (smem > 64 * 1024) { tdeed_set_error("gemm_ws: weights (%zu B) do not fit LDS", smem); return TDEED_ERR_ARG; }
+  const size_t wb = (size_t)p.NT * KS * 64 * 16, sb = (size_t)p.NT * 16 * 2 * sizeof(float);
+  const bool lds = wb + sb <= 64 * 1024 && ws_ks_ok(KS, true);
+  if (!lds && !ws_ks_ok(KS, false)) { tdeed_set_error("gemm_ws: unsupported K=%d", p.K); return TDEED_ERR_ARG; }
+  const size_t smem = (lds ? wb : 0) + sb;
   const long nchunks = ((long)p.M + 127) / 128;
   const int grid = (int)(nchunks < 1024 ? nchunks : 1024);
-#define WS_CASE(k) case k: hipLaunchKernelGGL((gemm_ws_kernel<T, k>), dim3(grid), dim3(256), smem, st, p); break;
-  switch (KS) {
-    WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10)
-    default: tdeed_set_error("gemm_ws: unsupported K=%d", p.K); return TDEED_ERR_ARG;
+#define WS_CASE(k, l) case k: hipLaunchKernelGGL((gemm_ws_kernel<T, k, l>), dim3(grid), dim3(256), smem, st, p); break;
+  if (lds) {
+    switch (KS) {
+      WS_CASE(1, true) WS_CASE(2, true) WS_CASE(3, true) WS_CASE(4, true) WS_CASE(5, true) WS_CASE(6, true)
+      WS_CASE(8, true) WS_CASE(10, true)
+      default: break;
+    }
+  } else {
+    switch (KS) {
+      WS_CASE(5, false) WS_CASE(10, false) WS_CASE(12, false)
+      default: break;
+    }
   }
 #undef WS_CASE
   TD_LAUNCH_CHECK("gemm_ws");
@@ -454,8 +501,9 @@ extern "C" int tdeed_gemm_ws_fits(int K, int N, int dtype) {
   const int KS = (K + 4 * epc - 1) / (4 * epc);
   const int NT = (N + 31) / 32 * 2;
   const size_t smem = (size_t)NT * KS * 64 * 16 + (size_t)NT * 16 * 2 * sizeof(float);
-  const bool ks_ok = KS == 1 || KS == 2 || KS == 3 || KS == 4 || KS == 5 || KS == 6 || KS == 8 || KS == 10;
-  return (smem <= 64 * 1024 && ks_ok) ? 1 : 0;
+  if (smem <= 64 * 1024 && ws_ks_ok(KS, true)) return 1;
+  if (dtype == TDEED_BF16 && N <= 1024 && ws_ks_ok(KS, false)) return 2;     // weights streamed from L2
+  return 0;
 }
 
 extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0,

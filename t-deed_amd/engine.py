@@ -9,6 +9,7 @@ compiler, no per-op host work in the steady state.
 Mirrors ``TDEEDModel.Impl.forward(x, inference=True)`` (/root/reference/model/model.py:105-149).
 """
 import math
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -102,13 +103,41 @@ def pack_ws_weights(W, act_dtype, device):
     return torch.from_numpy(fr).to(device).to(act_dtype).contiguous()
 
 
+def pack_rowtile_weights(W, device):
+    """[N][K] -> bf16 MFMA A-operand fragments [ceil(N/32)*2][ceil(K/32)][64][8], natural row order
+    (tile T row n = channel 16T+n): conv1 of the fused bottleneck, whose output goes to LDS."""
+    W = _np(W).astype(np.float32)
+    N, K = W.shape
+    KS = (K + 31) // 32
+    NT = (N + 31) // 32 * 2
+    Wp = np.zeros((NT * 16, KS * 32), np.float32)
+    Wp[:N, :K] = W
+    fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
+    return torch.from_numpy(np.ascontiguousarray(fr).reshape(NT, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
+
+
+def pack_se_bf16(fc1_w, fc2_w, device):
+    """SE weights for the fused bottleneck: fc1.weight [R][C][1][1] -> bf16 [C][ceil8(R)] (transposed, zero padded);
+    fc2.weight [C][R][1][1] -> bf16 [R][C] (transposed)."""
+    w1 = _np(fc1_w).astype(np.float32)
+    w1 = w1.reshape(w1.shape[0], -1)
+    w2 = _np(fc2_w).astype(np.float32)
+    w2 = w2.reshape(w2.shape[0], -1)
+    R, C = w1.shape
+    R8 = (R + 7) // 8 * 8
+    p1 = np.zeros((C, R8), np.float32)
+    p1[:, :R] = w1.T
+    bf = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device).to(torch.bfloat16).contiguous()   # noqa: E731
+    return dict(se_w1p=bf(p1), se_w2p=bf(w2.T))
+
+
 class DenseW:
     """A dense [N][K] weight in the layout the chosen contraction kernel wants."""
 
     def __init__(self, W, act_dtype, device):
         W = _np(W)
         self.N, self.K = W.shape
-        self.ws = ops.gemm_ws_fits(self.K, self.N, act_dtype) if str(device) != "cpu" else False
+        self.ws = (ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) == 1) if str(device) != "cpu" else False
         self.w = pack_ws_weights(W, act_dtype, device) if self.ws else _dense(W, act_dtype, device)
         self.kernel = "gemm_ws" if self.ws else "gemm"
 
@@ -116,6 +145,45 @@ class DenseW:
         if self.ws:
             return ops.gemm_ws(A, self.w, self.K, self.N, scale, shift, act, **kw)
         return ops.gemm(A, self.w, scale, shift, act, **kw)
+
+
+def pack_front_weights(stem_w, stem_sc, stem_sh, w1, sc1, sh1, wd, scd, shd, w2, gw, sc2, sh2, device):
+    """Weight fragments of s1_front_kernel (front.hip).  stem_w [32][3][3][3]; w1/wd [C1][32]; w2 [C1][gw][3][3].
+    Stem k-slot s = 4ks+q -> (ky = s>>1, half = s&1), element j -> (kx = 2half + j//4, c = j%4 (3 = pad));
+    conv1/downsample k-slot q element j -> stem channel 4q+j (j<4) / 16+4q+j-4: the order in which the stem's
+    MFMA accumulators hand the 32 channels over."""
+    stem_w, w1, wd = _np(stem_w).astype(np.float32), _np(w1).astype(np.float32), _np(wd).astype(np.float32)
+    C1 = w1.shape[0]
+    sw = np.zeros((2, 2, 64, 8), np.float32)
+    for t in range(2):
+        for ks in range(2):
+            for q in range(4):
+                s_ = 4 * ks + q
+                if s_ >= 6:
+                    continue
+                ky, half = s_ >> 1, s_ & 1
+                for j in range(8):
+                    kx, c = 2 * half + j // 4, j % 4
+                    if kx > 2 or c > 2:
+                        continue
+                    sw[t, ks, q * 16:(q + 1) * 16, j] = stem_w[t * 16:(t + 1) * 16, c, ky, kx]
+    nt = (C1 + 15) // 16
+
+    def kperm(W):
+        fr = np.zeros((nt, 64, 8), np.float32)
+        for t in range(nt):
+            for q in range(4):
+                for j in range(8):
+                    chn = 4 * q + j if j < 4 else 16 + 4 * q + j - 4
+                    for n in range(16):
+                        if t * 16 + n < C1:
+                            fr[t, q * 16 + n, j] = W[t * 16 + n, chn]
+        return fr
+    bf = lambda a: torch.from_numpy(a).to(device).to(torch.bfloat16).contiguous()      # noqa: E731
+    f32 = lambda a: _f32(_np(a), device)                                              # noqa: E731
+    return SimpleNamespace(C1=C1, stem_wf=bf(sw), stem_sc=f32(stem_sc), stem_sh=f32(stem_sh), w1f=bf(kperm(w1)),
+                           sc1=f32(sc1), sh1=f32(sh1), wdf=bf(kperm(wd)), scd=f32(scd), shd=f32(shd),
+                           w2f=pack_gconv_frags(w2, gw, device), sc2=f32(sc2), sh2=f32(sh2))
 
 
 def pack_gconv_frags(w, gw, device):
@@ -322,6 +390,16 @@ class PackedWeights:
             bw.se_b2 = f32(sd[bp + ".se.fc2.bias"])
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
+            bw.fused = None
+            if (act_dtype == torch.bfloat16 and str(device) != "cpu" and blk.stride == 1 and not blk.has_downsample
+                    and os.environ.get("TDEED_BNECK") == "1"):
+                # one-launch bottleneck (bneck.hip): correct, but measured slower than the 4-launch chain on
+                # MI355X (every frame re-streams ~1 MB of weights from L2: 180 vs 143 us per s4 block at B=8),
+                # so it is opt-in; see DESIGN.md section 6.
+                bw.fused = SimpleNamespace(
+                    w1f=pack_rowtile_weights(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), device),
+                    w3f=pack_rowtile_weights(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), device),
+                    **pack_se_bf16(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
             if blk.has_downsample:
                 bw.wd = DenseW(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
                 bw.sd, bw.hd = bn_fold(bp + ".downsample.bn")
@@ -340,6 +418,16 @@ class PackedWeights:
                 else:
                     bw.gs_cw1 = bw.gs_cb1 = bw.gs_cw2 = bw.gs_cb2 = None
             W.blocks.append(bw)
+        W.front = None
+        b0 = self.spec.blocks[0]
+        if act_dtype == torch.bfloat16 and b0.stride == 2 and b0.has_downsample and b0.cout <= 64 and not b0.gsf_fold \
+                and str(device) != "cpu":
+            bw0, bp0 = W.blocks[0], p + b0.name
+            W.front = pack_front_weights(
+                sd[p + "stem.conv.weight"], W.stem_scale, W.stem_shift,
+                sd[bp0 + ".conv1.conv.weight"].reshape(b0.cout, b0.cin), bw0.s1, bw0.h1,
+                sd[bp0 + ".downsample.conv.weight"].reshape(b0.cout, b0.cin), bw0.sd, bw0.hd,
+                sd[bp0 + ".conv2.conv.weight"], b0.gw, bw0.s2, bw0.h2, device)
         W.temp_enc = f32(sd["temp_enc"])
         C = self.spec.feat_dim
 
@@ -362,7 +450,7 @@ class PackedWeights:
 
 
 class ForwardEngine:
-    def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", use_graph=True):
+    def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", use_graph=True, fuse_front=True):
         if not torch.cuda.is_available():
             raise RuntimeError("tdeed_amd.ForwardEngine needs an MI355X (no CPU path)")
         _lib.load()
@@ -373,6 +461,7 @@ class ForwardEngine:
         self.act_dtype = act_dtype
         self.device = device
         self.use_graph = use_graph
+        self.fuse_front = fuse_front
         self._plans = {}
 
     # ------------------------------------------------------------------ plan construction
@@ -392,18 +481,82 @@ class ForwardEngine:
             crop = (int(round((H - ch) / 2.0)), int(round((W - cw) / 2.0)), ch, cw)
         frames = torch.empty((N, 3, H, W), dtype=torch.uint8, device=dev)
         Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
-        x = pool.take((N, Ho, Wo, 32), dt)
         es = _esz(dt)
-        steps.append(Step("stem", "stem", lambda x=x: ops.stem(frames, Wt.stem_w, Wt.stem_scale, Wt.stem_shift, dt, crop,
-                                                               flip, out=x),
-                          N * 3 * ch * cw + N * Ho * Wo * 32 * es, 2 * N * Ho * Wo * 32 * 27))
-        h, w = Ho, Wo
-        x_kept = "_features.stem" in taps
-        if x_kept:
-            keep["_features.stem"] = x
-        for bw in Wt.blocks:
+        blocks = list(Wt.blocks)
+        fused_front = Wt.front is not None and "_features.stem" not in taps and self.fuse_front
+        if fused_front:
+            bw = blocks.pop(0)
+            blk = bw.spec
+            h2, w2 = (Ho + 1) // 2, (Wo + 1) // 2
+            parts = ops.s1_front_parts(ch, cw, blk.cout)
+            y2 = pool.take((N, h2, w2, blk.cout), dt)
+            sc = pool.take((N, h2, w2, blk.cout), dt)
+            pooled = pool.take((N, parts, blk.cout), torch.float32)
+            gate = pool.take((N, blk.cout), torch.float32)
+            out = pool.take((N, h2, w2, blk.cout), dt)
+            M2 = N * h2 * w2
+            steps.append(Step("s1_front", "s1_front", lambda y2=y2, sc=sc, pooled=pooled: ops.s1_front(
+                frames, Wt.front, crop, flip, y2=y2, shortcut=sc, pooled=pooled),
+                              N * 3 * ch * cw + 2 * M2 * blk.cout * es,
+                              2 * N * Ho * Wo * 32 * (27 + 2 * blk.cout) // 1 + 2 * M2 * blk.cout * blk.gw * 9))
+            steps.append(Step(blk.name + ".se", "se_gate", lambda bw=bw, pooled=pooled, gate=gate, ic=1.0 / (h2 * w2): ops.se_gate(
+                pooled, ic, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate),
+                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda bw=bw, y2=y2, sc=sc, gate=gate, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
+                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
+                *gemm_cost(M2, blk.cout, blk.cout, es, True)))
+            for t_ in (y2, sc, pooled, gate):
+                pool.give(t_)
+            x, h, w = out, h2, w2
+            x_kept = ("_features." + blk.name) in taps
+            if x_kept:
+                keep["_features." + blk.name] = out
+        else:
+            x = pool.take((N, Ho, Wo, 32), dt)
+        if not fused_front:
+            steps.append(Step("stem", "stem", lambda x=x: ops.stem(frames, Wt.stem_w, Wt.stem_scale, Wt.stem_shift, dt, crop,
+                                                                   flip, out=x),
+                              N * 3 * ch * cw + N * Ho * Wo * 32 * es, 2 * N * Ho * Wo * 32 * 27))
+        if not fused_front:
+            h, w = Ho, Wo
+            x_kept = "_features.stem" in taps
+            if x_kept:
+                keep["_features.stem"] = x
+        for bw in blocks:
             blk = bw.spec
             M = N * h * w
+            if bw.fused is not None and ops.bneck_fits(h, w, blk.cout, blk.se_rd):
+                # whole bottleneck in one launch (gate-shift still produces the spliced columns G first)
+                G, Fp, gs_bufs = None, 0, []
+                if blk.gsf_fold:
+                    F = blk.gsf_fold
+                    Fp = (F + 7) // 8 * 8
+                    gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
+                              ysum=pool.take((N, F), torch.float32), xsum=pool.take((N, F), torch.float32),
+                              out=pool.take((M, Fp), dt))
+                    if bw.gs_cw1 is not None:
+                        gb["fw"] = pool.take((B, F, T), torch.float32)
+                    steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
+                        x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
+                        bw.gs_cw2, bw.gs_cb2, bufs=gb), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                    G = gb["out"]
+                    gs_bufs = list(gb.values())
+                out = pool.take((N, h, w, blk.cout), dt)
+                Cb = blk.cout
+                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, Fp=Fp, out=out: ops.bneck(
+                    x, bw, G, Fp, out=out),
+                    (3 * M * Cb + M * Fp) * es + (2 * Cb * Cb + Cb * blk.gw * 9) * es + 2 * Cb * blk.se_rd * 4,
+                    2 * M * Cb * (2 * Cb + blk.gw * 9) + 4 * N * Cb * blk.se_rd))
+                for t_ in gs_bufs:
+                    pool.give(t_)
+                if not x_kept:
+                    pool.give(x)
+                tapname = "_features." + blk.name
+                x_kept = tapname in taps
+                if x_kept:
+                    keep[tapname] = out
+                x = out
+                continue
             # conv1 (optionally behind the gate-shift splice)
             y1 = pool.take((N, h, w, blk.cout), dt)
             if blk.gsf_fold:

@@ -35,6 +35,32 @@ def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None)
     return out
 
 
+def s1_front_parts(ch, cw, C1):
+    return _lib.load().tdeed_s1_front_parts(ch, cw, C1)
+
+
+def s1_front(frames_u8, fw, crop=None, flip=False, y2=None, shortcut=None, pooled=None):
+    """Fused pre-proc + stem + s1.b1.{conv1, conv2, downsample} (bf16).  fw: engine.pack_front_weights(...).
+    frames (N,3,H,W) uint8 -> y2 (N,Ho,Wo,C1), shortcut (N,Ho,Wo,C1), pooled (N,parts,C1) fp32 sums."""
+    _chk(frames_u8, "frames", torch.uint8)
+    N, _, H, W = frames_u8.shape
+    top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
+    Hs, Ws = (ch + 1) // 2, (cw + 1) // 2
+    Ho, Wo = (Hs + 1) // 2, (Ws + 1) // 2
+    C1 = fw.C1
+    dev = frames_u8.device
+    if y2 is None:
+        y2 = torch.empty((N, Ho, Wo, C1), dtype=torch.bfloat16, device=dev)
+    if shortcut is None:
+        shortcut = torch.empty((N, Ho, Wo, C1), dtype=torch.bfloat16, device=dev)
+    if pooled is None:
+        pooled = torch.empty((N, s1_front_parts(ch, cw, C1), C1), dtype=torch.float32, device=dev)
+    call("tdeed_s1_front_fwd", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(fw.stem_wf), ptr(fw.stem_sc),
+         ptr(fw.stem_sh), C1, ptr(fw.w1f), ptr(fw.sc1), ptr(fw.sh1), ptr(fw.wdf), ptr(fw.scd), ptr(fw.shd),
+         ptr(fw.w2f), ptr(fw.sc2), ptr(fw.sh2), ptr(y2), ptr(shortcut), ptr(pooled), stream_ptr())
+    return y2, shortcut, pooled
+
+
 def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
          A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None):
     """C = act((A' @ W^T) * scale + shift + residual).  A (M,K) / W (N,K) same dtype.
@@ -59,8 +85,13 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     return out
 
 
+def gemm_ws_fits_mode(K, N, act_dtype):
+    """0: no; 1: weights fit LDS (preferred kernel for narrow layers); 2: weights streamed from L2 (wide layers)."""
+    return _lib.load().tdeed_gemm_ws_fits(K, N, dtype_code(act_dtype))
+
+
 def gemm_ws_fits(K, N, act_dtype):
-    return bool(_lib.load().tdeed_gemm_ws_fits(K, N, dtype_code(act_dtype)))
+    return gemm_ws_fits_mode(K, N, act_dtype) != 0
 
 
 def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
@@ -102,6 +133,23 @@ def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled
     call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(wfrag), ptr(scale), ptr(shift),
          ptr(out), ptr(pooled), dtype_code(x.dtype), stream_ptr())
     return out, pooled
+
+
+def bneck_fits(h, w, C, R):
+    return bool(_lib.load().tdeed_bneck_fits(h, w, C, R))
+
+
+def bneck(x, bw, G=None, Fp=0, out=None):
+    """Fused bottleneck (bf16): x (N,h,w,C) -> (N,h,w,C).  bw: engine block weights with .fused pack."""
+    _chk(x, "x", torch.bfloat16)
+    N, h, w, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    f = bw.fused
+    call("tdeed_bneck_fwd", ptr(x), ptr(G), Fp, N, h, w, C, ptr(f.w1f), ptr(bw.s1), ptr(bw.h1), ptr(bw.w2frag),
+         ptr(bw.s2), ptr(bw.h2), ptr(f.se_w1p), ptr(bw.se_b1), ptr(f.se_w2p), ptr(bw.se_b2), bw.spec.se_rd,
+         ptr(f.w3f), ptr(bw.s3), ptr(bw.h3), ptr(out), stream_ptr())
+    return out
 
 
 def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):

@@ -95,7 +95,7 @@ def test_gemm_se_scale_splice_gather(ops, dtype):
 
 
 WS_SHAPES = [(300, 32, 24), (1000, 24, 24), (257, 24, 56), (640, 56, 56), (999, 56, 152), (4097, 152, 152),
-             (500, 64, 128), (130, 128, 128)]
+             (500, 64, 128), (130, 128, 128), (777, 368, 368), (300, 152, 368)]
 
 
 @pytest.mark.parametrize("M,K,N", WS_SHAPES)
@@ -203,6 +203,78 @@ def test_avgpool_posenc(ops, dtype):
     ref = x.float().mean(dim=(1, 2)).view(B, T, C) + te[None]
     out = ops.avgpool_posenc(x.to(DEV), B, T, te.to(DEV))
     assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 64, None, False, 24, 8), (1, 72, 80, (4, 8, 64, 64), True, 24, 8),
+                                  (1, 224, 224, None, False, 24, 8), (1, 96, 64, None, False, 64, 16)])
+def test_s1_front_fused_vs_unfused_reference(ops, geom):
+    """stem -> conv1 -> conv2 (+ squeeze) and the stride-2 shortcut in one kernel == the same chain in torch fp32."""
+    from tdeed_amd.engine import pack_front_weights
+    from oracle import tdeed_oracle as O
+    N, H, W, crop, flip, C1, gw = geom
+    fr = synth.uint8_clip(81, (N, 3, H, W))
+    sw = rnd(82, "sw", (32, 3, 3, 3), 0.3)
+    w1, wd = rnd(83, "w1", (C1, 32), 0.25), rnd(84, "wd", (C1, 32), 0.25)
+    w2 = rnd(85, "w2", (C1, gw, 3, 3), 0.15)
+    aff = lambda i, c: (rnd(90 + i, "s", (c,)) * 0.2 + 1.0, rnd(95 + i, "h", (c,)) * 0.1)   # noqa: E731
+    (ss, sh), (s1, h1), (sd_, hd), (s2, h2) = aff(0, 32), aff(1, C1), aff(2, C1), aff(3, C1)
+    x = t(fr).float() / 255.0
+    if crop:
+        x = x[..., crop[0]:crop[0] + crop[2], crop[1]:crop[1] + crop[3]]
+    if flip:
+        x = x.flip(-1)
+    x = (x - torch.tensor(O.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(O.IMAGENET_STD).view(1, 3, 1, 1)
+    v = lambda a: a.view(1, -1, 1, 1)                                                       # noqa: E731
+    st = torch.relu(F.conv2d(x, sw, stride=2, padding=1) * v(ss) + v(sh))
+    y1 = torch.relu(F.conv2d(st, w1.view(C1, 32, 1, 1)) * v(s1) + v(h1))
+    y2 = torch.relu(F.conv2d(y1, w2, stride=2, padding=1, groups=C1 // gw) * v(s2) + v(h2))
+    scut = F.conv2d(st, wd.view(C1, 32, 1, 1), stride=2) * v(sd_) + v(hd)
+    fw = pack_front_weights(sw, ss, sh, w1, s1, h1, wd, sd_, hd, w2, gw, s2, h2, DEV)
+    g2, gs, gp = ops.s1_front(t(fr).to(DEV), fw, crop, flip)
+    assert g2.shape[1:3] == y2.shape[2:]
+    assert rel_err(g2.float().permute(0, 3, 1, 2), y2) < 4e-2
+    assert rel_err(gs.float().permute(0, 3, 1, 2), scut) < 4e-2
+    npix = y2.shape[2] * y2.shape[3]
+    assert rel_err(gp.sum(dim=1) / npix, y2.mean(dim=(2, 3))) < 4e-2
+
+
+@pytest.mark.parametrize("C,gw,R,h,w,Fp", [(368, 8, 92, 7, 7, 96), (368, 8, 92, 7, 7, 0), (152, 8, 38, 4, 5, 40),
+                                           (320, 16, 80, 7, 7, 80)])
+def test_bneck_fused_vs_chain(ops, C, gw, R, h, w, Fp):
+    """one-launch bottleneck == conv1 -> conv2 -> SE -> conv3 (+residual) computed in torch fp32."""
+    from tdeed_amd.engine import pack_rowtile_weights, pack_se_bf16, pack_gconv_frags
+    from types import SimpleNamespace
+    if not ops.bneck_fits(h, w, C, R):
+        pytest.skip("geometry not supported by the fused kernel")
+    N = 5
+    bf = torch.bfloat16
+    x = rnd(101, "x", (N, h, w, C)).to(bf)
+    G = rnd(102, "G", (N * h * w, max(Fp, 8))).to(bf)
+    W1, W3 = rnd(103, "W1", (C, C), 1 / np.sqrt(C)).to(bf), rnd(104, "W3", (C, C), 1 / np.sqrt(C)).to(bf)
+    W2 = rnd(105, "W2", (C, gw, 3, 3), 0.15).to(bf)
+    aff = lambda i: (rnd(110 + i, "s", (C,)) * 0.2 + 1.0, rnd(115 + i, "h", (C,)) * 0.1)      # noqa: E731
+    (s1, h1), (s2, h2), (s3, h3) = aff(0), aff(1), aff(2)
+    sw1, sb1 = rnd(120, "sw1", (R, C), 0.1).to(bf).float(), rnd(121, "sb1", (R,), 0.1)
+    sw2, sb2 = rnd(122, "sw2", (C, R), 0.2).to(bf).float(), rnd(123, "sb2", (C,), 0.1)
+    xin = x.float().view(N * h * w, C).clone()
+    if Fp:
+        xin[:, :Fp] = G[:, :Fp].float()
+    y1 = torch.relu(xin @ W1.float().T * s1 + h1).to(bf).float()
+    y1n = y1.view(N, h, w, C).permute(0, 3, 1, 2)
+    y2 = torch.relu(F.conv2d(y1n, W2.float(), padding=1, groups=C // gw) * s2.view(1, -1, 1, 1) + h2.view(1, -1, 1, 1))
+    y2 = y2.to(bf).float()
+    gate = torch.sigmoid(torch.relu(y2.mean(dim=(2, 3)) @ sw1.T + sb1) @ sw2.T + sb2)
+    a3 = (y2 * gate[:, :, None, None]).to(bf).float().permute(0, 2, 3, 1).reshape(N * h * w, C)
+    ref = torch.relu(a3 @ W3.float().T * s3 + h3 + x.float().view(N * h * w, C))
+    dev = lambda a: a.contiguous().to(DEV)                                                       # noqa: E731
+    bw = SimpleNamespace(spec=SimpleNamespace(se_rd=R), s1=dev(s1), h1=dev(h1), s2=dev(s2), h2=dev(h2), s3=dev(s3),
+                         h3=dev(h3), w2frag=pack_gconv_frags(W2.float().numpy(), gw, DEV), se_w1t=dev(sw1.T),
+                         se_b1=dev(sb1), se_w2t=dev(sw2.T), se_b2=dev(sb2),
+                         fused=SimpleNamespace(w1f=pack_rowtile_weights(W1.float().numpy(), DEV),
+                                               w3f=pack_rowtile_weights(W3.float().numpy(), DEV),
+                                               **pack_se_bf16(sw1.numpy(), sw2.numpy(), DEV)))
+    out = ops.bneck(dev(x), bw, dev(G[:, :Fp]) if Fp else None, Fp)
+    assert rel_err(out.float().view(N * h * w, C), ref) < 3e-2
 
 
 # ----------------------------------------------------------------------------- gate-shift (golden = reference output)
