@@ -120,7 +120,7 @@ def main():
         plan = eng.plan(B, H, W)
         T = cfg["clip_len"]
         # synthetic uint8 clips, generated on the device straight into the plan's input buffer
-        plan.frames.copy_(ops.fill_u8_hash((B * T, 3, H, W), 1000 + rank, dev))
+        eng.set_frames(plan, ops.fill_u8_hash((B, T, 3, H, W), 1000 + rank, dev))
         for _ in range(max(a.warmup, 1)):
             eng.run_plan(plan)
         stream.synchronize()

@@ -120,6 +120,12 @@ int tdeed_se_gate_fwd(const float* pooled, int n_parts, float inv_cnt, int N, in
                       const float* w1t, const float* b1, const float* w2t, const float* b2,
                       float* gate, void* stream);
 
+/* Same excitation with bf16 weights (throughput mode): w1p bf16 [C][ceil8(R)] (fc1.weight^T zero padded),
+ * w2p bf16 [R][C] (fc2.weight^T) = tdeed_amd.engine.pack_se_bf16. */
+int tdeed_se_gate_bf16_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R,
+                           const void* w1p, const float* b1, const void* w2p, const float* b2,
+                           float* gate, void* stream);
+
 /* ---- Gate-Shift(-Fuse) (model/impl/gsf.py:38-93, model/impl/gsm.py:89-116, eval BN) ------------
  * x: [B*T][h][w][C] (first F channels are gated).  Three launches:
  *  gate:   BN3d+ReLU+Conv3d(3x3x3, groups 2)+tanh -> gate fp32 [B*T][h][w][2]; also

@@ -474,6 +474,130 @@ extern "C" int tdeed_se_gate_fwd(const float* pooled, int n_parts, float inv_cnt
   return TDEED_OK;
 }
 
+// ---- bf16-weight variant (throughput mode): 16-byte weight loads (8 outputs each), every thread issues its
+// whole share of a weight matrix as ONE batch of independent loads, so each phase costs one L2 round trip.
+// w1p: bf16 [C][R8] (fc1.weight^T, R padded to 8), w2p: bf16 [R][C] (fc2.weight^T).
+__global__ __launch_bounds__(256) void se_gate_bf16_kernel(const float* __restrict__ pooled, int n_parts, float inv_cnt,
+                                                           int N, int C, int R, const bf16_t* __restrict__ w1p,
+                                                           const float* __restrict__ b1,
+                                                           const bf16_t* __restrict__ w2p,
+                                                           const float* __restrict__ b2, float* __restrict__ gate) {
+  extern __shared__ float sm[];
+  const int R8 = (R + 7) & ~7;
+  float* sp = sm;                                   // [FPB][C] means
+  float* shid = sp + SE_FPB * C;                    // [FPB][R8]
+  float* part = shid + SE_FPB * R8;                 // partial sums of either phase
+  const int f0 = blockIdx.x * SE_FPB;
+  for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
+    const int f = i / C, c = i - f * C;
+    float v = 0.f;
+    if (f0 + f < N) {
+      const float* src = pooled + ((long)(f0 + f) * n_parts) * C + c;
+      for (int q = 0; q < n_parts; ++q) v += src[(long)q * C];
+    }
+    sp[i] = v * inv_cnt;
+  }
+  __syncthreads();
+  constexpr int MAXB = 12;
+  {
+    const int NJ = R8 >> 3, nsl = 256 / NJ;
+    const int jo = threadIdx.x % NJ, sl = threadIdx.x / NJ;
+    if (sl < nsl) {
+      float a[SE_FPB][8];
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[f][e] = 0.f;
+      const int cper = (C + nsl - 1) / nsl;
+      const int c0 = sl * cper, c1 = min(C, c0 + cper);
+      for (int cb = c0; cb < c1; cb += MAXB) {
+        bf16x8 w[MAXB];
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i)
+          if (cb + i < c1) w[i] = *reinterpret_cast<const bf16x8*>(w1p + (long)(cb + i) * R8 + jo * 8);
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i)
+          if (cb + i < c1) {
+#pragma unroll
+            for (int f = 0; f < SE_FPB; ++f) {
+              const float pv = sp[f * C + cb + i];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[f][e] = fmaf(pv, (float)w[i][e], a[f][e]);
+            }
+          }
+      }
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(sl * SE_FPB + f) * R8 + jo * 8 + e] = a[f][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SE_FPB * R8; i += 256) {
+      const int j = i % R8;
+      float v = 0.f;
+      for (int s_ = 0; s_ < nsl; ++s_) v += part[s_ * SE_FPB * R8 + i];
+      shid[i] = j < R ? fmaxf(v + b1[j], 0.f) : 0.f;
+    }
+    __syncthreads();
+  }
+  {
+    const int NC = C >> 3;
+    const int nsl = 256 / NC > 0 ? 256 / NC : 1;
+    for (int co = threadIdx.x % NC, sl = threadIdx.x / NC; sl < nsl && threadIdx.x < NC * nsl; sl = nsl) {
+      float a[SE_FPB][8];
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[f][e] = 0.f;
+      const int jper = (R + nsl - 1) / nsl;
+      const int j0 = sl * jper, j1 = min(R, j0 + jper);
+      for (int jb = j0; jb < j1; jb += MAXB) {
+        bf16x8 w[MAXB];
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i)
+          if (jb + i < j1) w[i] = *reinterpret_cast<const bf16x8*>(w2p + (long)(jb + i) * C + co * 8);
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i)
+          if (jb + i < j1) {
+#pragma unroll
+            for (int f = 0; f < SE_FPB; ++f) {
+              const float hv = shid[f * R8 + jb + i];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[f][e] = fmaf(hv, (float)w[i][e], a[f][e]);
+            }
+          }
+      }
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(sl * SE_FPB + f) * C + co * 8 + e] = a[f][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
+      const int f = i / C, c = i - f * C;
+      float v = 0.f;
+      for (int s_ = 0; s_ < nsl; ++s_) v += part[s_ * SE_FPB * C + i];
+      if (f0 + f < N) gate[(long)(f0 + f) * C + c] = sigmoidf_(v + b2[c]);
+    }
+  }
+}
+
+extern "C" int tdeed_se_gate_bf16_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R,
+                                      const void* w1p, const float* b1, const void* w2p, const float* b2,
+                                      float* gate, void* stream) {
+  TD_CHECK(pooled && w1p && b1 && w2p && b2 && gate, "se_gate_bf16: null pointer");
+  TD_CHECK(N > 0 && C > 0 && C % 8 == 0 && C <= 2048 && R > 0 && R <= 2048 && n_parts > 0, "se_gate_bf16: bad sizes");
+  const int R8 = (R + 7) & ~7;
+  const size_t p1 = (size_t)(256 / (R8 / 8)) * SE_FPB * R8;
+  const size_t p2 = (size_t)(256 / (C / 8) > 0 ? 256 / (C / 8) : 1) * SE_FPB * C;
+  const size_t smem = ((size_t)SE_FPB * (C + R8) + (p1 > p2 ? p1 : p2)) * sizeof(float);
+  TD_CHECK(smem <= 64 * 1024, "se_gate_bf16: C=%d R=%d needs %zu B of LDS", C, R, smem);
+  hipLaunchKernelGGL(se_gate_bf16_kernel, dim3(cdiv(N, SE_FPB)), dim3(256), smem, (hipStream_t)stream, pooled,
+                     n_parts, inv_cnt, N, C, R, (const bf16_t*)w1p, b1, (const bf16_t*)w2p, b2, gate);
+  TD_LAUNCH_CHECK("se_gate_bf16");
+  return TDEED_OK;
+}
+
 // =========================================================================== avg-pool + pos-enc
 template <typename T>
 __global__ void avgpool_posenc_kernel(const T* __restrict__ x, int T_len, int hw, int C,

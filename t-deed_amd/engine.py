@@ -244,6 +244,13 @@ def pack_sgp_mixer(sd, pre, C, act_dtype, device):
     return o
 
 
+def _se(pooled, inv_cnt, bw, gate):
+    """SE excitation: bf16 packed weights in throughput mode, fp32 weights in parity mode."""
+    if bw.se_bf is not None:
+        return ops.se_gate_bf16(pooled, inv_cnt, bw.se_bf.se_w1p, bw.se_b1, bw.se_bf.se_w2p, bw.se_b2, bw.spec.se_rd, out=gate)
+    return ops.se_gate(pooled, inv_cnt, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate)
+
+
 class Step:
     """One kernel launch of a plan with its algorithmic cost (what a perfect kernel must move / compute)."""
     __slots__ = ("name", "kernel", "fn", "bytes", "flops")
@@ -388,6 +395,8 @@ class PackedWeights:
             bw.se_b1 = f32(sd[bp + ".se.fc1.bias"])
             bw.se_w2t = f32(sd[bp + ".se.fc2.weight"].reshape(blk.cout, blk.se_rd).T)
             bw.se_b2 = f32(sd[bp + ".se.fc2.bias"])
+            bw.se_bf = (SimpleNamespace(**pack_se_bf16(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
+                        if act_dtype == torch.bfloat16 and str(device) != "cpu" else None)
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
             bw.fused = None
@@ -450,7 +459,7 @@ class PackedWeights:
 
 
 class ForwardEngine:
-    def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", use_graph=True, fuse_front=True):
+    def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", use_graph=True, fuse_front=True, n_split=2):
         if not torch.cuda.is_available():
             raise RuntimeError("tdeed_amd.ForwardEngine needs an MI355X (no CPU path)")
         _lib.load()
@@ -462,10 +471,11 @@ class ForwardEngine:
         self.device = device
         self.use_graph = use_graph
         self.fuse_front = fuse_front
+        self.n_split = int(os.environ.get("TDEED_SPLIT", n_split))
         self._plans = {}
 
     # ------------------------------------------------------------------ plan construction
-    def _build(self, B, H, W, flip, taps):
+    def _build(self, B, H, W, flip, taps, head_out=None):
         pw, Wt = self.pw, self.pw.W
         T = pw.clip_len
         N = B * T
@@ -499,8 +509,7 @@ class ForwardEngine:
                 frames, Wt.front, crop, flip, y2=y2, shortcut=sc, pooled=pooled),
                               N * 3 * ch * cw + 2 * M2 * blk.cout * es,
                               2 * N * Ho * Wo * 32 * (27 + 2 * blk.cout) // 1 + 2 * M2 * blk.cout * blk.gw * 9))
-            steps.append(Step(blk.name + ".se", "se_gate", lambda bw=bw, pooled=pooled, gate=gate, ic=1.0 / (h2 * w2): ops.se_gate(
-                pooled, ic, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate),
+            steps.append(Step(blk.name + ".se", "se_gate", lambda bw=bw, pooled=pooled, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
                 2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
             steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda bw=bw, y2=y2, sc=sc, gate=gate, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
                 y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
@@ -590,8 +599,7 @@ class ForwardEngine:
             steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
                 y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
                 (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
-            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): ops.se_gate(
-                pooled, ic, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate),
+            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
                 2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
             if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
@@ -627,37 +635,85 @@ class ForwardEngine:
         sb = SgpBuilder(pool, steps, keep, taps, B, dt)
         cur = sb.pyramid(feat, T, pw.n_layers, Wt.sgp, Wt.mixer)
         keep["sgp_out"] = cur
-        head_out = torch.empty((N, pw.n_out), dtype=torch.float32, device=dev)
+        if head_out is None:
+            head_out = torch.empty((N, pw.n_out), dtype=torch.float32, device=dev)
         steps.append(Step("heads", "heads", lambda cur=cur: ops.heads(cur, Wt.head_w, Wt.head_b, out=head_out),
                           N * C * es + N * pw.n_out * 4, 2 * N * C * pw.n_out))
-        return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=head_out, graph=None,
+        return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=head_out,
                                pool_bytes=pool.total_bytes(), B=B, T=T)
 
     def plan(self, B, H, W, flip=False, taps=()):
+        """Launch plan for a batch geometry.  With n_split > 1 (and no taps) the batch is cut into n_split
+        sub-batches of whole clips, each with its own buffers and its own HIP stream: two half-batch
+        pipelines in flight keep the CUs busy while the other one sits in a latency-bound small launch."""
         key = (B, H, W, bool(flip), tuple(sorted(taps)))
-        if key not in self._plans:
-            self._plans[key] = self._build(B, H, W, bool(flip), set(taps))
-        return self._plans[key]
+        if key in self._plans:
+            return self._plans[key]
+        ns = self.n_split if (not taps and self.n_split > 1 and B % self.n_split == 0 and B >= self.n_split) else 1
+        if ns == 1:
+            sub = self._build(B, H, W, bool(flip), set(taps))
+            plan = SimpleNamespace(subs=[sub], streams=[None], head_out=sub.head_out, keep=sub.keep, graph=None,
+                                   steps=sub.steps, pool_bytes=sub.pool_bytes, B=B, T=sub.T)
+        else:
+            Bs = B // ns
+            T = self.pw.clip_len
+            head_out = torch.empty((B * T, self.pw.n_out), dtype=torch.float32, device=self.device)
+            subs = [self._build(Bs, H, W, bool(flip), set(), head_out=head_out[i * Bs * T:(i + 1) * Bs * T])
+                    for i in range(ns)]
+            plan = SimpleNamespace(subs=subs, streams=[None] + [torch.cuda.Stream(device=self.device) for _ in range(ns - 1)],
+                                   head_out=head_out, keep=subs[0].keep, graph=None,
+                                   steps=[st for sb in subs for st in sb.steps],
+                                   pool_bytes=sum(sb.pool_bytes for sb in subs), B=B, T=T)
+        self._plans[key] = plan
+        return plan
+
+    def set_frames(self, plan, frames_u8):
+        """Copy a (B,T,3,H,W) uint8 batch into the plan's input buffers (one per sub-batch)."""
+        B, T = frames_u8.shape[:2]
+        Bs = B // len(plan.subs)
+        for i, sb in enumerate(plan.subs):
+            sb.frames.copy_(frames_u8[i * Bs:(i + 1) * Bs].reshape(Bs * T, *frames_u8.shape[2:]), non_blocking=True)
 
     # ------------------------------------------------------------------ execution
-    def run_plan(self, plan):
-        """Launch the plan on the current stream (eager) or replay its HIP graph."""
-        if not self.use_graph:
-            for s_ in plan.steps:
+    def _launch_all(self, plan, main):
+        """Issue every sub-batch's launches: sub-batch 0 on `main`, the others forked onto their own streams."""
+        if len(plan.subs) == 1:
+            for s_ in plan.subs[0].steps:
                 s_.fn()
             return
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for sb, st in zip(plan.subs, plan.streams):
+            if st is None:
+                for s_ in sb.steps:
+                    s_.fn()
+            else:
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    for s_ in sb.steps:
+                        s_.fn()
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    joins.append(ev)
+        for ev in joins:
+            main.wait_event(ev)
+
+    def run_plan(self, plan):
+        """Launch the plan on the current stream (eager) or replay its HIP graph."""
         st = torch.cuda.current_stream()
+        if not self.use_graph:
+            self._launch_all(plan, st)
+            return
         if st.cuda_stream == 0:
             raise RuntimeError("graph replay needs a non-default stream: wrap the call in torch.cuda.stream(s)")
         if plan.graph is None:
-            for s_ in plan.steps:          # warm-up launch (module load, validates arguments)
-                s_.fn()
+            self._launch_all(plan, st)         # warm-up launch (module load, validates arguments)
             st.synchronize()
             import ctypes
             _lib.call("tdeed_graph_begin", st.cuda_stream)
             try:
-                for s_ in plan.steps:
-                    s_.fn()
+                self._launch_all(plan, st)     # forked streams join the capture through the fork event
             finally:
                 h = ctypes.c_void_p()
                 _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
@@ -672,7 +728,7 @@ class ForwardEngine:
         if T != self.pw.clip_len:
             raise ValueError(f"clip length {T} != clip_len {self.pw.clip_len} (gate-shift needs exact clips)")
         plan = self.plan(B, H, W, augment_inference, taps)
-        plan.frames.copy_(frames_u8.reshape(B * T, Cc, H, W), non_blocking=True)
+        self.set_frames(plan, frames_u8)
         self.run_plan(plan)
         return plan.head_out, plan
 

@@ -115,6 +115,16 @@ def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None,
     return out
 
 
+def se_gate_bf16(pooled, inv_cnt, w1p, b1, w2p, b2, R, out=None):
+    """SE excitation with bf16 packed weights (engine.pack_se_bf16): pooled (N,parts,C) sums -> gate (N,C)."""
+    N, parts, C = pooled.shape
+    if out is None:
+        out = torch.empty((N, C), dtype=torch.float32, device=pooled.device)
+    call("tdeed_se_gate_bf16_fwd", ptr(pooled), parts, float(inv_cnt), N, C, R, ptr(w1p), ptr(b1), ptr(w2p), ptr(b2),
+         ptr(out), stream_ptr())
+    return out
+
+
 def gconv3x3_parts(Hi, Wi, C, stride, act_dtype):
     return _lib.load().tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype_code(act_dtype))
 

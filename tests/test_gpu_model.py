@@ -12,9 +12,9 @@ DEV = "cuda"
 LOGIT_TOL_F32 = 1e-3      # BASELINE.json north_star: per-frame logits within 1e-3 in fp32
 
 
-def _engine(cfg, sd, dtype, use_graph=True):
+def _engine(cfg, sd, dtype, use_graph=True, n_split=1):
     from tdeed_amd.engine import ForwardEngine
-    return ForwardEngine(cfg, sd, dtype, DEV, use_graph=use_graph)
+    return ForwardEngine(cfg, sd, dtype, DEV, use_graph=use_graph, n_split=n_split)
 
 
 def _run(eng, clip, flip=False, taps=()):
@@ -118,6 +118,13 @@ def test_graph_replay_equals_eager_and_is_deterministic():
     h3, _ = _run(eng, clip2)
     assert torch.equal(h1, h_eager) and torch.equal(h1, h2)
     assert not torch.equal(h1, h3)
+    # the default engine cuts the batch into two sub-batches on forked streams inside one graph: same bits
+    eng2 = _engine(cfg, sd, torch.bfloat16, use_graph=True, n_split=2)
+    s1, plan2 = _run(eng2, clip)
+    s2, _ = _run(eng2, clip)
+    assert len(plan2.subs) == 2 and torch.equal(s1, h1) and torch.equal(s2, h1)
+    e2, _ = _run(_engine(cfg, sd, torch.bfloat16, use_graph=False, n_split=2), clip)
+    assert torch.equal(e2, h1)
 
 
 def test_model_api_predict_and_epoch():

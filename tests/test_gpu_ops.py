@@ -195,6 +195,18 @@ def test_se_gate(ops):
     assert rel_err(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,C,R", [(11, 152, 38), (800, 368, 92), (5, 24, 8), (7, 768, 192), (9, 56, 6)])
+def test_se_gate_bf16(ops, N, C, R):
+    from tdeed_amd.engine import pack_se_bf16
+    p = rnd(46, "p", (N, 3, C)).abs()
+    w1, b1 = rnd(47, "w1", (R, C), 0.1).to(torch.bfloat16).float(), rnd(48, "b1", (R,), 0.1)
+    w2, b2 = rnd(49, "w2", (C, R), 0.2).to(torch.bfloat16).float(), rnd(50, "b2", (C,), 0.1)
+    ref = torch.sigmoid(torch.relu((p.sum(1) / 5.0) @ w1.T + b1) @ w2.T + b2)
+    pk = pack_se_bf16(w1.numpy(), w2.numpy(), DEV)
+    out = ops.se_gate_bf16(p.to(DEV), 1.0 / 5.0, pk["se_w1p"], b1.to(DEV), pk["se_w2p"], b2.to(DEV), R)
+    assert rel_err(out, ref) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_avgpool_posenc(ops, dtype):
     B, T, hw, C = 2, 5, 49, 368

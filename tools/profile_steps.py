@@ -16,7 +16,7 @@ st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     eng = ForwardEngine(cfg, sd, dt, "cuda", use_graph=False)
     plan = eng.plan(B, H, W)
-    plan.frames.copy_(ops.fill_u8_hash((B * cfg["clip_len"], 3, H, W), 1000, "cuda"))
+    eng.set_frames(plan, ops.fill_u8_hash((B, cfg["clip_len"], 3, H, W), 1000, "cuda"))
     reps = 5
     acc = [0.0] * len(plan.steps)
     for r in range(reps + 1):
