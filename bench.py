@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import tdeed_amd  # noqa: E402,F401
-from tdeed_amd import synth, state_layout, ops  # noqa: E402
+from tdeed_amd import synth, state_layout, ops, dist as tdist  # noqa: E402
 from tdeed_amd.engine import ForwardEngine  # noqa: E402
 
 CONFIGS = {
@@ -99,17 +99,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+    rank, local, world = tdist.env_world()
+    torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    tdist.init(backend="nccl", device=torch.device("cuda", local))       # RCCL; no-op for a single process
     wl = CONFIGS[a.workload]
     cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -124,20 +117,15 @@ def main():
         for _ in range(max(a.warmup, 1)):
             eng.run_plan(plan)
         stream.synchronize()
-        if world > 1:
-            dist.barrier()
+        tdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             eng.run_plan(plan)
         stream.synchronize()
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dist.barrier()
-            el = float(tt.item())
+        el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+        tdist.barrier()
         prof = kernel_profile(eng, plan) if rank == 0 else None
 
     if rank == 0:
@@ -156,6 +144,16 @@ def main():
                     frac=round((tfs / MFMA_PEAK_TF[dt]) if mfma_bound else (gbs / HBM_PEAK_GBS), 4), traffic=None,
                     launches_per_step=d["launches"], ms_per_step=round(d["ms"], 4),
                     share_of_step=round(d["ms"] / sum(x["ms"] for x in prof.values()), 3))
+        # HBM bytes per launch of that kernel family from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+        # separately on this same command, corrected as MI355X_MICROARCH.md prescribes; tools/summarize_pmc.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                tr = json.load(fh)["kernels"].get(name)
+            if tr is not None and a.workload == "rny002_b8" and a.dtype == "bf16":
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(d["launches"], 1))
+        except (OSError, KeyError, ValueError):
+            pass
         sgp_steps = [s for s in plan.steps if s.name.startswith("_temp_fine.")]
         kernels = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
                            GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0,
@@ -175,6 +173,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -137,7 +137,9 @@ int tdeed_se_gate_bf16_fwd(const float* pooled, int n_parts, float inv_cnt, int 
  *          i.e. shift(y)+r), channels [F,Fp) copied from x (Fp = F rounded up to 8). */
 int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
                        const float* bn_scale, const float* bn_shift,
-                       const float* wq /*[27][F] tap-major conv3D weight*/, const float* b3d /*[2]*/,
+                       const float* wq /*[27][F] tap-major conv3D weight (VALU path)*/,
+                       const void* wqf /*bf16 MFMA fragments, engine.pack_gsf_q_frags; NULL => VALU*/,
+                       const float* b3d /*[2]*/,
                        float* Q /*scratch fp32 [B*T][h][w][6]*/, float* gate, float* ysum, float* xsum,
                        int dtype, void* stream);
 int tdeed_gsf_weight_fwd(const float* ysum, const float* xsum, int B, int T, int F, int hw,

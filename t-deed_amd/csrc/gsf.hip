@@ -119,6 +119,100 @@ __global__ __launch_bounds__(256) void gsf_q_kernel(const T* __restrict__ x, int
   }
 }
 
+// ---- launch 1a, bf16 throughput mode: the same partial sums as an implicit GEMM on the MFMA pipe.
+// D[jg][pixel] = sum_k Wt[jg][k] A[k][pixel], jg = (temporal tap j, gate g) = 6 of the 16 MFMA rows,
+// k = (spatial tap, 8-channel chunk): a lane's 8 k-values are one 16-byte read of the BN+ReLU'd frame
+// (bf16, zero halo, pixel stride an odd number of 16-byte slots => conflict-free ds_read_b128).
+// wqf: [KS][64] fragments (engine.pack_gsf_q_frags), rows jg >= 6 and channels of the other gate group are 0.
+__global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restrict__ x, int h, int w, int C, int F,
+                                                         int band, int nch, int PSQ, int KS,
+                                                         const float* __restrict__ bn_scale,
+                                                         const float* __restrict__ bn_shift,
+                                                         const bf16x8* __restrict__ wqf, float* __restrict__ Q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smq[];
+  const int f = blockIdx.x;
+  const int y0 = blockIdx.y * band;
+  const int y1 = min(h, y0 + band);
+  const int rows = y1 - y0 + 2, WP = w + 2;
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
+  unsigned char* a = smq + (size_t)KS * 64 * 16;               // [rows][WP][PSQ]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < KS * 64; i += 256) wl[i] = wqf[i];
+  // stage: relu(bn(x)) as bf16, 8-channel chunks; halo ring, channels >= F and the stride pad are zero
+  const int cpp = PSQ >> 4;                                     // 16-byte pieces per pixel incl. pad
+  const int total = rows * WP * cpp;
+  for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+    u32x4 v[4];
+    int meta[4];
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) {
+      const int i = i0 + b4 * 256;
+      meta[b4] = -1;
+      v[b4] = (u32x4){0u, 0u, 0u, 0u};
+      if (i < total) {
+        const int j = i % cpp, pix = i / cpp;
+        const int ry = pix / WP, rx = pix - ry * WP;
+        const int yy = y0 - 1 + ry, xx = rx - 1;
+        meta[b4] = -2 - j;                                      // zero piece
+        if (j < nch && yy >= 0 && yy < h && xx >= 0 && xx < w) {
+          const bf16_t* src = x + ((long)f * h * w + (long)yy * w + xx) * C + j * 8;
+          if (j * 8 + 8 <= F) {
+            v[b4] = *reinterpret_cast<const u32x4*>(src);
+          } else {                                              // last chunk of a fold that is not a multiple of 8
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(src);
+            v[b4] = (u32x4){lo[0], lo[1], 0u, 0u};
+          }
+          meta[b4] = j;
+        }
+      }
+    }
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) {
+      const int i = i0 + b4 * 256;
+      if (i >= total) continue;
+      u32x4 o = {0u, 0u, 0u, 0u};
+      if (meta[b4] >= 0) {
+        const int c0 = meta[b4] * 8;
+        float fv[8];
+        Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v[b4]), fv);
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c0 + e;
+          r[e] = (c < F) ? (bf16_t)fmaxf(fmaf(fv[e], bn_scale[c], bn_shift[c]), 0.f) : (bf16_t)0.f;
+        }
+        o = *reinterpret_cast<u32x4*>(&r);
+      }
+      *reinterpret_cast<u32x4*>(a + (long)i * 16) = o;
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  const int npix = (y1 - y0) * w;
+  const int ntl = (npix + 15) >> 4;
+  for (int mt = wv; mt < ntl; mt += 4) {
+    const int p = mt * 16 + pl;
+    const bool pok = p < npix;
+    const int pc = pok ? p : 0;
+    const int py = pc / w, px = pc - py * w;
+    const unsigned char* base = a + ((long)py * WP + px) * PSQ;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) {
+      const int s_ = 4 * ks + q;
+      const int tap = s_ / nch, ck = s_ - tap * nch;
+      const bool sok = tap < 9;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + (sok ? ((dy * WP + dx) * PSQ + ck * 16) : 0));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks * 64 + lane], af, acc, 0, 0, 0);
+    }
+    if (pok) {
+      float* dst = Q + ((long)f * h * w + (long)(y0 + py) * w + px) * 6;
+      if (q == 0) { dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3]; }
+      else if (q == 1) { dst[4] = acc[0]; dst[5] = acc[1]; }
+    }
+  }
+}
+
 // ---- launch 1b: gate = tanh(b + Q[t-1][0] + Q[t][1] + Q[t+1][2]) and the spatial sums of gate*x and x
 template <typename T>
 __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict__ x, const float* __restrict__ Q,
@@ -178,10 +272,10 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
 }
 
 extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
-                                  const float* bn_scale, const float* bn_shift, const float* wq,
+                                  const float* bn_scale, const float* bn_shift, const float* wq, const void* wqf,
                                   const float* b3d, float* Q, float* gate, float* ysum, float* xsum, int dtype,
                                   void* stream) {
-  TD_CHECK(x && bn_scale && bn_shift && wq && b3d && Q && gate && ysum && xsum, "gsf_gate: null pointer");
+  TD_CHECK(x && bn_scale && bn_shift && (wq || wqf) && b3d && Q && gate && ysum && xsum, "gsf_gate: null pointer");
   TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && F > 0 && F % 4 == 0 && F <= C && F <= 256,
            "gsf_gate: bad sizes B=%d T=%d h=%d w=%d C=%d F=%d", B, T, h, w, C, F);
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_gate: bad dtype %d", dtype);
@@ -198,7 +292,28 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
   size_t smem2 = (size_t)(2 * hw + 2 * S * F) * sizeof(float);
   TD_CHECK(smem2 <= 64 * 1024, "gsf_gate: frame too large for the gate/sum pass (%d px)", hw);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32) {
+  bool mfma_done = false;
+  if (dtype == TDEED_BF16 && wqf) {
+    const int nch = (F + 7) / 8;
+    int ps16 = nch + 1;
+    if ((ps16 & 1) == 0) ++ps16;
+    const int PSQ = ps16 * 16, KSq = (9 * nch + 3) / 4;
+    const long wbytes = (long)KSq * 64 * 16;
+    int bq = (int)((60 * 1024 - wbytes) / ((long)(w + 2) * PSQ)) - 2;
+    if (bq >= 1) {
+      if (bq > h) bq = h;
+      const int nbq = cdiv(h, bq);
+      const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ;
+      hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(B * T, nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
+                         nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q);
+      mfma_done = true;
+    }
+  }
+  if (!mfma_done) TD_CHECK(wq, "gsf_gate: fp32 tap weights needed for the VALU path");
+  if (mfma_done) {
+    hipLaunchKernelGGL(gsf_gate_sums_kernel<bf16_t>, dim3(B * T), dim3(256), smem2, st, (const bf16_t*)x, Q, T, hw,
+                       C, F, b3d, gate, ysum, xsum);
+  } else if (dtype == TDEED_F32) {
     hipLaunchKernelGGL(gsf_q_kernel<float>, dim3(B * T, nb), dim3(256), smem1, st, (const float*)x, h, w, C, F, band,
                        bn_scale, bn_shift, wq, Q);
     hipLaunchKernelGGL(gsf_gate_sums_kernel<float>, dim3(B * T), dim3(256), smem2, st, (const float*)x, Q, T, hw, C,

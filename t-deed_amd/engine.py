@@ -186,6 +186,32 @@ def pack_front_weights(stem_w, stem_sc, stem_sh, w1, sc1, sh1, wd, scd, shd, w2,
                            w2f=pack_gconv_frags(w2, gw, device), sc2=f32(sc2), sh2=f32(sh2))
 
 
+def pack_gsf_q_frags(w3d, device):
+    """conv3D.weight [2][F/2][3][3][3] -> bf16 MFMA A fragments [KS][64][8] for gsf_q_mfma_kernel:
+    row n = jg = 2*j_t + g (rows 6..15 zero); k-slot s = 4ks+q = tap*nch + chunk, element e = channel 8*chunk+e,
+    non-zero only for channels of gate group g."""
+    w3d = _np(w3d).astype(np.float32)
+    Fh = w3d.shape[1]
+    F = 2 * Fh
+    nch = (F + 7) // 8
+    KS = (9 * nch + 3) // 4
+    fr = np.zeros((KS, 64, 8), np.float32)
+    for ks in range(KS):
+        for q in range(4):
+            s_ = 4 * ks + q
+            tap, ck = divmod(s_, nch)
+            if tap >= 9:
+                continue
+            dy, dx = divmod(tap, 3)
+            for n in range(6):
+                jt, g = divmod(n, 2)
+                for e in range(8):
+                    c = ck * 8 + e
+                    if c < F and c // Fh == g:
+                        fr[ks, q * 16 + n, e] = w3d[g, c - g * Fh, jt, dy, dx]
+    return torch.from_numpy(fr).to(device).to(torch.bfloat16).contiguous()
+
+
 def pack_gconv_frags(w, gw, device):
     """Conv2d.weight [C][gw][3][3] -> bf16 MFMA A-operand fragments [ceil4(C/16)][5][64][8] for
     gconv3x3_mfma_kernel: unit u = output channels [16u,16u+16); lane l holds Wt[n=l&15][k=8(l>>4)+j];
@@ -419,6 +445,7 @@ class PackedWeights:
                 w3d = sd[gp + ".conv3D.weight"]                       # [2][F/2][3][3][3]
                 bw.gs_wq = f32(w3d.reshape(F, 27).T)                  # [27][F], c = g*F/2 + cl
                 bw.gs_b3d = f32(sd[gp + ".conv3D.bias"])
+                bw.gs_wqf = pack_gsf_q_frags(w3d, device) if (act_dtype == torch.bfloat16 and str(device) != "cpu") else None
                 if self.mode == "gsf":
                     bw.gs_cw1 = f32(sd[gp + ".channel_conv1.weight"].reshape(18))
                     bw.gs_cb1 = f32(sd[gp + ".channel_conv1.bias"])
@@ -547,7 +574,7 @@ class ForwardEngine:
                         gb["fw"] = pool.take((B, F, T), torch.float32)
                     steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                         x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                        bw.gs_cw2, bw.gs_cb2, bufs=gb), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                        bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                     G = gb["out"]
                     gs_bufs = list(gb.values())
                 out = pool.take((N, h, w, blk.cout), dt)
@@ -578,7 +605,7 @@ class ForwardEngine:
                     gb["fw"] = pool.take((B, F, T), torch.float32)
                 steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                    bw.gs_cw2, bw.gs_cb2, bufs=gb), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                 steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                     x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
                     *gemm_cost(M, blk.cin, blk.cout, es)))

@@ -310,6 +310,9 @@ def test_gate_shift_golden(ops, name, dtype):
         kw = dict(cw1=dev(sd["gs.channel_conv1.weight"].reshape(18)), cb1=dev(sd["gs.channel_conv1.bias"]),
                   cw2=dev(sd["gs.channel_conv2.weight"].reshape(18)), cb2=dev(sd["gs.channel_conv2.bias"]))
     Fp = (Fd + 7) // 8 * 8
+    if dtype == torch.bfloat16:
+        from tdeed_amd.engine import pack_gsf_q_frags
+        kw["wqf"] = pack_gsf_q_frags(sd["gs.conv3D.weight"], DEV)       # MFMA partial-sum kernel
     out = ops.gate_shift(t(xin).to(dtype).to(DEV), B, T, Fd, Fp, dev(s), dev(sh),
                          dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T), dev(sd["gs.conv3D.bias"]), **kw)
     out = out.float().cpu().view(B * T, h, w, Fp)
