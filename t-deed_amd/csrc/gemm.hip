@@ -64,8 +64,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int nb = (p.N + BN - 1) / BN;
-  const int tile_n = blockIdx.x % nb;
-  const long tile_m = blockIdx.x / nb;
+  // XCD-aware tile order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so
+  // logical tiles are renumbered such that consecutive ones (the N tiles of one M tile, which re-read the same
+  // A rows) share an XCD and therefore its L2, instead of fetching A from HBM / Infinity Cache once per XCD.
+  long lid;
+  {
+    const long nwg = gridDim.x, bid = blockIdx.x;
+    const long qx = nwg / 8, rx = nwg % 8, xcd = bid % 8;
+    lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + bid / 8;
+  }
+  const int tile_n = (int)(lid % nb);
+  const long tile_m = lid / nb;
   const long m0 = tile_m * 128;
   const int n0 = tile_n * BN;
 
