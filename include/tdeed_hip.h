@@ -149,6 +149,11 @@ int tdeed_gsf_apply_fwd(const void* x, const float* gate, const float* fw /*NULL
                         int T, int h, int w, int C, int F, int Fp, void* out, int dtype,
                         void* stream);
 
+/* weight + apply in one launch (GSF): every frame's block evaluates its own fusion weights from ysum/xsum first. */
+int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
+                              const float* cw1, const float* cb1, const float* cw2, const float* cb2, int B,
+                              int T, int h, int w, int C, int F, int Fp, void* out, int dtype, void* stream);
+
 /* ---- global average pool + positional encoding (model.py:133-137) --------------------------
  * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]). */
 int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,

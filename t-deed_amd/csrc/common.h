@@ -107,4 +107,12 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// XCD-aware workgroup renumbering (bijective): hardware deals workgroups round-robin over the 8 XCDs; this maps
+// blockIdx -> logical id so that consecutive logical ids sit on ONE XCD (one L2) and run close in time.  Used
+// wherever neighbouring work items re-read the same bytes (GEMM N tiles, conv halo rows).  Speed only.
+__device__ __forceinline__ long xcd_logical_id(long bid, long nwg) {
+  const long qx = nwg / 8, rx = nwg % 8, xcd = bid % 8;
+  return (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + bid / 8;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

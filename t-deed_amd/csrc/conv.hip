@@ -233,7 +233,11 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
                                                             int rows_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   __shared__ float red[4][16];
-  const int bnd = blockIdx.x, slab = blockIdx.y, n = blockIdx.z;
+  // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int nslabs_ = (C + CSP - 1) / CSP;
+  const int slab = (int)(lid % nslabs_);
+  const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
   const int cs0 = slab * CSP;
   const int oy0 = bnd * band;
   const int nrows_out = min(band, Ho - oy0);
@@ -371,7 +375,7 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
                      : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
     }
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-    dim3 grid(g.nbands, g.nslabs, N);
+    dim3 grid((unsigned)((long)g.nbands * g.nslabs * N));
     size_t smem = (size_t)g.rows_in * (Wi + 2) * g.PS;
     if (stride == 1)
       hipLaunchKernelGGL(gconv3x3_mfma_kernel<1>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,

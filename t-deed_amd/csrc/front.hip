@@ -31,7 +31,9 @@ template <int NT1>
 __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[4][16];
-  const int bnd = blockIdx.x, n = blockIdx.y;
+  // bands of one frame share halo rows: keep them on one XCD (one L2)
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int bnd = (int)(lid % p.nbands), n = (int)(lid / p.nbands);
   const int oy0 = bnd * p.band;
   const int nrows_out = min(p.band, p.Ho - oy0);
   const int y1r0 = 2 * oy0 - 1;                         // first conv1-map row held (may be -1)
@@ -292,11 +294,20 @@ static int front_band(int cw, int Ws, int PS, int Ho) {
   return best;
 }
 
+static size_t front_smem(int crop_w, int Ws, int PS, int band) {
+  const int ny1 = 2 * (band - 1) + 3, nin = 2 * (ny1 - 1) + 3;
+  return (((size_t)nin * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)ny1 * (Ws + 2) * PS;
+}
+
+// number of partial-sum rows of `pooled` per frame, or 0 when even a one-row band does not fit LDS
+// (very wide frames): the caller then uses the unfused stem / conv1 / conv2 / downsample kernels.
 extern "C" int tdeed_s1_front_parts(int crop_h, int crop_w, int C1) {
   const int Hs = (crop_h + 1) / 2, Ws = (crop_w + 1) / 2, Ho = (Hs + 1) / 2;
+  if (C1 % 8 != 0 || C1 < 8 || C1 > 64) return 0;
   const int CSP = C1 > 32 ? 64 : (C1 > 16 ? 32 : 16);
   const int band = front_band(crop_w, Ws, CSP * 2 + 16, Ho);
-  return band > 0 ? (Ho + band - 1) / band : 0;
+  if (band <= 0 || front_smem(crop_w, Ws, CSP * 2 + 16, band) > FRONT_LDS_CAP) return 0;
+  return (Ho + band - 1) / band;
 }
 
 extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
@@ -323,7 +334,8 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
   p.Hs = (crop_h + 1) / 2; p.Ws = (crop_w + 1) / 2;
   p.Ho = (p.Hs + 1) / 2; p.Wo = (p.Ws + 1) / 2;
   p.band = front_band(crop_w, p.Ws, p.PS, p.Ho);
-  TD_CHECK(p.band > 0, "s1_front: a row band of %d px does not fit LDS", crop_w);
+  TD_CHECK(p.band > 0 && front_smem(crop_w, p.Ws, p.PS, p.band) <= FRONT_LDS_CAP,
+           "s1_front: a row band of %d px does not fit LDS (use the unfused kernels)", crop_w);
   p.nbands = (p.Ho + p.band - 1) / p.band;
   const int ny1 = 2 * (p.band - 1) + 3, nin = 2 * (ny1 - 1) + 3;
   const size_t smem = (((size_t)nin * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)ny1 * (p.Ws + 2) * p.PS;
@@ -338,9 +350,9 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
     attr_set = true;
   }
   const int nt1 = p.CSP >> 4;
-  if (nt1 == 1) hipLaunchKernelGGL(s1_front_kernel<1>, dim3(p.nbands, N), dim3(256), smem, (hipStream_t)stream, p);
-  else if (nt1 == 2) hipLaunchKernelGGL(s1_front_kernel<2>, dim3(p.nbands, N), dim3(256), smem, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(s1_front_kernel<4>, dim3(p.nbands, N), dim3(256), smem, (hipStream_t)stream, p);
+  if (nt1 == 1) hipLaunchKernelGGL(s1_front_kernel<1>, dim3(p.nbands * N), dim3(256), smem, (hipStream_t)stream, p);
+  else if (nt1 == 2) hipLaunchKernelGGL(s1_front_kernel<2>, dim3(p.nbands * N), dim3(256), smem, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(s1_front_kernel<4>, dim3(p.nbands * N), dim3(256), smem, (hipStream_t)stream, p);
   TD_LAUNCH_CHECK("s1_front");
   return TDEED_OK;
 }

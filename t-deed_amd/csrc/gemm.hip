@@ -67,12 +67,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   // XCD-aware tile order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so
   // logical tiles are renumbered such that consecutive ones (the N tiles of one M tile, which re-read the same
   // A rows) share an XCD and therefore its L2, instead of fetching A from HBM / Infinity Cache once per XCD.
-  long lid;
-  {
-    const long nwg = gridDim.x, bid = blockIdx.x;
-    const long qx = nwg / 8, rx = nwg % 8, xcd = bid % 8;
-    lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + bid / 8;
-  }
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
   const int tile_n = (int)(lid % nb);
   const long tile_m = lid / nb;
   const long m0 = tile_m * 128;

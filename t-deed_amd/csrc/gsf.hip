@@ -431,6 +431,106 @@ __global__ __launch_bounds__(256) void gsf_apply_kernel(const T* __restrict__ x,
   }
 }
 
+// frame-per-block variant that also evaluates the fusion weights of its frame (the (channel,time)-plane
+// conv of launch 2) in its prologue: one launch less per site, no fw round trip through memory.
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_apply_fused_kernel(const T* __restrict__ x, const float* __restrict__ gate,
+                                                              const float* __restrict__ ysum,
+                                                              const float* __restrict__ xsum, float inv_hw,
+                                                              const float* __restrict__ cw1,
+                                                              const float* __restrict__ cb1,
+                                                              const float* __restrict__ cw2,
+                                                              const float* __restrict__ cb2, int T_len, int hw,
+                                                              int C, int F, int Fp, T* __restrict__ out) {
+  extern __shared__ float fwl[];                  // [F] fusion weight of this frame, indexed by source channel
+  const long f = blockIdx.x;
+  const int t = (int)(f % T_len);
+  const long b = f / T_len;
+  const int Fh = F >> 1, Fq = F >> 2;
+  for (int c = threadIdx.x; c < F; c += 256) {
+    const int g = c >= Fh;
+    const int cl = c - g * Fh;
+    const float* cw = g ? cw2 : cw1;
+    float a = g ? cb2[0] : cb1[0];
+#pragma unroll
+    for (int dc = -1; dc <= 1; ++dc) {
+      const int c2 = cl + dc;
+      if (c2 < 0 || c2 >= Fh) continue;
+      const int cc = g * Fh + c2;
+#pragma unroll
+      for (int dt = -1; dt <= 1; ++dt) {
+        const int t2 = t + dt;
+        if (t2 < 0 || t2 >= T_len) continue;
+        const long row = (b * T_len + t2) * F + cc;
+        const float rm = (xsum[row] - ysum[row]) * inv_hw;
+        const int ts = g ? t2 - 1 : t2 + 1;
+        const float ysh = (ts >= 0 && ts < T_len) ? ysum[(b * T_len + ts) * F + cc] * inv_hw : 0.f;
+        a = fmaf(cw[(dc + 1) * 3 + (dt + 1)], ysh, a);
+        a = fmaf(cw[9 + (dc + 1) * 3 + (dt + 1)], rm, a);
+      }
+    }
+    fwl[c] = sigmoidf_(a);
+  }
+  __syncthreads();
+  const int qpr = Fp >> 2;
+  for (int idx = threadIdx.x; idx < hw * qpr; idx += 256) {
+    const int q = idx % qpr;
+    const long pix = f * hw + idx / qpr;
+    const T* xp = x + pix * C;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = q * 4 + e;
+      if (co >= F) { o[e] = (float)xp[co]; continue; }
+      const int g = co >= Fh;
+      const int col = co - g * Fh;
+      const int j = col >> 1, i = col & 1;
+      const int ci = g * Fh + i * Fq + j;
+      const float gt = gate[pix * 2 + g];
+      const float xv = (float)xp[ci];
+      const float r = xv - gt * xv;
+      const int ts = g ? t - 1 : t + 1;
+      float ysh = 0.f;
+      if (ts >= 0 && ts < T_len) {
+        const long pix2 = pix + (long)(ts - t) * hw;
+        ysh = gate[pix2 * 2 + g] * (float)x[pix2 * C + ci];
+      }
+      const float wv = fwl[ci];
+      o[e] = ysh * wv + r * (1.0f - wv);
+    }
+    T* dst = out + pix * Fp + q * 4;
+    if constexpr (sizeof(T) == 4) {
+      Chunk<float>::store(reinterpret_cast<float*>(dst), o);
+    } else {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)o[e];
+      *reinterpret_cast<bf16x4*>(dst) = v;
+    }
+  }
+}
+
+extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
+                                         const float* cw1, const float* cb1, const float* cw2, const float* cb2,
+                                         int B, int T, int h, int w, int C, int F, int Fp, void* out, int dtype,
+                                         void* stream) {
+  TD_CHECK(x && gate && ysum && xsum && cw1 && cb1 && cw2 && cb2 && out, "gsf_apply_fused: null pointer");
+  TD_CHECK(F % 4 == 0 && Fp % 8 == 0 && Fp >= F && Fp <= C, "gsf_apply_fused: bad fold F=%d Fp=%d C=%d", F, Fp, C);
+  TD_CHECK(B > 0 && T > 0 && (long)B * T <= 0x7fffffffL, "gsf_apply_fused: bad sizes");
+  const int hw = h * w;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t smem = (size_t)F * sizeof(float);
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(gsf_apply_fused_kernel<float>, dim3(B * T), dim3(256), smem, st, (const float*)x, gate, ysum,
+                       xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (float*)out);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(gsf_apply_fused_kernel<bf16_t>, dim3(B * T), dim3(256), smem, st, (const bf16_t*)x, gate, ysum,
+                       xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (bf16_t*)out);
+  else { tdeed_set_error("gsf_apply_fused: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("gsf_apply_fused");
+  return TDEED_OK;
+}
+
 extern "C" int tdeed_gsf_apply_fwd(const void* x, const float* gate, const float* fw, int B, int T, int h, int w,
                                    int C, int F, int Fp, void* out, int dtype, void* stream) {
   TD_CHECK(x && gate && out, "gsf_apply: null pointer");

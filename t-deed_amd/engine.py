@@ -520,7 +520,8 @@ class ForwardEngine:
         Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
         es = _esz(dt)
         blocks = list(Wt.blocks)
-        fused_front = Wt.front is not None and "_features.stem" not in taps and self.fuse_front
+        fused_front = (Wt.front is not None and "_features.stem" not in taps and self.fuse_front
+                       and ops.s1_front_parts(ch, cw, Wt.blocks[0].spec.cout) > 0)
         if fused_front:
             bw = blocks.pop(0)
             blk = bw.spec

@@ -174,7 +174,7 @@ def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
 
 
 def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
-               bufs=None, wqf=None):
+               bufs=None, wqf=None, separate_weight=False):
     """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
     GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out."""
     _chk(x, "x")
@@ -199,6 +199,10 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     dc = dtype_code(x.dtype)
     call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
          ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+    if cw1 is not None and not separate_weight:
+        call("tdeed_gsf_apply_fused_fwd", ptr(x), ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
+             B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
+        return out
     fw = None
     if cw1 is not None:
         fw = bufs.get("fw")

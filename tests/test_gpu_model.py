@@ -105,6 +105,21 @@ def test_fused_bottleneck_opt_in_matches_default(monkeypatch):
     assert (base - fused).abs().max().item() < 0.08 * max(1.0, base.abs().max().item())
 
 
+def test_wide_frames_fall_back_to_unfused_front():
+    """A frame too wide for the fused front kernel's LDS band takes the unfused stem path: bf16 tracks fp32."""
+    from tdeed_amd import ops
+    cfg = dict(feature_arch="rny002_gsf", clip_len=4, crop_dim=None, n_layers=1, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    sd = model_state(cfg, 0)
+    H, W = 32, 512
+    assert ops.s1_front_parts(H, W, 24) == 0 and ops.s1_front_parts(224, 224, 24) > 0
+    clip = synth.uint8_clip(9, (2, 4, 3, H, W))
+    h32, _ = _run(_engine(cfg, sd, torch.float32), clip)
+    h16, plan = _run(_engine(cfg, sd, torch.bfloat16), clip)
+    assert plan.steps[0].kernel == "stem"
+    assert (h16 - h32).abs().max().item() < 0.08 * max(1.0, h32.abs().max().item())
+
+
 def test_graph_replay_equals_eager_and_is_deterministic():
     meta, g = load_golden("tiny_rny002_gsf")
     cfg = meta["cfg"]

@@ -315,6 +315,11 @@ def test_gate_shift_golden(ops, name, dtype):
         kw["wqf"] = pack_gsf_q_frags(sd["gs.conv3D.weight"], DEV)       # MFMA partial-sum kernel
     out = ops.gate_shift(t(xin).to(dtype).to(DEV), B, T, Fd, Fp, dev(s), dev(sh),
                          dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T), dev(sd["gs.conv3D.bias"]), **kw)
+    if mode == "gsf":      # the 3-launch form (separate fusion-weight kernel) gives the same bits as the fused apply
+        out3 = ops.gate_shift(t(xin).to(dtype).to(DEV), B, T, Fd, Fp, dev(s), dev(sh),
+                              dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T), dev(sd["gs.conv3D.bias"]),
+                              separate_weight=True, **kw)
+        assert torch.equal(out3, out)
     out = out.float().cpu().view(B * T, h, w, Fp)
     ref = t(g["y"]).permute(0, 2, 3, 1)
     tol = 2e-5 if dtype == torch.float32 else 3e-2
