@@ -492,95 +492,109 @@ __global__ __launch_bounds__(256) void se_gate_bf16_kernel(const float* __restri
   float* shid = sp + SE_FPB * C;                    // [FPB][R8]
   float* part = shid + SE_FPB * R8;                 // partial sums of either phase
   const int f0 = blockIdx.x * SE_FPB;
+  constexpr int MAXB = 20;
+  // thread roles of both phases; BOTH weight shares are requested before anything else so that the pooled
+  // sums, fc1 and fc2 weights travel in one memory round trip (the kernel is pure latency)
+  const int NJ = R8 >> 3, nsl1 = 256 / NJ;
+  const int jo = threadIdx.x % NJ, sl1 = threadIdx.x / NJ;
+  const int cper = (C + nsl1 - 1) / nsl1;
+  const int c0 = sl1 * cper, c1 = sl1 < nsl1 ? min(C, c0 + cper) : c0;
+  const int NC = C >> 3;
+  const int nsl2 = 256 / NC > 0 ? 256 / NC : 1;
+  const int co = threadIdx.x % NC, sl2 = threadIdx.x / NC;
+  const bool act2 = sl2 < nsl2 && threadIdx.x < NC * nsl2;
+  const int jper = (R + nsl2 - 1) / nsl2;
+  const int j0 = sl2 * jper, j1 = act2 ? min(R, j0 + jper) : j0;
+  bf16x8 w1r[MAXB], w2r[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i)
+    if (c0 + i < c1) w1r[i] = *reinterpret_cast<const bf16x8*>(w1p + (long)(c0 + i) * R8 + jo * 8);
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i)
+    if (j0 + i < j1) w2r[i] = *reinterpret_cast<const bf16x8*>(w2p + (long)(j0 + i) * C + co * 8);
   for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
     const int f = i / C, c = i - f * C;
     float v = 0.f;
     if (f0 + f < N) {
       const float* src = pooled + ((long)(f0 + f) * n_parts) * C + c;
+#pragma unroll 4
       for (int q = 0; q < n_parts; ++q) v += src[(long)q * C];
     }
     sp[i] = v * inv_cnt;
   }
   __syncthreads();
-  constexpr int MAXB = 12;
   {
-    const int NJ = R8 >> 3, nsl = 256 / NJ;
-    const int jo = threadIdx.x % NJ, sl = threadIdx.x / NJ;
-    if (sl < nsl) {
-      float a[SE_FPB][8];
+    float a[SE_FPB][8];
 #pragma unroll
-      for (int f = 0; f < SE_FPB; ++f)
+    for (int f = 0; f < SE_FPB; ++f)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[f][e] = 0.f;
-      const int cper = (C + nsl - 1) / nsl;
-      const int c0 = sl * cper, c1 = min(C, c0 + cper);
-      for (int cb = c0; cb < c1; cb += MAXB) {
-        bf16x8 w[MAXB];
+      for (int e = 0; e < 8; ++e) a[f][e] = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i)
-          if (cb + i < c1) w[i] = *reinterpret_cast<const bf16x8*>(w1p + (long)(cb + i) * R8 + jo * 8);
+    for (int i = 0; i < MAXB; ++i)
+      if (c0 + i < c1) {
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i)
-          if (cb + i < c1) {
+        for (int f = 0; f < SE_FPB; ++f) {
+          const float pv = sp[f * C + c0 + i];
 #pragma unroll
-            for (int f = 0; f < SE_FPB; ++f) {
-              const float pv = sp[f * C + cb + i];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) a[f][e] = fmaf(pv, (float)w[i][e], a[f][e]);
-            }
-          }
+          for (int e = 0; e < 8; ++e) a[f][e] = fmaf(pv, (float)w1r[i][e], a[f][e]);
+        }
       }
+    for (int cb = c0 + MAXB; cb < c1; ++cb) {          // shapes beyond the register batch (not hit by RegNetY-200/800MF)
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(w1p + (long)cb * R8 + jo * 8);
 #pragma unroll
       for (int f = 0; f < SE_FPB; ++f)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[(sl * SE_FPB + f) * R8 + jo * 8 + e] = a[f][e];
+        for (int e = 0; e < 8; ++e) a[f][e] = fmaf(sp[f * C + cb], (float)w[e], a[f][e]);
+    }
+    if (sl1 < nsl1) {
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(sl1 * SE_FPB + f) * R8 + jo * 8 + e] = a[f][e];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SE_FPB * R8; i += 256) {
       const int j = i % R8;
       float v = 0.f;
-      for (int s_ = 0; s_ < nsl; ++s_) v += part[s_ * SE_FPB * R8 + i];
+      for (int s_ = 0; s_ < nsl1; ++s_) v += part[s_ * SE_FPB * R8 + i];
       shid[i] = j < R ? fmaxf(v + b1[j], 0.f) : 0.f;
     }
     __syncthreads();
   }
   {
-    const int NC = C >> 3;
-    const int nsl = 256 / NC > 0 ? 256 / NC : 1;
-    for (int co = threadIdx.x % NC, sl = threadIdx.x / NC; sl < nsl && threadIdx.x < NC * nsl; sl = nsl) {
-      float a[SE_FPB][8];
+    float a[SE_FPB][8];
 #pragma unroll
-      for (int f = 0; f < SE_FPB; ++f)
+    for (int f = 0; f < SE_FPB; ++f)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[f][e] = 0.f;
-      const int jper = (R + nsl - 1) / nsl;
-      const int j0 = sl * jper, j1 = min(R, j0 + jper);
-      for (int jb = j0; jb < j1; jb += MAXB) {
-        bf16x8 w[MAXB];
+      for (int e = 0; e < 8; ++e) a[f][e] = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i)
-          if (jb + i < j1) w[i] = *reinterpret_cast<const bf16x8*>(w2p + (long)(jb + i) * C + co * 8);
+    for (int i = 0; i < MAXB; ++i)
+      if (j0 + i < j1) {
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i)
-          if (jb + i < j1) {
+        for (int f = 0; f < SE_FPB; ++f) {
+          const float hv = shid[f * R8 + j0 + i];
 #pragma unroll
-            for (int f = 0; f < SE_FPB; ++f) {
-              const float hv = shid[f * R8 + jb + i];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) a[f][e] = fmaf(hv, (float)w[i][e], a[f][e]);
-            }
-          }
+          for (int e = 0; e < 8; ++e) a[f][e] = fmaf(hv, (float)w2r[i][e], a[f][e]);
+        }
       }
+    for (int jb = j0 + MAXB; jb < j1; ++jb) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(w2p + (long)jb * C + co * 8);
 #pragma unroll
       for (int f = 0; f < SE_FPB; ++f)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[(sl * SE_FPB + f) * C + co * 8 + e] = a[f][e];
+        for (int e = 0; e < 8; ++e) a[f][e] = fmaf(shid[f * R8 + jb], (float)w[e], a[f][e]);
+    }
+    if (act2) {
+#pragma unroll
+      for (int f = 0; f < SE_FPB; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(sl2 * SE_FPB + f) * C + co * 8 + e] = a[f][e];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
       const int f = i / C, c = i - f * C;
       float v = 0.f;
-      for (int s_ = 0; s_ < nsl; ++s_) v += part[s_ * SE_FPB * C + i];
+      for (int s_ = 0; s_ < nsl2; ++s_) v += part[s_ * SE_FPB * C + i];
       if (f0 + f < N) gate[(long)(f0 + f) * C + c] = sigmoidf_(v + b2[c]);
     }
   }

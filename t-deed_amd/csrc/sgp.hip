@@ -297,21 +297,23 @@ __global__ __launch_bounds__(256) void mixer_branch_kernel(const T* __restrict__
   tile_mean(xt, T_hi, halo, red);
   const float mx = red[16 * SGP_CH + c];
   const bool cok = c0 + c < C;
-  // out1 (slab 0) / out3 (slab 2) from z ; out2 (slab 1) / out4 (slab 3) from x
-  for (int pass = 0; pass < 4; ++pass) {
-    const bool fromz = (pass & 1) == 0;
-    const float* tile = fromz ? zt : xt;
-    const float* wl = fromz ? wl1 : wl2;
-    const float* db = fromz ? db1 : db2;
-    const float mean_c = fromz ? mz : mx;
+  // one sweep per source: out1 (slab 0) and out3 (slab 2) from z, then out2 (slab 1) and out4 (slab 3) from x;
+  // each branch_eval yields both products, staged in two [T][16] tiles (res, res2) and stored as 16-byte chunks
+  float* res2 = red + 17 * SGP_CH;
+  for (int src = 0; src < 2; ++src) {
+    const float* tile = src == 0 ? zt : xt;
+    const float* wl = src == 0 ? wl1 : wl2;
+    const float* db = src == 0 ? db1 : db2;
+    const float mean_c = src == 0 ? mz : mx;
     __syncthreads();
     for (int t = tl; t < T_hi; t += 16) {
       BranchOut r = branch_eval(tile, wl, db, C, c0 + c, cok, t, c, halo, ks, up, mean_c);
-      res[t * SGP_CH + c] = pass < 2 ? r.conv_gate : r.inst;
+      res[t * SGP_CH + c] = r.conv_gate;
+      res2[t * SGP_CH + c] = r.inst;
     }
     __syncthreads();
-    const int slab = pass;   // pass 0: out1 (z), 1: out2 (x), 2: out3 (z), 3: out4 (x)
-    store_tile<T>(res, crow + (long)slab * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
+    store_tile<T>(res, crow + (long)src * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
+    store_tile<T>(res2, crow + (long)(2 + src) * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
   }
 }
 
@@ -321,8 +323,15 @@ extern "C" int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo,
   TD_CHECK(xn && dw1 && db1 && dw2 && db2 && cat, "mixer_branch: null pointer");
   TD_CHECK(B > 0 && T_hi >= T_lo && T_lo > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks,
            "mixer_branch: bad sizes");
-  size_t smem = sgp_smem(T_hi, ks, up, 2, 1);
-  TD_CHECK(smem <= 64 * 1024, "mixer_branch: T=%d too long for the LDS window", T_hi);
+  size_t smem = sgp_smem(T_hi, ks, up, 2, 2);
+  TD_CHECK(smem <= 128 * 1024, "mixer_branch: T=%d too long for the LDS window", T_hi);
+  static bool attr_set = false;
+  if (!attr_set) {        // long clips (T=250) need more than the default 64 KB of dynamic LDS
+    hipError_t e = hipFuncSetAttribute((const void*)mixer_branch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mixer_branch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) { tdeed_set_error("mixer_branch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set = true;
+  }
   dim3 grid(B, cdiv(C, SGP_CH));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
