@@ -40,6 +40,7 @@ def kernel_profile(eng, plan, reps=3):
     """Per-kernel-family device time, measured live with HIP events on the launch stream (eager replay
     of the same launches the graph holds)."""
     agg = {}
+    sgp_ms_acc = 0.0
     st = torch.cuda.current_stream()
     for r in range(reps + 1):
         for _ in range(3):            # keep the GPU busy so the host runs ahead of it: the event
@@ -58,13 +59,15 @@ def kernel_profile(eng, plan, reps=3):
         for s, a, b in evs:
             d = agg.setdefault(s.kernel, dict(ms=0.0, launches=0, bytes=0, flops=0))
             d["ms"] += a.elapsed_time(b)
+            if s.name.startswith("_temp_fine."):
+                sgp_ms_acc += a.elapsed_time(b)
             d["launches"] += 1
             d["bytes"] += s.bytes
             d["flops"] += s.flops
     for d in agg.values():
         for k in ("ms", "launches", "bytes", "flops"):
             d[k] = d[k] / reps
-    return agg
+    return agg, sgp_ms_acc / reps
 
 
 def cpu_baseline():
@@ -126,7 +129,7 @@ def main():
         torch.cuda.synchronize()
         el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
         tdist.barrier()
-        prof = kernel_profile(eng, plan) if rank == 0 else None
+        prof, sgp_stage_ms = kernel_profile(eng, plan) if rank == 0 else (None, None)
 
     if rank == 0:
         ms = el / a.steps * 1e3
@@ -155,6 +158,19 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         sgp_steps = [s for s in plan.steps if s.name.startswith("_temp_fine.")]
+        # SGP encoder-decoder against the HBM roof with the ALGORITHMIC byte count of SURVEY.md section 8d:
+        # es * [B*C*Sigma_T + W]: every block/mixer reads its inputs once and writes its output once, weights once
+        from tdeed_amd.regnet_spec import pyramid_lengths, sgp_up_size
+        n_l, Cc = cfg["n_layers"], eng.pw.spec.feat_dim
+        lens = pyramid_lengths(T, n_l)
+        sig = sum(2 * lens[i] + lens[i + 1] for i in range(n_l)) + 2 * lens[n_l] \
+            + sum((2 * lens[l] + lens[l + 1]) + 2 * lens[l] for l in range(n_l))
+        ks_, up_ = cfg["sgp_ks"], sgp_up_size(cfg["sgp_ks"], cfg["sgp_r"])
+        Wsgp = (2 * n_l + 1) * (8 * Cc * Cc + (2 * ks_ + up_ + 16) * Cc) + n_l * (14 * Cc * Cc + (4 * ks_ + 2 * up_ + 26) * Cc)
+        es_ = 2 if dt == torch.bfloat16 else 4
+        sgp_bytes = es_ * (B * Cc * sig + Wsgp)
+        # (stage time = all launches named _temp_fine.*, timed by step name: its contractions share the "gemm"
+        # family with the s4 trunk layers)
         kernels = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
                            GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0,
                            TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0)
@@ -167,7 +183,11 @@ def main():
                                         "random-init weights", clips_per_gpu=B, parallelism=f"dp{world} (clip-sharded, no collective)",
                                hip_graph=not a.no_graph),
                    roofline=roof, kernels=kernels,
-                   sgp_bytes_per_step=sum(s.bytes for s in sgp_steps),
+                   roofline_sgp=dict(bound="hbm", algorithmic_bytes=int(sgp_bytes), sigma_T=int(sig), weights=int(Wsgp),
+                                     ms=round(sgp_stage_ms, 4), achieved=round(sgp_bytes / (sgp_stage_ms * 1e-3) / 1e9, 2),
+                                     peak=HBM_PEAK_GBS, unit="GB/s",
+                                     frac=round(sgp_bytes / (sgp_stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     launches=len(sgp_steps)),
                    cpu_baseline=None)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
