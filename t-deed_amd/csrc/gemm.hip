@@ -324,7 +324,8 @@ struct GemmWsP {
   int act;
   void* C; long ldc;
   int g_stride, g_hi, g_wi, g_ho, g_wo;
-  int NT;
+  int NT;                         // n-tiles of the whole matrix
+  int NTS;                        // n-tiles per block slice (blockIdx.y selects the slice; == NT when W fits LDS)
 };
 
 // WLDS = false: the weights do not fit LDS (K = N = 368): fragments are read straight from global memory
@@ -334,20 +335,24 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
   constexpr int EPC = Chunk<T>::N;
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const size_t wbytes = WLDS ? (size_t)p.NT * KS * 64 * 16 : 0;
+  // a block owns the n-tile slice [nt0, nt0 + nts) of W (all of it when it fits LDS)
+  const int nt0 = WLDS ? blockIdx.y * p.NTS : 0;
+  const int nts = WLDS ? min(p.NTS, p.NT - nt0) : p.NT;
+  const size_t wbytes = WLDS ? (size_t)p.NTS * KS * 64 * 16 : 0;
   const frag_t* wl = WLDS ? reinterpret_cast<const frag_t*>(smem) : reinterpret_cast<const frag_t*>(p.Wf);
-  float* ssc = reinterpret_cast<float*>(smem + wbytes);               // [NT*16] scale (logical order)
-  float* ssh = ssc + p.NT * 16;
+  float* ssc = reinterpret_cast<float*>(smem + wbytes);               // [nts*16] scale (logical order)
+  float* ssh = ssc + (WLDS ? p.NTS : p.NT) * 16;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   {
     if (WLDS) {
       frag_t* wdst = reinterpret_cast<frag_t*>(smem);
-      const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf);
-      for (int i = tid; i < p.NT * KS * 64; i += 256) wdst[i] = src[i];
+      const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf) + (size_t)nt0 * KS * 64;
+      for (int i = tid; i < nts * KS * 64; i += 256) wdst[i] = src[i];
     }
-    for (int i = tid; i < p.NT * 16; i += 256) {
-      ssc[i] = (p.scale && i < p.N) ? p.scale[i] : 1.0f;
-      ssh[i] = (p.shift && i < p.N) ? p.shift[i] : 0.0f;
+    for (int i = tid; i < nts * 16; i += 256) {
+      const int n = nt0 * 16 + i;
+      ssc[i] = (p.scale && n < p.N) ? p.scale[n] : 1.0f;
+      ssh[i] = (p.shift && n < p.N) ? p.shift[n] : 0.0f;
     }
   }
   __syncthreads();
@@ -397,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
         xf[mt][ks] = *reinterpret_cast<frag_t*>(&v);
       }
     }
-    for (int tp = 0; tp < p.NT; tp += 2) {           // 32 output channels per pass
-      const int chp = tp * 16 + q * 8;
+    for (int tp = 0; tp < nts; tp += 2) {            // 32 output channels per pass (tp: tile within the slice)
+      const int chp = (nt0 + tp) * 16 + q * 8;
       u32x4 rpre[2][8 / EPC];
       if (p.R && chp < p.N) {                          // residual chunks: issued now, consumed after the MFMAs
 #pragma unroll
@@ -422,11 +427,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
           acc[1][mt] = mma<T>(w1, xf[mt][ks], acc[1][mt]);
         }
       }
-      const int ch = tp * 16 + q * 8;                 // first of this lane's 8 logical channels
+      const int ch = (nt0 + tp) * 16 + q * 8;         // first of this lane's 8 logical channels
       if (ch < p.N) {
         float sc[8], sh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = ssc[ch + e]; sh[e] = ssh[ch + e]; }
+        for (int e = 0; e < 8; ++e) { sc[e] = ssc[tp * 16 + q * 8 + e]; sh[e] = ssh[tp * 16 + q * 8 + e]; }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           if (!mok[mt]) continue;
@@ -467,33 +472,49 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
   }
 }
 
-static bool ws_ks_ok(int KS, bool lds) {
-  if (lds) return KS == 1 || KS == 2 || KS == 3 || KS == 4 || KS == 5 || KS == 6 || KS == 8 || KS == 10;
-  return KS == 5 || KS == 10 || KS == 12;       // global-weight mode: the wide s4 layers
+#define WS_LDS_CAP (96 * 1024)
+static bool ws_ks_ok(int KS) {
+  return KS == 1 || KS == 2 || KS == 3 || KS == 4 || KS == 5 || KS == 6 || KS == 8 || KS == 10 || KS == 12;
+}
+// n-tiles per block slice: everything when the whole W fits 64 KB (several blocks per CU), otherwise the widest
+// even slice that fits WS_LDS_CAP (one block per CU; the wide s4 layers)
+static int ws_slice_tiles(int NT, int KS) {
+  const size_t per_tile = (size_t)KS * 64 * 16 + 16 * 2 * sizeof(float);
+  if ((size_t)NT * per_tile <= 64 * 1024) return NT;
+  int nts = (int)(WS_LDS_CAP / per_tile) & ~1;
+  if (nts > NT) nts = NT;
+  return nts;
 }
 
 template <typename T>
-static int launch_gemm_ws(const GemmWsP& p, hipStream_t st) {
+static int launch_gemm_ws(GemmWsP& p, hipStream_t st) {
   constexpr int EPC = Chunk<T>::N;
   const int KS = (p.K + 4 * EPC - 1) / (4 * EPC);
-  const size_t wb = (size_t)p.NT * KS * 64 * 16, sb = (size_t)p.NT * 16 * 2 * sizeof(float);
-  const bool lds = wb + sb <= 64 * 1024 && ws_ks_ok(KS, true);
-  if (!lds && !ws_ks_ok(KS, false)) { tdeed_set_error("gemm_ws: unsupported K=%d", p.K); return TDEED_ERR_ARG; }
-  const size_t smem = (lds ? wb : 0) + sb;
+  if (!ws_ks_ok(KS)) { tdeed_set_error("gemm_ws: unsupported K=%d", p.K); return TDEED_ERR_ARG; }
+  p.NTS = ws_slice_tiles(p.NT, KS);
+  if (p.NTS < 2) { tdeed_set_error("gemm_ws: K=%d too deep for an LDS-resident weight slice", p.K); return TDEED_ERR_ARG; }
+  const int nsl = (p.NT + p.NTS - 1) / p.NTS;
+  const size_t smem = (size_t)p.NTS * KS * 64 * 16 + (size_t)p.NTS * 16 * 2 * sizeof(float);
   const long nchunks = ((long)p.M + 127) / 128;
-  const int grid = (int)(nchunks < 1024 ? nchunks : 1024);
-#define WS_CASE(k, l) case k: hipLaunchKernelGGL((gemm_ws_kernel<T, k, l>), dim3(grid), dim3(256), smem, st, p); break;
-  if (lds) {
-    switch (KS) {
-      WS_CASE(1, true) WS_CASE(2, true) WS_CASE(3, true) WS_CASE(4, true) WS_CASE(5, true) WS_CASE(6, true)
-      WS_CASE(8, true) WS_CASE(10, true)
-      default: break;
-    }
-  } else {
-    switch (KS) {
-      WS_CASE(5, false) WS_CASE(10, false) WS_CASE(12, false)
-      default: break;
-    }
+  long gx = smem > 64 * 1024 ? 256 : 1024 / nsl;     // persistent blocks; wide slices get one block per CU
+  if (gx > nchunks) gx = nchunks;
+  if (gx < 1) gx = 1;
+  static bool attr_set[16] = {false};
+#define WS_CASE(k)                                                                                              \
+  case k:                                                                                                       \
+    if (smem > 64 * 1024 && !attr_set[k]) {                                                                     \
+      if (hipFuncSetAttribute((const void*)gemm_ws_kernel<T, k, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              WS_LDS_CAP) != hipSuccess) {                                                      \
+        tdeed_set_error("gemm_ws: hipFuncSetAttribute failed");                                                 \
+        return TDEED_ERR_RUNTIME;                                                                               \
+      }                                                                                                         \
+      attr_set[k] = true;                                                                                       \
+    }                                                                                                           \
+    hipLaunchKernelGGL((gemm_ws_kernel<T, k, true>), dim3((unsigned)gx, nsl), dim3(256), smem, st, p);          \
+    break;
+  switch (KS) {
+    WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12)
+    default: break;
   }
 #undef WS_CASE
   TD_LAUNCH_CHECK("gemm_ws");
@@ -504,9 +525,10 @@ extern "C" int tdeed_gemm_ws_fits(int K, int N, int dtype) {
   const int epc = dtype == TDEED_F32 ? 4 : 8;
   const int KS = (K + 4 * epc - 1) / (4 * epc);
   const int NT = (N + 31) / 32 * 2;
-  const size_t smem = (size_t)NT * KS * 64 * 16 + (size_t)NT * 16 * 2 * sizeof(float);
-  if (smem <= 64 * 1024 && ws_ks_ok(KS, true)) return 1;
-  if (dtype == TDEED_BF16 && N <= 1024 && ws_ks_ok(KS, false)) return 2;     // weights streamed from L2
+  if (!ws_ks_ok(KS)) return 0;
+  const int nts = ws_slice_tiles(NT, KS);
+  if (nts == NT) return 1;                        // whole W in LDS
+  if (dtype == TDEED_BF16 && nts >= 4 && N <= 1024) return 2;     // sliced: wide s4 layers
   return 0;
 }
 
@@ -533,6 +555,7 @@ extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long l
   p.R = R; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
   p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
   p.NT = (N + 31) / 32 * 2;
+  p.NTS = p.NT;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm_ws<float>(p, st) : launch_gemm_ws<bf16_t>(p, st);
 }
