@@ -198,6 +198,23 @@ int tdeed_loss_fwd(const float* logits, int rows, int ld, int K1, const int64_t*
                    const float* soft, const float* cls_w, int displ_col, const float* labelD,
                    float* out, void* stream);
 
+/* ---- training path, first pieces (a13 backward, a14): see train.hip ------------------------------------------
+ * loss_bwd: dhead = grad_scale * d(CE + MSE)/d(head_out), same arguments as tdeed_loss_fwd; columns that do not
+ *           take part in the loss get 0.
+ * heads_bwd: FCLayers backward (modules.py:366-376): dx (activation dtype, may be NULL), dw fp32 [n_out][C],
+ *           db fp32 [n_out]; workspace of tdeed_heads_bwd_workspace() bytes (deterministic two-stage reduction).
+ * adamw_step: torch.optim.AdamW update (modules.py:37-39, defaults betas (0.9,0.999) eps 1e-8 wd 0.01) fused over
+ *           one flat fp32 buffer; `step` counts from 1; grad_scale pre-multiplies the gradient (1/world, 1/acc...). */
+int tdeed_loss_bwd(const float* head_out, int rows, int ld, int K1, const int64_t* hard, const float* soft,
+                   const float* cls_w, int displ_col, const float* labelD, float grad_scale, float* dhead,
+                   void* stream);
+long tdeed_heads_bwd_workspace(int rows, int C, int n_out);
+int tdeed_heads_bwd(const float* dout, const void* x, int rows, int C, const float* w, int n_out, void* dx,
+                    float* dw, float* db, void* workspace, int dtype, void* stream);
+int tdeed_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     void* stream);
+
 /* ---- post-proc (modules.py:406-426): softmax over the first K1 columns then scatter-max of
  * frame t onto clamp(t - rne(displ), 0, T-1).  scores fp32 [B][T][K1] (zero-initialised inside),
  * cls int64 [B][T] = argmax. */

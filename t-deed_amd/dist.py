@@ -66,3 +66,15 @@ def gather_clips(local, n_total):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def all_reduce_mean_(flat, async_op=False):
+    """Gradient all-reduce of one flat buffer (sum over ranks; the 1/world is folded into the optimizer's
+    grad_scale by the caller when async, applied here otherwise).  RCCL over xGMI under backend "nccl"."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    if async_op:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    return None

@@ -284,6 +284,38 @@ def loss(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=None, o
     return out
 
 
+def loss_bwd(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=None, grad_scale=1.0):
+    """d(CE+MSE)/d(head_out) (rows, ld) fp32."""
+    rows, ld = head_out.shape
+    dhead = torch.empty_like(head_out)
+    call("tdeed_loss_bwd", ptr(head_out), rows, ld, K1, ptr(hard), ptr(soft), ptr(cls_w), displ_col, ptr(labelD),
+         float(grad_scale), ptr(dhead), stream_ptr())
+    return dhead
+
+
+def heads_bwd(dout, x, w, need_dx=True):
+    """FCLayers backward: returns (dx | None, dw (n_out,C) fp32, db (n_out,) fp32)."""
+    rows, n_out = dout.shape
+    C = x.shape[-1]
+    ws = torch.empty(_lib.load().tdeed_heads_bwd_workspace(rows, C, n_out), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((n_out, C), dtype=torch.float32, device=x.device)
+    db = torch.empty((n_out,), dtype=torch.float32, device=x.device)
+    call("tdeed_heads_bwd", ptr(dout), ptr(x), rows, C, ptr(w), n_out, ptr(dx), ptr(dw), ptr(db), ptr(ws),
+         dtype_code(x.dtype), stream_ptr())
+    return dx, dw, db
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+               grad_scale=1.0):
+    """In-place fused AdamW on flat fp32 buffers (torch.optim.AdamW semantics)."""
+    for t_ in (param, grad, exp_avg, exp_avg_sq):
+        _chk(t_, "adamw buffer", torch.float32)
+    call("tdeed_adamw_step", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
+         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), stream_ptr())
+    return param
+
+
 def process_prediction(head_out, B, T, K1, displ_col):
     ld = head_out.shape[-1]
     scores = torch.empty((B, T, K1), dtype=torch.float32, device=head_out.device)

@@ -38,6 +38,9 @@ def _worker(rank, world, port, n_clips, q):
     # every rank "predicts" its own clips: scores carry the global clip index so that order is checkable
     local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 3).contiguous()
     full = tdist.gather_clips(local, n_clips)
+    grad = torch.full((10,), float(rank + 1))            # flat gradient buffer: mean over ranks = 1.5
+    tdist.all_reduce_mean_(grad)
+    assert torch.allclose(grad, torch.full((10,), 1.5))
     slow = tdist.max_over_ranks(0.5 + rank)            # rank 1 is the slow one
     tdist.barrier()
     q.put((rank, full[:, 0, 0].tolist(), slow))

@@ -171,3 +171,27 @@ def test_model_api_predict_and_epoch():
     assert abs(loss - ref) < 0.05 * max(1.0, abs(ref))      # bf16 forward
     with pytest.raises(NotImplementedError):
         m.epoch(loader, optimizer=object())
+
+
+def test_fused_adamw_on_flat_model_params_matches_torch():
+    """FlatParams + FusedAdamW (one launch for all 431 tensors) == torch.optim.AdamW on the same tensors."""
+    from tdeed_amd.optim import FlatParams, FusedAdamW, warmup_cosine_lr
+    cfg = load_golden("tiny_rny002_gsf")[0]["cfg"]
+    sd = {k: t(v).to(DEV) for k, v in model_state(cfg, 0).items()}
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items() if state_layout.is_parameter(k)}
+    opt_ref = torch.optim.AdamW(list(ref.values()), lr=8e-4)
+    fp = FlatParams(sd)
+    opt = FusedAdamW(fp, lr=8e-4)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for step in range(3):
+        for k, r in ref.items():
+            gr = torch.randn(r.shape, generator=g).to(DEV)
+            r.grad = gr.clone()
+            fp.grad_view(k).copy_(gr.reshape(-1))
+        f = warmup_cosine_lr(step, 2, 10)
+        for grp in opt_ref.param_groups:
+            grp["lr"] = 8e-4 * f
+        opt_ref.step()
+        opt.step(lr_factor=f)
+    for k, r in ref.items():
+        assert max_abs(sd[k], r.detach()) < 5e-6, k

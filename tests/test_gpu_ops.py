@@ -443,6 +443,61 @@ def test_loss_and_process_prediction_golden(ops):
     assert max_abs(s2.cpu(), g["process_double_head"]) < 1e-6
 
 
+# ----------------------------------------------------------------------------- training path, first pieces
+@pytest.mark.parametrize("soft", [False, True])
+def test_loss_bwd_matches_autograd(ops, soft):
+    from oracle import tdeed_oracle as O
+    B, T, K1, seed = 3, 20, 5, 8
+    logits = t(act(seed, "logits", (B, T, K1), 2.0)).requires_grad_(True)
+    displ = t(act(seed, "displ", (B, T), 1.5)).requires_grad_(True)
+    lab, labD = synth.labels(seed, B, T, K1 - 1, 2, fg_frac=0.3)
+    _, g = load_golden("loss_postproc")
+    label = t(g["soft_labels"]) if soft else t(lab)
+    O.loss_fn(logits, label, displ, t(labD)).backward()
+    head = torch.cat([logits.detach(), displ.detach()[..., None]], -1).reshape(B * T, K1 + 1).contiguous().to(DEV)
+    w = torch.tensor([1.0] + [5.0] * (K1 - 1), device=DEV)
+    kw = dict(soft=label.reshape(B * T, K1).contiguous().to(DEV)) if soft else dict(hard=label.reshape(-1).to(DEV))
+    d = ops.loss_bwd(head, K1, w, displ_col=K1, labelD=t(labD.reshape(-1).astype(np.float32)).to(DEV), **kw).cpu()
+    assert max_abs(d[:, :K1], logits.grad.reshape(B * T, K1)) < 1e-6
+    assert max_abs(d[:, K1], displ.grad.reshape(-1)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads_bwd_matches_autograd(ops, dtype):
+    rows, C, n_out = 213, 368, 6
+    x = rnd(131, "x", (rows, C)).to(dtype)
+    w = rnd(132, "w", (n_out, C), 0.05)
+    dout = rnd(133, "dout", (rows, n_out))
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = torch.zeros(n_out, requires_grad=True)
+    (F.linear(xr, wr, br) * dout).sum().backward()
+    dx, dw, db = ops.heads_bwd(dout.to(DEV), x.to(DEV), w.to(DEV))
+    assert rel_err(dx.float(), xr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel_err(dw, wr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+
+
+def test_adamw_step_matches_torch_optim(ops):
+    n = 100003                      # not a multiple of 4: exercises the scalar tail
+    p0 = rnd(141, "p", (n,))
+    opt_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([opt_p], lr=8e-4)           # reference defaults: betas (0.9,0.999), eps 1e-8, wd 0.01
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g = rnd(150 + step, "g", (n,))
+        opt_p.grad = g.clone()
+        opt.step()
+        ops.adamw_step(p, g.to(DEV), m, v, step, 8e-4)
+        assert max_abs(p.cpu(), opt_p.detach()) < 2e-6
+    p2 = p0.clone().to(DEV)       # data-parallel mean folded into the update: g/world
+    ops.adamw_step(p2, (2.0 * rnd(151, "g", (n,))).to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1,
+                   8e-4, grad_scale=0.5)
+    p3 = p0.clone().to(DEV)
+    ops.adamw_step(p3, rnd(151, "g", (n,)).to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1, 8e-4)
+    assert max_abs(p2.cpu(), p3.cpu()) < 1e-7
+
+
 def test_fill_u8_hash_matches_host(ops):
     for shape in [(2, 3, 3, 8, 8), (1, 5, 3, 7, 9)]:
         dev = ops.fill_u8_hash(shape, 1000).cpu().numpy()

@@ -76,3 +76,33 @@ def test_model_api_surface_on_cpu():
     assert update_labels_2heads(lab, [1, 2], 3)[1, 0].item() == 4
     with pytest.raises(RuntimeError, match="GPU"):
         m._model(torch.zeros(1, 16, 3, 32, 32, dtype=torch.uint8), inference=True)
+
+
+def test_warmup_cosine_lr_matches_torch_chained_scheduler():
+    """train_tdeed.py:79-87: LinearLR(0.01->1, warmup) chained with CosineAnnealingLR(T_max)."""
+    from torch.optim.lr_scheduler import ChainedScheduler, LinearLR, CosineAnnealingLR
+    from tdeed_amd.optim import warmup_cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=8e-4)
+    warm, cos = 30, 470
+    sch = ChainedScheduler([LinearLR(opt, start_factor=0.01, end_factor=1.0, total_iters=warm), CosineAnnealingLR(opt, cos)])
+    for step in range(0, 200):
+        assert abs(opt.param_groups[0]["lr"] - 8e-4 * warmup_cosine_lr(step, warm, cos)) < 1e-9, step
+        opt.step()
+        sch.step()
+
+
+def test_flat_params_alias_state_dict():
+    from tdeed_amd.optim import FlatParams
+    sd = {k: torch.from_numpy(v) for k, v in model_state(CFG).items()}
+    before = {k: v.clone() for k, v in sd.items()}
+    fp = FlatParams(sd, device="cpu")
+    n_param = sum(v.numel() for k, v in before.items() if state_layout.is_parameter(k))
+    assert n_param <= fp.numel < n_param + 4 * len(before)
+    for k, v in before.items():
+        assert torch.equal(sd[k], v)
+    fp.flat.add_(1.0)                                   # an optimizer step on the flat buffer is seen by the state
+    k0 = "_features.stem.conv.weight"
+    assert torch.allclose(sd[k0], before[k0] + 1.0)
+    assert sd["_features.stem.bn.running_mean"].data_ptr() != fp.flat.data_ptr()      # buffers stay outside
+    assert all(o % 4 == 0 for o, _ in fp.index.values())
