@@ -113,6 +113,14 @@ int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, i
                     const void* se_w1p, const float* se_b1, const void* se_w2p, const float* se_b2, int R,
                     const void* w3f, const float* s3, const float* h3, void* out, void* stream);
 
+/* grouped 3x3 (stride 1) + BN + ReLU + SE squeeze + excitation in ONE launch for small maps (one workgroup per
+ * frame; bf16): y = conv2_out * gate, i.e. the operand conv3 consumes, so conv3 needs no a_scale and the SE launch
+ * disappears.  tdeed_gconv_se_fits() != 0 tells whether (h, w, C, R) is supported. */
+int tdeed_gconv_se_fits(int h, int w, int C, int R);
+int tdeed_gconv_se_fwd(const void* x, int N, int h, int w, int C, const void* wfrag, const float* scale,
+                       const float* shift, const void* se_w1p, const float* se_b1, const void* se_w2p,
+                       const float* se_b2, int R, void* y, void* stream);
+
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
  * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled: fp32 [N][n_parts][C] partial sums, mean = inv_cnt *
  * sum over parts; gate: fp32 [N][C]; w1t [C][R] (fc1.weight transposed), w2t [R][C] (fc2.weight transposed). */

@@ -499,6 +499,12 @@ class ForwardEngine:
         self.use_graph = use_graph
         self.fuse_front = fuse_front
         self.n_split = int(os.environ.get("TDEED_SPLIT", n_split))
+        # conv2+SE in one launch (gconv_se): back to back it beats the conv2 / SE pair on 7x7 maps (31 vs 37 us, and
+        # conv3 loses its operand re-scale) and loses on 14x14 (one workgroup per CU, 51 vs 38 us); inside the
+        # two-stream graph the pair overlaps with the other half-batch better and the whole forward is 1.3 % slower
+        # with the fusion, so it is opt-in: TDEED_FUSE_SE=1 (7x7 only) or 2 (both).
+        self.fuse_se_max = int(os.environ.get("TDEED_FUSE_SE", "0"))
+        self.fuse_se = self.fuse_se_max > 0
         self._plans = {}
 
     # ------------------------------------------------------------------ plan construction
@@ -621,14 +627,24 @@ class ForwardEngine:
             h2, w2 = (h - 1) // s + 1, (w - 1) // s + 1
             M2 = N * h2 * w2
             y2 = pool.take((N, h2, w2, blk.cout), dt)
-            parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
-            pooled = pool.take((N, parts, blk.cout), torch.float32)
-            gate = pool.take((N, blk.cout), torch.float32)
-            steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
-                y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
-                (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
-            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
-                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            fuse_se = (bw.se_bf is not None and bw.w2frag is not None and s == 1 and self.fuse_se
+                       and 0 < ops.gconv_se_fits(h, w, blk.cout, blk.se_rd) <= self.fuse_se_max)
+            if fuse_se:
+                # conv2 + SE in one launch (frame per workgroup): y2 already carries the gate
+                pooled = gate = None
+                steps.append(Step(blk.name + ".conv2se", "gconv_se", lambda y1=y1, bw=bw, blk=blk, y2=y2: ops.gconv_se(
+                    y1, bw.w2frag, bw.s2, bw.h2, bw.se_bf.se_w1p, bw.se_b1, bw.se_bf.se_w2p, bw.se_b2, blk.se_rd, out=y2),
+                    (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 2 + 2 * blk.cout * blk.se_rd * 2,
+                    2 * M2 * blk.cout * blk.gw * 9 + 4 * N * blk.cout * blk.se_rd))
+            else:
+                parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
+                pooled = pool.take((N, parts, blk.cout), torch.float32)
+                gate = pool.take((N, blk.cout), torch.float32)
+                steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
+                    y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
+                    (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
+                steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
+                    2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
             if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
                 gather = (s, h, w, h2, w2) if s > 1 else None
@@ -642,7 +658,7 @@ class ForwardEngine:
                 y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
                 *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` dies here
-            for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
+            for t_ in [y1, y2] + ([pooled, gate] if pooled is not None else []) + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
             if not x_kept:
                 pool.give(x)

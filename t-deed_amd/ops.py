@@ -115,6 +115,22 @@ def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None,
     return out
 
 
+def gconv_se_fits(h, w, C, R):
+    """0 = unsupported; 1 = the <=8x8 map variant (two workgroups per CU); 2 = the <=14x14 variant (one per CU)."""
+    return _lib.load().tdeed_gconv_se_fits(h, w, C, R)
+
+
+def gconv_se(x, wfrag, scale, shift, se_w1p, se_b1, se_w2p, se_b2, R, out=None):
+    """grouped 3x3 + BN + ReLU + SE in one launch (bf16, stride 1, small maps): returns conv2_out * gate."""
+    _chk(x, "x", torch.bfloat16)
+    N, h, w, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_gconv_se_fwd", ptr(x), N, h, w, C, ptr(wfrag), ptr(scale), ptr(shift), ptr(se_w1p), ptr(se_b1),
+         ptr(se_w2p), ptr(se_b2), R, ptr(out), stream_ptr())
+    return out
+
+
 def se_gate_bf16(pooled, inv_cnt, w1p, b1, w2p, b2, R, out=None):
     """SE excitation with bf16 packed weights (engine.pack_se_bf16): pooled (N,parts,C) sums -> gate (N,C)."""
     N, parts, C = pooled.shape

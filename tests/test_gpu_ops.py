@@ -184,6 +184,29 @@ def test_gconv3x3(ops, dtype, C, gw, stride, H, W):
         assert rel_err(pooled.sum(dim=1) / npix, ref.mean(dim=(2, 3))) < tol
 
 
+@pytest.mark.parametrize("C,gw,R,h,w", [(368, 8, 92, 7, 7), (152, 8, 38, 14, 14), (152, 8, 38, 4, 5), (56, 8, 6, 8, 8),
+                                        (368, 8, 92, 4, 7), (128, 16, 16, 14, 14)])
+def test_gconv_se_fused_vs_chain(ops, C, gw, R, h, w):
+    """conv2 + BN + ReLU + SE in one launch == grouped conv, then SE gate, then the multiply (fp32 torch)."""
+    from tdeed_amd.engine import pack_gconv_frags, pack_se_bf16
+    assert ops.gconv_se_fits(h, w, C, R)
+    N = 5
+    x = rnd(131, "x", (N, C, h, w)).to(torch.bfloat16)
+    wt = rnd(132, "w", (C, gw, 3, 3), 0.2)
+    sc, sh = rnd(133, "sc", (C,)) * 0.2 + 1.0, rnd(134, "sh", (C,)) * 0.1
+    w1, b1 = rnd(135, "w1", (R, C), 0.1).to(torch.bfloat16).float(), rnd(136, "b1", (R,), 0.1)
+    w2, b2 = rnd(137, "w2", (C, R), 0.2).to(torch.bfloat16).float(), rnd(138, "b2", (C,), 0.1)
+    y2 = torch.relu(F.conv2d(x.float(), wt.to(torch.bfloat16).float(), padding=1, groups=C // gw) * sc.view(1, -1, 1, 1)
+                    + sh.view(1, -1, 1, 1)).to(torch.bfloat16).float()
+    gate = torch.sigmoid(torch.relu(y2.mean(dim=(2, 3)) @ w1.T + b1) @ w2.T + b2)
+    ref = y2 * gate[:, :, None, None]
+    pk = pack_se_bf16(w1.numpy(), w2.numpy(), DEV)
+    out = ops.gconv_se(x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_gconv_frags(wt, gw, DEV), sc.to(DEV), sh.to(DEV),
+                       pk["se_w1p"], b1.to(DEV), pk["se_w2p"], b2.to(DEV), R)
+    assert rel_err(out.float().permute(0, 3, 1, 2), ref) < BF16_TOL
+    assert not ops.gconv_se_fits(28, 28, 56, 6)
+
+
 def test_se_gate(ops):
     N, C, R = 11, 152, 38
     p = rnd(41, "p", (N, C)).abs()
