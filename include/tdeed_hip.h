@@ -113,6 +113,14 @@ int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, i
                     const void* se_w1p, const float* se_b1, const void* se_w2p, const float* se_b2, int R,
                     const void* w3f, const float* s3, const float* h3, void* out, void* stream);
 
+/* Split-K form of the contraction for the short sequences of the SGP encoder-decoder (a few hundred rows, K up to
+ * 6C; bf16): C = act((A . W^T) * scale + shift + R).  Two launches: S = tdeed_gemm_splitk_splits(K) partial products
+ * into `workspace` (fp32, S*M*N elements, caller-owned), then a reduce + epilogue pass. */
+int tdeed_gemm_splitk_splits(int K);
+int tdeed_gemm_splitk_fwd(const void* A, long lda, int M, int K, int N, const void* W, long ldw, const float* scale,
+                          const float* shift, const void* R, long ldr, int act, void* C, long ldc,
+                          float* workspace, void* stream);
+
 /* grouped 3x3 (stride 1) + BN + ReLU + SE squeeze + excitation in ONE launch for small maps (one workgroup per
  * frame; bf16): y = conv2_out * gate, i.e. the operand conv3 consumes, so conv3 needs no a_scale and the SE launch
  * disappears.  tdeed_gconv_se_fits() != 0 tells whether (h, w, C, R) is supported. */

@@ -559,3 +559,118 @@ extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long l
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm_ws<float>(p, st) : launch_gemm_ws<bf16_t>(p, st);
 }
+
+// =============================================================================================
+// Split-K contraction for the short sequences of the SGP encoder-decoder (M = B*T of a few hundred rows, K up to
+// 6C): with so few rows a tiled kernel has ~40 workgroups that each walk K in 20+ dependent global->LDS round
+// trips (30-43 us for 0.9 GFLOP).  Here K is cut into chunks of <=192: a workgroup issues ALL loads of its
+// 64 x 64 x 192 brick at once (12 x 16 B per lane), runs 6 MFMA k-steps out of LDS and writes an fp32 partial;
+// a second launch sums the partials and applies scale / shift / residual / activation.  bf16 operands.
+constexpr int SK_KC = 192, SK_RS = SK_KC * 2 + 16;     // K chunk, LDS row stride (bytes; the skew spreads banks)
+
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(const bf16_t* __restrict__ A, long lda,
+                                                          const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                          int n_tiles, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) unsigned char sa[64 * SK_RS];
+  __shared__ __attribute__((aligned(16))) unsigned char sw[64 * SK_RS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  const int tile = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int n0 = (tile % n_tiles) * 64, m0 = (tile / n_tiles) * 64;
+  const int z = blockIdx.y, k0 = z * SK_KC;
+  constexpr int PPR = SK_KC / 8;                       // 16-byte pieces per row
+  // branch-free: every lane loads from a clamped (always valid) address so all 12 loads are in flight together;
+  // out-of-range pieces are zeroed on the way into LDS
+  u32x4 va[6], vw[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i / PPR, pc = i - row * PPR;
+    const int k = min(k0 + pc * 8, K - 8);
+    va[j] = *reinterpret_cast<const u32x4*>(A + (long)min(m0 + row, M - 1) * lda + k);
+    vw[j] = *reinterpret_cast<const u32x4*>(W + (long)min(n0 + row, N - 1) * ldw + k);
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i / PPR, pc = i - row * PPR;
+    const bool kin = k0 + pc * 8 < K;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(sa + row * SK_RS + pc * 16) = (kin && m0 + row < M) ? va[j] : zero;
+    *reinterpret_cast<u32x4*>(sw + row * SK_RS + pc * 16) = (kin && n0 + row < N) ? vw[j] : zero;
+  }
+  __syncthreads();
+  f32x4 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < SK_KC / 32; ++ks) {
+    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (wv * 16 + pl) * SK_RS + (ks * 32 + q * 8) * 2);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(sa + (mt * 16 + pl) * SK_RS + (ks * 32 + q * 8) * 2);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[mt], 0, 0, 0);
+    }
+  }
+  const int n = n0 + wv * 16 + 4 * q;
+  if (n < N) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + mt * 16 + pl;
+      if (m < M) *reinterpret_cast<f32x4*>(part + ((long)z * M + m) * N + n) = acc[mt];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const bf16_t* __restrict__ R, long ldr, int act,
+                                                                 bf16_t* __restrict__ C, long ldc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)m * N + n);
+  for (int s_ = 1; s_ < S; ++s_) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(part + ((long)s_ * M + m) * N + n);
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  bf16x4 rr;
+  if (R) rr = *reinterpret_cast<const bf16x4*>(R + (long)m * ldr + n);
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    if (scale) x *= scale[n + e];
+    if (shift) x += shift[n + e];
+    if (R) x += (float)rr[e];
+    if (act == TDEED_ACT_RELU) x = fmaxf(x, 0.f);
+    else if (act == TDEED_ACT_GELU) x = gelu_erf(x);
+    o[e] = (bf16_t)x;
+  }
+  *reinterpret_cast<bf16x4*>(C + (long)m * ldc + n) = o;
+}
+
+extern "C" int tdeed_gemm_splitk_splits(int K) { return (K + SK_KC - 1) / SK_KC; }
+
+extern "C" int tdeed_gemm_splitk_fwd(const void* A, long lda, int M, int K, int N, const void* W, long ldw,
+                                     const float* scale, const float* shift, const void* R, long ldr, int act,
+                                     void* C, long ldc, float* workspace, void* stream) {
+  TD_CHECK(A && W && C && workspace, "gemm_splitk: null pointer");
+  TD_CHECK(M > 0 && K > 0 && N > 0, "gemm_splitk: bad sizes M=%d K=%d N=%d", M, K, N);
+  TD_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0),
+           "gemm_splitk: K=%d N=%d and the row strides must be multiples of 8", K, N);
+  TD_CHECK(act >= 0 && act <= 2, "gemm_splitk: bad act %d", act);
+  const int S = tdeed_gemm_splitk_splits(K);
+  TD_CHECK(S <= 65535, "gemm_splitk: K=%d too large", K);
+  const int n_tiles = (N + 63) / 64, m_tiles = (M + 63) / 64;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_splitk_kernel, dim3(n_tiles * m_tiles, S), dim3(256), 0, st, (const bf16_t*)A, lda,
+                     (const bf16_t*)W, ldw, M, N, K, n_tiles, workspace);
+  TD_LAUNCH_CHECK("gemm_splitk");
+  const long items = (long)M * (N / 4);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, workspace, S,
+                     M, N, scale, shift, (const bf16_t*)R, ldr, act, (bf16_t*)C, ldc);
+  TD_LAUNCH_CHECK("gemm_splitk_reduce");
+  return TDEED_OK;
+}

@@ -298,6 +298,23 @@ class SgpBuilder:
 
     def __init__(self, pool, steps, keep, taps, B, act_dtype):
         self.pool, self.steps, self.keep, self.taps, self.B, self.dt = pool, steps, keep, taps, B, act_dtype
+        self.splitk_rows = int(os.environ.get("TDEED_SPLITK_ROWS", "4096"))
+
+    def dense(self, name, A, Wt, bias, act, out, R, residual=None):
+        """One Conv1d(k=1) of the mlp / concat_fc.  Short sequences (bf16, <= splitk_rows rows) go through the split-K
+        kernel: a tiled contraction would be ~40 workgroups each walking K in 20+ dependent round trips."""
+        N, K = Wt.shape
+        es = _esz(self.dt)
+        if (self.dt == torch.bfloat16 and R <= self.splitk_rows and str(A.device) != "cpu"
+                and ops.gemm_splitk_splits(K) >= 4):      # K = 4C / 6C; for K = C the tiled kernel is faster (11 vs 15 us)
+            ws = self.pool.take((ops.gemm_splitk_splits(K), R, N), torch.float32)
+            self.steps.append(Step(name, "gemm_splitk", lambda: ops.gemm_splitk(A, Wt, None, bias, act, residual=residual,
+                                                                                 out=out, M=R, workspace=ws),
+                                   *gemm_cost(R, K, N, es, residual is not None)))
+            self.pool.give(ws)
+        else:
+            self.steps.append(Step(name, "gemm", lambda: ops.gemm(A, Wt, None, bias, act, residual=residual, out=out, M=R),
+                                   *gemm_cost(R, K, N, es, residual is not None)))
 
     def block(self, xin, Tn, o, name):
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
@@ -312,10 +329,8 @@ class SgpBuilder:
         steps.append(Step(name + ".branch", "sgp_branch", lambda: ops.sgp_branch(ln, xin, o.ks, o.up, o.dw, o.db, out=y),
                           3 * R * C * es + C * (wl + 5) * 4, 2 * R * C * (wl + 3)))
         steps.append(Step(name + ".gn", "groupnorm", lambda: ops.groupnorm(y, 16, o.gn_w, o.gn_b, out=gn), 2 * R * C * es))
-        steps.append(Step(name + ".fc1", "gemm", lambda: ops.gemm(gn, o.w_fc1, None, o.b_fc1, ops.ACT_GELU, out=hid, M=R),
-                          *gemm_cost(R, C, 4 * C, es)))
-        steps.append(Step(name + ".fc2", "gemm", lambda: ops.gemm(hid, o.w_fc2, None, o.b_fc2, ops.ACT_NONE, residual=y,
-                                                                  out=outb, M=R), *gemm_cost(R, 4 * C, C, es, True)))
+        self.dense(name + ".fc1", gn, o.w_fc1, o.b_fc1, ops.ACT_GELU, hid, R)
+        self.dense(name + ".fc2", hid, o.w_fc2, o.b_fc2, ops.ACT_NONE, outb, R, residual=y)
         for t_ in (ln, y, gn, hid):
             pool.give(t_)
         if name in self.taps:
@@ -339,13 +354,10 @@ class SgpBuilder:
         steps.append(Step(name + ".branch", "mixer_branch",
                           lambda: ops.mixer_branch(xn, cat, T_hi, o.ks, o.up, o.dw1, o.db1, o.dw2, o.db2),
                           (6 * R + Rl) * C * es + 2 * C * (wl + 5) * 4, 4 * R * C * (wl + 3)))
-        steps.append(Step(name + ".cat", "gemm", lambda: ops.gemm(cat, o.w_cat, None, o.b_cat, ops.ACT_GELU, out=mo, M=R),
-                          *gemm_cost(R, 6 * C, C, es)))
+        self.dense(name + ".cat", cat, o.w_cat, o.b_cat, ops.ACT_GELU, mo, R)
         steps.append(Step(name + ".gn", "groupnorm", lambda: ops.groupnorm(mo, 16, o.gn_w, o.gn_b, out=gn), 2 * R * C * es))
-        steps.append(Step(name + ".fc1", "gemm", lambda: ops.gemm(gn, o.w_fc1, None, o.b_fc1, ops.ACT_GELU, out=hid, M=R),
-                          *gemm_cost(R, C, 4 * C, es)))
-        steps.append(Step(name + ".fc2", "gemm", lambda: ops.gemm(hid, o.w_fc2, None, o.b_fc2, ops.ACT_NONE, residual=mo,
-                                                                  out=outb, M=R), *gemm_cost(R, 4 * C, C, es, True)))
+        self.dense(name + ".fc1", gn, o.w_fc1, o.b_fc1, ops.ACT_GELU, hid, R)
+        self.dense(name + ".fc2", hid, o.w_fc2, o.b_fc2, ops.ACT_NONE, outb, R, residual=mo)
         for t_ in (cat, xn, mo, gn, hid):
             pool.give(t_)
         if name in self.taps:

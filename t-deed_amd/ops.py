@@ -115,6 +115,31 @@ def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None,
     return out
 
 
+def gemm_splitk_splits(K):
+    return _lib.load().tdeed_gemm_splitk_splits(K)
+
+
+def gemm_splitk_workspace(M, K, N, device):
+    """fp32 scratch for gemm_splitk: one [M][N] partial per K chunk."""
+    return torch.empty((_lib.load().tdeed_gemm_splitk_splits(K), M, N), dtype=torch.float32, device=device)
+
+
+def gemm_splitk(A, W, scale, shift, act=ACT_NONE, residual=None, out=None, M=None, workspace=None):
+    """Split-K contraction for short sequences (bf16): act((A . W^T) * scale + shift + residual)."""
+    _chk(A, "A", torch.bfloat16)
+    _chk(W, "W", torch.bfloat16)
+    N, K = W.shape
+    if M is None:
+        M = A.numel() // K
+    if out is None:
+        out = torch.empty(tuple(A.shape[:-1]) + (N,), dtype=A.dtype, device=A.device)
+    if workspace is None:
+        workspace = gemm_splitk_workspace(M, K, N, A.device)
+    call("tdeed_gemm_splitk_fwd", ptr(A), K, M, K, N, ptr(W), K, ptr(scale), ptr(shift), ptr(residual), N, act,
+         ptr(out), N, ptr(workspace), stream_ptr())
+    return out
+
+
 def gconv_se_fits(h, w, C, R):
     """0 = unsupported; 1 = the <=8x8 map variant (two workgroups per CU); 2 = the <=14x14 variant (one per CU)."""
     return _lib.load().tdeed_gconv_se_fits(h, w, C, R)

@@ -184,6 +184,20 @@ def test_gconv3x3(ops, dtype, C, gw, stride, H, W):
         assert rel_err(pooled.sum(dim=1) / npix, ref.mean(dim=(2, 3))) < tol
 
 
+@pytest.mark.parametrize("M,K,N", [(800, 1472, 368), (400, 368, 1472), (200, 2208, 368), (37, 40, 24), (1000, 4608, 768)])
+@pytest.mark.parametrize("actn", [0, 1, 2])
+def test_gemm_splitk(ops, M, K, N, actn):
+    A, W = rnd(141, "A", (M, K)).to(torch.bfloat16), rnd(142, "W", (N, K), 0.05).to(torch.bfloat16)
+    sc, sh, R = rnd(143, "sc", (N,)) * 0.2 + 1.0, rnd(144, "sh", (N,), 0.1), rnd(145, "R", (M, N)).to(torch.bfloat16)
+    ref = (A.float() @ W.float().T) * sc + sh + R.float()
+    ref = [ref, torch.relu(ref), F.gelu(ref)][actn]
+    out = ops.gemm_splitk(A.to(DEV), W.to(DEV), sc.to(DEV), sh.to(DEV), actn, residual=R.to(DEV))
+    assert rel_err(out.float(), ref) < BF16_TOL
+    out2 = ops.gemm_splitk(A.to(DEV), W.to(DEV), None, None, actn)
+    ref2 = A.float() @ W.float().T
+    assert rel_err(out2.float(), [ref2, torch.relu(ref2), F.gelu(ref2)][actn]) < BF16_TOL
+
+
 @pytest.mark.parametrize("C,gw,R,h,w", [(368, 8, 92, 7, 7), (152, 8, 38, 14, 14), (152, 8, 38, 4, 5), (56, 8, 6, 8, 8),
                                         (368, 8, 92, 4, 7), (128, 16, 16, 14, 14)])
 def test_gconv_se_fused_vs_chain(ops, C, gw, R, h, w):
