@@ -506,19 +506,27 @@ __global__ __launch_bounds__(256) void se_gate_bf16_kernel(const float* __restri
   const int jper = (R + nsl2 - 1) / nsl2;
   const int j0 = sl2 * jper, j1 = act2 ? min(R, j0 + jper) : j0;
   bf16x8 w1r[MAXB], w2r[MAXB];
+  // branch-free (clamped rows: a guarded load compiles to load / wait per item); unused registers are never read
 #pragma unroll
   for (int i = 0; i < MAXB; ++i)
-    if (c0 + i < c1) w1r[i] = *reinterpret_cast<const bf16x8*>(w1p + (long)(c0 + i) * R8 + jo * 8);
+    w1r[i] = *reinterpret_cast<const bf16x8*>(w1p + (long)min(c0 + i, C - 1) * R8 + min(jo, NJ - 1) * 8);
 #pragma unroll
   for (int i = 0; i < MAXB; ++i)
-    if (j0 + i < j1) w2r[i] = *reinterpret_cast<const bf16x8*>(w2p + (long)(j0 + i) * C + co * 8);
+    w2r[i] = *reinterpret_cast<const bf16x8*>(w2p + (long)min(j0 + i, R - 1) * C + co * 8);
   for (int i = threadIdx.x; i < SE_FPB * C; i += 256) {
     const int f = i / C, c = i - f * C;
+    const float* src = pooled + ((long)min(f0 + f, N - 1) * n_parts) * C + c;
     float v = 0.f;
-    if (f0 + f < N) {
-      const float* src = pooled + ((long)(f0 + f) * n_parts) * C + c;
-#pragma unroll 4
-      for (int q = 0; q < n_parts; ++q) v += src[(long)q * C];
+    if (n_parts == 1) {
+      v = src[0];
+    } else {
+      for (int q0 = 0; q0 < n_parts; q0 += 8) {
+        float pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pv[q] = src[(long)min(q0 + q, n_parts - 1) * C];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += q0 + q < n_parts ? pv[q] : 0.f;
+      }
     }
     sp[i] = v * inv_cnt;
   }

@@ -9,6 +9,7 @@
 // straight from L2 (a 3-frame x fold slab is <= 110 KB, L2 resident); (2) the tiny (c,t)-plane conv;
 // (3) blend + shift + interleave, written as the first Fp columns of conv1's A operand.
 #include "common.h"
+#include <cstdlib>
 
 template <typename T> struct Pair;   // 2 consecutive elements (F/2 is always even)
 template <> struct Pair<float> {
@@ -119,6 +120,70 @@ __global__ __launch_bounds__(256) void gsf_q_kernel(const T* __restrict__ x, int
   }
 }
 
+// copy n 16-byte items global -> LDS with all loads of a batch of 8 in flight together (a plain copy loop compiles
+// to load / wait / write per item: one full memory round trip each)
+__device__ __forceinline__ void copy16_batched(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int n) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+    u32x4 r[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) r[b] = src[min(i0 + b * 256, n - 1)];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (i0 + b * 256 < n) dst[i0 + b * 256] = r[b];
+  }
+}
+
+// stage rows [y0-1, y0+rows-1) of frame f as relu(bn(x)) in bf16, 8-channel chunks, into a[rows][w+2][PSQ]:
+// zero halo ring, channels >= F and the stride pad are zero.  Branch-free loads (clamped addresses, select
+// afterwards) so a batch of 8 x 16 B per lane is in flight at once; sbn = BN scale[F] | shift[F] in LDS.
+__device__ __forceinline__ void gsf_stage_frame(unsigned char* a, const bf16_t* __restrict__ x, long f, int h, int w,
+                                                int C, int F, int y0, int rows, int nch, int PSQ,
+                                                const float* sbn) {
+  const int tid = threadIdx.x, WP = w + 2;
+  const int cpp = PSQ >> 4;                                     // 16-byte pieces per pixel incl. pad
+  const int total = rows * WP * cpp;
+  const bf16_t* xf = x + f * h * w * C;
+  for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+    u32x4 v[8];
+    int cj[8];
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = min(i0 + b8 * 256, total - 1);
+      const int j = i % cpp, pix = i / cpp;
+      const int ry = pix / WP, rx = pix - ry * WP;
+      const int yy = y0 - 1 + ry, xx = rx - 1;
+      const bool ok = j < nch && yy >= 0 && yy < h && xx >= 0 && xx < w;
+      cj[b8] = ok ? j : -1;
+      v[b8] = *reinterpret_cast<const u32x4*>(ok ? xf + ((long)yy * w + xx) * C + j * 8 : xf);
+    }
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = i0 + b8 * 256;
+      if (i >= total) continue;
+      u32x4 o = {0u, 0u, 0u, 0u};
+      if (cj[b8] >= 0) {
+        const int c0 = cj[b8] * 8;
+        float fv[8];
+        Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v[b8]), fv);
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = min(c0 + e, F - 1);
+          r[e] = (c0 + e < F) ? (bf16_t)fmaxf(fmaf(fv[e], sbn[c], sbn[F + c]), 0.f) : (bf16_t)0.f;
+        }
+        o = *reinterpret_cast<u32x4*>(&r);
+      }
+      *reinterpret_cast<u32x4*>(a + (long)i * 16) = o;
+    }
+  }
+}
+
+// BN scale / shift [F] each -> LDS sbn[2F]
+__device__ __forceinline__ void gsf_stage_bn(float* sbn, const float* __restrict__ bn_scale,
+                                             const float* __restrict__ bn_shift, int F) {
+  for (int i = threadIdx.x; i < 2 * F; i += 256) sbn[i] = i < F ? bn_scale[i] : bn_shift[i - F];
+}
+
 // ---- launch 1a, bf16 throughput mode: the same partial sums as an implicit GEMM on the MFMA pipe.
 // D[jg][pixel] = sum_k Wt[jg][k] A[k][pixel], jg = (temporal tap j, gate g) = 6 of the 16 MFMA rows,
 // k = (spatial tap, 8-channel chunk): a lane's 8 k-values are one 16-byte read of the BN+ReLU'd frame
@@ -136,56 +201,12 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   const int rows = y1 - y0 + 2, WP = w + 2;
   bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
   unsigned char* a = smq + (size_t)KS * 64 * 16;               // [rows][WP][PSQ]
+  float* sbn = reinterpret_cast<float*>(a + (size_t)(band + 2) * WP * PSQ);   // [2F]
   const int tid = threadIdx.x;
-  for (int i = tid; i < KS * 64; i += 256) wl[i] = wqf[i];
-  // stage: relu(bn(x)) as bf16, 8-channel chunks; halo ring, channels >= F and the stride pad are zero
-  const int cpp = PSQ >> 4;                                     // 16-byte pieces per pixel incl. pad
-  const int total = rows * WP * cpp;
-  for (int i0 = tid; i0 < total; i0 += 256 * 4) {
-    u32x4 v[4];
-    int meta[4];
-#pragma unroll
-    for (int b4 = 0; b4 < 4; ++b4) {
-      const int i = i0 + b4 * 256;
-      meta[b4] = -1;
-      v[b4] = (u32x4){0u, 0u, 0u, 0u};
-      if (i < total) {
-        const int j = i % cpp, pix = i / cpp;
-        const int ry = pix / WP, rx = pix - ry * WP;
-        const int yy = y0 - 1 + ry, xx = rx - 1;
-        meta[b4] = -2 - j;                                      // zero piece
-        if (j < nch && yy >= 0 && yy < h && xx >= 0 && xx < w) {
-          const bf16_t* src = x + ((long)f * h * w + (long)yy * w + xx) * C + j * 8;
-          if (j * 8 + 8 <= F) {
-            v[b4] = *reinterpret_cast<const u32x4*>(src);
-          } else {                                              // last chunk of a fold that is not a multiple of 8
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(src);
-            v[b4] = (u32x4){lo[0], lo[1], 0u, 0u};
-          }
-          meta[b4] = j;
-        }
-      }
-    }
-#pragma unroll
-    for (int b4 = 0; b4 < 4; ++b4) {
-      const int i = i0 + b4 * 256;
-      if (i >= total) continue;
-      u32x4 o = {0u, 0u, 0u, 0u};
-      if (meta[b4] >= 0) {
-        const int c0 = meta[b4] * 8;
-        float fv[8];
-        Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v[b4]), fv);
-        bf16x8 r;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = c0 + e;
-          r[e] = (c < F) ? (bf16_t)fmaxf(fmaf(fv[e], bn_scale[c], bn_shift[c]), 0.f) : (bf16_t)0.f;
-        }
-        o = *reinterpret_cast<u32x4*>(&r);
-      }
-      *reinterpret_cast<u32x4*>(a + (long)i * 16) = o;
-    }
-  }
+  gsf_stage_bn(sbn, bn_scale, bn_shift, F);
+  copy16_batched(reinterpret_cast<u32x4*>(wl), reinterpret_cast<const u32x4*>(wqf), KS * 64);
+  __syncthreads();
+  gsf_stage_frame(a, x, f, h, w, C, F, y0, rows, nch, PSQ, sbn);
   __syncthreads();
   const int lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
   const int npix = (y1 - y0) * w;
@@ -213,6 +234,50 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   }
 }
 
+// deterministic spatial sums of gate*x and x over one frame: channel pairs across lanes (coalesced), S pixel slices
+// per pair, 8 pixels of a slice loaded per batch, ordered reduce over the slices.  sg = gates [hw][2] in LDS.
+template <typename T>
+__device__ __forceinline__ void gsf_spatial_sums(const T* __restrict__ x, long f, int hw, int C, int F, const float* sg,
+                                                 float* part, float* __restrict__ ysum, float* __restrict__ xsum) {
+  const int Fh = F >> 1, nq = F >> 1;
+  const int S = 256 / nq;
+  const int cp = threadIdx.x % nq;
+  const int s = threadIdx.x / nq;
+  if (s < S) {
+    float y0 = 0.f, y1 = 0.f, x0 = 0.f, x1 = 0.f;
+    const T* xf = x + f * hw * C + 2 * cp;
+    const int g = (2 * cp) >= Fh;
+    for (int p0 = s; p0 < hw; p0 += S * 8) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) Pair<T>::load(xf + (long)min(p0 + b * S, hw - 1) * C, v0[b], v1[b]);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int p = p0 + b * S;
+        if (p < hw) {
+          const float gt = sg[2 * p + g];
+          x0 += v0[b]; x1 += v1[b];
+          y0 += v0[b] * gt; y1 += v1[b] * gt;
+        }
+      }
+    }
+    part[s * F + 2 * cp] = y0;
+    part[s * F + 2 * cp + 1] = y1;
+    part[(S + s) * F + 2 * cp] = x0;
+    part[(S + s) * F + 2 * cp + 1] = x1;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < F; c += 256) {
+    float ys = 0.f, xs = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) {
+      ys += part[s2 * F + c];
+      xs += part[(S + s2) * F + c];
+    }
+    ysum[f * F + c] = ys;
+    xsum[f * F + c] = xs;
+  }
+}
+
 // ---- launch 1b: gate = tanh(b + Q[t-1][0] + Q[t][1] + Q[t+1][2]) and the spatial sums of gate*x and x
 template <typename T>
 __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict__ x, const float* __restrict__ Q,
@@ -221,54 +286,98 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
                                                             float* __restrict__ gate, float* __restrict__ ysum,
                                                             float* __restrict__ xsum) {
   extern __shared__ float sm[];        // gates [hw][2], then partial sums [2][S][F]
-  const int f = blockIdx.x;
-  const int t = f % T_len;
-  const int Fh = F >> 1;
+  const long f = blockIdx.x;
+  const int t = (int)(f % T_len);
   float* sg = sm;
   float* part = sm + 2 * hw;
-  for (int i = threadIdx.x; i < 2 * hw; i += 256) {
-    const int p = i >> 1, g = i & 1;
-    float v = b3d[g] + Q[((long)f * hw + p) * 6 + 2 + g];
-    if (t > 0) v += Q[((long)(f - 1) * hw + p) * 6 + g];
-    if (t < T_len - 1) v += Q[((long)(f + 1) * hw + p) * 6 + 4 + g];
-    v = tanhf(v);
+  const float has_prev = t > 0 ? 1.f : 0.f, has_next = t < T_len - 1 ? 1.f : 0.f;
+  const long fp = t > 0 ? f - 1 : f, fn = t < T_len - 1 ? f + 1 : f;      // clamped: loads stay branch-free
+  const float b0 = b3d[0], b1 = b3d[1];
+  for (int i0 = threadIdx.x; i0 < 2 * hw; i0 += 256 * 4) {
+    float qc[4], qp[4], qn[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = min(i0 + b * 256, 2 * hw - 1);
+      const int p = i >> 1, g = i & 1;
+      qc[b] = Q[(f * hw + p) * 6 + 2 + g];
+      qp[b] = Q[(fp * hw + p) * 6 + g];
+      qn[b] = Q[(fn * hw + p) * 6 + 4 + g];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + b * 256;
+      if (i < 2 * hw) {
+        const float v = tanhf(((i & 1) ? b1 : b0) + qc[b] + has_prev * qp[b] + has_next * qn[b]);
+        sg[i] = v;
+        gate[f * hw * 2 + i] = v;
+      }
+    }
+  }
+  __syncthreads();
+  gsf_spatial_sums<T>(x, f, hw, C, F, sg, part, ysum, xsum);
+}
+
+// ---- launches 1a + 1b in one (bf16, frame fits one LDS tile): the workgroup of frame t stages frames t-1, t, t+1 in
+// turn and takes from each only the temporal tap it contributes, so the per-tap maps Q never exist in memory and the
+// gate / spatial sums follow in the same launch.  3x redundant MFMA work (trivial here) for one launch fewer.
+__global__ __launch_bounds__(256) void gsf_gate3_mfma_kernel(const bf16_t* __restrict__ x, int T_len, int h, int w, int C,
+                                                             int F, int nch, int PSQ, int KS,
+                                                             const float* __restrict__ bn_scale,
+                                                             const float* __restrict__ bn_shift,
+                                                             const bf16x8* __restrict__ wqf,
+                                                             const float* __restrict__ b3d, float* __restrict__ gate,
+                                                             float* __restrict__ ysum, float* __restrict__ xsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smq[];
+  const int f = blockIdx.x, t = f % T_len;
+  const int hw = h * w, WP = w + 2;
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
+  unsigned char* a = smq + (size_t)KS * 64 * 16;               // [h+2][WP][PSQ]
+  float* sg = reinterpret_cast<float*>(a + (size_t)(h + 2) * WP * PSQ);   // [hw][2] gate pre-activations
+  float* part = sg + 2 * hw;                                    // [2][S][F], S*F = 512
+  float* sbn = part + 1024;                                     // [2F]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  gsf_stage_bn(sbn, bn_scale, bn_shift, F);
+  copy16_batched(reinterpret_cast<u32x4*>(wl), reinterpret_cast<const u32x4*>(wqf), KS * 64);
+  {
+    const float b0 = b3d[0], b1 = b3d[1];
+    for (int i = tid; i < 2 * hw; i += 256) sg[i] = (i & 1) ? b1 : b0;
+  }
+  const int ntl = (hw + 15) >> 4;
+  for (int dt = -1; dt <= 1; ++dt) {
+    if (t + dt < 0 || t + dt >= T_len) continue;                // uniform per workgroup
+    __syncthreads();
+    gsf_stage_frame(a, x, (long)f + dt, h, w, C, F, 0, h + 2, nch, PSQ, sbn);
+    __syncthreads();
+    const int own_q = dt == 1 ? 1 : 0;                          // D rows 2j, 2j+1 (j = dt + 1) live in these lanes
+    for (int mt = wv; mt < ntl; mt += 4) {
+      const int p = mt * 16 + pl;
+      const bool pok = p < hw;
+      const int pc = pok ? p : 0;
+      const int py = pc / w, px = pc - py * w;
+      const unsigned char* base = a + ((long)py * WP + px) * PSQ;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < KS; ++ks) {
+        const int s_ = 4 * ks + q;
+        const int tap = s_ / nch, ck = s_ - tap * nch;
+        const bool sok = tap < 9;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + (sok ? ((dy * WP + dx) * PSQ + ck * 16) : 0));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks * 64 + lane], af, acc, 0, 0, 0);
+      }
+      if (pok && q == own_q) {
+        sg[2 * p] += dt == 0 ? acc[2] : acc[0];
+        sg[2 * p + 1] += dt == 0 ? acc[3] : acc[1];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * hw; i += 256) {
+    const float v = tanhf(sg[i]);
     sg[i] = v;
     gate[(long)f * hw * 2 + i] = v;
   }
   __syncthreads();
-  // deterministic spatial sums: channel pairs across lanes (coalesced), S pixel slices, ordered reduce
-  const int nq = F >> 1;
-  const int S = 256 / nq;
-  {
-    const int cp = threadIdx.x % nq;
-    const int s = threadIdx.x / nq;
-    if (s < S) {
-      float y0 = 0.f, y1 = 0.f, x0 = 0.f, x1 = 0.f;
-      const T* xf = x + (long)f * hw * C + 2 * cp;
-      const int g = (2 * cp) >= Fh;
-      for (int p = s; p < hw; p += S) {
-        float v0, v1;
-        Pair<T>::load(xf + (long)p * C, v0, v1);
-        const float gt = sg[2 * p + g];
-        x0 += v0; x1 += v1;
-        y0 += v0 * gt; y1 += v1 * gt;
-      }
-      part[s * F + 2 * cp] = y0;
-      part[s * F + 2 * cp + 1] = y1;
-      part[(S + s) * F + 2 * cp] = x0;
-      part[(S + s) * F + 2 * cp + 1] = x1;
-    }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < F; c += 256) {
-    float ys = 0.f, xs = 0.f;
-    for (int s = 0; s < S; ++s) {
-      ys += part[s * F + c];
-      xs += part[(S + s) * F + c];
-    }
-    ysum[(long)f * F + c] = ys;
-    xsum[(long)f * F + c] = xs;
-  }
+  gsf_spatial_sums<bf16_t>(x, (long)f, hw, C, F, sg, part, ysum, xsum);
 }
 
 extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
@@ -293,17 +402,27 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
   TD_CHECK(smem2 <= 64 * 1024, "gsf_gate: frame too large for the gate/sum pass (%d px)", hw);
   hipStream_t st = (hipStream_t)stream;
   bool mfma_done = false;
-  if (dtype == TDEED_BF16 && wqf) {
+  if (dtype == TDEED_BF16 && wqf && (F % 8 == 0 || F + 4 <= C)) {   // the staging reads whole 16-byte chunks
     const int nch = (F + 7) / 8;
     int ps16 = nch + 1;
     if ((ps16 & 1) == 0) ++ps16;
     const int PSQ = ps16 * 16, KSq = (9 * nch + 3) / 4;
     const long wbytes = (long)KSq * 64 * 16;
-    int bq = (int)((60 * 1024 - wbytes) / ((long)(w + 2) * PSQ)) - 2;
+    int bq = (int)((60 * 1024 - wbytes - 8L * F) / ((long)(w + 2) * PSQ)) - 2;
+    const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F) * sizeof(float);
+    // opt-in (TDEED_GSF_MERGE=1): one launch fewer, but the three staging phases run back to back inside each
+    // workgroup and the site gets slower on MI355X (85 vs 52 us at 14x14, F=40, 400 frames)
+    static const bool merge_ok = getenv("TDEED_GSF_MERGE") && atoi(getenv("TDEED_GSF_MERGE")) == 1;
+    if (merge_ok && sm3 <= 64 * 1024) {
+      hipLaunchKernelGGL(gsf_gate3_mfma_kernel, dim3(B * T), dim3(256), sm3, st, (const bf16_t*)x, T, h, w, C, F, nch,
+                         PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, b3d, gate, ysum, xsum);
+      TD_LAUNCH_CHECK("gsf_gate3");
+      return TDEED_OK;
+    }
     if (bq >= 1) {
       if (bq > h) bq = h;
       const int nbq = cdiv(h, bq);
-      const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ;
+      const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ + (size_t)8 * F;
       hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(B * T, nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
                          nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q);
       mfma_done = true;
@@ -510,6 +629,157 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_kernel(const T* __restric
   }
 }
 
+// bf16 throughput form of the same launch, built around loads in flight: the frame's channels [0,Fp), the
+// channels of its two temporal neighbours, the three gate maps and the five rows of spatial sums the fusion conv
+// touches are all fetched in wide batches into LDS (clamped addresses, no branches around loads); the blend and the
+// channel interleave then run out of LDS and leave as 8-byte stores.
+__global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t* __restrict__ x,
+                                                                   const float* __restrict__ gate,
+                                                                   const float* __restrict__ ysum,
+                                                                   const float* __restrict__ xsum, float inv_hw,
+                                                                   const float* __restrict__ cw1,
+                                                                   const float* __restrict__ cb1,
+                                                                   const float* __restrict__ cw2,
+                                                                   const float* __restrict__ cb2, int T_len, int hw,
+                                                                   int C, int F, int Fp, int pchunk,
+                                                                   bf16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sma[];
+  const long f = blockIdx.x;
+  const int t = (int)(f % T_len);
+  const long b = f / T_len;
+  const int Fh = F >> 1, Fq = F >> 2, tid = threadIdx.x;
+  float* ssum = reinterpret_cast<float*>(sma);                 // [2][5][F]: ysum, xsum of frames t-2 .. t+2 (0 outside)
+  float* fwl = ssum + 10 * F;                                   // [F] fusion weight, indexed by source channel
+  float* cwl = fwl + F;                                         // [2][18] conv weights, [2] biases
+  float* gc = cwl + 40;                                         // [pchunk][2] gates of this frame
+  float* gs = gc + 2 * pchunk;                                  // [pchunk][2] gate 0 of frame t+1 | gate 1 of frame t-1
+  bf16_t* xc = reinterpret_cast<bf16_t*>(gs + 2 * pchunk);      // [pchunk][Fp] this frame
+  bf16_t* xs = xc + (size_t)pchunk * Fp;                        // [pchunk][Fp] c < Fh: frame t+1, else frame t-1
+  const bool has_next = t < T_len - 1, has_prev = t > 0;
+  const long fn = has_next ? f + 1 : f, fp = has_prev ? f - 1 : f;
+  const int npc = Fp >> 2;                                      // 4-channel pieces per pixel
+  // ---- issue first: spatial sums of the 5 frames around t (F <= 256 -> at most 10 per lane), conv weights
+  float sv[10];
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const int i = min(tid + u * 256, 10 * F - 1);
+    const int arr = i / (5 * F), r = (i / F) % 5, c = i % F;
+    const int t2 = min(max(t + r - 2, 0), T_len - 1);
+    sv[u] = (arr ? xsum : ysum)[(b * T_len + t2) * F + c];
+  }
+  const float cwv = *(tid < 18 ? cw1 + tid : tid < 36 ? cw2 + (tid - 18) : tid == 36 ? cb1 : cb2);
+  for (int p0 = 0; p0 < hw; p0 += pchunk) {
+    const int pn = min(pchunk, hw - p0);
+    const int total = pn * npc;
+    __syncthreads();
+    // gates (one float2 per pixel from each of the three frames) and activations (8-byte pieces, three frames):
+    // the first batch of both is issued before anything is written, so one memory round trip covers sums + gates + x
+    for (int it = 0; it * 1024 < total || it * 512 < pn; ++it) {
+      f32x2 ga[2], gn_[2], gp_[2];
+      u32x2 vc[4], vn[4], vp[4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = p0 + min(it * 512 + tid + u * 256, pn - 1);
+        ga[u] = *reinterpret_cast<const f32x2*>(gate + (f * hw + p) * 2);
+        gn_[u] = *reinterpret_cast<const f32x2*>(gate + (fn * hw + p) * 2);
+        gp_[u] = *reinterpret_cast<const f32x2*>(gate + (fp * hw + p) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(it * 1024 + tid + u * 256, total - 1);
+        const int pj = i % npc, p = p0 + i / npc;
+        const long off = (long)p * C + pj * 4;
+        vc[u] = *reinterpret_cast<const u32x2*>(x + f * hw * C + off);
+        vn[u] = *reinterpret_cast<const u32x2*>(x + fn * hw * C + off);
+        vp[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
+      }
+      if (p0 == 0 && it == 0) {
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+          const int i = tid + u * 256;
+          if (i < 10 * F) {
+            const int t2 = t + (i / F) % 5 - 2;
+            ssum[i] = (t2 >= 0 && t2 < T_len) ? sv[u] : 0.f;
+          }
+        }
+        if (tid < 38) cwl[tid] = cwv;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = it * 512 + tid + u * 256;
+        if (i < pn) {
+          gc[2 * i] = ga[u][0];
+          gc[2 * i + 1] = ga[u][1];
+          gs[2 * i] = has_next ? gn_[u][0] : 0.f;
+          gs[2 * i + 1] = has_prev ? gp_[u][1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = it * 1024 + tid + u * 256;
+        if (i < total) {
+          const int pj = i % npc, pl_ = i / npc;
+          *reinterpret_cast<u32x2*>(xc + (long)pl_ * Fp + pj * 4) = vc[u];
+          const bf16x4 n4 = *reinterpret_cast<const bf16x4*>(&vn[u]);
+          const bf16x4 p4 = *reinterpret_cast<const bf16x4*>(&vp[u]);
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (pj * 4 + e < Fh) ? n4[e] : p4[e];
+          *reinterpret_cast<bf16x4*>(xs + (long)pl_ * Fp + pj * 4) = o4;
+        }
+      }
+    }
+    __syncthreads();
+    if (p0 == 0) {
+      // fusion weights of this frame: 3x3 conv over the (channel, time) plane of the spatial means + sigmoid
+      for (int c = tid; c < F; c += 256) {
+        const int g = c >= Fh;
+        const int cl = c - g * Fh;
+        const float* cw = cwl + 18 * g;
+        float a = cwl[36 + g];
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+          const int c2 = cl + dc;
+          if (c2 < 0 || c2 >= Fh) continue;
+          const int cc = g * Fh + c2;
+#pragma unroll
+          for (int dt = -1; dt <= 1; ++dt) {
+            const int t2 = t + dt;
+            if (t2 < 0 || t2 >= T_len) continue;
+            const float rm = (ssum[(5 + dt + 2) * F + cc] - ssum[(dt + 2) * F + cc]) * inv_hw;
+            const int r2 = dt + 2 + (g ? -1 : 1);                 // row of the shifted source frame (zeros outside the clip)
+            const float ysh = ssum[r2 * F + cc] * inv_hw;
+            a = fmaf(cw[(dc + 1) * 3 + (dt + 1)], ysh, a);
+            a = fmaf(cw[9 + (dc + 1) * 3 + (dt + 1)], rm, a);
+          }
+        }
+        fwl[c] = sigmoidf_(a);
+      }
+      __syncthreads();
+    }
+    for (int idx = tid; idx < total; idx += 256) {
+      const int qd = idx % npc, pl_ = idx / npc;
+      const bf16_t* xr = xc + (long)pl_ * Fp;
+      const bf16_t* sr = xs + (long)pl_ * Fp;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = qd * 4 + e;
+        if (co >= F) { o[e] = xr[co]; continue; }
+        const int g = co >= Fh;
+        const int col = co - g * Fh;
+        const int ci = g * Fh + (col & 1) * Fq + (col >> 1);
+        const float xv = (float)xr[ci];
+        const float r = xv - gc[2 * pl_ + g] * xv;
+        const float ysh = gs[2 * pl_ + g] * (float)sr[ci];
+        const float wv = fwl[ci];
+        o[e] = (bf16_t)(ysh * wv + r * (1.0f - wv));
+      }
+      *reinterpret_cast<bf16x4*>(out + (f * hw + p0 + pl_) * Fp + qd * 4) = o;
+    }
+  }
+}
+
 extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
                                          const float* cw1, const float* cb1, const float* cw2, const float* cb2,
                                          int B, int T, int h, int w, int C, int F, int Fp, void* out, int dtype,
@@ -523,9 +793,16 @@ extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(gsf_apply_fused_kernel<float>, dim3(B * T), dim3(256), smem, st, (const float*)x, gate, ysum,
                        xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (float*)out);
-  else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(gsf_apply_fused_kernel<bf16_t>, dim3(B * T), dim3(256), smem, st, (const bf16_t*)x, gate, ysum,
-                       xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (bf16_t*)out);
+  else if (dtype == TDEED_BF16) {
+    // pixels per LDS chunk: (2 gate pairs fp32 + 2 x Fp bf16) per pixel next to the fixed tables, within 60 KB
+    const long fixed = (long)(11 * F + 40) * sizeof(float);
+    long pchunk = (60 * 1024 - fixed) / (16 + 4L * Fp);
+    TD_CHECK(pchunk >= 1 && F <= 256, "gsf_apply_fused: fold %d too wide", F);
+    if (pchunk > hw) pchunk = hw;
+    const size_t smb = (size_t)fixed + (size_t)pchunk * (16 + 4 * Fp);
+    hipLaunchKernelGGL(gsf_apply_fused_bf16_kernel, dim3(B * T), dim3(256), smb, st, (const bf16_t*)x, gate, ysum, xsum,
+                       1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (int)pchunk, (bf16_t*)out);
+  }
   else { tdeed_set_error("gsf_apply_fused: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("gsf_apply_fused");
   return TDEED_OK;
