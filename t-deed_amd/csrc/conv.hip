@@ -625,42 +625,65 @@ extern "C" int tdeed_se_gate_bf16_fwd(const float* pooled, int n_parts, float in
 }
 
 // =========================================================================== avg-pool + pos-enc
+// One workgroup per frame, 256 lanes = (pixel slice, channel chunk); every lane fetches its pixels in batches of 8
+// independent loads (a plain accumulate loop costs one memory round trip per pixel), then an ordered reduce in LDS.
 template <typename T>
-__global__ void avgpool_posenc_kernel(const T* __restrict__ x, int T_len, int hw, int C,
-                                      const float* __restrict__ temp_enc, T* __restrict__ feat) {
+__global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict__ x, int T_len, int hw, int C,
+                                                             const float* __restrict__ temp_enc,
+                                                             T* __restrict__ feat) {
   constexpr int EPC = Chunk<T>::N;
+  extern __shared__ float red[];       // [S][C]
   const int f = blockIdx.x;            // frame = b*T + t
   const int t = f % T_len;
-  const int c0 = threadIdx.x * EPC;
-  if (c0 >= C) return;
-  float a[EPC];
+  const int nch = C / EPC;
+  const int S = 256 / nch > 0 ? 256 / nch : 1;
+  for (int ch = threadIdx.x % nch, s = threadIdx.x / nch; s < S && ch < nch; ch += 256) {   // one pass when nch <= 256
+    const int c0 = ch * EPC;
+    float a[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) a[e] = 0.f;
-  const T* src = x + (long)f * hw * C + c0;
-  for (int p = 0; p < hw; ++p) {
-    float v[EPC];
-    Chunk<T>::load(src + (long)p * C, v);
+    for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+    const T* src = x + (long)f * hw * C + c0;
+    for (int p0 = s; p0 < hw; p0 += S * 8) {
+      float v[8][EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) a[e] += v[e];
+      for (int b = 0; b < 8; ++b) Chunk<T>::load(src + (long)min(p0 + b * S, hw - 1) * C, v[b]);
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (p0 + b * S < hw) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) a[e] += v[b][e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[s * C + c0 + e] = a[e];
   }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < nch; ch += 256) {
+    const int c0 = ch * EPC;
+    float a[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) a[e] = a[e] / (float)hw + temp_enc[(long)t * C + c0 + e];
-  Chunk<T>::store(feat + (long)f * C + c0, a);
+    for (int e = 0; e < EPC; ++e) {
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += red[s * C + c0 + e];
+      a[e] = v / (float)hw + temp_enc[(long)t * C + c0 + e];
+    }
+    Chunk<T>::store(feat + (long)f * C + c0, a);
+  }
 }
 
 extern "C" int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
                                         void* feat, int dtype, void* stream) {
   TD_CHECK(x && temp_enc && feat, "avgpool: null pointer");
-  TD_CHECK(B > 0 && T > 0 && hw > 0 && C > 0 && C % 8 == 0, "avgpool: bad sizes");
+  TD_CHECK(B > 0 && T > 0 && hw > 0 && C > 0 && C % 8 == 0 && C <= 2048, "avgpool: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32) {
-    int thr = cdiv(C / 4, 64) * 64;
-    hipLaunchKernelGGL(avgpool_posenc_kernel<float>, dim3(B * T), dim3(thr), 0, st, (const float*)x, T, hw, C,
-                       temp_enc, (float*)feat);
+    const int nch = C / 4, S = 256 / nch > 0 ? 256 / nch : 1;
+    hipLaunchKernelGGL(avgpool_posenc_kernel<float>, dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
+                       (const float*)x, T, hw, C, temp_enc, (float*)feat);
   } else if (dtype == TDEED_BF16) {
-    int thr = cdiv(C / 8, 64) * 64;
-    hipLaunchKernelGGL(avgpool_posenc_kernel<bf16_t>, dim3(B * T), dim3(thr), 0, st, (const bf16_t*)x, T, hw, C,
-                       temp_enc, (bf16_t*)feat);
+    const int nch = C / 8, S = 256 / nch > 0 ? 256 / nch : 1;
+    hipLaunchKernelGGL(avgpool_posenc_kernel<bf16_t>, dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
+                       (const bf16_t*)x, T, hw, C, temp_enc, (bf16_t*)feat);
   } else { tdeed_set_error("avgpool: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("avgpool_posenc");
   return TDEED_OK;

@@ -109,12 +109,12 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, in
 
 // store a [T][16] fp32 LDS tile to dst rows (stride ld), optionally adding `add` (same geometry as dst)
 template <typename T>
-__device__ __forceinline__ void store_tile(const float* res, T* __restrict__ dst, long ld, int T_len, int c0,
-                                           int C, const T* __restrict__ add, long ld_add) {
+__device__ __forceinline__ void store_tile(const float* res, T* __restrict__ dst, long ld, int t_begin, int t_end,
+                                           int c0, int C, const T* __restrict__ add, long ld_add) {
   constexpr int EPC = Chunk<T>::N;
   constexpr int CPR = SGP_CH / EPC;
-  for (int i = threadIdx.x; i < T_len * CPR; i += 256) {
-    int t = i / CPR, ck = i - t * CPR;
+  for (int i = threadIdx.x; i < (t_end - t_begin) * CPR; i += 256) {
+    int t = t_begin + i / CPR, ck = i % CPR;
     if (c0 + ck * EPC >= C) continue;
     float v[EPC];
 #pragma unroll
@@ -137,6 +137,80 @@ __device__ __forceinline__ void load_dw(const float* __restrict__ dw, int wlen, 
   }
 }
 
+// ---- two-phase staging: every global load of a kernel is ISSUED (branch-free, clamped addresses) before anything
+// is written to LDS, so tiles, weights and biases share one memory round trip instead of one each.
+constexpr int SGP_TI = 4;       // tile items per lane: T * (16 / EPC) <= 1024
+constexpr int SGP_WI = 5;       // weight items per lane: wlen * 16 <= 1280
+
+template <typename T>
+__device__ __forceinline__ void tile_issue(const T* __restrict__ src, long ld, int T_len, int c0, int C,
+                                           float (&v)[SGP_TI][Chunk<T>::N]) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int CPR = SGP_CH / EPC;
+  const int n = T_len * CPR;
+#pragma unroll
+  for (int u = 0; u < SGP_TI; ++u) {
+    const int i = min((int)threadIdx.x + u * 256, n - 1);
+    const int t = i / CPR, ck = i - t * CPR;
+    const int cc = min(c0 + ck * EPC, C - EPC);                 // channel chunks past C are zeroed at commit
+    Chunk<T>::load(src + (long)t * ld + cc, v[u]);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void tile_commit(const float (&v)[SGP_TI][Chunk<T>::N], int T_len, int c0, int C,
+                                            float* tile, int halo) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int CPR = SGP_CH / EPC;
+  const int n = T_len * CPR;
+  for (int i = threadIdx.x; i < 2 * halo * SGP_CH; i += 256) {
+    int r = i / SGP_CH, c = i - r * SGP_CH;
+    int row = r < halo ? r : (T_len + r);
+    tile[row * SGP_CH + c] = 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < SGP_TI; ++u) {
+    const int i = threadIdx.x + u * 256;
+    if (i < n) {
+      const int t = i / CPR, ck = i - t * CPR;
+      const bool ok = c0 + ck * EPC < C;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) tile[(halo + t) * SGP_CH + ck * EPC + e] = ok ? v[u][e] : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void dw_issue(const float* __restrict__ dw, int wlen, int c0, int C, float (&w)[SGP_WI]) {
+  const int n = wlen * SGP_CH;
+#pragma unroll
+  for (int u = 0; u < SGP_WI; ++u) {
+    const int i = min((int)threadIdx.x + u * 256, n - 1);
+    const int c = i / wlen, k = i - c * wlen;
+    w[u] = dw[(long)min(c0 + c, C - 1) * wlen + k];
+  }
+}
+
+__device__ __forceinline__ void dw_commit(const float (&w)[SGP_WI], int wlen, int c0, int C, float* wl) {
+  const int n = wlen * SGP_CH;
+#pragma unroll
+  for (int u = 0; u < SGP_WI; ++u) {
+    const int i = threadIdx.x + u * 256;
+    if (i < n) {
+      const int c = i / wlen, k = i - c * wlen;
+      wl[k * SGP_CH + c] = (c0 + c < C) ? w[u] : 0.f;
+    }
+  }
+}
+
+struct Bias5 { float psi, cw, ckw, fc, g; };
+__device__ __forceinline__ Bias5 bias_issue(const float* __restrict__ bias5, long bstride, int cglob, int C) {
+  const int cc = min(cglob, C - 1);
+  Bias5 b;
+  b.psi = bias5[cc]; b.cw = bias5[bstride + cc]; b.ckw = bias5[2 * bstride + cc];
+  b.fc = bias5[3 * bstride + cc]; b.g = bias5[4 * bstride + cc];
+  return b;
+}
+
 // mean over T of the tile per channel; result broadcast through red[16]
 __device__ __forceinline__ void tile_mean(const float* tile, int T_len, int halo, float* red /*[17][16]*/) {
   const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
@@ -155,13 +229,11 @@ __device__ __forceinline__ void tile_mean(const float* tile, int T_len, int halo
 
 struct BranchOut { float conv_gate; float inst; };   // (convw+convkw)*psi ,  fc*phi
 
-__device__ __forceinline__ BranchOut branch_eval(const float* tile, const float* wl, const float* bias5,
-                                                 long bstride, int cglob, bool cok, int t, int c, int halo,
-                                                 int ks, int up, float mean_c) {
-  // bias5: [5][C] psi, convw, convkw, fc, gfc
-  const float b_psi = cok ? bias5[cglob] : 0.f, b_cw = cok ? bias5[bstride + cglob] : 0.f,
-              b_ckw = cok ? bias5[2 * bstride + cglob] : 0.f, b_fc = cok ? bias5[3 * bstride + cglob] : 0.f,
-              b_g = cok ? bias5[4 * bstride + cglob] : 0.f;
+__device__ __forceinline__ BranchOut branch_eval(const float* tile, const float* wl, const Bias5& bb, bool cok,
+                                                 int t, int c, int halo, int ks, int up, float mean_c) {
+  // bb: biases of psi, convw, convkw, fc, gfc for this lane's channel
+  const float b_psi = cok ? bb.psi : 0.f, b_cw = cok ? bb.cw : 0.f, b_ckw = cok ? bb.ckw : 0.f,
+              b_fc = cok ? bb.fc : 0.f, b_g = cok ? bb.g : 0.f;
   const float* col = tile + (halo + t) * SGP_CH + c;
   float psi = b_psi, cw = b_cw, ckw = b_ckw;
   const int hk = ks >> 1, hu = up >> 1;
@@ -195,19 +267,26 @@ __global__ __launch_bounds__(256) void sgp_branch_kernel(const T* __restrict__ o
   float* red = wl + wlen * SGP_CH;                    // [17][16]
   const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
   const long base = (long)b * T_len * C;
-  load_tile<T>(o + base, C, T_len, c0, C, tile, halo);
-  load_dw(dw, wlen, c0, C, wl);
-  __syncthreads();
-  tile_mean(tile, T_len, halo, red);
   const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const bool cok = c0 + c < C;
+  float tv[SGP_TI][Chunk<T>::N], wv[SGP_WI];
+  tile_issue<T>(o + base, C, T_len, c0, C, tv);
+  dw_issue(dw, wlen, c0, C, wv);
+  const Bias5 bb = bias_issue(db, C, c0 + c, C);
+  tile_commit<T>(tv, T_len, c0, C, tile, halo);
+  dw_commit(wv, wlen, c0, C, wl);
+  __syncthreads();
+  tile_mean(tile, T_len, halo, red);
   const float mean_c = red[16 * SGP_CH + c];
-  for (int t = tl; t < T_len; t += 16) {
-    BranchOut r = branch_eval(tile, wl, db, C, c0 + c, cok, t, c, halo, ks, up, mean_c);
+  // blockIdx.z owns a slice of the time axis (the whole tile is staged by every slice: the mean needs all of T)
+  const int tper = (T_len + gridDim.z - 1) / gridDim.z;
+  const int t_begin = blockIdx.z * tper, t_end = min(T_len, t_begin + tper);
+  for (int t = t_begin + tl; t < t_end; t += 16) {
+    BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);
     res[t * SGP_CH + c] = r.inst + r.conv_gate + tile[(halo + t) * SGP_CH + c];
   }
   __syncthreads();
-  store_tile<T>(res, y + base, C, T_len, c0, C, x + base, C);
+  store_tile<T>(res, y + base, C, t_begin, t_end, c0, C, x + base, C);
 }
 
 static size_t sgp_smem(int T_len, int ks, int up, int ntiles, int nres) {
@@ -220,6 +299,7 @@ extern "C" int tdeed_sgp_branch_fwd(const void* o, const void* x, int B, int T, 
                                     const float* dw, const float* db, void* y, int dtype, void* stream) {
   TD_CHECK(o && x && dw && db && y, "sgp_branch: null pointer");
   TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_branch: bad sizes");
+  TD_CHECK(T <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80, "sgp_branch: T=%d / ks=%d up=%d beyond the staging registers", T, ks, up);
   size_t smem = sgp_smem(T, ks, up, 1, 1);
   TD_CHECK(smem <= 64 * 1024, "sgp_branch: T=%d too long for the LDS window", T);
   dim3 grid(B, cdiv(C, SGP_CH));
@@ -256,18 +336,27 @@ __global__ __launch_bounds__(256) void mixer_branch_kernel(const T* __restrict__
   const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
   const long ldc = 6L * C;
   T* crow = cat + (long)b * T_hi * ldc;
-  load_tile<T>(crow + 4L * C, ldc, T_hi, c0, C, zt, halo);
-  // xn at T_lo -> res (no halo), then linear up-sampling (align_corners=True) into xt
-  load_tile<T>(xn + (long)b * T_lo * C, C, T_lo, c0, C, res, 0);
-  load_dw(dw1, wlen, c0, C, wl1);
-  load_dw(dw2, wlen, c0, C, wl2);
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const bool cok = c0 + c < C;
+  {
+    float zv[SGP_TI][Chunk<T>::N], xv[SGP_TI][Chunk<T>::N], w1v[SGP_WI], w2v[SGP_WI];
+    tile_issue<T>(crow + 4L * C, ldc, T_hi, c0, C, zv);
+    tile_issue<T>(xn + (long)b * T_lo * C, C, T_lo, c0, C, xv);
+    dw_issue(dw1, wlen, c0, C, w1v);
+    dw_issue(dw2, wlen, c0, C, w2v);
+    tile_commit<T>(zv, T_hi, c0, C, zt, halo);
+    // xn at T_lo -> res (no halo), then linear up-sampling (align_corners=True) into xt
+    tile_commit<T>(xv, T_lo, c0, C, res, 0);
+    dw_commit(w1v, wlen, c0, C, wl1);
+    dw_commit(w2v, wlen, c0, C, wl2);
+  }
+  const Bias5 bb1 = bias_issue(db1, C, c0 + c, C), bb2 = bias_issue(db2, C, c0 + c, C);
   for (int i = threadIdx.x; i < 2 * halo * SGP_CH; i += 256) {
     int r = i / SGP_CH, c = i - r * SGP_CH;
     int row = r < halo ? r : (T_hi + r);
     xt[row * SGP_CH + c] = 0.f;
   }
   __syncthreads();
-  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
   {
     const float scale = (T_hi > 1) ? (float)(T_lo - 1) / (float)(T_hi - 1) : 0.f;
     for (int t = tl; t < T_hi; t += 16) {
@@ -287,33 +376,35 @@ __global__ __launch_bounds__(256) void mixer_branch_kernel(const T* __restrict__
     }
   }
   __syncthreads();
+  // blockIdx.z owns a slice of the time axis; the tiles (and the means over all of T) are staged by every slice
+  const int tper = (T_hi + gridDim.z - 1) / gridDim.z;
+  const int t_begin = blockIdx.z * tper, t_end = min(T_hi, t_begin + tper);
   // slab 5 = xu
-  for (int t = tl; t < T_hi; t += 16) res[t * SGP_CH + c] = xt[(halo + t) * SGP_CH + c];
+  for (int t = t_begin + tl; t < t_end; t += 16) res[t * SGP_CH + c] = xt[(halo + t) * SGP_CH + c];
   __syncthreads();
-  store_tile<T>(res, crow + 5L * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
+  store_tile<T>(res, crow + 5L * C, ldc, t_begin, t_end, c0, C, (const T*)nullptr, 0);
   tile_mean(zt, T_hi, halo, red);
   const float mz = red[16 * SGP_CH + c];
   __syncthreads();
   tile_mean(xt, T_hi, halo, red);
   const float mx = red[16 * SGP_CH + c];
-  const bool cok = c0 + c < C;
   // one sweep per source: out1 (slab 0) and out3 (slab 2) from z, then out2 (slab 1) and out4 (slab 3) from x;
   // each branch_eval yields both products, staged in two [T][16] tiles (res, res2) and stored as 16-byte chunks
   float* res2 = red + 17 * SGP_CH;
   for (int src = 0; src < 2; ++src) {
     const float* tile = src == 0 ? zt : xt;
     const float* wl = src == 0 ? wl1 : wl2;
-    const float* db = src == 0 ? db1 : db2;
+    const Bias5 bb = src == 0 ? bb1 : bb2;
     const float mean_c = src == 0 ? mz : mx;
     __syncthreads();
-    for (int t = tl; t < T_hi; t += 16) {
-      BranchOut r = branch_eval(tile, wl, db, C, c0 + c, cok, t, c, halo, ks, up, mean_c);
+    for (int t = t_begin + tl; t < t_end; t += 16) {
+      BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);
       res[t * SGP_CH + c] = r.conv_gate;
       res2[t * SGP_CH + c] = r.inst;
     }
     __syncthreads();
-    store_tile<T>(res, crow + (long)src * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
-    store_tile<T>(res2, crow + (long)(2 + src) * C, ldc, T_hi, c0, C, (const T*)nullptr, 0);
+    store_tile<T>(res, crow + (long)src * C, ldc, t_begin, t_end, c0, C, (const T*)nullptr, 0);
+    store_tile<T>(res2, crow + (long)(2 + src) * C, ldc, t_begin, t_end, c0, C, (const T*)nullptr, 0);
   }
 }
 
@@ -323,6 +414,7 @@ extern "C" int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo,
   TD_CHECK(xn && dw1 && db1 && dw2 && db2 && cat, "mixer_branch: null pointer");
   TD_CHECK(B > 0 && T_hi >= T_lo && T_lo > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks,
            "mixer_branch: bad sizes");
+  TD_CHECK(T_hi <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80, "mixer_branch: T=%d / ks=%d up=%d beyond the staging registers", T_hi, ks, up);
   size_t smem = sgp_smem(T_hi, ks, up, 2, 2);
   TD_CHECK(smem <= 128 * 1024, "mixer_branch: T=%d too long for the LDS window", T_hi);
   static bool attr_set = false;
