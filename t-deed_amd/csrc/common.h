@@ -116,3 +116,27 @@ __device__ __forceinline__ long xcd_logical_id(long bid, long nwg) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Division by a run-time constant without the ~25-instruction integer-divide sequence (index arithmetic of the
+// staging loops is otherwise a large share of the instructions of the small latency-bound kernels): float
+// reciprocal estimate + one-step fix-up, exact for 0 <= i < 2^22.
+struct IDiv {
+  int d;
+  float r;
+  __device__ __forceinline__ explicit IDiv(int d_) : d(d_), r(1.0f / (float)d_) {}
+  __device__ __forceinline__ int div(int i) const {
+    int q = (int)((float)i * r);
+    const int rem = i - q * d;
+    q += (rem >= d) ? 1 : 0;
+    q -= (rem < 0) ? 1 : 0;
+    return q;
+  }
+  __device__ __forceinline__ void divmod(int i, int& q, int& m) const {
+    q = div(i);
+    m = i - q * d;
+  }
+};
+
+// compiler-level fence: keeps the loads issued above it ahead of the LDS writes below it (the scheduler otherwise
+// interleaves them and every write waits on its own load)
+#define TD_ISSUE_FENCE() asm volatile("" ::: "memory")

@@ -143,19 +143,22 @@ __device__ __forceinline__ void gsf_stage_frame(unsigned char* a, const bf16_t* 
   const int cpp = PSQ >> 4;                                     // 16-byte pieces per pixel incl. pad
   const int total = rows * WP * cpp;
   const bf16_t* xf = x + f * h * w * C;
+  const IDiv dcpp(cpp), dwp(WP);
   for (int i0 = tid; i0 < total; i0 += 256 * 8) {
     u32x4 v[8];
     int cj[8];
 #pragma unroll
     for (int b8 = 0; b8 < 8; ++b8) {
       const int i = min(i0 + b8 * 256, total - 1);
-      const int j = i % cpp, pix = i / cpp;
-      const int ry = pix / WP, rx = pix - ry * WP;
+      int j, pix, ry, rx;
+      dcpp.divmod(i, pix, j);
+      dwp.divmod(pix, ry, rx);
       const int yy = y0 - 1 + ry, xx = rx - 1;
       const bool ok = j < nch && yy >= 0 && yy < h && xx >= 0 && xx < w;
       cj[b8] = ok ? j : -1;
       v[b8] = *reinterpret_cast<const u32x4*>(ok ? xf + ((long)yy * w + xx) * C + j * 8 : xf);
     }
+    TD_ISSUE_FENCE();
 #pragma unroll
     for (int b8 = 0; b8 < 8; ++b8) {
       const int i = i0 + b8 * 256;
@@ -202,7 +205,13 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
   unsigned char* a = smq + (size_t)KS * 64 * 16;               // [rows][WP][PSQ]
   float* sbn = reinterpret_cast<float*>(a + (size_t)(band + 2) * WP * PSQ);   // [2F]
+  int* soff = reinterpret_cast<int*>(sbn + 2 * F);              // [KS*4]
   const int tid = threadIdx.x;
+  for (int s_ = tid; s_ < KS * 4; s_ += 256) {                  // byte offset of every k-slot (tap, 8-channel chunk)
+    const int tap = s_ / nch, ck = s_ - tap * nch;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    soff[s_] = tap < 9 ? (dy * WP + dx) * PSQ + ck * 16 : 0;
+  }
   gsf_stage_bn(sbn, bn_scale, bn_shift, F);
   copy16_batched(reinterpret_cast<u32x4*>(wl), reinterpret_cast<const u32x4*>(wqf), KS * 64);
   __syncthreads();
@@ -211,19 +220,17 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   const int lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
   const int npix = (y1 - y0) * w;
   const int ntl = (npix + 15) >> 4;
+  const IDiv dw_(w);
   for (int mt = wv; mt < ntl; mt += 4) {
     const int p = mt * 16 + pl;
     const bool pok = p < npix;
     const int pc = pok ? p : 0;
-    const int py = pc / w, px = pc - py * w;
+    int py, px;
+    dw_.divmod(pc, py, px);
     const unsigned char* base = a + ((long)py * WP + px) * PSQ;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < KS; ++ks) {
-      const int s_ = 4 * ks + q;
-      const int tap = s_ / nch, ck = s_ - tap * nch;
-      const bool sok = tap < 9;
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + (sok ? ((dy * WP + dx) * PSQ + ck * 16) : 0));
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + soff[ks * 4 + q]);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks * 64 + lane], af, acc, 0, 0, 0);
     }
     if (pok) {
@@ -335,7 +342,13 @@ __global__ __launch_bounds__(256) void gsf_gate3_mfma_kernel(const bf16_t* __res
   float* sg = reinterpret_cast<float*>(a + (size_t)(h + 2) * WP * PSQ);   // [hw][2] gate pre-activations
   float* part = sg + 2 * hw;                                    // [2][S][F], S*F = 512
   float* sbn = part + 1024;                                     // [2F]
+  int* soff = reinterpret_cast<int*>(sbn + 2 * F);              // [KS*4]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  for (int s_ = tid; s_ < KS * 4; s_ += 256) {                  // byte offset of every k-slot (tap, 8-channel chunk)
+    const int tap = s_ / nch, ck = s_ - tap * nch;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    soff[s_] = tap < 9 ? (dy * WP + dx) * PSQ + ck * 16 : 0;
+  }
   gsf_stage_bn(sbn, bn_scale, bn_shift, F);
   copy16_batched(reinterpret_cast<u32x4*>(wl), reinterpret_cast<const u32x4*>(wqf), KS * 64);
   {
@@ -357,11 +370,7 @@ __global__ __launch_bounds__(256) void gsf_gate3_mfma_kernel(const bf16_t* __res
       const unsigned char* base = a + ((long)py * WP + px) * PSQ;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < KS; ++ks) {
-        const int s_ = 4 * ks + q;
-        const int tap = s_ / nch, ck = s_ - tap * nch;
-        const bool sok = tap < 9;
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + (sok ? ((dy * WP + dx) * PSQ + ck * 16) : 0));
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + soff[ks * 4 + q]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks * 64 + lane], af, acc, 0, 0, 0);
       }
       if (pok && q == own_q) {
@@ -408,8 +417,8 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     if ((ps16 & 1) == 0) ++ps16;
     const int PSQ = ps16 * 16, KSq = (9 * nch + 3) / 4;
     const long wbytes = (long)KSq * 64 * 16;
-    int bq = (int)((60 * 1024 - wbytes - 8L * F) / ((long)(w + 2) * PSQ)) - 2;
-    const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F) * sizeof(float);
+    int bq = (int)((60 * 1024 - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
+    const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F + 4 * KSq) * sizeof(float);
     // opt-in (TDEED_GSF_MERGE=1): one launch fewer, but the three staging phases run back to back inside each
     // workgroup and the site gets slower on MI355X (85 vs 52 us at 14x14, F=40, 400 frames)
     static const bool merge_ok = getenv("TDEED_GSF_MERGE") && atoi(getenv("TDEED_GSF_MERGE")) == 1;
@@ -422,7 +431,7 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     if (bq >= 1) {
       if (bq > h) bq = h;
       const int nbq = cdiv(h, bq);
-      const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ + (size_t)8 * F;
+      const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ + (size_t)8 * F + (size_t)16 * KSq;
       hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(B * T, nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
                          nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q);
       mfma_done = true;
@@ -659,75 +668,94 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
   const long fn = has_next ? f + 1 : f, fp = has_prev ? f - 1 : f;
   const int npc = Fp >> 2;                                      // 4-channel pieces per pixel
   // ---- issue first: spatial sums of the 5 frames around t (F <= 256 -> at most 10 per lane), conv weights
+  const IDiv dF(F), dnpc(npc);
   float sv[10];
 #pragma unroll
   for (int u = 0; u < 10; ++u) {
     const int i = min(tid + u * 256, 10 * F - 1);
-    const int arr = i / (5 * F), r = (i / F) % 5, c = i % F;
+    int row, c;                                                 // row = arr * 5 + r
+    dF.divmod(i, row, c);
+    const int arr = row >= 5, r = row - 5 * arr;
     const int t2 = min(max(t + r - 2, 0), T_len - 1);
     sv[u] = (arr ? xsum : ysum)[(b * T_len + t2) * F + c];
   }
   const float cwv = *(tid < 18 ? cw1 + tid : tid < 36 ? cw2 + (tid - 18) : tid == 36 ? cb1 : cb2);
+  f32x2 ga[2];
+  float gn_[2], gp_[2];     // only gate 0 of frame t+1 and gate 1 of frame t-1 are needed (a half-used wide load
+                            // leaves a dead register that gets reused while the load is in flight: WAW stall)
+  u32x2 vc[4], vn[4], vp[4];
+  // gates (one float2 per pixel from each of the three frames) and activations (8-byte pieces, three frames)
+  auto issue = [&](int p0, int pn, int total, int it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = p0 + min(it * 512 + tid + u * 256, pn - 1);
+      ga[u] = *reinterpret_cast<const f32x2*>(gate + (f * hw + p) * 2);
+      gn_[u] = gate[(fn * hw + p) * 2];
+      gp_[u] = gate[(fp * hw + p) * 2 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(it * 1024 + tid + u * 256, total - 1);
+      int pj, pq;
+      dnpc.divmod(i, pq, pj);
+      const long off = (long)(p0 + pq) * C + pj * 4;
+      vc[u] = *reinterpret_cast<const u32x2*>(x + f * hw * C + off);
+      vn[u] = *reinterpret_cast<const u32x2*>(x + fn * hw * C + off);
+      vp[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
+    }
+  };
+  auto commit = [&](int pn, int total, int it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = it * 512 + tid + u * 256;
+      if (i < pn) {
+        gc[2 * i] = ga[u][0];
+        gc[2 * i + 1] = ga[u][1];
+        gs[2 * i] = has_next ? gn_[u] : 0.f;
+        gs[2 * i + 1] = has_prev ? gp_[u] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = it * 1024 + tid + u * 256;
+      if (i < total) {
+        int pj, pl_;
+        dnpc.divmod(i, pl_, pj);
+        *reinterpret_cast<u32x2*>(xc + (long)pl_ * Fp + pj * 4) = vc[u];
+        const bf16x4 n4 = *reinterpret_cast<const bf16x4*>(&vn[u]);
+        const bf16x4 p4 = *reinterpret_cast<const bf16x4*>(&vp[u]);
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (pj * 4 + e < Fh) ? n4[e] : p4[e];
+        *reinterpret_cast<bf16x4*>(xs + (long)pl_ * Fp + pj * 4) = o4;
+      }
+    }
+  };
+  // the first batch of the first chunk travels together with the sums: one memory round trip for everything
+  {
+    const int pn = min(pchunk, hw), total = pn * npc;
+    issue(0, pn, total, 0);
+    TD_ISSUE_FENCE();
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int i = tid + u * 256;
+      if (i < 10 * F) {
+        const int row = dF.div(i);
+        const int t2 = t + (row >= 5 ? row - 5 : row) - 2;
+        ssum[i] = (t2 >= 0 && t2 < T_len) ? sv[u] : 0.f;
+      }
+    }
+    if (tid < 38) cwl[tid] = cwv;
+    commit(pn, total, 0);
+  }
   for (int p0 = 0; p0 < hw; p0 += pchunk) {
     const int pn = min(pchunk, hw - p0);
     const int total = pn * npc;
-    __syncthreads();
-    // gates (one float2 per pixel from each of the three frames) and activations (8-byte pieces, three frames):
-    // the first batch of both is issued before anything is written, so one memory round trip covers sums + gates + x
-    for (int it = 0; it * 1024 < total || it * 512 < pn; ++it) {
-      f32x2 ga[2], gn_[2], gp_[2];
-      u32x2 vc[4], vn[4], vp[4];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int p = p0 + min(it * 512 + tid + u * 256, pn - 1);
-        ga[u] = *reinterpret_cast<const f32x2*>(gate + (f * hw + p) * 2);
-        gn_[u] = *reinterpret_cast<const f32x2*>(gate + (fn * hw + p) * 2);
-        gp_[u] = *reinterpret_cast<const f32x2*>(gate + (fp * hw + p) * 2);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = min(it * 1024 + tid + u * 256, total - 1);
-        const int pj = i % npc, p = p0 + i / npc;
-        const long off = (long)p * C + pj * 4;
-        vc[u] = *reinterpret_cast<const u32x2*>(x + f * hw * C + off);
-        vn[u] = *reinterpret_cast<const u32x2*>(x + fn * hw * C + off);
-        vp[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
-      }
-      if (p0 == 0 && it == 0) {
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-          const int i = tid + u * 256;
-          if (i < 10 * F) {
-            const int t2 = t + (i / F) % 5 - 2;
-            ssum[i] = (t2 >= 0 && t2 < T_len) ? sv[u] : 0.f;
-          }
-        }
-        if (tid < 38) cwl[tid] = cwv;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = it * 512 + tid + u * 256;
-        if (i < pn) {
-          gc[2 * i] = ga[u][0];
-          gc[2 * i + 1] = ga[u][1];
-          gs[2 * i] = has_next ? gn_[u][0] : 0.f;
-          gs[2 * i + 1] = has_prev ? gp_[u][1] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = it * 1024 + tid + u * 256;
-        if (i < total) {
-          const int pj = i % npc, pl_ = i / npc;
-          *reinterpret_cast<u32x2*>(xc + (long)pl_ * Fp + pj * 4) = vc[u];
-          const bf16x4 n4 = *reinterpret_cast<const bf16x4*>(&vn[u]);
-          const bf16x4 p4 = *reinterpret_cast<const bf16x4*>(&vp[u]);
-          bf16x4 o4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = (pj * 4 + e < Fh) ? n4[e] : p4[e];
-          *reinterpret_cast<bf16x4*>(xs + (long)pl_ * Fp + pj * 4) = o4;
-        }
-      }
+    if (p0 > 0) __syncthreads();
+    for (int it = p0 == 0 ? 1 : 0; it * 1024 < total || it * 512 < pn; ++it) {
+      issue(p0, pn, total, it);
+      TD_ISSUE_FENCE();
+      commit(pn, total, it);
     }
     __syncthreads();
     if (p0 == 0) {
@@ -758,7 +786,8 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
       __syncthreads();
     }
     for (int idx = tid; idx < total; idx += 256) {
-      const int qd = idx % npc, pl_ = idx / npc;
+      int qd, pl_;
+      dnpc.divmod(idx, pl_, qd);
       const bf16_t* xr = xc + (long)pl_ * Fp;
       const bf16_t* sr = xs + (long)pl_ * Fp;
       bf16x4 o;
