@@ -249,28 +249,28 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   const bf16_t* xin = x + (long)n * Hi * Wi * C;
   // batches of 8 independent 16-B loads per thread before the LDS stores (memory-level parallelism)
   const int total = nrow_used * WP * cpp;
+  const IDiv dcpp(cpp), dwp(WP);
   for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
     u32x4 v[8];
+    bool ok[8];
 #pragma unroll
     for (int b8 = 0; b8 < 8; ++b8) {
-      const int i = i0 + b8 * 256;
-      v[b8] = (u32x4){0u, 0u, 0u, 0u};
-      if (i < total) {
-        const int j = i % cpp;
-        const int pix = i / cpp;
-        const int r = pix / WP, xx = pix - r * WP;
-        const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
-        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C)
-          v[b8] = *reinterpret_cast<const u32x4*>(xin + ((long)iy * Wi + ix) * C + c);
-      }
+      const int i = min(i0 + b8 * 256, total - 1);
+      int j, pix, r, xx;
+      dcpp.divmod(i, pix, j);
+      dwp.divmod(pix, r, xx);
+      const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
+      ok[b8] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C;
+      v[b8] = *reinterpret_cast<const u32x4*>(ok[b8] ? xin + ((long)iy * Wi + ix) * C + c : xin);   // branch-free
     }
+    TD_ISSUE_FENCE();
 #pragma unroll
     for (int b8 = 0; b8 < 8; ++b8) {
       const int i = i0 + b8 * 256;
       if (i < total) {
-        const int j = i % cpp;
-        const int pix = i / cpp;
-        *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = v[b8];
+        int j, pix;
+        dcpp.divmod(i, pix, j);
+        *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = ok[b8] ? v[b8] : (u32x4){0u, 0u, 0u, 0u};
       }
     }
   }
@@ -305,11 +305,13 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   const int npix = nrows_out * Wo;
   const int ntiles = (npix + 15) >> 4;
   bf16_t* yout = y + ((long)n * Ho + oy0) * Wo * C;
+  const IDiv dwo(Wo);
   for (int mt = wv / units; mt < ntiles; mt += mstep) {
     const int p = mt * 16 + pl;
     const bool pok = p < npix;
     const int pc = pok ? p : 0;
-    const int oyl = pc / Wo, ox = pc - oyl * Wo;
+    int oyl, ox;
+    dwo.divmod(pc, oyl, ox);
     const unsigned char* base = tile + ((long)(oyl * STRIDE) * WP + ox * STRIDE) * PS;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
