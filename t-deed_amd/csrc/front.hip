@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
       // a thread owns 16 pixels of one row: three 16-byte loads (R,G,B planes) in flight, 16 8-byte LDS stores
       const int nch = p.cw >> 4;
       const int total = nin * nch;
+      const IDiv dnch(nch);
       for (int i = tid; i < total; i += 256) {
-        const int k = i % nch, r = i / nch;
+        int k, r;
+        dnch.divmod(i, r, k);
         const int iy = in_r0 + r;
         bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)r * INW + 16 * k + 1) * 4);
         if (iy >= 0 && iy < p.ch) {
@@ -151,9 +153,12 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
     const int r_lo = max(y1r0, 0), r_hi = min(y1r0 + ny1, p.Hs);
     const int tiles_per_row = (p.Ws + 15) >> 4;
     const int ntiles = (r_hi - r_lo) * tiles_per_row;
+    const IDiv dtpr(tiles_per_row);
     for (int tI = wv; tI < ntiles; tI += 4) {
-      const int r = r_lo + tI / tiles_per_row;
-      const int c0 = (tI % tiles_per_row) * 16;
+      int rq, rm;
+      dtpr.divmod(tI, rq, rm);
+      const int r = r_lo + rq;
+      const int c0 = rm * 16;
       const int c = c0 + px;
       const bool cok = c < p.Ws;
       const int cc = cok ? c : (p.Ws - 1);
@@ -232,11 +237,13 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
     const int npix = nrows_out * p.Wo;
     const int ntl = (npix + 15) >> 4;
     bf16_t* yout = p.y2 + ((long)n * p.Ho + oy0) * p.Wo * p.C1;
+    const IDiv dwo(p.Wo);
     for (int mt = wv / units; mt < ntl; mt += mstep) {
       const int pp = mt * 16 + px;
       const bool pok = pp < npix;
       const int pc = pok ? pp : 0;
-      const int oyl = pc / p.Wo, ox = pc - oyl * p.Wo;
+      int oyl, ox;
+      dwo.divmod(pc, oyl, ox);
       const unsigned char* base = y1t + ((long)(oyl * 2) * Y1W + ox * 2) * p.PS;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
