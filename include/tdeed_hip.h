@@ -121,6 +121,13 @@ int tdeed_gemm_splitk_fwd(const void* A, long lda, int M, int K, int N, const vo
                           const float* shift, const void* R, long ldr, int act, void* C, long ldc,
                           float* workspace, void* stream);
 
+/* SE excitation on the MFMA pipe (bf16 weights as A-operand fragments [ceil(R/16)][ceil(C/32)][64][8] and
+ * [ceil(C/16)][ceil(R/32)][64][8], tdeed_amd.engine.pack_se_mfma); 16 frames per workgroup; same contract as
+ * tdeed_se_gate_bf16_fwd.  tdeed_se_gate_mfma_fits(C, R) != 0 tells whether the shape is covered (C <= 384, R <= 96). */
+int tdeed_se_gate_mfma_fits(int C, int R);
+int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R, const void* w1f,
+                           const float* b1, const void* w2f, const float* b2, float* gate, void* stream);
+
 /* grouped 3x3 (stride 1) + BN + ReLU + SE squeeze + excitation in ONE launch for small maps (one workgroup per
  * frame; bf16): y = conv2_out * gate, i.e. the operand conv3 consumes, so conv3 needs no a_scale and the SE launch
  * disappears.  tdeed_gconv_se_fits() != 0 tells whether (h, w, C, R) is supported. */

@@ -45,6 +45,8 @@ _SIGS = {
     "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P], c_int),
     "tdeed_gemm_splitk_splits": ([c_int], c_int),
     "tdeed_gemm_splitk_fwd": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P, P, c_long, c_int, P, c_long, P, P], c_int),
+    "tdeed_se_gate_mfma_fits": ([c_int, c_int], c_int),
+    "tdeed_se_gate_mfma_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gconv_se_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_gconv_se_fwd": ([P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P, P], c_int),
     "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),

@@ -943,3 +943,200 @@ extern "C" int tdeed_gconv_se_fwd(const void* x, int N, int h, int w, int C, con
   TD_LAUNCH_CHECK("gconv_se");
   return TDEED_OK;
 }
+
+// =========================================================================== SE excitation on the MFMA pipe
+// 16 frames per workgroup are the 16 "pixels" of an MFMA tile: hid[r][frame] = relu(W1 . mean + b1), then
+// gate[c][frame] = sigmoid(W2 . hid + b2).  Weights arrive as MFMA A-operand fragments (engine.pack_se_mfma) and
+// EVERY weight / bias / pooled load of the launch is issued before the first LDS write, so the kernel is one memory
+// round trip + ~50 MFMAs per wave instead of the VALU kernel's three dependent round trips and ~2000 FMAs per lane.
+// The fp32 operands (pooled means, hidden units) are split hi + lo into two bf16 MFMAs: bf16 weights, fp32-accurate
+// activations, the numerics of se_gate_bf16_kernel.
+template <int KS1M, int NT1M, int NT2M, int KS2M>
+__global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restrict__ pooled, int n_parts, float inv_cnt,
+                                                           int N, int C, int R, const bf16x8* __restrict__ w1f,
+                                                           const float* __restrict__ b1,
+                                                           const bf16x8* __restrict__ w2f,
+                                                           const float* __restrict__ b2, float* __restrict__ gate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sme[];
+  const int KS1 = (C + 31) >> 5, RT = (R + 15) >> 4, CT = (C + 15) >> 4, KS2 = (R + 31) >> 5;
+  const int PS1 = KS1 * 32 + 8, PS2 = KS2 * 32 + 8;             // row strides (elements); +8 spreads the banks
+  bf16_t* Phi = reinterpret_cast<bf16_t*>(sme);                 // [16][PS1]
+  bf16_t* Plo = Phi + 16 * PS1;
+  bf16_t* Hhi = Plo + 16 * PS1;                                 // [16][PS2]
+  bf16_t* Hlo = Hhi + 16 * PS2;
+  f32x4* red = reinterpret_cast<f32x4*>(Hlo + 16 * PS2);        // [NS][16 * C/4] partial sums (n_parts > 1 only)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  const int f0 = blockIdx.x * 16;
+  // ---- issue: weights, biases (clamped indices: never a branch around a load)
+  bf16x8 w1r[NT1M][KS1M], w2r[NT2M][KS2M];
+  float b1v[NT1M][4], b2v[NT2M][4];
+#pragma unroll
+  for (int a = 0; a < NT1M; ++a) {
+    const int tc = min(wv + 4 * a, RT - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS1M; ++ks) w1r[a][ks] = w1f[((long)tc * KS1 + min(ks, KS1 - 1)) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b1v[a][e] = b1[min(tc * 16 + 4 * q + e, R - 1)];
+  }
+#pragma unroll
+  for (int a = 0; a < NT2M; ++a) {
+    const int tc = min(wv + 4 * a, CT - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS2M; ++ks) w2r[a][ks] = w2f[((long)tc * KS2 + min(ks, KS2 - 1)) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b2v[a][e] = b2[min(tc * 16 + 4 * q + e, C - 1)];
+  }
+  // ---- pooled sums -> means -> hi/lo bf16 in LDS
+  const int c4n = C >> 2, nitems = 16 * c4n;
+  const int NS = nitems >= 256 ? 1 : min(256 / nitems, n_parts);        // part slices summed in parallel
+  const IDiv dit(nitems), dc4(c4n);
+  for (int i = tid; i < 16 * PS1 / 8; i += 256) {                        // zero both P arrays (pad columns must be 0)
+    reinterpret_cast<u32x4*>(Phi)[i] = (u32x4){0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(Plo)[i] = (u32x4){0u, 0u, 0u, 0u};
+  }
+  for (int i = tid; i < 16 * PS2 / 8; i += 256) {
+    reinterpret_cast<u32x4*>(Hhi)[i] = (u32x4){0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(Hlo)[i] = (u32x4){0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  if (NS == 1) {
+    // wide layers (>= 256 float4 items, few partial rows): 8 items per lane per batch, all loads of a batch in flight
+    for (int i0 = tid; i0 < nitems; i0 += 256 * 8) {
+      f32x4 acc[8];
+      int fo[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int f, c4;
+        dc4.divmod(min(i0 + b * 256, nitems - 1), f, c4);
+        fo[b] = f * PS1 + c4 * 4;
+      }
+      for (int p = 0; p < n_parts; ++p) {
+        f32x4 v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          int f, c4;
+          dc4.divmod(min(i0 + b * 256, nitems - 1), f, c4);
+          v[b] = *reinterpret_cast<const f32x4*>(pooled + ((long)min(f0 + f, N - 1) * n_parts + p) * C + c4 * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { acc[b][0] += v[b][0]; acc[b][1] += v[b][1]; acc[b][2] += v[b][2]; acc[b][3] += v[b][3]; }
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (i0 + b * 256 < nitems) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float m = acc[b][e] * inv_cnt;
+            const bf16_t hi = (bf16_t)m;
+            Phi[fo[b] + e] = hi;
+            Plo[fo[b] + e] = (bf16_t)(m - (float)hi);
+          }
+        }
+    }
+  } else {
+    // narrow layers with many partial rows (s1: 56 per frame): slices of the partial rows summed in parallel
+    for (int i = tid; i < nitems * NS; i += 256) {
+      int slice, item, f, c4;
+      dit.divmod(i, slice, item);
+      dc4.divmod(item, f, c4);
+      const float* src = pooled + ((long)min(f0 + f, N - 1) * n_parts) * C + c4 * 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int p0 = slice; p0 < n_parts; p0 += NS * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[b] = *reinterpret_cast<const f32x4*>(src + (long)min(p0 + b * NS, n_parts - 1) * C);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (p0 + b * NS < n_parts) { acc[0] += v[b][0]; acc[1] += v[b][1]; acc[2] += v[b][2]; acc[3] += v[b][3]; }
+      }
+      red[i] = acc;
+    }
+  }
+  if (NS > 1) {
+    __syncthreads();
+    for (int item = tid; item < nitems; item += 256) {
+      int f, c4;
+      dc4.divmod(item, f, c4);
+      f32x4 acc = red[item];
+      for (int s_ = 1; s_ < NS; ++s_) {
+        const f32x4 t = red[s_ * nitems + item];
+        acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m = acc[e] * inv_cnt;
+        const bf16_t hi = (bf16_t)m;
+        Phi[f * PS1 + c4 * 4 + e] = hi;
+        Plo[f * PS1 + c4 * 4 + e] = (bf16_t)(m - (float)hi);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: hidden units
+#pragma unroll
+  for (int a = 0; a < NT1M; ++a) {
+    const int tile = wv + 4 * a;
+    if (tile < RT) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS1M; ++ks)
+        if (ks < KS1) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Phi + pl * PS1 + ks * 32 + q * 8);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Plo + pl * PS1 + ks * 32 + q * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[a][ks], bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[a][ks], bl, acc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = tile * 16 + 4 * q + e;
+        const float hv = r < R ? fmaxf(acc[e] + b1v[a][e], 0.f) : 0.f;
+        const bf16_t hi = (bf16_t)hv;
+        Hhi[pl * PS2 + r] = hi;
+        Hlo[pl * PS2 + r] = (bf16_t)(hv - (float)hi);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: gates
+#pragma unroll
+  for (int a = 0; a < NT2M; ++a) {
+    const int tile = wv + 4 * a;
+    if (tile < CT) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS2M; ++ks)
+        if (ks < KS2) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Hhi + pl * PS2 + ks * 32 + q * 8);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Hlo + pl * PS2 + ks * 32 + q * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2r[a][ks], bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2r[a][ks], bl, acc, 0, 0, 0);
+        }
+      const int c0 = tile * 16 + 4 * q;
+      if (c0 < C && f0 + pl < N) {
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + b2v[a][e]);
+        *reinterpret_cast<f32x4*>(gate + (long)(f0 + pl) * C + c0) = g;
+      }
+    }
+  }
+}
+
+extern "C" int tdeed_se_gate_mfma_fits(int C, int R) { return C % 8 == 0 && C <= 384 && R >= 1 && R <= 96; }
+
+extern "C" int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R,
+                                      const void* w1f, const float* b1, const void* w2f, const float* b2, float* gate,
+                                      void* stream) {
+  TD_CHECK(pooled && w1f && b1 && w2f && b2 && gate, "se_gate_mfma: null pointer");
+  TD_CHECK(N > 0 && n_parts > 0 && tdeed_se_gate_mfma_fits(C, R), "se_gate_mfma: C=%d R=%d unsupported", C, R);
+  const int KS1 = (C + 31) / 32, KS2 = (R + 31) / 32;
+  const int nitems = 16 * (C / 4);
+  const int NS = nitems >= 256 ? 1 : (256 / nitems < n_parts ? 256 / nitems : n_parts);
+  const size_t smem = (size_t)2 * 16 * (KS1 * 32 + 8) * 2 + (size_t)2 * 16 * (KS2 * 32 + 8) * 2 +
+                      (NS > 1 ? (size_t)NS * nitems * 16 : 0);
+  hipLaunchKernelGGL((se_gate_mfma_kernel<12, 2, 6, 3>), dim3(cdiv(N, 16)), dim3(256), smem, (hipStream_t)stream, pooled,
+                     n_parts, inv_cnt, N, C, R, (const bf16x8*)w1f, b1, (const bf16x8*)w2f, b2, gate);
+  TD_LAUNCH_CHECK("se_gate_mfma");
+  return TDEED_OK;
+}

@@ -131,6 +131,21 @@ def pack_se_bf16(fc1_w, fc2_w, device):
     return dict(se_w1p=bf(p1), se_w2p=bf(w2.T))
 
 
+def pack_se_mfma(fc1_w, fc2_w, device):
+    """SE weights as MFMA A-operand fragments: fc1.weight [R][C] -> [ceil(R/16)][ceil(C/32)][64][8],
+    fc2.weight [C][R] -> [ceil(C/16)][ceil(R/32)][64][8] (bf16, zero padded; lane l holds row l&15, k = 8*(l>>4)+j)."""
+    def frag(W):
+        W = _np(W).astype(np.float32)
+        W = W.reshape(W.shape[0], -1)
+        N, K = W.shape
+        NT, KS = (N + 15) // 16, (K + 31) // 32
+        Wp = np.zeros((NT * 16, KS * 32), np.float32)
+        Wp[:N, :K] = W
+        fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
+        return torch.from_numpy(np.ascontiguousarray(fr).reshape(NT, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
+    return dict(w1f=frag(fc1_w), w2f=frag(fc2_w))
+
+
 class DenseW:
     """A dense [N][K] weight in the layout the chosen contraction kernel wants."""
 
@@ -272,6 +287,8 @@ def pack_sgp_mixer(sd, pre, C, act_dtype, device):
 
 def _se(pooled, inv_cnt, bw, gate):
     """SE excitation: bf16 packed weights in throughput mode, fp32 weights in parity mode."""
+    if bw.se_mf is not None:
+        return ops.se_gate_mfma(pooled, inv_cnt, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2, bw.spec.se_rd, out=gate)
     if bw.se_bf is not None:
         return ops.se_gate_bf16(pooled, inv_cnt, bw.se_bf.se_w1p, bw.se_b1, bw.se_bf.se_w2p, bw.se_b2, bw.spec.se_rd, out=gate)
     return ops.se_gate(pooled, inv_cnt, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate)
@@ -435,6 +452,9 @@ class PackedWeights:
             bw.se_b2 = f32(sd[bp + ".se.fc2.bias"])
             bw.se_bf = (SimpleNamespace(**pack_se_bf16(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
                         if act_dtype == torch.bfloat16 and str(device) != "cpu" else None)
+            bw.se_mf = (SimpleNamespace(**pack_se_mfma(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
+                        if (bw.se_bf is not None and os.environ.get("TDEED_SE_MFMA", "1") == "1"
+                            and ops.se_gate_mfma_fits(blk.cout, blk.se_rd)) else None)
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
             bw.fused = None

@@ -156,6 +156,20 @@ def gconv_se(x, wfrag, scale, shift, se_w1p, se_b1, se_w2p, se_b2, R, out=None):
     return out
 
 
+def se_gate_mfma_fits(C, R):
+    return _lib.load().tdeed_se_gate_mfma_fits(C, R) != 0
+
+
+def se_gate_mfma(pooled, inv_cnt, w1f, b1, w2f, b2, R, out=None):
+    """SE excitation on the MFMA pipe; pooled (N, parts, C) fp32 partial sums -> gate (N, C) fp32."""
+    N, parts, C = pooled.shape
+    if out is None:
+        out = torch.empty((N, C), dtype=torch.float32, device=pooled.device)
+    call("tdeed_se_gate_mfma_fwd", ptr(pooled), parts, float(inv_cnt), N, C, R, ptr(w1f), ptr(b1), ptr(w2f), ptr(b2),
+         ptr(out), stream_ptr())
+    return out
+
+
 def se_gate_bf16(pooled, inv_cnt, w1p, b1, w2p, b2, R, out=None):
     """SE excitation with bf16 packed weights (engine.pack_se_bf16): pooled (N,parts,C) sums -> gate (N,C)."""
     N, parts, C = pooled.shape

@@ -244,6 +244,20 @@ def test_se_gate_bf16(ops, N, C, R):
     assert rel_err(out, ref) < 1e-4
 
 
+@pytest.mark.parametrize("N,C,R,parts", [(11, 152, 38, 1), (400, 368, 92, 1), (35, 24, 8, 56), (7, 56, 6, 10), (9, 152, 14, 2),
+                                          (16, 368, 38, 1)])
+def test_se_gate_mfma(ops, N, C, R, parts):
+    from tdeed_amd.engine import pack_se_mfma
+    assert ops.se_gate_mfma_fits(C, R) and not ops.se_gate_mfma_fits(768, 192)
+    p = rnd(146, "p", (N, parts, C)).abs()
+    w1, b1 = rnd(147, "w1", (R, C), 0.1).to(torch.bfloat16).float(), rnd(148, "b1", (R,), 0.1)
+    w2, b2 = rnd(149, "w2", (C, R), 0.2).to(torch.bfloat16).float(), rnd(150, "b2", (C,), 0.1)
+    ref = torch.sigmoid(torch.relu((p.sum(1) / 5.0) @ w1.T + b1) @ w2.T + b2)
+    pk = pack_se_mfma(w1.numpy(), w2.numpy(), DEV)
+    out = ops.se_gate_mfma(p.to(DEV), 1.0 / 5.0, pk["w1f"], b1.to(DEV), pk["w2f"], b2.to(DEV), R)
+    assert rel_err(out, ref) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_avgpool_posenc(ops, dtype):
     B, T, hw, C = 2, 5, 49, 368
