@@ -248,6 +248,35 @@ int tdeed_process_prediction(const float* head_out, int B, int T, int ld, int K1
 int tdeed_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 int tdeed_fill_u8_hash(uint8_t* dst, long n, uint64_t seed, void* stream); /* synthetic clips */
 
+/* ---- backward of the SGP encoder-decoder (training path; sgp_bwd.hip) ------------------------------------------
+ * Activations and activation gradients share the forward dtype; parameter gradients are fp32.  Every parameter
+ * gradient is produced as caller-owned per-workgroup partials (`part*`) folded in a fixed order: no float atomics,
+ * a step is bit-reproducible. */
+/* out[j] (+)= sum_p part[p][j], p < P, j < n */
+int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream);
+/* mode 0: y = gelu(x); 1: y = dy * gelu'(x); 2: y = x + dy.  n elements, multiple of 8 */
+int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream);
+/* [R][Cc] -> [Cc][R] (weight transposes for the input-gradient contractions) */
+int tdeed_transpose(const void* x, int R, int Cc, void* y, int dtype, void* stream);
+/* weight / bias gradient of a Conv1d(k=1) / 1x1 conv: dW[n][k] (+)= sum_m dY[m][n] X[m][k], db[n] (+)= sum_m dY[m][n]
+ * (db may be NULL).  part_w fp32 [Z][N][K], part_b fp32 [Z][N], Z = tdeed_wgrad_slices(M). */
+int tdeed_wgrad_slices(int M);
+int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w, float* part_b,
+                float* dW, float* db, int accumulate, int dtype, void* stream);
+/* channel LayerNorm backward (modules.py:320-363): dx (+)= d/dx, dw/db [C].  part fp32 [tdeed_layernorm_bwd_blocks(rows)][2][C] */
+int tdeed_layernorm_bwd_blocks(int rows);
+int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long ldy, int rows, int C, const float* w, float eps,
+                        void* dx, int accumulate, float* part, float* dw, float* db, int dtype, void* stream);
+/* GroupNorm(G) backward over NTC slabs.  part fp32 [B][2][C] */
+int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, int C, int G, const float* w, float eps, void* dx,
+                        int accumulate, float* part, float* dw, float* db, int dtype, void* stream);
+/* SGPBlock depthwise-branch backward (modules.py:164-170): o = LayerNorm output, dy = gradient of
+ * fc*phi + (convw+convkw)*psi + o; d_o [B][T][C]; d_dw [C][2ks+up+2], d_db [5][C] in tdeed_sgp_branch_fwd's packed
+ * layouts.  part_w fp32 [B][C][2ks+up+2], part_b fp32 [B][5][C]. */
+int tdeed_sgp_branch_bwd(const void* o, const void* dy, int B, int T, int C, int ks, int up, const float* dw,
+                         const float* db, void* d_o, float* part_w, float* part_b, float* d_dw, float* d_db, int dtype,
+                         void* stream);
+
 /* ---- HIP graph capture of a launch sequence (replaces eager op-by-op dispatch) ---------------
  * begin: hipStreamBeginCapture(stream); end: EndCapture + Instantiate -> handle; launch replays. */
 int tdeed_graph_begin(void* stream);

@@ -47,6 +47,15 @@ _SIGS = {
     "tdeed_gemm_splitk_fwd": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P, P, c_long, c_int, P, c_long, P, P], c_int),
     "tdeed_se_gate_mfma_fits": ([c_int, c_int], c_int),
     "tdeed_se_gate_mfma_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
+    "tdeed_reduce_partials": ([P, c_int, c_long, P, c_int, P], c_int),
+    "tdeed_eltwise": ([P, P, P, c_long, c_int, c_int, P], c_int),
+    "tdeed_transpose": ([P, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_wgrad_slices": ([c_int], c_int),
+    "tdeed_wgrad": ([P, c_long, P, c_long, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_layernorm_bwd_blocks": ([c_int], c_int),
+    "tdeed_layernorm_bwd": ([P, c_long, P, c_long, c_int, c_int, P, c_float, P, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_groupnorm_bwd": ([P, P, c_int, c_int, c_int, c_int, P, c_float, P, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_sgp_branch_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_gconv_se_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_gconv_se_fwd": ([P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P, P], c_int),
     "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libtdeed_hip.so")
-SOURCES = ["gemm.hip", "conv.hip", "front.hip", "bneck.hip", "gsf.hip", "sgp.hip", "train.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "conv.hip", "front.hip", "bneck.hip", "gsf.hip", "sgp.hip", "sgp_bwd.hip", "train.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall",
          "-Wno-unused-function"]
 
@@ -29,7 +29,7 @@ def _stale(obj, deps):
 
 
 def build(force=False, verbose=True):
-    hdrs = [os.path.join(CSRC, "common.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "sgp_tile.h"),
             os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "tdeed_hip.h")]
     jobs = []
     objs = []

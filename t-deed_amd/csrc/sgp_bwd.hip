@@ -1,0 +1,577 @@
+// Backward of the SGP encoder-decoder pieces (reference forward: /root/reference/model/modules.py:58-363), NTC
+// layout, activations/gradients in T (fp32 or bf16), parameter gradients always fp32.
+// Parameter gradients are produced as per-workgroup partials and folded by reduce_partials in a fixed order, so a
+// training step is bit-reproducible (no float atomics anywhere).
+#include "common.h"
+#include "sgp_tile.h"
+
+// =========================================================================== small generic pieces
+// out[j] = sum_p part[p][j]  (ordered), optionally out[j] += ...
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, long stride, long n,
+                                                              float* __restrict__ out, int accumulate) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int p0 = 0; p0 < P; p0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) v[b] = part[(long)min(p0 + b, P - 1) * stride + j];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) s += p0 + b < P ? v[b] : 0.f;
+  }
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+extern "C" int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream) {
+  TD_CHECK(part && out && P > 0 && n > 0, "reduce_partials: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     P, n, n, out, accumulate);
+  TD_LAUNCH_CHECK("reduce_partials");
+  return TDEED_OK;
+}
+
+// elementwise: mode 0: y = gelu(x);  1: y = dy * gelu'(x);  2: y = x + dy (gradient accumulation)
+template <typename T>
+__global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ y,
+                                                      long nchunks, int mode) {
+  constexpr int EPC = Chunk<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  float a[EPC], b[EPC], o[EPC];
+  Chunk<T>::load(x + i * EPC, a);
+  if (mode != 0) Chunk<T>::load(dy + i * EPC, b);
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    if (mode == 0) {
+      o[e] = gelu_erf(a[e]);
+    } else if (mode == 1) {
+      const float cdf = 0.5f * (1.0f + erff(a[e] * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * expf(-0.5f * a[e] * a[e]);
+      o[e] = b[e] * (cdf + a[e] * pdf);
+    } else {
+      o[e] = a[e] + b[e];
+    }
+  }
+  Chunk<T>::store(y + i * EPC, o);
+}
+
+extern "C" int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream) {
+  TD_CHECK(x && y && (mode == 0 || dy) && n > 0 && n % 8 == 0 && mode >= 0 && mode <= 2, "eltwise: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const long nc = n / 4;
+    hipLaunchKernelGGL(eltwise_kernel<float>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, (const float*)x,
+                       (const float*)dy, (float*)y, nc, mode);
+  } else if (dtype == TDEED_BF16) {
+    const long nc = n / 8;
+    hipLaunchKernelGGL(eltwise_kernel<bf16_t>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)y, nc, mode);
+  } else { tdeed_set_error("eltwise: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("eltwise");
+  return TDEED_OK;
+}
+
+// [R][Cc] -> [Cc][R] through a padded 32x32 LDS tile
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, int R, int Cc, T* __restrict__ y) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    tile[i][tx] = (r0 + i < R && c0 + tx < Cc) ? (float)x[(long)(r0 + i) * Cc + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < Cc && r0 + tx < R) y[(long)(c0 + i) * R + r0 + tx] = (T)tile[tx][i];
+}
+
+extern "C" int tdeed_transpose(const void* x, int R, int Cc, void* y, int dtype, void* stream) {
+  TD_CHECK(x && y && R > 0 && Cc > 0, "transpose: bad arguments");
+  dim3 grid(cdiv(Cc, 32), cdiv(R, 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, (const float*)x, R, Cc, (float*)y);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, R, Cc, (bf16_t*)y);
+  else { tdeed_set_error("transpose: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("transpose");
+  return TDEED_OK;
+}
+
+// =========================================================================== weight / bias gradients of a 1x1
+// dW[n][k] = sum_m dY[m][n] * X[m][k]   (+ db[n] = sum_m dY[m][n] from the k-tile-0 workgroups)
+// 64 x 64 output tile per workgroup, 4 x 4 outputs per lane, rows m staged 32 at a time as fp32 in LDS; blockIdx.z
+// slices M, slices land in `part` ([Z][N][K] then [Z][N] for the bias) and are folded by reduce_partials.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dY, long ldy, const T* __restrict__ X, long ldx,
+                                                    int M, int N, int K, float* __restrict__ part_w,
+                                                    float* __restrict__ part_b) {
+  __shared__ __attribute__((aligned(16))) float sy[32][64];
+  __shared__ __attribute__((aligned(16))) float sx[32][64];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, z = blockIdx.z, Z = gridDim.z;
+  const int mper = ((M + Z - 1) / Z + 31) / 32 * 32;
+  const int m_begin = z * mper, m_end = min(M, m_begin + mper);
+  const int tn = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  float bsum = 0.f;                                             // lanes 0..63 of k-tile 0: column sums of dY
+  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const bool rok = m0 + r < m_end;
+      sy[r][c] = (rok && n0 + c < N) ? (float)dY[(long)(m0 + r) * ldy + n0 + c] : 0.f;
+      sx[r][c] = (rok && k0 + c < K) ? (float)X[(long)(m0 + r) * ldx + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&sy[r][tn * 4]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&sx[r][tk * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    if (part_b && blockIdx.y == 0 && threadIdx.x < 64)
+      for (int r = 0; r < 32; ++r) bsum += sy[r][threadIdx.x];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + tn * 4 + i;
+    if (n >= N) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + tk * 4 + j;
+      if (k < K) part_w[((long)z * N + n) * K + k] = acc[i][j];
+    }
+  }
+  if (part_b && blockIdx.y == 0 && threadIdx.x < 64 && n0 + threadIdx.x < N)
+    part_b[(long)z * N + n0 + threadIdx.x] = bsum;
+}
+
+extern "C" int tdeed_wgrad_slices(int M) { int z = (M + 255) / 256; return z < 1 ? 1 : (z > 16 ? 16 : z); }
+
+// part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M); dW [N][K], db [N] (fp32)
+extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w,
+                           float* part_b, float* dW, float* db, int accumulate, int dtype, void* stream) {
+  TD_CHECK(dY && X && part_w && dW && (!db || part_b), "wgrad: null pointer");
+  TD_CHECK(M > 0 && N > 0 && K > 0, "wgrad: bad sizes");
+  const int Z = tdeed_wgrad_slices(M);
+  dim3 grid(cdiv(N, 64), cdiv(K, 64), Z);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, M, N, K,
+                       part_w, db ? part_b : nullptr);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N,
+                       K, part_w, db ? part_b : nullptr);
+  else { tdeed_set_error("wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("wgrad");
+  int rc = tdeed_reduce_partials(part_w, Z, (long)N * K, dW, accumulate, stream);
+  if (rc == TDEED_OK && db) rc = tdeed_reduce_partials(part_b, Z, N, db, accumulate, stream);
+  return rc;
+}
+
+// =========================================================================== channel LayerNorm backward
+// one wave per row, 32 rows per workgroup; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;
+// part[blk][0][c] = sum_rows dy * xhat (d weight), part[blk][1][c] = sum_rows dy (d bias)
+constexpr int LNB_ROWS = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+                                                            long ldy, int rows, int C, const float* __restrict__ w,
+                                                            float eps, T* __restrict__ dx, int accumulate,
+                                                            float* __restrict__ part) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int MAXCH = 4;
+  extern __shared__ float sred[];                              // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nch = C / EPC;
+  float dg[MAXCH][EPC], db[MAXCH][EPC], wr[MAXCH][EPC];
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ck = min(lane + 64 * i, nch - 1);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; wr[i][e] = w[ck * EPC + e]; }
+  }
+  for (int rr = wv; rr < LNB_ROWS; rr += 4) {
+    const long row = (long)blockIdx.x * LNB_ROWS + rr;
+    if (row >= rows) break;                                     // uniform per wave
+    float xv[MAXCH][EPC], gv[MAXCH][EPC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ck = min(lane + 64 * i, nch - 1);
+      Chunk<T>::load(x + row * ldx + (long)ck * EPC, xv[i]);
+      Chunk<T>::load(dy + row * ldy + (long)ck * EPC, gv[i]);
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s += xv[i][e];
+      }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { xv[i][e] -= mu; q += xv[i][e] * xv[i][e]; }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          xv[i][e] *= rstd;                                     // xhat
+          dg[i][e] += gv[i][e] * xv[i][e];
+          db[i][e] += gv[i][e];
+          gv[i][e] *= wr[i][e];                                 // g = dy * w
+          s1 += gv[i][e];
+          s2 += gv[i][e] * xv[i][e];
+        }
+      }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ck = lane + 64 * i;
+      if (ck < nch) {
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+        if (accumulate) {
+          float old[EPC];
+          Chunk<T>::load(dx + row * ldx + (long)ck * EPC, old);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] += old[e];
+        }
+        Chunk<T>::store(dx + row * ldx + (long)ck * EPC, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nch) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        sred[(wv * 2 + 0) * C + ck * EPC + e] = dg[i][e];
+        sred[(wv * 2 + 1) * C + ck * EPC + e] = db[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * C; j += 256) {
+    float v = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) v += sred[w2 * 2 * C + j];
+    part[(long)blockIdx.x * 2 * C + j] = v;
+  }
+}
+
+extern "C" int tdeed_layernorm_bwd_blocks(int rows) { return (rows + LNB_ROWS - 1) / LNB_ROWS; }
+
+// part: fp32 [blocks][2][C]; dw, db: fp32 [C]; dx has x's geometry (row stride ldx); accumulate: dx += instead of =
+extern "C" int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long ldy, int rows, int C, const float* w,
+                                   float eps, void* dx, int accumulate, float* part, float* dw, float* db, int dtype,
+                                   void* stream) {
+  TD_CHECK(x && dy && w && dx && part && dw && db, "layernorm_bwd: null pointer");
+  TD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm_bwd: bad sizes");
+  const int nb = tdeed_layernorm_bwd_blocks(rows);
+  const size_t smem = (size_t)8 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    TD_CHECK(C <= 4 * 64 * 4, "layernorm_bwd: C=%d too wide", C);
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), smem, st, (const float*)x, ldx, (const float*)dy,
+                       ldy, rows, C, w, eps, (float*)dx, accumulate, part);
+  } else if (dtype == TDEED_BF16) {
+    TD_CHECK(C <= 4 * 64 * 8, "layernorm_bwd: C=%d too wide", C);
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), smem, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, ldy, rows, C, w, eps, (bf16_t*)dx, accumulate, part);
+  } else { tdeed_set_error("layernorm_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("layernorm_bwd");
+  // part viewed as [nb][2C]: the first C columns of a row are d weight, the next C are d bias
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, nb, 2L * C, (long)C, dw, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part + C, nb, 2L * C, (long)C, db, 0);
+  TD_LAUNCH_CHECK("layernorm_bwd reduce");
+  return TDEED_OK;
+}
+
+// =========================================================================== GroupNorm backward
+// one workgroup per (clip, group): slab [T][cg] of x and dy cached in LDS; statistics recomputed;
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w over the slab;
+// part[b][0][c] = sum_t dy * xhat, part[b][1][c] = sum_t dy
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int T_len,
+                                                            int C, int G, const float* __restrict__ w, float eps,
+                                                            T* __restrict__ dx, int accumulate,
+                                                            float* __restrict__ part) {
+  extern __shared__ float sm[];     // xs [n], gs [n], col [2][cg], scratch [8]
+  const int b = blockIdx.x, g = blockIdx.y;
+  const int cg = C / G;
+  const int n = T_len * cg;
+  float* xs = sm;
+  float* gs = xs + n;
+  float* col = gs + n;
+  float* scratch = col + 2 * cg;
+  const long base = (long)b * T_len * C + g * cg;
+  const IDiv dcg(cg);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int t, cl;
+    dcg.divmod(i, t, cl);
+    const float v = (float)x[base + (long)t * C + cl];
+    xs[i] = v;
+    gs[i] = (float)dy[base + (long)t * C + cl];
+    s += v;
+  }
+  const float mean = block_sum<4>(s, scratch) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = xs[i] - mean;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(block_sum<4>(q, scratch) / (float)n + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int t, cl;
+    dcg.divmod(i, t, cl);
+    const float xh = (xs[i] - mean) * rstd;
+    xs[i] = xh;
+    const float gg = gs[i] * w[g * cg + cl];
+    s1 += gg;
+    s2 += gg * xh;
+  }
+  s1 = block_sum<4>(s1, scratch) / (float)n;
+  s2 = block_sum<4>(s2, scratch) / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int t, cl;
+    dcg.divmod(i, t, cl);
+    const float gg = gs[i] * w[g * cg + cl];
+    float o = rstd * (gg - s1 - xs[i] * s2);
+    T* dst = dx + base + (long)t * C + cl;
+    if (accumulate) o += (float)*dst;
+    *dst = (T)o;
+  }
+  // per-channel sums over t (ordered): lane cl walks its column
+  for (int cl = threadIdx.x; cl < cg; cl += 256) {
+    float a = 0.f, c2 = 0.f;
+    for (int t = 0; t < T_len; ++t) {
+      a += gs[t * cg + cl] * xs[t * cg + cl];
+      c2 += gs[t * cg + cl];
+    }
+    part[((long)b * 2 + 0) * C + g * cg + cl] = a;
+    part[((long)b * 2 + 1) * C + g * cg + cl] = c2;
+  }
+}
+
+// part: fp32 [B][2][C]; dw, db: fp32 [C]
+extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, int C, int G, const float* w, float eps,
+                                   void* dx, int accumulate, float* part, float* dw, float* db, int dtype,
+                                   void* stream) {
+  TD_CHECK(x && dy && w && dx && part && dw && db, "groupnorm_bwd: null pointer");
+  TD_CHECK(B > 0 && T > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad sizes");
+  const size_t smem = ((size_t)2 * T * (C / G) + 2 * (C / G) + 8) * sizeof(float);
+  TD_CHECK(smem <= 64 * 1024, "groupnorm_bwd: slab too large");
+  dim3 grid(B, G);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(groupnorm_bwd_kernel<float>, grid, dim3(256), smem, st, (const float*)x, (const float*)dy, T, C, G,
+                       w, eps, (float*)dx, accumulate, part);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(groupnorm_bwd_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, T, C,
+                       G, w, eps, (bf16_t*)dx, accumulate, part);
+  else { tdeed_set_error("groupnorm_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("groupnorm_bwd");
+  // part viewed as [B][2C]: the first C columns of each row are d weight, the next C are d bias
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, B, 2L * C, (long)C, dw, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part + C, B, 2L * C, (long)C, db, 0);
+  TD_LAUNCH_CHECK("groupnorm_bwd reduce");
+  return TDEED_OK;
+}
+
+// =========================================================================== depthwise-branch backward
+// Forward (per clip b, channel c; o = LayerNorm output):
+//   psi = dw_ks(o), cw = dw_ks(o), ckw = dw_up(o), fc = wf*o + bf, phi = relu(wg * mean_t(o) + bg)
+//   out = fc * phi + (cw + ckw) * psi + o
+// Given g = d out: everything is per channel, so a workgroup owns 16 channels of one clip exactly like the forward
+// kernel: o and g tiles in LDS, the forward products recomputed, d psi / d (cw+ckw) staged with a zero halo so the
+// input gradient is three more temporal correlations.  Weight gradients: one lane per (tap, channel) walks T.
+struct BranchBwdOut {            // per-lane partial sums over its t's
+  float dphi, sdpsi, sds, sg, sgo;
+};
+
+template <typename T>
+__device__ __forceinline__ void branch_bwd_core(const float* ot, const float* gt, float* dpsi, float* ds,
+                                                const float* wl, const Bias5& bb, bool cok, int T_len, int halo, int ks,
+                                                int up, float* red /*[17][16]*/, float* red5 /*[16][5][16]*/,
+                                                float mean_c, T* __restrict__ d_o, long ld_o, int c0, int C,
+                                                float* __restrict__ part_w /*[C][wlen] slice of this clip*/,
+                                                float* __restrict__ part_b /*[5][C] slice of this clip*/, float* res) {
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int wlen = 2 * ks + up + 2;
+  const int hk = ks >> 1, hu = up >> 1;
+  const float wf = wl[(2 * ks + up) * SGP_CH + c], wg = wl[(2 * ks + up + 1) * SGP_CH + c];
+  const float b_psi = cok ? bb.psi : 0.f, b_cw = cok ? bb.cw : 0.f, b_ckw = cok ? bb.ckw : 0.f,
+              b_fc = cok ? bb.fc : 0.f, b_g = cok ? bb.g : 0.f;
+  const float pre = fmaf(wg, mean_c, b_g);
+  const float phi = fmaxf(pre, 0.f);
+  // ---- phase A: forward products again, d psi and d (cw + ckw) into LDS, per-lane partial sums
+  float a_dphi = 0.f, a_dpsi = 0.f, a_ds = 0.f, a_g = 0.f, a_go = 0.f;
+  for (int t = tl; t < T_len; t += 16) {
+    const float* col = ot + (halo + t) * SGP_CH + c;
+    float psi = b_psi, cw = b_cw, ckw = b_ckw;
+    for (int k = 0; k < ks; ++k) {
+      const float v = col[(k - hk) * SGP_CH];
+      psi = fmaf(wl[k * SGP_CH + c], v, psi);
+      cw = fmaf(wl[(ks + k) * SGP_CH + c], v, cw);
+    }
+    for (int k = 0; k < up; ++k) ckw = fmaf(wl[(2 * ks + k) * SGP_CH + c], col[(k - hu) * SGP_CH], ckw);
+    const float o = col[0];
+    const float fc = fmaf(wf, o, b_fc);
+    const float g = gt[t * SGP_CH + c];
+    const float vdpsi = g * (cw + ckw), vds = g * psi;
+    dpsi[(halo + t) * SGP_CH + c] = vdpsi;
+    ds[(halo + t) * SGP_CH + c] = vds;
+    a_dphi += g * fc;
+    a_dpsi += vdpsi;
+    a_ds += vds;
+    a_g += g;
+    a_go += g * o;
+  }
+  red5[(tl * 5 + 0) * SGP_CH + c] = a_dphi;
+  red5[(tl * 5 + 1) * SGP_CH + c] = a_dpsi;
+  red5[(tl * 5 + 2) * SGP_CH + c] = a_ds;
+  red5[(tl * 5 + 3) * SGP_CH + c] = a_g;
+  red5[(tl * 5 + 4) * SGP_CH + c] = a_go;
+  __syncthreads();
+  if (threadIdx.x < 5 * SGP_CH) {                              // lane (which, c): ordered sum over the 16 time lanes
+    const int which = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += red5[(i * 5 + which) * SGP_CH + cc];
+    red[which * SGP_CH + cc] = a;
+  }
+  __syncthreads();
+  const float dphi = red[0 * SGP_CH + c], s_dpsi = red[1 * SGP_CH + c], s_ds = red[2 * SGP_CH + c],
+              s_g = red[3 * SGP_CH + c], s_go = red[4 * SGP_CH + c];
+  const float dpre = pre > 0.f ? dphi : 0.f;
+  const float dmean = dpre * wg / (float)T_len;
+  // ---- phase B: input gradient
+  for (int t = tl; t < T_len; t += 16) {
+    float a = gt[t * SGP_CH + c] * (1.0f + wf * phi) + dmean;
+    const float* dp = dpsi + (halo + t) * SGP_CH + c;
+    const float* dq = ds + (halo + t) * SGP_CH + c;
+    for (int k = 0; k < ks; ++k) {
+      a = fmaf(wl[k * SGP_CH + c], dp[(hk - k) * SGP_CH], a);
+      a = fmaf(wl[(ks + k) * SGP_CH + c], dq[(hk - k) * SGP_CH], a);
+    }
+    for (int k = 0; k < up; ++k) a = fmaf(wl[(2 * ks + k) * SGP_CH + c], dq[(hu - k) * SGP_CH], a);
+    res[t * SGP_CH + c] = a;
+  }
+  __syncthreads();
+  store_tile<T>(res, d_o, ld_o, 0, T_len, c0, C, (const T*)nullptr, 0);
+  // ---- phase C: weight gradients, one lane per (tap, channel)
+  const int ntap = 2 * ks + up;
+  for (int i = threadIdx.x; i < ntap * SGP_CH; i += 256) {
+    const int k = i >> 4, cc = i & 15;
+    const float* dsrc = k < ks ? dpsi : ds;
+    const int off = k < ks ? k - hk : (k < 2 * ks ? k - ks - hk : k - 2 * ks - hu);
+    float a = 0.f;
+    for (int t = 0; t < T_len; ++t) a = fmaf(dsrc[(halo + t) * SGP_CH + cc], ot[(halo + t + off) * SGP_CH + cc], a);
+    if (c0 + cc < C) part_w[(long)(c0 + cc) * wlen + k] = a;
+  }
+  if (tl == 0 && cok) {
+    part_w[(long)(c0 + c) * wlen + ntap] = phi * s_go;                       // d fc.weight
+    part_w[(long)(c0 + c) * wlen + ntap + 1] = dpre * mean_c;                 // d global_fc.weight
+    part_b[0 * (long)C + c0 + c] = s_dpsi;
+    part_b[1 * (long)C + c0 + c] = s_ds;
+    part_b[2 * (long)C + c0 + c] = s_ds;
+    part_b[3 * (long)C + c0 + c] = phi * s_g;
+    part_b[4 * (long)C + c0 + c] = dpre;
+  }
+}
+
+// o: LayerNorm output [B][T][C]; dy: gradient of (fc*phi + (cw+ckw)*psi + o) [B][T][C]; d_o out [B][T][C]
+// part_w fp32 [B][C][wlen], part_b fp32 [B][5][C]
+template <typename T>
+__global__ __launch_bounds__(256) void sgp_branch_bwd_kernel(const T* __restrict__ o, const T* __restrict__ dy, int T_len,
+                                                             int C, int ks, int up, const float* __restrict__ dw,
+                                                             const float* __restrict__ db, T* __restrict__ d_o,
+                                                             float* __restrict__ part_w, float* __restrict__ part_b) {
+  extern __shared__ float sm[];
+  const int halo = up >> 1;
+  const int wlen = 2 * ks + up + 2;
+  const int trows = T_len + 2 * halo;
+  float* ot = sm;
+  float* dpsi = ot + trows * SGP_CH;
+  float* ds = dpsi + trows * SGP_CH;
+  float* gt = ds + trows * SGP_CH;
+  float* res = gt + T_len * SGP_CH;
+  float* wl = res + T_len * SGP_CH;
+  float* red = wl + wlen * SGP_CH;                              // [17][16]
+  float* red5 = red + 17 * SGP_CH;                              // [16][5][16]
+  const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
+  const long base = (long)b * T_len * C;
+  const int c = threadIdx.x & 15;
+  const bool cok = c0 + c < C;
+  {
+    float ov[SGP_TI][Chunk<T>::N], gv[SGP_TI][Chunk<T>::N], wv[SGP_WI];
+    tile_issue<T>(o + base, C, T_len, c0, C, ov);
+    tile_issue<T>(dy + base, C, T_len, c0, C, gv);
+    dw_issue(dw, wlen, c0, C, wv);
+    tile_commit<T>(ov, T_len, c0, C, ot, halo);
+    tile_commit<T>(gv, T_len, c0, C, gt, 0);
+    dw_commit(wv, wlen, c0, C, wl);
+  }
+  const Bias5 bb = bias_issue(db, C, c0 + c, C);
+  for (int i = threadIdx.x; i < 2 * halo * SGP_CH; i += 256) {
+    const int r = i / SGP_CH, cc = i - r * SGP_CH;
+    const int row = r < halo ? r : (T_len + r);
+    dpsi[row * SGP_CH + cc] = 0.f;
+    ds[row * SGP_CH + cc] = 0.f;
+  }
+  __syncthreads();
+  tile_mean(ot, T_len, halo, red);
+  const float mean_c = red[16 * SGP_CH + c];
+  __syncthreads();
+  branch_bwd_core<T>(ot, gt, dpsi, ds, wl, bb, cok, T_len, halo, ks, up, red, red5, mean_c, d_o + base, C, c0, C,
+                     part_w + (long)b * C * wlen, part_b + (long)b * 5 * C, res);
+}
+
+// part_w: fp32 [B][C][wlen], part_b: fp32 [B][5][C]; d_dw [C][wlen], d_db [5][C] (the forward's packed layouts)
+extern "C" int tdeed_sgp_branch_bwd(const void* o, const void* dy, int B, int T, int C, int ks, int up, const float* dw,
+                                    const float* db, void* d_o, float* part_w, float* part_b, float* d_dw, float* d_db,
+                                    int dtype, void* stream) {
+  TD_CHECK(o && dy && dw && db && d_o && part_w && part_b && d_dw && d_db, "sgp_branch_bwd: null pointer");
+  TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_branch_bwd: bad sizes");
+  TD_CHECK(T <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80, "sgp_branch_bwd: T=%d / taps beyond the staging registers", T);
+  const int halo = up / 2, wlen = 2 * ks + up + 2;
+  const size_t smem = (size_t)(3 * (T + 2 * halo) * SGP_CH + 2 * T * SGP_CH + wlen * SGP_CH + 17 * SGP_CH + 80 * SGP_CH) *
+                      sizeof(float);
+  TD_CHECK(smem <= 128 * 1024, "sgp_branch_bwd: T=%d too long for the LDS window", T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) { tdeed_set_error("sgp_branch_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  dim3 grid(B, cdiv(C, SGP_CH));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(sgp_branch_bwd_kernel<float>, grid, dim3(256), smem, st, (const float*)o, (const float*)dy, T, C, ks,
+                       up, dw, db, (float*)d_o, part_w, part_b);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(sgp_branch_bwd_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)o, (const bf16_t*)dy, T, C,
+                       ks, up, dw, db, (bf16_t*)d_o, part_w, part_b);
+  else { tdeed_set_error("sgp_branch_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("sgp_branch_bwd");
+  int rc = tdeed_reduce_partials(part_w, B, (long)C * wlen, d_dw, 0, stream);
+  if (rc == TDEED_OK) rc = tdeed_reduce_partials(part_b, B, 5L * C, d_db, 0, stream);
+  return rc;
+}

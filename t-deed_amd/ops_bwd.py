@@ -1,0 +1,80 @@
+"""Torch-tensor wrappers of the backward entry points (training path).  Same conventions as ops.py: tensors are
+device memory handed over as raw pointers on the current stream; scratch (`part*`) is allocated here when the caller
+does not pass it (a training engine passes preallocated buffers)."""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr, dtype_code
+
+GELU_FWD, GELU_BWD, ADD = 0, 1, 2
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def eltwise(x, dy, mode, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_eltwise", ptr(x), ptr(dy), ptr(out), x.numel(), mode, dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def transpose(x, out=None):
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty((Cc, R), dtype=x.dtype, device=x.device)
+    call("tdeed_transpose", ptr(x), R, Cc, ptr(out), dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def wgrad(dY, X, with_bias=True, dW=None, db=None, accumulate=False, M=None):
+    """dW[n][k] = sum_m dY[m][n] X[m][k]; db[n] = sum_m dY[m][n].  dY (M,N), X (M,K) in the activation dtype."""
+    N, K = dY.shape[-1], X.shape[-1]
+    M = dY.numel() // N if M is None else M
+    Z = _lib.load().tdeed_wgrad_slices(M)
+    dev = dY.device
+    dW = _f32((N, K), dev) if dW is None else dW
+    if with_bias and db is None:
+        db = _f32((N,), dev)
+    pw, pb = _f32((Z, N, K), dev), (_f32((Z, N), dev) if with_bias else None)
+    call("tdeed_wgrad", ptr(dY), N, ptr(X), K, M, N, K, ptr(pw), ptr(pb), ptr(dW), ptr(db if with_bias else None),
+         int(accumulate), dtype_code(dY.dtype), stream_ptr())
+    return dW, db
+
+
+def layernorm_bwd(x, dy, w, eps=1e-5, dx=None, accumulate=False, ldx=None, ldy=None, rows=None, C=None):
+    C = x.shape[-1] if C is None else C
+    rows = x.numel() // x.shape[-1] if rows is None else rows
+    dev = x.device
+    if dx is None:
+        dx = torch.empty_like(x)
+    nb = _lib.load().tdeed_layernorm_bwd_blocks(rows)
+    part, dw, db = _f32((nb, 2, C), dev), _f32((C,), dev), _f32((C,), dev)
+    call("tdeed_layernorm_bwd", ptr(x), (C if ldx is None else ldx), ptr(dy), (C if ldy is None else ldy), rows, C, ptr(w),
+         eps, ptr(dx), int(accumulate), ptr(part), ptr(dw), ptr(db), dtype_code(x.dtype), stream_ptr())
+    return dx, dw, db
+
+
+def groupnorm_bwd(x, dy, G, w, eps=1e-5, dx=None, accumulate=False):
+    B, T, C = x.shape
+    dev = x.device
+    if dx is None:
+        dx = torch.empty_like(x)
+    part, dw, db = _f32((B, 2, C), dev), _f32((C,), dev), _f32((C,), dev)
+    call("tdeed_groupnorm_bwd", ptr(x), ptr(dy), B, T, C, G, ptr(w), eps, ptr(dx), int(accumulate), ptr(part), ptr(dw),
+         ptr(db), dtype_code(x.dtype), stream_ptr())
+    return dx, dw, db
+
+
+def sgp_branch_bwd(o, dy, ks, up, dw, db, d_o=None):
+    """-> d_o (B,T,C), d_dw (C, 2ks+up+2), d_db (5, C) in the packed layouts of ops.sgp_branch."""
+    B, T, C = o.shape
+    dev = o.device
+    wlen = 2 * ks + up + 2
+    if d_o is None:
+        d_o = torch.empty_like(o)
+    pw, pb, ddw, ddb = _f32((B, C, wlen), dev), _f32((B, 5, C), dev), _f32((C, wlen), dev), _f32((5, C), dev)
+    call("tdeed_sgp_branch_bwd", ptr(o), ptr(dy), B, T, C, ks, up, ptr(dw), ptr(db), ptr(d_o), ptr(pw), ptr(pb), ptr(ddw),
+         ptr(ddb), dtype_code(o.dtype), stream_ptr())
+    return d_o, ddw, ddb

@@ -1,0 +1,122 @@
+"""Backward kernels of the training path (through the C ABI) against torch autograd on the CPU oracle's fp32
+restatement of the same ops.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import act, module_state, t
+from oracle import tdeed_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+F32_TOL = 2e-4
+BF16_TOL = 4e-2
+
+
+@pytest.fixture(scope="module")
+def bops():
+    from tdeed_amd import ops_bwd as o, _lib
+    _lib.load()
+    return o
+
+
+def rel_err(a, b):
+    b = b.detach().cpu().double()
+    a = a.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def rnd(seed, name, shape, scale=1.0):
+    return t(act(seed, name, shape, scale))
+
+
+def tol(dtype):
+    return F32_TOL if dtype == torch.float32 else BF16_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(800, 1472, 368), (200, 368, 1472), (37, 24, 40), (1600, 368, 2208), (5000, 8, 368)])
+def test_wgrad(bops, dtype, M, N, K):
+    dY, X = rnd(201, "dy", (M, N)).to(dtype), rnd(202, "x", (M, K)).to(dtype)
+    dW, db = bops.wgrad(dY.to(DEV), X.to(DEV))
+    assert rel_err(dW, dY.float().T @ X.float()) < 1e-4
+    assert rel_err(db, dY.float().sum(0)) < 1e-4
+    dW2, _ = bops.wgrad(dY.to(DEV), X.to(DEV), with_bias=False, dW=dW.clone(), accumulate=True)
+    assert rel_err(dW2, 2 * (dY.float().T @ X.float())) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transpose_and_eltwise(bops, dtype):
+    x = rnd(203, "x", (75, 200)).to(dtype)
+    assert torch.equal(bops.transpose(x.to(DEV)).cpu(), x.T.contiguous())
+    h, g = rnd(204, "h", (64, 96), 2.0).to(dtype), rnd(205, "g", (64, 96)).to(dtype)
+    hf = h.float().requires_grad_(True)
+    y = F.gelu(hf)
+    y.backward(g.float())
+    assert rel_err(bops.eltwise(h.to(DEV), None, bops.GELU_FWD).float(), y) < tol(dtype)
+    assert rel_err(bops.eltwise(h.to(DEV), g.to(DEV), bops.GELU_BWD).float(), hf.grad) < tol(dtype)
+    assert rel_err(bops.eltwise(h.to(DEV), g.to(DEV), bops.ADD).float(), h.float() + g.float()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(200, 368), (77, 32), (800, 768)])
+def test_layernorm_bwd(bops, dtype, rows, C):
+    x, dy = rnd(206, "x", (rows, C), 2.0).to(dtype), rnd(207, "dy", (rows, C)).to(dtype)
+    w, b = rnd(208, "w", (C,)) * 0.3 + 1.0, rnd(209, "b", (C,), 0.1)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = O.channel_layernorm(xr.T[None], wr.view(1, C, 1), br.view(1, C, 1))[0].T      # oracle works on (B,C,T)
+    y.backward(dy.float())
+    dx, dw, db = bops.layernorm_bwd(x.to(DEV), dy.to(DEV), w.to(DEV))
+    assert rel_err(dx.float(), xr.grad) < tol(dtype)
+    assert rel_err(dw, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(db, br.grad) < 1e-4
+    base = rnd(210, "base", (rows, C)).to(dtype)
+    dx2, _, _ = bops.layernorm_bwd(x.to(DEV), dy.to(DEV), w.to(DEV), dx=base.clone().to(DEV), accumulate=True)
+    assert rel_err(dx2.float(), base.float() + xr.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,C", [(3, 25, 32), (2, 100, 368), (2, 50, 768)])
+def test_groupnorm_bwd(bops, dtype, B, T, C):
+    x, dy = rnd(211, "x", (B, T, C), 2.0).to(dtype), rnd(212, "dy", (B, T, C)).to(dtype)
+    w, b = rnd(213, "w", (C,)) * 0.3 + 1.0, rnd(214, "b", (C,), 0.1)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.group_norm(xr.permute(0, 2, 1), 16, wr, br, 1e-5).permute(0, 2, 1)
+    y.backward(dy.float())
+    dx, dw, db = bops.groupnorm_bwd(x.to(DEV), dy.to(DEV), 16, w.to(DEV))
+    assert rel_err(dx.float(), xr.grad) < tol(dtype)
+    assert rel_err(dw, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(db, br.grad) < 1e-4
+
+
+def _branch_ref(o, sd, pre):
+    """the depthwise-branch part of SGPBlock.forward (modules.py:164-170) without the residual"""
+    psi = O._dw(o, sd, pre + ".psi")
+    fc = O._dw(o, sd, pre + ".fc")
+    cw = O._dw(o, sd, pre + ".convw")
+    ckw = O._dw(o, sd, pre + ".convkw")
+    phi = torch.relu(O._dw(o.mean(dim=-1, keepdim=True), sd, pre + ".global_fc"))
+    return fc * phi + (cw + ckw) * psi + o
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,T,ks,r", [(2, 32, 25, 7, 4), (2, 368, 100, 7, 4), (1, 48, 13, 5, 2), (1, 64, 250, 9, 4)])
+def test_sgp_branch_bwd(bops, dtype, B, C, T, ks, r):
+    from tdeed_amd.engine import _dwpack
+    sd = {k: t(v).clone().requires_grad_(True) for k, v in module_state("sgp_block", "blk", 31, C=C, ks=ks, r=r).items()}
+    names = ["psi", "convw", "convkw", "fc", "global_fc"]
+    up = sd["blk.convkw.weight"].shape[-1]
+    o = rnd(215, "o", (B, T, C)).to(dtype)
+    dy = rnd(216, "dy", (B, T, C)).to(dtype)
+    orq = o.float().requires_grad_(True)
+    out = _branch_ref(orq.permute(0, 2, 1), sd, "blk").permute(0, 2, 1)
+    out.backward(dy.float())
+    dw, db = _dwpack({k: v.detach() for k, v in sd.items()}, "blk", names, C, DEV)
+    d_o, ddw, ddb = bops.sgp_branch_bwd(o.to(DEV), dy.to(DEV), ks, up, dw, db)
+    assert rel_err(d_o.float(), orq.grad) < tol(dtype)
+    ref_w = torch.cat([sd[f"blk.{n}.weight"].grad.reshape(C, -1) for n in names], dim=1)
+    ref_b = torch.stack([sd[f"blk.{n}.bias"].grad.reshape(C) for n in names], dim=0)
+    assert rel_err(ddw, ref_w) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(ddb, ref_b) < (2e-4 if dtype == torch.float32 else 2e-2)
