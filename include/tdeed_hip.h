@@ -254,7 +254,7 @@ int tdeed_fill_u8_hash(uint8_t* dst, long n, uint64_t seed, void* stream); /* sy
  * a step is bit-reproducible. */
 /* out[j] (+)= sum_p part[p][j], p < P, j < n */
 int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream);
-/* mode 0: y = gelu(x); 1: y = dy * gelu'(x); 2: y = x + dy.  n elements, multiple of 8 */
+/* mode 0: y = gelu(x); 1: y = dy * gelu'(x); 2: y = x + dy; 3: y = x * dy.  n elements, multiple of 8 */
 int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream);
 /* [R][Cc] -> [Cc][R] (weight transposes for the input-gradient contractions) */
 int tdeed_transpose(const void* x, int R, int Cc, void* y, int dtype, void* stream);
@@ -270,12 +270,20 @@ int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long ldy, int r
 /* GroupNorm(G) backward over NTC slabs.  part fp32 [B][2][C] */
 int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, int C, int G, const float* w, float eps, void* dx,
                         int accumulate, float* part, float* dw, float* db, int dtype, void* stream);
-/* SGPBlock depthwise-branch backward (modules.py:164-170): o = LayerNorm output, dy = gradient of
- * fc*phi + (convw+convkw)*psi + o; d_o [B][T][C]; d_dw [C][2ks+up+2], d_db [5][C] in tdeed_sgp_branch_fwd's packed
- * layouts.  part_w fp32 [B][C][2ks+up+2], part_b fp32 [B][5][C]. */
-int tdeed_sgp_branch_bwd(const void* o, const void* dy, int B, int T, int C, int ks, int up, const float* dw,
-                         const float* db, void* d_o, float* part_w, float* part_b, float* d_dw, float* d_db, int dtype,
-                         void* stream);
+/* depthwise-branch backward of SGPBlock (modules.py:164-170) and of either input of SGPMixer (modules.py:290-305):
+ * o = branch input (row stride ldo); g_conv / g_inst / g_id = gradients of (convw+convkw)*psi, of fc*phi and of the
+ * identity term (row stride ldg; SGPBlock passes one tensor three times, SGPMixer three slabs of d cat); d_o (row
+ * stride ld_do); d_dw [C][2ks+up+2], d_db [5][C] in tdeed_sgp_branch_fwd's packed layouts.
+ * part_w fp32 [B][C][2ks+up+2], part_b fp32 [B][5][C]. */
+int tdeed_sgp_branch_bwd(const void* o, long ldo, const void* g_conv, const void* g_inst, const void* g_id, long ldg,
+                         int B, int T, int C, int ks, int up, const float* dw, const float* db, void* d_o, long ld_do,
+                         float* part_w, float* part_b, float* d_dw, float* d_db, int dtype, void* stream);
+/* nn.Upsample(linear, align_corners=True) backward: d_xu [B][T_hi][.] (row stride ld) -> d_xn [B][T_lo][C] */
+int tdeed_upsample_bwd(const void* d_xu, long ld, int B, int T_hi, int T_lo, int C, void* d_xn, int dtype, void* stream);
+/* nn.AdaptiveMaxPool1d backward (first maximum of a window takes the gradient, like torch) */
+int tdeed_maxpool_bwd(const void* x, const void* dy, int B, int T_in, int T_out, int C, void* dx, int dtype,
+                      void* stream);
+
 
 /* ---- HIP graph capture of a launch sequence (replaces eager op-by-op dispatch) ---------------
  * begin: hipStreamBeginCapture(stream); end: EndCapture + Instantiate -> handle; launch replays. */

@@ -55,7 +55,10 @@ _SIGS = {
     "tdeed_layernorm_bwd_blocks": ([c_int], c_int),
     "tdeed_layernorm_bwd": ([P, c_long, P, c_long, c_int, c_int, P, c_float, P, c_int, P, P, P, c_int, P], c_int),
     "tdeed_groupnorm_bwd": ([P, P, c_int, c_int, c_int, c_int, P, c_float, P, c_int, P, P, P, c_int, P], c_int),
-    "tdeed_sgp_branch_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_sgp_branch_bwd": ([P, c_long, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, P, P, P, c_long, P, P, P, P,
+                              c_int, P], c_int),
+    "tdeed_upsample_bwd": ([P, c_long, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_maxpool_bwd": ([P, P, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gconv_se_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_gconv_se_fwd": ([P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P, P], c_int),
     "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),

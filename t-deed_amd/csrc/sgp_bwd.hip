@@ -30,7 +30,7 @@ extern "C" int tdeed_reduce_partials(const float* part, int P, long n, float* ou
   return TDEED_OK;
 }
 
-// elementwise: mode 0: y = gelu(x);  1: y = dy * gelu'(x);  2: y = x + dy (gradient accumulation)
+// elementwise: mode 0: y = gelu(x);  1: y = dy * gelu'(x);  2: y = x + dy (gradient accumulation);  3: y = x * dy (dropout mask)
 template <typename T>
 __global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ y,
                                                       long nchunks, int mode) {
@@ -48,15 +48,17 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ x, c
       const float cdf = 0.5f * (1.0f + erff(a[e] * 0.70710678118654752440f));
       const float pdf = 0.39894228040143267794f * expf(-0.5f * a[e] * a[e]);
       o[e] = b[e] * (cdf + a[e] * pdf);
-    } else {
+    } else if (mode == 2) {
       o[e] = a[e] + b[e];
+    } else {
+      o[e] = a[e] * b[e];
     }
   }
   Chunk<T>::store(y + i * EPC, o);
 }
 
 extern "C" int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream) {
-  TD_CHECK(x && y && (mode == 0 || dy) && n > 0 && n % 8 == 0 && mode >= 0 && mode <= 2, "eltwise: bad arguments");
+  TD_CHECK(x && y && (mode == 0 || dy) && n > 0 && n % 8 == 0 && mode >= 0 && mode <= 3, "eltwise: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32) {
     const long nc = n / 4;
@@ -401,12 +403,9 @@ extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, 
 // Given g = d out: everything is per channel, so a workgroup owns 16 channels of one clip exactly like the forward
 // kernel: o and g tiles in LDS, the forward products recomputed, d psi / d (cw+ckw) staged with a zero halo so the
 // input gradient is three more temporal correlations.  Weight gradients: one lane per (tap, channel) walks T.
-struct BranchBwdOut {            // per-lane partial sums over its t's
-  float dphi, sdpsi, sds, sg, sgo;
-};
-
 template <typename T>
-__device__ __forceinline__ void branch_bwd_core(const float* ot, const float* gt, float* dpsi, float* ds,
+__device__ __forceinline__ void branch_bwd_core(const float* ot, const float* gconv, const float* ginst,
+                                                const float* gid, float* dpsi, float* ds,
                                                 const float* wl, const Bias5& bb, bool cok, int T_len, int halo, int ks,
                                                 int up, float* red /*[17][16]*/, float* red5 /*[16][5][16]*/,
                                                 float mean_c, T* __restrict__ d_o, long ld_o, int c0, int C,
@@ -433,15 +432,15 @@ __device__ __forceinline__ void branch_bwd_core(const float* ot, const float* gt
     for (int k = 0; k < up; ++k) ckw = fmaf(wl[(2 * ks + k) * SGP_CH + c], col[(k - hu) * SGP_CH], ckw);
     const float o = col[0];
     const float fc = fmaf(wf, o, b_fc);
-    const float g = gt[t * SGP_CH + c];
-    const float vdpsi = g * (cw + ckw), vds = g * psi;
+    const float gc = gconv[t * SGP_CH + c], gi = ginst[t * SGP_CH + c];
+    const float vdpsi = gc * (cw + ckw), vds = gc * psi;
     dpsi[(halo + t) * SGP_CH + c] = vdpsi;
     ds[(halo + t) * SGP_CH + c] = vds;
-    a_dphi += g * fc;
+    a_dphi += gi * fc;
     a_dpsi += vdpsi;
     a_ds += vds;
-    a_g += g;
-    a_go += g * o;
+    a_g += gi;
+    a_go += gi * o;
   }
   red5[(tl * 5 + 0) * SGP_CH + c] = a_dphi;
   red5[(tl * 5 + 1) * SGP_CH + c] = a_dpsi;
@@ -463,7 +462,7 @@ __device__ __forceinline__ void branch_bwd_core(const float* ot, const float* gt
   const float dmean = dpre * wg / (float)T_len;
   // ---- phase B: input gradient
   for (int t = tl; t < T_len; t += 16) {
-    float a = gt[t * SGP_CH + c] * (1.0f + wf * phi) + dmean;
+    float a = gid[t * SGP_CH + c] + ginst[t * SGP_CH + c] * (wf * phi) + dmean;
     const float* dp = dpsi + (halo + t) * SGP_CH + c;
     const float* dq = ds + (halo + t) * SGP_CH + c;
     for (int k = 0; k < ks; ++k) {
@@ -496,12 +495,15 @@ __device__ __forceinline__ void branch_bwd_core(const float* ot, const float* gt
   }
 }
 
-// o: LayerNorm output [B][T][C]; dy: gradient of (fc*phi + (cw+ckw)*psi + o) [B][T][C]; d_o out [B][T][C]
-// part_w fp32 [B][C][wlen], part_b fp32 [B][5][C]
+// o: branch input [B][T][.] (row stride ldo); g_conv / g_inst / g_id: gradients of (convw+convkw)*psi, of fc*phi and of
+// the identity term (row stride ldg; SGPBlock passes the same tensor three times, SGPMixer three slabs of d cat);
+// d_o out (row stride ld_do).  part_w fp32 [B][C][wlen], part_b fp32 [B][5][C]
 template <typename T>
-__global__ __launch_bounds__(256) void sgp_branch_bwd_kernel(const T* __restrict__ o, const T* __restrict__ dy, int T_len,
-                                                             int C, int ks, int up, const float* __restrict__ dw,
-                                                             const float* __restrict__ db, T* __restrict__ d_o,
+__global__ __launch_bounds__(256) void sgp_branch_bwd_kernel(const T* __restrict__ o, long ldo, const T* __restrict__ g_conv,
+                                                             const T* __restrict__ g_inst, const T* __restrict__ g_id,
+                                                             long ldg, int T_len, int C, int ks, int up,
+                                                             const float* __restrict__ dw, const float* __restrict__ db,
+                                                             T* __restrict__ d_o, long ld_do,
                                                              float* __restrict__ part_w, float* __restrict__ part_b) {
   extern __shared__ float sm[];
   const int halo = up >> 1;
@@ -510,23 +512,32 @@ __global__ __launch_bounds__(256) void sgp_branch_bwd_kernel(const T* __restrict
   float* ot = sm;
   float* dpsi = ot + trows * SGP_CH;
   float* ds = dpsi + trows * SGP_CH;
-  float* gt = ds + trows * SGP_CH;
-  float* res = gt + T_len * SGP_CH;
+  float* gc = ds + trows * SGP_CH;
+  const bool same = (g_conv == g_inst) && (g_inst == g_id);     // SGPBlock: one gradient tile serves all three roles
+  float* gi = same ? gc : gc + T_len * SGP_CH;
+  float* gd = same ? gc : gi + T_len * SGP_CH;
+  float* res = gc + 3 * T_len * SGP_CH;
   float* wl = res + T_len * SGP_CH;
   float* red = wl + wlen * SGP_CH;                              // [17][16]
   float* red5 = red + 17 * SGP_CH;                              // [16][5][16]
   const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
-  const long base = (long)b * T_len * C;
   const int c = threadIdx.x & 15;
   const bool cok = c0 + c < C;
   {
     float ov[SGP_TI][Chunk<T>::N], gv[SGP_TI][Chunk<T>::N], wv[SGP_WI];
-    tile_issue<T>(o + base, C, T_len, c0, C, ov);
-    tile_issue<T>(dy + base, C, T_len, c0, C, gv);
+    tile_issue<T>(o + (long)b * T_len * ldo, ldo, T_len, c0, C, ov);
+    tile_issue<T>(g_conv + (long)b * T_len * ldg, ldg, T_len, c0, C, gv);
     dw_issue(dw, wlen, c0, C, wv);
     tile_commit<T>(ov, T_len, c0, C, ot, halo);
-    tile_commit<T>(gv, T_len, c0, C, gt, 0);
+    tile_commit<T>(gv, T_len, c0, C, gc, 0);
     dw_commit(wv, wlen, c0, C, wl);
+    if (!same) {
+      float g2[SGP_TI][Chunk<T>::N], g3[SGP_TI][Chunk<T>::N];
+      tile_issue<T>(g_inst + (long)b * T_len * ldg, ldg, T_len, c0, C, g2);
+      tile_issue<T>(g_id + (long)b * T_len * ldg, ldg, T_len, c0, C, g3);
+      tile_commit<T>(g2, T_len, c0, C, gi, 0);
+      tile_commit<T>(g3, T_len, c0, C, gd, 0);
+    }
   }
   const Bias5 bb = bias_issue(db, C, c0 + c, C);
   for (int i = threadIdx.x; i < 2 * halo * SGP_CH; i += 256) {
@@ -539,39 +550,163 @@ __global__ __launch_bounds__(256) void sgp_branch_bwd_kernel(const T* __restrict
   tile_mean(ot, T_len, halo, red);
   const float mean_c = red[16 * SGP_CH + c];
   __syncthreads();
-  branch_bwd_core<T>(ot, gt, dpsi, ds, wl, bb, cok, T_len, halo, ks, up, red, red5, mean_c, d_o + base, C, c0, C,
-                     part_w + (long)b * C * wlen, part_b + (long)b * 5 * C, res);
+  branch_bwd_core<T>(ot, gc, gi, gd, dpsi, ds, wl, bb, cok, T_len, halo, ks, up, red, red5, mean_c,
+                     d_o + (long)b * T_len * ld_do, ld_do, c0, C, part_w + (long)b * C * wlen, part_b + (long)b * 5 * C,
+                     res);
 }
 
 // part_w: fp32 [B][C][wlen], part_b: fp32 [B][5][C]; d_dw [C][wlen], d_db [5][C] (the forward's packed layouts)
-extern "C" int tdeed_sgp_branch_bwd(const void* o, const void* dy, int B, int T, int C, int ks, int up, const float* dw,
-                                    const float* db, void* d_o, float* part_w, float* part_b, float* d_dw, float* d_db,
+extern "C" int tdeed_sgp_branch_bwd(const void* o, long ldo, const void* g_conv, const void* g_inst, const void* g_id,
+                                    long ldg, int B, int T, int C, int ks, int up, const float* dw, const float* db,
+                                    void* d_o, long ld_do, float* part_w, float* part_b, float* d_dw, float* d_db,
                                     int dtype, void* stream) {
-  TD_CHECK(o && dy && dw && db && d_o && part_w && part_b && d_dw && d_db, "sgp_branch_bwd: null pointer");
-  TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_branch_bwd: bad sizes");
+  TD_CHECK(o && g_conv && g_inst && g_id && dw && db && d_o && part_w && part_b && d_dw && d_db,
+           "sgp_branch_bwd: null pointer");
+  TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks && ldo % 8 == 0 && ldg % 8 == 0 &&
+               ld_do % 8 == 0, "sgp_branch_bwd: bad sizes");
   TD_CHECK(T <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80, "sgp_branch_bwd: T=%d / taps beyond the staging registers", T);
   const int halo = up / 2, wlen = 2 * ks + up + 2;
-  const size_t smem = (size_t)(3 * (T + 2 * halo) * SGP_CH + 2 * T * SGP_CH + wlen * SGP_CH + 17 * SGP_CH + 80 * SGP_CH) *
+  const size_t smem = (size_t)(3 * (T + 2 * halo) * SGP_CH + 4 * T * SGP_CH + wlen * SGP_CH + 17 * SGP_CH + 80 * SGP_CH) *
                       sizeof(float);
-  TD_CHECK(smem <= 128 * 1024, "sgp_branch_bwd: T=%d too long for the LDS window", T);
+  TD_CHECK(smem <= 144 * 1024, "sgp_branch_bwd: T=%d too long for the LDS window", T);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     if (e != hipSuccess) { tdeed_set_error("sgp_branch_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
     attr_set = true;
   }
   dim3 grid(B, cdiv(C, SGP_CH));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(sgp_branch_bwd_kernel<float>, grid, dim3(256), smem, st, (const float*)o, (const float*)dy, T, C, ks,
-                       up, dw, db, (float*)d_o, part_w, part_b);
+    hipLaunchKernelGGL(sgp_branch_bwd_kernel<float>, grid, dim3(256), smem, st, (const float*)o, ldo, (const float*)g_conv,
+                       (const float*)g_inst, (const float*)g_id, ldg, T, C, ks, up, dw, db, (float*)d_o, ld_do, part_w,
+                       part_b);
   else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(sgp_branch_bwd_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)o, (const bf16_t*)dy, T, C,
-                       ks, up, dw, db, (bf16_t*)d_o, part_w, part_b);
+    hipLaunchKernelGGL(sgp_branch_bwd_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)o, ldo,
+                       (const bf16_t*)g_conv, (const bf16_t*)g_inst, (const bf16_t*)g_id, ldg, T, C, ks, up, dw, db,
+                       (bf16_t*)d_o, ld_do, part_w, part_b);
   else { tdeed_set_error("sgp_branch_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("sgp_branch_bwd");
   int rc = tdeed_reduce_partials(part_w, B, (long)C * wlen, d_dw, 0, stream);
   if (rc == TDEED_OK) rc = tdeed_reduce_partials(part_b, B, 5L * C, d_db, 0, stream);
   return rc;
+}
+
+// =========================================================================== linear up-sampling backward
+// forward (mixer_branch): xu[t] = l0 * xn[i0] + l1 * xn[i1], src = t * (T_lo-1)/(T_hi-1), i0 = floor(src),
+// i1 = min(i0+1, T_lo-1).  d xn[j] gathers over every t (T_hi is a few hundred): no atomics, fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ d_xu, long ld, int T_hi, int T_lo, int C,
+                                                           T* __restrict__ d_xn, long total) {
+  constexpr int EPC = Chunk<T>::N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cpr = C / EPC;
+  const int ck = (int)(idx % cpr);
+  const long r = idx / cpr;
+  const int j = (int)(r % T_lo);
+  const long b = r / T_lo;
+  const float scale = (T_hi > 1) ? (float)(T_lo - 1) / (float)(T_hi - 1) : 0.f;
+  float a[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+  for (int t = 0; t < T_hi; ++t) {
+    float wgt = 0.f;
+    if (T_hi == T_lo) {
+      wgt = t == j ? 1.f : 0.f;
+    } else {
+      const float src = scale * (float)t;
+      const int i0 = (int)src;
+      const int i1 = i0 + (i0 < T_lo - 1 ? 1 : 0);
+      const float l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+      if (i0 == j) wgt += 1.f - l1;
+      if (i1 == j) wgt += l1;
+    }
+    if (wgt != 0.f) {
+      float v[EPC];
+      Chunk<T>::load(d_xu + ((long)b * T_hi + t) * ld + ck * EPC, v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) a[e] = fmaf(wgt, v[e], a[e]);
+    }
+  }
+  Chunk<T>::store(d_xn + ((long)b * T_lo + j) * C + ck * EPC, a);
+}
+
+extern "C" int tdeed_upsample_bwd(const void* d_xu, long ld, int B, int T_hi, int T_lo, int C, void* d_xn, int dtype,
+                                  void* stream) {
+  TD_CHECK(d_xu && d_xn && B > 0 && T_hi >= T_lo && T_lo > 0 && C % 8 == 0 && ld % 8 == 0, "upsample_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const long total = (long)B * T_lo * (C / 4);
+    hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)d_xu, ld, T_hi, T_lo, C, (float*)d_xn, total);
+  } else if (dtype == TDEED_BF16) {
+    const long total = (long)B * T_lo * (C / 8);
+    hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)d_xu, ld, T_hi, T_lo, C, (bf16_t*)d_xn, total);
+  } else { tdeed_set_error("upsample_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("upsample_bwd");
+  return TDEED_OK;
+}
+
+// =========================================================================== adaptive max-pool backward
+// d x[t] = sum over the windows i that contain t and whose (first) maximum sits at t of d y[i]; windows as in the
+// forward: [floor(i*L/O), ceil((i+1)*L/O)).  Gather form, no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int T_in,
+                                                          int T_out, int C, T* __restrict__ dx, long total) {
+  constexpr int EPC = Chunk<T>::N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cpr = C / EPC;
+  const int ck = (int)(idx % cpr);
+  const long r = idx / cpr;
+  const int t = (int)(r % T_in);
+  const long b = r / T_in;
+  float a[EPC], xt[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+  Chunk<T>::load(x + ((long)b * T_in + t) * C + ck * EPC, xt);
+  // candidate windows: i with lo_i <= t < hi_i;  i ranges around t*O/L
+  const int i_lo = max(0, (int)(((long)t * T_out) / T_in) - 1), i_hi = min(T_out - 1, i_lo + 3);
+  for (int i = i_lo; i <= i_hi; ++i) {
+    const int lo = (int)(((long)i * T_in) / T_out);
+    const int hi = (int)((((long)(i + 1)) * T_in + T_out - 1) / T_out);
+    if (t < lo || t >= hi) continue;
+    bool first_max[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) first_max[e] = true;
+    for (int u = lo; u < hi; ++u) {
+      if (u == t) continue;
+      float v[EPC];
+      Chunk<T>::load(x + ((long)b * T_in + u) * C + ck * EPC, v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)                            // an earlier equal value wins the tie, a later one does not
+        if (v[e] > xt[e] || (u < t && v[e] == xt[e])) first_max[e] = false;
+    }
+    float g[EPC];
+    Chunk<T>::load(dy + ((long)b * T_out + i) * C + ck * EPC, g);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (first_max[e]) a[e] += g[e];
+  }
+  Chunk<T>::store(dx + ((long)b * T_in + t) * C + ck * EPC, a);
+}
+
+extern "C" int tdeed_maxpool_bwd(const void* x, const void* dy, int B, int T_in, int T_out, int C, void* dx, int dtype,
+                                 void* stream) {
+  TD_CHECK(x && dy && dx && B > 0 && T_in >= T_out && T_out > 0 && C % 8 == 0, "maxpool_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const long total = (long)B * T_in * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)x,
+                       (const float*)dy, T_in, T_out, C, (float*)dx, total);
+  } else if (dtype == TDEED_BF16) {
+    const long total = (long)B * T_in * (C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)x, (const bf16_t*)dy, T_in, T_out, C, (bf16_t*)dx, total);
+  } else { tdeed_set_error("maxpool_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("maxpool_bwd");
+  return TDEED_OK;
 }

@@ -6,7 +6,7 @@ import torch
 from . import _lib
 from ._lib import call, ptr, stream_ptr, dtype_code
 
-GELU_FWD, GELU_BWD, ADD = 0, 1, 2
+GELU_FWD, GELU_BWD, ADD, MUL = 0, 1, 2, 3
 
 
 def _f32(shape, dev):
@@ -67,14 +67,34 @@ def groupnorm_bwd(x, dy, G, w, eps=1e-5, dx=None, accumulate=False):
     return dx, dw, db
 
 
-def sgp_branch_bwd(o, dy, ks, up, dw, db, d_o=None):
-    """-> d_o (B,T,C), d_dw (C, 2ks+up+2), d_db (5, C) in the packed layouts of ops.sgp_branch."""
-    B, T, C = o.shape
+def sgp_branch_bwd(o, g, ks, up, dw, db, d_o=None, ldo=None, ldg=None, ld_do=None, B=None, T=None, C=None):
+    """-> d_o (B,T,C), d_dw (C, 2ks+up+2), d_db (5, C) in the packed layouts of ops.sgp_branch.
+    g: one tensor (SGPBlock) or a tuple (g_conv, g_inst, g_id) of views with a common row stride ldg (SGPMixer)."""
+    gs = g if isinstance(g, (tuple, list)) else (g, g, g)
+    if B is None:
+        B, T, C = o.shape
     dev = o.device
     wlen = 2 * ks + up + 2
     if d_o is None:
-        d_o = torch.empty_like(o)
+        d_o = torch.empty((B, T, C), dtype=o.dtype, device=dev)
     pw, pb, ddw, ddb = _f32((B, C, wlen), dev), _f32((B, 5, C), dev), _f32((C, wlen), dev), _f32((5, C), dev)
-    call("tdeed_sgp_branch_bwd", ptr(o), ptr(dy), B, T, C, ks, up, ptr(dw), ptr(db), ptr(d_o), ptr(pw), ptr(pb), ptr(ddw),
-         ptr(ddb), dtype_code(o.dtype), stream_ptr())
+    call("tdeed_sgp_branch_bwd", ptr(o), (C if ldo is None else ldo), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]),
+         (C if ldg is None else ldg), B, T, C, ks, up, ptr(dw), ptr(db), ptr(d_o), (C if ld_do is None else ld_do), ptr(pw),
+         ptr(pb), ptr(ddw), ptr(ddb), dtype_code(o.dtype), stream_ptr())
     return d_o, ddw, ddb
+
+
+def upsample_bwd(d_xu, T_lo, ld=None, B=None, T_hi=None, C=None):
+    if B is None:
+        B, T_hi, C = d_xu.shape
+    out = torch.empty((B, T_lo, C), dtype=d_xu.dtype, device=d_xu.device)
+    call("tdeed_upsample_bwd", ptr(d_xu), (C if ld is None else ld), B, T_hi, T_lo, C, ptr(out), dtype_code(d_xu.dtype),
+         stream_ptr())
+    return out
+
+
+def maxpool_bwd(x, dy):
+    B, T_in, C = x.shape
+    dx = torch.empty_like(x)
+    call("tdeed_maxpool_bwd", ptr(x), ptr(dy), B, T_in, dy.shape[1], C, ptr(dx), dtype_code(x.dtype), stream_ptr())
+    return dx

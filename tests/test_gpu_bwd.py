@@ -120,3 +120,92 @@ def test_sgp_branch_bwd(bops, dtype, B, C, T, ks, r):
     ref_b = torch.stack([sd[f"blk.{n}.bias"].grad.reshape(C) for n in names], dim=0)
     assert rel_err(ddw, ref_w) < (2e-4 if dtype == torch.float32 else 2e-2)
     assert rel_err(ddb, ref_b) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_and_maxpool_bwd(bops, dtype):
+    for (T_hi, T_lo) in [(25, 13), (100, 50), (250, 125), (13, 13)]:
+        g = rnd(217, "g", (2, T_hi, 32)).to(dtype)
+        xr = rnd(218, "x", (2, T_lo, 32)).float().requires_grad_(True)
+        O.upsample_linear(xr.permute(0, 2, 1), T_hi).permute(0, 2, 1).backward(g.float())
+        assert rel_err(bops.upsample_bwd(g.to(DEV), T_lo).float(), xr.grad) < tol(dtype)
+    for (T_in, T_out) in [(25, 13), (100, 50), (125, 63), (50, 25)]:
+        x = (rnd(219, "x", (2, T_in, 32)) * 4).round().div(4).to(dtype)          # quantised -> ties inside windows
+        g = rnd(220, "g", (2, T_out, 32)).to(dtype)
+        xr = x.float().requires_grad_(True)
+        # nn.AdaptiveMaxPool1d itself (the oracle's slice+amax restatement splits the gradient between tied maxima;
+        # the real op, like the kernel, gives it to the first maximum of the window)
+        y = F.adaptive_max_pool1d(xr.permute(0, 2, 1), T_out)
+        assert torch.equal(y, O.adaptive_max_pool(xr.permute(0, 2, 1), T_out))
+        y.permute(0, 2, 1).backward(g.float())
+        got = bops.maxpool_bwd(x.to(DEV), g.to(DEV)).float().cpu()
+        assert rel_err(got, xr.grad) < tol(dtype)
+
+
+def _temporal_state(C, T, n, ks, r, K1, radi, seed=41):
+    sd = {k: t(v) for k, v in module_state("pyramid", "_temp_fine", seed, C=C, ks=ks, r=r, n=n).items()}
+    sd["_pred_fine._fc_out.weight"] = rnd(seed, "hw", (K1, C), 0.2)
+    sd["_pred_fine._fc_out.bias"] = rnd(seed, "hb", (K1,), 0.1)
+    if radi:
+        sd["_pred_displ._fc_out.weight"] = rnd(seed, "dw", (1, C), 0.2)
+        sd["_pred_displ._fc_out.bias"] = rnd(seed, "db", (1,), 0.1)
+    return sd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [dict(B=2, C=32, T=25, n=2, ks=7, r=4, K1=5, radi=2, soft=False, drop=False),
+                                  dict(B=2, C=368, T=100, n=2, ks=7, r=4, K1=5, radi=2, soft=False, drop=True),
+                                  dict(B=1, C=64, T=50, n=3, ks=9, r=4, K1=13, radi=0, soft=True, drop=True)])
+def test_temporal_stack_loss_and_grads_match_autograd(dtype, geom):
+    """SGP encoder-decoder + heads (+dropout) + CE/MSE: loss, every parameter gradient and d loss / d features against
+    torch autograd on the CPU oracle."""
+    from tdeed_amd.temporal_train import TemporalStack
+    from tdeed_amd import synth
+    g = geom
+    B, C, T, K1 = g["B"], g["C"], g["T"], g["K1"]
+    cfg = dict(n_layers=g["n"], clip_len=T, num_classes=K1 - 1, radi_displacement=g["radi"])
+    sd = _temporal_state(C, T, g["n"], g["ks"], g["r"], K1, g["radi"])
+    feat = rnd(221, "feat", (B, T, C)).to(dtype)
+    lab_np, labD_np = synth.labels(222, B, T, K1 - 1, max(g["radi"], 1), fg_frac=0.3)
+    lab = t(lab_np).long()
+    labD = t(labD_np).float() if g["radi"] else None
+    soft = None
+    if g["soft"]:
+        a = torch.nn.functional.one_hot(lab, K1).float()
+        b2 = torch.nn.functional.one_hot(t(synth.labels(224, B, T, K1 - 1, 1, fg_frac=0.3)[0]).long(), K1).float()
+        soft = 0.7 * a + 0.3 * b2
+    masks = None
+    if g["drop"]:
+        masks = [(rnd(225 + i, "m", (B, T, C)) > 0).float() * 2.0 for i in range(2 if g["radi"] else 1)]
+    # ---- reference: autograd on the oracle (fp32, inputs rounded like the device tensors)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.float().requires_grad_(True)
+    enc = O.ed_sgp_mixer(fr, sdr, g["n"], T)
+    dm = None if masks is None else ((masks[1] if g["radi"] else None), masks[0])
+    cls, displ = O.heads(enc, sdr, g["radi"], drop_mask=dm)
+    ref_loss = O.loss_fn(cls, soft if g["soft"] else lab, displ, labD)
+    ref_loss.backward()
+    # ---- device
+    sdd = {k: v.to(DEV) for k, v in sd.items()}
+    ts = TemporalStack(sdd, cfg, act_dtype=dtype)
+    loss, grads, d_feat = ts.loss_and_grads(
+        feat.to(DEV), None if g["soft"] else lab.reshape(-1).to(DEV), labelD=None if labD is None else labD.reshape(-1).to(DEV),
+        soft=None if soft is None else soft.reshape(-1, K1).contiguous().to(DEV),
+        drop_masks=None if masks is None else [m.to(dtype).to(DEV) for m in masks])
+    lt = 1e-4 if dtype == torch.float32 else 3e-2
+    assert abs(float(loss[0]) - float(ref_loss.detach())) < lt * max(1.0, abs(float(ref_loss.detach())))
+    assert set(grads) == set(sd), set(sd) ^ set(grads)
+    if dtype == torch.float32:      # element-wise: max error relative to the tensor's largest entry
+        assert rel_err(d_feat.float(), fr.grad) < 2e-3
+        worst = max((rel_err(grads[k], sdr[k].grad), k) for k in sd)
+        assert worst[0] < 2e-3, worst
+    else:                           # bf16 activations and activation gradients: norm-wise
+        l2 = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))  # noqa: E731
+        assert l2(d_feat.float(), fr.grad) < 0.1        # ~10 modules deep, every gradient tensor rounded to bf16
+        # per tensor (sums with heavy cancellation, e.g. conv biases, carry the bf16 noise of the whole chain) ...
+        worst = max((l2(grads[k], sdr[k].grad), k) for k in sd)
+        assert worst[0] < 0.3, worst
+        # ... and the whole gradient vector
+        ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sd])
+        gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sd])
+        assert float((ga - gr).norm() / gr.norm()) < 3e-2
