@@ -97,7 +97,8 @@ int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0
 int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype);
 int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                        const float* w, const void* wfrag, const float* scale, const float* shift,
-                       void* y, float* pooled, int dtype, void* stream);
+                       void* y, float* pooled, int relu /* 0: y = conv*scale+shift (training: raw map for the
+                       batch statistics) */, int dtype, void* stream);
 
 /* ---- whole bottleneck in one launch (bf16, stride 1, identity shortcut, map <= 64 px: s4.b2.. of RegNetY-200MF)
  * conv1(+gate-shift splice G in front)+BN+ReLU -> grouped 3x3+BN+ReLU -> SE -> conv3+BN+residual+ReLU, one
@@ -284,6 +285,42 @@ int tdeed_upsample_bwd(const void* d_xu, long ld, int B, int T_hi, int T_lo, int
 int tdeed_maxpool_bwd(const void* x, const void* dy, int B, int T_in, int T_out, int C, void* dx, int dtype,
                       void* stream);
 
+
+/* ---- train-mode trunk pieces (trunk_bwd.hip): BatchNorm with batch statistics, SE with kept intermediates, grouped
+ * 3x3 backward.  Maps are channels-last [M][C] in the activation dtype; statistics and parameter gradients fp32. */
+int tdeed_bn_slabs(long M);
+/* statistics of the raw conv map z: mean/rstd (kept for the backward), a = w*rstd, b = bias - mean*a (for
+ * tdeed_bn_apply), running_mean/var updated in place when non-NULL (momentum 0.1, unbiased variance, like
+ * nn.BatchNorm2d).  part fp32 [tdeed_bn_slabs(M)][2][C] */
+int tdeed_bn_train_stats(const void* z, long M, int C, const float* w, const float* bias, float eps, float momentum,
+                         float* part, float* mean, float* rstd, float* a, float* b, float* run_mean, float* run_var,
+                         int dtype, void* stream);
+/* y = act(z * a[c] + b[c] + res) */
+int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu, void* y,
+                   int dtype, void* stream);
+/* BatchNorm (training) backward; y (the block's output) gives the ReLU mask when relu != 0; d_res (optional) receives
+ * the masked gradient = gradient of the residual summed in before the ReLU.  sums fp32 [2][C] scratch. */
+int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, int relu, long M, int C, const float* mean,
+                       const float* rstd, const float* w, float* part, float* sums, void* dz, void* d_res, float* dw,
+                       float* db, int dtype, void* stream);
+/* p[n][c] = mean_px x (x2 NULL: the SE squeeze) or sum_px x*x2 (gradient of the SE gate) */
+int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, float* p, int dtype, void* stream);
+/* SE excitation keeping the hidden units: w1t [C][R], w2t [R][C] */
+int tdeed_se_train_fwd(const float* p, int N, int C, int R, const float* w1t, const float* b1, const float* w2t,
+                       const float* b2, float* hid, float* gate, void* stream);
+/* its backward: w1 [R][C], w2 [C][R]; d_pre2 [N][C], d_hid [N][R] feed tdeed_wgrad, d_p [N][C] is d(squeeze) */
+int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid, int N, int C, int R, const float* w1,
+                       const float* w2, float* d_pre2, float* d_hid, float* d_p, void* stream);
+/* y[n][px][c] = x[n][px][c] * s[n][c] + add[n][c] * add_scale (add may be NULL) */
+int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C, void* y,
+                     int dtype, void* stream);
+/* grouped 3x3 backward: dx and dw (fp32, the forward's packed [G][9][gw][gw]).
+ * part fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw] */
+int tdeed_gconv_wgrad_slabs(long npix_out);
+int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride, const float* w,
+                       void* dx, float* part, float* dw, int dtype, void* stream);
+/* mode 0: out[(f,yo,xo)] = in[(f,2yo,2xo)] (operand of the stride-2 shortcut conv); mode 1: out[(f,2yo,2xo)] += in[(f,yo,xo)] */
+int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int wi, int C, int mode, int dtype, void* stream);
 
 /* ---- HIP graph capture of a launch sequence (replaces eager op-by-op dispatch) ---------------
  * begin: hipStreamBeginCapture(stream); end: EndCapture + Instantiate -> handle; launch replays. */

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NTHR) void gconv3x3_kernel(const T* __restrict__ x,
                                                         int stride, const float* __restrict__ wp,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, T* __restrict__ y,
-                                                        float* __restrict__ pooled, int Ho, int Wo) {
+                                                        float* __restrict__ pooled, int Ho, int Wo, int relu) {
   constexpr int EPC = Chunk<T>::N;
   constexpr int NCH = GW / EPC;   // 16-B chunks per pixel per group
   constexpr int NW = NTHR / 64;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NTHR) void gconv3x3_kernel(const T* __restrict__ x,
     float outv[GW];
 #pragma unroll
     for (int o = 0; o < GW; ++o) {
-      outv[o] = fmaxf(acc[o] * sc[o] + sh[o], 0.f);
+      outv[o] = relu ? fmaxf(acc[o] * sc[o] + sh[o], 0.f) : acc[o] * sc[o] + sh[o];
     }
     T* dst = yout + (long)p * C;
 #pragma unroll
@@ -172,15 +172,15 @@ __global__ __launch_bounds__(NTHR) void gconv3x3_kernel(const T* __restrict__ x,
 
 template <typename T, int GW>
 static int launch_gconv(const void* x, int N, int Hi, int Wi, int C, int stride, const float* w,
-                        const float* scale, const float* shift, void* y, float* pooled, hipStream_t st) {
+                        const float* scale, const float* shift, void* y, float* pooled, int relu, hipStream_t st) {
   const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   dim3 grid(C / GW, N);
   if (Ho * Wo <= 64)
     hipLaunchKernelGGL((gconv3x3_kernel<T, GW, 64>), grid, dim3(64), 0, st, (const T*)x, Hi, Wi, C, stride, w,
-                       scale, shift, (T*)y, pooled, Ho, Wo);
+                       scale, shift, (T*)y, pooled, Ho, Wo, relu);
   else
     hipLaunchKernelGGL((gconv3x3_kernel<T, GW, 256>), grid, dim3(256), 0, st, (const T*)x, Hi, Wi, C, stride, w,
-                       scale, shift, (T*)y, pooled, Ho, Wo);
+                       scale, shift, (T*)y, pooled, Ho, Wo, relu);
   TD_LAUNCH_CHECK("gconv3x3");
   return TDEED_OK;
 }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
                                                             const float* __restrict__ shift,
                                                             bf16_t* __restrict__ y, float* __restrict__ pooled,
                                                             int Ho, int Wo, int band, int nbands, int CSP, int PS,
-                                                            int rows_in) {
+                                                            int rows_in, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   __shared__ float red[4][16];
   // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = fmaxf(acc[r] * sc[r] + sh[r], 0.f);
+        const float v = relu ? fmaxf(acc[r] * sc[r] + sh[r], 0.f) : acc[r] * sc[r] + sh[r];
         o[r] = (bf16_t)v;
         psum[r] += (float)o[r];
       }
@@ -358,7 +358,7 @@ extern "C" int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype
 
 extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                                   const float* w, const void* wfrag, const float* scale, const float* shift,
-                                  void* y, float* pooled, int dtype, void* stream) {
+                                  void* y, float* pooled, int relu, int dtype, void* stream) {
   TD_CHECK(x && scale && shift && y && pooled, "gconv3x3: null pointer");
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "gconv3x3: group width %d / C %d unsupported", gw, C);
   TD_CHECK(stride == 1 || stride == 2, "gconv3x3: stride %d", stride);
@@ -366,15 +366,15 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32) {
     TD_CHECK(w, "gconv3x3: fp32 path needs the packed fp32 weights");
-    return gw == 8 ? launch_gconv<float, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
-                   : launch_gconv<float, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
+    return gw == 8 ? launch_gconv<float, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, relu, st)
+                   : launch_gconv<float, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, relu, st);
   }
   if (dtype == TDEED_BF16) {
     GcGeom g = gc_geom(Hi, Wi, C, stride);
     if (!wfrag || g.band <= 0) {     // no MFMA fragments given (or a row does not fit LDS): VALU kernel
       TD_CHECK(w, "gconv3x3: no weights");
-      return gw == 8 ? launch_gconv<bf16_t, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st)
-                     : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, st);
+      return gw == 8 ? launch_gconv<bf16_t, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, relu, st)
+                     : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, relu, st);
     }
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     dim3 grid((unsigned)((long)g.nbands * g.nslabs * N));
@@ -382,11 +382,11 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
     if (stride == 1)
       hipLaunchKernelGGL(gconv3x3_mfma_kernel<1>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
                          (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP,
-                         g.PS, g.rows_in);
+                         g.PS, g.rows_in, relu);
     else
       hipLaunchKernelGGL(gconv3x3_mfma_kernel<2>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
                          (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP,
-                         g.PS, g.rows_in);
+                         g.PS, g.rows_in, relu);
     TD_LAUNCH_CHECK("gconv3x3_mfma");
     return TDEED_OK;
   }

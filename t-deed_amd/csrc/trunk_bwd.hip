@@ -1,0 +1,609 @@
+// Train-mode pieces of the RegNetY trunk (timm Bottleneck / BatchNorm2d / SEModule as called from
+// /root/reference/model/model.py:38-45,133-135): batch-statistics BatchNorm forward and backward on channels-last
+// [M][C] maps, the SE excitation with its intermediates kept for the backward, and the small row-wise helpers
+// around them.  Parameter gradients come out of ordered partial sums (no float atomics).
+#include "common.h"
+
+// =========================================================================== column statistics of an [M][C] map
+// part[slab][0][c] = sum_m v(m,c), part[slab][1][c] = sum_m v(m,c) * u(m,c) over the slab's rows, where
+//   mode 0 (BN forward):  v = z,             u = z                      -> sum, sum of squares
+//   mode 1 (BN backward): v = g,             u = (z - mean) * rstd      -> sum g, sum g * xhat,
+//                         g = dy masked by y > 0 when a ReLU follows the BN (relu = 1)
+// lanes = (row lane, channel chunk); every lane keeps 4 loads in flight.
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, const T* __restrict__ dy,
+                                                       const T* __restrict__ y, long M, int C, int mode, int relu,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       long rows_per_slab, float* __restrict__ part) {
+  constexpr int EPC = Chunk<T>::N;
+  extern __shared__ float sred[];                              // [RL][2][C]
+  const int nch = C / EPC;
+  const int RL = 256 / nch > 0 ? 256 / nch : 1;
+  const long m0 = (long)blockIdx.x * rows_per_slab, m1 = min(M, m0 + rows_per_slab);
+  for (int ch = threadIdx.x % nch, rl = threadIdx.x / nch; rl < RL && ch < nch; ch += 256) {      // one pass if nch <= 256
+    const int c0 = ch * EPC;
+    float s1[EPC], s2[EPC], mu[EPC], rs[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      s1[e] = 0.f; s2[e] = 0.f;
+      mu[e] = mode ? mean[c0 + e] : 0.f;
+      rs[e] = mode ? rstd[c0 + e] : 0.f;
+    }
+    for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * 4) {
+      float zv[4][EPC], gv[4][EPC], yv[4][EPC];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const long r = min(r0 + (long)b * RL, m1 - 1);
+        Chunk<T>::load(z + r * C + c0, zv[b]);
+        if (mode) Chunk<T>::load(dy + r * C + c0, gv[b]);
+        if (mode && relu) Chunk<T>::load(y + r * C + c0, yv[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (r0 + (long)b * RL < m1) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            if (mode == 0) {
+              s1[e] += zv[b][e];
+              s2[e] = fmaf(zv[b][e], zv[b][e], s2[e]);
+            } else {
+              const float g = (relu && !(yv[b][e] > 0.f)) ? 0.f : gv[b][e];
+              s1[e] += g;
+              s2[e] = fmaf(g, (zv[b][e] - mu[e]) * rs[e], s2[e]);
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sred[(rl * 2 + 0) * C + c0 + e] = s1[e];
+      sred[(rl * 2 + 1) * C + c0 + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * C; j += 256) {
+    float v = 0.f;
+    for (int rl = 0; rl < RL; ++rl) v += sred[rl * 2 * C + j];
+    part[(long)blockIdx.x * 2 * C + j] = v;
+  }
+}
+
+// sums [2][C] (folded partials) -> mean, rstd, the affine a = w * rstd, b = bias - mean * a, running statistics
+// (torch BatchNorm: biased variance to normalise, unbiased M/(M-1) into running_var, momentum 0.1)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int P, long M, int C,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ a,
+                                                          float* __restrict__ b, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;                                    // a few hundred partials per channel: fold in double
+  for (int p = 0; p < P; ++p) {
+    s1 += (double)part[((long)p * 2 + 0) * C + c];
+    s2 += (double)part[((long)p * 2 + 1) * C + c];
+  }
+  const double mu = s1 / (double)M;
+  double var = s2 / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  rstd[c] = rs;
+  a[c] = w[c] * rs;
+  b[c] = bias[c] - (float)mu * w[c] * rs;
+  if (run_mean) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+}
+
+static int colstats_slabs(long M, long* rows_per_slab) {
+  long slabs = (M + 2047) / 2048;
+  if (slabs > 1024) slabs = 1024;
+  if (slabs < 1) slabs = 1;
+  *rows_per_slab = (M + slabs - 1) / slabs;
+  return (int)((M + *rows_per_slab - 1) / *rows_per_slab);
+}
+
+extern "C" int tdeed_bn_slabs(long M) { long r; return colstats_slabs(M, &r); }
+
+template <typename T>
+static int launch_colstats(const void* z, const void* dy, const void* y, long M, int C, int mode, int relu,
+                           const float* mean, const float* rstd, float* part, hipStream_t st) {
+  long rps;
+  const int slabs = colstats_slabs(M, &rps);
+  const int nch = C / Chunk<T>::N;
+  const int RL = 256 / nch > 0 ? 256 / nch : 1;
+  hipLaunchKernelGGL(colstats_kernel<T>, dim3(slabs), dim3(256), (size_t)RL * 2 * C * sizeof(float), st, (const T*)z,
+                     (const T*)dy, (const T*)y, M, C, mode, relu, mean, rstd, rps, part);
+  return slabs;
+}
+
+// BatchNorm (training) statistics of z [M][C]: mean/rstd [C] (kept for the backward), a/b [C] (the affine the apply
+// pass uses), running statistics updated in place when given.  part: fp32 [tdeed_bn_slabs(M)][2][C].
+extern "C" int tdeed_bn_train_stats(const void* z, long M, int C, const float* w, const float* bias, float eps,
+                                    float momentum, float* part, float* mean, float* rstd, float* a, float* b,
+                                    float* run_mean, float* run_var, int dtype, void* stream) {
+  TD_CHECK(z && w && bias && part && mean && rstd && a && b, "bn_train_stats: null pointer");
+  TD_CHECK(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "bn_train_stats: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  int slabs;
+  if (dtype == TDEED_F32) slabs = launch_colstats<float>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, part, st);
+  else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, part, st);
+  else { tdeed_set_error("bn_train_stats: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("bn colstats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, slabs, M, C, w, bias, eps, momentum,
+                     mean, rstd, a, b, run_mean, run_var);
+  TD_LAUNCH_CHECK("bn_finalize");
+  return TDEED_OK;
+}
+
+// =========================================================================== per-channel affine (+ residual, ReLU)
+// y = act(z * a[c] + b[c] + res)
+template <typename T>
+__global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, const float* __restrict__ a,
+                                                     const float* __restrict__ b, const T* __restrict__ res, int relu,
+                                                     T* __restrict__ y, long nchunks, int nch) {
+  constexpr int EPC = Chunk<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int c0 = (int)(i % nch) * EPC;
+  float v[EPC], r[EPC];
+  Chunk<T>::load(z + i * EPC, v);
+  if (res) Chunk<T>::load(res + i * EPC, r);
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    float o = fmaf(v[e], a[c0 + e], b[c0 + e]);
+    if (res) o += r[e];
+    v[e] = relu ? fmaxf(o, 0.f) : o;
+  }
+  Chunk<T>::store(y + i * EPC, v);
+}
+
+extern "C" int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu,
+                              void* y, int dtype, void* stream) {
+  TD_CHECK(z && a && b && y && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const long n = M * (C / 4);
+    hipLaunchKernelGGL(affine_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)z, a, b,
+                       (const float*)res, relu, (float*)y, n, C / 4);
+  } else if (dtype == TDEED_BF16) {
+    const long n = M * (C / 8);
+    hipLaunchKernelGGL(affine_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)z, a, b,
+                       (const bf16_t*)res, relu, (bf16_t*)y, n, C / 8);
+  } else { tdeed_set_error("bn_apply: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("bn_apply");
+  return TDEED_OK;
+}
+
+// =========================================================================== BatchNorm (training) backward
+// g = dy (masked by y > 0 if a ReLU followed), xhat = (z - mean) * rstd:
+//   dz = w * rstd * (g - sum(g)/M - xhat * sum(g * xhat)/M),   dw = sum(g * xhat),   db = sum(g)
+// d_res (optional) = g: the gradient of the residual that was added before the ReLU.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ dy,
+                                                           const T* __restrict__ y, int relu,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ w, const float* __restrict__ sums,
+                                                           float inv_M, T* __restrict__ dz, T* __restrict__ d_res,
+                                                           long nchunks, int nch) {
+  constexpr int EPC = Chunk<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int C = nch * EPC;
+  const int c0 = (int)(i % nch) * EPC;
+  float zv[EPC], gv[EPC], yv[EPC];
+  Chunk<T>::load(z + i * EPC, zv);
+  Chunk<T>::load(dy + i * EPC, gv);
+  if (relu) Chunk<T>::load(y + i * EPC, yv);
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int c = c0 + e;
+    const float g = (relu && !(yv[e] > 0.f)) ? 0.f : gv[e];
+    const float xh = (zv[e] - mean[c]) * rstd[c];
+    gv[e] = g;
+    zv[e] = w[c] * rstd[c] * (g - sums[c] * inv_M - xh * sums[C + c] * inv_M);
+  }
+  Chunk<T>::store(dz + i * EPC, zv);
+  if (d_res) Chunk<T>::store(d_res + i * EPC, gv);
+}
+
+// part: fp32 [tdeed_bn_slabs(M)][2][C]; sums: fp32 [2][C] scratch; dw, db: fp32 [C]
+extern "C" int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, int relu, long M, int C,
+                                  const float* mean, const float* rstd, const float* w, float* part, float* sums,
+                                  void* dz, void* d_res, float* dw, float* db, int dtype, void* stream) {
+  TD_CHECK(z && dy && (!relu || y) && mean && rstd && w && part && sums && dz && dw && db, "bn_train_bwd: null pointer");
+  TD_CHECK(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "bn_train_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  int slabs;
+  if (dtype == TDEED_F32) slabs = launch_colstats<float>(z, dy, y, M, C, 1, relu, mean, rstd, part, st);
+  else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, dy, y, M, C, 1, relu, mean, rstd, part, st);
+  else { tdeed_set_error("bn_train_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("bn bwd colstats");
+  int rc = tdeed_reduce_partials(part, slabs, 2L * C, sums, 0, stream);
+  if (rc != TDEED_OK) return rc;
+  const float inv_M = 1.0f / (float)M;
+  if (dtype == TDEED_F32) {
+    const long n = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)z,
+                       (const float*)dy, (const float*)y, relu, mean, rstd, w, sums, inv_M, (float*)dz, (float*)d_res, n,
+                       C / 4);
+  } else {
+    const long n = M * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)z,
+                       (const bf16_t*)dy, (const bf16_t*)y, relu, mean, rstd, w, sums, inv_M, (bf16_t*)dz, (bf16_t*)d_res,
+                       n, C / 8);
+  }
+  TD_LAUNCH_CHECK("bn_bwd_apply");
+  hipError_t e1 = hipMemcpyAsync(db, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  hipError_t e2 = hipMemcpyAsync(dw, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e1 != hipSuccess || e2 != hipSuccess) { tdeed_set_error("bn_train_bwd: copy failed"); return TDEED_ERR_RUNTIME; }
+  return TDEED_OK;
+}
+
+// =========================================================================== SE (training): squeeze, excitation, scale
+// mean over the hw pixels of a frame: x [N][hw][C] -> p [N][C] fp32 (lanes = (pixel slice, channel chunk), batched loads)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mean_kernel(const T* __restrict__ x, const T* __restrict__ x2, int hw, int C,
+                                                        float* __restrict__ p) {
+  constexpr int EPC = Chunk<T>::N;
+  extern __shared__ float red[];       // [S][C]
+  const long f = blockIdx.x;
+  const int nch = C / EPC;
+  const int S = 256 / nch > 0 ? 256 / nch : 1;
+  for (int ch = threadIdx.x % nch, s = threadIdx.x / nch; s < S && ch < nch; ch += 256) {
+    const int c0 = ch * EPC;
+    float a[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+    const long base = f * hw * C + c0;
+    for (int p0 = s; p0 < hw; p0 += S * 4) {
+      float v[4][EPC], u[4][EPC];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const long off = base + (long)min(p0 + b * S, hw - 1) * C;
+        Chunk<T>::load(x + off, v[b]);
+        if (x2) Chunk<T>::load(x2 + off, u[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (p0 + b * S < hw) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) a[e] += x2 ? v[b][e] * u[b][e] : v[b][e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[s * C + c0 + e] = a[e];
+  }
+  __syncthreads();
+  const float inv = x2 ? 1.0f : 1.0f / (float)hw;              // squeeze: mean;  x2 given: plain sum of products
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += red[s * C + c];
+    p[f * C + c] = v * inv;
+  }
+}
+
+// p [N][C] = mean_px x  (x2 == NULL)   or   sum_px x * x2  (the gradient of the SE gate)
+extern "C" int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, float* p, int dtype, void* stream) {
+  TD_CHECK(x && p && N > 0 && hw > 0 && C > 0 && C % 8 == 0 && C <= 2048, "pool_rows: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const int nch = C / 4, S = 256 / nch > 0 ? 256 / nch : 1;
+    hipLaunchKernelGGL(pool_mean_kernel<float>, dim3(N), dim3(256), (size_t)S * C * sizeof(float), st, (const float*)x,
+                       (const float*)x2, hw, C, p);
+  } else if (dtype == TDEED_BF16) {
+    const int nch = C / 8, S = 256 / nch > 0 ? 256 / nch : 1;
+    hipLaunchKernelGGL(pool_mean_kernel<bf16_t>, dim3(N), dim3(256), (size_t)S * C * sizeof(float), st, (const bf16_t*)x,
+                       (const bf16_t*)x2, hw, C, p);
+  } else { tdeed_set_error("pool_rows: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("pool_rows");
+  return TDEED_OK;
+}
+
+// hid = relu(W1 p + b1), gate = sigmoid(W2 hid + b2) per frame, hid kept for the backward.
+// w1t [C][R], w2t [R][C] (transposed: adjacent lanes read adjacent addresses)
+__global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restrict__ p, int C, int R,
+                                                           const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                           float* __restrict__ hid, float* __restrict__ gate) {
+  extern __shared__ float sm[];        // p [C], hid [R]
+  float* sp = sm;
+  float* sh = sm + C;
+  const long f = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) sp[c] = p[f * C + c];
+  __syncthreads();
+  for (int j = threadIdx.x; j < R; j += 256) {
+    float a = b1[j];
+    for (int c = 0; c < C; ++c) a = fmaf(sp[c], w1t[(long)c * R + j], a);
+    a = fmaxf(a, 0.f);
+    sh[j] = a;
+    hid[f * R + j] = a;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = b2[c];
+    for (int j = 0; j < R; ++j) a = fmaf(sh[j], w2t[(long)j * C + c], a);
+    gate[f * C + c] = sigmoidf_(a);
+  }
+}
+
+extern "C" int tdeed_se_train_fwd(const float* p, int N, int C, int R, const float* w1t, const float* b1,
+                                  const float* w2t, const float* b2, float* hid, float* gate, void* stream) {
+  TD_CHECK(p && w1t && b1 && w2t && b2 && hid && gate && N > 0 && C > 0 && R > 0 && C + R <= 12000, "se_train_fwd: bad arguments");
+  hipLaunchKernelGGL(se_train_fwd_kernel, dim3(N), dim3(256), (size_t)(C + R) * sizeof(float), (hipStream_t)stream, p, C,
+                     R, w1t, b1, w2t, b2, hid, gate);
+  TD_LAUNCH_CHECK("se_train_fwd");
+  return TDEED_OK;
+}
+
+// d_pre2 = d_gate * g * (1 - g);  d_hid = (hid > 0) * W2^T d_pre2;  d_p = W1^T d_hid
+// w1 [R][C], w2 [C][R] (the reference layouts: here the contraction runs down the rows)
+__global__ __launch_bounds__(256) void se_train_bwd_kernel(const float* __restrict__ d_gate, const float* __restrict__ gate,
+                                                           const float* __restrict__ hid, int C, int R,
+                                                           const float* __restrict__ w1, const float* __restrict__ w2,
+                                                           float* __restrict__ d_pre2, float* __restrict__ d_hid,
+                                                           float* __restrict__ d_p) {
+  extern __shared__ float sm[];        // d_pre2 [C], d_hid [R]
+  float* s2 = sm;
+  float* sh = sm + C;
+  const long f = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float g = gate[f * C + c];
+    const float v = d_gate[f * C + c] * g * (1.f - g);
+    s2[c] = v;
+    d_pre2[f * C + c] = v;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < R; j += 256) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(s2[c], w2[(long)c * R + j], a);
+    a = hid[f * R + j] > 0.f ? a : 0.f;
+    sh[j] = a;
+    d_hid[f * R + j] = a;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a = fmaf(sh[j], w1[(long)j * C + c], a);
+    d_p[f * C + c] = a;
+  }
+}
+
+extern "C" int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid, int N, int C, int R,
+                                  const float* w1, const float* w2, float* d_pre2, float* d_hid, float* d_p,
+                                  void* stream) {
+  TD_CHECK(d_gate && gate && hid && w1 && w2 && d_pre2 && d_hid && d_p && N > 0 && C > 0 && R > 0 && C + R <= 12000,
+           "se_train_bwd: bad arguments");
+  hipLaunchKernelGGL(se_train_bwd_kernel, dim3(N), dim3(256), (size_t)(C + R) * sizeof(float), (hipStream_t)stream, d_gate,
+                     gate, hid, C, R, w1, w2, d_pre2, d_hid, d_p);
+  TD_LAUNCH_CHECK("se_train_bwd");
+  return TDEED_OK;
+}
+
+// y[n][px][c] = x[n][px][c] * s[n][c] + add[n][c] * add_scale   (s, add fp32 [N][C]; add may be NULL)
+// forward: the SE scale; backward: d y2 = d(y2*gate) * gate + d_pool / hw
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                         const float* __restrict__ add, float add_scale, int hw,
+                                                         T* __restrict__ y, long nchunks, int nch) {
+  constexpr int EPC = Chunk<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int C = nch * EPC;
+  const int c0 = (int)(i % nch) * EPC;
+  const long n = (i / nch) / hw;
+  float v[EPC];
+  Chunk<T>::load(x + i * EPC, v);
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    v[e] *= s[n * C + c0 + e];
+    if (add) v[e] = fmaf(add[n * C + c0 + e], add_scale, v[e]);
+  }
+  Chunk<T>::store(y + i * EPC, v);
+}
+
+extern "C" int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C,
+                                void* y, int dtype, void* stream) {
+  TD_CHECK(x && s && y && N > 0 && hw > 0 && C > 0 && C % 8 == 0, "scale_rows: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const long n = (long)N * hw * (C / 4);
+    hipLaunchKernelGGL(scale_rows_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)x, s,
+                       add, add_scale, hw, (float*)y, n, C / 4);
+  } else if (dtype == TDEED_BF16) {
+    const long n = (long)N * hw * (C / 8);
+    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, s,
+                       add, add_scale, hw, (bf16_t*)y, n, C / 8);
+  } else { tdeed_set_error("scale_rows: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("scale_rows");
+  return TDEED_OK;
+}
+
+// =========================================================================== grouped 3x3 conv backward
+// forward: y[n][oy][ox][g*gw+co] = sum_{ky,kx,ci} x[n][oy*s+ky-1][ox*s+kx-1][g*gw+ci] * w[g][ky*3+kx][ci][co]
+// (w in the forward's packed fp32 layout [G][9][gw in][gw out]).  First versions on the vector ALU: one lane per
+// (input pixel, group) for the input gradient, LDS-staged pixel chunks for the weight gradient.
+template <typename T, int GW>
+__global__ __launch_bounds__(256) void gconv_dgrad_kernel(const T* __restrict__ dy, int Hi, int Wi, int Ho, int Wo, int C,
+                                                          int stride, const float* __restrict__ w, T* __restrict__ dx,
+                                                          long npix) {
+  __shared__ float sw[9 * GW * GW];
+  const int g = blockIdx.y;
+  for (int i = threadIdx.x; i < 9 * GW * GW; i += 256) sw[i] = w[(long)g * 9 * GW * GW + i];
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  const int ix = (int)(pix % Wi);
+  const int iy = (int)((pix / Wi) % Hi);
+  const long n = pix / ((long)Wi * Hi);
+  float acc[GW];
+#pragma unroll
+  for (int c = 0; c < GW; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride != 0) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride != 0) continue;
+      const int ox = tx / stride;
+      if (ox >= Wo) continue;
+      float d[GW];
+      const T* src = dy + ((n * Ho + oy) * Wo + ox) * C + g * GW;
+#pragma unroll
+      for (int c = 0; c < GW; c += Chunk<T>::N) Chunk<T>::load(src + c, *reinterpret_cast<float(*)[Chunk<T>::N]>(&d[c]));
+      const float* wt = sw + (ky * 3 + kx) * GW * GW;
+#pragma unroll
+      for (int ci = 0; ci < GW; ++ci) {
+        float a = acc[ci];
+#pragma unroll
+        for (int co = 0; co < GW; ++co) a = fmaf(d[co], wt[ci * GW + co], a);
+        acc[ci] = a;
+      }
+    }
+  }
+  T* dst = dx + pix * C + g * GW;
+#pragma unroll
+  for (int c = 0; c < GW; c += Chunk<T>::N) Chunk<T>::store(dst + c, *reinterpret_cast<float(*)[Chunk<T>::N]>(&acc[c]));
+}
+
+// weight gradient: workgroup = (slab of output pixels, group); chunks of 32 output pixels staged in LDS as
+// d[32][GW] and x9[32][9][GW]; lane (tap, ci, co) triples accumulate over the chunk.
+template <typename T, int GW>
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, int Hi, int Wi,
+                                                          int Ho, int Wo, int C, int stride, long npix_out,
+                                                          long pix_per_slab, float* __restrict__ part) {
+  constexpr int NW = 9 * GW * GW;                               // outputs per group
+  constexpr int PER = (NW + 255) / 256;
+  __shared__ float sd[32][GW];
+  __shared__ float sx[32][9][GW];
+  const int g = blockIdx.y;
+  const long p_begin = (long)blockIdx.x * pix_per_slab, p_end = min(npix_out, p_begin + pix_per_slab);
+  float acc[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) acc[i] = 0.f;
+  for (long p0 = p_begin; p0 < p_end; p0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * GW; i += 256) {
+      const int pp = i / GW, c = i % GW;
+      const long p = p0 + pp;
+      sd[pp][c] = p < p_end ? (float)dy[p * C + g * GW + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 32 * 9 * GW; i += 256) {
+      const int c = i % GW, tap = (i / GW) % 9, pp = i / (9 * GW);
+      const long p = p0 + pp;
+      float v = 0.f;
+      if (p < p_end) {
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+        const long n = p / ((long)Wo * Ho);
+        const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) v = (float)x[((n * Hi + iy) * Wi + ix) * C + g * GW + c];
+      }
+      sx[pp][tap][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int o = threadIdx.x + i * 256;
+      if (o < NW) {
+        const int co = o % GW, ci = (o / GW) % GW, tap = o / (GW * GW);
+        float a = acc[i];
+#pragma unroll 8
+        for (int pp = 0; pp < 32; ++pp) a = fmaf(sx[pp][tap][ci], sd[pp][co], a);
+        acc[i] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int o = threadIdx.x + i * 256;
+    if (o < NW) part[((long)blockIdx.x * gridDim.y + g) * NW + o] = acc[i];
+  }
+}
+
+extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
+  long s = (npix_out + 4095) / 4096;
+  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+}
+
+// dx [N][Hi][Wi][C] (activation dtype), dw fp32 [G][9][gw][gw] (the forward's packed layout);
+// part: fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw]
+extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride,
+                                  const float* w, void* dx, float* part, float* dw, int dtype, void* stream) {
+  TD_CHECK(x && dy && w && dx && part && dw, "gconv3x3_bwd: null pointer");
+  TD_CHECK((gw == 8 || gw == 16) && C % gw == 0 && (stride == 1 || stride == 2) && N > 0 && Hi > 0 && Wi > 0,
+           "gconv3x3_bwd: bad geometry");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gconv3x3_bwd: bad dtype %d", dtype);
+  const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1, G = C / gw;
+  const long npix_in = (long)N * Hi * Wi, npix_out = (long)N * Ho * Wo;
+  const int slabs = tdeed_gconv_wgrad_slabs(npix_out);
+  const long pps = ((npix_out + slabs - 1) / slabs + 31) / 32 * 32;
+  const int nsl = (int)((npix_out + pps - 1) / pps);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gd((unsigned)((npix_in + 255) / 256), G), gwg(nsl, G);
+#define TD_GC_LAUNCH(TT, GWv)                                                                                           \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((gconv_dgrad_kernel<TT, GWv>), gd, dim3(256), 0, st, (const TT*)dy, Hi, Wi, Ho, Wo, C, stride, w, \
+                       (TT*)dx, npix_in);                                                                               \
+    hipLaunchKernelGGL((gconv_wgrad_kernel<TT, GWv>), gwg, dim3(256), 0, st, (const TT*)x, (const TT*)dy, Hi, Wi, Ho, Wo, \
+                       C, stride, npix_out, pps, part);                                                                 \
+  } while (0)
+  if (dtype == TDEED_F32) { if (gw == 8) TD_GC_LAUNCH(float, 8); else TD_GC_LAUNCH(float, 16); }
+  else { if (gw == 8) TD_GC_LAUNCH(bf16_t, 8); else TD_GC_LAUNCH(bf16_t, 16); }
+#undef TD_GC_LAUNCH
+  TD_LAUNCH_CHECK("gconv3x3_bwd");
+  return tdeed_reduce_partials(part, nsl, (long)G * 9 * gw * gw, dw, 0, stream);
+}
+
+// =========================================================================== row gather / scatter for stride-2 1x1 convs
+// mode 0 (gather):  out[(f,yo,xo)][c]  = in[(f, yo*2, xo*2)][c]            (the shortcut conv's operand)
+// mode 1 (scatter): out[(f, yo*2, xo*2)][c] += in[(f,yo,xo)][c]            (its input gradient, added to the main path's)
+template <typename T>
+__global__ __launch_bounds__(256) void stride2_rows_kernel(const T* __restrict__ in, T* __restrict__ out, int hi, int wi,
+                                                           int ho, int wo, int C, int mode, long nchunks) {
+  constexpr int EPC = Chunk<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int nch = C / EPC;
+  const int ck = (int)(i % nch);
+  const long r = i / nch;
+  const int xo = (int)(r % wo), yo = (int)((r / wo) % ho);
+  const long f = r / ((long)wo * ho);
+  const long big = ((f * hi + yo * 2) * wi + xo * 2) * C + ck * EPC, small_ = r * C + ck * EPC;
+  float v[EPC];
+  if (mode == 0) {
+    Chunk<T>::load(in + big, v);
+    Chunk<T>::store(out + small_, v);
+  } else {
+    float o[EPC];
+    Chunk<T>::load(in + small_, v);
+    Chunk<T>::load(out + big, o);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o[e] += v[e];
+    Chunk<T>::store(out + big, o);
+  }
+}
+
+extern "C" int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int wi, int C, int mode, int dtype,
+                                  void* stream) {
+  TD_CHECK(in && out && F > 0 && hi > 0 && wi > 0 && C % 8 == 0 && (mode == 0 || mode == 1), "stride2_rows: bad arguments");
+  const int ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32) {
+    const long n = (long)F * ho * wo * (C / 4);
+    hipLaunchKernelGGL(stride2_rows_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)in,
+                       (float*)out, hi, wi, ho, wo, C, mode, n);
+  } else if (dtype == TDEED_BF16) {
+    const long n = (long)F * ho * wo * (C / 8);
+    hipLaunchKernelGGL(stride2_rows_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)in,
+                       (bf16_t*)out, hi, wi, ho, wo, C, mode, n);
+  } else { tdeed_set_error("stride2_rows: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("stride2_rows");
+  return TDEED_OK;
+}

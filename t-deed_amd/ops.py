@@ -184,7 +184,7 @@ def gconv3x3_parts(Hi, Wi, C, stride, act_dtype):
     return _lib.load().tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype_code(act_dtype))
 
 
-def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None):
+def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None, relu=True):
     """x (N,Hi,Wi,C) -> y (N,Ho,Wo,C), pooled (N,parts,C) fp32 partial sums over pixels.
     w_packed: fp32 [G][9][gw][gw] (VALU path); wfrag: bf16 MFMA fragments (bf16 path)."""
     _chk(x, "x")
@@ -196,7 +196,7 @@ def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled
     if pooled is None:
         pooled = torch.empty((N, parts, C), dtype=torch.float32, device=x.device)
     call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(wfrag), ptr(scale), ptr(shift),
-         ptr(out), ptr(pooled), dtype_code(x.dtype), stream_ptr())
+         ptr(out), ptr(pooled), int(relu), dtype_code(x.dtype), stream_ptr())
     return out, pooled
 
 

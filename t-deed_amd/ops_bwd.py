@@ -98,3 +98,96 @@ def maxpool_bwd(x, dy):
     dx = torch.empty_like(x)
     call("tdeed_maxpool_bwd", ptr(x), ptr(dy), B, T_in, dy.shape[1], C, ptr(dx), dtype_code(x.dtype), stream_ptr())
     return dx
+
+
+# ----------------------------------------------------------------------------- train-mode trunk pieces
+def bn_train(z, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, res=None, relu=True, out=None):
+    """BatchNorm with batch statistics over the rows of z (.., C) + optional residual + ReLU.
+    Returns (y, ctx) where ctx = (mean, rstd) for the backward."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    part = _f32((_lib.load().tdeed_bn_slabs(M), 2, C), dev)
+    mean, rstd, a, bb = (_f32((C,), dev) for _ in range(4))
+    call("tdeed_bn_train_stats", ptr(z), M, C, ptr(w), ptr(b), eps, momentum, ptr(part), ptr(mean), ptr(rstd), ptr(a),
+         ptr(bb), ptr(run_mean), ptr(run_var), dtype_code(z.dtype), stream_ptr())
+    if out is None:
+        out = torch.empty_like(z)
+    call("tdeed_bn_apply", ptr(z), M, C, ptr(a), ptr(bb), ptr(res), int(relu), ptr(out), dtype_code(z.dtype), stream_ptr())
+    return out, (mean, rstd)
+
+
+def bn_train_bwd(z, dy, y, ctx, w, relu=True, want_res=False):
+    """-> dz, d_res (or None), dw, db"""
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    mean, rstd = ctx
+    part, sums = _f32((_lib.load().tdeed_bn_slabs(M), 2, C), dev), _f32((2, C), dev)
+    dz = torch.empty_like(z)
+    d_res = torch.empty_like(z) if want_res else None
+    dw, db = _f32((C,), dev), _f32((C,), dev)
+    call("tdeed_bn_train_bwd", ptr(z), ptr(dy), ptr(y if relu else None), int(relu), M, C, ptr(mean), ptr(rstd), ptr(w),
+         ptr(part), ptr(sums), ptr(dz), ptr(d_res), ptr(dw), ptr(db), dtype_code(z.dtype), stream_ptr())
+    return dz, d_res, dw, db
+
+
+def pool_rows(x, x2=None):
+    """x (N,h,w,C): mean over pixels (x2 None) or sum over pixels of x*x2 -> (N,C) fp32"""
+    N, C = x.shape[0], x.shape[-1]
+    hw = x.numel() // (N * C)
+    p = _f32((N, C), x.device)
+    call("tdeed_pool_rows", ptr(x), ptr(x2), N, hw, C, ptr(p), dtype_code(x.dtype), stream_ptr())
+    return p
+
+
+def se_train_fwd(p, w1t, b1, w2t, b2):
+    N, C = p.shape
+    R = w1t.shape[1]
+    hid, gate = _f32((N, R), p.device), _f32((N, C), p.device)
+    call("tdeed_se_train_fwd", ptr(p), N, C, R, ptr(w1t), ptr(b1), ptr(w2t), ptr(b2), ptr(hid), ptr(gate), stream_ptr())
+    return hid, gate
+
+
+def se_train_bwd(d_gate, gate, hid, w1, w2):
+    N, C = gate.shape
+    R = hid.shape[1]
+    d_pre2, d_hid, d_p = _f32((N, C), gate.device), _f32((N, R), gate.device), _f32((N, C), gate.device)
+    call("tdeed_se_train_bwd", ptr(d_gate), ptr(gate), ptr(hid), N, C, R, ptr(w1), ptr(w2), ptr(d_pre2), ptr(d_hid),
+         ptr(d_p), stream_ptr())
+    return d_pre2, d_hid, d_p
+
+
+def scale_rows(x, s, add=None, add_scale=1.0, out=None):
+    N, C = x.shape[0], x.shape[-1]
+    hw = x.numel() // (N * C)
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_scale_rows", ptr(x), ptr(s), ptr(add), float(add_scale), N, hw, C, ptr(out), dtype_code(x.dtype),
+         stream_ptr())
+    return out
+
+
+def gconv3x3_bwd(x, dy, w_packed, gw, stride):
+    """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x, dw fp32 [G][9][gw][gw]"""
+    N, Hi, Wi, C = x.shape
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    G = C // gw
+    part = _f32((_lib.load().tdeed_gconv_wgrad_slabs(N * Ho * Wo), G * 9 * gw * gw), x.device)
+    dx, dw = torch.empty_like(x), _f32((G, 9, gw, gw), x.device)
+    call("tdeed_gconv3x3_bwd", ptr(x), ptr(dy), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(dx), ptr(part), ptr(dw),
+         dtype_code(x.dtype), stream_ptr())
+    return dx, dw
+
+
+def stride2_gather(x):
+    F_, hi, wi, C = x.shape
+    out = torch.empty((F_, (hi - 1) // 2 + 1, (wi - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    call("tdeed_stride2_rows", ptr(x), ptr(out), F_, hi, wi, C, 0, dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def stride2_scatter_add(d_small, d_big):
+    F_, hi, wi, C = d_big.shape
+    call("tdeed_stride2_rows", ptr(d_small), ptr(d_big), F_, hi, wi, C, 1, dtype_code(d_big.dtype), stream_ptr())
+    return d_big

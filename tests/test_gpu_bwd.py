@@ -209,3 +209,103 @@ def test_temporal_stack_loss_and_grads_match_autograd(dtype, geom):
         ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sd])
         gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sd])
         assert float((ga - gr).norm() / gr.norm()) < 3e-2
+
+
+# ============================================================================= train-mode trunk pieces
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,relu,res", [(3000, 24, True, False), (5001, 152, True, True), (700, 368, False, False),
+                                          (40000, 32, True, True)])
+def test_bn_train_fwd_bwd(bops, dtype, M, C, relu, res):
+    z = (rnd(231, "z", (M, C), 1.5) + rnd(232, "mu", (C,), 0.5)).to(dtype)
+    dy = rnd(233, "dy", (M, C)).to(dtype)
+    r = rnd(234, "r", (M, C)).to(dtype) if res else None
+    w, b = rnd(235, "w", (C,)) * 0.3 + 1.0, rnd(236, "b", (C,), 0.2)
+    rm, rv = rnd(237, "rm", (C,), 0.1), rnd(238, "rv", (C,)).abs() + 0.5
+    zr, wr, br = z.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = r.float().requires_grad_(True) if res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(zr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5)
+    if res:
+        y = y + rr
+    if relu:
+        y = torch.relu(y)
+    y.backward(dy.float())
+    rm_d, rv_d = rm.clone().to(DEV), rv.clone().to(DEV)
+    out, ctx = bops.bn_train(z.to(DEV), w.to(DEV), b.to(DEV), run_mean=rm_d, run_var=rv_d, res=None if r is None else r.to(DEV),
+                             relu=relu)
+    assert rel_err(out.float(), y) < tol(dtype)
+    assert rel_err(rm_d, rm_ref) < 1e-4 and rel_err(rv_d, rv_ref) < 1e-4
+    dz, d_res, dw, db = bops.bn_train_bwd(z.to(DEV), dy.to(DEV), out, ctx, w.to(DEV), relu=relu, want_res=res)
+    assert rel_err(dz.float(), zr.grad) < tol(dtype)
+    assert rel_err(dw, wr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(db, br.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    if res:
+        assert rel_err(d_res.float(), rr.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,h,w,C,R", [(6, 7, 7, 368, 92), (3, 28, 28, 56, 6), (2, 14, 14, 152, 38), (2, 56, 56, 24, 8)])
+def test_se_train_fwd_bwd(bops, dtype, N, h, w, C, R):
+    """squeeze -> fc1/ReLU/fc2/sigmoid -> scale, and its backward, against autograd on the oracle's _se."""
+    x = rnd(241, "x", (N, h, w, C)).to(dtype)
+    dy = rnd(242, "dy", (N, h, w, C)).to(dtype)
+    sd = {"se.fc1.weight": rnd(243, "w1", (R, C, 1, 1), 0.1), "se.fc1.bias": rnd(244, "b1", (R,), 0.1),
+          "se.fc2.weight": rnd(245, "w2", (C, R, 1, 1), 0.2), "se.fc2.bias": rnd(246, "b2", (C,), 0.1)}
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    y = O._se(xr, sdr, "se")
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    w1, w2 = sd["se.fc1.weight"].reshape(R, C), sd["se.fc2.weight"].reshape(C, R)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    p = bops.pool_rows(xd)
+    hid, gate = bops.se_train_fwd(p, w1.T.contiguous().to(DEV), sd["se.fc1.bias"].to(DEV), w2.T.contiguous().to(DEV),
+                                  sd["se.fc2.bias"].to(DEV))
+    ys = bops.scale_rows(xd, gate)
+    assert rel_err(ys.float().permute(0, 3, 1, 2), y) < tol(dtype)
+    d_gate = bops.pool_rows(dyd, xd)
+    d_pre2, d_hid, d_p = bops.se_train_bwd(d_gate, gate, hid, w1.to(DEV), w2.to(DEV))
+    dx = bops.scale_rows(dyd, gate, add=d_p, add_scale=1.0 / (h * w))
+    dW2, db2 = bops.wgrad(d_pre2, hid)
+    dW1, db1 = bops.wgrad(d_hid, p)
+    assert rel_err(dx.float().permute(0, 3, 1, 2), xr.grad) < tol(dtype)
+    gt = 5e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(dW1, sdr["se.fc1.weight"].grad.reshape(R, C)) < gt
+    assert rel_err(db1, sdr["se.fc1.bias"].grad) < gt
+    assert rel_err(dW2, sdr["se.fc2.weight"].grad.reshape(C, R)) < gt
+    assert rel_err(db2, sdr["se.fc2.bias"].grad) < gt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,gw,stride,H,W", [(24, 8, 2, 20, 22), (56, 8, 1, 9, 7), (64, 16, 2, 16, 16), (152, 8, 2, 28, 28),
+                                             (368, 8, 1, 7, 7), (128, 16, 1, 14, 14)])
+def test_gconv3x3_raw_fwd_and_bwd(bops, dtype, C, gw, stride, H, W):
+    from tdeed_amd import ops
+    N = 3
+    x = rnd(251, "x", (N, C, H, W)).to(dtype)
+    wt = rnd(252, "w", (C, gw, 3, 3), 0.2)
+    xr, wr = x.float().requires_grad_(True), wt.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=stride, padding=1, groups=C // gw)
+    dy = rnd(253, "dy", tuple(y.shape)).to(dtype)
+    y.backward(dy.float())
+    G = C // gw
+    wp = wt.reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1).reshape(G, 9, gw, gw).contiguous().to(DEV)
+    one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    yraw, _ = ops.gconv3x3(xd, wp, one, zero, gw, stride, relu=False)          # VALU path, no activation
+    assert rel_err(yraw.float().permute(0, 3, 1, 2), y) < tol(dtype)
+    dx, dw = bops.gconv3x3_bwd(xd, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wp, gw, stride)
+    assert rel_err(dx.float().permute(0, 3, 1, 2), xr.grad) < tol(dtype)
+    ref_dw = wr.grad.reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1).reshape(G, 9, gw, gw)
+    assert rel_err(dw, ref_dw) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stride2_rows(bops, dtype):
+    x = rnd(261, "x", (3, 9, 12, 24)).to(dtype)
+    g = bops.stride2_gather(x.to(DEV))
+    assert torch.equal(g.cpu(), x[:, ::2, ::2].contiguous())
+    big = rnd(262, "b", (3, 9, 12, 24)).to(dtype)
+    ref = big.float().clone()
+    ref[:, ::2, ::2] += g.cpu().float()
+    out = bops.stride2_scatter_add(g, big.clone().to(DEV))
+    assert rel_err(out.float(), ref) < tol(dtype)
