@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dY, lo
     part_b[(long)z * N + n0 + threadIdx.x] = bsum;
 }
 
-extern "C" int tdeed_wgrad_slices(int M) { int z = (M + 255) / 256; return z < 1 ? 1 : (z > 16 ? 16 : z); }
+extern "C" int tdeed_wgrad_slices(int M) { int z = (M + 2047) / 2048; return z < 1 ? 1 : (z > 128 ? 128 : z); }
 
 // part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M); dW [N][K], db [N] (fp32)
 extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w,

@@ -309,3 +309,65 @@ def test_stride2_rows(bops, dtype):
     ref[:, ::2, ::2] += g.cpu().float()
     out = bops.stride2_scatter_add(g, big.clone().to(DEV))
     assert rel_err(out.float(), ref) < tol(dtype)
+
+
+def _block_state(blk, seed=51):
+    from collections import OrderedDict
+    from tdeed_amd import synth
+    d = OrderedDict()
+    pre = "blk"
+    def conv_bn(n, co, ci, k):
+        d[f"{pre}.{n}.conv.weight"] = ((co, ci, k, k), "float32")
+        for s_ in ("weight", "bias", "running_mean", "running_var"):
+            d[f"{pre}.{n}.bn.{s_}"] = ((co,), "float32")
+    conv_bn("conv1", blk.cout, blk.cin, 1)
+    conv_bn("conv2", blk.cout, blk.gw, 3)
+    conv_bn("conv3", blk.cout, blk.cout, 1)
+    if blk.has_downsample:
+        conv_bn("downsample", blk.cout, blk.cin, 1)
+    d[pre + ".se.fc1.weight"] = ((blk.se_rd, blk.cout, 1, 1), "float32")
+    d[pre + ".se.fc1.bias"] = ((blk.se_rd,), "float32")
+    d[pre + ".se.fc2.weight"] = ((blk.cout, blk.se_rd, 1, 1), "float32")
+    d[pre + ".se.fc2.bias"] = ((blk.cout,), "float32")
+    return {k: t(v) for k, v in synth.make_state(d, seed).items()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [dict(cin=32, cout=24, stride=2, gw=8, N=3, h=20, w=24),      # s1.b1-like
+                                  dict(cin=24, cout=56, stride=2, gw=8, N=2, h=14, w=14),      # s2.b1-like
+                                  dict(cin=152, cout=152, stride=1, gw=8, N=4, h=7, w=7),      # identity block
+                                  dict(cin=64, cout=128, stride=1, gw=16, N=2, h=6, w=10)])    # 1x1 shortcut, stride 1
+def test_bottleneck_train_fwd_bwd_matches_autograd(dtype, geom):
+    """A whole RegNetY bottleneck in training mode (batch-stat BN, SE, shortcut): output, running statistics, every
+    parameter gradient and d x against autograd on the CPU oracle's regnet_block(training=True)."""
+    from tdeed_amd.trunk_train import BottleneckTrain
+    from tdeed_amd.regnet_spec import BlockSpec
+    g = geom
+    blk = BlockSpec(name="blk", stage=1, index=1, cin=g["cin"], cout=g["cout"], stride=g["stride"], groups=g["cout"] // g["gw"],
+                    gw=g["gw"], se_rd=int(round(g["cin"] * 0.25)), has_downsample=(g["cin"] != g["cout"] or g["stride"] != 1),
+                    gsf_fold=0, hin=g["h"])
+    sd = _block_state(blk)
+    x = rnd(271, "x", (g["N"], g["cin"], g["h"], g["w"])).abs().to(dtype)
+    sdr = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in sd.items()}
+    xr = x.float().requires_grad_(True)
+    ref = O.regnet_block(xr, sdr, "blk", blk, 1, "gsf", training=True)
+    dy = rnd(272, "dy", tuple(ref.shape)).to(dtype)
+    ref.backward(dy.float())
+    sdd = {k: v.clone().to(DEV) for k, v in sd.items()}
+    bt = BottleneckTrain(sdd, "blk", blk, act_dtype=dtype)
+    out = bt.forward(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert rel_err(out.float().permute(0, 3, 1, 2), ref) < (2e-4 if dtype == torch.float32 else 4e-2)
+    grads = {}
+    dx = bt.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV), grads)
+    want = {k for k in sd if "running" not in k}
+    assert set(grads) == want, set(grads) ^ want
+    if dtype == torch.float32:
+        assert rel_err(dx.float().permute(0, 3, 1, 2), xr.grad) < 2e-3
+        worst = max((rel_err(grads[k], sdr[k].grad), k) for k in want)
+        assert worst[0] < 2e-3, worst
+    else:
+        l2 = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))  # noqa: E731
+        assert l2(dx.float().permute(0, 3, 1, 2), xr.grad) < 0.1
+        ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sorted(want)])
+        gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sorted(want)])
+        assert float((ga - gr).norm() / gr.norm()) < 0.1      # batch-stat BN over a few hundred bf16 samples per channel
