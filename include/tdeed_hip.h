@@ -255,6 +255,8 @@ int tdeed_fill_u8_hash(uint8_t* dst, long n, uint64_t seed, void* stream); /* sy
  * a step is bit-reproducible. */
 /* out[j] (+)= sum_p part[p][j], p < P, j < n */
 int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream);
+/* the same over rows that are `stride` floats apart (several parameter groups side by side in one partial row) */
+int tdeed_reduce_strided(const float* part, int P, long stride, long n, float* out, void* stream);
 /* mode 0: y = gelu(x); 1: y = dy * gelu'(x); 2: y = x + dy; 3: y = x * dy.  n elements, multiple of 8 */
 int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream);
 /* [R][Cc] -> [Cc][R] (weight transposes for the input-gradient contractions) */
@@ -321,6 +323,22 @@ int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int
                        void* dx, float* part, float* dw, int dtype, void* stream);
 /* mode 0: out[(f,yo,xo)] = in[(f,2yo,2xo)] (operand of the stride-2 shortcut conv); mode 1: out[(f,2yo,2xo)] += in[(f,yo,xo)] */
 int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int wi, int C, int mode, int dtype, void* stream);
+
+/* ---- gate-shift-fuse backward (gsf_bwd.hip; forward tensors as saved by tdeed_gsf_gate_fwd / tdeed_gsf_weight_fwd).
+ * tdeed_gsf_slice: dense copy xs [M][Fp] of the module's channels (cols >= F zero): the BatchNorm3d operand in training.
+ * tdeed_gsf_bwd: from dA (gradient of the module output in conv1's operand layout, [N*hw][Fp]) to d_xs (direct part of
+ *   d x, dense [M][Fp]) and d_bn (gradient at the BatchNorm3d output, ReLU mask applied, dense [M][Fp]); parameter
+ *   gradients d_w3 [F][27] (conv3D.weight flattened), d_b3 [2], d_cw [2][18] (channel_conv1 | channel_conv2), d_cb [2].
+ *   w3 = conv3D.weight as [F][27]; sa/sb = the BatchNorm3d affine of this step; scratch fp32
+ *   [tdeed_gsf_bwd_scratch_floats(B,T,hw,F)].
+ * tdeed_gsf_add_cols: dx[m][0:Fp] += a[m][:] + b[m][:] (dx row stride C). */
+int tdeed_gsf_slice(const void* x, long M, int C, int F, int Fp, void* xs, int dtype, void* stream);
+long tdeed_gsf_bwd_scratch_floats(int B, int T, int hw, int F);
+int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                  const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3, const float* sa,
+                  const float* sb, const float* cw1, const float* cw2, float* scratch, void* d_xs, void* d_bn,
+                  float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype, void* stream);
+int tdeed_gsf_add_cols(const void* a, const void* b, long M, int C, int Fp, void* dx, int dtype, void* stream);
 
 /* ---- HIP graph capture of a launch sequence (replaces eager op-by-op dispatch) ---------------
  * begin: hipStreamBeginCapture(stream); end: EndCapture + Instantiate -> handle; launch replays. */

@@ -58,6 +58,12 @@ _SIGS = {
     "tdeed_gconv_wgrad_slabs": ([c_long], c_int),
     "tdeed_gconv3x3_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_stride2_rows": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
+    "tdeed_reduce_strided": ([P, c_int, c_long, c_long, P, P], c_int),
+    "tdeed_gsf_slice": ([P, c_long, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_gsf_bwd_scratch_floats": ([c_int, c_int, c_int, c_int], c_long),
+    "tdeed_gsf_bwd": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                       c_int, P], c_int),
+    "tdeed_gsf_add_cols": ([P, P, c_long, c_int, c_int, P, c_int, P], c_int),
     "tdeed_reduce_partials": ([P, c_int, c_long, P, c_int, P], c_int),
     "tdeed_eltwise": ([P, P, P, c_long, c_int, c_int, P], c_int),
     "tdeed_transpose": ([P, c_int, c_int, P, c_int, P], c_int),

@@ -1,0 +1,415 @@
+// Backward of the gate-shift-fuse module (`_GSF.forward`, /root/reference/model/impl/gsf.py:38-93) as wrapped by
+// `GatedShift` around conv1 of the s3/s4 bottlenecks (model/shift.py:64-93).  Same tensors as the forward in gsf.hip:
+//   x     [N][hw][C]   block input (N = B*T frames), the module acts on channels [0,F)
+//   gate  [N][hw][2]   tanh(conv3d(relu(bn(x))))            (saved by the forward)
+//   fw    [B][F][T]    fusion weights, indexed by source channel (saved by the forward)
+//   ysum, xsum [N][F]  spatial sums of gate*x and x           (saved by the forward)
+//   dA    [N*hw][Fp]   gradient w.r.t. the module output in conv1's operand layout: column co = g*Fh + 2j + i holds
+//                      source channel ci = g*Fh + i*Fq + j; columns [F,Fp) are pass-through copies of x
+// First versions: plain gather kernels (a lane per pixel or per (channel, tap)), ordered partial sums for parameters.
+#include "common.h"
+
+__device__ __forceinline__ int gsf_out_col(int ci, int Fh, int Fq) {
+  const int g = ci >= Fh, cl = ci - g * Fh;
+  const int i = cl >= Fq, j = cl - i * Fq;
+  return g * Fh + 2 * j + i;
+}
+
+// dense copy of the module's channels: xs[m][c] = x[m][c] for c < F, 0 for F <= c < Fp   (operand of the BatchNorm3d)
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_slice_kernel(const T* __restrict__ x, long M, int C, int F, int Fp,
+                                                        T* __restrict__ xs) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * Fp) return;
+  const long m = i / Fp;
+  const int c = (int)(i - m * Fp);
+  xs[i] = c < F ? x[m * C + c] : (T)0.f;
+}
+
+// ---- d fusion weight: d_wgt[f][ci] = sum_p dA[p][co(ci)] * (ys - r)
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ gate,
+                                                         const T* __restrict__ dA, int T_len, int hw, int C, int F, int Fp,
+                                                         float* __restrict__ d_wgt) {
+  extern __shared__ float red[];       // [S][F]
+  const long f = blockIdx.x;
+  const int t = (int)(f % T_len);
+  const int Fh = F >> 1, Fq = F >> 2;
+  const int S = 256 / F > 0 ? 256 / F : 1;
+  for (int ci = threadIdx.x % F, s = threadIdx.x / F; s < S && ci < F; ci += 256) {
+    const int g = ci >= Fh;
+    const int co = gsf_out_col(ci, Fh, Fq);
+    const int ts = g ? t - 1 : t + 1;
+    const bool has = ts >= 0 && ts < T_len;
+    const long fs = has ? f + (ts - t) : f;
+    float a = 0.f;
+    for (int p = s; p < hw; p += S) {
+      const long pix = f * hw + p, pixs = fs * hw + p;
+      const float xv = (float)x[pix * C + ci];
+      const float r = xv - gate[pix * 2 + g] * xv;
+      const float ys = has ? gate[pixs * 2 + g] * (float)x[pixs * C + ci] : 0.f;
+      a = fmaf((float)dA[pix * Fp + co], ys - r, a);
+    }
+    red[s * F + ci] = a;
+  }
+  __syncthreads();
+  for (int ci = threadIdx.x; ci < F; ci += 256) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += red[s * F + ci];
+    d_wgt[f * F + ci] = a;
+  }
+}
+
+// ---- fusion conv backward, step 1: dpw[b][c][t] = d_wgt * w * (1 - w)
+__global__ __launch_bounds__(256) void gsf_bwd_dpw_kernel(const float* __restrict__ d_wgt, const float* __restrict__ fw,
+                                                          int T_len, int F, long total, float* __restrict__ dpw) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;          // i = (b*F + c)*T + t
+  if (i >= total) return;
+  const int t = (int)(i % T_len);
+  const long bc = i / T_len;
+  const int c = (int)(bc % F);
+  const long b = bc / F;
+  const float w = fw[i];
+  dpw[i] = d_wgt[(b * T_len + t) * F + c] * w * (1.f - w);
+}
+
+// ---- step 2: gradients of the two input planes (shifted-y mean, r mean), frame-major [N][F]
+__global__ __launch_bounds__(256) void gsf_bwd_planes_kernel(const float* __restrict__ dpw, int T_len, int F,
+                                                             const float* __restrict__ cw1, const float* __restrict__ cw2,
+                                                             long total, float* __restrict__ d_ym,
+                                                             float* __restrict__ d_rm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;          // i = (b*T + t)*F + c
+  if (i >= total) return;
+  const int c = (int)(i % F);
+  const long ft = i / F;
+  const int t = (int)(ft % T_len);
+  const long b = ft / T_len;
+  const int Fh = F >> 1;
+  const int g = c >= Fh, cl = c - g * Fh;
+  const float* cw = g ? cw2 : cw1;
+  float ay = 0.f, ar = 0.f;
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc) {
+    const int c2 = cl - dc;                                     // output position that read this input with tap dc
+    if (c2 < 0 || c2 >= Fh) continue;
+#pragma unroll
+    for (int dt = -1; dt <= 1; ++dt) {
+      const int t2 = t - dt;
+      if (t2 < 0 || t2 >= T_len) continue;
+      const float v = dpw[(b * F + g * Fh + c2) * T_len + t2];
+      ay = fmaf(cw[(dc + 1) * 3 + (dt + 1)], v, ay);
+      ar = fmaf(cw[9 + (dc + 1) * 3 + (dt + 1)], v, ar);
+    }
+  }
+  d_ym[i] = ay;
+  d_rm[i] = ar;
+}
+
+// ---- step 3: d channel_conv weights / bias: part[b][g][19] (18 taps: plane 0 = shifted-y mean, plane 1 = r mean; bias)
+__global__ __launch_bounds__(256) void gsf_bwd_cw_kernel(const float* __restrict__ dpw, const float* __restrict__ ysum,
+                                                         const float* __restrict__ xsum, int T_len, int F, float inv_hw,
+                                                         float* __restrict__ part) {
+  __shared__ float scratch[8];
+  const int b = blockIdx.x, g = blockIdx.y;
+  const int Fh = F >> 1;
+  float acc[19];
+#pragma unroll
+  for (int k = 0; k < 19; ++k) acc[k] = 0.f;
+  for (int i = threadIdx.x; i < Fh * T_len; i += 256) {
+    const int cl = i / T_len, t = i - cl * T_len;
+    const float v = dpw[((long)b * F + g * Fh + cl) * T_len + t];
+    acc[18] += v;
+#pragma unroll
+    for (int dc = -1; dc <= 1; ++dc) {
+      const int c2 = cl + dc;
+      if (c2 < 0 || c2 >= Fh) continue;
+      const int cc = g * Fh + c2;
+#pragma unroll
+      for (int dt = -1; dt <= 1; ++dt) {
+        const int t2 = t + dt;
+        if (t2 < 0 || t2 >= T_len) continue;
+        const long row = ((long)b * T_len + t2) * F + cc;
+        const float rm = (xsum[row] - ysum[row]) * inv_hw;
+        const int ts = g ? t2 - 1 : t2 + 1;
+        const float ysh = (ts >= 0 && ts < T_len) ? ysum[((long)b * T_len + ts) * F + cc] * inv_hw : 0.f;
+        acc[(dc + 1) * 3 + (dt + 1)] = fmaf(v, ysh, acc[(dc + 1) * 3 + (dt + 1)]);
+        acc[9 + (dc + 1) * 3 + (dt + 1)] = fmaf(v, rm, acc[9 + (dc + 1) * 3 + (dt + 1)]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 19; ++k) {
+    const float s = block_sum<4>(acc[k], scratch);
+    if (threadIdx.x == 0) part[((long)b * 2 + g) * 19 + k] = s;
+  }
+}
+
+// ---- through the blend, the shift and the gate: lane = pixel of frame f.
+//   d_ys = dA*w + d_ym/hw,  d_r = dA*(1-w) + d_rm/hw,  d_y[t] = d_ys[t -/+ 1] - d_r[t],
+//   d_x(direct) = d_r + d_y*gate,  d_gate = sum_c d_y*x,  d_pre = d_gate * (1 - gate^2)
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_bwd_gate_kernel(const T* __restrict__ x, const float* __restrict__ gate,
+                                                           const float* __restrict__ fw, const T* __restrict__ dA,
+                                                           const float* __restrict__ d_ym, const float* __restrict__ d_rm,
+                                                           int T_len, int hw, int C, int F, int Fp,
+                                                           T* __restrict__ d_xs, float* __restrict__ d_pre) {
+  const long f = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int t = (int)(f % T_len);
+  const long b = f / T_len;
+  const int Fh = F >> 1, Fq = F >> 2;
+  const float inv_hw = 1.0f / (float)hw;
+  const long pix = f * hw + p;
+  float dg[2] = {0.f, 0.f};
+  for (int ci = 0; ci < F; ++ci) {
+    const int g = ci >= Fh;
+    const int co = gsf_out_col(ci, Fh, Fq);
+    const float w = fw[(b * F + ci) * T_len + t];
+    const float d_o = (float)dA[pix * Fp + co];
+    const float d_r = d_o * (1.f - w) + d_rm[f * F + ci] * inv_hw;
+    // y[t] was read by the output at frame t-1 (g = 0: ys[t-1] = y[t]) or t+1 (g = 1: ys[t+1] = y[t])
+    const int tu = g ? t + 1 : t - 1;
+    float d_ys = 0.f;
+    if (tu >= 0 && tu < T_len) {
+      const long fu = f + (tu - t);
+      d_ys = (float)dA[(fu * hw + p) * Fp + co] * fw[(b * F + ci) * T_len + tu] + d_ym[fu * F + ci] * inv_hw;
+    }
+    const float d_y = d_ys - d_r;
+    const float gt = gate[pix * 2 + g];
+    const float xv = (float)x[pix * C + ci];
+    d_xs[pix * Fp + ci] = (T)(d_r + d_y * gt);
+    dg[g] = fmaf(d_y, xv, dg[g]);
+  }
+  for (int c = F; c < Fp; ++c) d_xs[pix * Fp + c] = dA[pix * Fp + c];        // pass-through pad columns
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float gt = gate[pix * 2 + g];
+    d_pre[pix * 2 + g] = dg[g] * (1.f - gt * gt);
+  }
+}
+
+// ---- conv3d (3x3x3, groups = 2) input gradient + ReLU mask: lane = pixel; w3 [F][27] (channel-major), sa/sb = the
+// BatchNorm3d affine of this step (a = relu(x*sa + sb) is recomputed for the mask)
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx_kernel(const T* __restrict__ x, const float* __restrict__ d_pre,
+                                                                const float* __restrict__ w3,
+                                                                const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                int T_len, int h, int w, int C, int F, int Fp,
+                                                                T* __restrict__ d_bn) {
+  extern __shared__ float sw[];        // [F][27]
+  for (int i = threadIdx.x; i < F * 27; i += 256) sw[i] = w3[i];
+  __syncthreads();
+  const long f = blockIdx.y;
+  const int hw = h * w;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int t = (int)(f % T_len);
+  const int py = p / w, px = p - py * w;
+  const int Fh = F >> 1;
+  float dp[2][27];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt) {
+    const int t2 = t - dt + 1;                                  // output frame that read this input with tap dt
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y2 = py - dy + 1;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x2 = px - dx + 1;
+        const bool ok = t2 >= 0 && t2 < T_len && y2 >= 0 && y2 < h && x2 >= 0 && x2 < w;
+        const long q = ok ? ((f + (t2 - t)) * hw + y2 * w + x2) * 2 : 0;
+        dp[0][(dt * 3 + dy) * 3 + dx] = ok ? d_pre[q] : 0.f;
+        dp[1][(dt * 3 + dy) * 3 + dx] = ok ? d_pre[q + 1] : 0.f;
+      }
+    }
+  }
+  const long pix = f * hw + p;
+  for (int c = 0; c < F; ++c) {
+    const int g = c >= Fh;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a = fmaf(sw[c * 27 + k], dp[g][k], a);
+    const bool on = fmaf((float)x[pix * C + c], sa[c], sb[c]) > 0.f;
+    d_bn[pix * Fp + c] = (T)(on ? a : 0.f);
+  }
+  for (int c = F; c < Fp; ++c) d_bn[pix * Fp + c] = (T)0.f;
+}
+
+// ---- conv3d weight gradient: workgroup = frame f'; a[f'] (relu(bn(x))) tile in LDS, d_pre of frames f'-1..f'+1 with a
+// zero ring; lane (c, tap) walks the pixels.  part[f'][F*27 + 2] (the last two: d bias = sum_p d_pre[f'][p][g])
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_bwd_conv3d_dw_kernel(const T* __restrict__ x, const float* __restrict__ d_pre,
+                                                                const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                int T_len, int h, int w, int C, int F,
+                                                                float* __restrict__ part) {
+  extern __shared__ float sm[];
+  const int hw = h * w, WP = w + 2, HP = h + 2;
+  float* at = sm;                                               // [hw][F]
+  float* dpt = at + (size_t)hw * F;                             // [3][HP][WP][2]
+  __shared__ float scratch[8];
+  const long f = blockIdx.x;
+  const int t = (int)(f % T_len);
+  for (int i = threadIdx.x; i < hw * F; i += 256) {
+    const int p = i / F, c = i - p * F;
+    at[i] = fmaxf(fmaf((float)x[(f * hw + p) * C + c], sa[c], sb[c]), 0.f);
+  }
+  for (int i = threadIdx.x; i < 3 * HP * WP * 2; i += 256) {
+    const int g = i & 1;
+    const int r = i >> 1;
+    const int xx = r % WP, yy = (r / WP) % HP, k = r / (WP * HP);
+    const int t2 = t + k - 1, y2 = yy - 1, x2 = xx - 1;
+    float v = 0.f;
+    if (t2 >= 0 && t2 < T_len && y2 >= 0 && y2 < h && x2 >= 0 && x2 < w)
+      v = d_pre[((f + (k - 1)) * hw + y2 * w + x2) * 2 + g];
+    dpt[i] = v;
+  }
+  __syncthreads();
+  const int Fh = F >> 1;
+  // out frame t_out = t' - dt + 1 uses a[t'] with tap dt; its pixel = p - (dy-1, dx-1)
+  for (int o = threadIdx.x; o < F * 27; o += 256) {
+    const int c = o / 27, k = o - c * 27;
+    const int dt = k / 9, dy = (k / 3) % 3, dx = k % 3;
+    const int g = c >= Fh;
+    const int slab = 2 - dt;                                    // frame t'-dt+1 sits in slab (t_out - t') + 1 = 2 - dt
+    float a = 0.f;
+    for (int p = 0; p < hw; ++p) {
+      const int py = p / w, px = p - py * w;
+      const int y2 = py - dy + 1, x2 = px - dx + 1;             // ring coordinates: +1
+      a = fmaf(at[p * F + c], dpt[(((slab * HP) + y2 + 1) * WP + x2 + 1) * 2 + g], a);
+    }
+    part[f * (F * 27 + 2) + o] = a;
+  }
+  float b0 = 0.f, b1 = 0.f;
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const int py = p / w, px = p - py * w;
+    b0 += dpt[(((1 * HP) + py + 1) * WP + px + 1) * 2 + 0];
+    b1 += dpt[(((1 * HP) + py + 1) * WP + px + 1) * 2 + 1];
+  }
+  b0 = block_sum<4>(b0, scratch);
+  b1 = block_sum<4>(b1, scratch);
+  if (threadIdx.x == 0) {
+    part[f * (F * 27 + 2) + F * 27] = b0;
+    part[f * (F * 27 + 2) + F * 27 + 1] = b1;
+  }
+}
+
+// ---- dx[m][c] += a[m][c] + b[m][c] for c < Fp (dx row stride C; a, b dense [M][Fp])
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_add_cols_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
+                                                           int Fp, T* __restrict__ dx) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * Fp) return;
+  const long m = i / Fp;
+  const int c = (int)(i - m * Fp);
+  dx[m * C + c] = (T)((float)dx[m * C + c] + (float)a[i] + (float)b[i]);
+}
+
+extern "C" int tdeed_gsf_slice(const void* x, long M, int C, int F, int Fp, void* xs, int dtype, void* stream) {
+  TD_CHECK(x && xs && M > 0 && F > 0 && Fp >= F && Fp <= C, "gsf_slice: bad arguments");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_slice: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((M * Fp + 255) / 256));
+  if (dtype == TDEED_F32) hipLaunchKernelGGL(gsf_slice_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, C, F, Fp, (float*)xs);
+  else hipLaunchKernelGGL(gsf_slice_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, C, F, Fp, (bf16_t*)xs);
+  TD_LAUNCH_CHECK("gsf_slice");
+  return TDEED_OK;
+}
+
+extern "C" long tdeed_gsf_bwd_scratch_floats(int B, int T, int hw, int F) {
+  const long N = (long)B * T;
+  // d_wgt [N][F], dpw [B][F][T], d_ym [N][F], d_rm [N][F], d_pre [N][hw][2], part_cw [B][2][19], part_w3 [N][F*27+2]
+  return 4 * N * F + N * hw * 2 + (long)B * 38 + N * ((long)F * 27 + 2);
+}
+
+template <typename T>
+static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                          const void* dA_, int B, int T_len, int h, int w, int C, int F, int Fp, const float* w3,
+                          const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
+                          void* d_xs_, void* d_bn_, hipStream_t st) {
+  const T* x = (const T*)x_;
+  const T* dA = (const T*)dA_;
+  T* d_xs = (T*)d_xs_;
+  T* d_bn = (T*)d_bn_;
+  const int hw = h * w;
+  const long N = (long)B * T_len;
+  float* d_wgt = scratch;
+  float* dpw = d_wgt + N * F;
+  float* d_ym = dpw + N * F;
+  float* d_rm = d_ym + N * F;
+  float* d_pre = d_rm + N * F;
+  float* part_cw = d_pre + N * hw * 2;
+  float* part_w3 = part_cw + (long)B * 38;
+  const int S = 256 / F > 0 ? 256 / F : 1;
+  hipLaunchKernelGGL(gsf_bwd_dw_kernel<T>, dim3((unsigned)N), dim3(256), (size_t)S * F * sizeof(float), st, x, gate, dA, T_len,
+                     hw, C, F, Fp, d_wgt);
+  TD_LAUNCH_CHECK("gsf_bwd_dw");
+  const long nft = N * F;
+  hipLaunchKernelGGL(gsf_bwd_dpw_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, d_wgt, fw, T_len, F, nft, dpw);
+  hipLaunchKernelGGL(gsf_bwd_planes_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, dpw, T_len, F, cw1, cw2,
+                     nft, d_ym, d_rm);
+  hipLaunchKernelGGL(gsf_bwd_cw_kernel, dim3(B, 2), dim3(256), 0, st, dpw, ysum, xsum, T_len, F, 1.0f / (float)hw, part_cw);
+  TD_LAUNCH_CHECK("gsf_bwd fuse");
+  const dim3 gpix(cdiv(hw, 256), (unsigned)N);
+  hipLaunchKernelGGL(gsf_bwd_gate_kernel<T>, gpix, dim3(256), 0, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, d_xs,
+                     d_pre);
+  TD_LAUNCH_CHECK("gsf_bwd_gate");
+  hipLaunchKernelGGL(gsf_bwd_conv3d_dx_kernel<T>, gpix, dim3(256), (size_t)F * 27 * sizeof(float), st, x, d_pre, w3, sa, sb,
+                     T_len, h, w, C, F, Fp, d_bn);
+  TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx");
+  const size_t smw = ((size_t)hw * F + (size_t)3 * (h + 2) * (w + 2) * 2) * sizeof(float);
+  TD_CHECK(smw <= 150 * 1024, "gsf_bwd: frame %dx%d x %d channels does not fit LDS", h, w, F);
+  hipError_t e = hipFuncSetAttribute((const void*)gsf_bwd_conv3d_dw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     150 * 1024);
+  if (e != hipSuccess) { tdeed_set_error("gsf_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+  hipLaunchKernelGGL(gsf_bwd_conv3d_dw_kernel<T>, dim3((unsigned)N), dim3(256), smw, st, x, d_pre, sa, sb, T_len, h, w, C, F,
+                     part_w3);
+  TD_LAUNCH_CHECK("gsf_bwd_conv3d_dw");
+  return TDEED_OK;
+}
+
+// Everything between the module output gradient dA and (a) the direct part of d x (d_xs, dense [M][Fp]) and (b) the
+// gradient entering the BatchNorm3d output after the ReLU mask (d_bn, dense [M][Fp]); parameter gradients:
+// d_w3 [F][27] (= conv3D.weight (2, F/2, 3,3,3) flattened), d_b3 [2], d_cw [2][18] + d_cb [2] (channel_conv1 | 2).
+// sa/sb: the BatchNorm3d affine used by the forward of this step.  scratch: tdeed_gsf_bwd_scratch_floats() fp32.
+extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                             const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3,
+                             const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
+                             void* d_xs, void* d_bn, float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype,
+                             void* stream) {
+  TD_CHECK(x && gate && fw && ysum && xsum && dA && w3 && sa && sb && cw1 && cw2 && scratch && d_xs && d_bn && d_w3 &&
+               d_b3 && d_cw && d_cb, "gsf_bwd: null pointer");
+  TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && F > 0 && F % 4 == 0 && Fp >= F && Fp <= C && F <= 256, "gsf_bwd: bad sizes");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dtype == TDEED_F32
+               ? gsf_bwd_launch<float>(x, gate, fw, ysum, xsum, dA, B, T, h, w, C, F, Fp, w3, sa, sb, cw1, cw2, scratch, d_xs,
+                                       d_bn, st)
+               : gsf_bwd_launch<bf16_t>(x, gate, fw, ysum, xsum, dA, B, T, h, w, C, F, Fp, w3, sa, sb, cw1, cw2, scratch,
+                                        d_xs, d_bn, st);
+  if (rc != TDEED_OK) return rc;
+  const long N = (long)B * T;
+  float* part_cw = scratch + 4 * N * F + N * h * w * 2;
+  float* part_w3 = part_cw + (long)B * 38;
+  // fold the per-frame / per-clip partials (rows hold several parameter groups side by side)
+  const long row = (long)F * 27 + 2;
+  rc = tdeed_reduce_strided(part_w3, (int)N, row, (long)F * 27, d_w3, stream);
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_w3 + (long)F * 27, (int)N, row, 2, d_b3, stream);
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw, B, 38, 18, d_cw, stream);                 // channel_conv1 taps
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 19, B, 38, 18, d_cw + 18, stream);       // channel_conv2 taps
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 18, B, 38, 1, d_cb, stream);
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 37, B, 38, 1, d_cb + 1, stream);
+  return rc;
+}
+
+// dx[m][0:Fp] += a + b (dx row stride C): the module's input gradient joins conv1's pass-through gradient
+extern "C" int tdeed_gsf_add_cols(const void* a, const void* b, long M, int C, int Fp, void* dx, int dtype, void* stream) {
+  TD_CHECK(a && b && dx && M > 0 && Fp > 0 && Fp <= C, "gsf_add_cols: bad arguments");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_add_cols: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((M * Fp + 255) / 256));
+  if (dtype == TDEED_F32) hipLaunchKernelGGL(gsf_add_cols_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, M, C, Fp, (float*)dx);
+  else hipLaunchKernelGGL(gsf_add_cols_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, M, C, Fp, (bf16_t*)dx);
+  TD_LAUNCH_CHECK("gsf_add_cols");
+  return TDEED_OK;
+}

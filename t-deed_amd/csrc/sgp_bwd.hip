@@ -30,6 +30,15 @@ extern "C" int tdeed_reduce_partials(const float* part, int P, long n, float* ou
   return TDEED_OK;
 }
 
+// rows of `part` hold several parameter groups side by side: fold n columns of rows that are `stride` floats apart
+extern "C" int tdeed_reduce_strided(const float* part, int P, long stride, long n, float* out, void* stream) {
+  TD_CHECK(part && out && P > 0 && n > 0 && stride >= n, "reduce_strided: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     P, stride, n, out, 0);
+  TD_LAUNCH_CHECK("reduce_strided");
+  return TDEED_OK;
+}
+
 // elementwise: mode 0: y = gelu(x);  1: y = dy * gelu'(x);  2: y = x + dy (gradient accumulation);  3: y = x * dy (dropout mask)
 template <typename T>
 __global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ y,

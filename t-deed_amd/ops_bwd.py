@@ -191,3 +191,46 @@ def stride2_scatter_add(d_small, d_big):
     F_, hi, wi, C = d_big.shape
     call("tdeed_stride2_rows", ptr(d_small), ptr(d_big), F_, hi, wi, C, 1, dtype_code(d_big.dtype), stream_ptr())
     return d_big
+
+
+def bn_stats(z, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None):
+    """Batch statistics of z (.., C) only: -> (mean, rstd, a, b) with y = z*a + b the normalisation."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    part = _f32((_lib.load().tdeed_bn_slabs(M), 2, C), dev)
+    mean, rstd, a, bb = (_f32((C,), dev) for _ in range(4))
+    call("tdeed_bn_train_stats", ptr(z), M, C, ptr(w), ptr(b), eps, momentum, ptr(part), ptr(mean), ptr(rstd), ptr(a),
+         ptr(bb), ptr(run_mean), ptr(run_var), dtype_code(z.dtype), stream_ptr())
+    return mean, rstd, a, bb
+
+
+# ----------------------------------------------------------------------------- gate-shift-fuse
+def gsf_slice(x, F, Fp):
+    C = x.shape[-1]
+    M = x.numel() // C
+    xs = torch.empty((M, Fp), dtype=x.dtype, device=x.device)
+    call("tdeed_gsf_slice", ptr(x), M, C, F, Fp, ptr(xs), dtype_code(x.dtype), stream_ptr())
+    return xs
+
+
+def gsf_bwd(x, gate, fw, ysum, xsum, dA, B, T, F, Fp, w3, sa, sb, cw1, cw2):
+    """-> d_xs (M,Fp), d_bn (M,Fp), d_w3 (F,27), d_b3 (2,), d_cw (2,18), d_cb (2,)"""
+    N, h, w, C = x.shape
+    dev = x.device
+    scratch = _f32((_lib.load().tdeed_gsf_bwd_scratch_floats(B, T, h * w, F),), dev)
+    M = N * h * w
+    d_xs = torch.empty((M, Fp), dtype=x.dtype, device=dev)
+    d_bn = torch.empty((M, Fp), dtype=x.dtype, device=dev)
+    d_w3, d_b3, d_cw, d_cb = _f32((F, 27), dev), _f32((2,), dev), _f32((2, 18), dev), _f32((2,), dev)
+    call("tdeed_gsf_bwd", ptr(x), ptr(gate), ptr(fw), ptr(ysum), ptr(xsum), ptr(dA), B, T, h, w, C, F, Fp, ptr(w3), ptr(sa),
+         ptr(sb), ptr(cw1), ptr(cw2), ptr(scratch), ptr(d_xs), ptr(d_bn), ptr(d_w3), ptr(d_b3), ptr(d_cw), ptr(d_cb),
+         dtype_code(x.dtype), stream_ptr())
+    return d_xs, d_bn, d_w3, d_b3, d_cw, d_cb
+
+
+def gsf_add_cols(a, b, dx, Fp):
+    C = dx.shape[-1]
+    M = dx.numel() // C
+    call("tdeed_gsf_add_cols", ptr(a), ptr(b), M, C, Fp, ptr(dx), dtype_code(dx.dtype), stream_ptr())
+    return dx

@@ -3,7 +3,8 @@ mode, as `TDEEDModel.epoch(optimizer=...)` runs it: /root/reference/model/model.
 
 Like temporal_train.py this file only orders launches of the HIP kernels (ops.py / ops_bwd.py), keeps the activations the
 backward needs and maps the packed gradient layouts back to the reference's state_dict names.  The gate-shift wrapper of
-the s3/s4 blocks (shift.py:64-93) is not differentiated yet: blocks are handled with `gsf_fold == 0`."""
+the s3/s4 blocks (`GatedShift` + `_GSF`, shift.py:64-93, impl/gsf.py:38-93) is `GateShiftTrain`: its forward reuses the
+inference kernels with the BatchNorm3d affine taken from batch statistics, its backward is gsf_bwd.hip."""
 from types import SimpleNamespace
 
 import torch
@@ -19,19 +20,87 @@ def _dense(w, dt):
     return SimpleNamespace(w=w, wt=B_.transpose(w))
 
 
+class GateShiftTrain:
+    """`GatedShift` + `_GSF` on the first F channels of a block input, training mode."""
+
+    def __init__(self, sd, pre, F, T):
+        self.sd, self.pre, self.F, self.T = sd, pre, F, T
+        self.Fp = (F + 7) // 8 * 8
+        self.repack()
+
+    def repack(self):
+        sd, pre, F = self.sd, self.pre, self.F
+        w3 = sd[pre + ".conv3D.weight"].reshape(F, 27).contiguous()
+        self.w3 = w3                                   # [F][27]: backward
+        self.wq = w3.t().contiguous()                  # [27][F]: forward (VALU tap kernel)
+        self.b3 = sd[pre + ".conv3D.bias"]
+        self.cw1, self.cb1 = sd[pre + ".channel_conv1.weight"].reshape(18), sd[pre + ".channel_conv1.bias"]
+        self.cw2, self.cb2 = sd[pre + ".channel_conv2.weight"].reshape(18), sd[pre + ".channel_conv2.bias"]
+
+    def _pad(self, v, fill=0.0):
+        out = torch.full((self.Fp,), fill, dtype=torch.float32, device=v.device)
+        out[:self.F] = v
+        return out
+
+    def forward(self, x):
+        """x (N,h,w,C) -> G (N*h*w, Fp): the module output in conv1's operand layout (pad columns = copies of x)."""
+        sd, pre, F, Fp, T = self.sd, self.pre, self.F, self.Fp, self.T
+        N = x.shape[0]
+        c = SimpleNamespace(x=x, B=N // T)
+        c.xs = B_.gsf_slice(x, F, Fp)
+        rm, rv = self._pad(sd[pre + ".bn.running_mean"]), self._pad(sd[pre + ".bn.running_var"], 1.0)
+        c.w_pad = self._pad(sd[pre + ".bn.weight"])
+        c.mean, c.rstd, c.sa, c.sb = B_.bn_stats(c.xs, c.w_pad, self._pad(sd[pre + ".bn.bias"]), BN_EPS, 0.1, rm, rv)
+        sd[pre + ".bn.running_mean"].copy_(rm[:F])
+        sd[pre + ".bn.running_var"].copy_(rv[:F])
+        bufs = {}
+        dev = x.device
+        h, w = x.shape[1], x.shape[2]
+        bufs["gate"] = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
+        bufs["ysum"] = torch.empty((N, F), dtype=torch.float32, device=dev)
+        bufs["xsum"] = torch.empty((N, F), dtype=torch.float32, device=dev)
+        bufs["fw"] = torch.empty((c.B, F, T), dtype=torch.float32, device=dev)
+        G = ops.gate_shift(x, c.B, T, F, Fp, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.wq, self.b3, self.cw1,
+                           self.cb1, self.cw2, self.cb2, bufs=bufs, separate_weight=True)
+        c.bufs = bufs
+        self.ctx = c
+        return G
+
+    def backward(self, dA, grads):
+        """dA (N*h*w, Fp): gradient of forward()'s output.  Returns (d_xs, dz_bn): the two dense (M,Fp) parts of the
+        gradient w.r.t. x[..., :Fp] (to be added into the block-input gradient)."""
+        sd, pre, F, Fp, T, c = self.sd, self.pre, self.F, self.Fp, self.T, self.ctx
+        b = c.bufs
+        d_xs, d_bn, d_w3, d_b3, d_cw, d_cb = B_.gsf_bwd(c.x, b["gate"], b["fw"], b["ysum"], b["xsum"], dA, c.B, T, F, Fp,
+                                                       self.w3, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.cw1,
+                                                       self.cw2)
+        dz, _, dw, db = B_.bn_train_bwd(c.xs, d_bn, None, (c.mean, c.rstd), c.w_pad, relu=False)
+        grads[pre + ".conv3D.weight"] = d_w3.reshape(sd[pre + ".conv3D.weight"].shape)
+        grads[pre + ".conv3D.bias"] = d_b3
+        grads[pre + ".bn.weight"], grads[pre + ".bn.bias"] = dw[:F].contiguous(), db[:F].contiguous()
+        grads[pre + ".channel_conv1.weight"] = d_cw[0].reshape(sd[pre + ".channel_conv1.weight"].shape)
+        grads[pre + ".channel_conv2.weight"] = d_cw[1].reshape(sd[pre + ".channel_conv2.weight"].shape)
+        grads[pre + ".channel_conv1.bias"] = d_cb[0:1].contiguous()
+        grads[pre + ".channel_conv2.bias"] = d_cb[1:2].contiguous()
+        return d_xs, dz
+
+
 class BottleneckTrain:
     """One bottleneck in training mode.  sd: name -> fp32 master tensor on the device (reference names); BatchNorm
     running statistics in sd are updated in place by forward()."""
 
-    def __init__(self, sd, pre, blk, act_dtype=torch.float32):
-        assert blk.gsf_fold == 0, "gate-shift blocks: backward not built yet"
+    def __init__(self, sd, pre, blk, act_dtype=torch.float32, clip_len=None):
         self.sd, self.pre, self.blk, self.dt = sd, pre, blk, act_dtype
+        self.c1 = pre + (".conv1.net" if blk.gsf_fold else ".conv1")          # GatedShift keeps the conv as .net
+        self.gs = GateShiftTrain(sd, pre + ".conv1.gs", blk.gsf_fold, clip_len) if blk.gsf_fold else None
         self.repack()
 
     def repack(self):
         sd, pre, blk, dt = self.sd, self.pre, self.blk, self.dt
-        dev = sd[pre + ".conv1.conv.weight"].device
-        self.w1 = _dense(sd[pre + ".conv1.conv.weight"], dt)
+        dev = sd[self.c1 + ".conv.weight"].device
+        if self.gs is not None:
+            self.gs.repack()
+        self.w1 = _dense(sd[self.c1 + ".conv.weight"], dt)
         self.w3 = _dense(sd[pre + ".conv3.conv.weight"], dt)
         self.wd = _dense(sd[pre + ".downsample.conv.weight"], dt) if blk.has_downsample else None
         G, gw = blk.groups, blk.gw
@@ -44,7 +113,7 @@ class BottleneckTrain:
         self.se_w1t, self.se_w2t = self.se_w1.t().contiguous(), self.se_w2.t().contiguous()
 
     def _bn(self, z, name, res=None, relu=True):
-        sd, p = self.sd, f"{self.pre}.{name}.bn"
+        sd, p = self.sd, (self.c1 if name == "conv1" else f"{self.pre}.{name}") + ".bn"
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
 
@@ -54,7 +123,13 @@ class BottleneckTrain:
         N, h, w, Cin = x.shape
         C = blk.cout
         c = SimpleNamespace(x=x)
-        c.z1 = ops.gemm(x, self.w1.w, None, None, ops.ACT_NONE).view(N, h, w, C)
+        if self.gs is not None:
+            Fp = self.gs.Fp
+            c.a1 = x.clone()                                                    # conv1 operand: [G | x[..., Fp:]]
+            c.a1.view(-1, Cin)[:, :Fp] = self.gs.forward(x)
+        else:
+            c.a1 = x
+        c.z1 = ops.gemm(c.a1, self.w1.w, None, None, ops.ACT_NONE).view(N, h, w, C)
         c.y1, c.bn1 = self._bn(c.z1, "conv1")
         c.z2, _ = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, relu=False)
         c.y2, c.bn2 = self._bn(c.z2, "conv2")
@@ -80,7 +155,8 @@ class BottleneckTrain:
         hw2 = h2 * w2
 
         def bn_names(name, dw, db):
-            grads[f"{pre}.{name}.bn.weight"], grads[f"{pre}.{name}.bn.bias"] = dw, db
+            p = (self.c1 if name == "conv1" else f"{pre}.{name}") + ".bn"
+            grads[p + ".weight"], grads[p + ".bias"] = dw, db
 
         dz3, d_sc, dw, db = B_.bn_train_bwd(c.z3, dout, c.out, c.bn3, sd[pre + ".conv3.bn.weight"], relu=True, want_res=True)
         bn_names("conv3", dw, db)
@@ -105,12 +181,18 @@ class BottleneckTrain:
         grads[pre + ".conv2.conv.weight"] = (dw2p.reshape(G, 3, 3, gw, gw).permute(0, 4, 3, 1, 2)
                                              .reshape(sd[pre + ".conv2.conv.weight"].shape).contiguous())
         # conv1
-        dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, c.y1, c.bn1, sd[pre + ".conv1.bn.weight"], relu=True)
+        dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, c.y1, c.bn1, sd[self.c1 + ".bn.weight"], relu=True)
         bn_names("conv1", dw, db)
         Nf, h, w, Cin = c.x.shape
         dx = ops.gemm(dz1, self.w1.wt, None, None, ops.ACT_NONE).view(Nf, h, w, Cin)
-        grads[pre + ".conv1.conv.weight"] = B_.wgrad(dz1, c.x, with_bias=False, M=Nf * h * w)[0].reshape(
-            sd[pre + ".conv1.conv.weight"].shape)
+        grads[self.c1 + ".conv.weight"] = B_.wgrad(dz1, c.a1, with_bias=False, M=Nf * h * w)[0].reshape(
+            sd[self.c1 + ".conv.weight"].shape)
+        if self.gs is not None:
+            Fp = self.gs.Fp
+            dA = dx.view(-1, Cin)[:, :Fp].contiguous()                          # gradient of the gate-shift output
+            d_xs, dz_bn = self.gs.backward(dA, grads)
+            dx.view(-1, Cin)[:, :Fp] = 0
+            B_.gsf_add_cols(d_xs, dz_bn, dx, Fp)
         # shortcut
         if blk.has_downsample:
             dzd, _, dw, db = B_.bn_train_bwd(c.zd, d_sc, None, c.bnd, sd[pre + ".downsample.bn.weight"], relu=False)

@@ -320,7 +320,12 @@ def _block_state(blk, seed=51):
         d[f"{pre}.{n}.conv.weight"] = ((co, ci, k, k), "float32")
         for s_ in ("weight", "bias", "running_mean", "running_var"):
             d[f"{pre}.{n}.bn.{s_}"] = ((co,), "float32")
-    conv_bn("conv1", blk.cout, blk.cin, 1)
+    if blk.gsf_fold:
+        from tdeed_amd import state_layout
+        conv_bn("conv1.net", blk.cout, blk.cin, 1)
+        state_layout._gate_shift(d, pre + ".conv1.gs", blk.gsf_fold, "gsf")
+    else:
+        conv_bn("conv1", blk.cout, blk.cin, 1)
     conv_bn("conv2", blk.cout, blk.gw, 3)
     conv_bn("conv3", blk.cout, blk.cout, 1)
     if blk.has_downsample:
@@ -336,7 +341,9 @@ def _block_state(blk, seed=51):
 @pytest.mark.parametrize("geom", [dict(cin=32, cout=24, stride=2, gw=8, N=3, h=20, w=24),      # s1.b1-like
                                   dict(cin=24, cout=56, stride=2, gw=8, N=2, h=14, w=14),      # s2.b1-like
                                   dict(cin=152, cout=152, stride=1, gw=8, N=4, h=7, w=7),      # identity block
-                                  dict(cin=64, cout=128, stride=1, gw=16, N=2, h=6, w=10)])    # 1x1 shortcut, stride 1
+                                  dict(cin=64, cout=128, stride=1, gw=16, N=2, h=6, w=10),     # 1x1 shortcut, stride 1
+                                  dict(cin=152, cout=152, stride=1, gw=8, N=8, h=7, w=7, fold=40, T=4),     # s3.b2-like, GSF
+                                  dict(cin=56, cout=152, stride=2, gw=8, N=6, h=10, w=12, fold=16, T=3)])   # s3.b1-like, GSF
 def test_bottleneck_train_fwd_bwd_matches_autograd(dtype, geom):
     """A whole RegNetY bottleneck in training mode (batch-stat BN, SE, shortcut): output, running statistics, every
     parameter gradient and d x against autograd on the CPU oracle's regnet_block(training=True)."""
@@ -345,21 +352,23 @@ def test_bottleneck_train_fwd_bwd_matches_autograd(dtype, geom):
     g = geom
     blk = BlockSpec(name="blk", stage=1, index=1, cin=g["cin"], cout=g["cout"], stride=g["stride"], groups=g["cout"] // g["gw"],
                     gw=g["gw"], se_rd=int(round(g["cin"] * 0.25)), has_downsample=(g["cin"] != g["cout"] or g["stride"] != 1),
-                    gsf_fold=0, hin=g["h"])
+                    gsf_fold=g.get("fold", 0), hin=g["h"])
+    T = g.get("T", 1)
     sd = _block_state(blk)
     x = rnd(271, "x", (g["N"], g["cin"], g["h"], g["w"])).abs().to(dtype)
-    sdr = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in sd.items()}
+    sdr = {k: (v.clone().requires_grad_(True) if ("running" not in k and v.dtype == torch.float32) else v.clone())
+           for k, v in sd.items()}
     xr = x.float().requires_grad_(True)
-    ref = O.regnet_block(xr, sdr, "blk", blk, 1, "gsf", training=True)
+    ref = O.regnet_block(xr, sdr, "blk", blk, T, "gsf", training=True)
     dy = rnd(272, "dy", tuple(ref.shape)).to(dtype)
     ref.backward(dy.float())
     sdd = {k: v.clone().to(DEV) for k, v in sd.items()}
-    bt = BottleneckTrain(sdd, "blk", blk, act_dtype=dtype)
+    bt = BottleneckTrain(sdd, "blk", blk, act_dtype=dtype, clip_len=T)
     out = bt.forward(x.permute(0, 2, 3, 1).contiguous().to(DEV))
     assert rel_err(out.float().permute(0, 3, 1, 2), ref) < (2e-4 if dtype == torch.float32 else 4e-2)
     grads = {}
     dx = bt.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV), grads)
-    want = {k for k in sd if "running" not in k}
+    want = {k for k, v in sd.items() if "running" not in k and v.dtype == torch.float32}
     assert set(grads) == want, set(grads) ^ want
     if dtype == torch.float32:
         assert rel_err(dx.float().permute(0, 3, 1, 2), xr.grad) < 2e-3
@@ -371,3 +380,45 @@ def test_bottleneck_train_fwd_bwd_matches_autograd(dtype, geom):
         ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sorted(want)])
         gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sorted(want)])
         assert float((ga - gr).norm() / gr.norm()) < 0.1      # batch-stat BN over a few hundred bf16 samples per channel
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [dict(C=152, F=40, B=2, T=6, h=5, w=7), dict(C=56, F=16, B=1, T=5, h=9, w=8),
+                                  dict(C=368, F=92, B=2, T=4, h=7, w=7)])
+def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
+    """GatedShift + _GSF in training mode (BatchNorm3d batch statistics): module output, parameter gradients and d x
+    against autograd on the CPU oracle's gate_shift(training=True)."""
+    from tdeed_amd.trunk_train import GateShiftTrain
+    g = geom
+    C, F, B, T, h, w = g["C"], g["F"], g["B"], g["T"], g["h"], g["w"]
+    Fp = (F + 7) // 8 * 8
+    N = B * T
+    sd = {k: t(v) for k, v in module_state("gate_shift", "gs", 61, F=F, mode="gsf").items()}
+    x = rnd(281, "x", (N, C, h, w)).to(dtype)
+    sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd.items()}
+    xr = x.float().requires_grad_(True)
+    ref = O.gate_shift(xr[:, :F], sdr, "gs", T, "gsf", training=True)          # (N, F, h, w)
+    dy = rnd(282, "dy", (N, F, h, w)).to(dtype)
+    ref.backward(dy.float())
+    sdd = {k: v.clone().to(DEV) for k, v in sd.items()}
+    gs = GateShiftTrain(sdd, "gs", F, T)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    G = gs.forward(xd)
+    assert rel_err(G[:, :F].float().view(N, h, w, F).permute(0, 3, 1, 2), ref) < (2e-4 if dtype == torch.float32 else 4e-2)
+    dA = torch.zeros((N * h * w, Fp), dtype=dtype)
+    dA[:, :F] = dy.permute(0, 2, 3, 1).reshape(-1, F)
+    grads = {}
+    d_xs, dz = gs.backward(dA.to(DEV), grads)
+    dx = (d_xs.float() + dz.float())[:, :F].view(N, h, w, F).permute(0, 3, 1, 2)
+    want = {k for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k}
+    assert set(grads) == want, set(grads) ^ want
+    if dtype == torch.float32:
+        assert rel_err(dx, xr.grad[:, :F]) < 2e-3
+        worst = max((rel_err(grads[k], sdr[k].grad), k) for k in want)
+        assert worst[0] < 2e-3, worst
+    else:
+        l2 = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))  # noqa: E731
+        assert l2(dx, xr.grad[:, :F]) < 0.1
+        ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sorted(want)])
+        gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sorted(want)])
+        assert float((ga - gr).norm() / gr.norm()) < 0.1
