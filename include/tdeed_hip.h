@@ -37,8 +37,8 @@ int tdeed_device_info(int dev, char* name64, int* n_cu, int* is_gfx950);
  * frames: uint8 [N][3][H][W] (NCHW as the loader delivers it); out: [N][Ho][Wo][32], Ho=(crop_h+1)/2. */
 int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
                    int crop_h, int crop_w, int flip, const float* w /*[32][3][3][3]*/,
-                   const float* scale /*[32]*/, const float* shift /*[32]*/, void* out, int dtype,
-                   void* stream);
+                   const float* scale /*[32]*/, const float* shift /*[32]*/, void* out,
+                   int relu /* 0: raw conv*scale+shift (training) */, int dtype, void* stream);
 
 /* ---- fused trunk front (bf16 only): pre-proc + stem + s1.b1.conv1 + s1.b1.conv2 (+SE squeeze) + s1.b1.downsample
  * uint8 frames [N][3][H][W] -> y2 [N][Ho][Wo][C1] (conv2 output), shortcut [N][Ho][Wo][C1], pooled fp32
@@ -323,6 +323,13 @@ int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int
                        void* dx, float* part, float* dw, int dtype, void* stream);
 /* mode 0: out[(f,yo,xo)] = in[(f,2yo,2xo)] (operand of the stride-2 shortcut conv); mode 1: out[(f,2yo,2xo)] += in[(f,yo,xo)] */
 int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int wi, int C, int mode, int dtype, void* stream);
+
+/* avgpool + positional encoding backward: d x[f][p][c] = d feat[f][c]/hw, d temp_enc[t][c] = sum_b d feat[b][t][c] */
+int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw, int C, void* dx, float* d_temp_enc, int dtype,
+                             void* stream);
+/* stem weight gradient (the uint8 input needs none): dz [N][Ho][Wo][32] -> dw [32][3][3][3]; part fp32 [N][864] */
+int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h, int crop_w,
+                     int flip, const void* dz, float* part, float* dw, int dtype, void* stream);
 
 /* ---- gate-shift-fuse backward (gsf_bwd.hip; forward tensors as saved by tdeed_gsf_gate_fwd / tdeed_gsf_weight_fwd).
  * tdeed_gsf_slice: dense copy xs [M][Fp] of the module's channels (cols >= F zero): the BatchNorm3d operand in training.

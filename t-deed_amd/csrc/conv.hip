@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ f
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ scale,
                                                    const float* __restrict__ shift, T* __restrict__ out,
-                                                   int Ho, int Wo) {
+                                                   int Ho, int Wo, int relu) {
   __shared__ float tile[3][33][34];
   const int n = blockIdx.z;
   const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ f
       float a = 0.f;
 #pragma unroll
       for (int i = 0; i < 27; ++i) a = fmaf(in[i], wo[i], a);
-      v[e] = fmaxf(a * scale[o0 + e] + shift[o0 + e], 0.f);
+      v[e] = relu ? fmaxf(a * scale[o0 + e] + shift[o0 + e], 0.f) : a * scale[o0 + e] + shift[o0 + e];
     }
     Chunk<T>::store(dst + o0, v);
   }
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ f
 
 extern "C" int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
                               int crop_h, int crop_w, int flip, const float* w, const float* scale,
-                              const float* shift, void* out, int dtype, void* stream) {
+                              const float* shift, void* out, int relu, int dtype, void* stream) {
   TD_CHECK(frames && w && scale && shift && out, "stem: null pointer");
   TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 &&
                crop_top + crop_h <= H && crop_left + crop_w <= W,
@@ -74,10 +74,10 @@ extern "C" int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int cr
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
-                       crop_w, flip, w, scale, shift, (float*)out, Ho, Wo);
+                       crop_w, flip, w, scale, shift, (float*)out, Ho, Wo, relu);
   else if (dtype == TDEED_BF16)
     hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
-                       crop_w, flip, w, scale, shift, (bf16_t*)out, Ho, Wo);
+                       crop_w, flip, w, scale, shift, (bf16_t*)out, Ho, Wo, relu);
   else { tdeed_set_error("stem: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("stem");
   return TDEED_OK;

@@ -607,3 +607,131 @@ extern "C" int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int 
   TD_LAUNCH_CHECK("stride2_rows");
   return TDEED_OK;
 }
+
+// =========================================================================== global average pool + positional encoding
+// forward (avgpool_posenc): feat[b][t][c] = mean_p x[f][p][c] + temp_enc[t][c].  Backward:
+//   d x[f][p][c] = d feat[f][c] / hw  (broadcast),   d temp_enc[t][c] = sum_b d feat[b][t][c]
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ d_feat, int hw, int C, T* __restrict__ dx,
+                                                          long nchunks, int nch) {
+  constexpr int EPC = Chunk<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int ck = (int)(i % nch);
+  const long f = (i / nch) / hw;
+  float v[EPC];
+  Chunk<T>::load(d_feat + f * C + ck * EPC, v);
+  const float inv = 1.0f / (float)hw;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) v[e] *= inv;
+  Chunk<T>::store(dx + i * EPC, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void posenc_bwd_kernel(const T* __restrict__ d_feat, int B, long TC,
+                                                         float* __restrict__ d_enc) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= TC) return;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += (float)d_feat[(long)b * TC + j];
+  d_enc[j] = a;
+}
+
+extern "C" int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw, int C, void* dx, float* d_temp_enc,
+                                        int dtype, void* stream) {
+  TD_CHECK(d_feat && dx && d_temp_enc && B > 0 && T > 0 && hw > 0 && C % 8 == 0, "avgpool_posenc_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long TC = (long)T * C;
+  if (dtype == TDEED_F32) {
+    const long n = (long)B * T * hw * (C / 4);
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)d_feat,
+                       hw, C, (float*)dx, n, C / 4);
+    hipLaunchKernelGGL(posenc_bwd_kernel<float>, dim3((unsigned)((TC + 255) / 256)), dim3(256), 0, st, (const float*)d_feat, B,
+                       TC, d_temp_enc);
+  } else if (dtype == TDEED_BF16) {
+    const long n = (long)B * T * hw * (C / 8);
+    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)d_feat, hw, C, (bf16_t*)dx, n, C / 8);
+    hipLaunchKernelGGL(posenc_bwd_kernel<bf16_t>, dim3((unsigned)((TC + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)d_feat, B, TC, d_temp_enc);
+  } else { tdeed_set_error("avgpool_posenc_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("avgpool_posenc_bwd");
+  return TDEED_OK;
+}
+
+// =========================================================================== stem weight gradient
+// forward (stem_kernel): z[n][oy][ox][co] = sum_{c,ky,kx} w[co][c][ky][kx] * in[c][2oy+ky-1][2ox+kx-1], in = the cropped,
+// optionally flipped, /255 and ImageNet-standardised uint8 frame.  The input needs no gradient; the weight gradient is
+// dw[co][27] = sum_{n,oy,ox} dz * in.  One workgroup per frame walks its 16x16 output tiles (patch and dz tile in LDS,
+// lanes own (co, tap) pairs): part[n][32*27], folded by reduce_partials.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restrict__ frames, int H, int W, int top, int left,
+                                                         int ch, int cw, int flip, const T* __restrict__ dz, int Ho, int Wo,
+                                                         float* __restrict__ part) {
+  __shared__ float tile[3][33][34];
+  __shared__ float dzt[256][33];
+  const int n = blockIdx.x;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const uint8_t* src = frames + (long)n * 3 * H * W;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                           // outputs o = tid + 256*i < 864
+  for (int oy0 = 0; oy0 < Ho; oy0 += 16)
+    for (int ox0 = 0; ox0 < Wo; ox0 += 16) {
+      const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+      __syncthreads();
+      for (int i = threadIdx.x; i < 3 * 33 * 33; i += 256) {
+        const int c = i / (33 * 33);
+        const int r = i - c * 33 * 33;
+        const int y = r / 33, x = r - y * 33;
+        const int iy = iy0 + y, ix = ix0 + x;
+        float v = 0.f;
+        if (iy >= 0 && iy < ch && ix >= 0 && ix < cw) {
+          const int sx = flip ? (cw - 1 - ix) : ix;
+          const float u = (float)src[((long)c * H + (top + iy)) * W + (left + sx)];
+          v = (u / 255.0f - mean[c]) / stdv[c];
+        }
+        tile[c][y][x] = v;
+      }
+      for (int i = threadIdx.x; i < 256 * 32; i += 256) {
+        const int p = i >> 5, co = i & 31;
+        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+        dzt[p][co] = (oy < Ho && ox < Wo) ? (float)dz[(((long)n * Ho + oy) * Wo + ox) * 32 + co] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = threadIdx.x + 256 * i;
+        if (o < 864) {
+          const int co = o / 27, k = o - co * 27;
+          const int c = k / 9, ky = (k / 3) % 3, kx = k % 3;
+          float a = acc[i];
+          for (int p = 0; p < 256; ++p) a = fmaf(dzt[p][co], tile[c][2 * (p >> 4) + ky][2 * (p & 15) + kx], a);
+          acc[i] = a;
+        }
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = threadIdx.x + 256 * i;
+    if (o < 864) part[(long)n * 864 + o] = acc[i];
+  }
+}
+
+// dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N][864]
+extern "C" int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h,
+                                int crop_w, int flip, const void* dz, float* part, float* dw, int dtype, void* stream) {
+  TD_CHECK(frames && dz && part && dw, "stem_wgrad: null pointer");
+  TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= H &&
+               crop_left + crop_w <= W, "stem_wgrad: bad geometry");
+  const int Ho = (crop_h + 1) / 2, Wo = (crop_w + 1) / 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(N), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h, crop_w,
+                       flip, (const float*)dz, Ho, Wo, part);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(N), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
+                       crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
+  else { tdeed_set_error("stem_wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("stem_wgrad");
+  return tdeed_reduce_partials(part, N, 864, dw, 0, stream);
+}

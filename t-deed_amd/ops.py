@@ -22,7 +22,7 @@ def _chk(t, name, dtype=None):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
-def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None):
+def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None, relu=True):
     """frames (N,3,H,W) uint8 -> (N,Ho,Wo,32).  crop = (top,left,h,w) or None."""
     _chk(frames_u8, "frames", torch.uint8)
     N, _, H, W = frames_u8.shape
@@ -31,7 +31,7 @@ def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None)
     if out is None:
         out = torch.empty((N, Ho, Wo, 32), dtype=act_dtype, device=frames_u8.device)
     call("tdeed_stem_fwd", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(w), ptr(scale), ptr(shift),
-         ptr(out), dtype_code(act_dtype), stream_ptr())
+         ptr(out), int(relu), dtype_code(act_dtype), stream_ptr())
     return out
 
 

@@ -234,3 +234,22 @@ def gsf_add_cols(a, b, dx, Fp):
     M = dx.numel() // C
     call("tdeed_gsf_add_cols", ptr(a), ptr(b), M, C, Fp, ptr(dx), dtype_code(dx.dtype), stream_ptr())
     return dx
+
+
+def avgpool_posenc_bwd(d_feat, hw):
+    """d_feat (B,T,C) -> dx (B*T, hw, C) in d_feat's dtype, d_temp_enc (T,C) fp32"""
+    Bn, T, C = d_feat.shape
+    dx = torch.empty((Bn * T, hw, C), dtype=d_feat.dtype, device=d_feat.device)
+    d_enc = _f32((T, C), d_feat.device)
+    call("tdeed_avgpool_posenc_bwd", ptr(d_feat), Bn, T, hw, C, ptr(dx), ptr(d_enc), dtype_code(d_feat.dtype), stream_ptr())
+    return dx, d_enc
+
+
+def stem_wgrad(frames_u8, dz, crop=None, flip=False):
+    """frames (N,3,H,W) uint8, dz (N,Ho,Wo,32) -> dw (32,3,3,3) fp32"""
+    N, _, H, W = frames_u8.shape
+    top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
+    part, dw = _f32((N, 864), dz.device), _f32((32, 3, 3, 3), dz.device)
+    call("tdeed_stem_wgrad", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(dz), ptr(part), ptr(dw),
+         dtype_code(dz.dtype), stream_ptr())
+    return dw

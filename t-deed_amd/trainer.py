@@ -1,0 +1,99 @@
+"""One optimisation step of T-DEED on the HIP kernels: train-mode forward, loss, backward and fused AdamW, the
+counterpart of the training branch of `TDEEDModel.epoch` (/root/reference/model/model.py:193-263) and
+`BaseRGBModel.step` / `get_optimizer` (model/modules.py:37-39, 390-404) with the LR schedule of
+train_tdeed.py:79-87.
+
+    uint8 clip (B,T,3,H,W) --crop/flip/standardise + stem conv--> BN(batch stats)+ReLU --> 13/14 bottlenecks
+    (trunk_train.py; gate-shift on s3/s4) --> avg-pool + temp_enc --> SGP encoder-decoder + heads + loss
+    (temporal_train.py) --> the same chain backwards --> gradients in ONE flat fp32 buffer --> AdamW in one launch.
+
+This is the first complete version: every numeric step is a HIP kernel behind the C ABI and parity-tested against torch
+autograd on the CPU oracle, but the step is not yet captured in a HIP graph nor tuned (per-launch temporaries come from
+torch's caching allocator; the grouped-conv and gate-shift backward kernels are plain gather kernels)."""
+import torch
+
+from . import ops, ops_bwd as B_
+from .optim import FlatParams, FusedAdamW, warmup_cosine_lr
+from .regnet_spec import regnet_spec
+from .temporal_train import TemporalStack
+from .trunk_train import BottleneckTrain, BN_EPS
+
+
+class TrainEngine:
+    """state: name -> tensor (reference state_dict names; fp32 parameters, BN buffers).  The parameters are moved into one
+    flat buffer (`FlatParams`), `state` afterwards holds views into it."""
+
+    def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", lr=1e-3, weight_decay=0.01):
+        self.cfg, self.dt, self.device = dict(cfg), act_dtype, device
+        self.state = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)).to(device) for k, v in state.items()}
+        self.params = FlatParams(self.state, device)
+        self.opt = FusedAdamW(self.params, lr, weight_decay=weight_decay)
+        self.spec = regnet_spec(cfg["feature_arch"])
+        self.T = cfg["clip_len"]
+        sd = self.state
+        self.blocks = [BottleneckTrain(sd, "_features." + b.name, b, act_dtype, clip_len=self.T) for b in self.spec.blocks]
+        self.temporal = TemporalStack(sd, self.cfg, act_dtype)
+        self.one32 = torch.ones(32, device=device)
+        self.zero32 = torch.zeros(32, device=device)
+        self.sched_step = 0
+
+    # ------------------------------------------------------------------ forward + backward
+    def loss_and_grads(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None,
+                       fg_weight=5.0):
+        """frames (B,T,3,H,W) uint8 on the device; label int64 (B,T) or None with soft (B,T,K+1); labelD float (B,T).
+        crop = (top, left, h, w) (the one random crop the reference shares across B and T, model.py:115) or None.
+        Returns (loss[3] = total, ce, mse ; grads dict name -> fp32 tensor)."""
+        sd, dt = self.state, self.dt
+        Bn, T = frames_u8.shape[:2]
+        fr = frames_u8.reshape(Bn * T, *frames_u8.shape[2:])
+        z0 = ops.stem(fr, sd["_features.stem.conv.weight"], self.one32, self.zero32, dt, crop=crop, flip=flip, relu=False)
+        y0, bn0 = B_.bn_train(z0, sd["_features.stem.bn.weight"], sd["_features.stem.bn.bias"], BN_EPS, 0.1,
+                              sd["_features.stem.bn.running_mean"], sd["_features.stem.bn.running_var"], relu=True)
+        x = y0
+        for blk in self.blocks:
+            x = blk.forward(x)
+        hw = x.shape[1] * x.shape[2]
+        feat = ops.avgpool_posenc(x, Bn, T, sd["temp_enc"])
+        loss, grads, d_feat = self.temporal.loss_and_grads(
+            feat, None if label is None else label.reshape(-1), labelD=None if labelD is None else labelD.reshape(-1).float(),
+            soft=None if soft is None else soft.reshape(-1, soft.shape[-1]).contiguous(), drop_masks=drop_masks,
+            fg_weight=fg_weight)
+        dx, d_enc = B_.avgpool_posenc_bwd(d_feat, hw)
+        grads["temp_enc"] = d_enc
+        dx = dx.view(x.shape)
+        for blk in reversed(self.blocks):
+            dx = blk.backward(dx, grads)
+        dz0, _, dw, db = B_.bn_train_bwd(z0, dx, y0, bn0, sd["_features.stem.bn.weight"], relu=True)
+        grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
+        grads["_features.stem.conv.weight"] = B_.stem_wgrad(fr, dz0, crop=crop, flip=flip)
+        for k in sd:                                             # BatchNorm step counters (nn.BatchNorm.num_batches_tracked)
+            if k.endswith("num_batches_tracked"):
+                sd[k] += 1
+        return loss, grads
+
+    def repack(self):
+        for blk in self.blocks:
+            blk.repack()
+        self.temporal.repack()
+
+    # ------------------------------------------------------------------ one optimiser step
+    def step(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, lr_factor=1.0,
+             all_reduce=None):
+        """forward + backward + AdamW.  all_reduce: optional callable(flat_grad) for data-parallel jobs
+        (dist.all_reduce_mean_).  Returns the loss tensor [total, ce, mse]."""
+        loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks)
+        missing = set(self.params.index) - set(grads)
+        if missing:
+            raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
+        for k, g in grads.items():
+            self.params.grad_view(k).copy_(g.reshape(-1))
+        if all_reduce is not None:
+            all_reduce(self.params.grad)
+        self.opt.step(lr_factor=lr_factor)
+        self.repack()
+        return loss
+
+    def lr_factor(self, warmup_steps, cosine_steps):
+        f = warmup_cosine_lr(self.sched_step, warmup_steps, cosine_steps)
+        self.sched_step += 1
+        return f

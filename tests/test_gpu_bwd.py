@@ -422,3 +422,87 @@ def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
         ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sorted(want)])
         gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sorted(want)])
         assert float((ga - gr).norm() / gr.norm()) < 0.1
+
+
+def _oracle_train_loss(frames, sd, cfg, spec, lab, labD, masks, crop, flip):
+    """the training-branch forward of TDEEDModel on the CPU oracle (batch-stat BN, dropout masks, one shared crop)"""
+    x = frames.float() / 255.0
+    if crop is not None:
+        top, left, ch, cw = crop
+        x = x[..., top:top + ch, left:left + cw]
+    if flip:
+        x = x.flip(-1)
+    mean = torch.tensor(O.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(O.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    x = (x - mean) / std
+    B, T = x.shape[:2]
+    f = O.regnet_features(x.reshape(B * T, *x.shape[2:]), sd, spec, T, "gsf", training=True)
+    f = f.reshape(B, T, -1) + sd["temp_enc"][None]
+    enc = O.ed_sgp_mixer(f, sd, cfg["n_layers"], cfg["clip_len"])
+    dm = None if masks is None else (masks[1], masks[0])
+    cls, displ = O.heads(enc, sd, cfg["radi_displacement"], drop_mask=dm)
+    return O.loss_fn(cls, lab, displ, labD)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_train_step_matches_torch(dtype):
+    """One whole optimisation step (uint8 clip -> loss -> every gradient -> AdamW) of a small RegNetY-200MF+GSF+SGP model
+    against autograd + torch.optim.AdamW on the CPU oracle."""
+    from tdeed_amd import synth, state_layout
+    from tdeed_amd.regnet_spec import regnet_spec
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny002_gsf", clip_len=6, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, cfg["clip_len"], 72, 80
+    crop, flip = (4, 8, 64, 64), False
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 7).items()}
+    frames = t(synth.uint8_clip(301, (B, T, 3, H, W)))
+    lab_np, labD_np = synth.labels(302, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long(), t(labD_np).float()
+    C = regnet_spec(cfg["feature_arch"]).feat_dim
+    masks = [(rnd(303 + i, "m", (B, T, C)) > 0).float() * 2.0 for i in range(2)]
+    # ---- reference
+    par = [k for k in sd0 if state_layout.is_parameter(k)]
+    sdr = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
+    ref_loss = _oracle_train_loss(frames, sdr, cfg, regnet_spec(cfg["feature_arch"]), lab, labD, masks, crop, flip)
+    ref_loss.backward()
+    opt = torch.optim.AdamW([sdr[k] for k in par], lr=1e-3)
+    ref_grads = {k: sdr[k].grad.clone() for k in par}
+    opt.step()
+    # ---- device
+    eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dtype, lr=1e-3)
+    loss, grads = eng.loss_and_grads(frames.to(DEV), lab.to(DEV), labD.to(DEV), crop=crop, flip=flip,
+                                     drop_masks=[m.to(dtype).to(DEV) for m in masks])
+    assert set(grads) == set(par), set(grads) ^ set(par)
+    lt = 2e-4 if dtype == torch.float32 else 5e-2
+    assert abs(float(loss[0]) - float(ref_loss.detach())) < lt * max(1.0, abs(float(ref_loss.detach())))
+    ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in par])
+    gr = torch.cat([ref_grads[k].double().reshape(-1) for k in par])
+    gerr = float((ga - gr).norm() / gr.norm())
+    if dtype == torch.float32:
+        assert gerr < 2e-3, gerr
+        # per tensor: within 2 % of its own norm, plus a floor of 1e-4 of the whole gradient for near-zero tensors
+        # (single-scalar biases that are sums with heavy cancellation)
+        gn = float(gr.norm())
+        for k in par:
+            d = float((grads[k].detach().cpu().double() - ref_grads[k].double()).norm())
+            assert d <= 2e-2 * float(ref_grads[k].double().norm()) + 1e-4 * gn, (k, d, float(ref_grads[k].norm()))
+    else:
+        # bf16 maps through 13 bottlenecks whose BatchNorms see only B*T*h*w = 48..3k samples at this toy size: the
+        # direction of the gradient is what can be asserted
+        cos = float((ga * gr).sum() / (ga.norm() * gr.norm()))
+        assert gerr < 0.45 and cos > 0.9, (gerr, cos)
+    if dtype == torch.float32:
+        # the optimiser: same step on both sides (re-run the step through the engine's own path)
+        eng2 = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dtype, lr=1e-3)
+        eng2.step(frames.to(DEV), lab.to(DEV), labD.to(DEV), crop=crop, flip=flip,
+                  drop_masks=[m.to(dtype).to(DEV) for m in masks])
+        # the first Adam step moves every entry by ~lr * sign(g): compare where the sign of g is not in the noise
+        for k in par:
+            gref = ref_grads[k]
+            sel = gref.abs() > 5e-2 * gref.abs().max()
+            got, want_ = eng2.state[k].detach().cpu()[sel], sdr[k].detach()[sel]
+            assert float((got - want_).abs().max()) < 2e-5 + 1e-4 * float(want_.abs().max()), k
+            assert float((eng2.state[k].detach().cpu() - sd0[k]).abs().max()) < 1.2e-3     # |update| <= lr (+ decay)
+        nbt = [k for k in sd0 if k.endswith("num_batches_tracked")]
+        assert all(int(eng2.state[k]) == int(sd0[k]) + 1 for k in nbt)
