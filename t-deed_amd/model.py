@@ -157,10 +157,20 @@ class TDEEDModel:
         self._model.to(device)
         self._num_classes = args.num_classes + 1
         self._stream = None
+        self._train_dtype = torch.bfloat16          # the reference trains under autocast; fp32 for parity runs
 
     # BaseRGBModel (modules.py:35-55)
     def get_optimizer(self, opt_args):
-        raise NotImplementedError("optimizer / train step: next milestone (backward kernels + fused AdamW)")
+        """modules.py:37-39: AdamW over all parameters (+ a GradScaler in the reference; bf16 needs none -> None).
+        The returned optimizer is a torch.optim.Optimizer over the model's single flat parameter buffer whose step() is
+        the fused AdamW kernel, so torch LR schedulers work on it unchanged."""
+        from .trainer import TrainEngine, HipAdamW
+        if self._model._double_head:
+            raise NotImplementedError("training with the joint-dataset double head is not built yet")
+        eng = TrainEngine(self._model._cfg, self._model._state, act_dtype=self._train_dtype, device=self.device,
+                          lr=opt_args.get("lr", 1e-3))
+        self._model._engines = {}
+        return HipAdamW(eng, **opt_args), None
 
     def _get_params(self):
         return list(self._model.parameters())
@@ -203,10 +213,9 @@ class TDEEDModel:
 
     def epoch(self, loader, optimizer=None, scaler=None, lr_scheduler=None, acc_grad_iter=1, fg_weight=5,
               valMAP=False):
-        """model.py:193-332.  Validation pass (optimizer None) runs on the HIP path; the training
-        branch needs the backward kernels (next milestone)."""
+        """model.py:193-332: validation pass (optimizer None) or one training epoch (optimizer from get_optimizer)."""
         if optimizer is not None:
-            raise NotImplementedError("training epoch: backward kernels + fused AdamW are the next milestone")
+            return self._train_epoch(loader, optimizer, lr_scheduler, acc_grad_iter, fg_weight)
         self._model.eval()
         K1 = self._num_classes
         w = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32, device=self.device)
@@ -238,6 +247,53 @@ class TDEEDModel:
         if valMAP:
             return avg, torch.cat(map_labels, 0), torch.cat(map_preds, 0)
         return avg
+
+
+def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_weight):
+    """Training branch of model.py:193-332 + BaseRGBModel.step (modules.py:390-404).  One random crop per batch shared
+    by all clips and frames (model.py:115), dropout masks from the device RNG, gradient accumulation over
+    `acc_grad_iter` batches.  Not built yet: mixup batches ('frame2'), the host-side torchvision augmentations of
+    model.py:77-84 (ColorJitter / GaussianBlur), the double head."""
+    import random
+    eng = optimizer.engine
+    self._model.train()
+    optimizer.zero_grad()
+    C = self._model._feat_dim
+    n_heads = 2 if self._model._radi_displacement > 0 else 1
+    crop_dim = self._model._cfg.get("crop_dim")
+    total = torch.zeros((), dtype=torch.float32, device=self.device)
+    n = 0
+    with self._ctx():
+        for batch_idx, batch in enumerate(loader):
+            if "frame2" in batch:
+                raise NotImplementedError("mixup batches (frame2/label2) need the float-frame stem; not built yet")
+            frame = batch["frame"].to(self.device)
+            if frame.dtype != torch.uint8:
+                frame = frame.round().clamp_(0, 255).to(torch.uint8)
+            label = batch["label"].to(self.device)
+            labelD = batch["labelD"].to(self.device).float() if "labelD" in batch else None
+            B, T, _, H, W = frame.shape
+            crop = None
+            if crop_dim:
+                top, left = random.randint(0, H - crop_dim), random.randint(0, W - crop_dim)
+                crop = (top, left, crop_dim, crop_dim)
+            masks = [((torch.rand((B, T, C), device=self.device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
+            first = batch_idx % acc_grad_iter == 0
+            loss = eng.accumulate(frame.contiguous(), label, labelD, crop=crop, drop_masks=masks,
+                                  scale=1.0 / acc_grad_iter, first=first)
+            if (batch_idx + 1) % acc_grad_iter == 0:
+                optimizer.step()
+                if lr_scheduler is not None:
+                    lr_scheduler.step()
+                optimizer.zero_grad()
+            total += loss[0]
+            n += 1
+        self._stream.synchronize()
+    self._model._engines = {}                      # the inference engines hold packed copies of the old weights
+    return float(total.item()) / max(n, 1)
+
+
+TDEEDModel._train_epoch = _train_epoch_impl
 
 
 def update_labels_2heads(labels, datasets, num_classes1=1):

@@ -25,7 +25,10 @@ class TrainEngine:
 
     def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", lr=1e-3, weight_decay=0.01):
         self.cfg, self.dt, self.device = dict(cfg), act_dtype, device
-        self.state = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)).to(device) for k, v in state.items()}
+        for k in list(state):                                    # in place: the caller's dict ends up holding the views
+            v = state[k]
+            state[k] = (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)).to(device)
+        self.state = state
         self.params = FlatParams(self.state, device)
         self.opt = FusedAdamW(self.params, lr, weight_decay=weight_decay)
         self.spec = regnet_spec(cfg["feature_arch"])
@@ -77,23 +80,63 @@ class TrainEngine:
         self.temporal.repack()
 
     # ------------------------------------------------------------------ one optimiser step
-    def step(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, lr_factor=1.0,
-             all_reduce=None):
-        """forward + backward + AdamW.  all_reduce: optional callable(flat_grad) for data-parallel jobs
-        (dist.all_reduce_mean_).  Returns the loss tensor [total, ce, mse]."""
+    def accumulate(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, scale=1.0,
+                   first=True):
+        """forward + backward of one (micro-)batch; its gradients (times `scale`) go into the flat gradient buffer
+        (overwriting it when `first`, adding otherwise: `acc_grad_iter` of the reference's step())."""
         loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks)
         missing = set(self.params.index) - set(grads)
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
         for k, g in grads.items():
-            self.params.grad_view(k).copy_(g.reshape(-1))
+            dst = self.params.grad_view(k)
+            if first:
+                dst.copy_(g.reshape(-1))
+                if scale != 1.0:
+                    dst.mul_(scale)
+            else:
+                dst.add_(g.reshape(-1), alpha=scale)
+        return loss
+
+    def apply(self, lr=None, lr_factor=1.0, all_reduce=None):
+        """AdamW on the accumulated gradients (one launch), then refresh the kernels' views of the weights."""
         if all_reduce is not None:
             all_reduce(self.params.grad)
+        if lr is not None:
+            self.opt.lr = lr
         self.opt.step(lr_factor=lr_factor)
         self.repack()
+
+    def step(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, lr_factor=1.0,
+             all_reduce=None):
+        """forward + backward + AdamW.  all_reduce: optional callable(flat_grad) for data-parallel jobs
+        (dist.all_reduce_mean_).  Returns the loss tensor [total, ce, mse]."""
+        loss = self.accumulate(frames_u8, label, labelD, soft, crop, flip, drop_masks)
+        self.apply(lr_factor=lr_factor, all_reduce=all_reduce)
         return loss
 
     def lr_factor(self, warmup_steps, cosine_steps):
         f = warmup_cosine_lr(self.sched_step, warmup_steps, cosine_steps)
         self.sched_step += 1
         return f
+
+
+class HipAdamW(torch.optim.Optimizer):
+    """What `TDEEDModel.get_optimizer` returns: a torch.optim.Optimizer whose single "parameter" is the flat fp32
+    buffer and whose step() is the fused AdamW launch, so the reference's LR schedulers (LinearLR + CosineAnnealingLR
+    chained, train_tdeed.py:79-87) drive it unchanged through param_groups[0]['lr']."""
+
+    def __init__(self, engine: TrainEngine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.engine = engine
+        engine.opt.lr, engine.opt.betas, engine.opt.eps, engine.opt.wd = lr, betas, eps, weight_decay
+        super().__init__([engine.params.flat], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def zero_grad(self, set_to_none=False):
+        self.engine.opt.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None, all_reduce=None):
+        g = self.param_groups[0]
+        o = self.engine.opt
+        o.betas, o.eps, o.wd = g["betas"], g["eps"], g["weight_decay"]
+        self.engine.apply(lr=g["lr"], all_reduce=all_reduce)

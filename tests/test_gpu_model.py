@@ -169,8 +169,42 @@ def test_model_api_predict_and_epoch():
     loss = m.epoch(loader)
     ref = float(O.loss_fn(t(g["logits"]), t(lab), t(g["displ"]), t(labD)))
     assert abs(loss - ref) < 0.05 * max(1.0, abs(ref))      # bf16 forward
-    with pytest.raises(NotImplementedError):
-        m.epoch(loader, optimizer=object())
+
+
+def test_model_api_training_epochs_reduce_the_loss():
+    """The reference's training loop against the drop-in API: get_optimizer -> torch LR schedulers (LinearLR + cosine,
+    train_tdeed.py:79-87) -> epoch(loader, optimizer, scaler, lr_scheduler, acc_grad_iter).  Over-fitting one small
+    batch must drive the loss down, BN running statistics must move, validation must see the updated weights."""
+    from tdeed_amd.model import TDEEDModel
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    m = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    m.load({k: t(v) for k, v in model_state(cfg, meta["seed_w"]).items()})
+    clip = synth.uint8_clip(meta["seed_x"], (meta["B"], cfg["clip_len"], 3, meta["H"], meta["W"]))
+    lab, labD = synth.labels(3, meta["B"], cfg["clip_len"], cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
+    loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD))] * 2
+    val0 = m.epoch(loader[:1])
+    rm0 = m.state_dict()["_features.s2.b1.conv2.bn.running_mean"].clone()
+    optimizer, scaler = m.get_optimizer({"lr": 3e-4})
+    assert scaler is None and isinstance(optimizer, torch.optim.Optimizer)
+    steps = 40
+    sched = torch.optim.lr_scheduler.ChainedScheduler([
+        torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=0.01, end_factor=1.0, total_iters=4),
+        torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, steps)])
+    losses = [m.epoch(loader, optimizer=optimizer, scaler=scaler, lr_scheduler=sched, acc_grad_iter=1) for _ in range(steps // 2)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < 0.5 * losses[0], losses
+    assert optimizer.param_groups[0]["lr"] < 3e-4                     # the schedulers drove the fused optimizer's lr
+    sd = m.state_dict()
+    assert not torch.equal(sd["_features.s2.b1.conv2.bn.running_mean"], rm0)
+    assert int(sd["_features.stem.bn.num_batches_tracked"]) == steps
+    val1 = m.epoch(loader[:1])                                         # eval-mode forward with the trained weights
+    assert np.isfinite(val1) and val1 != val0
+    # gradient accumulation: two half-weighted micro-batches == one batch (same data) up to rounding
+    m2 = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    m2.load({k: t(v) for k, v in model_state(cfg, meta["seed_w"]).items()})
+    opt2, _ = m2.get_optimizer({"lr": 1e-3})
+    assert np.isfinite(m2.epoch(loader, optimizer=opt2, acc_grad_iter=2))
+    assert int(m2.state_dict()["_features.stem.bn.num_batches_tracked"]) == 2 and opt2.engine.opt.t == 1
 
 
 def test_fused_adamw_on_flat_model_params_matches_torch():
