@@ -3,6 +3,7 @@
 // Parameter gradients are produced as per-workgroup partials and folded by reduce_partials in a fixed order, so a
 // training step is bit-reproducible (no float atomics anywhere).
 #include "common.h"
+#include <cstdlib>
 #include "sgp_tile.h"
 
 // =========================================================================== small generic pieces
@@ -163,6 +164,87 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dY, lo
     part_b[(long)z * N + n0 + threadIdx.x] = bsum;
 }
 
+// bf16 form on the MFMA pipe.  The contraction runs over the ROWS of both operands, so a 32-row chunk is transposed on
+// its way into LDS (sT[col][row], row stride 36 elements: 8-byte aligned fragment reads, column groups on different
+// banks); a fragment is then 8 consecutive rows of one column.  dY^T is the MFMA A operand, X^T the B operand:
+// D[n][k], lanes of a wave hold consecutive k => coalesced partial stores.  The next chunk's global loads are issued
+// before the MFMAs of the current one.
+constexpr int WG_LD = 36;
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restrict__ dY, long ldy,
+                                                         const bf16_t* __restrict__ X, long ldx, int M, int N, int K,
+                                                         float* __restrict__ part_w, float* __restrict__ part_b) {
+  __shared__ __attribute__((aligned(16))) bf16_t sTy[64 * WG_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sTx[64 * WG_LD];
+  __shared__ float sb[32][65];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, z = blockIdx.z, Z = gridDim.z;
+  const int mper = ((M + Z - 1) / Z + 31) / 32 * 32;
+  const int m_begin = z * mper, m_end = min(M, m_begin + mper);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  const int r = tid >> 3, c8 = (tid & 7) * 8;
+  const bool nok = n0 + c8 < N, kok = k0 + c8 < K;
+  const bool want_b = part_b && blockIdx.y == 0;
+  f32x4 acc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long ycol = min(n0 + c8, N - 8), xcol = min(k0 + c8, K - 8);
+  u32x4 vy, vx;
+  auto issue = [&](int m0) {
+    const long row = min(m0 + r, M - 1);
+    vy = *reinterpret_cast<const u32x4*>(dY + row * ldy + ycol);
+    vx = *reinterpret_cast<const u32x4*>(X + row * ldx + xcol);
+  };
+  if (m_begin < m_end) issue(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+    const bool rok = m0 + r < m_end;
+    const bf16x8 ty = *reinterpret_cast<const bf16x8*>(&vy);
+    const bf16x8 tx = *reinterpret_cast<const bf16x8*>(&vx);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bf16_t a = (rok && nok) ? ty[e] : (bf16_t)0.f;
+      sTy[(c8 + e) * WG_LD + r] = a;
+      sTx[(c8 + e) * WG_LD + r] = (rok && kok) ? tx[e] : (bf16_t)0.f;
+      if (want_b) bsum[e] += (float)a;
+    }
+    __syncthreads();
+    if (m0 + 32 < m_end) issue(m0 + 32);
+    bf16x8 af;
+    {
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(sTy + (wv * 16 + pl) * WG_LD + q * 8);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(sTy + (wv * 16 + pl) * WG_LD + q * 8 + 4);
+      af = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(sTx + (kt * 16 + pl) * WG_LD + q * 8);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(sTx + (kt * 16 + pl) * WG_LD + q * 8 + 4);
+      const bf16x8 bfr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[kt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int k = k0 + kt * 16 + pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + wv * 16 + 4 * q + e;
+      if (n < N && k < K) part_w[((long)z * N + n) * K + k] = acc[kt][e];
+    }
+  }
+  if (want_b) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sb[r][c8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) {
+      float a = 0.f;
+      for (int rr = 0; rr < 32; ++rr) a += sb[rr][tid];
+      part_b[(long)z * N + n0 + tid] = a;
+    }
+  }
+}
+
 extern "C" int tdeed_wgrad_slices(int M) { int z = (M + 2047) / 2048; return z < 1 ? 1 : (z > 128 ? 128 : z); }
 
 // part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M); dW [N][K], db [N] (fp32)
@@ -176,9 +258,15 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, in
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, M, N, K,
                        part_w, db ? part_b : nullptr);
-  else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N,
-                       K, part_w, db ? part_b : nullptr);
+  else if (dtype == TDEED_BF16) {
+    static const bool valu = getenv("TDEED_WGRAD_VALU") && atoi(getenv("TDEED_WGRAD_VALU")) == 1;
+    if (!valu && N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0)
+      hipLaunchKernelGGL(wgrad_mfma_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
+                         part_w, db ? part_b : nullptr);
+    else
+      hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N,
+                         K, part_w, db ? part_b : nullptr);
+  }
   else { tdeed_set_error("wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("wgrad");
   int rc = tdeed_reduce_partials(part_w, Z, (long)N * K, dW, accumulate, stream);

@@ -9,7 +9,8 @@
 //   mode 0 (BN forward):  v = z,             u = z                      -> sum, sum of squares
 //   mode 1 (BN backward): v = g,             u = (z - mean) * rstd      -> sum g, sum g * xhat,
 //                         g = dy masked by y > 0 when a ReLU follows the BN (relu = 1)
-// lanes = (row lane, channel chunk); every lane keeps 4 loads in flight.
+// lanes = (row lane, channel chunk); every lane keeps CS_B row loads (x up to 3 tensors) in flight.
+constexpr int CS_B = 6;
 template <typename T>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, const T* __restrict__ dy,
                                                        const T* __restrict__ y, long M, int C, int mode, int relu,
@@ -29,17 +30,17 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
       mu[e] = mode ? mean[c0 + e] : 0.f;
       rs[e] = mode ? rstd[c0 + e] : 0.f;
     }
-    for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * 4) {
-      float zv[4][EPC], gv[4][EPC], yv[4][EPC];
+    for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * CS_B) {
+      float zv[CS_B][EPC], gv[CS_B][EPC], yv[CS_B][EPC];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < CS_B; ++b) {
         const long r = min(r0 + (long)b * RL, m1 - 1);
         Chunk<T>::load(z + r * C + c0, zv[b]);
         if (mode) Chunk<T>::load(dy + r * C + c0, gv[b]);
         if (mode && relu) Chunk<T>::load(y + r * C + c0, yv[b]);
       }
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < CS_B; ++b)
         if (r0 + (long)b * RL < m1) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
@@ -76,13 +77,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rstd, float* __restrict__ a,
                                                           float* __restrict__ b, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;                                    // a few hundred partials per channel: fold in double
-  for (int p = 0; p < P; ++p) {
+  // one workgroup per channel: the P slab partials are folded in double (lane-strided, then a fixed-order tree)
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = threadIdx.x; p < P; p += 256) {
     s1 += (double)part[((long)p * 2 + 0) * C + c];
     s2 += (double)part[((long)p * 2 + 1) * C + c];
   }
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+      r2[threadIdx.x] += r2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  s1 = r1[0];
+  s2 = r2[0];
   const double mu = s1 / (double)M;
   double var = s2 / (double)M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -99,8 +114,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 static int colstats_slabs(long M, long* rows_per_slab) {
-  long slabs = (M + 2047) / 2048;
-  if (slabs > 1024) slabs = 1024;
+  long slabs = (M + 511) / 512;
+  if (slabs > 4096) slabs = 4096;
   if (slabs < 1) slabs = 1;
   *rows_per_slab = (M + slabs - 1) / slabs;
   return (int)((M + *rows_per_slab - 1) / *rows_per_slab);
@@ -133,7 +148,7 @@ extern "C" int tdeed_bn_train_stats(const void* z, long M, int C, const float* w
   else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, part, st);
   else { tdeed_set_error("bn_train_stats: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("bn colstats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, slabs, M, C, w, bias, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, slabs, M, C, w, bias, eps, momentum,
                      mean, rstd, a, b, run_mean, run_var);
   TD_LAUNCH_CHECK("bn_finalize");
   return TDEED_OK;
