@@ -262,8 +262,8 @@ int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int 
 /* [R][Cc] -> [Cc][R] (weight transposes for the input-gradient contractions) */
 int tdeed_transpose(const void* x, int R, int Cc, void* y, int dtype, void* stream);
 /* weight / bias gradient of a Conv1d(k=1) / 1x1 conv: dW[n][k] (+)= sum_m dY[m][n] X[m][k], db[n] (+)= sum_m dY[m][n]
- * (db may be NULL).  part_w fp32 [Z][N][K], part_b fp32 [Z][N], Z = tdeed_wgrad_slices(M). */
-int tdeed_wgrad_slices(int M);
+ * (db may be NULL).  part_w fp32 [Z][N][K], part_b fp32 [Z][N], Z = tdeed_wgrad_slices(M, N, K). */
+int tdeed_wgrad_slices(int M, int N, int K);
 int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w, float* part_b,
                 float* dW, float* db, int accumulate, int dtype, void* stream);
 /* channel LayerNorm backward (modules.py:320-363): dx (+)= d/dx, dw/db [C].  part fp32 [tdeed_layernorm_bwd_blocks(rows)][2][C] */
@@ -327,7 +327,8 @@ int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int wi, int C, 
 /* avgpool + positional encoding backward: d x[f][p][c] = d feat[f][c]/hw, d temp_enc[t][c] = sum_b d feat[b][t][c] */
 int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw, int C, void* dx, float* d_temp_enc, int dtype,
                              void* stream);
-/* stem weight gradient (the uint8 input needs none): dz [N][Ho][Wo][32] -> dw [32][3][3][3]; part fp32 [N][864] */
+/* stem weight gradient (the uint8 input needs none): dz [N][Ho][Wo][32] -> dw [32][3][3][3]; part fp32
+ * [N * ceil(Ho/16)][864] */
 int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h, int crop_w,
                      int flip, const void* dz, float* part, float* dw, int dtype, void* stream);
 

@@ -245,14 +245,22 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restric
   }
 }
 
-extern "C" int tdeed_wgrad_slices(int M) { int z = (M + 2047) / 2048; return z < 1 ? 1 : (z > 128 ? 128 : z); }
+// number of M slices: enough workgroups to fill the chip (~1024) without slices shorter than 64 rows
+extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
+  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  long z = (1024 + tiles - 1) / tiles;
+  const long zmax = (M + 63) / 64;
+  if (z > zmax) z = zmax;
+  if (z > 128) z = 128;
+  return (int)(z < 1 ? 1 : z);
+}
 
-// part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M); dW [N][K], db [N] (fp32)
+// part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M, N, K); dW [N][K], db [N] (fp32)
 extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w,
                            float* part_b, float* dW, float* db, int accumulate, int dtype, void* stream) {
   TD_CHECK(dY && X && part_w && dW && (!db || part_b), "wgrad: null pointer");
   TD_CHECK(M > 0 && N > 0 && K > 0, "wgrad: bad sizes");
-  const int Z = tdeed_wgrad_slices(M);
+  const int Z = tdeed_wgrad_slices(M, N, K);
   dim3 grid(cdiv(N, 64), cdiv(K, 64), Z);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)

@@ -690,7 +690,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
   const uint8_t* src = frames + (long)n * 3 * H * W;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};                           // outputs o = tid + 256*i < 864
-  for (int oy0 = 0; oy0 < Ho; oy0 += 16)
+  {
+    const int oy0 = blockIdx.y * 16;                            // one row of 16x16 tiles per workgroup
     for (int ox0 = 0; ox0 < Wo; ox0 += 16) {
       const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
       __syncthreads();
@@ -725,14 +726,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
         }
       }
     }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int o = threadIdx.x + 256 * i;
-    if (o < 864) part[(long)n * 864 + o] = acc[i];
+    if (o < 864) part[((long)n * gridDim.y + blockIdx.y) * 864 + o] = acc[i];
   }
 }
 
-// dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N][864]
+// dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N*ceil(Ho/16)][864]
 extern "C" int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h,
                                 int crop_w, int flip, const void* dz, float* part, float* dw, int dtype, void* stream) {
   TD_CHECK(frames && dz && part && dw, "stem_wgrad: null pointer");
@@ -741,12 +743,12 @@ extern "C" int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int 
   const int Ho = (crop_h + 1) / 2, Wo = (crop_w + 1) / 2;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(N), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h, crop_w,
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h, crop_w,
                        flip, (const float*)dz, Ho, Wo, part);
   else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(N), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
+    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
                        crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
   else { tdeed_set_error("stem_wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("stem_wgrad");
-  return tdeed_reduce_partials(part, N, 864, dw, 0, stream);
+  return tdeed_reduce_partials(part, N * cdiv(Ho, 16), 864, dw, 0, stream);
 }

@@ -32,7 +32,7 @@ def wgrad(dY, X, with_bias=True, dW=None, db=None, accumulate=False, M=None):
     """dW[n][k] = sum_m dY[m][n] X[m][k]; db[n] = sum_m dY[m][n].  dY (M,N), X (M,K) in the activation dtype."""
     N, K = dY.shape[-1], X.shape[-1]
     M = dY.numel() // N if M is None else M
-    Z = _lib.load().tdeed_wgrad_slices(M)
+    Z = _lib.load().tdeed_wgrad_slices(M, N, K)
     dev = dY.device
     dW = _f32((N, K), dev) if dW is None else dW
     if with_bias and db is None:
@@ -249,7 +249,7 @@ def stem_wgrad(frames_u8, dz, crop=None, flip=False):
     """frames (N,3,H,W) uint8, dz (N,Ho,Wo,32) -> dw (32,3,3,3) fp32"""
     N, _, H, W = frames_u8.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
-    part, dw = _f32((N, 864), dz.device), _f32((32, 3, 3, 3), dz.device)
+    part, dw = _f32((N * ((dz.shape[1] + 15) // 16), 864), dz.device), _f32((32, 3, 3, 3), dz.device)
     call("tdeed_stem_wgrad", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(dz), ptr(part), ptr(dw),
          dtype_code(dz.dtype), stream_ptr())
     return dw
