@@ -35,7 +35,8 @@ int tdeed_device_info(int dev, char* name64, int* n_cu, int* is_gfx950);
  * normalize /255, crop, optional h-flip, ImageNet standardize (model.py:107-129,151-167) fused
  * into timm RegNet stem Conv3x3 s2 (3->32) + BN(eval, folded to scale/shift) + ReLU (model.py:133).
  * frames: uint8 [N][3][H][W] (NCHW as the loader delivers it); out: [N][Ho][Wo][32], Ho=(crop_h+1)/2. */
-int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
+int tdeed_stem_fwd(const void* frames /* uint8, or fp32 0..255 when frames_f32 (mixup batches) */, int frames_f32,
+                   int N, int H, int W, int crop_top, int crop_left,
                    int crop_h, int crop_w, int flip, const float* w /*[32][3][3][3]*/,
                    const float* scale /*[32]*/, const float* shift /*[32]*/, void* out,
                    int relu /* 0: raw conv*scale+shift (training) */, int dtype, void* stream);
@@ -329,8 +330,11 @@ int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw, int C, vo
                              void* stream);
 /* stem weight gradient (the uint8 input needs none): dz [N][Ho][Wo][32] -> dw [32][3][3][3]; part fp32
  * [N * ceil(Ho/16)][864] */
-int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h, int crop_w,
+int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h, int crop_w,
                      int flip, const void* dz, float* part, float* dw, int dtype, void* stream);
+
+/* mixup (model.py:240-256): out[b] = lam[b]*a[b] + (1-lam[b])*b[b], uint8 clips -> fp32 frames for tdeed_stem_fwd(frames_f32=1) */
+int tdeed_mix_frames(const uint8_t* a, const uint8_t* b, const float* lam, int B, long per_clip, float* out, void* stream);
 
 /* ---- gate-shift-fuse backward (gsf_bwd.hip; forward tensors as saved by tdeed_gsf_gate_fwd / tdeed_gsf_weight_fwd).
  * tdeed_gsf_slice: dense copy xs [M][Fp] of the module's channels (cols >= F zero): the BatchNorm3d operand in training.

@@ -29,9 +29,10 @@ P = c_void_p
 _SIGS = {
     "tdeed_abi_version": ([], c_int),
     "tdeed_device_info": ([c_int, c_char_p, POINTER(c_int), POINTER(c_int)], c_int),
-    "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_mix_frames": ([P, P, P, c_int, c_long, P, P], c_int),
     "tdeed_avgpool_posenc_bwd": ([P, c_int, c_int, c_int, c_int, P, P, c_int, P], c_int),
-    "tdeed_stem_wgrad": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_stem_wgrad": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_s1_front_parts": ([c_int, c_int, c_int], c_int),
     "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,
                             P, P, P, P, P, P, P], c_int),

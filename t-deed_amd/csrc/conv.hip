@@ -6,8 +6,9 @@
 
 // =========================================================================== stem
 // 16x16 output pixels per block; the 33x33x3 input patch is normalised once into LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ frames, int H, int W,
+// IN = uint8_t (the normal path: 1 byte/px in HBM) or float (mixup batches: l*frame + (1-l)*frame2 is not integral)
+template <typename T, typename IN>
+__global__ __launch_bounds__(256) void stem_kernel(const IN* __restrict__ frames, int H, int W,
                                                    int top, int left, int ch, int cw, int flip,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ scale,
@@ -19,7 +20,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ f
   const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
-  const uint8_t* src = frames + (long)n * 3 * H * W;
+  const IN* src = frames + (long)n * 3 * H * W;
   for (int i = threadIdx.x; i < 3 * 33 * 33; i += 256) {
     int c = i / (33 * 33);
     int r = i - c * 33 * 33;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ f
   }
 }
 
-extern "C" int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left,
+extern "C" int tdeed_stem_fwd(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
                               int crop_h, int crop_w, int flip, const float* w, const float* scale,
                               const float* shift, void* out, int relu, int dtype, void* stream) {
   TD_CHECK(frames && w && scale && shift && out, "stem: null pointer");
@@ -72,12 +73,12 @@ extern "C" int tdeed_stem_fwd(const uint8_t* frames, int N, int H, int W, int cr
   const int Ho = (crop_h + 1) / 2, Wo = (crop_w + 1) / 2;
   dim3 grid(cdiv(Wo, 16), cdiv(Ho, 16), N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
-                       crop_w, flip, w, scale, shift, (float*)out, Ho, Wo, relu);
-  else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
-                       crop_w, flip, w, scale, shift, (bf16_t*)out, Ho, Wo, relu);
+#define TD_STEM(TT, IN)                                                                                                \
+  hipLaunchKernelGGL((stem_kernel<TT, IN>), grid, dim3(256), 0, st, (const IN*)frames, H, W, crop_top, crop_left, crop_h, \
+                     crop_w, flip, w, scale, shift, (TT*)out, Ho, Wo, relu)
+  if (dtype == TDEED_F32) { if (frames_f32) TD_STEM(float, float); else TD_STEM(float, uint8_t); }
+  else if (dtype == TDEED_BF16) { if (frames_f32) TD_STEM(bf16_t, float); else TD_STEM(bf16_t, uint8_t); }
+#undef TD_STEM
   else { tdeed_set_error("stem: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("stem");
   return TDEED_OK;

@@ -679,8 +679,8 @@ extern "C" int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw
 // optionally flipped, /255 and ImageNet-standardised uint8 frame.  The input needs no gradient; the weight gradient is
 // dw[co][27] = sum_{n,oy,ox} dz * in.  One workgroup per frame walks its 16x16 output tiles (patch and dz tile in LDS,
 // lanes own (co, tap) pairs): part[n][32*27], folded by reduce_partials.
-template <typename T>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restrict__ frames, int H, int W, int top, int left,
+template <typename T, typename IN>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const IN* __restrict__ frames, int H, int W, int top, int left,
                                                          int ch, int cw, int flip, const T* __restrict__ dz, int Ho, int Wo,
                                                          float* __restrict__ part) {
   __shared__ float tile[3][33][34];
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
   const int n = blockIdx.x;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
-  const uint8_t* src = frames + (long)n * 3 * H * W;
+  const IN* src = frames + (long)n * 3 * H * W;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};                           // outputs o = tid + 256*i < 864
   {
     const int oy0 = blockIdx.y * 16;                            // one row of 16x16 tiles per workgroup
@@ -735,20 +735,45 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
 }
 
 // dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N*ceil(Ho/16)][864]
-extern "C" int tdeed_stem_wgrad(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h,
-                                int crop_w, int flip, const void* dz, float* part, float* dw, int dtype, void* stream) {
+extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
+                                int crop_h, int crop_w, int flip, const void* dz, float* part, float* dw, int dtype,
+                                void* stream) {
   TD_CHECK(frames && dz && part && dw, "stem_wgrad: null pointer");
   TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= H &&
                crop_left + crop_w <= W, "stem_wgrad: bad geometry");
   const int Ho = (crop_h + 1) / 2, Wo = (crop_w + 1) / 2;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h, crop_w,
-                       flip, (const float*)dz, Ho, Wo, part);
-  else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, frames, H, W, crop_top, crop_left, crop_h,
-                       crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
+#define TD_SWG(TT, IN)                                                                                                 \
+  hipLaunchKernelGGL((stem_wgrad_kernel<TT, IN>), dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const IN*)frames, H, W, crop_top, \
+                     crop_left, crop_h, crop_w, flip, (const TT*)dz, Ho, Wo, part)
+  if (dtype == TDEED_F32) { if (frames_f32) TD_SWG(float, float); else TD_SWG(float, uint8_t); }
+  else if (dtype == TDEED_BF16) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
+#undef TD_SWG
   else { tdeed_set_error("stem_wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("stem_wgrad");
   return tdeed_reduce_partials(part, N * cdiv(Ho, 16), 864, dw, 0, stream);
+}
+
+// =========================================================================== mixup of two uint8 clips
+// out[b][i] = lam[b] * a[b][i] + (1 - lam[b]) * b[b][i]   (model.py:246: frame[i] = l*frame[i] + (1-l)*frame2[i]), fp32 out
+__global__ __launch_bounds__(256) void mix_frames_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                         const float* __restrict__ lam, long per_clip, long total,
+                                                         float* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  const float l = lam[i / per_clip];
+  const uchar4 va = *reinterpret_cast<const uchar4*>(a + i), vb = *reinterpret_cast<const uchar4*>(b + i);
+  f32x4 o = {l * (float)va.x + (1.f - l) * (float)vb.x, l * (float)va.y + (1.f - l) * (float)vb.y,
+             l * (float)va.z + (1.f - l) * (float)vb.z, l * (float)va.w + (1.f - l) * (float)vb.w};
+  *reinterpret_cast<f32x4*>(out + i) = o;
+}
+
+extern "C" int tdeed_mix_frames(const uint8_t* a, const uint8_t* b, const float* lam, int B, long per_clip, float* out,
+                                void* stream) {
+  TD_CHECK(a && b && lam && out && B > 0 && per_clip > 0 && per_clip % 4 == 0, "mix_frames: bad arguments");
+  const long total = (long)B * per_clip;
+  hipLaunchKernelGGL(mix_frames_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     lam, per_clip, total, out);
+  TD_LAUNCH_CHECK("mix_frames");
+  return TDEED_OK;
 }

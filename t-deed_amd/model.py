@@ -252,8 +252,9 @@ class TDEEDModel:
 def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_weight):
     """Training branch of model.py:193-332 + BaseRGBModel.step (modules.py:390-404).  One random crop per batch shared
     by all clips and frames (model.py:115), dropout masks from the device RNG, gradient accumulation over
-    `acc_grad_iter` batches.  Not built yet: mixup batches ('frame2'), the host-side torchvision augmentations of
-    model.py:77-84 (ColorJitter / GaussianBlur), the double head."""
+    `acc_grad_iter` batches, mixup batches ('frame2'/'label2'/'labelD2', model.py:233-260: Beta(0.2,0.2) weights, soft
+    labels).  Not built: the host-side torchvision augmentations of model.py:77-84 (ColorJitter / GaussianBlur), the
+    double head."""
     import random
     eng = optimizer.engine
     self._model.train()
@@ -265,21 +266,32 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
     n = 0
     with self._ctx():
         for batch_idx, batch in enumerate(loader):
-            if "frame2" in batch:
-                raise NotImplementedError("mixup batches (frame2/label2) need the float-frame stem; not built yet")
-            frame = batch["frame"].to(self.device)
-            if frame.dtype != torch.uint8:
-                frame = frame.round().clamp_(0, 255).to(torch.uint8)
+            def u8(x):
+                x = x.to(self.device)
+                return (x if x.dtype == torch.uint8 else x.round().clamp_(0, 255).to(torch.uint8)).contiguous()
+            frame = u8(batch["frame"])
             label = batch["label"].to(self.device)
             labelD = batch["labelD"].to(self.device).float() if "labelD" in batch else None
             B, T, _, H, W = frame.shape
+            soft = None
+            if "frame2" in batch:
+                from . import ops_bwd
+                K1 = self._num_classes
+                lam = torch.tensor([random.betavariate(0.2, 0.2) for _ in range(B)], dtype=torch.float32, device=self.device)
+                frame = ops_bwd.mix_frames(frame, u8(batch["frame2"]), lam)          # fp32 0..255 frames
+                label2 = batch["label2"].to(self.device)
+                oh = torch.nn.functional.one_hot
+                soft = (lam.view(B, 1, 1) * oh(label, K1).float() + (1 - lam).view(B, 1, 1) * oh(label2, K1).float())
+                label = None
+                if "labelD2" in batch:
+                    labelD = lam.view(B, 1) * labelD + (1 - lam).view(B, 1) * batch["labelD2"].to(self.device).float()
             crop = None
             if crop_dim:
                 top, left = random.randint(0, H - crop_dim), random.randint(0, W - crop_dim)
                 crop = (top, left, crop_dim, crop_dim)
             masks = [((torch.rand((B, T, C), device=self.device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
             first = batch_idx % acc_grad_iter == 0
-            loss = eng.accumulate(frame.contiguous(), label, labelD, crop=crop, drop_masks=masks,
+            loss = eng.accumulate(frame.contiguous(), label, labelD, soft=soft, crop=crop, drop_masks=masks,
                                   scale=1.0 / acc_grad_iter, first=first)
             if (batch_idx + 1) % acc_grad_iter == 0:
                 optimizer.step()

@@ -23,14 +23,15 @@ def _chk(t, name, dtype=None):
 
 
 def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None, relu=True):
-    """frames (N,3,H,W) uint8 -> (N,Ho,Wo,32).  crop = (top,left,h,w) or None."""
-    _chk(frames_u8, "frames", torch.uint8)
+    """frames (N,3,H,W) uint8 (or fp32 holding 0..255: mixup batches) -> (N,Ho,Wo,32).  crop = (top,left,h,w) or None."""
+    _chk(frames_u8, "frames", torch.float32 if frames_u8.dtype == torch.float32 else torch.uint8)
     N, _, H, W = frames_u8.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
     Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
     if out is None:
         out = torch.empty((N, Ho, Wo, 32), dtype=act_dtype, device=frames_u8.device)
-    call("tdeed_stem_fwd", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(w), ptr(scale), ptr(shift),
+    call("tdeed_stem_fwd", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, int(flip),
+         ptr(w), ptr(scale), ptr(shift),
          ptr(out), int(relu), dtype_code(act_dtype), stream_ptr())
     return out
 

@@ -250,6 +250,15 @@ def stem_wgrad(frames_u8, dz, crop=None, flip=False):
     N, _, H, W = frames_u8.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
     part, dw = _f32((N * ((dz.shape[1] + 15) // 16), 864), dz.device), _f32((32, 3, 3, 3), dz.device)
-    call("tdeed_stem_wgrad", ptr(frames_u8), N, H, W, top, left, ch, cw, int(flip), ptr(dz), ptr(part), ptr(dw),
+    call("tdeed_stem_wgrad", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, int(flip),
+         ptr(dz), ptr(part), ptr(dw),
          dtype_code(dz.dtype), stream_ptr())
     return dw
+
+
+def mix_frames(a_u8, b_u8, lam):
+    """mixup of two uint8 clip batches (B,T,3,H,W) with per-clip weights lam (B,) fp32 -> fp32 frames"""
+    Bn = a_u8.shape[0]
+    out = torch.empty(a_u8.shape, dtype=torch.float32, device=a_u8.device)
+    call("tdeed_mix_frames", ptr(a_u8), ptr(b_u8), ptr(lam), Bn, a_u8.numel() // Bn, ptr(out), stream_ptr())
+    return out

@@ -506,3 +506,35 @@ def test_full_train_step_matches_torch(dtype):
             assert float((eng2.state[k].detach().cpu() - sd0[k]).abs().max()) < 1.2e-3     # |update| <= lr (+ decay)
         nbt = [k for k in sd0 if k.endswith("num_batches_tracked")]
         assert all(int(eng2.state[k]) == int(sd0[k]) + 1 for k in nbt)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mix_frames_and_float_frame_stem(bops, dtype):
+    """mixup (model.py:246) feeds fp32 frames: the stem and its weight gradient read them like the uint8 ones."""
+    from tdeed_amd import ops, synth
+    B, T, H, W = 2, 3, 40, 48
+    a, b = t(synth.uint8_clip(311, (B, T, 3, H, W))), t(synth.uint8_clip(312, (B, T, 3, H, W)))
+    lam = torch.tensor([0.3, 0.85])
+    mixed = bops.mix_frames(a.to(DEV), b.to(DEV), lam.to(DEV))
+    ref_mix = lam.view(B, 1, 1, 1, 1) * a.float() + (1 - lam).view(B, 1, 1, 1, 1) * b.float()
+    assert rel_err(mixed, ref_mix) < 1e-6
+    wt = rnd(313, "w", (32, 3, 3, 3), 0.3)
+    crop = (2, 4, 32, 40)
+    x = O.preprocess(ref_mix, None)[..., 2:34, 4:44].reshape(B * T, 3, 32, 40)
+    wr = wt.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, stride=2, padding=1)
+    dz = rnd(314, "dz", tuple(y.shape)).to(dtype)
+    y.backward(dz.float())
+    one, zero = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+    fr = mixed.view(B * T, 3, H, W)
+    z = ops.stem(fr, wt.to(DEV), one, zero, dtype, crop=crop, relu=False)
+    assert rel_err(z.float().permute(0, 3, 1, 2), y) < tol(dtype)
+    dw = bops.stem_wgrad(fr, dz.permute(0, 2, 3, 1).contiguous().to(DEV), crop=crop)
+    assert rel_err(dw, wr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    # and the uint8 path of the same kernels
+    x8 = O.preprocess(a, None)[..., 2:34, 4:44].reshape(B * T, 3, 32, 40)
+    wr2 = wt.clone().requires_grad_(True)
+    y8 = F.conv2d(x8, wr2, stride=2, padding=1)
+    y8.backward(dz.float())
+    dw8 = bops.stem_wgrad(a.view(B * T, 3, H, W).to(DEV), dz.permute(0, 2, 3, 1).contiguous().to(DEV), crop=crop)
+    assert rel_err(dw8, wr2.grad) < (2e-4 if dtype == torch.float32 else 2e-2)

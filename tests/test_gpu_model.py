@@ -199,6 +199,11 @@ def test_model_api_training_epochs_reduce_the_loss():
     assert int(sd["_features.stem.bn.num_batches_tracked"]) == steps
     val1 = m.epoch(loader[:1])                                         # eval-mode forward with the trained weights
     assert np.isfinite(val1) and val1 != val0
+    # mixup batches (frame2 / label2 / labelD2 -> fp32 frames, soft labels)
+    clip2 = synth.uint8_clip(meta["seed_x"] + 1, clip.shape)
+    lab2, labD2 = synth.labels(4, meta["B"], cfg["clip_len"], cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
+    mix_loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD), frame2=t(clip2), label2=t(lab2), labelD2=t(labD2))]
+    assert np.isfinite(m.epoch(mix_loader, optimizer=optimizer))
     # gradient accumulation: two half-weighted micro-batches == one batch (same data) up to rounding
     m2 = TDEEDModel(device=DEV, args=cfg_ns(cfg))
     m2.load({k: t(v) for k, v in model_state(cfg, meta["seed_w"]).items()})
