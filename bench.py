@@ -91,6 +91,56 @@ def cpu_baseline():
                 sec_per_clip=round(best, 4))
 
 
+def main_train(a):
+    """BASELINE.json configs[2]/[3]-style measurement: optimisation steps per second of the training path.
+    A step = train-mode forward + CE/MSE loss + full backward + (N > 1: one RCCL all-reduce of the flat fp32 gradient
+    buffer) + fused AdamW, on synthetic uint8 clips resident in HBM, dropout masks fixed."""
+    from tdeed_amd.trainer import TrainEngine
+    from tdeed_amd.regnet_spec import regnet_spec
+    rank, local, world = tdist.env_world()
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    tdist.init(backend="nccl", device=torch.device("cuda", local))
+    wl = CONFIGS[a.workload]
+    cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    T = cfg["clip_len"]
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 0).items()}
+    eng = TrainEngine(cfg, sd, dt, dev, lr=1e-4)
+    frames = ops.fill_u8_hash((B, T, 3, H, W), 1000 + rank, dev)
+    lab_np, labD_np = synth.labels(5 + rank, B, T, cfg["num_classes"], max(cfg["radi_displacement"], 1))
+    lab = torch.from_numpy(lab_np).to(dev)
+    labD = torch.from_numpy(labD_np).float().to(dev) if cfg["radi_displacement"] else None
+    C = regnet_spec(cfg["feature_arch"]).feat_dim
+    masks = [((torch.rand((B, T, C), device=dev) >= 0.5).to(dt) * 2.0) for _ in range(2 if cfg["radi_displacement"] else 1)]
+    ar = tdist.all_reduce_mean_ if world > 1 else None
+    for _ in range(max(a.warmup, 1)):
+        eng.step(frames, lab, labD, drop_masks=masks, all_reduce=ar)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = eng.step(frames, lab, labD, drop_masks=masks, all_reduce=ar)
+    torch.cuda.synchronize()
+    el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    tdist.barrier()
+    if rank == 0:
+        out = dict(metric="clips/sec (L=%d, %dx%d, %s) training step (fwd + loss + bwd + AdamW)" % (T, H, W, a.dtype),
+                   value=round(world * B * a.steps / el, 2), unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=round(el / a.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=a.dtype, data="synthetic",
+                   config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']}, L={T}, "
+                                        f"{H}x{W}, batch {B}/GPU, training step, random-init weights", clips_per_gpu=B,
+                               parallelism=f"dp{world}" + (" (RCCL all-reduce of one flat fp32 gradient buffer)" if world > 1 else ""),
+                               grad_buffer_mb=round(eng.params.numel * 4 / 2 ** 20, 1), final_loss=round(float(loss[0]), 4)),
+                   roofline=None, cpu_baseline=None)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +150,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, the BASELINE metric): forward of configs[1]; train: one optimisation step "
+                         "(train-mode forward + loss + backward + fused AdamW, gradient all-reduce over RCCL when N > 1)")
     a = ap.parse_args()
+    if a.mode == "train":
+        return main_train(a)
 
     rank, local, world = tdist.env_world()
     torch.cuda.set_device(local)
