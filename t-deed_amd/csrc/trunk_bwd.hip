@@ -3,6 +3,7 @@
 // [M][C] maps, the SE excitation with its intermediates kept for the backward, and the small row-wise helpers
 // around them.  Parameter gradients come out of ordered partial sums (no float atomics).
 #include "common.h"
+#include <cstdlib>
 
 // =========================================================================== column statistics of an [M][C] map
 // part[slab][0][c] = sum_m v(m,c), part[slab][1][c] = sum_m v(m,c) * u(m,c) over the slab's rows, where
@@ -542,6 +543,104 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const T* __restrict__ 
   }
 }
 
+// bf16 weight gradient on the MFMA pipe.  Unit = 16 channels (two gw=8 groups, or one gw=16 group); per chunk of 32
+// output pixels the gradient rows d[px][16 co] and the nine shifted input rows x[px+tap][16 ci] go to LDS transposed
+// ([channel][pixel]) so that the pixel contraction is the MFMA k index: D[ci][co] += x_tap^T . d, one MFMA per tap.
+// For gw=8 only the two diagonal 8x8 blocks of D are weight gradients (the off-diagonal cross terms are dropped).
+constexpr int GW_LD = 36;
+template <int GW>
+__global__ __launch_bounds__(256) void gconv_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                               int Hi, int Wi, int Ho, int Wo, int C, int stride,
+                                                               long npix_out, long pix_per_slab, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) bf16_t sd[16 * GW_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sx[9 * 16 * GW_LD];
+  const int unit = blockIdx.y, c0 = unit * 16;
+  const long p_begin = (long)blockIdx.x * pix_per_slab, p_end = min(npix_out, p_begin + pix_per_slab);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  const bool cok8[2] = {c0 < C, c0 + 8 < C};
+  f32x4 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const IDiv dwo(Wo), dho(Ho);
+  for (long p0 = p_begin; p0 < p_end; p0 += 32) {
+    // ---- issue: this lane's pieces (piece = (tap | 9 for dy, pixel, 8-channel half)): 10 * 32 * 2 = 640 pieces
+    u32x4 v[3];
+    int meta[3];                                                // LDS row base (channel*LD + px) or -1
+    bool ok[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = tid + u * 256;
+      meta[u] = -1;
+      ok[u] = false;
+      v[u] = (u32x4){0u, 0u, 0u, 0u};
+      const int ic = min(i, 639);
+      const int half = ic & 1, pp = (ic >> 1) & 31, tap = ic >> 6;
+      const long p = min(p0 + pp, p_end - 1);
+      int oy, ox, tmp;
+      dwo.divmod((int)(p % ((long)Ho * Wo)), oy, ox);
+      (void)tmp; (void)dho;
+      const long n = p / ((long)Ho * Wo);
+      const bf16_t* src;
+      bool valid = (p0 + pp < p_end) && cok8[half] && i < 640;
+      if (tap == 9) {
+        src = dy + p * C + c0 + half * 8;
+      } else {
+        const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+        const bool in = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+        valid = valid && in;
+        src = x + ((n * Hi + (in ? iy : 0)) * Wi + (in ? ix : 0)) * C + c0 + half * 8;
+      }
+      if (!cok8[half]) src = x;                                 // keep the address valid; the value is dropped
+      v[u] = *reinterpret_cast<const u32x4*>(src);
+      ok[u] = valid;
+      if (i < 640) meta[u] = (tap * 16 + half * 8) * GW_LD + pp;
+    }
+    TD_ISSUE_FENCE();
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (meta[u] < 0) continue;
+      const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[u]);
+      const bool isd = meta[u] >= 9 * 16 * GW_LD;
+      bf16_t* dst = isd ? sd + (meta[u] - 9 * 16 * GW_LD) : sx + meta[u];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e * GW_LD] = ok[u] ? t8[e] : (bf16_t)0.f;
+    }
+    __syncthreads();
+    bf16x8 bfr;
+    {
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(sd + pl * GW_LD + q * 8);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(sd + pl * GW_LD + q * 8 + 4);
+      bfr = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tap = wv + 4 * i;
+      if (tap < 9) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(sx + (tap * 16 + pl) * GW_LD + q * 8);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(sx + (tap * 16 + pl) * GW_LD + q * 8 + 4);
+        const bf16x8 afr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  // D[ci = 4q+e][co = pl] of tap wv + 4i  ->  part[slab][g][tap][ci_local][co_local]
+  const int G = C / GW;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tap = wv + 4 * i;
+    if (tap >= 9) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ci = 4 * q + e, co = pl;
+      if (GW == 8 && (ci >> 3) != (co >> 3)) continue;          // cross-group term
+      const int g = (c0 + ci) / GW;
+      if (c0 + ci >= C || c0 + co >= C) continue;
+      part[(((long)blockIdx.x * G + g) * 9 + tap) * GW * GW + (ci % GW) * GW + (co % GW)] = acc[i][e];
+    }
+  }
+}
+
 extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
   long s = (npix_out + 4095) / 4096;
   return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
@@ -562,16 +661,28 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   const int nsl = (int)((npix_out + pps - 1) / pps);
   hipStream_t st = (hipStream_t)stream;
   dim3 gd((unsigned)((npix_in + 255) / 256), G), gwg(nsl, G);
+  static const bool wg_valu = getenv("TDEED_GCONV_WGRAD_VALU") && atoi(getenv("TDEED_GCONV_WGRAD_VALU")) == 1;
+  const bool mfma_w = dtype == TDEED_BF16 && !wg_valu && C % 8 == 0;
+  const dim3 gwm(nsl, (C + 15) / 16);
 #define TD_GC_LAUNCH(TT, GWv)                                                                                           \
   do {                                                                                                                  \
     hipLaunchKernelGGL((gconv_dgrad_kernel<TT, GWv>), gd, dim3(256), 0, st, (const TT*)dy, Hi, Wi, Ho, Wo, C, stride, w, \
                        (TT*)dx, npix_in);                                                                               \
-    hipLaunchKernelGGL((gconv_wgrad_kernel<TT, GWv>), gwg, dim3(256), 0, st, (const TT*)x, (const TT*)dy, Hi, Wi, Ho, Wo, \
-                       C, stride, npix_out, pps, part);                                                                 \
+    if (!mfma_w)                                                                                                        \
+      hipLaunchKernelGGL((gconv_wgrad_kernel<TT, GWv>), gwg, dim3(256), 0, st, (const TT*)x, (const TT*)dy, Hi, Wi, Ho,  \
+                         Wo, C, stride, npix_out, pps, part);                                                           \
   } while (0)
   if (dtype == TDEED_F32) { if (gw == 8) TD_GC_LAUNCH(float, 8); else TD_GC_LAUNCH(float, 16); }
   else { if (gw == 8) TD_GC_LAUNCH(bf16_t, 8); else TD_GC_LAUNCH(bf16_t, 16); }
 #undef TD_GC_LAUNCH
+  if (mfma_w) {
+    if (gw == 8)
+      hipLaunchKernelGGL(gconv_wgrad_mfma_kernel<8>, gwm, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, Hi, Wi, Ho, Wo,
+                         C, stride, npix_out, pps, part);
+    else
+      hipLaunchKernelGGL(gconv_wgrad_mfma_kernel<16>, gwm, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, Hi, Wi, Ho,
+                         Wo, C, stride, npix_out, pps, part);
+  }
   TD_LAUNCH_CHECK("gconv3x3_bwd");
   return tdeed_reduce_partials(part, nsl, (long)G * 9 * gw * gw, dw, 0, stream);
 }
