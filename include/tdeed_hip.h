@@ -317,7 +317,8 @@ int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid,
 /* y[n][px][c] = x[n][px][c] * s[n][c] + add[n][c] * add_scale (add may be NULL) */
 int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C, void* y,
                      int dtype, void* stream);
-/* grouped 3x3 backward: dx and dw (fp32, the forward's packed [G][9][gw][gw]).
+/* grouped 3x3 backward: dx (may be NULL: a stride-1 input gradient is itself a grouped 3x3 conv of dy with the flipped,
+ * transposed weights and can run on tdeed_gconv3x3_fwd's MFMA kernel) and dw (fp32, the forward's packed [G][9][gw][gw]).
  * part fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw] */
 int tdeed_gconv_wgrad_slabs(long npix_out);
 int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride, const float* w,

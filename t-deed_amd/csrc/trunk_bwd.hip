@@ -650,7 +650,7 @@ extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
 // part: fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw]
 extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride,
                                   const float* w, void* dx, float* part, float* dw, int dtype, void* stream) {
-  TD_CHECK(x && dy && w && dx && part && dw, "gconv3x3_bwd: null pointer");
+  TD_CHECK(x && dy && w && part && dw, "gconv3x3_bwd: null pointer");      // dx may be NULL: weight gradient only
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0 && (stride == 1 || stride == 2) && N > 0 && Hi > 0 && Wi > 0,
            "gconv3x3_bwd: bad geometry");
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gconv3x3_bwd: bad dtype %d", dtype);
@@ -666,8 +666,9 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   const dim3 gwm(nsl, (C + 15) / 16);
 #define TD_GC_LAUNCH(TT, GWv)                                                                                           \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((gconv_dgrad_kernel<TT, GWv>), gd, dim3(256), 0, st, (const TT*)dy, Hi, Wi, Ho, Wo, C, stride, w, \
-                       (TT*)dx, npix_in);                                                                               \
+    if (dx)                                                                                                             \
+      hipLaunchKernelGGL((gconv_dgrad_kernel<TT, GWv>), gd, dim3(256), 0, st, (const TT*)dy, Hi, Wi, Ho, Wo, C, stride,  \
+                         w, (TT*)dx, npix_in);                                                                          \
     if (!mfma_w)                                                                                                        \
       hipLaunchKernelGGL((gconv_wgrad_kernel<TT, GWv>), gwg, dim3(256), 0, st, (const TT*)x, (const TT*)dy, Hi, Wi, Ho,  \
                          Wo, C, stride, npix_out, pps, part);                                                           \

@@ -232,7 +232,10 @@ def pack_gconv_frags(w, gw, device):
     gconv3x3_mfma_kernel: unit u = output channels [16u,16u+16); lane l holds Wt[n=l&15][k=8(l>>4)+j];
     k-slot s = 4*ks + (l>>4) = half*9 + tap; for gw=8 'half' selects which of the unit's two groups
     the 8 input channels belong to (block-diagonal), for gw=16 which half of the group's 16 inputs."""
-    w = _np(w).astype(np.float32)
+    return torch.from_numpy(_gconv_frags_np(_np(w).astype(np.float32), gw)).to(device).to(torch.bfloat16).contiguous()
+
+
+def _gconv_frags_np(w, gw):
     C = w.shape[0]
     nu = (C + 15) // 16
     nu4 = (nu + 3) // 4 * 4
@@ -254,7 +257,28 @@ def pack_gconv_frags(w, gw, device):
                         fr[u, ks, lane, :] = w[co, half * 8:half * 8 + 8, ky, kx]
                     elif n // 8 == half:
                         fr[u, ks, lane, :] = w[co, :, ky, kx]
-    return torch.from_numpy(fr).to(device).to(torch.bfloat16).contiguous()
+    return fr
+
+
+_GCONV_IDX = {}
+
+
+def gconv_frag_index(C, gw, device):
+    """Index map of pack_gconv_frags: frags = cat([0, w.reshape(-1)])[idx], so a training step can re-pack the MFMA
+    fragments of an updated weight on the device (one gather) instead of through numpy."""
+    key = (C, gw, str(device))
+    if key not in _GCONV_IDX:
+        ids = (np.arange(C * gw * 9, dtype=np.float32) + 1).reshape(C, gw, 3, 3)     # exact in fp32 (< 2^24)
+        fr = _gconv_frags_np(ids, gw)
+        _GCONV_IDX[key] = torch.from_numpy(fr.astype(np.int64)).to(device)
+    return _GCONV_IDX[key]
+
+
+def gconv_frags_on_device(w, gw):
+    """Conv2d.weight (C,gw,3,3) fp32 on the device -> bf16 MFMA fragments (same layout as pack_gconv_frags)."""
+    idx = gconv_frag_index(w.shape[0], gw, w.device)
+    ext = torch.cat([torch.zeros(1, dtype=w.dtype, device=w.device), w.reshape(-1)])
+    return ext[idx].to(torch.bfloat16).contiguous()
 
 
 def pack_sgp_block(sd, pre, C, act_dtype, device):

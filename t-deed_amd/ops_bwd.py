@@ -168,13 +168,13 @@ def scale_rows(x, s, add=None, add_scale=1.0, out=None):
     return out
 
 
-def gconv3x3_bwd(x, dy, w_packed, gw, stride):
-    """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x, dw fp32 [G][9][gw][gw]"""
+def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True):
+    """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x (None if not want_dx), dw fp32 [G][9][gw][gw]"""
     N, Hi, Wi, C = x.shape
     Ho, Wo = dy.shape[1], dy.shape[2]
     G = C // gw
     part = _f32((_lib.load().tdeed_gconv_wgrad_slabs(N * Ho * Wo), G * 9 * gw * gw), x.device)
-    dx, dw = torch.empty_like(x), _f32((G, 9, gw, gw), x.device)
+    dx, dw = (torch.empty_like(x) if want_dx else None), _f32((G, 9, gw, gw), x.device)
     call("tdeed_gconv3x3_bwd", ptr(x), ptr(dy), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(dx), ptr(part), ptr(dw),
          dtype_code(x.dtype), stream_ptr())
     return dx, dw

@@ -107,6 +107,16 @@ class BottleneckTrain:
         self.w2p = (sd[pre + ".conv2.conv.weight"].reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1)
                     .reshape(G, 9, gw, gw).contiguous())
         self.one, self.zero = torch.ones(blk.cout, device=dev), torch.zeros(blk.cout, device=dev)
+        # bf16: conv2 forward and (stride 1) its input gradient run on the MFMA grouped-conv kernel; the input gradient is
+        # a grouped conv of dy with the weights flipped in space and transposed inside each group
+        self.w2frag = self.w2frag_t = None
+        if dt == torch.bfloat16:
+            from .engine import gconv_frags_on_device
+            w2 = sd[pre + ".conv2.conv.weight"]
+            self.w2frag = gconv_frags_on_device(w2, gw)
+            if blk.stride == 1:
+                wt = w2.reshape(G, gw, gw, 3, 3).transpose(1, 2).flip(3, 4).reshape(blk.cout, gw, 3, 3)
+                self.w2frag_t = gconv_frags_on_device(wt, gw)
         R, C = blk.se_rd, blk.cout
         self.se_w1 = sd[pre + ".se.fc1.weight"].reshape(R, C).contiguous()
         self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, R).contiguous()
@@ -131,7 +141,7 @@ class BottleneckTrain:
             c.a1 = x
         c.z1 = ops.gemm(c.a1, self.w1.w, None, None, ops.ACT_NONE).view(N, h, w, C)
         c.y1, c.bn1 = self._bn(c.z1, "conv1")
-        c.z2, _ = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, relu=False)
+        c.z2, _ = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, wfrag=self.w2frag, relu=False)
         c.y2, c.bn2 = self._bn(c.z2, "conv2")
         h2, w2 = c.z2.shape[1], c.z2.shape[2]
         c.p = B_.pool_rows(c.y2)
@@ -176,7 +186,11 @@ class BottleneckTrain:
         # conv2
         dz2, _, dw, db = B_.bn_train_bwd(c.z2, d_y2, c.y2, c.bn2, sd[pre + ".conv2.bn.weight"], relu=True)
         bn_names("conv2", dw, db)
-        d_y1, dw2p = B_.gconv3x3_bwd(c.y1, dz2, self.w2p, blk.gw, blk.stride)
+        if self.w2frag_t is not None:
+            d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)
+            _, dw2p = B_.gconv3x3_bwd(c.y1, dz2, self.w2p, blk.gw, blk.stride, want_dx=False)
+        else:
+            d_y1, dw2p = B_.gconv3x3_bwd(c.y1, dz2, self.w2p, blk.gw, blk.stride)
         G, gw = blk.groups, blk.gw
         grads[pre + ".conv2.conv.weight"] = (dw2p.reshape(G, 3, 3, gw, gw).permute(0, 4, 3, 1, 2)
                                              .reshape(sd[pre + ".conv2.conv.weight"].shape).contiguous())
