@@ -6,7 +6,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 def load(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*", "*counter_collection.csv")) + glob.glob(os.path.join(d, "*counter_collection.csv")))[0]
     acc = defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -15,7 +15,7 @@ def load(d, counter):
         acc[name][0] += float(r["Counter_Value"]); acc[name][1] += 1
     return acc
 
-FAMILY = [("gemm_ws_kernel", "gemm_ws"), ("gemm_kernel", "gemm"), ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"),
+FAMILY = [("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_kernel", "gemm"), ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"),
           ("gsf_", "gate_shift"), ("se_gate", "se_gate"), ("stem_kernel", "stem"), ("mixer_branch", "mixer_branch"),
           ("sgp_branch", "sgp_branch"), ("layernorm", "layernorm"), ("groupnorm", "groupnorm"), ("maxpool", "maxpool"),
           ("avgpool", "avgpool_posenc"), ("heads", "heads"), ("bneck", "bneck")]
