@@ -48,8 +48,12 @@ __device__ __forceinline__ f32x4 mma<float>(const f32x4& a, const f32x4& b, f32x
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+// SE: the per-frame operand re-scale (conv3 after the SE gate) is compiled in only where it is used (32 VGPRs of gate
+// values).  __launch_bounds__(256, 2) makes the compiler keep two workgroups per CU resident; a variant with a second
+// register stage (two K slabs in flight) was measured: it needs > 256 VGPRs, spills, and loses (43 vs 32 us at
+// M=39200, K=N=368).
+template <typename T, int BN, bool SE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int EPC = Chunk<T>::N;        // elements per 16-B chunk
   constexpr int KT = 8 * EPC;             // elements of K per slab
   constexpr int NT = BN / 32;             // 16-wide column tiles per wave
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 
   u32x4 areg[4], breg[BROWS];
-  f32x4 greg[4][EPC / 4];                // SE gate values of the prefetched slab (applied at LDS-store time)
+  f32x4 greg[SE ? 4 : 1][EPC / 4];       // SE gate values of the prefetched slab (applied at LDS-store time)
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // branch-free prefetch: out-of-range chunks read a valid dummy address and are zeroed by a select
@@ -126,16 +130,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(brow[i] + kc);
       breg[i] = (kok && bok[i]) ? v : zero4;
     }
-    if (p.a_scale) {
+    if constexpr (SE) {
+      if (p.a_scale) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int h = 0; h < EPC / 4; ++h) greg[i][h] = *reinterpret_cast<const f32x4*>(srow[i] + kc + 4 * h);
+          for (int h = 0; h < EPC / 4; ++h) greg[i][h] = *reinterpret_cast<const f32x4*>(srow[i] + kc + 4 * h);
+      }
     }
   };
   auto lstore = [&](int buf) {
     unsigned char* base = lds + buf * STAGE;
-    if (p.a_scale) {
+    if (SE && p.a_scale) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[EPC];
@@ -159,12 +165,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (p.K + KT - 1) / KT;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  if (nkt > 1) gload(1);                       // tile k+1 sits in registers while tile k is consumed from LDS
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto compute = [&]() {
     const unsigned char* abase = lds;
     const unsigned char* bbase = abase + A_BYTES;
 #pragma unroll
@@ -181,6 +183,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma<T>(af[mt], bfr[nt], acc[mt][nt]);
     }
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  if (nkt > 1) gload(1);                       // tile k+1 sits in registers while tile k is consumed from LDS
+  for (int kt = 0; kt < nkt; ++kt) {
+    compute();
     __syncthreads();                           // every wave is done reading tile kt
     if (kt + 1 < nkt) {
       lstore(0);
@@ -264,9 +273,16 @@ static int launch_gemm(const GemmP& p, hipStream_t st) {
   const long nb = (p.N + bn - 1) / bn;
   const long grid = mb * nb;
   if (grid > 0x7fffffffL) { tdeed_set_error("gemm: grid too large"); return TDEED_ERR_ARG; }
-  if (bn == 32) hipLaunchKernelGGL((gemm_kernel<T, 32>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<T, 64>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  const bool se = p.a_scale != nullptr;
+#define TD_GEMM(BNv)                                                                                                   \
+  do {                                                                                                                 \
+    if (se) hipLaunchKernelGGL((gemm_kernel<T, BNv, true>), dim3((unsigned)grid), dim3(256), 0, st, p);                \
+    else hipLaunchKernelGGL((gemm_kernel<T, BNv, false>), dim3((unsigned)grid), dim3(256), 0, st, p);                  \
+  } while (0)
+  if (bn == 32) TD_GEMM(32);
+  else if (bn == 64) TD_GEMM(64);
+  else TD_GEMM(128);
+#undef TD_GEMM
   TD_LAUNCH_CHECK("gemm");
   return TDEED_OK;
 }
