@@ -48,11 +48,12 @@ __device__ __forceinline__ f32x4 mma<float>(const f32x4& a, const f32x4& b, f32x
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-// SE: the per-frame operand re-scale (conv3 after the SE gate) is compiled in only where it is used (32 VGPRs of gate
-// values).  __launch_bounds__(256, 2) makes the compiler keep two workgroups per CU resident; a variant with a second
+// SE: the per-frame operand re-scale (conv3 after the SE gate) is compiled in only where it is used.  SE = 2 keeps the
+// gates of the (few) frames a 128-row tile touches in LDS (dynamic, frames x K floats) and reads them when a slab is
+// stored; SE = 1 is the general form that prefetches them in registers next to the slab (32 VGPRs).  __launch_bounds__(256, 2) makes the compiler keep two workgroups per CU resident; a variant with a second
 // register stage (two K slabs in flight) was measured: it needs > 256 VGPRs, spills, and loses (43 vs 32 us at
 // M=39200, K=N=368).
-template <typename T, int BN, bool SE>
+template <typename T, int BN, int SE>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int EPC = Chunk<T>::N;        // elements per 16-B chunk
   constexpr int KT = 8 * EPC;             // elements of K per slab
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int CS_LD = BN + 4;
   constexpr int LDS_BYTES = (STAGE > 64 * CS_LD * 4) ? STAGE : 64 * CS_LD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) float gtab[];     // SE == 2: [frames of this tile][K]
   typedef typename Frag<T>::type frag_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   }
 
   u32x4 areg[4], breg[BROWS];
-  f32x4 greg[SE ? 4 : 1][EPC / 4];       // SE gate values of the prefetched slab (applied at LDS-store time)
+  f32x4 greg[SE == 1 ? 4 : 1][EPC / 4];  // SE gate values of the prefetched slab (applied at LDS-store time)
+  int gfi[4] = {0, 0, 0, 0};             // SE == 2: row -> frame slot in gtab
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // branch-free prefetch: out-of-range chunks read a valid dummy address and are zeroed by a select
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(brow[i] + kc);
       breg[i] = (kok && bok[i]) ? v : zero4;
     }
-    if constexpr (SE) {
+    if constexpr (SE == 1) {
       if (p.a_scale) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -139,15 +142,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int kt) {
     unsigned char* base = lds + buf * STAGE;
-    if (SE && p.a_scale) {
+    if (SE == 1 && p.a_scale) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[EPC];
         Chunk<T>::load(reinterpret_cast<const T*>(&areg[i]), v);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v[e] *= greg[i][e >> 2][e & 3];
+        Chunk<T>::store(reinterpret_cast<T*>(&areg[i]), v);
+      }
+    }
+    if constexpr (SE == 2) {
+      const int kc = min(kt * KT + ch * EPC, p.K - EPC);        // out-of-range slabs are zero already
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[EPC];
+        Chunk<T>::load(reinterpret_cast<const T*>(&areg[i]), v);
+#pragma unroll
+        for (int h = 0; h < EPC / 4; ++h) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(gtab + gfi[i] * p.K + kc + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * h + e] *= g[e];
+        }
         Chunk<T>::store(reinterpret_cast<T*>(&areg[i]), v);
       }
     }
@@ -185,14 +203,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     }
   };
   gload(0);
-  lstore(0);
+  if constexpr (SE == 2) {
+    // gates of the frames this tile touches -> LDS (rows of one tile span at most 128 / a_scale_rows + 2 frames)
+    const long f_first = m0 / p.a_scale_rows;
+    const long f_last = (p.M - 1) / p.a_scale_rows;
+    const int nf = 128 / p.a_scale_rows + 2;
+    for (int i = tid * 4; i < nf * p.K; i += 1024) {
+      const int f = i / p.K, k = i - f * p.K;
+      *reinterpret_cast<f32x4*>(gtab + i) =
+          *reinterpret_cast<const f32x4*>(p.a_scale + min(f_first + f, f_last) * (long)p.K + k);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = min(m0 + r0 + 32 * i, (long)p.M - 1);
+      gfi[i] = (int)(m / p.a_scale_rows - f_first);
+    }
+    __syncthreads();
+  }
+  lstore(0, 0);
   __syncthreads();
   if (nkt > 1) gload(1);                       // tile k+1 sits in registers while tile k is consumed from LDS
   for (int kt = 0; kt < nkt; ++kt) {
     compute();
     __syncthreads();                           // every wave is done reading tile kt
     if (kt + 1 < nkt) {
-      lstore(0);
+      lstore(0, kt + 1);
       if (kt + 2 < nkt) gload(kt + 2);
     }
     __syncthreads();
@@ -273,11 +308,16 @@ static int launch_gemm(const GemmP& p, hipStream_t st) {
   const long nb = (p.N + bn - 1) / bn;
   const long grid = mb * nb;
   if (grid > 0x7fffffffL) { tdeed_set_error("gemm: grid too large"); return TDEED_ERR_ARG; }
-  const bool se = p.a_scale != nullptr;
+  // SE gate table in LDS when the frames of one 128-row tile fit 24 KB (K % 4 == 0 holds: K is a multiple of 8)
+  const size_t gt_bytes = p.a_scale ? (size_t)(128 / p.a_scale_rows + 2) * p.K * sizeof(float) : 0;
+  static int se_tab = -1;
+  if (se_tab < 0) { const char* e = getenv("TDEED_GEMM_SE_TABLE"); se_tab = e ? atoi(e) : 1; }
+  const int se = !p.a_scale ? 0 : ((se_tab && gt_bytes <= 24 * 1024) ? 2 : 1);
 #define TD_GEMM(BNv)                                                                                                   \
   do {                                                                                                                 \
-    if (se) hipLaunchKernelGGL((gemm_kernel<T, BNv, true>), dim3((unsigned)grid), dim3(256), 0, st, p);                \
-    else hipLaunchKernelGGL((gemm_kernel<T, BNv, false>), dim3((unsigned)grid), dim3(256), 0, st, p);                  \
+    if (se == 2) hipLaunchKernelGGL((gemm_kernel<T, BNv, 2>), dim3((unsigned)grid), dim3(256), gt_bytes, st, p);      \
+    else if (se == 1) hipLaunchKernelGGL((gemm_kernel<T, BNv, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
+    else hipLaunchKernelGGL((gemm_kernel<T, BNv, 0>), dim3((unsigned)grid), dim3(256), 0, st, p);                      \
   } while (0)
   if (bn == 32) TD_GEMM(32);
   else if (bn == 64) TD_GEMM(64);
