@@ -91,16 +91,24 @@ def cpu_baseline():
                 sec_per_clip=round(best, 4))
 
 
+def _dist_setup():
+    """One process per GPU under torch.distributed.run; RCCL (backend "nccl").  TDEED_DIST_BACKEND=gloo lets several
+    ranks share one GPU to exercise the multi-process path on a single-GPU box (functional check, not a measurement)."""
+    rank, local, world = tdist.env_world()
+    backend = os.environ.get("TDEED_DIST_BACKEND", "nccl")
+    local_dev = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+    torch.cuda.set_device(local_dev)
+    tdist.init(backend=backend, device=torch.device("cuda", local_dev))   # no-op for a single process
+    return rank, local, world, f"cuda:{local_dev}"
+
+
 def main_train(a):
     """BASELINE.json configs[2]/[3]-style measurement: optimisation steps per second of the training path.
     A step = train-mode forward + CE/MSE loss + full backward + (N > 1: one RCCL all-reduce of the flat fp32 gradient
     buffer) + fused AdamW, on synthetic uint8 clips resident in HBM, dropout masks fixed."""
     from tdeed_amd.trainer import TrainEngine
     from tdeed_amd.regnet_spec import regnet_spec
-    rank, local, world = tdist.env_world()
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
-    tdist.init(backend="nccl", device=torch.device("cuda", local))
+    rank, local, world, dev = _dist_setup()
     wl = CONFIGS[a.workload]
     cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -157,10 +165,7 @@ def main():
     if a.mode == "train":
         return main_train(a)
 
-    rank, local, world = tdist.env_world()
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
-    tdist.init(backend="nccl", device=torch.device("cuda", local))       # RCCL; no-op for a single process
+    rank, local, world, dev = _dist_setup()
     wl = CONFIGS[a.workload]
     cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
