@@ -158,6 +158,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight: consecutive steps alternate between this many independent buffer sets / HIP "
+                         "graphs on their own streams, so the latency-bound tail of one batch overlaps the next one's "
+                         "head (every step still runs the full forward on its own batch of B clips)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer (default, the BASELINE metric): forward of configs[1]; train: one optimisation step "
                          "(train-mode forward + loss + backward + fused AdamW, gradient all-reduce over RCCL when N > 1)")
@@ -170,25 +174,34 @@ def main():
     cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     sd = synth.make_state(state_layout.model_state_shapes(cfg), 0)       # random-init weights of the architecture
-    stream = torch.cuda.Stream()
+    depth = max(1, a.inflight)
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    stream = streams[0]
     with torch.cuda.stream(stream):
         eng = ForwardEngine(cfg, sd, dt, dev, use_graph=not a.no_graph)
-        plan = eng.plan(B, H, W)
         T = cfg["clip_len"]
-        # synthetic uint8 clips, generated on the device straight into the plan's input buffer
-        eng.set_frames(plan, ops.fill_u8_hash((B, T, 3, H, W), 1000 + rank, dev))
-        for _ in range(max(a.warmup, 1)):
-            eng.run_plan(plan)
-        stream.synchronize()
-        tdist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            eng.run_plan(plan)
-        stream.synchronize()
-        torch.cuda.synchronize()
-        el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
-        tdist.barrier()
+        plans = [eng.plan(B, H, W, slot=i) for i in range(depth)]
+        plan = plans[0]
+        # synthetic uint8 clips, generated on the device straight into each plan's input buffer
+        for i, pl in enumerate(plans):
+            eng.set_frames(pl, ops.fill_u8_hash((B, T, 3, H, W), 1000 + rank + 97 * i, dev))
+    torch.cuda.synchronize()
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % depth]):
+                eng.run_plan(plans[i % depth])
+
+    run(max(a.warmup, depth))
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize()
+    el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    tdist.barrier()
+    with torch.cuda.stream(stream):
         prof, sgp_stage_ms = kernel_profile(eng, plan) if rank == 0 else (None, None)
 
     if rank == 0:
@@ -241,7 +254,7 @@ def main():
                    config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']} "
                                         f"ks={cfg['sgp_ks']}, L={T}, {H}x{W}, batch {B}/GPU, inference forward, "
                                         "random-init weights", clips_per_gpu=B, parallelism=f"dp{world} (clip-sharded, no collective)",
-                               hip_graph=not a.no_graph),
+                               hip_graph=not a.no_graph, batches_in_flight=depth),
                    roofline=roof, kernels=kernels,
                    roofline_sgp=dict(bound="hbm", algorithmic_bytes=int(sgp_bytes), sigma_T=int(sig), weights=int(Wsgp),
                                      ms=round(sgp_stage_ms, 4), achieved=round(sgp_bytes / (sgp_stage_ms * 1e-3) / 1e9, 2),

@@ -742,11 +742,12 @@ class ForwardEngine:
         return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=head_out,
                                pool_bytes=pool.total_bytes(), B=B, T=T)
 
-    def plan(self, B, H, W, flip=False, taps=()):
+    def plan(self, B, H, W, flip=False, taps=(), slot=0):
         """Launch plan for a batch geometry.  With n_split > 1 (and no taps) the batch is cut into n_split
         sub-batches of whole clips, each with its own buffers and its own HIP stream: two half-batch
         pipelines in flight keep the CUs busy while the other one sits in a latency-bound small launch."""
-        key = (B, H, W, bool(flip), tuple(sorted(taps)))
+        # slot: independent buffer sets / graphs of the same geometry, so that consecutive batches can be in flight together
+        key = (B, H, W, bool(flip), tuple(sorted(taps)), slot)
         if key in self._plans:
             return self._plans[key]
         ns = self.n_split if (not taps and self.n_split > 1 and B % self.n_split == 0 and B >= self.n_split) else 1
