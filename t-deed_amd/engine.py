@@ -821,14 +821,15 @@ class ForwardEngine:
             plan.graph = h
         _lib.call("tdeed_graph_launch", plan.graph, st.cuda_stream)
 
-    def forward(self, frames_u8, augment_inference=False, taps=()):
-        """frames: uint8 (B,T,3,H,W) on the GPU.  Returns head_out fp32 (B*T, n_cls [+1])."""
+    def forward(self, frames_u8, augment_inference=False, taps=(), slot=0):
+        """frames: uint8 (B,T,3,H,W) on the GPU.  Returns head_out fp32 (B*T, n_cls [+1]) (a view of the plan's buffer:
+        consume it on the launching stream before the same slot runs again)."""
         if frames_u8.dtype != torch.uint8:
             raise TypeError("frames must be uint8 (0..255); callers holding floats convert with .to(torch.uint8)")
         B, T, Cc, H, W = frames_u8.shape
         if T != self.pw.clip_len:
             raise ValueError(f"clip length {T} != clip_len {self.pw.clip_len} (gate-shift needs exact clips)")
-        plan = self.plan(B, H, W, augment_inference, taps)
+        plan = self.plan(B, H, W, augment_inference, taps, slot=slot)
         self.set_frames(plan, frames_u8)
         self.run_plan(plan)
         return plan.head_out, plan

@@ -127,18 +127,19 @@ class TDEEDModel:
                 self._engines[act_dtype] = ForwardEngine(self._cfg, self._state, act_dtype, self._device)
             return self._engines[act_dtype]
 
-        def forward(self, x, y=None, inference=False, augment_inference=False, act_dtype=torch.bfloat16):
-            """model.py:105-149.  x: (B,T,3,H,W) uint8, or float holding 0..255 integers."""
+        def forward(self, x, y=None, inference=False, augment_inference=False, act_dtype=torch.bfloat16, slot=0):
+            """model.py:105-149.  x: (B,T,3,H,W) uint8, or float holding 0..255 integers.  slot: which of the engine's
+            independent buffer sets to use (two batches can be in flight on two streams)."""
             if not inference or self.training:
                 raise NotImplementedError(
-                    "training-mode forward (batch-stat BN, dropout, random crop/augment) lands with the "
-                    "backward kernels; this build serves inference=True in eval() mode")
+                    "Impl.forward serves inference=True in eval() mode; the train-mode forward (batch-stat BN, dropout, "
+                    "random crop) is fused with its backward in TDEEDModel.epoch(loader, optimizer, ...) (trainer.TrainEngine)")
             if x.dtype != torch.uint8:
                 x = x.round().clamp_(0, 255).to(torch.uint8)
             x = x.to(self._device)
             B, T = x.shape[:2]
             eng = self.engine(act_dtype)
-            head, _ = eng.forward(x.contiguous(), augment_inference)
+            head, _ = eng.forward(x.contiguous(), augment_inference, slot=slot)
             pw = eng.pw
             head = head.view(B, T, pw.n_out)
             im_feat = head[..., :pw.n_cls]
@@ -219,15 +220,23 @@ class TDEEDModel:
         self._model.eval()
         K1 = self._num_classes
         w = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32, device=self.device)
-        total = torch.zeros((), dtype=torch.float32, device=self.device)
         map_labels, map_preds = [], []
         n = 0
-        with self._ctx():
-            for batch in loader:
+        # two batches in flight: consecutive batches alternate between two buffer sets / HIP graphs on two streams
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        if getattr(self, "_stream2", None) is None:
+            self._stream2 = torch.cuda.Stream()
+        streams = [self._stream, self._stream2]
+        totals = [torch.zeros((), dtype=torch.float32, device=self.device) for _ in streams]
+        torch.cuda.current_stream().synchronize()     # w / totals were filled on the current stream; the two are non-blocking
+        for i, batch in enumerate(loader):
+            slot = i % 2
+            with torch.cuda.stream(streams[slot]):
                 frame = batch["frame"].to(self.device)
                 label = batch["label"].to(self.device)
                 B, T = frame.shape[:2]
-                pred, _ = self._model(frame, y=label, inference=True)
+                pred, _ = self._model(frame, y=label, inference=True, slot=slot)
                 labelD = batch["labelD"].to(self.device).float().reshape(-1).contiguous() if "labelD" in batch else None
                 if isinstance(pred, dict):
                     head = pred["_head_out"].reshape(B * T, -1)
@@ -235,14 +244,16 @@ class TDEEDModel:
                 else:
                     head, dcol = pred.reshape(B * T, -1).contiguous(), -1
                 out = ops.loss(head, K1, w, hard=label.reshape(-1).contiguous(), displ_col=dcol, labelD=labelD)
-                total += out[0]
+                totals[slot] += out[0]
                 n += 1
                 if valMAP:
                     cls, scores = ops.process_prediction(head, B, T, K1, dcol)
                     map_preds.append(scores.cpu())
                     from .modules import process_labels
                     map_labels.append(process_labels(label.cpu(), batch.get("labelD"), num_classes=K1))
-            self._stream.synchronize()
+        for st in streams:
+            st.synchronize()
+        total = totals[0] + totals[1]
         avg = float(total.item()) / max(n, 1)       # one device sync per epoch, not per batch
         if valMAP:
             return avg, torch.cat(map_labels, 0), torch.cat(map_preds, 0)

@@ -169,6 +169,14 @@ def test_model_api_predict_and_epoch():
     loss = m.epoch(loader)
     ref = float(O.loss_fn(t(g["logits"]), t(lab), t(g["displ"]), t(labD)))
     assert abs(loss - ref) < 0.05 * max(1.0, abs(ref))      # bf16 forward
+    # several batches: consecutive batches alternate between two buffer sets on two streams (two in flight)
+    batches = []
+    for i in range(3):
+        c = synth.uint8_clip(meta["seed_x"] + 10 + i, clip.shape)
+        l2, d2 = synth.labels(20 + i, meta["B"], cfg["clip_len"], cfg["num_classes"], cfg["radi_displacement"])
+        batches.append(dict(frame=t(c), label=t(l2), labelD=t(d2)))
+    singles = [m.epoch([b]) for b in batches]
+    assert abs(m.epoch(batches) - float(np.mean(singles))) < 1e-5 * max(1.0, abs(float(np.mean(singles))))
 
 
 def test_model_api_training_epochs_reduce_the_loss():
