@@ -122,14 +122,19 @@ def main_train(a):
     C = regnet_spec(cfg["feature_arch"]).feat_dim
     masks = [((torch.rand((B, T, C), device=dev) >= 0.5).to(dt) * 2.0) for _ in range(2 if cfg["radi_displacement"] else 1)]
     ar = tdist.all_reduce_mean_ if world > 1 else None
+    if a.no_graph:
+        step = lambda: eng.step(frames, lab, labD, drop_masks=masks, all_reduce=ar)                      # noqa: E731
+    else:
+        hnd = eng.build_graph(B, H, W)
+        step = lambda: eng.step_graph(hnd, frames, lab, labD, drop_masks=masks, all_reduce=ar)           # noqa: E731
     for _ in range(max(a.warmup, 1)):
-        eng.step(frames, lab, labD, drop_masks=masks, all_reduce=ar)
+        step()
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = eng.step(frames, lab, labD, drop_masks=masks, all_reduce=ar)
+        loss = step()
     torch.cuda.synchronize()
     el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
     tdist.barrier()
@@ -141,7 +146,8 @@ def main_train(a):
                    config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']}, L={T}, "
                                         f"{H}x{W}, batch {B}/GPU, training step, random-init weights", clips_per_gpu=B,
                                parallelism=f"dp{world}" + (" (RCCL all-reduce of one flat fp32 gradient buffer)" if world > 1 else ""),
-                               grad_buffer_mb=round(eng.params.numel * 4 / 2 ** 20, 1), final_loss=round(float(loss[0]), 4)),
+                               grad_buffer_mb=round(eng.params.numel * 4 / 2 ** 20, 1), final_loss=round(float(loss[0]), 4),
+                               hip_graph=not a.no_graph),
                    roofline=None, cpu_baseline=None)
         print(json.dumps(out))
     if world > 1:

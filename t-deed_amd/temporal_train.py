@@ -56,6 +56,7 @@ class TemporalStack:
         self.T = cfg["clip_len"]
         self.K1 = cfg["num_classes"] + 1
         self.radi = cfg.get("radi_displacement", 0)
+        self._cls_w = {}
         self.repack()
 
     # ------------------------------------------------------------------ per-step parameter views
@@ -235,7 +236,10 @@ class TemporalStack:
         outs = [ops.heads(xs[i], ws[i], bs[i]) for i in range(len(ws))]
         head_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1).contiguous()
         K1 = self.K1
-        cls_w = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32, device=feat.device)
+        if fg_weight not in self._cls_w:            # built once per weight: no host->device copy inside a captured step
+            self._cls_w[fg_weight] = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32,
+                                                  device=feat.device)
+        cls_w = self._cls_w[fg_weight]
         dcol = K1 if self.radi > 0 else -1
         ld = labelD if self.radi > 0 else None
         loss = ops.loss(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld)

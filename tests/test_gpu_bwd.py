@@ -538,3 +538,31 @@ def test_mix_frames_and_float_frame_stem(bops, dtype):
     y8.backward(dz.float())
     dw8 = bops.stem_wgrad(a.view(B * T, 3, H, W).to(DEV), dz.permute(0, 2, 3, 1).contiguous().to(DEV), crop=crop)
     assert rel_err(dw8, wr2.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_train_step_graph_replay_matches_eager():
+    """The captured step (weight re-pack + forward + loss + backward + gradient write-out in one HIP graph, AdamW outside)
+    walks the same trajectory as the eager step."""
+    from tdeed_amd import synth, state_layout
+    from tdeed_amd.regnet_spec import regnet_spec
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny002_gsf", clip_len=6, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, cfg["clip_len"], 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 7).items()}
+    C = regnet_spec(cfg["feature_arch"]).feat_dim
+    data = []
+    for i in range(3):
+        lab_np, labD_np = synth.labels(330 + i, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+        data.append((t(synth.uint8_clip(320 + i, (B, T, 3, H, W))).to(DEV), t(lab_np).long().to(DEV), t(labD_np).float().to(DEV),
+                     [((rnd(340 + i + 10 * j, "m", (B, T, C)) > 0).float() * 2.0).to(DEV) for j in range(2)]))
+    e1 = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.float32, lr=1e-3)
+    e2 = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.float32, lr=1e-3)
+    h = e2.build_graph(B, H, W)
+    for fr, lab, labD, masks in data:
+        l1 = e1.step(fr, lab, labD, drop_masks=masks)
+        l2 = e2.step_graph(h, fr, lab, labD, drop_masks=masks)
+        assert abs(float(l1[0]) - float(l2[0])) < 1e-5 * max(1.0, abs(float(l1[0])))
+    for k in sd0:
+        a, b = e1.state[k], e2.state[k]
+        assert torch.equal(a, b) or rel_err(b.float(), a.float()) < 1e-5, k
