@@ -233,6 +233,11 @@ int tdeed_loss_fwd(const float* logits, int rows, int ld, int K1, const int64_t*
 int tdeed_loss_bwd(const float* head_out, int rows, int ld, int K1, const int64_t* hard, const float* soft,
                    const float* cls_w, int displ_col, const float* labelD, float grad_scale, float* dhead,
                    void* stream);
+/* joint-dataset double head (model.py:278-306): per-clip CE on the clip's own class slice (K1a | K1b columns, dataset[i] in
+ * {1,2}, labels of dataset 2 shifted by K1a), mean over clips, + displacement MSE.  out [3] and/or dhead (either NULL). */
+int tdeed_loss2(const float* head_out, int B, int T, int ld, int K1a, int K1b, const int64_t* dataset, const int64_t* hard,
+                const float* cls_w, int displ_col, const float* labelD, float grad_scale, float* out, float* dhead,
+                void* stream);
 long tdeed_heads_bwd_workspace(int rows, int C, int n_out);
 int tdeed_heads_bwd(const float* dout, const void* x, int rows, int C, const float* w, int n_out, void* dx,
                     float* dw, float* db, void* workspace, int dtype, void* stream);

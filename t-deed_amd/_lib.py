@@ -61,6 +61,7 @@ _SIGS = {
     "tdeed_gconv_wgrad_slabs": ([c_long], c_int),
     "tdeed_gconv3x3_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_stride2_rows": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
+    "tdeed_loss2": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_float, P, P, P], c_int),
     "tdeed_reduce_strided": ([P, c_int, c_long, c_long, P, P], c_int),
     "tdeed_gsf_slice": ([P, c_long, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gsf_bwd_scratch_floats": ([c_int, c_int, c_int, c_int], c_long),

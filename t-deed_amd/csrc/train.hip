@@ -199,3 +199,79 @@ extern "C" int tdeed_adamw_step(float* param, const float* grad, float* exp_avg,
   TD_LAUNCH_CHECK("adamw");
   return TDEED_OK;
 }
+
+// =========================================================================== joint-dataset (double head) loss
+// model.py:278-306: the class head is two heads side by side (K1a | K1b columns); clip i belongs to dataset ds[i] in
+// {1, 2} and is scored on its own slice only: loss = sum_i CE_i / B with CE_i = sum_t w[y] nll / sum_t w[y] over the
+// clip's T frames (labels of dataset 2 arrive shifted by K1a: update_labels_2heads), + the displacement MSE over all rows.
+// One workgroup walks the clips (B is a few dozen, T a few hundred): fixed-order sums.
+__global__ __launch_bounds__(256) void loss2_kernel(const float* __restrict__ head, int B, int T_len, int ld, int K1a,
+                                                    int K1b, const int64_t* __restrict__ ds,
+                                                    const int64_t* __restrict__ hard, const float* __restrict__ cls_w,
+                                                    int displ_col, const float* __restrict__ labelD, float gscale,
+                                                    float* __restrict__ out, float* __restrict__ dhead) {
+  __shared__ float scratch[8];
+  float ce = 0.f, se_tot = 0.f;
+  const long rows = (long)B * T_len;
+  for (int i = 0; i < B; ++i) {
+    const bool first = ds[i] == 1;
+    const int col0 = first ? 0 : K1a, K = first ? K1a : K1b;
+    float num = 0.f, den = 0.f, se = 0.f;
+    for (int t = threadIdx.x; t < T_len; t += 256) {
+      const long r = (long)i * T_len + t;
+      const float* lg = head + r * ld + col0;
+      const int y = (int)hard[r] - col0;
+      float m = lg[0];
+      for (int k = 1; k < K; ++k) m = fmaxf(m, lg[k]);
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += expf(lg[k] - m);
+      const float w = cls_w[y];
+      num += w * (m + logf(s) - lg[y]);
+      den += w;
+      if (displ_col >= 0 && labelD) {
+        const float d = head[r * ld + displ_col] - labelD[r];
+        se += d * d;
+      }
+    }
+    num = block_sum<4>(num, scratch);
+    den = block_sum<4>(den, scratch);
+    se = block_sum<4>(se, scratch);
+    ce += num / den / (float)B;
+    se_tot += se;
+    if (dhead) {
+      const float inv = gscale / (den * (float)B);
+      for (int t = threadIdx.x; t < T_len; t += 256) {
+        const long r = (long)i * T_len + t;
+        const float* lg = head + r * ld + col0;
+        float* dg = dhead + r * ld;
+        for (int k = 0; k < ld; ++k) dg[k] = 0.f;
+        const int y = (int)hard[r] - col0;
+        float m = lg[0];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, lg[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(lg[k] - m);
+        const float wy = cls_w[y], is = 1.0f / s;
+        for (int k = 0; k < K; ++k) dg[col0 + k] = wy * (expf(lg[k] - m) * is - (k == y ? 1.f : 0.f)) * inv;
+        if (displ_col >= 0 && labelD) dg[displ_col] = 2.0f * (head[r * ld + displ_col] - labelD[r]) * gscale / (float)rows;
+      }
+    }
+  }
+  if (threadIdx.x == 0 && out) {
+    const float mse = (displ_col >= 0 && labelD) ? se_tot / (float)rows : 0.f;
+    out[0] = ce + mse;
+    out[1] = ce;
+    out[2] = mse;
+  }
+}
+
+// out fp32 [3] (total, CE, MSE) and/or dhead fp32 [B*T][ld] (either may be NULL); cls_w has max(K1a, K1b) entries
+extern "C" int tdeed_loss2(const float* head_out, int B, int T, int ld, int K1a, int K1b, const int64_t* dataset,
+                           const int64_t* hard, const float* cls_w, int displ_col, const float* labelD, float grad_scale,
+                           float* out, float* dhead, void* stream) {
+  TD_CHECK(head_out && dataset && hard && cls_w && (out || dhead), "loss2: null pointer");
+  TD_CHECK(B > 0 && T > 0 && K1a > 0 && K1b > 0 && K1a + K1b <= ld && displ_col < ld, "loss2: bad sizes");
+  hipLaunchKernelGGL(loss2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, head_out, B, T, ld, K1a, K1b, dataset, hard,
+                     cls_w, displ_col, labelD, grad_scale, out, dhead);
+  TD_LAUNCH_CHECK("loss2");
+  return TDEED_OK;
+}

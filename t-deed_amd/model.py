@@ -166,8 +166,6 @@ class TDEEDModel:
         The returned optimizer is a torch.optim.Optimizer over the model's single flat parameter buffer whose step() is
         the fused AdamW kernel, so torch LR schedulers work on it unchanged."""
         from .trainer import TrainEngine, HipAdamW
-        if self._model._double_head:
-            raise NotImplementedError("training with the joint-dataset double head is not built yet")
         eng = TrainEngine(self._model._cfg, self._model._state, act_dtype=self._train_dtype, device=self.device,
                           lr=opt_args.get("lr", 1e-3))
         self._model._engines = {}
@@ -243,7 +241,15 @@ class TDEEDModel:
                     dcol = self._model.engine(torch.bfloat16).pw.displ_col if labelD is not None else -1
                 else:
                     head, dcol = pred.reshape(B * T, -1).contiguous(), -1
-                out = ops.loss(head, K1, w, hard=label.reshape(-1).contiguous(), displ_col=dcol, labelD=labelD)
+                if self._model._double_head:
+                    # joint-dataset validation (model.py:278-306): per-clip CE on the clip's own head
+                    k1a, k1b = self._model._head_classes
+                    ds = torch.as_tensor(batch["dataset"]).to(self.device).long()
+                    lab2 = update_labels_2heads(label.clone(), ds, self._args.num_classes).reshape(-1).contiguous()
+                    w2 = torch.tensor([1.0] + [float(fg_weight)] * (max(k1a, k1b) - 1), dtype=torch.float32, device=self.device)
+                    out, _ = ops.loss2(head, B, T, k1a, k1b, ds, lab2, w2, displ_col=dcol, labelD=labelD)
+                else:
+                    out = ops.loss(head, K1, w, hard=label.reshape(-1).contiguous(), displ_col=dcol, labelD=labelD)
                 totals[slot] += out[0]
                 n += 1
                 if valMAP:
@@ -264,14 +270,14 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
     """Training branch of model.py:193-332 + BaseRGBModel.step (modules.py:390-404).  One random crop per batch shared
     by all clips and frames (model.py:115), dropout masks from the device RNG, gradient accumulation over
     `acc_grad_iter` batches, mixup batches ('frame2'/'label2'/'labelD2', model.py:233-260: Beta(0.2,0.2) weights, soft
-    labels).  Not built: the host-side torchvision augmentations of model.py:77-84 (ColorJitter / GaussianBlur), the
-    double head."""
+    labels), the joint-dataset double head ('dataset' per clip, model.py:219-221, 278-306).  Not built: the host-side
+    torchvision augmentations of model.py:77-84 (ColorJitter / GaussianBlur); mixup together with the double head."""
     import random
     eng = optimizer.engine
     self._model.train()
     optimizer.zero_grad()
     C = self._model._feat_dim
-    n_heads = 2 if self._model._radi_displacement > 0 else 1
+    n_heads = (2 if self._model._double_head else 1) + (1 if self._model._radi_displacement > 0 else 0)
     crop_dim = self._model._cfg.get("crop_dim")
     total = torch.zeros((), dtype=torch.float32, device=self.device)
     n = 0
@@ -285,6 +291,10 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
             labelD = batch["labelD"].to(self.device).float() if "labelD" in batch else None
             B, T, _, H, W = frame.shape
             soft = None
+            dataset = None
+            if self._model._double_head:
+                dataset = torch.as_tensor(batch["dataset"]).to(self.device).long()
+                label = update_labels_2heads(label.clone(), dataset, self._args.num_classes)
             if "frame2" in batch:
                 from . import ops_bwd
                 K1 = self._num_classes
@@ -303,7 +313,7 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
             masks = [((torch.rand((B, T, C), device=self.device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
             first = batch_idx % acc_grad_iter == 0
             loss = eng.accumulate(frame.contiguous(), label, labelD, soft=soft, crop=crop, drop_masks=masks,
-                                  scale=1.0 / acc_grad_iter, first=first)
+                                  scale=1.0 / acc_grad_iter, first=first, dataset=dataset, fg_weight=fg_weight)
             if (batch_idx + 1) % acc_grad_iter == 0:
                 optimizer.step()
                 if lr_scheduler is not None:

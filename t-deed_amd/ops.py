@@ -349,6 +349,16 @@ def loss_bwd(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=Non
     return dhead
 
 
+def loss2(head_out, B, T, K1a, K1b, dataset, hard, cls_w, displ_col=-1, labelD=None, want_grad=False, grad_scale=1.0):
+    """Double-head (joint dataset) loss of model.py:278-306 -> (out[3], dhead | None)."""
+    ld = head_out.shape[-1]
+    out = torch.empty(3, dtype=torch.float32, device=head_out.device)
+    dhead = torch.empty_like(head_out) if want_grad else None
+    call("tdeed_loss2", ptr(head_out), B, T, ld, K1a, K1b, ptr(dataset), ptr(hard), ptr(cls_w), displ_col, ptr(labelD),
+         float(grad_scale), ptr(out), ptr(dhead), stream_ptr())
+    return out, dhead
+
+
 def heads_bwd(dout, x, w, need_dx=True):
     """FCLayers backward: returns (dx | None, dw (n_out,C) fp32, db (n_out,) fp32)."""
     rows, n_out = dout.shape

@@ -215,39 +215,56 @@ class TemporalStack:
         return d_cur
 
     # ------------------------------------------------------------------ heads + loss
-    def _head_weights(self):
+    def _head_names(self):
+        """FCLayers of the model in output-column order (each has its own Dropout, modules.py:366-387)."""
         sd = self.sd
-        w = [sd["_pred_fine._fc_out.weight"]]
-        b = [sd["_pred_fine._fc_out.bias"]]
+        names = (["_pred_fine._fc1._fc_out", "_pred_fine._fc2._fc_out"] if "_pred_fine._fc1._fc_out.weight" in sd
+                 else ["_pred_fine._fc_out"])
         if self.radi > 0:
-            w.append(sd["_pred_displ._fc_out.weight"])
-            b.append(sd["_pred_displ._fc_out.bias"])
-        return w, b
+            names.append("_pred_displ._fc_out")
+        return names
 
-    def loss_and_grads(self, feat, label, labelD=None, soft=None, drop_masks=None, fg_weight=5.0, grad_scale=1.0):
+    def loss_and_grads(self, feat, label, labelD=None, soft=None, drop_masks=None, fg_weight=5.0, grad_scale=1.0,
+                       dataset=None):
         """feat (B,T,C) in the activation dtype; label int64 (B*T,) or soft (B*T,K1) fp32; labelD fp32 (B*T,).
-        drop_masks: optional [(B,T,C) keep-mask scaled by 1/(1-p)] per head, activation dtype (train-mode dropout).
+        drop_masks: optional [(B,T,C) keep-mask scaled by 1/(1-p)] per FCLayers (class head(s) first, displacement last),
+        activation dtype (train-mode dropout).  dataset: int64 (B,) in {1,2} when the model has the joint-dataset double
+        head (labels of dataset 2 already shifted, update_labels_2heads).
         Returns (loss scalar tensor [total, ce, mse], grads dict, d_feat)."""
         Bn, T, C = feat.shape
         R = Bn * T
         enc, tape = self.pyramid_fwd(feat)
-        ws, bs = self._head_weights()
+        names = self._head_names()
+        sd = self.sd
+        ws, bs = [sd[n + ".weight"] for n in names], [sd[n + ".bias"] for n in names]
         xs = [enc if drop_masks is None else B_.eltwise(enc, drop_masks[i], B_.MUL) for i in range(len(ws))]
         outs = [ops.heads(xs[i], ws[i], bs[i]) for i in range(len(ws))]
         head_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1).contiguous()
-        K1 = self.K1
-        if fg_weight not in self._cls_w:            # built once per weight: no host->device copy inside a captured step
-            self._cls_w[fg_weight] = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32,
-                                                  device=feat.device)
-        cls_w = self._cls_w[fg_weight]
-        dcol = K1 if self.radi > 0 else -1
+        double = len(names) - (1 if self.radi > 0 else 0) == 2
+        n_cls = sum(w_.shape[0] for w_ in ws) - (1 if self.radi > 0 else 0)
+        dcol = n_cls if self.radi > 0 else -1
         ld = labelD if self.radi > 0 else None
-        loss = ops.loss(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld)
-        dhead = ops.loss_bwd(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld, grad_scale=grad_scale)
+        if double:
+            if soft is not None:
+                raise NotImplementedError("mixup (soft labels) together with the joint-dataset double head")
+            K1a, K1b = ws[0].shape[0], ws[1].shape[0]
+            key = ("2h", fg_weight, max(K1a, K1b))
+            if key not in self._cls_w:
+                self._cls_w[key] = torch.tensor([1.0] + [float(fg_weight)] * (max(K1a, K1b) - 1), dtype=torch.float32,
+                                                device=feat.device)
+            loss, dhead = ops.loss2(head_out, Bn, T, K1a, K1b, dataset, label, self._cls_w[key], displ_col=dcol, labelD=ld,
+                                    want_grad=True, grad_scale=grad_scale)
+        else:
+            K1 = self.K1
+            if fg_weight not in self._cls_w:        # built once per weight: no host->device copy inside a captured step
+                self._cls_w[fg_weight] = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32,
+                                                      device=feat.device)
+            cls_w = self._cls_w[fg_weight]
+            loss = ops.loss(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld)
+            dhead = ops.loss_bwd(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld, grad_scale=grad_scale)
         grads = {}
         d_enc = None
         col = 0
-        names = ["_pred_fine._fc_out"] + (["_pred_displ._fc_out"] if self.radi > 0 else [])
         for i, nm in enumerate(names):
             n_out = ws[i].shape[0]
             dpart = dhead[:, col:col + n_out].contiguous()

@@ -42,7 +42,7 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ forward + backward
     def loss_and_grads(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None,
-                       fg_weight=5.0):
+                       fg_weight=5.0, dataset=None):
         """frames (B,T,3,H,W) uint8 on the device; label int64 (B,T) or None with soft (B,T,K+1); labelD float (B,T).
         crop = (top, left, h, w) (the one random crop the reference shares across B and T, model.py:115) or None.
         Returns (loss[3] = total, ce, mse ; grads dict name -> fp32 tensor)."""
@@ -60,7 +60,7 @@ class TrainEngine:
         loss, grads, d_feat = self.temporal.loss_and_grads(
             feat, None if label is None else label.reshape(-1), labelD=None if labelD is None else labelD.reshape(-1).float(),
             soft=None if soft is None else soft.reshape(-1, soft.shape[-1]).contiguous(), drop_masks=drop_masks,
-            fg_weight=fg_weight)
+            fg_weight=fg_weight, dataset=dataset)
         dx, d_enc = B_.avgpool_posenc_bwd(d_feat, hw)
         grads["temp_enc"] = d_enc
         dx = dx.view(x.shape)
@@ -81,21 +81,23 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ one optimiser step
     def accumulate(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, scale=1.0,
-                   first=True):
+                   first=True, dataset=None, fg_weight=5.0):
         """forward + backward of one (micro-)batch; its gradients (times `scale`) go into the flat gradient buffer
         (overwriting it when `first`, adding otherwise: `acc_grad_iter` of the reference's step())."""
-        loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks)
+        loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks, fg_weight, dataset)
         missing = set(self.params.index) - set(grads)
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
-        for k, g in grads.items():
-            dst = self.params.grad_view(k)
-            if first:
-                dst.copy_(g.reshape(-1))
-                if scale != 1.0:
-                    dst.mul_(scale)
-            else:
-                dst.add_(g.reshape(-1), alpha=scale)
+        # gradient write-out into the flat buffer: multi-tensor copies (a handful of launches instead of one per tensor)
+        keys = list(grads)
+        dsts = [self.params.grad_view(k).view(grads[k].shape) for k in keys]
+        srcs = [grads[k] for k in keys]
+        if first:
+            torch._foreach_copy_(dsts, srcs)
+            if scale != 1.0:
+                self.params.grad.mul_(scale)
+        else:
+            torch._foreach_add_(dsts, srcs, alpha=scale)
         return loss
 
     def apply(self, lr=None, lr_factor=1.0, all_reduce=None):

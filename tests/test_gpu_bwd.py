@@ -566,3 +566,51 @@ def test_train_step_graph_replay_matches_eager():
     for k in sd0:
         a, b = e1.state[k], e2.state[k]
         assert torch.equal(a, b) or rel_err(b.float(), a.float()) < 1e-5, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_double_head_loss_and_grads_match_autograd(dtype):
+    """Joint-dataset training (model.py:278-306): two class heads side by side, every clip scored on its dataset's head."""
+    from tdeed_amd.temporal_train import TemporalStack
+    from tdeed_amd import synth
+    B, C, T, n, ks, r, k1a, k1b, radi = 3, 32, 25, 2, 7, 4, 4, 6, 2
+    cfg = dict(n_layers=n, clip_len=T, num_classes=k1a - 1, radi_displacement=radi)
+    sd = {k: t(v) for k, v in module_state("pyramid", "_temp_fine", 43, C=C, ks=ks, r=r, n=n).items()}
+    for nm, k in (("_pred_fine._fc1._fc_out", k1a), ("_pred_fine._fc2._fc_out", k1b), ("_pred_displ._fc_out", 1)):
+        sd[nm + ".weight"], sd[nm + ".bias"] = rnd(44, nm + "w", (k, C), 0.2), rnd(44, nm + "b", (k,), 0.1)
+    feat = rnd(351, "feat", (B, T, C)).to(dtype)
+    ds = torch.tensor([1, 2, 2])
+    lab = torch.stack([t(synth.labels(352 + i, 1, T, (k1a if ds[i] == 1 else k1b) - 1, 1, fg_frac=0.3)[0][0]).long() for i in range(B)])
+    labD = t(synth.labels(355, B, T, 3, radi)[1]).float()
+    masks = [(rnd(356 + i, "m", (B, T, C)) > 0).float() * 2.0 for i in range(3)]
+    # reference: the loop of model.py:284-306 on the oracle's heads
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.float().requires_grad_(True)
+    enc = O.ed_sgp_mixer(fr, sdr, n, T)
+    fc = lambda nm, m: F.linear(enc * m, sdr[nm + ".weight"], sdr[nm + ".bias"])          # noqa: E731
+    pred = torch.cat([fc("_pred_fine._fc1._fc_out", masks[0]), fc("_pred_fine._fc2._fc_out", masks[1])], dim=2)
+    predD = fc("_pred_displ._fc_out", masks[2]).squeeze(-1)
+    wgt = torch.tensor([1.0] + [5.0] * (max(k1a, k1b) - 1))
+    ref = 0.0
+    for i in range(B):
+        if ds[i] == 1:
+            ref = ref + F.cross_entropy(pred[i][:, :k1a], lab[i], weight=wgt[:k1a]) / B
+        else:
+            ref = ref + F.cross_entropy(pred[i][:, k1a:], lab[i], weight=wgt[:k1b]) / B
+    ref = ref + F.mse_loss(predD, labD, reduction="none").mean()
+    ref.backward()
+    # device: labels of dataset 2 arrive shifted (update_labels_2heads)
+    lab_shift = lab.clone()
+    lab_shift[ds == 2] += k1a
+    ts = TemporalStack({k: v.to(DEV) for k, v in sd.items()}, cfg, act_dtype=dtype)
+    loss, grads, d_feat = ts.loss_and_grads(feat.to(DEV), lab_shift.reshape(-1).to(DEV), labelD=labD.reshape(-1).to(DEV),
+                                            drop_masks=[m.to(dtype).to(DEV) for m in masks], dataset=ds.to(DEV))
+    assert abs(float(loss[0]) - float(ref.detach())) < (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(float(ref.detach())))
+    assert set(grads) == set(sd)
+    ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sd])
+    gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sd])
+    assert float((ga - gr).norm() / gr.norm()) < (2e-3 if dtype == torch.float32 else 4e-2)
+    if dtype == torch.float32:
+        assert rel_err(d_feat.float(), fr.grad) < 2e-3
+        for k in [k for k in sd if k.startswith("_pred")]:
+            assert rel_err(grads[k], sdr[k].grad) < 1e-3, k

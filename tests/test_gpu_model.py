@@ -242,3 +242,27 @@ def test_fused_adamw_on_flat_model_params_matches_torch():
         opt.step(lr_factor=f)
     for k, r in ref.items():
         assert max_abs(sd[k], r.detach()) < 5e-6, k
+
+
+def test_model_api_double_head_training_and_validation():
+    """Joint-dataset mode (train_tdeed.py:147-148 -> update_pred_head; model.py:219-221, 278-306): training epochs and
+    the validation loss run on the per-clip head selection."""
+    from tdeed_amd.model import TDEEDModel
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    m = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    m.load({k: t(v) for k, v in model_state(cfg, meta["seed_w"]).items()})
+    k1a, k1b = cfg["num_classes"] + 1, 6
+    m._model.update_pred_head([k1a, k1b])
+    B, T = meta["B"], cfg["clip_len"]
+    clip = synth.uint8_clip(meta["seed_x"], (B, T, 3, meta["H"], meta["W"]))
+    ds = [1, 2][:B] if B >= 2 else [2]
+    labs = [synth.labels(30 + i, 1, T, (k1a if ds[i] == 1 else k1b) - 1, cfg["radi_displacement"], fg_frac=0.3) for i in range(B)]
+    lab = np.concatenate([l[0] for l in labs], 0)
+    labD = np.concatenate([l[1] for l in labs], 0)
+    loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD), dataset=torch.tensor(ds))]
+    v0 = m.epoch(loader)
+    optimizer, _ = m.get_optimizer({"lr": 3e-4})
+    losses = [m.epoch(loader, optimizer=optimizer) for _ in range(20)]
+    assert np.isfinite(v0) and all(np.isfinite(losses)) and np.mean(losses[-3:]) < 0.6 * losses[0], (v0, losses)
+    assert np.isfinite(m.epoch(loader))
