@@ -201,6 +201,85 @@ def mod_loss(name="loss_postproc", seed=8):
          d_half=d_half, process_prediction_half=pp_half)
 
 
+def mod_eval_utils(name="eval_utils", seed=12):
+    """Row f3: clip stitching, frame -> event conversion, (soft) NMS and mAP of the reference (util/eval.py,
+    util/score.py) on synthetic score tracks.  Only expected outputs are stored; the inputs are regenerated from
+    tdeed_amd.synth by the test."""
+    for nm in ("SoccerNet", "SoccerNet.Evaluation", "SoccerNet.Evaluation.ActionSpotting", "SoccerNet.Evaluation.utils",
+               "matplotlib", "matplotlib.pyplot"):
+        if nm not in sys.modules:
+            sys.modules[nm] = types.ModuleType(nm)
+    sys.modules["SoccerNet.Evaluation.ActionSpotting"].average_mAP = None
+    sys.modules["SoccerNet.Evaluation.utils"].LoadJsonFromZip = None
+    import util.eval as reval
+    import util.score as rscore
+    K1, T = 5, 20
+    videos = [("vid_b", 57, 25.0), ("vid_a", 43, 30.0), ("vid_c", 30, 25.0)]
+    classes = {f"c{k}": k for k in range(1, K1)}
+
+    class DS:
+        pass
+    ds = DS()
+    ds.videos = videos
+    ds._dataset = "finediving"
+    labels = {}
+    for vi, (v, L, _) in enumerate(videos):
+        lab = synth.labels(seed + vi, 1, L, K1 - 1, 1, fg_frac=0.15)[0][0]
+        labels[v] = lab
+    ds.get_labels = lambda v: labels[v]
+    # clips: stride T//2 starting before 0, softmax-like non-negative scores; some all-zero rows
+    pred_dict = {v: (np.zeros((L, K1), np.float32), np.zeros(L, np.int32)) for v, L, _ in videos}
+    clips = []
+    for vi, (v, L, _) in enumerate(videos):
+        for ci, start in enumerate(range(-T // 2, L, T // 2)):
+            sc = np.abs(act(seed + 10 * vi + ci, f"clip{vi}_{ci}", (T, K1))).astype(np.float32)
+            sc[:, 0] *= 2.5
+            sc /= sc.sum(axis=1, keepdims=True)
+            sc[(ci * 7) % T] = 0.0
+            clips.append((v, start, sc))
+            scores, support = pred_dict[v]
+            ps, st = sc, start
+            if st < 0:
+                ps = ps[-st:, :]
+                st = 0
+            end = st + ps.shape[0]
+            if end >= scores.shape[0]:
+                end = scores.shape[0]
+                ps = ps[:end - st, :]
+            scores[st:end, :] += ps        # the accumulation of evaluate() (util/eval.py:299-313), which itself needs a model + DataLoader
+            support[st:end] += (ps.sum(axis=1) != 0) * 1
+    stitched = {v: (pred_dict[v][0].copy(), pred_dict[v][1].copy()) for v in pred_dict}
+    err, f1, pe, pehr, pscores = reval.process_frame_predictions(ds, classes, pred_dict, high_recall_score_threshold=0.05)
+
+    def pack(evlist):
+        out = {}
+        inv = classes
+        for x in evlist:
+            out[x["video"]] = np.array([[e["frame"], inv[e["label"]], e["score"]] for e in x["events"]], np.float64).reshape(-1, 3)
+        return out
+    nms1 = reval.non_maximum_supression(pehr, window=2, threshold=0.10)
+    nms2 = reval.non_maximum_supression(pehr, window=[1, 3, 2, 4], threshold=0.0)
+    snms = reval.soft_non_maximum_supression(pehr, window=3, threshold=0.05)
+    truth = [{"video": v, "events": [{"label": f"c{int(k)}", "frame": int(i)} for i, k in enumerate(labels[v]) if k != 0]}
+             for v, _, _ in videos]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        maps_hr, _ = rscore.compute_mAPs(truth, pehr, tolerances=[0, 1, 2, 4])
+        maps_nms, _ = rscore.compute_mAPs(truth, nms1, tolerances=[1, 2, 4])
+        maps_pe, _ = rscore.compute_mAPs(truth, pe, tolerances=[0, 2])
+    arrays = dict(err=np.float64(err.get()), f1_any=np.float64(f1.get(None)),
+                  f1_cls=np.array([f1.get(k) for k in range(1, K1)], np.float64),
+                  tpfpfn=np.array([f1.tp_fp_fn(k) for k in [None] + list(range(1, K1))], np.int64),
+                  maps_hr=np.array(maps_hr), maps_nms=np.array(maps_nms), maps_pe=np.array(maps_pe))
+    for tag, evl in (("pe", pe), ("pehr", pehr), ("nms1", nms1), ("nms2", nms2), ("snms", snms)):
+        for v, a in pack(evl).items():
+            arrays[f"{tag}__{v}"] = a
+    for v in stitched:
+        arrays[f"scores__{v}"] = stitched[v][0]
+        arrays[f"support__{v}"] = stitched[v][1]
+    save(name, dict(kind="eval_utils", seed=seed, K1=K1, T=T, videos=videos, hr_thr=0.05), **arrays)
+
+
 def hf_regnet_crosscheck(name, arch, seed=9):
     """Independent structural check of the RegNetY trunk restatement (timm is absent): HuggingFace's
     RegNetYLayer stack, weights copied from the same synthetic state, same input -> pooled features."""
@@ -245,6 +324,7 @@ def hf_regnet_crosscheck(name, arch, seed=9):
 CASES = {
     "misc_ops": lambda: mod_misc(),
     "loss_postproc": lambda: mod_loss(),
+    "eval_utils": lambda: mod_eval_utils(),
     "sgp_block_c32_t25": lambda: mod_sgp_block("sgp_block_c32_t25", 32, 25, 2, 5, 2),
     "sgp_block_c368_t100": lambda: mod_sgp_block("sgp_block_c368_t100", 368, 100, 1, 7, 4),
     "sgp_block_c48_t13": lambda: mod_sgp_block("sgp_block_c48_t13", 48, 13, 2, 9, 4),
