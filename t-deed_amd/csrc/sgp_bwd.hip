@@ -483,7 +483,14 @@ extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, 
   TD_CHECK(x && dy && w && dx && part && dw && db, "groupnorm_bwd: null pointer");
   TD_CHECK(B > 0 && T > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad sizes");
   const size_t smem = ((size_t)2 * T * (C / G) + 2 * (C / G) + 8) * sizeof(float);
-  TD_CHECK(smem <= 64 * 1024, "groupnorm_bwd: slab too large");
+  TD_CHECK(smem <= 150 * 1024, "groupnorm_bwd: slab too large");
+  static bool attr_set = false;
+  if (!attr_set) {      // long clips with wide groups (T=250, 48 channels per group: 96 KB) exceed the default 64 KB
+    hipError_t e = hipFuncSetAttribute((const void*)groupnorm_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)groupnorm_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { tdeed_set_error("groupnorm_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set = true;
+  }
   dim3 grid(B, G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)

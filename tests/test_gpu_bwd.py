@@ -78,7 +78,7 @@ def test_layernorm_bwd(bops, dtype, rows, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,T,C", [(3, 25, 32), (2, 100, 368), (2, 50, 768)])
+@pytest.mark.parametrize("B,T,C", [(3, 25, 32), (2, 100, 368), (2, 50, 768), (1, 250, 768)])
 def test_groupnorm_bwd(bops, dtype, B, T, C):
     x, dy = rnd(211, "x", (B, T, C), 2.0).to(dtype), rnd(212, "dy", (B, T, C)).to(dtype)
     w, b = rnd(213, "w", (C,)) * 0.3 + 1.0, rnd(214, "b", (C,), 0.1)
