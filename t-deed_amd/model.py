@@ -86,7 +86,9 @@ class TDEEDModel:
                     v = torch.as_tensor(v)
                     if tuple(v.shape) != tuple(self._state[k].shape):
                         raise RuntimeError(f"shape mismatch for {k}: {tuple(v.shape)} vs {tuple(self._state[k].shape)}")
-                    self._state[k] = v.detach().to(self._state[k].dtype).to(self._device).clone()
+                    # in place: after get_optimizer() the parameters are views into one flat buffer that the fused
+                    # optimizer and the train engine hold on to
+                    self._state[k].copy_(v.detach().to(self._state[k].dtype).to(self._device))
             self._engines = {}
 
         def parameters(self):

@@ -207,6 +207,14 @@ def test_model_api_training_epochs_reduce_the_loss():
     assert int(sd["_features.stem.bn.num_batches_tracked"]) == steps
     val1 = m.epoch(loader[:1])                                         # eval-mode forward with the trained weights
     assert np.isfinite(val1) and val1 != val0
+    # checkpoint round trip while the optimizer is alive: load() writes into the flat buffer the optimizer owns
+    ck = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.epoch(loader, optimizer=optimizer)                               # move the weights away from the checkpoint
+    m.load(ck)
+    assert abs(m.epoch(loader[:1]) - val1) < 1e-6 * max(1.0, abs(val1))
+    w_name = "_features.s2.b1.conv1.conv.weight"
+    assert m.state_dict()[w_name].data_ptr() == optimizer.engine.state[w_name].data_ptr()
+    assert np.isfinite(m.epoch(loader, optimizer=optimizer))
     # mixup batches (frame2 / label2 / labelD2 -> fp32 frames, soft labels)
     clip2 = synth.uint8_clip(meta["seed_x"] + 1, clip.shape)
     lab2, labD2 = synth.labels(4, meta["B"], cfg["clip_len"], cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
