@@ -6,7 +6,7 @@ same buffer is what a data-parallel job all-reduces (``dist.all_reduce_mean_``).
 ``BaseRGBModel.get_optimizer`` (/root/reference/model/modules.py:37-39: torch.optim.AdamW with default betas / eps /
 weight decay 0.01 on *all* parameters), ``warmup_cosine_lr`` mirrors ``get_lr_scheduler``
 (/root/reference/train_tdeed.py:79-87: LinearLR(0.01 -> 1) chained with CosineAnnealingLR, both stepping from 0).
-The backward kernels that fill the gradient buffer are the next milestone; these classes are complete and tested.
+`trainer.TrainEngine` fills the gradient buffer (train-mode forward + backward kernels) and drives these classes.
 """
 import math
 

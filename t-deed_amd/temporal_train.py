@@ -5,8 +5,8 @@
 Everything numeric runs in the HIP kernels behind the C ABI (ops.py / ops_bwd.py); this file only orders the launches,
 keeps the activations the backward needs and maps the kernels' packed gradient layouts back onto the reference's
 state_dict names.  Inputs: trunk features (B, T, C) *after* the positional encoding; outputs: the loss, the gradient of
-every `_temp_fine.*`, `_pred_fine.*`, `_pred_displ.*` parameter and the gradient w.r.t. the features (the hand-over
-point to the trunk backward, which is the next piece of the training path to land)."""
+every `_temp_fine.*`, `_pred_fine.*`, `_pred_displ.*` parameter and the gradient w.r.t. the features, which
+`trainer.TrainEngine` hands on to the trunk backward (trunk_train.py)."""
 from types import SimpleNamespace
 
 import torch

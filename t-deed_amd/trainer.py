@@ -7,9 +7,10 @@ train_tdeed.py:79-87.
     (trunk_train.py; gate-shift on s3/s4) --> avg-pool + temp_enc --> SGP encoder-decoder + heads + loss
     (temporal_train.py) --> the same chain backwards --> gradients in ONE flat fp32 buffer --> AdamW in one launch.
 
-This is the first complete version: every numeric step is a HIP kernel behind the C ABI and parity-tested against torch
-autograd on the CPU oracle, but the step is not yet captured in a HIP graph nor tuned (per-launch temporaries come from
-torch's caching allocator; the grouped-conv and gate-shift backward kernels are plain gather kernels)."""
+Every numeric step is a HIP kernel behind the C ABI and is parity-tested against torch autograd on the CPU oracle
+(tests/test_gpu_bwd.py).  `build_graph/step_graph` capture weight re-packing + forward + loss + backward + gradient
+write-out into one HIP graph (AdamW stays outside: lr and the step count change every step).  The step is correct but only
+lightly tuned: DESIGN.md section 8 has the per-kernel breakdown."""
 import torch
 
 from . import ops, ops_bwd as B_
