@@ -26,25 +26,30 @@ def family(n):
             return v
     return None
 
-fd, wd, out = sys.argv[1:4]
-fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-fam = defaultdict(lambda: dict(launches=0, fetch_bytes=0.0, write_bytes=0.0))
-for n, (v, c) in fe.items():
-    k = family(n)
-    if k:
-        fam[k]["launches"] += c
-        fam[k]["fetch_bytes"] += v * 1024 * 2          # gfx950: FETCH_SIZE = 1/2 of wide streaming reads
-for n, (v, c) in wr.items():
-    k = family(n)
-    if k:
-        fam[k]["write_bytes"] += v * 1024
-res = {}
-for k, d in fam.items():
-    L = max(d["launches"], 1)
-    res[k] = dict(launches_profiled=d["launches"], hbm_bytes_per_launch=round((d["fetch_bytes"] + d["write_bytes"]) / L),
-                  fetch_bytes_per_launch=round(d["fetch_bytes"] / L), write_bytes_per_launch=round(d["write_bytes"] / L))
-json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950), "
-                    "bench.py rny002_b8 bf16; averages over every launch of the kernel family",
-               kernels=res), open(out, "w"), indent=1)
-for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"]):
-    print(f"{k:16s} launches {v['launches_profiled']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB (rd {v['fetch_bytes_per_launch']/1e6:8.2f} wr {v['write_bytes_per_launch']/1e6:8.2f})")
+def main():
+    fd, wd, out = sys.argv[1:4]
+    fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    fam = defaultdict(lambda: dict(launches=0, fetch_bytes=0.0, write_bytes=0.0))
+    for n, (v, c) in fe.items():
+        k = family(n)
+        if k:
+            fam[k]["launches"] += c
+            fam[k]["fetch_bytes"] += v * 1024 * 2          # gfx950: FETCH_SIZE = 1/2 of wide streaming reads
+    for n, (v, c) in wr.items():
+        k = family(n)
+        if k:
+            fam[k]["write_bytes"] += v * 1024
+    res = {}
+    for k, d in fam.items():
+        L = max(d["launches"], 1)
+        res[k] = dict(launches_profiled=d["launches"], hbm_bytes_per_launch=round((d["fetch_bytes"] + d["write_bytes"]) / L),
+                      fetch_bytes_per_launch=round(d["fetch_bytes"] / L), write_bytes_per_launch=round(d["write_bytes"] / L))
+    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950), "
+                        "bench.py rny002_b8 bf16; averages over every launch of the kernel family",
+                   kernels=res), open(out, "w"), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"]):
+        print(f"{k:16s} launches {v['launches_profiled']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB (rd {v['fetch_bytes_per_launch']/1e6:8.2f} wr {v['write_bytes_per_launch']/1e6:8.2f})")
+
+
+if __name__ == "__main__":
+    main()
