@@ -155,7 +155,8 @@ def _temporal_state(C, T, n, ks, r, K1, radi, seed=41):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("geom", [dict(B=2, C=32, T=25, n=2, ks=7, r=4, K1=5, radi=2, soft=False, drop=False),
                                   dict(B=2, C=368, T=100, n=2, ks=7, r=4, K1=5, radi=2, soft=False, drop=True),
-                                  dict(B=1, C=64, T=50, n=3, ks=9, r=4, K1=13, radi=0, soft=True, drop=True)])
+                                  dict(B=1, C=64, T=50, n=3, ks=9, r=4, K1=13, radi=0, soft=True, drop=True),
+                                  dict(B=1, C=48, T=250, n=2, ks=9, r=4, K1=13, radi=4, soft=False, drop=False)])   # SoccerNetBall lengths
 def test_temporal_stack_loss_and_grads_match_autograd(dtype, geom):
     """SGP encoder-decoder + heads (+dropout) + CE/MSE: loss, every parameter gradient and d loss / d features against
     torch autograd on the CPU oracle."""
@@ -442,6 +443,32 @@ def _oracle_train_loss(frames, sd, cfg, spec, lab, labD, masks, crop, flip):
     dm = None if masks is None else (masks[1], masks[0])
     cls, displ = O.heads(enc, sd, cfg["radi_displacement"], drop_mask=dm)
     return O.loss_fn(cls, lab, displ, labD)
+
+
+def test_full_train_step_800mf_matches_autograd():
+    """The RegNetY-800MF variant (group width 16, folds 32/80/192, n_layers 3) through the same check, fp32."""
+    from tdeed_amd import synth, state_layout
+    from tdeed_amd.regnet_spec import regnet_spec
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny008_gsf", clip_len=4, crop_dim=None, n_layers=3, sgp_ks=7, sgp_r=4, num_classes=5,
+               radi_displacement=0)
+    B, T, H, W = 2, cfg["clip_len"], 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 9).items()}
+    frames = t(synth.uint8_clip(361, (B, T, 3, H, W)))
+    lab = t(synth.labels(362, B, T, cfg["num_classes"], 1, fg_frac=0.4)[0]).long()
+    par = [k for k in sd0 if state_layout.is_parameter(k)]
+    sdr = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
+    ref_loss = _oracle_train_loss(frames, sdr, cfg, regnet_spec(cfg["feature_arch"]), lab, None, None, None, False)
+    ref_loss.backward()
+    eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.float32, lr=1e-3)
+    loss, grads = eng.loss_and_grads(frames.to(DEV), lab.to(DEV))
+    assert set(grads) == set(par)
+    assert abs(float(loss[0]) - float(ref_loss.detach())) < 2e-4 * max(1.0, abs(float(ref_loss.detach())))
+    ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in par])
+    gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in par])
+    assert float((ga - gr).norm() / gr.norm()) < 2e-3
+    eng.step(frames.to(DEV), lab.to(DEV))          # and the optimiser launch over the 800MF flat buffer
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
