@@ -26,6 +26,9 @@ class TrainEngine:
 
     def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", lr=1e-3, weight_decay=0.01):
         self.cfg, self.dt, self.device = dict(cfg), act_dtype, device
+        if str(cfg["feature_arch"]).endswith("_gsm"):
+            raise NotImplementedError("training the optional `_gsm` backbones (model/impl/gsm.py; unused by the reference's "
+                                      "configs) is not built: gsf_bwd.hip differentiates the gate-shift-FUSE module only")
         for k in list(state):                                    # in place: the caller's dict ends up holding the views
             v = state[k]
             state[k] = (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)).to(device)
