@@ -846,6 +846,81 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const IN* __restrict__ 
   }
 }
 
+// bf16 form on the MFMA pipe: per 16x16 output tile the 256 pixels are the contraction index; dz^T [32 co][256 px] and
+// the im2col patch^T [27 -> 32 taps][256 px] go to LDS as bf16 (pixel-contiguous rows), wave (co-tile, tap-tile) runs 8
+// MFMAs per tile and keeps its 16x16 block of dW in registers across the tiles of the row.
+constexpr int SW_LD = 256 + 8;
+template <typename IN>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const IN* __restrict__ frames, int H, int W, int top, int left,
+                                                              int ch, int cw, int flip, const bf16_t* __restrict__ dz,
+                                                              int Ho, int Wo, float* __restrict__ part) {
+  __shared__ float tile[3][33][34];
+  __shared__ __attribute__((aligned(16))) bf16_t dzT[32 * SW_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t inT[32 * SW_LD];
+  const int n = blockIdx.x, oy0 = blockIdx.y * 16;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const IN* src = frames + (long)n * 3 * H * W;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  const int ty = tid >> 4, tx = tid & 15;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 5 * SW_LD; i += 256) inT[27 * SW_LD + i] = (bf16_t)0.f;      // taps 27..31 stay zero
+  for (int ox0 = 0; ox0 < Wo; ox0 += 16) {
+    const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+    __syncthreads();
+    for (int i = tid; i < 3 * 33 * 33; i += 256) {
+      const int c = i / (33 * 33);
+      const int r = i - c * 33 * 33;
+      const int y = r / 33, x = r - y * 33;
+      const int iy = iy0 + y, ix = ix0 + x;
+      float v = 0.f;
+      if (iy >= 0 && iy < ch && ix >= 0 && ix < cw) {
+        const int sx = flip ? (cw - 1 - ix) : ix;
+        v = ((float)src[((long)c * H + (top + iy)) * W + (left + sx)] / 255.0f - mean[c]) / stdv[c];
+      }
+      tile[c][y][x] = v;
+    }
+    {     // this lane's pixel: its 32 gradient channels, transposed into dzT
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      const bool ok = oy < Ho && ox < Wo;
+      const bf16_t* g = dz + (((long)n * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * 32;
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const u32x4*>(g + 8 * j);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dzT[(8 * j + e) * SW_LD + tid] = ok ? t8[e] : (bf16_t)0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) inT[(c * 9 + ky * 3 + kx) * SW_LD + tid] = (bf16_t)tile[c][2 * ty + ky][2 * tx + kx];
+    __syncthreads();
+    const bf16_t* ar = dzT + ((wv & 1) * 16 + pl) * SW_LD + q * 8;
+    const bf16_t* br = inT + ((wv >> 1) * 16 + pl) * SW_LD + q * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(ar + ks * 32);
+      const bf16x8 bf_ = *reinterpret_cast<const bf16x8*>(br + ks * 32);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf_, acc, 0, 0, 0);
+    }
+  }
+  const int k = (wv >> 1) * 16 + pl;
+  if (k < 27) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = (wv & 1) * 16 + 4 * q + e;
+      part[((long)n * gridDim.y + blockIdx.y) * 864 + co * 27 + k] = acc[e];
+    }
+  }
+}
+
 // dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N*ceil(Ho/16)][864]
 extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
                                 int crop_h, int crop_w, int flip, const void* dz, float* part, float* dw, int dtype,
@@ -859,7 +934,16 @@ extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H
   hipLaunchKernelGGL((stem_wgrad_kernel<TT, IN>), dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const IN*)frames, H, W, crop_top, \
                      crop_left, crop_h, crop_w, flip, (const TT*)dz, Ho, Wo, part)
   if (dtype == TDEED_F32) { if (frames_f32) TD_SWG(float, float); else TD_SWG(float, uint8_t); }
-  else if (dtype == TDEED_BF16) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
+  else if (dtype == TDEED_BF16) {
+    static const bool valu = getenv("TDEED_STEM_WGRAD_VALU") && atoi(getenv("TDEED_STEM_WGRAD_VALU")) == 1;
+    if (valu) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
+    else if (frames_f32)
+      hipLaunchKernelGGL(stem_wgrad_mfma_kernel<float>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const float*)frames, H, W,
+                         crop_top, crop_left, crop_h, crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
+    else
+      hipLaunchKernelGGL(stem_wgrad_mfma_kernel<uint8_t>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const uint8_t*)frames, H,
+                         W, crop_top, crop_left, crop_h, crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
+  }
 #undef TD_SWG
   else { tdeed_set_error("stem_wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("stem_wgrad");
