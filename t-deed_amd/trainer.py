@@ -155,7 +155,8 @@ class TrainEngine:
         for k, v in keep.items():
             self.state[k].copy_(v)
         h.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(h.graph, stream=side):
+        # thread-local capture: other threads (the RCCL watchdog of a data-parallel job) may keep calling the runtime
+        with torch.cuda.graph(h.graph, stream=side, capture_error_mode="thread_local"):
             self.repack()
             h.loss = run()
         for k, v in keep.items():                                # capture does not execute, but stay explicit
