@@ -37,7 +37,10 @@ int tdeed_device_info(int dev, char* name64, int* n_cu, int* is_gfx950);
  * frames: uint8 [N][3][H][W] (NCHW as the loader delivers it); out: [N][Ho][Wo][32], Ho=(crop_h+1)/2. */
 int tdeed_stem_fwd(const void* frames /* uint8, or fp32 0..255 when frames_f32 (mixup batches) */, int frames_f32,
                    int N, int H, int W, int crop_top, int crop_left,
-                   int crop_h, int crop_w, int flip, const float* w /*[32][3][3][3]*/,
+                   int crop_h, int crop_w, int flip /* all frames (eval TTA, model.py:159-162) */,
+                   const unsigned char* flip_mask /* NULL, or [N] per-frame h-flip flags: the train-time
+                                                     RandomHorizontalFlip drawn per clip (model.py:83,154-157) */,
+                   const float* w /*[32][3][3][3]*/,
                    const float* scale /*[32]*/, const float* shift /*[32]*/, void* out,
                    int relu /* 0: raw conv*scale+shift (training) */, int dtype, void* stream);
 
@@ -234,10 +237,13 @@ int tdeed_loss_bwd(const float* head_out, int rows, int ld, int K1, const int64_
                    const float* cls_w, int displ_col, const float* labelD, float grad_scale, float* dhead,
                    void* stream);
 /* joint-dataset double head (model.py:278-306): per-clip CE on the clip's own class slice (K1a | K1b columns, dataset[i] in
- * {1,2}, labels of dataset 2 shifted by K1a), mean over clips, + displacement MSE.  out [3] and/or dhead (either NULL). */
+ * {1,2}, labels of dataset 2 shifted by K1a), mean over clips, + displacement MSE.  out [3] and/or dhead (either NULL).
+ * hard: int64 [B*T], or soft: fp32 [B*T][K1a+K1b] label distributions (mixup with the double head: the 3-D label branch
+ * of model.py:286-300).  Labels outside [0, K) of their slice are never used as an index: the loss comes back NaN
+ * (the same holds for tdeed_loss_fwd / tdeed_loss_bwd; torch's cross_entropy raises in that case). */
 int tdeed_loss2(const float* head_out, int B, int T, int ld, int K1a, int K1b, const int64_t* dataset, const int64_t* hard,
-                const float* cls_w, int displ_col, const float* labelD, float grad_scale, float* out, float* dhead,
-                void* stream);
+                const float* soft, const float* cls_w, int displ_col, const float* labelD, float grad_scale, float* out,
+                float* dhead, void* stream);
 long tdeed_heads_bwd_workspace(int rows, int C, int n_out);
 int tdeed_heads_bwd(const float* dout, const void* x, int rows, int C, const float* w, int n_out, void* dx,
                     float* dw, float* db, void* workspace, int dtype, void* stream);
@@ -337,7 +343,18 @@ int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw, int C, vo
 /* stem weight gradient (the uint8 input needs none): dz [N][Ho][Wo][32] -> dw [32][3][3][3]; part fp32
  * [N * ceil(Ho/16)][864] */
 int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h, int crop_w,
-                     int flip, const void* dz, float* part, float* dw, int dtype, void* stream);
+                     int flip, const unsigned char* flip_mask /* NULL or [N], as tdeed_stem_fwd */, const void* dz,
+                     float* part, float* dw, int dtype, void* stream);
+
+/* train-time augmentation inside Impl.forward (model.py:76-83, 154-157): per clip ColorJitter(hue), (saturation),
+ * (brightness), (contrast), GaussianBlur(5) on the cropped frames (torchvision 0.18.1 float-tensor arithmetic restated in
+ * csrc/augment.hip); RandomHorizontalFlip is the flip_mask of tdeed_stem_fwd.  prm fp32 [B][8] on the device =
+ * {hue shift, saturation, brightness, contrast, blur sigma (0 = off), -, -, -}, identity = {0,1,1,1,0}.  frames uint8 (or
+ * fp32 0..255) [B*T][3][H][W] -> out fp32 0..255 [B*T][3][crop_h][crop_w] (feed to tdeed_stem_fwd with frames_f32 = 1 and
+ * no crop).  part: tdeed_augment_scratch_floats(B*T) floats; tmp: same size as out (blur staging). */
+long tdeed_augment_scratch_floats(int N);
+int tdeed_augment_clips(const void* frames, int frames_f32, int B, int T, int H, int W, int crop_top, int crop_left,
+                        int crop_h, int crop_w, const float* prm, float* part, float* out, float* tmp, void* stream);
 
 /* mixup (model.py:240-256): out[b] = lam[b]*a[b] + (1-lam[b])*b[b], uint8 clips -> fp32 frames for tdeed_stem_fwd(frames_f32=1) */
 int tdeed_mix_frames(const uint8_t* a, const uint8_t* b, const float* lam, int B, long per_clip, float* out, void* stream);

@@ -65,6 +65,74 @@ def preprocess(frames, crop_dim=None, augment_inference=False):
     return (x - mean) / std
 
 
+
+
+# ----------------------------------------------------------------------------- train-time augmentation
+# model/model.py:76-83, 154-157 apply torchvision transforms (requirements.txt:41, torchvision==0.18.1, NOT vendored and not
+# installed here: PARITY UNPINNED for this section) per clip on the cropped 0..1 frames.  Restated from the published
+# float-tensor functional ops (torchvision/transforms/_functional_tensor.py: _rgb2hsv, _hsv2rgb, _blend, adjust_*,
+# gaussian_blur).
+def _gray(img):
+    r, g, b = img.unbind(dim=-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+
+
+def _blend(a, b, ratio):
+    return (ratio * a + (1.0 - ratio) * b).clamp(0, 1.0)
+
+
+def adjust_hue(img, f):
+    r, g, b = img.unbind(dim=-3)
+    maxc, minc = img.max(dim=-3).values, img.min(dim=-3).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s_ = cr / torch.where(eqc, ones, maxc)
+    crd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    h = (h + f) % 1.0
+    v = maxc
+    i = torch.floor(h * 6.0)
+    fr = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    p_ = (v * (1.0 - s_)).clamp(0, 1)
+    q_ = (v * (1.0 - s_ * fr)).clamp(0, 1)
+    t_ = (v * (1.0 - s_ * (1.0 - fr))).clamp(0, 1)
+    sel = lambda opts: sum((i == k) * o for k, o in enumerate(opts))    # noqa: E731
+    return torch.stack((sel((v, q_, p_, p_, t_, v)), sel((t_, v, v, q_, p_, p_)), sel((p_, p_, t_, v, v, q_))), dim=-3)
+
+
+def gaussian_blur5(img, sigma):
+    half = 2.0
+    x = torch.linspace(-half, half, 5)
+    pdf = torch.exp(-0.5 * (x / sigma) ** 2)
+    k1 = pdf / pdf.sum()
+    k2 = torch.outer(k1, k1)
+    C = img.shape[-3]
+    pad = F.pad(img, (2, 2, 2, 2), mode="reflect")
+    return F.conv2d(pad, k2[None, None].expand(C, 1, 5, 5).contiguous(), groups=C)
+
+
+def augment_clip(x01, prm):
+    """x01 (T,3,h,w) in 0..1; prm = (hue, sat, bri, con, sigma) with identity (0,1,1,1,0): the colour / blur stages of the
+    reference's `self.augmentation` in Compose order (the flip is applied by the caller)."""
+    hue, sat, bri, con, sigma = [float(v) for v in prm[:5]]
+    x = x01
+    if hue != 0.0:
+        x = adjust_hue(x, hue)
+    if sat != 1.0:
+        x = _blend(x, _gray(x), sat)
+    if bri != 1.0:
+        x = _blend(x, torch.zeros_like(x), bri)
+    if con != 1.0:
+        x = _blend(x, _gray(x).mean(dim=(-3, -2, -1), keepdim=True), con)
+    if sigma > 0.0:
+        x = gaussian_blur5(x, sigma)
+    return x
 # ----------------------------------------------------------------------------- GSF / GSM
 def _shift_left(y):   # y[t] <- y[t+1], last = 0        (gsf.py:28-31)
     return torch.cat([y[:, :, 1:], torch.zeros_like(y[:, :, :1])], dim=2)

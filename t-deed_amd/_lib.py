@@ -29,10 +29,12 @@ P = c_void_p
 _SIGS = {
     "tdeed_abi_version": ([], c_int),
     "tdeed_device_info": ([c_int, c_char_p, POINTER(c_int), POINTER(c_int)], c_int),
-    "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_stem_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_augment_scratch_floats": ([c_int], c_long),
+    "tdeed_augment_clips": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P], c_int),
     "tdeed_mix_frames": ([P, P, P, c_int, c_long, P, P], c_int),
     "tdeed_avgpool_posenc_bwd": ([P, c_int, c_int, c_int, c_int, P, P, c_int, P], c_int),
-    "tdeed_stem_wgrad": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_stem_wgrad": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_s1_front_parts": ([c_int, c_int, c_int], c_int),
     "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,
                             P, P, P, P, P, P, P], c_int),
@@ -61,7 +63,7 @@ _SIGS = {
     "tdeed_gconv_wgrad_slabs": ([c_long], c_int),
     "tdeed_gconv3x3_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_stride2_rows": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
-    "tdeed_loss2": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_float, P, P, P], c_int),
+    "tdeed_loss2": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, c_float, P, P, P], c_int),
     "tdeed_reduce_strided": ([P, c_int, c_long, c_long, P, P], c_int),
     "tdeed_gsf_slice": ([P, c_long, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gsf_bwd_scratch_floats": ([c_int, c_int, c_int, c_int], c_long),

@@ -9,7 +9,8 @@
 // IN = uint8_t (the normal path: 1 byte/px in HBM) or float (mixup batches: l*frame + (1-l)*frame2 is not integral)
 template <typename T, typename IN>
 __global__ __launch_bounds__(256) void stem_kernel(const IN* __restrict__ frames, int H, int W,
-                                                   int top, int left, int ch, int cw, int flip,
+                                                   int top, int left, int ch, int cw, int flip_all,
+                                                   const unsigned char* __restrict__ flip_mask,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ scale,
                                                    const float* __restrict__ shift, T* __restrict__ out,
@@ -21,6 +22,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const IN* __restrict__ frames
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
   const IN* src = frames + (long)n * 3 * H * W;
+  const int flip = flip_mask ? (int)flip_mask[n] : flip_all;      // per-frame h-flip (train-time augment) or one flag
   for (int i = threadIdx.x; i < 3 * 33 * 33; i += 256) {
     int c = i / (33 * 33);
     int r = i - c * 33 * 33;
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const IN* __restrict__ frames
 }
 
 extern "C" int tdeed_stem_fwd(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
-                              int crop_h, int crop_w, int flip, const float* w, const float* scale,
-                              const float* shift, void* out, int relu, int dtype, void* stream) {
+                              int crop_h, int crop_w, int flip, const unsigned char* flip_mask, const float* w,
+                              const float* scale, const float* shift, void* out, int relu, int dtype, void* stream) {
   TD_CHECK(frames && w && scale && shift && out, "stem: null pointer");
   TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 &&
                crop_top + crop_h <= H && crop_left + crop_w <= W,
@@ -75,7 +77,7 @@ extern "C" int tdeed_stem_fwd(const void* frames, int frames_f32, int N, int H, 
   hipStream_t st = (hipStream_t)stream;
 #define TD_STEM(TT, IN)                                                                                                \
   hipLaunchKernelGGL((stem_kernel<TT, IN>), grid, dim3(256), 0, st, (const IN*)frames, H, W, crop_top, crop_left, crop_h, \
-                     crop_w, flip, w, scale, shift, (TT*)out, Ho, Wo, relu)
+                     crop_w, flip, flip_mask, w, scale, shift, (TT*)out, Ho, Wo, relu)
   if (dtype == TDEED_F32) { if (frames_f32) TD_STEM(float, float); else TD_STEM(float, uint8_t); }
   else if (dtype == TDEED_BF16) { if (frames_f32) TD_STEM(bf16_t, float); else TD_STEM(bf16_t, uint8_t); }
 #undef TD_STEM

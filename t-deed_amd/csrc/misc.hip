@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
                                                    const float* __restrict__ cls_w, int displ_col,
                                                    const float* __restrict__ labelD, float* __restrict__ out) {
   __shared__ float scratch[8];
-  float num = 0.f, den = 0.f, se = 0.f;
+  float num = 0.f, den = 0.f, se = 0.f, bad = 0.f;
   for (int r = threadIdx.x; r < rows; r += 256) {
     const float* lg = logits + (long)r * ld;
     float m = lg[0];
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
       for (int k = 0; k < K1; ++k) a += cls_w[k] * p[k] * (lse - lg[k]);
       num += a;
     } else {
-      const int yk = (int)hard[r];
+      int yk = (int)hard[r];
+      if (yk < 0 || yk >= K1) { bad = 1.f; yk = 0; }               // never indexed; the loss becomes NaN (torch raises here)
       num += cls_w[yk] * (lse - lg[yk]);
       den += cls_w[yk];
     }
@@ -118,8 +119,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
   num = block_sum<4>(num, scratch);
   den = block_sum<4>(den, scratch);
   se = block_sum<4>(se, scratch);
+  bad = block_sum<4>(bad, scratch);
   if (threadIdx.x == 0) {
-    const float ce = soft ? num / (float)rows : num / den;
+    const float ce = bad > 0.f ? __builtin_nanf("") : (soft ? num / (float)rows : num / den);
     const float mse = (displ_col >= 0 && labelD) ? se / (float)rows : 0.f;
     out[0] = ce + mse;
     out[1] = ce;

@@ -19,7 +19,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
   __shared__ float scratch[8];
   float den = 0.f;
   if (!soft)
-    for (int r = threadIdx.x; r < rows; r += 256) den += cls_w[(int)hard[r]];
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      const int y = (int)hard[r];
+      den += cls_w[(y >= 0 && y < K1) ? y : 0];                  // out-of-range labels are never indexed (tdeed_loss_fwd -> NaN)
+    }
   den = soft ? (float)rows : block_sum<4>(den, scratch);
   const float inv = gscale / den;
   for (int r = threadIdx.x; r < rows; r += 256) {
@@ -37,7 +40,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
       for (int k = 0; k < K1; ++k) wp += cls_w[k] * p[k];
       for (int k = 0; k < K1; ++k) dg[k] = (expf(lg[k] - m) * is * wp - cls_w[k] * p[k]) * inv;
     } else {
-      const int y = (int)hard[r];
+      int y = (int)hard[r];
+      if (y < 0 || y >= K1) y = 0;
       const float wy = cls_w[y];
       for (int k = 0; k < K1; ++k) dg[k] = wy * (expf(lg[k] - m) * is - (k == y ? 1.f : 0.f)) * inv;
     }
@@ -207,12 +211,14 @@ extern "C" int tdeed_adamw_step(float* param, const float* grad, float* exp_avg,
 // One workgroup walks the clips (B is a few dozen, T a few hundred): fixed-order sums.
 __global__ __launch_bounds__(256) void loss2_kernel(const float* __restrict__ head, int B, int T_len, int ld, int K1a,
                                                     int K1b, const int64_t* __restrict__ ds,
-                                                    const int64_t* __restrict__ hard, const float* __restrict__ cls_w,
+                                                    const int64_t* __restrict__ hard, const float* __restrict__ soft,
+                                                    const float* __restrict__ cls_w,
                                                     int displ_col, const float* __restrict__ labelD, float gscale,
                                                     float* __restrict__ out, float* __restrict__ dhead) {
   __shared__ float scratch[8];
-  float ce = 0.f, se_tot = 0.f;
+  float ce = 0.f, se_tot = 0.f, bad = 0.f;
   const long rows = (long)B * T_len;
+  const int Ks = K1a + K1b;                                       // soft rows: distributions over both heads' columns
   for (int i = 0; i < B; ++i) {
     const bool first = ds[i] == 1;
     const int col0 = first ? 0 : K1a, K = first ? K1a : K1b;
@@ -220,21 +226,28 @@ __global__ __launch_bounds__(256) void loss2_kernel(const float* __restrict__ he
     for (int t = threadIdx.x; t < T_len; t += 256) {
       const long r = (long)i * T_len + t;
       const float* lg = head + r * ld + col0;
-      const int y = (int)hard[r] - col0;
       float m = lg[0];
       for (int k = 1; k < K; ++k) m = fmaxf(m, lg[k]);
       float s = 0.f;
       for (int k = 0; k < K; ++k) s += expf(lg[k] - m);
-      const float w = cls_w[y];
-      num += w * (m + logf(s) - lg[y]);
-      den += w;
+      const float lse = m + logf(s);
+      if (soft) {                                                 // mixup: -sum_c w_c p_c log softmax_c, mean over the T rows
+        const float* p = soft + r * Ks + col0;
+        for (int k = 0; k < K; ++k) num += cls_w[k] * p[k] * (lse - lg[k]);
+      } else {
+        int y = (int)hard[r] - col0;
+        if (y < 0 || y >= K) { bad = 1.f; y = 0; }              // label outside the clip's own head: never indexed, loss -> NaN
+        const float w = cls_w[y];
+        num += w * (lse - lg[y]);
+        den += w;
+      }
       if (displ_col >= 0 && labelD) {
         const float d = head[r * ld + displ_col] - labelD[r];
         se += d * d;
       }
     }
     num = block_sum<4>(num, scratch);
-    den = block_sum<4>(den, scratch);
+    den = soft ? (float)T_len : block_sum<4>(den, scratch);
     se = block_sum<4>(se, scratch);
     ce += num / den / (float)B;
     se_tot += se;
@@ -245,33 +258,46 @@ __global__ __launch_bounds__(256) void loss2_kernel(const float* __restrict__ he
         const float* lg = head + r * ld + col0;
         float* dg = dhead + r * ld;
         for (int k = 0; k < ld; ++k) dg[k] = 0.f;
-        const int y = (int)hard[r] - col0;
         float m = lg[0];
         for (int k = 1; k < K; ++k) m = fmaxf(m, lg[k]);
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += expf(lg[k] - m);
-        const float wy = cls_w[y], is = 1.0f / s;
-        for (int k = 0; k < K; ++k) dg[col0 + k] = wy * (expf(lg[k] - m) * is - (k == y ? 1.f : 0.f)) * inv;
+        const float is = 1.0f / s;
+        if (soft) {
+          const float* p = soft + r * Ks + col0;
+          float wp = 0.f;
+          for (int k = 0; k < K; ++k) wp += cls_w[k] * p[k];
+          for (int k = 0; k < K; ++k) dg[col0 + k] = (expf(lg[k] - m) * is * wp - cls_w[k] * p[k]) * inv;
+        } else {
+          int y = (int)hard[r] - col0;
+          if (y < 0 || y >= K) y = 0;
+          const float wy = cls_w[y];
+          for (int k = 0; k < K; ++k) dg[col0 + k] = wy * (expf(lg[k] - m) * is - (k == y ? 1.f : 0.f)) * inv;
+        }
         if (displ_col >= 0 && labelD) dg[displ_col] = 2.0f * (head[r * ld + displ_col] - labelD[r]) * gscale / (float)rows;
       }
     }
   }
+  bad = block_sum<4>(bad, scratch);
   if (threadIdx.x == 0 && out) {
     const float mse = (displ_col >= 0 && labelD) ? se_tot / (float)rows : 0.f;
+    if (bad > 0.f) ce = __builtin_nanf("");                     // torch's cross_entropy raises here; a NaN loss is this path's alarm
     out[0] = ce + mse;
     out[1] = ce;
     out[2] = mse;
   }
 }
 
-// out fp32 [3] (total, CE, MSE) and/or dhead fp32 [B*T][ld] (either may be NULL); cls_w has max(K1a, K1b) entries
+// out fp32 [3] (total, CE, MSE) and/or dhead fp32 [B*T][ld] (either may be NULL); cls_w has max(K1a, K1b) entries.
+// hard: int64 [B*T] labels over the concatenated heads, or soft: fp32 [B*T][K1a+K1b] (mixup; model.py:278-306 with 3-D labels).
+// A hard label outside its clip's head slice is never used as an index: the row gets class 0 and the loss becomes NaN.
 extern "C" int tdeed_loss2(const float* head_out, int B, int T, int ld, int K1a, int K1b, const int64_t* dataset,
-                           const int64_t* hard, const float* cls_w, int displ_col, const float* labelD, float grad_scale,
-                           float* out, float* dhead, void* stream) {
-  TD_CHECK(head_out && dataset && hard && cls_w && (out || dhead), "loss2: null pointer");
+                           const int64_t* hard, const float* soft, const float* cls_w, int displ_col, const float* labelD,
+                           float grad_scale, float* out, float* dhead, void* stream) {
+  TD_CHECK(head_out && dataset && (hard || soft) && cls_w && (out || dhead), "loss2: null pointer");
   TD_CHECK(B > 0 && T > 0 && K1a > 0 && K1b > 0 && K1a + K1b <= ld && displ_col < ld, "loss2: bad sizes");
   hipLaunchKernelGGL(loss2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, head_out, B, T, ld, K1a, K1b, dataset, hard,
-                     cls_w, displ_col, labelD, grad_scale, out, dhead);
+                     soft, cls_w, displ_col, labelD, grad_scale, out, dhead);
   TD_LAUNCH_CHECK("loss2");
   return TDEED_OK;
 }

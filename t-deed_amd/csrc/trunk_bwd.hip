@@ -793,11 +793,14 @@ extern "C" int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw
 // lanes own (co, tap) pairs): part[n][32*27], folded by reduce_partials.
 template <typename T, typename IN>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const IN* __restrict__ frames, int H, int W, int top, int left,
-                                                         int ch, int cw, int flip, const T* __restrict__ dz, int Ho, int Wo,
+                                                         int ch, int cw, int flip_all,
+                                                         const unsigned char* __restrict__ flip_mask,
+                                                         const T* __restrict__ dz, int Ho, int Wo,
                                                          float* __restrict__ part) {
   __shared__ float tile[3][33][34];
   __shared__ float dzt[256][33];
   const int n = blockIdx.x;
+  const int flip = flip_mask ? (int)flip_mask[n] : flip_all;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
   const IN* src = frames + (long)n * 3 * H * W;
@@ -852,12 +855,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const IN* __restrict__ 
 constexpr int SW_LD = 256 + 8;
 template <typename IN>
 __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const IN* __restrict__ frames, int H, int W, int top, int left,
-                                                              int ch, int cw, int flip, const bf16_t* __restrict__ dz,
+                                                              int ch, int cw, int flip_all,
+                                                              const unsigned char* __restrict__ flip_mask,
+                                                              const bf16_t* __restrict__ dz,
                                                               int Ho, int Wo, float* __restrict__ part) {
   __shared__ float tile[3][33][34];
   __shared__ __attribute__((aligned(16))) bf16_t dzT[32 * SW_LD];
   __shared__ __attribute__((aligned(16))) bf16_t inT[32 * SW_LD];
   const int n = blockIdx.x, oy0 = blockIdx.y * 16;
+  const int flip = flip_mask ? (int)flip_mask[n] : flip_all;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
   const IN* src = frames + (long)n * 3 * H * W;
@@ -923,8 +929,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const IN* __restri
 
 // dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N*ceil(Ho/16)][864]
 extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
-                                int crop_h, int crop_w, int flip, const void* dz, float* part, float* dw, int dtype,
-                                void* stream) {
+                                int crop_h, int crop_w, int flip, const unsigned char* flip_mask, const void* dz,
+                                float* part, float* dw, int dtype, void* stream) {
   TD_CHECK(frames && dz && part && dw, "stem_wgrad: null pointer");
   TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= H &&
                crop_left + crop_w <= W, "stem_wgrad: bad geometry");
@@ -932,17 +938,17 @@ extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H
   hipStream_t st = (hipStream_t)stream;
 #define TD_SWG(TT, IN)                                                                                                 \
   hipLaunchKernelGGL((stem_wgrad_kernel<TT, IN>), dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const IN*)frames, H, W, crop_top, \
-                     crop_left, crop_h, crop_w, flip, (const TT*)dz, Ho, Wo, part)
+                     crop_left, crop_h, crop_w, flip, flip_mask, (const TT*)dz, Ho, Wo, part)
   if (dtype == TDEED_F32) { if (frames_f32) TD_SWG(float, float); else TD_SWG(float, uint8_t); }
   else if (dtype == TDEED_BF16) {
     static const bool valu = getenv("TDEED_STEM_WGRAD_VALU") && atoi(getenv("TDEED_STEM_WGRAD_VALU")) == 1;
     if (valu) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
     else if (frames_f32)
       hipLaunchKernelGGL(stem_wgrad_mfma_kernel<float>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const float*)frames, H, W,
-                         crop_top, crop_left, crop_h, crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
+                         crop_top, crop_left, crop_h, crop_w, flip, flip_mask, (const bf16_t*)dz, Ho, Wo, part);
     else
       hipLaunchKernelGGL(stem_wgrad_mfma_kernel<uint8_t>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const uint8_t*)frames, H,
-                         W, crop_top, crop_left, crop_h, crop_w, flip, (const bf16_t*)dz, Ho, Wo, part);
+                         W, crop_top, crop_left, crop_h, crop_w, flip, flip_mask, (const bf16_t*)dz, Ho, Wo, part);
   }
 #undef TD_SWG
   else { tdeed_set_error("stem_wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }

@@ -12,7 +12,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from . import ops, synth, state_layout
+from . import ops, synth, state_layout, augment
 from .engine import ForwardEngine
 from .regnet_spec import regnet_spec
 
@@ -55,11 +55,21 @@ class TDEEDModel:
             self._device = "cpu"
             self.training = False
             self._engines = {}
+            self._train_engine = None               # trainer.TrainEngine over self._state (get_optimizer / first train-mode call)
+            self._train_dtype = torch.bfloat16      # the reference trains under autocast; torch.float32 for parity runs
+            self._train_ctx = None                  # activations of the last train-mode forward (for the backward)
+            self.augment_fn = None                  # optional hook replacing the built-in train-time augmentation:
+            #   augment_fn(frames (B,T,3,H,W) uint8|fp32 0..255 on the device, crop (top,left,h,w)|None) -> frames of the
+            #   crop window (B,T,3,h,w), uint8 or fp32 0..255, on the device (flips included, if wanted)
+            self.augment_generator = None           # torch.Generator for the augmentation draws (None: the global CPU one)
 
         # ---- nn.Module-like surface the reference's callers touch
         def to(self, device):
+            if self._train_engine is not None and str(device) != self._device:
+                raise RuntimeError("the model cannot change device once its training engine exists")
             self._device = str(device)
-            self._state = {k: v.to(device) for k, v in self._state.items()}
+            for k in list(self._state):          # in place: trainer / optimizer may hold this dict
+                self._state[k] = self._state[k].to(device)
             self._engines = {}
             return self
 
@@ -90,6 +100,9 @@ class TDEEDModel:
                     # optimizer and the train engine hold on to
                     self._state[k].copy_(v.detach().to(self._state[k].dtype).to(self._device))
             self._engines = {}
+            if self._train_engine is not None:
+                # the train engine keeps packed copies (bf16 casts, transposes, MFMA fragments) of the master weights
+                self._train_engine.repack()
 
         def parameters(self):
             return [v for k, v in self._state.items() if state_layout.is_parameter(k)]
@@ -111,6 +124,8 @@ class TDEEDModel:
             self._double_head = True
             self._head_classes = list(num_classes)
             self._engines = {}
+            if self._train_engine is not None:
+                raise RuntimeError("update_pred_head() must be called before get_optimizer() (train_tdeed.py:147-151 does)")
 
         def print_stats(self):
             def cnt(pfx):
@@ -129,13 +144,80 @@ class TDEEDModel:
                 self._engines[act_dtype] = ForwardEngine(self._cfg, self._state, act_dtype, self._device)
             return self._engines[act_dtype]
 
+        def train_engine(self):
+            """The training engine over this model's state (created by get_optimizer(), or lazily by the first
+            train-mode forward): moves the parameters into one flat buffer, `self._state` then holds views into it."""
+            if self._train_engine is None:
+                if not str(self._device).startswith("cuda"):
+                    raise RuntimeError("tdeed_amd runs on the GPU only: construct TDEEDModel(device='cuda')")
+                from .trainer import TrainEngine
+                self._train_engine = TrainEngine(self._cfg, self._state, act_dtype=self._train_dtype, device=self._device)
+                self._engines = {}
+            return self._train_engine
+
+        def _pack_head(self, head, B, T, n_cls, displ_col, y):
+            head = head.view(B, T, -1)
+            im_feat = head[..., :n_cls]
+            if self._radi_displacement > 0:
+                return {"im_feat": im_feat, "displ_feat": head[..., displ_col], "_head_out": head}, y
+            return im_feat, y
+
+        def _forward_train(self, x, y, inference, augment_inference):
+            """model.py:105-149 under .train(): batch-statistics BatchNorm (running stats updated), dropout in the heads;
+            `inference` only selects the crop / augmentation branch (model.py:110-129) like in the reference."""
+            import random
+            eng = self.train_engine()
+            if x.dtype not in (torch.uint8, torch.float32):
+                x = x.float()
+            x = x.to(self._device).contiguous()           # uint8, or fp32 0..255 (mixup batches / callers' .float())
+            B, T, _, H, W = x.shape
+            if self._require_clip_len > 0 and T != self._require_clip_len:
+                raise ValueError(f"clip length {T} != clip_len {self._require_clip_len} (gate-shift needs exact clips)")
+            cd = self.croping
+            crop, flip = None, False
+            if not inference:
+                if cd and (cd != H or cd != W):
+                    # torchvision RandomCrop.get_params: torch.randint for the row, then for the column; ONE window for
+                    # the whole batch (model.py:115 crops the 5-D tensor)
+                    g = self.augment_generator
+                    top = int(torch.randint(0, H - cd + 1, size=(1,), generator=g).item())
+                    left = int(torch.randint(0, W - cd + 1, size=(1,), generator=g).item())
+                    crop = (top, left, cd, cd)
+                if self.augment_fn is not None:
+                    x = self.augment_fn(x, crop)
+                    crop = None
+                    if x.dtype not in (torch.uint8, torch.float32) or not x.is_cuda:
+                        raise TypeError("augment_fn must return uint8 / float32 frames on the device")
+                    x = x.contiguous()
+                else:
+                    prm, flip_c = augment.draw_params(B, self.augment_generator)
+                    if not augment.is_identity(prm):
+                        x = augment.apply(x, prm, crop)
+                        crop = None
+                    flip = flip_c.to(self._device) if bool(flip_c.any()) else False
+            else:
+                if cd and (cd != H or cd != W):
+                    crop = (int(round((H - cd) / 2.0)), int(round((W - cd) / 2.0)), cd, cd)
+                flip = bool(augment_inference)
+            C = self._feat_dim
+            n_heads = (2 if self._double_head else 1) + (1 if self._radi_displacement > 0 else 0)
+            masks = [((torch.rand((B, T, C), device=self._device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
+            head, ctx = eng.forward_train(x, crop=crop, flip=flip, drop_masks=masks)
+            self._train_ctx = ctx
+            n_cls, dcol, _ = eng.temporal.head_layout()
+            return self._pack_head(head, B, T, n_cls, dcol, y)
+
         def forward(self, x, y=None, inference=False, augment_inference=False, act_dtype=torch.bfloat16, slot=0):
-            """model.py:105-149.  x: (B,T,3,H,W) uint8, or float holding 0..255 integers.  slot: which of the engine's
-            independent buffer sets to use (two batches can be in flight on two streams)."""
-            if not inference or self.training:
+            """model.py:105-149.  x: (B,T,3,H,W) uint8, or float holding 0..255 values.  Like the reference's nn.Module,
+            .train()/.eval() select BatchNorm statistics + dropout and `inference` selects the crop / augmentation branch.
+            slot (eval only): which of the engine's independent buffer sets to use (two batches in flight on two streams)."""
+            if self.training:
+                return self._forward_train(x, y, inference, augment_inference)
+            if not inference:
                 raise NotImplementedError(
-                    "Impl.forward serves inference=True in eval() mode; the train-mode forward (batch-stat BN, dropout, "
-                    "random crop) is fused with its backward in TDEEDModel.epoch(loader, optimizer, ...) (trainer.TrainEngine)")
+                    "Impl.forward(inference=False) in eval() mode (running-statistics BatchNorm on randomly cropped and "
+                    "augmented clips) is a combination no caller of the reference uses: epoch() pairs train() with "
+                    "inference=False and eval() with inference=True (model.py:196-203)")
             if x.dtype != torch.uint8:
                 x = x.round().clamp_(0, 255).to(torch.uint8)
             x = x.to(self._device)
@@ -143,11 +225,7 @@ class TDEEDModel:
             eng = self.engine(act_dtype)
             head, _ = eng.forward(x.contiguous(), augment_inference, slot=slot)
             pw = eng.pw
-            head = head.view(B, T, pw.n_out)
-            im_feat = head[..., :pw.n_cls]
-            if self._radi_displacement > 0:
-                return {"im_feat": im_feat, "displ_feat": head[..., pw.displ_col], "_head_out": head}, y
-            return im_feat, y
+            return self._pack_head(head, B, T, pw.n_cls, pw.displ_col, y)
 
         __call__ = forward
 
@@ -160,18 +238,25 @@ class TDEEDModel:
         self._model.to(device)
         self._num_classes = args.num_classes + 1
         self._stream = None
-        self._train_dtype = torch.bfloat16          # the reference trains under autocast; fp32 for parity runs
 
     # BaseRGBModel (modules.py:35-55)
     def get_optimizer(self, opt_args):
         """modules.py:37-39: AdamW over all parameters (+ a GradScaler in the reference; bf16 needs none -> None).
         The returned optimizer is a torch.optim.Optimizer over the model's single flat parameter buffer whose step() is
         the fused AdamW kernel, so torch LR schedulers work on it unchanged."""
-        from .trainer import TrainEngine, HipAdamW
-        eng = TrainEngine(self._model._cfg, self._model._state, act_dtype=self._train_dtype, device=self.device,
-                          lr=opt_args.get("lr", 1e-3))
-        self._model._engines = {}
+        from .trainer import HipAdamW
+        eng = self._model.train_engine()
         return HipAdamW(eng, **opt_args), None
+
+    @property
+    def _train_dtype(self):
+        return self._model._train_dtype
+
+    @_train_dtype.setter
+    def _train_dtype(self, dt):
+        if self._model._train_engine is not None:
+            raise RuntimeError("set _train_dtype before get_optimizer() / the first train-mode forward")
+        self._model._train_dtype = dt
 
     def _get_params(self):
         return list(self._model.parameters())
@@ -269,21 +354,22 @@ class TDEEDModel:
 
 
 def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_weight):
-    """Training branch of model.py:193-332 + BaseRGBModel.step (modules.py:390-404).  One random crop per batch shared
-    by all clips and frames (model.py:115), dropout masks from the device RNG, gradient accumulation over
-    `acc_grad_iter` batches, mixup batches ('frame2'/'label2'/'labelD2', model.py:233-260: Beta(0.2,0.2) weights, soft
-    labels), the joint-dataset double head ('dataset' per clip, model.py:219-221, 278-306).  Not built: the host-side
-    torchvision augmentations of model.py:77-84 (ColorJitter / GaussianBlur); mixup together with the double head."""
+    """Training branch of model.py:193-332 + BaseRGBModel.step (modules.py:390-404): per batch, mixup when the loader
+    delivers 'frame2'/'label2'/'labelD2' (model.py:233-260: Beta(0.2,0.2) weights from `random`, soft labels), the
+    train-mode `Impl.forward(frame, inference=False)` (one random crop per batch, per-clip augmentation, dropout), the
+    loss (single or joint-dataset double head, hard or soft labels), the backward and, every `acc_grad_iter` batches,
+    the optimizer + scheduler step."""
     import random
     eng = optimizer.engine
+    if eng is not self._model.train_engine():
+        raise RuntimeError("the optimizer was built for another model")
     self._model.train()
     optimizer.zero_grad()
-    C = self._model._feat_dim
-    n_heads = (2 if self._model._double_head else 1) + (1 if self._model._radi_displacement > 0 else 0)
-    crop_dim = self._model._cfg.get("crop_dim")
     total = torch.zeros((), dtype=torch.float32, device=self.device)
     n = 0
+    cur = torch.cuda.current_stream()
     with self._ctx():
+        self._stream.wait_stream(cur)        # engine construction / load() / zero_grad were queued on the caller's stream
         for batch_idx, batch in enumerate(loader):
             def u8(x):
                 x = x.to(self.device)
@@ -291,7 +377,7 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
             frame = u8(batch["frame"])
             label = batch["label"].to(self.device)
             labelD = batch["labelD"].to(self.device).float() if "labelD" in batch else None
-            B, T, _, H, W = frame.shape
+            B, T = frame.shape[:2]
             soft = None
             dataset = None
             if self._model._double_head:
@@ -299,7 +385,7 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
                 label = update_labels_2heads(label.clone(), dataset, self._args.num_classes)
             if "frame2" in batch:
                 from . import ops_bwd
-                K1 = self._num_classes
+                K1 = self._num_classes                               # train_tdeed.py:148 widens it for the double head
                 lam = torch.tensor([random.betavariate(0.2, 0.2) for _ in range(B)], dtype=torch.float32, device=self.device)
                 frame = ops_bwd.mix_frames(frame, u8(batch["frame2"]), lam)          # fp32 0..255 frames
                 label2 = batch["label2"].to(self.device)
@@ -308,14 +394,16 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
                 label = None
                 if "labelD2" in batch:
                     labelD = lam.view(B, 1) * labelD + (1 - lam).view(B, 1) * batch["labelD2"].to(self.device).float()
-            crop = None
-            if crop_dim:
-                top, left = random.randint(0, H - crop_dim), random.randint(0, W - crop_dim)
-                crop = (top, left, crop_dim, crop_dim)
-            masks = [((torch.rand((B, T, C), device=self.device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
-            first = batch_idx % acc_grad_iter == 0
-            loss = eng.accumulate(frame.contiguous(), label, labelD, soft=soft, crop=crop, drop_masks=masks,
-                                  scale=1.0 / acc_grad_iter, first=first, dataset=dataset, fg_weight=fg_weight)
+            pred, _ = self._model(frame, y=label, inference=False)
+            head = (pred["_head_out"] if isinstance(pred, dict) else pred).reshape(B * T, -1)
+            scale = 1.0 / acc_grad_iter
+            loss, dhead = eng.temporal.loss_fwd_bwd(
+                head, B, T, None if label is None else label.reshape(-1).contiguous(),
+                labelD=None if labelD is None else labelD.reshape(-1).contiguous(),
+                soft=None if soft is None else soft.reshape(B * T, -1).contiguous(), fg_weight=fg_weight, dataset=dataset)
+            grads = eng.backward_train(self._model._train_ctx, dhead)
+            self._model._train_ctx = None
+            eng.write_grads(grads, scale=scale, first=batch_idx % acc_grad_iter == 0)
             if (batch_idx + 1) % acc_grad_iter == 0:
                 optimizer.step()
                 if lr_scheduler is not None:

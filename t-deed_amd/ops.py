@@ -22,16 +22,28 @@ def _chk(t, name, dtype=None):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+def _flip_args(flip, N):
+    """flip: bool (all frames) or a uint8/bool tensor of N per-frame flags -> (int flag, mask tensor | None)."""
+    if isinstance(flip, torch.Tensor):
+        m = flip.to(torch.uint8).contiguous()
+        if m.numel() != N or not m.is_cuda:
+            raise ValueError(f"flip mask must hold one flag per frame on the GPU ({m.numel()} vs {N})")
+        return 0, m
+    return int(bool(flip)), None
+
+
 def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None, relu=True):
-    """frames (N,3,H,W) uint8 (or fp32 holding 0..255: mixup batches) -> (N,Ho,Wo,32).  crop = (top,left,h,w) or None."""
+    """frames (N,3,H,W) uint8 (or fp32 holding 0..255: mixup batches) -> (N,Ho,Wo,32).  crop = (top,left,h,w) or None.
+    flip: bool for all frames, or a (N,) uint8 tensor of per-frame flags."""
     _chk(frames_u8, "frames", torch.float32 if frames_u8.dtype == torch.float32 else torch.uint8)
     N, _, H, W = frames_u8.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
     Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
     if out is None:
         out = torch.empty((N, Ho, Wo, 32), dtype=act_dtype, device=frames_u8.device)
-    call("tdeed_stem_fwd", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, int(flip),
-         ptr(w), ptr(scale), ptr(shift),
+    fl, fmask = _flip_args(flip, N)
+    call("tdeed_stem_fwd", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, fl,
+         ptr(fmask), ptr(w), ptr(scale), ptr(shift),
          ptr(out), int(relu), dtype_code(act_dtype), stream_ptr())
     return out
 
@@ -331,8 +343,31 @@ def heads(x, w, b, out=None):
     return out
 
 
+def _chk_labels(head_out, hard, soft, labelD, K):
+    """Host-side argument checks of the loss entry points (dtype / contiguity / shape; no device sync).  Label VALUES are
+    checked by the kernels: a label outside [0, K) is never used as an index and turns the loss into NaN."""
+    _chk(head_out, "head_out", torch.float32)
+    rows = head_out.shape[0]
+    if hard is not None:
+        _chk(hard, "labels", torch.int64)
+        if hard.numel() != rows:
+            raise ValueError(f"labels: {hard.numel()} entries for {rows} rows")
+    if soft is not None:
+        _chk(soft, "soft labels", torch.float32)
+        if soft.numel() != rows * K:
+            raise ValueError(f"soft labels: {tuple(soft.shape)} for {rows} rows x {K} classes")
+    if labelD is not None:
+        _chk(labelD, "labelD", torch.float32)
+        if labelD.numel() != rows:
+            raise ValueError(f"labelD: {labelD.numel()} entries for {rows} rows")
+    if hard is None and soft is None:
+        raise ValueError("loss needs hard or soft labels")
+
+
 def loss(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=None, out=None):
     rows, ld = head_out.shape
+    _chk_labels(head_out, hard, soft, labelD, K1)
+    _chk(cls_w, "cls_w", torch.float32)
     if out is None:
         out = torch.empty(3, dtype=torch.float32, device=head_out.device)
     call("tdeed_loss_fwd", ptr(head_out), rows, ld, K1, ptr(hard), ptr(soft), ptr(cls_w), displ_col, ptr(labelD),
@@ -343,20 +378,31 @@ def loss(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=None, o
 def loss_bwd(head_out, K1, cls_w, hard=None, soft=None, displ_col=-1, labelD=None, grad_scale=1.0):
     """d(CE+MSE)/d(head_out) (rows, ld) fp32."""
     rows, ld = head_out.shape
+    _chk_labels(head_out, hard, soft, labelD, K1)
     dhead = torch.empty_like(head_out)
     call("tdeed_loss_bwd", ptr(head_out), rows, ld, K1, ptr(hard), ptr(soft), ptr(cls_w), displ_col, ptr(labelD),
          float(grad_scale), ptr(dhead), stream_ptr())
     return dhead
 
 
-def loss2(head_out, B, T, K1a, K1b, dataset, hard, cls_w, displ_col=-1, labelD=None, want_grad=False, grad_scale=1.0):
-    """Double-head (joint dataset) loss of model.py:278-306 -> (out[3], dhead | None)."""
+def loss2(head_out, B, T, K1a, K1b, dataset, hard, cls_w, displ_col=-1, labelD=None, want_grad=False, grad_scale=1.0,
+          soft=None):
+    """Double-head (joint dataset) loss of model.py:278-306 -> (out[3], dhead | None).  hard: int64 labels over the
+    concatenated heads, or soft: (B*T, K1a+K1b) fp32 label distributions (mixup)."""
     ld = head_out.shape[-1]
+    _chk_labels(head_out, hard, soft, labelD, K1a + K1b)
+    _chk(dataset, "dataset", torch.int64)
+    if dataset.numel() != B or cls_w.numel() < max(K1a, K1b):
+        raise ValueError("loss2: dataset needs one id per clip, cls_w max(K1a, K1b) weights")
     out = torch.empty(3, dtype=torch.float32, device=head_out.device)
     dhead = torch.empty_like(head_out) if want_grad else None
-    call("tdeed_loss2", ptr(head_out), B, T, ld, K1a, K1b, ptr(dataset), ptr(hard), ptr(cls_w), displ_col, ptr(labelD),
-         float(grad_scale), ptr(out), ptr(dhead), stream_ptr())
+    call("tdeed_loss2", ptr(head_out), B, T, ld, K1a, K1b, ptr(dataset), ptr(hard), ptr(soft), ptr(cls_w), displ_col,
+         ptr(labelD), float(grad_scale), ptr(out), ptr(dhead), stream_ptr())
     return out, dhead
+
+
+def loss2_soft(head_out, B, T, K1a, K1b, dataset, soft, cls_w, displ_col=-1, labelD=None, grad_scale=1.0):
+    return loss2(head_out, B, T, K1a, K1b, dataset, None, cls_w, displ_col, labelD, True, grad_scale, soft=soft)
 
 
 def heads_bwd(dout, x, w, need_dx=True):

@@ -250,8 +250,10 @@ def stem_wgrad(frames_u8, dz, crop=None, flip=False):
     N, _, H, W = frames_u8.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
     part, dw = _f32((N * ((dz.shape[1] + 15) // 16), 864), dz.device), _f32((32, 3, 3, 3), dz.device)
-    call("tdeed_stem_wgrad", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, int(flip),
-         ptr(dz), ptr(part), ptr(dw),
+    from .ops import _flip_args
+    fl, fmask = _flip_args(flip, N)
+    call("tdeed_stem_wgrad", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, fl,
+         ptr(fmask), ptr(dz), ptr(part), ptr(dw),
          dtype_code(dz.dtype), stream_ptr())
     return dw
 

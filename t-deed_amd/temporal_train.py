@@ -224,6 +224,70 @@ class TemporalStack:
             names.append("_pred_displ._fc_out")
         return names
 
+    def forward_heads(self, feat, drop_masks=None):
+        """Train-mode forward of the temporal stack: SGP pyramid, dropout (the given keep-masks), heads.
+        Returns (head_out (B*T, n_out) fp32, ctx for `backward_heads`)."""
+        enc, tape = self.pyramid_fwd(feat)
+        names = self._head_names()
+        sd = self.sd
+        ws, bs = [sd[n + ".weight"] for n in names], [sd[n + ".bias"] for n in names]
+        xs = [enc if drop_masks is None else B_.eltwise(enc, drop_masks[i], B_.MUL) for i in range(len(ws))]
+        outs = [ops.heads(xs[i], ws[i], bs[i]) for i in range(len(ws))]
+        head_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1).contiguous()
+        ctx = SimpleNamespace(tape=tape, names=names, ws=ws, xs=xs, drop_masks=drop_masks, shape=feat.shape)
+        return head_out, ctx
+
+    def head_layout(self):
+        """(n_cls, displ_col, double) of the head_out columns."""
+        names = self._head_names()
+        ws = [self.sd[n + ".weight"] for n in names]
+        double = len(names) - (1 if self.radi > 0 else 0) == 2
+        n_cls = sum(w_.shape[0] for w_ in ws) - (1 if self.radi > 0 else 0)
+        return n_cls, (n_cls if self.radi > 0 else -1), double
+
+    def loss_fwd_bwd(self, head_out, Bn, T, label, labelD=None, soft=None, fg_weight=5.0, grad_scale=1.0, dataset=None):
+        """Loss of model.py:308-319 (double head: 278-306) and its gradient w.r.t. head_out."""
+        n_cls, dcol, double = self.head_layout()
+        ld = labelD if self.radi > 0 else None
+        dev = head_out.device
+        if double:
+            names = self._head_names()
+            K1a, K1b = self.sd[names[0] + ".weight"].shape[0], self.sd[names[1] + ".weight"].shape[0]
+            key = ("2h", fg_weight, max(K1a, K1b))
+            if key not in self._cls_w:
+                self._cls_w[key] = torch.tensor([1.0] + [float(fg_weight)] * (max(K1a, K1b) - 1), dtype=torch.float32,
+                                                device=dev)
+            if soft is not None:
+                # mixup with the joint-dataset head (model.py:278-306 with 3-D labels): soft labels over the clip's own
+                # head slice; labels were built over the concatenated (K1a + K1b) columns
+                return ops.loss2_soft(head_out, Bn, T, K1a, K1b, dataset, soft, self._cls_w[key], displ_col=dcol,
+                                      labelD=ld, grad_scale=grad_scale)
+            return ops.loss2(head_out, Bn, T, K1a, K1b, dataset, label, self._cls_w[key], displ_col=dcol, labelD=ld,
+                             want_grad=True, grad_scale=grad_scale)
+        K1 = self.K1
+        if fg_weight not in self._cls_w:        # built once per weight: no host->device copy inside a captured step
+            self._cls_w[fg_weight] = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32, device=dev)
+        cls_w = self._cls_w[fg_weight]
+        loss = ops.loss(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld)
+        dhead = ops.loss_bwd(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld, grad_scale=grad_scale)
+        return loss, dhead
+
+    def backward_heads(self, ctx, dhead, grads):
+        """Backward of forward_heads: fills grads for every head / SGP parameter, returns d feat."""
+        Bn, T, C = ctx.shape
+        d_enc = None
+        col = 0
+        for i, nm in enumerate(ctx.names):
+            n_out = ctx.ws[i].shape[0]
+            dpart = dhead[:, col:col + n_out].contiguous()
+            col += n_out
+            dx, dw, db = ops.heads_bwd(dpart, ctx.xs[i], ctx.ws[i])
+            if ctx.drop_masks is not None:
+                dx = B_.eltwise(dx, ctx.drop_masks[i], B_.MUL)
+            d_enc = dx if d_enc is None else B_.eltwise(d_enc, dx, B_.ADD)
+            grads[nm + ".weight"], grads[nm + ".bias"] = dw, db
+        return self.pyramid_bwd(d_enc.view(Bn, T, C), ctx.tape, grads)
+
     def loss_and_grads(self, feat, label, labelD=None, soft=None, drop_masks=None, fg_weight=5.0, grad_scale=1.0,
                        dataset=None):
         """feat (B,T,C) in the activation dtype; label int64 (B*T,) or soft (B*T,K1) fp32; labelD fp32 (B*T,).
@@ -232,47 +296,8 @@ class TemporalStack:
         head (labels of dataset 2 already shifted, update_labels_2heads).
         Returns (loss scalar tensor [total, ce, mse], grads dict, d_feat)."""
         Bn, T, C = feat.shape
-        R = Bn * T
-        enc, tape = self.pyramid_fwd(feat)
-        names = self._head_names()
-        sd = self.sd
-        ws, bs = [sd[n + ".weight"] for n in names], [sd[n + ".bias"] for n in names]
-        xs = [enc if drop_masks is None else B_.eltwise(enc, drop_masks[i], B_.MUL) for i in range(len(ws))]
-        outs = [ops.heads(xs[i], ws[i], bs[i]) for i in range(len(ws))]
-        head_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1).contiguous()
-        double = len(names) - (1 if self.radi > 0 else 0) == 2
-        n_cls = sum(w_.shape[0] for w_ in ws) - (1 if self.radi > 0 else 0)
-        dcol = n_cls if self.radi > 0 else -1
-        ld = labelD if self.radi > 0 else None
-        if double:
-            if soft is not None:
-                raise NotImplementedError("mixup (soft labels) together with the joint-dataset double head")
-            K1a, K1b = ws[0].shape[0], ws[1].shape[0]
-            key = ("2h", fg_weight, max(K1a, K1b))
-            if key not in self._cls_w:
-                self._cls_w[key] = torch.tensor([1.0] + [float(fg_weight)] * (max(K1a, K1b) - 1), dtype=torch.float32,
-                                                device=feat.device)
-            loss, dhead = ops.loss2(head_out, Bn, T, K1a, K1b, dataset, label, self._cls_w[key], displ_col=dcol, labelD=ld,
-                                    want_grad=True, grad_scale=grad_scale)
-        else:
-            K1 = self.K1
-            if fg_weight not in self._cls_w:        # built once per weight: no host->device copy inside a captured step
-                self._cls_w[fg_weight] = torch.tensor([1.0] + [float(fg_weight)] * (K1 - 1), dtype=torch.float32,
-                                                      device=feat.device)
-            cls_w = self._cls_w[fg_weight]
-            loss = ops.loss(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld)
-            dhead = ops.loss_bwd(head_out, K1, cls_w, hard=label, soft=soft, displ_col=dcol, labelD=ld, grad_scale=grad_scale)
+        head_out, ctx = self.forward_heads(feat, drop_masks)
+        loss, dhead = self.loss_fwd_bwd(head_out, Bn, T, label, labelD, soft, fg_weight, grad_scale, dataset)
         grads = {}
-        d_enc = None
-        col = 0
-        for i, nm in enumerate(names):
-            n_out = ws[i].shape[0]
-            dpart = dhead[:, col:col + n_out].contiguous()
-            col += n_out
-            dx, dw, db = ops.heads_bwd(dpart, xs[i], ws[i])
-            if drop_masks is not None:
-                dx = B_.eltwise(dx, drop_masks[i], B_.MUL)
-            d_enc = dx if d_enc is None else B_.eltwise(d_enc, dx, B_.ADD)
-            grads[nm + ".weight"], grads[nm + ".bias"] = dw, db
-        d_feat = self.pyramid_bwd(d_enc.view(Bn, T, C), tape, grads)
+        d_feat = self.backward_heads(ctx, dhead, grads)
         return loss, grads, d_feat

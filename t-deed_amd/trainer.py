@@ -45,15 +45,24 @@ class TrainEngine:
         self.sched_step = 0
 
     # ------------------------------------------------------------------ forward + backward
-    def loss_and_grads(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None,
-                       fg_weight=5.0, dataset=None):
-        """frames (B,T,3,H,W) uint8 on the device; label int64 (B,T) or None with soft (B,T,K+1); labelD float (B,T).
-        crop = (top, left, h, w) (the one random crop the reference shares across B and T, model.py:115) or None.
-        Returns (loss[3] = total, ce, mse ; grads dict name -> fp32 tensor)."""
+    def _frame_flip(self, flip, Bn, T):
+        """bool (all frames) or per-clip flags (B,) -> what ops.stem takes: bool or per-frame uint8 flags (B*T,)."""
+        if isinstance(flip, torch.Tensor):
+            if flip.numel() != Bn:
+                raise ValueError(f"flip: one flag per clip expected ({flip.numel()} vs {Bn})")
+            return flip.to(self.device).to(torch.uint8).repeat_interleave(T).contiguous()
+        return bool(flip)
+
+    def forward_train(self, frames_u8, crop=None, flip=False, drop_masks=None):
+        """Train-mode forward (`Impl.forward` under .train(): batch-statistics BatchNorm with running-stat updates, dropout
+        through the given keep-masks, model.py:105-149).  frames (B,T,3,H,W) uint8 (or fp32 0..255) on the device;
+        crop = (top, left, h, w) shared by all clips (model.py:115); flip: bool or per-clip flags (B,) (model.py:83).
+        Returns (head_out (B*T, n_out) fp32, ctx for backward_train)."""
         sd, dt = self.state, self.dt
         Bn, T = frames_u8.shape[:2]
         fr = frames_u8.reshape(Bn * T, *frames_u8.shape[2:])
-        z0 = ops.stem(fr, sd["_features.stem.conv.weight"], self.one32, self.zero32, dt, crop=crop, flip=flip, relu=False)
+        fl = self._frame_flip(flip, Bn, T)
+        z0 = ops.stem(fr, sd["_features.stem.conv.weight"], self.one32, self.zero32, dt, crop=crop, flip=fl, relu=False)
         y0, bn0 = B_.bn_train(z0, sd["_features.stem.bn.weight"], sd["_features.stem.bn.bias"], BN_EPS, 0.1,
                               sd["_features.stem.bn.running_mean"], sd["_features.stem.bn.running_var"], relu=True)
         x = y0
@@ -61,22 +70,41 @@ class TrainEngine:
             x = blk.forward(x)
         hw = x.shape[1] * x.shape[2]
         feat = ops.avgpool_posenc(x, Bn, T, sd["temp_enc"])
-        loss, grads, d_feat = self.temporal.loss_and_grads(
-            feat, None if label is None else label.reshape(-1), labelD=None if labelD is None else labelD.reshape(-1).float(),
-            soft=None if soft is None else soft.reshape(-1, soft.shape[-1]).contiguous(), drop_masks=drop_masks,
-            fg_weight=fg_weight, dataset=dataset)
-        dx, d_enc = B_.avgpool_posenc_bwd(d_feat, hw)
-        grads["temp_enc"] = d_enc
-        dx = dx.view(x.shape)
-        for blk in reversed(self.blocks):
-            dx = blk.backward(dx, grads)
-        dz0, _, dw, db = B_.bn_train_bwd(z0, dx, y0, bn0, sd["_features.stem.bn.weight"], relu=True)
-        grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
-        grads["_features.stem.conv.weight"] = B_.stem_wgrad(fr, dz0, crop=crop, flip=flip)
+        head_out, tctx = self.temporal.forward_heads(feat, drop_masks)
         for k in sd:                                             # BatchNorm step counters (nn.BatchNorm.num_batches_tracked)
             if k.endswith("num_batches_tracked"):
                 sd[k] += 1
-        return loss, grads
+        from types import SimpleNamespace
+        return head_out, SimpleNamespace(fr=fr, crop=crop, flip=fl, z0=z0, y0=y0, bn0=bn0, x_shape=x.shape, hw=hw, tctx=tctx,
+                                         B=Bn, T=T)
+
+    def backward_train(self, ctx, dhead):
+        """Backward of forward_train from d(loss)/d(head_out): returns grads dict name -> fp32 tensor."""
+        sd = self.state
+        grads = {}
+        d_feat = self.temporal.backward_heads(ctx.tctx, dhead, grads)
+        dx, d_enc = B_.avgpool_posenc_bwd(d_feat, ctx.hw)
+        grads["temp_enc"] = d_enc
+        dx = dx.view(ctx.x_shape)
+        for blk in reversed(self.blocks):
+            dx = blk.backward(dx, grads)
+        dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
+        grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
+        grads["_features.stem.conv.weight"] = B_.stem_wgrad(ctx.fr, dz0, crop=ctx.crop, flip=ctx.flip)
+        return grads
+
+    def loss_and_grads(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None,
+                       fg_weight=5.0, dataset=None):
+        """frames (B,T,3,H,W) uint8 on the device; label int64 (B,T) or None with soft (B,T,K+1); labelD float (B,T).
+        crop = (top, left, h, w) (the one random crop the reference shares across B and T, model.py:115) or None.
+        Returns (loss[3] = total, ce, mse ; grads dict name -> fp32 tensor)."""
+        head_out, ctx = self.forward_train(frames_u8, crop, flip, drop_masks)
+        loss, dhead = self.temporal.loss_fwd_bwd(
+            head_out, ctx.B, ctx.T, None if label is None else label.reshape(-1).contiguous(),
+            labelD=None if labelD is None else labelD.reshape(-1).float().contiguous(),
+            soft=None if soft is None else soft.reshape(-1, soft.shape[-1]).contiguous(), fg_weight=fg_weight,
+            dataset=dataset)
+        return loss, self.backward_train(ctx, dhead)
 
     def repack(self):
         for blk in self.blocks:
@@ -84,15 +112,12 @@ class TrainEngine:
         self.temporal.repack()
 
     # ------------------------------------------------------------------ one optimiser step
-    def accumulate(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, scale=1.0,
-                   first=True, dataset=None, fg_weight=5.0):
-        """forward + backward of one (micro-)batch; its gradients (times `scale`) go into the flat gradient buffer
-        (overwriting it when `first`, adding otherwise: `acc_grad_iter` of the reference's step())."""
-        loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks, fg_weight, dataset)
+    def write_grads(self, grads, scale=1.0, first=True):
+        """Gradient write-out into the flat buffer (times `scale`; overwriting when `first`, adding otherwise:
+        `acc_grad_iter` of the reference's step()): multi-tensor copies, a handful of launches instead of one per tensor."""
         missing = set(self.params.index) - set(grads)
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
-        # gradient write-out into the flat buffer: multi-tensor copies (a handful of launches instead of one per tensor)
         keys = list(grads)
         dsts = [self.params.grad_view(k).view(grads[k].shape) for k in keys]
         srcs = [grads[k] for k in keys]
@@ -102,6 +127,12 @@ class TrainEngine:
                 self.params.grad.mul_(scale)
         else:
             torch._foreach_add_(dsts, srcs, alpha=scale)
+
+    def accumulate(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, scale=1.0,
+                   first=True, dataset=None, fg_weight=5.0):
+        """forward + backward of one (micro-)batch; its gradients (times `scale`) go into the flat gradient buffer."""
+        loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks, fg_weight, dataset)
+        self.write_grads(grads, scale, first)
         return loss
 
     def apply(self, lr=None, lr_factor=1.0, all_reduce=None):

@@ -193,6 +193,8 @@ def test_model_api_training_epochs_reduce_the_loss():
     loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD))] * 2
     val0 = m.epoch(loader[:1])
     rm0 = m.state_dict()["_features.s2.b1.conv2.bn.running_mean"].clone()
+    from tdeed_amd import augment
+    m._model.augment_fn = augment.crop_only          # over-fitting ONE batch: keep it the same batch every step
     optimizer, scaler = m.get_optimizer({"lr": 3e-4})
     assert scaler is None and isinstance(optimizer, torch.optim.Optimizer)
     steps = 40
@@ -270,6 +272,8 @@ def test_model_api_double_head_training_and_validation():
     labD = np.concatenate([l[1] for l in labs], 0)
     loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD), dataset=torch.tensor(ds))]
     v0 = m.epoch(loader)
+    from tdeed_amd import augment
+    m._model.augment_fn = augment.crop_only
     optimizer, _ = m.get_optimizer({"lr": 3e-4})
     losses = [m.epoch(loader, optimizer=optimizer) for _ in range(20)]
     assert np.isfinite(v0) and all(np.isfinite(losses)) and np.mean(losses[-3:]) < 0.6 * losses[0], (v0, losses)

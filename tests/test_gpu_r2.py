@@ -1,0 +1,438 @@
+"""Round-2 parity tests on the MI355X (through the C ABI): the hyper-parameter tuples of every shipped config, batch
+invariance at the bench batch, the full-length RegNetY-800MF train step (BASELINE configs[2]), the train-mode
+`Impl.forward`, per-clip flips and the train-time augmentation, label validation, mixup x double head, loading a
+checkpoint while an optimizer is alive.  -m gpu only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, model_state, t, max_abs, cfg_ns
+from tdeed_amd import synth, state_layout
+from tdeed_amd.regnet_spec import regnet_spec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (feature_arch, n_layers, sgp_ks, sgp_r, num_classes, radi) of the 14 files under /root/reference/config/*/ (duplicates
+# removed); clip_len is 100 in all of them, crop_dim 224 or -1.
+CONFIG_TUPLES = [
+    ("rny008_gsf", 2, 9, 4, 4, 1),      # FigureSkatingComp_big
+    ("rny002_gsf", 3, 5, 4, 4, 1),      # FigureSkatingComp_small
+    ("rny008_gsf", 3, 9, 4, 4, 1),      # FigureSkatingPerf_big
+    ("rny002_gsf", 3, 9, 2, 4, 1),      # FigureSkatingPerf_small
+    ("rny008_gsf", 3, 7, 4, 4, 2),      # FineDiving_big
+    ("rny002_gsf", 2, 7, 4, 4, 2),      # FineDiving_small
+    ("rny008_gsf", 3, 9, 4, 32, 0),     # FineGym_big
+    ("rny002_gsf", 3, 11, 4, 32, 0),    # FineGym_small
+    ("rny008_gsf", 3, 11, 4, 17, 3),    # SoccerNet_big
+    ("rny002_gsf", 3, 9, 4, 17, 3),     # SoccerNet_small
+    ("rny002_gsf", 2, 9, 4, 12, 4),     # SoccerNetBall_challenge1
+    ("rny008_gsf", 2, 9, 4, 12, 4),     # SoccerNetBall_challenge2
+    ("rny008_gsf", 3, 11, 4, 6, 1),     # Tennis_big
+    ("rny002_gsf", 3, 11, 2, 6, 1),     # Tennis_small
+]
+
+
+def _fwd(eng, clip, **kw):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        head, plan = eng.forward(t(clip).to(DEV), **kw)
+        st.synchronize()
+    return head.float().cpu(), plan
+
+
+@pytest.mark.parametrize("arch,n_layers,ks,r,K,radi", CONFIG_TUPLES)
+def test_forward_fp32_matches_oracle_on_every_shipped_hparam_tuple(arch, n_layers, ks, r, K, radi):
+    """fp32 forward at the shipped clip length (100) and 64x64 frames against the CPU oracle, tolerance 1e-3 on the
+    logits (BASELINE.json north_star)."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.engine import ForwardEngine
+    cfg = dict(feature_arch=arch, clip_len=100, crop_dim=None, n_layers=n_layers, sgp_ks=ks, sgp_r=r, num_classes=K,
+               radi_displacement=radi)
+    sd = model_state(cfg, 11)
+    clip = synth.uint8_clip(500 + ks + K, (1, 100, 3, 64, 64))
+    with torch.no_grad():
+        logits, displ, _ = O.forward(t(clip), sd, cfg, regnet_spec(arch))
+    head, _ = _fwd(ForwardEngine(cfg, sd, torch.float32, DEV), clip)
+    head = head.view(1, 100, -1)
+    assert head.shape[-1] == K + 1 + (1 if radi > 0 else 0)
+    assert max_abs(head[..., :K + 1], logits) < 1e-3
+    if radi > 0:
+        assert max_abs(head[..., K + 1], displ) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batch_of_8_equals_single_clip_forwards(dtype):
+    """BASELINE configs[1] geometry (200MF, L=100, 224x224, B=8): the per-clip logits of the bench batch equal the B=1
+    result of each clip (the sub-batch split / tile decomposition must not leak between clips)."""
+    from tdeed_amd.engine import ForwardEngine
+    meta, g = load_golden("finediving_small")
+    cfg = meta["cfg"]
+    sd = model_state(cfg, meta["seed_w"])
+    T, H, W = cfg["clip_len"], meta["H"], meta["W"]
+    B = 8 if dtype == torch.bfloat16 else 2
+    clips = np.concatenate([synth.uint8_clip(meta["seed_x"] + i, (1, T, 3, H, W)) for i in range(B)], 0)
+    eng = ForwardEngine(cfg, sd, dtype, DEV)
+    hb, plan = _fwd(eng, clips)
+    assert len(plan.subs) == 2                                    # the bench's two sub-batches on forked streams
+    hb = hb.view(B, T, -1).clone()
+    K1 = cfg["num_classes"] + 1
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for i in range(B):
+        h1, _ = _fwd(eng, clips[i:i + 1])
+        assert max_abs(h1.view(T, -1), hb[i]) <= tol, i
+    # clip 0 is the golden clip: the reference's own logits
+    err = max_abs(hb[0, :, :K1], g["logits"][0])
+    assert err < (1e-3 if dtype == torch.float32 else 0.08 * max(1.0, float(np.abs(g["logits"]).max())))
+
+
+def _oracle_train_loss(O, frames, sd, cfg, spec, lab, labD, crop=None, flip_clips=None):
+    x = frames.float() / 255.0
+    if crop is not None:
+        tp, lf, ch, cw = crop
+        x = x[..., tp:tp + ch, lf:lf + cw]
+    if flip_clips is not None:
+        x = torch.stack([xi.flip(-1) if f else xi for xi, f in zip(x, flip_clips)], 0)
+    mean = torch.tensor(O.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(O.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    x = (x - mean) / std
+    B, T = x.shape[:2]
+    f = O.regnet_features(x.reshape(B * T, *x.shape[2:]), sd, spec, T, "gsf", training=True)
+    f = f.reshape(B, T, -1) + sd["temp_enc"][None]
+    enc = O.ed_sgp_mixer(f, sd, cfg["n_layers"], cfg["clip_len"])
+    cls, displ = O.heads(enc, sd, cfg["radi_displacement"])
+    return O.loss_fn(cls, lab, displ, labD), cls, displ
+
+
+def test_cfg3_full_length_800mf_train_step_matches_autograd():
+    """BASELINE configs[2] at its real clip geometry (RegNetY-800MF, n_layers=3, L=100, 224x224; B=2 instead of 16): loss
+    and gradients of one train-mode forward/backward in fp32 against autograd on the CPU oracle, every tensor checked."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny008_gsf", clip_len=100, crop_dim=224, n_layers=3, sgp_ks=7, sgp_r=4, num_classes=4,
+               radi_displacement=2)
+    B, T, H, W = 2, 100, 224, 224
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 21).items()}
+    frames = t(synth.uint8_clip(701, (B, T, 3, H, W)))
+    lab_np, labD_np = synth.labels(702, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.2)
+    lab, labD = t(lab_np).long(), t(labD_np).float()
+    par = [k for k in sd0 if state_layout.is_parameter(k)]
+    sdr = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
+    ref, _, _ = _oracle_train_loss(O, frames, sdr, cfg, regnet_spec(cfg["feature_arch"]), lab, labD)
+    ref.backward()
+    eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.float32, lr=1e-4)
+    loss, grads = eng.loss_and_grads(frames.to(DEV), lab.to(DEV), labD.to(DEV))
+    torch.cuda.synchronize()
+    assert set(grads) == set(par)
+    assert abs(float(loss[0]) - float(ref.detach())) < 5e-4 * max(1.0, abs(float(ref.detach())))
+    ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in par])
+    gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in par])
+    gn = float(gr.norm())
+    assert float((ga - gr).norm()) / gn < 5e-3
+    worst = max(((float((grads[k].detach().cpu().double() - sdr[k].grad.double()).norm())
+                  - 3e-2 * float(sdr[k].grad.double().norm())) / gn, k) for k in par)
+    assert worst[0] <= 2e-4, worst
+    # the bf16 engine (the measured mode) on the same batch: loss within 5 %, gradient direction per tensor group
+    eng16 = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.bfloat16, lr=1e-4)
+    loss16, g16 = eng16.loss_and_grads(frames.to(DEV), lab.to(DEV), labD.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss16[0]) - float(ref.detach())) < 5e-2 * max(1.0, abs(float(ref.detach())))
+    for grp in ("_features.s1", "_features.s2", "_features.s3", "_features.s4", "_temp_fine", "_pred"):
+        ks = [k for k in par if k.startswith(grp)]
+        a = torch.cat([g16[k].detach().cpu().double().reshape(-1) for k in ks])
+        b = torch.cat([sdr[k].grad.double().reshape(-1) for k in ks])
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        ratio = float(a.norm() / b.norm())
+        assert cos > 0.9 and 0.7 < ratio < 1.4, (grp, cos, ratio)
+
+
+def test_bf16_train_step_per_tensor_direction():
+    """bf16 training path, per parameter tensor: cosine > 0.95 and norm ratio within 0.7..1.4 against autograd for every
+    tensor whose gradient is not in the noise (a toy size with enough BatchNorm samples: T=8, 96x96, B=4)."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny002_gsf", clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 4, 8, 96, 96
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 31).items()}
+    frames = t(synth.uint8_clip(801, (B, T, 3, H, W)))
+    lab_np, labD_np = synth.labels(802, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long(), t(labD_np).float()
+    par = [k for k in sd0 if state_layout.is_parameter(k)]
+    sdr = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
+    ref, _, _ = _oracle_train_loss(O, frames, sdr, cfg, regnet_spec(cfg["feature_arch"]), lab, labD)
+    ref.backward()
+    eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.bfloat16, lr=1e-3)
+    loss, grads = eng.loss_and_grads(frames.to(DEV), lab.to(DEV), labD.to(DEV))
+    torch.cuda.synchronize()
+    gn = float(torch.cat([sdr[k].grad.double().reshape(-1) for k in par]).norm())
+    bad = []
+    for k in par:
+        a, b = grads[k].detach().cpu().double().reshape(-1), sdr[k].grad.double().reshape(-1)
+        if float(b.norm()) < 2e-3 * gn:                      # tensors whose whole gradient is below the bf16 noise floor
+            assert float(a.norm()) < 1e-2 * gn, k
+            continue
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        ratio = float(a.norm() / b.norm())
+        if not (cos > 0.95 and 0.7 < ratio < 1.4):
+            bad.append((k, round(cos, 3), round(ratio, 3)))
+    assert not bad, bad
+
+
+def test_per_clip_flip_in_stem_and_its_weight_gradient():
+    """RandomHorizontalFlip per clip (model.py:83): the per-frame flip flags of tdeed_stem_fwd / tdeed_stem_wgrad equal
+    running flipped and unflipped clips separately."""
+    from tdeed_amd import ops, ops_bwd
+    N, H, W = 6, 40, 48
+    fr = t(synth.uint8_clip(900, (1, N, 3, H, W)))[0].to(DEV)
+    w = t(np.random.RandomState(0).randn(32, 3, 3, 3).astype(np.float32)).to(DEV)
+    one, zero = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+    mask = torch.tensor([1, 0, 0, 1, 1, 0], dtype=torch.uint8, device=DEV)
+    crop = (2, 4, 32, 40)
+    for dt in (torch.float32, torch.bfloat16):
+        y = ops.stem(fr, w, one, zero, dt, crop=crop, flip=mask, relu=False)
+        y1 = ops.stem(fr, w, one, zero, dt, crop=crop, flip=True, relu=False)
+        y0 = ops.stem(fr, w, one, zero, dt, crop=crop, flip=False, relu=False)
+        want = torch.where(mask.view(-1, 1, 1, 1).bool(), y1, y0)
+        assert torch.equal(y, want)
+        dz = torch.randn(y.shape, device=DEV).to(dt)
+        g = ops_bwd.stem_wgrad(fr, dz, crop=crop, flip=mask)
+        m = mask.bool()
+        g_ref = ops_bwd.stem_wgrad(fr[m].contiguous(), dz[m].contiguous(), crop=crop, flip=True) + \
+            ops_bwd.stem_wgrad(fr[~m].contiguous(), dz[~m].contiguous(), crop=crop, flip=False)
+        assert max_abs(g, g_ref) < 1e-3 * float(g_ref.abs().max())
+
+
+@pytest.mark.parametrize("f32_in", [False, True])
+def test_augment_kernels_match_oracle(f32_in):
+    """ColorJitter(hue / saturation / brightness / contrast) + GaussianBlur(5) per clip (model.py:76-83) against the
+    oracle's restatement of the torchvision float ops, in every on/off combination that matters."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd import augment
+    B, T, H, W = 6, 3, 44, 52
+    crop = (3, 5, 36, 40)
+    fr = t(synth.uint8_clip(910, (B, T, 3, H, W)))
+    prm = torch.tensor([[0.0, 1.0, 1.0, 1.0, 0.0, 0, 0, 0],          # identity
+                        [0.13, 1.0, 1.0, 1.0, 0.0, 0, 0, 0],         # hue only
+                        [-0.2, 0.75, 1.15, 0.8, 1.3, 0, 0, 0],       # everything
+                        [0.0, 1.2, 0.7, 1.0, 0.0, 0, 0, 0],          # saturation + brightness
+                        [0.0, 1.0, 1.0, 1.19, 0.1, 0, 0, 0],         # contrast + the narrowest blur
+                        [0.2, 1.0, 1.0, 1.0, 2.0, 0, 0, 0]], dtype=torch.float32)
+    src = fr.float() if f32_in else fr
+    out = augment.apply(src.to(DEV), prm, crop).cpu()
+    assert out.shape == (B, T, 3, 36, 40)
+    x01 = fr.float()[..., 3:39, 5:45] / 255.0
+    for b in range(B):
+        ref = O.augment_clip(x01[b], prm[b]) * 255.0
+        assert max_abs(out[b], ref) < 2e-2, (b, max_abs(out[b], ref))      # 0..255 scale: < 1e-4 of the range
+    assert torch.equal(out[0], fr.float()[0, ..., 3:39, 5:45])
+
+
+def test_train_mode_forward_is_callable_and_matches_the_oracle():
+    """`Impl.forward(x, y, inference=False)` under .train() (model.py:105-149): batch-statistics BatchNorm with running-stat
+    updates, dropout, random crop + per-clip augmentation.  With the augmentation hook reduced to the crop and dropout
+    masks of all ones the logits equal the oracle's train-mode forward; with the built-in augmentation they equal the
+    oracle on the augmented clips (same seeded draws)."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd import augment
+    from tdeed_amd.model import TDEEDModel
+    cfg = dict(feature_arch="rny002_gsf", clip_len=6, crop_dim=64, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 3, 6, 72, 80
+    m = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    m._model._train_dtype = torch.float32
+    sd0 = {k: t(v) for k, v in model_state(cfg, 41).items()}
+    m.load(sd0)
+    frames = t(synth.uint8_clip(920, (B, T, 3, H, W)))
+    spec = regnet_spec(cfg["feature_arch"])
+    m._model.train()
+    # ---- (a) the crop only
+    seen = {}
+
+    def crop_only(x, crop):
+        seen["crop"] = crop
+        tp, lf, ch, cw = crop
+        return x[..., tp:tp + ch, lf:lf + cw].contiguous()
+    m._model.augment_fn = crop_only
+    rm0 = m.state_dict()["_features.s1.b1.conv1.bn.running_mean"].clone()
+    torch.manual_seed(5)
+    pred, y = m._model(frames.float(), y="labels", inference=False)           # callers pass .float() frames
+    torch.cuda.synchronize()
+    assert y == "labels" and set(pred) >= {"im_feat", "displ_feat"} and pred["im_feat"].shape == (B, T, 4)
+    assert not torch.equal(m.state_dict()["_features.s1.b1.conv1.bn.running_mean"], rm0)
+    # dropout active: a second call differs; the deterministic part is checked through the engine with masks = None
+    eng = m._model.train_engine()
+    head, _ = eng.forward_train(frames.to(DEV), crop=seen["crop"], flip=False, drop_masks=None)
+    with torch.no_grad():
+        _, cls, displ = _oracle_train_loss(O, frames, sd0, cfg, spec, torch.zeros((B, T), dtype=torch.long), None,
+                                           crop=seen["crop"])
+    head = head.cpu().view(B, T, -1)
+    assert max_abs(head[..., :4], cls) < 1e-3 and max_abs(head[..., 4], displ) < 1e-3
+    # ---- (b) built-in augmentation, seeded: same draws on both sides
+    m._model.augment_fn = None
+    torch.manual_seed(123)
+    gen_state = torch.get_rng_state()
+    pred, _ = m._model(frames, inference=False)
+    torch.cuda.synchronize()
+    torch.set_rng_state(gen_state)
+    tp = int(torch.randint(0, H - 64 + 1, size=(1,)).item())
+    lf = int(torch.randint(0, W - 64 + 1, size=(1,)).item())
+    prm, flip = augment.draw_params(B)
+    ctx = m._model._train_ctx
+    x01 = frames.float()[..., tp:tp + 64, lf:lf + 64] / 255.0
+    xa = torch.stack([O.augment_clip(x01[b], prm[b]) for b in range(B)], 0)
+    xa = torch.stack([xi.flip(-1) if f else xi for xi, f in zip(xa, flip.tolist())], 0)
+    mean = torch.tensor(O.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(O.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    with torch.no_grad():
+        z0_ref = torch.nn.functional.conv2d(((xa - mean) / std).reshape(B * T, 3, 64, 64), sd0["_features.stem.conv.weight"],
+                                            stride=2, padding=1).permute(0, 2, 3, 1)
+    assert max_abs(ctx.z0.float().cpu(), z0_ref) < 2e-3 * max(1.0, float(z0_ref.abs().max()))
+    # ---- train() + inference=True: centre crop, no augmentation, still batch statistics
+    pred_i, _ = m._model(frames, inference=True)
+    assert pred_i["im_feat"].shape == (B, T, 4) and bool(torch.isfinite(pred_i["im_feat"]).all())
+    # ---- eval() + inference=False is the one combination that is refused, loudly
+    m._model.eval()
+    with pytest.raises(NotImplementedError):
+        m._model(frames, inference=False)
+
+
+def test_augmentation_draws_follow_the_documented_order():
+    """RNG contract of augment.draw_params (host): consumes the CPU generator in torchvision's order."""
+    from tdeed_amd import augment
+    g = torch.Generator().manual_seed(7)
+    prm, flip = augment.draw_params(5, g)
+    g2 = torch.Generator().manual_seed(7)
+    for i in range(5):
+        row = [0.0, 1.0, 1.0, 1.0, 0.0]
+        for slot, (lo, hi) in enumerate([(-0.2, 0.2), (0.7, 1.2), (0.7, 1.2), (0.7, 1.2)]):
+            if not (0.25 < float(torch.rand(1, generator=g2))):
+                torch.randperm(4, generator=g2)
+                row[slot] = float(torch.empty(1).uniform_(lo, hi, generator=g2))
+        if not (0.25 < float(torch.rand(1, generator=g2))):
+            row[4] = float(torch.empty(1).uniform_(0.1, 2.0, generator=g2))
+        f = float(torch.rand(1, generator=g2)) < 0.5
+        assert prm[i, :5].tolist() == pytest.approx(row) and bool(flip[i]) == f
+
+
+def test_out_of_range_labels_turn_the_loss_into_nan_without_faulting():
+    from tdeed_amd import ops
+    rows, K1 = 64, 5
+    head = torch.randn(rows, K1 + 1, device=DEV)
+    w = torch.tensor([1.0, 5, 5, 5, 5], device=DEV)
+    lab = torch.randint(0, K1, (rows,), device=DEV)
+    ok = ops.loss(head, K1, w, hard=lab)
+    assert bool(torch.isfinite(ok).all())
+    bad = lab.clone()
+    bad[3] = K1 + 40
+    bad[9] = -1
+    out = ops.loss(head, K1, w, hard=bad)
+    dh = ops.loss_bwd(head, K1, w, hard=bad)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[0])) and bool(torch.isfinite(dh).all())
+    with pytest.raises(TypeError):
+        ops.loss(head, K1, w, hard=lab.int())
+    with pytest.raises(ValueError):
+        ops.loss(head, K1, w, hard=lab[:-1])
+    # double head: a label outside its clip's slice
+    B, T, Ka, Kb = 2, 32, 5, 4
+    head2 = torch.randn(B * T, Ka + Kb + 1, device=DEV)
+    ds = torch.tensor([1, 2], device=DEV)
+    lab2 = torch.cat([torch.randint(0, Ka, (T,)), Ka + torch.randint(0, Kb, (T,))]).to(DEV)
+    w2 = torch.tensor([1.0, 5, 5, 5, 5], device=DEV)
+    o, _ = ops.loss2(head2, B, T, Ka, Kb, ds, lab2, w2)
+    assert bool(torch.isfinite(o).all())
+    lab2b = lab2.clone()
+    lab2b[T + 1] = 1                 # a dataset-1 label in a dataset-2 clip
+    o, d = ops.loss2(head2, B, T, Ka, Kb, ds, lab2b, w2, want_grad=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(o[0])) and bool(torch.isfinite(d).all())
+
+
+def test_double_head_soft_label_loss_matches_torch():
+    """mixup x joint-dataset head: the 3-D label branch of model.py:286-300 (soft labels over the clip's own slice)."""
+    from tdeed_amd import ops
+    import torch.nn.functional as F
+    B, T, Ka, Kb = 3, 20, 5, 7
+    ld = Ka + Kb + 1
+    g = torch.Generator().manual_seed(3)
+    head = torch.randn(B * T, ld, generator=g)
+    soft = torch.rand(B * T, Ka + Kb, generator=g)
+    ds = torch.tensor([1, 2, 2])
+    for i in range(B):
+        sl = slice(0, Ka) if ds[i] == 1 else slice(Ka, Ka + Kb)
+        blk = soft[i * T:(i + 1) * T]
+        other = torch.ones(Ka + Kb, dtype=torch.bool)
+        other[sl] = False
+        blk[:, other] = 0
+        blk[:, sl] /= blk[:, sl].sum(-1, keepdim=True)
+    labD = torch.randn(B * T, generator=g)
+    w = torch.tensor([1.0] + [5.0] * (max(Ka, Kb) - 1))
+    hr = head.clone().requires_grad_(True)
+    ref = 0.0
+    for i in range(B):
+        rows = slice(i * T, (i + 1) * T)
+        if ds[i] == 1:
+            ref = ref + F.cross_entropy(hr[rows, :Ka], soft[rows, :Ka], weight=w[:Ka]) / B
+        else:
+            ref = ref + F.cross_entropy(hr[rows, Ka:Ka + Kb], soft[rows, Ka:], weight=w[:Kb]) / B
+    ref = ref + F.mse_loss(hr[:, ld - 1], labD)
+    ref.backward()
+    out, dh = ops.loss2_soft(head.to(DEV), B, T, Ka, Kb, ds.to(DEV), soft.to(DEV).contiguous(), w.to(DEV),
+                             displ_col=ld - 1, labelD=labD.to(DEV))
+    assert abs(float(out[0]) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert max_abs(dh, hr.grad) < 1e-6 + 1e-4 * float(hr.grad.abs().max())
+
+
+def test_mixup_with_double_head_trains():
+    from tdeed_amd.model import TDEEDModel
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    m = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    k1a, k1b = cfg["num_classes"] + 1, 6
+    m._model.update_pred_head([k1a, k1b])
+    m._num_classes = k1a + k1b                                   # train_tdeed.py:148
+    B, T = 2, cfg["clip_len"]
+    clip = synth.uint8_clip(1, (B, T, 3, meta["H"], meta["W"]))
+    clip2 = synth.uint8_clip(2, (B, T, 3, meta["H"], meta["W"]))
+    ds = [1, 2]
+    lab = np.stack([synth.labels(30 + i, 1, T, (k1a if ds[i] == 1 else k1b) - 1, 2, fg_frac=0.3)[0][0] for i in range(B)])
+    lab2 = np.stack([synth.labels(40 + i, 1, T, (k1a if ds[i] == 1 else k1b) - 1, 2, fg_frac=0.3)[0][0] for i in range(B)])
+    labD = synth.labels(50, B, T, 3, cfg["radi_displacement"])[1]
+    # label2 arrives un-shifted from the loader like label; the reference shifts only `label` (model.py:219-221) and adds
+    # label2's one-hot at its raw index (model.py:250): dataset-2 clips therefore need label2 given in shifted form to
+    # stay inside their slice -- the loader of the joint dataset pairs clips of the same dataset (frame.py:655-659)
+    lab2s = lab2.copy()
+    lab2s[1] += k1a
+    loader = [dict(frame=t(clip), label=t(lab), labelD=t(labD), frame2=t(clip2), label2=t(lab2s), labelD2=t(labD),
+                   dataset=torch.tensor(ds))]
+    opt, _ = m.get_optimizer({"lr": 3e-4})
+    losses = [m.epoch(loader, optimizer=opt) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+
+
+def test_load_after_get_optimizer_refreshes_the_packed_weights():
+    """load() after get_optimizer() must reach the train engine's packed copies (bf16 casts, transposes, MFMA
+    fragments), not only the flat master buffer."""
+    from tdeed_amd.model import TDEEDModel
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    B, T = meta["B"], cfg["clip_len"]
+    clip = t(synth.uint8_clip(meta["seed_x"], (B, T, 3, meta["H"], meta["W"]))).to(DEV)
+    lab, labD = synth.labels(3, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
+    lab, labD = t(lab).to(DEV), t(labD).float().to(DEV)
+    ck = {k: t(v) for k, v in model_state(cfg, 77).items()}
+
+    def loss_of(model):
+        eng = model._model.train_engine()
+        out = eng.loss_and_grads(clip, lab, labD)[0]
+        torch.cuda.synchronize()
+        return float(out[0])
+    a = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    a.get_optimizer({"lr": 1e-3})                    # engine packs the synthetic init
+    a.load(ck)                                       # ... then the checkpoint arrives
+    b = TDEEDModel(device=DEV, args=cfg_ns(cfg))
+    b.load(ck)
+    b.get_optimizer({"lr": 1e-3})
+    la, lb = loss_of(a), loss_of(b)
+    assert abs(la - lb) < 1e-6 * max(1.0, abs(lb)), (la, lb)
