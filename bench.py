@@ -1,17 +1,21 @@
 """Headline benchmark: clips/s of the T-DEED forward (BASELINE.json configs[1]: RegNetY-200MF + GSF + SGP,
 L=100, 224x224, batch 8 per GPU, bf16 inference) on N MI355X, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --mode train --workload rny008_b16          # BASELINE configs[2]: one optimisation step
 
 A step = one pass of the whole hot path (uint8 clips resident in HBM -> per-frame logits) over one batch
 of B synthetic clips per GPU.  Clips shard over ranks with no data-path collective (inference), so
-scaling is weak: value = N * B * K / max-over-ranks(time).  Rank 0 prints ONE JSON line.
+scaling is weak: value = N * B * K / max-over-ranks(time).  W untimed warm-up steps, then `--repeats` timed regions of
+EXACTLY K steps each, every one bracketed by barrier + device synchronisation on both sides; the line reports the
+MEDIAN region (all regions are listed in `ms_per_step_repeats`).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,13 +31,51 @@ CONFIGS = {
     # BASELINE.json configs[1] -- the configuration the metric is quoted on
     "rny002_b8": dict(cfg=dict(feature_arch="rny002_gsf", clip_len=100, crop_dim=224, n_layers=2, sgp_ks=7, sgp_r=4,
                                num_classes=4, radi_displacement=2), B=8, H=224, W=224),
+    # configs[2] (train step) / configs[3] per-GPU share is rny008 at B=8
     "rny008_b16": dict(cfg=dict(feature_arch="rny008_gsf", clip_len=100, crop_dim=224, n_layers=3, sgp_ks=7, sgp_r=4,
                                 num_classes=4, radi_displacement=2), B=16, H=224, W=224),
+    "rny008_b8": dict(cfg=dict(feature_arch="rny008_gsf", clip_len=100, crop_dim=224, n_layers=3, sgp_ks=7, sgp_r=4,
+                               num_classes=4, radi_displacement=2), B=8, H=224, W=224),
+    # configs[4] per-GPU share: SoccerNetBall hyper-parameters at T=250
     "snb_t250_b4": dict(cfg=dict(feature_arch="rny008_gsf", clip_len=250, crop_dim=None, n_layers=2, sgp_ks=9, sgp_r=4,
                                  num_classes=12, radi_displacement=4), B=4, H=224, W=224),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {torch.bfloat16: 2500.0, torch.float32: 157.3}
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+
+
+def git_head():
+    from tdeed_amd import buildinfo
+    return buildinfo.head()
+
+
+def timed_regions(run, steps, repeats, dev, streams):
+    """`repeats` regions of exactly `steps` steps.  Per region: barrier + synchronize, host clock, HIP events on the
+    launching streams (start on every stream before the first step, end after the last), synchronize + barrier.
+    Returns (wall seconds per region [max over ranks], event ms per region [this rank])."""
+    walls, evs = [], []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        tdist.barrier()
+        torch.cuda.synchronize()
+        starts = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        t0 = time.perf_counter()
+        for s, e in zip(streams, starts):
+            e.record(s)
+        run(steps)
+        for s, e in zip(streams, ends):
+            e.record(s)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        walls.append(tdist.max_over_ranks(el, device=dev))
+        tdist.barrier()
+        # device time of the region: first start -> last end
+        t_end = max(starts[0].elapsed_time(e) for e in ends)
+        t_beg = min(starts[0].elapsed_time(s) for s in starts)
+        evs.append(t_end - t_beg)
+    return walls, evs
 
 
 def kernel_profile(eng, plan, reps=3):
@@ -70,25 +112,62 @@ def kernel_profile(eng, plan, reps=3):
     return agg, sgp_ms_acc / reps
 
 
-def cpu_baseline():
+def sgp_stage_time(plan, reps=20):
+    """Device time of the SGP encoder-decoder alone (the launches named _temp_fine.*), back to back on one stream,
+    first sub-batch only and scaled: a direct measurement of the stage, not a sum of padded event intervals."""
+    st = torch.cuda.current_stream()
+    out = []
+    for sub in plan.subs:
+        steps = [s for s in sub.steps if s.name.startswith("_temp_fine.")]
+        for s in steps:
+            s.fn()
+        st.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        for _ in range(reps):
+            for s in steps:
+                s.fn()
+        b.record(st)
+        st.synchronize()
+        out.append((a.elapsed_time(b) / reps, len(steps)))
+    return out
+
+
+def cpu_baseline(engs=None, dev=None):
     """The oracle (our CPU port of the reference forward) timed on this host: BASELINE.json configs[0]
-    = FineDiving_small, 1 synthetic clip, fp32, all host cores.  Bounded: 1 warm-up + 3 timed clips."""
+    = FineDiving_small, 1 synthetic clip, fp32, all host cores.  Bounded: 1 warm-up + 3 timed clips.
+    Also the checker of this run's logits: the fp32 and bf16 engines run the same clip with the same weights."""
     from oracle import tdeed_oracle as O
     from tdeed_amd.regnet_spec import regnet_spec
     c = CONFIGS["rny002_b8"]["cfg"]
-    sd = O.as_torch_state(synth.make_state(state_layout.model_state_shapes(c), 0))
-    clip = torch.from_numpy(synth.uint8_clip(1000, (1, 100, 3, 224, 224)))
+    sd_np = synth.make_state(state_layout.model_state_shapes(c), 0)
+    sd = O.as_torch_state(sd_np)
+    clip_np = synth.uint8_clip(1000, (1, 100, 3, 224, 224))
+    clip = torch.from_numpy(clip_np)
     spec = regnet_spec(c["feature_arch"])
     ts = []
     with torch.no_grad():
         for i in range(4):
             t0 = time.perf_counter()
-            O.forward(clip, sd, c, spec)
+            logits, displ, _ = O.forward(clip, sd, c, spec)
             ts.append(time.perf_counter() - t0)
     best = sorted(ts[1:])[len(ts[1:]) // 2]
-    return dict(value=round(1.0 / best, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
-                sample="FineDiving_small forward, 1 synthetic clip (100x3x224x224), fp32, median of 3 after 1 warm-up",
-                sec_per_clip=round(best, 4))
+    res = dict(value=round(1.0 / best, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+               sample="FineDiving_small forward, 1 synthetic clip (100x3x224x224), fp32, median of 3 after 1 warm-up",
+               sec_per_clip=round(best, 4))
+    errs = {}
+    if dev is not None:
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+                eng = ForwardEngine(c, sd_np, dt, dev)
+                head, _ = eng.forward(clip.to(dev))
+                st.synchronize()
+                h = head.float().cpu().view(1, 100, -1)
+                errs[name] = max(float((h[..., :5] - logits).abs().max()), float((h[..., 5] - displ).abs().max()))
+                del eng
+        errs["logit_abs_max"] = float(logits.abs().max())
+    return res, errs
 
 
 def _dist_setup():
@@ -102,16 +181,27 @@ def _dist_setup():
     return rank, local, world, f"cuda:{local_dev}"
 
 
-def main_train(a):
-    """BASELINE.json configs[2]/[3]-style measurement: optimisation steps per second of the training path.
-    A step = train-mode forward + CE/MSE loss + full backward + (N > 1: one RCCL all-reduce of the flat fp32 gradient
-    buffer) + fused AdamW, on synthetic uint8 clips resident in HBM, dropout masks fixed."""
+# ----------------------------------------------------------------------------------------------------- training step
+def forward_layer_bytes(cfg, B, H, W, dt, dev):
+    """Layer-granular algorithmic bytes of ONE forward of this geometry (every fused layer reads its
+    inputs once and writes its output once, weights once): the sum of engine.Step.bytes over an unfused-front plan."""
+    sd = synth.make_state(state_layout.model_state_shapes(cfg), 0)
+    eng = ForwardEngine(cfg, sd, dt, dev, use_graph=False, n_split=1)
+    plan = eng.plan(B, H, W)
+    b, f = sum(s.bytes for s in plan.steps), sum(s.flops for s in plan.steps)
+    del eng, plan
+    torch.cuda.empty_cache()
+    return b, f
+
+
+def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use_graph=True, want_cpu=False):
+    """Optimisation steps of the training path on synthetic uint8 clips resident in HBM: train-mode forward + CE/MSE loss
+    + full backward + (N > 1: gradient all-reduce over RCCL) + fused AdamW; dropout masks fixed."""
     from tdeed_amd.trainer import TrainEngine
     from tdeed_amd.regnet_spec import regnet_spec
-    rank, local, world, dev = _dist_setup()
-    wl = CONFIGS[a.workload]
+    wl = CONFIGS[workload]
     cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
     T = cfg["clip_len"]
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 0).items()}
     eng = TrainEngine(cfg, sd, dt, dev, lr=1e-4)
@@ -121,34 +211,83 @@ def main_train(a):
     labD = torch.from_numpy(labD_np).float().to(dev) if cfg["radi_displacement"] else None
     C = regnet_spec(cfg["feature_arch"]).feat_dim
     masks = [((torch.rand((B, T, C), device=dev) >= 0.5).to(dt) * 2.0) for _ in range(2 if cfg["radi_displacement"] else 1)]
-    ar = tdist.all_reduce_mean_ if world > 1 else None
-    if a.no_graph:
-        step = lambda: eng.step(frames, lab, labD, drop_masks=masks, all_reduce=ar)                      # noqa: E731
-    else:
-        hnd = eng.build_graph(B, H, W)
-        step = lambda: eng.step_graph(hnd, frames, lab, labD, drop_masks=masks, all_reduce=ar)           # noqa: E731
-    for _ in range(max(a.warmup, 1)):
+    step = eng.make_step(B, H, W, frames, lab, labD, masks, use_graph=use_graph, world=world)
+    for _ in range(max(warmup, 1)):
         step()
-    torch.cuda.synchronize()
-    tdist.barrier()
-    torch.cuda.synchronize()
+    st = torch.cuda.current_stream()
+    loss_box = {}
+
+    def run(n):
+        for _ in range(n):
+            loss_box["l"] = step()
+    walls, evs = timed_regions(run, steps, repeats, dev, [st])
+    el = statistics.median(walls)
+    fb, ff = forward_layer_bytes(cfg, B, H, W, dt, dev)
+    ms = el / steps * 1e3
+    # algorithmic bytes of a train step at layer granularity: the forward's maps move once in the forward, once in the
+    # input-gradient pass (dy in, dx out) and once in the weight-gradient pass (dy and x in): 3x the forward's bytes
+    # (optimizer state adds 16 B per parameter).  The same convention as `roofline_step` of the forward.
+    tb = 3 * fb + 16 * eng.params.numel
+    rec = dict(workload=f"{workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']}, L={T}, {H}x{W}, "
+                        f"batch {B}/GPU, training step (train-mode fwd + loss + bwd + AdamW), random-init weights",
+               value=round(world * B * steps / el, 2), unit="clips/s", ms_per_step=round(ms, 3),
+               ms_per_step_repeats=[round(w / steps * 1e3, 3) for w in walls], steps=steps, repeats=repeats, dtype=dtype,
+               hip_graph=bool(use_graph), grad_buffer_mb=round(eng.params.numel * 4 / 2 ** 20, 1),
+               final_loss=round(float(loss_box["l"][0]), 4),
+               parallelism=f"dp{world}" + (" (RCCL all-reduce of the flat fp32 gradient buffer, bucketed, overlapped "
+                                           "with the backward)" if world > 1 else ""),
+               roofline=dict(bound="hbm", kernel="whole step (layer-granular algorithmic bytes: 3 x forward + optimizer)",
+                             algorithmic_bytes=int(tb), achieved=round(tb / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=round(tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                             flops=int(3 * ff), tflops=round(3 * ff / (ms * 1e-3) / 1e12, 1)),
+               cpu_baseline=None)
+    if want_cpu and rank == 0:
+        rec["cpu_baseline"] = cpu_train_baseline()
+    del eng, step
+    torch.cuda.empty_cache()
+    return rec
+
+
+def cpu_train_baseline():
+    """The oracle's training step (train-mode forward + CE/MSE + autograd backward) on the host cores: FineDiving_small
+    hyper-parameters, ONE synthetic clip of 100 frames at 224x224, fp32; bounded to one warm-up-free pass (~10-30 s)."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.regnet_spec import regnet_spec
+    c = CONFIGS["rny002_b8"]["cfg"]
+    sd0 = O.as_torch_state(synth.make_state(state_layout.model_state_shapes(c), 0))
+    par = [k for k in sd0 if state_layout.is_parameter(k)]
+    sd = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
+    clip = torch.from_numpy(synth.uint8_clip(1000, (1, 100, 3, 224, 224)))
+    lab_np, labD_np = synth.labels(5, 1, 100, c["num_classes"], c["radi_displacement"])
+    spec = regnet_spec(c["feature_arch"])
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
-    tdist.barrier()
+    x = O.preprocess(clip, c["crop_dim"])
+    f = O.regnet_features(x.reshape(100, *x.shape[2:]), sd, spec, 100, "gsf", training=True).reshape(1, 100, -1)
+    enc = O.ed_sgp_mixer(f + sd["temp_enc"][None], sd, c["n_layers"], 100)
+    cls, dsp = O.heads(enc, sd, c["radi_displacement"])
+    loss = O.loss_fn(cls, torch.from_numpy(lab_np), dsp, torch.from_numpy(labD_np).float())
+    loss.backward()
+    el = time.perf_counter() - t0
+    return dict(value=round(1.0 / el, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                sample="FineDiving_small training step (train-mode forward + loss + autograd backward, no optimizer), "
+                       "1 synthetic clip (100x3x224x224), fp32, one pass", sec_per_clip=round(el, 3))
+
+
+def main_train(a):
+    rank, local, world, dev = _dist_setup()
+    rec = train_measure(a.workload, a.dtype, a.steps, a.warmup, a.repeats, rank, world, dev, use_graph=not a.no_graph,
+                        want_cpu=(world == 1 and not a.no_cpu_baseline))
     if rank == 0:
+        wl = CONFIGS[a.workload]
+        T, H, W = wl["cfg"]["clip_len"], wl["H"], wl["W"]
         out = dict(metric="clips/sec (L=%d, %dx%d, %s) training step (fwd + loss + bwd + AdamW)" % (T, H, W, a.dtype),
-                   value=round(world * B * a.steps / el, 2), unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                   ms_per_step=round(el / a.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   value=rec["value"], unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=rec["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=a.dtype, data="synthetic",
-                   config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']}, L={T}, "
-                                        f"{H}x{W}, batch {B}/GPU, training step, random-init weights", clips_per_gpu=B,
-                               parallelism=f"dp{world}" + (" (RCCL all-reduce of one flat fp32 gradient buffer)" if world > 1 else ""),
-                               grad_buffer_mb=round(eng.params.numel * 4 / 2 ** 20, 1), final_loss=round(float(loss[0]), 4),
-                               hip_graph=not a.no_graph),
-                   roofline=None, cpu_baseline=None)
+                   config=dict(workload=rec["workload"], clips_per_gpu=wl["B"], parallelism=rec["parallelism"],
+                               grad_buffer_mb=rec["grad_buffer_mb"], final_loss=rec["final_loss"], hip_graph=rec["hip_graph"]),
+                   repeats=a.repeats, ms_per_step_repeats=rec["ms_per_step_repeats"],
+                   roofline=rec["roofline"], cpu_baseline=rec["cpu_baseline"], git_head=git_head())
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
@@ -158,11 +297,13 @@ def main_train(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--workload", default="rny002_b8", choices=list(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-records of the default line")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight: consecutive steps alternate between this many independent buffer sets / HIP "
@@ -199,16 +340,22 @@ def main():
                 eng.run_plan(plans[i % depth])
 
     run(max(a.warmup, depth))
-    torch.cuda.synchronize()
-    tdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(a.steps)
-    torch.cuda.synchronize()
-    el = tdist.max_over_ranks(time.perf_counter() - t0, device=dev)
-    tdist.barrier()
+    walls, evs = timed_regions(run, a.steps, a.repeats, dev, streams)
+    el = statistics.median(walls)
+    # latency of ONE batch with nothing else in flight (graph replay + sync per step)
+    lat = []
+    if rank == 0:
+        with torch.cuda.stream(stream):
+            for _ in range(12):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                eng.run_plan(plan)
+                e1.record(stream)
+                stream.synchronize()
+                lat.append(e0.elapsed_time(e1))
     with torch.cuda.stream(stream):
         prof, sgp_stage_ms = kernel_profile(eng, plan) if rank == 0 else (None, None)
+        sgp_direct = sgp_stage_time(plan) if rank == 0 else None
 
     if rank == 0:
         ms = el / a.steps * 1e3
@@ -219,21 +366,26 @@ def main():
         gbs = d["bytes"] / max(d["launches"], 1) / per_launch_s / 1e9
         tfs = d["flops"] / max(d["launches"], 1) / per_launch_s / 1e12
         # bound: whichever roof the kernel's algorithmic intensity puts it under
-        mfma_bound = name == "gemm" and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
+        mfma_bound = name.startswith("gemm") and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
         roof = dict(kernel=name, bound="mfma" if mfma_bound else "hbm",
                     achieved=round(tfs if mfma_bound else gbs, 2), peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
                     frac=round((tfs / MFMA_PEAK_TF[dt]) if mfma_bound else (gbs / HBM_PEAK_GBS), 4), traffic=None,
+                    traffic_source=None, algorithmic_bytes_per_launch=int(d["bytes"] / max(d["launches"], 1)),
+                    avg_launch_us=round(per_launch_s * 1e6, 2),
                     launches_per_step=d["launches"], ms_per_step=round(d["ms"], 4),
                     share_of_step=round(d["ms"] / sum(x["ms"] for x in prof.values()), 3))
-        # HBM bytes per launch of that kernel family from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
-        # separately on this same command, corrected as MI355X_MICROARCH.md prescribes; tools/summarize_pmc.py)
+        # HBM bytes per launch of that kernel family: NOT measured by this run.  It comes from separate rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE passes over this same command (MI355X_MICROARCH.md corrections; tools/summarize_pmc.py);
+        # the file names the passes, their time stamps and the git HEAD they were taken at.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
-                tr = json.load(fh)["kernels"].get(name)
+            with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
+                tj = json.load(fh)
+            tr = tj["kernels"].get(name)
             if tr is not None and a.workload == "rny002_b8" and a.dtype == "bf16":
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
-                roof["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(d["launches"], 1))
+                roof["traffic_source"] = (f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes at git {tj.get('git_head')} "
+                                          f"({tj.get('fetch_pass', {}).get('mtime')}); not measured by this run")
         except (OSError, KeyError, ValueError):
             pass
         sgp_steps = [s for s in plan.steps if s.name.startswith("_temp_fine.")]
@@ -248,12 +400,16 @@ def main():
         Wsgp = (2 * n_l + 1) * (8 * Cc * Cc + (2 * ks_ + up_ + 16) * Cc) + n_l * (14 * Cc * Cc + (4 * ks_ + 2 * up_ + 26) * Cc)
         es_ = 2 if dt == torch.bfloat16 else 4
         sgp_bytes = es_ * (B * Cc * sig + Wsgp)
-        # (stage time = all launches named _temp_fine.*, timed by step name: its contractions share the "gemm"
-        # family with the s4 trunk layers)
+        sgp_flops = sum(s.flops for s in sgp_steps)
+        # stage time: the sub-batches' stage chains timed back to back on one stream (they overlap other work inside the
+        # graph; this is the stage's own device time)
+        sgp_ms = sum(x[0] for x in sgp_direct)
         kernels = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
                            GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0,
                            TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        step_bytes = sum(s.bytes for s in plan.steps)
+        step_flops = sum(s.flops for s in plan.steps)
         out = dict(metric="clips/sec (L=100, 224^2, bf16) forward, per-frame logits", value=round(value, 2),
                    unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
@@ -261,15 +417,44 @@ def main():
                                         f"ks={cfg['sgp_ks']}, L={T}, {H}x{W}, batch {B}/GPU, inference forward, "
                                         "random-init weights", clips_per_gpu=B, parallelism=f"dp{world} (clip-sharded, no collective)",
                                hip_graph=not a.no_graph, batches_in_flight=depth),
-                   roofline=roof, kernels=kernels,
+                   repeats=a.repeats, ms_per_step_repeats=[round(w / a.steps * 1e3, 4) for w in walls],
+                   ms_per_step_hip_events=round(statistics.median(evs) / a.steps, 4),
+                   latency_ms_inflight1=round(statistics.median(lat), 4),
+                   roofline=roof,
+                   roofline_step=dict(bound="hbm", note="whole forward, layer-granular algorithmic bytes (every fused layer "
+                                      "reads its inputs and writes its output once) / ms_per_step",
+                                      algorithmic_bytes=int(step_bytes), achieved=round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                                      peak=HBM_PEAK_GBS, unit="GB/s", frac=round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      tflops=round(step_flops / (ms * 1e-3) / 1e12, 1)),
+                   kernels=kernels,
                    roofline_sgp=dict(bound="hbm", algorithmic_bytes=int(sgp_bytes), sigma_T=int(sig), weights=int(Wsgp),
-                                     ms=round(sgp_stage_ms, 4), achieved=round(sgp_bytes / (sgp_stage_ms * 1e-3) / 1e9, 2),
+                                     ms=round(sgp_ms, 4), ms_event_sum=round(sgp_stage_ms, 4),
+                                     achieved=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9, 2),
                                      peak=HBM_PEAK_GBS, unit="GB/s",
-                                     frac=round(sgp_bytes / (sgp_stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     launches=len(sgp_steps)),
-                   cpu_baseline=None)
+                                     frac=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     launches=len(sgp_steps), launches_per_sub_batch=[x[1] for x in sgp_direct],
+                                     us_per_sub_batch=[round(x[0] * 1e3, 1) for x in sgp_direct],
+                                     mfma_tflops=round(sgp_flops / (sgp_ms * 1e-3) / 1e12, 2),
+                                     mfma_frac=round(sgp_flops / (sgp_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dt], 4)),
+                   cpu_baseline=None, git_head=git_head())
+    del plans, plan, eng
+    torch.cuda.empty_cache()
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], errs = cpu_baseline(dev=dev)
+            out["logit_max_abs_err_fp32"] = round(errs["fp32"], 7)
+            out["logit_max_abs_err_bf16"] = round(errs["bf16"], 5)
+            out["logit_abs_max"] = round(errs["logit_abs_max"], 4)
+    if world == 1 and not a.no_train and a.workload == "rny002_b8" and a.dtype == "bf16":
+        # driver-visible training-step records: BASELINE configs[2] (800MF, B=16) and the 200MF geometry of the headline
+        tr = {}
+        for wk, st_ in (("rny008_b16", 6), ("rny002_b8", 10)):
+            try:
+                tr[wk] = train_measure(wk, "bf16", st_, 2, 3, rank, world, dev, use_graph=True)
+            except Exception as e:       # noqa: BLE001  (the headline line must still be printed)
+                tr[wk] = dict(error=f"{type(e).__name__}: {e}"[:300])
+        out["train"] = tr
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -215,6 +215,16 @@ class TrainEngine:
         self.opt.step(lr_factor=lr_factor)                      # the next replay starts with repack(): no refresh needed here
         return h.loss
 
+    def make_step(self, B, H, W, frames, label, labelD=None, drop_masks=None, use_graph=True, world=1):
+        """A zero-argument callable running one optimisation step on the given (static) batch: through the captured HIP graph
+        or eagerly; for world > 1 the flat gradient buffer is all-reduced (RCCL) before AdamW."""
+        from . import dist as tdist
+        ar = tdist.all_reduce_mean_ if world > 1 else None
+        if not use_graph:
+            return lambda: self.step(frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
+        hnd = self.build_graph(B, H, W)
+        return lambda: self.step_graph(hnd, frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
+
     def lr_factor(self, warmup_steps, cosine_steps):
         f = warmup_cosine_lr(self.sched_step, warmup_steps, cosine_steps)
         self.sched_step += 1

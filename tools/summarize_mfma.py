@@ -5,11 +5,11 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from summarize_pmc import family  # noqa: E402  (same kernel-name -> family map)
+from summarize_pmc import family, one_csv  # noqa: E402  (same kernel-name -> family map, same one-pass-per-dir rule)
 
 
 def load(d):
-    f = (glob.glob(os.path.join(d, "*", "*counter_collection.csv")) + glob.glob(os.path.join(d, "*counter_collection.csv")))[0]
+    f = one_csv(d)
     acc = defaultdict(lambda: defaultdict(float))
     n = defaultdict(int)
     for r in csv.DictReader(open(f)):

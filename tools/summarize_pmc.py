@@ -1,24 +1,48 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic per launch.
 Units and gfx950 corrections as MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KiB;
 FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 -> doubled; WRITE_SIZE is exact.
-    python tools/summarize_pmc.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01_hbm_traffic.json"""
-import csv, glob, json, os, re, sys
+
+    python tools/summarize_pmc.py <fetch pass dir> <write pass dir> profiles/rNN_hbm_traffic.json [--cmd "..."]
+
+Each pass directory must hold exactly ONE *counter_collection.csv (anywhere below it): a directory that collected
+several passes is ambiguous and refused, so a stale pass can never be summarised by accident.  The output records which
+files were read (path, mtime, size), the git HEAD and the profiled command."""
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+import time
 from collections import defaultdict
 
-def load(d, counter):
-    f = (glob.glob(os.path.join(d, "*", "*counter_collection.csv")) + glob.glob(os.path.join(d, "*counter_collection.csv")))[0]
+FAMILY = [("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_big", "gemm_big"), ("gemm_kernel", "gemm"),
+          ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"), ("gsf_", "gate_shift"), ("se_gate", "se_gate"),
+          ("stem_kernel", "stem"), ("sgp_mlp", "sgp_mlp"), ("sgp_front", "sgp_front"), ("mixer_branch", "mixer_branch"),
+          ("sgp_branch", "sgp_branch"), ("layernorm", "layernorm"), ("groupnorm", "groupnorm"), ("maxpool", "maxpool"),
+          ("avgpool", "avgpool_posenc"), ("heads", "heads"), ("bneck", "bneck")]
+
+
+def one_csv(d):
+    fs = sorted(set(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)))
+    if len(fs) != 1:
+        raise SystemExit(f"{d}: expected exactly one *counter_collection.csv below it, found {len(fs)}: {fs}")
+    return fs[0]
+
+
+def load(path, counter):
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
+    for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         name = re.sub(r"\(.*", "", r["Kernel_Name"])
-        acc[name][0] += float(r["Counter_Value"]); acc[name][1] += 1
+        acc[name][0] += float(r["Counter_Value"])
+        acc[name][1] += 1
+    if not acc:
+        raise SystemExit(f"{path}: no {counter} rows")
     return acc
 
-FAMILY = [("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_kernel", "gemm"), ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"),
-          ("gsf_", "gate_shift"), ("se_gate", "se_gate"), ("stem_kernel", "stem"), ("mixer_branch", "mixer_branch"),
-          ("sgp_branch", "sgp_branch"), ("layernorm", "layernorm"), ("groupnorm", "groupnorm"), ("maxpool", "maxpool"),
-          ("avgpool", "avgpool_posenc"), ("heads", "heads"), ("bneck", "bneck")]
 
 def family(n):
     for k, v in FAMILY:
@@ -26,9 +50,22 @@ def family(n):
             return v
     return None
 
+
+def stamp(path):
+    st = os.stat(path)
+    return dict(path=path, mtime=time.strftime("%Y-%m-%dT%H:%M:%S", time.localtime(st.st_mtime)), bytes=st.st_size)
+
+
 def main():
-    fd, wd, out = sys.argv[1:4]
-    fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    args = [a for a in sys.argv[1:]]
+    cmd = None
+    if "--cmd" in args:
+        i = args.index("--cmd")
+        cmd = args[i + 1]
+        del args[i:i + 2]
+    fd, wd, out = args[:3]
+    ff, wf = one_csv(fd), one_csv(wd)
+    fe, wr = load(ff, "FETCH_SIZE"), load(wf, "WRITE_SIZE")
     fam = defaultdict(lambda: dict(launches=0, fetch_bytes=0.0, write_bytes=0.0))
     for n, (v, c) in fe.items():
         k = family(n)
@@ -44,11 +81,18 @@ def main():
         L = max(d["launches"], 1)
         res[k] = dict(launches_profiled=d["launches"], hbm_bytes_per_launch=round((d["fetch_bytes"] + d["write_bytes"]) / L),
                       fetch_bytes_per_launch=round(d["fetch_bytes"] / L), write_bytes_per_launch=round(d["write_bytes"] / L))
-    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950), "
-                        "bench.py rny002_b8 bf16; averages over every launch of the kernel family",
-                   kernels=res), open(out, "w"), indent=1)
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                              cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except OSError:
+        head = None
+    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950); "
+                        "averages over every launch of the kernel family",
+                   command=cmd, git_head=head, fetch_pass=stamp(ff), write_pass=stamp(wf), kernels=res),
+              open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"]):
-        print(f"{k:16s} launches {v['launches_profiled']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB (rd {v['fetch_bytes_per_launch']/1e6:8.2f} wr {v['write_bytes_per_launch']/1e6:8.2f})")
+        print(f"{k:16s} launches {v['launches_profiled']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB "
+              f"(rd {v['fetch_bytes_per_launch']/1e6:8.2f} wr {v['write_bytes_per_launch']/1e6:8.2f})")
 
 
 if __name__ == "__main__":
