@@ -112,24 +112,38 @@ def kernel_profile(eng, plan, reps=3):
     return agg, sgp_ms_acc / reps
 
 
-def sgp_stage_time(plan, reps=20):
-    """Device time of the SGP encoder-decoder alone (the launches named _temp_fine.*), back to back on one stream,
-    first sub-batch only and scaled: a direct measurement of the stage, not a sum of padded event intervals."""
+def sgp_stage_time(plan, reps=30):
+    """Device time of the SGP encoder-decoder alone: the launches named _temp_fine.* of each chain (one chain behind the
+    sub-batch join, or one per sub-batch) captured into a HIP graph of their own and replayed back to back on one
+    stream -- device time including the kernel-to-kernel boundaries, without host launch gaps."""
+    import ctypes
+    from tdeed_amd import _lib
     st = torch.cuda.current_stream()
     out = []
-    for sub in plan.subs:
-        steps = [s for s in sub.steps if s.name.startswith("_temp_fine.")]
+    chains = [plan.tail.steps] if getattr(plan, "tail", None) is not None else [sub.steps for sub in plan.subs]
+    for chain in chains:
+        steps = [s for s in chain if s.name.startswith("_temp_fine.")]
         for s in steps:
             s.fn()
+        st.synchronize()
+        h = ctypes.c_void_p()
+        _lib.call("tdeed_graph_begin", st.cuda_stream)
+        try:
+            for s in steps:
+                s.fn()
+        finally:
+            _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
+        for _ in range(3):
+            _lib.call("tdeed_graph_launch", h, st.cuda_stream)
         st.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
         for _ in range(reps):
-            for s in steps:
-                s.fn()
+            _lib.call("tdeed_graph_launch", h, st.cuda_stream)
         b.record(st)
         st.synchronize()
         out.append((a.elapsed_time(b) / reps, len(steps)))
+        _lib.call("tdeed_graph_destroy", h)
     return out
 
 
@@ -432,8 +446,10 @@ def main():
                                      achieved=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9, 2),
                                      peak=HBM_PEAK_GBS, unit="GB/s",
                                      frac=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     launches=len(sgp_steps), launches_per_sub_batch=[x[1] for x in sgp_direct],
-                                     us_per_sub_batch=[round(x[0] * 1e3, 1) for x in sgp_direct],
+                                     launches=len(sgp_steps), launches_per_chain=[x[1] for x in sgp_direct],
+                                     us_per_chain=[round(x[0] * 1e3, 1) for x in sgp_direct],
+                                     chains=("one for the whole batch (behind the sub-batch join)"
+                                             if getattr(plan, "tail", None) is not None else "one per sub-batch"),
                                      mfma_tflops=round(sgp_flops / (sgp_ms * 1e-3) / 1e12, 2),
                                      mfma_frac=round(sgp_flops / (sgp_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dt], 4)),
                    cpu_baseline=None, git_head=git_head())

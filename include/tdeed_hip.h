@@ -205,6 +205,30 @@ int tdeed_sgp_branch_fwd(const void* o, const void* x, int B, int T, int C, int 
 int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int ks, int up,
                            const float* dw1, const float* db1, const float* dw2,
                            const float* db2, void* cat, int dtype, void* stream);
+/* ---- fused SGP launches (sgp_fused.hip): a block = sgp_front + sgp_mlp, a mixer = mixer_front + concat_fc + sgp_mlp.
+ * sgp_front:   y = x + LN(x) + fc*phi + (convw+convkw)*psi   (modules.py:159-184; LayerNorm 320-363 computed in-kernel)
+ * mixer_front: cat [B][T_hi][6C] = (out1,out2,out3,out4,LN1(z),up(LN2(x_lo)))   (modules.py:286-308)
+ * sgp_mlp (bf16): out = y + mlp(GroupNorm16(y)), mlp = Conv1d(C,4C,1) -> GELU(erf) -> Conv1d(4C,C,1)   (modules.py:186,316);
+ *              W1 / W2 bf16 in MFMA fragment order, each [4][C/16][ceil(C/32)][64][8]: chunk c (C hidden units), 16-row tile
+ *              t, k-step s, lane l, element j  =  W1[c*C + 16t + (l&15)][32s + 8(l>>4) + j]  resp.
+ *              W2[16t + (l&15)][c*C + 32s + 8(l>>4) + j], zero where the k index passes C (tdeed_amd.engine.pack_mlp_frags);
+ *              biases / GroupNorm affine fp32.  tdeed_sgp_mlp_fits tells whether the geometry (R = B*T rows) is served;
+ *              callers otherwise use groupnorm + two tdeed_gemm_fwd. */
+/* chsum (optional, fp32 [B][C][2]): per clip and channel the sum and sum of squares over T of the stored y, which
+ * tdeed_sgp_mlp_fwd takes instead of re-reading the clip for its GroupNorm statistics */
+int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w, const float* ln_b, float eps,
+                        const float* dw, const float* db, void* y, float* chsum, int dtype, void* stream);
+int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T_lo, int C, int ks, int up,
+                          const float* ln1_w, const float* ln1_b, const float* ln2_w, const float* ln2_b, float eps,
+                          const float* dw1, const float* db1, const float* dw2, const float* db2, void* cat, int dtype,
+                          void* stream);
+int tdeed_sgp_mlp_fits(int R, int T, int C, int G);
+/* hidden-chunk split S of the launch (1, 2 or 4); for S > 1 `partial` must hold S*R*C floats (fp32 partials, folded in a
+ * fixed order by a second launch) */
+int tdeed_sgp_mlp_splits(int R, int C);
+int tdeed_sgp_mlp_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
+                      const void* W1, const float* b1, const void* W2, const float* b2, void* out, float* partial,
+                      const float* chsum /* optional, see tdeed_sgp_front_fwd */, void* stream);
 /* nn.GroupNorm(G, C) over (C/G x T) per clip (modules.py:115,186): x,y [B][T][C]. */
 int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* w, const float* b,
                         float eps, void* y, int dtype, void* stream);

@@ -80,6 +80,9 @@ def _pack_mlp(sd, pre, C, o, act_dtype, device):
     o.w_fc2 = _dense(_np(sd[pre + ".mlp.2.weight"]).reshape(C, 4 * C), act_dtype, device)
     o.b_fc2 = _f32(_np(sd[pre + ".mlp.2.bias"]), device)
     o.gn_w, o.gn_b = _f32(_np(sd[pre + ".gn.weight"]), device), _f32(_np(sd[pre + ".gn.bias"]), device)
+    o.w1f = o.w2f = None
+    if act_dtype == torch.bfloat16 and str(device) != "cpu" and C % 16 == 0 and 64 <= C <= 768:
+        o.w1f, o.w2f = pack_mlp_frags(sd[pre + ".mlp.0.weight"], sd[pre + ".mlp.2.weight"], device)
 
 
 def pack_ws_weights(W, act_dtype, device):
@@ -114,6 +117,26 @@ def pack_rowtile_weights(W, device):
     Wp[:N, :K] = W
     fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
     return torch.from_numpy(np.ascontiguousarray(fr).reshape(NT, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
+
+
+def pack_mlp_frags(w1, w2, device):
+    """mlp.0.weight (4C,C) and mlp.2.weight (C,4C) -> bf16 MFMA A-operand fragments for sgp_mlp_kernel, each
+    [4][C/16][ceil(C/32)][64][8]: chunk c of C hidden units, 16-row tile t, k-step s, lane l holds row l&15 and
+    k = 32s + 8(l>>4) + j (zero past C), so that a wave's fragment load is 1 KB of consecutive bytes."""
+    w1, w2 = _np(w1).astype(np.float32), _np(w2).astype(np.float32)
+    C = w1.shape[1]
+    w1, w2 = w1.reshape(4 * C, C), w2.reshape(C, 4 * C)
+    nt, KS = C // 16, (C + 31) // 32
+    KP = KS * 32
+    a = np.zeros((4, C, KP), np.float32)
+    a[:, :, :C] = w1.reshape(4, C, C)                                   # [chunk][hidden unit][k]
+    b = np.zeros((4, C, KP), np.float32)
+    b[:, :, :C] = w2.reshape(C, 4, C).transpose(1, 0, 2)                # [chunk][out feature][k within chunk]
+
+    def frag(x):
+        fr = x.reshape(4, nt, 16, KS, 4, 8).transpose(0, 1, 3, 4, 2, 5)     # [c][t][s][q][n][j]
+        return torch.from_numpy(np.ascontiguousarray(fr).reshape(4, nt, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
+    return frag(a), frag(b)
 
 
 def pack_se_bf16(fc1_w, fc2_w, device):
@@ -340,6 +363,10 @@ class SgpBuilder:
     def __init__(self, pool, steps, keep, taps, B, act_dtype):
         self.pool, self.steps, self.keep, self.taps, self.B, self.dt = pool, steps, keep, taps, B, act_dtype
         self.splitk_rows = int(os.environ.get("TDEED_SPLITK_ROWS", "4096"))
+        # fused launches (sgp_fused.hip): LayerNorm inside the branch kernels (both dtypes), GroupNorm + fc1 + GELU + fc2 +
+        # residual in one MFMA launch (bf16).  TDEED_SGP_FUSED=0 restores the launch-per-op chain (A/B measurements).
+        self.fused = os.environ.get("TDEED_SGP_FUSED", "1") == "1"
+        self.mlp_maxc = int(os.environ.get("TDEED_SGP_MLP_MAXC", "384"))
 
     def dense(self, name, A, Wt, bias, act, out, R, residual=None):
         """One Conv1d(k=1) of the mlp / concat_fc.  Short sequences (bf16, <= splitk_rows rows) go through the split-K
@@ -357,8 +384,46 @@ class SgpBuilder:
             self.steps.append(Step(name, "gemm", lambda: ops.gemm(A, Wt, None, bias, act, residual=residual, out=out, M=R),
                                    *gemm_cost(R, K, N, es, residual is not None)))
 
+    def _mlp(self, name, y, o, outb, Tn, chsum=None):
+        """out = y + mlp(GN(y)): one launch where sgp_mlp serves the geometry, else groupnorm + two contractions."""
+        pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        es, R = _esz(dt), B * Tn
+        # every workgroup of the fused launch streams all 16*C*C bytes of W1 and W2 through its CU (~16 us at C=368, ~70 us
+        # at C=768): beyond mlp_maxc the tiled contractions, which spread the weights over many CUs, win
+        if (self.fused and dt == torch.bfloat16 and str(y.device) != "cpu" and C <= self.mlp_maxc and o.w1f is not None
+                and ops.sgp_mlp_fits(R, Tn, C)):
+            ws = pool.take((4, R, C), torch.float32)          # partials of the hidden-split form (S <= 4)
+            steps.append(Step(name + ".mlp", "sgp_mlp", lambda: ops.sgp_mlp(y, o.gn_w, o.gn_b, o.w1f, o.b_fc1, o.w2f,
+                                                                          o.b_fc2, out=outb, partial=ws, chsum=chsum),
+                              2 * R * C * es + 8 * C * C * es, 2 * R * 8 * C * C))
+            pool.give(ws)
+            return
+        gn = pool.take((B, Tn, C), dt)
+        hid = pool.take((B, Tn, 4 * C), dt)
+        steps.append(Step(name + ".gn", "groupnorm", lambda: ops.groupnorm(y, 16, o.gn_w, o.gn_b, out=gn), 2 * R * C * es))
+        self.dense(name + ".fc1", gn, o.w_fc1, o.b_fc1, ops.ACT_GELU, hid, R)
+        self.dense(name + ".fc2", hid, o.w_fc2, o.b_fc2, ops.ACT_NONE, outb, R, residual=y)
+        pool.give(gn)
+        pool.give(hid)
+
     def block(self, xin, Tn, o, name):
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        if self.fused and str(xin.device) != "cpu":
+            y = pool.take((B, Tn, C), dt)
+            outb = pool.take((B, Tn, C), dt)
+            es, R = _esz(dt), B * Tn
+            wl = 2 * o.ks + o.up + 2
+            chs = pool.take((B, C, 2), torch.float32) if dt == torch.bfloat16 else None
+            steps.append(Step(name + ".front", "sgp_front", lambda: ops.sgp_front(xin, o.ks, o.up, o.ln_w, o.ln_b, o.dw, o.db,
+                                                                                 out=y, chsum=chs),
+                              2 * R * C * es + C * (wl + 7) * 4, 2 * R * C * (wl + 3)))
+            self._mlp(name, y, o, outb, Tn, chsum=chs)
+            pool.give(y)
+            if chs is not None:
+                pool.give(chs)
+            if name in self.taps:
+                self.keep[name] = outb
+            return outb
         ln = pool.take((B, Tn, C), dt)
         y = pool.take((B, Tn, C), dt)
         gn = pool.take((B, Tn, C), dt)
@@ -380,6 +445,23 @@ class SgpBuilder:
 
     def mixer(self, xlo, T_lo, z, T_hi, o, name):
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        if self.fused and str(z.device) != "cpu":
+            cat = pool.take((B, T_hi, 6 * C), dt)
+            mo = pool.take((B, T_hi, C), dt)
+            outb = pool.take((B, T_hi, C), dt)
+            es, R, Rl = _esz(dt), B * T_hi, B * T_lo
+            wl = 2 * o.ks + o.up + 2
+            steps.append(Step(name + ".front", "mixer_front",
+                              lambda: ops.mixer_front(z, xlo, cat, o.ks, o.up, o.ln1_w, o.ln1_b, o.ln2_w, o.ln2_b, o.dw1,
+                                                      o.db1, o.dw2, o.db2),
+                              (7 * R + Rl) * C * es + 2 * C * (wl + 7) * 4, 4 * R * C * (wl + 3)))
+            self.dense(name + ".cat", cat, o.w_cat, o.b_cat, ops.ACT_GELU, mo, R)
+            self._mlp(name, mo, o, outb, T_hi)
+            pool.give(cat)
+            pool.give(mo)
+            if name in self.taps:
+                self.keep[name] = outb
+            return outb
         cat = pool.take((B, T_hi, 6 * C), dt)
         xn = pool.take((B, T_lo, C), dt)
         mo = pool.take((B, T_hi, C), dt)
@@ -561,10 +643,25 @@ class ForwardEngine:
         # with the fusion, so it is opt-in: TDEED_FUSE_SE=1 (7x7 only) or 2 (both).
         self.fuse_se_max = int(os.environ.get("TDEED_FUSE_SE", "0"))
         self.fuse_se = self.fuse_se_max > 0
+        # the temporal stage (SGP encoder-decoder + heads) of a split batch runs ONCE over all clips behind the join of the
+        # sub-batch trunks: its launches are latency bound and their cost does not depend on the row count at these sizes
+        self.merge_tail = os.environ.get("TDEED_SGP_MERGE", "1") == "1"
         self._plans = {}
 
     # ------------------------------------------------------------------ plan construction
-    def _build(self, B, H, W, flip, taps, head_out=None):
+    def _build_tail(self, B, feat, head_out):
+        """SGP encoder-decoder + heads over a (B,T,C) feature tensor (the launches behind the sub-batch join)."""
+        pw, Wt = self.pw, self.pw.W
+        T, C, dt = pw.clip_len, pw.spec.feat_dim, self.act_dtype
+        pool, steps, keep = _Pool(self.device), [], {}
+        sb = SgpBuilder(pool, steps, keep, set(), B, dt)
+        cur = sb.pyramid(feat, T, pw.n_layers, Wt.sgp, Wt.mixer)
+        N = B * T
+        steps.append(Step("heads", "heads", lambda cur=cur: ops.heads(cur, Wt.head_w, Wt.head_b, out=head_out),
+                          N * C * _esz(dt) + N * pw.n_out * 4, 2 * N * C * pw.n_out))
+        return SimpleNamespace(steps=steps, pool_bytes=pool.total_bytes(), sgp_out=cur)
+
+    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None):
         pw, Wt = self.pw, self.pw.W
         T = pw.clip_len
         N = B * T
@@ -724,12 +821,14 @@ class ForwardEngine:
                 keep[tapname] = out
             x, h, w = out, h2, w2
         C = pw.spec.feat_dim
-        feat = pool.take((B, T, C), dt)
+        feat = pool.take((B, T, C), dt) if feat_out is None else feat_out
         steps.append(Step("avgpool", "avgpool_posenc", lambda x=x, feat=feat: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat),
                           (N * h * w + N) * C * es))
         keep["feat"] = feat
         if not x_kept:
             pool.give(x)
+        if feat_out is not None:         # trunk only: the temporal stage runs once for all sub-batches (plan.tail)
+            return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=None, pool_bytes=pool.total_bytes(), B=B, T=T)
 
         # ---------------- SGP encoder-decoder
         sb = SgpBuilder(pool, steps, keep, taps, B, dt)
@@ -753,18 +852,24 @@ class ForwardEngine:
         ns = self.n_split if (not taps and self.n_split > 1 and B % self.n_split == 0 and B >= self.n_split) else 1
         if ns == 1:
             sub = self._build(B, H, W, bool(flip), set(taps))
-            plan = SimpleNamespace(subs=[sub], streams=[None], head_out=sub.head_out, keep=sub.keep, graph=None,
+            plan = SimpleNamespace(subs=[sub], streams=[None], head_out=sub.head_out, keep=sub.keep, graph=None, tail=None,
                                    steps=sub.steps, pool_bytes=sub.pool_bytes, B=B, T=sub.T)
         else:
             Bs = B // ns
             T = self.pw.clip_len
             head_out = torch.empty((B * T, self.pw.n_out), dtype=torch.float32, device=self.device)
-            subs = [self._build(Bs, H, W, bool(flip), set(), head_out=head_out[i * Bs * T:(i + 1) * Bs * T])
-                    for i in range(ns)]
+            tail = None
+            if self.merge_tail:
+                feat = torch.empty((B, T, self.pw.spec.feat_dim), dtype=self.act_dtype, device=self.device)
+                subs = [self._build(Bs, H, W, bool(flip), set(), feat_out=feat[i * Bs:(i + 1) * Bs]) for i in range(ns)]
+                tail = self._build_tail(B, feat, head_out)
+            else:
+                subs = [self._build(Bs, H, W, bool(flip), set(), head_out=head_out[i * Bs * T:(i + 1) * Bs * T])
+                        for i in range(ns)]
             plan = SimpleNamespace(subs=subs, streams=[None] + [torch.cuda.Stream(device=self.device) for _ in range(ns - 1)],
-                                   head_out=head_out, keep=subs[0].keep, graph=None,
-                                   steps=[st for sb in subs for st in sb.steps],
-                                   pool_bytes=sum(sb.pool_bytes for sb in subs), B=B, T=T)
+                                   head_out=head_out, keep=subs[0].keep, graph=None, tail=tail,
+                                   steps=[st for sb in subs for st in sb.steps] + (tail.steps if tail else []),
+                                   pool_bytes=sum(sb.pool_bytes for sb in subs) + (tail.pool_bytes if tail else 0), B=B, T=T)
         self._plans[key] = plan
         return plan
 
@@ -799,6 +904,9 @@ class ForwardEngine:
                     joins.append(ev)
         for ev in joins:
             main.wait_event(ev)
+        if plan.tail is not None:
+            for s_ in plan.tail.steps:
+                s_.fn()
 
     def run_plan(self, plan):
         """Launch the plan on the current stream (eager) or replay its HIP graph."""

@@ -317,6 +317,50 @@ def mixer_branch(xn, cat, T_hi, ks, up, dw1, db1, dw2, db2):
     return cat
 
 
+def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None):
+    """SGPBlock front half with the LayerNorm computed in-kernel: y = x + LN(x) + fc*phi + (convw+convkw)*psi.
+    chsum: optional fp32 (B, C, 2) output, per-channel sum / sum of squares over T of y (for sgp_mlp's GroupNorm)."""
+    B, T, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_sgp_front_fwd", ptr(x), B, T, C, ks, up, ptr(ln_w), ptr(ln_b), eps, ptr(dw), ptr(db), ptr(out),
+         ptr(chsum), dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def mixer_front(z, xlo, cat, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, dw1, db1, dw2, db2, eps=1e-5):
+    """SGPMixer front half with both LayerNorms in-kernel: fills all six slabs of cat (B, T_hi, 6C)."""
+    B, T_hi, C = z.shape
+    T_lo = xlo.shape[1]
+    call("tdeed_mixer_front_fwd", ptr(z), ptr(xlo), B, T_hi, T_lo, C, ks, up, ptr(ln1_w), ptr(ln1_b), ptr(ln2_w),
+         ptr(ln2_b), eps, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(cat), dtype_code(z.dtype), stream_ptr())
+    return cat
+
+
+def sgp_mlp_fits(R, T, C, G=16):
+    return bool(_lib.load().tdeed_sgp_mlp_fits(R, T, C, G))
+
+
+def sgp_mlp_partial_shape(R, C):
+    """fp32 scratch (S, R, C) of the hidden-split form of sgp_mlp (S = 1: none needed)."""
+    return (_lib.load().tdeed_sgp_mlp_splits(R, C), R, C)
+
+
+def sgp_mlp(y, gn_w, gn_b, W1, b1, W2, b2, G=16, eps=1e-5, out=None, partial=None, chsum=None):
+    """out = y + fc2(GELU(fc1(GroupNorm(y)))) (bf16): one launch, or hidden-split partials + a fold launch at small row
+    counts.  y (B,T,C); W1 / W2: engine.pack_mlp_frags(...) fragments; partial: fp32 scratch of sgp_mlp_partial_shape
+    (allocated if None)."""
+    _chk(y, "y", torch.bfloat16); _chk(W1, "W1", torch.bfloat16); _chk(W2, "W2", torch.bfloat16)
+    B, T, C = y.shape
+    if out is None:
+        out = torch.empty_like(y)
+    if partial is None:
+        partial = torch.empty((4, B * T, C), dtype=torch.float32, device=y.device)
+    call("tdeed_sgp_mlp_fwd", ptr(y), B * T, T, C, G, ptr(gn_w), ptr(gn_b), eps, ptr(W1), ptr(b1), ptr(W2), ptr(b2),
+         ptr(out), ptr(partial), ptr(chsum), stream_ptr())
+    return out
+
+
 def groupnorm(x, G, w, b, eps=1e-5, out=None):
     B, T, C = x.shape
     if out is None:

@@ -438,3 +438,34 @@ def test_load_after_get_optimizer_refreshes_the_packed_weights():
     b.get_optimizer({"lr": 1e-3})
     la, lb = loss_of(a), loss_of(b)
     assert abs(la - lb) < 1e-6 * max(1.0, abs(lb)), (la, lb)
+
+
+@pytest.mark.parametrize("C,T,B,n", [(368, 100, 4, 2), (768, 50, 2, 2), (64, 26, 3, 3), (128, 100, 1, 2)])
+def test_fused_sgp_launches_match_the_launch_per_op_chain(C, T, B, n, monkeypatch):
+    """sgp_front / mixer_front / sgp_mlp (LayerNorm and GroupNorm folded into their consumers, fc1+GELU+fc2 in one MFMA
+    launch) against the launch-per-op chain on the same weights: same rounding points, so bf16 results agree to bf16
+    resolution; fp32 (fused fronts only) to 1e-5."""
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, pack_sgp_mixer, _Pool
+    from helpers import module_state, act
+    sd = module_state("pyramid", "_temp_fine", 5, C=C, ks=7, r=4, n=n)
+    for dtype in (torch.bfloat16, torch.float32):
+        x = t(act(9, "x", (B, T, C))).to(dtype).to(DEV)
+        outs = {}
+        for fused, maxc in (("1", "4096"), ("0", "384")):
+            monkeypatch.setenv("TDEED_SGP_FUSED", fused)
+            monkeypatch.setenv("TDEED_SGP_MLP_MAXC", maxc)
+            sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, dtype, DEV) for i in range(2 * n + 1)]
+            mix = [pack_sgp_mixer(sd, f"_temp_fine._sgpMixer.{i}", C, dtype, DEV) for i in range(n)]
+            steps, keep = [], {}
+            sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, dtype)
+            out = sb.pyramid(x, T, n, sgp, mix)
+            for s_ in steps:
+                s_.fn()
+            torch.cuda.synchronize()
+            outs[fused] = (out.float().cpu(), len(steps), sorted({s_.kernel for s_ in steps}))
+        a, b = outs["1"][0], outs["0"][0]
+        assert outs["1"][1] < outs["0"][1]
+        if dtype == torch.bfloat16:
+            assert "sgp_mlp" in outs["1"][2]
+        tol = 1e-5 if dtype == torch.float32 else 4e-2
+        assert max_abs(a, b) < tol * max(1.0, float(b.abs().max())), (dtype, max_abs(a, b), float(b.abs().max()))
