@@ -399,6 +399,23 @@ int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float
                   float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype, void* stream);
 int tdeed_gsf_add_cols(const void* a, const void* b, long M, int C, int Fp, void* dx, int dtype, void* stream);
 
+/* ---- data-parallel gradient reduction over RCCL / xGMI (comm.hip) ---------------------------------------------------
+ * New functionality (the reference is single-GPU: model/model.py:184-190): one process per GPU, one
+ * communicator with its own high-priority HIP stream.  tdeed_comm_all_reduce enqueues an in-place SUM of buf[0,n) over all
+ * ranks behind the work already given to `compute_stream` and returns at once (the backward goes on); tdeed_comm_join makes
+ * `compute_stream` wait for every collective enqueued so far (call it before the optimizer reads the gradients; the 1/world
+ * goes into tdeed_adamw_step's grad_scale).  No host synchronisation in either; legal under stream capture.  librccl is
+ * dlopen'ed at the first tdeed_comm_* call.  id128: 128 opaque bytes made on rank 0 (tdeed_comm_unique_id) and handed to
+ * every rank by the caller (torch.distributed broadcast, a file ...); tdeed_comm_init is collective over the ranks. */
+int tdeed_comm_unique_id(void* id128);
+int tdeed_comm_init(void** comm_out, const void* id128, int world, int rank);
+int tdeed_comm_info(void* comm, int* world, int* rank);
+int tdeed_comm_all_reduce(void* comm, void* buf, long n, int dtype, void* compute_stream);
+/* the same sum as reduce-scatter + all-gather (n a multiple of world): for the large bucket on point-to-point xGMI */
+int tdeed_comm_all_reduce_rs_ag(void* comm, void* buf, long n, int dtype, void* compute_stream);
+int tdeed_comm_join(void* comm, void* compute_stream);
+int tdeed_comm_destroy(void* comm);
+
 /* ---- HIP graph capture of a launch sequence (replaces eager op-by-op dispatch) ---------------
  * begin: hipStreamBeginCapture(stream); end: EndCapture + Instantiate -> handle; launch replays. */
 int tdeed_graph_begin(void* stream);

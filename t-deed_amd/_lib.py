@@ -110,6 +110,13 @@ _SIGS = {
     "tdeed_process_prediction": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P], c_int),
     "tdeed_cast_f32_to_bf16": ([P, P, c_long, P], c_int),
     "tdeed_fill_u8_hash": ([P, c_long, c_uint64, P], c_int),
+    "tdeed_comm_unique_id": ([P], c_int),
+    "tdeed_comm_init": ([POINTER(c_void_p), P, c_int, c_int], c_int),
+    "tdeed_comm_info": ([P, POINTER(c_int), POINTER(c_int)], c_int),
+    "tdeed_comm_all_reduce": ([P, P, c_long, c_int, P], c_int),
+    "tdeed_comm_all_reduce_rs_ag": ([P, P, c_long, c_int, P], c_int),
+    "tdeed_comm_join": ([P, P], c_int),
+    "tdeed_comm_destroy": ([P], c_int),
     "tdeed_graph_begin": ([P], c_int),
     "tdeed_graph_end": ([P, POINTER(c_void_p)], c_int),
     "tdeed_graph_launch": ([P, P], c_int),

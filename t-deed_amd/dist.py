@@ -68,6 +68,101 @@ def gather_clips(local, n_total):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+class RcclComm:
+    """The C-ABI communicator (csrc/comm.hip): RCCL on its own high-priority HIP stream.  The 128-byte unique id is made
+    on rank 0 and broadcast through the default torch.distributed group (any backend), which is also what launched us."""
+
+    def __init__(self, device):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        world, rank = dist.get_world_size(), dist.get_rank()
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            _lib.call("tdeed_comm_unique_id", raw)
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        on_dev = dist.get_backend() == "nccl"
+        t = idbuf.to(device) if on_dev else idbuf
+        dist.broadcast(t, src=0)
+        raw = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.call("tdeed_comm_init", ctypes.byref(self.handle), raw, world, rank)
+        self.world, self.rank = world, rank
+
+    def all_reduce(self, t, rs_ag=False):
+        from ._lib import dtype_code, ptr, stream_ptr
+        fn = "tdeed_comm_all_reduce_rs_ag" if (rs_ag and t.numel() % self.world == 0) else "tdeed_comm_all_reduce"
+        self._lib.call(fn, self.handle, ptr(t), t.numel(), dtype_code(t.dtype), stream_ptr())
+
+    def join(self):
+        from ._lib import stream_ptr
+        self._lib.call("tdeed_comm_join", self.handle, stream_ptr())
+
+    def close(self):
+        if self.handle:
+            self._lib.call("tdeed_comm_destroy", self.handle)
+            self.handle = None
+
+
+class GradReducer:
+    """Bucketed gradient reduction of ONE flat buffer, overlapped with the backward.
+
+    `buckets` = [(lo, hi), ...] element ranges in the order the backward completes them (temporal stack + heads first:
+    92 % of the 800MF gradient bytes, then the trunk).  reduce_bucket(i) enqueues the SUM over ranks of that range behind
+    the work already queued on the current stream and returns; join() makes the current stream wait for all of them.  The
+    mean's 1/world is NOT applied here: the fused AdamW launch takes it as grad_scale (`scale`).
+    backend "rccl": the C-ABI communicator (own stream, capturable into a HIP graph); backend "torch": torch.distributed
+    async all_reduce on a side stream (gloo works with GPU tensors: the 2-process single-GPU tests; also CPU tensors)."""
+
+    def __init__(self, flat, buckets, backend=None, device=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
+        self.flat, self.buckets = flat, [(int(a), int(b)) for a, b in buckets]
+        self.world = dist.get_world_size()
+        self.scale = 1.0 / self.world
+        if backend is None:
+            backend = "rccl" if (flat.is_cuda and dist.get_backend() == "nccl") else "torch"
+        self.backend = backend
+        self.capturable = backend == "rccl"
+        self._works = []
+        self._side = torch.cuda.Stream(device=flat.device) if (backend == "torch" and flat.is_cuda) else None
+        self._comm = RcclComm(device if device is not None else flat.device) if backend == "rccl" else None
+
+    def reduce_bucket(self, i):
+        lo, hi = self.buckets[i]
+        view = self.flat[lo:hi]
+        if self.world == 1:
+            return
+        if self._comm is not None:
+            self._comm.all_reduce(view, rs_ag=(hi - lo) * 4 >= (32 << 20))      # RS+AG for the big bucket
+        elif self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def reduce_all(self):
+        for i in range(len(self.buckets)):
+            self.reduce_bucket(i)
+
+    def join(self):
+        if self._comm is not None:
+            self._comm.join()
+            return
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def close(self):
+        if self._comm is not None:
+            self._comm.close()
+
+
 def all_reduce_mean_(flat, async_op=False):
     """Gradient all-reduce of one flat buffer (sum over ranks; the 1/world is folded into the optimizer's
     grad_scale by the caller when async, applied here otherwise).  RCCL over xGMI under backend "nccl"."""

@@ -246,6 +246,8 @@ class TDEEDModel:
         the fused AdamW kernel, so torch LR schedulers work on it unchanged."""
         from .trainer import HipAdamW
         eng = self._model.train_engine()
+        if eng.reducer is None:
+            eng.set_reducer("auto")          # data-parallel job (torch.distributed initialised, world > 1): bucketed all-reduce
         return HipAdamW(eng, **opt_args), None
 
     @property
@@ -401,10 +403,13 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
                 head, B, T, None if label is None else label.reshape(-1).contiguous(),
                 labelD=None if labelD is None else labelD.reshape(-1).contiguous(),
                 soft=None if soft is None else soft.reshape(B * T, -1).contiguous(), fg_weight=fg_weight, dataset=dataset)
-            grads = eng.backward_train(self._model._train_ctx, dhead)
+            last = (batch_idx + 1) % acc_grad_iter == 0
+            # data parallel (one process per GPU under torchrun): the bucket all-reduces of the step's last micro-batch are
+            # enqueued from inside the backward; optimizer.step() waits for them on the device
+            eng.backward_and_write(self._model._train_ctx, dhead, scale=scale, first=batch_idx % acc_grad_iter == 0,
+                                   reduce=last and eng.reducer is not None)
             self._model._train_ctx = None
-            eng.write_grads(grads, scale=scale, first=batch_idx % acc_grad_iter == 0)
-            if (batch_idx + 1) % acc_grad_iter == 0:
+            if last:
                 optimizer.step()
                 if lr_scheduler is not None:
                     lr_scheduler.step()

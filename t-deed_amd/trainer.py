@@ -43,6 +43,26 @@ class TrainEngine:
         self.one32 = torch.ones(32, device=device)
         self.zero32 = torch.zeros(32, device=device)
         self.sched_step = 0
+        self.reducer = None                                      # dist.GradReducer of a data-parallel job (set_reducer)
+
+    # ------------------------------------------------------------------ data parallel
+    def grad_buckets(self):
+        """Element ranges of the flat gradient buffer in the order the backward completes them: [temporal stack + heads]
+        (everything from the first `_temp_fine.` tensor to the end of the buffer), then [temp_enc + trunk]."""
+        first = min(o for k, (o, n) in self.params.index.items() if k.startswith(("_temp_fine.", "_pred_")))
+        return [(first, self.params.numel), (0, first)]
+
+    def set_reducer(self, reducer="auto"):
+        """Attach the gradient reducer of a data-parallel job (one process per GPU).  "auto": a dist.GradReducer over this
+        engine's flat gradient buffer when torch.distributed is initialised with more than one rank, else none."""
+        from . import dist as tdist
+        import torch.distributed as td
+        if reducer == "auto":
+            reducer = None
+            if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+                reducer = tdist.GradReducer(self.params.grad, self.grad_buckets(), device=torch.device(self.device))
+        self.reducer = reducer
+        return reducer
 
     # ------------------------------------------------------------------ forward + backward
     def _frame_flip(self, flip, Bn, T):
@@ -80,9 +100,15 @@ class TrainEngine:
 
     def backward_train(self, ctx, dhead):
         """Backward of forward_train from d(loss)/d(head_out): returns grads dict name -> fp32 tensor."""
-        sd = self.state
         grads = {}
         d_feat = self.temporal.backward_heads(ctx.tctx, dhead, grads)
+        grads.update(self.backward_trunk(ctx, d_feat))
+        return grads
+
+    def backward_trunk(self, ctx, d_feat):
+        """Backward of avg-pool + positional encoding, the bottlenecks and the stem from d(loss)/d(features)."""
+        sd = self.state
+        grads = {}
         dx, d_enc = B_.avgpool_posenc_bwd(d_feat, ctx.hw)
         grads["temp_enc"] = d_enc
         dx = dx.view(ctx.x_shape)
@@ -112,43 +138,75 @@ class TrainEngine:
         self.temporal.repack()
 
     # ------------------------------------------------------------------ one optimiser step
-    def write_grads(self, grads, scale=1.0, first=True):
+    def write_grads(self, grads, scale=1.0, first=True, partial=False):
         """Gradient write-out into the flat buffer (times `scale`; overwriting when `first`, adding otherwise:
         `acc_grad_iter` of the reference's step()): multi-tensor copies, a handful of launches instead of one per tensor."""
-        missing = set(self.params.index) - set(grads)
-        if missing:
-            raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
+        if not partial:
+            missing = set(self.params.index) - set(grads)
+            if missing:
+                raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
         keys = list(grads)
         dsts = [self.params.grad_view(k).view(grads[k].shape) for k in keys]
         srcs = [grads[k] for k in keys]
         if first:
             torch._foreach_copy_(dsts, srcs)
             if scale != 1.0:
-                self.params.grad.mul_(scale)
+                torch._foreach_mul_(dsts, scale)
         else:
             torch._foreach_add_(dsts, srcs, alpha=scale)
 
     def accumulate(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, scale=1.0,
-                   first=True, dataset=None, fg_weight=5.0):
-        """forward + backward of one (micro-)batch; its gradients (times `scale`) go into the flat gradient buffer."""
-        loss, grads = self.loss_and_grads(frames_u8, label, labelD, soft, crop, flip, drop_masks, fg_weight, dataset)
-        self.write_grads(grads, scale, first)
+                   first=True, dataset=None, fg_weight=5.0, reduce=False):
+        """forward + backward of one (micro-)batch; its gradients (times `scale`) go into the flat gradient buffer.
+        reduce (data parallel, last micro-batch of a step): each bucket's all-reduce is enqueued as soon as the backward has
+        produced it -- the temporal stack + heads travel over xGMI while the trunk backward runs."""
+        head_out, ctx = self.forward_train(frames_u8, crop, flip, drop_masks)
+        loss, dhead = self.temporal.loss_fwd_bwd(
+            head_out, ctx.B, ctx.T, None if label is None else label.reshape(-1).contiguous(),
+            labelD=None if labelD is None else labelD.reshape(-1).float().contiguous(),
+            soft=None if soft is None else soft.reshape(-1, soft.shape[-1]).contiguous(), fg_weight=fg_weight,
+            dataset=dataset)
+        self.backward_and_write(ctx, dhead, scale, first, reduce)
         return loss
 
+    def backward_and_write(self, ctx, dhead, scale=1.0, first=True, reduce=False):
+        """Backward of forward_train from d(loss)/d(head_out) with the gradients (times `scale`) written into the flat
+        buffer bucket by bucket; with `reduce` each bucket's all-reduce starts as soon as it is complete."""
+        red = self.reducer if reduce else None
+        g_t = {}
+        d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
+        self.write_grads(g_t, scale, first, partial=True)
+        if red is not None:
+            red.reduce_bucket(0)
+        g_b = self.backward_trunk(ctx, d_feat)
+        missing = set(self.params.index) - set(g_t) - set(g_b)
+        if missing:
+            raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
+        self.write_grads(g_b, scale, first, partial=True)
+        if red is not None:
+            red.reduce_bucket(1)
+
     def apply(self, lr=None, lr_factor=1.0, all_reduce=None):
-        """AdamW on the accumulated gradients (one launch), then refresh the kernels' views of the weights."""
+        """AdamW on the accumulated gradients (one launch), then refresh the kernels' views of the weights.  With a reducer
+        attached the current stream first waits for the bucket all-reduces and the 1/world of the mean rides on AdamW's
+        grad_scale; `all_reduce` is the older blocking form (callable(flat_grad))."""
+        gs = 1.0
         if all_reduce is not None:
             all_reduce(self.params.grad)
+        elif self.reducer is not None:
+            self.reducer.join()
+            gs = self.reducer.scale
         if lr is not None:
             self.opt.lr = lr
-        self.opt.step(lr_factor=lr_factor)
+        self.opt.step(lr_factor=lr_factor, grad_scale=gs)
         self.repack()
 
     def step(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, lr_factor=1.0,
              all_reduce=None):
-        """forward + backward + AdamW.  all_reduce: optional callable(flat_grad) for data-parallel jobs
-        (dist.all_reduce_mean_).  Returns the loss tensor [total, ce, mse]."""
-        loss = self.accumulate(frames_u8, label, labelD, soft, crop, flip, drop_masks)
+        """forward + backward + (data parallel: bucketed gradient all-reduce overlapped with the backward) + AdamW.
+        all_reduce: the older blocking form, a callable(flat_grad) (dist.all_reduce_mean_).  Returns [total, ce, mse]."""
+        loss = self.accumulate(frames_u8, label, labelD, soft, crop, flip, drop_masks,
+                               reduce=self.reducer is not None and all_reduce is None)
         self.apply(lr_factor=lr_factor, all_reduce=all_reduce)
         return loss
 
@@ -172,7 +230,10 @@ class TrainEngine:
         h.soft = torch.full((B, T, K1), 1.0 / K1, dtype=torch.float32, device=dev) if soft else None
         h.labelD = torch.zeros((B, T), dtype=torch.float32, device=dev) if with_labelD else None
         h.masks = [torch.ones((B, T, C), dtype=self.dt, device=dev) for _ in range(2 if radi > 0 else 1)]
-        run = lambda: self.accumulate(h.frames, h.label, h.labelD, soft=h.soft, drop_masks=h.masks)      # noqa: E731
+        red = self.reducer
+        h.reduce_in_graph = red is not None and red.capturable          # RCCL on its own stream joins the capture
+        run = lambda: self.accumulate(h.frames, h.label, h.labelD, soft=h.soft, drop_masks=h.masks,      # noqa: E731
+                                      reduce=h.reduce_in_graph)
         # eager warm-up on a side stream (lazy kernel attributes / module loads must happen outside the capture); the
         # BatchNorm buffers it touches are restored afterwards
         keep = {k: v.clone() for k, v in self.state.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
@@ -181,6 +242,8 @@ class TrainEngine:
         with torch.cuda.stream(side):
             self.repack()
             run()
+            if h.reduce_in_graph:
+                red.join()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for k, v in keep.items():
@@ -190,6 +253,8 @@ class TrainEngine:
         with torch.cuda.graph(h.graph, stream=side, capture_error_mode="thread_local"):
             self.repack()
             h.loss = run()
+            if h.reduce_in_graph:
+                red.join()
         for k, v in keep.items():                                # capture does not execute, but stay explicit
             self.state[k].copy_(v)
         torch.cuda.synchronize()
@@ -208,18 +273,25 @@ class TrainEngine:
             for dst, src in zip(h.masks, drop_masks):
                 dst.copy_(src, non_blocking=True)
         h.graph.replay()
+        gs = 1.0
         if all_reduce is not None:
             all_reduce(self.params.grad)
+        elif self.reducer is not None:
+            if not h.reduce_in_graph:                           # torch.distributed backends cannot be captured
+                self.reducer.reduce_all()
+                self.reducer.join()
+            gs = self.reducer.scale
         if lr is not None:
             self.opt.lr = lr
-        self.opt.step(lr_factor=lr_factor)                      # the next replay starts with repack(): no refresh needed here
+        self.opt.step(lr_factor=lr_factor, grad_scale=gs)       # the next replay starts with repack(): no refresh needed here
         return h.loss
 
     def make_step(self, B, H, W, frames, label, labelD=None, drop_masks=None, use_graph=True, world=1):
         """A zero-argument callable running one optimisation step on the given (static) batch: through the captured HIP graph
         or eagerly; for world > 1 the flat gradient buffer is all-reduced (RCCL) before AdamW."""
-        from . import dist as tdist
-        ar = tdist.all_reduce_mean_ if world > 1 else None
+        ar = None
+        if world > 1 and self.reducer is None:
+            self.set_reducer("auto")
         if not use_graph:
             return lambda: self.step(frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
         hnd = self.build_graph(B, H, W)

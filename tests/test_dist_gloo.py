@@ -62,3 +62,32 @@ def test_two_rank_gather_and_timing(n_clips):
     for rank, order, slow in res:
         assert order == [float(i) for i in range(n_clips)]      # global clip order restored on every rank
         assert slow == 1.5                                        # max over ranks
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    tdist.init(backend="gloo")
+    flat = torch.arange(100, dtype=torch.float32) * (rank + 1)          # rank 0: i, rank 1: 2i
+    red = tdist.GradReducer(flat, [(60, 100), (0, 60)])
+    assert red.backend == "torch" and not red.capturable and red.scale == 0.5
+    red.reduce_bucket(0)                                               # the late bucket first, like the backward
+    red.reduce_bucket(1)
+    red.join()
+    q.put((rank, flat.tolist()))
+    tdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_reducer_sums_every_bucket_over_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    want = [3.0 * i for i in range(100)]
+    assert res[0][1] == want and res[1][1] == want

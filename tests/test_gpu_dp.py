@@ -1,0 +1,120 @@
+"""Data-parallel training on the GPU box: the RCCL communicator behind the C ABI (single rank), and a 2-process job that
+shares the one GPU over gloo (TDEED_DIST_BACKEND=gloo style): the DP step must equal AdamW on the MEAN of the per-rank
+single-process gradients (SURVEY.md section 8e "DP parity test").  -m gpu only."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import t
+from tdeed_amd import synth, state_layout
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CFG = dict(feature_arch="rny002_gsf", clip_len=6, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+           radi_displacement=2)
+
+
+def test_rccl_communicator_single_rank_all_reduce_and_join():
+    """tdeed_comm_* through ctypes: unique id, init (world 1), in-place sum on the communicator's stream, join, also inside a
+    captured HIP graph (the form the training step uses)."""
+    from tdeed_amd import _lib
+    raw = (ctypes.c_ubyte * 128)()
+    _lib.call("tdeed_comm_unique_id", raw)
+    h = ctypes.c_void_p()
+    _lib.call("tdeed_comm_init", ctypes.byref(h), raw, 1, 0)
+    w, r = ctypes.c_int(), ctypes.c_int()
+    _lib.call("tdeed_comm_info", h, ctypes.byref(w), ctypes.byref(r))
+    assert (w.value, r.value) == (1, 0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        x = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
+        ref = x.clone()
+        x.mul_(2.0)
+        _lib.call("tdeed_comm_all_reduce", h, x.data_ptr(), x.numel(), 0, st.cuda_stream)
+        _lib.call("tdeed_comm_all_reduce_rs_ag", h, x.data_ptr(), x.numel(), 0, st.cuda_stream)
+        _lib.call("tdeed_comm_join", h, st.cuda_stream)
+        y = x + 1.0
+        st.synchronize()
+    assert torch.equal(y, ref * 2.0 + 1.0)
+    xb = torch.ones(4096, dtype=torch.bfloat16, device=DEV)
+    with torch.cuda.stream(st):
+        _lib.call("tdeed_comm_all_reduce", h, xb.data_ptr(), xb.numel(), 1, st.cuda_stream)
+        _lib.call("tdeed_comm_join", h, st.cuda_stream)
+        st.synchronize()
+    assert float(xb.float().sum()) == 4096.0
+    _lib.call("tdeed_comm_destroy", h)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(rank):
+    B, T = 2, CFG["clip_len"]
+    frames = t(synth.uint8_clip(1300 + rank, (B, T, 3, 64, 64)))
+    lab, labD = synth.labels(1400 + rank, B, T, CFG["num_classes"], CFG["radi_displacement"], fg_frac=0.4)
+    return frames, t(lab).long(), t(labD).float()
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from tdeed_amd import dist as tdist
+    from tdeed_amd.trainer import TrainEngine
+    torch.cuda.set_device(0)                                  # both ranks share the one GPU of the box
+    tdist.init(backend="gloo")
+    sd = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(CFG), 17).items()}
+    eng = TrainEngine(CFG, sd, act_dtype=torch.float32, device="cuda:0", lr=1e-3)
+    red = eng.set_reducer("auto")
+    assert red is not None and red.backend == "torch" and red.world == world and len(red.buckets) == 2
+    frames, lab, labD = _batch(rank)
+    eng.step(frames.to("cuda:0"), lab.to("cuda:0"), labD.to("cuda:0"))
+    torch.cuda.synchronize()
+    keys = [k for k in eng.params.index]
+    q.put((rank, {k: eng.state[k].detach().cpu().numpy() for k in keys},
+           eng.params.grad.detach().cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_step_equals_adamw_on_the_mean_of_per_rank_gradients():
+    from tdeed_amd.trainer import TrainEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process reference: per-rank gradients from fresh engines, averaged, one AdamW step
+    grads = []
+    for rank in range(2):
+        sd = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(CFG), 17).items()}
+        eng = TrainEngine(CFG, sd, act_dtype=torch.float32, device=DEV, lr=1e-3)
+        frames, lab, labD = _batch(rank)
+        eng.accumulate(frames.to(DEV), lab.to(DEV), labD.to(DEV))
+        grads.append(eng.params.grad.clone())
+    mean = (grads[0] + grads[1]) * 0.5
+    # both ranks hold the summed gradient buffer and identical parameters afterwards
+    assert np.array_equal(res[0][2], res[1][2])
+    assert float((torch.from_numpy(res[0][2]).to(DEV) * 0.5 - mean).abs().max()) <= 1e-6 * float(mean.abs().max()) + 1e-12
+    eng.params.grad.copy_(mean)
+    eng.apply()
+    torch.cuda.synchronize()
+    for k in eng.params.index:
+        want = eng.state[k].detach().cpu().numpy()
+        for r in (0, 1):
+            assert np.abs(res[r][1][k] - want).max() <= 2e-7 + 1e-6 * np.abs(want).max(), (k, r)
