@@ -69,12 +69,15 @@ int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top,
  *       [F][gather_ho][gather_wo] grid reads input row (f, yo*s, xo*s) of [F][gather_hi][gather_wi].
  *   W   [N][K] row stride ldw, same dtype as A.   scale/shift: fp32 [N], either may be NULL.
  *   R   optional residual [M][N] row stride ldr.   C: [M][N] row stride ldc.
- * K, N, k0, lda, lda0, ldw, ldr, ldc must be multiples of 8. */
+ * K, N, k0, lda, lda0, ldw, ldr, ldc must be multiples of 8.
+ *   colpart  optional fp32 [ceil(M/128)][2][N]: per 128-row tile the column sums and sums of squares of the stored C
+ *       (training: the BatchNorm batch statistics of a raw conv output come out of the conv's own epilogue; fold them
+ *       with tdeed_bn_finalize(colpart, colpart + N, 2N, ceil(M/128), M, N, ...)). */
 int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
                    const float* a_scale, int a_scale_rows, int M, int K, int N, const void* W,
                    long ldw, const float* scale, const float* shift, const void* R, long ldr,
                    int act, void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
-                   int gather_ho, int gather_wo, int dtype, void* stream);
+                   int gather_ho, int gather_wo, float* colpart, int dtype, void* stream);
 
 /* Weight-stationary variant of the same contraction for narrow layers (whole W in LDS, activations
  * streamed global->registers in MFMA fragment shape, persistent blocks; see gemm.hip).  Same
@@ -97,12 +100,14 @@ int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0
  *   wfrag  bf16 MFMA operand fragments [ceil4(C/16)][5][64][8] (see tdeed_amd.engine.pack_gconv_frags);
  *          TDEED_BF16 only: implicit GEMM on v_mfma_f32_16x16x32_bf16 from an LDS-staged halo band.
  *   pooled fp32 [N][parts][C]: per-band partial SUMS of y over pixels, parts =
- *          tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype) (1 on the VALU path). */
+ *          tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype) (1 on the VALU path).
+ *   pooled_sq  optional (bf16 MFMA path), same shape: partial sums of y^2 -- with pooled the BatchNorm batch statistics
+ *          of the raw conv output (tdeed_bn_finalize(pooled, pooled_sq, C, N*parts, N*Ho*Wo, C, ...)). */
 int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype);
 int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                        const float* w, const void* wfrag, const float* scale, const float* shift,
-                       void* y, float* pooled, int relu /* 0: y = conv*scale+shift (training: raw map for the
-                       batch statistics) */, int dtype, void* stream);
+                       void* y, float* pooled, float* pooled_sq, int relu /* 0: y = conv*scale+shift (training: raw map
+                       for the batch statistics) */, int dtype, void* stream);
 
 /* ---- whole bottleneck in one launch (bf16, stride 1, identity shortcut, map <= 64 px: s4.b2.. of RegNetY-200MF)
  * conv1(+gate-shift splice G in front)+BN+ReLU -> grouped 3x3+BN+ReLU -> SE -> conv3+BN+residual+ReLU, one
@@ -293,6 +298,10 @@ int tdeed_fill_u8_hash(uint8_t* dst, long n, uint64_t seed, void* stream); /* sy
 int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream);
 /* the same over rows that are `stride` floats apart (several parameter groups side by side in one partial row) */
 int tdeed_reduce_strided(const float* part, int P, long stride, long n, float* out, void* stream);
+/* gradient write-out of a whole step in one launch: tab = device array of nt records {const float* src; long dst_offset;
+ * long n; long first_chunk} (first_chunk = running sum of ceil(n / 4096) over the records before it), n_chunks = that sum
+ * over all records; dst[off + i] = (accumulate ? dst[off + i] : 0) + scale * src[i]. */
+int tdeed_multi_copy(const void* tab, int nt, long n_chunks, float* dst, float scale, int accumulate, void* stream);
 /* mode 0: y = gelu(x); 1: y = dy * gelu'(x); 2: y = x + dy; 3: y = x * dy.  n elements, multiple of 8 */
 int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream);
 /* [R][Cc] -> [Cc][R] (weight transposes for the input-gradient contractions) */
@@ -333,14 +342,21 @@ int tdeed_bn_slabs(long M);
 int tdeed_bn_train_stats(const void* z, long M, int C, const float* w, const float* bias, float eps, float momentum,
                          float* part, float* mean, float* rstd, float* a, float* b, float* run_mean, float* run_var,
                          int dtype, void* stream);
+/* the finalisation alone, from partial sums a producer's epilogue wrote (see tdeed_gemm_fwd colpart, tdeed_gconv3x3_fwd
+ * pooled_sq): P rows of per-channel sums (part_s) / sums of squares (part_q), pstride floats apart, covering M rows */
+int tdeed_bn_finalize(const float* part_s, const float* part_q, long pstride, int P, long M, int C, const float* w,
+                      const float* bias, float eps, float momentum, float* mean, float* rstd, float* a, float* b,
+                      float* run_mean, float* run_var, void* stream);
 /* y = act(z * a[c] + b[c] + res) */
 int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu, void* y,
                    int dtype, void* stream);
-/* BatchNorm (training) backward; y (the block's output) gives the ReLU mask when relu != 0; d_res (optional) receives
- * the masked gradient = gradient of the residual summed in before the ReLU.  sums fp32 [2][C] scratch. */
+/* BatchNorm (training) backward; when relu != 0 the ReLU mask comes from y (the block's output) or, with y NULL (no
+ * residual in front of the ReLU), from z through the forward affine fa, fb (y > 0 <=> fa*z + fb > 0: one map less to
+ * read); d_res (optional) receives the masked gradient = gradient of the residual summed in before the ReLU.  sums fp32
+ * [2][C]: sums[0] = db, sums[1] = dw (also copied to db / dw when those are non-NULL). */
 int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, int relu, long M, int C, const float* mean,
-                       const float* rstd, const float* w, float* part, float* sums, void* dz, void* d_res, float* dw,
-                       float* db, int dtype, void* stream);
+                       const float* rstd, const float* w, const float* fa, const float* fb, float* part, float* sums,
+                       void* dz, void* d_res, float* dw, float* db, int dtype, void* stream);
 /* p[n][c] = mean_px x (x2 NULL: the SE squeeze) or sum_px x*x2 (gradient of the SE gate) */
 int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, float* p, int dtype, void* stream);
 /* SE excitation keeping the hidden units: w1t [C][R], w2t [R][C] */

@@ -39,12 +39,12 @@ _SIGS = {
     "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,
                             P, P, P, P, P, P, P], c_int),
     "tdeed_gemm_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, c_long, P, P, P, c_long,
-                        c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
+                        c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gemm_ws_fits": ([c_int, c_int, c_int], c_int),
     "tdeed_gemm_ws_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, c_long,
                            c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gconv3x3_parts": ([c_int, c_int, c_int, c_int, c_int], c_int),
-    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_bneck_set_debug": ([P], c_int),
     "tdeed_bneck_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P], c_int),
@@ -55,7 +55,8 @@ _SIGS = {
     "tdeed_bn_slabs": ([c_long], c_int),
     "tdeed_bn_train_stats": ([P, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_bn_apply": ([P, c_long, c_int, P, P, P, c_int, P, c_int, P], c_int),
-    "tdeed_bn_train_bwd": ([P, P, P, c_int, c_long, c_int, P, P, P, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_bn_train_bwd": ([P, P, P, c_int, c_long, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_bn_finalize": ([P, P, c_long, c_int, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P], c_int),
     "tdeed_pool_rows": ([P, P, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_se_train_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P, P], c_int),
     "tdeed_se_train_bwd": ([P, P, P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
@@ -70,6 +71,7 @@ _SIGS = {
     "tdeed_gsf_bwd": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                        c_int, P], c_int),
     "tdeed_gsf_add_cols": ([P, P, c_long, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_multi_copy": ([P, c_int, c_long, P, c_float, c_int, P], c_int),
     "tdeed_reduce_partials": ([P, c_int, c_long, P, c_int, P], c_int),
     "tdeed_eltwise": ([P, P, P, c_long, c_int, c_int, P], c_int),
     "tdeed_transpose": ([P, c_int, c_int, P, c_int, P], c_int),

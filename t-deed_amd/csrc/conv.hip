@@ -232,10 +232,12 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             bf16_t* __restrict__ y, float* __restrict__ pooled,
+                                                            float* __restrict__ pooled_sq,
                                                             int Ho, int Wo, int band, int nbands, int CSP, int PS,
                                                             int rows_in, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   __shared__ float red[4][16];
+  __shared__ float redq[4][16];
   // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
   const int nslabs_ = (C + CSP - 1) / CSP;
@@ -297,13 +299,14 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
     off[ks] = sidx < 18 ? (dy * WP + dx) * PS + half * 16 + unit * 32 : unit * 32;
   }
   const int ch0 = cs0 + unit * 16 + q * 4;      // this lane's 4 output channels
-  float sc[4], sh[4], psum[4];
+  float sc[4], sh[4], psum[4], psq[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const bool ok = ch0 + r < C;
     sc[r] = ok ? scale[ch0 + r] : 0.f;
     sh[r] = ok ? shift[ch0 + r] : 0.f;
     psum[r] = 0.f;
+    psq[r] = 0.f;
   }
   const int npix = nrows_out * Wo;
   const int ntiles = (npix + 15) >> 4;
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
         const float v = relu ? fmaxf(acc[r] * sc[r] + sh[r], 0.f) : acc[r] * sc[r] + sh[r];
         o[r] = (bf16_t)v;
         psum[r] += (float)o[r];
+        psq[r] = fmaf((float)o[r], (float)o[r], psq[r]);
       }
       *reinterpret_cast<bf16x4*>(yout + (long)pc * C + ch0) = o;
     }
@@ -342,14 +346,28 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
     v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 8, 64);
     if (pl == 0) red[wv][q * 4 + r] = v;
+    if (pooled_sq) {            // training: sums of squares too (BatchNorm statistics of the raw conv output)
+      float w = psq[r];
+      w += __shfl_xor(w, 1, 64);
+      w += __shfl_xor(w, 2, 64);
+      w += __shfl_xor(w, 4, 64);
+      w += __shfl_xor(w, 8, 64);
+      if (pl == 0) redq[wv][q * 4 + r] = w;
+    }
   }
   __syncthreads();
   if (threadIdx.x < units * 16) {
     const int u = threadIdx.x >> 4, cc = threadIdx.x & 15;
-    float sres = 0.f;
-    for (int w2 = u; w2 < 4; w2 += units) sres += red[w2][cc];
+    float sres = 0.f, qres = 0.f;
+    for (int w2 = u; w2 < 4; w2 += units) {
+      sres += red[w2][cc];
+      if (pooled_sq) qres += redq[w2][cc];
+    }
     const int ch = cs0 + u * 16 + cc;
-    if (ch < C) pooled[((long)n * nbands + bnd) * C + ch] = sres;
+    if (ch < C) {
+      pooled[((long)n * nbands + bnd) * C + ch] = sres;
+      if (pooled_sq) pooled_sq[((long)n * nbands + bnd) * C + ch] = qres;
+    }
   }
 }
 
@@ -361,8 +379,9 @@ extern "C" int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype
 
 extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                                   const float* w, const void* wfrag, const float* scale, const float* shift,
-                                  void* y, float* pooled, int relu, int dtype, void* stream) {
+                                  void* y, float* pooled, float* pooled_sq, int relu, int dtype, void* stream) {
   TD_CHECK(x && scale && shift && y && pooled, "gconv3x3: null pointer");
+  TD_CHECK(!pooled_sq || (dtype == TDEED_BF16 && wfrag), "gconv3x3: sums of squares come from the bf16 MFMA kernel only");
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "gconv3x3: group width %d / C %d unsupported", gw, C);
   TD_CHECK(stride == 1 || stride == 2, "gconv3x3: stride %d", stride);
   TD_CHECK(N > 0 && N <= 65535 && Hi > 0 && Wi > 0, "gconv3x3: bad sizes");
@@ -384,11 +403,11 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
     size_t smem = (size_t)g.rows_in * (Wi + 2) * g.PS;
     if (stride == 1)
       hipLaunchKernelGGL(gconv3x3_mfma_kernel<1>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
-                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP,
+                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, pooled_sq, Ho, Wo, g.band, g.nbands, g.CSP,
                          g.PS, g.rows_in, relu);
     else
       hipLaunchKernelGGL(gconv3x3_mfma_kernel<2>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
-                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP,
+                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, pooled_sq, Ho, Wo, g.band, g.nbands, g.CSP,
                          g.PS, g.rows_in, relu);
     TD_LAUNCH_CHECK("gconv3x3_mfma");
     return TDEED_OK;

@@ -27,6 +27,7 @@ struct GemmP {
   int act;
   void* C; long ldc;
   int g_stride, g_hi, g_wi, g_ho, g_wo;
+  float* colpart;      // optional [M tiles][2][N]: per-tile column sums / sums of squares of the stored C (BatchNorm statistics)
 };
 
 template <typename T> struct Frag;
@@ -244,6 +245,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     sh[nt] = (p.shift && ok) ? p.shift[n] : 0.0f;
   }
   constexpr int CPR = BN / EPC;   // chunks per tile row
+  // training: column sum / sum of squares of what is stored (rounded to T), per M tile: the BatchNorm statistics of a raw
+  // conv output come out of its own epilogue instead of a second pass over the map.  A thread always serves the same
+  // column chunk (CPR divides 256), so it accumulates over its rows in registers; lanes are folded through LDS at the end.
+  float cs1[EPC], cs2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) cs1[e] = cs2[e] = 0.f;
   for (int half = 0; half < 2; ++half) {
     if (wr == half) {
 #pragma unroll
@@ -280,9 +287,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
           for (int e = 0; e < EPC; ++e) v[e] = gelu_erf(v[e]);
         }
         Chunk<T>::store(reinterpret_cast<T*>(p.C) + m * p.ldc + n, v);
+        if (p.colpart) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float r = round_to<T>(v[e]);
+            cs1[e] += r;
+            cs2[e] = fmaf(r, r, cs2[e]);
+          }
+        }
       }
     }
     __syncthreads();
+  }
+  if (p.colpart) {
+    constexpr int RLN = 256 / CPR;          // row lanes per column chunk
+    float* red = reinterpret_cast<float*>(lds);                 // [RLN][2][BN]  (<= 64 * CS_LD floats)
+    const int cj = tid % CPR, rl = tid / CPR;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red[(rl * 2 + 0) * BN + cj * EPC + e] = cs1[e];
+      red[(rl * 2 + 1) * BN + cj * EPC + e] = cs2[e];
+    }
+    __syncthreads();
+    for (int j = tid; j < 2 * BN; j += 256) {
+      const int which = j / BN, col = j - which * BN;
+      if (n0 + col < p.N) {
+        float a = 0.f;
+        for (int i = 0; i < RLN; ++i) a += red[(i * 2 + which) * BN + col];
+        p.colpart[((long)tile_m * 2 + which) * p.N + n0 + col] = a;
+      }
+    }
   }
 }
 
@@ -332,7 +366,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
                               const void* W, long ldw, const float* scale, const float* shift,
                               const void* R, long ldr, int act, void* C, long ldc,
                               int gather_stride, int gather_hi, int gather_wi, int gather_ho,
-                              int gather_wo, int dtype, void* stream) {
+                              int gather_wo, float* colpart, int dtype, void* stream) {
   TD_CHECK(A && W && C, "gemm: null pointer");
   TD_CHECK(M > 0 && K > 0 && N > 0, "gemm: bad sizes M=%d K=%d N=%d", M, K, N);
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gemm: bad dtype %d", dtype);
@@ -352,6 +386,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   p.M = M; p.K = K; p.N = N; p.W = W; p.ldw = ldw; p.scale = scale; p.shift = shift;
   p.R = R; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
   p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
+  p.colpart = colpart;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st) : launch_gemm<bf16_t>(p, st);
 }

@@ -8,25 +8,48 @@
 
 // =========================================================================== small generic pieces
 // out[j] = sum_p part[p][j]  (ordered), optionally out[j] += ...
+// A workgroup owns CW consecutive columns; its 256 / CW row lanes each sum every (256/CW)-th partial (8 loads in flight
+// per lane), then the lanes' sums are folded in a fixed order through LDS: same result on every run, and a fold over
+// thousands of partials is a few microseconds instead of one serial chain per output.
+template <int CW>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, long stride, long n,
                                                               float* __restrict__ out, int accumulate) {
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  constexpr int PL = 256 / CW;
+  __shared__ float red[PL][CW + 1];
+  const int c = threadIdx.x % CW, pl = threadIdx.x / CW;
+  const long j = (long)blockIdx.x * CW + c;
+  const long jj = min(j, n - 1);
   float s = 0.f;
-  for (int p0 = 0; p0 < P; p0 += 8) {
+  for (int p0 = pl; p0 < P; p0 += 8 * PL) {
     float v[8];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) v[b] = part[(long)min(p0 + b, P - 1) * stride + j];
+    for (int b = 0; b < 8; ++b) v[b] = part[(long)min(p0 + b * PL, P - 1) * stride + jj];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) s += p0 + b < P ? v[b] : 0.f;
+    for (int b = 0; b < 8; ++b) s += p0 + b * PL < P ? v[b] : 0.f;
   }
-  out[j] = accumulate ? out[j] + s : s;
+  red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && j < n) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) a += red[i][c];
+    out[j] = accumulate ? out[j] + a : a;
+  }
+}
+
+static void launch_reduce(const float* part, int P, long stride, long n, float* out, int accumulate, hipStream_t st) {
+  // few partials: 64 columns x 4 lanes; many partials of a narrow output: 8 columns x 32 lanes (more workgroups, shorter chains)
+  if (P >= 512 && n <= 4096)
+    hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
+  else if (P >= 64)
+    hipLaunchKernelGGL(reduce_partials_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
 }
 
 extern "C" int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream) {
   TD_CHECK(part && out && P > 0 && n > 0, "reduce_partials: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
-                     P, n, n, out, accumulate);
+  launch_reduce(part, P, n, n, out, accumulate, (hipStream_t)stream);
   TD_LAUNCH_CHECK("reduce_partials");
   return TDEED_OK;
 }
@@ -34,9 +57,39 @@ extern "C" int tdeed_reduce_partials(const float* part, int P, long n, float* ou
 // rows of `part` hold several parameter groups side by side: fold n columns of rows that are `stride` floats apart
 extern "C" int tdeed_reduce_strided(const float* part, int P, long stride, long n, float* out, void* stream) {
   TD_CHECK(part && out && P > 0 && n > 0 && stride >= n, "reduce_strided: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
-                     P, stride, n, out, 0);
+  launch_reduce(part, P, stride, n, out, 0, (hipStream_t)stream);
   TD_LAUNCH_CHECK("reduce_strided");
+  return TDEED_OK;
+}
+
+// gradient write-out: a table of (source pointer, destination offset in `dst`, element count) for every parameter
+// tensor of a step; dst[off + i] = (accumulate ? dst[off + i] : 0) + scale * src[i].  One launch for all tensors (a
+// per-tensor device copy is ~3 us; a 200MF step has 431 of them).  Workgroup b serves chunk b of the concatenated ranges
+// (chunk = 4096 elements; `first_chunk[t]` = first chunk of tensor t, binary-searched).
+struct CopyEnt { const float* src; long off; long n; long first_chunk; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyEnt* __restrict__ tab, int nt, float* __restrict__ dst,
+                                                         float scale, int accumulate) {
+  const long b = blockIdx.x;
+  int lo = 0, hi = nt - 1;
+  while (lo < hi) {                                              // last entry with first_chunk <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_chunk <= b) lo = mid; else hi = mid - 1;
+  }
+  const CopyEnt e = tab[lo];
+  const long i0 = (b - e.first_chunk) * 4096;
+  for (long i = i0 + threadIdx.x; i < min(e.n, i0 + 4096); i += 256) {
+    const float v = scale * e.src[i];
+    dst[e.off + i] = accumulate ? dst[e.off + i] + v : v;
+  }
+}
+
+// tab: device array of nt entries {src pointer, dst offset, n, first chunk}; n_chunks = total chunks (sum of ceil(n / 4096))
+extern "C" int tdeed_multi_copy(const void* tab, int nt, long n_chunks, float* dst, float scale, int accumulate,
+                                void* stream) {
+  TD_CHECK(tab && dst && nt > 0 && n_chunks > 0 && n_chunks < 0x7fffffffL, "multi_copy: bad arguments");
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const CopyEnt*)tab, nt,
+                     dst, scale, accumulate);
+  TD_LAUNCH_CHECK("multi_copy");
   return TDEED_OK;
 }
 
@@ -245,13 +298,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restric
   }
 }
 
-// number of M slices: enough workgroups to fill the chip (~1024) without slices shorter than 64 rows
+// number of M slices: enough workgroups that every CU holds several (each one is a chain of dependent 32-row steps:
+// latency hidden by its neighbours), without slices shorter than 256 rows or more than 32 MB of partials
 extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
   const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
-  long z = (1024 + tiles - 1) / tiles;
-  const long zmax = (M + 63) / 64;
+  long z = (2048 + tiles - 1) / tiles;
+  const long zmax = (M + 255) / 256;
   if (z > zmax) z = zmax;
-  if (z > 128) z = 128;
+  const long zbytes = (32L << 20) / ((long)N * K * 4);
+  if (z > zbytes) z = zbytes;
+  if (z > 2048) z = 2048;
   return (int)(z < 1 ? 1 : z);
 }
 
@@ -402,8 +458,8 @@ extern "C" int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long
   } else { tdeed_set_error("layernorm_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("layernorm_bwd");
   // part viewed as [nb][2C]: the first C columns of a row are d weight, the next C are d bias
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, nb, 2L * C, (long)C, dw, 0);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part + C, nb, 2L * C, (long)C, db, 0);
+  launch_reduce(part, nb, 2L * C, (long)C, dw, 0, st);
+  launch_reduce(part + C, nb, 2L * C, (long)C, db, 0, st);
   TD_LAUNCH_CHECK("layernorm_bwd reduce");
   return TDEED_OK;
 }
@@ -502,8 +558,8 @@ extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, 
   else { tdeed_set_error("groupnorm_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("groupnorm_bwd");
   // part viewed as [B][2C]: the first C columns of each row are d weight, the next C are d bias
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, B, 2L * C, (long)C, dw, 0);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part + C, B, 2L * C, (long)C, db, 0);
+  launch_reduce(part, B, 2L * C, (long)C, dw, 0, st);
+  launch_reduce(part + C, B, 2L * C, (long)C, db, 0, st);
   TD_LAUNCH_CHECK("groupnorm_bwd reduce");
   return TDEED_OK;
 }

@@ -16,6 +16,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, const T* __restrict__ dy,
                                                        const T* __restrict__ y, long M, int C, int mode, int relu,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ fa, const float* __restrict__ fb,
                                                        long rows_per_slab, float* __restrict__ part) {
   constexpr int EPC = Chunk<T>::N;
   extern __shared__ float sred[];                              // [RL][2][C]
@@ -24,12 +25,17 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
   const long m0 = (long)blockIdx.x * rows_per_slab, m1 = min(M, m0 + rows_per_slab);
   for (int ch = threadIdx.x % nch, rl = threadIdx.x / nch; rl < RL && ch < nch; ch += 256) {      // one pass if nch <= 256
     const int c0 = ch * EPC;
-    float s1[EPC], s2[EPC], mu[EPC], rs[EPC];
+    // ReLU mask of the backward: from the stored activation y, or (no residual in front of the ReLU: y == nullptr)
+    // recomputed from z through the forward affine, y > 0 <=> fa * z + fb > 0 -- one map less to read
+    const bool zmask = mode && relu && !y;
+    float s1[EPC], s2[EPC], mu[EPC], rs[EPC], ma[EPC], mb[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       s1[e] = 0.f; s2[e] = 0.f;
       mu[e] = mode ? mean[c0 + e] : 0.f;
       rs[e] = mode ? rstd[c0 + e] : 0.f;
+      ma[e] = zmask ? fa[c0 + e] : 0.f;
+      mb[e] = zmask ? fb[c0 + e] : 0.f;
     }
     for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * CS_B) {
       float zv[CS_B][EPC], gv[CS_B][EPC], yv[CS_B][EPC];
@@ -38,7 +44,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
         const long r = min(r0 + (long)b * RL, m1 - 1);
         Chunk<T>::load(z + r * C + c0, zv[b]);
         if (mode) Chunk<T>::load(dy + r * C + c0, gv[b]);
-        if (mode && relu) Chunk<T>::load(y + r * C + c0, yv[b]);
+        if (mode && relu && !zmask) Chunk<T>::load(y + r * C + c0, yv[b]);
       }
 #pragma unroll
       for (int b = 0; b < CS_B; ++b)
@@ -49,7 +55,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
               s1[e] += zv[b][e];
               s2[e] = fmaf(zv[b][e], zv[b][e], s2[e]);
             } else {
-              const float g = (relu && !(yv[b][e] > 0.f)) ? 0.f : gv[b][e];
+              const float act = zmask ? fmaf(zv[b][e], ma[e], mb[e]) : yv[b][e];
+              const float g = (relu && !(act > 0.f)) ? 0.f : gv[b][e];
               s1[e] += g;
               s2[e] = fmaf(g, (zv[b][e] - mu[e]) * rs[e], s2[e]);
             }
@@ -72,7 +79,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
 
 // sums [2][C] (folded partials) -> mean, rstd, the affine a = w * rstd, b = bias - mean * a, running statistics
 // (torch BatchNorm: biased variance to normalise, unbiased M/(M-1) into running_var, momentum 0.1)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int P, long M, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part_s, const float* __restrict__ part_q,
+                                                          long pstride, int P, long M, int C,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ a,
@@ -83,8 +91,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int p = threadIdx.x; p < P; p += 256) {
-    s1 += (double)part[((long)p * 2 + 0) * C + c];
-    s2 += (double)part[((long)p * 2 + 1) * C + c];
+    s1 += (double)part_s[(long)p * pstride + c];
+    s2 += (double)part_q[(long)p * pstride + c];
   }
   r1[threadIdx.x] = s1;
   r2[threadIdx.x] = s2;
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 static int colstats_slabs(long M, long* rows_per_slab) {
   long slabs = (M + 511) / 512;
-  if (slabs > 4096) slabs = 4096;
+  if (slabs > 2048) slabs = 2048;
   if (slabs < 1) slabs = 1;
   *rows_per_slab = (M + slabs - 1) / slabs;
   return (int)((M + *rows_per_slab - 1) / *rows_per_slab);
@@ -126,13 +134,14 @@ extern "C" int tdeed_bn_slabs(long M) { long r; return colstats_slabs(M, &r); }
 
 template <typename T>
 static int launch_colstats(const void* z, const void* dy, const void* y, long M, int C, int mode, int relu,
-                           const float* mean, const float* rstd, float* part, hipStream_t st) {
+                           const float* mean, const float* rstd, const float* fa, const float* fb, float* part,
+                           hipStream_t st) {
   long rps;
   const int slabs = colstats_slabs(M, &rps);
   const int nch = C / Chunk<T>::N;
   const int RL = 256 / nch > 0 ? 256 / nch : 1;
   hipLaunchKernelGGL(colstats_kernel<T>, dim3(slabs), dim3(256), (size_t)RL * 2 * C * sizeof(float), st, (const T*)z,
-                     (const T*)dy, (const T*)y, M, C, mode, relu, mean, rstd, rps, part);
+                     (const T*)dy, (const T*)y, M, C, mode, relu, mean, rstd, fa, fb, rps, part);
   return slabs;
 }
 
@@ -145,12 +154,26 @@ extern "C" int tdeed_bn_train_stats(const void* z, long M, int C, const float* w
   TD_CHECK(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "bn_train_stats: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   int slabs;
-  if (dtype == TDEED_F32) slabs = launch_colstats<float>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, part, st);
-  else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, part, st);
+  if (dtype == TDEED_F32) slabs = launch_colstats<float>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, nullptr, nullptr, part, st);
+  else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, nullptr, nullptr, part, st);
   else { tdeed_set_error("bn_train_stats: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("bn colstats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, slabs, M, C, w, bias, eps, momentum,
-                     mean, rstd, a, b, run_mean, run_var);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, part + C, 2L * C, slabs, M, C, w, bias, eps,
+                     momentum, mean, rstd, a, b, run_mean, run_var);
+  TD_LAUNCH_CHECK("bn_finalize");
+  return TDEED_OK;
+}
+
+// The same finalisation from partial sums a producer wrote in its own epilogue: part_s / part_q hold P rows of per-channel
+// sums / sums of squares, `pstride` floats apart (tdeed_gemm_fwd's colpart: part_q = part_s + N, pstride = 2N;
+// tdeed_gconv3x3_fwd's pooled / pooled_sq: pstride = C).  M = rows the sums cover.
+extern "C" int tdeed_bn_finalize(const float* part_s, const float* part_q, long pstride, int P, long M, int C,
+                                 const float* w, const float* bias, float eps, float momentum, float* mean, float* rstd,
+                                 float* a, float* b, float* run_mean, float* run_var, void* stream) {
+  TD_CHECK(part_s && part_q && w && bias && mean && rstd && a && b, "bn_finalize: null pointer");
+  TD_CHECK(P > 0 && M > 0 && C > 0 && pstride >= C, "bn_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part_s, part_q, pstride, P, M, C, w,
+                     bias, eps, momentum, mean, rstd, a, b, run_mean, run_var);
   TD_LAUNCH_CHECK("bn_finalize");
   return TDEED_OK;
 }
@@ -203,6 +226,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, int relu,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ w, const float* __restrict__ sums,
+                                                           const float* __restrict__ fa, const float* __restrict__ fb,
                                                            float inv_M, T* __restrict__ dz, T* __restrict__ d_res,
                                                            long nchunks, int nch) {
   constexpr int EPC = Chunk<T>::N;
@@ -213,11 +237,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   float zv[EPC], gv[EPC], yv[EPC];
   Chunk<T>::load(z + i * EPC, zv);
   Chunk<T>::load(dy + i * EPC, gv);
-  if (relu) Chunk<T>::load(y + i * EPC, yv);
+  const bool zmask = relu && !y;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) yv[e] = 1.f;
+  if (relu && !zmask) Chunk<T>::load(y + i * EPC, yv);
+  // every per-channel vector is loaded unconditionally (a load under a per-element run-time select is a branch and a
+  // full wait per element): without the forward affine a valid dummy array is read and ignored
+  const float* pa = zmask ? fa : mean;
+  const float* pb = zmask ? fb : mean;
+  float av[EPC], bv[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    av[e] = pa[c0 + e];
+    bv[e] = pb[c0 + e];
+  }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     const int c = c0 + e;
-    const float g = (relu && !(yv[e] > 0.f)) ? 0.f : gv[e];
+    const float act = zmask ? fmaf(zv[e], av[e], bv[e]) : yv[e];
+    const float g = (relu && !(act > 0.f)) ? 0.f : gv[e];
     const float xh = (zv[e] - mean[c]) * rstd[c];
     gv[e] = g;
     zv[e] = w[c] * rstd[c] * (g - sums[c] * inv_M - xh * sums[C + c] * inv_M);
@@ -228,14 +266,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 // part: fp32 [tdeed_bn_slabs(M)][2][C]; sums: fp32 [2][C] scratch; dw, db: fp32 [C]
 extern "C" int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, int relu, long M, int C,
-                                  const float* mean, const float* rstd, const float* w, float* part, float* sums,
-                                  void* dz, void* d_res, float* dw, float* db, int dtype, void* stream) {
-  TD_CHECK(z && dy && (!relu || y) && mean && rstd && w && part && sums && dz && dw && db, "bn_train_bwd: null pointer");
+                                  const float* mean, const float* rstd, const float* w, const float* fa, const float* fb,
+                                  float* part, float* sums, void* dz, void* d_res, float* dw, float* db, int dtype,
+                                  void* stream) {
+  TD_CHECK(z && dy && (!relu || y || (fa && fb)) && mean && rstd && w && part && sums && dz, "bn_train_bwd: null pointer");
   TD_CHECK(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "bn_train_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   int slabs;
-  if (dtype == TDEED_F32) slabs = launch_colstats<float>(z, dy, y, M, C, 1, relu, mean, rstd, part, st);
-  else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, dy, y, M, C, 1, relu, mean, rstd, part, st);
+  if (dtype == TDEED_F32) slabs = launch_colstats<float>(z, dy, y, M, C, 1, relu, mean, rstd, fa, fb, part, st);
+  else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, dy, y, M, C, 1, relu, mean, rstd, fa, fb, part, st);
   else { tdeed_set_error("bn_train_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("bn bwd colstats");
   int rc = tdeed_reduce_partials(part, slabs, 2L * C, sums, 0, stream);
@@ -244,18 +283,24 @@ extern "C" int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, 
   if (dtype == TDEED_F32) {
     const long n = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)z,
-                       (const float*)dy, (const float*)y, relu, mean, rstd, w, sums, inv_M, (float*)dz, (float*)d_res, n,
-                       C / 4);
+                       (const float*)dy, (const float*)y, relu, mean, rstd, w, sums, fa, fb, inv_M, (float*)dz, (float*)d_res,
+                       n, C / 4);
   } else {
     const long n = M * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)z,
-                       (const bf16_t*)dy, (const bf16_t*)y, relu, mean, rstd, w, sums, inv_M, (bf16_t*)dz, (bf16_t*)d_res,
-                       n, C / 8);
+                       (const bf16_t*)dy, (const bf16_t*)y, relu, mean, rstd, w, sums, fa, fb, inv_M, (bf16_t*)dz,
+                       (bf16_t*)d_res, n, C / 8);
   }
   TD_LAUNCH_CHECK("bn_bwd_apply");
-  hipError_t e1 = hipMemcpyAsync(db, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
-  hipError_t e2 = hipMemcpyAsync(dw, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e1 != hipSuccess || e2 != hipSuccess) { tdeed_set_error("bn_train_bwd: copy failed"); return TDEED_ERR_RUNTIME; }
+  // db = sums[0:C], dw = sums[C:2C]: callers that pass NULL read them straight out of `sums`
+  if (db) {
+    hipError_t e1 = hipMemcpyAsync(db, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e1 != hipSuccess) { tdeed_set_error("bn_train_bwd: copy failed"); return TDEED_ERR_RUNTIME; }
+  }
+  if (dw) {
+    hipError_t e2 = hipMemcpyAsync(dw, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e2 != hipSuccess) { tdeed_set_error("bn_train_bwd: copy failed"); return TDEED_ERR_RUNTIME; }
+  }
   return TDEED_OK;
 }
 

@@ -74,8 +74,13 @@ def s1_front(frames_u8, fw, crop=None, flip=False, y2=None, shortcut=None, poole
     return y2, shortcut, pooled
 
 
+def gemm_colpart_rows(M):
+    """rows of the per-tile column-statistics buffer of gemm(colpart=...): one per 128-row tile"""
+    return (M + 127) // 128
+
+
 def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
-         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None):
+         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None, colpart=None):
     """C = act((A' @ W^T) * scale + shift + residual).  A (M,K) / W (N,K) same dtype.
     gather = (stride, hi, wi, ho, wo) for the stride-2 1x1 shortcut."""
     _chk(A, "A"); _chk(W, "W", A.dtype)
@@ -94,7 +99,7 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     call("tdeed_gemm_fwd", ptr(A), lda, ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0,
          ptr(a_scale), a_scale_rows, M, K, N, ptr(W), W.shape[1], ptr(scale), ptr(shift),
          ptr(residual), (residual.shape[-1] if residual is not None else 0), act, ptr(out), ldc,
-         g[0], g[1], g[2], g[3], g[4], dtype_code(A.dtype), stream_ptr())
+         g[0], g[1], g[2], g[3], g[4], ptr(colpart), dtype_code(A.dtype), stream_ptr())
     return out
 
 
@@ -197,7 +202,7 @@ def gconv3x3_parts(Hi, Wi, C, stride, act_dtype):
     return _lib.load().tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype_code(act_dtype))
 
 
-def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None, relu=True):
+def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None, relu=True, pooled_sq=None):
     """x (N,Hi,Wi,C) -> y (N,Ho,Wo,C), pooled (N,parts,C) fp32 partial sums over pixels.
     w_packed: fp32 [G][9][gw][gw] (VALU path); wfrag: bf16 MFMA fragments (bf16 path)."""
     _chk(x, "x")
@@ -209,7 +214,7 @@ def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled
     if pooled is None:
         pooled = torch.empty((N, parts, C), dtype=torch.float32, device=x.device)
     call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(wfrag), ptr(scale), ptr(shift),
-         ptr(out), ptr(pooled), int(relu), dtype_code(x.dtype), stream_ptr())
+         ptr(out), ptr(pooled), ptr(pooled_sq), int(relu), dtype_code(x.dtype), stream_ptr())
     return out, pooled
 
 

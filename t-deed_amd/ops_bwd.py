@@ -114,22 +114,41 @@ def bn_train(z, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, res=N
     if out is None:
         out = torch.empty_like(z)
     call("tdeed_bn_apply", ptr(z), M, C, ptr(a), ptr(bb), ptr(res), int(relu), ptr(out), dtype_code(z.dtype), stream_ptr())
-    return out, (mean, rstd)
+    return out, (mean, rstd, a, bb)
 
 
-def bn_train_bwd(z, dy, y, ctx, w, relu=True, want_res=False):
-    """-> dz, d_res (or None), dw, db"""
+def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, res=None,
+                      relu=True, out=None):
+    """BatchNorm(batch statistics) of z from per-channel partial sums a producer's epilogue wrote (gemm(colpart=...),
+    gconv3x3(pooled_sq=...)) + the apply pass.  Returns (y, (mean, rstd, a, b))."""
     C = z.shape[-1]
     M = z.numel() // C
     dev = z.device
-    mean, rstd = ctx
+    mean, rstd, a, bb = (_f32((C,), dev) for _ in range(4))
+    call("tdeed_bn_finalize", ptr(part_s), ptr(part_q), pstride, P, M, C, ptr(w), ptr(b), eps, momentum, ptr(mean),
+         ptr(rstd), ptr(a), ptr(bb), ptr(run_mean), ptr(run_var), stream_ptr())
+    if out is None:
+        out = torch.empty_like(z)
+    call("tdeed_bn_apply", ptr(z), M, C, ptr(a), ptr(bb), ptr(res), int(relu), ptr(out), dtype_code(z.dtype), stream_ptr())
+    return out, (mean, rstd, a, bb)
+
+
+def bn_train_bwd(z, dy, y, ctx, w, relu=True, want_res=False):
+    """-> dz, d_res (or None), dw, db.  ctx = (mean, rstd[, a, b]): with the forward affine a, b in ctx and y None the ReLU
+    mask is recomputed from z (no residual in front of the ReLU)."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    mean, rstd = ctx[0], ctx[1]
+    fa, fb = (ctx[2], ctx[3]) if len(ctx) >= 4 else (None, None)
+    if relu and y is None and fa is None:
+        raise ValueError("bn_train_bwd: the ReLU mask needs y or the forward affine in ctx")
     part, sums = _f32((_lib.load().tdeed_bn_slabs(M), 2, C), dev), _f32((2, C), dev)
     dz = torch.empty_like(z)
     d_res = torch.empty_like(z) if want_res else None
-    dw, db = _f32((C,), dev), _f32((C,), dev)
     call("tdeed_bn_train_bwd", ptr(z), ptr(dy), ptr(y if relu else None), int(relu), M, C, ptr(mean), ptr(rstd), ptr(w),
-         ptr(part), ptr(sums), ptr(dz), ptr(d_res), ptr(dw), ptr(db), dtype_code(z.dtype), stream_ptr())
-    return dz, d_res, dw, db
+         ptr(fa), ptr(fb), ptr(part), ptr(sums), ptr(dz), ptr(d_res), None, None, dtype_code(z.dtype), stream_ptr())
+    return dz, d_res, sums[1], sums[0]              # dw = sum g * xhat, db = sum g: views of the folded sums, no copies
 
 
 def pool_rows(x, x2=None):
@@ -264,3 +283,59 @@ def mix_frames(a_u8, b_u8, lam):
     out = torch.empty(a_u8.shape, dtype=torch.float32, device=a_u8.device)
     call("tdeed_mix_frames", ptr(a_u8), ptr(b_u8), ptr(lam), Bn, a_u8.numel() // Bn, ptr(out), stream_ptr())
     return out
+
+
+class PinnedTables:
+    """Pinned host buffers for the record tables of multi_copy, one small ring per call site (`role`).  A buffer is
+    rewritten only after the copy that last read it has finished (event), so eager steps may run ahead of the GPU;
+    under stream capture nothing may be allocated or waited for: the warm-up pass has created the buffers, and a
+    replayed graph re-reads the same table from the same buffer."""
+
+    def __init__(self, max_entries=2048, depth=4):
+        self.max_entries, self.depth = max_entries, depth
+        self.rings = {}
+
+    def get(self, role):
+        ring = self.rings.setdefault(role, dict(bufs=[], evs=[], i=0))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if len(ring["bufs"]) < self.depth and not capturing:
+            ring["bufs"].append(torch.empty((self.max_entries, 4), dtype=torch.int64).pin_memory())
+            ring["evs"].append(None)
+            j = len(ring["bufs"]) - 1
+        else:
+            if not ring["bufs"]:
+                raise RuntimeError("multi_copy under stream capture needs a warm-up call outside the capture first")
+            j = 0 if capturing else ring["i"] % len(ring["bufs"])
+        ring["i"] = j + 1
+        if ring["evs"][j] is not None and not capturing:
+            ring["evs"][j].synchronize()
+        return ring, j
+
+
+def multi_copy(srcs, offsets, dst_flat, scale=1.0, accumulate=False, tables=None, role=0):
+    """dst_flat[off_i : off_i + n_i] (= or +=) scale * srcs[i] for every i, one launch.  srcs: contiguous fp32 device
+    tensors; offsets: element offsets into dst_flat.  tables: a PinnedTables (reused across steps; required for calls
+    inside a stream capture)."""
+    nt = len(srcs)
+    tables = tables if tables is not None else PinnedTables(max(nt, 16), depth=1)
+    if nt > tables.max_entries:
+        raise ValueError(f"multi_copy: {nt} tensors exceed the table size {tables.max_entries}")
+    ring, j = tables.get(role)
+    host = ring["bufs"][j]
+    rows = []
+    chunk = 0
+    for t_, off in zip(srcs, offsets):
+        if t_.dtype != torch.float32 or not t_.is_contiguous():
+            raise TypeError("multi_copy: contiguous fp32 sources expected")
+        n = t_.numel()
+        rows.append((t_.data_ptr(), off, n, chunk))
+        chunk += (n + 4095) // 4096
+    host[:nt] = torch.tensor(rows, dtype=torch.int64)
+    dev = host[:nt].to(dst_flat.device, non_blocking=True)
+    if not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["evs"][j] = ev
+    ring["live"] = (dev, list(srcs))                 # keep the device table and the sources alive until the next call
+    call("tdeed_multi_copy", ptr(dev), nt, chunk, ptr(dst_flat), float(scale), int(accumulate), stream_ptr())
+    return dev

@@ -114,7 +114,8 @@ class TrainEngine:
         dx = dx.view(ctx.x_shape)
         for blk in reversed(self.blocks):
             dx = blk.backward(dx, grads)
-        dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
+        from .trunk_train import ZMASK
+        dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, None if ZMASK else ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
         grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
         grads["_features.stem.conv.weight"] = B_.stem_wgrad(ctx.fr, dz0, crop=ctx.crop, flip=ctx.flip)
         return grads
@@ -138,7 +139,7 @@ class TrainEngine:
         self.temporal.repack()
 
     # ------------------------------------------------------------------ one optimiser step
-    def write_grads(self, grads, scale=1.0, first=True, partial=False):
+    def write_grads(self, grads, scale=1.0, first=True, partial=False, role=0):
         """Gradient write-out into the flat buffer (times `scale`; overwriting when `first`, adding otherwise:
         `acc_grad_iter` of the reference's step()): multi-tensor copies, a handful of launches instead of one per tensor."""
         if not partial:
@@ -146,14 +147,15 @@ class TrainEngine:
             if missing:
                 raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
         keys = list(grads)
-        dsts = [self.params.grad_view(k).view(grads[k].shape) for k in keys]
-        srcs = [grads[k] for k in keys]
-        if first:
-            torch._foreach_copy_(dsts, srcs)
-            if scale != 1.0:
-                torch._foreach_mul_(dsts, scale)
-        else:
-            torch._foreach_add_(dsts, srcs, alpha=scale)
+        srcs = [grads[k] if grads[k].is_contiguous() else grads[k].contiguous() for k in keys]
+        for k, g in zip(keys, srcs):
+            if g.numel() != self.params.index[k][1] or g.dtype != torch.float32:
+                raise RuntimeError(f"gradient of {k}: {tuple(g.shape)} {g.dtype} does not match the parameter")
+        # one launch for all tensors (a per-tensor device copy is ~3 us and a step has 431 of them)
+        if not hasattr(self, "_grad_tabs"):
+            self._grad_tabs = B_.PinnedTables(max_entries=len(self.params.index) + 8)
+        B_.multi_copy(srcs, [self.params.index[k][0] for k in keys], self.params.grad, scale=scale, accumulate=not first,
+                      tables=self._grad_tabs, role=role)
 
     def accumulate(self, frames_u8, label, labelD=None, soft=None, crop=None, flip=False, drop_masks=None, scale=1.0,
                    first=True, dataset=None, fg_weight=5.0, reduce=False):
@@ -175,14 +177,14 @@ class TrainEngine:
         red = self.reducer if reduce else None
         g_t = {}
         d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
-        self.write_grads(g_t, scale, first, partial=True)
+        self.write_grads(g_t, scale, first, partial=True, role=0)
         if red is not None:
             red.reduce_bucket(0)
         g_b = self.backward_trunk(ctx, d_feat)
         missing = set(self.params.index) - set(g_t) - set(g_b)
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
-        self.write_grads(g_b, scale, first, partial=True)
+        self.write_grads(g_b, scale, first, partial=True, role=1)
         if red is not None:
             red.reduce_bucket(1)
 
@@ -255,6 +257,7 @@ class TrainEngine:
             h.loss = run()
             if h.reduce_in_graph:
                 red.join()
+        h.keep = self._grad_tabs                                 # the gradient write-out tables the graph's copies read
         for k, v in keep.items():                                # capture does not execute, but stay explicit
             self.state[k].copy_(v)
         torch.cuda.synchronize()

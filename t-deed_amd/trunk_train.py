@@ -12,6 +12,9 @@ import torch
 from . import ops, ops_bwd as B_
 
 BN_EPS = 1e-5
+# ReLU masks of the BatchNorm backward recomputed from z (fa * z + fb > 0) instead of read from the stored activation
+import os as _os
+ZMASK = _os.environ.get("TDEED_TRAIN_ZMASK", "1") == "1"
 
 
 def _dense(w, dt):
@@ -93,6 +96,10 @@ class BottleneckTrain:
         self.sd, self.pre, self.blk, self.dt = sd, pre, blk, act_dtype
         self.c1 = pre + (".conv1.net" if blk.gsf_fold else ".conv1")          # GatedShift keeps the conv as .net
         self.gs = GateShiftTrain(sd, pre + ".conv1.gs", blk.gsf_fold, clip_len) if blk.gsf_fold else None
+        # BatchNorm statistics out of the producing conv's epilogue (bf16 MFMA kernels); TDEED_TRAIN_EPI_STATS=0 restores the
+        # separate column-statistics pass
+        import os
+        self.epi_stats = act_dtype == torch.bfloat16 and os.environ.get("TDEED_TRAIN_EPI_STATS", "1") == "1"
         self.repack()
 
     def repack(self):
@@ -122,10 +129,26 @@ class BottleneckTrain:
         self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, R).contiguous()
         self.se_w1t, self.se_w2t = self.se_w1.t().contiguous(), self.se_w2.t().contiguous()
 
-    def _bn(self, z, name, res=None, relu=True):
+    def _bn(self, z, name, res=None, relu=True, part=None):
+        """BatchNorm(batch statistics) + residual + ReLU of a raw conv output.  part = (sums, sums of squares, row stride,
+        rows): the per-channel partial sums the conv's own epilogue wrote (no second pass over z for the statistics)."""
         sd, p = self.sd, (self.c1 if name == "conv1" else f"{self.pre}.{name}") + ".bn"
+        if part is not None:
+            ps, pq, stride, P = part
+            return B_.bn_finalize_apply(z, ps, pq, stride, P, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1,
+                                        sd[p + ".running_mean"], sd[p + ".running_var"], res=res, relu=relu)
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
+
+    def _conv1x1(self, a, w, M, N):
+        """raw 1x1 conv; with the column statistics of its output from the epilogue -> (z, part | None)"""
+        if not self.epi_stats:
+            return ops.gemm(a, w, None, None, ops.ACT_NONE, M=M), None
+        P = ops.gemm_colpart_rows(M)
+        cp = torch.empty((P, 2, N), dtype=torch.float32, device=a.device)
+        z = ops.gemm(a, w, None, None, ops.ACT_NONE, M=M, colpart=cp)
+        flat = cp.view(-1)
+        return z, (flat, flat[N:], 2 * N, P)
 
     def forward(self, x):
         """x (N,h,w,Cin) activation dtype -> (N,h2,w2,Cout); ctx kept on self."""
@@ -139,22 +162,33 @@ class BottleneckTrain:
             c.a1.view(-1, Cin)[:, :Fp] = self.gs.forward(x)
         else:
             c.a1 = x
-        c.z1 = ops.gemm(c.a1, self.w1.w, None, None, ops.ACT_NONE).view(N, h, w, C)
-        c.y1, c.bn1 = self._bn(c.z1, "conv1")
-        c.z2, _ = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, wfrag=self.w2frag, relu=False)
-        c.y2, c.bn2 = self._bn(c.z2, "conv2")
+        z1, part = self._conv1x1(c.a1, self.w1.w, N * h * w, C)
+        c.z1 = z1.view(N, h, w, C)
+        c.y1, c.bn1 = self._bn(c.z1, "conv1", part=part)
+        if self.epi_stats and self.w2frag is not None:
+            parts = ops.gconv3x3_parts(h, w, C, blk.stride, self.dt)
+            psq = torch.empty((N, parts, C), dtype=torch.float32, device=x.device)
+            c.z2, pooled = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, wfrag=self.w2frag, relu=False,
+                                        pooled_sq=psq)
+            part2 = (pooled.view(-1), psq.view(-1), C, N * parts)
+        else:
+            c.z2, _ = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, wfrag=self.w2frag, relu=False)
+            part2 = None
+        c.y2, c.bn2 = self._bn(c.z2, "conv2", part=part2)
         h2, w2 = c.z2.shape[1], c.z2.shape[2]
         c.p = B_.pool_rows(c.y2)
         c.hid, c.gate = B_.se_train_fwd(c.p, self.se_w1t, sd[pre + ".se.fc1.bias"], self.se_w2t, sd[pre + ".se.fc2.bias"])
         c.y2s = B_.scale_rows(c.y2, c.gate)
-        c.z3 = ops.gemm(c.y2s, self.w3.w, None, None, ops.ACT_NONE).view(N, h2, w2, C)
+        z3, part3 = self._conv1x1(c.y2s, self.w3.w, N * h2 * w2, C)
+        c.z3 = z3.view(N, h2, w2, C)
         if blk.has_downsample:
             c.xs = B_.stride2_gather(x) if blk.stride == 2 else x
-            c.zd = ops.gemm(c.xs, self.wd.w, None, None, ops.ACT_NONE).view(N, h2, w2, C)
-            c.sc, c.bnd = self._bn(c.zd, "downsample", relu=False)
+            zd, partd = self._conv1x1(c.xs, self.wd.w, N * h2 * w2, C)
+            c.zd = zd.view(N, h2, w2, C)
+            c.sc, c.bnd = self._bn(c.zd, "downsample", relu=False, part=partd)
         else:
             c.sc = x
-        c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.sc, relu=True)
+        c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.sc, relu=True, part=part3)
         self.ctx = c
         return c.out
 
@@ -184,7 +218,7 @@ class BottleneckTrain:
         grads[pre + ".se.fc2.weight"] = dW2.reshape(sd[pre + ".se.fc2.weight"].shape)
         grads[pre + ".se.fc2.bias"] = db2
         # conv2
-        dz2, _, dw, db = B_.bn_train_bwd(c.z2, d_y2, c.y2, c.bn2, sd[pre + ".conv2.bn.weight"], relu=True)
+        dz2, _, dw, db = B_.bn_train_bwd(c.z2, d_y2, None if ZMASK else c.y2, c.bn2, sd[pre + ".conv2.bn.weight"], relu=True)
         bn_names("conv2", dw, db)
         if self.w2frag_t is not None:
             d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)
@@ -195,7 +229,7 @@ class BottleneckTrain:
         grads[pre + ".conv2.conv.weight"] = (dw2p.reshape(G, 3, 3, gw, gw).permute(0, 4, 3, 1, 2)
                                              .reshape(sd[pre + ".conv2.conv.weight"].shape).contiguous())
         # conv1
-        dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, c.y1, c.bn1, sd[self.c1 + ".bn.weight"], relu=True)
+        dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, None if ZMASK else c.y1, c.bn1, sd[self.c1 + ".bn.weight"], relu=True)
         bn_names("conv1", dw, db)
         Nf, h, w, Cin = c.x.shape
         dx = ops.gemm(dz1, self.w1.wt, None, None, ops.ACT_NONE).view(Nf, h, w, Cin)
