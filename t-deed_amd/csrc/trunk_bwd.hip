@@ -686,9 +686,11 @@ __global__ __launch_bounds__(256) void gconv_wgrad_mfma_kernel(const bf16_t* __r
   }
 }
 
+// pixel slabs of the grouped-conv weight gradient: a workgroup is a chain of dependent 32-pixel steps (stage, barrier,
+// MFMA), so slabs are short (>= 1024 pixels = 32 steps) and many -- the chip hides one chain's latency behind the others
 extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
-  long s = (npix_out + 4095) / 4096;
-  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+  long s = (npix_out + 1023) / 1024;
+  return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
 }
 
 // dx [N][Hi][Wi][C] (activation dtype), dw fp32 [G][9][gw][gw] (the forward's packed layout);

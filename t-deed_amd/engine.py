@@ -646,78 +646,21 @@ class ForwardEngine:
         # the temporal stage (SGP encoder-decoder + heads) of a split batch runs ONCE over all clips behind the join of the
         # sub-batch trunks: its launches are latency bound and their cost does not depend on the row count at these sizes
         self.merge_tail = os.environ.get("TDEED_SGP_MERGE", "1") == "1"
+        # where the sub-batch pipelines join inside the trunk (index into the block list; None = behind the last block)
+        ja = os.environ.get("TDEED_JOIN_AT", "")
+        self.join_at = int(ja) if ja not in ("", "none") else None
         self._plans = {}
 
     # ------------------------------------------------------------------ plan construction
-    def _build_tail(self, B, feat, head_out):
-        """SGP encoder-decoder + heads over a (B,T,C) feature tensor (the launches behind the sub-batch join)."""
-        pw, Wt = self.pw, self.pw.W
-        T, C, dt = pw.clip_len, pw.spec.feat_dim, self.act_dtype
-        pool, steps, keep = _Pool(self.device), [], {}
-        sb = SgpBuilder(pool, steps, keep, set(), B, dt)
-        cur = sb.pyramid(feat, T, pw.n_layers, Wt.sgp, Wt.mixer)
-        N = B * T
-        steps.append(Step("heads", "heads", lambda cur=cur: ops.heads(cur, Wt.head_w, Wt.head_b, out=head_out),
-                          N * C * _esz(dt) + N * pw.n_out * 4, 2 * N * C * pw.n_out))
-        return SimpleNamespace(steps=steps, pool_bytes=pool.total_bytes(), sgp_out=cur)
-
-    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None):
+    def _blocks(self, pool, steps, keep, taps, B, x, h, w, blocks, x_kept, out_last=None):
+        """Appends the launches of a run of bottlenecks for B clips (N = B*T frames) to `steps`; x (N,h,w,Cin) is the input
+        map (owned by `pool` unless x_kept).  out_last: where the last block writes its output (a slice of a buffer shared
+        with the plan that continues the trunk) instead of a pool buffer.  Returns (x, h, w, x_kept)."""
         pw, Wt = self.pw, self.pw.W
         T = pw.clip_len
         N = B * T
         dt = self.act_dtype
-        dev = self.device
-        pool = _Pool(dev)
-        steps = []
-        keep = {}
-        crop = None
-        ch, cw = H, W
-        if self.crop_dim is not None and self.crop_dim > 0 and (self.crop_dim != H or self.crop_dim != W):
-            ch = cw = self.crop_dim
-            crop = (int(round((H - ch) / 2.0)), int(round((W - cw) / 2.0)), ch, cw)
-        frames = torch.empty((N, 3, H, W), dtype=torch.uint8, device=dev)
-        Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
         es = _esz(dt)
-        blocks = list(Wt.blocks)
-        fused_front = (Wt.front is not None and "_features.stem" not in taps and self.fuse_front
-                       and ops.s1_front_parts(ch, cw, Wt.blocks[0].spec.cout) > 0)
-        if fused_front:
-            bw = blocks.pop(0)
-            blk = bw.spec
-            h2, w2 = (Ho + 1) // 2, (Wo + 1) // 2
-            parts = ops.s1_front_parts(ch, cw, blk.cout)
-            y2 = pool.take((N, h2, w2, blk.cout), dt)
-            sc = pool.take((N, h2, w2, blk.cout), dt)
-            pooled = pool.take((N, parts, blk.cout), torch.float32)
-            gate = pool.take((N, blk.cout), torch.float32)
-            out = pool.take((N, h2, w2, blk.cout), dt)
-            M2 = N * h2 * w2
-            steps.append(Step("s1_front", "s1_front", lambda y2=y2, sc=sc, pooled=pooled: ops.s1_front(
-                frames, Wt.front, crop, flip, y2=y2, shortcut=sc, pooled=pooled),
-                              N * 3 * ch * cw + 2 * M2 * blk.cout * es,
-                              2 * N * Ho * Wo * 32 * (27 + 2 * blk.cout) // 1 + 2 * M2 * blk.cout * blk.gw * 9))
-            steps.append(Step(blk.name + ".se", "se_gate", lambda bw=bw, pooled=pooled, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
-                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
-            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda bw=bw, y2=y2, sc=sc, gate=gate, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
-                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
-                *gemm_cost(M2, blk.cout, blk.cout, es, True)))
-            for t_ in (y2, sc, pooled, gate):
-                pool.give(t_)
-            x, h, w = out, h2, w2
-            x_kept = ("_features." + blk.name) in taps
-            if x_kept:
-                keep["_features." + blk.name] = out
-        else:
-            x = pool.take((N, Ho, Wo, 32), dt)
-        if not fused_front:
-            steps.append(Step("stem", "stem", lambda x=x: ops.stem(frames, Wt.stem_w, Wt.stem_scale, Wt.stem_shift, dt, crop,
-                                                                   flip, out=x),
-                              N * 3 * ch * cw + N * Ho * Wo * 32 * es, 2 * N * Ho * Wo * 32 * 27))
-        if not fused_front:
-            h, w = Ho, Wo
-            x_kept = "_features.stem" in taps
-            if x_kept:
-                keep["_features.stem"] = x
         for bw in blocks:
             blk = bw.spec
             M = N * h * w
@@ -737,7 +680,7 @@ class ForwardEngine:
                         bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                     G = gb["out"]
                     gs_bufs = list(gb.values())
-                out = pool.take((N, h, w, blk.cout), dt)
+                out = (out_last if (out_last is not None and bw is blocks[-1]) else pool.take((N, h, w, blk.cout), dt))
                 Cb = blk.cout
                 steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, Fp=Fp, out=out: ops.bneck(
                     x, bw, G, Fp, out=out),
@@ -745,7 +688,7 @@ class ForwardEngine:
                     2 * M * Cb * (2 * Cb + blk.gw * 9) + 4 * N * Cb * blk.se_rd))
                 for t_ in gs_bufs:
                     pool.give(t_)
-                if not x_kept:
+                if not x_kept and hasattr(x, "_td_raw"):
                     pool.give(x)
                 tapname = "_features." + blk.name
                 x_kept = tapname in taps
@@ -806,20 +749,105 @@ class ForwardEngine:
                     *gemm_cost(M2, blk.cin, blk.cout, es)))
             else:
                 sc = x
-            out = pool.take((N, h2, w2, blk.cout), dt)
+            out = (out_last if (out_last is not None and bw is blocks[-1]) else pool.take((N, h2, w2, blk.cout), dt))
             steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
                 y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
                 *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` dies here
             for t_ in [y1, y2] + ([pooled, gate] if pooled is not None else []) + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
-            if not x_kept:
+            if not x_kept and hasattr(x, "_td_raw"):
                 pool.give(x)
             tapname = "_features." + blk.name
             x_kept = tapname in taps
             if x_kept:
                 keep[tapname] = out
             x, h, w = out, h2, w2
+        return x, h, w, x_kept
+
+    def _build_tail(self, B, feat, head_out, trunk_in=None, start=None):
+        """The launches behind the sub-batch join, over all B clips: optionally the rest of the trunk (blocks[start:] on the
+        map `trunk_in` = (x, h, w) that the sub-batch plans wrote) + avg-pool, then SGP encoder-decoder + heads."""
+        pw, Wt = self.pw, self.pw.W
+        T, C, dt = pw.clip_len, pw.spec.feat_dim, self.act_dtype
+        pool, steps, keep = _Pool(self.device), [], {}
+        N = B * T
+        if trunk_in is not None:
+            x, h, w = trunk_in
+            x, h, w, _ = self._blocks(pool, steps, keep, set(), B, x, h, w, list(Wt.blocks[start:]), True)
+            steps.append(Step("avgpool", "avgpool_posenc", lambda x=x: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat),
+                              (N * h * w + N) * C * _esz(dt)))
+        sb = SgpBuilder(pool, steps, keep, set(), B, dt)
+        cur = sb.pyramid(feat, T, pw.n_layers, Wt.sgp, Wt.mixer)
+        steps.append(Step("heads", "heads", lambda cur=cur: ops.heads(cur, Wt.head_w, Wt.head_b, out=head_out),
+                          N * C * _esz(dt) + N * pw.n_out * 4, 2 * N * C * pw.n_out))
+        return SimpleNamespace(steps=steps, pool_bytes=pool.total_bytes(), sgp_out=cur)
+
+    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None, stop_at=None, trunk_out=None):
+        pw, Wt = self.pw, self.pw.W
+        T = pw.clip_len
+        N = B * T
+        dt = self.act_dtype
+        dev = self.device
+        pool = _Pool(dev)
+        steps = []
+        keep = {}
+        crop = None
+        ch, cw = H, W
+        if self.crop_dim is not None and self.crop_dim > 0 and (self.crop_dim != H or self.crop_dim != W):
+            ch = cw = self.crop_dim
+            crop = (int(round((H - ch) / 2.0)), int(round((W - cw) / 2.0)), ch, cw)
+        frames = torch.empty((N, 3, H, W), dtype=torch.uint8, device=dev)
+        Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
+        es = _esz(dt)
+        blocks = list(Wt.blocks)
+        fused_front = (Wt.front is not None and "_features.stem" not in taps and self.fuse_front
+                       and ops.s1_front_parts(ch, cw, Wt.blocks[0].spec.cout) > 0)
+        if fused_front:
+            bw = blocks.pop(0)
+            blk = bw.spec
+            h2, w2 = (Ho + 1) // 2, (Wo + 1) // 2
+            parts = ops.s1_front_parts(ch, cw, blk.cout)
+            y2 = pool.take((N, h2, w2, blk.cout), dt)
+            sc = pool.take((N, h2, w2, blk.cout), dt)
+            pooled = pool.take((N, parts, blk.cout), torch.float32)
+            gate = pool.take((N, blk.cout), torch.float32)
+            out = pool.take((N, h2, w2, blk.cout), dt)
+            M2 = N * h2 * w2
+            steps.append(Step("s1_front", "s1_front", lambda y2=y2, sc=sc, pooled=pooled: ops.s1_front(
+                frames, Wt.front, crop, flip, y2=y2, shortcut=sc, pooled=pooled),
+                              N * 3 * ch * cw + 2 * M2 * blk.cout * es,
+                              2 * N * Ho * Wo * 32 * (27 + 2 * blk.cout) // 1 + 2 * M2 * blk.cout * blk.gw * 9))
+            steps.append(Step(blk.name + ".se", "se_gate", lambda bw=bw, pooled=pooled, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
+                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda bw=bw, y2=y2, sc=sc, gate=gate, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
+                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
+                *gemm_cost(M2, blk.cout, blk.cout, es, True)))
+            for t_ in (y2, sc, pooled, gate):
+                pool.give(t_)
+            x, h, w = out, h2, w2
+            x_kept = ("_features." + blk.name) in taps
+            if x_kept:
+                keep["_features." + blk.name] = out
+        else:
+            x = pool.take((N, Ho, Wo, 32), dt)
+        if not fused_front:
+            steps.append(Step("stem", "stem", lambda x=x: ops.stem(frames, Wt.stem_w, Wt.stem_scale, Wt.stem_shift, dt, crop,
+                                                                   flip, out=x),
+                              N * 3 * ch * cw + N * Ho * Wo * 32 * es, 2 * N * Ho * Wo * 32 * 27))
+        if not fused_front:
+            h, w = Ho, Wo
+            x_kept = "_features.stem" in taps
+            if x_kept:
+                keep["_features.stem"] = x
+        if stop_at is not None:
+            blocks = blocks[:max(0, stop_at - (1 if fused_front else 0))]
+        if trunk_out is not None and not blocks:
+            raise ValueError("TDEED_JOIN_AT must leave at least one un-fused bottleneck in the sub-batch plans")
+        x, h, w, x_kept = self._blocks(pool, steps, keep, taps, B, x, h, w, blocks, x_kept, out_last=trunk_out)
+        if stop_at is not None:          # trunk head only: the rest of the trunk runs once for all sub-batches (plan.tail)
+            return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=None, pool_bytes=pool.total_bytes(), B=B, T=T,
+                                   h=h, w=w)
         C = pw.spec.feat_dim
         feat = pool.take((B, T, C), dt) if feat_out is None else feat_out
         steps.append(Step("avgpool", "avgpool_posenc", lambda x=x, feat=feat: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat),
@@ -861,8 +889,23 @@ class ForwardEngine:
             tail = None
             if self.merge_tail:
                 feat = torch.empty((B, T, self.pw.spec.feat_dim), dtype=self.act_dtype, device=self.device)
-                subs = [self._build(Bs, H, W, bool(flip), set(), feat_out=feat[i * Bs:(i + 1) * Bs]) for i in range(ns)]
-                tail = self._build_tail(B, feat, head_out)
+                k = self.join_at
+                if k is not None and 0 < k < len(self.pw.W.blocks):
+                    # the sub-batches split only the bandwidth-bound head of the trunk (blocks [0, k)); the latency-bound
+                    # small maps behind it run once for the whole batch, like the temporal stage
+                    blk = self.pw.W.blocks[k - 1].spec
+                    ch = self.crop_dim if (self.crop_dim and self.crop_dim > 0) else H
+                    cw = self.crop_dim if (self.crop_dim and self.crop_dim > 0) else W
+                    hh, ww = (ch + 1) // 2, (cw + 1) // 2
+                    for b_ in self.pw.W.blocks[:k]:
+                        hh, ww = (hh - 1) // b_.spec.stride + 1, (ww - 1) // b_.spec.stride + 1
+                    shared = torch.empty((B * T, hh, ww, blk.cout), dtype=self.act_dtype, device=self.device)
+                    subs = [self._build(Bs, H, W, bool(flip), set(), stop_at=k,
+                                        trunk_out=shared[i * Bs * T:(i + 1) * Bs * T]) for i in range(ns)]
+                    tail = self._build_tail(B, feat, head_out, trunk_in=(shared, hh, ww), start=k)
+                else:
+                    subs = [self._build(Bs, H, W, bool(flip), set(), feat_out=feat[i * Bs:(i + 1) * Bs]) for i in range(ns)]
+                    tail = self._build_tail(B, feat, head_out)
             else:
                 subs = [self._build(Bs, H, W, bool(flip), set(), head_out=head_out[i * Bs * T:(i + 1) * Bs * T])
                         for i in range(ns)]

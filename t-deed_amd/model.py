@@ -317,9 +317,11 @@ class TDEEDModel:
         streams = [self._stream, self._stream2]
         totals = [torch.zeros((), dtype=torch.float32, device=self.device) for _ in streams]
         torch.cuda.current_stream().synchronize()     # w / totals were filled on the current stream; the two are non-blocking
-        for i, batch in enumerate(loader):
+        from . import feeder
+        for i, batch in enumerate(feeder.prefetch(loader, self.device, auto=False)):
             slot = i % 2
             with torch.cuda.stream(streams[slot]):
+                feeder.wait(batch)                     # uint8 frames: pinned staging ring + copy stream, one batch ahead
                 frame = batch["frame"].to(self.device)
                 label = batch["label"].to(self.device)
                 B, T = frame.shape[:2]
@@ -346,6 +348,7 @@ class TDEEDModel:
                     map_preds.append(scores.cpu())
                     from .modules import process_labels
                     map_labels.append(process_labels(label.cpu(), batch.get("labelD"), num_classes=K1))
+                feeder.done(batch)
         for st in streams:
             st.synchronize()
         total = totals[0] + totals[1]
@@ -372,7 +375,10 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
     cur = torch.cuda.current_stream()
     with self._ctx():
         self._stream.wait_stream(cur)        # engine construction / load() / zero_grad were queued on the caller's stream
-        for batch_idx, batch in enumerate(loader):
+        from . import feeder
+        for batch_idx, batch in enumerate(feeder.prefetch(loader, self.device, auto=False)):
+            feeder.wait(batch)
+
             def u8(x):
                 x = x.to(self.device)
                 return (x if x.dtype == torch.uint8 else x.round().clamp_(0, 255).to(torch.uint8)).contiguous()
@@ -416,6 +422,7 @@ def _train_epoch_impl(self, loader, optimizer, lr_scheduler, acc_grad_iter, fg_w
                 optimizer.zero_grad()
             total += loss[0]
             n += 1
+            feeder.done(batch)
         self._stream.synchronize()
     self._model._engines = {}                      # the inference engines hold packed copies of the old weights
     return float(total.item()) / max(n, 1)
