@@ -165,15 +165,18 @@ __global__ __launch_bounds__(256) void gsf_bwd_gate_kernel(const T* __restrict__
   for (int ci = 0; ci < F; ++ci) {
     const int g = ci >= Fh;
     const int co = gsf_out_col(ci, Fh, Fq);
-    const float w = fw[(b * F + ci) * T_len + t];
+    // gate-shift-FUSE: out = ys * w + r * (1 - w) with the fusion weight w (and its spatial-mean inputs d_ym / d_rm);
+    // plain gate-shift (_GSM, fw == nullptr): out = ys + r
+    const float w = fw ? fw[(b * F + ci) * T_len + t] : 1.f;
     const float d_o = (float)dA[pix * Fp + co];
-    const float d_r = d_o * (1.f - w) + d_rm[f * F + ci] * inv_hw;
+    const float d_r = fw ? d_o * (1.f - w) + d_rm[f * F + ci] * inv_hw : d_o;
     // y[t] was read by the output at frame t-1 (g = 0: ys[t-1] = y[t]) or t+1 (g = 1: ys[t+1] = y[t])
     const int tu = g ? t + 1 : t - 1;
     float d_ys = 0.f;
     if (tu >= 0 && tu < T_len) {
       const long fu = f + (tu - t);
-      d_ys = (float)dA[(fu * hw + p) * Fp + co] * fw[(b * F + ci) * T_len + tu] + d_ym[fu * F + ci] * inv_hw;
+      d_ys = fw ? (float)dA[(fu * hw + p) * Fp + co] * fw[(b * F + ci) * T_len + tu] + d_ym[fu * F + ci] * inv_hw
+                : (float)dA[(fu * hw + p) * Fp + co];
     }
     const float d_y = d_ys - d_r;
     const float gt = gate[pix * 2 + g];
@@ -341,15 +344,19 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
   float* part_cw = d_pre + N * hw * 2;
   float* part_w3 = part_cw + (long)B * 38;
   const int S = 256 / F > 0 ? 256 / F : 1;
-  hipLaunchKernelGGL(gsf_bwd_dw_kernel<T>, dim3((unsigned)N), dim3(256), (size_t)S * F * sizeof(float), st, x, gate, dA, T_len,
-                     hw, C, F, Fp, d_wgt);
-  TD_LAUNCH_CHECK("gsf_bwd_dw");
-  const long nft = N * F;
-  hipLaunchKernelGGL(gsf_bwd_dpw_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, d_wgt, fw, T_len, F, nft, dpw);
-  hipLaunchKernelGGL(gsf_bwd_planes_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, dpw, T_len, F, cw1, cw2,
-                     nft, d_ym, d_rm);
-  hipLaunchKernelGGL(gsf_bwd_cw_kernel, dim3(B, 2), dim3(256), 0, st, dpw, ysum, xsum, T_len, F, 1.0f / (float)hw, part_cw);
-  TD_LAUNCH_CHECK("gsf_bwd fuse");
+  if (fw) {          // the fusion-weight path exists in gate-shift-FUSE only
+    hipLaunchKernelGGL(gsf_bwd_dw_kernel<T>, dim3((unsigned)N), dim3(256), (size_t)S * F * sizeof(float), st, x, gate, dA,
+                       T_len, hw, C, F, Fp, d_wgt);
+    TD_LAUNCH_CHECK("gsf_bwd_dw");
+    const long nft = N * F;
+    hipLaunchKernelGGL(gsf_bwd_dpw_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, d_wgt, fw, T_len, F, nft,
+                       dpw);
+    hipLaunchKernelGGL(gsf_bwd_planes_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, dpw, T_len, F, cw1,
+                       cw2, nft, d_ym, d_rm);
+    hipLaunchKernelGGL(gsf_bwd_cw_kernel, dim3(B, 2), dim3(256), 0, st, dpw, ysum, xsum, T_len, F, 1.0f / (float)hw,
+                       part_cw);
+    TD_LAUNCH_CHECK("gsf_bwd fuse");
+  }
   const dim3 gpix(cdiv(hw, 256), (unsigned)N);
   hipLaunchKernelGGL(gsf_bwd_gate_kernel<T>, gpix, dim3(256), 0, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, d_xs,
                      d_pre);
@@ -377,8 +384,10 @@ extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, 
                              const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
                              void* d_xs, void* d_bn, float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype,
                              void* stream) {
-  TD_CHECK(x && gate && fw && ysum && xsum && dA && w3 && sa && sb && cw1 && cw2 && scratch && d_xs && d_bn && d_w3 &&
-               d_b3 && d_cw && d_cb, "gsf_bwd: null pointer");
+  // fw == NULL selects the plain gate-shift module (_GSM, impl/gsm.py:89-116: out = shift(gate*x) + (x - gate*x), no
+  // fusion conv): ysum / xsum / cw1 / cw2 / d_cw / d_cb are then unused and may be NULL
+  TD_CHECK(x && gate && dA && w3 && sa && sb && scratch && d_xs && d_bn && d_w3 && d_b3, "gsf_bwd: null pointer");
+  TD_CHECK(!fw || (ysum && xsum && cw1 && cw2 && d_cw && d_cb), "gsf_bwd: the fuse path needs ysum, xsum, cw1, cw2, d_cw, d_cb");
   TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && F > 0 && F % 4 == 0 && Fp >= F && Fp <= C && F <= 256, "gsf_bwd: bad sizes");
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
@@ -395,6 +404,7 @@ extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, 
   const long row = (long)F * 27 + 2;
   rc = tdeed_reduce_strided(part_w3, (int)N, row, (long)F * 27, d_w3, stream);
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_w3 + (long)F * 27, (int)N, row, 2, d_b3, stream);
+  if (!fw) return rc;
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw, B, 38, 18, d_cw, stream);                 // channel_conv1 taps
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 19, B, 38, 18, d_cw + 18, stream);       // channel_conv2 taps
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 18, B, 38, 1, d_cb, stream);

@@ -234,14 +234,17 @@ def gsf_slice(x, F, Fp):
 
 
 def gsf_bwd(x, gate, fw, ysum, xsum, dA, B, T, F, Fp, w3, sa, sb, cw1, cw2):
-    """-> d_xs (M,Fp), d_bn (M,Fp), d_w3 (F,27), d_b3 (2,), d_cw (2,18), d_cb (2,)"""
+    """-> d_xs (M,Fp), d_bn (M,Fp), d_w3 (F,27), d_b3 (2,), d_cw (2,18), d_cb (2,).  fw None: the plain gate-shift module
+    (_GSM): no fusion conv, d_cw / d_cb come back None."""
     N, h, w, C = x.shape
     dev = x.device
     scratch = _f32((_lib.load().tdeed_gsf_bwd_scratch_floats(B, T, h * w, F),), dev)
     M = N * h * w
     d_xs = torch.empty((M, Fp), dtype=x.dtype, device=dev)
     d_bn = torch.empty((M, Fp), dtype=x.dtype, device=dev)
-    d_w3, d_b3, d_cw, d_cb = _f32((F, 27), dev), _f32((2,), dev), _f32((2, 18), dev), _f32((2,), dev)
+    d_w3, d_b3 = _f32((F, 27), dev), _f32((2,), dev)
+    fuse = fw is not None
+    d_cw, d_cb = (_f32((2, 18), dev), _f32((2,), dev)) if fuse else (None, None)
     call("tdeed_gsf_bwd", ptr(x), ptr(gate), ptr(fw), ptr(ysum), ptr(xsum), ptr(dA), B, T, h, w, C, F, Fp, ptr(w3), ptr(sa),
          ptr(sb), ptr(cw1), ptr(cw2), ptr(scratch), ptr(d_xs), ptr(d_bn), ptr(d_w3), ptr(d_b3), ptr(d_cw), ptr(d_cb),
          dtype_code(x.dtype), stream_ptr())

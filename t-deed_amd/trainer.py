@@ -10,7 +10,8 @@ train_tdeed.py:79-87.
 Every numeric step is a HIP kernel behind the C ABI and is parity-tested against torch autograd on the CPU oracle
 (tests/test_gpu_bwd.py).  `build_graph/step_graph` capture weight re-packing + forward + loss + backward + gradient
 write-out into one HIP graph (AdamW stays outside: lr and the step count change every step).  The step is correct but only
-lightly tuned: DESIGN.md section 8 has the per-kernel breakdown."""
+lightly tuned: DESIGN.md section 8 has the per-kernel breakdown.  Both gate-shift variants train: `_gsf` (every shipped
+config) and the optional `_gsm` (impl/gsm.py; the same backward kernels without the fusion-conv path)."""
 import torch
 
 from . import ops, ops_bwd as B_
@@ -26,9 +27,6 @@ class TrainEngine:
 
     def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", lr=1e-3, weight_decay=0.01):
         self.cfg, self.dt, self.device = dict(cfg), act_dtype, device
-        if str(cfg["feature_arch"]).endswith("_gsm"):
-            raise NotImplementedError("training the optional `_gsm` backbones (model/impl/gsm.py; unused by the reference's "
-                                      "configs) is not built: gsf_bwd.hip differentiates the gate-shift-FUSE module only")
         for k in list(state):                                    # in place: the caller's dict ends up holding the views
             v = state[k]
             state[k] = (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)).to(device)

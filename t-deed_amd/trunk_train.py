@@ -28,6 +28,7 @@ class GateShiftTrain:
 
     def __init__(self, sd, pre, F, T):
         self.sd, self.pre, self.F, self.T = sd, pre, F, T
+        self.fuse = (pre + ".channel_conv1.weight") in sd          # _GSF; the plain _GSM has no fusion conv
         self.Fp = (F + 7) // 8 * 8
         self.repack()
 
@@ -37,8 +38,11 @@ class GateShiftTrain:
         self.w3 = w3                                   # [F][27]: backward
         self.wq = w3.t().contiguous()                  # [27][F]: forward (VALU tap kernel)
         self.b3 = sd[pre + ".conv3D.bias"]
-        self.cw1, self.cb1 = sd[pre + ".channel_conv1.weight"].reshape(18), sd[pre + ".channel_conv1.bias"]
-        self.cw2, self.cb2 = sd[pre + ".channel_conv2.weight"].reshape(18), sd[pre + ".channel_conv2.bias"]
+        if self.fuse:
+            self.cw1, self.cb1 = sd[pre + ".channel_conv1.weight"].reshape(18), sd[pre + ".channel_conv1.bias"]
+            self.cw2, self.cb2 = sd[pre + ".channel_conv2.weight"].reshape(18), sd[pre + ".channel_conv2.bias"]
+        else:
+            self.cw1 = self.cb1 = self.cw2 = self.cb2 = None
 
     def _pad(self, v, fill=0.0):
         out = torch.full((self.Fp,), fill, dtype=torch.float32, device=v.device)
@@ -62,7 +66,8 @@ class GateShiftTrain:
         bufs["gate"] = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
         bufs["ysum"] = torch.empty((N, F), dtype=torch.float32, device=dev)
         bufs["xsum"] = torch.empty((N, F), dtype=torch.float32, device=dev)
-        bufs["fw"] = torch.empty((c.B, F, T), dtype=torch.float32, device=dev)
+        if self.fuse:
+            bufs["fw"] = torch.empty((c.B, F, T), dtype=torch.float32, device=dev)
         G = ops.gate_shift(x, c.B, T, F, Fp, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.wq, self.b3, self.cw1,
                            self.cb1, self.cw2, self.cb2, bufs=bufs, separate_weight=True)
         c.bufs = bufs
@@ -74,17 +79,18 @@ class GateShiftTrain:
         gradient w.r.t. x[..., :Fp] (to be added into the block-input gradient)."""
         sd, pre, F, Fp, T, c = self.sd, self.pre, self.F, self.Fp, self.T, self.ctx
         b = c.bufs
-        d_xs, d_bn, d_w3, d_b3, d_cw, d_cb = B_.gsf_bwd(c.x, b["gate"], b["fw"], b["ysum"], b["xsum"], dA, c.B, T, F, Fp,
+        d_xs, d_bn, d_w3, d_b3, d_cw, d_cb = B_.gsf_bwd(c.x, b["gate"], b.get("fw"), b["ysum"], b["xsum"], dA, c.B, T, F, Fp,
                                                        self.w3, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.cw1,
                                                        self.cw2)
         dz, _, dw, db = B_.bn_train_bwd(c.xs, d_bn, None, (c.mean, c.rstd), c.w_pad, relu=False)
         grads[pre + ".conv3D.weight"] = d_w3.reshape(sd[pre + ".conv3D.weight"].shape)
         grads[pre + ".conv3D.bias"] = d_b3
         grads[pre + ".bn.weight"], grads[pre + ".bn.bias"] = dw[:F].contiguous(), db[:F].contiguous()
-        grads[pre + ".channel_conv1.weight"] = d_cw[0].reshape(sd[pre + ".channel_conv1.weight"].shape)
-        grads[pre + ".channel_conv2.weight"] = d_cw[1].reshape(sd[pre + ".channel_conv2.weight"].shape)
-        grads[pre + ".channel_conv1.bias"] = d_cb[0:1].contiguous()
-        grads[pre + ".channel_conv2.bias"] = d_cb[1:2].contiguous()
+        if self.fuse:
+            grads[pre + ".channel_conv1.weight"] = d_cw[0].reshape(sd[pre + ".channel_conv1.weight"].shape)
+            grads[pre + ".channel_conv2.weight"] = d_cw[1].reshape(sd[pre + ".channel_conv2.weight"].shape)
+            grads[pre + ".channel_conv1.bias"] = d_cb[0:1].contiguous()
+            grads[pre + ".channel_conv2.bias"] = d_cb[1:2].contiguous()
         return d_xs, dz
 
 

@@ -385,7 +385,7 @@ def test_bottleneck_train_fwd_bwd_matches_autograd(dtype, geom):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("geom", [dict(C=152, F=40, B=2, T=6, h=5, w=7), dict(C=56, F=16, B=1, T=5, h=9, w=8),
-                                  dict(C=368, F=92, B=2, T=4, h=7, w=7)])
+                                  dict(C=368, F=92, B=2, T=4, h=7, w=7), dict(C=152, F=40, B=2, T=6, h=5, w=7, mode="gsm")])
 def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
     """GatedShift + _GSF in training mode (BatchNorm3d batch statistics): module output, parameter gradients and d x
     against autograd on the CPU oracle's gate_shift(training=True)."""
@@ -394,11 +394,12 @@ def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
     C, F, B, T, h, w = g["C"], g["F"], g["B"], g["T"], g["h"], g["w"]
     Fp = (F + 7) // 8 * 8
     N = B * T
-    sd = {k: t(v) for k, v in module_state("gate_shift", "gs", 61, F=F, mode="gsf").items()}
+    mode = g.get("mode", "gsf")                  # "gsm": the plain gate-shift module (impl/gsm.py), no fusion conv
+    sd = {k: t(v) for k, v in module_state("gate_shift", "gs", 61, F=F, mode=mode).items()}
     x = rnd(281, "x", (N, C, h, w)).to(dtype)
     sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd.items()}
     xr = x.float().requires_grad_(True)
-    ref = O.gate_shift(xr[:, :F], sdr, "gs", T, "gsf", training=True)          # (N, F, h, w)
+    ref = O.gate_shift(xr[:, :F], sdr, "gs", T, mode, training=True)           # (N, F, h, w)
     dy = rnd(282, "dy", (N, F, h, w)).to(dtype)
     ref.backward(dy.float())
     sdd = {k: v.clone().to(DEV) for k, v in sd.items()}

@@ -86,7 +86,7 @@ def test_batch_of_8_equals_single_clip_forwards(dtype):
     assert err < (1e-3 if dtype == torch.float32 else 0.08 * max(1.0, float(np.abs(g["logits"]).max())))
 
 
-def _oracle_train_loss(O, frames, sd, cfg, spec, lab, labD, crop=None, flip_clips=None):
+def _oracle_train_loss(O, frames, sd, cfg, spec, lab, labD, crop=None, flip_clips=None, shift_mode="gsf"):
     x = frames.float() / 255.0
     if crop is not None:
         tp, lf, ch, cw = crop
@@ -97,7 +97,7 @@ def _oracle_train_loss(O, frames, sd, cfg, spec, lab, labD, crop=None, flip_clip
     std = torch.tensor(O.IMAGENET_STD).view(1, 1, 3, 1, 1)
     x = (x - mean) / std
     B, T = x.shape[:2]
-    f = O.regnet_features(x.reshape(B * T, *x.shape[2:]), sd, spec, T, "gsf", training=True)
+    f = O.regnet_features(x.reshape(B * T, *x.shape[2:]), sd, spec, T, shift_mode, training=True)
     f = f.reshape(B, T, -1) + sd["temp_enc"][None]
     enc = O.ed_sgp_mixer(f, sd, cfg["n_layers"], cfg["clip_len"])
     cls, displ = O.heads(enc, sd, cfg["radi_displacement"])
@@ -473,3 +473,41 @@ def test_fused_sgp_launches_match_the_launch_per_op_chain(C, T, B, n, monkeypatc
             assert "sgp_mlp" in outs["1"][2]
         tol = 1e-5 if dtype == torch.float32 else 4e-2
         assert max_abs(a, b) < tol * max(1.0, float(b.abs().max())), (dtype, max_abs(a, b), float(b.abs().max()))
+
+
+def test_gsm_backbone_trains_and_matches_autograd():
+    """The optional `_gsm` backbones (model/impl/gsm.py:69-116, `feature_arch` ending in _gsm): one fp32 train step (loss
+    and every gradient) against autograd on the oracle, then a few optimisation steps through the model API."""
+    from oracle import tdeed_oracle as O
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny002_gsm", clip_len=6, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, 6, 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 51).items()}
+    for k in sd0:                                   # _GSM zero-initialises conv3D (gsm.py:75-76): use a trained-like state
+        if k.endswith("gs.conv3D.weight"):
+            sd0[k] = sd0[k] + 0.05 * torch.randn(sd0[k].shape, generator=torch.Generator().manual_seed(1))
+    frames = t(synth.uint8_clip(1501, (B, T, 3, H, W)))
+    lab_np, labD_np = synth.labels(1502, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long(), t(labD_np).float()
+    par = [k for k in sd0 if state_layout.is_parameter(k)]
+    assert not any("channel_conv" in k for k in par)
+    sdr = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
+    ref, _, _ = _oracle_train_loss(O, frames, sdr, cfg, regnet_spec(cfg["feature_arch"]), lab, labD, shift_mode="gsm")
+    ref.backward()
+    eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.float32, lr=1e-3)
+    loss, grads = eng.loss_and_grads(frames.to(DEV), lab.to(DEV), labD.to(DEV))
+    torch.cuda.synchronize()
+    assert set(grads) == set(par)
+    assert abs(float(loss[0]) - float(ref.detach())) < 2e-4 * max(1.0, abs(float(ref.detach())))
+    ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in par])
+    gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in par])
+    assert float((ga - gr).norm() / gr.norm()) < 2e-3
+    k3 = [k for k in par if k.endswith("gs.conv3D.weight")]
+    assert k3 and all(float(sdr[k].grad.abs().max()) > 0 for k in k3)
+    for k in k3:
+        assert max_abs(grads[k], sdr[k].grad) < 5e-3 * float(sdr[k].grad.abs().max()) + 1e-6, k
+    l0 = float(eng.step(frames.to(DEV), lab.to(DEV), labD.to(DEV))[0])
+    for _ in range(6):
+        l1 = float(eng.step(frames.to(DEV), lab.to(DEV), labD.to(DEV))[0])
+    assert np.isfinite(l1) and l1 < l0
