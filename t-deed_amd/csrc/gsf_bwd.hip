@@ -8,6 +8,7 @@
 //                      source channel ci = g*Fh + i*Fq + j; columns [F,Fp) are pass-through copies of x
 // First versions: plain gather kernels (a lane per pixel or per (channel, tap)), ordered partial sums for parameters.
 #include "common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ int gsf_out_col(int ci, int Fh, int Fq) {
   const int g = ci >= Fh, cl = ci - g * Fh;
@@ -239,6 +240,178 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx_kernel(const T* __restr
   for (int c = F; c < Fp; ++c) d_bn[pix * Fp + c] = (T)0.f;
 }
 
+// 8 consecutive elements <-> fp32 registers (16 bytes of bf16, 2 x 16 bytes of fp32)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) { Chunk<bf16_t>::load(p, v); }
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) { Chunk<bf16_t>::store(p, v); }
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+// ---- coalesced forms of the two pixel-wise kernels above (bf16 / fp32).  A workgroup owns PT consecutive pixels of one
+// frame; lane = (pixel, 8-channel chunk in SOURCE-channel order).  The rows of dA (this frame and its two temporal
+// neighbours) are contiguous in memory and go to LDS with 16-byte loads; the output-column interleave co(ci) is then an LDS
+// index instead of a 2-byte global gather, x is read and d_xs / d_bn are written as 16-byte chunks, the per-pixel sums
+// over channels (d gate) are folded through LDS in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_bwd_gate2_kernel(const T* __restrict__ x, const float* __restrict__ gate,
+                                                            const float* __restrict__ fw, const T* __restrict__ dA,
+                                                            const float* __restrict__ d_ym, const float* __restrict__ d_rm,
+                                                            int T_len, int hw, int C, int F, int Fp, int PT,
+                                                            T* __restrict__ d_xs, float* __restrict__ d_pre) {
+  constexpr int EPC = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  const int NCH = Fp / EPC;
+  T* tA = reinterpret_cast<T*>(smraw);                         // [3][PT][Fp]: frame f, f-1, f+1
+  float* par = reinterpret_cast<float*>(tA + 3 * PT * Fp);     // [4][F]: w(t), d_rm/hw, w(tu), d_ym(tu)/hw
+  float* dgp = par + 4 * F;                                    // [PT][NCH][2]
+  const long f = blockIdx.y;
+  const int p0 = blockIdx.x * PT;
+  const int np = min(PT, hw - p0);
+  const int t = (int)(f % T_len);
+  const long b = f / T_len;
+  const int Fh = F >> 1, Fq = F >> 2;
+  const float inv_hw = 1.0f / (float)hw;
+  const int tid = threadIdx.x;
+  // ---- stage dA rows (contiguous: np * Fp elements per frame)
+  {
+    const int n16 = np * Fp / EPC;                             // 16-byte (bf16) / 32-byte (fp32) chunks of 8 elements
+    for (int fi = 0; fi < 3; ++fi) {
+      const int tt = t + (fi == 0 ? 0 : (fi == 1 ? -1 : 1));
+      const bool ok = tt >= 0 && tt < T_len;
+      const T* src = dA + ((f + (tt - t)) * hw + p0) * (long)Fp;
+      T* dst = tA + fi * PT * Fp;
+      for (int i = tid; i < n16; i += 256) {
+        T v[EPC];
+        if (ok) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] = src[(long)i * EPC + e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] = (T)0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dst[i * EPC + e] = v[e];
+      }
+    }
+    for (int ci = tid; ci < F; ci += 256) {
+      const int g = ci >= Fh;
+      const int tu = g ? t + 1 : t - 1;
+      const bool ok = tu >= 0 && tu < T_len;
+      par[ci] = fw ? fw[(b * F + ci) * T_len + t] : 1.f;
+      par[F + ci] = fw ? d_rm[f * F + ci] * inv_hw : 0.f;
+      par[2 * F + ci] = ok ? (fw ? fw[(b * F + ci) * T_len + tu] : 1.f) : 0.f;
+      par[3 * F + ci] = (ok && fw) ? d_ym[(f + (tu - t)) * F + ci] * inv_hw : 0.f;
+    }
+  }
+  __syncthreads();
+  const int pl = tid / NCH, k = tid - pl * NCH;
+  float dg0 = 0.f, dg1 = 0.f;
+  const bool act = pl < np;
+  if (act) {
+    const long pix = f * hw + p0 + pl;
+    const float g0 = gate[pix * 2], g1 = gate[pix * 2 + 1];
+    float xv[EPC], o[EPC];
+    ld8<T>(x + pix * C + k * EPC, xv);                         // Fp <= C: the chunk lies inside the row
+    const T* rA = tA + pl * Fp;
+    const T* rP = tA + (PT + pl) * Fp;
+    const T* rN = tA + (2 * PT + pl) * Fp;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int ci = k * EPC + e;
+      if (ci < F) {
+        const int g = ci >= Fh, cl = ci - g * Fh;
+        const int i2 = cl >= Fq, j = cl - i2 * Fq;
+        const int co = g * Fh + 2 * j + i2;
+        const float d_o = (float)rA[co];
+        const float d_r = fw ? d_o * (1.f - par[ci]) + par[F + ci] : d_o;
+        // y[t] was read by the output at frame t-1 (g = 0) or t+1 (g = 1)
+        const float dau = (float)(g ? rN[co] : rP[co]);
+        const float d_ys = dau * par[2 * F + ci] + par[3 * F + ci];
+        const float d_y = d_ys - d_r;
+        const float gt = g ? g1 : g0;
+        o[e] = d_r + d_y * gt;
+        if (g) dg1 = fmaf(d_y, xv[e], dg1); else dg0 = fmaf(d_y, xv[e], dg0);
+      } else {
+        o[e] = (float)rA[ci];                                  // pass-through pad columns
+      }
+    }
+    st8<T>(d_xs + pix * Fp + k * EPC, o);
+    dgp[(pl * NCH + k) * 2] = dg0;
+    dgp[(pl * NCH + k) * 2 + 1] = dg1;
+  }
+  __syncthreads();
+  for (int i = tid; i < np * 2; i += 256) {
+    const int pp = i >> 1, g = i & 1;
+    float a = 0.f;
+    for (int kk = 0; kk < NCH; ++kk) a += dgp[(pp * NCH + kk) * 2 + g];
+    const long pix = f * hw + p0 + pp;
+    const float gt = gate[pix * 2 + g];
+    d_pre[pix * 2 + g] = a * (1.f - gt * gt);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __restrict__ x, const float* __restrict__ d_pre,
+                                                                 const float* __restrict__ w3,
+                                                                 const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                 int T_len, int h, int w, int C, int F, int Fp, int PT,
+                                                                 T* __restrict__ d_bn) {
+  constexpr int EPC = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  float* sw = reinterpret_cast<float*>(smraw);                 // [F][27]
+  float* dp = sw + F * 27;                                     // [PT][2][27] (+1 pad per row)
+  float* aff = dp + PT * 55;                                   // [2][F]
+  const int NCH = Fp / EPC;
+  const long f = blockIdx.y;
+  const int hw = h * w;
+  const int p0 = blockIdx.x * PT;
+  const int np = min(PT, hw - p0);
+  const int t = (int)(f % T_len);
+  const int Fh = F >> 1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < F * 27; i += 256) sw[i] = w3[i];
+  for (int i = tid; i < F; i += 256) { aff[i] = sa[i]; aff[F + i] = sb[i]; }
+  for (int i = tid; i < np * 27; i += 256) {
+    const int pp = i / 27, kq = i - pp * 27;
+    const int dt = kq / 9, dy = (kq / 3) % 3, dx = kq % 3;
+    const int p = p0 + pp;
+    const int py = p / w, px = p - py * w;
+    const int t2 = t - dt + 1, y2 = py - dy + 1, x2 = px - dx + 1;      // output position that read this input with tap kq
+    const bool ok = t2 >= 0 && t2 < T_len && y2 >= 0 && y2 < h && x2 >= 0 && x2 < w;
+    const long q = ok ? ((f + (t2 - t)) * hw + y2 * w + x2) * 2 : 0;
+    dp[pp * 55 + kq] = ok ? d_pre[q] : 0.f;
+    dp[pp * 55 + 27 + kq] = ok ? d_pre[q + 1] : 0.f;
+  }
+  __syncthreads();
+  const int pl = tid / NCH, k = tid - pl * NCH;
+  if (pl >= np) return;
+  const long pix = f * hw + p0 + pl;
+  float xv[EPC], o[EPC];
+  ld8<T>(x + pix * C + k * EPC, xv);
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int c = k * EPC + e;
+    float a = 0.f;
+    if (c < F) {
+      const float* d = dp + pl * 55 + (c >= Fh ? 27 : 0);
+      const float* wc = sw + c * 27;
+#pragma unroll
+      for (int kq = 0; kq < 27; ++kq) a = fmaf(wc[kq], d[kq], a);
+      if (!(fmaf(xv[e], aff[c], aff[F + c]) > 0.f)) a = 0.f;
+    }
+    o[e] = a;
+  }
+  st8<T>(d_bn + pix * Fp + k * EPC, o);
+}
+
 // ---- conv3d weight gradient: workgroup = frame f'; a[f'] (relu(bn(x))) tile in LDS, d_pre of frames f'-1..f'+1 with a
 // zero ring; lane (c, tap) walks the pixels.  part[f'][F*27 + 2] (the last two: d bias = sum_p d_pre[f'][p][g])
 template <typename T>
@@ -358,12 +531,28 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
     TD_LAUNCH_CHECK("gsf_bwd fuse");
   }
   const dim3 gpix(cdiv(hw, 256), (unsigned)N);
-  hipLaunchKernelGGL(gsf_bwd_gate_kernel<T>, gpix, dim3(256), 0, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, d_xs,
-                     d_pre);
-  TD_LAUNCH_CHECK("gsf_bwd_gate");
-  hipLaunchKernelGGL(gsf_bwd_conv3d_dx_kernel<T>, gpix, dim3(256), (size_t)F * 27 * sizeof(float), st, x, d_pre, w3, sa, sb,
-                     T_len, h, w, C, F, Fp, d_bn);
-  TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx");
+  static const bool old_pix = getenv("TDEED_GSF_BWD_PIXEL") && atoi(getenv("TDEED_GSF_BWD_PIXEL")) == 1;
+  if (!old_pix && Fp % 8 == 0 && Fp <= C && Fp / 8 <= 64) {
+    // coalesced forms: PT pixels x (Fp / 8) channel chunks per workgroup
+    const int NCH = Fp / 8;
+    const int PT = 256 / NCH;
+    const dim3 g2(cdiv(hw, PT), (unsigned)N);
+    const size_t sm_g = (size_t)3 * PT * Fp * sizeof(T) + (size_t)(4 * F + PT * NCH * 2) * sizeof(float);
+    hipLaunchKernelGGL(gsf_bwd_gate2_kernel<T>, g2, dim3(256), sm_g, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, PT,
+                       d_xs, d_pre);
+    TD_LAUNCH_CHECK("gsf_bwd_gate2");
+    const size_t sm_d = (size_t)(F * 27 + PT * 55 + 2 * F) * sizeof(float);
+    hipLaunchKernelGGL(gsf_bwd_conv3d_dx2_kernel<T>, g2, dim3(256), sm_d, st, x, d_pre, w3, sa, sb, T_len, h, w, C, F, Fp,
+                       PT, d_bn);
+    TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx2");
+  } else {
+    hipLaunchKernelGGL(gsf_bwd_gate_kernel<T>, gpix, dim3(256), 0, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, d_xs,
+                       d_pre);
+    TD_LAUNCH_CHECK("gsf_bwd_gate");
+    hipLaunchKernelGGL(gsf_bwd_conv3d_dx_kernel<T>, gpix, dim3(256), (size_t)F * 27 * sizeof(float), st, x, d_pre, w3, sa,
+                       sb, T_len, h, w, C, F, Fp, d_bn);
+    TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx");
+  }
   const size_t smw = ((size_t)hw * F + (size_t)3 * (h + 2) * (w + 2) * 2) * sizeof(float);
   TD_CHECK(smw <= 150 * 1024, "gsf_bwd: frame %dx%d x %d channels does not fit LDS", h, w, F);
   hipError_t e = hipFuncSetAttribute((const void*)gsf_bwd_conv3d_dw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
