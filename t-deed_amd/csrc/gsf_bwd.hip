@@ -426,9 +426,34 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dw_kernel(const T* __restr
   __shared__ float scratch[8];
   const long f = blockIdx.x;
   const int t = (int)(f % T_len);
-  for (int i = threadIdx.x; i < hw * F; i += 256) {
-    const int p = i / F, c = i - p * F;
-    at[i] = fmaxf(fmaf((float)x[(f * hw + p) * C + c], sa[c], sb[c]), 0.f);
+  if (F % 8 == 0) {                                             // 8 channels per load (16 bytes of bf16)
+    const int nck = F / 8;
+    const IDiv dck(nck);
+    for (int i0 = threadIdx.x; i0 < hw * nck; i0 += 256 * 4) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * 256, hw * nck - 1);
+        int p, ck;
+        dck.divmod(i, p, ck);
+        ld8<T>(x + (f * hw + p) * C + ck * 8, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < hw * nck) {
+          int p, ck;
+          dck.divmod(i, p, ck);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) at[p * F + ck * 8 + e] = fmaxf(fmaf(v[u][e], sa[ck * 8 + e], sb[ck * 8 + e]), 0.f);
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw * F; i += 256) {
+      const int p = i / F, c = i - p * F;
+      at[i] = fmaxf(fmaf((float)x[(f * hw + p) * C + c], sa[c], sb[c]), 0.f);
+    }
   }
   for (int i = threadIdx.x; i < 3 * HP * WP * 2; i += 256) {
     const int g = i & 1;
@@ -449,10 +474,13 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dw_kernel(const T* __restr
     const int g = c >= Fh;
     const int slab = 2 - dt;                                    // frame t'-dt+1 sits in slab (t_out - t') + 1 = 2 - dt
     float a = 0.f;
-    for (int p = 0; p < hw; ++p) {
-      const int py = p / w, px = p - py * w;
-      const int y2 = py - dy + 1, x2 = px - dx + 1;             // ring coordinates: +1
-      a = fmaf(at[p * F + c], dpt[(((slab * HP) + y2 + 1) * WP + x2 + 1) * 2 + g], a);
+    // rows and columns walked by two nested loops (no per-pixel division); ring coordinates: +1
+    const float* dbase = dpt + (((slab * HP) + (2 - dy)) * WP + (2 - dx)) * 2 + g;
+    for (int py = 0; py < h; ++py) {
+      const float* arow = at + (py * w) * F + c;
+      const float* drow = dbase + py * WP * 2;
+#pragma unroll 4
+      for (int px = 0; px < w; ++px) a = fmaf(arow[px * F], drow[px * 2], a);
     }
     part[f * (F * 27 + 2) + o] = a;
   }

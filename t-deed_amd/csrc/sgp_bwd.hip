@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restric
 extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
   const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
   long z = (2048 + tiles - 1) / tiles;
-  const long zmax = (M + 255) / 256;
+  const long zmax = M >= 8192 ? (M + 255) / 256 : (M + 63) / 64;       // few rows (SE / head layers): 64-row slices
   if (z > zmax) z = zmax;
   const long zbytes = (32L << 20) / ((long)N * K * 4);
   if (z > zbytes) z = zbytes;

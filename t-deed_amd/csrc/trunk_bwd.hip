@@ -365,81 +365,145 @@ extern "C" int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int
 }
 
 // hid = relu(W1 p + b1), gate = sigmoid(W2 hid + b2) per frame, hid kept for the backward.
-// w1t [C][R], w2t [R][C] (transposed: adjacent lanes read adjacent addresses)
-__global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restrict__ p, int C, int R,
+// w1t [C][R], w2t [R][C] (transposed: adjacent lanes read adjacent addresses).  SEF frames share every weight load; a
+// contraction whose output is narrower than the workgroup (R <= 128 hidden units) is split over 256 / RP slices of its
+// input range (partial sums folded through LDS in a fixed order); loops are unrolled so that 8 loads are in flight.
+constexpr int SEF = 4;
+__device__ __forceinline__ int se_rp(int R) { return R <= 32 ? 32 : (R <= 64 ? 64 : (R <= 128 ? 128 : 256)); }
+
+// out[f][j] (j < J) = sum_{i < I} in[f][i] * wt[i * J + j], all 256 threads: (j, slice of I); part: [nsl][SEF][J] floats
+__device__ __forceinline__ void se_contract(const float* in /*LDS [SEF][I]*/, int I, const float* __restrict__ wt, int J,
+                                            float* part, float* out /*LDS [SEF][J]*/) {
+  const int JP = se_rp(J);
+  const int nsl = 256 / JP;
+  for (int j0 = 0; j0 < J; j0 += JP) {                          // one pass when J <= 256
+    const int j = j0 + threadIdx.x % JP, sl = threadIdx.x / JP;
+    float a[SEF];
+#pragma unroll
+    for (int f = 0; f < SEF; ++f) a[f] = 0.f;
+    if (j < J) {
+      const int per = (I + nsl - 1) / nsl;
+      const int i_lo = sl * per, i_hi = min(I, i_lo + per);
+#pragma unroll 8
+      for (int i = i_lo; i < i_hi; ++i) {
+        const float wv = wt[(long)i * J + j];
+#pragma unroll
+        for (int f = 0; f < SEF; ++f) a[f] = fmaf(in[f * I + i], wv, a[f]);
+      }
+#pragma unroll
+      for (int f = 0; f < SEF; ++f) part[(sl * SEF + f) * J + j] = a[f];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < SEF * JP; idx += 256) {
+      const int f = idx / JP, jj = j0 + idx % JP;
+      if (jj < J) {
+        float v = 0.f;
+        for (int q = 0; q < nsl; ++q) v += part[(q * SEF + f) * J + jj];
+        out[f * J + jj] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restrict__ p, int N, int C, int R,
                                                            const float* __restrict__ w1t, const float* __restrict__ b1,
                                                            const float* __restrict__ w2t, const float* __restrict__ b2,
                                                            float* __restrict__ hid, float* __restrict__ gate) {
-  extern __shared__ float sm[];        // p [C], hid [R]
+  extern __shared__ float sm[];        // p [SEF][C], hid [SEF][R], out [SEF][C], part [slices][SEF][J]
   float* sp = sm;
-  float* sh = sm + C;
-  const long f = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) sp[c] = p[f * C + c];
-  __syncthreads();
-  for (int j = threadIdx.x; j < R; j += 256) {
-    float a = b1[j];
-    for (int c = 0; c < C; ++c) a = fmaf(sp[c], w1t[(long)c * R + j], a);
-    a = fmaxf(a, 0.f);
-    sh[j] = a;
-    hid[f * R + j] = a;
+  float* sh = sp + SEF * C;
+  float* so = sh + SEF * R;
+  float* part = so + SEF * C;
+  const long f0 = (long)blockIdx.x * SEF;
+  for (int i = threadIdx.x; i < SEF * C; i += 256) {
+    const int f = i / C;
+    sp[i] = f0 + f < N ? p[(f0 + f) * C + (i - f * C)] : 0.f;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = b2[c];
-    for (int j = 0; j < R; ++j) a = fmaf(sh[j], w2t[(long)j * C + c], a);
-    gate[f * C + c] = sigmoidf_(a);
+  se_contract(sp, C, w1t, R, part, sh);
+  for (int i = threadIdx.x; i < SEF * R; i += 256) {
+    const int f = i / R, j = i - f * R;
+    const float a = fmaxf(sh[i] + b1[j], 0.f);
+    sh[i] = a;
+    if (f0 + f < N) hid[(f0 + f) * R + j] = a;
   }
+  __syncthreads();
+  se_contract(sh, R, w2t, C, part, so);
+  for (int i = threadIdx.x; i < SEF * C; i += 256) {
+    const int f = i / C, c = i - f * C;
+    if (f0 + f < N) gate[(f0 + f) * C + c] = sigmoidf_(so[i] + b2[c]);
+  }
+}
+
+static size_t se_train_smem(int C, int R) {
+  const int mx = C > R ? C : R;
+  const int part = SEF * mx > 1024 ? SEF * mx : 1024;           // (256 / RP) slices x SEF x J <= max(1024, SEF * J)
+  return (size_t)(SEF * (2 * C + R) + part) * sizeof(float);
 }
 
 extern "C" int tdeed_se_train_fwd(const float* p, int N, int C, int R, const float* w1t, const float* b1,
                                   const float* w2t, const float* b2, float* hid, float* gate, void* stream) {
-  TD_CHECK(p && w1t && b1 && w2t && b2 && hid && gate && N > 0 && C > 0 && R > 0 && C + R <= 12000, "se_train_fwd: bad arguments");
-  hipLaunchKernelGGL(se_train_fwd_kernel, dim3(N), dim3(256), (size_t)(C + R) * sizeof(float), (hipStream_t)stream, p, C,
-                     R, w1t, b1, w2t, b2, hid, gate);
+  TD_CHECK(p && w1t && b1 && w2t && b2 && hid && gate && N > 0 && C > 0 && R > 0, "se_train_fwd: bad arguments");
+  const size_t smem = se_train_smem(C, R);
+  TD_CHECK(smem <= 64 * 1024, "se_train_fwd: C=%d R=%d beyond the LDS budget", C, R);
+  hipLaunchKernelGGL(se_train_fwd_kernel, dim3(cdiv(N, SEF)), dim3(256), smem, (hipStream_t)stream, p, N, C, R, w1t, b1, w2t,
+                     b2, hid, gate);
   TD_LAUNCH_CHECK("se_train_fwd");
   return TDEED_OK;
 }
 
 // d_pre2 = d_gate * g * (1 - g);  d_hid = (hid > 0) * W2^T d_pre2;  d_p = W1^T d_hid
-// w1 [R][C], w2 [C][R] (the reference layouts: here the contraction runs down the rows)
+// w1 [R][C], w2 [C][R] (the reference layouts: here the contraction runs down the rows, so they are already "transposed")
 __global__ __launch_bounds__(256) void se_train_bwd_kernel(const float* __restrict__ d_gate, const float* __restrict__ gate,
-                                                           const float* __restrict__ hid, int C, int R,
+                                                           const float* __restrict__ hid, int N, int C, int R,
                                                            const float* __restrict__ w1, const float* __restrict__ w2,
                                                            float* __restrict__ d_pre2, float* __restrict__ d_hid,
                                                            float* __restrict__ d_p) {
-  extern __shared__ float sm[];        // d_pre2 [C], d_hid [R]
+  extern __shared__ float sm[];        // d_pre2 [SEF][C], d_hid [SEF][R], out [SEF][C], part
   float* s2 = sm;
-  float* sh = sm + C;
-  const long f = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float g = gate[f * C + c];
-    const float v = d_gate[f * C + c] * g * (1.f - g);
-    s2[c] = v;
-    d_pre2[f * C + c] = v;
+  float* sh = s2 + SEF * C;
+  float* so = sh + SEF * R;
+  float* part = so + SEF * C;
+  const long f0 = (long)blockIdx.x * SEF;
+  for (int i = threadIdx.x; i < SEF * C; i += 256) {
+    const int f = i / C, c = i - f * C;
+    float v = 0.f;
+    if (f0 + f < N) {
+      const float g = gate[(f0 + f) * C + c];
+      v = d_gate[(f0 + f) * C + c] * g * (1.f - g);
+      d_pre2[(f0 + f) * C + c] = v;
+    }
+    s2[i] = v;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < R; j += 256) {
+  se_contract(s2, C, w2, R, part, sh);                         // d_hid[j] = sum_c d_pre2[c] * w2[c][j]
+  for (int i = threadIdx.x; i < SEF * R; i += 256) {
+    const int f = i / R, j = i - f * R;
     float a = 0.f;
-    for (int c = 0; c < C; ++c) a = fmaf(s2[c], w2[(long)c * R + j], a);
-    a = hid[f * R + j] > 0.f ? a : 0.f;
-    sh[j] = a;
-    d_hid[f * R + j] = a;
+    if (f0 + f < N) {
+      a = hid[(f0 + f) * R + j] > 0.f ? sh[i] : 0.f;
+      d_hid[(f0 + f) * R + j] = a;
+    }
+    sh[i] = a;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f;
-    for (int j = 0; j < R; ++j) a = fmaf(sh[j], w1[(long)j * C + c], a);
-    d_p[f * C + c] = a;
+  se_contract(sh, R, w1, C, part, so);                         // d_p[c] = sum_j d_hid[j] * w1[j][c]
+  for (int i = threadIdx.x; i < SEF * C; i += 256) {
+    const int f = i / C, c = i - f * C;
+    if (f0 + f < N) d_p[(f0 + f) * C + c] = so[i];
   }
 }
 
 extern "C" int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid, int N, int C, int R,
                                   const float* w1, const float* w2, float* d_pre2, float* d_hid, float* d_p,
                                   void* stream) {
-  TD_CHECK(d_gate && gate && hid && w1 && w2 && d_pre2 && d_hid && d_p && N > 0 && C > 0 && R > 0 && C + R <= 12000,
+  TD_CHECK(d_gate && gate && hid && w1 && w2 && d_pre2 && d_hid && d_p && N > 0 && C > 0 && R > 0,
            "se_train_bwd: bad arguments");
-  hipLaunchKernelGGL(se_train_bwd_kernel, dim3(N), dim3(256), (size_t)(C + R) * sizeof(float), (hipStream_t)stream, d_gate,
-                     gate, hid, C, R, w1, w2, d_pre2, d_hid, d_p);
+  const size_t smem = se_train_smem(C, R);
+  TD_CHECK(smem <= 64 * 1024, "se_train_bwd: C=%d R=%d beyond the LDS budget", C, R);
+  hipLaunchKernelGGL(se_train_bwd_kernel, dim3(cdiv(N, SEF)), dim3(256), smem, (hipStream_t)stream, d_gate, gate, hid, N, C,
+                     R, w1, w2, d_pre2, d_hid, d_p);
   TD_LAUNCH_CHECK("se_train_bwd");
   return TDEED_OK;
 }
@@ -532,6 +596,108 @@ __global__ __launch_bounds__(256) void gconv_dgrad_kernel(const T* __restrict__ 
   T* dst = dx + pix * C + g * GW;
 #pragma unroll
   for (int c = 0; c < GW; c += Chunk<T>::N) Chunk<T>::store(dst + c, *reinterpret_cast<float(*)[Chunk<T>::N]>(&acc[c]));
+}
+
+// Stride-2 input gradient, tiled (bf16 and fp32).  A workgroup owns a 16x16 tile of input pixels of one frame; the
+// (8+2) x (8+2) output pixels whose gradient reaches it sit in LDS as whole rows (coalesced 16-byte loads; the row-per-lane
+// form above fetches 16 bytes per 100..700-byte row).  A wave serves one group at a time (4 groups in flight); its 64 lanes
+// are the 64 pixels of ONE parity class (iy & 1, ix & 1), so all lanes take the same taps -- 1, 2, 2 or 4 of the 9 --
+// with no divergence; the group's 9 x gw x gw weights are wave-uniform LDS reads.
+template <typename T, int GW>
+__global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const T* __restrict__ dy, int Hi, int Wi, int Ho, int Wo, int C,
+                                                             const float* __restrict__ w, T* __restrict__ dx) {
+  constexpr int EPC = Chunk<T>::N;
+  constexpr int TO = 10;                                        // output rows / columns staged: 16 / 2 + 2
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  const int CP = C + EPC;                                       // row pad: rows shift by one 16-byte bank slot
+  T* dyt = reinterpret_cast<T*>(smraw);                         // [TO*TO][CP]
+  float* sw = reinterpret_cast<float*>(dyt + TO * TO * CP);     // [4][9*GW*GW]
+  const int n = blockIdx.z;
+  const int iy0 = blockIdx.y * 16, ix0 = blockIdx.x * 16;
+  const int oyb = iy0 / 2 - (iy0 > 0 ? 0 : 0), oxb = ix0 / 2;   // output row of tile-local ty = 0 is iy0 / 2 (iy0 even)
+  // ty = iy + 1 - ky in [iy0 - 1, iy0 + 16]: outputs oy in [iy0/2 - 0 (ty = iy0: ky = 1) ... ] -> stage oy in [iy0/2 - 1 + 1, ...]:
+  // valid ty are even; smallest even ty >= iy0 - 1 is iy0 (oy = iy0/2), largest <= iy0 + 16 is iy0 + 16 (oy = iy0/2 + 8)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nck = C / EPC;
+  {
+    const IDiv dck(nck);
+    for (int i0 = tid; i0 < TO * TO * nck; i0 += 256 * 4) {
+      u32x4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * 256, TO * TO * nck - 1);
+        int px, ck;
+        dck.divmod(i, px, ck);
+        const int ry = px / TO, rx = px - ry * TO;
+        const int oy = oyb + ry, ox = oxb + rx;
+        ok[u] = oy < Ho && ox < Wo;
+        v[u] = *reinterpret_cast<const u32x4*>(dy + (((long)n * Ho + (ok[u] ? oy : 0)) * Wo + (ok[u] ? ox : 0)) * C + ck * EPC);
+      }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < TO * TO * nck) {
+          int px, ck;
+          dck.divmod(i, px, ck);
+          *reinterpret_cast<u32x4*>(dyt + px * CP + ck * EPC) = ok[u] ? v[u] : (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+  const int G = C / GW;
+  const int ly = lane >> 3, lx = lane & 7;                      // this lane's position inside its parity class (8 x 8)
+  for (int g0 = 0; g0 < G; g0 += 4) {
+    __syncthreads();                                            // dy tile staged / previous round's weights consumed
+    for (int i = tid; i < 4 * 9 * GW * GW; i += 256) {
+      const int gg = i / (9 * GW * GW);
+      sw[i] = g0 + gg < G ? w[(long)(g0 + gg) * 9 * GW * GW + (i - gg * 9 * GW * GW)] : 0.f;
+    }
+    __syncthreads();
+    const int g = g0 + wv;
+    if (g < G) {
+      const float* wg = sw + wv * 9 * GW * GW;
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls) {
+        const int pyc = cls >> 1, pxc = cls & 1;                // parity of (iy, ix)
+        const int iy = iy0 + 2 * ly + pyc, ix = ix0 + 2 * lx + pxc;
+        float acc[GW];
+#pragma unroll
+        for (int c = 0; c < GW; ++c) acc[c] = 0.f;
+        // ty = iy + 1 - ky even: iy even -> ky = 1; iy odd -> ky in {0, 2}
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if (pyc == 0 && a == 1) continue;
+          const int ky = pyc == 0 ? 1 : 2 * a;
+          const int ry = (2 * ly + pyc + 1 - ky) / 2;           // (iy + 1 - ky) / 2 - iy0 / 2, in [0, 8]
+#pragma unroll
+          for (int bq = 0; bq < 2; ++bq) {
+            if (pxc == 0 && bq == 1) continue;
+            const int kx = pxc == 0 ? 1 : 2 * bq;
+            const int rx = (2 * lx + pxc + 1 - kx) / 2;
+            float d[GW];
+            const T* src = dyt + (ry * TO + rx) * CP + g * GW;
+#pragma unroll
+            for (int c = 0; c < GW; c += EPC) Chunk<T>::load(src + c, *reinterpret_cast<float(*)[EPC]>(&d[c]));
+            const float* wt = wg + (ky * 3 + kx) * GW * GW;
+#pragma unroll
+            for (int ci = 0; ci < GW; ++ci) {
+              float s = acc[ci];
+#pragma unroll
+              for (int co = 0; co < GW; ++co) s = fmaf(d[co], wt[ci * GW + co], s);
+              acc[ci] = s;
+            }
+          }
+        }
+        if (iy < Hi && ix < Wi) {
+          T* dst = dx + (((long)n * Hi + iy) * Wi + ix) * C + g * GW;
+#pragma unroll
+          for (int c = 0; c < GW; c += EPC) Chunk<T>::store(dst + c, *reinterpret_cast<float(*)[EPC]>(&acc[c]));
+        }
+      }
+    }
+  }
 }
 
 // weight gradient: workgroup = (slab of output pixels, group); chunks of 32 output pixels staged in LDS as
@@ -711,9 +877,27 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   static const bool wg_valu = getenv("TDEED_GCONV_WGRAD_VALU") && atoi(getenv("TDEED_GCONV_WGRAD_VALU")) == 1;
   const bool mfma_w = dtype == TDEED_BF16 && !wg_valu && C % 8 == 0;
   const dim3 gwm(nsl, (C + 15) / 16);
+  static const bool dg_old = getenv("TDEED_GCONV_DGRAD_ROWS") && atoi(getenv("TDEED_GCONV_DGRAD_ROWS")) == 1;
+  const size_t sm_s2 = (size_t)100 * (C + (dtype == TDEED_F32 ? 4 : 8)) * (dtype == TDEED_F32 ? 4 : 2) + (size_t)4 * 9 * gw * gw * 4;
+  const bool dg_tiled = dx && stride == 2 && !dg_old && sm_s2 <= 120 * 1024 && Hi % 2 == 0 && Wi % 2 == 0 && N <= 65535;
+  if (dg_tiled && sm_s2 > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e != hipSuccess) { tdeed_set_error("gconv3x3_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+      attr_set = true;
+    }
+  }
+  const dim3 gts2(cdiv(Wi, 16), cdiv(Hi, 16), N);
 #define TD_GC_LAUNCH(TT, GWv)                                                                                           \
   do {                                                                                                                  \
-    if (dx)                                                                                                             \
+    if (dg_tiled)                                                                                                       \
+      hipLaunchKernelGGL((gconv_dgrad_s2_kernel<TT, GWv>), gts2, dim3(256), sm_s2, st, (const TT*)dy, Hi, Wi, Ho, Wo, C,  \
+                         w, (TT*)dx);                                                                                   \
+    else if (dx)                                                                                                        \
       hipLaunchKernelGGL((gconv_dgrad_kernel<TT, GWv>), gd, dim3(256), 0, st, (const TT*)dy, Hi, Wi, Ho, Wo, C, stride,  \
                          w, (TT*)dx, npix_in);                                                                          \
     if (!mfma_w)                                                                                                        \

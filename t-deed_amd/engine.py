@@ -224,11 +224,22 @@ def pack_front_weights(stem_w, stem_sc, stem_sh, w1, sc1, sh1, wd, scd, shd, w2,
                            w2f=pack_gconv_frags(w2, gw, device), sc2=f32(sc2), sh2=f32(sh2))
 
 
-def pack_gsf_q_frags(w3d, device):
-    """conv3D.weight [2][F/2][3][3][3] -> bf16 MFMA A fragments [KS][64][8] for gsf_q_mfma_kernel:
-    row n = jg = 2*j_t + g (rows 6..15 zero); k-slot s = 4ks+q = tap*nch + chunk, element e = channel 8*chunk+e,
-    non-zero only for channels of gate group g."""
-    w3d = _np(w3d).astype(np.float32)
+_GSFQ_IDX = {}
+
+
+def gsf_q_frags_on_device(w3d):
+    """conv3D.weight (2,F/2,3,3,3) fp32 on the device -> the bf16 MFMA fragments of pack_gsf_q_frags, by one gather
+    through a cached index map (a training step re-packs the updated weight without a host round trip)."""
+    Fh = w3d.shape[1]
+    key = (Fh, str(w3d.device))
+    if key not in _GSFQ_IDX:
+        ids = (np.arange(2 * Fh * 27, dtype=np.float32) + 1).reshape(2, Fh, 3, 3, 3)       # exact in fp32
+        _GSFQ_IDX[key] = torch.from_numpy(_gsf_q_frags_np(ids).astype(np.int64)).to(w3d.device)
+    ext = torch.cat([torch.zeros(1, dtype=w3d.dtype, device=w3d.device), w3d.reshape(-1)])
+    return ext[_GSFQ_IDX[key]].to(torch.bfloat16).contiguous()
+
+
+def _gsf_q_frags_np(w3d):
     Fh = w3d.shape[1]
     F = 2 * Fh
     nch = (F + 7) // 8
@@ -247,7 +258,14 @@ def pack_gsf_q_frags(w3d, device):
                     c = ck * 8 + e
                     if c < F and c // Fh == g:
                         fr[ks, q * 16 + n, e] = w3d[g, c - g * Fh, jt, dy, dx]
-    return torch.from_numpy(fr).to(device).to(torch.bfloat16).contiguous()
+    return fr
+
+
+def pack_gsf_q_frags(w3d, device):
+    """conv3D.weight [2][F/2][3][3][3] -> bf16 MFMA A fragments [KS][64][8] for gsf_q_mfma_kernel:
+    row n = jg = 2*j_t + g (rows 6..15 zero); k-slot s = 4ks+q = tap*nch + chunk, element e = channel 8*chunk+e,
+    non-zero only for channels of gate group g."""
+    return torch.from_numpy(_gsf_q_frags_np(_np(w3d).astype(np.float32))).to(device).to(torch.bfloat16).contiguous()
 
 
 def pack_gconv_frags(w, gw, device):

@@ -26,8 +26,8 @@ def _dense(w, dt):
 class GateShiftTrain:
     """`GatedShift` + `_GSF` on the first F channels of a block input, training mode."""
 
-    def __init__(self, sd, pre, F, T):
-        self.sd, self.pre, self.F, self.T = sd, pre, F, T
+    def __init__(self, sd, pre, F, T, act_dtype=torch.float32):
+        self.sd, self.pre, self.F, self.T, self.dt = sd, pre, F, T, act_dtype
         self.fuse = (pre + ".channel_conv1.weight") in sd          # _GSF; the plain _GSM has no fusion conv
         self.Fp = (F + 7) // 8 * 8
         self.repack()
@@ -37,6 +37,10 @@ class GateShiftTrain:
         w3 = sd[pre + ".conv3D.weight"].reshape(F, 27).contiguous()
         self.w3 = w3                                   # [F][27]: backward
         self.wq = w3.t().contiguous()                  # [27][F]: forward (VALU tap kernel)
+        self.wqf = None                                # bf16: the tap convolution runs on the MFMA kernel of the inference path
+        if self.dt == torch.bfloat16:
+            from .engine import gsf_q_frags_on_device
+            self.wqf = gsf_q_frags_on_device(sd[pre + ".conv3D.weight"])
         self.b3 = sd[pre + ".conv3D.bias"]
         if self.fuse:
             self.cw1, self.cb1 = sd[pre + ".channel_conv1.weight"].reshape(18), sd[pre + ".channel_conv1.bias"]
@@ -69,7 +73,7 @@ class GateShiftTrain:
         if self.fuse:
             bufs["fw"] = torch.empty((c.B, F, T), dtype=torch.float32, device=dev)
         G = ops.gate_shift(x, c.B, T, F, Fp, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.wq, self.b3, self.cw1,
-                           self.cb1, self.cw2, self.cb2, bufs=bufs, separate_weight=True)
+                           self.cb1, self.cw2, self.cb2, bufs=bufs, wqf=self.wqf, separate_weight=True)
         c.bufs = bufs
         self.ctx = c
         return G
@@ -101,7 +105,7 @@ class BottleneckTrain:
     def __init__(self, sd, pre, blk, act_dtype=torch.float32, clip_len=None):
         self.sd, self.pre, self.blk, self.dt = sd, pre, blk, act_dtype
         self.c1 = pre + (".conv1.net" if blk.gsf_fold else ".conv1")          # GatedShift keeps the conv as .net
-        self.gs = GateShiftTrain(sd, pre + ".conv1.gs", blk.gsf_fold, clip_len) if blk.gsf_fold else None
+        self.gs = GateShiftTrain(sd, pre + ".conv1.gs", blk.gsf_fold, clip_len, act_dtype) if blk.gsf_fold else None
         # BatchNorm statistics out of the producing conv's epilogue (bf16 MFMA kernels); TDEED_TRAIN_EPI_STATS=0 restores the
         # separate column-statistics pass
         import os

@@ -403,7 +403,7 @@ def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
     dy = rnd(282, "dy", (N, F, h, w)).to(dtype)
     ref.backward(dy.float())
     sdd = {k: v.clone().to(DEV) for k, v in sd.items()}
-    gs = GateShiftTrain(sdd, "gs", F, T)
+    gs = GateShiftTrain(sdd, "gs", F, T, dtype)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     G = gs.forward(xd)
     assert rel_err(G[:, :F].float().view(N, h, w, F).permute(0, 3, 1, 2), ref) < (2e-4 if dtype == torch.float32 else 4e-2)
