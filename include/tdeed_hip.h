@@ -347,6 +347,9 @@ int tdeed_bn_train_stats(const void* z, long M, int C, const float* w, const flo
 int tdeed_bn_finalize(const float* part_s, const float* part_q, long pstride, int P, long M, int C, const float* w,
                       const float* bias, float eps, float momentum, float* mean, float* rstd, float* a, float* b,
                       float* run_mean, float* run_var, void* stream);
+/* out[s][j] = sum of part[p * pstride + j] over the rows p of slice s (slices of ceil(P / slices) rows), j < n; rows of out
+ * are `ostride` floats apart.  A first fold for tdeed_bn_finalize when a producer left one partial row per (frame, band). */
+int tdeed_fold_rows(const float* part, long pstride, int P, int n, int slices, float* out, long ostride, void* stream);
 /* y = act(z * a[c] + b[c] + res) */
 int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu, void* y,
                    int dtype, void* stream);

@@ -56,6 +56,7 @@ _SIGS = {
     "tdeed_bn_train_stats": ([P, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_bn_apply": ([P, c_long, c_int, P, P, P, c_int, P, c_int, P], c_int),
     "tdeed_bn_train_bwd": ([P, P, P, c_int, c_long, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_fold_rows": ([P, c_long, c_int, c_int, c_int, P, c_long, P], c_int),
     "tdeed_bn_finalize": ([P, P, c_long, c_int, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P], c_int),
     "tdeed_pool_rows": ([P, P, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_se_train_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P, P], c_int),

@@ -86,27 +86,37 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rstd, float* __restrict__ a,
                                                           float* __restrict__ b, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var) {
-  // one workgroup per channel: the P slab partials are folded in double (lane-strided, then a fixed-order tree)
-  __shared__ double r1[256], r2[256];
-  const int c = blockIdx.x;
+  // one workgroup per 8 channels: lanes = (32 partial lanes, 8 channels), 8 row loads per lane in flight; the P slab
+  // partials are folded in double (lane-strided, then a fixed-order chain)
+  __shared__ double r1[32][9], r2[32][9];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int p = threadIdx.x; p < P; p += 256) {
-    s1 += (double)part_s[(long)p * pstride + c];
-    s2 += (double)part_q[(long)p * pstride + c];
-  }
-  r1[threadIdx.x] = s1;
-  r2[threadIdx.x] = s2;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      r1[threadIdx.x] += r1[threadIdx.x + o];
-      r2[threadIdx.x] += r2[threadIdx.x + o];
+  for (int p0 = pl; p0 < P; p0 += 8 * 32) {
+    float v1[8], v2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long p = min(p0 + u * 32, P - 1);
+      v1[u] = part_s[p * pstride + c];
+      v2[u] = part_q[p * pstride + c];
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u * 32 < P) {
+        s1 += (double)v1[u];
+        s2 += (double)v2[u];
+      }
   }
-  if (threadIdx.x != 0) return;
-  s1 = r1[0];
-  s2 = r2[0];
+  r1[pl][cl] = s1;
+  r2[pl][cl] = s2;
+  __syncthreads();
+  if (pl != 0) return;
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int i = 0; i < 32; ++i) {
+    s1 += r1[i][cl];
+    s2 += r2[i][cl];
+  }
   const double mu = s1 / (double)M;
   double var = s2 / (double)M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 static int colstats_slabs(long M, long* rows_per_slab) {
-  long slabs = (M + 511) / 512;
+  long slabs = (M + 63) / 64;                                  // >= 600 workgroups already for the 7x7 maps of a batch
   if (slabs > 2048) slabs = 2048;
   if (slabs < 1) slabs = 1;
   *rows_per_slab = (M + slabs - 1) / slabs;
@@ -158,7 +168,7 @@ extern "C" int tdeed_bn_train_stats(const void* z, long M, int C, const float* w
   else if (dtype == TDEED_BF16) slabs = launch_colstats<bf16_t>(z, nullptr, nullptr, M, C, 0, 0, nullptr, nullptr, nullptr, nullptr, part, st);
   else { tdeed_set_error("bn_train_stats: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("bn colstats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, part + C, 2L * C, slabs, M, C, w, bias, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 8), dim3(256), 0, st, part, part + C, 2L * C, slabs, M, C, w, bias, eps,
                      momentum, mean, rstd, a, b, run_mean, run_var);
   TD_LAUNCH_CHECK("bn_finalize");
   return TDEED_OK;
@@ -171,48 +181,123 @@ extern "C" int tdeed_bn_finalize(const float* part_s, const float* part_q, long 
                                  const float* w, const float* bias, float eps, float momentum, float* mean, float* rstd,
                                  float* a, float* b, float* run_mean, float* run_var, void* stream) {
   TD_CHECK(part_s && part_q && w && bias && mean && rstd && a && b, "bn_finalize: null pointer");
-  TD_CHECK(P > 0 && M > 0 && C > 0 && pstride >= C, "bn_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part_s, part_q, pstride, P, M, C, w,
+  TD_CHECK(P > 0 && M > 0 && C > 0 && C % 8 == 0 && pstride >= C, "bn_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 8), dim3(256), 0, (hipStream_t)stream, part_s, part_q, pstride, P, M, C, w,
                      bias, eps, momentum, mean, rstd, a, b, run_mean, run_var);
   TD_LAUNCH_CHECK("bn_finalize");
   return TDEED_OK;
 }
 
+// out[s][j] = sum over the rows p of slice s of part[p * pstride + j], j < n: a first, wide fold for producers that leave
+// one partial row per (frame, band) -- tens of thousands of rows for a few dozen channels -- so that the finalisation
+// above (one workgroup per 8 channels) is left with `slices` rows.  Ordered, no atomics.
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ part, long pstride, int P, int n,
+                                                        int rows_per_slice, float* __restrict__ out, long ostride) {
+  __shared__ float red[32][9];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int j = blockIdx.x * 8 + cl, jj = min(j, n - 1);
+  const int p_lo = blockIdx.y * rows_per_slice, p_hi = min(P, p_lo + rows_per_slice);
+  float s = 0.f;
+  for (int p0 = p_lo + pl; p0 < p_hi; p0 += 8 * 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)min(p0 + u * 32, p_hi - 1) * pstride + jj];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += p0 + u * 32 < p_hi ? v[u] : 0.f;
+  }
+  red[pl][cl] = s;
+  __syncthreads();
+  if (pl == 0 && j < n) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a += red[i][cl];
+    out[(long)blockIdx.y * ostride + j] = a;
+  }
+}
+
+extern "C" int tdeed_fold_rows(const float* part, long pstride, int P, int n, int slices, float* out, long ostride,
+                               void* stream) {
+  TD_CHECK(part && out && P > 0 && n > 0 && slices > 0 && slices <= 65535 && pstride >= n && ostride >= n, "fold_rows: bad arguments");
+  const int rps = (P + slices - 1) / slices;
+  hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((n + 7) / 8), (unsigned)slices), dim3(256), 0, (hipStream_t)stream, part,
+                     pstride, P, n, rps, out, ostride);
+  TD_LAUNCH_CHECK("fold_rows");
+  return TDEED_OK;
+}
+
 // =========================================================================== per-channel affine (+ residual, ReLU)
 // y = act(z * a[c] + b[c] + res)
+// Thread map of the row-wise kernels below: thread = (row lane rl, 16-byte channel chunk ck), both fixed for the thread's
+// life, so the per-channel constants are loaded once and no per-element index division is needed; a workgroup walks
+// ROWS_PER_WG rows with RW_U row loads per lane in flight.
+constexpr int RW_U = 4;
+struct RowMap {
+  int ck, rl, RL;
+  bool on;
+  __device__ __forceinline__ explicit RowMap(int nch) {
+    RL = 256 / nch;
+    rl = threadIdx.x / nch;
+    ck = threadIdx.x - rl * nch;
+    on = rl < RL;
+  }
+};
+static inline int rows_per_wg(int nch) { return (256 / nch) * RW_U * 4; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, const float* __restrict__ a,
                                                      const float* __restrict__ b, const T* __restrict__ res, int relu,
-                                                     T* __restrict__ y, long nchunks, int nch) {
+                                                     T* __restrict__ y, long M, int nch, int rpw) {
   constexpr int EPC = Chunk<T>::N;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nchunks) return;
-  const int c0 = (int)(i % nch) * EPC;
-  float v[EPC], r[EPC];
-  Chunk<T>::load(z + i * EPC, v);
-  if (res) Chunk<T>::load(res + i * EPC, r);
+  const RowMap mp(nch);
+  if (!mp.on) return;
+  const int C = nch * EPC, c0 = mp.ck * EPC;
+  float av[EPC], bv[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
-    float o = fmaf(v[e], a[c0 + e], b[c0 + e]);
-    if (res) o += r[e];
-    v[e] = relu ? fmaxf(o, 0.f) : o;
+    av[e] = a[c0 + e];
+    bv[e] = b[c0 + e];
   }
-  Chunk<T>::store(y + i * EPC, v);
+  const long m0 = (long)blockIdx.x * rpw, m1 = min(M, m0 + rpw);
+  for (long r0 = m0 + mp.rl; r0 < m1; r0 += (long)mp.RL * RW_U) {
+    float v[RW_U][EPC], rv[RW_U][EPC];
+#pragma unroll
+    for (int u = 0; u < RW_U; ++u) {
+      const long r = min(r0 + (long)u * mp.RL, m1 - 1);
+      Chunk<T>::load(z + r * C + c0, v[u]);
+      if (res) Chunk<T>::load(res + r * C + c0, rv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < RW_U; ++u) {
+      const long r = r0 + (long)u * mp.RL;
+      if (r < m1) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float o = fmaf(v[u][e], av[e], bv[e]);
+          if (res) o += rv[u][e];
+          v[u][e] = relu ? fmaxf(o, 0.f) : o;
+        }
+        Chunk<T>::store(y + r * C + c0, v[u]);
+      }
+    }
+  }
 }
 
 extern "C" int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu,
                               void* y, int dtype, void* stream) {
   TD_CHECK(z && a && b && y && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32) {
-    const long n = M * (C / 4);
-    hipLaunchKernelGGL(affine_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)z, a, b,
-                       (const float*)res, relu, (float*)y, n, C / 4);
-  } else if (dtype == TDEED_BF16) {
-    const long n = M * (C / 8);
-    hipLaunchKernelGGL(affine_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)z, a, b,
-                       (const bf16_t*)res, relu, (bf16_t*)y, n, C / 8);
-  } else { tdeed_set_error("bn_apply: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "bn_apply: bad dtype %d", dtype);
+  const int nch = C / (dtype == TDEED_F32 ? 4 : 8);
+  TD_CHECK(nch <= 256, "bn_apply: C=%d too wide", C);
+  const int rpw = rows_per_wg(nch);
+  const long nwg = (M + rpw - 1) / rpw;
+  TD_CHECK(nwg < 0x7fffffffL, "bn_apply: too many rows");
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(affine_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)z, a, b, (const float*)res,
+                       relu, (float*)y, M, nch, rpw);
+  else
+    hipLaunchKernelGGL(affine_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), 0, st, (const bf16_t*)z, a, b,
+                       (const bf16_t*)res, relu, (bf16_t*)y, M, nch, rpw);
   TD_LAUNCH_CHECK("bn_apply");
   return TDEED_OK;
 }
@@ -221,6 +306,8 @@ extern "C" int tdeed_bn_apply(const void* z, long M, int C, const float* a, cons
 // g = dy (masked by y > 0 if a ReLU followed), xhat = (z - mean) * rstd:
 //   dz = w * rstd * (g - sum(g)/M - xhat * sum(g * xhat)/M),   dw = sum(g * xhat),   db = sum(g)
 // d_res (optional) = g: the gradient of the residual that was added before the ReLU.
+// with k1 = w * rstd, k2 = -k1 * rstd * sum(g xhat) / M, k3 = k1 * (mean * rstd * sum(g xhat) - sum(g)) / M (per channel,
+// computed once per thread):  dz = k1 * g + k2 * z + k3
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ dy,
                                                            const T* __restrict__ y, int relu,
@@ -228,40 +315,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ w, const float* __restrict__ sums,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            float inv_M, T* __restrict__ dz, T* __restrict__ d_res,
-                                                           long nchunks, int nch) {
+                                                           long M, int nch, int rpw) {
   constexpr int EPC = Chunk<T>::N;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nchunks) return;
-  const int C = nch * EPC;
-  const int c0 = (int)(i % nch) * EPC;
-  float zv[EPC], gv[EPC], yv[EPC];
-  Chunk<T>::load(z + i * EPC, zv);
-  Chunk<T>::load(dy + i * EPC, gv);
+  const RowMap mp(nch);
+  if (!mp.on) return;
+  const int C = nch * EPC, c0 = mp.ck * EPC;
   const bool zmask = relu && !y;
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) yv[e] = 1.f;
-  if (relu && !zmask) Chunk<T>::load(y + i * EPC, yv);
-  // every per-channel vector is loaded unconditionally (a load under a per-element run-time select is a branch and a
-  // full wait per element): without the forward affine a valid dummy array is read and ignored
+  // the forward affine of the z-mask is read unconditionally (valid dummy when unused): no load under a select
   const float* pa = zmask ? fa : mean;
   const float* pb = zmask ? fb : mean;
-  float av[EPC], bv[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    av[e] = pa[c0 + e];
-    bv[e] = pb[c0 + e];
-  }
+  float k1[EPC], k2[EPC], k3[EPC], av[EPC], bv[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     const int c = c0 + e;
-    const float act = zmask ? fmaf(zv[e], av[e], bv[e]) : yv[e];
-    const float g = (relu && !(act > 0.f)) ? 0.f : gv[e];
-    const float xh = (zv[e] - mean[c]) * rstd[c];
-    gv[e] = g;
-    zv[e] = w[c] * rstd[c] * (g - sums[c] * inv_M - xh * sums[C + c] * inv_M);
+    const float rs = rstd[c], mu = mean[c], s1 = sums[c] * inv_M, s2 = sums[C + c] * inv_M;
+    k1[e] = w[c] * rs;
+    k2[e] = -k1[e] * rs * s2;
+    k3[e] = k1[e] * (mu * rs * s2 - s1);
+    av[e] = pa[c];
+    bv[e] = pb[c];
   }
-  Chunk<T>::store(dz + i * EPC, zv);
-  if (d_res) Chunk<T>::store(d_res + i * EPC, gv);
+  const long m0 = (long)blockIdx.x * rpw, m1 = min(M, m0 + rpw);
+  for (long r0 = m0 + mp.rl; r0 < m1; r0 += (long)mp.RL * RW_U) {
+    float zv[RW_U][EPC], gv[RW_U][EPC], yv[RW_U][EPC];
+#pragma unroll
+    for (int u = 0; u < RW_U; ++u) {
+      const long r = min(r0 + (long)u * mp.RL, m1 - 1);
+      Chunk<T>::load(z + r * C + c0, zv[u]);
+      Chunk<T>::load(dy + r * C + c0, gv[u]);
+      if (relu && !zmask) Chunk<T>::load(y + r * C + c0, yv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < RW_U; ++u) {
+      const long r = r0 + (long)u * mp.RL;
+      if (r < m1) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float act = zmask ? fmaf(zv[u][e], av[e], bv[e]) : yv[u][e];
+          const float g = (relu && !(act > 0.f)) ? 0.f : gv[u][e];
+          gv[u][e] = g;
+          zv[u][e] = fmaf(k1[e], g, fmaf(k2[e], zv[u][e], k3[e]));
+        }
+        Chunk<T>::store(dz + r * C + c0, zv[u]);
+        if (d_res) Chunk<T>::store(d_res + r * C + c0, gv[u]);
+      }
+    }
+  }
 }
 
 // part: fp32 [tdeed_bn_slabs(M)][2][C]; sums: fp32 [2][C] scratch; dw, db: fp32 [C]
@@ -280,17 +379,17 @@ extern "C" int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, 
   int rc = tdeed_reduce_partials(part, slabs, 2L * C, sums, 0, stream);
   if (rc != TDEED_OK) return rc;
   const float inv_M = 1.0f / (float)M;
-  if (dtype == TDEED_F32) {
-    const long n = M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)z,
-                       (const float*)dy, (const float*)y, relu, mean, rstd, w, sums, fa, fb, inv_M, (float*)dz, (float*)d_res,
-                       n, C / 4);
-  } else {
-    const long n = M * (C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)z,
-                       (const bf16_t*)dy, (const bf16_t*)y, relu, mean, rstd, w, sums, fa, fb, inv_M, (bf16_t*)dz,
-                       (bf16_t*)d_res, n, C / 8);
-  }
+  const int nch = C / (dtype == TDEED_F32 ? 4 : 8);
+  TD_CHECK(nch <= 256, "bn_train_bwd: C=%d too wide", C);
+  const int rpw = rows_per_wg(nch);
+  const long nwg = (M + rpw - 1) / rpw;
+  TD_CHECK(nwg < 0x7fffffffL, "bn_train_bwd: too many rows");
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)z, (const float*)dy,
+                       (const float*)y, relu, mean, rstd, w, sums, fa, fb, inv_M, (float*)dz, (float*)d_res, M, nch, rpw);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dy,
+                       (const bf16_t*)y, relu, mean, rstd, w, sums, fa, fb, inv_M, (bf16_t*)dz, (bf16_t*)d_res, M, nch, rpw);
   TD_LAUNCH_CHECK("bn_bwd_apply");
   // db = sums[0:C], dw = sums[C:2C]: callers that pass NULL read them straight out of `sums`
   if (db) {
@@ -513,36 +612,54 @@ extern "C" int tdeed_se_train_bwd(const float* d_gate, const float* gate, const 
 template <typename T>
 __global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x, const float* __restrict__ s,
                                                          const float* __restrict__ add, float add_scale, int hw,
-                                                         T* __restrict__ y, long nchunks, int nch) {
+                                                         T* __restrict__ y, int nch, int rpw) {
   constexpr int EPC = Chunk<T>::N;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nchunks) return;
-  const int C = nch * EPC;
-  const int c0 = (int)(i % nch) * EPC;
-  const long n = (i / nch) / hw;
-  float v[EPC];
-  Chunk<T>::load(x + i * EPC, v);
+  const RowMap mp(nch);
+  if (!mp.on) return;
+  const int C = nch * EPC, c0 = mp.ck * EPC;
+  const long n = blockIdx.y;
+  const float* pad = add ? add : s;                             // read unconditionally (scaled by 0 when there is no add)
+  const float asc = add ? add_scale : 0.f;
+  float sv[EPC], ad[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
-    v[e] *= s[n * C + c0 + e];
-    if (add) v[e] = fmaf(add[n * C + c0 + e], add_scale, v[e]);
+    sv[e] = s[n * C + c0 + e];
+    ad[e] = pad[n * C + c0 + e] * asc;
   }
-  Chunk<T>::store(y + i * EPC, v);
+  const int m0 = blockIdx.x * rpw, m1 = min(hw, m0 + rpw);
+  const T* xf = x + n * hw * C + c0;
+  T* yf = y + n * hw * C + c0;
+  for (int r0 = m0 + mp.rl; r0 < m1; r0 += mp.RL * RW_U) {
+    float v[RW_U][EPC];
+#pragma unroll
+    for (int u = 0; u < RW_U; ++u) Chunk<T>::load(xf + (long)min(r0 + u * mp.RL, m1 - 1) * C, v[u]);
+#pragma unroll
+    for (int u = 0; u < RW_U; ++u) {
+      const int r = r0 + u * mp.RL;
+      if (r < m1) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[u][e] = fmaf(v[u][e], sv[e], ad[e]);
+        Chunk<T>::store(yf + (long)r * C, v[u]);
+      }
+    }
+  }
 }
 
 extern "C" int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C,
                                 void* y, int dtype, void* stream) {
   TD_CHECK(x && s && y && N > 0 && hw > 0 && C > 0 && C % 8 == 0, "scale_rows: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32) {
-    const long n = (long)N * hw * (C / 4);
-    hipLaunchKernelGGL(scale_rows_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)x, s,
-                       add, add_scale, hw, (float*)y, n, C / 4);
-  } else if (dtype == TDEED_BF16) {
-    const long n = (long)N * hw * (C / 8);
-    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, s,
-                       add, add_scale, hw, (bf16_t*)y, n, C / 8);
-  } else { tdeed_set_error("scale_rows: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "scale_rows: bad dtype %d", dtype);
+  const int nch = C / (dtype == TDEED_F32 ? 4 : 8);
+  TD_CHECK(nch <= 256 && N <= 65535, "scale_rows: C=%d / N=%d out of range", C, N);
+  int rpw = rows_per_wg(nch);
+  const dim3 grid((unsigned)cdiv(hw, rpw), (unsigned)N);
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(scale_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, s, add, add_scale, hw, (float*)y,
+                       nch, rpw);
+  else
+    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, s, add, add_scale, hw,
+                       (bf16_t*)y, nch, rpw);
   TD_LAUNCH_CHECK("scale_rows");
   return TDEED_OK;
 }
@@ -694,6 +811,120 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const T* __restrict
           T* dst = dx + (((long)n * Hi + iy) * Wi + ix) * C + g * GW;
 #pragma unroll
           for (int c = 0; c < GW; c += EPC) Chunk<T>::store(dst + c, *reinterpret_cast<float(*)[EPC]>(&acc[c]));
+        }
+      }
+    }
+  }
+}
+
+// Stride-2 input gradient on the MFMA pipe (bf16).  Per parity class of input pixels the gradient is a small GEMM
+//   dx[pixel][ci] = sum_{taps of the class} sum_co dy[tap pixel][co] * W[tap][ci][co]
+// over a 16-channel unit (one gw = 16 group, or two gw = 8 groups as a block-diagonal weight): K = (tap slot, co) = 32 is one
+// v_mfma_f32_16x16x32_bf16 for the classes with 1 or 2 taps and two for the (odd, odd) class with 4.  The weights are the
+// MFMA A operand (rows = ci), so a lane ends with 4 consecutive channels of one pixel.
+// wfrag: [C/16][5][64] fragments: f = 0 (even, even): tap (1,1); f = 1 (even y, odd x): (1,0) (1,2); f = 2 (odd y, even x):
+// (0,1) (2,1); f = 3, 4 (odd, odd): (0,0) (0,2) and (2,0) (2,2).
+__global__ __launch_bounds__(256) void gconv_dgrad_s2_pack_kernel(const float* __restrict__ w, int C, int gw,
+                                                                  bf16x8* __restrict__ wfrag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int U = (C + 15) / 16;
+  if (i >= U * 5 * 64) return;
+  const int lane = i & 63, f = (i >> 6) % 5, u = i / 320;
+  const int m = lane & 15, kq = lane >> 4, ts = kq >> 1, co0 = (kq & 1) * 8;
+  int ky, kx;
+  if (f == 0) { ky = 1; kx = 1; }
+  else if (f == 1) { ky = 1; kx = ts ? 2 : 0; }
+  else if (f == 2) { kx = 1; ky = ts ? 2 : 0; }
+  else { ky = f == 3 ? 0 : 2; kx = ts ? 2 : 0; }
+  const bool tap_ok = !(f == 0 && ts == 1);
+  bf16x8 out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int co = co0 + j;
+    float v = 0.f;
+    if (tap_ok) {
+      if (gw == 16) v = w[(((long)u * 9 + ky * 3 + kx) * 16 + m) * 16 + co];
+      else if ((co >> 3) == (m >> 3) && (2 * u + (m >> 3)) * 8 < C)
+        v = w[(((long)(2 * u + (m >> 3)) * 9 + ky * 3 + kx) * 8 + (m & 7)) * 8 + (co & 7)];
+    }
+    out[j] = (__bf16)v;
+  }
+  wfrag[i] = out;
+}
+
+// workgroup = (band of 16 input rows, frame, chunk of 64 channels), walking the 16-pixel-wide tiles of the band; wave =
+// one 16-channel unit of the chunk with its 5 weight fragments in registers; the 10 x 10 output pixels that reach a tile
+// are staged in LDS (zero outside the map).
+__global__ __launch_bounds__(256) void gconv_dgrad_s2_mfma_kernel(const bf16_t* __restrict__ dy, int Hi, int Wi, int Ho,
+                                                                  int Wo, int C, const bf16x8* __restrict__ wfrag,
+                                                                  bf16_t* __restrict__ dx) {
+  constexpr int TO = 10, CP = 64 + 8;                           // pixel stride 144 B: odd number of 16-byte slots
+  __shared__ __attribute__((aligned(16))) bf16_t dyt[TO * TO * CP];
+  const int n = blockIdx.y, iy0 = blockIdx.x * 16, c0 = blockIdx.z * 64;
+  const int CH = min(64, C - c0), nck = ((CH + 15) >> 4) * 2;   // 16-byte chunks staged (an odd 8-channel tail is zero-padded)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kq = lane >> 4, ts = kq >> 1, pl = lane & 15;
+  const bool active = c0 + wv * 16 < C;
+  const int u = (c0 >> 4) + wv;
+  bf16x8 af[5];
+#pragma unroll
+  for (int f = 0; f < 5; ++f) af[f] = wfrag[((long)(active ? u : 0) * 5 + f) * 64 + lane];
+  const int oyb = iy0 >> 1;
+  const IDiv dck(nck);
+  const int ntx = (Wi + 15) >> 4;
+  for (int tx = 0; tx < ntx; ++tx) {
+    const int ix0 = tx * 16, oxb = ix0 >> 1;
+    __syncthreads();
+    for (int i0 = tid; i0 < TO * TO * nck; i0 += 256 * 4) {
+      u32x4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = min(i0 + b * 256, TO * TO * nck - 1);
+        int px, ck;
+        dck.divmod(i, px, ck);
+        const int ry = px / TO, rx = px - ry * TO;
+        const int oy = oyb + ry, ox = oxb + rx;
+        ok[b] = oy < Ho && ox < Wo && ck * 8 < CH;
+        v[b] = *reinterpret_cast<const u32x4*>(dy + (((long)n * Ho + (ok[b] ? oy : 0)) * Wo + (ok[b] ? ox : 0)) * C + c0 + (ok[b] ? ck * 8 : 0));
+      }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = i0 + b * 256;
+        if (i < TO * TO * nck) {
+          int px, ck;
+          dck.divmod(i, px, ck);
+          *reinterpret_cast<u32x4*>(dyt + px * CP + ck * 8) = ok[b] ? v[b] : (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    const bf16_t* colb = dyt + wv * 16 + (kq & 1) * 8;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const int pyc = cls >> 1, pxc = cls & 1;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int p = mt * 16 + pl, ly = p >> 3, lx = p & 7;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (cls == 0) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], *reinterpret_cast<const bf16x8*>(colb + (ly * TO + lx) * CP), acc, 0, 0, 0);
+        } else if (cls == 1) {                                  // ky = 1 (ry = ly); kx = 0 -> rx = lx + 1, kx = 2 -> rx = lx
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], *reinterpret_cast<const bf16x8*>(colb + (ly * TO + lx + 1 - ts) * CP), acc, 0, 0, 0);
+        } else if (cls == 2) {                                  // kx = 1 (rx = lx); ky = 0 -> ry = ly + 1, ky = 2 -> ry = ly
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], *reinterpret_cast<const bf16x8*>(colb + ((ly + 1 - ts) * TO + lx) * CP), acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3], *reinterpret_cast<const bf16x8*>(colb + ((ly + 1) * TO + lx + 1 - ts) * CP), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4], *reinterpret_cast<const bf16x8*>(colb + (ly * TO + lx + 1 - ts) * CP), acc, 0, 0, 0);
+        }
+        const int iy = iy0 + 2 * ly + pyc, ix = ix0 + 2 * lx + pxc;
+        if (iy < Hi && ix < Wi && u * 16 + kq * 4 < C) {
+          bf16_t* dst = dx + (((long)n * Hi + iy) * Wi + ix) * C + u * 16 + kq * 4;
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+          *reinterpret_cast<bf16x4*>(dst) = o;
         }
       }
     }
@@ -855,8 +1086,8 @@ __global__ __launch_bounds__(256) void gconv_wgrad_mfma_kernel(const bf16_t* __r
 // pixel slabs of the grouped-conv weight gradient: a workgroup is a chain of dependent 32-pixel steps (stage, barrier,
 // MFMA), so slabs are short (>= 1024 pixels = 32 steps) and many -- the chip hides one chain's latency behind the others
 extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
-  long s = (npix_out + 1023) / 1024;
-  return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
+  long s = (npix_out + 1023) / 1024;                           // >= 2: the head of `part` also carries the stride-2 input
+  return (int)(s < 2 ? 2 : (s > 2048 ? 2048 : s));             // gradient's weight fragments (80 C floats)
 }
 
 // dx [N][Hi][Wi][C] (activation dtype), dw fp32 [G][9][gw][gw] (the forward's packed layout);
@@ -892,9 +1123,22 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
     }
   }
   const dim3 gts2(cdiv(Wi, 16), cdiv(Hi, 16), N);
+  // bf16: the MFMA form; its weight fragments are packed into the head of `part` (the weight-gradient launch that follows
+  // on the same stream overwrites them only after this kernel has finished)
+  static const bool dg_valu = getenv("TDEED_GCONV_DGRAD_VALU") && atoi(getenv("TDEED_GCONV_DGRAD_VALU")) == 1;
+  const long frag_bytes = (long)((C + 15) / 16) * 5 * 64 * 16;
+  const bool dg_mfma = dx && stride == 2 && dtype == TDEED_BF16 && !dg_old && !dg_valu && C % 8 == 0 && Hi % 2 == 0 && Wi % 2 == 0 &&
+                       N <= 65535 && frag_bytes <= (long)slabs * G * 9 * gw * gw * 4;
+  if (dg_mfma) {
+    hipLaunchKernelGGL(gconv_dgrad_s2_pack_kernel, dim3((unsigned)cdiv((C + 15) / 16 * 320, 256)), dim3(256), 0, st, w, C, gw,
+                       (bf16x8*)part);
+    hipLaunchKernelGGL(gconv_dgrad_s2_mfma_kernel, dim3(cdiv(Hi, 16), N, cdiv(C, 64)), dim3(256), 0, st, (const bf16_t*)dy, Hi,
+                       Wi, Ho, Wo, C, (const bf16x8*)part, (bf16_t*)dx);
+  }
 #define TD_GC_LAUNCH(TT, GWv)                                                                                           \
   do {                                                                                                                  \
-    if (dg_tiled)                                                                                                       \
+    if (dg_mfma) {                                                                                                      \
+    } else if (dg_tiled)                                                                                                \
       hipLaunchKernelGGL((gconv_dgrad_s2_kernel<TT, GWv>), gts2, dim3(256), sm_s2, st, (const TT*)dy, Hi, Wi, Ho, Wo, C,  \
                          w, (TT*)dx);                                                                                   \
     else if (dx)                                                                                                        \

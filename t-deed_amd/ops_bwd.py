@@ -125,6 +125,11 @@ def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.
     M = z.numel() // C
     dev = z.device
     mean, rstd, a, bb = (_f32((C,), dev) for _ in range(4))
+    if P > 2048:                                 # one partial row per (frame, band): fold to 64 rows first, chip-wide
+        tmp = _f32((64, 2, C), dev)
+        call("tdeed_fold_rows", ptr(part_s), pstride, P, C, 64, ptr(tmp), 2 * C, stream_ptr())
+        call("tdeed_fold_rows", ptr(part_q), pstride, P, C, 64, ptr(tmp.view(-1)[C:]), 2 * C, stream_ptr())
+        part_s, part_q, pstride, P = tmp.view(-1), tmp.view(-1)[C:], 2 * C, 64
     call("tdeed_bn_finalize", ptr(part_s), ptr(part_q), pstride, P, M, C, ptr(w), ptr(b), eps, momentum, ptr(mean),
          ptr(rstd), ptr(a), ptr(bb), ptr(run_mean), ptr(run_var), stream_ptr())
     if out is None:
