@@ -288,6 +288,10 @@ int tdeed_process_prediction(const float* head_out, int B, int T, int ld, int K1
 
 /* ---- utility ------------------------------------------------------------------------------- */
 int tdeed_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+/* out[i] = idx[i] ? src[idx[i] - 1] : 0 for i < n (n a multiple of 8), out fp32 or bf16: all kernel-layout copies of the
+ * master parameters (casts, transposes, MFMA fragment orders, zero pads) refreshed in one launch from a recorded index
+ * table; replaces the per-tensor `.to(bf16)` / `.t().contiguous()` of a framework step. */
+int tdeed_gather_cast(const float* src, const int* idx, long n, void* out, int dtype, void* stream);
 int tdeed_fill_u8_hash(uint8_t* dst, long n, uint64_t seed, void* stream); /* synthetic clips */
 
 /* ---- backward of the SGP encoder-decoder (training path; sgp_bwd.hip) ------------------------------------------

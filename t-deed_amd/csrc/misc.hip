@@ -211,6 +211,44 @@ extern "C" int tdeed_cast_f32_to_bf16(const float* src, void* dst, long n, void*
   return TDEED_OK;
 }
 
+// Kernel-layout copies of the master parameters in one launch: out[i] = idx[i] ? src[idx[i] - 1] : 0 (fp32 or bf16 out).
+// Every packed tensor of the training engine -- bf16 casts, transposes, MFMA fragment orders, zero-padded vectors -- is a
+// fixed permutation (with holes) of the flat fp32 parameter buffer, recorded once as an index table (repack.py); a
+// training step refreshes all of them with two of these launches instead of ~350 small cast / transpose / gather kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restrict__ src, const int* __restrict__ idx, long n8,
+                                                          T* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int4 a = *reinterpret_cast<const int4*>(idx + i * 8), b = *reinterpret_cast<const int4*>(idx + i * 8 + 4);
+    const int j[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[j[e] > 0 ? j[e] - 1 : 0];     // always a valid address; selected afterwards
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = j[e] > 0 ? v[e] : 0.f;
+    if constexpr (sizeof(T) == 2) {
+      Chunk<bf16_t>::store(reinterpret_cast<bf16_t*>(out) + i * 8, v);
+    } else {
+      float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+      Chunk<float>::store(reinterpret_cast<float*>(out) + i * 8, lo);
+      Chunk<float>::store(reinterpret_cast<float*>(out) + i * 8 + 4, hi);
+    }
+  }
+}
+// n: a multiple of 8 (pad the table with zeros); idx entries are 1-based positions in src, 0 = literal zero
+extern "C" int tdeed_gather_cast(const float* src, const int* idx, long n, void* out, int dtype, void* stream) {
+  TD_CHECK(src && idx && out && n > 0 && n % 8 == 0, "gather_cast: bad arguments");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gather_cast: bad dtype %d", dtype);
+  const long n8 = n / 8;
+  const int grid = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(gather_cast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, idx, n8, (float*)out);
+  else
+    hipLaunchKernelGGL(gather_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, idx, n8, (bf16_t*)out);
+  TD_LAUNCH_CHECK("gather_cast");
+  return TDEED_OK;
+}
+
 // same bytes as tdeed_amd.synth.uint8_clip: word i = splitmix64(splitmix64(i ^ base) + i), little endian
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;

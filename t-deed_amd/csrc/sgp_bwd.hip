@@ -298,6 +298,97 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restric
   }
 }
 
+// The same contraction with transposing LDS reads (gfx950 ds_read_b64_tr_b16): 64-row chunks of dY and X go to LDS as
+// they are (16-byte vector writes instead of eight 2-byte scatter writes per piece); an MFMA operand -- one column, 8
+// consecutive rows -- is two transposing reads (per 16-lane group the hardware returns lane i column i of 4 rows).
+// Half the barriers and a quarter of the LDS instructions per row of the kernel above.
+constexpr int WT_RS = 80;                                       // LDS row stride in elements: 64 columns + 32 bytes
+typedef __bf16 wt_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x8 wt_tr_read8(const bf16_t* lo, const bf16_t* hi) {
+  typedef __attribute__((address_space(3))) wt_bf16x4 lds_v4;
+  const wt_bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(lo));
+  const wt_bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(hi));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const bf16_t* __restrict__ dY, long ldy, const bf16_t* __restrict__ X,
+                                                       long ldx, int M, int N, int K, float* __restrict__ part_w,
+                                                       float* __restrict__ part_b) {
+  __shared__ __attribute__((aligned(16))) bf16_t sY[64 * WT_RS];
+  __shared__ __attribute__((aligned(16))) bf16_t sX[64 * WT_RS];
+  __shared__ float sb[32][65];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, z = blockIdx.z, Z = gridDim.z;
+  const int mper = ((M + Z - 1) / Z + 63) / 64 * 64;
+  const int m_begin = z * mper, m_end = min(M, m_begin + mper);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15;
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int r = tid >> 3, c8 = (tid & 7) * 8;
+  const bool nok = n0 + c8 < N, kok = k0 + c8 < K;
+  const bool want_b = part_b && blockIdx.y == 0;
+  f32x4 acc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long ycol = min(n0 + c8, N - 8), xcol = min(k0 + c8, K - 8);
+  // the pad columns are never read (a unit reads columns < 64), rows are rewritten every chunk: no initial fill needed
+  u32x4 vy[2], vx[2];
+  auto issue = [&](int m0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long row = min(m0 + r + 32 * h, M - 1);
+      vy[h] = *reinterpret_cast<const u32x4*>(dY + row * ldy + ycol);
+      vx[h] = *reinterpret_cast<const u32x4*>(X + row * ldx + xcol);
+    }
+  };
+  if (m_begin < m_end) issue(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool rok = m0 + r + 32 * h < m_end;
+      const u32x4 zy = (rok && nok) ? vy[h] : (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(sY + (r + 32 * h) * WT_RS + c8) = zy;
+      *reinterpret_cast<u32x4*>(sX + (r + 32 * h) * WT_RS + c8) = (rok && kok) ? vx[h] : (u32x4){0u, 0u, 0u, 0u};
+      if (want_b) {
+        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&zy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += (float)t8[e];
+      }
+    }
+    __syncthreads();
+    if (m0 + 64 < m_end) issue(m0 + 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = ks * 32 + g4 * 8 + q4;
+      const bf16x8 af = wt_tr_read8(sY + row * WT_RS + wv * 16 + p4 * 4, sY + (row + 4) * WT_RS + wv * 16 + p4 * 4);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16x8 bfr = wt_tr_read8(sX + row * WT_RS + kt * 16 + p4 * 4, sX + (row + 4) * WT_RS + kt * 16 + p4 * 4);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[kt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int k = k0 + kt * 16 + pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + wv * 16 + 4 * g4 + e;
+      if (n < N && k < K) part_w[((long)z * N + n) * K + k] = acc[kt][e];
+    }
+  }
+  if (want_b) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sb[r][c8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) {
+      float a = 0.f;
+      for (int rr = 0; rr < 32; ++rr) a += sb[rr][tid];
+      part_b[(long)z * N + n0 + tid] = a;
+    }
+  }
+}
+
 // number of M slices: enough workgroups that every CU holds several (each one is a chain of dependent 32-row steps:
 // latency hidden by its neighbours), without slices shorter than 256 rows or more than 32 MB of partials
 extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
@@ -324,7 +415,12 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, in
                        part_w, db ? part_b : nullptr);
   else if (dtype == TDEED_BF16) {
     static const bool valu = getenv("TDEED_WGRAD_VALU") && atoi(getenv("TDEED_WGRAD_VALU")) == 1;
-    if (!valu && N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0)
+    static const bool scatter = getenv("TDEED_WGRAD_SCATTER") && atoi(getenv("TDEED_WGRAD_SCATTER")) == 1;
+    const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
+    if (!valu && vec_ok && !scatter && M >= 4096)               // long contractions: transposing LDS reads, 64-row chunks
+      hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
+                         part_w, db ? part_b : nullptr);
+    else if (!valu && vec_ok)
       hipLaunchKernelGGL(wgrad_mfma_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
                          part_w, db ? part_b : nullptr);
     else

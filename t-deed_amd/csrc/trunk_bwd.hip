@@ -1083,6 +1083,122 @@ __global__ __launch_bounds__(256) void gconv_wgrad_mfma_kernel(const bf16_t* __r
   }
 }
 
+// bf16 weight gradient, transposing LDS reads (gfx950 ds_read_b64_tr_b16).  The contraction index of
+//   dW[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co]
+// is the pixel, which is the STRIDED direction of both channels-last maps, so an MFMA operand lane (one channel, 8
+// consecutive pixels) is a column of a [pixel][channel] image.  The kernel above transposes with 2-byte LDS scatter
+// writes (8 per 16-byte piece, and every input pixel is fetched once per tap); here the input patch of an 8 x 8 output
+// tile and the tile's dy rows go to LDS as they are (16-byte vector writes, each input pixel fetched ONCE), and every
+// operand is two transposing reads: per 16-lane group the hardware hands lane i column i of 4 rows whose addresses the
+// lanes supply -- 4 consecutive output pixels, wherever the tap and the stride put their input pixels in the patch.
+// workgroup = (run of tiles, chunk of 64 channels); wave = one 16-channel unit with all 9 tap accumulators.
+typedef __bf16 bf16x4_t __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x8 tr_read8(const bf16_t* lo, const bf16_t* hi) {
+  typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+  const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(lo));
+  const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(hi));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+constexpr int GWT_RS = 80;                                      // LDS row stride (elements): 64 channels + 32 bytes
+template <int S, int GW>
+__global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             int N, int Hi, int Wi, int Ho, int Wo, int C, int tiles_per_wg,
+                                                             float* __restrict__ part) {
+  constexpr int PW = 8 * S + (S == 1 ? 2 : 1);                  // patch width / height in input pixels: 10 or 17
+  constexpr int NPIX = PW * PW;
+  __shared__ __attribute__((aligned(16))) bf16_t patch[NPIX * GWT_RS];
+  __shared__ __attribute__((aligned(16))) bf16_t dyt[64 * GWT_RS];
+  const int c0 = blockIdx.y * 64, CH = min(64, C - c0), nck = CH >> 3;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool active = c0 + wv * 16 < C;
+  const int tyN = (Ho + 7) >> 3, txN = (Wo + 7) >> 3;
+  const long total = (long)N * tyN * txN;
+  const long t_lo = (long)blockIdx.x * tiles_per_wg, t_hi = min(total, t_lo + tiles_per_wg);
+  f32x4 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the pad columns of both images are read by the unit that holds an 8-channel tail: keep them finite
+  for (int i = tid; i < (NPIX + 64) * (GWT_RS / 8); i += 256) {
+    bf16_t* base = i < NPIX * (GWT_RS / 8) ? patch + (long)i * 8 : dyt + (long)(i - NPIX * (GWT_RS / 8)) * 8;
+    *reinterpret_cast<u32x4*>(base) = (u32x4){0u, 0u, 0u, 0u};
+  }
+  const IDiv dck(nck), dpw(PW), dtx(txN), dty(tyN);
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  for (long t = t_lo; t < t_hi; ++t) {
+    int rest, txi, tyi, n;
+    dtx.divmod((int)t, rest, txi);
+    dty.divmod(rest, n, tyi);
+    const int oy0 = tyi * 8, ox0 = txi * 8;
+    __syncthreads();                                            // previous tile consumed (and the zero fill done)
+    const int n_patch = NPIX * nck, n_all = n_patch + 64 * nck;
+    for (int i0 = tid; i0 < n_all; i0 += 256 * 4) {
+      u32x4 v[4];
+      bool ok[4];
+      int dst[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = min(i0 + b * 256, n_all - 1);
+        int px, ck;
+        const bf16_t* src;
+        if (i < n_patch) {
+          dck.divmod(i, px, ck);
+          int py, pxx;
+          dpw.divmod(px, py, pxx);
+          const int iy = oy0 * S - 1 + py, ix = ox0 * S - 1 + pxx;
+          ok[b] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+          src = x + (((long)n * Hi + (ok[b] ? iy : 0)) * Wi + (ok[b] ? ix : 0)) * C + c0 + ck * 8;
+          dst[b] = px * GWT_RS + ck * 8;
+        } else {
+          dck.divmod(i - n_patch, px, ck);
+          const int oy = oy0 + (px >> 3), ox = ox0 + (px & 7);
+          ok[b] = oy < Ho && ox < Wo;
+          src = dy + (((long)n * Ho + (ok[b] ? oy : 0)) * Wo + (ok[b] ? ox : 0)) * C + c0 + ck * 8;
+          dst[b] = NPIX * GWT_RS + px * GWT_RS + ck * 8;        // dyt follows patch in the shared segment? no: flagged below
+        }
+        v[b] = *reinterpret_cast<const u32x4*>(src);
+      }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (i0 + b * 256 < n_all) {
+          bf16_t* d = dst[b] < NPIX * GWT_RS ? patch + dst[b] : dyt + (dst[b] - NPIX * GWT_RS);
+          *reinterpret_cast<u32x4*>(d) = ok[b] ? v[b] : (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int colo = wv * 16 + p4 * 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ty = ks * 4 + g4;
+      const bf16x8 bfr = tr_read8(dyt + (ty * 8 + q4) * GWT_RS + colo, dyt + (ty * 8 + q4 + 4) * GWT_RS + colo);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int r0 = (ty * S + ky) * PW + q4 * S + kx;
+        const bf16x8 afr = tr_read8(patch + r0 * GWT_RS + colo, patch + (r0 + 4 * S) * GWT_RS + colo);
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  // D[ci = 4 (lane >> 4) + e][co = lane & 15] of every tap  ->  part[slab][g][tap][ci_local][co_local]
+  const int G = C / GW, u0 = c0 + wv * 16;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ci = 4 * g4 + e, co = lane & 15;
+      if (GW == 8 && (ci >> 3) != (co >> 3)) continue;          // cross-group term
+      if (u0 + ci >= C || u0 + co >= C) continue;
+      const int g = (u0 + ci) / GW;
+      part[(((long)blockIdx.x * G + g) * 9 + tap) * GW * GW + (ci % GW) * GW + (co % GW)] = acc[tap][e];
+    }
+  }
+}
+
 // pixel slabs of the grouped-conv weight gradient: a workgroup is a chain of dependent 32-pixel steps (stage, barrier,
 // MFMA), so slabs are short (>= 1024 pixels = 32 steps) and many -- the chip hides one chain's latency behind the others
 extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
@@ -1151,16 +1267,30 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   if (dtype == TDEED_F32) { if (gw == 8) TD_GC_LAUNCH(float, 8); else TD_GC_LAUNCH(float, 16); }
   else { if (gw == 8) TD_GC_LAUNCH(bf16_t, 8); else TD_GC_LAUNCH(bf16_t, 16); }
 #undef TD_GC_LAUNCH
+  int nrows = nsl;                                              // partial rows the launches below leave in `part`
   if (mfma_w) {
-    if (gw == 8)
+    static const bool wg_scatter = getenv("TDEED_GCONV_WGRAD_SCATTER") && atoi(getenv("TDEED_GCONV_WGRAD_SCATTER")) == 1;
+    const long tiles = (long)N * cdiv(Ho, 8) * cdiv(Wo, 8);
+    if (!wg_scatter && tiles < (1L << 22)) {                    // transposing LDS reads, one fetch per input pixel
+      const int tpw = (int)((tiles + slabs - 1) / slabs);
+      nrows = (int)((tiles + tpw - 1) / tpw);
+      const dim3 gt((unsigned)nrows, (unsigned)cdiv(C, 64));
+#define TD_GWT(Sv, GWv)                                                                                                 \
+  hipLaunchKernelGGL((gconv_wgrad_tr_kernel<Sv, GWv>), gt, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, N, Hi, Wi, \
+                     Ho, Wo, C, tpw, part)
+      if (stride == 1) { if (gw == 8) TD_GWT(1, 8); else TD_GWT(1, 16); }
+      else { if (gw == 8) TD_GWT(2, 8); else TD_GWT(2, 16); }
+#undef TD_GWT
+    } else if (gw == 8) {
       hipLaunchKernelGGL(gconv_wgrad_mfma_kernel<8>, gwm, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, Hi, Wi, Ho, Wo,
                          C, stride, npix_out, pps, part);
-    else
+    } else {
       hipLaunchKernelGGL(gconv_wgrad_mfma_kernel<16>, gwm, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, Hi, Wi, Ho,
                          Wo, C, stride, npix_out, pps, part);
+    }
   }
   TD_LAUNCH_CHECK("gconv3x3_bwd");
-  return tdeed_reduce_partials(part, nsl, (long)G * 9 * gw * gw, dw, 0, stream);
+  return tdeed_reduce_partials(part, nrows, (long)G * 9 * gw * gw, dw, 0, stream);
 }
 
 // =========================================================================== row gather / scatter for stride-2 1x1 convs

@@ -235,8 +235,9 @@ def gsf_q_frags_on_device(w3d):
     if key not in _GSFQ_IDX:
         ids = (np.arange(2 * Fh * 27, dtype=np.float32) + 1).reshape(2, Fh, 3, 3, 3)       # exact in fp32
         _GSFQ_IDX[key] = torch.from_numpy(_gsf_q_frags_np(ids).astype(np.int64)).to(w3d.device)
+    from . import repack as R
     ext = torch.cat([torch.zeros(1, dtype=w3d.dtype, device=w3d.device), w3d.reshape(-1)])
-    return ext[_GSFQ_IDX[key]].to(torch.bfloat16).contiguous()
+    return R.to_bf16(ext[_GSFQ_IDX[key]]).contiguous()
 
 
 def _gsf_q_frags_np(w3d):
@@ -318,8 +319,9 @@ def gconv_frag_index(C, gw, device):
 def gconv_frags_on_device(w, gw):
     """Conv2d.weight (C,gw,3,3) fp32 on the device -> bf16 MFMA fragments (same layout as pack_gconv_frags)."""
     idx = gconv_frag_index(w.shape[0], gw, w.device)
+    from . import repack as R
     ext = torch.cat([torch.zeros(1, dtype=w.dtype, device=w.device), w.reshape(-1)])
-    return ext[idx].to(torch.bfloat16).contiguous()
+    return R.to_bf16(ext[idx]).contiguous()
 
 
 def pack_sgp_block(sd, pre, C, act_dtype, device):

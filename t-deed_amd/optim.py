@@ -28,12 +28,19 @@ class FlatParams:
         self.numel = cur
         self.flat = torch.zeros(cur, dtype=torch.float32, device=device)
         self.grad = torch.zeros(cur, dtype=torch.float32, device=device)
-        self.index = {}
+        self.index, self.shapes = {}, {}
         for k, o, n in zip(keys, offs, sizes):
             view = self.flat[o:o + n].view(state[k].shape)
             view.copy_(state[k].to(device=device, dtype=torch.float32))
             state[k] = view                      # the state_dict entry now aliases the flat buffer
             self.index[k] = (o, n)
+            self.shapes[k] = tuple(view.shape)
+        # BatchNorm step counters (nn.BatchNorm.num_batches_tracked): one int64 vector, bumped by one launch per step
+        nbt = [k for k in state if k.endswith("num_batches_tracked")]
+        self.nbt = torch.zeros(max(len(nbt), 1), dtype=torch.int64, device=device)
+        for i, k in enumerate(nbt):
+            self.nbt[i] = state[k].to(device=device, dtype=torch.int64).reshape(())
+            state[k] = self.nbt[i:i + 1].view(())
 
     def grad_view(self, key):
         o, n = self.index[key]

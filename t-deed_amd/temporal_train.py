@@ -11,7 +11,7 @@ from types import SimpleNamespace
 
 import torch
 
-from . import ops, ops_bwd as B_
+from . import ops, ops_bwd as B_, repack as R
 from .regnet_spec import pyramid_lengths
 
 _BR = ["psi", "convw", "convkw", "fc", "global_fc"]
@@ -26,8 +26,8 @@ class _Dense:
 
     def __init__(self, w_master, dt):
         w = _flat(w_master)
-        self.w = w if dt == torch.float32 else ops.cast_bf16(w)
-        self.wt = B_.transpose(self.w)
+        self.w = w if dt == torch.float32 else R.cast_bf16(w)
+        self.wt = R.transpose(self.w)
         self.N, self.K = w.shape
 
 

@@ -42,6 +42,13 @@ class TrainEngine:
         self.zero32 = torch.zeros(32, device=device)
         self.sched_step = 0
         self.reducer = None                                      # dist.GradReducer of a data-parallel job (set_reducer)
+        # kernel-layout weight copies through recorded index tables (TDEED_REPACK_GATHER=0: every module re-packs itself
+        # with its own casts / transposes / gathers, ~350 small launches per step)
+        import os
+        self.pack = None
+        self.pack_gather = os.environ.get("TDEED_REPACK_GATHER", "1") == "1"
+        if self.pack_gather:
+            self.repack()
 
     # ------------------------------------------------------------------ data parallel
     def grad_buckets(self):
@@ -89,9 +96,7 @@ class TrainEngine:
         hw = x.shape[1] * x.shape[2]
         feat = ops.avgpool_posenc(x, Bn, T, sd["temp_enc"])
         head_out, tctx = self.temporal.forward_heads(feat, drop_masks)
-        for k in sd:                                             # BatchNorm step counters (nn.BatchNorm.num_batches_tracked)
-            if k.endswith("num_batches_tracked"):
-                sd[k] += 1
+        self.params.nbt += 1                                     # BatchNorm step counters (nn.BatchNorm.num_batches_tracked)
         from types import SimpleNamespace
         return head_out, SimpleNamespace(fr=fr, crop=crop, flip=fl, z0=z0, y0=y0, bn0=bn0, x_shape=x.shape, hw=hw, tctx=tctx,
                                          B=Bn, T=T)
@@ -132,9 +137,17 @@ class TrainEngine:
         return loss, self.backward_train(ctx, dhead)
 
     def repack(self):
-        for blk in self.blocks:
-            blk.repack()
-        self.temporal.repack()
+        """Refresh the kernel-layout copies of the weights (after an optimizer step or a load_state_dict): one gather
+        launch per dtype through the recorded index tables (repack.PackPlan)."""
+        if not self.pack_gather:
+            for blk in self.blocks:
+                blk.repack()
+            self.temporal.repack()
+        elif self.pack is None:
+            from .repack import PackPlan
+            self.pack = PackPlan(self.params, self.device).build(list(self.blocks) + [self.temporal])
+        else:
+            self.pack.run()
 
     # ------------------------------------------------------------------ one optimiser step
     def write_grads(self, grads, scale=1.0, first=True, partial=False, role=0):

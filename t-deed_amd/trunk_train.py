@@ -9,7 +9,7 @@ from types import SimpleNamespace
 
 import torch
 
-from . import ops, ops_bwd as B_
+from . import ops, ops_bwd as B_, repack as R
 
 BN_EPS = 1e-5
 # ReLU masks of the BatchNorm backward recomputed from z (fa * z + fb > 0) instead of read from the stored activation
@@ -19,8 +19,8 @@ ZMASK = _os.environ.get("TDEED_TRAIN_ZMASK", "1") == "1"
 
 def _dense(w, dt):
     w = w.reshape(w.shape[0], -1).contiguous()
-    w = w if dt == torch.float32 else ops.cast_bf16(w)
-    return SimpleNamespace(w=w, wt=B_.transpose(w))
+    w = w if dt == torch.float32 else R.cast_bf16(w)
+    return SimpleNamespace(w=w, wt=R.transpose(w))
 
 
 class GateShiftTrain:
@@ -30,6 +30,14 @@ class GateShiftTrain:
         self.sd, self.pre, self.F, self.T, self.dt = sd, pre, F, T, act_dtype
         self.fuse = (pre + ".channel_conv1.weight") in sd          # _GSF; the plain _GSM has no fusion conv
         self.Fp = (F + 7) // 8 * 8
+        # BatchNorm3d running statistics live in Fp-wide buffers (pad columns: mean 0, var 1) that the state dict entries
+        # alias, so the statistics kernel updates them in place without a copy in / copy out per step
+        dev = sd[pre + ".bn.running_mean"].device
+        self.rm_pad = torch.zeros(self.Fp, dtype=torch.float32, device=dev)
+        self.rv_pad = torch.ones(self.Fp, dtype=torch.float32, device=dev)
+        self.rm_pad[:F] = sd[pre + ".bn.running_mean"]
+        self.rv_pad[:F] = sd[pre + ".bn.running_var"]
+        sd[pre + ".bn.running_mean"], sd[pre + ".bn.running_var"] = self.rm_pad[:F], self.rv_pad[:F]
         self.repack()
 
     def repack(self):
@@ -42,16 +50,13 @@ class GateShiftTrain:
             from .engine import gsf_q_frags_on_device
             self.wqf = gsf_q_frags_on_device(sd[pre + ".conv3D.weight"])
         self.b3 = sd[pre + ".conv3D.bias"]
+        self.w_pad = R.pad1d(sd[pre + ".bn.weight"], self.Fp)      # BatchNorm3d affine, zero in the pad columns
+        self.b_pad = R.pad1d(sd[pre + ".bn.bias"], self.Fp)
         if self.fuse:
             self.cw1, self.cb1 = sd[pre + ".channel_conv1.weight"].reshape(18), sd[pre + ".channel_conv1.bias"]
             self.cw2, self.cb2 = sd[pre + ".channel_conv2.weight"].reshape(18), sd[pre + ".channel_conv2.bias"]
         else:
             self.cw1 = self.cb1 = self.cw2 = self.cb2 = None
-
-    def _pad(self, v, fill=0.0):
-        out = torch.full((self.Fp,), fill, dtype=torch.float32, device=v.device)
-        out[:self.F] = v
-        return out
 
     def forward(self, x):
         """x (N,h,w,C) -> G (N*h*w, Fp): the module output in conv1's operand layout (pad columns = copies of x)."""
@@ -59,11 +64,8 @@ class GateShiftTrain:
         N = x.shape[0]
         c = SimpleNamespace(x=x, B=N // T)
         c.xs = B_.gsf_slice(x, F, Fp)
-        rm, rv = self._pad(sd[pre + ".bn.running_mean"]), self._pad(sd[pre + ".bn.running_var"], 1.0)
-        c.w_pad = self._pad(sd[pre + ".bn.weight"])
-        c.mean, c.rstd, c.sa, c.sb = B_.bn_stats(c.xs, c.w_pad, self._pad(sd[pre + ".bn.bias"]), BN_EPS, 0.1, rm, rv)
-        sd[pre + ".bn.running_mean"].copy_(rm[:F])
-        sd[pre + ".bn.running_var"].copy_(rv[:F])
+        c.w_pad = self.w_pad
+        c.mean, c.rstd, c.sa, c.sb = B_.bn_stats(c.xs, self.w_pad, self.b_pad, BN_EPS, 0.1, self.rm_pad, self.rv_pad)
         bufs = {}
         dev = x.device
         h, w = x.shape[1], x.shape[2]
@@ -110,6 +112,8 @@ class BottleneckTrain:
         # separate column-statistics pass
         import os
         self.epi_stats = act_dtype == torch.bfloat16 and os.environ.get("TDEED_TRAIN_EPI_STATS", "1") == "1"
+        dev = sd[self.c1 + ".conv.weight"].device
+        self.one, self.zero = torch.ones(blk.cout, device=dev), torch.zeros(blk.cout, device=dev)
         self.repack()
 
     def repack(self):
@@ -123,7 +127,6 @@ class BottleneckTrain:
         G, gw = blk.groups, blk.gw
         self.w2p = (sd[pre + ".conv2.conv.weight"].reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1)
                     .reshape(G, 9, gw, gw).contiguous())
-        self.one, self.zero = torch.ones(blk.cout, device=dev), torch.zeros(blk.cout, device=dev)
         # bf16: conv2 forward and (stride 1) its input gradient run on the MFMA grouped-conv kernel; the input gradient is
         # a grouped conv of dy with the weights flipped in space and transposed inside each group
         self.w2frag = self.w2frag_t = None

@@ -510,3 +510,59 @@ def test_gsm_backbone_trains_and_matches_autograd():
     eng.opt.lr = 2e-4                               # Adam without warm-up: the first steps are noisy at 1e-3
     ls = [float(eng.step(frames.to(DEV), lab.to(DEV), labD.to(DEV))[0]) for _ in range(16)]
     assert all(np.isfinite(ls)) and min(ls[-5:]) < ls[0], ls
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gathered_weight_copies_equal_the_per_module_repack(dtype, monkeypatch):
+    """repack.PackPlan (one gather launch per dtype through recorded index tables) against every module packing its own
+    casts / transposes / fragments: the same bytes in every packed tensor, and bit-identical losses over two optimizer
+    steps (the second step runs on re-packed, updated weights)."""
+    from types import SimpleNamespace
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny002_gsf", clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, 8, 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 41).items()}
+    frames = t(synth.uint8_clip(811, (B, T, 3, H, W))).to(DEV)
+    lab_np, labD_np = synth.labels(812, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long().to(DEV), t(labD_np).float().to(DEV)
+    monkeypatch.setenv("TDEED_REPACK_GATHER", "1")
+    e1 = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dtype, lr=1e-3)
+    monkeypatch.setenv("TDEED_REPACK_GATHER", "0")
+    e0 = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dtype, lr=1e-3)
+    assert e1.pack is not None and e0.pack is None and e1.pack.n_packed > 50
+
+    def tensors(obj, path, out, depth=0):
+        items = enumerate(obj) if isinstance(obj, list) else vars(obj).items()
+        for k, v in items:
+            if k in ("sd", "ctx", "blk", "rm_pad", "rv_pad"):
+                continue
+            if isinstance(v, torch.Tensor):
+                out[f"{path}.{k}"] = v
+            elif isinstance(v, (list, SimpleNamespace)) or (hasattr(v, "__dict__") and not callable(v) and depth < 5):
+                tensors(v, f"{path}.{k}", out, depth + 1)
+        return out
+
+    def compare():
+        n = 0
+        for i, (a, b) in enumerate(zip(list(e1.blocks) + [e1.temporal], list(e0.blocks) + [e0.temporal])):
+            ta, tb = tensors(a, str(i), {}), tensors(b, str(i), {})
+            assert set(ta) == set(tb)
+            for k in ta:
+                assert ta[k].dtype == tb[k].dtype and ta[k].shape == tb[k].shape, k
+                assert torch.equal(ta[k], tb[k]), k
+                n += 1
+        return n
+
+    assert compare() > 200
+    for _ in range(2):
+        l1 = e1.step(frames, lab, labD)
+        l0 = e0.step(frames, lab, labD)
+        torch.cuda.synchronize()
+        assert torch.equal(l1, l0)
+        assert torch.equal(e1.params.flat, e0.params.flat)
+        compare()
+    # BatchNorm bookkeeping through the flat counters / padded running buffers
+    k = "_features.s3.b1.conv1.gs.bn.running_mean"
+    assert torch.equal(e1.state[k], e0.state[k]) and e1.state[k].shape == sd0[k].shape
+    assert int(e1.state["_features.stem.bn.num_batches_tracked"]) == 2
