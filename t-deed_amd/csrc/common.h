@@ -137,6 +137,18 @@ struct IDiv {
   }
 };
 
+// MFMA operand (one column, 8 consecutive rows) out of a row-major [row][column] bf16 LDS image with two transposing
+// reads (gfx950 ds_read_b64_tr_b16): per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4-row x 16-column block and lane i receives column i of the 4 rows.  lo / hi: this lane's address in rows 0..3 / 4..7.
+// EXEC must be all ones (call from wave-uniform code only).
+typedef __bf16 td_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x8 td_tr_read8(const bf16_t* lo, const bf16_t* hi) {
+  typedef __attribute__((address_space(3))) td_bf16x4 lds_v4;
+  const td_bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(lo));
+  const td_bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(hi));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 // compiler-level fence: keeps the loads issued above it ahead of the LDS writes below it (the scheduler otherwise
 // interleaves them and every write waits on its own load)
 #define TD_ISSUE_FENCE() asm volatile("" ::: "memory")

@@ -498,6 +498,128 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dw_kernel(const T* __restr
   }
 }
 
+// ---- the same weight gradient on the MFMA pipe (bf16): per frame f' a GEMM  D[c][(g, tap)] = sum_p a[f'][p][c] * B[p][(g, tap)]
+// with B[p][(g, tap)] = d_pre[g][f' - dt + 1][p - (dy - 1, dx - 1)].  The contraction index is the pixel: a (relu(bn(x)),
+// bf16) goes to LDS as a row-major [pixel][channel] image and its operand -- one channel, 8 consecutive pixels -- comes
+// from two transposing reads; the B operand (54 of 64 columns used) is gathered from the zero-ringed d_pre tile, 8 scalar
+// LDS reads per lane and 32-pixel step, shared by all channel tiles.  Both gate groups are computed for a channel tile
+// that straddles F/2; the output keeps each channel's own group.  Same partial layout as the kernel above.
+__global__ __launch_bounds__(256) void gsf_bwd_conv3d_dw_mfma_kernel(const bf16_t* __restrict__ x,
+                                                                     const float* __restrict__ d_pre,
+                                                                     const float* __restrict__ sa,
+                                                                     const float* __restrict__ sb, int T_len, int h, int w,
+                                                                     int C, int F, int RS, int KST, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  const int hw = h * w, WP = w + 2, HP = h + 2;
+  bf16_t* at = reinterpret_cast<bf16_t*>(smraw);                // [KST * 32][RS]
+  float* dpt = reinterpret_cast<float*>(at + (size_t)KST * 32 * RS);      // [3][HP][WP][2]
+  int* poff = reinterpret_cast<int*>(dpt + 3 * HP * WP * 2);    // [KST * 32]: ring offset of pixel p (or of a zero cell)
+  __shared__ float scratch[8];
+  const long f = blockIdx.x;
+  const int t = (int)(f % T_len);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nck = (F + 7) >> 3, NP = KST * 32;
+  {
+    const IDiv dck(nck);
+    for (int i0 = tid; i0 < NP * nck; i0 += 256 * 4) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * 256, NP * nck - 1);
+        int p, ck;
+        dck.divmod(i, p, ck);
+        v[u] = *reinterpret_cast<const u32x4*>(x + (f * hw + min(p, hw - 1)) * C + ck * 8);
+      }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < NP * nck) {
+          int p, ck;
+          dck.divmod(i, p, ck);
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[u]);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = ck * 8 + e, cc = min(c, F - 1);
+            const float a = fmaxf(fmaf((float)t8[e], sa[cc], sb[cc]), 0.f);
+            o[e] = (p < hw && c < F) ? (bf16_t)a : (bf16_t)0.f;
+          }
+          *reinterpret_cast<bf16x8*>(at + (size_t)p * RS + ck * 8) = o;
+        }
+      }
+    }
+  }
+  for (int i = tid; i < 3 * HP * WP * 2; i += 256) {
+    const int g = i & 1;
+    const int r = i >> 1;
+    const int xx = r % WP, yy = (r / WP) % HP, k = r / (WP * HP);
+    const int t2 = t + k - 1, y2 = yy - 1, x2 = xx - 1;
+    float v = 0.f;
+    if (t2 >= 0 && t2 < T_len && y2 >= 0 && y2 < h && x2 >= 0 && x2 < w)
+      v = d_pre[((f + (k - 1)) * hw + y2 * w + x2) * 2 + g];
+    dpt[i] = v;
+  }
+  for (int p = tid; p < NP; p += 256) {
+    const int py = p / w, px = p - py * w;
+    poff[p] = p < hw ? ((py + 1) * WP + px + 1) * 2 : 0;         // ring cell (0, 0) of slab 0..2 is zero: a pad pixel's a is 0 anyway
+  }
+  __syncthreads();
+  const int Fh = F >> 1;
+  const int MT = (F + 15) >> 4;
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3, pl = lane & 15;
+  // jobs = (channel tile, gate group the tile touches, half of that group's 32 columns), dealt round-robin to the 4 waves
+  int njobs = 0;
+  for (int mt = 0; mt < MT; ++mt) njobs += ((mt * 16 < Fh) ? 2 : 0) + ((mt * 16 + 15 >= Fh) ? 2 : 0);
+  for (int job = wv; job < njobs; job += 4) {
+    int mt = 0, g = 0, nh = 0, acc_j = job;
+    for (mt = 0; mt < MT; ++mt) {
+      const int n0 = (mt * 16 < Fh) ? 2 : 0, n1 = (mt * 16 + 15 >= Fh) ? 2 : 0;
+      if (acc_j < n0) { g = 0; nh = acc_j; break; }
+      acc_j -= n0;
+      if (acc_j < n1) { g = 1; nh = acc_j; break; }
+      acc_j -= n1;
+    }
+    const int tap = nh * 16 + pl;                                // this lane's B column
+    const bool tok = tap < 27;
+    const int tc = tok ? tap : 0;
+    const int dt = tc / 9, dy = (tc / 3) % 3, dx = tc % 3;
+    // B[p][(g, tap)] = dpt[slab 2 - dt][py + 2 - dy][px + 2 - dx][g] = dpt[base + poff[p]], poff = ((py + 1) WP + px + 1) 2
+    const int base = (((2 - dt) * HP + (1 - dy)) * WP + (1 - dx)) * 2 + g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KST; ++ks) {
+      const int row = ks * 32 + g4 * 8;
+      const bf16x8 af = td_tr_read8(at + (size_t)(row + q4) * RS + mt * 16 + p4 * 4, at + (size_t)(row + q4 + 4) * RS + mt * 16 + p4 * 4);
+      bf16x8 bfr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int p = row + e;
+        const float v = dpt[(p < hw ? base : g) + poff[p]];
+        bfr[e] = tok ? (bf16_t)v : (bf16_t)0.f;
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc, 0, 0, 0);
+    }
+    if (tok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = mt * 16 + 4 * g4 + e;
+        if (c < F && (c >= Fh) == (g == 1)) part[f * (F * 27 + 2) + (long)c * 27 + tap] = acc[e];
+      }
+    }
+  }
+  float b0 = 0.f, b1 = 0.f;
+  for (int p = tid; p < hw; p += 256) {
+    b0 += dpt[HP * WP * 2 + poff[p]];
+    b1 += dpt[HP * WP * 2 + poff[p] + 1];
+  }
+  b0 = block_sum<4>(b0, scratch);
+  b1 = block_sum<4>(b1, scratch);
+  if (tid == 0) {
+    part[f * (F * 27 + 2) + F * 27] = b0;
+    part[f * (F * 27 + 2) + F * 27 + 1] = b1;
+  }
+}
+
 // ---- dx[m][c] += a[m][c] + b[m][c] for c < Fp (dx row stride C; a, b dense [M][Fp])
 template <typename T>
 __global__ __launch_bounds__(256) void gsf_add_cols_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
@@ -580,6 +702,21 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
     hipLaunchKernelGGL(gsf_bwd_conv3d_dx_kernel<T>, gpix, dim3(256), (size_t)F * 27 * sizeof(float), st, x, d_pre, w3, sa,
                        sb, T_len, h, w, C, F, Fp, d_bn);
     TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx");
+  }
+  if constexpr (sizeof(T) == 2) {
+    static const bool dw_valu = getenv("TDEED_GSF_DW_VALU") && atoi(getenv("TDEED_GSF_DW_VALU")) == 1;
+    const int KST = (hw + 31) / 32, MTn = (F + 15) / 16;
+    const int RS = MTn * 16 + 16;                               // row stride (elements): whole channel tiles + 32 bytes
+    const size_t smm = (size_t)KST * 32 * RS * 2 + (size_t)3 * (h + 2) * (w + 2) * 2 * 4 + (size_t)KST * 32 * 4;
+    if (!dw_valu && smm <= 150 * 1024 && ((F + 7) / 8) * 8 <= C) {
+      hipError_t e2 = hipFuncSetAttribute((const void*)gsf_bwd_conv3d_dw_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          150 * 1024);
+      if (e2 != hipSuccess) { tdeed_set_error("gsf_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e2)); return TDEED_ERR_RUNTIME; }
+      hipLaunchKernelGGL(gsf_bwd_conv3d_dw_mfma_kernel, dim3((unsigned)N), dim3(256), smm, st, (const bf16_t*)x, d_pre, sa, sb,
+                         T_len, h, w, C, F, RS, KST, part_w3);
+      TD_LAUNCH_CHECK("gsf_bwd_conv3d_dw_mfma");
+      return TDEED_OK;
+    }
   }
   const size_t smw = ((size_t)hw * F + (size_t)3 * (h + 2) * (w + 2) * 2) * sizeof(float);
   TD_CHECK(smw <= 150 * 1024, "gsf_bwd: frame %dx%d x %d channels does not fit LDS", h, w, F);

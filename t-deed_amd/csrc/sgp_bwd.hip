@@ -303,13 +303,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restric
 // consecutive rows -- is two transposing reads (per 16-lane group the hardware returns lane i column i of 4 rows).
 // Half the barriers and a quarter of the LDS instructions per row of the kernel above.
 constexpr int WT_RS = 80;                                       // LDS row stride in elements: 64 columns + 32 bytes
-typedef __bf16 wt_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
-__device__ __forceinline__ bf16x8 wt_tr_read8(const bf16_t* lo, const bf16_t* hi) {
-  typedef __attribute__((address_space(3))) wt_bf16x4 lds_v4;
-  const wt_bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(lo));
-  const wt_bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(hi));
-  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-}
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const bf16_t* __restrict__ dY, long ldy, const bf16_t* __restrict__ X,
                                                        long ldx, int M, int N, int K, float* __restrict__ part_w,
                                                        float* __restrict__ part_b) {
@@ -359,10 +352,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int row = ks * 32 + g4 * 8 + q4;
-      const bf16x8 af = wt_tr_read8(sY + row * WT_RS + wv * 16 + p4 * 4, sY + (row + 4) * WT_RS + wv * 16 + p4 * 4);
+      const bf16x8 af = td_tr_read8(sY + row * WT_RS + wv * 16 + p4 * 4, sY + (row + 4) * WT_RS + wv * 16 + p4 * 4);
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const bf16x8 bfr = wt_tr_read8(sX + row * WT_RS + kt * 16 + p4 * 4, sX + (row + 4) * WT_RS + kt * 16 + p4 * 4);
+        const bf16x8 bfr = td_tr_read8(sX + row * WT_RS + kt * 16 + p4 * 4, sX + (row + 4) * WT_RS + kt * 16 + p4 * 4);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[kt], 0, 0, 0);
       }
     }

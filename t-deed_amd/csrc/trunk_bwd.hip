@@ -1092,14 +1092,6 @@ __global__ __launch_bounds__(256) void gconv_wgrad_mfma_kernel(const bf16_t* __r
 // operand is two transposing reads: per 16-lane group the hardware hands lane i column i of 4 rows whose addresses the
 // lanes supply -- 4 consecutive output pixels, wherever the tap and the stride put their input pixels in the patch.
 // workgroup = (run of tiles, chunk of 64 channels); wave = one 16-channel unit with all 9 tap accumulators.
-typedef __bf16 bf16x4_t __attribute__((__vector_size__(4 * sizeof(__bf16))));
-__device__ __forceinline__ bf16x8 tr_read8(const bf16_t* lo, const bf16_t* hi) {
-  typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
-  const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(lo));
-  const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(hi));
-  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-}
-
 constexpr int GWT_RS = 80;                                      // LDS row stride (elements): 64 channels + 32 bytes
 template <int S, int GW>
 __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -1173,12 +1165,12 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ty = ks * 4 + g4;
-      const bf16x8 bfr = tr_read8(dyt + (ty * 8 + q4) * GWT_RS + colo, dyt + (ty * 8 + q4 + 4) * GWT_RS + colo);
+      const bf16x8 bfr = td_tr_read8(dyt + (ty * 8 + q4) * GWT_RS + colo, dyt + (ty * 8 + q4 + 4) * GWT_RS + colo);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int r0 = (ty * S + ky) * PW + q4 * S + kx;
-        const bf16x8 afr = tr_read8(patch + r0 * GWT_RS + colo, patch + (r0 + 4 * S) * GWT_RS + colo);
+        const bf16x8 afr = td_tr_read8(patch + r0 * GWT_RS + colo, patch + (r0 + 4 * S) * GWT_RS + colo);
         acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[tap], 0, 0, 0);
       }
     }
