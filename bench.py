@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-records of the default line")
     ap.add_argument("--no-feed", action="store_true", help="skip the fed-from-pinned-host-memory measurement")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pmc-pass", action="store_true",
+                    help="only the timed steps (for rocprofv3 --pmc counter passes: eager launches, no side measurements)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight: consecutive steps alternate between this many independent buffer sets / HIP "
                          "graphs on their own streams, so the latency-bound tail of one batch overlaps the next one's "
@@ -357,6 +359,11 @@ def main():
     run(max(a.warmup, depth))
     walls, evs = timed_regions(run, a.steps, a.repeats, dev, streams)
     el = statistics.median(walls)
+    if a.pmc_pass:
+        if rank == 0:
+            print(json.dumps({"pmc_pass": True, "workload": a.workload, "steps": a.steps, "ms_per_step": round(el / a.steps * 1e3, 4),
+                              "hip_graph": not a.no_graph, "git_head": git_head()}))
+        return
     # latency of ONE batch with nothing else in flight (graph replay + sync per step)
     lat = []
     if rank == 0:
@@ -440,7 +447,9 @@ def main():
                 tj = json.load(fh)
             tr = tj["kernels"].get(name)
             if tr is not None and a.workload == "rny002_b8" and a.dtype == "bf16":
-                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                # per launch of THIS line's launch unit (an engine step; a gate-shift site is three kernels)
+                roof["traffic"] = (int(tr["hbm_bytes_per_forward"] / max(d["launches"], 1)) if "hbm_bytes_per_forward" in tr
+                                   else tr["hbm_bytes_per_launch"])
                 roof["traffic_source"] = (f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes at git {tj.get('git_head')} "
                                           f"({tj.get('fetch_pass', {}).get('mtime')}); not measured by this run")
         except (OSError, KeyError, ValueError):
@@ -467,7 +476,7 @@ def main():
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         step_bytes = sum(s.bytes for s in plan.steps)
         step_flops = sum(s.flops for s in plan.steps)
-        out = dict(metric="clips/sec (L=100, 224^2, bf16) forward, per-frame logits", value=round(value, 2),
+        out = dict(metric=f"clips/sec (L={T}, 224^2, {a.dtype}) forward, per-frame logits", value=round(value, 2),
                    unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
                    config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']} "

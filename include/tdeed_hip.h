@@ -109,20 +109,6 @@ int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int 
                        void* y, float* pooled, float* pooled_sq, int relu /* 0: y = conv*scale+shift (training: raw map
                        for the batch statistics) */, int dtype, void* stream);
 
-/* ---- whole bottleneck in one launch (bf16, stride 1, identity shortcut, map <= 64 px: s4.b2.. of RegNetY-200MF)
- * conv1(+gate-shift splice G in front)+BN+ReLU -> grouped 3x3+BN+ReLU -> SE -> conv3+BN+residual+ReLU, one
- * frame per workgroup, intermediates in LDS/registers (bneck.hip).  x,out [N][h*w][C]; G [N*h*w][Fp] or NULL.
- * w1f / w3f = engine.pack_rowtile_weights(W1 / W3), w2f = pack_gconv_frags(W2) (bf16);
- * s1..s3 / h1..h3: folded eval BatchNorm scale / shift; se_w1p bf16 [C][ceil8(R)] (fc1.weight^T, zero padded),
- * se_w2p bf16 [R][C] (fc2.weight^T); SE biases fp32. */
-int tdeed_bneck_fits(int h, int w, int C, int R);
-/* diagnostic only: device buffer of 8 int64 per frame receiving phase time stamps (NULL switches it off) */
-int tdeed_bneck_set_debug(void* buf);
-int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f,
-                    const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
-                    const void* se_w1p, const float* se_b1, const void* se_w2p, const float* se_b2, int R,
-                    const void* w3f, const float* s3, const float* h3, void* out, void* stream);
-
 /* Split-K form of the contraction for the short sequences of the SGP encoder-decoder (a few hundred rows, K up to
  * 6C; bf16): C = act((A . W^T) * scale + shift + R).  Two launches: S = tdeed_gemm_splitk_splits(K) partial products
  * into `workspace` (fp32, S*M*N elements, caller-owned), then a reduce + epilogue pass. */
@@ -137,14 +123,6 @@ int tdeed_gemm_splitk_fwd(const void* A, long lda, int M, int K, int N, const vo
 int tdeed_se_gate_mfma_fits(int C, int R);
 int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R, const void* w1f,
                            const float* b1, const void* w2f, const float* b2, float* gate, void* stream);
-
-/* grouped 3x3 (stride 1) + BN + ReLU + SE squeeze + excitation in ONE launch for small maps (one workgroup per
- * frame; bf16): y = conv2_out * gate, i.e. the operand conv3 consumes, so conv3 needs no a_scale and the SE launch
- * disappears.  tdeed_gconv_se_fits() != 0 tells whether (h, w, C, R) is supported. */
-int tdeed_gconv_se_fits(int h, int w, int C, int R);
-int tdeed_gconv_se_fwd(const void* x, int N, int h, int w, int C, const void* wfrag, const float* scale,
-                       const float* shift, const void* se_w1p, const float* se_b1, const void* se_w2p,
-                       const float* se_b2, int R, void* y, void* stream);
 
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
  * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled: fp32 [N][n_parts][C] partial sums, mean = inv_cnt *

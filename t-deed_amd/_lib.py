@@ -45,9 +45,6 @@ _SIGS = {
                            c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gconv3x3_parts": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_int, P], c_int),
-    "tdeed_bneck_set_debug": ([P], c_int),
-    "tdeed_bneck_fits": ([c_int, c_int, c_int, c_int], c_int),
-    "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P], c_int),
     "tdeed_gemm_splitk_splits": ([c_int], c_int),
     "tdeed_gemm_splitk_fwd": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P, P, c_long, c_int, P, c_long, P, P], c_int),
     "tdeed_se_gate_mfma_fits": ([c_int, c_int], c_int),
@@ -85,8 +82,6 @@ _SIGS = {
                               c_int, P], c_int),
     "tdeed_upsample_bwd": ([P, c_long, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_maxpool_bwd": ([P, P, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
-    "tdeed_gconv_se_fits": ([c_int, c_int, c_int, c_int], c_int),
-    "tdeed_gconv_se_fwd": ([P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P, P], c_int),
     "tdeed_se_gate_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_se_gate_bf16_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gsf_gate_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P], c_int),

@@ -11,10 +11,10 @@
 //   mode 1 (BN backward): v = g,             u = (z - mean) * rstd      -> sum g, sum g * xhat,
 //                         g = dy masked by y > 0 when a ReLU follows the BN (relu = 1)
 // lanes = (row lane, channel chunk); every lane keeps CS_B row loads (x up to 3 tensors) in flight.
-constexpr int CS_B = 6;
-template <typename T>
+constexpr int CS_B = 4;
+template <typename T, int MODE>                                // 0: forward sums; 1: backward, mask from z (or none); 2: backward, mask from y
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, const T* __restrict__ dy,
-                                                       const T* __restrict__ y, long M, int C, int mode, int relu,
+                                                       const T* __restrict__ y, long M, int C, int relu,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ fa, const float* __restrict__ fb,
                                                        long rows_per_slab, float* __restrict__ part) {
@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
     const int c0 = ch * EPC;
     // ReLU mask of the backward: from the stored activation y, or (no residual in front of the ReLU: y == nullptr)
     // recomputed from z through the forward affine, y > 0 <=> fa * z + fb > 0 -- one map less to read
-    const bool zmask = mode && relu && !y;
+    constexpr bool mode = MODE != 0;
+    const bool zmask = MODE == 1 && relu;
     float s1[EPC], s2[EPC], mu[EPC], rs[EPC], ma[EPC], mb[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -35,30 +36,32 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
       mu[e] = mode ? mean[c0 + e] : 0.f;
       rs[e] = mode ? rstd[c0 + e] : 0.f;
       ma[e] = zmask ? fa[c0 + e] : 0.f;
-      mb[e] = zmask ? fb[c0 + e] : 0.f;
+      mb[e] = zmask ? fb[c0 + e] : 1.f;                          // no ReLU: act = 1 > 0 keeps every gradient
     }
     for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * CS_B) {
-      float zv[CS_B][EPC], gv[CS_B][EPC], yv[CS_B][EPC];
+      float zv[CS_B][EPC], gv[MODE ? CS_B : 1][EPC], yv[MODE == 2 ? CS_B : 1][EPC];
 #pragma unroll
       for (int b = 0; b < CS_B; ++b) {
         const long r = min(r0 + (long)b * RL, m1 - 1);
         Chunk<T>::load(z + r * C + c0, zv[b]);
-        if (mode) Chunk<T>::load(dy + r * C + c0, gv[b]);
-        if (mode && relu && !zmask) Chunk<T>::load(y + r * C + c0, yv[b]);
+        if constexpr (MODE != 0) Chunk<T>::load(dy + r * C + c0, gv[b]);
+        if constexpr (MODE == 2) Chunk<T>::load(y + r * C + c0, yv[b]);
       }
 #pragma unroll
       for (int b = 0; b < CS_B; ++b)
         if (r0 + (long)b * RL < m1) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
-            if (mode == 0) {
+            if constexpr (MODE == 0) {
               s1[e] += zv[b][e];
               s2[e] = fmaf(zv[b][e], zv[b][e], s2[e]);
             } else {
-              const float act = zmask ? fmaf(zv[b][e], ma[e], mb[e]) : yv[b][e];
-              const float g = (relu && !(act > 0.f)) ? 0.f : gv[b][e];
+              float act;
+              if constexpr (MODE == 2) act = relu ? yv[b][e] : 1.f;
+              else act = fmaf(zv[b][e], ma[e], mb[e]);
+              const float g = act > 0.f ? gv[b][e] : 0.f;
               s1[e] += g;
-              s2[e] = fmaf(g, (zv[b][e] - mu[e]) * rs[e], s2[e]);
+              s2[e] = fmaf(g, zv[b][e] - mu[e], s2[e]);         // times rstd once, below
             }
           }
         }
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ z, 
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       sred[(rl * 2 + 0) * C + c0 + e] = s1[e];
-      sred[(rl * 2 + 1) * C + c0 + e] = s2[e];
+      sred[(rl * 2 + 1) * C + c0 + e] = mode ? s2[e] * rs[e] : s2[e];
     }
   }
   __syncthreads();
@@ -150,8 +153,16 @@ static int launch_colstats(const void* z, const void* dy, const void* y, long M,
   const int slabs = colstats_slabs(M, &rps);
   const int nch = C / Chunk<T>::N;
   const int RL = 256 / nch > 0 ? 256 / nch : 1;
-  hipLaunchKernelGGL(colstats_kernel<T>, dim3(slabs), dim3(256), (size_t)RL * 2 * C * sizeof(float), st, (const T*)z,
-                     (const T*)dy, (const T*)y, M, C, mode, relu, mean, rstd, fa, fb, rps, part);
+  const size_t sm = (size_t)RL * 2 * C * sizeof(float);
+  if (mode == 0)
+    hipLaunchKernelGGL((colstats_kernel<T, 0>), dim3(slabs), dim3(256), sm, st, (const T*)z, (const T*)dy, (const T*)y, M, C, relu,
+                       mean, rstd, fa, fb, rps, part);
+  else if (relu && y)
+    hipLaunchKernelGGL((colstats_kernel<T, 2>), dim3(slabs), dim3(256), sm, st, (const T*)z, (const T*)dy, (const T*)y, M, C, relu,
+                       mean, rstd, fa, fb, rps, part);
+  else
+    hipLaunchKernelGGL((colstats_kernel<T, 1>), dim3(slabs), dim3(256), sm, st, (const T*)z, (const T*)dy, (const T*)y, M, C, relu,
+                       mean, rstd, fa, fb, rps, part);
   return slabs;
 }
 

@@ -106,19 +106,6 @@ def pack_ws_weights(W, act_dtype, device):
     return torch.from_numpy(fr).to(device).to(act_dtype).contiguous()
 
 
-def pack_rowtile_weights(W, device):
-    """[N][K] -> bf16 MFMA A-operand fragments [ceil(N/32)*2][ceil(K/32)][64][8], natural row order
-    (tile T row n = channel 16T+n): conv1 of the fused bottleneck, whose output goes to LDS."""
-    W = _np(W).astype(np.float32)
-    N, K = W.shape
-    KS = (K + 31) // 32
-    NT = (N + 31) // 32 * 2
-    Wp = np.zeros((NT * 16, KS * 32), np.float32)
-    Wp[:N, :K] = W
-    fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
-    return torch.from_numpy(np.ascontiguousarray(fr).reshape(NT, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
-
-
 def pack_mlp_frags(w1, w2, device):
     """mlp.0.weight (4C,C) and mlp.2.weight (C,4C) -> bf16 MFMA A-operand fragments for sgp_mlp_kernel, each
     [4][C/16][ceil(C/32)][64][8]: chunk c of C hidden units, 16-row tile t, k-step s, lane l holds row l&15 and
@@ -140,7 +127,7 @@ def pack_mlp_frags(w1, w2, device):
 
 
 def pack_se_bf16(fc1_w, fc2_w, device):
-    """SE weights for the fused bottleneck: fc1.weight [R][C][1][1] -> bf16 [C][ceil8(R)] (transposed, zero padded);
+    """SE weights for the bf16 excitation kernel: fc1.weight [R][C][1][1] -> bf16 [C][ceil8(R)] (transposed, zero padded);
     fc2.weight [C][R][1][1] -> bf16 [R][C] (transposed)."""
     w1 = _np(fc1_w).astype(np.float32)
     w1 = w1.reshape(w1.shape[0], -1)
@@ -583,16 +570,6 @@ class PackedWeights:
                             and ops.se_gate_mfma_fits(blk.cout, blk.se_rd)) else None)
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
-            bw.fused = None
-            if (act_dtype == torch.bfloat16 and str(device) != "cpu" and blk.stride == 1 and not blk.has_downsample
-                    and os.environ.get("TDEED_BNECK") == "1"):
-                # one-launch bottleneck (bneck.hip): correct, but measured slower than the 4-launch chain on
-                # MI355X (every frame re-streams ~1 MB of weights from L2: 180 vs 143 us per s4 block at B=8),
-                # so it is opt-in; see DESIGN.md section 6.
-                bw.fused = SimpleNamespace(
-                    w1f=pack_rowtile_weights(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), device),
-                    w3f=pack_rowtile_weights(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), device),
-                    **pack_se_bf16(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
             if blk.has_downsample:
                 bw.wd = DenseW(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
                 bw.sd, bw.hd = bn_fold(bp + ".downsample.bn")
@@ -657,12 +634,6 @@ class ForwardEngine:
         self.use_graph = use_graph
         self.fuse_front = fuse_front
         self.n_split = int(os.environ.get("TDEED_SPLIT", n_split))
-        # conv2+SE in one launch (gconv_se): back to back it beats the conv2 / SE pair on 7x7 maps (31 vs 37 us, and
-        # conv3 loses its operand re-scale) and loses on 14x14 (one workgroup per CU, 51 vs 38 us); inside the
-        # two-stream graph the pair overlaps with the other half-batch better and the whole forward is 1.3 % slower
-        # with the fusion, so it is opt-in: TDEED_FUSE_SE=1 (7x7 only) or 2 (both).
-        self.fuse_se_max = int(os.environ.get("TDEED_FUSE_SE", "0"))
-        self.fuse_se = self.fuse_se_max > 0
         # the temporal stage (SGP encoder-decoder + heads) of a split batch runs ONCE over all clips behind the join of the
         # sub-batch trunks: its launches are latency bound and their cost does not depend on the row count at these sizes
         self.merge_tail = os.environ.get("TDEED_SGP_MERGE", "1") == "1"
@@ -684,38 +655,6 @@ class ForwardEngine:
         for bw in blocks:
             blk = bw.spec
             M = N * h * w
-            if bw.fused is not None and ops.bneck_fits(h, w, blk.cout, blk.se_rd):
-                # whole bottleneck in one launch (gate-shift still produces the spliced columns G first)
-                G, Fp, gs_bufs = None, 0, []
-                if blk.gsf_fold:
-                    F = blk.gsf_fold
-                    Fp = (F + 7) // 8 * 8
-                    gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
-                              ysum=pool.take((N, F), torch.float32), xsum=pool.take((N, F), torch.float32),
-                              out=pool.take((M, Fp), dt))
-                    if bw.gs_cw1 is not None:
-                        gb["fw"] = pool.take((B, F, T), torch.float32)
-                    steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
-                        x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                        bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
-                    G = gb["out"]
-                    gs_bufs = list(gb.values())
-                out = (out_last if (out_last is not None and bw is blocks[-1]) else pool.take((N, h, w, blk.cout), dt))
-                Cb = blk.cout
-                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, Fp=Fp, out=out: ops.bneck(
-                    x, bw, G, Fp, out=out),
-                    (3 * M * Cb + M * Fp) * es + (2 * Cb * Cb + Cb * blk.gw * 9) * es + 2 * Cb * blk.se_rd * 4,
-                    2 * M * Cb * (2 * Cb + blk.gw * 9) + 4 * N * Cb * blk.se_rd))
-                for t_ in gs_bufs:
-                    pool.give(t_)
-                if not x_kept and hasattr(x, "_td_raw"):
-                    pool.give(x)
-                tapname = "_features." + blk.name
-                x_kept = tapname in taps
-                if x_kept:
-                    keep[tapname] = out
-                x = out
-                continue
             # conv1 (optionally behind the gate-shift splice)
             y1 = pool.take((N, h, w, blk.cout), dt)
             if blk.gsf_fold:
@@ -743,24 +682,14 @@ class ForwardEngine:
             h2, w2 = (h - 1) // s + 1, (w - 1) // s + 1
             M2 = N * h2 * w2
             y2 = pool.take((N, h2, w2, blk.cout), dt)
-            fuse_se = (bw.se_bf is not None and bw.w2frag is not None and s == 1 and self.fuse_se
-                       and 0 < ops.gconv_se_fits(h, w, blk.cout, blk.se_rd) <= self.fuse_se_max)
-            if fuse_se:
-                # conv2 + SE in one launch (frame per workgroup): y2 already carries the gate
-                pooled = gate = None
-                steps.append(Step(blk.name + ".conv2se", "gconv_se", lambda y1=y1, bw=bw, blk=blk, y2=y2: ops.gconv_se(
-                    y1, bw.w2frag, bw.s2, bw.h2, bw.se_bf.se_w1p, bw.se_b1, bw.se_bf.se_w2p, bw.se_b2, blk.se_rd, out=y2),
-                    (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 2 + 2 * blk.cout * blk.se_rd * 2,
-                    2 * M2 * blk.cout * blk.gw * 9 + 4 * N * blk.cout * blk.se_rd))
-            else:
-                parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
-                pooled = pool.take((N, parts, blk.cout), torch.float32)
-                gate = pool.take((N, blk.cout), torch.float32)
-                steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
-                    y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
-                    (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
-                steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
-                    2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
+            pooled = pool.take((N, parts, blk.cout), torch.float32)
+            gate = pool.take((N, blk.cout), torch.float32)
+            steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
+                y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
+                (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
+            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
+                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
             if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
                 gather = (s, h, w, h2, w2) if s > 1 else None
@@ -774,7 +703,7 @@ class ForwardEngine:
                 y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
                 *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` dies here
-            for t_ in [y1, y2] + ([pooled, gate] if pooled is not None else []) + gs_bufs + ([sc] if blk.has_downsample else []):
+            for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
             if not x_kept and hasattr(x, "_td_raw"):
                 pool.give(x)

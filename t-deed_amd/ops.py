@@ -158,22 +158,6 @@ def gemm_splitk(A, W, scale, shift, act=ACT_NONE, residual=None, out=None, M=Non
     return out
 
 
-def gconv_se_fits(h, w, C, R):
-    """0 = unsupported; 1 = the <=8x8 map variant (two workgroups per CU); 2 = the <=14x14 variant (one per CU)."""
-    return _lib.load().tdeed_gconv_se_fits(h, w, C, R)
-
-
-def gconv_se(x, wfrag, scale, shift, se_w1p, se_b1, se_w2p, se_b2, R, out=None):
-    """grouped 3x3 + BN + ReLU + SE in one launch (bf16, stride 1, small maps): returns conv2_out * gate."""
-    _chk(x, "x", torch.bfloat16)
-    N, h, w, C = x.shape
-    if out is None:
-        out = torch.empty_like(x)
-    call("tdeed_gconv_se_fwd", ptr(x), N, h, w, C, ptr(wfrag), ptr(scale), ptr(shift), ptr(se_w1p), ptr(se_b1),
-         ptr(se_w2p), ptr(se_b2), R, ptr(out), stream_ptr())
-    return out
-
-
 def se_gate_mfma_fits(C, R):
     return _lib.load().tdeed_se_gate_mfma_fits(C, R) != 0
 
@@ -216,23 +200,6 @@ def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled
     call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(wfrag), ptr(scale), ptr(shift),
          ptr(out), ptr(pooled), ptr(pooled_sq), int(relu), dtype_code(x.dtype), stream_ptr())
     return out, pooled
-
-
-def bneck_fits(h, w, C, R):
-    return bool(_lib.load().tdeed_bneck_fits(h, w, C, R))
-
-
-def bneck(x, bw, G=None, Fp=0, out=None):
-    """Fused bottleneck (bf16): x (N,h,w,C) -> (N,h,w,C).  bw: engine block weights with .fused pack."""
-    _chk(x, "x", torch.bfloat16)
-    N, h, w, C = x.shape
-    if out is None:
-        out = torch.empty_like(x)
-    f = bw.fused
-    call("tdeed_bneck_fwd", ptr(x), ptr(G), Fp, N, h, w, C, ptr(f.w1f), ptr(bw.s1), ptr(bw.h1), ptr(bw.w2frag),
-         ptr(bw.s2), ptr(bw.h2), ptr(f.se_w1p), ptr(bw.se_b1), ptr(f.se_w2p), ptr(bw.se_b2), bw.spec.se_rd,
-         ptr(f.w3f), ptr(bw.s3), ptr(bw.h3), ptr(out), stream_ptr())
-    return out
 
 
 def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):

@@ -92,19 +92,6 @@ def test_forward_bf16_close_to_reference(name):
     assert (head[..., :K1].argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
 
 
-def test_fused_bottleneck_opt_in_matches_default(monkeypatch):
-    """TDEED_BNECK=1 routes the stride-1 s3/s4 blocks through the one-launch bottleneck kernel: same logits (bf16 noise)."""
-    meta, g = load_golden("finediving_small")
-    cfg = meta["cfg"]
-    sd = model_state(cfg, meta["seed_w"])
-    clip = synth.uint8_clip(meta["seed_x"], (1, cfg["clip_len"], 3, 224, 224))
-    base, _ = _run(_engine(cfg, sd, torch.bfloat16), clip)
-    monkeypatch.setenv("TDEED_BNECK", "1")
-    fused, plan = _run(_engine(cfg, sd, torch.bfloat16), clip)
-    assert any(s.kernel == "bneck" for s in plan.steps)
-    assert (base - fused).abs().max().item() < 0.08 * max(1.0, base.abs().max().item())
-
-
 def test_wide_frames_fall_back_to_unfused_front():
     """A frame too wide for the fused front kernel's LDS band takes the unfused stem path: bf16 tracks fp32."""
     from tdeed_amd import ops

@@ -198,29 +198,6 @@ def test_gemm_splitk(ops, M, K, N, actn):
     assert rel_err(out2.float(), [ref2, torch.relu(ref2), F.gelu(ref2)][actn]) < BF16_TOL
 
 
-@pytest.mark.parametrize("C,gw,R,h,w", [(368, 8, 92, 7, 7), (152, 8, 38, 14, 14), (152, 8, 38, 4, 5), (56, 8, 6, 8, 8),
-                                        (368, 8, 92, 4, 7), (128, 16, 16, 14, 14)])
-def test_gconv_se_fused_vs_chain(ops, C, gw, R, h, w):
-    """conv2 + BN + ReLU + SE in one launch == grouped conv, then SE gate, then the multiply (fp32 torch)."""
-    from tdeed_amd.engine import pack_gconv_frags, pack_se_bf16
-    assert ops.gconv_se_fits(h, w, C, R)
-    N = 5
-    x = rnd(131, "x", (N, C, h, w)).to(torch.bfloat16)
-    wt = rnd(132, "w", (C, gw, 3, 3), 0.2)
-    sc, sh = rnd(133, "sc", (C,)) * 0.2 + 1.0, rnd(134, "sh", (C,)) * 0.1
-    w1, b1 = rnd(135, "w1", (R, C), 0.1).to(torch.bfloat16).float(), rnd(136, "b1", (R,), 0.1)
-    w2, b2 = rnd(137, "w2", (C, R), 0.2).to(torch.bfloat16).float(), rnd(138, "b2", (C,), 0.1)
-    y2 = torch.relu(F.conv2d(x.float(), wt.to(torch.bfloat16).float(), padding=1, groups=C // gw) * sc.view(1, -1, 1, 1)
-                    + sh.view(1, -1, 1, 1)).to(torch.bfloat16).float()
-    gate = torch.sigmoid(torch.relu(y2.mean(dim=(2, 3)) @ w1.T + b1) @ w2.T + b2)
-    ref = y2 * gate[:, :, None, None]
-    pk = pack_se_bf16(w1.numpy(), w2.numpy(), DEV)
-    out = ops.gconv_se(x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_gconv_frags(wt, gw, DEV), sc.to(DEV), sh.to(DEV),
-                       pk["se_w1p"], b1.to(DEV), pk["se_w2p"], b2.to(DEV), R)
-    assert rel_err(out.float().permute(0, 3, 1, 2), ref) < BF16_TOL
-    assert not ops.gconv_se_fits(28, 28, 56, 6)
-
-
 def test_se_gate(ops):
     N, C, R = 11, 152, 38
     p = rnd(41, "p", (N, C)).abs()
@@ -301,46 +278,6 @@ def test_s1_front_fused_vs_unfused_reference(ops, geom):
     assert rel_err(gp.sum(dim=1) / npix, y2.mean(dim=(2, 3))) < 4e-2
 
 
-@pytest.mark.parametrize("C,gw,R,h,w,Fp", [(368, 8, 92, 7, 7, 96), (368, 8, 92, 7, 7, 0), (152, 8, 38, 4, 5, 40),
-                                           (320, 16, 80, 7, 7, 80)])
-def test_bneck_fused_vs_chain(ops, C, gw, R, h, w, Fp):
-    """one-launch bottleneck == conv1 -> conv2 -> SE -> conv3 (+residual) computed in torch fp32."""
-    from tdeed_amd.engine import pack_rowtile_weights, pack_se_bf16, pack_gconv_frags
-    from types import SimpleNamespace
-    if not ops.bneck_fits(h, w, C, R):
-        pytest.skip("geometry not supported by the fused kernel")
-    N = 5
-    bf = torch.bfloat16
-    x = rnd(101, "x", (N, h, w, C)).to(bf)
-    G = rnd(102, "G", (N * h * w, max(Fp, 8))).to(bf)
-    W1, W3 = rnd(103, "W1", (C, C), 1 / np.sqrt(C)).to(bf), rnd(104, "W3", (C, C), 1 / np.sqrt(C)).to(bf)
-    W2 = rnd(105, "W2", (C, gw, 3, 3), 0.15).to(bf)
-    aff = lambda i: (rnd(110 + i, "s", (C,)) * 0.2 + 1.0, rnd(115 + i, "h", (C,)) * 0.1)      # noqa: E731
-    (s1, h1), (s2, h2), (s3, h3) = aff(0), aff(1), aff(2)
-    sw1, sb1 = rnd(120, "sw1", (R, C), 0.1).to(bf).float(), rnd(121, "sb1", (R,), 0.1)
-    sw2, sb2 = rnd(122, "sw2", (C, R), 0.2).to(bf).float(), rnd(123, "sb2", (C,), 0.1)
-    xin = x.float().view(N * h * w, C).clone()
-    if Fp:
-        xin[:, :Fp] = G[:, :Fp].float()
-    y1 = torch.relu(xin @ W1.float().T * s1 + h1).to(bf).float()
-    y1n = y1.view(N, h, w, C).permute(0, 3, 1, 2)
-    y2 = torch.relu(F.conv2d(y1n, W2.float(), padding=1, groups=C // gw) * s2.view(1, -1, 1, 1) + h2.view(1, -1, 1, 1))
-    y2 = y2.to(bf).float()
-    gate = torch.sigmoid(torch.relu(y2.mean(dim=(2, 3)) @ sw1.T + sb1) @ sw2.T + sb2)
-    a3 = (y2 * gate[:, :, None, None]).to(bf).float().permute(0, 2, 3, 1).reshape(N * h * w, C)
-    ref = torch.relu(a3 @ W3.float().T * s3 + h3 + x.float().view(N * h * w, C))
-    dev = lambda a: a.contiguous().to(DEV)                                                       # noqa: E731
-    bw = SimpleNamespace(spec=SimpleNamespace(se_rd=R), s1=dev(s1), h1=dev(h1), s2=dev(s2), h2=dev(h2), s3=dev(s3),
-                         h3=dev(h3), w2frag=pack_gconv_frags(W2.float().numpy(), gw, DEV), se_w1t=dev(sw1.T),
-                         se_b1=dev(sb1), se_w2t=dev(sw2.T), se_b2=dev(sb2),
-                         fused=SimpleNamespace(w1f=pack_rowtile_weights(W1.float().numpy(), DEV),
-                                               w3f=pack_rowtile_weights(W3.float().numpy(), DEV),
-                                               **pack_se_bf16(sw1.numpy(), sw2.numpy(), DEV)))
-    out = ops.bneck(dev(x), bw, dev(G[:, :Fp]) if Fp else None, Fp)
-    assert rel_err(out.float().view(N * h * w, C), ref) < 3e-2
-
-
-# ----------------------------------------------------------------------------- gate-shift (golden = reference output)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("name", ["gsf_f16", "gsf_f40", "gsf_f92", "gsm_f16"])
 def test_gate_shift_golden(ops, name, dtype):

@@ -2,7 +2,7 @@
 Units and gfx950 corrections as MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KiB;
 FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 -> doubled; WRITE_SIZE is exact.
 
-    python tools/summarize_pmc.py <fetch pass dir> <write pass dir> profiles/rNN_hbm_traffic.json [--cmd "..."]
+    python tools/summarize_pmc.py <fetch pass dir> <write pass dir> profiles/rNN_hbm_traffic.json [--cmd "..."] [--steps N]
 
 Each pass directory must hold exactly ONE *counter_collection.csv (anywhere below it): a directory that collected
 several passes is ambiguous and refused, so a stale pass can never be summarised by accident.  The output records which
@@ -19,7 +19,7 @@ from collections import defaultdict
 
 FAMILY = [("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_big", "gemm_big"), ("gemm_kernel", "gemm"),
           ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"), ("gsf_", "gate_shift"), ("se_gate", "se_gate"),
-          ("stem_kernel", "stem"), ("sgp_mlp", "sgp_mlp"), ("sgp_front", "sgp_front"), ("mixer_branch", "mixer_branch"),
+          ("stem_kernel", "stem"), ("sgp_mlp", "sgp_mlp"), ("sgp_front", "sgp_front"), ("mixer_front", "mixer_front"), ("mixer_branch", "mixer_branch"),
           ("sgp_branch", "sgp_branch"), ("layernorm", "layernorm"), ("groupnorm", "groupnorm"), ("maxpool", "maxpool"),
           ("avgpool", "avgpool_posenc"), ("heads", "heads"), ("bneck", "bneck")]
 
@@ -58,10 +58,14 @@ def stamp(path):
 
 def main():
     args = [a for a in sys.argv[1:]]
-    cmd = None
+    cmd, steps = None, None
     if "--cmd" in args:
         i = args.index("--cmd")
         cmd = args[i + 1]
+        del args[i:i + 2]
+    if "--steps" in args:                        # forward passes the profiled command ran (warm-up + timed): per-step totals
+        i = args.index("--steps")
+        steps = int(args[i + 1])
         del args[i:i + 2]
     fd, wd, out = args[:3]
     ff, wf = one_csv(fd), one_csv(wd)
@@ -81,6 +85,11 @@ def main():
         L = max(d["launches"], 1)
         res[k] = dict(launches_profiled=d["launches"], hbm_bytes_per_launch=round((d["fetch_bytes"] + d["write_bytes"]) / L),
                       fetch_bytes_per_launch=round(d["fetch_bytes"] / L), write_bytes_per_launch=round(d["write_bytes"] / L))
+        if steps:
+            # a bench "launch" of a family can be several kernels (a gate-shift site is 3): per-forward totals let the bench
+            # line divide by ITS launch count
+            res[k]["kernel_launches_per_forward"] = round(d["launches"] / steps, 2)
+            res[k]["hbm_bytes_per_forward"] = round((d["fetch_bytes"] + d["write_bytes"]) / steps)
     try:
         head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
                               cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
@@ -88,7 +97,7 @@ def main():
         head = None
     json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950); "
                         "averages over every launch of the kernel family",
-                   command=cmd, git_head=head, fetch_pass=stamp(ff), write_pass=stamp(wf), kernels=res),
+                   command=cmd, forwards_profiled=steps, git_head=head, fetch_pass=stamp(ff), write_pass=stamp(wf), kernels=res),
               open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"]):
         print(f"{k:16s} launches {v['launches_profiled']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB "
