@@ -248,13 +248,19 @@ def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use
                ms_per_step_repeats=[round(w / steps * 1e3, 3) for w in walls], steps=steps, repeats=repeats, dtype=dtype,
                hip_graph=bool(use_graph), grad_buffer_mb=round(eng.params.numel * 4 / 2 ** 20, 1),
                final_loss=round(float(loss_box["l"][0]), 4),
-               parallelism=f"dp{world}" + (" (RCCL all-reduce of the flat fp32 gradient buffer, bucketed, overlapped "
-                                           "with the backward)" if world > 1 else ""),
+               parallelism=f"dp{world}" + ((" (%s all-reduce of the flat fp32 gradient buffer, bucketed, overlapped with the "
+                                            "backward)" % ("RCCL" if eng.reducer is not None and eng.reducer.backend == "rccl"
+                                                           else "torch.distributed")) if world > 1 else ""),
                roofline=dict(bound="hbm", kernel="whole step (layer-granular algorithmic bytes: 3 x forward + optimizer)",
                              algorithmic_bytes=int(tb), achieved=round(tb / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                              unit="GB/s", frac=round(tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                              flops=int(3 * ff), tflops=round(3 * ff / (ms * 1e-3) / 1e12, 1)),
                cpu_baseline=None)
+    if eng.reducer is not None:                                  # N > 1: which transport reduced the gradients, ranks RCCL saw
+        rec["reducer"] = eng.reducer.describe()
+        if use_graph:
+            rec["reducer"]["collectives"] = ("inside the captured step" if eng.last_graph.mode == "one"
+                                             else "launched between the two captured halves of the step")
     if want_cpu and rank == 0:
         rec["cpu_baseline"] = cpu_train_baseline()
     del eng, step
@@ -302,9 +308,12 @@ def main_train(a):
                                grad_buffer_mb=rec["grad_buffer_mb"], final_loss=rec["final_loss"], hip_graph=rec["hip_graph"]),
                    repeats=a.repeats, ms_per_step_repeats=rec["ms_per_step_repeats"],
                    roofline=rec["roofline"], cpu_baseline=rec["cpu_baseline"], git_head=git_head())
+        if "reducer" in rec:
+            out["config"]["reducer"] = rec["reducer"]
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        tdist.barrier()                                          # rank 0's side measurements are over: leave together
         dist.destroy_process_group()
 
 
@@ -379,7 +388,7 @@ def main():
     # buffers while the other plan computes (row f4; `value` above has the clips resident in HBM, this is the rate with the
     # PCIe leg in)
     feed = None
-    if rank == 0 and depth >= 2 and not a.no_feed:
+    if world == 1 and depth >= 2 and not a.no_feed:       # single-process side measurement (its timed regions hold barriers)
         hosts = [torch.randint(0, 256, (B, T, 3, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
         copy_st = torch.cuda.Stream()
         freed = [None] * depth            # event: plan i's forward has consumed its input buffers
@@ -526,6 +535,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        tdist.barrier()                                          # rank 0's side measurements are over: leave together
         dist.destroy_process_group()
 
 

@@ -91,6 +91,12 @@ class RcclComm:
             _lib.call("tdeed_comm_init", ctypes.byref(self.handle), raw, world, rank)
         self.world, self.rank = world, rank
 
+    def info(self):
+        """(world, rank) as the communicator itself reports them (tdeed_comm_info)."""
+        w, r = self._ct.c_int(0), self._ct.c_int(0)
+        self._lib.call("tdeed_comm_info", self.handle, self._ct.byref(w), self._ct.byref(r))
+        return int(w.value), int(r.value)
+
     def all_reduce(self, t, rs_ag=False):
         from ._lib import dtype_code, ptr, stream_ptr
         fn = "tdeed_comm_all_reduce_rs_ag" if (rs_ag and t.numel() % self.world == 0) else "tdeed_comm_all_reduce"
@@ -143,6 +149,15 @@ class GradReducer:
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def describe(self):
+        """What the bench line prints about the reduction path of a data-parallel run."""
+        d = dict(backend=self.backend, world=self.world, buckets_mb=[round((b - a) * 4 / 2 ** 20, 1) for a, b in self.buckets],
+                 capturable=self.capturable)
+        if self._comm is not None:
+            w, r = self._comm.info()
+            d["rccl_ranks"], d["rccl_rank"] = w, r
+        return d
 
     def reduce_all(self):
         for i in range(len(self.buckets)):

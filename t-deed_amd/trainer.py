@@ -226,10 +226,18 @@ class TrainEngine:
     # ------------------------------------------------------------------ the step as one HIP graph
     def build_graph(self, B, H, W, frames_dtype=torch.uint8, with_labelD=None, soft=False, fg_weight=5.0):
         """Capture weight re-packing + train-mode forward + loss + backward + gradient write-out for one batch geometry
-        into a HIP graph (the eager step is bound by ~3000 host-side launches: 49 ms wall for 17 ms of kernels at
-        200MF/B=8).  Inputs live in static buffers (`.frames/.label/.labelD/.soft/.masks` of the returned handle); the
-        AdamW launch stays outside the graph because lr and the step count change every step.  torch's graph-private
-        memory pool keeps every temporary of the step alive between replays."""
+        into a HIP graph (the eager step is host-bound: ~1700 launches).  Inputs live in static buffers
+        (`.frames/.label/.labelD/.soft/.masks` of the returned handle); the AdamW launch stays outside the graph because lr
+        and the step count change every step.  torch's graph-private memory pool keeps every temporary of the step alive
+        between replays.
+        Data parallel: with the C-ABI RCCL communicator the bucket all-reduces are part of the capture (its stream forks
+        from / joins the captured stream through events): `mode == "one"`.  With a transport that cannot be captured (the
+        torch.distributed fallback), when TDEED_DP_IN_GRAPH=0, or when capturing the collectives fails, the step is captured
+        as TWO graphs -- [re-pack, forward, loss, temporal backward, bucket 0 write-out] and [trunk backward, bucket 1
+        write-out] -- and bucket 0's all-reduce is launched between the two replays, so it still travels while the trunk
+        backward runs: `mode == "two"`."""
+        import os
+        import sys
         from types import SimpleNamespace
         dev, T = self.device, self.T
         K1 = self.cfg["num_classes"] + 1
@@ -244,33 +252,91 @@ class TrainEngine:
         h.labelD = torch.zeros((B, T), dtype=torch.float32, device=dev) if with_labelD else None
         h.masks = [torch.ones((B, T, C), dtype=self.dt, device=dev) for _ in range(2 if radi > 0 else 1)]
         red = self.reducer
-        h.reduce_in_graph = red is not None and red.capturable          # RCCL on its own stream joins the capture
-        run = lambda: self.accumulate(h.frames, h.label, h.labelD, soft=h.soft, drop_masks=h.masks,      # noqa: E731
-                                      reduce=h.reduce_in_graph)
-        # eager warm-up on a side stream (lazy kernel attributes / module loads must happen outside the capture); the
-        # BatchNorm buffers it touches are restored afterwards
+        want_in_graph = red is not None and red.capturable and os.environ.get("TDEED_DP_IN_GRAPH", "1") == "1"
         keep = {k: v.clone() for k, v in self.state.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self.repack()
-            run()
-            if h.reduce_in_graph:
+
+        def restore():
+            for k, v in keep.items():
+                self.state[k].copy_(v)
+
+        def part_a():
+            head_out, ctx = self.forward_train(h.frames, None, False, h.masks)
+            loss, dhead = self.temporal.loss_fwd_bwd(
+                head_out, ctx.B, ctx.T, None if h.label is None else h.label.reshape(-1),
+                labelD=None if h.labelD is None else h.labelD.reshape(-1),
+                soft=None if h.soft is None else h.soft.reshape(-1, h.soft.shape[-1]), fg_weight=fg_weight)
+            g_t = {}
+            d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
+            self.write_grads(g_t, 1.0, True, partial=True, role=0)
+            return loss, ctx, d_feat, set(g_t)
+
+        def part_b(ctx, d_feat, done):
+            g_b = self.backward_trunk(ctx, d_feat)
+            missing = set(self.params.index) - done - set(g_b)
+            if missing:
+                raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
+            self.write_grads(g_b, 1.0, True, partial=True, role=1)
+
+        def capture_one(in_graph):
+            run = lambda: self.accumulate(h.frames, h.label, h.labelD, soft=h.soft, drop_masks=h.masks,      # noqa: E731
+                                          reduce=in_graph, fg_weight=fg_weight)
+            # eager warm-up on a side stream (lazy kernel attributes / module loads must happen outside the capture); the
+            # BatchNorm buffers it touches are restored afterwards
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.repack()
+                run()
+                if in_graph:
+                    red.join()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            restore()
+            g = torch.cuda.CUDAGraph()
+            # thread-local capture: other threads (the RCCL watchdog of a data-parallel job) may keep calling the runtime
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                self.repack()
+                h.loss = run()
+                if in_graph:
+                    red.join()
+            h.graph, h.graph_b, h.mode, h.reduce_in_graph = g, None, "one", in_graph
+
+        def capture_two():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.repack()
+                _, ctx, d_feat, done = part_a()
+                red.reduce_bucket(0)
+                part_b(ctx, d_feat, done)
+                red.reduce_bucket(1)
                 red.join()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for k, v in keep.items():
-            self.state[k].copy_(v)
-        h.graph = torch.cuda.CUDAGraph()
-        # thread-local capture: other threads (the RCCL watchdog of a data-parallel job) may keep calling the runtime
-        with torch.cuda.graph(h.graph, stream=side, capture_error_mode="thread_local"):
-            self.repack()
-            h.loss = run()
-            if h.reduce_in_graph:
-                red.join()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            restore()
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, stream=side, capture_error_mode="thread_local"):
+                self.repack()
+                h.loss, ctx, d_feat, done = part_a()
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode="thread_local"):
+                part_b(ctx, d_feat, done)
+            h.keep_ctx = (ctx, d_feat)                           # activations of the first half that the second half reads
+            h.graph, h.graph_b, h.mode, h.reduce_in_graph = ga, gb, "two", False
+
+        if red is None:
+            capture_one(False)
+        elif want_in_graph:
+            try:
+                capture_one(True)
+            except Exception as e:                               # noqa: BLE001  (a runtime that cannot capture the collectives)
+                print(f"[tdeed_amd] capturing the RCCL collectives failed ({type(e).__name__}: {e}); "
+                      f"falling back to two graphs with the all-reduces launched between them", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                capture_two()
+        else:
+            capture_two()
         h.keep = self._grad_tabs                                 # the gradient write-out tables the graph's copies read
-        for k, v in keep.items():                                # capture does not execute, but stay explicit
-            self.state[k].copy_(v)
+        restore()                                                # capture does not execute, but stay explicit
         torch.cuda.synchronize()
         return h
 
@@ -288,13 +354,19 @@ class TrainEngine:
                 dst.copy_(src, non_blocking=True)
         h.graph.replay()
         gs = 1.0
+        if h.mode == "two":
+            # bucket 0 (temporal stack + heads) is complete: its all-reduce travels while the trunk backward replays
+            if all_reduce is None:
+                self.reducer.reduce_bucket(0)
+            h.graph_b.replay()
+            if all_reduce is None:
+                self.reducer.reduce_bucket(1)
+                self.reducer.join()
+                gs = self.reducer.scale
+        elif all_reduce is None and self.reducer is not None:
+            gs = self.reducer.scale                             # reduced and joined inside the graph
         if all_reduce is not None:
             all_reduce(self.params.grad)
-        elif self.reducer is not None:
-            if not h.reduce_in_graph:                           # torch.distributed backends cannot be captured
-                self.reducer.reduce_all()
-                self.reducer.join()
-            gs = self.reducer.scale
         if lr is not None:
             self.opt.lr = lr
         self.opt.step(lr_factor=lr_factor, grad_scale=gs)       # the next replay starts with repack(): no refresh needed here
@@ -309,6 +381,7 @@ class TrainEngine:
         if not use_graph:
             return lambda: self.step(frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
         hnd = self.build_graph(B, H, W)
+        self.last_graph = hnd                                    # (tests / the bench line read .mode)
         return lambda: self.step_graph(hnd, frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
 
     def lr_factor(self, warmup_steps, cosine_steps):

@@ -37,7 +37,8 @@ def tol(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(800, 1472, 368), (200, 368, 1472), (37, 24, 40), (1600, 368, 2208), (5000, 8, 368)])
+@pytest.mark.parametrize("M,N,K", [(800, 1472, 368), (200, 368, 1472), (37, 24, 40), (1600, 368, 2208), (5000, 8, 368),
+                                   (4100, 24, 40), (9001, 152, 56), (20000, 64, 32)])     # M >= 4096: the transposing-read kernel
 def test_wgrad(bops, dtype, M, N, K):
     dY, X = rnd(201, "dy", (M, N)).to(dtype), rnd(202, "x", (M, K)).to(dtype)
     dW, db = bops.wgrad(dY.to(DEV), X.to(DEV))

@@ -65,7 +65,7 @@ def _batch(rank):
     return frames, t(lab).long(), t(labD).float()
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, graph=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -78,7 +78,15 @@ def _dp_worker(rank, world, port, q):
     red = eng.set_reducer("auto")
     assert red is not None and red.backend == "torch" and red.world == world and len(red.buckets) == 2
     frames, lab, labD = _batch(rank)
-    eng.step(frames.to("cuda:0"), lab.to("cuda:0"), labD.to("cuda:0"))
+    if graph:
+        # the captured form: gloo cannot be captured, so the step is two graphs with bucket 0's all-reduce launched between
+        # them (the same structure a capture failure of the RCCL collectives falls back to)
+        step = eng.make_step(frames.shape[0], 64, 64, frames.to("cuda:0"), lab.to("cuda:0"), labD.to("cuda:0"), None,
+                             use_graph=True, world=world)
+        assert eng.last_graph.mode == "two" and eng.last_graph.graph_b is not None
+        step()
+    else:
+        eng.step(frames.to("cuda:0"), lab.to("cuda:0"), labD.to("cuda:0"))
     torch.cuda.synchronize()
     keys = [k for k in eng.params.index]
     q.put((rank, {k: eng.state[k].detach().cpu().numpy() for k in keys},
@@ -87,12 +95,13 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_dp_step_equals_adamw_on_the_mean_of_per_rank_gradients():
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_dp_step_equals_adamw_on_the_mean_of_per_rank_gradients(graph):
     from tdeed_amd.trainer import TrainEngine
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
@@ -118,3 +127,31 @@ def test_two_rank_dp_step_equals_adamw_on_the_mean_of_per_rank_gradients():
         want = eng.state[k].detach().cpu().numpy()
         for r in (0, 1):
             assert np.abs(res[r][1][k] - want).max() <= 2e-7 + 1e-6 * np.abs(want).max(), (k, r)
+
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_runs_as_two_ranks_on_one_gpu(mode):
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with
+    two ranks sharing this box's GPU over gloo: every rank must reach every collective (barriers, max over ranks, gradient
+    buckets) and rank 0 must print one JSON line for the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TDEED_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--no-cpu-baseline"]
+    if mode == "train":
+        cmd += ["--mode", "train", "--workload", "rny002_b8"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["clips_per_gpu"] == 8
+    if mode == "train":
+        red = rec["config"]["reducer"]
+        assert red["world"] == 2 and len(red["buckets_mb"]) == 2 and "between the two captured halves" in red["collectives"]
