@@ -230,12 +230,12 @@ class TrainEngine:
         (`.frames/.label/.labelD/.soft/.masks` of the returned handle); the AdamW launch stays outside the graph because lr
         and the step count change every step.  torch's graph-private memory pool keeps every temporary of the step alive
         between replays.
-        Data parallel: with the C-ABI RCCL communicator the bucket all-reduces are part of the capture (its stream forks
-        from / joins the captured stream through events): `mode == "one"`.  With a transport that cannot be captured (the
-        torch.distributed fallback), when TDEED_DP_IN_GRAPH=0, or when capturing the collectives fails, the step is captured
-        as TWO graphs -- [re-pack, forward, loss, temporal backward, bucket 0 write-out] and [trunk backward, bucket 1
-        write-out] -- and bucket 0's all-reduce is launched between the two replays, so it still travels while the trunk
-        backward runs: `mode == "two"`."""
+        Data parallel (default, `mode == "two"`): the step is captured as TWO graphs -- [re-pack, forward, loss, temporal
+        backward, bucket 0 write-out] and [trunk backward, bucket 1 write-out] -- and bucket 0's all-reduce is launched
+        between the two replays on the communicator's own stream, so it travels while the trunk backward runs.  With
+        TDEED_DP_IN_GRAPH=1 and the C-ABI RCCL communicator the all-reduces are captured into ONE graph instead (its stream
+        forks from / joins the captured stream through events, `mode == "one"`); if that capture fails the two-graph form is
+        built."""
         import os
         import sys
         from types import SimpleNamespace
@@ -252,7 +252,10 @@ class TrainEngine:
         h.labelD = torch.zeros((B, T), dtype=torch.float32, device=dev) if with_labelD else None
         h.masks = [torch.ones((B, T, C), dtype=self.dt, device=dev) for _ in range(2 if radi > 0 else 1)]
         red = self.reducer
-        want_in_graph = red is not None and red.capturable and os.environ.get("TDEED_DP_IN_GRAPH", "1") == "1"
+        # default: two graphs with the collectives launched eagerly between them -- the same overlap, and nothing depends
+        # on the collective library's behaviour under stream capture (which no single-GPU box can exercise);
+        # TDEED_DP_IN_GRAPH=1 captures the RCCL calls into one graph instead
+        want_in_graph = red is not None and red.capturable and os.environ.get("TDEED_DP_IN_GRAPH", "0") == "1"
         keep = {k: v.clone() for k, v in self.state.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
 
         def restore():
