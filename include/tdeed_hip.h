@@ -104,10 +104,15 @@ int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0
  *   pooled_sq  optional (bf16 MFMA path), same shape: partial sums of y^2 -- with pooled the BatchNorm batch statistics
  *          of the raw conv output (tdeed_bn_finalize(pooled, pooled_sq, C, N*parts, N*Ho*Wo, C, ...)). */
 int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype);
+int tdeed_gconv3x3_mfma_fits(int Hi, int Wi, int C, int stride);   /* 1: the bf16 MFMA kernel (wfrag, in_a) serves it */
+/*   in_a, in_b  optional fp32 [C] (bf16 MFMA path, training): x is the RAW output of the conv in front and
+ *          relu(in_a[c] * x + in_b[c]) -- the BatchNorm(batch statistics) + ReLU between the two convs -- is applied while
+ *          the band is staged, so the post-BN map is never written; bit-identical to running on the materialised map. */
 int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                        const float* w, const void* wfrag, const float* scale, const float* shift,
-                       void* y, float* pooled, float* pooled_sq, int relu /* 0: y = conv*scale+shift (training: raw map
-                       for the batch statistics) */, int dtype, void* stream);
+                       void* y, float* pooled, float* pooled_sq, const float* in_a, const float* in_b,
+                       int relu /* 0: y = conv*scale+shift (training: raw map for the batch statistics) */, int dtype,
+                       void* stream);
 
 /* Split-K form of the contraction for the short sequences of the SGP encoder-decoder (a few hundred rows, K up to
  * 6C; bf16): C = act((A . W^T) * scale + shift + R).  Two launches: S = tdeed_gemm_splitk_splits(K) partial products
@@ -342,23 +347,28 @@ int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b,
 int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, int relu, long M, int C, const float* mean,
                        const float* rstd, const float* w, const float* fa, const float* fb, float* part, float* sums,
                        void* dz, void* d_res, float* dw, float* db, int dtype, void* stream);
-/* p[n][c] = mean_px x (x2 NULL: the SE squeeze) or sum_px x*x2 (gradient of the SE gate) */
-int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, float* p, int dtype, void* stream);
+/* p[n][c] = mean_px x (x2 NULL: the SE squeeze) or sum_px x*x2 (gradient of the SE gate).  aff_on = 1 / 2: x / x2 is a
+ * raw conv output and relu(in_a[c] * . + in_b[c]) (BatchNorm + ReLU) is applied on load; 0: none (in_a, in_b may be NULL) */
+int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, const float* in_a, const float* in_b, int aff_on,
+                    float* p, int dtype, void* stream);
 /* SE excitation keeping the hidden units: w1t [C][R], w2t [R][C] */
 int tdeed_se_train_fwd(const float* p, int N, int C, int R, const float* w1t, const float* b1, const float* w2t,
                        const float* b2, float* hid, float* gate, void* stream);
 /* its backward: w1 [R][C], w2 [C][R]; d_pre2 [N][C], d_hid [N][R] feed tdeed_wgrad, d_p [N][C] is d(squeeze) */
 int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid, int N, int C, int R, const float* w1,
                        const float* w2, float* d_pre2, float* d_hid, float* d_p, void* stream);
-/* y[n][px][c] = x[n][px][c] * s[n][c] + add[n][c] * add_scale (add may be NULL) */
-int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C, void* y,
-                     int dtype, void* stream);
+/* y[n][px][c] = x'[n][px][c] * s[n][c] + add[n][c] * add_scale (add may be NULL); x' = x, or with in_a / in_b given
+ * relu(in_a[c] * x + in_b[c]) (x a raw conv output: BatchNorm + ReLU applied on load) */
+int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C,
+                     const float* in_a, const float* in_b, void* y, int dtype, void* stream);
 /* grouped 3x3 backward: dx (may be NULL: a stride-1 input gradient is itself a grouped 3x3 conv of dy with the flipped,
  * transposed weights and can run on tdeed_gconv3x3_fwd's MFMA kernel) and dw (fp32, the forward's packed [G][9][gw][gw]).
  * part fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw] */
 int tdeed_gconv_wgrad_slabs(long npix_out);
+/* in_a, in_b (optional, bf16): x is the raw output of the conv in front, relu(in_a[c] * x + in_b[c]) is applied on load
+ * (as in tdeed_gconv3x3_fwd) */
 int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride, const float* w,
-                       void* dx, float* part, float* dw, int dtype, void* stream);
+                       const float* in_a, const float* in_b, void* dx, float* part, float* dw, int dtype, void* stream);
 /* mode 0: out[(f,yo,xo)] = in[(f,2yo,2xo)] (operand of the stride-2 shortcut conv); mode 1: out[(f,2yo,2xo)] += in[(f,yo,xo)] */
 int tdeed_stride2_rows(const void* in, void* out, int F, int hi, int wi, int C, int mode, int dtype, void* stream);
 

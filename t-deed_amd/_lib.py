@@ -44,7 +44,8 @@ _SIGS = {
     "tdeed_gemm_ws_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, c_long,
                            c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gconv3x3_parts": ([c_int, c_int, c_int, c_int, c_int], c_int),
-    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_gconv3x3_mfma_fits": ([c_int, c_int, c_int, c_int], c_int),
+    "tdeed_gconv3x3_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_gemm_splitk_splits": ([c_int], c_int),
     "tdeed_gemm_splitk_fwd": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P, P, c_long, c_int, P, c_long, P, P], c_int),
     "tdeed_se_gate_mfma_fits": ([c_int, c_int], c_int),
@@ -55,12 +56,12 @@ _SIGS = {
     "tdeed_bn_train_bwd": ([P, P, P, c_int, c_long, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_fold_rows": ([P, c_long, c_int, c_int, c_int, P, c_long, P], c_int),
     "tdeed_bn_finalize": ([P, P, c_long, c_int, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P], c_int),
-    "tdeed_pool_rows": ([P, P, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_pool_rows": ([P, P, c_int, c_int, c_int, P, P, c_int, P, c_int, P], c_int),
     "tdeed_se_train_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P, P], c_int),
     "tdeed_se_train_bwd": ([P, P, P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
-    "tdeed_scale_rows": ([P, P, P, c_float, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_scale_rows": ([P, P, P, c_float, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_gconv_wgrad_slabs": ([c_long], c_int),
-    "tdeed_gconv3x3_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
+    "tdeed_gconv3x3_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_stride2_rows": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_loss2": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, c_float, P, P, P], c_int),
     "tdeed_reduce_strided": ([P, c_int, c_long, c_long, P, P], c_int),

@@ -226,8 +226,12 @@ static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
   return g;
 }
 
-template <int STRIDE>
+// AFF (training): the input is a RAW conv output z and the BatchNorm affine + ReLU of the layer in front,
+// relu(in_a[c] * z + in_b[c]), is applied while the band is staged (the halo stays zero): the post-BN map is never
+// materialised.  Rounded to bf16 like the materialised map would be, so the result is bit-identical.
+template <int STRIDE, bool AFF>
 __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ x, int Hi, int Wi, int C,
+                                                            const float* __restrict__ in_a, const float* __restrict__ in_b,
                                                             const bf16x8* __restrict__ wfrag,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
@@ -255,6 +259,17 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   // batches of 8 independent 16-B loads per thread before the LDS stores (memory-level parallelism)
   const int total = nrow_used * WP * cpp;
   const IDiv dcpp(cpp), dwp(WP);
+  // cpp (4 or 8) divides 256: a thread stages the same 8-channel chunk in every iteration, its affine lives in registers
+  float ia[8], ib[8];
+  if constexpr (AFF) {
+    const int jt = threadIdx.x % cpp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = min(cs0 + jt * 8 + e, C - 1);
+      ia[e] = in_a[c];
+      ib[e] = in_b[c];
+    }
+  }
   for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
     u32x4 v[8];
     bool ok[8];
@@ -275,6 +290,13 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
       if (i < total) {
         int j, pix;
         dcpp.divmod(i, pix, j);
+        if constexpr (AFF) {
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[b8]);
+          bf16x8 o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)fmaxf(fmaf((float)t8[e], ia[e], ib[e]), 0.f);
+          v[b8] = *reinterpret_cast<const u32x4*>(&o8);
+        }
         *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = ok[b8] ? v[b8] : (u32x4){0u, 0u, 0u, 0u};
       }
     }
@@ -371,6 +393,11 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   }
 }
 
+// 1 if the bf16 MFMA kernel serves this geometry (a band of input rows fits LDS), i.e. if wfrag / in_a are usable
+extern "C" int tdeed_gconv3x3_mfma_fits(int Hi, int Wi, int C, int stride) {
+  return gc_geom(Hi, Wi, C, stride).band > 0 ? 1 : 0;
+}
+
 extern "C" int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype) {
   if (dtype != TDEED_BF16) return 1;
   GcGeom g = gc_geom(Hi, Wi, C, stride);
@@ -379,8 +406,11 @@ extern "C" int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype
 
 extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                                   const float* w, const void* wfrag, const float* scale, const float* shift,
-                                  void* y, float* pooled, float* pooled_sq, int relu, int dtype, void* stream) {
+                                  void* y, float* pooled, float* pooled_sq, const float* in_a, const float* in_b, int relu,
+                                  int dtype, void* stream) {
   TD_CHECK(x && scale && shift && y && pooled, "gconv3x3: null pointer");
+  TD_CHECK(!in_a == !in_b, "gconv3x3: in_a and in_b come together");
+  TD_CHECK(!in_a || (dtype == TDEED_BF16 && wfrag), "gconv3x3: the on-load input affine exists in the bf16 MFMA kernel only");
   TD_CHECK(!pooled_sq || (dtype == TDEED_BF16 && wfrag), "gconv3x3: sums of squares come from the bf16 MFMA kernel only");
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "gconv3x3: group width %d / C %d unsupported", gw, C);
   TD_CHECK(stride == 1 || stride == 2, "gconv3x3: stride %d", stride);
@@ -395,20 +425,20 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
     GcGeom g = gc_geom(Hi, Wi, C, stride);
     if (!wfrag || g.band <= 0) {     // no MFMA fragments given (or a row does not fit LDS): VALU kernel
       TD_CHECK(w, "gconv3x3: no weights");
+      TD_CHECK(!in_a, "gconv3x3: a row of %d px x %d ch does not fit LDS; no on-load input affine on the VALU path", Wi, C);
       return gw == 8 ? launch_gconv<bf16_t, 8>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, relu, st)
                      : launch_gconv<bf16_t, 16>(x, N, Hi, Wi, C, stride, w, scale, shift, y, pooled, relu, st);
     }
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     dim3 grid((unsigned)((long)g.nbands * g.nslabs * N));
     size_t smem = (size_t)g.rows_in * (Wi + 2) * g.PS;
-    if (stride == 1)
-      hipLaunchKernelGGL(gconv3x3_mfma_kernel<1>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
-                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, pooled_sq, Ho, Wo, g.band, g.nbands, g.CSP,
-                         g.PS, g.rows_in, relu);
-    else
-      hipLaunchKernelGGL(gconv3x3_mfma_kernel<2>, grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C,
-                         (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, pooled_sq, Ho, Wo, g.band, g.nbands, g.CSP,
-                         g.PS, g.rows_in, relu);
+#define TD_GCF(Sv, Av)                                                                                                   \
+  hipLaunchKernelGGL((gconv3x3_mfma_kernel<Sv, Av>), grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C, in_a, in_b,      \
+                     (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, pooled_sq, Ho, Wo, g.band, g.nbands, g.CSP, g.PS, \
+                     g.rows_in, relu)
+    if (stride == 1) { if (in_a) TD_GCF(1, true); else TD_GCF(1, false); }
+    else { if (in_a) TD_GCF(2, true); else TD_GCF(2, false); }
+#undef TD_GCF
     TD_LAUNCH_CHECK("gconv3x3_mfma");
     return TDEED_OK;
   }

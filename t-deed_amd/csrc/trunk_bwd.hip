@@ -416,9 +416,12 @@ extern "C" int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, 
 
 // =========================================================================== SE (training): squeeze, excitation, scale
 // mean over the hw pixels of a frame: x [N][hw][C] -> p [N][C] fp32 (lanes = (pixel slice, channel chunk), batched loads)
+// aff_on = 1 / 2: x / x2 is a raw conv output and relu(in_a[c] * . + in_b[c]) is applied on load (the post-BN map is not
+// materialised in training)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_mean_kernel(const T* __restrict__ x, const T* __restrict__ x2, int hw, int C,
-                                                        float* __restrict__ p) {
+                                                        const float* __restrict__ in_a, const float* __restrict__ in_b,
+                                                        int aff_on, float* __restrict__ p) {
   constexpr int EPC = Chunk<T>::N;
   extern __shared__ float red[];       // [S][C]
   const long f = blockIdx.x;
@@ -426,9 +429,15 @@ __global__ __launch_bounds__(256) void pool_mean_kernel(const T* __restrict__ x,
   const int S = 256 / nch > 0 ? 256 / nch : 1;
   for (int ch = threadIdx.x % nch, s = threadIdx.x / nch; s < S && ch < nch; ch += 256) {
     const int c0 = ch * EPC;
-    float a[EPC];
+    float a[EPC], ia[EPC], ib[EPC];
+    const float* pa = aff_on ? in_a : p;                         // unconditional loads (valid dummy when unused)
+    const float* pb = aff_on ? in_b : p;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+    for (int e = 0; e < EPC; ++e) {
+      a[e] = 0.f;
+      ia[e] = aff_on ? pa[c0 + e] : 1.f;
+      ib[e] = aff_on ? pb[c0 + e] : 0.f;
+    }
     const long base = f * hw * C + c0;
     for (int p0 = s; p0 < hw; p0 += S * 4) {
       float v[4][EPC], u[4][EPC];
@@ -442,7 +451,13 @@ __global__ __launch_bounds__(256) void pool_mean_kernel(const T* __restrict__ x,
       for (int b = 0; b < 4; ++b)
         if (p0 + b * S < hw) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) a[e] += x2 ? v[b][e] * u[b][e] : v[b][e];
+          for (int e = 0; e < EPC; ++e) {
+            float xv = v[b][e], uv = x2 ? u[b][e] : 1.f;
+            // rounded to T like the materialised map would be: bit-identical results with and without the map
+            if (aff_on == 1) xv = (float)(T)fmaxf(fmaf(xv, ia[e], ib[e]), 0.f);
+            if (aff_on == 2) uv = (float)(T)fmaxf(fmaf(uv, ia[e], ib[e]), 0.f);
+            a[e] += x2 ? xv * uv : xv;
+          }
         }
     }
 #pragma unroll
@@ -458,17 +473,19 @@ __global__ __launch_bounds__(256) void pool_mean_kernel(const T* __restrict__ x,
 }
 
 // p [N][C] = mean_px x  (x2 == NULL)   or   sum_px x * x2  (the gradient of the SE gate)
-extern "C" int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, float* p, int dtype, void* stream) {
+extern "C" int tdeed_pool_rows(const void* x, const void* x2, int N, int hw, int C, const float* in_a, const float* in_b,
+                               int aff_on, float* p, int dtype, void* stream) {
   TD_CHECK(x && p && N > 0 && hw > 0 && C > 0 && C % 8 == 0 && C <= 2048, "pool_rows: bad arguments");
+  TD_CHECK(aff_on == 0 || ((aff_on == 1 || (aff_on == 2 && x2)) && in_a && in_b), "pool_rows: bad on-load affine arguments");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32) {
     const int nch = C / 4, S = 256 / nch > 0 ? 256 / nch : 1;
     hipLaunchKernelGGL(pool_mean_kernel<float>, dim3(N), dim3(256), (size_t)S * C * sizeof(float), st, (const float*)x,
-                       (const float*)x2, hw, C, p);
+                       (const float*)x2, hw, C, in_a, in_b, aff_on, p);
   } else if (dtype == TDEED_BF16) {
     const int nch = C / 8, S = 256 / nch > 0 ? 256 / nch : 1;
     hipLaunchKernelGGL(pool_mean_kernel<bf16_t>, dim3(N), dim3(256), (size_t)S * C * sizeof(float), st, (const bf16_t*)x,
-                       (const bf16_t*)x2, hw, C, p);
+                       (const bf16_t*)x2, hw, C, in_a, in_b, aff_on, p);
   } else { tdeed_set_error("pool_rows: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("pool_rows");
   return TDEED_OK;
@@ -623,6 +640,7 @@ extern "C" int tdeed_se_train_bwd(const float* d_gate, const float* gate, const 
 template <typename T>
 __global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x, const float* __restrict__ s,
                                                          const float* __restrict__ add, float add_scale, int hw,
+                                                         const float* __restrict__ in_a, const float* __restrict__ in_b,
                                                          T* __restrict__ y, int nch, int rpw) {
   constexpr int EPC = Chunk<T>::N;
   const RowMap mp(nch);
@@ -631,11 +649,17 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x
   const long n = blockIdx.y;
   const float* pad = add ? add : s;                             // read unconditionally (scaled by 0 when there is no add)
   const float asc = add ? add_scale : 0.f;
-  float sv[EPC], ad[EPC];
+  // in_a given: x is a raw conv output, relu(in_a[c] * x + in_b[c]) (BatchNorm + ReLU) is applied on load
+  const bool aff = in_a != nullptr;
+  const float* pia = aff ? in_a : s;
+  const float* pib = aff ? in_b : s;
+  float sv[EPC], ad[EPC], ia[EPC], ib[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     sv[e] = s[n * C + c0 + e];
     ad[e] = pad[n * C + c0 + e] * asc;
+    ia[e] = pia[c0 + e];
+    ib[e] = pib[c0 + e];
   }
   const int m0 = blockIdx.x * rpw, m1 = min(hw, m0 + rpw);
   const T* xf = x + n * hw * C + c0;
@@ -649,7 +673,10 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x
       const int r = r0 + u * mp.RL;
       if (r < m1) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[u][e] = fmaf(v[u][e], sv[e], ad[e]);
+        for (int e = 0; e < EPC; ++e) {
+          const float xv = aff ? (float)(T)fmaxf(fmaf(v[u][e], ia[e], ib[e]), 0.f) : v[u][e];     // rounded like the map
+          v[u][e] = fmaf(xv, sv[e], ad[e]);
+        }
         Chunk<T>::store(yf + (long)r * C, v[u]);
       }
     }
@@ -657,8 +684,9 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x
 }
 
 extern "C" int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C,
-                                void* y, int dtype, void* stream) {
+                                const float* in_a, const float* in_b, void* y, int dtype, void* stream) {
   TD_CHECK(x && s && y && N > 0 && hw > 0 && C > 0 && C % 8 == 0, "scale_rows: bad arguments");
+  TD_CHECK(!in_a == !in_b, "scale_rows: in_a and in_b come together");
   hipStream_t st = (hipStream_t)stream;
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "scale_rows: bad dtype %d", dtype);
   const int nch = C / (dtype == TDEED_F32 ? 4 : 8);
@@ -666,10 +694,10 @@ extern "C" int tdeed_scale_rows(const void* x, const float* s, const float* add,
   int rpw = rows_per_wg(nch);
   const dim3 grid((unsigned)cdiv(hw, rpw), (unsigned)N);
   if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(scale_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, s, add, add_scale, hw, (float*)y,
-                       nch, rpw);
+    hipLaunchKernelGGL(scale_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, s, add, add_scale, hw, in_a, in_b,
+                       (float*)y, nch, rpw);
   else
-    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, s, add, add_scale, hw,
+    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, s, add, add_scale, hw, in_a, in_b,
                        (bf16_t*)y, nch, rpw);
   TD_LAUNCH_CHECK("scale_rows");
   return TDEED_OK;
@@ -1104,15 +1132,25 @@ __global__ __launch_bounds__(256) void gconv_wgrad_mfma_kernel(const bf16_t* __r
 // lanes supply -- 4 consecutive output pixels, wherever the tap and the stride put their input pixels in the patch.
 // workgroup = (run of tiles, chunk of 64 channels); wave = one 16-channel unit with all 9 tap accumulators.
 constexpr int GWT_RS = 80;                                      // LDS row stride (elements): 64 channels + 32 bytes
-template <int S, int GW>
+// AFF: x is the RAW output z of the conv in front and relu(in_a[c] * z + in_b[c]) -- the BatchNorm + ReLU between the two
+// convs -- is applied while the patch is staged (zero padding stays zero): the post-BN map is never materialised.
+template <int S, int GW, bool AFF>
 __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             const float* __restrict__ in_a, const float* __restrict__ in_b,
                                                              int N, int Hi, int Wi, int Ho, int Wo, int C, int tiles_per_wg,
                                                              float* __restrict__ part) {
   constexpr int PW = 8 * S + (S == 1 ? 2 : 1);                  // patch width / height in input pixels: 10 or 17
   constexpr int NPIX = PW * PW;
   __shared__ __attribute__((aligned(16))) bf16_t patch[NPIX * GWT_RS];
   __shared__ __attribute__((aligned(16))) bf16_t dyt[64 * GWT_RS];
+  __shared__ __attribute__((aligned(16))) float saff[2][64];
   const int c0 = blockIdx.y * 64, CH = min(64, C - c0), nck = CH >> 3;
+  if constexpr (AFF) {
+    if (threadIdx.x < 128) {
+      const int c = c0 + (threadIdx.x & 63);
+      saff[threadIdx.x >> 6][threadIdx.x & 63] = c < C ? (threadIdx.x < 64 ? in_a : in_b)[c] : 0.f;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool active = c0 + wv * 16 < C;
   const int tyN = (Ho + 7) >> 3, txN = (Wo + 7) >> 3;
@@ -1138,14 +1176,16 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
     for (int i0 = tid; i0 < n_all; i0 += 256 * 4) {
       u32x4 v[4];
       bool ok[4];
-      int dst[4];
+      int dst[4], cko[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int i = min(i0 + b * 256, n_all - 1);
         int px, ck;
         const bf16_t* src;
+        cko[b] = -1;
         if (i < n_patch) {
           dck.divmod(i, px, ck);
+          cko[b] = ck * 8;
           int py, pxx;
           dpw.divmod(px, py, pxx);
           const int iy = oy0 * S - 1 + py, ix = ox0 * S - 1 + pxx;
@@ -1166,6 +1206,16 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
       for (int b = 0; b < 4; ++b) {
         if (i0 + b * 256 < n_all) {
           bf16_t* d = dst[b] < NPIX * GWT_RS ? patch + dst[b] : dyt + (dst[b] - NPIX * GWT_RS);
+          if constexpr (AFF) {
+            if (cko[b] >= 0) {                                  // an input piece: BatchNorm affine + ReLU of the layer in front
+              const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[b]);
+              bf16x8 o8;
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                o8[e] = (bf16_t)fmaxf(fmaf((float)t8[e], saff[0][cko[b] + e], saff[1][cko[b] + e]), 0.f);
+              v[b] = *reinterpret_cast<const u32x4*>(&o8);
+            }
+          }
           *reinterpret_cast<u32x4*>(d) = ok[b] ? v[b] : (u32x4){0u, 0u, 0u, 0u};
         }
       }
@@ -1212,8 +1262,10 @@ extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
 // dx [N][Hi][Wi][C] (activation dtype), dw fp32 [G][9][gw][gw] (the forward's packed layout);
 // part: fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw]
 extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride,
-                                  const float* w, void* dx, float* part, float* dw, int dtype, void* stream) {
+                                  const float* w, const float* in_a, const float* in_b, void* dx, float* part, float* dw,
+                                  int dtype, void* stream) {
   TD_CHECK(x && dy && w && part && dw, "gconv3x3_bwd: null pointer");      // dx may be NULL: weight gradient only
+  TD_CHECK(!in_a == !in_b, "gconv3x3_bwd: in_a and in_b come together");
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0 && (stride == 1 || stride == 2) && N > 0 && Hi > 0 && Wi > 0,
            "gconv3x3_bwd: bad geometry");
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gconv3x3_bwd: bad dtype %d", dtype);
@@ -1279,11 +1331,18 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
       nrows = (int)((tiles + tpw - 1) / tpw);
       const dim3 gt((unsigned)nrows, (unsigned)cdiv(C, 64));
 #define TD_GWT(Sv, GWv)                                                                                                 \
-  hipLaunchKernelGGL((gconv_wgrad_tr_kernel<Sv, GWv>), gt, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, N, Hi, Wi, \
-                     Ho, Wo, C, tpw, part)
+  do {                                                                                                                  \
+    if (in_a)                                                                                                           \
+      hipLaunchKernelGGL((gconv_wgrad_tr_kernel<Sv, GWv, true>), gt, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, \
+                         in_a, in_b, N, Hi, Wi, Ho, Wo, C, tpw, part);                                                  \
+    else                                                                                                                \
+      hipLaunchKernelGGL((gconv_wgrad_tr_kernel<Sv, GWv, false>), gt, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, \
+                         in_a, in_b, N, Hi, Wi, Ho, Wo, C, tpw, part);                                                  \
+  } while (0)
       if (stride == 1) { if (gw == 8) TD_GWT(1, 8); else TD_GWT(1, 16); }
       else { if (gw == 8) TD_GWT(2, 8); else TD_GWT(2, 16); }
 #undef TD_GWT
+      in_a = nullptr;                                           // consumed
     } else if (gw == 8) {
       hipLaunchKernelGGL(gconv_wgrad_mfma_kernel<8>, gwm, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, Hi, Wi, Ho, Wo,
                          C, stride, npix_out, pps, part);
@@ -1293,6 +1352,7 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
     }
   }
   TD_LAUNCH_CHECK("gconv3x3_bwd");
+  TD_CHECK(!in_a, "gconv3x3_bwd: the on-load input affine needs the bf16 transposing-read weight-gradient kernel");
   return tdeed_reduce_partials(part, nrows, (long)G * 9 * gw * gw, dw, 0, stream);
 }
 

@@ -182,13 +182,19 @@ def se_gate_bf16(pooled, inv_cnt, w1p, b1, w2p, b2, R, out=None):
     return out
 
 
+def gconv3x3_mfma_fits(Hi, Wi, C, stride):
+    return _lib.load().tdeed_gconv3x3_mfma_fits(Hi, Wi, C, stride) != 0
+
+
 def gconv3x3_parts(Hi, Wi, C, stride, act_dtype):
     return _lib.load().tdeed_gconv3x3_parts(Hi, Wi, C, stride, dtype_code(act_dtype))
 
 
-def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None, relu=True, pooled_sq=None):
+def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled=None, relu=True, pooled_sq=None,
+             in_affine=None):
     """x (N,Hi,Wi,C) -> y (N,Ho,Wo,C), pooled (N,parts,C) fp32 partial sums over pixels.
-    w_packed: fp32 [G][9][gw][gw] (VALU path); wfrag: bf16 MFMA fragments (bf16 path)."""
+    w_packed: fp32 [G][9][gw][gw] (VALU path); wfrag: bf16 MFMA fragments (bf16 path).
+    in_affine = (a, b) fp32 [C] (bf16 MFMA path): x is a raw conv output, relu(a*x + b) is applied while it is staged."""
     _chk(x, "x")
     N, Hi, Wi, C = x.shape
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
@@ -198,7 +204,8 @@ def gconv3x3(x, w_packed, scale, shift, gw, stride, wfrag=None, out=None, pooled
     if pooled is None:
         pooled = torch.empty((N, parts, C), dtype=torch.float32, device=x.device)
     call("tdeed_gconv3x3_fwd", ptr(x), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(wfrag), ptr(scale), ptr(shift),
-         ptr(out), ptr(pooled), ptr(pooled_sq), int(relu), dtype_code(x.dtype), stream_ptr())
+         ptr(out), ptr(pooled), ptr(pooled_sq), ptr(in_affine[0] if in_affine else None),
+         ptr(in_affine[1] if in_affine else None), int(relu), dtype_code(x.dtype), stream_ptr())
     return out, pooled
 
 

@@ -117,8 +117,18 @@ def bn_train(z, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, res=N
     return out, (mean, rstd, a, bb)
 
 
+def bn_apply(z, a, b, res=None, relu=True, out=None):
+    """y = act(z * a[c] + b[c] + res): the apply pass of a BatchNorm whose affine is known (tdeed_bn_apply)."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    if out is None:
+        out = torch.empty_like(z)
+    call("tdeed_bn_apply", ptr(z), M, C, ptr(a), ptr(b), ptr(res), int(relu), ptr(out), dtype_code(z.dtype), stream_ptr())
+    return out
+
+
 def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, res=None,
-                      relu=True, out=None):
+                      relu=True, out=None, apply=True):
     """BatchNorm(batch statistics) of z from per-channel partial sums a producer's epilogue wrote (gemm(colpart=...),
     gconv3x3(pooled_sq=...)) + the apply pass.  Returns (y, (mean, rstd, a, b))."""
     C = z.shape[-1]
@@ -132,6 +142,8 @@ def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.
         part_s, part_q, pstride, P = tmp.view(-1), tmp.view(-1)[C:], 2 * C, 64
     call("tdeed_bn_finalize", ptr(part_s), ptr(part_q), pstride, P, M, C, ptr(w), ptr(b), eps, momentum, ptr(mean),
          ptr(rstd), ptr(a), ptr(bb), ptr(run_mean), ptr(run_var), stream_ptr())
+    if not apply:                                # the consumers apply relu(a*z + b) in their own loads: no post-BN map
+        return None, (mean, rstd, a, bb)
     if out is None:
         out = torch.empty_like(z)
     call("tdeed_bn_apply", ptr(z), M, C, ptr(a), ptr(bb), ptr(res), int(relu), ptr(out), dtype_code(z.dtype), stream_ptr())
@@ -156,12 +168,14 @@ def bn_train_bwd(z, dy, y, ctx, w, relu=True, want_res=False):
     return dz, d_res, sums[1], sums[0]              # dw = sum g * xhat, db = sum g: views of the folded sums, no copies
 
 
-def pool_rows(x, x2=None):
-    """x (N,h,w,C): mean over pixels (x2 None) or sum over pixels of x*x2 -> (N,C) fp32"""
+def pool_rows(x, x2=None, affine=None, affine_on=1):
+    """x (N,h,w,C): mean over pixels (x2 None) or sum over pixels of x*x2 -> (N,C) fp32.  affine = (a, b) fp32 [C]:
+    operand `affine_on` (1: x, 2: x2) is a raw conv output and relu(a*. + b) is applied on load."""
     N, C = x.shape[0], x.shape[-1]
     hw = x.numel() // (N * C)
     p = _f32((N, C), x.device)
-    call("tdeed_pool_rows", ptr(x), ptr(x2), N, hw, C, ptr(p), dtype_code(x.dtype), stream_ptr())
+    call("tdeed_pool_rows", ptr(x), ptr(x2), N, hw, C, ptr(affine[0] if affine else None), ptr(affine[1] if affine else None),
+         int(affine_on) if affine else 0, ptr(p), dtype_code(x.dtype), stream_ptr())
     return p
 
 
@@ -182,24 +196,27 @@ def se_train_bwd(d_gate, gate, hid, w1, w2):
     return d_pre2, d_hid, d_p
 
 
-def scale_rows(x, s, add=None, add_scale=1.0, out=None):
+def scale_rows(x, s, add=None, add_scale=1.0, out=None, affine=None):
+    """out = x' * s[n] + add[n] * add_scale; x' = x, or relu(a*x + b) with affine = (a, b) (x a raw conv output)"""
     N, C = x.shape[0], x.shape[-1]
     hw = x.numel() // (N * C)
     if out is None:
         out = torch.empty_like(x)
-    call("tdeed_scale_rows", ptr(x), ptr(s), ptr(add), float(add_scale), N, hw, C, ptr(out), dtype_code(x.dtype),
-         stream_ptr())
+    call("tdeed_scale_rows", ptr(x), ptr(s), ptr(add), float(add_scale), N, hw, C, ptr(affine[0] if affine else None),
+         ptr(affine[1] if affine else None), ptr(out), dtype_code(x.dtype), stream_ptr())
     return out
 
 
-def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True):
-    """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x (None if not want_dx), dw fp32 [G][9][gw][gw]"""
+def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True, in_affine=None):
+    """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x (None if not want_dx), dw fp32 [G][9][gw][gw].
+    in_affine = (a, b) (bf16): x is a raw conv output, relu(a*x + b) is applied on load for the weight gradient."""
     N, Hi, Wi, C = x.shape
     Ho, Wo = dy.shape[1], dy.shape[2]
     G = C // gw
     part = _f32((_lib.load().tdeed_gconv_wgrad_slabs(N * Ho * Wo), G * 9 * gw * gw), x.device)
     dx, dw = (torch.empty_like(x) if want_dx else None), _f32((G, 9, gw, gw), x.device)
-    call("tdeed_gconv3x3_bwd", ptr(x), ptr(dy), N, Hi, Wi, C, gw, stride, ptr(w_packed), ptr(dx), ptr(part), ptr(dw),
+    call("tdeed_gconv3x3_bwd", ptr(x), ptr(dy), N, Hi, Wi, C, gw, stride, ptr(w_packed),
+         ptr(in_affine[0] if in_affine else None), ptr(in_affine[1] if in_affine else None), ptr(dx), ptr(part), ptr(dw),
          dtype_code(x.dtype), stream_ptr())
     return dx, dw
 

@@ -114,6 +114,10 @@ class BottleneckTrain:
         self.epi_stats = act_dtype == torch.bfloat16 and os.environ.get("TDEED_TRAIN_EPI_STATS", "1") == "1"
         dev = sd[self.c1 + ".conv.weight"].device
         self.one, self.zero = torch.ones(blk.cout, device=dev), torch.zeros(blk.cout, device=dev)
+        # the post-BN maps behind conv1 and conv2 are not materialised: their consumers (grouped conv forward and weight
+        # gradient; SE squeeze / scale and the gate gradient) apply relu(a*z + b) in their own loads.  Needs the epilogue
+        # statistics, the z-recomputed ReLU masks and the bf16 MFMA kernels; TDEED_TRAIN_ONLOAD=0 restores the maps.
+        self.onload = (self.epi_stats and ZMASK and os.environ.get("TDEED_TRAIN_ONLOAD", "1") == "1")
         self.repack()
 
     def repack(self):
@@ -142,14 +146,15 @@ class BottleneckTrain:
         self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, R).contiguous()
         self.se_w1t, self.se_w2t = self.se_w1.t().contiguous(), self.se_w2.t().contiguous()
 
-    def _bn(self, z, name, res=None, relu=True, part=None):
+    def _bn(self, z, name, res=None, relu=True, part=None, apply=True):
         """BatchNorm(batch statistics) + residual + ReLU of a raw conv output.  part = (sums, sums of squares, row stride,
-        rows): the per-channel partial sums the conv's own epilogue wrote (no second pass over z for the statistics)."""
+        rows): the per-channel partial sums the conv's own epilogue wrote (no second pass over z for the statistics).
+        apply=False (with part): statistics and affine only, the map is applied by its consumers."""
         sd, p = self.sd, (self.c1 if name == "conv1" else f"{self.pre}.{name}") + ".bn"
         if part is not None:
             ps, pq, stride, P = part
             return B_.bn_finalize_apply(z, ps, pq, stride, P, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1,
-                                        sd[p + ".running_mean"], sd[p + ".running_var"], res=res, relu=relu)
+                                        sd[p + ".running_mean"], sd[p + ".running_var"], res=res, relu=relu, apply=apply)
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
 
@@ -177,21 +182,26 @@ class BottleneckTrain:
             c.a1 = x
         z1, part = self._conv1x1(c.a1, self.w1.w, N * h * w, C)
         c.z1 = z1.view(N, h, w, C)
-        c.y1, c.bn1 = self._bn(c.z1, "conv1", part=part)
+        onload = (self.onload and part is not None and self.w2frag is not None
+                  and ops.gconv3x3_mfma_fits(h, w, C, blk.stride))
+        c.onload = onload
+        c.y1, c.bn1 = self._bn(c.z1, "conv1", part=part, apply=not onload)
+        aff1 = (c.bn1[2], c.bn1[3]) if onload else None
         if self.epi_stats and self.w2frag is not None:
             parts = ops.gconv3x3_parts(h, w, C, blk.stride, self.dt)
             psq = torch.empty((N, parts, C), dtype=torch.float32, device=x.device)
-            c.z2, pooled = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, wfrag=self.w2frag, relu=False,
-                                        pooled_sq=psq)
+            c.z2, pooled = ops.gconv3x3(c.z1 if onload else c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride,
+                                        wfrag=self.w2frag, relu=False, pooled_sq=psq, in_affine=aff1)
             part2 = (pooled.view(-1), psq.view(-1), C, N * parts)
         else:
             c.z2, _ = ops.gconv3x3(c.y1, self.w2p, self.one, self.zero, blk.gw, blk.stride, wfrag=self.w2frag, relu=False)
             part2 = None
-        c.y2, c.bn2 = self._bn(c.z2, "conv2", part=part2)
+        c.y2, c.bn2 = self._bn(c.z2, "conv2", part=part2, apply=not onload)
+        aff2 = (c.bn2[2], c.bn2[3]) if onload else None
         h2, w2 = c.z2.shape[1], c.z2.shape[2]
-        c.p = B_.pool_rows(c.y2)
+        c.p = B_.pool_rows(c.z2 if onload else c.y2, affine=aff2)
         c.hid, c.gate = B_.se_train_fwd(c.p, self.se_w1t, sd[pre + ".se.fc1.bias"], self.se_w2t, sd[pre + ".se.fc2.bias"])
-        c.y2s = B_.scale_rows(c.y2, c.gate)
+        c.y2s = B_.scale_rows(c.z2 if onload else c.y2, c.gate, affine=aff2)
         z3, part3 = self._conv1x1(c.y2s, self.w3.w, N * h2 * w2, C)
         c.z3 = z3.view(N, h2, w2, C)
         if blk.has_downsample:
@@ -221,7 +231,10 @@ class BottleneckTrain:
         grads[pre + ".conv3.conv.weight"] = B_.wgrad(dz3, c.y2s, with_bias=False, M=N * hw2)[0].reshape(
             sd[pre + ".conv3.conv.weight"].shape)
         # SE
-        d_gate = B_.pool_rows(d_y2s, c.y2)
+        if c.onload:
+            d_gate = B_.pool_rows(d_y2s, c.z2, affine=(c.bn2[2], c.bn2[3]), affine_on=2)
+        else:
+            d_gate = B_.pool_rows(d_y2s, c.y2)
         d_pre2, d_hid, d_p = B_.se_train_bwd(d_gate, c.gate, c.hid, self.se_w1, self.se_w2)
         d_y2 = B_.scale_rows(d_y2s, c.gate, add=d_p, add_scale=1.0 / hw2)
         dW2, db2 = B_.wgrad(d_pre2, c.hid)
@@ -233,11 +246,12 @@ class BottleneckTrain:
         # conv2
         dz2, _, dw, db = B_.bn_train_bwd(c.z2, d_y2, None if ZMASK else c.y2, c.bn2, sd[pre + ".conv2.bn.weight"], relu=True)
         bn_names("conv2", dw, db)
+        xin, aff1 = (c.z1, (c.bn1[2], c.bn1[3])) if c.onload else (c.y1, None)
         if self.w2frag_t is not None:
             d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)
-            _, dw2p = B_.gconv3x3_bwd(c.y1, dz2, self.w2p, blk.gw, blk.stride, want_dx=False)
+            _, dw2p = B_.gconv3x3_bwd(xin, dz2, self.w2p, blk.gw, blk.stride, want_dx=False, in_affine=aff1)
         else:
-            d_y1, dw2p = B_.gconv3x3_bwd(c.y1, dz2, self.w2p, blk.gw, blk.stride)
+            d_y1, dw2p = B_.gconv3x3_bwd(xin, dz2, self.w2p, blk.gw, blk.stride, in_affine=aff1)
         G, gw = blk.groups, blk.gw
         grads[pre + ".conv2.conv.weight"] = (dw2p.reshape(G, 3, 3, gw, gw).permute(0, 4, 3, 1, 2)
                                              .reshape(sd[pre + ".conv2.conv.weight"].shape).contiguous())

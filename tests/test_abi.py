@@ -41,7 +41,7 @@ def test_argument_validation_without_gpu(lib):
         call("tdeed_gemm_fwd", 1 << 20, 12, None, 0, 0, None, 0, 8, 12, 8, 1 << 20, 12, None, None, None, 0, 0,
              1 << 20, 8, 1, 0, 0, 0, 0, None, 0, None)
     with pytest.raises(HipCallError, match="group width"):
-        call("tdeed_gconv3x3_fwd", 1 << 20, 1, 8, 8, 24, 12, 1, 1 << 20, None, 1 << 20, 1 << 20, 1 << 20, 1 << 20, None, 1, 0, None)
+        call("tdeed_gconv3x3_fwd", 1 << 20, 1, 8, 8, 24, 12, 1, 1 << 20, None, 1 << 20, 1 << 20, 1 << 20, 1 << 20, None, None, None, 1, 0, None)
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):

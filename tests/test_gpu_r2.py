@@ -13,6 +13,11 @@ from tdeed_amd.regnet_spec import regnet_spec
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
+
+def rnd(seed, name, shape, scale=1.0):
+    from helpers import act
+    return t(act(seed, name, shape, scale))
+
 # (feature_arch, n_layers, sgp_ks, sgp_r, num_classes, radi) of the 14 files under /root/reference/config/*/ (duplicates
 # removed); clip_len is 100 in all of them, crop_dim 224 or -1.
 CONFIG_TUPLES = [
@@ -180,7 +185,10 @@ def test_bf16_train_step_per_tensor_direction():
         # noise itself is sizeable at this toy size (BatchNorms over a few hundred samples): measured worst cosines 0.79
         # (an SE weight), 0.86 .. 0.94 for the stem / s1 tensors, >= 0.9 for the bulk; identical whether the ReLU masks
         # are read from y or recomputed from z
-        if not (cos > 0.7 and 0.6 < ratio < 1.6):
+        lo, hi = (0.4, 2.5) if k.endswith("conv3D.bias") else (0.6, 1.6)
+        # conv3D.bias (2 elements) is the sum of the gate pre-activation gradient over every pixel of every frame: heavy
+        # cancellation, norm 0.002 .. 0.003 of the total -- measured ratios 0.52 .. 1.31 with either form of the BN maps
+        if not (cos > 0.7 and lo < ratio < hi):
             bad.append((k, round(cos, 3), round(ratio, 3)))
     assert not bad, bad
 
@@ -566,3 +574,59 @@ def test_gathered_weight_copies_equal_the_per_module_repack(dtype, monkeypatch):
     k = "_features.s3.b1.conv1.gs.bn.running_mean"
     assert torch.equal(e1.state[k], e0.state[k]) and e1.state[k].shape == sd0[k].shape
     assert int(e1.state["_features.stem.bn.num_batches_tracked"]) == 2
+
+
+@pytest.mark.parametrize("C,gw,stride,H,W", [(24, 8, 2, 20, 22), (64, 16, 1, 14, 14), (152, 8, 1, 9, 7), (56, 8, 2, 16, 16)])
+def test_onload_bn_affine_equals_the_materialised_map(C, gw, stride, H, W):
+    """Training keeps no post-BN map behind conv1 / conv2: the grouped conv (forward, weight gradient), the SE squeeze / scale
+    and the gate gradient apply relu(a*z + b) in their own loads, rounded to bf16 like the map would be: bit-identical to
+    running on the materialised map."""
+    from tdeed_amd import ops, ops_bwd as B_
+    from tdeed_amd.engine import pack_gconv_frags
+    N = 3
+    z = rnd(901, "z", (N, H, W, C), 2.0).to(torch.bfloat16).to(DEV)
+    a = (rnd(902, "a", (C,), 0.5) + 1.0).to(DEV)
+    b = rnd(903, "b", (C,), 0.5).to(DEV)
+    y = B_.bn_apply(z, a, b, relu=True)                          # the materialised map, as the training forward would write it
+    assert float((y.float() - (z.float() * a + b).clamp_min(0)).abs().max()) < 0.05
+    wt = rnd(904, "w", (C, gw, 3, 3), 0.2)
+    G = C // gw
+    wp = wt.reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1).reshape(G, 9, gw, gw).contiguous().to(DEV)
+    wf = pack_gconv_frags(wt, gw, DEV)
+    one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    assert ops.gconv3x3_mfma_fits(H, W, C, stride)
+    o1, p1 = ops.gconv3x3(y, wp, one, zero, gw, stride, wfrag=wf, relu=False)
+    o2, p2 = ops.gconv3x3(z, wp, one, zero, gw, stride, wfrag=wf, relu=False, in_affine=(a, b))
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    dy = rnd(905, "dy", tuple(o1.shape)).to(torch.bfloat16).to(DEV)
+    _, dw1 = B_.gconv3x3_bwd(y, dy, wp, gw, stride, want_dx=False)
+    _, dw2 = B_.gconv3x3_bwd(z, dy, wp, gw, stride, want_dx=False, in_affine=(a, b))
+    assert torch.equal(dw1, dw2)
+    assert torch.equal(B_.pool_rows(z, affine=(a, b)), B_.pool_rows(y))
+    d = rnd(906, "d", (N, H, W, C)).to(torch.bfloat16).to(DEV)
+    assert torch.equal(B_.pool_rows(d, z, affine=(a, b), affine_on=2), B_.pool_rows(d, y))
+    gate = torch.sigmoid(rnd(907, "g", (N, C))).to(DEV)
+    assert torch.equal(B_.scale_rows(z, gate, affine=(a, b)), B_.scale_rows(y, gate))
+
+
+def test_training_with_and_without_materialised_post_bn_maps_agree(monkeypatch):
+    """TDEED_TRAIN_ONLOAD=0 (post-BN maps written and read back) against the default (applied in the consumers' loads): the
+    same loss and the same gradients, bit for bit."""
+    from tdeed_amd.trainer import TrainEngine
+    cfg = dict(feature_arch="rny002_gsf", clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, 8, 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 43).items()}
+    frames = t(synth.uint8_clip(821, (B, T, 3, H, W))).to(DEV)
+    lab_np, labD_np = synth.labels(822, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long().to(DEV), t(labD_np).float().to(DEV)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TDEED_TRAIN_ONLOAD", flag)
+        eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.bfloat16, lr=1e-3)
+        assert all(b.onload == (flag == "1") for b in eng.blocks)
+        loss, grads = eng.loss_and_grads(frames, lab, labD)
+        torch.cuda.synchronize()
+        out[flag] = (loss.clone(), torch.cat([grads[k].reshape(-1) for k in sorted(grads)]).clone())
+    assert torch.equal(out["1"][0], out["0"][0])                  # every on-load value is rounded like the map: bit-identical
+    assert torch.equal(out["1"][1], out["0"][1])
