@@ -563,7 +563,18 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
   }
 }
 
-#define WS_LDS_CAP (96 * 1024)
+// LDS budget of a weight slice when the whole matrix does not fit 64 KB (TDEED_WS_CAP_KB: 96 by default, up to 150)
+static size_t ws_lds_cap() {
+  static const size_t cap = [] {
+    const char* e = getenv("TDEED_WS_CAP_KB");
+    long kb = e ? atol(e) : 96;
+    if (kb < 64) kb = 64;
+    if (kb > 150) kb = 150;
+    return (size_t)kb * 1024;
+  }();
+  return cap;
+}
+#define WS_LDS_CAP ws_lds_cap()
 static bool ws_ks_ok(int KS) {
   return KS == 1 || KS == 2 || KS == 3 || KS == 4 || KS == 5 || KS == 6 || KS == 8 || KS == 10 || KS == 12;
 }

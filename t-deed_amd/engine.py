@@ -162,7 +162,10 @@ class DenseW:
     def __init__(self, W, act_dtype, device):
         W = _np(W)
         self.N, self.K = W.shape
-        self.ws = (ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) == 1) if str(device) != "cpu" else False
+        # mode 1: the whole W sits in LDS; mode 2 (wide s4 layers: W sliced over blockIdx.y, activations re-read per slice)
+        # is opt-in (TDEED_WS_SLICED=1)
+        ok_modes = (1, 2) if os.environ.get("TDEED_WS_SLICED", "0") == "1" else (1,)
+        self.ws = (ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) in ok_modes) if str(device) != "cpu" else False
         self.w = pack_ws_weights(W, act_dtype, device) if self.ws else _dense(W, act_dtype, device)
         self.kernel = "gemm_ws" if self.ws else "gemm"
 
