@@ -289,12 +289,21 @@ int tdeed_reduce_strided(const float* part, int P, long stride, long n, float* o
  * long n; long first_chunk} (first_chunk = running sum of ceil(n / 4096) over the records before it), n_chunks = that sum
  * over all records; dst[off + i] = (accumulate ? dst[off + i] : 0) + scale * src[i]. */
 int tdeed_multi_copy(const void* tab, int nt, long n_chunks, float* dst, float scale, int accumulate, void* stream);
+/* the same write-out with the fold of per-workgroup partials inside.  tab: device array of nt entries of 8 int64
+ * {src pointer, dst offset, n, first workgroup, P | cw << 32, pstride, cols, ld}: P == 1 copies n elements from a source of
+ * `cols` contiguous elements per row, rows `ld` apart (4096 elements per workgroup); P > 1 writes
+ * dst[off + j] = scale * sum_p src[p * pstride + j] with cw = tdeed_multi_fold_cw(P, n) columns per workgroup (the partials
+ * tdeed_wgrad leaves when called with accumulate = -1).  n_wgs = total workgroups of all entries. */
+int tdeed_multi_fold_cw(int P, long n);
+int tdeed_multi_fold(const void* tab, int nt, long n_wgs, float* dst, float scale, int accumulate, void* stream);
 /* mode 0: y = gelu(x); 1: y = dy * gelu'(x); 2: y = x + dy; 3: y = x * dy.  n elements, multiple of 8 */
 int tdeed_eltwise(const void* x, const void* dy, void* y, long n, int mode, int dtype, void* stream);
 /* [R][Cc] -> [Cc][R] (weight transposes for the input-gradient contractions) */
 int tdeed_transpose(const void* x, int R, int Cc, void* y, int dtype, void* stream);
 /* weight / bias gradient of a Conv1d(k=1) / 1x1 conv: dW[n][k] (+)= sum_m dY[m][n] X[m][k], db[n] (+)= sum_m dY[m][n]
- * (db may be NULL).  part_w fp32 [Z][N][K], part_b fp32 [Z][N], Z = tdeed_wgrad_slices(M, N, K). */
+ * (db may be NULL).  part_w fp32 [Z][N][K], part_b fp32 [Z][N], Z = tdeed_wgrad_slices(M, N, K).
+ * accumulate = -1: the partials are left unfolded (dW / db may be NULL; part_b is filled when given): tdeed_multi_fold folds
+ * them together with the gradient write-out. */
 int tdeed_wgrad_slices(int M, int N, int K);
 int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w, float* part_b,
                 float* dW, float* db, int accumulate, int dtype, void* stream);

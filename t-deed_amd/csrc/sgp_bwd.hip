@@ -83,6 +83,74 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyEnt* __restri
   }
 }
 
+// The same write-out with the fold of per-workgroup partials inside: entry = {src, dst offset, n, first workgroup,
+// P | cw << 32, pstride, cols, ld}.  P == 1: a copy of n elements whose source is `cols` contiguous elements per row, rows
+// `ld` apart (cols == n: contiguous), 4096 elements per workgroup.  P > 1: dst[off + j] = scale * sum_p src[p * pstride + j]
+// (the weight-gradient kernels' partials), cw columns per workgroup, 256 / cw lanes walking the P rows (ordered fold through
+// LDS: the same sum as tdeed_reduce_partials).  One launch per gradient bucket instead of one fold per parameter tensor.
+struct FoldEnt { const float* src; long off; long n; long first_wg; long pcw; long pstride; long cols; long ld; };
+__global__ __launch_bounds__(256) void multi_fold_kernel(const FoldEnt* __restrict__ tab, int nt, float* __restrict__ dst,
+                                                         float scale, int accumulate) {
+  __shared__ float red[32 * 65];
+  const long b = blockIdx.x;
+  int lo = 0, hi = nt - 1;
+  while (lo < hi) {                                              // last entry with first_wg <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_wg <= b) lo = mid; else hi = mid - 1;
+  }
+  const FoldEnt e = tab[lo];
+  const long w = b - e.first_wg;
+  const int P = (int)(e.pcw & 0xffffffffL), cw = (int)(e.pcw >> 32);
+  if (P <= 1) {
+    const long i0 = w * 4096, i1 = min(e.n, i0 + 4096);
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+      long si = i;
+      if (e.cols != e.n) {
+        const long r = i / e.cols;
+        si = r * e.ld + (i - r * e.cols);
+      }
+      const float v = scale * e.src[si];
+      dst[e.off + i] = accumulate ? dst[e.off + i] + v : v;
+    }
+    return;
+  }
+  const int PL = 256 / cw;
+  const int c = threadIdx.x % cw, pl = threadIdx.x / cw;
+  const long j = w * cw + c, jj = min(j, e.n - 1);
+  float s = 0.f;
+  for (int p0 = pl; p0 < P; p0 += 8 * PL) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = e.src[(long)min(p0 + u * PL, P - 1) * e.pstride + jj];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += p0 + u * PL < P ? v[u] : 0.f;
+  }
+  red[pl * (cw + 1) + c] = s;
+  __syncthreads();
+  if (pl == 0 && j < e.n) {
+    float a = 0.f;
+    for (int i = 0; i < PL; ++i) a += red[i * (cw + 1) + c];
+    a *= scale;
+    dst[e.off + j] = accumulate ? dst[e.off + j] + a : a;
+  }
+}
+
+// columns per workgroup of a fold entry (the host sizes the table with it): many partials of a narrow output -> 8
+// columns x 32 lanes, else 32 x 8 or 64 x 4 (the same rule as tdeed_reduce_partials)
+extern "C" int tdeed_multi_fold_cw(int P, long n) {
+  if (P <= 1) return 4096;
+  if (P >= 512 && n <= 4096) return 8;
+  return P >= 64 ? 32 : 64;
+}
+
+extern "C" int tdeed_multi_fold(const void* tab, int nt, long n_wgs, float* dst, float scale, int accumulate, void* stream) {
+  TD_CHECK(tab && dst && nt > 0 && n_wgs > 0 && n_wgs < 0x7fffffffL, "multi_fold: bad arguments");
+  hipLaunchKernelGGL(multi_fold_kernel, dim3((unsigned)n_wgs), dim3(256), 0, (hipStream_t)stream, (const FoldEnt*)tab, nt,
+                     dst, scale, accumulate);
+  TD_LAUNCH_CHECK("multi_fold");
+  return TDEED_OK;
+}
+
 // tab: device array of nt entries {src pointer, dst offset, n, first chunk}; n_chunks = total chunks (sum of ceil(n / 4096))
 extern "C" int tdeed_multi_copy(const void* tab, int nt, long n_chunks, float* dst, float scale, int accumulate,
                                 void* stream) {
@@ -398,30 +466,31 @@ extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
 // part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M, N, K); dW [N][K], db [N] (fp32)
 extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w,
                            float* part_b, float* dW, float* db, int accumulate, int dtype, void* stream) {
-  TD_CHECK(dY && X && part_w && dW && (!db || part_b), "wgrad: null pointer");
+  TD_CHECK(dY && X && part_w && (dW || accumulate < 0) && (!db || part_b), "wgrad: null pointer");
   TD_CHECK(M > 0 && N > 0 && K > 0, "wgrad: bad sizes");
   const int Z = tdeed_wgrad_slices(M, N, K);
   dim3 grid(cdiv(N, 64), cdiv(K, 64), Z);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, M, N, K,
-                       part_w, db ? part_b : nullptr);
+                       part_w, (db || accumulate < 0) ? part_b : nullptr);
   else if (dtype == TDEED_BF16) {
     static const bool valu = getenv("TDEED_WGRAD_VALU") && atoi(getenv("TDEED_WGRAD_VALU")) == 1;
     static const bool scatter = getenv("TDEED_WGRAD_SCATTER") && atoi(getenv("TDEED_WGRAD_SCATTER")) == 1;
     const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
     if (!valu && vec_ok && !scatter && M >= 4096)               // long contractions: transposing LDS reads, 64-row chunks
       hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
-                         part_w, db ? part_b : nullptr);
+                         part_w, (db || accumulate < 0) ? part_b : nullptr);
     else if (!valu && vec_ok)
       hipLaunchKernelGGL(wgrad_mfma_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
-                         part_w, db ? part_b : nullptr);
+                         part_w, (db || accumulate < 0) ? part_b : nullptr);
     else
       hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N,
-                         K, part_w, db ? part_b : nullptr);
+                         K, part_w, (db || accumulate < 0) ? part_b : nullptr);
   }
   else { tdeed_set_error("wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("wgrad");
+  if (accumulate < 0) return TDEED_OK;           // partials only: folded later (tdeed_multi_fold, with the gradient write-out)
   int rc = tdeed_reduce_partials(part_w, Z, (long)N * K, dW, accumulate, stream);
   if (rc == TDEED_OK && db) rc = tdeed_reduce_partials(part_b, Z, N, db, accumulate, stream);
   return rc;

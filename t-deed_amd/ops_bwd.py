@@ -28,12 +28,49 @@ def transpose(x, out=None):
     return out
 
 
+class LazyFold:
+    """A parameter gradient still in per-workgroup partials [P][n] (fp32, contiguous): the gradient write-out launch
+    (`multi_copy` -> tdeed_multi_fold) folds it on its way into the flat gradient buffer, instead of one fold launch per
+    tensor (~280 per step).  Quacks like the tensor it stands for as far as the write-out needs (numel / dtype / reshape)."""
+
+    def __init__(self, part, P, n, shape=None):
+        self.part, self.P, self.n = part, int(P), int(n)
+        self.shape = tuple(shape) if shape is not None else (self.n,)
+        self.dtype, self.device = torch.float32, part.device
+
+    def numel(self):
+        return self.n
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        return LazyFold(self.part, self.P, self.n, shape)
+
+    view = reshape
+
+    def materialize(self):
+        out = _f32((self.n,), self.device)
+        call("tdeed_reduce_partials", ptr(self.part), self.P, self.n, ptr(out), 0, stream_ptr())
+        return out.view(self.shape)
+
+
+LAZY_WGRAD = False          # set by TrainEngine.backward_and_write: wgrad() then returns LazyFold objects
+
+
+def materialize(g):
+    return g.materialize() if isinstance(g, LazyFold) else g
+
+
 def wgrad(dY, X, with_bias=True, dW=None, db=None, accumulate=False, M=None):
-    """dW[n][k] = sum_m dY[m][n] X[m][k]; db[n] = sum_m dY[m][n].  dY (M,N), X (M,K) in the activation dtype."""
+    """dW[n][k] = sum_m dY[m][n] X[m][k]; db[n] = sum_m dY[m][n].  dY (M,N), X (M,K) in the activation dtype.
+    With LAZY_WGRAD set (and no caller-provided outputs) the results are LazyFold objects."""
     N, K = dY.shape[-1], X.shape[-1]
     M = dY.numel() // N if M is None else M
     Z = _lib.load().tdeed_wgrad_slices(M, N, K)
     dev = dY.device
+    if LAZY_WGRAD and dW is None and db is None and not accumulate:
+        pw, pb = _f32((Z, N, K), dev), (_f32((Z, N), dev) if with_bias else None)
+        call("tdeed_wgrad", ptr(dY), N, ptr(X), K, M, N, K, ptr(pw), ptr(pb), None, None, -1, dtype_code(dY.dtype), stream_ptr())
+        return LazyFold(pw, Z, N * K, (N, K)), (LazyFold(pb, Z, N, (N,)) if with_bias else None)
     dW = _f32((N, K), dev) if dW is None else dW
     if with_bias and db is None:
         db = _f32((N,), dev)
@@ -324,7 +361,7 @@ class PinnedTables:
         ring = self.rings.setdefault(role, dict(bufs=[], evs=[], i=0))
         capturing = torch.cuda.is_current_stream_capturing()
         if len(ring["bufs"]) < self.depth and not capturing:
-            ring["bufs"].append(torch.empty((self.max_entries, 4), dtype=torch.int64).pin_memory())
+            ring["bufs"].append(torch.empty((self.max_entries, 8), dtype=torch.int64).pin_memory())
             ring["evs"].append(None)
             j = len(ring["bufs"]) - 1
         else:
@@ -338,9 +375,10 @@ class PinnedTables:
 
 
 def multi_copy(srcs, offsets, dst_flat, scale=1.0, accumulate=False, tables=None, role=0):
-    """dst_flat[off_i : off_i + n_i] (= or +=) scale * srcs[i] for every i, one launch.  srcs: contiguous fp32 device
-    tensors; offsets: element offsets into dst_flat.  tables: a PinnedTables (reused across steps; required for calls
-    inside a stream capture)."""
+    """dst_flat[off_i : off_i + n_i] (= or +=) scale * srcs[i] for every i, one launch (tdeed_multi_fold).  srcs: fp32
+    device tensors -- contiguous, or 2-D with unit column stride (a column slice of a wider matrix) -- or LazyFold partials,
+    which are folded on the way; offsets: element offsets into dst_flat.  tables: a PinnedTables (reused across steps;
+    required for calls inside a stream capture)."""
     nt = len(srcs)
     tables = tables if tables is not None else PinnedTables(max(nt, 16), depth=1)
     if nt > tables.max_entries:
@@ -348,19 +386,38 @@ def multi_copy(srcs, offsets, dst_flat, scale=1.0, accumulate=False, tables=None
     ring, j = tables.get(role)
     host = ring["bufs"][j]
     rows = []
-    chunk = 0
+    keep = []
+    wg = 0
+    cwf = _lib.load().tdeed_multi_fold_cw
     for t_, off in zip(srcs, offsets):
-        if t_.dtype != torch.float32 or not t_.is_contiguous():
-            raise TypeError("multi_copy: contiguous fp32 sources expected")
+        if isinstance(t_, LazyFold):
+            cw = cwf(t_.P, t_.n)
+            rows.append((t_.part.data_ptr(), off, t_.n, wg, t_.P | (cw << 32), t_.n, t_.n, t_.n))
+            wg += (t_.n + cw - 1) // cw if t_.P > 1 else (t_.n + 4095) // 4096
+            keep.append(t_.part)
+            continue
+        if t_.dtype != torch.float32:
+            raise TypeError("multi_copy: fp32 sources expected")
         n = t_.numel()
-        rows.append((t_.data_ptr(), off, n, chunk))
-        chunk += (n + 4095) // 4096
+        sq = t_ if t_.is_contiguous() else t_.squeeze()
+        if t_.is_contiguous():
+            cols, ld = n, n
+        elif sq.dim() == 2 and sq.stride(1) == 1 and sq.stride(0) >= sq.shape[1]:      # column slice of a wider matrix
+            cols, ld = sq.shape[1], sq.stride(0)
+        elif sq.dim() == 1 and sq.stride(0) >= 1:                                      # one column of it
+            cols, ld = 1, sq.stride(0)
+        else:
+            t_ = t_.contiguous()
+            cols, ld = n, n
+        rows.append((t_.data_ptr(), off, n, wg, 1 | (4096 << 32), n, cols, ld))
+        wg += (n + 4095) // 4096
+        keep.append(t_)
     host[:nt] = torch.tensor(rows, dtype=torch.int64)
     dev = host[:nt].to(dst_flat.device, non_blocking=True)
     if not torch.cuda.is_current_stream_capturing():
         ev = torch.cuda.Event()
         ev.record()
         ring["evs"][j] = ev
-    ring["live"] = (dev, list(srcs))                 # keep the device table and the sources alive until the next call
-    call("tdeed_multi_copy", ptr(dev), nt, chunk, ptr(dst_flat), float(scale), int(accumulate), stream_ptr())
+    ring["live"] = (dev, keep)                       # keep the device table and the sources alive until the next call
+    call("tdeed_multi_fold", ptr(dev), nt, wg, ptr(dst_flat), float(scale), int(accumulate), stream_ptr())
     return dev

@@ -12,6 +12,8 @@ Every numeric step is a HIP kernel behind the C ABI and is parity-tested against
 write-out into one HIP graph (AdamW stays outside: lr and the step count change every step).  The step is correct but only
 lightly tuned: DESIGN.md section 8 has the per-kernel breakdown.  Both gate-shift variants train: `_gsf` (every shipped
 config) and the optional `_gsm` (impl/gsm.py; the same backward kernels without the fusion-conv path)."""
+import os
+
 import torch
 
 from . import ops, ops_bwd as B_
@@ -106,7 +108,7 @@ class TrainEngine:
         grads = {}
         d_feat = self.temporal.backward_heads(ctx.tctx, dhead, grads)
         grads.update(self.backward_trunk(ctx, d_feat))
-        return grads
+        return {k: B_.materialize(g) for k, g in grads.items()}
 
     def backward_trunk(self, ctx, d_feat):
         """Backward of avg-pool + positional encoding, the bottlenecks and the stem from d(loss)/d(features)."""
@@ -158,7 +160,7 @@ class TrainEngine:
             if missing:
                 raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
         keys = list(grads)
-        srcs = [grads[k] if grads[k].is_contiguous() else grads[k].contiguous() for k in keys]
+        srcs = [grads[k] for k in keys]                          # tensors (contiguous or column slices) or LazyFold partials
         for k, g in zip(keys, srcs):
             if g.numel() != self.params.index[k][1] or g.dtype != torch.float32:
                 raise RuntimeError(f"gradient of {k}: {tuple(g.shape)} {g.dtype} does not match the parameter")
@@ -187,11 +189,21 @@ class TrainEngine:
         buffer bucket by bucket; with `reduce` each bucket's all-reduce starts as soon as it is complete."""
         red = self.reducer if reduce else None
         g_t = {}
-        d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
+        # weight gradients stay in their per-workgroup partials until the bucket's write-out launch folds them
+        lazy = os.environ.get("TDEED_LAZY_WGRAD", "1") == "1"
+        B_.LAZY_WGRAD = lazy
+        try:
+            d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
+        finally:
+            B_.LAZY_WGRAD = False
         self.write_grads(g_t, scale, first, partial=True, role=0)
         if red is not None:
             red.reduce_bucket(0)
-        g_b = self.backward_trunk(ctx, d_feat)
+        B_.LAZY_WGRAD = lazy
+        try:
+            g_b = self.backward_trunk(ctx, d_feat)
+        finally:
+            B_.LAZY_WGRAD = False
         missing = set(self.params.index) - set(g_t) - set(g_b)
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
@@ -269,12 +281,20 @@ class TrainEngine:
                 labelD=None if h.labelD is None else h.labelD.reshape(-1),
                 soft=None if h.soft is None else h.soft.reshape(-1, h.soft.shape[-1]), fg_weight=fg_weight)
             g_t = {}
-            d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
+            B_.LAZY_WGRAD = os.environ.get("TDEED_LAZY_WGRAD", "1") == "1"
+            try:
+                d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
+            finally:
+                B_.LAZY_WGRAD = False
             self.write_grads(g_t, 1.0, True, partial=True, role=0)
             return loss, ctx, d_feat, set(g_t)
 
         def part_b(ctx, d_feat, done):
-            g_b = self.backward_trunk(ctx, d_feat)
+            B_.LAZY_WGRAD = os.environ.get("TDEED_LAZY_WGRAD", "1") == "1"
+            try:
+                g_b = self.backward_trunk(ctx, d_feat)
+            finally:
+                B_.LAZY_WGRAD = False
             missing = set(self.params.index) - done - set(g_b)
             if missing:
                 raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")

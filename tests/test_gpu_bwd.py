@@ -643,3 +643,59 @@ def test_double_head_loss_and_grads_match_autograd(dtype):
         assert rel_err(d_feat.float(), fr.grad) < 2e-3
         for k in [k for k in sd if k.startswith("_pred")]:
             assert rel_err(grads[k], sdr[k].grad) < 1e-3, k
+
+
+def test_gradient_write_out_folds_partials_and_reads_column_slices(bops):
+    """tdeed_multi_fold: one launch writes contiguous tensors, column slices of wider matrices and still-unfolded
+    weight-gradient partials (LazyFold) into the flat buffer, scaled, overwriting or accumulating."""
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(300, generator=g).to(DEV)
+    wide = torch.randn(7, 50, generator=g).to(DEV)
+    part = torch.randn(600, 96, generator=g).to(DEV)              # many partials of a narrow output: 8 columns per workgroup
+    part2 = torch.randn(3, 5000, generator=g).to(DEV)             # few partials: 64 columns per workgroup
+    part3 = torch.randn(100, 40, generator=g).to(DEV)
+    srcs = [a, wide[:, 10:25].reshape(7, 1, 15), bops.LazyFold(part, 600, 96, (12, 8)), bops.LazyFold(part2, 3, 5000),
+            wide[:, 3:4].reshape(7, 1, 1), bops.LazyFold(part3, 100, 40).reshape(5, 8)]
+    sizes = [300, 105, 96, 5000, 7, 40]
+    offs, cur = [], 4
+    for n in sizes:
+        offs.append(cur)
+        cur += (n + 3) // 4 * 4
+    flat = torch.full((cur + 8,), 0.5, device=DEV)
+    ref = flat.clone()
+    want = [a, wide[:, 10:25].reshape(-1), part.sum(0), part2.sum(0), wide[:, 3], part3.sum(0)]
+    for o, w_ in zip(offs, want):
+        ref[o:o + w_.numel()] = 2.0 * w_.reshape(-1)
+    bops.multi_copy(srcs, offs, flat, scale=2.0, accumulate=False)
+    assert rel_err(flat, ref) < 1e-5
+    bops.multi_copy(srcs, offs, flat, scale=2.0, accumulate=True)
+    ref2 = ref.clone()
+    for o, w_ in zip(offs, want):
+        ref2[o:o + w_.numel()] += 2.0 * w_.reshape(-1)
+    assert rel_err(flat, ref2) < 1e-5
+    assert torch.equal(srcs[2].materialize(), srcs[2].materialize()) and srcs[2].materialize().shape == (12, 8)
+    assert rel_err(srcs[2].materialize().reshape(-1), part.sum(0)) < 1e-5
+
+
+def test_lazy_weight_gradients_give_the_same_step(monkeypatch):
+    """TDEED_LAZY_WGRAD=0 (every weight gradient folded by its own launch) against the default (folded by the bucket's
+    write-out launch): the same sums in the same order -- bit-identical parameters after two optimizer steps."""
+    from tdeed_amd.trainer import TrainEngine
+    from tdeed_amd import synth, state_layout
+    cfg = dict(feature_arch="rny002_gsf", clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, 8, 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 47).items()}
+    frames = t(synth.uint8_clip(831, (B, T, 3, H, W))).to(DEV)
+    lab_np, labD_np = synth.labels(832, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long().to(DEV), t(labD_np).float().to(DEV)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TDEED_LAZY_WGRAD", flag)
+        eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.bfloat16, lr=1e-3)
+        for _ in range(2):
+            loss = eng.step(frames, lab, labD)
+        torch.cuda.synchronize()
+        res[flag] = (loss.clone(), eng.params.flat.clone(), eng.params.grad.clone())
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][2], res["0"][2]) and torch.equal(res["1"][1], res["0"][1])

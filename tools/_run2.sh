@@ -1,7 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-run() { python bench.py --no-train --no-feed --no-cpu-baseline --repeats 3 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().split("\n")[-1]); print(d["value"], d["ms_per_step"], d["latency_ms_inflight1"], {k:(v["ms"],v["launches"]) for k,v in d["kernels"].items() if k in ("gemm","gemm_ws")})'; }
-echo "default: $(run)" > gpurun_out/ws_exp.txt
-echo "sliced cap96: $(TDEED_WS_SLICED=1 run)" >> gpurun_out/ws_exp.txt
-echo "sliced cap150: $(TDEED_WS_SLICED=1 TDEED_WS_CAP_KB=150 run)" >> gpurun_out/ws_exp.txt
-echo "sliced cap128: $(TDEED_WS_SLICED=1 TDEED_WS_CAP_KB=128 run)" >> gpurun_out/ws_exp.txt
-cat gpurun_out/ws_exp.txt
+(timeout 1800 python -m pytest tests/test_gpu_bwd.py tests/test_gpu_r2.py tests/test_gpu_model.py tests/test_gpu_dp.py -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -25) > gpurun_out/t_all.txt
+python bench.py --mode train --workload rny002_b8 --no-cpu-baseline > gpurun_out/train_b8.json 2> gpurun_out/train_b8.err
+python bench.py --mode train --workload rny008_b16 --no-cpu-baseline > gpurun_out/train_b16.json 2> gpurun_out/train_b16.err
+tail -12 gpurun_out/t_all.txt | cut -c1-300; tail -1 gpurun_out/train_b8.json | cut -c1-250;  tail -1 gpurun_out/train_b16.json | cut -c1-250; tail -3 gpurun_out/train_b8.err
