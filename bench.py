@@ -390,42 +390,59 @@ def main():
     feed = None
     if world == 1 and depth >= 2 and not a.no_feed:       # single-process side measurement (its timed regions hold barriers)
         hosts = [torch.randint(0, 256, (B, T, 3, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
-        copy_st = torch.cuda.Stream()
-        freed = [None] * depth            # event: plan i's forward has consumed its input buffers
-        arrived = [None] * depth
+        # H2D lands in a ring of device staging buffers on two copy streams (the link carries 50 GB/s with one stream, 56
+        # with two); the forward's first act is a device-to-device copy (1 TB/s, 0.12 ms) staging -> the plan's input
+        # buffers, after which the staging slot is free again: the upload of batch i+2 never waits for a forward to END,
+        # only for the head of the forward that last used its slot.
+        NST = 3
+        stage = [torch.empty((B, T, 3, H, W), dtype=torch.uint8, device=dev) for _ in range(NST)]
+        copy_sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+        freed = [None] * NST              # event: the D2D copy out of staging slot j has run
+        arrived = [None] * NST
 
-        def upload(i, step):
-            pl = plans[i]
-            Bs = B // len(pl.subs)
-            with torch.cuda.stream(copy_st):
-                if freed[i] is not None:
-                    copy_st.wait_event(freed[i])
-                for k_, sb in enumerate(pl.subs):
-                    sb.frames.copy_(hosts[step % 3][k_ * Bs:(k_ + 1) * Bs].view(Bs * T, 3, H, W), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_st)
-            arrived[i] = ev
+        def upload(step):
+            j = step % NST
+            half = B // 2
+            evs = []
+            for k_, cs in enumerate(copy_sts):
+                with torch.cuda.stream(cs):
+                    if freed[j] is not None:
+                        cs.wait_event(freed[j])
+                    lo, hi = (0, half) if k_ == 0 else (half, B)
+                    stage[j][lo:hi].copy_(hosts[step % 3][lo:hi], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(cs)
+                    evs.append(ev)
+            arrived[j] = evs
 
         def run_fed(n):
-            upload(0, 0)
+            upload(0)
+            if n > 1:
+                upload(1)
             for i in range(n):
-                p_ = i % depth
-                if i + 1 < n:
-                    upload((i + 1) % depth, i + 1)
+                p_, j = i % depth, i % NST
+                pl = plans[p_]
+                Bs = B // len(pl.subs)
                 with torch.cuda.stream(streams[p_]):
-                    streams[p_].wait_event(arrived[p_])
-                    eng.run_plan(plans[p_])
+                    for ev in arrived[j]:
+                        streams[p_].wait_event(ev)
+                    for k_, sb in enumerate(pl.subs):
+                        sb.frames.copy_(stage[j][k_ * Bs:(k_ + 1) * Bs].view(Bs * T, 3, H, W), non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(streams[p_])
-                    freed[p_] = ev
+                    freed[j] = ev
+                    eng.run_plan(pl)
+                if i + 2 < n:
+                    upload(i + 2)
 
         run_fed(6)
-        walls_f, _ = timed_regions(run_fed, a.steps, 3, dev, streams + [copy_st])
+        walls_f, _ = timed_regions(run_fed, a.steps, 3, dev, streams + copy_sts)
         el_f = statistics.median(walls_f)
         feed = dict(value=round(B * a.steps / el_f, 2), unit="clips/s", ms_per_step=round(el_f / a.steps * 1e3, 4),
                     h2d_GBps=round(B * T * 3 * H * W / (el_f / a.steps) / 1e9, 2),
-                    note="uint8 clips in pinned host memory -> async H2D on a copy stream into the idle plan's buffers, "
-                         "overlapped with the other plan's forward; 15 MB per clip over PCIe")
+                    note="uint8 clips in pinned host memory -> async H2D on two copy streams into a ring of 3 device staging "
+                         "buffers, two batches ahead of the forward that consumes them (its first act: a device-to-device copy "
+                         "into the plan's input buffers); 15 MB per clip over PCIe")
     with torch.cuda.stream(stream):
         prof, sgp_stage_ms = kernel_profile(eng, plan) if rank == 0 else (None, None)
         sgp_direct = sgp_stage_time(plan) if rank == 0 else None
