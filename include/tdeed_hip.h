@@ -305,8 +305,10 @@ int tdeed_transpose(const void* x, int R, int Cc, void* y, int dtype, void* stre
  * accumulate = -1: the partials are left unfolded (dW / db may be NULL; part_b is filled when given): tdeed_multi_fold folds
  * them together with the gradient write-out. */
 int tdeed_wgrad_slices(int M, int N, int K);
-int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w, float* part_b,
-                float* dW, float* db, int accumulate, int dtype, void* stream);
+/* X0 (optional, bf16, M >= 4096): columns k < k0 of the X operand come from X0 (row stride ldx0): the gate-shift splice
+ * [G | x[:, k0:]] of a conv1 operand is never materialised (as A0 / k0 of tdeed_gemm_fwd) */
+int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, const void* X0, long ldx0, int k0, int M, int N, int K,
+                float* part_w, float* part_b, float* dW, float* db, int accumulate, int dtype, void* stream);
 /* channel LayerNorm backward (modules.py:320-363): dx (+)= d/dx, dw/db [C].  part fp32 [tdeed_layernorm_bwd_blocks(rows)][2][C] */
 int tdeed_layernorm_bwd_blocks(int rows);
 int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long ldy, int rows, int C, const float* w, float eps,

@@ -77,7 +77,7 @@ _SIGS = {
     "tdeed_eltwise": ([P, P, P, c_long, c_int, c_int, P], c_int),
     "tdeed_transpose": ([P, c_int, c_int, P, c_int, P], c_int),
     "tdeed_wgrad_slices": ([c_int, c_int, c_int], c_int),
-    "tdeed_wgrad": ([P, c_long, P, c_long, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_wgrad": ([P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_layernorm_bwd_blocks": ([c_int], c_int),
     "tdeed_layernorm_bwd": ([P, c_long, P, c_long, c_int, c_int, P, c_float, P, c_int, P, P, P, c_int, P], c_int),
     "tdeed_groupnorm_bwd": ([P, P, c_int, c_int, c_int, c_int, P, c_float, P, c_int, P, P, P, c_int, P], c_int),

@@ -371,9 +371,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16_t* __restric
 // consecutive rows -- is two transposing reads (per 16-lane group the hardware returns lane i column i of 4 rows).
 // Half the barriers and a quarter of the LDS instructions per row of the kernel above.
 constexpr int WT_RS = 80;                                       // LDS row stride in elements: 64 columns + 32 bytes
+// X0 (optional): the columns k < k0 of the X operand come from X0 (row stride ldx0) instead of X -- the gate-shift splice of
+// a s3 / s4 conv1 (shift.py:89-93): [G | x[:, Fp:]] is never materialised.
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const bf16_t* __restrict__ dY, long ldy, const bf16_t* __restrict__ X,
-                                                       long ldx, int M, int N, int K, float* __restrict__ part_w,
-                                                       float* __restrict__ part_b) {
+                                                       long ldx, const bf16_t* __restrict__ X0, long ldx0, int k0s, int M, int N,
+                                                       int K, float* __restrict__ part_w, float* __restrict__ part_b) {
   __shared__ __attribute__((aligned(16))) bf16_t sY[64 * WT_RS];
   __shared__ __attribute__((aligned(16))) bf16_t sX[64 * WT_RS];
   __shared__ float sb[32][65];
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const bf16_t* __restrict_
     for (int h = 0; h < 2; ++h) {
       const long row = min(m0 + r + 32 * h, M - 1);
       vy[h] = *reinterpret_cast<const u32x4*>(dY + row * ldy + ycol);
-      vx[h] = *reinterpret_cast<const u32x4*>(X + row * ldx + xcol);
+      vx[h] = *reinterpret_cast<const u32x4*>(xcol < k0s ? X0 + row * ldx0 + xcol : X + row * ldx + xcol);
     }
   };
   if (m_begin < m_end) issue(m_begin);
@@ -464,8 +466,11 @@ extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
 }
 
 // part_w: fp32 [Z][N][K], part_b: fp32 [Z][N] or NULL, Z = tdeed_wgrad_slices(M, N, K); dW [N][K], db [N] (fp32)
-extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* part_w,
-                           float* part_b, float* dW, float* db, int accumulate, int dtype, void* stream) {
+extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, const void* X0, long ldx0, int k0, int M,
+                           int N, int K, float* part_w, float* part_b, float* dW, float* db, int accumulate, int dtype,
+                           void* stream) {
+  TD_CHECK(!X0 || (k0 > 0 && k0 % 8 == 0 && k0 <= K && ldx0 % 8 == 0 && dtype == TDEED_BF16 && M >= 4096),
+           "wgrad: the spliced X operand needs bf16, M >= 4096 and k0 a multiple of 8");
   TD_CHECK(dY && X && part_w && (dW || accumulate < 0) && (!db || part_b), "wgrad: null pointer");
   TD_CHECK(M > 0 && N > 0 && K > 0, "wgrad: bad sizes");
   const int Z = tdeed_wgrad_slices(M, N, K);
@@ -478,9 +483,10 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, in
     static const bool valu = getenv("TDEED_WGRAD_VALU") && atoi(getenv("TDEED_WGRAD_VALU")) == 1;
     static const bool scatter = getenv("TDEED_WGRAD_SCATTER") && atoi(getenv("TDEED_WGRAD_SCATTER")) == 1;
     const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
+    TD_CHECK(!X0 || (!valu && vec_ok && !scatter), "wgrad: the spliced X operand needs the transposing-read kernel");
     if (!valu && vec_ok && !scatter && M >= 4096)               // long contractions: transposing LDS reads, 64-row chunks
-      hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
-                         part_w, (db || accumulate < 0) ? part_b : nullptr);
+      hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx,
+                         (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w, (db || accumulate < 0) ? part_b : nullptr);
     else if (!valu && vec_ok)
       hipLaunchKernelGGL(wgrad_mfma_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M, N, K,
                          part_w, (db || accumulate < 0) ? part_b : nullptr);

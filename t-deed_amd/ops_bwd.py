@@ -60,22 +60,30 @@ def materialize(g):
     return g.materialize() if isinstance(g, LazyFold) else g
 
 
-def wgrad(dY, X, with_bias=True, dW=None, db=None, accumulate=False, M=None):
+def wgrad_splice_ok(dtype, M):
+    """whether wgrad(X0=..., k0=...) is served (bf16, long contractions: the transposing-read kernel)"""
+    return dtype == torch.bfloat16 and M >= 4096
+
+
+def wgrad(dY, X, with_bias=True, dW=None, db=None, accumulate=False, M=None, X0=None, k0=0):
     """dW[n][k] = sum_m dY[m][n] X[m][k]; db[n] = sum_m dY[m][n].  dY (M,N), X (M,K) in the activation dtype.
+    X0 (M,k0): columns k < k0 of the X operand come from X0 (the gate-shift splice, never materialised).
     With LAZY_WGRAD set (and no caller-provided outputs) the results are LazyFold objects."""
     N, K = dY.shape[-1], X.shape[-1]
+    x0a = (ptr(X0), (X0.shape[-1] if X0 is not None else 0), int(k0) if X0 is not None else 0)
     M = dY.numel() // N if M is None else M
     Z = _lib.load().tdeed_wgrad_slices(M, N, K)
     dev = dY.device
     if LAZY_WGRAD and dW is None and db is None and not accumulate:
         pw, pb = _f32((Z, N, K), dev), (_f32((Z, N), dev) if with_bias else None)
-        call("tdeed_wgrad", ptr(dY), N, ptr(X), K, M, N, K, ptr(pw), ptr(pb), None, None, -1, dtype_code(dY.dtype), stream_ptr())
+        call("tdeed_wgrad", ptr(dY), N, ptr(X), K, *x0a, M, N, K, ptr(pw), ptr(pb), None, None, -1, dtype_code(dY.dtype),
+             stream_ptr())
         return LazyFold(pw, Z, N * K, (N, K)), (LazyFold(pb, Z, N, (N,)) if with_bias else None)
     dW = _f32((N, K), dev) if dW is None else dW
     if with_bias and db is None:
         db = _f32((N,), dev)
     pw, pb = _f32((Z, N, K), dev), (_f32((Z, N), dev) if with_bias else None)
-    call("tdeed_wgrad", ptr(dY), N, ptr(X), K, M, N, K, ptr(pw), ptr(pb), ptr(dW), ptr(db if with_bias else None),
+    call("tdeed_wgrad", ptr(dY), N, ptr(X), K, *x0a, M, N, K, ptr(pw), ptr(pb), ptr(dW), ptr(db if with_bias else None),
          int(accumulate), dtype_code(dY.dtype), stream_ptr())
     return dW, db
 

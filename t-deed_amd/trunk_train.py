@@ -158,13 +158,13 @@ class BottleneckTrain:
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
 
-    def _conv1x1(self, a, w, M, N):
+    def _conv1x1(self, a, w, M, N, A0=None, k0=0):
         """raw 1x1 conv; with the column statistics of its output from the epilogue -> (z, part | None)"""
         if not self.epi_stats:
-            return ops.gemm(a, w, None, None, ops.ACT_NONE, M=M), None
+            return ops.gemm(a, w, None, None, ops.ACT_NONE, M=M, A0=A0, k0=k0), None
         P = ops.gemm_colpart_rows(M)
         cp = torch.empty((P, 2, N), dtype=torch.float32, device=a.device)
-        z = ops.gemm(a, w, None, None, ops.ACT_NONE, M=M, colpart=cp)
+        z = ops.gemm(a, w, None, None, ops.ACT_NONE, M=M, colpart=cp, A0=A0, k0=k0)
         flat = cp.view(-1)
         return z, (flat, flat[N:], 2 * N, P)
 
@@ -174,13 +174,20 @@ class BottleneckTrain:
         N, h, w, Cin = x.shape
         C = blk.cout
         c = SimpleNamespace(x=x)
+        c.G = None
         if self.gs is not None:
             Fp = self.gs.Fp
-            c.a1 = x.clone()                                                    # conv1 operand: [G | x[..., Fp:]]
-            c.a1.view(-1, Cin)[:, :Fp] = self.gs.forward(x)
+            G = self.gs.forward(x)
+            if B_.wgrad_splice_ok(self.dt, N * h * w) and _os.environ.get("TDEED_TRAIN_SPLICE", "1") == "1":
+                # conv1 operand [G | x[..., Fp:]] is never built: the contraction and its weight gradient read the first Fp
+                # columns from G and the rest from x (shift.py:89-93 as an operand splice, like the inference path)
+                c.a1, c.G = x, G
+            else:
+                c.a1 = x.clone()
+                c.a1.view(-1, Cin)[:, :Fp] = G
         else:
             c.a1 = x
-        z1, part = self._conv1x1(c.a1, self.w1.w, N * h * w, C)
+        z1, part = self._conv1x1(c.a1, self.w1.w, N * h * w, C, A0=c.G, k0=(self.gs.Fp if c.G is not None else 0))
         c.z1 = z1.view(N, h, w, C)
         onload = (self.onload and part is not None and self.w2frag is not None
                   and ops.gconv3x3_mfma_fits(h, w, C, blk.stride))
@@ -260,7 +267,8 @@ class BottleneckTrain:
         bn_names("conv1", dw, db)
         Nf, h, w, Cin = c.x.shape
         dx = ops.gemm(dz1, self.w1.wt, None, None, ops.ACT_NONE).view(Nf, h, w, Cin)
-        grads[self.c1 + ".conv.weight"] = B_.wgrad(dz1, c.a1, with_bias=False, M=Nf * h * w)[0].reshape(
+        grads[self.c1 + ".conv.weight"] = B_.wgrad(dz1, c.a1, with_bias=False, M=Nf * h * w, X0=c.G,
+                                                   k0=(self.gs.Fp if c.G is not None else 0))[0].reshape(
             sd[self.c1 + ".conv.weight"].shape)
         if self.gs is not None:
             Fp = self.gs.Fp

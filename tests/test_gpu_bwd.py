@@ -699,3 +699,28 @@ def test_lazy_weight_gradients_give_the_same_step(monkeypatch):
         res[flag] = (loss.clone(), eng.params.flat.clone(), eng.params.grad.clone())
     assert torch.equal(res["1"][0], res["0"][0])
     assert torch.equal(res["1"][2], res["0"][2]) and torch.equal(res["1"][1], res["0"][1])
+
+
+def test_conv1_operand_splice_gives_the_same_step(monkeypatch):
+    """s3 / s4 conv1 of a gate-shift block: contraction and weight gradient reading [G | x[:, Fp:]] as two sources
+    (TDEED_TRAIN_SPLICE=1, default, for M >= 4096 rows) against the materialised operand: bit-identical step."""
+    from tdeed_amd.trainer import TrainEngine
+    from tdeed_amd import synth, state_layout
+    cfg = dict(feature_arch="rny002_gsf", clip_len=24, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 1, 24, 224, 224                                 # s3: 24 frames x 14 x 14 = 4704 rows
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 53).items()}
+    frames = t(synth.uint8_clip(841, (B, T, 3, H, W))).to(DEV)
+    lab_np, labD_np = synth.labels(842, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long().to(DEV), t(labD_np).float().to(DEV)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TDEED_TRAIN_SPLICE", flag)
+        eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=torch.bfloat16, lr=1e-3)
+        loss = eng.step(frames, lab, labD)
+        torch.cuda.synchronize()
+        spliced = [b.ctx.G is not None for b in eng.blocks if b.gs is not None]
+        assert any(spliced) == (flag == "1")
+        res[flag] = (loss.clone(), eng.params.grad.clone(), eng.params.flat.clone())
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
