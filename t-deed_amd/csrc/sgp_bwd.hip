@@ -37,14 +37,61 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// few partials (P < 64): one thread per output (or per 4 outputs when rows are 16-byte aligned), the P rows summed in
+// order with 8 loads in flight -- a 64-column x 4-lane workgroup per 64 outputs is pure dispatch overhead when a step folds
+// tens of millions of weight-gradient elements from 3-4 partial slices each.  tdeed_multi_fold sums in the same order.
+__device__ __forceinline__ float fold_seq1(const float* __restrict__ src, int P, long pstride, long j) {
+  float s = 0.f;
+  for (int p0 = 0; p0 < P; p0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long)min(p0 + u, P - 1) * pstride + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += p0 + u < P ? v[u] : 0.f;
+  }
+  return s;
+}
+__device__ __forceinline__ f32x4 fold_seq4(const float* __restrict__ src, int P, long pstride, long j) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int p0 = 0; p0 < P; p0 += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)min(p0 + u, P - 1) * pstride + j);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u < P) s += v[u];
+  }
+  return s;
+}
+__global__ __launch_bounds__(256) void reduce_seq_kernel(const float* __restrict__ part, int P, long stride, long n,
+                                                         float* __restrict__ out, int accumulate, int vec) {
+  if (vec) {
+    const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= n) return;
+    f32x4 s = fold_seq4(part, P, stride, j);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(out + j);
+    *reinterpret_cast<f32x4*>(out + j) = s;
+  } else {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float s = fold_seq1(part, P, stride, j);
+    out[j] = accumulate ? out[j] + s : s;
+  }
+}
+
 static void launch_reduce(const float* part, int P, long stride, long n, float* out, int accumulate, hipStream_t st) {
-  // few partials: 64 columns x 4 lanes; many partials of a narrow output: 8 columns x 32 lanes (more workgroups, shorter chains)
+  if (P < 64) {
+    const int vec = (n % 4 == 0 && stride % 4 == 0 && ((uintptr_t)part % 16) == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
+    const long per = vec ? 1024 : 256;
+    hipLaunchKernelGGL(reduce_seq_kernel, dim3((unsigned)((n + per - 1) / per)), dim3(256), 0, st, part, P, stride, n, out,
+                       accumulate, vec);
+    return;
+  }
+  // many partials of a narrow output: 8 columns x 32 lanes (more workgroups, shorter chains), else 32 columns x 8 lanes
   if (P >= 512 && n <= 4096)
     hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
-  else if (P >= 64)
-    hipLaunchKernelGGL(reduce_partials_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
   else
-    hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, P, stride, n, out, accumulate);
 }
 
 extern "C" int tdeed_reduce_partials(const float* part, int P, long n, float* out, int accumulate, void* stream) {
@@ -114,6 +161,22 @@ __global__ __launch_bounds__(256) void multi_fold_kernel(const FoldEnt* __restri
     }
     return;
   }
+  if (cw == 1024) {                                              // few partials, 16-byte aligned rows: 4 outputs per thread
+    const long j = w * 1024 + threadIdx.x * 4;
+    if (j >= e.n) return;
+    f32x4 sv = fold_seq4(e.src, P, e.pstride, j);
+    sv *= scale;
+    if (accumulate) sv += *reinterpret_cast<const f32x4*>(dst + e.off + j);
+    *reinterpret_cast<f32x4*>(dst + e.off + j) = sv;
+    return;
+  }
+  if (cw == 256) {                                               // few partials: one output per thread
+    const long j = w * 256 + threadIdx.x;
+    if (j >= e.n) return;
+    const float a = scale * fold_seq1(e.src, P, e.pstride, j);
+    dst[e.off + j] = accumulate ? dst[e.off + j] + a : a;
+    return;
+  }
   const int PL = 256 / cw;
   const int c = threadIdx.x % cw, pl = threadIdx.x / cw;
   const long j = w * cw + c, jj = min(j, e.n - 1);
@@ -139,8 +202,9 @@ __global__ __launch_bounds__(256) void multi_fold_kernel(const FoldEnt* __restri
 // columns x 32 lanes, else 32 x 8 or 64 x 4 (the same rule as tdeed_reduce_partials)
 extern "C" int tdeed_multi_fold_cw(int P, long n) {
   if (P <= 1) return 4096;
+  if (P < 64) return n % 4 == 0 ? 1024 : 256;                    // sequential folds (the caller's rows are 16-byte aligned)
   if (P >= 512 && n <= 4096) return 8;
-  return P >= 64 ? 32 : 64;
+  return 32;
 }
 
 extern "C" int tdeed_multi_fold(const void* tab, int nt, long n_wgs, float* dst, float scale, int accumulate, void* stream) {
