@@ -724,3 +724,34 @@ def test_conv1_operand_splice_gives_the_same_step(monkeypatch):
         res[flag] = (loss.clone(), eng.params.grad.clone(), eng.params.flat.clone())
     assert torch.equal(res["1"][0], res["0"][0])
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradient_accumulation_over_micro_batches(dtype):
+    """`acc_grad_iter` of the reference's step() (model.py:321-332: loss / acc_grad_iter, optimizer step every acc_grad_iter
+    batches): two accumulate() calls with scale 1/2 (overwrite, then add -- the bucket write-out folds the weight-gradient
+    partials and accumulates in the same launch) leave the mean of the two micro-batch gradients in the flat buffer."""
+    from tdeed_amd.trainer import TrainEngine
+    from tdeed_amd import synth, state_layout
+    cfg = dict(feature_arch="rny002_gsf", clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, 8, 64, 64
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 59).items()}
+    batches = []
+    for i in range(2):
+        frames = t(synth.uint8_clip(851 + i, (B, T, 3, H, W))).to(DEV)
+        lab_np, labD_np = synth.labels(861 + i, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+        batches.append((frames, t(lab_np).long().to(DEV), t(labD_np).float().to(DEV)))
+    eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dtype, lr=1e-3)
+    eng.accumulate(*batches[0], scale=0.5, first=True)
+    eng.accumulate(*batches[1], scale=0.5, first=False)
+    torch.cuda.synchronize()
+    acc = eng.params.grad.clone()
+    ref = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dtype, lr=1e-3)
+    want = torch.zeros_like(acc)
+    for b in batches:
+        _, grads = ref.loss_and_grads(*b)
+        for k, (o, n) in ref.params.index.items():
+            want[o:o + n] += 0.5 * grads[k].reshape(-1)
+    torch.cuda.synchronize()
+    assert rel_err(acc, want) < (1e-5 if dtype == torch.float32 else 1e-5)
