@@ -13,6 +13,11 @@ LIB = os.path.join(CSRC, "libtdeed_hip.so")
 SOURCES = ["gemm.hip", "conv.hip", "front.hip", "gsf.hip", "sgp.hip", "sgp_fused.hip", "sgp_bwd.hip", "trunk_bwd.hip", "gsf_bwd.hip", "train.hip", "misc.hip", "augment.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall",
          "-Wno-unused-function"]
+# MFMA accumulators in VGPRs instead of AGPRs for the files whose epilogues are VALU-bound: every accumulator element
+# otherwise costs a v_accvgpr_read before the BatchNorm / ReLU arithmetic (s1_front: 24 of ~170 vector instructions per
+# 16-pixel tile).  Not for the tiled GEMM: its 64 accumulator registers would leave the VGPR budget of 3 waves per SIMD.
+VGPR_MFMA = set(filter(None, os.environ.get("TDEED_VGPR_MFMA", "front.hip").split(",")))
+EXTRA = {s: ["-mllvm", "-amdgpu-mfma-vgpr-form"] for s in VGPR_MFMA}
 
 
 def _hipcc():
@@ -38,7 +43,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, "-c", src, "-o", obj])
+            jobs.append([_hipcc(), *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

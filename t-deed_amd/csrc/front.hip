@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
         const int ky = s >> 1, half = s & 1;
         const int prow = (s < 6) ? (2 * r - 1 + ky - in_r0) : 0;
         const int pcol = (s < 6) ? (2 * cc + 2 * half) : 0;
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(inp + ((long)prow * INW + pcol) * 4);
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(inp + (prow * INW + pcol) * 4);       // LDS offsets: 32-bit
         sa[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][ks], xf, sa[0], 0, 0, 0);
         sa[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][ks], xf, sa[1], 0, 0, 0);
       }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
         sf[e] = (bf16_t)fmaxf(sa[0][e] * ssc[e] + ssh[e], 0.f);
         sf[4 + e] = (bf16_t)fmaxf(sa[1][e] * ssc[4 + e] + ssh[4 + e], 0.f);
       }
-      unsigned char* y1p = y1t + ((long)(r - y1r0) * Y1W + (cc + 1)) * p.PS;
+      unsigned char* y1p = y1t + ((r - y1r0) * Y1W + (cc + 1)) * p.PS;
       const bool do_ds = ((r & 1) == 0) && (r >> 1) >= oy0 && (r >> 1) < oy0 + nrows_out;
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
       const int pc = pok ? pp : 0;
       int oyl, ox;
       dwo.divmod(pc, oyl, ox);
-      const unsigned char* base = y1t + ((long)(oyl * 2) * Y1W + ox * 2) * p.PS;
+      const unsigned char* base = y1t + ((oyl * 2) * Y1W + ox * 2) * p.PS;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) {
