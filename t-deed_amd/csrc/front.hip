@@ -16,6 +16,21 @@
 #include "common.h"
 #include <stdlib.h>
 
+// ReLU on packed bf16: a negative value has its sign bit set, i.e. is negative as a signed 16-bit integer, so one
+// v_pk_max_i16 against 0 clamps two elements (the kernel is bound by vector-ALU issue: this halves its ReLU instructions)
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 relu_bf16x8(bf16x8 v) {
+  short8v s = __builtin_bit_cast(short8v, v);
+  s = __builtin_elementwise_max(s, (short8v)(0));
+  return __builtin_bit_cast(bf16x8, s);
+}
+__device__ __forceinline__ bf16x4 relu_bf16x4(bf16x4 v) {
+  short4v s = __builtin_bit_cast(short4v, v);
+  s = __builtin_elementwise_max(s, (short4v)(0));
+  return __builtin_bit_cast(bf16x4, s);
+}
+
 struct FrontP {
   const uint8_t* frames; int H, W, top, left, ch, cw, flip;
   const bf16x8* stem_wf;  const float* stem_sc; const float* stem_sh;     // [2][2][64]
@@ -178,9 +193,10 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
       bf16x8 sf;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sf[e] = (bf16_t)fmaxf(sa[0][e] * ssc[e] + ssh[e], 0.f);
-        sf[4 + e] = (bf16_t)fmaxf(sa[1][e] * ssc[4 + e] + ssh[4 + e], 0.f);
+        sf[e] = (bf16_t)(sa[0][e] * ssc[e] + ssh[e]);
+        sf[4 + e] = (bf16_t)(sa[1][e] * ssc[4 + e] + ssh[4 + e]);
       }
+      sf = relu_bf16x8(sf);
       unsigned char* y1p = y1t + ((r - y1r0) * Y1W + (cc + 1)) * p.PS;
       const bool do_ds = ((r & 1) == 0) && (r >> 1) >= oy0 && (r >> 1) < oy0 + nrows_out;
 #pragma unroll
@@ -191,8 +207,8 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
         if (cok) {          // channels >= C1 get exact zeros (their scale/shift are 0): the band needs no pre-clear
           bf16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(a1[e] * c1s[t][e] + c1h[t][e], 0.f);
-          *reinterpret_cast<bf16x4*>(y1p + ch0 * 2) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(a1[e] * c1s[t][e] + c1h[t][e]);
+          *reinterpret_cast<bf16x4*>(y1p + ch0 * 2) = relu_bf16x4(o);
         }
         if (do_ds) {
           f32x4 ad = {0.f, 0.f, 0.f, 0.f};
@@ -254,10 +270,10 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
       if (pok && ch0 < p.C1) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = (bf16_t)fmaxf(acc[r] * sc[r] + sh[r], 0.f);
-          psum[r] += (float)o[r];
-        }
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[r] * sc[r] + sh[r]);
+        o = relu_bf16x4(o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psum[r] += (float)o[r];
         *reinterpret_cast<bf16x4*>(yout + (long)pc * p.C1 + ch0) = o;
       }
     }
