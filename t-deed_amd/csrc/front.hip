@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
   bf16_t* inp = reinterpret_cast<bf16_t*>(smem);                       // [nin][INW][4]
   const int in_bytes = ((2 * (2 * (p.band - 1) + 3 - 1) + 3) * INW * 8 + 15) & ~15;
   unsigned char* y1t = smem + in_bytes;                                 // [ny1][Y1W][PS]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the wave index as a scalar: tile loops and their index arithmetic then run on the scalar unit (the kernel is bound by
+  // vector-ALU issue)
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, q = lane >> 4;
 
   // ---- A. fill the patch: normalised input as bf16 [row][col][RGB0]; zero halo columns / rows outside the
