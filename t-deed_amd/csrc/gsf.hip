@@ -418,6 +418,24 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     const int PSQ = ps16 * 16, KSq = (9 * nch + 3) / 4;
     const long wbytes = (long)KSq * 64 * 16;
     int bq = (int)((60 * 1024 - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
+    long q_cap = 60 * 1024;
+    if (bq < 1) {
+      // wide slices (F = 196 of RegNetY-800MF s4: 58 KB of tap-weight fragments alone): up to 150 KB of LDS, one
+      // workgroup per CU, instead of falling back to the vector-ALU tap kernel (118 vs ~35 us per site)
+      q_cap = 150 * 1024;
+      bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
+      if (bq >= 1) {
+        static bool attr_q = false;
+        if (!attr_q) {
+          if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+              hipSuccess) {
+            tdeed_set_error("gsf_gate: hipFuncSetAttribute failed");
+            return TDEED_ERR_RUNTIME;
+          }
+          attr_q = true;
+        }
+      }
+    }
     const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F + 4 * KSq) * sizeof(float);
     // opt-in (TDEED_GSF_MERGE=1): one launch fewer, but the three staging phases run back to back inside each
     // workgroup and the site gets slower on MI355X (85 vs 52 us at 14x14, F=40, 400 frames)
