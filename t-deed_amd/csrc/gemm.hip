@@ -251,6 +251,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   float cs1[EPC], cs2[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) cs1[e] = cs2[e] = 0.f;
+  // residual chunks of both passes are requested NOW (bf16: 2 x BN / 32 x 16 bytes per thread, in the registers the operand
+  // staging no longer needs): they travel while the accumulators go through LDS, instead of one exposed round trip per pass
+  // (a 320 x 320 layer over 156800 rows: 112 -> ~85 us)
+  constexpr bool RPRE = sizeof(T) == 2;
+  constexpr int NPT = (64 * CPR + 255) / 256;
+  u32x4 rres[RPRE ? 2 : 1][RPRE ? NPT : 1];
+  if constexpr (RPRE) {
+    if (p.R) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+          const int idx = min(tid + it * 256, 64 * CPR - 1);
+          const int row = idx / CPR, cj = idx - row * CPR;
+          const long m = min(m0 + half * 64 + row, (long)p.M - 1);
+          const int n = min(n0 + cj * EPC, p.N - EPC);
+          rres[half][it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + m * p.ldr + n);
+        }
+    }
+  }
   for (int half = 0; half < 2; ++half) {
     if (wr == half) {
 #pragma unroll
@@ -265,7 +285,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
           }
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx >= 64 * CPR) break;
       int row = idx / CPR, cj = idx - row * CPR;
       long m = m0 + half * 64 + row;
       int n = n0 + cj * EPC;
@@ -275,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         for (int e = 0; e < EPC; ++e) v[e] = cs[row * CS_LD + cj * EPC + e];
         if (p.R) {
           float rv[EPC];
-          Chunk<T>::load(reinterpret_cast<const T*>(p.R) + m * p.ldr + n, rv);
+          if constexpr (RPRE) Chunk<T>::load(reinterpret_cast<const T*>(&rres[half][it]), rv);
+          else Chunk<T>::load(reinterpret_cast<const T*>(p.R) + m * p.ldr + n, rv);
 #pragma unroll
           for (int e = 0; e < EPC; ++e) v[e] += rv[e];
         }

@@ -133,7 +133,10 @@ class GradReducer:
         self.backend = backend
         self.capturable = backend == "rccl"
         self._works = []
-        self._side = torch.cuda.Stream(device=flat.device) if (backend == "torch" and flat.is_cuda) else None
+        self._side = None
+        if backend == "torch" and flat.is_cuda:
+            from .streams import new_stream
+            self._side = new_stream(flat.device)
         self._comm = RcclComm(device if device is not None else flat.device) if backend == "rccl" else None
 
     def reduce_bucket(self, i):

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import ops, _lib
+from .streams import new_stream
 from .regnet_spec import regnet_spec, sgp_up_size, pyramid_lengths
 
 BN_EPS = 1e-5
@@ -623,6 +624,20 @@ class PackedWeights:
         self.W = W
 
 
+_DEAD_GRAPHS = []          # graph executables of dropped engines, destroyed by _drain_dead_graphs()
+_CAPTURING = 0
+
+
+def _drain_dead_graphs():
+    """Destroy the graph executables of engines that were garbage-collected (safe point: no capture in progress; the device
+    is synchronised first so that none of them is still executing)."""
+    if not _DEAD_GRAPHS or _CAPTURING:
+        return
+    torch.cuda.synchronize()
+    while _DEAD_GRAPHS:
+        _lib.call("tdeed_graph_destroy", _DEAD_GRAPHS.pop())
+
+
 class ForwardEngine:
     def __init__(self, cfg, state, act_dtype=torch.bfloat16, device="cuda", use_graph=True, fuse_front=True, n_split=2):
         if not torch.cuda.is_available():
@@ -861,7 +876,10 @@ class ForwardEngine:
             else:
                 subs = [self._build(Bs, H, W, bool(flip), set(), head_out=head_out[i * Bs * T:(i + 1) * Bs * T])
                         for i in range(ns)]
-            plan = SimpleNamespace(subs=subs, streams=[None] + [torch.cuda.Stream(device=self.device) for _ in range(ns - 1)],
+            forks = []
+            for _ in range(ns - 1):
+                forks.append(new_stream(self.device, avoid=forks))
+            plan = SimpleNamespace(subs=subs, streams=[None] + forks,
                                    head_out=head_out, keep=subs[0].keep, graph=None, tail=tail,
                                    steps=[st for sb in subs for st in sb.steps] + (tail.steps if tail else []),
                                    pool_bytes=sum(sb.pool_bytes for sb in subs) + (tail.pool_bytes if tail else 0), B=B, T=T)
@@ -886,7 +904,7 @@ class ForwardEngine:
         fork.record(main)
         joins = []
         for sb, st in zip(plan.subs, plan.streams):
-            if st is None:
+            if st is None or st.cuda_stream == main.cuda_stream:   # (the pool handed the launching stream out again)
                 for s_ in sb.steps:
                     s_.fn()
             else:
@@ -912,15 +930,29 @@ class ForwardEngine:
         if st.cuda_stream == 0:
             raise RuntimeError("graph replay needs a non-default stream: wrap the call in torch.cuda.stream(s)")
         if plan.graph is None:
+            _drain_dead_graphs()
             self._launch_all(plan, st)         # warm-up launch (module load, validates arguments)
             st.synchronize()
             import ctypes
+            import gc
+            # no cyclic garbage collection between begin and end of the capture: the finaliser of an engine that an earlier
+            # caller dropped would otherwise run here at a random allocation and call into the HIP runtime (graph
+            # destruction, frees) from the capturing thread -- the graph launched afterwards then crashed the host
+            global _CAPTURING
+            gc_was = gc.isenabled()
+            gc.disable()
+            _CAPTURING += 1
             _lib.call("tdeed_graph_begin", st.cuda_stream)
             try:
                 self._launch_all(plan, st)     # forked streams join the capture through the fork event
             finally:
                 h = ctypes.c_void_p()
-                _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
+                try:
+                    _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
+                finally:
+                    _CAPTURING -= 1
+                    if gc_was:
+                        gc.enable()
             plan.graph = h
         _lib.call("tdeed_graph_launch", plan.graph, st.cuda_stream)
 
@@ -938,9 +970,13 @@ class ForwardEngine:
         return plan.head_out, plan
 
     def __del__(self):
+        # graph executables are not destroyed from a finaliser (it may run at any allocation, e.g. inside another engine's
+        # capture, and the graph may still be executing): they are parked and destroyed at the next plan build, after a
+        # device synchronisation
         try:
             for p in self._plans.values():
                 if p.graph is not None:
-                    _lib.call("tdeed_graph_destroy", p.graph)
+                    _DEAD_GRAPHS.append(p.graph)
+                    p.graph = None
         except Exception:
             pass

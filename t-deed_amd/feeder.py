@@ -80,7 +80,8 @@ class PinnedRing:
         self.dev = [torch.empty(self.shape, dtype=torch.uint8, device=device) for _ in range(depth)]
         self.copied = [None] * depth            # event: H2D copy of the slot finished
         self.consumed = [None] * depth          # event: the consumer is done with the device buffer
-        self.stream = torch.cuda.Stream(device=device)
+        from .streams import new_stream
+        self.stream = new_stream(device)                  # never the consumer's own stream (torch's pool wraps around)
         self.i = 0
 
     def next_slot(self):

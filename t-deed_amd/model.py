@@ -271,7 +271,8 @@ class TDEEDModel:
 
     def _ctx(self):
         if self._stream is None:
-            self._stream = torch.cuda.Stream()
+            from .streams import new_stream
+            self._stream = new_stream()
         return torch.cuda.stream(self._stream)
 
     def predict(self, seq, use_amp=True, augment_inference=False):
@@ -310,10 +311,11 @@ class TDEEDModel:
         map_labels, map_preds = [], []
         n = 0
         # two batches in flight: consecutive batches alternate between two buffer sets / HIP graphs on two streams
+        from .streams import new_stream
         if self._stream is None:
-            self._stream = torch.cuda.Stream()
+            self._stream = new_stream()
         if getattr(self, "_stream2", None) is None:
-            self._stream2 = torch.cuda.Stream()
+            self._stream2 = new_stream(avoid=[self._stream])
         streams = [self._stream, self._stream2]
         totals = [torch.zeros((), dtype=torch.float32, device=self.device) for _ in streams]
         torch.cuda.current_stream().synchronize()     # w / totals were filled on the current stream; the two are non-blocking

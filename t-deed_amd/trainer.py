@@ -17,6 +17,7 @@ import os
 import torch
 
 from . import ops, ops_bwd as B_
+from .streams import new_stream
 from .optim import FlatParams, FusedAdamW, warmup_cosine_lr
 from .regnet_spec import regnet_spec
 from .temporal_train import TemporalStack
@@ -305,7 +306,7 @@ class TrainEngine:
                                           reduce=in_graph, fg_weight=fg_weight)
             # eager warm-up on a side stream (lazy kernel attributes / module loads must happen outside the capture); the
             # BatchNorm buffers it touches are restored afterwards
-            side = torch.cuda.Stream()
+            side = new_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self.repack()
@@ -325,7 +326,7 @@ class TrainEngine:
             h.graph, h.graph_b, h.mode, h.reduce_in_graph = g, None, "one", in_graph
 
         def capture_two():
-            side = torch.cuda.Stream()
+            side = new_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self.repack()

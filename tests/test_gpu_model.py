@@ -129,6 +129,33 @@ def test_graph_replay_equals_eager_and_is_deterministic():
     assert torch.equal(e2, h1)
 
 
+def test_sub_batch_fork_survives_torchs_wrapping_stream_pool():
+    """torch.cuda.Stream() hands out the next of 32 pooled streams: in a long-lived process the stream a sub-batch is forked
+    onto can be the very stream that launches (and captures) the forward.  That sub-batch then runs inline; new_stream()
+    never returns the current stream.  (The captured graph of such a plan used to crash the host in hipGraphLaunch.)"""
+    from tdeed_amd.streams import new_stream
+    meta, g = load_golden("tiny_rny002_gsf")
+    cfg = meta["cfg"]
+    sd = model_state(cfg, 0)
+    clip = t(synth.uint8_clip(5, (2, cfg["clip_len"], 3, 64, 64))).to(DEV)
+    ref, _ = _run(_engine(cfg, sd, torch.bfloat16, use_graph=True, n_split=2), clip.cpu().numpy())
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        seen = {new_stream().cuda_stream for _ in range(80)}           # more than the pool holds
+        assert st.cuda_stream not in seen and len(seen) > 8
+        a = new_stream()
+        assert new_stream(avoid=[a]).cuda_stream not in (a.cuda_stream, st.cuda_stream)
+        eng = _engine(cfg, sd, torch.bfloat16, use_graph=True, n_split=2)
+        plan = eng.plan(2, 64, 64)
+        assert len(plan.subs) == 2 and plan.streams[1].cuda_stream != st.cuda_stream
+        plan.streams[1] = st                                              # what a wrapped pool used to produce
+        eng.set_frames(plan, clip)
+        eng.run_plan(plan)                                                # warm-up + capture + launch
+        eng.run_plan(plan)                                                # replay
+        st.synchronize()
+        assert torch.equal(plan.head_out.float().cpu(), ref)
+
+
 def test_model_api_predict_and_epoch():
     """TDEEDModel drop-in surface: predict() against the reference's own predict() output, epoch() val loss
     against the oracle loss, state_dict round trip."""
