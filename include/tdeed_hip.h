@@ -72,12 +72,15 @@ int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top,
  * K, N, k0, lda, lda0, ldw, ldr, ldc must be multiples of 8.
  *   colpart  optional fp32 [ceil(M/128)][2][N]: per 128-row tile the column sums and sums of squares of the stored C
  *       (training: the BatchNorm batch statistics of a raw conv output come out of the conv's own epilogue; fold them
- *       with tdeed_bn_finalize(colpart, colpart + N, 2N, ceil(M/128), M, N, ...)). */
+ *       with tdeed_bn_finalize(colpart, colpart + N, 2N, ceil(M/128), M, N, ...)).
+ *   C2  optional second output [M][n2] row stride ldc2 (n2, ldc2 multiples of 8, n2 <= N): a compact copy of columns
+ *       [0, n2) of C.  The next bottleneck's gate-shift reads only that channel slice (shift.py:46-93), three times; out of
+ *       the channels-last map every such read drags whole rows' cache lines along (measured 4.5x the slice's bytes). */
 int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
                    const float* a_scale, int a_scale_rows, int M, int K, int N, const void* W,
                    long ldw, const float* scale, const float* shift, const void* R, long ldr,
                    int act, void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
-                   int gather_ho, int gather_wo, float* colpart, int dtype, void* stream);
+                   int gather_ho, int gather_wo, float* colpart, void* C2, long ldc2, int n2, int dtype, void* stream);
 
 /* Weight-stationary variant of the same contraction for narrow layers (whole W in LDS, activations
  * streamed global->registers in MFMA fragment shape, persistent blocks; see gemm.hip).  Same
@@ -90,7 +93,7 @@ int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long lda0, int k0
                       const float* a_scale, int a_scale_rows, int M, int K, int N, const void* Wfrag,
                       const float* scale, const float* shift, const void* R, long ldr, int act,
                       void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
-                      int gather_ho, int gather_wo, int dtype, void* stream);
+                      int gather_ho, int gather_wo, void* C2, long ldc2, int n2, int dtype, void* stream);
 
 /* ---- grouped 3x3 conv + BN + ReLU + SE squeeze ---------------------------------------------
  * timm Bottleneck.conv2 (groups = C/gw, stride 1|2, pad 1) + BN(eval) + ReLU, and the SE

@@ -28,6 +28,7 @@ struct GemmP {
   void* C; long ldc;
   int g_stride, g_hi, g_wi, g_ho, g_wo;
   float* colpart;      // optional [M tiles][2][N]: per-tile column sums / sums of squares of the stored C (BatchNorm statistics)
+  void* C2; long ldc2; int n2;   // optional second, compact copy of columns [0, n2) of C (the next block's gate-shift slice)
 };
 
 template <typename T> struct Frag;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
           for (int e = 0; e < EPC; ++e) v[e] = gelu_erf(v[e]);
         }
         Chunk<T>::store(reinterpret_cast<T*>(p.C) + m * p.ldc + n, v);
+        if (p.C2 && n < p.n2) Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + n, v);
         if (p.colpart) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
@@ -390,8 +392,10 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
                               const void* W, long ldw, const float* scale, const float* shift,
                               const void* R, long ldr, int act, void* C, long ldc,
                               int gather_stride, int gather_hi, int gather_wi, int gather_ho,
-                              int gather_wo, float* colpart, int dtype, void* stream) {
+                              int gather_wo, float* colpart, void* C2, long ldc2, int n2, int dtype, void* stream) {
   TD_CHECK(A && W && C, "gemm: null pointer");
+  TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm: bad second output n2=%d ldc2=%ld",
+           n2, ldc2);
   TD_CHECK(M > 0 && K > 0 && N > 0, "gemm: bad sizes M=%d K=%d N=%d", M, K, N);
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gemm: bad dtype %d", dtype);
   const int q = 8;
@@ -411,6 +415,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   p.R = R; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
   p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
   p.colpart = colpart;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st) : launch_gemm<bf16_t>(p, st);
 }
@@ -441,6 +446,7 @@ struct GemmWsP {
   int g_stride, g_hi, g_wi, g_ho, g_wo;
   int NT;                         // n-tiles of the whole matrix
   int NTS;                        // n-tiles per block slice (blockIdx.y selects the slice; == NT when W fits LDS)
+  void* C2; long ldc2; int n2;    // optional second, compact copy of columns [0, n2) of C
 };
 
 // WLDS = false: the weights do not fit LDS (K = N = 368): fragments are read straight from global memory
@@ -574,12 +580,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmWsP p) {
             for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
           }
           T* cp = reinterpret_cast<T*>(p.C) + m * p.ldc + ch;
+          T* cp2 = (p.C2 && ch < p.n2) ? reinterpret_cast<T*>(p.C2) + m * p.ldc2 + ch : nullptr;
 #pragma unroll
           for (int h = 0; h < 8 / EPC; ++h) {
             float o[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o[e] = v[h * EPC + e];
             Chunk<T>::store(cp + h * EPC, o);
+            if (cp2) Chunk<T>::store(cp2 + h * EPC, o);
           }
         }
       }
@@ -662,8 +670,11 @@ extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long l
                                  const float* a_scale, int a_scale_rows, int M, int K, int N,
                                  const void* Wfrag, const float* scale, const float* shift, const void* R,
                                  long ldr, int act, void* C, long ldc, int gather_stride, int gather_hi,
-                                 int gather_wi, int gather_ho, int gather_wo, int dtype, void* stream) {
+                                 int gather_wi, int gather_ho, int gather_wo, void* C2, long ldc2, int n2, int dtype,
+                                 void* stream) {
   TD_CHECK(A && Wfrag && C, "gemm_ws: null pointer");
+  TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2),
+           "gemm_ws: bad second output n2=%d ldc2=%ld", n2, ldc2);
   TD_CHECK(M > 0 && K > 0 && N > 0, "gemm_ws: bad sizes M=%d K=%d N=%d", M, K, N);
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gemm_ws: bad dtype %d", dtype);
   TD_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldc % 8 == 0, "gemm_ws: K, N, lda, ldc must be multiples of 8");
@@ -682,6 +693,7 @@ extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long l
   p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
   p.NT = (N + 31) / 32 * 2;
   p.NTS = p.NT;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm_ws<float>(p, st) : launch_gemm_ws<bf16_t>(p, st);
 }

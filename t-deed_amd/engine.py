@@ -157,6 +157,9 @@ def pack_se_mfma(fc1_w, fc2_w, device):
     return dict(w1f=frag(fc1_w), w2f=frag(fc2_w))
 
 
+GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
+
+
 class DenseW:
     """A dense [N][K] weight in the layout the chosen contraction kernel wants."""
 
@@ -672,7 +675,8 @@ class ForwardEngine:
         N = B * T
         dt = self.act_dtype
         es = _esz(dt)
-        for bw in blocks:
+        xs = None           # compact copy of the first Fp channels of x, written by the producer of x (see below)
+        for bi, bw in enumerate(blocks):
             blk = bw.spec
             M = N * h * w
             # conv1 (optionally behind the gate-shift splice)
@@ -685,7 +689,10 @@ class ForwardEngine:
                           xsum=pool.take((N, F), torch.float32), out=pool.take((M, Fp), dt))
                 if bw.gs_cw1 is not None:
                     gb["fw"] = pool.take((B, F, T), torch.float32)
-                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=x, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
+                # the three gate-shift launches read only channels [0, Fp): from the compact slice the previous block's
+                # conv3 wrote beside its output when there is one (a slice of the channels-last map drags whole cache lines)
+                xg = xs if (xs is not None and xs.shape[-1] == Fp) else x
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
                     bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                 steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
@@ -693,7 +700,7 @@ class ForwardEngine:
                     *gemm_cost(M, blk.cin, blk.cout, es)))
                 if blk.name and ("_features." + blk.name + ".gs_out") in taps:
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
-                gs_bufs = list(gb.values())
+                gs_bufs = list(gb.values()) + ([xs] if xs is not None else [])
             else:
                 steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
                     x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
@@ -719,12 +726,17 @@ class ForwardEngine:
             else:
                 sc = x
             out = (out_last if (out_last is not None and bw is blocks[-1]) else pool.take((N, h2, w2, blk.cout), dt))
-            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
-                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
+            nxt = blocks[bi + 1].spec if bi + 1 < len(blocks) else None
+            xs_next = None
+            if nxt is not None and nxt.gsf_fold and GS_SLICE:
+                xs_next = pool.take((N, h2, w2, (nxt.gsf_fold + 7) // 8 * 8), dt)
+            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: bw.w3.run(
+                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2, out2=xs_next),
                 *gemm_cost(M2, blk.cout, blk.cout, es, True)))
-            # liveness: everything but `out` dies here
+            # liveness: everything but `out` (and the next block's slice) dies here
             for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
+            xs = xs_next
             if not x_kept and hasattr(x, "_td_raw"):
                 pool.give(x)
             tapname = "_features." + blk.name

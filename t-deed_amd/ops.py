@@ -79,10 +79,17 @@ def gemm_colpart_rows(M):
     return (M + 127) // 128
 
 
+def _out2(out2, A):
+    if out2 is None:
+        return None, 0, 0
+    _chk(out2, "out2", A.dtype)
+    return ptr(out2), out2.shape[-1], out2.shape[-1]
+
+
 def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
-         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None, colpart=None):
+         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None, colpart=None, out2=None):
     """C = act((A' @ W^T) * scale + shift + residual).  A (M,K) / W (N,K) same dtype.
-    gather = (stride, hi, wi, ho, wo) for the stride-2 1x1 shortcut."""
+    gather = (stride, hi, wi, ho, wo) for the stride-2 1x1 shortcut.  out2 (.., n2): also receives columns [0, n2)."""
     _chk(A, "A"); _chk(W, "W", A.dtype)
     K = W.shape[1]
     N = W.shape[0]
@@ -99,7 +106,7 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     call("tdeed_gemm_fwd", ptr(A), lda, ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0,
          ptr(a_scale), a_scale_rows, M, K, N, ptr(W), W.shape[1], ptr(scale), ptr(shift),
          ptr(residual), (residual.shape[-1] if residual is not None else 0), act, ptr(out), ldc,
-         g[0], g[1], g[2], g[3], g[4], ptr(colpart), dtype_code(A.dtype), stream_ptr())
+         g[0], g[1], g[2], g[3], g[4], ptr(colpart), *_out2(out2, A), dtype_code(A.dtype), stream_ptr())
     return out
 
 
@@ -113,7 +120,7 @@ def gemm_ws_fits(K, N, act_dtype):
 
 
 def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
-            A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None):
+            A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None, out2=None):
     """Weight-stationary streaming form of gemm(); Wfrag from engine.pack_ws_weights."""
     _chk(A, "A")
     if M is None:
@@ -129,7 +136,7 @@ def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None,
     call("tdeed_gemm_ws_fwd", ptr(A), lda, ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0,
          ptr(a_scale), a_scale_rows, M, K, N, ptr(Wfrag), ptr(scale), ptr(shift),
          ptr(residual), (residual.shape[-1] if residual is not None else 0), act, ptr(out), ldc,
-         g[0], g[1], g[2], g[3], g[4], dtype_code(A.dtype), stream_ptr())
+         g[0], g[1], g[2], g[3], g[4], *_out2(out2, A), dtype_code(A.dtype), stream_ptr())
     return out
 
 

@@ -94,6 +94,32 @@ def test_gemm_se_scale_splice_gather(ops, dtype):
     assert rel_err(out.float(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,n2", [(333, 152, 152, 40), (4097, 152, 152, 40), (1999, 368, 368, 96), (640, 56, 56, 16),
+                                      (257, 56, 152, 40)])
+def test_gemm_second_compact_output(ops, M, K, N, n2, dtype):
+    """out2: the epilogue also stores columns [0, n2) of C as a compact (M, n2) tensor -- the next bottleneck's gate-shift
+    slice (shift.py:46-93 reads only those channels).  Bit-identical to slicing C, in the tiled and the weight-stationary
+    kernel, with the full epilogue (residual + ReLU) in front; guard columns behind n2 stay untouched."""
+    from tdeed_amd.engine import pack_ws_weights
+    A = rnd(201, f"A{M}", (M, K)).to(dtype).to(DEV)
+    W = rnd(202, f"W{N}", (N, K), 1.0 / np.sqrt(K)).to(dtype)
+    R = rnd(203, "R", (M, N)).to(dtype).to(DEV)
+    sh = rnd(204, "sh", (N,)).to(DEV)
+    out2 = torch.full((M, n2), 7.0, dtype=dtype, device=DEV)
+    out = ops.gemm(A, W.to(DEV), None, sh, ops.ACT_RELU, residual=R, out2=out2)
+    assert torch.equal(out2, out[:, :n2])
+    assert torch.equal(out, ops.gemm(A, W.to(DEV), None, sh, ops.ACT_RELU, residual=R))
+    if ops.gemm_ws_fits(K, N, dtype):
+        Wf = pack_ws_weights(W.float().numpy(), dtype, DEV)
+        out2.fill_(7.0)
+        out = ops.gemm_ws(A, Wf, K, N, None, sh, ops.ACT_RELU, residual=R, out2=out2)
+        assert torch.equal(out2, out[:, :n2])
+        assert torch.equal(out, ops.gemm_ws(A, Wf, K, N, None, sh, ops.ACT_RELU, residual=R))
+    with pytest.raises(Exception, match="second output"):
+        ops.gemm(A, W.to(DEV), None, sh, ops.ACT_RELU, out2=torch.empty((M, N + 8), dtype=dtype, device=DEV))
+
+
 WS_SHAPES = [(300, 32, 24), (1000, 24, 24), (257, 24, 56), (640, 56, 56), (999, 56, 152), (4097, 152, 152),
              (500, 64, 128), (130, 128, 128), (777, 368, 368), (300, 152, 368)]
 
