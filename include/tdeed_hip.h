@@ -44,6 +44,17 @@ int tdeed_stem_fwd(const void* frames /* uint8, or fp32 0..255 when frames_f32 (
                    const float* scale /*[32]*/, const float* shift /*[32]*/, void* out,
                    int relu /* 0: raw conv*scale+shift (training) */, int dtype, void* stream);
 
+/* Training stem (bf16): the same pre-processing + conv on the MFMA pipe, RAW conv output z [N][Ho][Wo][32] (BatchNorm runs
+ * on batch statistics in training, model.py:133 under .train()) and per workgroup the per-channel sum / sum of squares of what
+ * it stored: colpart fp32 [N * tdeed_stem_mfma_parts(crop_h, crop_w)][2][32] (fold with tdeed_bn_finalize(colpart,
+ * colpart + 32, 64, N * parts, N*Ho*Wo, 32, ...)).  wfrag: the [2][2][64][8] fragments of tdeed_s1_front_fwd's stem_wf in fp32 (operands are split into bf16 head + tail
+ * in the kernel: three MFMAs per product, z is the fp32 conv rounded once).
+ * frames / crop / flip / flip_mask as tdeed_stem_fwd.  tdeed_stem_mfma_parts == 0: the row band does not fit LDS. */
+int tdeed_stem_mfma_parts(int crop_h, int crop_w);
+int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h,
+                        int crop_w, int flip, const unsigned char* flip_mask, const void* wfrag, void* z, float* colpart,
+                        void* stream);
+
 /* ---- fused trunk front (bf16 only): pre-proc + stem + s1.b1.conv1 + s1.b1.conv2 (+SE squeeze) + s1.b1.downsample
  * uint8 frames [N][3][H][W] -> y2 [N][Ho][Wo][C1] (conv2 output), shortcut [N][Ho][Wo][C1], pooled fp32
  * [N][parts][C1] partial sums of y2 (parts = tdeed_s1_front_parts(crop_h, crop_w, C1)).  The 112^2 stem and conv1

@@ -34,6 +34,8 @@ _SIGS = {
     "tdeed_augment_clips": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P], c_int),
     "tdeed_mix_frames": ([P, P, P, c_int, c_long, P, P], c_int),
     "tdeed_avgpool_posenc_bwd": ([P, c_int, c_int, c_int, c_int, P, P, c_int, P], c_int),
+    "tdeed_stem_mfma_parts": ([c_int, c_int], c_int),
+    "tdeed_stem_mfma_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P], c_int),
     "tdeed_stem_wgrad": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_s1_front_parts": ([c_int, c_int, c_int], c_int),
     "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,

@@ -381,3 +381,246 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
   TD_LAUNCH_CHECK("s1_front");
   return TDEED_OK;
 }
+
+// =============================================================================================
+// Training stem: the same pre-processing + 3x3 stride-2 conv on the MFMA pipe as phase A / B of s1_front_kernel, as its
+// own launch that writes the RAW conv output z0 (bf16; BatchNorm runs on batch statistics in training) and, per workgroup,
+// the per-channel sum / sum of squares of what it stored -- the BatchNorm statistics come out of the conv's epilogue instead
+// of a second pass over the 112^2 x 32 map.  One workgroup = one frame x a band of output rows; the normalised input band
+// ([row][col][RGB0] bf16, zero halo) sits in LDS, a lane's 8 k-values (two horizontally adjacent taps) are one 16-byte
+// read, 2 k-steps x 2 channel tiles per 16 pixels.  The VALU stem (train.hip) spends 27 x 32 FMAs per pixel and ran at a
+// quarter of what writing z0 costs (519 vs ~120 us for 800 frames of 224^2).
+// Precision: both operands are split into a bf16 head and a bf16 tail (x = xh + xl, w = wh + wl) and the product is taken as
+// wh xh + wh xl + wl xh (three MFMAs, fp32 accumulation; the dropped wl xl term is 2^-16 of the result), so z0 is the fp32
+// conv rounded once to bf16 like the VALU stem's -- rounding the operands themselves to bf16 (as the inference front may)
+// measurably degrades the gradient direction of the noise-prone small tensors (SE weights) in training.
+struct StemP {
+  const void* frames; int H, W, top, left, ch, cw, flip;
+  const unsigned char* flip_mask;
+  const float* wf;                                  // [2][2][64][8] fp32 fragments (engine.stem_frags_on_device)
+  bf16_t* z; float* colpart;                        // z [N][Hs][Ws][32]; colpart [N * nbands][2][32]
+  int Hs, Ws, band, nbands, vec16;
+};
+
+template <typename IN>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[4][64];
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int bnd = (int)(lid % p.nbands), n = (int)(lid / p.nbands);
+  const int r0 = bnd * p.band;
+  const int nrows = min(p.band, p.Hs - r0);
+  const int in_r0 = 2 * r0 - 1, nin = 2 * nrows + 1;
+  const int INW = p.cw + 2;
+  bf16_t* inp = reinterpret_cast<bf16_t*>(smem);                        // heads [nin][INW][4] (+ 16 B of slack behind)
+  const int plane_el = (nin * INW + 2) * 4;                             // elements per plane
+  bf16_t* inl = inp + plane_el;                                         // tails, same layout
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, q = lane >> 4;
+  const int flip = p.flip_mask ? (int)p.flip_mask[n] : p.flip;
+  {
+    const float na[3] = {1.0f / (255.0f * 0.229f), 1.0f / (255.0f * 0.224f), 1.0f / (255.0f * 0.225f)};
+    const float nb[3] = {-0.485f / 0.229f, -0.456f / 0.224f, -0.406f / 0.225f};
+    const IN* src = reinterpret_cast<const IN*>(p.frames) + (long)n * 3 * p.H * p.W;
+    const long plane = (long)p.H * p.W;
+    const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    bool done = false;
+    if constexpr (sizeof(IN) == 1) {
+      if (p.vec16) {
+        // a thread owns 16 pixels of one row: three 16-byte loads (R, G, B planes) in flight, 16 8-byte LDS stores
+        const int nch = p.cw >> 4;
+        const int total = nin * nch;
+        const IDiv dnch(nch);
+        for (int i = tid; i < total; i += 256) {
+          int k, r;
+          dnch.divmod(i, r, k);
+          const int iy = in_r0 + r;
+          bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)r * INW + 16 * k + 1) * 4);
+          bf16x4* dsl = reinterpret_cast<bf16x4*>(inl + ((long)r * INW + 16 * k + 1) * 4);
+          if (iy >= 0 && iy < p.ch) {
+            const int scol = flip ? (p.cw - 16 - 16 * k) : 16 * k;
+            const uint8_t* s0 = reinterpret_cast<const uint8_t*>(src) + (long)(p.top + iy) * p.W + p.left + scol;
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(s0);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(s0 + plane);
+            const u32x4 v2 = *reinterpret_cast<const u32x4*>(s0 + 2 * plane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const unsigned int sh8 = 8 * (e & 3);
+              const float f0 = fmaf((float)((v0[e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
+              const float f1 = fmaf((float)((v1[e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
+              const float f2 = fmaf((float)((v2[e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
+              bf16x4 o, l;
+              o[0] = (bf16_t)f0; o[1] = (bf16_t)f1; o[2] = (bf16_t)f2; o[3] = (bf16_t)0.f;
+              l[0] = (bf16_t)(f0 - (float)o[0]); l[1] = (bf16_t)(f1 - (float)o[1]); l[2] = (bf16_t)(f2 - (float)o[2]);
+              l[3] = (bf16_t)0.f;
+              dst[flip ? (15 - e) : e] = o;
+              dsl[flip ? (15 - e) : e] = l;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dst[e] = z4; dsl[e] = z4; }
+          }
+        }
+        done = true;
+      }
+    }
+    if (!done) {
+      const IDiv dcw(p.cw);
+      for (int i = tid; i < nin * p.cw; i += 256) {
+        int r, ix;
+        dcw.divmod(i, r, ix);
+        const int iy = in_r0 + r;
+        bf16x4 v4 = z4, l4 = z4;
+        if (iy >= 0 && iy < p.ch) {
+          const int sx = flip ? (p.cw - 1 - ix) : ix;
+          const long o = (long)(p.top + iy) * p.W + (p.left + sx);
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            const float f = fmaf((float)src[c3 * plane + o], na[c3], nb[c3]);
+            v4[c3] = (bf16_t)f;
+            l4[c3] = (bf16_t)(f - (float)v4[c3]);
+          }
+        }
+        *reinterpret_cast<bf16x4*>(inp + ((long)r * INW + ix + 1) * 4) = v4;
+        *reinterpret_cast<bf16x4*>(inl + ((long)r * INW + ix + 1) * 4) = l4;
+      }
+    }
+    for (int i = tid; i < nin * 2; i += 256) {        // halo columns (input col -1 and cw)
+      const long o = ((long)(i >> 1) * INW + ((i & 1) ? (p.cw + 1) : 0)) * 4;
+      *reinterpret_cast<bf16x4*>(inp + o) = z4;
+      *reinterpret_cast<bf16x4*>(inl + o) = z4;
+    }
+    if (tid < 2) {                                     // slack (odd widths read one pixel on)
+      *reinterpret_cast<bf16x4*>(inp + ((long)nin * INW + tid) * 4) = z4;
+      *reinterpret_cast<bf16x4*>(inl + ((long)nin * INW + tid) * 4) = z4;
+    }
+  }
+  __syncthreads();
+
+  bf16x8 swf[2][2], swl[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* wp = p.wf + ((long)((t * 2 + ks) * 64 + lane)) * 8;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = e < 4 ? w0[e] : w1[e - 4];
+        swf[t][ks][e] = (bf16_t)f;
+        swl[t][ks][e] = (bf16_t)(f - (float)swf[t][ks][e]);
+      }
+    }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const int tiles_per_row = (p.Ws + 15) >> 4;
+  const int ntiles = nrows * tiles_per_row;
+  const IDiv dtpr(tiles_per_row);
+  bf16_t* zf = p.z + (long)n * p.Hs * p.Ws * 32;
+  for (int tI = wv; tI < ntiles; tI += 4) {
+    int rq, rm;
+    dtpr.divmod(tI, rq, rm);
+    const int c = rm * 16 + px;
+    const bool cok = c < p.Ws;
+    const int cc = cok ? c : (p.Ws - 1);
+    f32x4 sa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int s = 4 * ks + q;                          // slot -> (ky = s >> 1, half = s & 1); slots 6, 7 carry zero weights
+      const int ky = s >> 1, half = s & 1;
+      const int prow = (s < 6) ? (2 * rq + ky) : 0;
+      const int pcol = (s < 6) ? (2 * cc + 2 * half) : 0;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(inp + (prow * INW + pcol) * 4);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(inl + (prow * INW + pcol) * 4);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swl[t][ks], xf, sa[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[t][ks], xl, sa[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[t][ks], xf, sa[t], 0, 0, 0);
+      }
+    }
+    bf16x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o0[e] = (bf16_t)sa[0][e]; o1[e] = (bf16_t)sa[1][e]; }
+    if (cok) {
+      bf16_t* zp = zf + ((long)(r0 + rq) * p.Ws + c) * 32 + 4 * q;
+      *reinterpret_cast<bf16x4*>(zp) = o0;
+      *reinterpret_cast<bf16x4*>(zp + 16) = o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = (float)o0[e], b = (float)o1[e];
+        s1[e] += a; s2[e] = fmaf(a, a, s2[e]);
+        s1[4 + e] += b; s2[4 + e] = fmaf(b, b, s2[4 + e]);
+      }
+    }
+  }
+  // fold: the 16 pixel lanes of a k-slot group, then the 4 waves; channel of element e: 4q + e (e < 4), 16 + 4q + e - 4
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      s1[e] += __shfl_xor(s1[e], o, 64);
+      s2[e] += __shfl_xor(s2[e], o, 64);
+    }
+  }
+  if (px == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int chn = (e < 4) ? (4 * q + e) : (16 + 4 * q + e - 4);
+      red[wv][chn] = s1[e];
+      red[wv][32 + chn] = s2[e];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) p.colpart[lid * 64 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+static int stem_band(int cw, int Hs) {
+  const long rowb = (long)(cw + 2) * 16;                 // head + tail planes
+  long cap = 48 * 1024;                                  // three workgroups per CU
+  int band = (int)((cap / rowb - 1) / 2);
+  if (band > 16) band = 16;
+  if (band < 1) band = 1;
+  if (band > Hs) band = Hs;
+  return band;
+}
+
+// row bands per frame = rows of colpart per frame
+extern "C" int tdeed_stem_mfma_parts(int crop_h, int crop_w) {
+  const int Hs = (crop_h + 1) / 2;
+  const int band = stem_band(crop_w, Hs);
+  if (2 * ((size_t)(2 * band + 1) * (crop_w + 2) * 8 + 16) > FRONT_LDS_CAP) return 0;
+  return (Hs + band - 1) / band;
+}
+
+extern "C" int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
+                                   int crop_h, int crop_w, int flip, const unsigned char* flip_mask, const void* wfrag,
+                                   void* z, float* colpart, void* stream) {
+  TD_CHECK(frames && wfrag && z && colpart, "stem_mfma: null pointer");
+  TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= H &&
+               crop_left + crop_w <= W, "stem_mfma: bad geometry");
+  StemP p;
+  p.frames = frames; p.H = H; p.W = W; p.top = crop_top; p.left = crop_left; p.ch = crop_h; p.cw = crop_w; p.flip = flip;
+  p.flip_mask = flip_mask; p.wf = (const float*)wfrag; p.z = (bf16_t*)z; p.colpart = colpart;
+  p.Hs = (crop_h + 1) / 2; p.Ws = (crop_w + 1) / 2;
+  p.band = stem_band(crop_w, p.Hs);
+  p.nbands = (p.Hs + p.band - 1) / p.band;
+  const size_t smem = 2 * ((size_t)(2 * p.band + 1) * (crop_w + 2) * 8 + 16);
+  TD_CHECK(smem <= FRONT_LDS_CAP, "stem_mfma: a row band of %d px does not fit LDS (use tdeed_stem_fwd)", crop_w);
+  const long grid = (long)p.nbands * N;
+  TD_CHECK(grid <= 0x7fffffffL, "stem_mfma: grid too large");
+  p.vec16 = !frames_f32 && (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
+            (((uintptr_t)frames & 15) == 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e != hipSuccess) { tdeed_set_error("stem_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  if (frames_f32) hipLaunchKernelGGL(stem_mfma_kernel<float>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(stem_mfma_kernel<uint8_t>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+  TD_LAUNCH_CHECK("stem_mfma");
+  return TDEED_OK;
+}

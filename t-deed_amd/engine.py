@@ -186,19 +186,7 @@ def pack_front_weights(stem_w, stem_sc, stem_sh, w1, sc1, sh1, wd, scd, shd, w2,
     MFMA accumulators hand the 32 channels over."""
     stem_w, w1, wd = _np(stem_w).astype(np.float32), _np(w1).astype(np.float32), _np(wd).astype(np.float32)
     C1 = w1.shape[0]
-    sw = np.zeros((2, 2, 64, 8), np.float32)
-    for t in range(2):
-        for ks in range(2):
-            for q in range(4):
-                s_ = 4 * ks + q
-                if s_ >= 6:
-                    continue
-                ky, half = s_ >> 1, s_ & 1
-                for j in range(8):
-                    kx, c = 2 * half + j // 4, j % 4
-                    if kx > 2 or c > 2:
-                        continue
-                    sw[t, ks, q * 16:(q + 1) * 16, j] = stem_w[t * 16:(t + 1) * 16, c, ky, kx]
+    sw = _stem_frags_np(stem_w)
     nt = (C1 + 15) // 16
 
     def kperm(W):
@@ -216,6 +204,40 @@ def pack_front_weights(stem_w, stem_sc, stem_sh, w1, sc1, sh1, wd, scd, shd, w2,
     return SimpleNamespace(C1=C1, stem_wf=bf(sw), stem_sc=f32(stem_sc), stem_sh=f32(stem_sh), w1f=bf(kperm(w1)),
                            sc1=f32(sc1), sh1=f32(sh1), wdf=bf(kperm(wd)), scd=f32(scd), shd=f32(shd),
                            w2f=pack_gconv_frags(w2, gw, device), sc2=f32(sc2), sh2=f32(sh2))
+
+
+def _stem_frags_np(stem_w):
+    """stem conv weight [32][3][3][3] -> MFMA A fragments [2 channel tiles][2 k-steps][64 lanes][8] (front.hip: k-slot
+    s = 4ks+q -> (ky = s>>1, half = s&1), element j -> (kx = 2half + j//4, c = j%4, 3 = pad))."""
+    sw = np.zeros((2, 2, 64, 8), stem_w.dtype)
+    for t in range(2):
+        for ks in range(2):
+            for q in range(4):
+                s_ = 4 * ks + q
+                if s_ >= 6:
+                    continue
+                ky, half = s_ >> 1, s_ & 1
+                for j in range(8):
+                    kx, c = 2 * half + j // 4, j % 4
+                    if kx > 2 or c > 2:
+                        continue
+                    sw[t, ks, q * 16:(q + 1) * 16, j] = stem_w[t * 16:(t + 1) * 16, c, ky, kx]
+    return sw
+
+
+_STEM_IDX = {}
+
+
+def stem_frags_on_device(w):
+    """_features.stem.conv.weight (32,3,3,3) fp32 on the device -> the fragments of _stem_frags_np (kept in fp32: the training
+    stem splits them into bf16 head + tail itself) by one gather through a cached index map (the training step re-packs the
+    updated weight without a host round trip)."""
+    key = str(w.device)
+    if key not in _STEM_IDX:
+        ids = (np.arange(32 * 27, dtype=np.float32) + 1).reshape(32, 3, 3, 3)              # exact in fp32
+        _STEM_IDX[key] = torch.from_numpy(_stem_frags_np(ids).astype(np.int64)).to(w.device)
+    ext = torch.cat([torch.zeros(1, dtype=w.dtype, device=w.device), w.reshape(-1)])
+    return ext[_STEM_IDX[key]].contiguous()
 
 
 _GSFQ_IDX = {}

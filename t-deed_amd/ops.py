@@ -48,6 +48,28 @@ def stem(frames_u8, w, scale, shift, act_dtype, crop=None, flip=False, out=None,
     return out
 
 
+def stem_mfma_parts(ch, cw):
+    return _lib.load().tdeed_stem_mfma_parts(ch, cw)
+
+
+def stem_mfma(frames, wfrag, crop=None, flip=False):
+    """Training stem on the MFMA pipe (bf16): frames (N,3,H,W) uint8 or fp32 0..255 -> (z (N,Ho,Wo,32) raw conv output,
+    colpart (N*parts, 2, 32) fp32 per-workgroup column sums / sums of squares of z)."""
+    _chk(frames, "frames", torch.float32 if frames.dtype == torch.float32 else torch.uint8)
+    _chk(wfrag, "wfrag", torch.float32)
+    N, _, H, W = frames.shape
+    top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
+    parts = stem_mfma_parts(ch, cw)
+    if parts <= 0:
+        raise RuntimeError(f"stem_mfma: a {cw}-pixel row band does not fit LDS")
+    z = torch.empty((N, (ch + 1) // 2, (cw + 1) // 2, 32), dtype=torch.bfloat16, device=frames.device)
+    colpart = torch.empty((N * parts, 2, 32), dtype=torch.float32, device=frames.device)
+    fl, fmask = _flip_args(flip, N)
+    call("tdeed_stem_mfma_fwd", ptr(frames), int(frames.dtype == torch.float32), N, H, W, top, left, ch, cw, fl, ptr(fmask),
+         ptr(wfrag), ptr(z), ptr(colpart), stream_ptr())
+    return z, colpart
+
+
 def s1_front_parts(ch, cw, C1):
     return _lib.load().tdeed_s1_front_parts(ch, cw, C1)
 

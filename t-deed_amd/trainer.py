@@ -21,7 +21,9 @@ from .streams import new_stream
 from .optim import FlatParams, FusedAdamW, warmup_cosine_lr
 from .regnet_spec import regnet_spec
 from .temporal_train import TemporalStack
-from .trunk_train import BottleneckTrain, BN_EPS
+from .trunk_train import BottleneckTrain, StemTrain, BN_EPS
+
+STEM_MFMA = os.environ.get("TDEED_TRAIN_STEM_MFMA", "1") == "1"
 
 
 class TrainEngine:
@@ -41,6 +43,7 @@ class TrainEngine:
         sd = self.state
         self.blocks = [BottleneckTrain(sd, "_features." + b.name, b, act_dtype, clip_len=self.T) for b in self.spec.blocks]
         self.temporal = TemporalStack(sd, self.cfg, act_dtype)
+        self.stem = StemTrain(sd, act_dtype)
         self.one32 = torch.ones(32, device=device)
         self.zero32 = torch.zeros(32, device=device)
         self.sched_step = 0
@@ -90,9 +93,19 @@ class TrainEngine:
         Bn, T = frames_u8.shape[:2]
         fr = frames_u8.reshape(Bn * T, *frames_u8.shape[2:])
         fl = self._frame_flip(flip, Bn, T)
-        z0 = ops.stem(fr, sd["_features.stem.conv.weight"], self.one32, self.zero32, dt, crop=crop, flip=fl, relu=False)
-        y0, bn0 = B_.bn_train(z0, sd["_features.stem.bn.weight"], sd["_features.stem.bn.bias"], BN_EPS, 0.1,
-                              sd["_features.stem.bn.running_mean"], sd["_features.stem.bn.running_var"], relu=True)
+        H_, W_ = fr.shape[-2:]
+        chw = (crop[2], crop[3]) if crop is not None else (H_, W_)
+        if self.stem.wf is not None and STEM_MFMA and ops.stem_mfma_parts(*chw) > 0:
+            # bf16: conv on the MFMA pipe, BatchNorm statistics from its epilogue (no second pass over the 112^2 map)
+            z0, cp = ops.stem_mfma(fr, self.stem.wf, crop=crop, flip=fl)
+            cpf = cp.view(-1)
+            y0, bn0 = B_.bn_finalize_apply(z0, cpf, cpf[32:], 64, cp.shape[0], sd["_features.stem.bn.weight"],
+                                           sd["_features.stem.bn.bias"], BN_EPS, 0.1, sd["_features.stem.bn.running_mean"],
+                                           sd["_features.stem.bn.running_var"], relu=True)
+        else:
+            z0 = ops.stem(fr, sd["_features.stem.conv.weight"], self.one32, self.zero32, dt, crop=crop, flip=fl, relu=False)
+            y0, bn0 = B_.bn_train(z0, sd["_features.stem.bn.weight"], sd["_features.stem.bn.bias"], BN_EPS, 0.1,
+                                  sd["_features.stem.bn.running_mean"], sd["_features.stem.bn.running_var"], relu=True)
         x = y0
         for blk in self.blocks:
             x = blk.forward(x)
@@ -146,9 +159,10 @@ class TrainEngine:
             for blk in self.blocks:
                 blk.repack()
             self.temporal.repack()
+            self.stem.repack()
         elif self.pack is None:
             from .repack import PackPlan
-            self.pack = PackPlan(self.params, self.device).build(list(self.blocks) + [self.temporal])
+            self.pack = PackPlan(self.params, self.device).build(list(self.blocks) + [self.temporal, self.stem])
         else:
             self.pack.run()
 

