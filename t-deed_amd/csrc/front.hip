@@ -394,12 +394,104 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
 // wh xh + wh xl + wl xh (three MFMAs, fp32 accumulation; the dropped wl xl term is 2^-16 of the result), so z0 is the fp32
 // conv rounded once to bf16 like the VALU stem's -- rounding the operands themselves to bf16 (as the inference front may)
 // measurably degrades the gradient direction of the noise-prone small tensors (SE weights) in training.
+struct StemGeo { int H, W, top, left, ch, cw, vec16; };
+
+// normalised input rows [in_r0, in_r0 + nin) of one frame -> LDS as [row][col -1 .. cw][RGB0] bf16 (heads in inp, the bf16
+// tails of the fp32 values in inl when SPLIT), zero outside the image, h-flip applied; ends with the two slack pixels behind
+// the last row zeroed (odd widths read one pixel past the row).  Caller synchronises.
+template <typename IN, bool SPLIT>
+__device__ __forceinline__ void stem_fill_patch(bf16_t* inp, bf16_t* inl, const IN* src, const StemGeo& g, int in_r0, int nin,
+                                                int flip) {
+  const int tid = threadIdx.x;
+  const int INW = g.cw + 2;
+  const float na[3] = {1.0f / (255.0f * 0.229f), 1.0f / (255.0f * 0.224f), 1.0f / (255.0f * 0.225f)};
+  const float nb[3] = {-0.485f / 0.229f, -0.456f / 0.224f, -0.406f / 0.225f};
+  const long plane = (long)g.H * g.W;
+  const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  bool done = false;
+  if constexpr (sizeof(IN) == 1) {
+    if (g.vec16) {
+      // a thread owns 16 pixels of one row: three 16-byte loads (R, G, B planes) in flight, 16 8-byte LDS stores
+      const int nch = g.cw >> 4;
+      const int total = nin * nch;
+      const IDiv dnch(nch);
+      for (int i = tid; i < total; i += 256) {
+        int k, r;
+        dnch.divmod(i, r, k);
+        const int iy = in_r0 + r;
+        bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)r * INW + 16 * k + 1) * 4);
+        bf16x4* dsl = reinterpret_cast<bf16x4*>(inl + ((long)r * INW + 16 * k + 1) * 4);
+        if (iy >= 0 && iy < g.ch) {
+          const int scol = flip ? (g.cw - 16 - 16 * k) : 16 * k;
+          const uint8_t* s0 = reinterpret_cast<const uint8_t*>(src) + (long)(g.top + iy) * g.W + g.left + scol;
+          const u32x4 v0 = *reinterpret_cast<const u32x4*>(s0);
+          const u32x4 v1 = *reinterpret_cast<const u32x4*>(s0 + plane);
+          const u32x4 v2 = *reinterpret_cast<const u32x4*>(s0 + 2 * plane);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const unsigned int sh8 = 8 * (e & 3);
+            const float f0 = fmaf((float)((v0[e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
+            const float f1 = fmaf((float)((v1[e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
+            const float f2 = fmaf((float)((v2[e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
+            bf16x4 o;
+            o[0] = (bf16_t)f0; o[1] = (bf16_t)f1; o[2] = (bf16_t)f2; o[3] = (bf16_t)0.f;
+            dst[flip ? (15 - e) : e] = o;
+            if constexpr (SPLIT) {
+              bf16x4 l;
+              l[0] = (bf16_t)(f0 - (float)o[0]); l[1] = (bf16_t)(f1 - (float)o[1]); l[2] = (bf16_t)(f2 - (float)o[2]);
+              l[3] = (bf16_t)0.f;
+              dsl[flip ? (15 - e) : e] = l;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            dst[e] = z4;
+            if constexpr (SPLIT) dsl[e] = z4;
+          }
+        }
+      }
+      done = true;
+    }
+  }
+  if (!done) {
+    const IDiv dcw(g.cw);
+    for (int i = tid; i < nin * g.cw; i += 256) {
+      int r, ix;
+      dcw.divmod(i, r, ix);
+      const int iy = in_r0 + r;
+      bf16x4 v4 = z4, l4 = z4;
+      if (iy >= 0 && iy < g.ch) {
+        const int sx = flip ? (g.cw - 1 - ix) : ix;
+        const long o = (long)(g.top + iy) * g.W + (g.left + sx);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+          const float f = fmaf((float)src[c3 * plane + o], na[c3], nb[c3]);
+          v4[c3] = (bf16_t)f;
+          l4[c3] = (bf16_t)(f - (float)v4[c3]);
+        }
+      }
+      *reinterpret_cast<bf16x4*>(inp + ((long)r * INW + ix + 1) * 4) = v4;
+      if constexpr (SPLIT) *reinterpret_cast<bf16x4*>(inl + ((long)r * INW + ix + 1) * 4) = l4;
+    }
+  }
+  for (int i = tid; i < nin * 2; i += 256) {        // halo columns (input col -1 and cw)
+    const long o = ((long)(i >> 1) * INW + ((i & 1) ? (g.cw + 1) : 0)) * 4;
+    *reinterpret_cast<bf16x4*>(inp + o) = z4;
+    if constexpr (SPLIT) *reinterpret_cast<bf16x4*>(inl + o) = z4;
+  }
+  if (tid < 2) {                                     // slack
+    *reinterpret_cast<bf16x4*>(inp + ((long)nin * INW + tid) * 4) = z4;
+    if constexpr (SPLIT) *reinterpret_cast<bf16x4*>(inl + ((long)nin * INW + tid) * 4) = z4;
+  }
+}
+
 struct StemP {
-  const void* frames; int H, W, top, left, ch, cw, flip;
+  const void* frames; StemGeo g; int flip;
   const unsigned char* flip_mask;
   const float* wf;                                  // [2][2][64][8] fp32 fragments (engine.stem_frags_on_device)
   bf16_t* z; float* colpart;                        // z [N][Hs][Ws][32]; colpart [N * nbands][2][32]
-  int Hs, Ws, band, nbands, vec16;
+  int Hs, Ws, band, nbands;
 };
 
 template <typename IN>
@@ -411,90 +503,14 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemP p) {
   const int r0 = bnd * p.band;
   const int nrows = min(p.band, p.Hs - r0);
   const int in_r0 = 2 * r0 - 1, nin = 2 * nrows + 1;
-  const int INW = p.cw + 2;
+  const int INW = p.g.cw + 2;
   bf16_t* inp = reinterpret_cast<bf16_t*>(smem);                        // heads [nin][INW][4] (+ 16 B of slack behind)
   const int plane_el = (nin * INW + 2) * 4;                             // elements per plane
   bf16_t* inl = inp + plane_el;                                         // tails, same layout
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, q = lane >> 4;
   const int flip = p.flip_mask ? (int)p.flip_mask[n] : p.flip;
-  {
-    const float na[3] = {1.0f / (255.0f * 0.229f), 1.0f / (255.0f * 0.224f), 1.0f / (255.0f * 0.225f)};
-    const float nb[3] = {-0.485f / 0.229f, -0.456f / 0.224f, -0.406f / 0.225f};
-    const IN* src = reinterpret_cast<const IN*>(p.frames) + (long)n * 3 * p.H * p.W;
-    const long plane = (long)p.H * p.W;
-    const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    bool done = false;
-    if constexpr (sizeof(IN) == 1) {
-      if (p.vec16) {
-        // a thread owns 16 pixels of one row: three 16-byte loads (R, G, B planes) in flight, 16 8-byte LDS stores
-        const int nch = p.cw >> 4;
-        const int total = nin * nch;
-        const IDiv dnch(nch);
-        for (int i = tid; i < total; i += 256) {
-          int k, r;
-          dnch.divmod(i, r, k);
-          const int iy = in_r0 + r;
-          bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)r * INW + 16 * k + 1) * 4);
-          bf16x4* dsl = reinterpret_cast<bf16x4*>(inl + ((long)r * INW + 16 * k + 1) * 4);
-          if (iy >= 0 && iy < p.ch) {
-            const int scol = flip ? (p.cw - 16 - 16 * k) : 16 * k;
-            const uint8_t* s0 = reinterpret_cast<const uint8_t*>(src) + (long)(p.top + iy) * p.W + p.left + scol;
-            const u32x4 v0 = *reinterpret_cast<const u32x4*>(s0);
-            const u32x4 v1 = *reinterpret_cast<const u32x4*>(s0 + plane);
-            const u32x4 v2 = *reinterpret_cast<const u32x4*>(s0 + 2 * plane);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const unsigned int sh8 = 8 * (e & 3);
-              const float f0 = fmaf((float)((v0[e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
-              const float f1 = fmaf((float)((v1[e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
-              const float f2 = fmaf((float)((v2[e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
-              bf16x4 o, l;
-              o[0] = (bf16_t)f0; o[1] = (bf16_t)f1; o[2] = (bf16_t)f2; o[3] = (bf16_t)0.f;
-              l[0] = (bf16_t)(f0 - (float)o[0]); l[1] = (bf16_t)(f1 - (float)o[1]); l[2] = (bf16_t)(f2 - (float)o[2]);
-              l[3] = (bf16_t)0.f;
-              dst[flip ? (15 - e) : e] = o;
-              dsl[flip ? (15 - e) : e] = l;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { dst[e] = z4; dsl[e] = z4; }
-          }
-        }
-        done = true;
-      }
-    }
-    if (!done) {
-      const IDiv dcw(p.cw);
-      for (int i = tid; i < nin * p.cw; i += 256) {
-        int r, ix;
-        dcw.divmod(i, r, ix);
-        const int iy = in_r0 + r;
-        bf16x4 v4 = z4, l4 = z4;
-        if (iy >= 0 && iy < p.ch) {
-          const int sx = flip ? (p.cw - 1 - ix) : ix;
-          const long o = (long)(p.top + iy) * p.W + (p.left + sx);
-#pragma unroll
-          for (int c3 = 0; c3 < 3; ++c3) {
-            const float f = fmaf((float)src[c3 * plane + o], na[c3], nb[c3]);
-            v4[c3] = (bf16_t)f;
-            l4[c3] = (bf16_t)(f - (float)v4[c3]);
-          }
-        }
-        *reinterpret_cast<bf16x4*>(inp + ((long)r * INW + ix + 1) * 4) = v4;
-        *reinterpret_cast<bf16x4*>(inl + ((long)r * INW + ix + 1) * 4) = l4;
-      }
-    }
-    for (int i = tid; i < nin * 2; i += 256) {        // halo columns (input col -1 and cw)
-      const long o = ((long)(i >> 1) * INW + ((i & 1) ? (p.cw + 1) : 0)) * 4;
-      *reinterpret_cast<bf16x4*>(inp + o) = z4;
-      *reinterpret_cast<bf16x4*>(inl + o) = z4;
-    }
-    if (tid < 2) {                                     // slack (odd widths read one pixel on)
-      *reinterpret_cast<bf16x4*>(inp + ((long)nin * INW + tid) * 4) = z4;
-      *reinterpret_cast<bf16x4*>(inl + ((long)nin * INW + tid) * 4) = z4;
-    }
-  }
+  stem_fill_patch<IN, true>(inp, inl, reinterpret_cast<const IN*>(p.frames) + (long)n * 3 * p.g.H * p.g.W, p.g, in_r0, nin, flip);
   __syncthreads();
 
   bf16x8 swf[2][2], swl[2][2];
@@ -601,8 +617,8 @@ extern "C" int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, in
   TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= H &&
                crop_left + crop_w <= W, "stem_mfma: bad geometry");
   StemP p;
-  p.frames = frames; p.H = H; p.W = W; p.top = crop_top; p.left = crop_left; p.ch = crop_h; p.cw = crop_w; p.flip = flip;
-  p.flip_mask = flip_mask; p.wf = (const float*)wfrag; p.z = (bf16_t*)z; p.colpart = colpart;
+  p.frames = frames; p.g.H = H; p.g.W = W; p.g.top = crop_top; p.g.left = crop_left; p.g.ch = crop_h; p.g.cw = crop_w;
+  p.flip = flip; p.flip_mask = flip_mask; p.wf = (const float*)wfrag; p.z = (bf16_t*)z; p.colpart = colpart;
   p.Hs = (crop_h + 1) / 2; p.Ws = (crop_w + 1) / 2;
   p.band = stem_band(crop_w, p.Hs);
   p.nbands = (p.Hs + p.band - 1) / p.band;
@@ -610,8 +626,8 @@ extern "C" int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, in
   TD_CHECK(smem <= FRONT_LDS_CAP, "stem_mfma: a row band of %d px does not fit LDS (use tdeed_stem_fwd)", crop_w);
   const long grid = (long)p.nbands * N;
   TD_CHECK(grid <= 0x7fffffffL, "stem_mfma: grid too large");
-  p.vec16 = !frames_f32 && (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
-            (((uintptr_t)frames & 15) == 0);
+  p.g.vec16 = !frames_f32 && (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
+              (((uintptr_t)frames & 15) == 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
@@ -623,4 +639,135 @@ extern "C" int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, in
   else hipLaunchKernelGGL(stem_mfma_kernel<uint8_t>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
   TD_LAUNCH_CHECK("stem_mfma");
   return TDEED_OK;
+}
+
+// =============================================================================================
+// Stem weight gradient (bf16) without an im2col: dW[co][c][ky][kx] = sum_px dz[px][co] x[2y+ky-1][2x+kx-1][c].
+// Pixels are the contraction index.  Both MFMA operands are "one column, 8 consecutive rows" of a row-major LDS image and
+// come from transposing reads (ds_read_b64_tr_b16, td_tr_read8):
+//   A = dz^T : the dz rows of the band, copied to LDS as they are ([px][32 co], 16-byte copies);
+//   B        : for one ky, the row of pixel x is the 16 contiguous bf16 at patch[2y+ky][2x] = (kx 0..3, c 0..3) of the
+//              normalised input band ([row][col][RGB0], the forward's image); consecutive pixels are 16 bytes apart, so the
+//              "rows" overlap -- every lane supplies its own address, which is all the transposing read needs.  Columns with
+//              kx = 3 or c = 3 are by-products and dropped at the end.
+// One workgroup = one frame x 16 output rows (the partial layout of the kernel it replaces), in sub-bands of 4 rows; wave w
+// takes row w of the sub-band, 32 pixels per MFMA k-step, 2 channel tiles x 3 ky tiles accumulate in registers over the
+// whole 16 rows; the waves' partial sums are folded through LDS.  The previous MFMA form built dz^T and the im2col patch^T
+// element-wise in LDS (59 two-byte stores and 27 reads per pixel) and ran at 546 us for 800 frames of 224^2 where reading
+// dz costs ~120 us.
+struct StemWgP {
+  const void* frames; StemGeo g; int flip;
+  const unsigned char* flip_mask;
+  const bf16_t* dz; float* part;
+  int Ho, Wo, WoP, groups;
+};
+
+template <typename IN>
+__global__ __launch_bounds__(256) void stem_wgrad_tr_kernel(const StemWgP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = blockIdx.x / p.groups, grp = blockIdx.x - n * p.groups;
+  const int INW = p.g.cw + 2;
+  bf16_t* inp = reinterpret_cast<bf16_t*>(smem);                          // [9][INW][4] + slack
+  const int patch_el = ((9 * INW + 2) * 4 + 7) & ~7;
+  bf16_t* dzs = inp + patch_el;                                           // [4][WoP][32]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g16 = lane >> 4, l16 = lane & 15, qq = l16 >> 2, pp = l16 & 3;
+  const int flip = p.flip_mask ? (int)p.flip_mask[n] : p.flip;
+  const IN* src = reinterpret_cast<const IN*>(p.frames) + (long)n * 3 * p.g.H * p.g.W;
+  const bf16_t* dzf = p.dz + (long)n * p.Ho * p.Wo * 32;
+  f32x4 acc[2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) acc[t][ky] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int cpr = p.WoP * 4;                                              // 16-byte chunks per dz image row
+  for (int sb = 0; sb < 4; ++sb) {
+    const int oy0 = grp * 16 + sb * 4;
+    if (oy0 >= p.Ho) break;
+    if (sb) __syncthreads();                                              // the previous sub-band has been consumed
+    stem_fill_patch<IN, false>(inp, nullptr, src, p.g, 2 * oy0 - 1, 9, flip);
+    for (int i = tid; i < 4 * cpr; i += 256) {
+      const int ry = i / cpr, cx = i - ry * cpr;
+      const int oy = oy0 + ry;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (oy < p.Ho && cx < p.Wo * 4) v = *reinterpret_cast<const u32x4*>(dzf + ((long)oy * p.Wo) * 32 + (long)cx * 8);
+      *reinterpret_cast<u32x4*>(dzs + (long)i * 8) = v;
+    }
+    __syncthreads();
+    // wave wv: output row oy0 + wv; its pixels in k-steps of 32
+    const bf16_t* arow = dzs + (long)wv * p.WoP * 32;
+    for (int x0 = 0; x0 < p.WoP; x0 += 32) {
+      const int xr = x0 + 8 * g16 + qq;                                   // this lane's address row (pixel) in rows 0..3
+      bf16x8 af[2], bfr[3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        af[t] = td_tr_read8(arow + (long)xr * 32 + t * 16 + 4 * pp, arow + (long)(xr + 4) * 32 + t * 16 + 4 * pp);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const bf16_t* prow = inp + (long)(2 * wv + ky) * INW * 4;
+        bfr[ky] = td_tr_read8(prow + 2 * xr * 4 + 4 * pp, prow + 2 * (xr + 4) * 4 + 4 * pp);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[t][ky] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bfr[ky], acc[t][ky], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                            // [4 waves][6 tiles][64 lanes][4]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) *reinterpret_cast<f32x4*>(red + ((wv * 6 + t * 3 + ky) * 64 + lane) * 4) = acc[t][ky];
+  __syncthreads();
+  float* out = p.part + ((long)n * p.groups + grp) * 864;
+  for (int i = tid; i < 6 * 64; i += 256) {
+    const int tile = i >> 6, l = i & 63;
+    const int t = tile / 3, ky = tile - 3 * t;
+    const int j = l & 15, kx = j >> 2, c = j & 3;
+    if (kx < 3 && c < 3) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(red + ((0 * 6 + tile) * 64 + l) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(red + ((w * 6 + tile) * 64 + l) * 4);
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = 16 * t + 4 * (l >> 4) + e;
+        out[co * 27 + c * 9 + ky * 3 + kx] = a[e];
+      }
+    }
+  }
+}
+
+// launcher used by tdeed_stem_wgrad (trunk_bwd.hip); returns 0 when the geometry does not fit (the caller falls back)
+int td_stem_wgrad_tr_launch(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h,
+                            int crop_w, int flip, const unsigned char* flip_mask, const void* dz, float* part,
+                            hipStream_t st) {
+  StemWgP p;
+  p.frames = frames; p.g.H = H; p.g.W = W; p.g.top = crop_top; p.g.left = crop_left; p.g.ch = crop_h; p.g.cw = crop_w;
+  p.flip = flip; p.flip_mask = flip_mask; p.dz = (const bf16_t*)dz; p.part = part;
+  p.Ho = (crop_h + 1) / 2; p.Wo = (crop_w + 1) / 2;
+  p.WoP = (p.Wo + 31) / 32 * 32;
+  p.groups = (p.Ho + 15) / 16;
+  const size_t patch_b = (size_t)((((9 * (crop_w + 2) + 2) * 4 + 7) & ~7)) * 2;
+  size_t smem = patch_b + (size_t)4 * p.WoP * 64;
+  if (smem < 4 * 6 * 64 * 4 * sizeof(float)) smem = 4 * 6 * 64 * 4 * sizeof(float);
+  // the last k-step of a row reads patch columns up to 2 (WoP - 1) + 3: inside the shared allocation (the dz image follows)
+  if (smem > FRONT_LDS_CAP || ((size_t)8 * (crop_w + 2) + 2 * (size_t)p.WoP + 4) * 8 > patch_b + (size_t)4 * p.WoP * 64) return 0;
+  p.g.vec16 = !frames_f32 && (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
+              (((uintptr_t)frames & 15) == 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)stem_wgrad_tr_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_wgrad_tr_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+    if (e != hipSuccess) return 0;
+    attr_set = true;
+  }
+  const long grid = (long)N * p.groups;
+  if (grid > 0x7fffffffL) return 0;
+  if (frames_f32) hipLaunchKernelGGL(stem_wgrad_tr_kernel<float>, dim3((unsigned)grid), dim3(256), smem, st, p);
+  else hipLaunchKernelGGL(stem_wgrad_tr_kernel<uint8_t>, dim3((unsigned)grid), dim3(256), smem, st, p);
+  return 1;
 }

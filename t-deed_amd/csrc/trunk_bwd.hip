@@ -1596,6 +1596,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const IN* __restri
 }
 
 // dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N*ceil(Ho/16)][864]
+int td_stem_wgrad_tr_launch(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h,
+                            int crop_w, int flip, const unsigned char* flip_mask, const void* dz, float* part,
+                            hipStream_t st);
+
 extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
                                 int crop_h, int crop_w, int flip, const unsigned char* flip_mask, const void* dz,
                                 float* part, float* dw, int dtype, void* stream) {
@@ -1610,7 +1614,12 @@ extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H
   if (dtype == TDEED_F32) { if (frames_f32) TD_SWG(float, float); else TD_SWG(float, uint8_t); }
   else if (dtype == TDEED_BF16) {
     static const bool valu = getenv("TDEED_STEM_WGRAD_VALU") && atoi(getenv("TDEED_STEM_WGRAD_VALU")) == 1;
+    static const bool old_mfma = getenv("TDEED_STEM_WGRAD_IM2COL") && atoi(getenv("TDEED_STEM_WGRAD_IM2COL")) == 1;
     if (valu) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
+    else if (!old_mfma && td_stem_wgrad_tr_launch(frames, frames_f32, N, H, W, crop_top, crop_left, crop_h, crop_w, flip, flip_mask,
+                                                  dz, part, st)) {
+      // transposing-read form (front.hip): same partial layout
+    }
     else if (frames_f32)
       hipLaunchKernelGGL(stem_wgrad_mfma_kernel<float>, dim3(N, cdiv(Ho, 16)), dim3(256), 0, st, (const float*)frames, H, W,
                          crop_top, crop_left, crop_h, crop_w, flip, flip_mask, (const bf16_t*)dz, Ho, Wo, part);

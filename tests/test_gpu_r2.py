@@ -667,3 +667,25 @@ def test_training_stem_on_the_mfma_pipe(geom, f32_frames):
     s1, s2 = cp[:, 0].sum(0), cp[:, 1].sum(0)
     assert torch.allclose(s1, zs.sum(0), rtol=1e-4, atol=1e-2)
     assert torch.allclose(s2, (zs * zs).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(6, 224, 224, None), (5, 96, 128, (8, 16, 80, 96)), (3, 70, 90, (3, 5, 61, 75)), (2, 40, 600, None)])
+@pytest.mark.parametrize("f32_frames", [False, True])
+def test_stem_weight_gradient_on_transposing_reads(geom, f32_frames, monkeypatch):
+    """tdeed_stem_wgrad in bf16 (dz^T and the input band as MFMA operands through ds_read_b64_tr_b16, no im2col) against the
+    fp32 VALU form of the same sum -- per-frame flip flags, crops (aligned and not), odd sizes, a band too wide for LDS (falls
+    back to the im2col kernel), uint8 and fp32 (mixup) frames."""
+    from tdeed_amd import ops_bwd
+    DEV = "cuda"
+    N, H, W, crop = geom
+    fr = torch.from_numpy(synth.uint8_clip(911, (N, 3, H, W))).to(DEV)
+    if f32_frames:
+        fr = fr.float() * 0.75 + 3.0
+    ch, cw = (crop[2], crop[3]) if crop else (H, W)
+    dz = (rnd(912, "dz", (N, (ch + 1) // 2, (cw + 1) // 2, 32)) * 0.5).to(torch.bfloat16).to(DEV)
+    flip = (torch.arange(N, device=DEV) % 2).to(torch.uint8)
+    ref = ops_bwd.stem_wgrad(fr, dz.float(), crop=crop, flip=flip)
+    got = ops_bwd.stem_wgrad(fr, dz, crop=crop, flip=flip)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err                        # the input is rounded to bf16 for the MFMA (2^-9 per element, averaged out)
