@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemP p) {
 
 static int stem_band(int cw, int Hs) {
   const long rowb = (long)(cw + 2) * 16;                 // head + tail planes
-  long cap = 48 * 1024;                                  // three workgroups per CU
+  static long cap = -1;                                  // 48 KB: three workgroups per CU
+  if (cap < 0) { const char* e = getenv("TDEED_STEM_LDS_KB"); cap = e ? atol(e) * 1024 : 48 * 1024; }
   int band = (int)((cap / rowb - 1) / 2);
   if (band > 16) band = 16;
   if (band < 1) band = 1;
