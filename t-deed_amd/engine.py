@@ -402,7 +402,7 @@ class SgpBuilder:
         # fused launches (sgp_fused.hip): LayerNorm inside the branch kernels (both dtypes), GroupNorm + fc1 + GELU + fc2 +
         # residual in one MFMA launch (bf16).  TDEED_SGP_FUSED=0 restores the launch-per-op chain (A/B measurements).
         self.fused = os.environ.get("TDEED_SGP_FUSED", "1") == "1"
-        # widest feature dimension served by the fused MLP launch: covers RegNetY-800MF (C = 784: 46 -> 26 launches for the
+        # widest feature dimension served by the fused MLP launch: covers RegNetY-800MF (C = 768: 46 -> 26 launches for the
         # stage, 1421 -> 1465 clips/s at B = 16)
         self.mlp_maxc = int(os.environ.get("TDEED_SGP_MLP_MAXC", "800"))
 
