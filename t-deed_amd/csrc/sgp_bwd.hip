@@ -516,11 +516,114 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const bf16_t* __restrict_
   }
 }
 
+// 128 x 128 output tile of the same contraction for the wide layers (N, K >= 96): waves 2 x 2, each 64 x 64 (16 accumulator
+// tiles), so a 64-row chunk feeds 32 MFMAs per wave between two barriers instead of 8, and the operands are re-read by
+// 3 x 3 instead of 5 x 5 workgroups at N = K = 320 (the 64 x 64 form ran at 229 TFLOP/s and 1.4 TB/s on M = 313600,
+// N = K = 320: bound by neither).
+constexpr int WT_RS2 = 144;                                     // LDS row stride in elements: 128 columns + 32 bytes
+__global__ __launch_bounds__(256) void wgrad_tr128_kernel(const bf16_t* __restrict__ dY, long ldy, const bf16_t* __restrict__ X,
+                                                          long ldx, const bf16_t* __restrict__ X0, long ldx0, int k0s, int M, int N,
+                                                          int K, float* __restrict__ part_w, float* __restrict__ part_b) {
+  __shared__ __attribute__((aligned(16))) bf16_t sY[64 * WT_RS2];
+  __shared__ __attribute__((aligned(16))) bf16_t sX[64 * WT_RS2];
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, z = blockIdx.z, Z = gridDim.z;
+  const int mper = ((M + Z - 1) / Z + 63) / 64 * 64;
+  const int m_begin = z * mper, m_end = min(M, m_begin + mper);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), pl = lane & 15;
+  const int wn = wv >> 1, wk = wv & 1;
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int r = tid >> 4, c8 = (tid & 15) * 8;                  // staging: rows r + 16 h, 16-byte chunk c8
+  const bool nok = n0 + c8 < N, kok = k0 + c8 < K;
+  const bool want_b = part_b && blockIdx.y == 0;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long ycol = min(n0 + c8, N - 8), xcol = min(k0 + c8, K - 8);
+  u32x4 vy[4], vx[4];
+  auto issue = [&](int m0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const long row = min(m0 + r + 16 * h, M - 1);
+      vy[h] = *reinterpret_cast<const u32x4*>(dY + row * ldy + ycol);
+      vx[h] = *reinterpret_cast<const u32x4*>(xcol < k0s ? X0 + row * ldx0 + xcol : X + row * ldx + xcol);
+    }
+  };
+  if (m_begin < m_end) issue(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const bool rok = m0 + r + 16 * h < m_end;
+      const u32x4 zy = (rok && nok) ? vy[h] : (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(sY + (r + 16 * h) * WT_RS2 + c8) = zy;
+      *reinterpret_cast<u32x4*>(sX + (r + 16 * h) * WT_RS2 + c8) = (rok && kok) ? vx[h] : (u32x4){0u, 0u, 0u, 0u};
+      if (want_b) {
+        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&zy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += (float)t8[e];
+      }
+    }
+    __syncthreads();
+    if (m0 + 64 < m_end) issue(m0 + 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = ks * 32 + g4 * 8 + q4;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bf16_t* a = sY + row * WT_RS2 + wn * 64 + nt * 16 + p4 * 4;
+        af[nt] = td_tr_read8(a, a + 4 * WT_RS2);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16_t* b = sX + row * WT_RS2 + wk * 64 + kt * 16 + p4 * 4;
+        bfr[kt] = td_tr_read8(b, b + 4 * WT_RS2);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wk * 64 + kt * 16 + pl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * g4 + e;
+        if (n < N && k < K) part_w[((long)z * N + n) * K + k] = acc[nt][kt][e];
+      }
+    }
+  if (want_b) {
+    __syncthreads();
+    float* sb = reinterpret_cast<float*>(sY);                   // [16][129]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sb[r * 129 + c8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < N) {
+      float a = 0.f;
+      for (int rr = 0; rr < 16; ++rr) a += sb[rr * 129 + tid];
+      part_b[(long)z * N + n0 + tid] = a;
+    }
+  }
+}
+
+static bool wgrad_wide(int M, int N, int K) {
+  static const bool off = getenv("TDEED_WGRAD_TILE64") && atoi(getenv("TDEED_WGRAD_TILE64")) == 1;
+  return !off && N >= 96 && K >= 96 && M >= 4096;
+}
+
 // number of M slices: enough workgroups that every CU holds several (each one is a chain of dependent 32-row steps:
 // latency hidden by its neighbours), without slices shorter than 256 rows or more than 32 MB of partials
 extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
-  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
-  long z = (2048 + tiles - 1) / tiles;
+  const int tw = wgrad_wide(M, N, K) ? 128 : 64;
+  const long tiles = (long)((N + tw - 1) / tw) * ((K + tw - 1) / tw);
+  long z = ((tw == 128 ? 1024 : 2048) + tiles - 1) / tiles;
   const long zmax = M >= 8192 ? (M + 255) / 256 : (M + 63) / 64;       // few rows (SE / head layers): 64-row slices
   if (z > zmax) z = zmax;
   const long zbytes = (32L << 20) / ((long)N * K * 4);
@@ -548,7 +651,11 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, co
     static const bool scatter = getenv("TDEED_WGRAD_SCATTER") && atoi(getenv("TDEED_WGRAD_SCATTER")) == 1;
     const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
     TD_CHECK(!X0 || (!valu && vec_ok && !scatter), "wgrad: the spliced X operand needs the transposing-read kernel");
-    if (!valu && vec_ok && !scatter && M >= 4096)               // long contractions: transposing LDS reads, 64-row chunks
+    if (!valu && vec_ok && !scatter && wgrad_wide(M, N, K))     // wide layers: 128 x 128 output tiles
+      hipLaunchKernelGGL(wgrad_tr128_kernel, dim3(cdiv(N, 128), cdiv(K, 128), Z), dim3(256), 0, st, (const bf16_t*)dY, ldy,
+                         (const bf16_t*)X, ldx, (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w,
+                         (db || accumulate < 0) ? part_b : nullptr);
+    else if (!valu && vec_ok && !scatter && M >= 4096)          // long contractions: transposing LDS reads, 64-row chunks
       hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx,
                          (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w, (db || accumulate < 0) ? part_b : nullptr);
     else if (!valu && vec_ok)
