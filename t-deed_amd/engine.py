@@ -158,18 +158,25 @@ def pack_se_mfma(fc1_w, fc2_w, device):
 
 
 GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
+WS_NARROW_ONLY = os.environ.get("TDEED_WS_NARROW_ONLY", "1") == "1"
 
 
 class DenseW:
     """A dense [N][K] weight in the layout the chosen contraction kernel wants."""
 
-    def __init__(self, W, act_dtype, device):
+    def __init__(self, W, act_dtype, device, gated=False):
+        """gated: the layer is a conv3 (SE gate on its operand + residual)."""
         W = _np(W)
         self.N, self.K = W.shape
         # mode 1: the whole W sits in LDS; mode 2 (wide s4 layers: W sliced over blockIdx.y, activations re-read per slice)
         # is opt-in (TDEED_WS_SLICED=1)
         ok_modes = (1, 2) if os.environ.get("TDEED_WS_SLICED", "0") == "1" else (1,)
         self.ws = (ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) in ok_modes) if str(device) != "cpu" else False
+        # The weight-stationary kernel was built for the narrow RegNetY-200MF layers (24 .. 152 channels), where it wins by
+        # 20-35 %; on the 64- and 128-wide layers of the 800MF trunk the tiled kernel is the faster one
+        # (tools/bench_ws_vs_gemm.py, us: 64x64 conv1 135 vs 152, conv3 190 vs 221; 128x128 conv3 101 vs 123; conv1 a tie)
+        if self.ws and WS_NARROW_ONLY and ((self.K == 64 and self.N == 64) or (gated and self.K >= 64 and self.K % 64 == 0)):
+            self.ws = False
         self.w = pack_ws_weights(W, act_dtype, device) if self.ws else _dense(W, act_dtype, device)
         self.kernel = "gemm_ws" if self.ws else "gemm"
 
@@ -599,7 +606,7 @@ class PackedWeights:
             bw.se_mf = (SimpleNamespace(**pack_se_mfma(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
                         if (bw.se_bf is not None and os.environ.get("TDEED_SE_MFMA", "1") == "1"
                             and ops.se_gate_mfma_fits(blk.cout, blk.se_rd)) else None)
-            bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device)
+            bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device, gated=True)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
             if blk.has_downsample:
                 bw.wd = DenseW(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)

@@ -1,37 +1,35 @@
-"""GPU tool: the narrow 1x1 convs of the training step on the tiled gemm kernel vs the weight-stationary one.
-    python tools/bench_ws_vs_gemm.py"""
-import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+"""GPU micro-benchmark: weight-stationary vs tiled contraction on the narrow / mid-width 1x1 convs of the inference forward
+(sub-batch of 4 clips at 200MF, 8 clips at 800MF), plain and as conv3 (SE gate on the operand + residual + ReLU)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import numpy as np
-import tdeed_amd  # noqa
 from tdeed_amd import ops
 from tdeed_amd.engine import pack_ws_weights
 
-def tm(fn, n=10):
+def timeit(fn, reps=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-
-shapes = [(800 * 112 * 112, 32, 24), (800 * 112 * 112, 24, 32), (800 * 56 * 56, 24, 24), (800 * 56 * 56, 24, 56), (800 * 28 * 28, 56, 56),
-          (800 * 28 * 28, 56, 152), (800 * 14 * 14, 152, 152), (1600 * 112 * 112, 32, 64), (1600 * 56 * 56, 64, 64), (1600 * 56 * 56, 64, 144),
-          (1600 * 28 * 28, 144, 144)]
-for M, K, N in shapes:
-    A = torch.randn((M, K), device="cuda", dtype=torch.bfloat16)
-    W = (np.random.randn(N, K) * 0.1).astype(np.float32)
-    Wd = torch.from_numpy(W).cuda().to(torch.bfloat16)
-    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-    t_g = tm(lambda: ops.gemm(A, Wd, None, None, ops.ACT_NONE, out=out, M=M))
-    byts = (M * K + M * N) * 2
-    line = f"M={M:9d} K={K:3d} N={N:3d}  gemm {t_g:8.1f} us {byts/t_g/1e6:6.2f} TB/s"
-    if ops.gemm_ws_fits_mode(K, N, torch.bfloat16) == 1:
-        Wf = pack_ws_weights(W, torch.bfloat16, "cuda")
-        t_w = tm(lambda: ops.gemm_ws(A, Wf, K, N, None, None, ops.ACT_NONE, out=out, M=M))
-        line += f" | gemm_ws {t_w:8.1f} us {byts/t_w/1e6:6.2f} TB/s"
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+for (M, K, N, hw) in [(2508800, 64, 64, 3136), (2508800, 64, 128, 3136), (627200, 128, 128, 784), (627200, 128, 320, 784), (156800, 320, 320, 196),
+                      (1254400, 24, 24, 3136), (313600, 56, 56, 784), (313600, 56, 152, 784), (78400, 152, 152, 196), (78400, 152, 368, 196)]:
+    if not ops.gemm_ws_fits(K, N, torch.bfloat16):
+        print(f"M={M} K={K} N={N}: does not fit the weight-stationary kernel"); continue
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+    Wf = pack_ws_weights(W.float().cpu().numpy(), torch.bfloat16, "cuda")
+    sc, sh = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    t0 = timeit(lambda: ops.gemm(A, W, sc, sh, 1, out=out))
+    t1 = timeit(lambda: ops.gemm_ws(A, Wf, K, N, sc, sh, 1, out=out))
+    line = f"M={M:8d} K={K:4d} N={N:4d}: conv1  tiled {t0:7.1f} us  ws {t1:7.1f} us"
+    if K == N:
+        R = torch.randn(M, N, device="cuda").bfloat16()
+        gate = torch.rand(M // hw, K, device="cuda")
+        t2 = timeit(lambda: ops.gemm(A, W, sc, sh, 1, residual=R, a_scale=gate, a_scale_rows=hw, out=out))
+        t3 = timeit(lambda: ops.gemm_ws(A, Wf, K, N, sc, sh, 1, residual=R, a_scale=gate, a_scale_rows=hw, out=out))
+        line += f" | conv3  tiled {t2:7.1f} us  ws {t3:7.1f} us"
     print(line, flush=True)
-    del A, out
