@@ -86,12 +86,16 @@ int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top,
  *       with tdeed_bn_finalize(colpart, colpart + N, 2N, ceil(M/128), M, N, ...)).
  *   C2  optional second output [M][n2] row stride ldc2 (n2, ldc2 multiples of 8, n2 <= N): a compact copy of columns
  *       [0, n2) of C.  The next bottleneck's gate-shift reads only that channel slice (shift.py:46-93), three times; out of
- *       the channels-last map every such read drags whole rows' cache lines along (measured 4.5x the slice's bytes). */
+ *       the channels-last map every such read drags whole rows' cache lines along (measured 4.5x the slice's bytes).
+ *       c2_pre (tdeed_gemm_fwd only): C2 receives the value before residual and activation and columns [0, n2) of C keep the
+ *       residual alone -- the input gradient of a gate-shifted conv1 (shift.py:89-93 backwards): those columns belong to the
+ *       gate-shift module's backward, the block's shortcut gradient R joins the rest in this epilogue. */
 int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0, int k0,
                    const float* a_scale, int a_scale_rows, int M, int K, int N, const void* W,
                    long ldw, const float* scale, const float* shift, const void* R, long ldr,
                    int act, void* C, long ldc, int gather_stride, int gather_hi, int gather_wi,
-                   int gather_ho, int gather_wo, float* colpart, void* C2, long ldc2, int n2, int dtype, void* stream);
+                   int gather_ho, int gather_wo, float* colpart, void* C2, long ldc2, int n2, int c2_pre, int dtype,
+                   void* stream);
 
 /* Weight-stationary variant of the same contraction for narrow layers (whole W in LDS, activations
  * streamed global->registers in MFMA fragment shape, persistent blocks; see gemm.hip).  Same

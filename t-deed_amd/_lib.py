@@ -41,7 +41,7 @@ _SIGS = {
     "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,
                             P, P, P, P, P, P, P], c_int),
     "tdeed_gemm_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, c_long, P, P, P, c_long,
-                        c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_int, c_int, P], c_int),
+                        c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_int, c_int, c_int, P], c_int),
     "tdeed_gemm_ws_fits": ([c_int, c_int, c_int], c_int),
     "tdeed_gemm_ws_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, c_long,
                            c_int, P, c_long, c_int, c_int, c_int, c_int, c_int, P, c_long, c_int, c_int, P], c_int),

@@ -177,11 +177,11 @@ extern "C" int tdeed_comm_join(void* comm, void* compute_stream) {
 extern "C" int tdeed_comm_destroy(void* comm) {
   if (!comm) return TDEED_OK;
   Comm* c = (Comm*)comm;
-  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl && g_api.CommDestroy) g_api.CommDestroy(c->nccl);
-  if (c->fork) hipEventDestroy(c->fork);
-  if (c->join) hipEventDestroy(c->join);
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->fork) (void)hipEventDestroy(c->fork);
+  if (c->join) (void)hipEventDestroy(c->join);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return TDEED_OK;
 }

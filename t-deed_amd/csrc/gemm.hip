@@ -29,6 +29,7 @@ struct GemmP {
   int g_stride, g_hi, g_wi, g_ho, g_wo;
   float* colpart;      // optional [M tiles][2][N]: per-tile column sums / sums of squares of the stored C (BatchNorm statistics)
   void* C2; long ldc2; int n2;   // optional second, compact copy of columns [0, n2) of C (the next block's gate-shift slice)
+  int c2_pre;                    // C2 takes the value BEFORE residual / activation and C keeps only the residual in those columns
 };
 
 template <typename T> struct Frag;
@@ -297,6 +298,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         float v[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v[e] = cs[row * CS_LD + cj * EPC + e];
+        if (p.c2_pre && n < p.n2) {               // input gradient of a gate-shift conv1: these columns go to the module only
+          Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + n, v);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+        }
         if (p.R) {
           float rv[EPC];
           if constexpr (RPRE) Chunk<T>::load(reinterpret_cast<const T*>(&rres[half][it]), rv);
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
           for (int e = 0; e < EPC; ++e) v[e] = gelu_erf(v[e]);
         }
         Chunk<T>::store(reinterpret_cast<T*>(p.C) + m * p.ldc + n, v);
-        if (p.C2 && n < p.n2) Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + n, v);
+        if (p.C2 && !p.c2_pre && n < p.n2) Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + n, v);
         if (p.colpart) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
@@ -392,7 +398,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
                               const void* W, long ldw, const float* scale, const float* shift,
                               const void* R, long ldr, int act, void* C, long ldc,
                               int gather_stride, int gather_hi, int gather_wi, int gather_ho,
-                              int gather_wo, float* colpart, void* C2, long ldc2, int n2, int dtype, void* stream) {
+                              int gather_wo, float* colpart, void* C2, long ldc2, int n2, int c2_pre, int dtype, void* stream) {
   TD_CHECK(A && W && C, "gemm: null pointer");
   TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm: bad second output n2=%d ldc2=%ld",
            n2, ldc2);
@@ -415,7 +421,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   p.R = R; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
   p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
   p.colpart = colpart;
-  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0; p.c2_pre = (C2 && c2_pre) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st) : launch_gemm<bf16_t>(p, st);
 }

@@ -109,9 +109,10 @@ def _out2(out2, A):
 
 
 def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0,
-         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None, colpart=None, out2=None):
+         A0=None, k0=0, gather=None, out=None, M=None, lda=None, ldc=None, colpart=None, out2=None, out2_pre=False):
     """C = act((A' @ W^T) * scale + shift + residual).  A (M,K) / W (N,K) same dtype.
-    gather = (stride, hi, wi, ho, wo) for the stride-2 1x1 shortcut.  out2 (.., n2): also receives columns [0, n2)."""
+    gather = (stride, hi, wi, ho, wo) for the stride-2 1x1 shortcut.  out2 (.., n2): also receives columns [0, n2);
+    out2_pre: out2 gets them before residual / activation and C keeps only the residual there."""
     _chk(A, "A"); _chk(W, "W", A.dtype)
     K = W.shape[1]
     N = W.shape[0]
@@ -128,7 +129,7 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     call("tdeed_gemm_fwd", ptr(A), lda, ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0,
          ptr(a_scale), a_scale_rows, M, K, N, ptr(W), W.shape[1], ptr(scale), ptr(shift),
          ptr(residual), (residual.shape[-1] if residual is not None else 0), act, ptr(out), ldc,
-         g[0], g[1], g[2], g[3], g[4], ptr(colpart), *_out2(out2, A), dtype_code(A.dtype), stream_ptr())
+         g[0], g[1], g[2], g[3], g[4], ptr(colpart), *_out2(out2, A), int(bool(out2_pre)), dtype_code(A.dtype), stream_ptr())
     return out
 
 

@@ -14,6 +14,8 @@ from . import ops, ops_bwd as B_, repack as R
 BN_EPS = 1e-5
 # ReLU masks of the BatchNorm backward recomputed from z (fa * z + fb > 0) instead of read from the stored activation
 import os as _os
+
+FUSE_RES = _os.environ.get("TDEED_TRAIN_FUSE_RES", "1") == "1"
 ZMASK = _os.environ.get("TDEED_TRAIN_ZMASK", "1") == "1"
 
 
@@ -281,15 +283,23 @@ class BottleneckTrain:
         dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, None if ZMASK else c.y1, c.bn1, sd[self.c1 + ".bn.weight"], relu=True)
         bn_names("conv1", dw, db)
         Nf, h, w, Cin = c.x.shape
-        dx = ops.gemm(dz1, self.w1.wt, None, None, ops.ACT_NONE).view(Nf, h, w, Cin)
+        # identity shortcut: its gradient joins dx in the contraction's epilogue (no separate add pass); behind a gate-shift the
+        # first Fp columns of the contraction belong to the module's backward alone: they leave as a compact tensor and dx keeps
+        # only the shortcut gradient there (no slice copy / zero fill)
+        fuse = FUSE_RES and not blk.has_downsample
+        dA = (torch.empty((Nf * h * w, self.gs.Fp), dtype=dz1.dtype, device=dz1.device)
+              if (self.gs is not None and FUSE_RES) else None)
+        dx = ops.gemm(dz1, self.w1.wt, None, None, ops.ACT_NONE, residual=(d_sc.view(-1, Cin) if fuse else None),
+                      out2=dA, out2_pre=dA is not None).view(Nf, h, w, Cin)
         grads[self.c1 + ".conv.weight"] = B_.wgrad(dz1, c.a1, with_bias=False, M=Nf * h * w, X0=c.G,
                                                    k0=(self.gs.Fp if c.G is not None else 0))[0].reshape(
             sd[self.c1 + ".conv.weight"].shape)
         if self.gs is not None:
             Fp = self.gs.Fp
-            dA = dx.view(-1, Cin)[:, :Fp].contiguous()                          # gradient of the gate-shift output
+            if dA is None:
+                dA = dx.view(-1, Cin)[:, :Fp].contiguous()                      # gradient of the gate-shift output
+                dx.view(-1, Cin)[:, :Fp] = 0
             d_xs, dz_bn = self.gs.backward(dA, grads)
-            dx.view(-1, Cin)[:, :Fp] = 0
             B_.gsf_add_cols(d_xs, dz_bn, dx, Fp)
         # shortcut
         if blk.has_downsample:
@@ -302,6 +312,6 @@ class BottleneckTrain:
                 B_.stride2_scatter_add(d_xs, dx)
             else:
                 dx = B_.eltwise(dx, d_xs, B_.ADD)
-        else:
+        elif not fuse:
             dx = B_.eltwise(dx, d_sc, B_.ADD)
         return dx

@@ -36,10 +36,10 @@ def test_argument_validation_without_gpu(lib):
     from tdeed_amd._lib import call, HipCallError
     with pytest.raises(HipCallError, match="null pointer"):
         call("tdeed_gemm_fwd", None, 8, None, 0, 0, None, 0, 8, 8, 8, None, 8, None, None, None, 0, 0, None, 8,
-             1, 0, 0, 0, 0, None, None, 0, 0, 0, None)
+             1, 0, 0, 0, 0, None, None, 0, 0, 0, 0, None)
     with pytest.raises(HipCallError, match="multiples of 8"):
         call("tdeed_gemm_fwd", 1 << 20, 12, None, 0, 0, None, 0, 8, 12, 8, 1 << 20, 12, None, None, None, 0, 0,
-             1 << 20, 8, 1, 0, 0, 0, 0, None, None, 0, 0, 0, None)
+             1 << 20, 8, 1, 0, 0, 0, 0, None, None, 0, 0, 0, 0, None)
     with pytest.raises(HipCallError, match="group width"):
         call("tdeed_gconv3x3_fwd", 1 << 20, 1, 8, 8, 24, 12, 1, 1 << 20, None, 1 << 20, 1 << 20, 1 << 20, 1 << 20, None, None, None, 1, 0, None)
 

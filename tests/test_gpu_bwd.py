@@ -701,6 +701,34 @@ def test_lazy_weight_gradients_give_the_same_step(monkeypatch):
     assert torch.equal(res["1"][2], res["0"][2]) and torch.equal(res["1"][1], res["0"][1])
 
 
+def test_shortcut_gradient_joins_in_the_contraction_epilogue(monkeypatch):
+    """TDEED_TRAIN_FUSE_RES=1 (default: the identity shortcut's gradient is the residual operand of conv1's input-gradient
+    contraction, the gate-shift columns leave it as a compact tensor) against 0 (separate add / slice copy / zero fill): the
+    same sums with one bf16 rounding instead of two -- losses equal, gradients within bf16 rounding of each other."""
+    from tdeed_amd.trainer import TrainEngine
+    from tdeed_amd import synth, state_layout
+    import tdeed_amd.trunk_train as TT
+    cfg = dict(feature_arch="rny002_gsf", clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    B, T, H, W = 2, 8, 96, 96
+    sd0 = {k: t(v) for k, v in synth.make_state(state_layout.model_state_shapes(cfg), 61).items()}
+    frames = t(synth.uint8_clip(871, (B, T, 3, H, W))).to(DEV)
+    lab_np, labD_np = synth.labels(872, B, T, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.4)
+    lab, labD = t(lab_np).long().to(DEV), t(labD_np).float().to(DEV)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(TT, "FUSE_RES", flag)
+        for dt in (torch.float32, torch.bfloat16):
+            eng = TrainEngine(cfg, {k: v.clone() for k, v in sd0.items()}, act_dtype=dt, lr=1e-3)
+            loss = eng.step(frames, lab, labD)
+            torch.cuda.synchronize()
+            res[(flag, dt)] = (loss.clone(), eng.params.grad.clone())
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 3e-2)):
+        a, b = res[(True, dt)], res[(False, dt)]
+        assert torch.equal(a[0], b[0])                          # the forward is untouched
+        assert rel_err(a[1], b[1]) < tol, (dt, rel_err(a[1], b[1]))
+
+
 def test_conv1_operand_splice_gives_the_same_step(monkeypatch):
     """s3 / s4 conv1 of a gate-shift block: contraction and weight gradient reading [G | x[:, Fp:]] as two sources
     (TDEED_TRAIN_SPLICE=1, default, for M >= 4096 rows) against the materialised operand: bit-identical step."""

@@ -118,6 +118,14 @@ def test_gemm_second_compact_output(ops, M, K, N, n2, dtype):
         assert torch.equal(out, ops.gemm_ws(A, Wf, K, N, None, sh, ops.ACT_RELU, residual=R))
     with pytest.raises(Exception, match="second output"):
         ops.gemm(A, W.to(DEV), None, sh, ops.ACT_RELU, out2=torch.empty((M, N + 8), dtype=dtype, device=DEV))
+    # out2_pre (input gradient of a gate-shifted conv1): out2 = the contraction alone, C keeps only the residual in those columns
+    plain = ops.gemm(A, W.to(DEV), None, None, ops.ACT_NONE)
+    full = ops.gemm(A, W.to(DEV), None, None, ops.ACT_NONE, residual=R)
+    out2.fill_(7.0)
+    out = ops.gemm(A, W.to(DEV), None, None, ops.ACT_NONE, residual=R, out2=out2, out2_pre=True)
+    assert torch.equal(out2, plain[:, :n2]) and torch.equal(out[:, :n2], R[:, :n2]) and torch.equal(out[:, n2:], full[:, n2:])
+    out = ops.gemm(A, W.to(DEV), None, None, ops.ACT_NONE, out2=out2, out2_pre=True)
+    assert torch.equal(out2, plain[:, :n2]) and float(out[:, :n2].abs().max()) == 0.0 and torch.equal(out[:, n2:], plain[:, n2:])
 
 
 WS_SHAPES = [(300, 32, 24), (1000, 24, 24), (257, 24, 56), (640, 56, 56), (999, 56, 152), (4097, 152, 152),
