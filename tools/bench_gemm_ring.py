@@ -1,5 +1,6 @@
-"""GPU micro-benchmark: register-staged tile (TDEED_GEMM_RING=0) against the LDS-DMA ring form, run as two child
-processes per setting (the switch is read once per process).  python tools/bench_gemm_ring.py [child]"""
+"""GPU micro-benchmark: register-staged tile (TDEED_GEMM_RING=0) against the LDS-DMA ring forms, run as child processes per
+setting (the switch is read once per process).  The ring kernels are parked in experiments/gemm_ring.hip: without them plugged
+into gemm.hip (see the header of that file) every setting measures the shipped kernel.  python tools/bench_gemm_ring.py [child]"""
 import sys, os, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(19600, 368, 368), (19600, 152, 368), (78400, 152, 152), (156800, 320, 320), (39200, 784, 784), (78400, 784, 784),
