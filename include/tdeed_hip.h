@@ -451,7 +451,8 @@ int tdeed_comm_unique_id(void* id128);
 int tdeed_comm_init(void** comm_out, const void* id128, int world, int rank);
 int tdeed_comm_info(void* comm, int* world, int* rank);
 int tdeed_comm_all_reduce(void* comm, void* buf, long n, int dtype, void* compute_stream);
-/* the same sum as reduce-scatter + all-gather (n a multiple of world): for the large bucket on point-to-point xGMI */
+/* the same sum as reduce-scatter + all-gather over the first floor(n / world) * world elements plus a plain all-reduce of the
+ * (< world) elements behind them: for the large bucket on point-to-point xGMI; any n is legal */
 int tdeed_comm_all_reduce_rs_ag(void* comm, void* buf, long n, int dtype, void* compute_stream);
 int tdeed_comm_join(void* comm, void* compute_stream);
 int tdeed_comm_destroy(void* comm);

@@ -145,20 +145,28 @@ extern "C" int tdeed_comm_all_reduce(void* comm, void* buf, long n, int dtype, v
 }
 
 // reduce-scatter + all-gather form of the same sum (every link carries 1/world of the buffer twice instead of a ring
-// pass over the whole buffer): n must be a multiple of world
+// pass over the whole buffer) over the largest prefix of buf that divides evenly over the ranks; the rest
+// (< world elements; none when the caller pads its buckets, optim.FlatParams does) goes out as a plain all-reduce, so
+// any n is legal and no rank count silently loses the RS+AG form
 extern "C" int tdeed_comm_all_reduce_rs_ag(void* comm, void* buf, long n, int dtype, void* compute_stream) {
   TD_CHECK(comm && buf && n > 0, "comm_all_reduce_rs_ag: bad arguments");
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "comm_all_reduce_rs_ag: bad dtype %d", dtype);
   Comm* c = (Comm*)comm;
-  TD_CHECK(n % c->world == 0, "comm_all_reduce_rs_ag: n=%ld not a multiple of world=%d", n, c->world);
   const size_t per = (size_t)(n / c->world);
+  const size_t main_n = per * (size_t)c->world;
   const size_t es = dtype == TDEED_F32 ? 4 : 2;
   const int dt = dtype == TDEED_F32 ? NCCL_FLOAT32 : NCCL_BFLOAT16;
   char* mine = (char*)buf + (size_t)c->rank * per * es;
   TD_HIP(hipEventRecord(c->fork, (hipStream_t)compute_stream), "hipEventRecord");
   TD_HIP(hipStreamWaitEvent(c->stream, c->fork, 0), "hipStreamWaitEvent");
-  TD_NCCL(g_api.ReduceScatter(buf, mine, per, dt, NCCL_SUM, c->nccl, c->stream), "ncclReduceScatter");
-  TD_NCCL(g_api.AllGather(mine, buf, per, dt, c->nccl, c->stream), "ncclAllGather");
+  if (per > 0) {
+    TD_NCCL(g_api.ReduceScatter(buf, mine, per, dt, NCCL_SUM, c->nccl, c->stream), "ncclReduceScatter");
+    TD_NCCL(g_api.AllGather(mine, buf, per, dt, c->nccl, c->stream), "ncclAllGather");
+  }
+  if ((size_t)n > main_n) {
+    char* tail = (char*)buf + main_n * es;
+    TD_NCCL(g_api.AllReduce(tail, tail, (size_t)n - main_n, dt, NCCL_SUM, c->nccl, c->stream), "ncclAllReduce (tail)");
+  }
   c->pending++;
   return TDEED_OK;
 }

@@ -98,8 +98,10 @@ class RcclComm:
         return int(w.value), int(r.value)
 
     def all_reduce(self, t, rs_ag=False):
+        """In-place sum over ranks.  rs_ag: reduce-scatter + all-gather over the largest prefix that divides evenly over
+        the ranks, a plain all-reduce of the (< world elements) rest -- tdeed_comm_all_reduce_rs_ag does both."""
         from ._lib import dtype_code, ptr, stream_ptr
-        fn = "tdeed_comm_all_reduce_rs_ag" if (rs_ag and t.numel() % self.world == 0) else "tdeed_comm_all_reduce"
+        fn = "tdeed_comm_all_reduce_rs_ag" if rs_ag else "tdeed_comm_all_reduce"
         self._lib.call(fn, self.handle, ptr(t), t.numel(), dtype_code(t.dtype), stream_ptr())
 
     def join(self):
@@ -122,12 +124,17 @@ class GradReducer:
     backend "rccl": the C-ABI communicator (own stream, capturable into a HIP graph); backend "torch": torch.distributed
     async all_reduce on a side stream (gloo works with GPU tensors: the 2-process single-GPU tests; also CPU tensors)."""
 
-    def __init__(self, flat, buckets, backend=None, device=None):
+    RS_AG_MIN_BYTES = 32 << 20      # buckets at least this large go out as reduce-scatter + all-gather
+
+    def __init__(self, flat, buckets, backend=None, device=None, rs_ag_min_bytes=None):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.flat, self.buckets = flat, [(int(a), int(b)) for a, b in buckets]
         self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
         self.scale = 1.0 / self.world
+        self.rs_ag_min_bytes = self.RS_AG_MIN_BYTES if rs_ag_min_bytes is None else int(rs_ag_min_bytes)
+        self.launched = []                                          # collectives actually enqueued, per call (describe())
         if backend is None:
             backend = "rccl" if (flat.is_cuda and dist.get_backend() == "nccl") else "torch"
         self.backend = backend
@@ -139,23 +146,63 @@ class GradReducer:
             self._side = new_stream(flat.device)
         self._comm = RcclComm(device if device is not None else flat.device) if backend == "rccl" else None
 
+    def plan(self, i):
+        """The collective(s) bucket i goes out as: {"collective": "rs_ag" | "all_reduce", "numel", "rs_ag_numel" (the prefix
+        that divides evenly over the ranks), "tail" (the rest, < world elements, plain all-reduce), "shard_aligned" (every
+        rank's shard starts on a 16-byte boundary)}.  Both transports follow it."""
+        lo, hi = self.buckets[i]
+        n = hi - lo
+        es = self.flat.element_size()
+        if n * es >= self.rs_ag_min_bytes and self.world > 1 and n >= self.world:
+            main = n // self.world * self.world
+            per = main // self.world
+            return dict(collective="rs_ag", numel=n, rs_ag_numel=main, tail=n - main,
+                        shard_aligned=(lo * es) % 16 == 0 and (per * es) % 16 == 0)
+        return dict(collective="all_reduce", numel=n, rs_ag_numel=0, tail=0, shard_aligned=(lo * es) % 16 == 0)
+
+    def _torch_collectives(self, view, pl):
+        """torch.distributed form of plan(): returns what join() finishes -- async works, or (for RS+AG) a closure that
+        waits for the reduce-scatter and then gathers the shards (gloo runs independent async works concurrently, so the
+        all-gather must not be enqueued before the reduce-scatter has produced its shard; the shard lives in a buffer of
+        its own because gloo's reduce-scatter does not support an output aliasing its input)."""
+        if pl["collective"] != "rs_ag":
+            return [dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)]
+        main, per = pl["rs_ag_numel"], pl["rs_ag_numel"] // self.world
+        shard = torch.empty(per, dtype=view.dtype, device=view.device)
+        rs = dist.reduce_scatter_tensor(shard, view[:main], op=dist.ReduceOp.SUM, async_op=True)
+        tail = dist.all_reduce(view[main:], op=dist.ReduceOp.SUM, async_op=True) if pl["tail"] else None
+
+        class _Chain:
+            def wait(_self):
+                rs.wait()
+                dist.all_gather_into_tensor(view[:main], shard)
+                if tail is not None:
+                    tail.wait()
+        return [_Chain()]
+
     def reduce_bucket(self, i):
         lo, hi = self.buckets[i]
         view = self.flat[lo:hi]
         if self.world == 1:
             return
+        pl = self.plan(i)
+        self.launched.append((i, pl["collective"]))
         if self._comm is not None:
-            self._comm.all_reduce(view, rs_ag=(hi - lo) * 4 >= (32 << 20))      # RS+AG for the big bucket
+            self._comm.all_reduce(view, rs_ag=pl["collective"] == "rs_ag")
         elif self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                self._works += self._torch_collectives(view, pl)
         else:
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self._works += self._torch_collectives(view, pl)
 
     def describe(self):
-        """What the bench line prints about the reduction path of a data-parallel run."""
+        """What the bench line prints about the reduction path of a data-parallel run: per bucket its size and the
+        collective it goes out as (plan()), and -- from the communicator itself -- how many ranks RCCL really has."""
         d = dict(backend=self.backend, world=self.world, buckets_mb=[round((b - a) * 4 / 2 ** 20, 1) for a, b in self.buckets],
+                 bucket_collectives=[self.plan(i)["collective"] if self.world > 1 else "none" for i in range(len(self.buckets))],
+                 rs_ag_tail_elems=[self.plan(i)["tail"] for i in range(len(self.buckets))],
+                 shards_16B_aligned=[self.plan(i)["shard_aligned"] for i in range(len(self.buckets))],
                  capturable=self.capturable)
         if self._comm is not None:
             w, r = self._comm.info()
@@ -170,11 +217,16 @@ class GradReducer:
         if self._comm is not None:
             self._comm.join()
             return
+        if self._side is not None:
+            with torch.cuda.stream(self._side):
+                for w in self._works:
+                    w.wait()
+            self._works = []
+            torch.cuda.current_stream().wait_stream(self._side)
+            return
         for w in self._works:
             w.wait()
         self._works = []
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
 
     def close(self):
         if self._comm is not None:

@@ -38,6 +38,13 @@ def read_frame(path, out=None):
     return out
 
 
+def load_clip_video(frame_dir, dataset, video_name, start, end, pad=False, stride=1, source_info=None, out=None):
+    """`FrameReaderVideo.load_frames(video_name, start, end, pad, stride, source_info)` (frame.py:558-626) with the
+    reference's per-dataset file naming (`frame_locator`)."""
+    _, _, _, path_fn = frame_locator(frame_dir, dataset, video_name, source_info)
+    return load_clip(path_fn, start, end, stride=stride, pad=pad, out=out)
+
+
 def load_clip(frame_path_fn, start, end, stride=1, pad=False, out=None):
     """`FrameReaderVideo.load_frames` (frame.py:558-626) for one clip: frames start, start+stride, ... < end through
     `frame_path_fn(frame_num) -> path`; frames before 0 pad the start with zeros, missing files pad the end (kept only
@@ -69,6 +76,152 @@ def load_clip(frame_path_fn, start, end, stride=1, pad=False, out=None):
     if n_pad_start > 0 or (pad and n_pad_end > 0):
         clip = torch.nn.functional.pad(clip, (0, 0, 0, 0, 0, 0, n_pad_start, n_pad_end if pad else 0))
     return clip
+
+
+def frame_locator(frame_dir, dataset, video_name, source_info=None):
+    """Where the frames of one video live, per dataset, as both of the reference's readers lay it out
+    (frame.py:274-292 / 563-578 for the directory and the first frame number, 303-338 / 586-609 for the file names).
+    Returns (base_path, frame0, ndigits, path_fn): frame index n of the video (0 = its first frame) is the file
+    path_fn(n); ndigits is the zero-padded width of FineDiving's file names, -1 for the 'frame<N>.jpg' datasets."""
+    ndigits = -1
+    frame0 = 0
+    if dataset == "finediving":
+        base = os.path.join(frame_dir, video_name.replace("__", "/"))
+        first = sorted(os.listdir(base))[0]
+        ndigits, frame0 = len(first[:-4]), int(first[:-4])
+        return base, frame0, ndigits, (lambda n: os.path.join(base, str(frame0 + n).zfill(ndigits) + ".jpg"))
+    if dataset == "tennis":
+        parts = video_name.split("_")
+        frame0 = int(parts[-2])
+        base = os.path.join(frame_dir, "_".join(parts[:-2]))
+    elif dataset == "finegym":
+        frame0 = source_info["start_frame"] - source_info["pad"][0]
+        base = os.path.join(frame_dir, video_name.split("_")[0])
+    elif dataset in ("soccernetball", "soccernet", "fs_comp", "fs_perf"):
+        base = os.path.join(frame_dir, video_name)
+    else:
+        raise ValueError(f"unknown dataset {dataset!r}")
+    return base, frame0, ndigits, (lambda n: os.path.join(base, "frame" + str(frame0 + n) + ".jpg"))
+
+
+def load_paths(frame_dir, dataset, video_name, start, end, stride=1, source_info=None):
+    """`FrameReader.load_paths` (frame.py:273-351), the training reader's clip descriptor:
+    [base_path, first existing frame NUMBER (file numbering, -1 if none), pad_start, pad_end, ndigits, length] with
+    length = (end - start) // stride.  Frames before 0 count as start padding; from the first missing file on every
+    remaining step counts as end padding (the reference stops looking: a later file that exists is not read)."""
+    base, frame0, ndigits, path_fn = frame_locator(frame_dir, dataset, video_name, source_info)
+    found_start, pad_start, pad_end = -1, 0, 0
+    for n in range(start, end, stride):
+        if n < 0:
+            pad_start += 1
+            continue
+        if pad_end > 0:
+            pad_end += 1
+            continue
+        if os.path.exists(path_fn(n)):
+            if found_start == -1:
+                found_start = frame0 + n
+        else:
+            pad_end += 1
+    return [base, found_start, pad_start, pad_end, ndigits, (end - start) // stride]
+
+
+def load_frames(paths, pad=False, stride=1, out=None, pool=None):
+    """`FrameReader.load_frames` (frame.py:353-382): the `length - pad_start - pad_end` frames numbered paths[1],
+    paths[1] + stride, ... decoded into a uint8 (T,3,H,W) clip, zero frames in front for pad_start, behind for pad_end when
+    `pad`.  out: optional uint8 buffer (>= T frames: a pinned ring slot) to decode into; pool: a DecodePool to decode the
+    frames concurrently."""
+    base, start, pad_start, pad_end, ndigits, length = paths
+    n_real = length - pad_start - pad_end
+    if ndigits == -1:
+        names = [os.path.join(base, "frame") + str(start + j * stride) + ".jpg" for j in range(n_real)]
+    else:
+        names = [base + "/" + str(start + j * stride).zfill(ndigits) + ".jpg" for j in range(n_real)]
+    return _assemble(names, pad_start, pad_end if pad else 0, out, pool)
+
+
+def _assemble(names, n_pad_start, n_pad_end, out, pool):
+    """Decode `names` into [zeros * n_pad_start | frames | zeros * n_pad_end]."""
+    if out is None:
+        first = read_frame(names[0])
+        total = n_pad_start + len(names) + n_pad_end
+        out = torch.zeros((total,) + tuple(first.shape), dtype=torch.uint8)
+        out[n_pad_start].copy_(first)
+        rest = [(nm, out[n_pad_start + 1 + i]) for i, nm in enumerate(names[1:])]
+    else:
+        total = n_pad_start + len(names) + n_pad_end
+        if out.shape[0] < total:
+            raise ValueError(f"staging buffer holds {out.shape[0]} frames, the clip needs {total}")
+        if n_pad_start:
+            out[:n_pad_start].zero_()
+        if n_pad_end:
+            out[n_pad_start + len(names):total].zero_()
+        rest = [(nm, out[n_pad_start + i]) for i, nm in enumerate(names)]
+    if pool is not None:
+        pool.decode(rest)
+    else:
+        for nm, dst in rest:
+            read_frame(nm, out=dst)
+    return out[:total]
+
+
+class DecodePool:
+    """Decode threads of the input pipeline (the reference uses 4-8 DataLoader worker PROCESSES, train_tdeed.py:131-139;
+    Pillow releases the GIL inside libjpeg, so threads scale and decode straight into pinned ring slots without a copy
+    between processes).  decode([(path, uint8 (3,H,W) destination), ...]) returns when all frames are in place."""
+
+    def __init__(self, threads=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self.threads = threads if threads else min(32, (os.cpu_count() or 8))
+        self.ex = ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix="tdeed-decode")
+
+    def decode(self, jobs):
+        futs = [self.ex.submit(read_frame, nm, dst) for nm, dst in jobs]
+        for f in futs:
+            f.result()
+
+    def submit(self, jobs):
+        """Asynchronous form: returns the futures (wait with .result())."""
+        return [self.ex.submit(read_frame, nm, dst) for nm, dst in jobs]
+
+    def close(self):
+        self.ex.shutdown(wait=True)
+
+
+def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, pad=True):
+    """Batches of decoded clips in pinned staging slots, ready for `prefetch`: `clips` is a list of descriptors
+    dict(paths=<load_paths result>, stride=..) (+ any label entries, passed through per batch as lists); every batch dict
+    holds 'frame' = a PINNED uint8 (B,T,3,H,W) tensor filled by `pool` (all frames of the batch are decode jobs of one
+    pool call, so B * T JPEGs decode concurrently).  The slots rotate: a batch must be consumed (copied to the device)
+    before `depth` further batches are produced -- `prefetch` copies it one batch later."""
+    own = pool is None
+    pool = pool if pool is not None else DecodePool()
+    slots = [torch.zeros((batch_size, clip_len) + tuple(frame_shape), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    try:
+        for bi, lo in enumerate(range(0, len(clips) - batch_size + 1, batch_size)):
+            slot = slots[bi % depth]
+            group = clips[lo:lo + batch_size]
+            futs = []
+            for i, c in enumerate(group):
+                base, start, pad_start, pad_end, ndigits, length = c["paths"]
+                stride = c.get("stride", 1)
+                n_real = length - pad_start - pad_end
+                dst = slot[i]
+                if pad_start:
+                    dst[:pad_start].zero_()
+                if pad and pad_end:
+                    dst[pad_start + n_real:pad_start + n_real + pad_end].zero_()
+                for j in range(n_real):
+                    num = start + j * stride
+                    nm = (os.path.join(base, "frame") + str(num) + ".jpg") if ndigits == -1 else (base + "/" + str(num).zfill(ndigits) + ".jpg")
+                    futs += pool.submit([(nm, dst[pad_start + j])])
+            for f in futs:
+                f.result()
+            extra = {k: [c[k] for c in group] for k in group[0] if k not in ("paths", "stride")}
+            yield dict(frame=slot, **extra)
+    finally:
+        if own:
+            pool.close()
 
 
 class PinnedRing:

@@ -12,7 +12,8 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from . import ops, synth, state_layout, augment
+from . import ops, state_layout, augment
+from . import init as ref_init
 from .engine import ForwardEngine
 from .regnet_spec import regnet_spec
 
@@ -31,7 +32,7 @@ class TDEEDModel:
     class Impl:
         """The network.  Holds the fp32 master state in the reference's key grammar."""
 
-        def __init__(self, args=None, seed=0):
+        def __init__(self, args=None, seed=None):
             self._modality = args.modality
             assert self._modality == "rgb", "Only RGB supported for now"
             self._temp_arch = args.temporal_arch
@@ -48,10 +49,14 @@ class TDEEDModel:
             self._require_clip_len = args.clip_len if self._feature_arch.endswith(("_gsm", "_gsf")) else -1
             self.croping = self._cfg["crop_dim"]
             self._head_classes = None
-            # No network, no pretrained ImageNet weights (model.py:38-41 downloads them): deterministic
-            # synthetic init; real weights arrive through load()/load_state_dict().
+            # The reference's construction-time state (init.py: timm's RegNet init with zero_init_last, BatchNorm identity
+            # statistics, temp_enc ~ N(0, 1/L), depthwise convs N(0, 0.1) with zero biases, torch defaults elsewhere;
+            # model.py:38-70, modules.py:146-157, 255-275).  There is no network here, so the ImageNet weights that
+            # `pretrained=True` (model.py:38-41) downloads arrive through load_timm_backbone() / load().
+            # seed: None draws from torch's global CPU generator like the reference's constructors do.
             shapes = state_layout.model_state_shapes(self._cfg)
-            self._state = {k: torch.from_numpy(v) for k, v in synth.make_state(shapes, seed).items()}
+            gen = None if seed is None else torch.Generator().manual_seed(int(seed))
+            self._state = ref_init.reference_init(shapes, self._cfg, gen)
             self._device = "cpu"
             self.training = False
             self._engines = {}
@@ -64,8 +69,15 @@ class TDEEDModel:
             self.augment_generator = None           # torch.Generator for the augmentation draws (None: the global CPU one)
 
         # ---- nn.Module-like surface the reference's callers touch
+        @staticmethod
+        def _norm_device(device):
+            d = torch.device(device)
+            if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+                d = torch.device("cuda", torch.cuda.current_device())
+            return d
+
         def to(self, device):
-            if self._train_engine is not None and str(device) != self._device:
+            if self._train_engine is not None and self._norm_device(device) != self._norm_device(self._device):
                 raise RuntimeError("the model cannot change device once its training engine exists")
             self._device = str(device)
             for k in list(self._state):          # in place: trainer / optimizer may hold this dict
@@ -104,6 +116,16 @@ class TDEEDModel:
                 # the train engine keeps packed copies (bf16 casts, transposes, MFMA fragments) of the master weights
                 self._train_engine.repack()
 
+        def load_timm_backbone(self, timm_state_dict):
+            """Fill the trunk from a timm `regnety_002` / `regnety_008` state_dict (what `timm.create_model(...,
+            pretrained=True)` holds at model.py:38-41): `stem.* / s{1..4}.b{n}.*` -> `_features.*`, with `conv1.*` ->
+            `conv1.net.*` on the gate-shift stages s3 / s4 (shift.py:46-59); `head.fc.*` is dropped (model.py:45).  The
+            gate-shift modules, temp_enc, the temporal stack and the heads keep their construction-time state.
+            Returns the list of keys it filled."""
+            mapped = ref_init.map_timm_backbone(timm_state_dict, self._cfg)
+            self.load_state_dict(mapped, strict=False)
+            return list(mapped)
+
         def parameters(self):
             return [v for k, v in self._state.items() if state_layout.is_parameter(k)]
 
@@ -116,7 +138,7 @@ class TDEEDModel:
             for i, n in enumerate(num_classes, start=1):
                 shapes[f"_pred_fine._fc{i}._fc_out.weight"] = ((n, C), "float32")
                 shapes[f"_pred_fine._fc{i}._fc_out.bias"] = ((n,), "float32")
-            new = {k: torch.from_numpy(v).to(self._device) for k, v in synth.make_state(shapes, 1).items()}
+            new = {k: v.to(self._device) for k, v in ref_init.reference_init(shapes, self._cfg, None).items()}   # nn.Linear defaults
             # keep the reference's key order: heads sit before _pred_displ
             displ = {k: self._state.pop(k) for k in [k for k in self._state if k.startswith("_pred_displ.")]}
             self._state.update(new)

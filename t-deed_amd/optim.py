@@ -15,16 +15,50 @@ import torch
 from . import ops, state_layout
 
 
+BUCKET_ALIGN = 64      # elements: bucket boundaries of the flat buffer are multiples of this (see FlatParams)
+
+
+def is_late_bucket_key(key):
+    """Tensors whose gradients the backward completes first (temporal stack + heads): bucket 0 of the data-parallel
+    reduction (trainer.TrainEngine.grad_buckets)."""
+    return key.startswith(("_temp_fine.", "_pred_"))
+
+
 class FlatParams:
+    @staticmethod
+    def _layout(keys, sizes):
+        """-> (offsets, numel).  Every tensor starts on a 16-byte boundary so that per-tensor kernels can use vector
+        accesses; the boundary between the trunk and the temporal stack (= the boundary between the two gradient buckets of
+        a data-parallel job) and the end of the buffer sit on multiples of BUCKET_ALIGN elements, so that each bucket
+        divides evenly over 2, 4 and 8 ranks with 16-byte-aligned shards: the reduce-scatter + all-gather form of the
+        all-reduce wants that (with 4-element padding only, both buckets were 4 mod 8 and fell back to
+        a plain all-reduce at 8 ranks)."""
+        offs, cur = [], 0
+        prev_late = None
+        for k, n in zip(keys, sizes):
+            late = is_late_bucket_key(k)
+            if prev_late is not None and late != prev_late:
+                cur = (cur + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
+            prev_late = late
+            offs.append(cur)
+            cur += (n + 3) // 4 * 4
+        cur = (cur + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
+        return offs, cur
+
+    @classmethod
+    def layout_only(cls, state):
+        """The index / numel this class would give `state` (name -> anything with .numel() / .shape), nothing allocated."""
+        from types import SimpleNamespace
+        keys = [k for k in state if state_layout.is_parameter(k)]
+        sizes = [int(state[k].numel()) for k in keys]
+        offs, numel = cls._layout(keys, sizes)
+        return SimpleNamespace(numel=numel, index={k: (o, n) for k, o, n in zip(keys, offs, sizes)})
+
     def __init__(self, state, device=None):
         keys = [k for k in state if state_layout.is_parameter(k)]
         device = device if device is not None else state[keys[0]].device
         sizes = [int(state[k].numel()) for k in keys]
-        # every tensor starts on a 16-byte boundary so that per-tensor kernels can use vector accesses
-        offs, cur = [], 0
-        for n in sizes:
-            offs.append(cur)
-            cur += (n + 3) // 4 * 4
+        offs, cur = self._layout(keys, sizes)
         self.numel = cur
         self.flat = torch.zeros(cur, dtype=torch.float32, device=device)
         self.grad = torch.zeros(cur, dtype=torch.float32, device=device)

@@ -18,7 +18,7 @@ import torch
 
 from . import ops, ops_bwd as B_
 from .streams import new_stream
-from .optim import FlatParams, FusedAdamW, warmup_cosine_lr
+from .optim import FlatParams, FusedAdamW, warmup_cosine_lr, is_late_bucket_key
 from .regnet_spec import regnet_spec
 from .temporal_train import TemporalStack
 from .trunk_train import BottleneckTrain, StemTrain, BN_EPS
@@ -60,8 +60,22 @@ class TrainEngine:
     def grad_buckets(self):
         """Element ranges of the flat gradient buffer in the order the backward completes them: [temporal stack + heads]
         (everything from the first `_temp_fine.` tensor to the end of the buffer), then [temp_enc + trunk]."""
-        first = min(o for k, (o, n) in self.params.index.items() if k.startswith(("_temp_fine.", "_pred_")))
+        idx = self.params.index
+        first = min(o for k, (o, n) in idx.items() if is_late_bucket_key(k))
+        stray = [k for k, (o, n) in idx.items() if (o >= first) != is_late_bucket_key(k)]
+        if stray:
+            # the buckets are element RANGES reduced as soon as backward_heads / backward_trunk have written them: a state
+            # dict whose trunk tensors sit behind the temporal stack would have them reduced before they are written
+            raise RuntimeError(f"state_dict order: trunk and temporal-stack tensors interleave in the flat buffer ({stray[:3]} ...)")
         return [(first, self.params.numel), (0, first)]
+
+    def _check_bucket_keys(self, keys, role):
+        """Every gradient the write-out of bucket `role` carries must lie inside that bucket's element range (the range is
+        all-reduced right after the write-out)."""
+        bad = [k for k in keys if is_late_bucket_key(k) != (role == 0)]
+        if bad:
+            raise RuntimeError(f"gradient of {bad[0]} was produced by the {'temporal' if role == 0 else 'trunk'} backward "
+                               f"but belongs to the other gradient bucket")
 
     def set_reducer(self, reducer="auto"):
         """Attach the gradient reducer of a data-parallel job (one process per GPU).  "auto": a dist.GradReducer over this
@@ -211,6 +225,7 @@ class TrainEngine:
             d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
         finally:
             B_.LAZY_WGRAD = False
+        self._check_bucket_keys(g_t, 0)
         self.write_grads(g_t, scale, first, partial=True, role=0)
         if red is not None:
             red.reduce_bucket(0)
@@ -222,9 +237,11 @@ class TrainEngine:
         missing = set(self.params.index) - set(g_t) - set(g_b)
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
+        self._check_bucket_keys(g_b, 1)
         self.write_grads(g_b, scale, first, partial=True, role=1)
         if red is not None:
             red.reduce_bucket(1)
+        self._reduced = red is not None                          # apply() checks it (scale only what was reduced)
 
     def apply(self, lr=None, lr_factor=1.0, all_reduce=None):
         """AdamW on the accumulated gradients (one launch), then refresh the kernels' views of the weights.  With a reducer
@@ -234,8 +251,13 @@ class TrainEngine:
         if all_reduce is not None:
             all_reduce(self.params.grad)
         elif self.reducer is not None:
+            if not getattr(self, "_reduced", False):
+                # the step's gradients were accumulated without `reduce=True` (e.g. accumulate() called directly): sum them
+                # over the ranks now, blocking on nothing but the device -- never scale un-reduced gradients by 1/world
+                self.reducer.reduce_all()
             self.reducer.join()
             gs = self.reducer.scale
+        self._reduced = False
         if lr is not None:
             self.opt.lr = lr
         self.opt.step(lr_factor=lr_factor, grad_scale=gs)
@@ -279,6 +301,10 @@ class TrainEngine:
         h.labelD = torch.zeros((B, T), dtype=torch.float32, device=dev) if with_labelD else None
         h.masks = [torch.ones((B, T, C), dtype=self.dt, device=dev) for _ in range(2 if radi > 0 else 1)]
         red = self.reducer
+        # the gradient write-out launches read their record tables from pinned host memory at every replay: the graph gets
+        # tables of its own (the eager steps' ring and other graphs of this engine must never rewrite them)
+        eager_tabs = getattr(self, "_grad_tabs", None)
+        self._grad_tabs = B_.PinnedTables(max_entries=len(self.params.index) + 8, depth=1)
         # default: two graphs with the collectives launched eagerly between them -- the same overlap, and nothing depends
         # on the collective library's behaviour under stream capture (which no single-GPU box can exercise);
         # TDEED_DP_IN_GRAPH=1 captures the RCCL calls into one graph instead
@@ -301,6 +327,7 @@ class TrainEngine:
                 d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
             finally:
                 B_.LAZY_WGRAD = False
+            self._check_bucket_keys(g_t, 0)
             self.write_grads(g_t, 1.0, True, partial=True, role=0)
             return loss, ctx, d_feat, set(g_t)
 
@@ -313,6 +340,7 @@ class TrainEngine:
             missing = set(self.params.index) - done - set(g_b)
             if missing:
                 raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
+            self._check_bucket_keys(g_b, 1)
             self.write_grads(g_b, 1.0, True, partial=True, role=1)
 
         def capture_one(in_graph):
@@ -374,6 +402,11 @@ class TrainEngine:
         else:
             capture_two()
         h.keep = self._grad_tabs                                 # the gradient write-out tables the graph's copies read
+        if eager_tabs is not None:
+            self._grad_tabs = eager_tabs
+        else:
+            del self._grad_tabs
+        self._reduced = False                                    # (the warm-up pass of an in-graph capture reduced)
         restore()                                                # capture does not execute, but stay explicit
         torch.cuda.synchronize()
         return h
@@ -402,7 +435,11 @@ class TrainEngine:
                 self.reducer.join()
                 gs = self.reducer.scale
         elif all_reduce is None and self.reducer is not None:
-            gs = self.reducer.scale                             # reduced and joined inside the graph
+            if not h.reduce_in_graph:
+                # a graph captured before set_reducer(): its gradients are local, reduce them here
+                self.reducer.reduce_all()
+                self.reducer.join()
+            gs = self.reducer.scale                             # (else: reduced and joined inside the graph)
         if all_reduce is not None:
             all_reduce(self.params.grad)
         if lr is not None:

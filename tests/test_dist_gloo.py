@@ -91,3 +91,95 @@ def test_bucketed_grad_reducer_sums_every_bucket_over_two_ranks():
         p.join(timeout=60)
     want = [3.0 * i for i in range(100)]
     assert res[0][1] == want and res[1][1] == want
+
+
+# ---------------------------------------------------------------------------------------------- world = 8
+CFG3 = dict(feature_arch="rny008_gsf", clip_len=100, crop_dim=224, n_layers=3, sgp_ks=7, sgp_r=4, num_classes=4,
+            radi_displacement=2)
+CFG5 = dict(feature_arch="rny008_gsf", clip_len=250, crop_dim=None, n_layers=2, sgp_ks=9, sgp_r=4, num_classes=12,
+            radi_displacement=4)
+CFG2 = dict(feature_arch="rny002_gsf", clip_len=100, crop_dim=224, n_layers=2, sgp_ks=7, sgp_r=4, num_classes=4,
+            radi_displacement=2)
+
+
+def _flat_layout(cfg):
+    """(numel, first element of the temporal-stack bucket) of the real flat parameter buffer, computed from the shapes
+    alone (optim.FlatParams' rule; no tensors of that size are allocated)."""
+    from tdeed_amd import state_layout
+    from tdeed_amd.optim import FlatParams
+
+    class Meta:                       # stands in for a tensor: FlatParams only needs numel / shape / copy semantics
+        pass
+    shapes = state_layout.model_state_shapes(cfg)
+    state = {k: torch.empty(sh, dtype=torch.float32 if dt == "float32" else torch.int64, device="meta")
+             for k, (sh, dt) in shapes.items()}
+    fp = FlatParams.layout_only(state)
+    first = min(o for k, (o, n) in fp.index.items() if k.startswith(("_temp_fine.", "_pred_")))
+    return fp.numel, first, fp.index
+
+
+@pytest.mark.parametrize("cfg", [CFG2, CFG3, CFG5], ids=["cfg2_200MF", "cfg3_800MF", "cfg5_snb_t250"])
+def test_real_flat_buffer_buckets_divide_over_eight_ranks(cfg):
+    """Both gradient buckets of the real models split evenly over 2, 4 and 8 ranks with 16-byte-aligned shards, so the
+    large bucket takes the reduce-scatter + all-gather path at world 8 (with 4-element padding only it was 4 mod 8)."""
+    numel, first, index = _flat_layout(cfg)
+    for lo, hi in [(first, numel), (0, first)]:
+        n = hi - lo
+        for world in (2, 4, 8):
+            assert n % world == 0, (lo, hi, world)
+            assert (n // world) % 4 == 0 and lo % 4 == 0                # fp32 shards start on 16-byte boundaries
+    # every tensor still starts on a 16-byte boundary and nothing overlaps
+    spans = sorted(index.values())
+    assert all(o % 4 == 0 for o, n in spans)
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] <= numel
+
+
+def _reducer8_worker(rank, world, port, first, numel, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    tdist.init(backend="gloo")
+    # a flat buffer shaped like the real one scaled down by 512 (same residues mod 8 as the real offsets would have
+    # without the padding fix are covered by the odd-bucket case below); rank r holds (r + 1) * i
+    base = (torch.arange(numel) % 1021).float()                  # small integers: every partial sum is exact in fp32
+    flat = base * (rank + 1)
+    red = tdist.GradReducer(flat, [(first, numel), (0, first)], rs_ag_min_bytes=1024)
+    plans = [red.plan(0), red.plan(1)]
+    red.reduce_bucket(0)
+    red.reduce_bucket(1)
+    red.join()
+    d = red.describe()
+    # an unpadded bucket (length 4 mod 8): RS+AG over the prefix that divides, plain all-reduce of the 4-element tail
+    odd = torch.ones(8 * 37 + 4) * (rank + 1)
+    red2 = tdist.GradReducer(odd, [(0, odd.numel())], rs_ag_min_bytes=16)
+    p_odd = red2.plan(0)
+    red2.reduce_bucket(0)
+    red2.join()
+    q.put((rank, float((flat - base * 36.0).abs().max()), plans, d,
+           p_odd, float((odd - 36.0).abs().max()), red.launched))
+    tdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_reducer_takes_rs_ag_on_the_real_bucket_layout():
+    """world = 8 over gloo: GradReducer on a buffer with the real model's bucket boundaries (scaled) must plan AND launch
+    reduce-scatter + all-gather for the large bucket, sum correctly, and report the collective per bucket."""
+    numel, first, _ = _flat_layout(CFG3)
+    assert numel % 64 == 0 and first % 64 == 0
+    # scale the 58 M-element buffer down, keeping both boundaries multiples of 64
+    s_first, s_numel = first // 64 // 64 * 64, numel // 64 // 64 * 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer8_worker, args=(r, 8, port, s_first, s_numel, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, plans, d, p_odd, err_odd, launched in res:
+        assert err == 0.0 and err_odd == 0.0
+        assert plans[0]["collective"] == "rs_ag" and plans[0]["tail"] == 0 and plans[0]["shard_aligned"]
+        assert d["bucket_collectives"][0] == "rs_ag" and d["world"] == 8 and d["rs_ag_tail_elems"] == [0, 0]
+        assert launched[0] == (0, "rs_ag")
+        assert p_odd["collective"] == "rs_ag" and p_odd["tail"] == 4 and p_odd["rs_ag_numel"] == 8 * 37

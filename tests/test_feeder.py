@@ -62,3 +62,50 @@ def test_prefetch_delivers_the_same_batches_on_the_device():
             feeder.done(b)
     torch.cuda.synchronize()
     assert [float(o) for o in outs] == [float(b["frame"].float().sum()) for b in batches]
+
+
+def _golden_frames():
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", "frame_reader.npz"))
+    return json.loads(str(g["meta"])), g, os.path.join(ROOT, "tests", "golden", "frames")
+
+
+def test_clip_readers_match_the_reference_on_the_committed_jpeg_directories():
+    """The fixture holds what the reference's FrameReaderVideo.load_frames / FrameReader.load_paths + load_frames returned
+    (tools/make_goldens.py:frame_reader, dataset/frame.py:263-382, 546-626) for four dataset layouts x eight
+    (start, end, stride, pad) spans on tests/golden/frames/: file naming, start / end padding, stride, missing files."""
+    meta, g, base = _golden_frames()
+    assert len(meta["cases"]) == 32
+    pool = feeder.DecodePool(4)
+    for c in meta["cases"]:
+        ds, si = c["dataset"], meta["source_info"].get(c["dataset"])
+        fdir = os.path.join(base, ds)
+        want = g[c["video_key"]]
+        got = feeder.load_clip_video(fdir, ds, c["video"], c["start"], c["end"], pad=c["pad"], stride=c["stride"], source_info=si)
+        if want.shape == ():
+            assert got == -1, c
+        else:
+            assert got.dtype == torch.uint8 and np.array_equal(got.numpy(), want), c
+        paths = feeder.load_paths(fdir, ds, c["video"], c["start"], c["end"], stride=c["stride"], source_info=si)
+        assert [os.path.relpath(paths[0], base)] + paths[1:] == c["paths"], (c, paths)
+        if "train_key" in c:
+            tr = feeder.load_frames(paths, pad=c["pad"], stride=c["stride"])
+            assert np.array_equal(tr.numpy(), g[c["train_key"]]), c
+            # decoding through the thread pool into a (larger) staging buffer gives the same clip
+            buf = torch.full((12, 3, meta["h"], meta["w"]), 7, dtype=torch.uint8)
+            tr2 = feeder.load_frames(paths, pad=c["pad"], stride=c["stride"], out=buf, pool=pool)
+            assert np.array_equal(tr2.numpy(), g[c["train_key"]]), c
+    pool.close()
+
+
+@pytest.mark.gpu
+def test_clip_batches_decodes_whole_batches_into_pinned_slots():
+    meta, g, base = _golden_frames()
+    cs = [c for c in meta["cases"] if "train_key" in c and g[c["train_key"]].shape[0] == 7 and c["stride"] == 1]
+    assert len(cs) >= 4
+    clips = [dict(paths=[os.path.join(base, c["paths"][0])] + c["paths"][1:], stride=1, tag=i) for i, c in enumerate(cs[:4])]
+    out = list(feeder.clip_batches(clips, 2, (3, meta["h"], meta["w"]), 7, depth=2))
+    assert len(out) == 2 and out[0]["tag"] == [0, 1] and out[1]["frame"].is_pinned()
+    for b, lo in zip(out, (0, 2)):
+        for i in range(2):
+            assert np.array_equal(b["frame"][i].numpy(), g[cs[lo + i]["train_key"]])

@@ -106,3 +106,103 @@ def test_flat_params_alias_state_dict():
     assert torch.allclose(sd[k0], before[k0] + 1.0)
     assert sd["_features.stem.bn.running_mean"].data_ptr() != fp.flat.data_ptr()      # buffers stay outside
     assert all(o % 4 == 0 for o, _ in fp.index.values())
+
+
+# ------------------------------------------------------------------ construction-time state (VERDICT r2 missing 1)
+def _golden(name):
+    import json
+    import os
+    from helpers import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    return json.loads(str(g["meta"])), g
+
+
+@pytest.mark.parametrize("tag", ["gsf", "gsm"])
+def test_default_init_follows_the_reference_constructors(tag):
+    """init.reference_init against statistics recorded from freshly constructed REFERENCE models (tools/make_goldens.py:
+    init_stats; model.py:65, modules.py:146-157, 255-275, gsf.py:17-24, gsm.py:75-76): constants exactly, random tensors by
+    mean / std / range within sampling tolerance.  The trunk convolutions follow timm's own init (unpinned: timm absent)."""
+    from tdeed_amd import init as ref_init
+    meta, g = _golden("init_stats")
+    case = meta["cases"][tag]
+    cfg = case["cfg"]
+    shapes = state_layout.model_state_shapes(cfg)
+    draws = [ref_init.reference_init(shapes, cfg, torch.Generator().manual_seed(100 + i)) for i in range(meta["n_models"])]
+    stats = g[f"{tag}_stats"]
+    assert set(case["keys"]) <= set(shapes)
+    for k, (mean, std, lo, hi, n) in zip(case["keys"], stats):
+        a = np.concatenate([d[k].double().reshape(-1).numpy() for d in draws])
+        assert a.size == int(n), k
+        if std == 0.0:                                   # constants: BatchNorm / LayerNorm identity, zero biases, GSM's conv3D
+            assert np.all(a == mean), (k, mean, a[:4])
+            continue
+        span = max(abs(lo), abs(hi))
+        if n < 30:                                       # 3..24 samples (conv biases of the gate-shift): order of magnitude only
+            assert 0.0 < np.abs(a).max() < 5 * span, (k, np.abs(a).max(), span)
+            continue
+        se = std / np.sqrt(n)
+        assert abs(a.mean() - mean) < 6 * np.sqrt(2) * se + 1e-12, (k, a.mean(), mean)
+        if n >= 200:
+            assert abs(a.std() / std - 1.0) < 0.15, (k, a.std(), std)
+        # uniform draws are bounded by the same 1/sqrt(fan_in); normal ones only statistically
+        assert np.abs(a).max() < 1.6 * span + 1e-12, (k, np.abs(a).max(), span)
+    # timm's RegNet init for the trunk: zero_init_last, conv N(0, sqrt(2 / fan_out)), SE biases zero
+    d0 = draws[0]
+    assert float(d0["_features.s3.b1.conv3.bn.weight"].abs().max()) == 0.0
+    assert float(d0["_features.s3.b1.conv1.net.bn.weight"].min()) == 1.0
+    w = d0["_features.s4.b2.conv2.conv.weight"]          # grouped 3x3: fan_out = 9 * 368 // 46
+    assert abs(float(w.std()) / np.sqrt(2.0 / (9 * 368 // 46)) - 1.0) < 0.05
+    assert float(d0["_features.s2.b1.se.fc1.bias"].abs().max()) == 0.0
+
+
+def test_model_constructor_uses_the_reference_init_not_the_fixture_generator():
+    from tdeed_amd.model import TDEEDModel
+    torch.manual_seed(3)
+    m = TDEEDModel(device="cpu", args=cfg_ns(CFG))
+    sd = m.state_dict()
+    assert float(sd["_features.stem.bn.running_var"].min()) == 1.0 and float(sd["_features.stem.bn.running_mean"].abs().max()) == 0.0
+    assert float(sd["_temp_fine._sgp.0.psi.bias"].abs().max()) == 0.0
+    assert abs(float(sd["temp_enc"].std()) * CFG["clip_len"] - 1.0) < 0.1
+    torch.manual_seed(3)
+    m2 = TDEEDModel(device="cpu", args=cfg_ns(CFG))          # the global generator decides, like torch.nn constructors
+    assert all(torch.equal(v, m2.state_dict()[k]) for k, v in sd.items())
+
+
+@pytest.mark.parametrize("arch", ["rny002_gsf", "rny008_gsf", "rny002_gsm", "rny002"])
+def test_timm_backbone_key_map_equals_the_references_wrapping(arch):
+    """init.timm_key_map against the (reference key <- timm key) pairs recorded from the reference itself by tensor
+    identity through make_temporal_shift (tools/make_goldens.py:timm_keymap; model/shift.py:46-59)."""
+    from tdeed_amd import init as ref_init
+    meta, _ = _golden("timm_keymap")
+    rec = meta["archs"][arch]
+    cfg = dict(CFG, feature_arch=arch, clip_len=8)
+    assert ref_init.timm_key_map(cfg) == {a: b for a, b in rec["pairs"]}
+    assert rec["dropped"] == ["head.fc.bias", "head.fc.weight"]
+
+
+def test_load_timm_backbone_round_trip():
+    from tdeed_amd import init as ref_init
+    from tdeed_amd.model import TDEEDModel
+    m = TDEEDModel(device="cpu", args=cfg_ns(CFG))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    # a timm regnety_002 state dict = the plain-trunk layout without the `_features.` prefix, plus the classifier
+    plain = state_layout.model_state_shapes(dict(CFG, feature_arch="rny002"))
+    timm_sd = {k[len("_features."):]: torch.from_numpy(v) for k, v in synth.make_state(
+        {k: v for k, v in plain.items() if k.startswith("_features.")}, 5).items()}
+    timm_sd["head.fc.weight"], timm_sd["head.fc.bias"] = torch.zeros(1000, 368), torch.zeros(1000)
+    filled = m._model.load_timm_backbone({"module." + k: v for k, v in timm_sd.items()})      # DataParallel prefix tolerated
+    after = m.state_dict()
+    trunk = [k for k in after if k.startswith("_features.") and ".gs." not in k]
+    assert sorted(filled) == sorted(trunk)
+    assert torch.equal(after["_features.s3.b2.conv1.net.conv.weight"], timm_sd["s3.b2.conv1.conv.weight"])
+    assert torch.equal(after["_features.s1.b1.conv1.conv.weight"], timm_sd["s1.b1.conv1.conv.weight"])
+    assert torch.equal(after["_features.s4.b7.se.fc2.bias"], timm_sd["s4.b7.se.fc2.bias"])
+    for k in after:                                              # everything else keeps its construction-time state
+        if k not in trunk:
+            assert torch.equal(after[k], before[k]), k
+    with pytest.raises(ValueError, match="shape"):
+        bad = dict(timm_sd)
+        bad["s4.b1.conv3.conv.weight"] = torch.zeros(768, 768, 1, 1)
+        m._model.load_timm_backbone(bad)
+    with pytest.raises(KeyError):
+        m._model.load_timm_backbone({k: v for k, v in timm_sd.items() if k != "stem.conv.weight"})

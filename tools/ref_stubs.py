@@ -150,6 +150,22 @@ def install():
     for n in ("RandomApply", "ColorJitter", "GaussianBlur", "RandomCrop"):
         setattr(T, n, _dummy(n))
     tv.transforms = T
+    # torchvision.io.read_image (dataset/frame.py:271, 555) over Pillow's libjpeg: uint8 (3,H,W) RGB; a missing or
+    # unreadable file raises RuntimeError like torchvision's decoder does (frame.py:611-615 relies on that)
+    tvio = types.ModuleType("torchvision.io")
+
+    def read_image(path):
+        import numpy as np
+        from PIL import Image
+        try:
+            with Image.open(path) as im:
+                a = np.asarray(im.convert("RGB"))
+        except (OSError, FileNotFoundError) as e:
+            raise RuntimeError(str(e))
+        return torch.from_numpy(np.ascontiguousarray(np.moveaxis(a, 2, 0)))
+    tvio.read_image = read_image
+    tv.io = tvio
+    sys.modules["torchvision.io"] = tvio
     for n, m in [("torchvision", tv), ("torchvision.models", tv.models), ("torchvision.models.resnet", tv.models.resnet),
                  ("torchvision.ops", tv.ops), ("torchvision.ops.misc", tv.ops.misc), ("torchvision.transforms", T)]:
         sys.modules[n] = m
