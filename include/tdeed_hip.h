@@ -136,6 +136,8 @@ int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int 
  * 6C; bf16): C = act((A . W^T) * scale + shift + R).  Two launches: S = tdeed_gemm_splitk_splits(K) partial products
  * into `workspace` (fp32, S*M*N elements, caller-owned), then a reduce + epilogue pass. */
 int tdeed_gemm_splitk_splits(int K);
+int tdeed_gemm_splitk_partials(const void* A, long lda, int M, int K, int N, const void* W, long ldw, float* workspace,
+                               void* stream);   /* the partial products only: workspace [splits(K)][M][N] fp32 */
 int tdeed_gemm_splitk_fwd(const void* A, long lda, int M, int K, int N, const void* W, long ldw, const float* scale,
                           const float* shift, const void* R, long ldr, int act, void* C, long ldc,
                           float* workspace, void* stream);
@@ -222,12 +224,15 @@ int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int
  *              callers otherwise use groupnorm + two tdeed_gemm_fwd. */
 /* chsum (optional, fp32 [B][C][2]): per clip and channel the sum and sum of squares over T of the stored y, which
  * tdeed_sgp_mlp_fwd takes instead of re-reading the clip for its GroupNorm statistics */
+/* rowstat* (optional, fp32 [rows][2] = LayerNorm mean, rstd of every input row, as tdeed_sgp_mlp2_fwd leaves them for the
+ * rows it writes): taken instead of re-deriving the statistics from the clip's (T x C) slab */
 int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w, const float* ln_b, float eps,
-                        const float* dw, const float* db, void* y, float* chsum, int dtype, void* stream);
+                        const float* dw, const float* db, void* y, float* chsum, const float* rowstat, int dtype,
+                        void* stream);
 int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T_lo, int C, int ks, int up,
                           const float* ln1_w, const float* ln1_b, const float* ln2_w, const float* ln2_b, float eps,
-                          const float* dw1, const float* db1, const float* dw2, const float* db2, void* cat, int dtype,
-                          void* stream);
+                          const float* dw1, const float* db1, const float* dw2, const float* db2, void* cat,
+                          const float* rowstat_z, const float* rowstat_x, int dtype, void* stream);
 int tdeed_sgp_mlp_fits(int R, int T, int C, int G);
 /* hidden-chunk split S of the launch (1, 2 or 4); for S > 1 `partial` must hold S*R*C floats (fp32 partials, folded in a
  * fixed order by a second launch) */
@@ -235,6 +240,23 @@ int tdeed_sgp_mlp_splits(int R, int C);
 int tdeed_sgp_mlp_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
                       const void* W1, const float* b1, const void* W2, const float* b2, void* out, float* partial,
                       const float* chsum /* optional, see tdeed_sgp_front_fwd */, void* stream);
+/* sgp_mlp2 (sgp_mlp2.hip, bf16, C <= 384): the same out = y + mlp(GroupNorm16(y)) (modules.py:186, 316) cut into
+ * R/64 row tiles x S = ceil(4C/128) slices of 128 hidden units, so that a few hundred rows still spread the weight stream
+ * over ~150 workgroups; every workgroup issues all its loads up front.  W1p bf16 [S*8][12][64][8]: hidden tile h, k-step
+ * s, lane l, element j = W1[16h + (l&15)][32s + 8(l>>4) + j]; W2p bf16 [S][C/16][4][64][8]: slice q, output tile t, k-step
+ * s = W2[16t + (l&15)][128q + 32s + 8(l>>4) + j]; zeros past C resp. 4C; b1p fp32 [S*128] zero padded
+ * (tdeed_amd.engine.pack_mlp2_frags).  partial: fp32 scratch [S][R][C]; chsum REQUIRED (tdeed_sgp_front_fwd's);
+ * rowstat (optional output, fp32 [R][2]): LayerNorm mean / rstd (eps ln_eps) over C of every stored output row. */
+int tdeed_sgp_mlp2_slices(int C);
+/* fold of a split-K contraction organised by (clip, 16 channels): out = bf16(act(sum_s partial[s] + bias)) and chsum
+ * [B][C][2] = per-channel (sum, sum of squares) over T of the stored values -- the mixer's concat_fc + GELU
+ * (modules.py:308-309) feeding tdeed_sgp_mlp2_fwd.  partial: [S][B*T][C] fp32 from tdeed_gemm_splitk_partials. */
+int tdeed_sgp_fold_cols(const float* partial, int S, int B, int T, int C, const float* bias, int act, void* out,
+                        float* chsum, void* stream);
+int tdeed_sgp_mlp2_fits(int R, int T, int C, int G);
+int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
+                       const void* W1p, const float* b1p, const void* W2p, const float* b2, void* out, float* partial,
+                       const float* chsum, float* rowstat, float ln_eps, void* stream);
 /* nn.GroupNorm(G, C) over (C/G x T) per clip (modules.py:115,186): x,y [B][T][C]. */
 int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* w, const float* b,
                         float eps, void* y, int dtype, void* stream);

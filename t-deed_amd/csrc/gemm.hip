@@ -797,6 +797,23 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 
 extern "C" int tdeed_gemm_splitk_splits(int K) { return (K + SK_KC - 1) / SK_KC; }
 
+// the partial products alone (workspace [tdeed_gemm_splitk_splits(K)][M][N] fp32): for callers that fold them in a kernel of
+// their own (tdeed_sgp_fold_cols: bias + GELU + the per-channel sums the next GroupNorm needs)
+extern "C" int tdeed_gemm_splitk_partials(const void* A, long lda, int M, int K, int N, const void* W, long ldw,
+                                          float* workspace, void* stream) {
+  TD_CHECK(A && W && workspace, "gemm_splitk_partials: null pointer");
+  TD_CHECK(M > 0 && K > 0 && N > 0, "gemm_splitk_partials: bad sizes M=%d K=%d N=%d", M, K, N);
+  TD_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0,
+           "gemm_splitk_partials: K=%d N=%d and the row strides must be multiples of 8", K, N);
+  const int S = tdeed_gemm_splitk_splits(K);
+  TD_CHECK(S <= 65535, "gemm_splitk_partials: K=%d too large", K);
+  const int n_tiles = (N + 63) / 64, m_tiles = (M + 63) / 64;
+  hipLaunchKernelGGL(gemm_splitk_kernel, dim3(n_tiles * m_tiles, S), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
+                     lda, (const bf16_t*)W, ldw, M, N, K, n_tiles, workspace);
+  TD_LAUNCH_CHECK("gemm_splitk_partials");
+  return TDEED_OK;
+}
+
 extern "C" int tdeed_gemm_splitk_fwd(const void* A, long lda, int M, int K, int N, const void* W, long ldw,
                                      const float* scale, const float* shift, const void* R, long ldr, int act,
                                      void* C, long ldc, float* workspace, void* stream) {

@@ -55,6 +55,15 @@ __device__ __forceinline__ void ln_row_stats(const T* __restrict__ slab, long ld
   }
 }
 
+// the same statistics handed over by the producer of the rows (sgp_fold_rows_kernel: rowstat [rows][2] = mean, rstd)
+__device__ __forceinline__ void ln_row_stats_load(const float* __restrict__ rowstat, int T_len, float* mu, float* rs) {
+  for (int t = threadIdx.x; t < T_len; t += blockDim.x) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(rowstat + (long)t * 2);
+    mu[t] = v[0];
+    rs[t] = v[1];
+  }
+}
+
 // LayerNorm applied to the interior rows of a staged tile: tile[halo + t][c] = (x - mu[t]) / den[t] * w[c] + b[c]
 __device__ __forceinline__ void ln_apply_tile(float* tile, int T_len, int halo, const float* mu, const float* rs, float w,
                                               float b, bool cok) {
@@ -73,7 +82,8 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                         float eps, const float* __restrict__ dw,
                                                         const float* __restrict__ db, T* __restrict__ y,
-                                                        float* __restrict__ chsum) {
+                                                        float* __restrict__ chsum,
+                                                        const float* __restrict__ rowstat) {
   extern __shared__ float sm[];
   const int halo = up >> 1;
   const int wlen = 2 * ks + up + 2;
@@ -92,7 +102,8 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
   dw_issue(dw, wlen, c0, C, wv);
   const Bias5 bb = bias_issue(db, C, c0 + c, C);
   const float lw = ln_w[min(c0 + c, C - 1)], lb = ln_b[min(c0 + c, C - 1)];
-  ln_row_stats<T>(x + base, C, T_len, C, eps, mu, rs);
+  if (rowstat) ln_row_stats_load(rowstat + (long)b * T_len * 2, T_len, mu, rs);
+  else ln_row_stats<T>(x + base, C, T_len, C, eps, mu, rs);
   tile_commit<T>(tv, T_len, c0, C, tile, halo);
   dw_commit(wv, wlen, c0, C, wl);
   __syncthreads();
@@ -143,7 +154,7 @@ static size_t front_smem(int T_len, int ks, int up, int ntiles, int nres, int ns
 
 extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w,
                                    const float* ln_b, float eps, const float* dw, const float* db, void* y,
-                                   float* chsum, int dtype, void* stream) {
+                                   float* chsum, const float* rowstat, int dtype, void* stream) {
   TD_CHECK(x && ln_w && ln_b && dw && db && y, "sgp_front: null pointer");
   TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_front: bad sizes");
   TD_CHECK(T <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80,
@@ -155,10 +166,10 @@ extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(sgp_front_kernel<float>, grid, dim3(256), smem, st, (const float*)x, T, C, ks, up, ln_w, ln_b, eps,
-                       dw, db, (float*)y, chsum);
+                       dw, db, (float*)y, chsum, rowstat);
   else if (dtype == TDEED_BF16)
     hipLaunchKernelGGL(sgp_front_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)x, T, C, ks, up, ln_w, ln_b,
-                       eps, dw, db, (bf16_t*)y, chsum);
+                       eps, dw, db, (bf16_t*)y, chsum, rowstat);
   else { tdeed_set_error("sgp_front: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("sgp_front");
   return TDEED_OK;
@@ -174,7 +185,9 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
                                                           const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
                                                           float eps, const float* __restrict__ dw1,
                                                           const float* __restrict__ db1, const float* __restrict__ dw2,
-                                                          const float* __restrict__ db2, T* __restrict__ cat) {
+                                                          const float* __restrict__ db2, T* __restrict__ cat,
+                                                          const float* __restrict__ rowstat_z,
+                                                          const float* __restrict__ rowstat_x) {
   extern __shared__ float sm[];
   const int halo = up >> 1;
   const int wlen = 2 * ks + up + 2;
@@ -201,7 +214,9 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
     float sv[SGP_TI][Chunk<T>::N], wv[SGP_WI];
     tile_issue<T>(sb, C, T_src, c0, C, sv);
     dw_issue(dw, wlen, c0, C, wv);
-    ln_row_stats<T>(sb, C, T_src, C, eps, mu, rs);
+    const float* rst = src == 0 ? rowstat_z : rowstat_x;
+    if (rst) ln_row_stats_load(rst + (long)b * T_src * 2, T_src, mu, rs);
+    else ln_row_stats<T>(sb, C, T_src, C, eps, mu, rs);
     if (src == 0) tile_commit<T>(sv, T_hi, c0, C, tile, halo);
     else tile_commit<T>(sv, T_lo, c0, C, res, 0);          // x_lo at T_lo -> res (no halo)
     dw_commit(wv, wlen, c0, C, wl);
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
 extern "C" int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T_lo, int C, int ks, int up,
                                      const float* ln1_w, const float* ln1_b, const float* ln2_w, const float* ln2_b,
                                      float eps, const float* dw1, const float* db1, const float* dw2, const float* db2,
-                                     void* cat, int dtype, void* stream) {
+                                     void* cat, const float* rowstat_z, const float* rowstat_x, int dtype, void* stream) {
   TD_CHECK(z && xlo && ln1_w && ln1_b && ln2_w && ln2_b && dw1 && db1 && dw2 && db2 && cat, "mixer_front: null pointer");
   TD_CHECK(B > 0 && T_hi >= T_lo && T_lo > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks,
            "mixer_front: bad sizes");
@@ -271,10 +286,10 @@ extern "C" int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(mixer_front_kernel<float>, grid, dim3(256), smem, st, (const float*)z, (const float*)xlo, T_hi, T_lo,
-                       C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (float*)cat);
+                       C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (float*)cat, rowstat_z, rowstat_x);
   else if (dtype == TDEED_BF16)
     hipLaunchKernelGGL(mixer_front_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)z, (const bf16_t*)xlo, T_hi,
-                       T_lo, C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (bf16_t*)cat);
+                       T_lo, C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (bf16_t*)cat, rowstat_z, rowstat_x);
   else { tdeed_set_error("mixer_front: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("mixer_front");
   return TDEED_OK;
