@@ -191,9 +191,10 @@ int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysu
                               int T, int h, int w, int C, int F, int Fp, void* out, int dtype, void* stream);
 
 /* ---- global average pool + positional encoding (model.py:133-137) --------------------------
- * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]). */
+ * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]).  rowstat (optional, fp32
+ * [B*T][2]): LayerNorm mean / rstd over C of every stored feature row, for tdeed_sgp_front_fwd of the first SGP block. */
 int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
-                             void* feat, int dtype, void* stream);
+                             void* feat, float* rowstat, int dtype, void* stream);
 
 /* ---- SGP pyramid pieces (model/modules.py:58-363), NTC layout ------------------------------- */
 /* channel LayerNorm of every row (modules.py:320-363): y[r][c] = (x-mu)/sqrt(var+eps)*w[c]+b[c];
@@ -246,7 +247,10 @@ int tdeed_sgp_mlp_fwd(const void* y, int R, int T, int C, int G, const float* gn
  * s, lane l, element j = W1[16h + (l&15)][32s + 8(l>>4) + j]; W2p bf16 [S][C/16][4][64][8]: slice q, output tile t, k-step
  * s = W2[16t + (l&15)][128q + 32s + 8(l>>4) + j]; zeros past C resp. 4C; b1p fp32 [S*128] zero padded
  * (tdeed_amd.engine.pack_mlp2_frags).  partial: fp32 scratch [S][R][C]; chsum REQUIRED (tdeed_sgp_front_fwd's);
- * rowstat (optional output, fp32 [R][2]): LayerNorm mean / rstd (eps ln_eps) over C of every stored output row. */
+ * rowstat (optional output, fp32 [R][2]): LayerNorm mean / rstd (eps ln_eps) over C of every stored output row.
+ * T_pool > 0 (T/2 <= T_pool <= T): the fold also applies the AdaptiveMaxPool1d(T_pool) that follows an encoder block
+ * (modules.py:64, 75-77): pooled (R/T, T_pool, C) bf16 and rowstat_pool [R/T*T_pool][2] (optional) come out of the same
+ * launch. */
 int tdeed_sgp_mlp2_slices(int C);
 /* fold of a split-K contraction organised by (clip, 16 channels): out = bf16(act(sum_s partial[s] + bias)) and chsum
  * [B][C][2] = per-channel (sum, sum of squares) over T of the stored values -- the mixer's concat_fc + GELU
@@ -254,9 +258,16 @@ int tdeed_sgp_mlp2_slices(int C);
 int tdeed_sgp_fold_cols(const float* partial, int S, int B, int T, int C, const float* bias, int act, void* out,
                         float* chsum, void* stream);
 int tdeed_sgp_mlp2_fits(int R, int T, int C, int G);
+/* diagnostic build of the sgp_mlp2 main kernel with in-kernel phase stamps (tools/stamp_sgp_mlp2.py): stamps
+ * [R/rows * S][8] u64 = s_memtime at start / loads issued / statistics / A tile staged / fc1 done / first partial store /
+ * stores landed, [7] = s_memrealtime at start.  Not part of the product path. */
+int tdeed_sgp_mlp2_stamped(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
+                           const void* W1p, const float* b1p, const void* W2p, float* partial, const float* chsum,
+                           unsigned long long* stamps, int rows, int dbg, void* stream);
 int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
                        const void* W1p, const float* b1p, const void* W2p, const float* b2, void* out, float* partial,
-                       const float* chsum, float* rowstat, float ln_eps, void* stream);
+                       const float* chsum, float* rowstat, float ln_eps, int T_pool, void* pooled, float* rowstat_pool,
+                       void* stream);
 /* nn.GroupNorm(G, C) over (C/G x T) per clip (modules.py:115,186): x,y [B][T][C]. */
 int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* w, const float* b,
                         float eps, void* y, int dtype, void* stream);

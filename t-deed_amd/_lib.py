@@ -93,7 +93,7 @@ _SIGS = {
     "tdeed_gsf_weight_fwd": ([P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gsf_apply_fwd": ([P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gsf_apply_fused_fwd": ([P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
-    "tdeed_avgpool_posenc_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_int, P], c_int),
+    "tdeed_avgpool_posenc_fwd": ([P, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_layernorm_fwd": ([P, c_long, c_int, c_int, P, P, c_float, P, c_long, c_int, P], c_int),
     "tdeed_sgp_branch_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_mixer_branch_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
@@ -101,10 +101,12 @@ _SIGS = {
     "tdeed_mixer_front_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P, P, c_int,
                                P], c_int),
     "tdeed_sgp_mlp2_slices": ([c_int], c_int),
+    "tdeed_sgp_mlp2_stamped": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_sgp_fold_cols": ([P, c_int, c_int, c_int, c_int, P, c_int, P, P, P], c_int),
     "tdeed_gemm_splitk_partials": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P], c_int),
     "tdeed_sgp_mlp2_fits": ([c_int, c_int, c_int, c_int], c_int),
-    "tdeed_sgp_mlp2_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, P, P, c_float, P], c_int),
+    "tdeed_sgp_mlp2_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, P, P, c_float, c_int, P, P, P],
+                           c_int),
     "tdeed_sgp_mlp_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_sgp_mlp_splits": ([c_int, c_int], c_int),
     "tdeed_sgp_mlp_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, P, P], c_int),

@@ -684,7 +684,8 @@ extern "C" int tdeed_se_gate_bf16_fwd(const float* pooled, int n_parts, float in
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict__ x, int T_len, int hw, int C,
                                                              const float* __restrict__ temp_enc,
-                                                             T* __restrict__ feat) {
+                                                             T* __restrict__ feat, float* __restrict__ rowstat,
+                                                             float ln_eps) {
   constexpr int EPC = Chunk<T>::N;
   extern __shared__ float red[];       // [S][C]
   const int f = blockIdx.x;            // frame = b*T + t
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict
     for (int e = 0; e < EPC; ++e) red[s * C + c0 + e] = a[e];
   }
   __syncthreads();
+  float rs1 = 0.f, rs2 = 0.f;
   for (int ch = threadIdx.x; ch < nch; ch += 256) {
     const int c0 = ch * EPC;
     float a[EPC];
@@ -722,22 +724,39 @@ __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict
       a[e] = v / (float)hw + temp_enc[(long)t * C + c0 + e];
     }
     Chunk<T>::store(feat + (long)f * C + c0, a);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float v = round_to<T>(a[e]);
+      rs1 += v;
+      rs2 = fmaf(v, v, rs2);
+    }
+  }
+  if (rowstat) {
+    // LayerNorm statistics of the stored row (mean, rstd over C; modules.py:353-357) for the first SGP block's front kernel
+    __shared__ float scr[8];
+    const float t1 = block_sum<4>(rs1, scr);
+    const float t2 = block_sum<4>(rs2, scr + 4);
+    if (threadIdx.x == 0) {
+      const float m = t1 / (float)C;
+      rowstat[(long)f * 2] = m;
+      rowstat[(long)f * 2 + 1] = 1.0f / sqrtf(fmaxf(t2 / (float)C - m * m, 0.f) + ln_eps);
+    }
   }
 }
 
 extern "C" int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
-                                        void* feat, int dtype, void* stream) {
+                                        void* feat, float* rowstat, int dtype, void* stream) {
   TD_CHECK(x && temp_enc && feat, "avgpool: null pointer");
   TD_CHECK(B > 0 && T > 0 && hw > 0 && C > 0 && C % 8 == 0 && C <= 2048, "avgpool: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32) {
     const int nch = C / 4, S = 256 / nch > 0 ? 256 / nch : 1;
     hipLaunchKernelGGL(avgpool_posenc_kernel<float>, dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
-                       (const float*)x, T, hw, C, temp_enc, (float*)feat);
+                       (const float*)x, T, hw, C, temp_enc, (float*)feat, rowstat, 1e-5f);
   } else if (dtype == TDEED_BF16) {
     const int nch = C / 8, S = 256 / nch > 0 ? 256 / nch : 1;
     hipLaunchKernelGGL(avgpool_posenc_kernel<bf16_t>, dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
-                       (const bf16_t*)x, T, hw, C, temp_enc, (bf16_t*)feat);
+                       (const bf16_t*)x, T, hw, C, temp_enc, (bf16_t*)feat, rowstat, 1e-5f);
   } else { tdeed_set_error("avgpool: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("avgpool_posenc");
   return TDEED_OK;

@@ -28,7 +28,7 @@ constexpr int M2_NT2 = 3;           // output tiles per wave in fc2: 8 waves x 3
 constexpr int M2_KP = M2_KS1 * 32;
 constexpr int M2_LD = M2_KP + 8;    // A-tile row stride (elements): rows shift by one 16-byte bank slot
 constexpr int M2_LDH = M2_HS + 8;
-constexpr int M2_MAXCL = 8;         // clips one row tile may touch
+constexpr int M2_MAXCL = 4;         // clips one row tile may touch
 
 __device__ __forceinline__ float gelu_fast2(float x) {      // erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
   const float z = fabsf(x) * 0.70710678118654752440f;
@@ -38,187 +38,220 @@ __device__ __forceinline__ float gelu_fast2(float x) {      // erf by Abramowitz
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-template <int MT>
+// STAMP: diagnostic build only (tools/stamp_sgp_mlp2.py): wave 0 of every workgroup leaves s_memtime / s_memrealtime
+// stamps of its phases in `stamps` [workgroup][8]; never instantiated by the product path
+#define M2_STAMP(i)                                                                                     \
+  if constexpr (STAMP) {                                                                                \
+    if (tid == 0) stamps[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  }
+
+// sum over each row of 16 lanes, every lane gets it: four DPP moves (quad swaps, half-row mirror, row mirror) instead of
+// four ds_bpermute round trips through the LDS crossbar (~100 cycles each when nothing else covers them)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // 7 - lane in the half
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // 15 - lane in the row
+  return v;
+}
+
+template <int MT, bool STAMP = false>
 __global__ __launch_bounds__(M2_NW * 64, 2) void sgp_mlp2_kernel(
     const bf16_t* __restrict__ y, int R, int T_len, int C, int G, const float* __restrict__ gn_w,
     const float* __restrict__ gn_b, float eps, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
-    const bf16_t* __restrict__ W2, float* __restrict__ partial, const float* __restrict__ chsum) {
+    const bf16_t* __restrict__ W2, float* __restrict__ partial, const float* __restrict__ chsum, int nslice,
+    unsigned long long* __restrict__ stamps = nullptr, int dbg = 0) {
   constexpr int ROWS = 16 * MT;
   constexpr int NTHR = M2_NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   bf16_t* At = reinterpret_cast<bf16_t*>(smraw);                    // [ROWS][M2_LD]  GN(y) rows, bf16, K pad zero
   bf16_t* Ht = At + ROWS * M2_LD;                                   // [ROWS][M2_LDH] GELU(fc1) of this slice
-  float* gstat = reinterpret_cast<float*>(Ht + ROWS * M2_LDH);      // [M2_MAXCL][G][2] (mean, rstd)
-  f32x2* aff = reinterpret_cast<f32x2*>(gstat + M2_MAXCL * 32 * 2);  // [M2_MAXCL][C] GroupNorm as y * scale + shift
+  float* gstat = reinterpret_cast<float*>(Ht + ROWS * M2_LDH);      // [M2_MAXCL][32][2] (mean, rstd)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  const int r0 = blockIdx.x * ROWS;
-  const int s = blockIdx.y;
+  // workgroup -> (row tile, slice): every row tile of one slice runs on ONE XCD (ids equal mod 8 share an XCD's L2 under
+  // round-robin placement -- speed only), so a slice's 192 KB of weights leave the memory side once per launch instead of
+  // once per XCD that happens to host one of its row tiles
+  const int nrt = (R + ROWS - 1) / ROWS;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int s = xcd + 8 * (jx / nrt);
+  if (s >= nslice) return;
+  const int r0 = (jx % nrt) * ROWS;
   const int c_lo = r0 / T_len, c_hi = min(R - 1, r0 + ROWS - 1) / T_len;
   const int cg = C / G;
   const int nck = C / 8;
   const int nto = C / 16;
+  if constexpr (STAMP) {
+    if (tid == 0) stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  }
+  M2_STAMP(0)
 
-  // ---- every global load of the kernel is issued here, oldest-needed first (vmcnt retires in issue order):
-  // per-channel sums for the GroupNorm statistics, the row tile, then both weight slices.
-  // (1) GroupNorm partial sums: 16 lanes per group walk the group's channels
+  // ---- loads, oldest-needed first (vmcnt retires in issue order): per-channel sums for the GroupNorm statistics, the
+  // GroupNorm affine of this thread's channel chunk, the row tile, the fc1 weight tile.  (The fc2 tiles are requested
+  // behind the A-tile staging: their latency then hides behind fc1 and their registers are free for fc1's LDS reads.)
+  // (1) GroupNorm partial sums: 16 lanes per group walk the group's channels, <= M2_MAXCL clips per tile
   constexpr int MAXG = 2;                                           // channels per lane and group: cg <= 32
-  float cs[M2_MAXCL > 4 ? 4 : M2_MAXCL][MAXG][2];
+  float cs[M2_MAXCL][MAXG][2];
   const int ncl = c_hi - c_lo + 1;
   const bool gthr = tid < G * 16;
-  const int gg = tid >> 4, gj = tid & 15;
+  const int gg = min(gthr ? tid >> 4 : 0, G - 1), gj = tid & 15;
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci)
+  for (int ci = 0; ci < M2_MAXCL; ++ci)
 #pragma unroll
     for (int u = 0; u < MAXG; ++u) {
       const int cl = min(gj + 16 * u, cg - 1);
-      const int cc = min(gthr ? gg : 0, G - 1) * cg + cl;
-      const float* p = chsum + ((long)min(c_lo + ci, c_hi) * C + cc) * 2;
-      const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+      const f32x2 v = *reinterpret_cast<const f32x2*>(chsum + ((long)min(c_lo + ci, c_hi) * C + gg * cg + cl) * 2);
       cs[ci][u][0] = v[0];
       cs[ci][u][1] = v[1];
     }
-  // (2) the GroupNorm affine of this lane's channel and the row tile (16-byte chunks)
-  const float gw_c = gn_w[min(tid, C - 1)], gb_c = gn_b[min(tid, C - 1)];
-  constexpr int MAXIT = (ROWS * 48 + NTHR - 1) / NTHR;              // C <= 384: 48 chunks per row
-  const IDiv dck(nck), dcg(cg), dT(T_len);
-  const int nitem = ROWS * nck;
+  // (2) staging roles: thread = (channel chunk ck, row lane rl); rows r0 + rl, + NRL, ...: the chunk's GroupNorm affine is
+  // loaded once, the (clip, group) statistics are re-read from LDS only when the clip changes
+  const int NRL = NTHR / nck;                                       // row lanes (>= 10 for C <= 384)
+  const int ck = tid % nck, rl = tid / nck;
+  const bool sthr = rl < NRL;
+  constexpr int MAXIT = (ROWS + 9) / 10;
+  f32x4 gw[2], gb[2];
+  gw[0] = *reinterpret_cast<const f32x4*>(gn_w + ck * 8);
+  gw[1] = *reinterpret_cast<const f32x4*>(gn_w + ck * 8 + 4);
+  gb[0] = *reinterpret_cast<const f32x4*>(gn_b + ck * 8);
+  gb[1] = *reinterpret_cast<const f32x4*>(gn_b + ck * 8 + 4);
   bf16x8 yv[MAXIT];
+  const long rbase = (STAMP && (dbg & 2)) ? 0 : r0;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int i = min(tid + it * NTHR, nitem - 1);
-    int row, ck;
-    dck.divmod(i, row, ck);
-    const long r = min((long)r0 + row, (long)R - 1);
+    const int row = min(rl + it * NRL, ROWS - 1);
+    const long r = min(rbase + row, (long)R - 1);
     yv[it] = *reinterpret_cast<const bf16x8*>(y + r * C + ck * 8);
   }
-  // (3) weights: fc1 tile (slice s, this wave), fc2 tiles (this wave's 3 output tiles x 4 k-steps); pre-packed in MFMA
-  // A-operand fragment order, one wave-load = 1 KB of consecutive bytes
-  bf16x8 w1[M2_KS1], w2[M2_NT2][M2_KS2];
+  // (3) fc1 weight tile of this wave (slice s), pre-packed in MFMA A-operand fragment order: one wave-load = 1 KB
+  const int sw = (STAMP && (dbg & 1)) ? 0 : s;
+  bf16x8 w1[M2_KS1];
   {
-    const bf16_t* p1 = W1 + (((long)s * M2_NW + wid) * M2_KS1 * 64 + lane) * 8;
+    const bf16_t* p1 = W1 + (((long)sw * M2_NW + wid) * M2_KS1 * 64 + lane) * 8;
 #pragma unroll
     for (int ks = 0; ks < M2_KS1; ++ks) w1[ks] = *reinterpret_cast<const bf16x8*>(p1 + ks * 512);
-#pragma unroll
-    for (int nt = 0; nt < M2_NT2; ++nt) {
-      const int ot = min(wid * M2_NT2 + nt, nto - 1);
-      const bf16_t* p2 = W2 + ((((long)s * nto + ot) * M2_KS2) * 64 + lane) * 8;
-#pragma unroll
-      for (int ks = 0; ks < M2_KS2; ++ks) w2[nt][ks] = *reinterpret_cast<const bf16x8*>(p2 + ks * 512);
-    }
   }
-  const float bias1_0 = b1[s * M2_HS + wid * 16 + lq * 4 + 0], bias1_1 = b1[s * M2_HS + wid * 16 + lq * 4 + 1],
-              bias1_2 = b1[s * M2_HS + wid * 16 + lq * 4 + 2], bias1_3 = b1[s * M2_HS + wid * 16 + lq * 4 + 3];
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + s * M2_HS + wid * 16 + lq * 4);
   TD_ISSUE_FENCE();
+  M2_STAMP(1)
 
   // ---- GroupNorm statistics of the clips this tile touches (fixed-order butterfly over the group's channels)
-  for (int ci0 = 0; ci0 < ncl; ci0 += 4) {
-    if (ci0 > 0) {                                                  // tiles that touch more than 4 clips (short levels)
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+  for (int ci = 0; ci < M2_MAXCL; ++ci) {
+    float a = 0.f, bq = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXG; ++u) {
-          const int cl = min(gj + 16 * u, cg - 1);
-          const int cc = min(gthr ? gg : 0, G - 1) * cg + cl;
-          const f32x2 v = *reinterpret_cast<const f32x2*>(chsum + ((long)min(c_lo + ci0 + ci, c_hi) * C + cc) * 2);
-          cs[ci][u][0] = v[0];
-          cs[ci][u][1] = v[1];
-        }
-    }
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-      float a = 0.f, bq = 0.f;
-#pragma unroll
-      for (int u = 0; u < MAXG; ++u)
-        if (gj + 16 * u < cg) {
-          a += cs[ci][u][0];
-          bq += cs[ci][u][1];
-        }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        bq += __shfl_xor(bq, o, 64);
+    for (int u = 0; u < MAXG; ++u)
+      if (gj + 16 * u < cg) {
+        a += cs[ci][u][0];
+        bq += cs[ci][u][1];
       }
-      if (gthr && gj == 0 && ci0 + ci < ncl) {
-        const float n = (float)(cg * T_len);
-        const float mean = a / n;
-        const float var = fmaxf(bq / n - mean * mean, 0.f);
-        gstat[((ci0 + ci) * G + gg) * 2] = mean;
-        gstat[((ci0 + ci) * G + gg) * 2 + 1] = 1.0f / sqrtf(var + eps);
-      }
+    a = row16_sum(a);
+    bq = row16_sum(bq);
+    if (gthr && gj == 0 && ci < ncl) {
+      const float n = (float)(cg * T_len);
+      const float mean = a / n;
+      const float var = fmaxf(bq / n - mean * mean, 0.f);
+      gstat[(ci * 32 + gg) * 2] = mean;
+      gstat[(ci * 32 + gg) * 2 + 1] = 1.0f / sqrtf(var + eps);
     }
   }
   __syncthreads();
+  M2_STAMP(2)
 
-  // per (clip, channel): GN(y) = y * scale + shift with scale = rstd_g * w_c, shift = b_c - mean_g * scale
-  if (tid < C) {
-    const int g = dcg.div(tid);
-    for (int ci = 0; ci < ncl; ++ci) {
-      const float sc = gstat[(ci * G + g) * 2 + 1] * gw_c;
-      aff[ci * C + tid] = f32x2{sc, fmaf(-gstat[(ci * G + g) * 2], sc, gb_c)};
-    }
-  }
-  __syncthreads();
-
-  // ---- A = GN(y rows) as bf16 into LDS, K pad columns zero
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int i = tid + it * NTHR;
-    if (i < nitem) {
-      int row, ck;
-      dck.divmod(i, row, ck);
-      const long r = (long)r0 + row;
-      bf16x8 o;
-      if (r < R) {
-        const int ci = dT.div((int)r) - c_lo;
-        const f32x4* ap = reinterpret_cast<const f32x4*>(aff + ci * C + ck * 8);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const f32x4 a2 = ap[h];                                  // (scale, shift) of channels 2h, 2h + 1 of the chunk
-          o[2 * h] = (bf16_t)fmaf((float)yv[it][2 * h], a2[0], a2[1]);
-          o[2 * h + 1] = (bf16_t)fmaf((float)yv[it][2 * h + 1], a2[2], a2[3]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)0.f;
-      }
-      *reinterpret_cast<bf16x8*>(At + row * M2_LD + ck * 8) = o;
-    }
-  }
+  // ---- A = GN(y rows) as bf16 into LDS (K pad columns zero): GN(y) = y * sc + sh, sc = rstd_g * w_c, sh = b_c - mean_g * sc
   {
+    const IDiv dT(T_len), dcg(cg);
+    const int g0 = dcg.div(ck * 8);
+    const int split = (g0 + 1) * cg - ck * 8;                       // chunk elements >= split belong to group g0 + 1
+    const int g1 = min(g0 + 1, G - 1);
+    float sc[8], sh[8];
+    int cur = -1;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int row = rl + it * NRL;
+      if (sthr && row < ROWS) {
+        const long r = (long)r0 + row;
+        bf16x8 o;
+        if (r < R) {
+          const int ci = dT.div((int)r) - c_lo;
+          if (ci != cur) {
+            cur = ci;
+            const f32x2 st0 = *reinterpret_cast<const f32x2*>(gstat + (ci * 32 + g0) * 2);
+            const f32x2 st1 = *reinterpret_cast<const f32x2*>(gstat + (ci * 32 + g1) * 2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                           // groups hold >= 8 channels: a chunk spans at most two
+              const bool hi = e >= split;
+              const float mean = hi ? st1[0] : st0[0], rstd = hi ? st1[1] : st0[1];
+              sc[e] = rstd * gw[e >> 2][e & 3];
+              sh[e] = fmaf(-mean, sc[e], gb[e >> 2][e & 3]);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaf((float)yv[it][e], sc[e], sh[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(At + row * M2_LD + ck * 8) = o;
+      }
+    }
     const int padc = (M2_LD - C) / 8;                               // 16-byte chunks of padding per row
     for (int i = tid; i < ROWS * padc; i += NTHR) {
-      const int row = i / padc, ck = i - row * padc;
+      const int row = i / padc, pk = i - row * padc;
       bf16x8 zz;
 #pragma unroll
       for (int e = 0; e < 8; ++e) zz[e] = (bf16_t)0.f;
-      *reinterpret_cast<bf16x8*>(At + row * M2_LD + C + ck * 8) = zz;
+      *reinterpret_cast<bf16x8*>(At + row * M2_LD + C + pk * 8) = zz;
     }
   }
+  // (4) fc2 weight tiles of this wave (3 output tiles x 4 k-steps): requested now, needed after fc1
+  bf16x8 w2[M2_NT2][M2_KS2];
+#pragma unroll
+  for (int nt = 0; nt < M2_NT2; ++nt) {
+    const int ot = min(wid * M2_NT2 + nt, nto - 1);
+    const bf16_t* p2 = W2 + ((((long)sw * nto + ot) * M2_KS2) * 64 + lane) * 8;
+#pragma unroll
+    for (int ks = 0; ks < M2_KS2; ++ks) w2[nt][ks] = *reinterpret_cast<const bf16x8*>(p2 + ks * 512);
+  }
   __syncthreads();
+  M2_STAMP(3)
 
   // ---- fc1: this wave's 16 hidden units x ROWS rows (weights = MFMA A operand, activation rows = B operand: lane l
-  // ends up with units 4*(l>>4) .. +3 of activation row l&15)
+  // ends up with units 4*(l>>4) .. +3 of activation row l&15).  LDS reads go out a batch of k-steps ahead of the MFMAs
+  // that consume them: at 2 waves per SIMD nothing else hides their latency.
   f32x4 acc1[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int KB = MT <= 2 ? 4 : 2;                               // k-steps per batch: KB * MT fragments per buffer
+  constexpr int NB = M2_KS1 / KB;
+  bf16x8 xf[2][KB][MT];
+  auto read_batch = [&](bf16x8 (&dst)[KB][MT], int kb) {
 #pragma unroll
-  for (int ks = 0; ks < M2_KS1; ++ks) {
+    for (int k = 0; k < KB; ++k)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(At + (mt * 16 + lr) * M2_LD + ks * 32 + lq * 8);
-      acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ks], xf, acc1[mt], 0, 0, 0);
-    }
+      for (int mt = 0; mt < MT; ++mt)
+        dst[k][mt] = *reinterpret_cast<const bf16x8*>(At + (mt * 16 + lr) * M2_LD + (kb * KB + k) * 32 + lq * 8);
+  };
+  read_batch(xf[0], 0);
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    if (kb + 1 < NB) read_batch(xf[(kb + 1) & 1], kb + 1);
+    __builtin_amdgcn_sched_barrier(0);                              // the next batch's reads stay ahead of this batch's MFMAs
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kb * KB + k], xf[kb & 1][k][mt], acc1[mt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     bf16x4 o;
-    o[0] = (bf16_t)gelu_fast2(acc1[mt][0] + bias1_0);
-    o[1] = (bf16_t)gelu_fast2(acc1[mt][1] + bias1_1);
-    o[2] = (bf16_t)gelu_fast2(acc1[mt][2] + bias1_2);
-    o[3] = (bf16_t)gelu_fast2(acc1[mt][3] + bias1_3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)gelu_fast2(acc1[mt][j] + bias1[j]);
     *reinterpret_cast<bf16x4*>(Ht + (mt * 16 + lr) * M2_LDH + wid * 16 + lq * 4) = o;
   }
   __syncthreads();
+  M2_STAMP(4)
 
   // ---- fc2 partial of this slice: out features of this wave's tiles += W2[:, slice] . Hs
   f32x4 acc2[M2_NT2][MT];
@@ -226,15 +259,20 @@ __global__ __launch_bounds__(M2_NW * 64, 2) void sgp_mlp2_kernel(
   for (int nt = 0; nt < M2_NT2; ++nt)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc2[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    bf16x8 hf[M2_KS2][MT];
 #pragma unroll
-  for (int ks = 0; ks < M2_KS2; ++ks) {
-    bf16x8 hf[MT];
+    for (int ks = 0; ks < M2_KS2; ++ks)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) hf[mt] = *reinterpret_cast<const bf16x8*>(Ht + (mt * 16 + lr) * M2_LDH + ks * 32 + lq * 8);
+      for (int mt = 0; mt < MT; ++mt)
+        hf[ks][mt] = *reinterpret_cast<const bf16x8*>(Ht + (mt * 16 + lr) * M2_LDH + ks * 32 + lq * 8);
 #pragma unroll
-    for (int nt = 0; nt < M2_NT2; ++nt)
+    for (int ks = 0; ks < M2_KS2; ++ks)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt][ks], hf[mt], acc2[nt][mt], 0, 0, 0);
+      for (int nt = 0; nt < M2_NT2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt][ks], hf[ks][mt], acc2[nt][mt], 0, 0, 0);
   }
 #pragma unroll
   for (int nt = 0; nt < M2_NT2; ++nt) {
@@ -246,6 +284,11 @@ __global__ __launch_bounds__(M2_NW * 64, 2) void sgp_mlp2_kernel(
         if (r < R) *reinterpret_cast<f32x4*>(partial + ((long)s * R + r) * C + n0) = acc2[nt][mt];
       }
     }
+    if (nt == 0) { M2_STAMP(5) }
+  }
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    M2_STAMP(6)
   }
 }
 
@@ -272,6 +315,10 @@ __global__ __launch_bounds__(256) void sgp_fold_rows_kernel(const float* __restr
 #pragma unroll
     for (int s = 0; s < 16; ++s)
       if (s < S) { a[0] += pv[s][0]; a[1] += pv[s][1]; a[2] += pv[s][2]; a[3] += pv[s][3]; }
+    for (int s = 16; s < S; ++s) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(p + (long)s * RC);
+      a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3];
+    }
     bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
     *reinterpret_cast<bf16x4*>(out + (long)r * C + c0) = o;
 #pragma unroll
@@ -289,6 +336,95 @@ __global__ __launch_bounds__(256) void sgp_fold_rows_kernel(const float* __restr
       const float var = fmaxf(s2 / (float)C - m * m, 0.f);
       rowstat[(long)r * 2] = m;
       rowstat[(long)r * 2 + 1] = 1.0f / sqrtf(var + eps);
+    }
+  }
+}
+
+// The same fold with the AdaptiveMaxPool1d that follows an encoder block (modules.py:64, 75-77) folded in: one workgroup
+// per POOLED row i of a clip, one wave per block-output row of its window [floor(i T/O), ceil((i+1) T/O)) (<= 3 rows).
+// Wave k folds row lo + k exactly like sgp_fold_rows_kernel, stores it with its LayerNorm statistics if this window
+// owns it (row t belongs to the window whose start is the last one <= t: overlapping windows of odd lengths fold a shared
+// row twice and store it once), and leaves the stored (rounded) values in LDS; wave 0 then takes the element-wise maximum
+// as the pooled row and its statistics.  Removes the max-pool launch and its pass over the map.
+__global__ __launch_bounds__(192) void sgp_fold_rows_pool_kernel(const float* __restrict__ partial, int S, int B, int T_in,
+                                                                 int T_out, int C, const float* __restrict__ b2,
+                                                                 const bf16_t* __restrict__ y, bf16_t* __restrict__ out,
+                                                                 float* __restrict__ rowstat, bf16_t* __restrict__ pooled,
+                                                                 float* __restrict__ rowstat_p, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  bf16_t* rows = reinterpret_cast<bf16_t*>(fsm);                    // [3][C] stored values of the window's rows
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const int b = blockIdx.x / T_out, i = blockIdx.x - b * T_out;
+  const int lo = (int)(((long)i * T_in) / T_out);
+  const int hi = (int)((((long)(i + 1)) * T_in + T_out - 1) / T_out);
+  const int lo_next = i + 1 < T_out ? (int)(((long)(i + 1) * T_in) / T_out) : T_in;
+  const int nwin = hi - lo;
+  const long RC = (long)B * T_in * C;
+  if (k < nwin) {
+    const long r = (long)b * T_in + lo + k;
+    const bool own = lo + k < lo_next;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+      const bf16x4 yr = *reinterpret_cast<const bf16x4*>(y + r * C + c0);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + c0);
+      f32x4 a = {(float)yr[0] + bb[0], (float)yr[1] + bb[1], (float)yr[2] + bb[2], (float)yr[3] + bb[3]};
+      const float* p = partial + r * C + c0;
+      f32x4 pv[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) pv[s] = *reinterpret_cast<const f32x4*>(p + (long)min(s, S - 1) * RC);
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (s < S) { a[0] += pv[s][0]; a[1] += pv[s][1]; a[2] += pv[s][2]; a[3] += pv[s][3]; }
+      for (int s = 16; s < S; ++s) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p + (long)s * RC);
+        a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3];
+      }
+      const bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+      if (own) *reinterpret_cast<bf16x4*>(out + r * C + c0) = o;
+      *reinterpret_cast<bf16x4*>(rows + k * C + c0) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = (float)o[e];
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+    if (own && rowstat) {
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        const float m = s1 / (float)C;
+        rowstat[r * 2] = m;
+        rowstat[r * 2 + 1] = 1.0f / sqrtf(fmaxf(s2 / (float)C - m * m, 0.f) + eps);
+      }
+    }
+  }
+  __syncthreads();
+  if (k == 0) {
+    float p1 = 0.f, p2 = 0.f;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+      bf16x4 m = *reinterpret_cast<const bf16x4*>(rows + c0);
+      for (int j = 1; j < nwin; ++j) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(rows + j * C + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = (float)v[e] > (float)m[e] ? v[e] : m[e];
+      }
+      *reinterpret_cast<bf16x4*>(pooled + ((long)b * T_out + i) * C + c0) = m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = (float)m[e];
+        p1 += v;
+        p2 = fmaf(v, v, p2);
+      }
+    }
+    if (rowstat_p) {
+      p1 = wave_sum(p1);
+      p2 = wave_sum(p2);
+      if (lane == 0) {
+        const float m = p1 / (float)C;
+        rowstat_p[((long)b * T_out + i) * 2] = m;
+        rowstat_p[((long)b * T_out + i) * 2 + 1] = 1.0f / sqrtf(fmaxf(p2 / (float)C - m * m, 0.f) + eps);
+      }
     }
   }
 }
@@ -346,8 +482,21 @@ __global__ __launch_bounds__(256) void sgp_fold_cols_kernel(const float* __restr
   }
 }
 
+// 1-D grid: 8 x ceil(S / 8) x row tiles ids; id -> XCD id % 8, slices {x, x + 8, ...} live on XCD x (ids whose slice falls
+// past S exit at once)
+int mlp2_grid(int R, int rows, int S) { return 8 * ((S + 7) / 8) * ((R + rows - 1) / rows); }
+
 size_t mlp2_smem(int rows, int C) {
-  return (size_t)rows * (M2_LD + M2_LDH) * 2 + (size_t)M2_MAXCL * 32 * 2 * sizeof(float) + (size_t)M2_MAXCL * C * 2 * sizeof(float);
+  (void)C;
+  return (size_t)rows * (M2_LD + M2_LDH) * 2 + (size_t)M2_MAXCL * 32 * 2 * sizeof(float);
+}
+
+// rows per workgroup: 64 while a tile then touches at most M2_MAXCL clips and the grid stays wide, else 32
+int mlp2_rows(int R, int T, int S) {
+  static const int force_rows = getenv("TDEED_SGP_MLP2_ROWS") ? atoi(getenv("TDEED_SGP_MLP2_ROWS")) : 0;
+  const bool ok64 = (64 - 1) / T + 2 <= M2_MAXCL;
+  if (force_rows == 32 || (force_rows == 64 && ok64)) return force_rows;
+  return (ok64 && cdiv(R, 64) * S >= 128) ? 64 : 32;
 }
 
 }  // namespace
@@ -363,15 +512,37 @@ extern "C" int tdeed_sgp_fold_cols(const float* partial, int S, int B, int T, in
   return TDEED_OK;
 }
 
+// diagnostic: the 64-row kernel with phase stamps (stamps: [R/64 * S][8] u64; [0..6] s_memtime at start / loads issued /
+// statistics done / A tile staged / fc1 done / first partial store issued / stores landed, [7] s_memrealtime at start)
+extern "C" int tdeed_sgp_mlp2_stamped(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b,
+                                      float eps, const void* W1p, const float* b1p, const void* W2p, float* partial,
+                                      const float* chsum, unsigned long long* stamps, int rows, int dbg, void* stream) {
+  TD_CHECK(y && W1p && W2p && partial && chsum && stamps, "sgp_mlp2_stamped: null pointer");
+  TD_CHECK(tdeed_sgp_mlp2_fits(R, T, C, G), "sgp_mlp2_stamped: geometry not served");
+  const int S = (4 * C + M2_HS - 1) / M2_HS;
+  hipError_t e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { tdeed_set_error("sgp_mlp2_stamped: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+  if (rows == 64)
+    hipLaunchKernelGGL((sgp_mlp2_kernel<4, true>), dim3(mlp2_grid(R, 64, S)), dim3(M2_NW * 64), mlp2_smem(64, C), (hipStream_t)stream,
+                       (const bf16_t*)y, R, T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum, S, stamps, dbg);
+  else
+    hipLaunchKernelGGL((sgp_mlp2_kernel<2, true>), dim3(mlp2_grid(R, 32, S)), dim3(M2_NW * 64), mlp2_smem(32, C), (hipStream_t)stream,
+                       (const bf16_t*)y, R, T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum, S, stamps, dbg);
+  TD_LAUNCH_CHECK("sgp_mlp2_stamped");
+  return TDEED_OK;
+}
+
 // hidden slices of the narrow form: ceil(4C / 128)
 extern "C" int tdeed_sgp_mlp2_slices(int C) { return (4 * C + M2_HS - 1) / M2_HS; }
 
 // 1 when sgp_mlp2 serves the geometry: bf16, C a multiple of 16 with C <= 384, G groups of <= 32 channels, producer
 // supplies per-channel sums (chsum)
 extern "C" int tdeed_sgp_mlp2_fits(int R, int T, int C, int G) {
-  if (C % 16 != 0 || C > M2_KP || C < 64 || G <= 0 || G > 32 || C % G != 0 || C / G > 32 || T <= 0 || R % T != 0) return 0;
+  if (C % 16 != 0 || C > M2_KP || C < 64 || G <= 0 || G > 32 || C % G != 0 || C / G > 32 || C / G < 8 || T <= 0 || R % T != 0)
+    return 0;
   if (tdeed_sgp_mlp2_slices(C) > 16) return 0;
-  if ((64 - 1) / T + 2 > M2_MAXCL) return 0;
+  if ((32 - 1) / T + 2 > M2_MAXCL) return 0;                         // even a 32-row tile would touch too many clips
   return 1;
 }
 
@@ -380,7 +551,8 @@ extern "C" int tdeed_sgp_mlp2_fits(int R, int T, int C, int G) {
 // [tdeed_sgp_mlp2_slices(C)][R][C]; rowstat: optional [R][2] output (LayerNorm mean, rstd of every output row).
 extern "C" int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
                                   const void* W1p, const float* b1p, const void* W2p, const float* b2, void* out,
-                                  float* partial, const float* chsum, float* rowstat, float ln_eps, void* stream) {
+                                  float* partial, const float* chsum, float* rowstat, float ln_eps, int T_pool,
+                                  void* pooled, float* rowstat_pool, void* stream) {
   TD_CHECK(y && gn_w && gn_b && W1p && b1p && W2p && b2 && out && partial && chsum, "sgp_mlp2: null pointer");
   TD_CHECK(tdeed_sgp_mlp2_fits(R, T, C, G), "sgp_mlp2: geometry R=%d T=%d C=%d G=%d not served", R, T, C, G);
   const int S = tdeed_sgp_mlp2_slices(C);
@@ -392,17 +564,23 @@ extern "C" int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, con
     if (e != hipSuccess) { tdeed_set_error("sgp_mlp2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
     attr_set = true;
   }
-  static const int force_rows = getenv("TDEED_SGP_MLP2_ROWS") ? atoi(getenv("TDEED_SGP_MLP2_ROWS")) : 0;
   // 64-row tiles while they fill the chip (R / 64 x S workgroups); 32-row tiles for the short pyramid levels
-  const int rows = force_rows == 32 || force_rows == 64 ? force_rows : (cdiv(R, 64) * S >= 128 ? 64 : 32);
+  const int rows = mlp2_rows(R, T, S);
   if (rows == 64)
-    hipLaunchKernelGGL((sgp_mlp2_kernel<4>), dim3(cdiv(R, 64), S), dim3(M2_NW * 64), mlp2_smem(64, C), st, (const bf16_t*)y, R,
-                       T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum);
+    hipLaunchKernelGGL((sgp_mlp2_kernel<4>), dim3(mlp2_grid(R, 64, S)), dim3(M2_NW * 64), mlp2_smem(64, C), st, (const bf16_t*)y, R,
+                       T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum, S);
   else
-    hipLaunchKernelGGL((sgp_mlp2_kernel<2>), dim3(cdiv(R, 32), S), dim3(M2_NW * 64), mlp2_smem(32, C), st, (const bf16_t*)y, R,
-                       T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum);
-  hipLaunchKernelGGL(sgp_fold_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, partial, S, R, C, b2, (const bf16_t*)y,
-                     (bf16_t*)out, rowstat, ln_eps);
+    hipLaunchKernelGGL((sgp_mlp2_kernel<2>), dim3(mlp2_grid(R, 32, S)), dim3(M2_NW * 64), mlp2_smem(32, C), st, (const bf16_t*)y, R,
+                       T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum, S);
+  if (T_pool > 0) {
+    // windows of AdaptiveMaxPool1d(T_pool) over T rows hold at most 3 rows for T_pool >= T / 2 (the pyramid halves, rounding up)
+    TD_CHECK(pooled && T_pool <= T && 2 * T_pool >= T, "sgp_mlp2: pooled output needs T/2 <= T_pool <= T (T=%d, T_pool=%d)", T, T_pool);
+    const int Bn = R / T;
+    hipLaunchKernelGGL(sgp_fold_rows_pool_kernel, dim3(Bn * T_pool), dim3(192), (size_t)3 * C * sizeof(bf16_t), st, partial, S,
+                       Bn, T, T_pool, C, b2, (const bf16_t*)y, (bf16_t*)out, rowstat, (bf16_t*)pooled, rowstat_pool, ln_eps);
+  } else
+    hipLaunchKernelGGL(sgp_fold_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, partial, S, R, C, b2, (const bf16_t*)y,
+                       (bf16_t*)out, rowstat, ln_eps);
   TD_LAUNCH_CHECK("sgp_mlp2");
   return TDEED_OK;
 }

@@ -461,20 +461,30 @@ class SgpBuilder:
             self.steps.append(Step(name, "gemm", lambda: ops.gemm(A, Wt, None, bias, act, residual=residual, out=out, M=R),
                                    *gemm_cost(R, K, N, es, residual is not None)))
 
-    def _mlp(self, name, y, o, outb, Tn, chsum=None):
+    def _mlp(self, name, y, o, outb, Tn, chsum=None, pool_to=None):
         """out = y + mlp(GN(y)): one launch where sgp_mlp serves the geometry, else groupnorm + two contractions."""
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
         es, R = _esz(dt), B * Tn
         self.last_rowstat = None
+        self.last_pooled = None
         # narrow feature dimension (C <= 384) with the producer's per-channel sums at hand: row tiles x hidden slices, and
         # the fold leaves the LayerNorm statistics of the output rows for whichever front kernel reads them next
         if (self.fused and dt == torch.bfloat16 and str(y.device) != "cpu" and chsum is not None
                 and getattr(o, "w1p", None) is not None and ops.sgp_mlp2_fits(R, Tn, C)):
             ws = pool.take((ops.sgp_mlp2_slices(C), R, C), torch.float32)
             rst = torch.empty((R, 2), dtype=torch.float32, device=y.device)       # lives as long as the plan (tiny)
+            pooled = rsp = None
+            if pool_to is not None and 2 * pool_to >= Tn:
+                # the AdaptiveMaxPool1d behind an encoder block rides on the fold launch
+                pooled = pool.take((B, pool_to, C), dt)
+                rsp = torch.empty((B * pool_to, 2), dtype=torch.float32, device=y.device)
+                pooled._td_rowstat = rsp
+                self.last_pooled = pooled
             steps.append(Step(name + ".mlp", "sgp_mlp2", lambda: ops.sgp_mlp2(y, o.gn_w, o.gn_b, o.w1p, o.b1p, o.w2p, o.b_fc2,
-                                                                            chsum, out=outb, partial=ws, rowstat=rst),
-                              2 * R * C * es + 8 * C * C * es, 2 * R * 8 * C * C))
+                                                                            chsum, out=outb, partial=ws, rowstat=rst,
+                                                                            pooled=pooled, rowstat_pool=rsp),
+                              2 * R * C * es + 8 * C * C * es + (0 if pooled is None else B * pool_to * C * es),
+                              2 * R * 8 * C * C))
             pool.give(ws)
             self.last_rowstat = rst
             return
@@ -496,8 +506,11 @@ class SgpBuilder:
         pool.give(gn)
         pool.give(hid)
 
-    def block(self, xin, Tn, o, name):
+    def block(self, xin, Tn, o, name, pool_to=None):
+        """One SGPBlock.  pool_to: length of the AdaptiveMaxPool1d that follows (encoder half); when the MLP launch can
+        carry it, `self.last_pooled` holds the pooled tensor afterwards (else None: the caller adds a max-pool launch)."""
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        self.last_pooled = None
         if self.fused and str(xin.device) != "cpu":
             y = pool.take((B, Tn, C), dt)
             outb = pool.take((B, Tn, C), dt)
@@ -508,7 +521,7 @@ class SgpBuilder:
             steps.append(Step(name + ".front", "sgp_front", lambda: ops.sgp_front(xin, o.ks, o.up, o.ln_w, o.ln_b, o.dw, o.db,
                                                                                  out=y, chsum=chs, rowstat=rs_in),
                               2 * R * C * es + C * (wl + 7) * 4, 2 * R * C * (wl + 3)))
-            self._mlp(name, y, o, outb, Tn, chsum=chs)
+            self._mlp(name, y, o, outb, Tn, chsum=chs, pool_to=pool_to)
             if self.last_rowstat is not None:
                 outb._td_rowstat = self.last_rowstat
             pool.give(y)
@@ -605,11 +618,13 @@ class SgpBuilder:
         cur = feat
         stash = []
         for i in range(n):
-            cur = self.block(cur, lens[i], sgp[i], f"{pre}_sgp.{i}")
+            cur = self.block(cur, lens[i], sgp[i], f"{pre}_sgp.{i}", pool_to=lens[i + 1])
             stash.append(cur)
-            pooled = pool.take((B, lens[i + 1], C), dt)
-            steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1]: ops.maxpool(a, L, out=b),
-                              B * (lens[i] + lens[i + 1]) * C * _esz(dt)))
+            pooled = self.last_pooled
+            if pooled is None:
+                pooled = pool.take((B, lens[i + 1], C), dt)
+                steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1]: ops.maxpool(a, L, out=b),
+                                  B * (lens[i] + lens[i + 1]) * C * _esz(dt)))
             cur = pooled
         cur = self.block(cur, lens[n], sgp[n], f"{pre}_sgp.{n}")
         for i in range(n):
@@ -850,7 +865,10 @@ class ForwardEngine:
         if trunk_in is not None:
             x, h, w = trunk_in
             x, h, w, _ = self._blocks(pool, steps, keep, set(), B, x, h, w, list(Wt.blocks[start:]), True)
-            steps.append(Step("avgpool", "avgpool_posenc", lambda x=x: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat),
+            frs = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+            feat._td_rowstat = frs
+            steps.append(Step("avgpool", "avgpool_posenc", lambda x=x: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat,
+                                                                                       rowstat=frs),
                               (N * h * w + N) * C * _esz(dt)))
         sb = SgpBuilder(pool, steps, keep, set(), B, dt)
         cur = sb.pyramid(feat, T, pw.n_layers, Wt.sgp, Wt.mixer)
@@ -858,7 +876,7 @@ class ForwardEngine:
                           N * C * _esz(dt) + N * pw.n_out * 4, 2 * N * C * pw.n_out))
         return SimpleNamespace(steps=steps, pool_bytes=pool.total_bytes(), sgp_out=cur)
 
-    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None, stop_at=None, trunk_out=None):
+    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None, stop_at=None, trunk_out=None, feat_rs=None):
         pw, Wt = self.pw, self.pw.W
         T = pw.clip_len
         N = B * T
@@ -925,8 +943,12 @@ class ForwardEngine:
                                    h=h, w=w)
         C = pw.spec.feat_dim
         feat = pool.take((B, T, C), dt) if feat_out is None else feat_out
-        steps.append(Step("avgpool", "avgpool_posenc", lambda x=x, feat=feat: ops.avgpool_posenc(x, B, T, Wt.temp_enc, out=feat),
-                          (N * h * w + N) * C * es))
+        # LayerNorm statistics of the feature rows for the first SGP block's front kernel (the caller's slice of the shared
+        # buffer when the temporal stage runs once for all sub-batches)
+        frs = feat_rs if feat_rs is not None else torch.empty((N, 2), dtype=torch.float32, device=dev)
+        feat._td_rowstat = frs
+        steps.append(Step("avgpool", "avgpool_posenc", lambda x=x, feat=feat, frs=frs: ops.avgpool_posenc(
+            x, B, T, Wt.temp_enc, out=feat, rowstat=frs), (N * h * w + N) * C * es))
         keep["feat"] = feat
         if not x_kept:
             pool.give(x)
@@ -979,7 +1001,10 @@ class ForwardEngine:
                                         trunk_out=shared[i * Bs * T:(i + 1) * Bs * T]) for i in range(ns)]
                     tail = self._build_tail(B, feat, head_out, trunk_in=(shared, hh, ww), start=k)
                 else:
-                    subs = [self._build(Bs, H, W, bool(flip), set(), feat_out=feat[i * Bs:(i + 1) * Bs]) for i in range(ns)]
+                    frs = torch.empty((B * T, 2), dtype=torch.float32, device=self.device)
+                    feat._td_rowstat = frs
+                    subs = [self._build(Bs, H, W, bool(flip), set(), feat_out=feat[i * Bs:(i + 1) * Bs],
+                                        feat_rs=frs[i * Bs * T:(i + 1) * Bs * T]) for i in range(ns)]
                     tail = self._build_tail(B, feat, head_out)
             else:
                 subs = [self._build(Bs, H, W, bool(flip), set(), head_out=head_out[i * Bs * T:(i + 1) * Bs * T])

@@ -306,11 +306,12 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     return out
 
 
-def avgpool_posenc(x, B, T, temp_enc, out=None):
+def avgpool_posenc(x, B, T, temp_enc, out=None, rowstat=None):
+    """rowstat: optional fp32 (B*T, 2) output, LayerNorm mean / rstd over C of every feature row."""
     N, h, w, C = x.shape
     if out is None:
         out = torch.empty((B, T, C), dtype=x.dtype, device=x.device)
-    call("tdeed_avgpool_posenc_fwd", ptr(x), B, T, h * w, C, ptr(temp_enc), ptr(out), dtype_code(x.dtype),
+    call("tdeed_avgpool_posenc_fwd", ptr(x), B, T, h * w, C, ptr(temp_enc), ptr(out), ptr(rowstat), dtype_code(x.dtype),
          stream_ptr())
     return out
 
@@ -372,10 +373,12 @@ def sgp_mlp2_slices(C):
     return int(_lib.load().tdeed_sgp_mlp2_slices(C))
 
 
-def sgp_mlp2(y, gn_w, gn_b, W1p, b1p, W2p, b2, chsum, G=16, eps=1e-5, out=None, partial=None, rowstat=None, ln_eps=1e-5):
+def sgp_mlp2(y, gn_w, gn_b, W1p, b1p, W2p, b2, chsum, G=16, eps=1e-5, out=None, partial=None, rowstat=None, ln_eps=1e-5,
+             pooled=None, rowstat_pool=None):
     """out = y + fc2(GELU(fc1(GroupNorm(y)))) for C <= 384 (bf16), row tiles x 128-unit hidden slices + a row-wise fold
     that also leaves the LayerNorm statistics of the output rows in `rowstat` (fp32 (B*T, 2), optional).  W1p / b1p / W2p:
-    engine.pack_mlp2_frags; chsum: sgp_front's per-channel sums of y; partial: fp32 scratch (sgp_mlp2_slices(C), B*T, C)."""
+    engine.pack_mlp2_frags; chsum: sgp_front's per-channel sums of y; partial: fp32 scratch (sgp_mlp2_slices(C), B*T, C).
+    pooled (B, T_pool, C): also the AdaptiveMaxPool1d(T_pool) of the output (+ its LayerNorm statistics in rowstat_pool)."""
     _chk(y, "y", torch.bfloat16); _chk(W1p, "W1p", torch.bfloat16); _chk(W2p, "W2p", torch.bfloat16)
     B, T, C = y.shape
     if out is None:
@@ -383,7 +386,8 @@ def sgp_mlp2(y, gn_w, gn_b, W1p, b1p, W2p, b2, chsum, G=16, eps=1e-5, out=None, 
     if partial is None:
         partial = torch.empty((sgp_mlp2_slices(C), B * T, C), dtype=torch.float32, device=y.device)
     call("tdeed_sgp_mlp2_fwd", ptr(y), B * T, T, C, G, ptr(gn_w), ptr(gn_b), eps, ptr(W1p), ptr(b1p), ptr(W2p), ptr(b2),
-         ptr(out), ptr(partial), ptr(chsum), ptr(rowstat), ln_eps, stream_ptr())
+         ptr(out), ptr(partial), ptr(chsum), ptr(rowstat), ln_eps, 0 if pooled is None else pooled.shape[1], ptr(pooled),
+         ptr(rowstat_pool), stream_ptr())
     return out
 
 

@@ -12,6 +12,8 @@ from tdeed_amd import ops, _lib
 from tdeed_amd.engine import SgpBuilder, pack_sgp_block, pack_sgp_mixer, _Pool
 from helpers import module_state
 
+PROFILE = "--profile" in sys.argv      # only the default chain as a graph, replayed (for rocprofv3 --kernel-trace --stats)
+sys.argv = [a for a in sys.argv if a != "--profile"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 368
@@ -54,7 +56,7 @@ sd = module_state("pyramid", "_temp_fine", 5, C=C, ks=7, r=4, n=n)
 dt = torch.bfloat16
 x = torch.randn((B, T, C), device=DEV).to(dt)
 with torch.cuda.stream(torch.cuda.Stream()):
-    for fused, mlp2 in (("1", "1"), ("1", "0"), ("0", "0")):
+    for fused, mlp2 in ((("1", "1"),) if PROFILE else (("1", "1"), ("1", "0"), ("0", "0"))):
         os.environ["TDEED_SGP_FUSED"] = fused
         os.environ["TDEED_SGP_MLP2"] = mlp2
         sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, dt, DEV) for i in range(2 * n + 1)]
@@ -62,6 +64,8 @@ with torch.cuda.stream(torch.cuda.Stream()):
         steps, keep = [], {}
         sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, dt)
         sb.pyramid(x, T, n, sgp, mix)
-        print(f"fused={fused} mlp2={mlp2}: {len(steps)} steps, chain as one HIP graph {graph_time(steps):.1f} us")
+        print(f"fused={fused} mlp2={mlp2}: {len(steps)} steps, chain as one HIP graph {graph_time(steps, 200 if PROFILE else 50):.1f} us")
+        if PROFILE:
+            break
         for s in steps:
             print(f"   {s.name:40s} {s.kernel:14s} {timeit(s.fn):7.1f} us")
