@@ -42,7 +42,10 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {torch.bfloat16: 2500.0, torch.float32: 157.3}
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r03_train_hbm_traffic.json")
+# C-ABI entry -> kernel family of tools/summarize_pmc.py (what the counter passes are keyed by)
+TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
 
 
 def git_head():
@@ -147,9 +150,21 @@ def sgp_stage_time(plan, reps=30):
     return out
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(engs=None, dev=None):
-    """The oracle (our CPU port of the reference forward) timed on this host: BASELINE.json configs[0]
-    = FineDiving_small, 1 synthetic clip, fp32, all host cores.  Bounded: 1 warm-up + 3 timed clips.
+    """The oracle (our CPU port of the reference forward) timed on this host: BASELINE.json configs[0] = FineDiving_small,
+    1 synthetic clip, fp32: a thread sweep {1, 8, 32, all cores} -- the reported `value` is the BEST
+    of them (an oversubscribed all-core run was slower than 8 threads in round 2) -- with the CPU model string and the SGP
+    encoder-decoder alone.  Bounded: 1 pass at 1 thread, warm-up + 2 passes at the other counts (~40 s in all).
     Also the checker of this run's logits: the fp32 and bf16 engines run the same clip with the same weights."""
     from oracle import tdeed_oracle as O
     from tdeed_amd.regnet_spec import regnet_spec
@@ -159,16 +174,35 @@ def cpu_baseline(engs=None, dev=None):
     clip_np = synth.uint8_clip(1000, (1, 100, 3, 224, 224))
     clip = torch.from_numpy(clip_np)
     spec = regnet_spec(c["feature_arch"])
-    ts = []
+    ncpu = os.cpu_count() or 1
+    have = torch.get_num_threads()
+    sweep = {}
+    logits = displ = None
+    feat = torch.randn(1, 100, spec.feat_dim)
+    sgp_sweep = {}
     with torch.no_grad():
-        for i in range(4):
+        for nt in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
+            torch.set_num_threads(nt)
+            ts = []
+            for i in range(1 if nt == 1 else 3):
+                t0 = time.perf_counter()
+                logits, displ, _ = O.forward(clip, sd, c, spec)
+                ts.append(time.perf_counter() - t0)
+            sweep[nt] = min(ts[1:]) if len(ts) > 1 else ts[0]
+            O.ed_sgp_mixer(feat, sd, c["n_layers"], 100)
             t0 = time.perf_counter()
-            logits, displ, _ = O.forward(clip, sd, c, spec)
-            ts.append(time.perf_counter() - t0)
-    best = sorted(ts[1:])[len(ts[1:]) // 2]
-    res = dict(value=round(1.0 / best, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
-               sample="FineDiving_small forward, 1 synthetic clip (100x3x224x224), fp32, median of 3 after 1 warm-up",
-               sec_per_clip=round(best, 4))
+            for _ in range(3):
+                O.ed_sgp_mixer(feat, sd, c["n_layers"], 100)
+            sgp_sweep[nt] = (time.perf_counter() - t0) / 3
+    torch.set_num_threads(have)
+    best_nt = min(sweep, key=sweep.get)
+    best = sweep[best_nt]
+    res = dict(value=round(1.0 / best, 4), unit="clips/s", cores=best_nt, kind="port",
+               sample="FineDiving_small forward, 1 synthetic clip (100x3x224x224), fp32; best of a thread sweep (1 pass at 1 "
+                      "thread, best of 2 after a warm-up at the other counts)",
+               sec_per_clip=round(best, 4), host_cores=ncpu, cpu_model=_cpu_model(),
+               thread_sweep_sec_per_clip={str(k): round(v, 4) for k, v in sweep.items()},
+               sgp_only_ms_per_clip={str(k): round(v * 1e3, 2) for k, v in sgp_sweep.items()})
     errs = {}
     if dev is not None:
         st = torch.cuda.Stream()
@@ -208,7 +242,63 @@ def forward_layer_bytes(cfg, B, H, W, dt, dev):
     return b, f
 
 
-def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use_graph=True, want_cpu=False):
+def train_family_roofline(eng, workload, frames, lab, labD, masks, dt):
+    """Roofline of the dominant kernel family of the training step, measured live: one EAGER step with every C-ABI call
+    bracketed by HIP events on its launch stream (`_lib.profile`), device time summed per entry point.  For the 1x1-conv
+    contraction family (tdeed_gemm_fwd: forward + input-gradient GEMMs) the algorithmic bytes come from each call's own
+    (M, K, N, residual) arguments: (M K + N K + M N (1 + residual)) * element size.  `traffic` = HBM bytes per launch of the
+    same family from the committed counter passes (profiles/r03_train_hbm_traffic.json), null when that file is absent."""
+    from tdeed_amd import _lib
+    es = 2 if dt == torch.bfloat16 else 4
+    for _ in range(2):                                           # keep the device busy: event brackets then hold device time
+        eng.step(frames, lab, labD, drop_masks=masks)
+    with _lib.profile() as pr:
+        eng.step(frames, lab, labD, drop_masks=masks)
+    summ = pr.summary()
+    total = sum(d["ms"] for d in summ.values())
+    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    fam = {k: dict(ms=round(v["ms"], 3), calls=v["calls"], share=round(v["ms"] / total, 3))
+           for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    rec = dict(kernel=name, family=TRAIN_FAMILY.get(name), measured="one eager step, HIP events around every C-ABI call",
+               ms_per_step=round(d["ms"], 3), launches_per_step=d["calls"], share_of_step=round(d["ms"] / total, 3),
+               families_ms=fam, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, traffic_source=None)
+    g = summ.get("tdeed_gemm_fwd")
+    if g is not None:
+        # tdeed_gemm_fwd(A, lda, A0, lda0, k0, a_scale, a_scale_rows, M, K, N, W, ldw, scale, shift, residual, ...)
+        gb = sum((a[7] * a[8] + a[9] * a[8] + a[7] * a[9] * (2 if a[14] else 1)) * es for a in g["args"])
+        gf = sum(2.0 * a[7] * a[8] * a[9] for a in g["args"])
+        gsec = g["ms"] * 1e-3
+        ai = gf / max(gb, 1)
+        mfma_bound = ai > MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        gemm = dict(ms_per_step=round(g["ms"], 3), launches_per_step=g["calls"], algorithmic_bytes=int(gb), flops=int(gf),
+                    GBps=round(gb / gsec / 1e9, 1), TFLOPs=round(gf / gsec / 1e12, 1),
+                    frac_hbm=round(gb / gsec / 1e9 / HBM_PEAK_GBS, 4), frac_mfma=round(gf / gsec / 1e12 / MFMA_PEAK_TF[dt], 4),
+                    bound="mfma" if mfma_bound else "hbm")
+        rec["gemm_family"] = gemm
+        if name == "tdeed_gemm_fwd":
+            rec.update(bound=gemm["bound"], algorithmic_bytes_per_launch=int(gb / g["calls"]),
+                       avg_launch_us=round(g["ms"] / g["calls"] * 1e3, 2),
+                       achieved=gemm["TFLOPs"] if mfma_bound else gemm["GBps"],
+                       peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS, unit="TFLOP/s" if mfma_bound else "GB/s",
+                       frac=gemm["frac_mfma"] if mfma_bound else gemm["frac_hbm"])
+    try:
+        with open(os.path.join(ROOT, TRAIN_TRAFFIC_FILE)) as fh:
+            tj = json.load(fh)
+        if tj.get("workload") == workload:
+            tr = tj["kernels"].get(TRAIN_FAMILY.get(name, ""))
+            if tr is not None:
+                rec["traffic"] = int(tr["hbm_bytes_per_step"] / max(d["calls"], 1)) if "hbm_bytes_per_step" in tr \
+                    else tr["hbm_bytes_per_launch"]
+                rec["traffic_source"] = (f"{TRAIN_TRAFFIC_FILE}: separate rocprofv3 --pmc passes at git {tj.get('git_head')} "
+                                         f"({tj.get('fetch_pass', {}).get('mtime')}); not measured by this run")
+            rec["step_hbm_bytes_measured"] = tj.get("step_hbm_bytes")
+    except (OSError, KeyError, ValueError):
+        pass
+    return rec
+
+
+def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use_graph=True, want_cpu=False,
+                  family_roofline=True):
     """Optimisation steps of the training path on synthetic uint8 clips resident in HBM: train-mode forward + CE/MSE loss
     + full backward + (N > 1: gradient all-reduce over RCCL) + fused AdamW; dropout masks fixed."""
     from tdeed_amd.trainer import TrainEngine
@@ -256,8 +346,16 @@ def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use
                              unit="GB/s", frac=round(tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                              flops=int(3 * ff), tflops=round(3 * ff / (ms * 1e-3) / 1e12, 1)),
                cpu_baseline=None)
+    if rank == 0 and world == 1 and family_roofline:
+        try:
+            rec["roofline_family"] = train_family_roofline(eng, workload, frames, lab, labD, masks, dt)
+        except Exception as e:       # noqa: BLE001  (a side measurement must not take the line down)
+            rec["roofline_family"] = dict(error=f"{type(e).__name__}: {e}"[:300])
     if eng.reducer is not None:                                  # N > 1: which transport reduced the gradients, ranks RCCL saw
         rec["reducer"] = eng.reducer.describe()
+        rec["reducer"]["rccl_ranks_expected"] = world
+        if "rccl_ranks" in rec["reducer"] and rec["reducer"]["rccl_ranks"] != world:
+            raise RuntimeError(f"RCCL communicator has {rec['reducer']['rccl_ranks']} ranks, WORLD_SIZE is {world}")
         if use_graph:
             rec["reducer"]["collectives"] = ("inside the captured step" if eng.last_graph.mode == "one"
                                              else "launched between the two captured halves of the step")
@@ -268,11 +366,57 @@ def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use
     return rec
 
 
+def decode_rate(B, T, H, W, seconds=3.0):
+    """Row f4: JPEG decode throughput of the input pipeline on this host -- feeder.clip_batches with a DecodePool decoding
+    whole batches of B clips x T frames (synthetic H x W JPEGs written to a temporary directory, quality 90) straight into
+    pinned staging slots.  No GPU work; bounded to ~`seconds`."""
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from tdeed_amd import feeder
+    d = tempfile.mkdtemp(prefix="tdeed_frames_")
+    rs = np.random.RandomState(0)
+    base = rs.randint(0, 256, (H // 8, W // 8, 3), dtype=np.uint8)          # blocky content: a realistic ~10-20 KB per frame
+    for i in range(T):
+        img = np.kron(np.roll(base, i, axis=1), np.ones((8, 8, 1), dtype=np.uint8))
+        img = (img.astype(np.int16) + rs.randint(-12, 13, img.shape)).clip(0, 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(d, f"frame{i}.jpg"), quality=90)
+    kb = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / T / 1024
+    out = {}
+    ncpu = os.cpu_count() or 1
+    for thr in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
+        pool = feeder.DecodePool(thr)
+        clips = [dict(paths=[d, 0, 0, 0, -1, T], stride=1)] * (B * 64)
+        n, t0 = 0, time.perf_counter()
+        for batch in feeder.clip_batches(clips, B, (3, H, W), T, pool=pool, depth=2):
+            n += B
+            if time.perf_counter() - t0 > seconds / 3:
+                break
+        out[str(thr)] = round(n / (time.perf_counter() - t0), 1)
+        pool.close()
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    best = max(out, key=out.get)
+    return dict(decode_clips_per_s=out[best], threads=int(best), by_threads=out, jpeg_kb_per_frame=round(kb, 1),
+                note=f"Pillow (libjpeg) decode of {T} x {H}x{W} JPEG frames per clip by a thread pool into pinned staging "
+                     "slots (feeder.clip_batches); the reference decodes with torchvision.io.read_image in 4-8 DataLoader "
+                     "worker processes (train_tdeed.py:131-139)")
+
+
 def cpu_train_baseline():
     """The oracle's training step (train-mode forward + CE/MSE + autograd backward) on the host cores: FineDiving_small
     hyper-parameters, ONE synthetic clip of 100 frames at 224x224, fp32; bounded to one warm-up-free pass (~10-30 s)."""
     from oracle import tdeed_oracle as O
     from tdeed_amd.regnet_spec import regnet_spec
+    have = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))          # the forward sweep's best region (all cores oversubscribe)
+    try:
+        return _cpu_train_baseline(O, regnet_spec)
+    finally:
+        torch.set_num_threads(have)
+
+
+def _cpu_train_baseline(O, regnet_spec):
     c = CONFIGS["rny002_b8"]["cfg"]
     sd0 = O.as_torch_state(synth.make_state(state_layout.model_state_shapes(c), 0))
     par = [k for k in sd0 if state_layout.is_parameter(k)]
@@ -289,6 +433,7 @@ def cpu_train_baseline():
     loss.backward()
     el = time.perf_counter() - t0
     return dict(value=round(1.0 / el, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                host_cores=os.cpu_count(), cpu_model=_cpu_model(),
                 sample="FineDiving_small training step (train-mode forward + loss + autograd backward, no optimizer), "
                        "1 synthetic clip (100x3x224x224), fp32, one pass", sec_per_clip=round(el, 3))
 
@@ -442,7 +587,12 @@ def main():
                     h2d_GBps=round(B * T * 3 * H * W / (el_f / a.steps) / 1e9, 2),
                     note="uint8 clips in pinned host memory -> async H2D on two copy streams into a ring of 3 device staging "
                          "buffers, two batches ahead of the forward that consumes them (its first act: a device-to-device copy "
-                         "into the plan's input buffers); 15 MB per clip over PCIe")
+                         "into the plan's input buffers); 15 MB per clip over PCIe",
+                    frac_of_resident=round((B * a.steps / el_f) / (world * B * a.steps / el), 3))
+        try:
+            feed.update(decode_rate(B, T, H, W))
+        except Exception as e:       # noqa: BLE001
+            feed["decode_error"] = f"{type(e).__name__}: {e}"[:200]
     with torch.cuda.stream(stream):
         prof, sgp_stage_ms = kernel_profile(eng, plan) if rank == 0 else (None, None)
         sgp_direct = sgp_stage_time(plan) if rank == 0 else None
@@ -544,7 +694,10 @@ def main():
         tr = {}
         for wk, st_ in (("rny008_b16", 6), ("rny002_b8", 10)):
             try:
-                tr[wk] = train_measure(wk, "bf16", st_, 2, 3, rank, world, dev, use_graph=True)
+                # the cfg3 record (BASELINE configs[2]) is a full (d) line: cpu_baseline + the dominant family's roofline
+                tr[wk] = train_measure(wk, "bf16", st_, 2, 3, rank, world, dev, use_graph=True,
+                                       want_cpu=(wk == "rny008_b16" and not a.no_cpu_baseline),
+                                       family_roofline=(wk == "rny008_b16"))
             except Exception as e:       # noqa: BLE001  (the headline line must still be printed)
                 tr[wk] = dict(error=f"{type(e).__name__}: {e}"[:300])
         out["train"] = tr

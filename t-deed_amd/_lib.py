@@ -159,9 +159,46 @@ def load():
     return lib
 
 
+_PROFILE = None      # list of (entry name, start event, end event, args) while a `profile()` block is open
+
+
+class profile:
+    """Device time per C-ABI entry point: inside the block every `call()` is bracketed by two HIP events on the current
+    stream; `.summary()` (after the block) synchronises and returns {name: dict(ms, calls, args=[...])}.  Measurement
+    plumbing for bench.py's per-family roofline of the training step (the product path never opens one)."""
+
+    def __enter__(self):
+        global _PROFILE
+        self.rec = _PROFILE = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, args in self.rec:
+            d = out.setdefault(name, dict(ms=0.0, calls=0, args=[]))
+            d["ms"] += a.elapsed_time(b)
+            d["calls"] += 1
+            d["args"].append(args)
+        return out
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _PROFILE is not None and name not in ("tdeed_graph_begin", "tdeed_graph_end", "tdeed_graph_launch"):
+        st = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        rc = getattr(lib, name)(*args)
+        b.record(st)
+        _PROFILE.append((name, a, b, args))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise HipCallError(f"{name} -> {rc}: {lib.tdeed_last_error().decode(errors='replace')}")
 

@@ -1,5 +1,6 @@
 # round-2 profiling passes on the GPU box (outputs under gpurun_out/r02; summaries are made from them afterwards)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -eu
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/r02; rm -rf $O; mkdir -p $O
 INF="bench.py --no-graph --inflight 1 --steps 4 --warmup 2 --repeats 1 --pmc-pass"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_infer -o b -- python3 bench.py --no-train --no-feed --no-cpu-baseline --repeats 3 > $O/kt_infer.json 2> $O/kt_infer.err

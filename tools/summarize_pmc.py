@@ -17,6 +17,12 @@ import sys
 import time
 from collections import defaultdict
 
+# training-step kernels (trunk_bwd.hip, sgp_bwd.hip, gsf_bwd.hip, train.hip) first: their names contain inference names
+TRAIN_FAMILY = [("bn_bwd_apply", "bn_bwd"), ("colstats", "bn_bwd"), ("wgrad", "wgrad"), ("gconv_dgrad", "gconv_bwd"),
+                ("gconv_wgrad", "gconv_bwd"), ("gsf_bwd", "gate_shift_bwd"), ("affine_kernel", "bn_apply"),
+                ("bn_apply", "bn_apply"), ("pool_mean", "se_train"), ("scale_rows", "se_train"), ("se_train", "se_train"),
+                ("adamw", "adamw"), ("multi_fold", "grad_writeout"), ("gather_cast", "repack"), ("stem_mfma", "stem"),
+                ("stem_wgrad", "stem")]
 FAMILY = [("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_big", "gemm_big"), ("gemm_kernel", "gemm"),
           ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"), ("gsf_", "gate_shift"), ("se_gate", "se_gate"),
           ("stem_kernel", "stem"), ("sgp_mlp", "sgp_mlp"), ("sgp_front", "sgp_front"), ("mixer_front", "mixer_front"), ("mixer_branch", "mixer_branch"),
@@ -44,11 +50,11 @@ def load(path, counter):
     return acc
 
 
-def family(n):
-    for k, v in FAMILY:
+def family(n, train=False):
+    for k, v in (TRAIN_FAMILY + FAMILY) if train else FAMILY:
         if k in n:
             return v
-    return None
+    return "other" if train else None
 
 
 def stamp(path):
@@ -67,17 +73,23 @@ def main():
         i = args.index("--steps")
         steps = int(args[i + 1])
         del args[i:i + 2]
+    workload = None
+    if "--train-workload" in args:               # the passes profiled training steps of this bench workload
+        i = args.index("--train-workload")
+        workload = args[i + 1]
+        del args[i:i + 2]
+    train = workload is not None
     fd, wd, out = args[:3]
     ff, wf = one_csv(fd), one_csv(wd)
     fe, wr = load(ff, "FETCH_SIZE"), load(wf, "WRITE_SIZE")
     fam = defaultdict(lambda: dict(launches=0, fetch_bytes=0.0, write_bytes=0.0))
     for n, (v, c) in fe.items():
-        k = family(n)
+        k = family(n, train)
         if k:
             fam[k]["launches"] += c
             fam[k]["fetch_bytes"] += v * 1024 * 2          # gfx950: FETCH_SIZE = 1/2 of wide streaming reads
     for n, (v, c) in wr.items():
-        k = family(n)
+        k = family(n, train)
         if k:
             fam[k]["write_bytes"] += v * 1024
     res = {}
@@ -90,6 +102,9 @@ def main():
             # line divide by ITS launch count
             res[k]["kernel_launches_per_forward"] = round(d["launches"] / steps, 2)
             res[k]["hbm_bytes_per_forward"] = round((d["fetch_bytes"] + d["write_bytes"]) / steps)
+            if train:
+                res[k]["hbm_bytes_per_step"] = res[k].pop("hbm_bytes_per_forward")
+                res[k]["kernel_launches_per_step"] = res[k].pop("kernel_launches_per_forward")
     try:
         head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
                               cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
@@ -97,7 +112,9 @@ def main():
         head = None
     json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950); "
                         "averages over every launch of the kernel family",
-                   command=cmd, forwards_profiled=steps, git_head=head, fetch_pass=stamp(ff), write_pass=stamp(wf), kernels=res),
+                   command=cmd, forwards_profiled=steps, git_head=head, fetch_pass=stamp(ff), write_pass=stamp(wf), kernels=res,
+                   **(dict(workload=workload, step_hbm_bytes=round(sum((d["fetch_bytes"] + d["write_bytes"]) for d in fam.values())
+                                                                  / max(steps or 1, 1))) if train else {})),
               open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"]):
         print(f"{k:16s} launches {v['launches_profiled']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB "
