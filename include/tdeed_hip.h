@@ -189,16 +189,6 @@ int tdeed_gsf_apply_fwd(const void* x, const float* gate, const float* fw /*NULL
 int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
                               const float* cw1, const float* cb1, const float* cw2, const float* cb2, int B,
                               int T, int h, int w, int C, int F, int Fp, void* out, int dtype, void* stream);
-/* The whole gate-shift(-fuse) module of a site in ONE launch (bf16, small maps: gsf.py:38-93 / gsm.py:89-116 +
- * shift.py:89-93): a workgroup owns a chunk of consecutive frames of a clip, passes the frames t0-3 .. t0+TC+2 through an LDS
- * ring (BN + ReLU, conv3d taps on the MFMA pipe, gates, spatial sums) and writes the blended / shifted / interleaved first Fp
- * columns of conv1's A operand.  No Q / gate / ysum / xsum tensors cross a launch boundary.  x: rows [B*T*h*w][ldx]
- * (the channels-last map with ldx = C, or the compact slice with ldx = Fp); cw1 == NULL: plain gate-shift (_GSM).
- * tdeed_gsf_fused_chunk: frames per workgroup, 0 when the site is not served (callers then use the three launches). */
-int tdeed_gsf_fused_chunk(int B, int T, int h, int w, int F, int Fp);
-int tdeed_gsf_fused_fwd(const void* x, long ldx, int B, int T, int h, int w, int F, int Fp, const float* bn_scale,
-                        const float* bn_shift, const void* wqf, const float* b3d, const float* cw1, const float* cb1,
-                        const float* cw2, const float* cb2, void* out, void* stream);
 
 /* ---- global average pool + positional encoding (model.py:133-137) --------------------------
  * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]).  rowstat (optional, fp32

@@ -76,9 +76,6 @@ def _dwpack(sd, pre, names, C, device):
 
 
 # narrow-C form of the fused GroupNorm + MLP launch (sgp_mlp2.hip): row tiles x 128-unit hidden slices
-GSF_FUSED = os.environ.get("TDEED_GSF_FUSED", "1") == "1"     # one-launch gate-shift for the small maps
-
-
 def _sgp_mlp2_on():
     return os.environ.get("TDEED_SGP_MLP2", "1") == "1"
 
@@ -799,23 +796,14 @@ class ForwardEngine:
                 # the gate-shift launches read only channels [0, Fp): from the compact slice the previous block's conv3 wrote
                 # beside its output when there is one (a slice of the channels-last map drags whole cache lines)
                 xg = xs if (xs is not None and xs.shape[-1] == Fp) else x
-                one_launch = (GSF_FUSED and dt == torch.bfloat16 and bw.gs_wqf is not None and str(x.device) != "cpu"
-                              and ops.gate_shift_fused_chunk(B, T, h, w, F, Fp) > 0)
-                if one_launch:
-                    # small maps: the whole module in one launch (a workgroup owns a chunk of frames; gsf.hip gsf_fused_kernel)
-                    gb = dict(out=pool.take((M, Fp), dt))
-                    steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp, h=h, w=w: ops.gate_shift_fused(
-                        x, B, T, h, w, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wqf, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1, bw.gs_cw2,
-                        bw.gs_cb2, out=gb["out"]), M * (F + Fp) * es, 2 * M * F * 27))
-                else:
-                    gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
-                              ysum=pool.take((N, F), torch.float32),
-                              xsum=pool.take((N, F), torch.float32), out=pool.take((M, Fp), dt))
-                    if bw.gs_cw1 is not None:
-                        gb["fw"] = pool.take((B, F, T), torch.float32)
-                    steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
-                        x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                        bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
+                          ysum=pool.take((N, F), torch.float32),
+                          xsum=pool.take((N, F), torch.float32), out=pool.take((M, Fp), dt))
+                if bw.gs_cw1 is not None:
+                    gb["fw"] = pool.take((B, F, T), torch.float32)
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
+                    x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                 steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                     x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
                     *gemm_cost(M, blk.cin, blk.cout, es)))

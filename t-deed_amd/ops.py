@@ -306,23 +306,6 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     return out
 
 
-def gate_shift_fused_chunk(B, T, h, w, F, Fp):
-    """Frames per workgroup of the one-launch gate-shift form for this site, 0 when it is not served."""
-    return int(_lib.load().tdeed_gsf_fused_chunk(B, T, h, w, F, Fp))
-
-
-def gate_shift_fused(x, B, T, h, w, F, Fp, bn_scale, bn_shift, wqf, b3d, cw1=None, cb1=None, cw2=None, cb2=None, out=None):
-    """The gate-shift(-fuse) module of a site in one launch (bf16, small maps).  x: (B*T, h, w, C) channels-last map or
-    the compact (B*T*h*w, Fp) slice; -> (B*T*h*w, Fp)."""
-    _chk(x, "x", torch.bfloat16)
-    ldx = x.shape[-1]
-    if out is None:
-        out = torch.empty((B * T * h * w, Fp), dtype=x.dtype, device=x.device)
-    call("tdeed_gsf_fused_fwd", ptr(x), ldx, B, T, h, w, F, Fp, ptr(bn_scale), ptr(bn_shift), ptr(wqf), ptr(b3d), ptr(cw1),
-         ptr(cb1), ptr(cw2), ptr(cb2), ptr(out), stream_ptr())
-    return out
-
-
 def avgpool_posenc(x, B, T, temp_enc, out=None, rowstat=None):
     """rowstat: optional fp32 (B*T, 2) output, LayerNorm mean / rstd over C of every feature row."""
     N, h, w, C = x.shape

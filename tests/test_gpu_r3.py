@@ -201,51 +201,3 @@ def test_apply_reduces_gradients_that_were_accumulated_without_reduce():
         b.apply()
         st.synchronize()
         assert b.reducer.calls == [0, 1, "join"]                    # reduced inside the backward, not a second time
-
-
-@pytest.mark.parametrize("name", ["gsf_f16", "gsf_f40", "gsf_f92", "gsm_f16"])
-@pytest.mark.parametrize("chunk", [0, 1, 3])
-def test_one_launch_gate_shift_matches_the_reference_and_the_three_launch_form(name, chunk, monkeypatch):
-    """gsf_fused_kernel (a workgroup owns a chunk of frames: ring of raw slices, tap products on MFMA, gates, spatial sums,
-    fusion conv and blend in one launch) against the reference's own _GSF / _GSM outputs (tests/golden/gs*.npz, generated
-    from model/impl/gsf.py:38-93 and gsm.py:89-116) and against the three-launch form on the same bf16 inputs, for the
-    automatic chunk length and for forced chunks of 1 and 3 frames (clip ends inside a chunk, T not a multiple of it), read
-    from a full channels-last map and from the compact slice."""
-    from helpers import load_golden, module_state, act, max_abs
-    from tdeed_amd import ops
-    from tdeed_amd.engine import pack_gsf_q_frags
-    if chunk:
-        monkeypatch.setenv("TDEED_GSF_FUSED_TC", str(chunk))
-    meta, g = load_golden(name)
-    Fd, T, B, h, w, mode = meta["F"], meta["T"], meta["B"], meta["h"], meta["w"], meta["mode"]
-    sd = module_state("gate_shift", "gs", meta["seed"], F=Fd, mode=mode)
-    x = act(meta["seed"], name + ":x", (B * T, Fd, h, w))
-    Fp = (Fd + 7) // 8 * 8
-    C = Fp + 8
-    xin = np.zeros((B * T, h, w, C), np.float32)
-    xin[..., :Fd] = x.transpose(0, 2, 3, 1)
-    xin[..., Fd:] = act(99, "pad", (B * T, h, w, C - Fd))
-    s_ = sd["gs.bn.weight"].astype(np.float64) / np.sqrt(sd["gs.bn.running_var"].astype(np.float64) + 1e-5)
-    sh = sd["gs.bn.bias"].astype(np.float64) - sd["gs.bn.running_mean"].astype(np.float64) * s_
-    dev = lambda a: t(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
-    kw = {}
-    if mode == "gsf":
-        kw = dict(cw1=dev(sd["gs.channel_conv1.weight"].reshape(18)), cb1=dev(sd["gs.channel_conv1.bias"]),
-                  cw2=dev(sd["gs.channel_conv2.weight"].reshape(18)), cb2=dev(sd["gs.channel_conv2.bias"]))
-    wqf = pack_gsf_q_frags(sd["gs.conv3D.weight"], DEV)
-    xb = t(xin).to(torch.bfloat16).to(DEV)
-    assert ops.gate_shift_fused_chunk(B, T, h, w, Fd, Fp) > 0
-    got = ops.gate_shift_fused(xb, B, T, h, w, Fd, Fp, dev(s_), dev(sh), wqf, dev(sd["gs.conv3D.bias"]), **kw)
-    xs = xb.view(-1, C)[:, :Fp].contiguous()                       # the compact slice a producer writes
-    got2 = ops.gate_shift_fused(xs, B, T, h, w, Fd, Fp, dev(s_), dev(sh), wqf, dev(sd["gs.conv3D.bias"]), **kw)
-    old = ops.gate_shift(xb, B, T, Fd, Fp, dev(s_), dev(sh), dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T),
-                         dev(sd["gs.conv3D.bias"]), wqf=wqf, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal(got, got2)
-    ref = t(g["y"]).permute(0, 2, 3, 1)
-    scale = max(1.0, float(ref.abs().max()))
-    assert max_abs(got.float().cpu().view(B * T, h, w, Fp)[..., :Fd], ref) < 3e-2 * scale
-    # same bf16 inputs, same products; only the order of the three temporal taps' fp32 sums differs from the Q-map form
-    assert max_abs(got.float().cpu(), old.float().cpu()) <= 2e-2 * scale
-    assert float((got.float() - old.float()).abs().mean()) < 1e-3 * scale
-    assert torch.equal(got.view(B * T, h, w, Fp)[..., Fd:], xb[..., Fd:Fp])          # pass-through pad columns
