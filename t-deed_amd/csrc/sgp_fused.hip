@@ -111,10 +111,17 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
   __syncthreads();
   tile_mean(tile, T_len, halo, red);
   const float mean_c = red[16 * SGP_CH + c];
-  for (int t = tl; t < T_len; t += 16) {
-    BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);
-    res[t * SGP_CH + c] = r.inst + r.conv_gate + tile[(halo + t) * SGP_CH + c];
+#define FRONT_FAST(KS_, UP_)                                                                                   \
+  branch_runs<KS_, UP_>(tile, wl, bb, cok, c, tl, T_len, halo, mean_c,                                         \
+                        [&](int t, const BranchOut& r, float o) { res[t * SGP_CH + c] = r.inst + r.conv_gate + o; });
+#define FRONT_GENERIC                                                                                          \
+  for (int t = tl; t < T_len; t += 16) {                                                                       \
+    BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);                                  \
+    res[t * SGP_CH + c] = r.inst + r.conv_gate + tile[(halo + t) * SGP_CH + c];                                \
   }
+  SGP_BRANCH_DISPATCH(ks, up, FRONT_FAST, FRONT_GENERIC)
+#undef FRONT_FAST
+#undef FRONT_GENERIC
   __syncthreads();
   store_tile<T>(res, y + base, C, 0, T_len, c0, C, x + base, C);
   if (chsum) {
@@ -260,11 +267,20 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
   store_tile<T>(tile + halo * SGP_CH, crow + (long)(4 + src) * C, ldc, 0, T_hi, c0, C, (const T*)nullptr, 0);
   tile_mean(tile, T_hi, halo, red);
   const float mean_c = red[16 * SGP_CH + c];
-  for (int t = tl; t < T_hi; t += 16) {
-    BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);
-    res[t * SGP_CH + c] = r.conv_gate;
-    res2[t * SGP_CH + c] = r.inst;
+#define MIX_FAST(KS_, UP_)                                                                                     \
+  branch_runs<KS_, UP_>(tile, wl, bb, cok, c, tl, T_hi, halo, mean_c, [&](int t, const BranchOut& r, float) {  \
+    res[t * SGP_CH + c] = r.conv_gate;                                                                         \
+    res2[t * SGP_CH + c] = r.inst;                                                                             \
+  });
+#define MIX_GENERIC                                                                                            \
+  for (int t = tl; t < T_hi; t += 16) {                                                                        \
+    BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);                                  \
+    res[t * SGP_CH + c] = r.conv_gate;                                                                         \
+    res2[t * SGP_CH + c] = r.inst;                                                                             \
   }
+  SGP_BRANCH_DISPATCH(ks, up, MIX_FAST, MIX_GENERIC)
+#undef MIX_FAST
+#undef MIX_GENERIC
   __syncthreads();
   store_tile<T>(res, crow + (long)src * C, ldc, 0, T_hi, c0, C, (const T*)nullptr, 0);
   store_tile<T>(res2, crow + (long)(2 + src) * C, ldc, 0, T_hi, c0, C, (const T*)nullptr, 0);

@@ -68,14 +68,14 @@ __global__ __launch_bounds__(M2_NW * 64, 2) void sgp_mlp2_kernel(
   bf16_t* Ht = At + ROWS * M2_LD;                                   // [ROWS][M2_LDH] GELU(fc1) of this slice
   float* gstat = reinterpret_cast<float*>(Ht + ROWS * M2_LDH);      // [M2_MAXCL][32][2] (mean, rstd)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  // workgroup -> (row tile, slice): every row tile of one slice runs on ONE XCD (ids equal mod 8 share an XCD's L2 under
-  // round-robin placement -- speed only), so a slice's 192 KB of weights leave the memory side once per launch instead of
-  // once per XCD that happens to host one of its row tiles
+  // workgroup -> (slice, row tile), row tiles fastest: consecutive ids (dealt round-robin over the 8 XCDs) give every XCD
+  // the same number of workgroups.  (Pinning each slice's row tiles to one XCD -- its 192 KB of weights then leave the
+  // memory side once -- was measured: -3 % cycles per workgroup at 64-row tiles, but 12 slices over 8 XCDs put 34 workgroups
+  // on four XCDs of 32 CUs at 48-row tiles and the launch took 20 % longer.)
   const int nrt = (R + ROWS - 1) / ROWS;
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int s = xcd + 8 * (jx / nrt);
+  const int s = blockIdx.x / nrt;
   if (s >= nslice) return;
-  const int r0 = (jx % nrt) * ROWS;
+  const int r0 = (blockIdx.x - s * nrt) * ROWS;
   const int c_lo = r0 / T_len, c_hi = min(R - 1, r0 + ROWS - 1) / T_len;
   const int cg = C / G;
   const int nck = C / 8;
@@ -482,21 +482,24 @@ __global__ __launch_bounds__(256) void sgp_fold_cols_kernel(const float* __restr
   }
 }
 
-// 1-D grid: 8 x ceil(S / 8) x row tiles ids; id -> XCD id % 8, slices {x, x + 8, ...} live on XCD x (ids whose slice falls
-// past S exit at once)
-int mlp2_grid(int R, int rows, int S) { return 8 * ((S + 7) / 8) * ((R + rows - 1) / rows); }
+// 1-D grid: slices x row tiles
+int mlp2_grid(int R, int rows, int S) { return S * ((R + rows - 1) / rows); }
 
 size_t mlp2_smem(int rows, int C) {
   (void)C;
   return (size_t)rows * (M2_LD + M2_LDH) * 2 + (size_t)M2_MAXCL * 32 * 2 * sizeof(float);
 }
 
-// rows per workgroup: 64 while a tile then touches at most M2_MAXCL clips and the grid stays wide, else 32
+// rows per workgroup: the smallest of 32 / 48 / 64 whose grid (row tiles x slices) still fits the chip's 256 CUs at one
+// workgroup each (per-workgroup time grows with the rows: GroupNorm + GELU are vector-ALU work, the A tile LDS traffic),
+// as long as a tile then touches at most M2_MAXCL clips
 int mlp2_rows(int R, int T, int S) {
   static const int force_rows = getenv("TDEED_SGP_MLP2_ROWS") ? atoi(getenv("TDEED_SGP_MLP2_ROWS")) : 0;
-  const bool ok64 = (64 - 1) / T + 2 <= M2_MAXCL;
-  if (force_rows == 32 || (force_rows == 64 && ok64)) return force_rows;
-  return (ok64 && cdiv(R, 64) * S >= 128) ? 64 : 32;
+  auto ok = [&](int rows) { return (rows - 1) / T + 2 <= M2_MAXCL; };
+  if ((force_rows == 32 || force_rows == 48 || force_rows == 64) && ok(force_rows)) return force_rows;
+  for (int rows = 32; rows <= 64; rows += 16)
+    if (ok(rows) && cdiv(R, rows) * S <= 256) return rows;
+  return ok(64) ? 64 : (ok(48) ? 48 : 32);
 }
 
 }  // namespace
@@ -560,6 +563,7 @@ extern "C" int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, con
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { tdeed_set_error("sgp_mlp2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
     attr_set = true;
@@ -568,6 +572,9 @@ extern "C" int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, con
   const int rows = mlp2_rows(R, T, S);
   if (rows == 64)
     hipLaunchKernelGGL((sgp_mlp2_kernel<4>), dim3(mlp2_grid(R, 64, S)), dim3(M2_NW * 64), mlp2_smem(64, C), st, (const bf16_t*)y, R,
+                       T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum, S);
+  else if (rows == 48)
+    hipLaunchKernelGGL((sgp_mlp2_kernel<3>), dim3(mlp2_grid(R, 48, S)), dim3(M2_NW * 64), mlp2_smem(48, C), st, (const bf16_t*)y, R,
                        T, C, G, gn_w, gn_b, eps, (const bf16_t*)W1p, b1p, (const bf16_t*)W2p, partial, chsum, S);
   else
     hipLaunchKernelGGL((sgp_mlp2_kernel<2>), dim3(mlp2_grid(R, 32, S)), dim3(M2_NW * 64), mlp2_smem(32, C), st, (const bf16_t*)y, R,

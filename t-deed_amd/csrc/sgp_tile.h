@@ -177,3 +177,60 @@ __device__ __forceinline__ BranchOut branch_eval(const float* tile, const float*
   return r;
 }
 
+
+
+// The same branches for a RUN of consecutive rows per thread, fully unrolled for a compile-time (KS, UP): thread (c, g)
+// takes rows [r*RUN, r*RUN + RUN) for r = g, g + 16, ...; its channel's taps live in registers and the UP + RUN - 1 window
+// values of a run are read from the tile ONCE (branch_eval re-reads 2 x (2 KS + UP) LDS words per output: the front
+// kernels were bound by those reads).  Same arithmetic order per output as branch_eval: bit-identical results.
+template <int KS, int UP, typename F>
+__device__ __forceinline__ void branch_runs(const float* tile, const float* wl, const Bias5& bb, bool cok, int c, int g,
+                                            int T_len, int halo, float mean_c, F&& emit) {
+  constexpr int RUN = 7, HK = KS >> 1, HU = UP >> 1, WN = UP + RUN - 1;
+  float wpsi[KS], wcw[KS], wckw[UP];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    wpsi[k] = wl[k * SGP_CH + c];
+    wcw[k] = wl[(KS + k) * SGP_CH + c];
+  }
+#pragma unroll
+  for (int k = 0; k < UP; ++k) wckw[k] = wl[(2 * KS + k) * SGP_CH + c];
+  const float wfc = wl[(2 * KS + UP) * SGP_CH + c], wg = wl[(2 * KS + UP + 1) * SGP_CH + c];
+  const float b_psi = cok ? bb.psi : 0.f, b_cw = cok ? bb.cw : 0.f, b_ckw = cok ? bb.ckw : 0.f,
+              b_fc = cok ? bb.fc : 0.f, b_g = cok ? bb.g : 0.f;
+  const float phi = fmaxf(fmaf(wg, mean_c, b_g), 0.f);
+  const int last = T_len + 2 * halo - 1;                           // last row of the tile (halo rows are zero)
+  for (int t0 = g * RUN; t0 < T_len; t0 += 16 * RUN) {
+    float v[WN];
+    // window rows t0 - HU .. t0 + RUN - 1 + HU of the sequence = tile rows halo - HU + t0 + j (halo >= HU)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) v[j] = tile[min(halo - HU + t0 + j, last) * SGP_CH + c];
+#pragma unroll
+    for (int i = 0; i < RUN; ++i) {
+      if (t0 + i < T_len) {
+        float psi = b_psi, cw = b_cw, ckw = b_ckw;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const float x = v[i + HU - HK + k];
+          psi = fmaf(wpsi[k], x, psi);
+          cw = fmaf(wcw[k], x, cw);
+        }
+#pragma unroll
+        for (int k = 0; k < UP; ++k) ckw = fmaf(wckw[k], v[i + k], ckw);
+        BranchOut r;
+        r.conv_gate = (cw + ckw) * psi;
+        r.inst = fmaf(wfc, v[i + HU], b_fc) * phi;
+        emit(t0 + i, r, v[i + HU]);
+      }
+    }
+  }
+}
+
+// dispatch over the (kernel size, long-kernel size) pairs of the shipped configs (sgp_ks 5/7/9/11 x sgp_r 4; modules.py
+// 119-126: up = round((ks + 1) r) made odd); other pairs take the generic loop
+#define SGP_BRANCH_DISPATCH(ks, up, CALL_FAST, CALL_GENERIC)            \
+  if ((ks) == 7 && (up) == 33) { CALL_FAST(7, 33) }                      \
+  else if ((ks) == 9 && (up) == 41) { CALL_FAST(9, 41) }                 \
+  else if ((ks) == 11 && (up) == 49) { CALL_FAST(11, 49) }               \
+  else if ((ks) == 5 && (up) == 25) { CALL_FAST(5, 25) }                 \
+  else { CALL_GENERIC }

@@ -24,7 +24,7 @@ y = torch.randn((B, T, C), device=DEV).to(torch.bfloat16)
 chs = torch.stack([y.float().sum(1), (y.float() ** 2).sum(1)], -1).contiguous()
 S = ops.sgp_mlp2_slices(C)
 part = torch.empty((S, R, C), dtype=torch.float32, device=DEV)
-nwg = 8 * ((S + 7) // 8) * ((R + rows - 1) // rows)
+nwg = S * ((R + rows - 1) // rows)
 st = torch.zeros((nwg, 8), dtype=torch.int64, device=DEV)
 # some cache-cold traffic in front, like the stage sees it
 junk = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
