@@ -215,6 +215,7 @@ def cpu_baseline(engs=None, dev=None):
                 st.synchronize()
                 h = head.float().cpu().view(1, 100, -1)
                 errs[name] = max(float((h[..., :5] - logits).abs().max()), float((h[..., 5] - displ).abs().max()))
+                errs[name + "_rms"] = float((h[..., :5] - logits).pow(2).mean().sqrt())
                 del eng
         errs["logit_abs_max"] = float(logits.abs().max())
     return res, errs
@@ -283,6 +284,20 @@ def train_family_roofline(eng, workload, frames, lab, labD, masks, dt):
                        achieved=gemm["TFLOPs"] if mfma_bound else gemm["GBps"],
                        peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS, unit="TFLOP/s" if mfma_bound else "GB/s",
                        frac=gemm["frac_mfma"] if mfma_bound else gemm["frac_hbm"])
+    bn = summ.get("tdeed_bn_train_bwd")
+    if bn is not None:
+        # tdeed_bn_train_bwd(z, dy, y, relu, M, C, ..., dz [13], d_res [14], ...): BatchNorm (batch statistics) backward.
+        # Algorithmic bytes = every input map read once (z, dy, and y where the ReLU mask comes from the block output), every
+        # output map written once (dz, and d_res where the residual branch takes the masked gradient); the kernel pair reads
+        # its inputs twice (statistics pass, then apply pass): that shows in `traffic`, not here.
+        bb = sum((2 + (1 if a[2] else 0) + 1 + (1 if a[14] else 0)) * a[4] * a[5] * es for a in bn["args"])
+        bsec = bn["ms"] * 1e-3
+        rec["bn_bwd_family"] = dict(ms_per_step=round(bn["ms"], 3), launches_per_step=bn["calls"], algorithmic_bytes=int(bb),
+                                    GBps=round(bb / bsec / 1e9, 1), frac_hbm=round(bb / bsec / 1e9 / HBM_PEAK_GBS, 4))
+        if name == "tdeed_bn_train_bwd":
+            rec.update(bound="hbm", algorithmic_bytes_per_launch=int(bb / bn["calls"]),
+                       avg_launch_us=round(bn["ms"] / bn["calls"] * 1e3, 2), achieved=round(bb / bsec / 1e9, 1),
+                       peak=HBM_PEAK_GBS, unit="GB/s", frac=round(bb / bsec / 1e9 / HBM_PEAK_GBS, 4))
     try:
         with open(os.path.join(ROOT, TRAIN_TRAFFIC_FILE)) as fh:
             tj = json.load(fh)
@@ -691,6 +706,8 @@ def main():
             out["logit_max_abs_err_fp32"] = round(errs["fp32"], 7)
             out["logit_max_abs_err_bf16"] = round(errs["bf16"], 5)
             out["logit_abs_max"] = round(errs["logit_abs_max"], 4)
+            out["logit_rms_err_fp32"] = round(errs["fp32_rms"], 8)
+            out["logit_rms_err_bf16"] = round(errs["bf16_rms"], 5)
     if world == 1 and not a.no_train and a.workload == "rny002_b8" and a.dtype == "bf16":
         # driver-visible training-step records: BASELINE configs[2] (800MF, B=16) and the 200MF geometry of the headline
         tr = {}

@@ -876,7 +876,9 @@ class ForwardEngine:
                           N * C * _esz(dt) + N * pw.n_out * 4, 2 * N * C * pw.n_out))
         return SimpleNamespace(steps=steps, pool_bytes=pool.total_bytes(), sgp_out=cur)
 
-    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None, stop_at=None, trunk_out=None, feat_rs=None):
+    def _build(self, B, H, W, flip, taps, head_out=None, feat_out=None, stop_at=None, trunk_out=None, feat_rs=None,
+               frames_dtype=torch.uint8):
+        """flip: bool (all frames) or a uint8 device tensor (B*T,) of per-frame flags (the augmented eval path)."""
         pw, Wt = self.pw, self.pw.W
         T = pw.clip_len
         N = B * T
@@ -890,11 +892,12 @@ class ForwardEngine:
         if self.crop_dim is not None and self.crop_dim > 0 and (self.crop_dim != H or self.crop_dim != W):
             ch = cw = self.crop_dim
             crop = (int(round((H - ch) / 2.0)), int(round((W - cw) / 2.0)), ch, cw)
-        frames = torch.empty((N, 3, H, W), dtype=torch.uint8, device=dev)
+        frames = torch.empty((N, 3, H, W), dtype=frames_dtype, device=dev)
         Ho, Wo = (ch + 1) // 2, (cw + 1) // 2
         es = _esz(dt)
         blocks = list(Wt.blocks)
         fused_front = (Wt.front is not None and "_features.stem" not in taps and self.fuse_front
+                       and frames_dtype == torch.uint8 and not isinstance(flip, torch.Tensor)
                        and ops.s1_front_parts(ch, cw, Wt.blocks[0].spec.cout) > 0)
         if fused_front:
             bw = blocks.pop(0)
@@ -1101,6 +1104,34 @@ class ForwardEngine:
         self.set_frames(plan, frames_u8)
         self.run_plan(plan)
         return plan.head_out, plan
+
+    def forward_augmented(self, frames, flip_frames=None):
+        """Eval-mode forward (running-statistics BatchNorm) of frames that the caller has already cropped / augmented:
+        frames (B,T,3,h,w) uint8 or fp32 0..255 on the GPU, flip_frames: optional uint8 (B*T,) per-frame h-flip flags.
+        What `Impl.forward(inference=False)` runs under .eval() (model/model.py:105-129 with the BatchNorms in eval mode).
+        Eager launches of a cached plan (fp32 frames and per-frame flips go through the stand-alone stem kernel)."""
+        if frames.dtype not in (torch.uint8, torch.float32):
+            raise TypeError("frames must be uint8 or float32 (0..255)")
+        B, T, Cc, H, W = frames.shape
+        if T != self.pw.clip_len:
+            raise ValueError(f"clip length {T} != clip_len {self.pw.clip_len} (gate-shift needs exact clips)")
+        key = ("aug", B, H, W, frames.dtype, flip_frames is not None)
+        plan = self._plans.get(key)
+        if plan is None:
+            fbuf = torch.zeros((B * T,), dtype=torch.uint8, device=self.device) if flip_frames is not None else False
+            crop_dim, self.crop_dim = self.crop_dim, None           # the caller's window: no centre crop on top of it
+            try:
+                sub = self._build(B, H, W, fbuf, set(), frames_dtype=frames.dtype)
+            finally:
+                self.crop_dim = crop_dim
+            plan = SimpleNamespace(sub=sub, flip_buf=fbuf if flip_frames is not None else None, graph=None)
+            self._plans[key] = plan
+        plan.sub.frames.copy_(frames.reshape(B * T, Cc, H, W), non_blocking=True)
+        if flip_frames is not None:
+            plan.flip_buf.copy_(flip_frames.to(torch.uint8), non_blocking=True)
+        for s_ in plan.sub.steps:
+            s_.fn()
+        return plan.sub.head_out, plan
 
     def __del__(self):
         # graph executables are not destroyed from a finaliser (it may run at any allocation, e.g. inside another engine's

@@ -229,6 +229,41 @@ class TDEEDModel:
             n_cls, dcol, _ = eng.temporal.head_layout()
             return self._pack_head(head, B, T, n_cls, dcol, y)
 
+        def _forward_eval_augmented(self, x, y, act_dtype):
+            """model.py:105-129 with `inference=False` on a module in eval() mode: the training branch's random crop (one
+            window for the whole batch, model.py:115) and per-clip augmentation (model.py:76-83, 154-157) in front of
+            running-statistics BatchNorm and no dropout.  No caller of the reference uses this pairing (epoch() pairs
+            train() with inference=False and eval() with inference=True, model.py:196-203); it is here because the
+            reference's nn.Module allows it.  Same RNG draw order as the train-mode forward."""
+            if x.dtype not in (torch.uint8, torch.float32):
+                x = x.float()
+            x = x.to(self._device).contiguous()
+            B, T, _, H, W = x.shape
+            cd = self.croping
+            crop = None
+            if cd and (cd != H or cd != W):
+                g = self.augment_generator
+                top = int(torch.randint(0, H - cd + 1, size=(1,), generator=g).item())
+                left = int(torch.randint(0, W - cd + 1, size=(1,), generator=g).item())
+                crop = (top, left, cd, cd)
+            flip_frames = None
+            if self.augment_fn is not None:
+                x = self.augment_fn(x, crop)
+                if x.dtype not in (torch.uint8, torch.float32) or not x.is_cuda:
+                    raise TypeError("augment_fn must return uint8 / float32 frames on the device")
+            else:
+                prm, flip_c = augment.draw_params(B, self.augment_generator)
+                if not augment.is_identity(prm):
+                    x = augment.apply(x, prm, crop)                 # fp32 0..255 frames of the crop window
+                elif crop is not None:
+                    x = x[..., crop[0]:crop[0] + cd, crop[1]:crop[1] + cd]
+                if bool(flip_c.any()):
+                    flip_frames = flip_c.to(self._device).to(torch.uint8).repeat_interleave(T).contiguous()
+            eng = self.engine(act_dtype)
+            head, _ = eng.forward_augmented(x.contiguous(), flip_frames)
+            pw = eng.pw
+            return self._pack_head(head, B, T, pw.n_cls, pw.displ_col, y)
+
         def forward(self, x, y=None, inference=False, augment_inference=False, act_dtype=torch.bfloat16, slot=0):
             """model.py:105-149.  x: (B,T,3,H,W) uint8, or float holding 0..255 values.  Like the reference's nn.Module,
             .train()/.eval() select BatchNorm statistics + dropout and `inference` selects the crop / augmentation branch.
@@ -236,10 +271,7 @@ class TDEEDModel:
             if self.training:
                 return self._forward_train(x, y, inference, augment_inference)
             if not inference:
-                raise NotImplementedError(
-                    "Impl.forward(inference=False) in eval() mode (running-statistics BatchNorm on randomly cropped and "
-                    "augmented clips) is a combination no caller of the reference uses: epoch() pairs train() with "
-                    "inference=False and eval() with inference=True (model.py:196-203)")
+                return self._forward_eval_augmented(x, y, act_dtype)
             if x.dtype != torch.uint8:
                 x = x.round().clamp_(0, 255).to(torch.uint8)
             x = x.to(self._device)

@@ -312,10 +312,41 @@ def test_train_mode_forward_is_callable_and_matches_the_oracle():
     # ---- train() + inference=True: centre crop, no augmentation, still batch statistics
     pred_i, _ = m._model(frames, inference=True)
     assert pred_i["im_feat"].shape == (B, T, 4) and bool(torch.isfinite(pred_i["im_feat"]).all())
-    # ---- eval() + inference=False is the one combination that is refused, loudly
+    # ---- eval() + inference=False (model.py:105-129 on a module in eval mode; no reference caller pairs them): the training
+    # branch's random crop + per-clip augmentation in front of running-statistics BatchNorm, no dropout -> deterministic
+    # given the draws: equals the oracle's eval forward on the same augmented clips
     m._model.eval()
-    with pytest.raises(NotImplementedError):
-        m._model(frames, inference=False)
+    m._model._engines = {}
+    torch.manual_seed(321)
+    gen_state = torch.get_rng_state()
+    pred_e, _ = m._model(frames, inference=False, act_dtype=torch.float32)
+    torch.cuda.synchronize()
+    torch.set_rng_state(gen_state)
+    tp = int(torch.randint(0, H - 64 + 1, size=(1,)).item())
+    lf = int(torch.randint(0, W - 64 + 1, size=(1,)).item())
+    prm, flip = augment.draw_params(B)
+    x01 = frames.float()[..., tp:tp + 64, lf:lf + 64] / 255.0
+    xa = torch.stack([O.augment_clip(x01[b], prm[b]) for b in range(B)], 0)
+    xa = torch.stack([xi.flip(-1) if f else xi for xi, f in zip(xa, flip.tolist())], 0)
+    sd_now = {k: v.detach().cpu() for k, v in m.state_dict().items()}          # the running statistics moved above
+    with torch.no_grad():
+        xn = (xa - mean) / std
+        f_ref = O.regnet_features(xn.reshape(B * T, 3, 64, 64), sd_now, spec, T, "gsf", training=False).reshape(B, T, -1)
+        enc = O.ed_sgp_mixer(f_ref + sd_now["temp_enc"][None], sd_now, cfg["n_layers"], T)
+        cls_e, displ_e = O.heads(enc, sd_now, cfg["radi_displacement"])
+    assert max_abs(pred_e["im_feat"].float().cpu(), cls_e) < 2e-3 and max_abs(pred_e["displ_feat"].float().cpu(), displ_e) < 2e-3
+    # crop only (augment_fn): the same result as the ordinary inference path on the pre-cropped clip
+    m._model.augment_fn = crop_only
+    pred_c, _ = m._model(frames, inference=False, act_dtype=torch.float32)
+    tpc, lfc = seen["crop"][:2]
+    m._model.croping = None
+    eng_c = m._model.engine(torch.float32)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        head_c, _ = eng_c.forward_augmented(frames[..., tpc:tpc + 64, lfc:lfc + 64].contiguous().to(DEV))
+        st.synchronize()
+    torch.cuda.synchronize()
+    assert max_abs(pred_c["im_feat"].float().cpu(), head_c.float().cpu().view(B, T, -1)[..., :4]) < 1e-5
 
 
 def test_augmentation_draws_follow_the_documented_order():

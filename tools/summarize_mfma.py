@@ -13,7 +13,7 @@ def load(d):
     acc = defaultdict(lambda: defaultdict(float))
     n = defaultdict(int)
     for r in csv.DictReader(open(f)):
-        k = family(re.sub(r"\(.*", "", r["Kernel_Name"]))
+        k = family(re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")))
         if k is None:
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -42,7 +42,7 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = re.sub(r"\(.*", "", r["Kernel_Name"])
+        name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
         acc[name][0] += float(r["Counter_Value"])
         acc[name][1] += 1
     if not acc:
