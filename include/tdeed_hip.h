@@ -149,6 +149,19 @@ int tdeed_se_gate_mfma_fits(int C, int R);
 int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R, const void* w1f,
                            const float* b1, const void* w2f, const float* b2, float* gate, void* stream);
 
+/* conv3 of a RegNetY bottleneck WITH its SE excitation (timm Bottleneck.forward: x = conv3(se(conv2(x)))):
+ * the contraction of tdeed_gemm_fwd whose operand rows are re-scaled per (frame, k) by gates that every workgroup derives
+ * itself, for the frames of its 128-row tile, from conv2's squeeze sums -- pooled fp32 [M / rows_per_frame][n_parts][K],
+ * inv_cnt = 1 / (Ho * Wo), weights as for tdeed_se_gate_mfma_fwd (R hidden units) -- so that no tdeed_se_gate_* launch sits
+ * between conv2 and conv3.  bf16 operands only.  gate_out: optional fp32 [M / rows_per_frame][K], also receives the gates
+ * (bit-identical to tdeed_se_gate_mfma_fwd for n_parts = 1).  tdeed_gemm_se_fits(rows_per_frame, K, R) != 0 tells whether
+ * the shape is covered (at most 16 frames per 128-row tile, K <= 384, R <= 96). */
+int tdeed_gemm_se_fits(int rows_per_frame, int K, int R);
+int tdeed_gemm_se_fwd(const void* A, long lda, int rows_per_frame, const float* pooled, int n_parts, float inv_cnt, int R,
+                      const void* w1f, const float* b1, const void* w2f, const float* b2, float* gate_out, int M, int K,
+                      int N, const void* W, long ldw, const float* scale, const float* shift, const void* Res, long ldr,
+                      int act, void* C, long ldc, void* C2, long ldc2, int n2, void* stream);
+
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
  * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled: fp32 [N][n_parts][C] partial sums, mean = inv_cnt *
  * sum over parts; gate: fp32 [N][C]; w1t [C][R] (fc1.weight transposed), w2t [R][C] (fc2.weight transposed). */

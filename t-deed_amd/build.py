@@ -34,7 +34,7 @@ def _stale(obj, deps):
 
 
 def build(force=False, verbose=True):
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "sgp_tile.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "sgp_tile.h"), os.path.join(CSRC, "se_excite.h"),
             os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "tdeed_hip.h")]
     jobs = []
     objs = []

@@ -191,6 +191,7 @@ def pack_se_mfma(fc1_w, fc2_w, device):
 
 GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
 WS_NARROW_ONLY = os.environ.get("TDEED_WS_NARROW_ONLY", "1") == "1"
+WS_WIDE_MIN_ROWS = int(os.environ.get("TDEED_WS_WIDE_MIN_ROWS", "250000"))     # 0: never the sliced form
 
 
 class DenseW:
@@ -200,21 +201,37 @@ class DenseW:
         """gated: the layer is a conv3 (SE gate on its operand + residual)."""
         W = _np(W)
         self.N, self.K = W.shape
-        # mode 1: the whole W sits in LDS; mode 2 (wide s4 layers: W sliced over blockIdx.y, activations re-read per slice)
-        # is opt-in (TDEED_WS_SLICED=1)
-        ok_modes = (1, 2) if os.environ.get("TDEED_WS_SLICED", "0") == "1" else (1,)
-        self.ws = (ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) in ok_modes) if str(device) != "cpu" else False
+        # mode 1: the whole W sits in LDS; mode 2: W does not fit, equal column slices over blockIdx.y (activations re-read per
+        # slice, 8 waves per workgroup).  TDEED_WS_SLICED=1 sends mode-2 layers there at every row count
+        mode = ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) if str(device) != "cpu" else 0
+        self.ws = mode == 1 or (mode == 2 and os.environ.get("TDEED_WS_SLICED", "0") == "1")
         # The weight-stationary kernel was built for the narrow RegNetY-200MF layers (24 .. 152 channels), where it wins by
         # 20-35 %; on the 64- and 128-wide layers of the 800MF trunk the tiled kernel is the faster one
         # (tools/bench_ws_vs_gemm.py, us: 64x64 conv1 135 vs 152, conv3 190 vs 221; 128x128 conv3 101 vs 123; conv1 a tie)
         if self.ws and WS_NARROW_ONLY and ((self.K == 64 and self.N == 64) or (gated and self.K >= 64 and self.K % 64 == 0)):
             self.ws = False
         self.w = pack_ws_weights(W, act_dtype, device) if self.ws else _dense(W, act_dtype, device)
+        # wide layers over MANY rows (the 320-wide s3 layers of RegNetY-800MF at 3 * 10^5 rows): the sliced form reads the
+        # activations once per slice instead of once per 64-column tile -- tools/bench_ws_wide.py, M = 313600, K = N = 320: 134
+        # vs 180 us.  Below that the operands of the micro-benchmark sit in the Infinity Cache and in the forward, where two
+        # sub-batches share the chip, a kernel that takes whole CUs (150 KB of LDS) pushes the other stream's launches out:
+        # 800MF B = 16 (156 800 rows per sub-batch) 1437 vs 1460 clips/s with it, cfg2 3525 vs 3560 -- hence the threshold
+        self.wide = (not self.ws) and mode == 2 and WS_WIDE_MIN_ROWS > 0
+        self.w_wide = pack_ws_weights(W, act_dtype, device) if self.wide else None
         self.kernel = "gemm_ws" if self.ws else "gemm"
+
+    def _use_wide(self, M):
+        return self.wide and M is not None and M >= WS_WIDE_MIN_ROWS
+
+    def kern(self, M):
+        """kernel family that serves this layer at M rows"""
+        return "gemm_ws" if (self.ws or self._use_wide(M)) else "gemm"
 
     def run(self, A, scale, shift, act, **kw):
         if self.ws:
             return ops.gemm_ws(A, self.w, self.K, self.N, scale, shift, act, **kw)
+        if self._use_wide(kw.get("M")):
+            return ops.gemm_ws(A, self.w_wide, self.K, self.N, scale, shift, act, **kw)
         return ops.gemm(A, self.w, scale, shift, act, **kw)
 
 
@@ -414,6 +431,15 @@ def _se(pooled, inv_cnt, bw, gate):
     if bw.se_bf is not None:
         return ops.se_gate_bf16(pooled, inv_cnt, bw.se_bf.se_w1p, bw.se_b1, bw.se_bf.se_w2p, bw.se_b2, bw.spec.se_rd, out=gate)
     return ops.se_gate(pooled, inv_cnt, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate)
+
+
+SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
+
+
+def _se_fused(bw, rows_per_frame, taps=()):
+    """True when conv3 of this block computes its SE gates itself (bf16, the tiled contraction, shape covered)."""
+    return bool(SE_IN_CONV3 and bw.se_mf is not None and not bw.w3.ws
+                and ops.gemm_se_fits(rows_per_frame, bw.spec.cout, bw.spec.se_rd))
 
 
 class Step:
@@ -804,14 +830,14 @@ class ForwardEngine:
                 steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
                     bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
-                steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
+                steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                     x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
                     *gemm_cost(M, blk.cin, blk.cout, es)))
                 if blk.name and ("_features." + blk.name + ".gs_out") in taps:
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
                 gs_bufs = list(gb.values()) + ([xs] if xs is not None else [])
             else:
-                steps.append(Step(blk.name + ".conv1", bw.w1.kernel, lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
+                steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
                     x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
                 gs_bufs = []
             s = blk.stride
@@ -824,12 +850,16 @@ class ForwardEngine:
             steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
                 y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
                 (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
-            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
-                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            # SE excitation inside conv3 (tdeed_gemm_se_fwd: every workgroup derives the gates of its tile's frames from the
+            # squeeze sums) where the tiled kernel serves conv3 and the shape is covered; a launch of its own otherwise
+            se_in_conv3 = _se_fused(bw, h2 * w2, taps)
+            if not se_in_conv3:
+                steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
+                    2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
             if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
                 gather = (s, h, w, h2, w2) if s > 1 else None
-                steps.append(Step(blk.name + ".downsample", bw.wd.kernel, lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: bw.wd.run(
+                steps.append(Step(blk.name + ".downsample", bw.wd.kern(M2), lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: bw.wd.run(
                     x, bw.sd, bw.hd, ops.ACT_NONE, gather=gather, out=sc, M=M2),
                     *gemm_cost(M2, blk.cin, blk.cout, es)))
             else:
@@ -839,9 +869,16 @@ class ForwardEngine:
             xs_next = None
             if nxt is not None and nxt.gsf_fold and GS_SLICE:
                 xs_next = pool.take((N, h2, w2, (nxt.gsf_fold + 7) // 8 * 8), dt)
-            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: bw.w3.run(
-                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2, out2=xs_next),
-                *gemm_cost(M2, blk.cout, blk.cout, es, True)))
+            if se_in_conv3:
+                steps.append(Step(blk.name + ".conv3", "gemm", lambda y2=y2, bw=bw, pooled=pooled, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: ops.gemm_se(
+                    y2, bw.w3.w, hw2, pooled, 1.0 / hw2, bw.spec.se_rd, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
+                    bw.s3, bw.h3, ops.ACT_RELU, residual=sc, out=out, M=M2, out2=xs_next),
+                    gemm_cost(M2, blk.cout, blk.cout, es, True)[0] + 2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4,
+                    gemm_cost(M2, blk.cout, blk.cout, es, True)[1] + 4 * N * blk.cout * blk.se_rd))
+            else:
+                steps.append(Step(blk.name + ".conv3", bw.w3.kern(M2), lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: bw.w3.run(
+                    y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2, out2=xs_next),
+                    *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` (and the next block's slice) dies here
             for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
@@ -916,7 +953,7 @@ class ForwardEngine:
                               2 * N * Ho * Wo * 32 * (27 + 2 * blk.cout) // 1 + 2 * M2 * blk.cout * blk.gw * 9))
             steps.append(Step(blk.name + ".se", "se_gate", lambda bw=bw, pooled=pooled, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
                 2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
-            steps.append(Step(blk.name + ".conv3", bw.w3.kernel, lambda bw=bw, y2=y2, sc=sc, gate=gate, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
+            steps.append(Step(blk.name + ".conv3", bw.w3.kern(M2), lambda bw=bw, y2=y2, sc=sc, gate=gate, out=out, M2=M2, hw2=h2 * w2: bw.w3.run(
                 y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2),
                 *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             for t_ in (y2, sc, pooled, gate):

@@ -133,6 +133,26 @@ def gemm(A, W, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None
     return out
 
 
+def gemm_se_fits(rows_per_frame, K, R):
+    return _lib.load().tdeed_gemm_se_fits(rows_per_frame, K, R) != 0
+
+
+def gemm_se(A, W, rows_per_frame, pooled, inv_cnt, R, w1f, b1, w2f, b2, scale=None, shift=None, act=ACT_NONE, residual=None,
+            out=None, M=None, out2=None, gate_out=None):
+    """conv3 with the SE excitation inside (tdeed_gemm_se_fwd): C = act(((A * gate[frame]) @ W^T) * scale + shift + residual),
+    gate = sigmoid(fc2 relu(fc1 mean)) from pooled (frames, parts, K) squeeze sums.  bf16."""
+    _chk(A, "A", torch.bfloat16); _chk(W, "W", torch.bfloat16); _chk(pooled, "pooled", torch.float32)
+    N, K = W.shape
+    if M is None:
+        M = A.numel() // A.shape[-1]
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    call("tdeed_gemm_se_fwd", ptr(A), A.shape[-1], rows_per_frame, ptr(pooled), pooled.shape[1], float(inv_cnt), R, ptr(w1f),
+         ptr(b1), ptr(w2f), ptr(b2), ptr(gate_out), M, K, N, ptr(W), W.shape[1], ptr(scale), ptr(shift), ptr(residual),
+         (residual.shape[-1] if residual is not None else 0), act, ptr(out), N, *_out2(out2, A), stream_ptr())
+    return out
+
+
 def gemm_ws_fits_mode(K, N, act_dtype):
     """0: no; 1: weights fit LDS (preferred kernel for narrow layers); 2: weights streamed from L2 (wide layers)."""
     return _lib.load().tdeed_gemm_ws_fits(K, N, dtype_code(act_dtype))

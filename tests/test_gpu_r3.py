@@ -282,3 +282,83 @@ def test_concat_fc_fold_per_clip_and_channels():
     of = out.float()
     assert torch.allclose(chs[..., 0], of.sum(1), rtol=1e-5, atol=1e-3)
     assert torch.allclose(chs[..., 1], (of * of).sum(1), rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ SE excitation inside conv3
+@pytest.mark.parametrize("hw,C,R,parts,N", [(49, 368, 92, 1, 37), (49, 368, 38, 1, 8), (196, 152, 38, 3, 5), (25, 320, 80, 1, 19),
+                                            (784, 128, 16, 2, 3), (9, 56, 6, 1, 40)])
+def test_conv3_with_the_se_excitation_inside_equals_se_gate_then_conv3(hw, C, R, parts, N):
+    """tdeed_gemm_se_fwd (every workgroup derives the gates of its row tile's frames from conv2's squeeze sums) against the
+    two launches it replaces, tdeed_se_gate_mfma_fwd + tdeed_gemm_fwd(a_scale=gate): gates to fp32 rounding (bitwise for one
+    partial row), conv3 output bitwise then; and both against the SE arithmetic in torch fp32 (timm SEModule: mean ->
+    fc1 -> ReLU -> fc2 -> sigmoid)."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_se_mfma
+    assert ops.gemm_se_fits(hw, C, R) and ops.se_gate_mfma_fits(C, R)
+    g = torch.Generator().manual_seed(hw * 1000 + C + R)
+    M = N * hw
+    y2 = (torch.randn(M, C, generator=g)).to(torch.bfloat16).to(DEV)
+    res = (torch.randn(M, C, generator=g)).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(C, C, generator=g) / C ** 0.5).to(torch.bfloat16).to(DEV)
+    sc = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    pooled = (torch.randn(N, parts, C, generator=g) * hw / parts + 0.3 * hw / parts).to(DEV)
+    fc1 = torch.randn(R, C, generator=g) / C ** 0.5
+    fc2 = torch.randn(C, R, generator=g) / R ** 0.5
+    b1 = (torch.randn(R, generator=g) * 0.1).to(DEV)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    pk = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
+    gate_ref = ops.se_gate_mfma(pooled, 1.0 / hw, pk["w1f"], b1, pk["w2f"], b2, R)
+    out_ref = ops.gemm(y2, W, sc, sh, ops.ACT_RELU, residual=res, a_scale=gate_ref, a_scale_rows=hw)
+    gate = torch.full((N, C), float("nan"), device=DEV)
+    n2 = 16 if C >= 16 else 8
+    out2 = torch.empty((M, n2), dtype=torch.bfloat16, device=DEV)
+    out = ops.gemm_se(y2, W, hw, pooled, 1.0 / hw, R, pk["w1f"], b1, pk["w2f"], b2, sc, sh, ops.ACT_RELU, residual=res,
+                      gate_out=gate, out2=out2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(gate).all()
+    if parts == 1:
+        assert torch.equal(gate, gate_ref)
+        assert torch.equal(out, out_ref)
+    else:
+        assert torch.allclose(gate, gate_ref, rtol=1e-5, atol=1e-6)
+        d = (out.float() - out_ref.float()).abs()
+        assert float(d.max()) <= 2 ** -6 * float(out_ref.float().abs().max())
+    assert torch.equal(out2, out[:, :n2].contiguous())
+    mean = pooled.sum(1).cpu() / hw
+    gt = torch.sigmoid(torch.relu(mean @ fc1.to(torch.bfloat16).float().t() + b1.cpu()) @ fc2.to(torch.bfloat16).float().t()
+                       + b2.cpu())
+    assert torch.allclose(gate.cpu(), gt, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,K,N,hw", [(70000 - 70000 % 196, 320, 320, 196), (60025, 320, 768, 49), (61152, 368, 368, 49)])
+def test_sliced_weight_stationary_contraction_of_the_wide_layers(M, K, N, hw):
+    """gemm_ws with W cut into equal column slices (8 waves per workgroup; what engine.DenseW picks for the 320-wide layers of
+    RegNetY-800MF above engine.WS_WIDE_MIN_ROWS rows) against the tiled contraction on the same operands: bitwise, with every operand feature
+    of a bottleneck's conv1 / conv3 (gate-shift splice, SE re-scale, residual, second compact output)."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_ws_weights, DenseW
+    assert ops.gemm_ws_fits_mode(K, N, torch.bfloat16) == 2
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    A0 = torch.randn(M, 80, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    sc, sh = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    gate = torch.rand(M // hw, K, generator=g).to(DEV)
+    Wd, Wf = W.to(DEV), pack_ws_weights(W.float().numpy(), torch.bfloat16, DEV)
+    for kw in (dict(), dict(A0=A0, k0=80), dict(residual=res, a_scale=gate, a_scale_rows=hw)):
+        o2a = torch.empty((M, 32), dtype=torch.bfloat16, device=DEV)
+        o2b = torch.empty_like(o2a)
+        ref = ops.gemm(A, Wd, sc, sh, ops.ACT_RELU, out2=o2a, **kw)
+        got = ops.gemm_ws(A, Wf, K, N, sc, sh, ops.ACT_RELU, out2=o2b, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and torch.equal(o2a, o2b), kw.keys()
+    from tdeed_amd import engine
+    d = DenseW(W.float().numpy(), torch.bfloat16, DEV)
+    assert d.kern(engine.WS_WIDE_MIN_ROWS) == "gemm_ws" and d.kern(1000) == "gemm"
+    old, engine.WS_WIDE_MIN_ROWS = engine.WS_WIDE_MIN_ROWS, 1000
+    try:
+        assert torch.equal(d.run(A, sc, sh, ops.ACT_RELU, M=M), ops.gemm(A, Wd, sc, sh, ops.ACT_RELU))
+    finally:
+        engine.WS_WIDE_MIN_ROWS = old
