@@ -752,8 +752,10 @@ extern "C" int tdeed_gemm_ws_fits(int K, int N, int dtype) {
   const int NT = (N + 31) / 32 * 2;
   if (!ws_ks_ok(KS)) return 0;
   const int nts = ws_slice_tiles(NT, KS);
-  if (nts == NT) return 1;                        // whole W in LDS
-  if (dtype == TDEED_BF16 && nts >= 4 && N <= 1024) return 2;     // sliced: wide s4 layers
+  const size_t per_tile = (size_t)KS * 64 * 16 + 16 * 2 * sizeof(float);
+  if ((size_t)NT * per_tile <= 64 * 1024) return 1;               // whole W in LDS, several workgroups per CU
+  if (dtype == TDEED_F32 && (size_t)NT * per_tile <= 96 * 1024) return 1;   // parity mode: whole W, one workgroup per CU
+  if (dtype == TDEED_BF16 && nts >= 4 && N <= 1024) return 2;     // one workgroup per CU: a slice (or all) of a wide W
   return 0;
 }
 
