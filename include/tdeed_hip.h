@@ -149,6 +149,24 @@ int tdeed_se_gate_mfma_fits(int C, int R);
 int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R, const void* w1f,
                            const float* b1, const void* w2f, const float* b2, float* gate, void* stream);
 
+/* A whole stride-1 RegNetY bottleneck with identity shortcut on a small map in ONE launch (timm Bottleneck.forward:
+ * conv1 -> conv2 -> se -> conv3 + shortcut -> ReLU, with the gate-shift splice of shift.py:89-93 on conv1's operand;
+ * SURVEY §8 a2 / a3): the frames of a workgroup stay in LDS, only x and the output cross HBM.  bf16.
+ *   x [N][h][w][C]; G optional [N*h*w][Fp] compact gate-shift output replacing channels [0, Fp) of conv1's operand (the
+ *   residual is x itself); w1f / w3f: conv weights [C][C] as MFMA A-operand fragments [ceil(C/16)][ceil(C/32)][64][8]
+ *   (tdeed_amd.engine.pack_mfma_frags); w2f as for tdeed_gconv3x3_fwd (pack_gconv_frags, group width 8 or 16); se_w1f /
+ *   se_w2f / R as for tdeed_se_gate_mfma_fwd; s*, h*: folded BatchNorm scale / shift; out [N][h][w][C]; out2 optional
+ *   [N*h*w][n2] compact copy of channels [0, n2) (the next block's gate-shift slice).
+ * Bit-identical to tdeed_gemm_fwd -> tdeed_gconv3x3_fwd -> tdeed_se_gate_mfma_fwd -> tdeed_gemm_fwd on the same operands.
+ * tdeed_bneck_fits: 7x7x368 (two frames per workgroup) and 14x14x152 are the shapes it was built for.
+ * tdeed_bneck_set_debug(buf): diagnostic, int64 [workgroups][16] phase time stamps (null switches it off). */
+int tdeed_bneck_fits(int h, int w, int C, int R);
+int tdeed_bneck_set_debug(void* buf);
+int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f, const float* s1,
+                    const float* h1, const void* w2f, const float* s2, const float* h2, const void* se_w1f,
+                    const float* se_b1, const void* se_w2f, const float* se_b2, int R, const void* w3f, const float* s3,
+                    const float* h3, void* out, void* out2, int n2, void* stream);
+
 /* conv3 of a RegNetY bottleneck WITH its SE excitation (timm Bottleneck.forward: x = conv3(se(conv2(x)))):
  * the contraction of tdeed_gemm_fwd whose operand rows are re-scaled per (frame, k) by gates that every workgroup derives
  * itself, for the frames of its 128-row tile, from conv2's squeeze sums -- pooled fp32 [M / rows_per_frame][n_parts][K],

@@ -1,0 +1,416 @@
+// A whole stride-1 RegNetY bottleneck with identity shortcut on a SMALL map in one launch (bf16 throughput mode):
+//   conv1 1x1 (+ gate-shift splice) + BN + ReLU -> conv2 grouped 3x3 + BN + ReLU -> SE squeeze / excite
+//   -> conv3 1x1 on y2 * gate + BN + residual + ReLU          (timm Bottleneck.forward)
+// for the blocks whose frames fit LDS twice over: s4.b2..b7 (7 x 7 x 368, TWO frames per workgroup) and s3.b2..b4
+// (14 x 14 x 152, one frame) of RegNetY-200MF.  The launch-per-layer chain moves x, y1, y2 through HBM / L2 seven times
+// in four latency-bound launches (80 us per s4 block for 29 MB); here a workgroup's frames stay in LDS -- region A holds
+// x (gate-shift columns spliced in), later y2; region B holds y1, later the SE scratch, later the output rows -- and the
+// weights stream from L2 as MFMA A-operand fragments, one 16-channel tile per wave at a time, the next tile's fragments
+// requested while the current one is multiplied.  Two frames per workgroup halve the weight bytes per frame (the round-1
+// one-frame form, experiments/, re-streamed ~0.7 MB per frame and lost); 8 waves keep two waves per SIMD.
+// Rounding points are those of the chain (y1, y2, y2 * gate, out in bf16; everything else fp32, same k order); only the
+// squeeze sums of a workgroup's SECOND frame associate differently (its pixels sit in other lanes of the tiles), i.e. the
+// result equals gemm -> gconv3x3 -> se_gate_mfma -> gemm up to the last bit of those fp32 sums.
+#include "common.h"
+#include "se_excite.h"
+
+struct BneckP {
+  const bf16_t* x; const bf16_t* G; int Fp;       // block input [N][hw][C]; gate-shift splice [N * hw][Fp] (or null)
+  const bf16x8* w1f; const float* s1; const float* h1;        // [NT][KS][64]
+  const bf16x8* w2f; const float* s2; const float* h2;        // [NT4][5][64]  (engine.pack_gconv_frags)
+  SeP se;                                                     // weights / biases / R (pooled, n_parts, C filled in-kernel)
+  const bf16x8* w3f; const float* s3; const float* h3;        // [NT][KS][64]
+  bf16_t* out; bf16_t* out2; int n2;              // out [N][hw][C]; optional compact copy of channels [0, n2)
+  int N, h, w, C;
+  long long* dbg;                                 // diagnostic: per-workgroup phase time stamps (or null)
+};
+
+#define BN_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+
+constexpr int BNK_NW = 8, BNK_THR = BNK_NW * 64;
+
+// activation row stride in bytes: C * 2 rounded up to 96 mod 128.  The 16 pixel rows x 4 k-chunks of an MFMA operand read
+// (ds_read_b128, lane groups {0-3,12-15,20-27}, ...) then fall on 16 distinct 16-byte bank slots per group: 4.0 LDS cycles
+// per read against 7.7 with a plain 16-byte skew (C = 368: stride 736, no pad at all; C = 152: 352)
+__host__ __device__ inline int bneck_rs(int C) { return C * 2 + ((96 - (C * 2) % 128) + 128) % 128; }
+
+// sum over each row of 16 lanes (the 16 pixels of an MFMA tile), every lane gets it: DPP moves, the pairing of a
+// shuffle-xor butterfly (bit-identical to it), none of its four LDS crossbar round trips
+__device__ __forceinline__ float bnk_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // other quad
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // other half
+  return v;
+}
+
+// FPW frames per workgroup, NPTM >= ceil(FPW * hw / 16) pixel tiles
+template <int KS, int FPW, int NPTM>
+__global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int hw = p.h * p.w, C = p.C;
+  const int f0 = blockIdx.x * FPW;
+  const int nfr = min(FPW, p.N - f0);                    // frames of this workgroup
+  const int npix = nfr * hw;
+  const int RS = bneck_rs(C);                            // activation row stride (bytes)
+  const int NT = (C + 15) >> 4;
+  unsigned char* At = smem;                              // [FPW * hw][RS]   x, later y2
+  unsigned char* Bt = At + FPW * hw * RS;                // [FPW * hw][RS]   y1, later SE scratch, later the output rows
+  unsigned char* Zr = Bt + FPW * hw * RS;                // one row of zeros (taps outside the map) + slack for the k pad
+  unsigned char* Tr = Zr + RS + 64;                      // one row nobody reads: where the lanes of a ragged last tile store
+  float* pooled = reinterpret_cast<float*>(Tr + RS);     // [FPW][C] squeeze sums
+  float* gtab = pooled + FPW * C;                        // [FPW][C] gates
+  float* bnv = gtab + FPW * C;                           // [6][NT * 16]: folded BatchNorm scale / shift of conv1, conv2, conv3
+  const int CP = ((C + 15) >> 4) << 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pl = lane & 15, q = lane >> 4;
+  const bf16_t* xg = p.x + (long)f0 * hw * C;
+
+  // The first channel tile's weights of each contraction are requested one phase early (conv1's before the frames are
+  // loaded, conv2's before conv1 runs, conv3's before the SE phase): a phase otherwise opens with a bare L2 round trip.
+  const int NT_ = (C + 15) >> 4;
+  bf16x8 wc1[KS], wf2[5];
+  if (wv < NT_) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wc1[ks] = p.w1f[((long)wv * KS + ks) * 64 + lane];
+  }
+  BN_STAMP(0);
+  // ---- P0: x (gate-shift columns spliced in) -> region A; pads, zero row
+  {
+    const int cpr = C >> 3;
+    const bf16_t* gg = p.G ? p.G + (long)f0 * hw * p.Fp : nullptr;
+    const int total = npix * cpr;
+    const IDiv dcpr(cpr);
+    for (int i0 = tid; i0 < total; i0 += BNK_THR * 6) {          // 6 independent 16-byte loads in flight per thread
+      u32x4 v[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int i = min(i0 + b * BNK_THR, total - 1);
+        int px, ck;
+        dcpr.divmod(i, px, ck);
+        const int k = ck * 8;
+        const bf16_t* src = (gg && k < p.Fp) ? gg + (long)px * p.Fp + k : xg + (long)px * C + k;
+        v[b] = *reinterpret_cast<const u32x4*>(src);
+      }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int i = i0 + b * BNK_THR;
+        if (i < total) {
+          int px, ck;
+          dcpr.divmod(i, px, ck);
+          *reinterpret_cast<u32x4*>(At + px * RS + ck * 16) = v[b];
+        }
+      }
+    }
+    // the pad bytes behind every row (they meet the zero weights of the k pad, but 0 * stale NaN = NaN), the zero row
+    const int padp = (RS - C * 2) >> 4;
+    for (int i = tid; i < 2 * FPW * hw * padp; i += BNK_THR) {
+      const int r = i / padp, j = i - r * padp;
+      *reinterpret_cast<u32x4*>(smem + r * RS + C * 2 + j * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    for (int i = tid; i < (RS + 64) >> 4; i += BNK_THR) *reinterpret_cast<u32x4*>(Zr + i * 16) = (u32x4){0u, 0u, 0u, 0u};
+    // the k pad of the last loaded row reads on into the next row (KS * 32 > C + pad / 2): region B's head, or the first
+    // unused row of region A when the workgroup has fewer frames -- finite before anything has been written there
+    if (tid < 4) *reinterpret_cast<u32x4*>(At + npix * RS + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < 6 * CP; i += BNK_THR) {
+      const int v = i / CP, c = i - v * CP;
+      const float* src = v == 0 ? p.s1 : v == 1 ? p.h1 : v == 2 ? p.s2 : v == 3 ? p.h2 : v == 4 ? p.s3 : p.h3;
+      bnv[i] = c < C ? src[c] : 0.f;                     // channels >= C: exact zeros out of every epilogue
+    }
+  }
+  __syncthreads();
+  BN_STAMP(1);
+
+  // this lane's pixel row in each pixel tile (rows beyond npix clamp to row 0 and are never stored)
+  // ... and where it stores, as an offset from a region's base: its own row, or the trash row (no branch around a store:
+  // the tiles of a wave then schedule as one block)
+  int prow[NPTM], srowA[NPTM];
+#pragma unroll
+  for (int pt = 0; pt < NPTM; ++pt) {
+    const int px = pt * 16 + pl;
+    prow[pt] = (px < npix ? px : 0) * RS;
+    srowA[pt] = px < npix ? px * RS : (int)(Tr - At);
+  }
+  const int dAB = (int)(Bt - At);
+  // one 16-channel tile of a 1x1 conv: acc[pt] = sum_ks W[ks] . act[pixel tile pt][ks]
+  auto contract = [&](const bf16x8 (&wc)[KS], const unsigned char* act, f32x4 (&acc)[NPTM]) {
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kb = (32 * ks + 8 * q) * 2;
+      bf16x8 a[NPTM];                                  // every tile, always (rows beyond npix read row 0): no branches
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb);
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks], a[pt], acc[pt], 0, 0, 0);
+    }
+  };
+
+  // ---- P1: conv1: y1 = relu(bn(W1 x'))  (wave = channel tiles wv, wv + 8, ...)
+  {
+    bf16x8 (&wc)[KS] = wc1;
+    bf16x8 wn[KS];
+    if (wv < NT) {
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) wf2[ks] = p.w2f[((long)wv * 5 + ks) * 64 + lane];       // conv2's first unit
+    }
+    for (int T = wv; T < NT; T += BNK_NW) {
+      if (T + BNK_NW < NT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = p.w1f[((long)(T + BNK_NW) * KS + ks) * 64 + lane];
+      }
+      const int ch0 = T * 16 + 4 * q;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + ch0), sh = *reinterpret_cast<const f32x4*>(bnv + CP + ch0);
+      f32x4 acc[NPTM];
+      contract(wc, At, acc);
+      // channels >= C of the last tile get exact zeros (scale = shift = 0) and land in the row pad
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[pt][r] * sc[r] + sh[r], 0.f);
+        unsigned char* dst = At + srowA[pt];
+        *reinterpret_cast<bf16x4*>((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) = o;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wc[ks] = wn[ks];
+    }
+  }
+  __syncthreads();
+  BN_STAMP(2);
+
+  // ---- P2: conv2 grouped 3x3 from y1 (taps outside the map read the zero row) -> y2 in region A; squeeze sums per frame
+  {
+    const int NU = NT;
+    // per (pixel tile, k-step): LDS offset of the tap pixel's 8 input channels in region B (k-slot s = 4 ks + q = half * 9 +
+    // tap), or of the zero row -- the same for every 16-channel unit up to the unit's own 32-byte column offset
+    int toff[NPTM][5];
+    {
+      const int zoff = (int)(Zr - Bt);
+      int dyv[5], dxv[5], doff[5];
+      bool sok[5];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {                   // k-slot -> (half, dy, dx) with compares only
+        const int sidx = 4 * ks + q;
+        const int half = sidx >= 9 ? 1 : 0, tap = sidx - 9 * half;
+        const int ty = (tap >= 3 ? 1 : 0) + (tap >= 6 ? 1 : 0);
+        dyv[ks] = ty - 1;
+        dxv[ks] = tap - 3 * ty - 1;
+        sok[ks] = sidx < 18;
+        doff[ks] = (dyv[ks] * p.w + dxv[ks]) * RS + half * 16;
+      }
+      const IDiv dhw(hw), dw(p.w);
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) {
+        const int px = min(pt * 16 + pl, npix - 1);
+        int f, r, oy, ox;
+        dhw.divmod(px, f, r);
+        dw.divmod(r, oy, ox);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+          const bool ok = sok[ks] && (unsigned)(oy + dyv[ks]) < (unsigned)p.h && (unsigned)(ox + dxv[ks]) < (unsigned)p.w;
+          toff[pt][ks] = ok ? px * RS + doff[ks] : zoff;
+        }
+      }
+    }
+    // the weights of ALL of this wave's units are requested up front (the first came with conv1): a unit is ~1.3 k cycles of
+    // work, far less than an L2 round trip, so a one-ahead prefetch would expose one round trip per unit
+    constexpr int MAXU = 3;
+    bf16x8 (&wf)[5] = wf2;
+    bf16x8 wfx[MAXU - 1][5];
+#pragma unroll
+    for (int j = 1; j < MAXU; ++j) {
+      const int U = min(wv + j * BNK_NW, NU - 1);
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) wfx[j - 1][ks] = p.w2f[((long)U * 5 + ks) * 64 + lane];
+    }
+    int ju = 0;
+    BN_STAMP(8);
+    for (int U = wv; U < NU; U += BNK_NW, ++ju) {
+      const int ch0 = U * 16 + 4 * q;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 2 * CP + ch0), sh = *reinterpret_cast<const f32x4*>(bnv + 3 * CP + ch0);
+      float psum[FPW][4];
+#pragma unroll
+      for (int f = 0; f < FPW; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psum[f][r] = 0.f;
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) {
+        {
+          const int px = pt * 16 + pl;
+          const bool pok = px < npix;
+          bf16x8 yf[5];
+#pragma unroll
+          for (int ks = 0; ks < 5; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(Bt + toff[pt][ks] + U * 32);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 5; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yf[ks], acc, 0, 0, 0);
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[r] * sc[r] + sh[r], 0.f);
+          *reinterpret_cast<bf16x4*>(At + srowA[pt] + ch0 * 2) = o;
+          const bool second = FPW > 1 && px >= hw;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = pok ? (float)o[r] : 0.f;
+            if (FPW > 1) psum[FPW - 1][r] += second ? v : 0.f;
+            psum[0][r] += second ? 0.f : v;
+          }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < FPW; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = bnk_row16_sum(psum[f][r]);
+          if (pl == 0 && ch0 + r < C) pooled[f * C + ch0 + r] = v;
+        }
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) wf[ks] = ju == 0 ? wfx[0][ks] : wfx[MAXU - 2][ks];
+      BN_STAMP(9 + ju);
+    }
+  }
+  __syncthreads();
+  BN_STAMP(3);
+
+  bf16x8 wc3[KS];
+  if (wv < NT) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wc3[ks] = p.w3f[((long)wv * KS + ks) * 64 + lane];
+  }
+  // ---- P3: SE excitation of the workgroup's frames on the MFMA pipe (scratch: the dead y1 region), y2 *= gate in place
+  {
+    SeP se = p.se;
+    se.pooled = pooled; se.n_parts = 1; se.inv_cnt = 1.0f / (float)hw; se.C = C; se.gate_out = nullptr;
+    se_excite_lds<KS, 3, true, BNK_NW>(se, 0, nfr, nfr - 1, gtab, C, Bt);
+    const int cpr = C >> 3;
+    const IDiv dcpr(cpr);
+    for (int i = tid; i < npix * cpr; i += BNK_THR) {
+      int px, ck;
+      dcpr.divmod(i, px, ck);
+      const float* g = gtab + ((FPW > 1 && px >= hw) ? C : 0) + ck * 8;
+      bf16x8* ptr8 = reinterpret_cast<bf16x8*>(At + px * RS + ck * 16);
+      bf16x8 v = *ptr8;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (bf16_t)((float)v[e] * g0[e]);
+        v[4 + e] = (bf16_t)((float)v[4 + e] * g1[e]);
+      }
+      *ptr8 = v;
+    }
+  }
+  __syncthreads();
+  BN_STAMP(4);
+
+  // ---- P4: conv3 on the gated y2, + residual x, ReLU -> output rows in region B
+  {
+    bf16x8 (&wc)[KS] = wc3;
+    bf16x8 wn[KS];
+    for (int T = wv; T < NT; T += BNK_NW) {
+      if (T + BNK_NW < NT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = p.w3f[((long)(T + BNK_NW) * KS + ks) * 64 + lane];
+      }
+      const int ch0 = T * 16 + 4 * q;
+      const bool cok = ch0 < C;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 4 * CP + ch0), sh = *reinterpret_cast<const f32x4*>(bnv + 5 * CP + ch0);
+      bf16x4 rres[NPTM];                                 // residual: 4 channels of this lane's pixel, L2-hot
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) {
+        const int px = pt * 16 + pl;
+        rres[pt] = *reinterpret_cast<const bf16x4*>(xg + (long)((px < npix && cok) ? px : 0) * C + (cok ? ch0 : 0));
+      }
+      f32x4 acc[NPTM];
+      contract(wc, At, acc);
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[pt][r] * sc[r] + sh[r] + (float)rres[pt][r], 0.f);
+        unsigned char* dst = At + srowA[pt];
+        *reinterpret_cast<bf16x4*>((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) = o;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wc[ks] = wn[ks];
+    }
+  }
+  __syncthreads();
+  BN_STAMP(5);
+  // ---- P5: the output rows leave as whole 16-byte pieces (the frames of a workgroup are contiguous in memory)
+  {
+    const int cpr = C >> 3;
+    const IDiv dcpr(cpr);
+    bf16_t* og = p.out + (long)f0 * hw * C;
+    for (int i = tid; i < npix * cpr; i += BNK_THR) {
+      int px, ck;
+      dcpr.divmod(i, px, ck);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Bt + px * RS + ck * 16);
+      *reinterpret_cast<u32x4*>(og + (long)px * C + ck * 8) = v;
+      if (p.out2 && ck * 8 < p.n2) *reinterpret_cast<u32x4*>(p.out2 + ((long)f0 * hw + px) * p.n2 + ck * 8) = v;
+    }
+  }
+  BN_STAMP(6);
+}
+
+static size_t bneck_smem(int fpw, int hw, int C) {
+  const size_t RS = (size_t)bneck_rs(C);
+  return 2 * (size_t)fpw * hw * RS + 2 * RS + 64 + (size_t)2 * fpw * C * 4 + (size_t)6 * ((C + 15) / 16 * 16) * 4;
+}
+static int bneck_fpw(int hw) { return hw <= 64 ? 2 : 1; }
+
+static long long* g_bneck_dbg = nullptr;
+extern "C" int tdeed_bneck_set_debug(void* buf) { g_bneck_dbg = (long long*)buf; return TDEED_OK; }
+
+// 1 when (h, w, C, R) is served: 7 x 7 x 368 (two frames per workgroup) and 14 x 14 x 152 (one) are what it was built for
+extern "C" int tdeed_bneck_fits(int h, int w, int C, int R) {
+  const int hw = h * w, KS = (C + 31) / 32, fpw = bneck_fpw(hw);
+  if (h < 3 || w < 3 || C % 8 != 0 || R < 1 || R > 96 || C > 384) return 0;
+  if (!(KS == 5 || KS == 12)) return 0;
+  if ((C + 15) / 16 > 3 * BNK_NW) return 0;              // conv2 keeps the weights of at most 3 units per wave
+  if ((fpw * hw + 15) / 16 > (KS == 12 ? 7 : (fpw == 2 ? 8 : 13))) return 0;
+  if ((size_t)se_excite_scratch_bytes(C, R) > (size_t)fpw * hw * bneck_rs(C)) return 0;       // SE scratch lives in the y1 region
+  return bneck_smem(fpw, hw, C) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f,
+                               const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
+                               const void* se_w1f, const float* se_b1, const void* se_w2f, const float* se_b2, int R,
+                               const void* w3f, const float* s3, const float* h3, void* out, void* out2, int n2,
+                               void* stream) {
+  TD_CHECK(x && w1f && s1 && h1 && w2f && s2 && h2 && se_w1f && se_b1 && se_w2f && se_b2 && w3f && s3 && h3 && out,
+           "bneck: null pointer");
+  TD_CHECK(N > 0 && tdeed_bneck_fits(h, w, C, R), "bneck: geometry h=%d w=%d C=%d R=%d unsupported", h, w, C, R);
+  TD_CHECK(!G || (Fp % 8 == 0 && Fp > 0 && Fp <= C), "bneck: bad splice width %d", Fp);
+  TD_CHECK(!out2 || (n2 % 8 == 0 && n2 > 0 && n2 <= C), "bneck: bad second output width %d", n2);
+  BneckP p;
+  p.x = (const bf16_t*)x; p.G = (const bf16_t*)G; p.Fp = G ? Fp : 0;
+  p.w1f = (const bf16x8*)w1f; p.s1 = s1; p.h1 = h1;
+  p.w2f = (const bf16x8*)w2f; p.s2 = s2; p.h2 = h2;
+  p.se = SeP{};
+  p.se.R = R; p.se.w1f = (const bf16x8*)se_w1f; p.se.b1 = se_b1; p.se.w2f = (const bf16x8*)se_w2f; p.se.b2 = se_b2;
+  p.w3f = (const bf16x8*)w3f; p.s3 = s3; p.h3 = h3;
+  p.out = (bf16_t*)out; p.out2 = (bf16_t*)out2; p.n2 = out2 ? n2 : 0;
+  p.N = N; p.h = h; p.w = w; p.C = C;
+  p.dbg = g_bneck_dbg;
+  const int hw = h * w, fpw = bneck_fpw(hw), KS = (C + 31) / 32;
+  const size_t smem = bneck_smem(fpw, hw, C);
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)bneck_kernel<12, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 1, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { tdeed_set_error("bneck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  const int grid = (N + fpw - 1) / fpw;
+  if (KS == 12 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<12, 2, 7>), dim3(grid), dim3(BNK_THR), smem, st, p);
+  else if (KS == 5 && fpw == 1) hipLaunchKernelGGL((bneck_kernel<5, 1, 13>), dim3(grid), dim3(BNK_THR), smem, st, p);
+  else if (KS == 5 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<5, 2, 8>), dim3(grid), dim3(BNK_THR), smem, st, p);
+  else { tdeed_set_error("bneck: KS=%d with %d frames per workgroup", KS, fpw); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("bneck");
+  return TDEED_OK;
+}

@@ -26,8 +26,9 @@ __host__ __device__ inline int se_excite_scratch_bytes(int C, int R) {
 }
 
 // gates of frames [f_first, f_first + nf) (nf <= 16, frames beyond f_last clamp to it) -> gtab[f][ldg] (LDS, fp32).
-// All 256 threads of the workgroup call it; it ends with a barrier (gtab and scratch are then free to read / reuse).
-template <int KS1M, int KS2M, bool EARLY = true>
+// All NW * 64 threads of the workgroup call it; it ends with a barrier (gtab and scratch are then free to read / reuse).
+// se.pooled may point into LDS (generic address).
+template <int KS1M, int KS2M, bool EARLY = true, int NW = 4>
 __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int nf, long f_last, float* gtab, int ldg,
                                               unsigned char* scratch) {
   const int C = se.C, R = se.R;
@@ -47,7 +48,7 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
   }
   // ---- squeeze sums -> means -> hi / lo (pad columns and unused frame columns are zero)
   const int c4n = KS1 * 8;
-  for (int i = tid; i < 16 * c4n; i += 256) {
+  for (int i = tid; i < 16 * c4n; i += NW * 64) {
     const int f = i / c4n, c = (i - f * c4n) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (f < nf && c < C) {
@@ -67,10 +68,10 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
     *reinterpret_cast<bf16x4*>(Phi + f * PS1 + c) = hi;
     *reinterpret_cast<bf16x4*>(Plo + f * PS1 + c) = lo;
   }
-  for (int i = tid; i < 2 * 16 * PS2 / 8; i += 256) reinterpret_cast<u32x4*>(Hhi)[i] = (u32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < 2 * 16 * PS2 / 8; i += NW * 64) reinterpret_cast<u32x4*>(Hhi)[i] = (u32x4){0u, 0u, 0u, 0u};
   __syncthreads();
-  // ---- hidden units: tiles wv, wv + 4, ...
-  for (int tile = wv; tile < RT; tile += 4) {
+  // ---- hidden units: tiles wv, wv + NW, ...
+  for (int tile = wv; tile < RT; tile += NW) {
     if (!EARLY || tile != wv) {
 #pragma unroll
       for (int ks = 0; ks < KS1M; ++ks) w1r[ks] = se.w1f[((long)tile * KS1 + min(ks, KS1 - 1)) * 64 + lane];
@@ -94,8 +95,8 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
     }
   }
   __syncthreads();
-  // ---- gates: channel tiles wv, wv + 4, ...
-  for (int tile = wv; tile < CT; tile += 4) {
+  // ---- gates: channel tiles wv, wv + NW, ...
+  for (int tile = wv; tile < CT; tile += NW) {
     bf16x8 w2r[KS2M];
 #pragma unroll
     for (int ks = 0; ks < KS2M; ++ks) w2r[ks] = se.w2f[((long)tile * KS2 + min(ks, KS2 - 1)) * 64 + lane];

@@ -174,19 +174,23 @@ def pack_se_bf16(fc1_w, fc2_w, device):
     return dict(se_w1p=bf(p1), se_w2p=bf(w2.T))
 
 
+def pack_mfma_frags(W, device):
+    """A dense [N][K] weight as MFMA A-operand fragments [ceil(N/16)][ceil(K/32)][64][8] (bf16, zero padded; lane l holds row
+    l&15, k = 8*(l>>4)+j of the 16 x 32 tile)."""
+    W = _np(W).astype(np.float32)
+    W = W.reshape(W.shape[0], -1)
+    N, K = W.shape
+    NT, KS = (N + 15) // 16, (K + 31) // 32
+    Wp = np.zeros((NT * 16, KS * 32), np.float32)
+    Wp[:N, :K] = W
+    fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
+    return torch.from_numpy(np.ascontiguousarray(fr).reshape(NT, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
+
+
 def pack_se_mfma(fc1_w, fc2_w, device):
     """SE weights as MFMA A-operand fragments: fc1.weight [R][C] -> [ceil(R/16)][ceil(C/32)][64][8],
-    fc2.weight [C][R] -> [ceil(C/16)][ceil(R/32)][64][8] (bf16, zero padded; lane l holds row l&15, k = 8*(l>>4)+j)."""
-    def frag(W):
-        W = _np(W).astype(np.float32)
-        W = W.reshape(W.shape[0], -1)
-        N, K = W.shape
-        NT, KS = (N + 15) // 16, (K + 31) // 32
-        Wp = np.zeros((NT * 16, KS * 32), np.float32)
-        Wp[:N, :K] = W
-        fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
-        return torch.from_numpy(np.ascontiguousarray(fr).reshape(NT, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
-    return dict(w1f=frag(fc1_w), w2f=frag(fc2_w))
+    fc2.weight [C][R] -> [ceil(C/16)][ceil(R/32)][64][8] (pack_mfma_frags)."""
+    return dict(w1f=pack_mfma_frags(fc1_w, device), w2f=pack_mfma_frags(fc2_w, device))
 
 
 GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
@@ -434,6 +438,16 @@ def _se(pooled, inv_cnt, bw, gate):
 
 
 SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
+BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
+
+
+def _bneck_fused(bw, h, w, out_is_slice):
+    """True when the whole block runs as ONE launch (tdeed_bneck_fwd): bf16, stride 1, identity shortcut, a map small enough
+    for a workgroup's frames to stay in LDS (s3.b2-b4 and s4.b2-b7 of RegNetY-200MF), contiguous output."""
+    blk = bw.spec
+    return bool(BNECK_ONE_LAUNCH and getattr(bw, "fused", None) is not None and bw.se_mf is not None and blk.stride == 1
+                and not blk.has_downsample and blk.cin == blk.cout and not out_is_slice
+                and ops.bneck_fits(h, w, blk.cout, blk.se_rd))
 
 
 def _se_fused(bw, rows_per_frame, taps=()):
@@ -713,6 +727,11 @@ class PackedWeights:
                         if (bw.se_bf is not None and os.environ.get("TDEED_SE_MFMA", "1") == "1"
                             and ops.se_gate_mfma_fits(blk.cout, blk.se_rd)) else None)
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device, gated=True)
+            # MFMA-fragment copies of conv1 / conv3 for the one-launch bottleneck (stride-1 identity blocks up to 384 wide)
+            bw.fused = (SimpleNamespace(w1f=pack_mfma_frags(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), device),
+                                        w3f=pack_mfma_frags(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), device))
+                        if (bw.se_mf is not None and blk.stride == 1 and not blk.has_downsample and blk.cin == blk.cout
+                            and blk.cout <= 384) else None)
             bw.s3, bw.h3 = bn_fold(bp + ".conv3.bn")
             if blk.has_downsample:
                 bw.wd = DenseW(sd[bp + ".downsample.conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
@@ -814,8 +833,9 @@ class ForwardEngine:
         for bi, bw in enumerate(blocks):
             blk = bw.spec
             M = N * h * w
+            one_launch = _bneck_fused(bw, h, w, out_last is not None and bw is blocks[-1])
             # conv1 (optionally behind the gate-shift splice)
-            y1 = pool.take((N, h, w, blk.cout), dt)
+            y1 = None if one_launch else pool.take((N, h, w, blk.cout), dt)
             if blk.gsf_fold:
                 F = blk.gsf_fold
                 Fp = (F + 7) // 8 * 8
@@ -830,16 +850,42 @@ class ForwardEngine:
                 steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
                     bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
-                steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
-                    x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
-                    *gemm_cost(M, blk.cin, blk.cout, es)))
+                if not one_launch:
+                    steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
+                        x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
+                        *gemm_cost(M, blk.cin, blk.cout, es)))
                 if blk.name and ("_features." + blk.name + ".gs_out") in taps:
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
                 gs_bufs = list(gb.values()) + ([xs] if xs is not None else [])
             else:
-                steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
-                    x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
+                if not one_launch:
+                    steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
+                        x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
                 gs_bufs = []
+            if one_launch:
+                # conv1 (+ splice) -> conv2 -> SE -> conv3 + shortcut in one launch: only x and the output cross HBM
+                out = pool.take((N, h, w, blk.cout), dt)
+                nxt = blocks[bi + 1].spec if bi + 1 < len(blocks) else None
+                xs_next = (pool.take((N, h, w, (nxt.gsf_fold + 7) // 8 * 8), dt)
+                           if (nxt is not None and nxt.gsf_fold and GS_SLICE) else None)
+                G = gb["out"] if blk.gsf_fold else None
+                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, out=out, xs_next=xs_next: ops.bneck(
+                    x, bw.fused.w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
+                    bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out,
+                    out2=(xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None)),
+                    2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
+                    2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
+                for t_ in gs_bufs:
+                    pool.give(t_)
+                xs = xs_next
+                if not x_kept and hasattr(x, "_td_raw"):
+                    pool.give(x)
+                tapname = "_features." + blk.name
+                x_kept = tapname in taps
+                if x_kept:
+                    keep[tapname] = out
+                x = out
+                continue
             s = blk.stride
             h2, w2 = (h - 1) // s + 1, (w - 1) // s + 1
             M2 = N * h2 * w2

@@ -362,3 +362,61 @@ def test_sliced_weight_stationary_contraction_of_the_wide_layers(M, K, N, hw):
         assert torch.equal(d.run(A, sc, sh, ops.ACT_RELU, M=M), ops.gemm(A, Wd, sc, sh, ops.ACT_RELU))
     finally:
         engine.WS_WIDE_MIN_ROWS = old
+
+
+# ------------------------------------------------------------------------------------ whole bottleneck in one launch
+@pytest.mark.parametrize("h,w,C,gw,R,Fp,N", [(7, 7, 368, 8, 92, 96, 37), (14, 14, 152, 8, 38, 40, 5), (7, 7, 152, 8, 38, 0, 6),
+                                              (7, 7, 368, 16, 38, 0, 4), (5, 5, 368, 8, 92, 96, 3)])
+def test_one_launch_bottleneck_equals_the_launch_per_layer_chain(h, w, C, gw, R, Fp, N):
+    """tdeed_bneck_fwd (conv1 + gate-shift splice -> grouped 3x3 -> SE -> conv3 + shortcut, a workgroup's frames resident in
+    LDS) against the four launches it replaces on the same operands -- bitwise, including the compact second output -- and
+    against the block in torch fp32 (timm Bottleneck.forward with the splice of shift.py:89-93)."""
+    import torch.nn.functional as Fn
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma
+    assert ops.bneck_fits(h, w, C, R)
+    g = torch.Generator().manual_seed(h * 100 + C + R + Fp)
+    hw = h * w
+    M = N * hw
+    x = torch.relu(torch.randn(N, h, w, C, generator=g)).to(torch.bfloat16)
+    G = torch.randn(M, Fp, generator=g).to(torch.bfloat16) if Fp else None
+    W1 = torch.randn(C, C, generator=g) / C ** 0.5
+    W3 = torch.randn(C, C, generator=g) / C ** 0.5
+    W2 = torch.randn(C, gw, 3, 3, generator=g) / (gw * 9) ** 0.5
+    fc1 = torch.randn(R, C, generator=g) / C ** 0.5
+    fc2 = torch.randn(C, R, generator=g) / R ** 0.5
+    vec = lambda n, s=0.1, o=0.0: (torch.randn(n, generator=g) * s + o).to(DEV)          # noqa: E731
+    s1, h1, s2, h2, s3, h3 = vec(C, 0.1, 1.0), vec(C), vec(C, 0.1, 1.0), vec(C), vec(C, 0.1, 0.5), vec(C)
+    b1, b2 = vec(R), vec(C)
+    bf = lambda t: t.to(torch.bfloat16)                                                     # noqa: E731
+    W1d, W3d = bf(W1).to(DEV), bf(W3).to(DEV)
+    w2f = pack_gconv_frags(W2.numpy(), gw, DEV)
+    se = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
+    xd, Gd = x.to(DEV), (G.to(DEV) if Fp else None)
+    # the chain
+    y1 = ops.gemm(xd.view(M, C), W1d, s1, h1, ops.ACT_RELU, **(dict(A0=Gd, k0=Fp) if Fp else {}))
+    y2, pooled = ops.gconv3x3(y1.view(N, h, w, C), None, s2, h2, gw, 1, wfrag=w2f)
+    gate = ops.se_gate_mfma(pooled, 1.0 / hw, se["w1f"], b1, se["w2f"], b2, R)
+    n2 = 48
+    ref2 = torch.empty((M, n2), dtype=torch.bfloat16, device=DEV)
+    ref = ops.gemm(y2.view(M, C), W3d, s3, h3, ops.ACT_RELU, residual=xd.view(M, C), a_scale=gate, a_scale_rows=hw, out2=ref2)
+    # one launch
+    out2 = torch.empty_like(ref2)
+    out = ops.bneck(xd, pack_mfma_frags(W1.numpy(), DEV), s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R,
+                    pack_mfma_frags(W3.numpy(), DEV), s3, h3, G=Gd, out2=out2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out.view(M, C), ref), float((out.view(M, C).float() - ref.float()).abs().max())
+    assert torch.equal(out2, ref2)
+    # torch fp32 on the bf16-rounded weights
+    xin = x.float().view(M, C).clone()
+    if Fp:
+        xin[:, :Fp] = G.float()
+    t1 = torch.relu(xin @ bf(W1).float().t() * s1.cpu() + h1.cpu()).to(torch.bfloat16).float()
+    t2 = Fn.conv2d(t1.view(N, h, w, C).permute(0, 3, 1, 2), bf(W2).float(), None, 1, 1, 1, C // gw)
+    t2 = torch.relu(t2 * s2.cpu()[None, :, None, None] + h2.cpu()[None, :, None, None]).to(torch.bfloat16).float()
+    gt = torch.sigmoid(torch.relu(t2.mean((2, 3)) @ bf(fc1).float().t() + b1.cpu()) @ bf(fc2).float().t() + b2.cpu())
+    t3 = (t2 * gt[:, :, None, None]).permute(0, 2, 3, 1).reshape(M, C).to(torch.bfloat16).float()
+    want = torch.relu(t3 @ bf(W3).float().t() * s3.cpu() + h3.cpu() + x.float().view(M, C))
+    err = (out.view(M, C).float().cpu() - want).abs().max() / want.abs().max()
+    assert float(err) < 2e-2, float(err)

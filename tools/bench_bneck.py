@@ -1,0 +1,77 @@
+"""GPU micro-benchmark: a stride-1 bottleneck as one launch (tdeed_bneck_fwd) against the four launches it replaces (conv1 ->
+grouped 3x3 -> SE -> conv3), at the sub-batch sizes of cfg2 (400 frames), with the kernel's phase time stamps.
+    python tools/bench_bneck.py [frames]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tdeed_amd import ops, _lib
+from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+DEV = "cuda"
+
+
+def timeit(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
+    g = torch.Generator().manual_seed(1)
+    hw, M = h * w, N * h * w
+    x = torch.relu(torch.randn(N, h, w, C, generator=g)).to(torch.bfloat16).to(DEV)
+    G = torch.randn(M, Fp, generator=g).to(torch.bfloat16).to(DEV)
+    W1, W3 = torch.randn(C, C, generator=g) / C ** 0.5, torch.randn(C, C, generator=g) / C ** 0.5
+    W2 = torch.randn(C, gw, 3, 3, generator=g) / (gw * 9) ** 0.5
+    fc1, fc2 = torch.randn(R, C, generator=g) / C ** 0.5, torch.randn(C, R, generator=g) / R ** 0.5
+    vec = lambda n, s=0.1, o=0.0: (torch.randn(n, generator=g) * s + o).to(DEV)      # noqa: E731
+    s1, h1, s2, h2, s3, h3, b1, b2 = vec(C, .1, 1.), vec(C), vec(C, .1, 1.), vec(C), vec(C, .1, .5), vec(C), vec(R), vec(C)
+    W1d, W3d = W1.to(torch.bfloat16).to(DEV), W3.to(torch.bfloat16).to(DEV)
+    w1f, w3f = pack_mfma_frags(W1.numpy(), DEV), pack_mfma_frags(W3.numpy(), DEV)
+    w2f = pack_gconv_frags(W2.numpy(), gw, DEV)
+    se = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
+    y1 = torch.empty((M, C), dtype=torch.bfloat16, device=DEV)
+    y2 = torch.empty((N, h, w, C), dtype=torch.bfloat16, device=DEV)
+    parts = ops.gconv3x3_parts(h, w, C, 1, torch.bfloat16)
+    pooled = torch.empty((N, parts, C), device=DEV)
+    gate = torch.empty((N, C), device=DEV)
+    out = torch.empty((M, C), dtype=torch.bfloat16, device=DEV)
+    out2 = torch.empty((M, 96), dtype=torch.bfloat16, device=DEV)
+    outb = torch.empty((N, h, w, C), dtype=torch.bfloat16, device=DEV)
+
+    def chain():
+        ops.gemm(x.view(M, C), W1d, s1, h1, ops.ACT_RELU, A0=G, k0=Fp, out=y1)
+        ops.gconv3x3(y1.view(N, h, w, C), None, s2, h2, gw, 1, wfrag=w2f, out=y2, pooled=pooled)
+        ops.se_gate_mfma(pooled, 1.0 / hw, se["w1f"], b1, se["w2f"], b2, R, out=gate)
+        ops.gemm(y2.view(M, C), W3d, s3, h3, ops.ACT_RELU, residual=x.view(M, C), a_scale=gate, a_scale_rows=hw, out=out,
+                 out2=out2)
+
+    def fused():
+        ops.bneck(x, w1f, s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R, w3f, s3, h3, G=G, out=outb, out2=out2)
+
+    t0, t1 = timeit(chain), timeit(fused)
+    chain(); ref = out.clone(); fused(); torch.cuda.synchronize()
+    print(f"{h}x{w}x{C} N={N}: chain {t0:7.1f} us   one launch {t1:7.1f} us   equal {torch.equal(ref, outb.view(M, C))}", flush=True)
+    nwg = (N + (1 if hw > 64 else 2) - 1) // (1 if hw > 64 else 2)
+    dbg = torch.zeros((nwg, 16), dtype=torch.int64, device=DEV)
+    _lib.call("tdeed_bneck_set_debug", dbg.data_ptr())
+    fused(); torch.cuda.synchronize()
+    _lib.call("tdeed_bneck_set_debug", None)
+    d = dbg.cpu().numpy().astype(np.float64)
+    sub = [np.median(d[:, 8] - d[:, 2])] + [np.median(d[:, 9 + j] - d[:, 8 + j]) for j in range(3)]
+    print("   conv2 of wave 0, cycles: tap offsets + weight requests %.0f, units %s" % (sub[0], ", ".join("%.0f" % v for v in sub[1:])))
+    ph = np.diff(d[:, :7], axis=1) / 100.0          # clock64 ticks (shader clock, ~2.4 GHz) / 100
+    names = ["load x", "conv1", "conv2", "SE + gate", "conv3", "store"]
+    print("   phase cycles / 100 (median over workgroups): " + ", ".join(f"{n} {np.median(ph[:, i]):.2f}" for i, n in enumerate(names))
+          + f"; workgroup total {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}; first start -> last end "
+          f"{(d[:, 6].max() - d[:, 0].min()) / 100.0:.2f}", flush=True)
