@@ -133,18 +133,32 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     srowA[pt] = px < npix ? px * RS : (int)(Tr - At);
   }
   const int dAB = (int)(Bt - At);
-  // one 16-channel tile of a 1x1 conv: acc[pt] = sum_ks W[ks] . act[pixel tile pt][ks]
+  // one 16-channel tile of a 1x1 conv: acc[pt] = sum_ks W[ks] . act[pixel tile pt][ks].  The pixel tiles go in two halves:
+  // the LDS reads of one half are issued before the MFMAs of the other (sched_barrier pins that order), so a wave's reads
+  // travel under its own MFMAs instead of in front of them
+  constexpr int HA = (NPTM + 1) / 2;
   auto contract = [&](const bf16x8 (&wc)[KS], const unsigned char* act, f32x4 (&acc)[NPTM]) {
 #pragma unroll
     for (int pt = 0; pt < NPTM; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[NPTM];
+    const int kq = 16 * q;
+#pragma unroll
+    for (int pt = 0; pt < HA; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kq);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int kb = (32 * ks + 8 * q) * 2;
-      bf16x8 a[NPTM];                                  // every tile, always (rows beyond npix read row 0): no branches
+      const int kb = 64 * ks + kq;
 #pragma unroll
-      for (int pt = 0; pt < NPTM; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb);
+      for (int pt = HA; pt < NPTM; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb);
 #pragma unroll
-      for (int pt = 0; pt < NPTM; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks], a[pt], acc[pt], 0, 0, 0);
+      for (int pt = 0; pt < HA; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks], a[pt], acc[pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int pt = 0; pt < HA; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb + 64);
+      }
+#pragma unroll
+      for (int pt = HA; pt < NPTM; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks], a[pt], acc[pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -236,28 +250,45 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       for (int f = 0; f < FPW; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) psum[f][r] = 0.f;
+      // k-step outer, pixel tile inner: NPTM independent accumulators (a tile-at-a-time loop is five dependent MFMAs)
+      f32x4 acc[NPTM];
+#pragma unroll
+      for (int pt = 0; pt < NPTM; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      {
+        bf16x8 yf[NPTM];
+        const unsigned char* bu = Bt + U * 32;
+#pragma unroll
+        for (int pt = 0; pt < HA; ++pt) yf[pt] = *reinterpret_cast<const bf16x8*>(bu + toff[pt][0]);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+#pragma unroll
+          for (int pt = HA; pt < NPTM; ++pt) yf[pt] = *reinterpret_cast<const bf16x8*>(bu + toff[pt][ks]);
+#pragma unroll
+          for (int pt = 0; pt < HA; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yf[pt], acc[pt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < 5) {
+#pragma unroll
+            for (int pt = 0; pt < HA; ++pt) yf[pt] = *reinterpret_cast<const bf16x8*>(bu + toff[pt][ks + 1]);
+          }
+#pragma unroll
+          for (int pt = HA; pt < NPTM; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yf[pt], acc[pt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int pt = 0; pt < NPTM; ++pt) {
-        {
-          const int px = pt * 16 + pl;
-          const bool pok = px < npix;
-          bf16x8 yf[5];
+        const int px = pt * 16 + pl;
+        const bool pok = px < npix;
+        bf16x4 o;
 #pragma unroll
-          for (int ks = 0; ks < 5; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(Bt + toff[pt][ks] + U * 32);
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[pt][r] * sc[r] + sh[r], 0.f);
+        *reinterpret_cast<bf16x4*>(At + srowA[pt] + ch0 * 2) = o;
+        const bool second = FPW > 1 && px >= hw;
 #pragma unroll
-          for (int ks = 0; ks < 5; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yf[ks], acc, 0, 0, 0);
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[r] * sc[r] + sh[r], 0.f);
-          *reinterpret_cast<bf16x4*>(At + srowA[pt] + ch0 * 2) = o;
-          const bool second = FPW > 1 && px >= hw;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = pok ? (float)o[r] : 0.f;
-            if (FPW > 1) psum[FPW - 1][r] += second ? v : 0.f;
-            psum[0][r] += second ? 0.f : v;
-          }
+        for (int r = 0; r < 4; ++r) {
+          const float v = pok ? (float)o[r] : 0.f;
+          if (FPW > 1) psum[FPW - 1][r] += second ? v : 0.f;
+          psum[0][r] += second ? 0.f : v;
         }
       }
 #pragma unroll

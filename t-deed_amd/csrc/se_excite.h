@@ -46,6 +46,29 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
 #pragma unroll
     for (int ks = 0; ks < KS1M; ++ks) w1r[ks] = se.w1f[((long)tc * KS1 + min(ks, KS1 - 1)) * 64 + lane];
   }
+  // fc2 fragments of ALL this wave's channel tiles, requested now as well (EARLY): the gate phase otherwise walks its tiles
+  // through one L2 round trip each
+  constexpr int MAXT2 = (24 + NW - 1) / NW;             // C <= 384: at most 24 channel tiles
+  bf16x8 w2r[EARLY ? MAXT2 : 1][KS2M];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int j = 0; j < MAXT2; ++j) {
+      const int tc = min(wv + j * NW, CT - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS2M; ++ks) w2r[j][ks] = se.w2f[((long)tc * KS2 + min(ks, KS2 - 1)) * 64 + lane];
+    }
+  }
+  // ... and the biases of this lane's rows (a load behind the MFMAs would be one more exposed round trip per tile)
+  constexpr int MAXT1 = (6 + NW - 1) / NW;               // R <= 96: at most 6 hidden tiles
+  float b1v[MAXT1][4], b2v[MAXT2][4];
+#pragma unroll
+  for (int j = 0; j < MAXT1; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b1v[j][e] = se.b1[min((wv + j * NW) * 16 + 4 * q + e, R - 1)];
+#pragma unroll
+  for (int j = 0; j < MAXT2; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b2v[j][e] = se.b2[min((wv + j * NW) * 16 + 4 * q + e, C - 1)];
   // ---- squeeze sums -> means -> hi / lo (pad columns and unused frame columns are zero)
   const int c4n = KS1 * 8;
   for (int i = tid; i < 16 * c4n; i += NW * 64) {
@@ -71,7 +94,10 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
   for (int i = tid; i < 2 * 16 * PS2 / 8; i += NW * 64) reinterpret_cast<u32x4*>(Hhi)[i] = (u32x4){0u, 0u, 0u, 0u};
   __syncthreads();
   // ---- hidden units: tiles wv, wv + NW, ...
-  for (int tile = wv; tile < RT; tile += NW) {
+#pragma unroll
+  for (int j1 = 0; j1 < MAXT1; ++j1) {
+    const int tile = wv + j1 * NW;
+    if (tile >= RT) break;
     if (!EARLY || tile != wv) {
 #pragma unroll
       for (int ks = 0; ks < KS1M; ++ks) w1r[ks] = se.w1f[((long)tile * KS1 + min(ks, KS1 - 1)) * 64 + lane];
@@ -88,7 +114,7 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int r = tile * 16 + 4 * q + e;
-      const float hv = r < R ? fmaxf(acc[e] + se.b1[min(r, R - 1)], 0.f) : 0.f;
+      const float hv = r < R ? fmaxf(acc[e] + b1v[j1][e], 0.f) : 0.f;
       const bf16_t hi = (bf16_t)hv;
       Hhi[pl * PS2 + r] = hi;
       Hlo[pl * PS2 + r] = (bf16_t)(hv - (float)hi);
@@ -96,24 +122,30 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
   }
   __syncthreads();
   // ---- gates: channel tiles wv, wv + NW, ...
-  for (int tile = wv; tile < CT; tile += NW) {
-    bf16x8 w2r[KS2M];
 #pragma unroll
-    for (int ks = 0; ks < KS2M; ++ks) w2r[ks] = se.w2f[((long)tile * KS2 + min(ks, KS2 - 1)) * 64 + lane];
+  for (int j = 0; j < MAXT2; ++j) {
+    const int tile = wv + j * NW;
+    if (tile >= CT) break;
+    bf16x8 wt[KS2M];
+#pragma unroll
+    for (int ks = 0; ks < KS2M; ++ks) {
+      if constexpr (EARLY) wt[ks] = w2r[j][ks];
+      else wt[ks] = se.w2f[((long)tile * KS2 + min(ks, KS2 - 1)) * 64 + lane];
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS2M; ++ks)
       if (ks < KS2) {
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Hhi + pl * PS2 + ks * 32 + q * 8);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Hlo + pl * PS2 + ks * 32 + q * 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2r[ks], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2r[ks], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], bl, acc, 0, 0, 0);
       }
     const int c0 = tile * 16 + 4 * q;
     if (c0 < C && pl < nf) {
       f32x4 g;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + se.b2[min(c0 + e, C - 1)]);
+      for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + b2v[j][e]);
       *reinterpret_cast<f32x4*>(gtab + pl * ldg + c0) = g;
       if (se.gate_out && f_first + pl <= f_last) *reinterpret_cast<f32x4*>(se.gate_out + (f_first + pl) * (long)C + c0) = g;
     }
