@@ -439,6 +439,10 @@ def _se(pooled, inv_cnt, bw, gate):
 
 SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
+# one graph per sub-batch stream (joined by events) instead of a fork inside one graph: opt-in.  A graph of trivial kernels
+# replays 4x faster per node that way (tools/bench_dispatch.py), the forward does not: 3670 vs 3696 clips/s with 4 hardware
+# queues, 2900 with 8 (more queues than the command processor keeps resident are time-multiplexed)
+GRAPH_SPLIT = os.environ.get("TDEED_GRAPH_SPLIT", "0") == "1"
 
 
 def _bneck_fused(bw, h, w, out_is_slice):
@@ -1140,39 +1144,80 @@ class ForwardEngine:
             for s_ in plan.tail.steps:
                 s_.fn()
 
+    def _capture(self, st, fn):
+        """Capture what fn() launches on stream `st` into a graph executable (fn has run once already: modules loaded,
+        arguments validated)."""
+        import ctypes
+        import gc
+        # no cyclic garbage collection between begin and end of the capture: the finaliser of an engine that an earlier
+        # caller dropped would otherwise run here at a random allocation and call into the HIP runtime (graph
+        # destruction, frees) from the capturing thread -- the graph launched afterwards then crashed the host
+        global _CAPTURING
+        gc_was = gc.isenabled()
+        gc.disable()
+        _CAPTURING += 1
+        _lib.call("tdeed_graph_begin", st.cuda_stream)
+        try:
+            fn()
+        finally:
+            h = ctypes.c_void_p()
+            try:
+                _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
+            finally:
+                _CAPTURING -= 1
+                if gc_was:
+                    gc.enable()
+        return h
+
+    def _run_split(self, plan, st):
+        """Several sub-batches as SEPARATE single-chain graphs, one per stream, joined by events in front of the tail's graph.
+        A fork INSIDE one graph replays at ~3.7 us per TRIVIAL kernel node over both branches together
+        (tools/bench_dispatch.py: 256 nodes on two branches 960 us per replay), two single-chain graphs on two streams at 0.9 us
+        per node in aggregate.  With real kernels the dispatch hides behind the other stream's execution: measured a tie with
+        four hardware queues and a loss with eight, so this path is opt-in (TDEED_GRAPH_SPLIT=1)."""
+        streams = [st if (s_ is None or s_.cuda_stream == st.cuda_stream) else s_ for s_ in plan.streams]
+        if plan.graph is None:
+            _drain_dead_graphs()
+            self._launch_all(plan, st)         # warm-up launch (module load, validates arguments)
+            st.synchronize()
+            gs = []
+            for sb, s_ in zip(plan.subs, streams):
+                s_.synchronize()
+                with torch.cuda.stream(s_):
+                    gs.append(self._capture(s_, lambda sb=sb: [x.fn() for x in sb.steps]))
+            gt = self._capture(st, lambda: [x.fn() for x in plan.tail.steps]) if plan.tail is not None else None
+            plan.graph = SimpleNamespace(subs=gs, tail=gt, fork=torch.cuda.Event(),
+                                         joins=[torch.cuda.Event() for _ in streams])
+        g = plan.graph
+        g.fork.record(st)
+        for i, s_ in enumerate(streams):
+            if s_.cuda_stream != st.cuda_stream:
+                s_.wait_event(g.fork)
+            _lib.call("tdeed_graph_launch", g.subs[i], s_.cuda_stream)
+            if s_.cuda_stream != st.cuda_stream:
+                g.joins[i].record(s_)
+        for i, s_ in enumerate(streams):
+            if s_.cuda_stream != st.cuda_stream:
+                st.wait_event(g.joins[i])
+        if g.tail is not None:
+            _lib.call("tdeed_graph_launch", g.tail, st.cuda_stream)
+
     def run_plan(self, plan):
-        """Launch the plan on the current stream (eager) or replay its HIP graph."""
+        """Launch the plan on the current stream (eager) or replay its HIP graph(s)."""
         st = torch.cuda.current_stream()
         if not self.use_graph:
             self._launch_all(plan, st)
             return
         if st.cuda_stream == 0:
             raise RuntimeError("graph replay needs a non-default stream: wrap the call in torch.cuda.stream(s)")
+        if len(plan.subs) > 1 and GRAPH_SPLIT:
+            self._run_split(plan, st)
+            return
         if plan.graph is None:
             _drain_dead_graphs()
             self._launch_all(plan, st)         # warm-up launch (module load, validates arguments)
             st.synchronize()
-            import ctypes
-            import gc
-            # no cyclic garbage collection between begin and end of the capture: the finaliser of an engine that an earlier
-            # caller dropped would otherwise run here at a random allocation and call into the HIP runtime (graph
-            # destruction, frees) from the capturing thread -- the graph launched afterwards then crashed the host
-            global _CAPTURING
-            gc_was = gc.isenabled()
-            gc.disable()
-            _CAPTURING += 1
-            _lib.call("tdeed_graph_begin", st.cuda_stream)
-            try:
-                self._launch_all(plan, st)     # forked streams join the capture through the fork event
-            finally:
-                h = ctypes.c_void_p()
-                try:
-                    _lib.call("tdeed_graph_end", st.cuda_stream, ctypes.byref(h))
-                finally:
-                    _CAPTURING -= 1
-                    if gc_was:
-                        gc.enable()
-            plan.graph = h
+            plan.graph = self._capture(st, lambda: self._launch_all(plan, st))   # forked streams join through the fork event
         _lib.call("tdeed_graph_launch", plan.graph, st.cuda_stream)
 
     def forward(self, frames_u8, augment_inference=False, taps=(), slot=0):
@@ -1223,7 +1268,10 @@ class ForwardEngine:
         try:
             for p in self._plans.values():
                 if p.graph is not None:
-                    _DEAD_GRAPHS.append(p.graph)
+                    if isinstance(p.graph, SimpleNamespace):
+                        _DEAD_GRAPHS.extend([g_ for g_ in list(p.graph.subs) + [p.graph.tail] if g_ is not None])
+                    else:
+                        _DEAD_GRAPHS.append(p.graph)
                     p.graph = None
         except Exception:
             pass
