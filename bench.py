@@ -493,7 +493,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pmc-pass", action="store_true",
                     help="only the timed steps (for rocprofv3 --pmc counter passes: eager launches, no side measurements)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--split", type=int, default=1,
+                    help="sub-batches of whole clips per batch, each on its own stream inside the batch's HIP graph (1: none; "
+                         "2 gives the shortest single-batch latency, 1 with three batches in flight the highest throughput)")
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight: consecutive steps alternate between this many independent buffer sets / HIP "
                          "graphs on their own streams, so the latency-bound tail of one batch overlaps the next one's "
                          "head (every step still runs the full forward on its own batch of B clips)")
@@ -513,7 +516,7 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(depth)]
     stream = streams[0]
     with torch.cuda.stream(stream):
-        eng = ForwardEngine(cfg, sd, dt, dev, use_graph=not a.no_graph)
+        eng = ForwardEngine(cfg, sd, dt, dev, use_graph=not a.no_graph, n_split=a.split)
         T = cfg["clip_len"]
         plans = [eng.plan(B, H, W, slot=i) for i in range(depth)]
         plan = plans[0]
@@ -623,7 +626,7 @@ def main():
         gbs = d["bytes"] / max(d["launches"], 1) / per_launch_s / 1e9
         tfs = d["flops"] / max(d["launches"], 1) / per_launch_s / 1e12
         # bound: whichever roof the kernel's algorithmic intensity puts it under
-        mfma_bound = name.startswith("gemm") and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
+        mfma_bound = name.startswith(("gemm", "bneck")) and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
         roof = dict(kernel=name, bound="mfma" if mfma_bound else "hbm",
                     achieved=round(tfs if mfma_bound else gbs, 2), peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
@@ -675,7 +678,8 @@ def main():
                    config=dict(workload=f"{a.workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']} "
                                         f"ks={cfg['sgp_ks']}, L={T}, {H}x{W}, batch {B}/GPU, inference forward, "
                                         "random-init weights", clips_per_gpu=B, parallelism=f"dp{world} (clip-sharded, no collective)",
-                               hip_graph=not a.no_graph, batches_in_flight=depth),
+                               hip_graph=not a.no_graph, batches_in_flight=depth,
+                               sub_batches_per_batch=len(plan.subs)),
                    repeats=a.repeats, ms_per_step_repeats=[round(w / a.steps * 1e3, 4) for w in walls],
                    ms_per_step_hip_events=round(statistics.median(evs) / a.steps, 4),
                    latency_ms_inflight1=round(statistics.median(lat), 4),

@@ -151,11 +151,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("TDEED_LIB_FLAVOUR", "release") == "debug":
+        # the asserting build (csrc/common.h TD_DEV_ASSERT): `python t-deed_amd/build.py --debug`
+        path = LIB_PATH.replace("libtdeed_hip.so", "libtdeed_hip_dbg.so")
+    if not os.path.exists(path):
         raise HipLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950).  tdeed_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950; the debug flavour with `python t-deed_amd/build.py --debug`).  "
+            "tdeed_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
     for name, (args, res) in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args

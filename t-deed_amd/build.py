@@ -33,17 +33,27 @@ def _stale(obj, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+DEBUG_FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-DTDEED_DEBUG=1", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall",
+               "-Wno-unused-function"]
+LIB_DEBUG = os.path.join(CSRC, "libtdeed_hip_dbg.so")
+
+
+def build(force=False, verbose=True, flavour="release", only=None):
+    """flavour "debug": -O1 -g -DTDEED_DEBUG=1 (device asserts on LDS offsets and table indices, common.h) into
+    csrc/libtdeed_hip_dbg.so; loaded instead of the release library when TDEED_LIB_FLAVOUR=debug.  only: compile just these
+    sources and do not link (a quick does-it-compile check)."""
+    debug = flavour == "debug"
+    flags, lib, osuf = (DEBUG_FLAGS, LIB_DEBUG, ".dbg.o") if debug else (FLAGS, LIB, ".o")
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "sgp_tile.h"), os.path.join(CSRC, "se_excite.h"),
             os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "tdeed_hip.h")]
     jobs = []
     objs = []
-    for s in SOURCES:
+    for s in (only or SOURCES):
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", osuf))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
+            jobs.append([_hipcc(), *flags, *([] if debug else EXTRA.get(s, [])), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -55,10 +65,12 @@ def build(force=False, verbose=True):
             print(r.stderr, file=sys.stderr)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
-    return LIB
+    if only:
+        return objs
+    if jobs or not os.path.exists(lib):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, flavour="debug" if "--debug" in sys.argv else "release"))

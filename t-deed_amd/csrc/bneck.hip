@@ -34,6 +34,11 @@ constexpr int BNK_NW = 8, BNK_THR = BNK_NW * 64;
 // per read against 7.7 with a plain 16-byte skew (C = 368: stride 736, no pad at all; C = 152: 352)
 __host__ __device__ inline int bneck_rs(int C) { return C * 2 + ((96 - (C * 2) % 128) + 128) % 128; }
 
+__host__ __device__ static inline size_t bneck_smem(int fpw, int hw, int C) {
+  const size_t RS = (size_t)bneck_rs(C);
+  return 2 * (size_t)fpw * hw * RS + 2 * RS + 64 + (size_t)2 * fpw * C * 4 + (size_t)6 * ((C + 15) / 16 * 16) * 4;
+}
+
 // sum over each row of 16 lanes (the 16 pixels of an MFMA tile), every lane gets it: DPP moves, the pairing of a
 // shuffle-xor butterfly (bit-identical to it), none of its four LDS crossbar round trips
 __device__ __forceinline__ float bnk_row16_sum(float v) {
@@ -65,6 +70,9 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pl = lane & 15, q = lane >> 4;
   const bf16_t* xg = p.x + (long)f0 * hw * C;
+  [[maybe_unused]] const long lds_bytes = (long)bneck_smem(FPW, hw, C);     // what the launch asked for (debug flavour checks)
+  TD_DEV_ASSERT(nfr >= 1 && (npix + 15) / 16 <= NPTM && (C + 31) / 32 == KS);
+  TD_LDS_CHECK((unsigned char*)(bnv + 6 * CP) - smem, 0, lds_bytes);
 
   // The first channel tile's weights of each contraction are requested one phase early (conv1's before the frames are
   // loaded, conv2's before conv1 runs, conv3's before the SE phase): a phase otherwise opens with a bare L2 round trip.
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
         if (i < total) {
           int px, ck;
           dcpr.divmod(i, px, ck);
+          TD_LDS_CHECK(px * RS + ck * 16, 16, FPW * hw * RS);
           *reinterpret_cast<u32x4*>(At + px * RS + ck * 16) = v[b];
         }
       }
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[pt][r] * sc[r] + sh[r], 0.f);
         unsigned char* dst = At + srowA[pt];
+        TD_LDS_CHECK(((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) - smem, 8, (Tr + RS) - smem);
         *reinterpret_cast<bf16x4*>((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) = o;
       }
 #pragma unroll
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
         for (int ks = 0; ks < 5; ++ks) {
           const bool ok = sok[ks] && (unsigned)(oy + dyv[ks]) < (unsigned)p.h && (unsigned)(ox + dxv[ks]) < (unsigned)p.w;
           toff[pt][ks] = ok ? px * RS + doff[ks] : zoff;
+          TD_LDS_CHECK((Bt - smem) + toff[pt][ks] + (NT - 1) * 32, 16, lds_bytes);
         }
       }
     }
@@ -386,10 +397,6 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   BN_STAMP(6);
 }
 
-static size_t bneck_smem(int fpw, int hw, int C) {
-  const size_t RS = (size_t)bneck_rs(C);
-  return 2 * (size_t)fpw * hw * RS + 2 * RS + 64 + (size_t)2 * fpw * C * 4 + (size_t)6 * ((C + 15) / 16 * 16) * 4;
-}
 static int bneck_fpw(int hw) { return hw <= 64 ? 2 : 1; }
 
 static long long* g_bneck_dbg = nullptr;

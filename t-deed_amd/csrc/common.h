@@ -33,6 +33,26 @@ void tdeed_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// --------------------------------------------------------------------------- debug flavour (python t-deed_amd/build.py --debug)
+// TD_DEV_ASSERT / TD_LDS_CHECK compile to nothing in the release library.  The debug library (-O1 -g -DTDEED_DEBUG=1,
+// csrc/libtdeed_hip_dbg.so, loaded with TDEED_LIB_FLAVOUR=debug) traps the wave at the first violated condition: LDS
+// offsets against the bytes the launch asked for, tile / frame indices against their tables (the reference
+// has no race / bounds tooling of its own; GPU AddressSanitizer is not available on this pool).
+#if defined(TDEED_DEBUG) && TDEED_DEBUG
+#define TD_DEV_ASSERT(cond)                                                                              \
+  do {                                                                                                   \
+    if (!(cond)) {                                                                                       \
+      printf("tdeed device assert %s:%d: %s (block %d thread %d)\n", __FILE__, __LINE__, #cond, (int)blockIdx.x, \
+             (int)threadIdx.x);                                                                          \
+      __builtin_trap();                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#else
+#define TD_DEV_ASSERT(cond) do { } while (0)
+#endif
+// byte offset `off` (+ `len` bytes) inside a dynamic LDS allocation of `limit` bytes
+#define TD_LDS_CHECK(off, len, limit) TD_DEV_ASSERT((long)(off) >= 0 && (long)(off) + (long)(len) <= (long)(limit))
+
 // --------------------------------------------------------------------------- element access (T = float | bf16_t)
 template <typename T> struct Elem;
 template <> struct Elem<float> {

@@ -543,6 +543,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ws_kernel(const
     if (WLDS) {
       frag_t* wdst = reinterpret_cast<frag_t*>(smem);
       const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf) + (size_t)nt0 * KS * 64;
+      TD_DEV_ASSERT(nts <= p.NTS && nt0 + nts <= p.NT);
       for (int i = tid; i < nts * KS * 64; i += NTHR) wdst[i] = src[i];
     }
     for (int i = tid; i < nts * 16; i += NTHR) {

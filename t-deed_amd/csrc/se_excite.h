@@ -88,6 +88,7 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
       hi[e] = (bf16_t)m;
       lo[e] = (bf16_t)(m - (float)hi[e]);
     }
+    TD_LDS_CHECK((f * PS1 + c) * 2, 8, 16 * PS1 * 2);
     *reinterpret_cast<bf16x4*>(Phi + f * PS1 + c) = hi;
     *reinterpret_cast<bf16x4*>(Plo + f * PS1 + c) = lo;
   }
@@ -146,6 +147,7 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
       f32x4 g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + b2v[j][e]);
+      TD_DEV_ASSERT(pl < 16 && c0 + 4 <= ldg);
       *reinterpret_cast<f32x4*>(gtab + pl * ldg + c0) = g;
       if (se.gate_out && f_first + pl <= f_last) *reinterpret_cast<f32x4*>(se.gate_out + (f_first + pl) * (long)C + c0) = g;
     }

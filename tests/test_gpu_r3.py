@@ -420,3 +420,45 @@ def test_one_launch_bottleneck_equals_the_launch_per_layer_chain(h, w, C, gw, R,
     want = torch.relu(t3 @ bf(W3).float().t() * s3.cpu() + h3.cpu() + x.float().view(M, C))
     err = (out.view(M, C).float().cpu() - want).abs().max() / want.abs().max()
     assert float(err) < 2e-2, float(err)
+
+
+def test_debug_flavour_runs_the_hot_path_without_a_trap():
+    """The asserting build (TDEED_LIB_FLAVOUR=debug: LDS offsets and table indices checked on the device) runs a small
+    forward through the one-launch bottleneck, the SGP stage and the heads in a child process, and agrees with the release
+    library on the logits."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_tdeed_build_dbg", os.path.join(root, "t-deed_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(flavour="debug", verbose=False)
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import tdeed_amd\n"
+        "from tdeed_amd import synth, state_layout, _lib\n"
+        "from tdeed_amd.engine import ForwardEngine\n"
+        "assert _lib.load()._name.endswith(sys.argv[1]), _lib.load()._name\n"
+        "cfg = dict(feature_arch='rny002_gsf', clip_len=8, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3, radi_displacement=2)\n"
+        "sd = synth.make_state(state_layout.model_state_shapes(cfg), 0)\n"
+        "clip = torch.from_numpy(synth.uint8_clip(5, (2, 8, 3, 224, 224))).cuda()\n"
+        "st = torch.cuda.Stream()\n"
+        "with torch.cuda.stream(st):\n"
+        "    eng = ForwardEngine(cfg, sd, torch.bfloat16, 'cuda', use_graph=False)\n"
+        "    plan = eng.plan(2, 224, 224)\n"
+        "    assert any(s.kernel == 'bneck' for s in plan.steps)\n"
+        "    out, _ = eng.forward(clip)\n"
+        "    st.synchronize()\n"
+        "torch.save(out.cpu(), sys.argv[2])\n" % root)
+    outs = []
+    for flav, suffix in (("debug", "libtdeed_hip_dbg.so"), ("release", "libtdeed_hip.so")):
+        path = os.path.join("/tmp", f"tdeed_flavour_{flav}.pt")
+        env = dict(os.environ, TDEED_LIB_FLAVOUR=flav)
+        r = subprocess.run([sys.executable, "-c", code, suffix, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (flav, r.stdout[-2000:], r.stderr[-2000:])
+        outs.append(torch.load(path))
+    assert torch.isfinite(outs[0]).all()
+    # -O1 contracts floating point differently from -O3; in bf16 that moves logits by the usual bf16 noise (DESIGN §5)
+    assert float((outs[0] - outs[1]).abs().max()) < 0.1 * float(outs[1].abs().max())

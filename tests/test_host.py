@@ -206,3 +206,20 @@ def test_load_timm_backbone_round_trip():
         m._model.load_timm_backbone(bad)
     with pytest.raises(KeyError):
         m._model.load_timm_backbone({k: v for k, v in timm_sd.items() if k != "stem.conv.weight"})
+
+
+def test_debug_flavour_compiles_with_device_asserts():
+    """`python t-deed_amd/build.py --debug` (SURVEY §5 'race detection / sanitizers': an asserting build): one source is enough
+    here -- the object must carry the TD_DEV_ASSERT message text, the release object must not."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_tdeed_build_dbg", os.path.join(root, "t-deed_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    (obj,) = mod.build(flavour="debug", only=["bneck.hip"], verbose=False)
+    assert os.path.exists(obj) and obj.endswith(".dbg.o")
+    assert b"tdeed device assert" in open(obj, "rb").read()
+    rel = os.path.join(os.path.dirname(obj), "bneck.o")
+    if os.path.exists(rel):
+        assert b"tdeed device assert" not in open(rel, "rb").read()
