@@ -89,10 +89,11 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     const bf16_t* gg = p.G ? p.G + (long)f0 * hw * p.Fp : nullptr;
     const int total = npix * cpr;
     const IDiv dcpr(cpr);
-    for (int i0 = tid; i0 < total; i0 += BNK_THR * 6) {          // 6 independent 16-byte loads in flight per thread
-      u32x4 v[6];
+    constexpr int NLD = 9;                                       // independent 16-byte loads in flight per thread: a workgroup's
+    for (int i0 = tid; i0 < total; i0 += BNK_THR * NLD) {        // 72 KB (7 x 7 x 368, two frames) in ONE round trip
+      u32x4 v[NLD];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
+      for (int b = 0; b < NLD; ++b) {
         const int i = min(i0 + b * BNK_THR, total - 1);
         int px, ck;
         dcpr.divmod(i, px, ck);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       }
       TD_ISSUE_FENCE();
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
+      for (int b = 0; b < NLD; ++b) {
         const int i = i0 + b * BNK_THR;
         if (i < total) {
           int px, ck;
