@@ -149,6 +149,18 @@ int tdeed_se_gate_mfma_fits(int C, int R);
 int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R, const void* w1f,
                            const float* b1, const void* w2f, const float* b2, float* gate, void* stream);
 
+/* conv1 (1x1 + BN + ReLU, with the gate-shift splice of shift.py:89-93) IN FRONT of the grouped 3x3 of the same timm
+ * Bottleneck, one launch: the y1 band the grouped conv reads is computed in LDS from the block input, the y1 map (the
+ * largest intermediate of a stride-2 block) never exists.  bf16.  x [N][Hi][Wi][Cin]; G optional [N*Hi*Wi][Fp]; w1f: conv1
+ * weight [C][Cin] as MFMA A-operand fragments [tdeed_c1_gconv_slab_tiles()][ceil(Cin/32)][64][8] (zero padded to whole
+ * slabs); s1 / h1: its folded BatchNorm; wfrag / scale / shift / y / pooled as tdeed_gconv3x3_fwd (ReLU applied).
+ * Bit-identical to tdeed_gemm_fwd (or tdeed_gemm_ws_fwd) followed by tdeed_gconv3x3_fwd.  tdeed_c1_gconv_fits: Cin <= 64. */
+int tdeed_c1_gconv_fits(int Hi, int Wi, int Cin, int C, int stride);
+int tdeed_c1_gconv_slab_tiles(int Hi, int Wi, int C, int stride);
+int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int Wi, int Cin, int C, int gw, int stride,
+                       const void* w1f, const float* s1, const float* h1, const void* wfrag, const float* scale,
+                       const float* shift, void* y, float* pooled, void* stream);
+
 /* A whole stride-1 RegNetY bottleneck with identity shortcut on a small map in ONE launch (timm Bottleneck.forward:
  * conv1 -> conv2 -> se -> conv3 + shortcut -> ReLU, with the gate-shift splice of shift.py:89-93 on conv1's operand;
  * SURVEY §8 a2 / a3): the frames of a workgroup stay in LDS, only x and the output cross HBM.  bf16.

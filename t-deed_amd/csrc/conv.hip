@@ -229,79 +229,18 @@ static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
 // AFF (training): the input is a RAW conv output z and the BatchNorm affine + ReLU of the layer in front,
 // relu(in_a[c] * z + in_b[c]), is applied while the band is staged (the halo stays zero): the post-BN map is never
 // materialised.  Rounded to bf16 like the materialised map would be, so the result is bit-identical.
-template <int STRIDE, bool AFF>
-__global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ x, int Hi, int Wi, int C,
-                                                            const float* __restrict__ in_a, const float* __restrict__ in_b,
-                                                            const bf16x8* __restrict__ wfrag,
-                                                            const float* __restrict__ scale,
-                                                            const float* __restrict__ shift,
-                                                            bf16_t* __restrict__ y, float* __restrict__ pooled,
-                                                            float* __restrict__ pooled_sq,
-                                                            int Ho, int Wo, int band, int nbands, int CSP, int PS,
-                                                            int rows_in, int relu) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
-  __shared__ float red[4][16];
-  __shared__ float redq[4][16];
-  // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
-  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int nslabs_ = (C + CSP - 1) / CSP;
-  const int slab = (int)(lid % nslabs_);
-  const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
-  const int cs0 = slab * CSP;
-  const int oy0 = bnd * band;
-  const int nrows_out = min(band, Ho - oy0);
+// The grouped 3x3 itself, from a zero-haloed band of the (post-BN-ReLU) input in LDS: implicit GEMM per 16-channel unit,
+// BatchNorm (+ ReLU), output rows, SE squeeze partial sums (and sums of squares in training).  Shared by the kernel that
+// stages the band from a stored map and by the one that computes it (conv1 in front, c1_gconv_mfma_kernel).
+template <int STRIDE>
+__device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float (*red)[16], float (*redq)[16], int Wi, int C,
+                                               const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, bf16_t* __restrict__ y,
+                                               float* __restrict__ pooled, float* __restrict__ pooled_sq, int Ho, int Wo,
+                                               int nbands, int CSP, int PS, int relu, int n, int bnd, int slab, int oy0,
+                                               int nrows_out) {
   const int WP = Wi + 2;
-  const int iy0 = oy0 * STRIDE - 1;
-  // ---- stage the zero-padded input band: (row, col, chunk) with chunk fastest
-  const int cpp = CSP >> 3;
-  const int nrow_used = (nrows_out - 1) * STRIDE + 3;
-  const bf16_t* xin = x + (long)n * Hi * Wi * C;
-  // batches of 8 independent 16-B loads per thread before the LDS stores (memory-level parallelism)
-  const int total = nrow_used * WP * cpp;
-  const IDiv dcpp(cpp), dwp(WP);
-  // cpp (4 or 8) divides 256: a thread stages the same 8-channel chunk in every iteration, its affine lives in registers
-  float ia[8], ib[8];
-  if constexpr (AFF) {
-    const int jt = threadIdx.x % cpp;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = min(cs0 + jt * 8 + e, C - 1);
-      ia[e] = in_a[c];
-      ib[e] = in_b[c];
-    }
-  }
-  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
-    u32x4 v[8];
-    bool ok[8];
-#pragma unroll
-    for (int b8 = 0; b8 < 8; ++b8) {
-      const int i = min(i0 + b8 * 256, total - 1);
-      int j, pix, r, xx;
-      dcpp.divmod(i, pix, j);
-      dwp.divmod(pix, r, xx);
-      const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
-      ok[b8] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C;
-      v[b8] = *reinterpret_cast<const u32x4*>(ok[b8] ? xin + ((long)iy * Wi + ix) * C + c : xin);   // branch-free
-    }
-    TD_ISSUE_FENCE();
-#pragma unroll
-    for (int b8 = 0; b8 < 8; ++b8) {
-      const int i = i0 + b8 * 256;
-      if (i < total) {
-        int j, pix;
-        dcpp.divmod(i, pix, j);
-        if constexpr (AFF) {
-          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[b8]);
-          bf16x8 o8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)fmaxf(fmaf((float)t8[e], ia[e], ib[e]), 0.f);
-          v[b8] = *reinterpret_cast<const u32x4*>(&o8);
-        }
-        *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = ok[b8] ? v[b8] : (u32x4){0u, 0u, 0u, 0u};
-      }
-    }
-  }
-  __syncthreads();
+  const int cs0 = slab * CSP;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int q = lane >> 4, pl = lane & 15;
   const int units = CSP >> 4;
@@ -393,6 +332,193 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   }
 }
 
+template <int STRIDE, bool AFF>
+__global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ x, int Hi, int Wi, int C,
+                                                            const float* __restrict__ in_a, const float* __restrict__ in_b,
+                                                            const bf16x8* __restrict__ wfrag,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            bf16_t* __restrict__ y, float* __restrict__ pooled,
+                                                            float* __restrict__ pooled_sq,
+                                                            int Ho, int Wo, int band, int nbands, int CSP, int PS,
+                                                            int rows_in, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+  __shared__ float red[4][16];
+  __shared__ float redq[4][16];
+  // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int nslabs_ = (C + CSP - 1) / CSP;
+  const int slab = (int)(lid % nslabs_);
+  const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
+  const int cs0 = slab * CSP;
+  const int oy0 = bnd * band;
+  const int nrows_out = min(band, Ho - oy0);
+  const int WP = Wi + 2;
+  const int iy0 = oy0 * STRIDE - 1;
+  // ---- stage the zero-padded input band: (row, col, chunk) with chunk fastest
+  const int cpp = CSP >> 3;
+  const int nrow_used = (nrows_out - 1) * STRIDE + 3;
+  const bf16_t* xin = x + (long)n * Hi * Wi * C;
+  // batches of 8 independent 16-B loads per thread before the LDS stores (memory-level parallelism)
+  const int total = nrow_used * WP * cpp;
+  const IDiv dcpp(cpp), dwp(WP);
+  // cpp (4 or 8) divides 256: a thread stages the same 8-channel chunk in every iteration, its affine lives in registers
+  float ia[8], ib[8];
+  if constexpr (AFF) {
+    const int jt = threadIdx.x % cpp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = min(cs0 + jt * 8 + e, C - 1);
+      ia[e] = in_a[c];
+      ib[e] = in_b[c];
+    }
+  }
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
+    u32x4 v[8];
+    bool ok[8];
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = min(i0 + b8 * 256, total - 1);
+      int j, pix, r, xx;
+      dcpp.divmod(i, pix, j);
+      dwp.divmod(pix, r, xx);
+      const int iy = iy0 + r, ix = xx - 1, c = cs0 + j * 8;
+      ok[b8] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && c < C;
+      v[b8] = *reinterpret_cast<const u32x4*>(ok[b8] ? xin + ((long)iy * Wi + ix) * C + c : xin);   // branch-free
+    }
+    TD_ISSUE_FENCE();
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = i0 + b8 * 256;
+      if (i < total) {
+        int j, pix;
+        dcpp.divmod(i, pix, j);
+        if constexpr (AFF) {
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[b8]);
+          bf16x8 o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)fmaxf(fmaf((float)t8[e], ia[e], ib[e]), 0.f);
+          v[b8] = *reinterpret_cast<const u32x4*>(&o8);
+        }
+        *reinterpret_cast<u32x4*>(tile + (long)pix * PS + j * 16) = ok[b8] ? v[b8] : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  __syncthreads();
+  gconv_band_mma<STRIDE>(tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, pooled_sq, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
+                         slab, oy0, nrows_out);
+}
+
+// conv1 (1x1 + BN + ReLU, optionally behind the gate-shift splice) IN FRONT of the grouped 3x3 of the same bottleneck, one
+// launch: the band of y1 rows that gconv3x3_mfma_kernel stages from HBM is COMPUTED here from the block input x -- each
+// workgroup contracts the pixels of its band with the 64 conv1 output channels of its slab (a grouped conv only reads its
+// own group's channels, so a slab needs no other) and writes them, BN + ReLU applied, into the zero-haloed LDS band.  The
+// y1 map (at the block's INPUT resolution: the largest intermediate of a stride-2 block, 281 MB for s2.b1 of RegNetY-200MF
+// at 800 frames, written once and read 2.25 x) never exists.  x rows are MFMA B operands straight from global memory
+// (lane = pixel l & 15, k-chunk l >> 4), the conv1 weights of the slab are A-operand fragments in registers
+// (w1f: [slabs * CSP / 16][KS1][64], engine.pack_mfma_frags, zero padded).
+template <int STRIDE, int KS1>
+__global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G, int Fp,
+                                                            int Hi, int Wi, int Cin, int C, const bf16x8* __restrict__ w1f,
+                                                            const float* __restrict__ s1, const float* __restrict__ h1,
+                                                            const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, bf16_t* __restrict__ y,
+                                                            float* __restrict__ pooled, int Ho, int Wo, int band, int nbands,
+                                                            int CSP, int PS, int rows_in, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+  __shared__ float red[4][16];
+  __shared__ float redq[4][16];
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int nslabs_ = (C + CSP - 1) / CSP;
+  const int slab = (int)(lid % nslabs_);
+  const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
+  const int oy0 = bnd * band;
+  const int nrows_out = min(band, Ho - oy0);
+  const int WP = Wi + 2;
+  const int iy0 = oy0 * STRIDE - 1;
+  const int nrow_used = (nrows_out - 1) * STRIDE + 3;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pl = lane & 15, q = lane >> 4;
+  const int nts = CSP >> 4;                                // conv1 output tiles of this slab (<= 4)
+  // conv1 weights of the slab, BN affine of this lane's 4 channels per tile
+  bf16x8 w1r[4][KS1];
+  float a1[4][4], b1[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tt = slab * nts + min(t, nts - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) w1r[t][ks] = w1f[((long)tt * KS1 + ks) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = slab * CSP + t * 16 + 4 * q + e;
+      const bool ok = t < nts && c < C;
+      a1[t][e] = ok ? s1[c] : 0.f;                          // channels beyond C: exact zeros
+      b1[t][e] = ok ? h1[c] : 0.f;
+    }
+  }
+  // ---- zero the halo columns of every band row and the rows that fall outside the map
+  {
+    const int cpp = PS >> 4;
+    for (int i = tid; i < nrow_used * 2 * cpp; i += 256) {
+      const int j = i % cpp, rc = i / cpp;
+      const int rr = rc >> 1, col = (rc & 1) ? (Wi + 1) : 0;
+      *reinterpret_cast<u32x4*>(tile + ((long)rr * WP + col) * PS + j * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    for (int rr = 0; rr < nrow_used; ++rr) {
+      const int r = iy0 + rr;
+      if (r >= 0 && r < Hi) continue;
+      for (int i = tid; i < WP * cpp; i += 256)
+        *reinterpret_cast<u32x4*>(tile + (long)rr * WP * PS + (long)i * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    // the 16 pad bytes behind the channels of every interior pixel are never read (k-slot offsets stay below CSP * 2)
+  }
+  // ---- conv1 over the band's pixels (rows inside the map), 16 pixels per MFMA tile, tiles dealt over the four waves
+  {
+    const int r_lo = max(iy0, 0), r_hi = min(iy0 + nrow_used, Hi);
+    const int npx = (r_hi - r_lo) * Wi;
+    const int ntl = (npx + 15) >> 4;
+    const IDiv dwi(Wi);
+    const bf16_t* xn = x + (long)n * Hi * Wi * Cin;
+    const bf16_t* gn = G ? G + (long)n * Hi * Wi * Fp : nullptr;
+    for (int t0 = wv; t0 < ntl; t0 += 4) {
+      const int p = t0 * 16 + pl;
+      const bool pok = p < npx;
+      int rr, cc;
+      dwi.divmod(pok ? p : 0, rr, cc);
+      const long pix = (long)(r_lo + rr) * Wi + cc;
+      bf16x8 xf[KS1];
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const int k = 32 * ks + 8 * q;
+        const bool ok = pok && k < Cin;
+        const bf16_t* src = (gn && k < Fp) ? gn + pix * Fp + k : xn + pix * Cin + k;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? src : xn);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const u32x4 w = ok ? v : z;
+        xf[ks] = *reinterpret_cast<const bf16x8*>(&w);
+      }
+      unsigned char* dst = tile + ((long)(r_lo + rr - iy0) * WP + cc + 1) * PS + 8 * q;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nts) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t][ks], xf[ks], acc, 0, 0, 0);
+          if (pok) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(acc[e] * a1[t][e] + b1[t][e], 0.f);
+            *reinterpret_cast<bf16x4*>(dst + t * 32) = o;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  gconv_band_mma<STRIDE>(tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, nullptr, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
+                         slab, oy0, nrows_out);
+}
+
 // 1 if the bf16 MFMA kernel serves this geometry (a band of input rows fits LDS), i.e. if wfrag / in_a are usable
 extern "C" int tdeed_gconv3x3_mfma_fits(int Hi, int Wi, int C, int stride) {
   return gc_geom(Hi, Wi, C, stride).band > 0 ? 1 : 0;
@@ -444,6 +570,44 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
   }
   tdeed_set_error("gconv3x3: bad dtype %d", dtype);
   return TDEED_ERR_ARG;
+}
+
+// conv1 + grouped 3x3 of one bottleneck in one launch (bf16).  x [N][Hi][Wi][Cin]; G optional [N*Hi*Wi][Fp] compact
+// gate-shift output replacing channels [0, Fp) of x; w1f: conv1 weight [C][Cin] as MFMA A fragments padded to whole slabs
+// ([nslabs * CSP / 16][ceil(Cin / 32)][64][8]); the rest as tdeed_gconv3x3_fwd.  tdeed_c1_gconv_fits: Cin <= 64 and a band of
+// rows fits LDS.
+extern "C" int tdeed_c1_gconv_fits(int Hi, int Wi, int Cin, int C, int stride) {
+  if (Cin % 8 != 0 || Cin < 8 || Cin > 64 || C % 8 != 0) return 0;
+  return gc_geom(Hi, Wi, C, stride).band > 0 ? 1 : 0;
+}
+extern "C" int tdeed_c1_gconv_slab_tiles(int Hi, int Wi, int C, int stride) {     // rows of w1f: nslabs * CSP / 16
+  const GcGeom g = gc_geom(Hi, Wi, C, stride);
+  return g.nslabs * (g.CSP >> 4);
+}
+extern "C" int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int Wi, int Cin, int C, int gw,
+                                  int stride, const void* w1f, const float* s1, const float* h1, const void* wfrag,
+                                  const float* scale, const float* shift, void* y, float* pooled, void* stream) {
+  TD_CHECK(x && w1f && s1 && h1 && wfrag && scale && shift && y && pooled, "c1_gconv: null pointer");
+  TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "c1_gconv: group width %d / C %d unsupported", gw, C);
+  TD_CHECK(stride == 1 || stride == 2, "c1_gconv: stride %d", stride);
+  TD_CHECK(N > 0 && N <= 65535 && tdeed_c1_gconv_fits(Hi, Wi, Cin, C, stride), "c1_gconv: Hi=%d Wi=%d Cin=%d C=%d unsupported",
+           Hi, Wi, Cin, C);
+  TD_CHECK(!G || (Fp % 8 == 0 && Fp > 0 && Fp <= Cin), "c1_gconv: bad splice width %d", Fp);
+  const GcGeom g = gc_geom(Hi, Wi, C, stride);
+  const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+  dim3 grid((unsigned)((long)g.nbands * g.nslabs * N));
+  const size_t smem = (size_t)g.rows_in * (Wi + 2) * g.PS;
+  hipStream_t st = (hipStream_t)stream;
+  const int KS1 = (Cin + 31) / 32;
+#define TD_C1G(Sv, Kv)                                                                                                     \
+  hipLaunchKernelGGL((c1_gconv_mfma_kernel<Sv, Kv>), grid, dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)G, G ? Fp : 0, \
+                     Hi, Wi, Cin, C, (const bf16x8*)w1f, s1, h1, (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, \
+                     g.band, g.nbands, g.CSP, g.PS, g.rows_in, 1)
+  if (stride == 2) { if (KS1 == 1) TD_C1G(2, 1); else TD_C1G(2, 2); }
+  else { if (KS1 == 1) TD_C1G(1, 1); else TD_C1G(1, 2); }
+#undef TD_C1G
+  TD_LAUNCH_CHECK("c1_gconv");
+  return TDEED_OK;
 }
 
 // =========================================================================== SE excitation

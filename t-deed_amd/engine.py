@@ -174,13 +174,13 @@ def pack_se_bf16(fc1_w, fc2_w, device):
     return dict(se_w1p=bf(p1), se_w2p=bf(w2.T))
 
 
-def pack_mfma_frags(W, device):
+def pack_mfma_frags(W, device, rows=None):
     """A dense [N][K] weight as MFMA A-operand fragments [ceil(N/16)][ceil(K/32)][64][8] (bf16, zero padded; lane l holds row
-    l&15, k = 8*(l>>4)+j of the 16 x 32 tile)."""
+    l&15, k = 8*(l>>4)+j of the 16 x 32 tile).  rows: pad N up to this many rows (whole channel slabs)."""
     W = _np(W).astype(np.float32)
     W = W.reshape(W.shape[0], -1)
     N, K = W.shape
-    NT, KS = (N + 15) // 16, (K + 31) // 32
+    NT, KS = (max(N, rows or 0) + 15) // 16, (K + 31) // 32
     Wp = np.zeros((NT * 16, KS * 32), np.float32)
     Wp[:N, :K] = W
     fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)
@@ -439,6 +439,7 @@ def _se(pooled, inv_cnt, bw, gate):
 
 SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
+C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 computed inside the grouped conv's launch (Cin <= 64)
 # one graph per sub-batch stream (joined by events) instead of a fork inside one graph: opt-in.  A graph of trivial kernels
 # replays 4x faster per node that way (tools/bench_dispatch.py), the forward does not: 3670 vs 3696 clips/s with 4 hardware
 # queues, 2900 with 8 (more queues than the command processor keeps resident are time-multiplexed)
@@ -714,6 +715,8 @@ class PackedWeights:
             bw = SimpleNamespace(spec=blk)
             c1 = bp + (".conv1.net" if blk.gsf_fold else ".conv1")
             bw.w1 = DenseW(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
+            bw.w1_raw = _np(sd[c1 + ".conv.weight"]).reshape(blk.cout, blk.cin) if blk.cin <= 64 else None
+            bw.c1g_w1f = None       # conv1 as MFMA fragments padded to whole channel slabs (tdeed_c1_gconv_fwd), packed on first use
             bw.s1, bw.h1 = bn_fold(c1 + ".bn")
             w2 = sd[bp + ".conv2.conv.weight"]                       # [C][gw][3][3]
             G, gw = blk.groups, blk.gw
@@ -838,8 +841,13 @@ class ForwardEngine:
             blk = bw.spec
             M = N * h * w
             one_launch = _bneck_fused(bw, h, w, out_last is not None and bw is blocks[-1])
+            # conv1 inside the grouped conv's launch (the y1 map never exists): narrow block inputs, bf16
+            c1g = bool(C1_GCONV and not one_launch and dt == torch.bfloat16 and bw.w2frag is not None and bw.w1_raw is not None
+                       and ops.c1_gconv_fits(h, w, blk.cin, blk.cout, blk.stride))
+            if c1g and bw.c1g_w1f is None:
+                bw.c1g_w1f = pack_mfma_frags(bw.w1_raw, self.device, rows=16 * ops.c1_gconv_slab_tiles(h, w, blk.cout, blk.stride))
             # conv1 (optionally behind the gate-shift splice)
-            y1 = None if one_launch else pool.take((N, h, w, blk.cout), dt)
+            y1 = None if (one_launch or c1g) else pool.take((N, h, w, blk.cout), dt)
             if blk.gsf_fold:
                 F = blk.gsf_fold
                 Fp = (F + 7) // 8 * 8
@@ -854,7 +862,7 @@ class ForwardEngine:
                 steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
                     bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
-                if not one_launch:
+                if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
                         *gemm_cost(M, blk.cin, blk.cout, es)))
@@ -862,7 +870,7 @@ class ForwardEngine:
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
                 gs_bufs = list(gb.values()) + ([xs] if xs is not None else [])
             else:
-                if not one_launch:
+                if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
                 gs_bufs = []
@@ -897,9 +905,16 @@ class ForwardEngine:
             parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
             pooled = pool.take((N, parts, blk.cout), torch.float32)
             gate = pool.take((N, blk.cout), torch.float32)
-            steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
-                y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
-                (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
+            if c1g:
+                G = gb["out"] if blk.gsf_fold else None
+                steps.append(Step(blk.name + ".conv1_conv2", "c1_gconv", lambda x=x, bw=bw, blk=blk, G=G, y2=y2, pooled=pooled: ops.c1_gconv(
+                    x, bw.c1g_w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, blk.gw, blk.stride, blk.cout, G=G, out=y2, pooled=pooled),
+                    (M * blk.cin + M2 * blk.cout) * es + blk.cout * (blk.cin + blk.gw * 9) * es,
+                    2 * M * blk.cin * blk.cout + 2 * M2 * blk.cout * blk.gw * 9))
+            else:
+                steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
+                    y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
+                    (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
             # SE excitation inside conv3 (tdeed_gemm_se_fwd: every workgroup derives the gates of its tile's frames from the
             # squeeze sums) where the tiled kernel serves conv3 and the shape is covered; a launch of its own otherwise
             se_in_conv3 = _se_fused(bw, h2 * w2, taps)
@@ -930,7 +945,7 @@ class ForwardEngine:
                     y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2, out2=xs_next),
                     *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` (and the next block's slice) dies here
-            for t_ in [y1, y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
+            for t_ in ([y1] if y1 is not None else []) + [y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
             xs = xs_next
             if not x_kept and hasattr(x, "_td_raw"):

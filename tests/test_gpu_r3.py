@@ -462,3 +462,30 @@ def test_debug_flavour_runs_the_hot_path_without_a_trap():
     assert torch.isfinite(outs[0]).all()
     # -O1 contracts floating point differently from -O3; in bf16 that moves logits by the usual bf16 noise
     assert float((outs[0] - outs[1]).abs().max()) < 0.1 * float(outs[1].abs().max())
+
+
+@pytest.mark.parametrize("H,W,Cin,C,gw,stride,Fp,N", [(56, 56, 24, 56, 8, 2, 0, 3), (28, 28, 56, 152, 8, 2, 16, 4),
+                                                       (20, 12, 32, 64, 16, 1, 8, 2), (28, 28, 64, 152, 8, 2, 0, 2)])
+def test_conv1_in_front_of_the_grouped_conv_equals_the_two_launches(H, W, Cin, C, gw, stride, Fp, N):
+    """tdeed_c1_gconv_fwd (the y1 band computed in LDS from the block input) against conv1 (tdeed_gemm_fwd with the gate-shift
+    splice) followed by tdeed_gconv3x3_fwd: output rows and squeeze partial sums bitwise."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags
+    assert ops.c1_gconv_fits(H, W, Cin, C, stride)
+    g = torch.Generator().manual_seed(H * 10 + C)
+    M = N * H * W
+    x = torch.relu(torch.randn(N, H, W, Cin, generator=g)).to(torch.bfloat16).to(DEV)
+    G = torch.randn(M, Fp, generator=g).to(torch.bfloat16).to(DEV) if Fp else None
+    W1 = torch.randn(C, Cin, generator=g) / Cin ** 0.5
+    W2 = torch.randn(C, gw, 3, 3, generator=g) / (gw * 9) ** 0.5
+    vec = lambda n, s=0.1, o=0.0: (torch.randn(n, generator=g) * s + o).to(DEV)          # noqa: E731
+    s1, h1, s2, h2 = vec(C, 0.1, 1.0), vec(C), vec(C, 0.1, 1.0), vec(C)
+    w2f = pack_gconv_frags(W2.numpy(), gw, DEV)
+    y1 = ops.gemm(x.view(M, Cin), W1.to(torch.bfloat16).to(DEV), s1, h1, ops.ACT_RELU, **(dict(A0=G, k0=Fp) if Fp else {}))
+    ref, pref = ops.gconv3x3(y1.view(N, H, W, C), None, s2, h2, gw, stride, wfrag=w2f)
+    tiles = ops.c1_gconv_slab_tiles(H, W, C, stride)
+    w1f = pack_mfma_frags(W1.numpy(), DEV, rows=tiles * 16)
+    out, pooled = ops.c1_gconv(x, w1f, s1, h1, w2f, s2, h2, gw, stride, C, G=G)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+    assert torch.equal(pooled, pref)
