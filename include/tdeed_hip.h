@@ -154,12 +154,16 @@ int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int 
  * largest intermediate of a stride-2 block) never exists.  bf16.  x [N][Hi][Wi][Cin]; G optional [N*Hi*Wi][Fp]; w1f: conv1
  * weight [C][Cin] as MFMA A-operand fragments [tdeed_c1_gconv_slab_tiles()][ceil(Cin/32)][64][8] (zero padded to whole
  * slabs); s1 / h1: its folded BatchNorm; wfrag / scale / shift / y / pooled as tdeed_gconv3x3_fwd (ReLU applied).
- * Bit-identical to tdeed_gemm_fwd (or tdeed_gemm_ws_fwd) followed by tdeed_gconv3x3_fwd.  tdeed_c1_gconv_fits: Cin <= 64. */
+ * wdf / sd / hd / shortcut (optional, together): the block's downsample shortcut (1x1 conv of the same stride + BN on x,
+ * weight [C][Cin] laid out like w1f) -> shortcut [N][Ho][Wo][C] from the same x fragments (timm Bottleneck.downsample).
+ * Bit-identical to tdeed_gemm_fwd (or tdeed_gemm_ws_fwd) followed by tdeed_gconv3x3_fwd (and to the strided
+ * tdeed_gemm_ws_fwd of the shortcut).  tdeed_c1_gconv_fits: Cin <= 64, or 97..160 (k-steps of 32: 1, 2, 4, 5). */
 int tdeed_c1_gconv_fits(int Hi, int Wi, int Cin, int C, int stride);
 int tdeed_c1_gconv_slab_tiles(int Hi, int Wi, int C, int stride);
 int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int Wi, int Cin, int C, int gw, int stride,
-                       const void* w1f, const float* s1, const float* h1, const void* wfrag, const float* scale,
-                       const float* shift, void* y, float* pooled, void* stream);
+                       const void* w1f, const float* s1, const float* h1, const void* wdf, const float* sd, const float* hd,
+                       void* shortcut, const void* wfrag, const float* scale, const float* shift, void* y, float* pooled,
+                       void* stream);
 
 /* A whole stride-1 RegNetY bottleneck with identity shortcut on a small map in ONE launch (timm Bottleneck.forward:
  * conv1 -> conv2 -> se -> conv3 + shortcut -> ReLU, with the gate-shift splice of shift.py:89-93 on conv1's operand;

@@ -54,7 +54,8 @@ _SIGS = {
     "tdeed_se_gate_mfma_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_c1_gconv_fits": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "tdeed_c1_gconv_slab_tiles": ([c_int, c_int, c_int, c_int], c_int),
-    "tdeed_c1_gconv_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P], c_int),
+    "tdeed_c1_gconv_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                            P], c_int),
     "tdeed_bneck_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_bneck_set_debug": ([P], c_int),
     "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int,

@@ -439,7 +439,12 @@ def _se(pooled, inv_cnt, bw, gate):
 
 SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
-C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 computed inside the grouped conv's launch (Cin <= 64)
+C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
+C1_GCONV_MAX_CIN = int(os.environ.get("TDEED_C1_GCONV_MAX_CIN", "128"))
+# ... and the downsample shortcut out of the same launch: opt-in (bit-identical, measured slower on the same box: cfg2 3890 vs
+# 4048 clips/s, 800MF B=16 1454 vs 1543: the scattered 8-byte shortcut stores and 40 more registers cost more than the
+# strided contraction of its own)
+C1_GCONV_DS = os.environ.get("TDEED_C1_GCONV_DS", "0") == "1"
 # one graph per sub-batch stream (joined by events) instead of a fork inside one graph: opt-in.  A graph of trivial kernels
 # replays 4x faster per node that way (tools/bench_dispatch.py), the forward does not: 3670 vs 3696 clips/s with 4 hardware
 # queues, 2900 with 8 (more queues than the command processor keeps resident are time-multiplexed)
@@ -715,8 +720,10 @@ class PackedWeights:
             bw = SimpleNamespace(spec=blk)
             c1 = bp + (".conv1.net" if blk.gsf_fold else ".conv1")
             bw.w1 = DenseW(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
-            bw.w1_raw = _np(sd[c1 + ".conv.weight"]).reshape(blk.cout, blk.cin) if blk.cin <= 64 else None
-            bw.c1g_w1f = None       # conv1 as MFMA fragments padded to whole channel slabs (tdeed_c1_gconv_fwd), packed on first use
+            bw.w1_raw = _np(sd[c1 + ".conv.weight"]).reshape(blk.cout, blk.cin)
+            bw.wd_raw = _np(sd[bp + ".downsample.conv.weight"]).reshape(blk.cout, blk.cin) if blk.has_downsample else None
+            bw.c1g_w1f = bw.c1g_wdf = None    # conv1 / downsample as MFMA fragments padded to whole channel slabs
+                                              # (tdeed_c1_gconv_fwd), packed on first use
             bw.s1, bw.h1 = bn_fold(c1 + ".bn")
             w2 = sd[bp + ".conv2.conv.weight"]                       # [C][gw][3][3]
             G, gw = blk.groups, blk.gw
@@ -842,10 +849,15 @@ class ForwardEngine:
             M = N * h * w
             one_launch = _bneck_fused(bw, h, w, out_last is not None and bw is blocks[-1])
             # conv1 inside the grouped conv's launch (the y1 map never exists): narrow block inputs, bf16
-            c1g = bool(C1_GCONV and not one_launch and dt == torch.bfloat16 and bw.w2frag is not None and bw.w1_raw is not None
+            # (block inputs up to 128 channels: at 152 -> 368, s4.b1 of RegNetY-200MF, the 40 weight fragments a wave then
+            # holds leave one workgroup per CU and the launch takes 310 us against 98 for the two it replaces)
+            c1g = bool(C1_GCONV and not one_launch and dt == torch.bfloat16 and bw.w2frag is not None and blk.cin <= C1_GCONV_MAX_CIN
                        and ops.c1_gconv_fits(h, w, blk.cin, blk.cout, blk.stride))
             if c1g and bw.c1g_w1f is None:
-                bw.c1g_w1f = pack_mfma_frags(bw.w1_raw, self.device, rows=16 * ops.c1_gconv_slab_tiles(h, w, blk.cout, blk.stride))
+                rows_ = 16 * ops.c1_gconv_slab_tiles(h, w, blk.cout, blk.stride)
+                bw.c1g_w1f = pack_mfma_frags(bw.w1_raw, self.device, rows=rows_)
+                if blk.has_downsample:
+                    bw.c1g_wdf = pack_mfma_frags(bw.wd_raw, self.device, rows=rows_)
             # conv1 (optionally behind the gate-shift splice)
             y1 = None if (one_launch or c1g) else pool.take((N, h, w, blk.cout), dt)
             if blk.gsf_fold:
@@ -905,12 +917,16 @@ class ForwardEngine:
             parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
             pooled = pool.take((N, parts, blk.cout), torch.float32)
             gate = pool.take((N, blk.cout), torch.float32)
+            sc_fused = None
             if c1g:
                 G = gb["out"] if blk.gsf_fold else None
-                steps.append(Step(blk.name + ".conv1_conv2", "c1_gconv", lambda x=x, bw=bw, blk=blk, G=G, y2=y2, pooled=pooled: ops.c1_gconv(
-                    x, bw.c1g_w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, blk.gw, blk.stride, blk.cout, G=G, out=y2, pooled=pooled),
-                    (M * blk.cin + M2 * blk.cout) * es + blk.cout * (blk.cin + blk.gw * 9) * es,
-                    2 * M * blk.cin * blk.cout + 2 * M2 * blk.cout * blk.gw * 9))
+                if blk.has_downsample and C1_GCONV_DS:     # the shortcut conv reads the same x fragments: out of the same launch
+                    sc_fused = pool.take((N, h2, w2, blk.cout), dt)
+                steps.append(Step(blk.name + ".conv1_conv2", "c1_gconv", lambda x=x, bw=bw, blk=blk, G=G, y2=y2, pooled=pooled, sc_=sc_fused: ops.c1_gconv(
+                    x, bw.c1g_w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, blk.gw, blk.stride, blk.cout, G=G, out=y2, pooled=pooled,
+                    ds=((bw.c1g_wdf, bw.sd, bw.hd) if sc_ is not None else None), shortcut=sc_),
+                    (M * blk.cin + (2 if blk.has_downsample else 1) * M2 * blk.cout) * es + blk.cout * (2 * blk.cin + blk.gw * 9) * es,
+                    2 * M * blk.cin * blk.cout + 2 * M2 * blk.cout * (blk.gw * 9 + (blk.cin if blk.has_downsample else 0))))
             else:
                 steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
                     y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
@@ -921,7 +937,9 @@ class ForwardEngine:
             if not se_in_conv3:
                 steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
                     2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
-            if blk.has_downsample:
+            if sc_fused is not None:
+                sc = sc_fused
+            elif blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
                 gather = (s, h, w, h2, w2) if s > 1 else None
                 steps.append(Step(blk.name + ".downsample", bw.wd.kern(M2), lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: bw.wd.run(

@@ -141,9 +141,10 @@ def c1_gconv_slab_tiles(Hi, Wi, C, stride):
     return _lib.load().tdeed_c1_gconv_slab_tiles(Hi, Wi, C, stride)
 
 
-def c1_gconv(x, w1f, s1, h1, wfrag, scale, shift, gw, stride, C, G=None, out=None, pooled=None):
+def c1_gconv(x, w1f, s1, h1, wfrag, scale, shift, gw, stride, C, G=None, out=None, pooled=None, ds=None, shortcut=None):
     """conv1 + grouped 3x3 of one bottleneck in one launch (tdeed_c1_gconv_fwd): x (N,Hi,Wi,Cin) bf16 -> y2 (N,Ho,Wo,C),
-    pooled (N, parts, C) squeeze partial sums.  G (N*Hi*Wi, Fp): gate-shift output spliced into conv1's operand."""
+    pooled (N, parts, C) squeeze partial sums.  G (N*Hi*Wi, Fp): gate-shift output spliced into conv1's operand.
+    ds = (wdf, sd, hd): also the block's downsample shortcut -> `shortcut` (N,Ho,Wo,C)."""
     _chk(x, "x", torch.bfloat16); _chk(G, "G", torch.bfloat16)
     N, Hi, Wi, Cin = x.shape
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
@@ -151,9 +152,13 @@ def c1_gconv(x, w1f, s1, h1, wfrag, scale, shift, gw, stride, C, G=None, out=Non
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     if pooled is None:
         pooled = torch.empty((N, gconv3x3_parts(Hi, Wi, C, stride, x.dtype), C), dtype=torch.float32, device=x.device)
+    if ds is not None and shortcut is None:
+        shortcut = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    wdf, sd, hd = ds if ds is not None else (None, None, None)
     call("tdeed_c1_gconv_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else 0), N, Hi, Wi, Cin, C, gw, stride, ptr(w1f),
-         ptr(s1), ptr(h1), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), ptr(pooled), stream_ptr())
-    return out, pooled
+         ptr(s1), ptr(h1), ptr(wdf), ptr(sd), ptr(hd), ptr(shortcut), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), ptr(pooled),
+         stream_ptr())
+    return (out, pooled, shortcut) if ds is not None else (out, pooled)
 
 
 def bneck_fits(h, w, C, R):

@@ -465,10 +465,13 @@ def test_debug_flavour_runs_the_hot_path_without_a_trap():
 
 
 @pytest.mark.parametrize("H,W,Cin,C,gw,stride,Fp,N", [(56, 56, 24, 56, 8, 2, 0, 3), (28, 28, 56, 152, 8, 2, 16, 4),
-                                                       (20, 12, 32, 64, 16, 1, 8, 2), (28, 28, 64, 152, 8, 2, 0, 2)])
+                                                       (20, 12, 32, 64, 16, 1, 8, 2), (28, 28, 64, 152, 8, 2, 0, 2),
+                                                       (14, 14, 152, 368, 8, 2, 40, 3), (28, 28, 128, 320, 16, 2, 32, 2),
+                                                       (15, 13, 24, 56, 8, 2, 0, 2)])
 def test_conv1_in_front_of_the_grouped_conv_equals_the_two_launches(H, W, Cin, C, gw, stride, Fp, N):
     """tdeed_c1_gconv_fwd (the y1 band computed in LDS from the block input) against conv1 (tdeed_gemm_fwd with the gate-shift
-    splice) followed by tdeed_gconv3x3_fwd: output rows and squeeze partial sums bitwise."""
+    splice) followed by tdeed_gconv3x3_fwd: output rows and squeeze partial sums bitwise; with the downsample shortcut out of
+    the same launch against the strided contraction of its own (timm Bottleneck.downsample)."""
     from tdeed_amd import ops
     from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags
     assert ops.c1_gconv_fits(H, W, Cin, C, stride)
@@ -489,3 +492,14 @@ def test_conv1_in_front_of_the_grouped_conv_equals_the_two_launches(H, W, Cin, C
     torch.cuda.synchronize()
     assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
     assert torch.equal(pooled, pref)
+    # + the downsample shortcut
+    Wd = torch.randn(C, Cin, generator=g) / Cin ** 0.5
+    sd_, hd_ = vec(C, 0.1, 1.0), vec(C)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    sref = ops.gemm(x, Wd.to(torch.bfloat16).to(DEV), sd_, hd_, ops.ACT_NONE,
+                    gather=(stride, H, W, Ho, Wo) if stride > 1 else None)
+    out2, pooled2, sc = ops.c1_gconv(x, w1f, s1, h1, w2f, s2, h2, gw, stride, C, G=G,
+                                     ds=(pack_mfma_frags(Wd.numpy(), DEV, rows=tiles * 16), sd_, hd_))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, ref) and torch.equal(pooled2, pref)
+    assert torch.equal(sc.view(-1, C), sref.view(-1, C)), float((sc.view(-1, C).float() - sref.view(-1, C).float()).abs().max())
