@@ -440,7 +440,7 @@ def _se(pooled, inv_cnt, bw, gate):
 SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
 C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
-C1_GCONV_MAX_CIN = int(os.environ.get("TDEED_C1_GCONV_MAX_CIN", "128"))
+C1_GCONV_MAX_CIN = int(os.environ.get("TDEED_C1_GCONV_MAX_CIN", "160"))
 # ... and the downsample shortcut out of the same launch: opt-in (bit-identical, measured slower on the same box: cfg2 3890 vs
 # 4048 clips/s, 800MF B=16 1454 vs 1543: the scattered 8-byte shortcut stores and 40 more registers cost more than the
 # strided contraction of its own)
@@ -849,8 +849,8 @@ class ForwardEngine:
             M = N * h * w
             one_launch = _bneck_fused(bw, h, w, out_last is not None and bw is blocks[-1])
             # conv1 inside the grouped conv's launch (the y1 map never exists): narrow block inputs, bf16
-            # (block inputs up to 128 channels: at 152 -> 368, s4.b1 of RegNetY-200MF, the 40 weight fragments a wave then
-            # holds leave one workgroup per CU and the launch takes 310 us against 98 for the two it replaces)
+            # (block inputs up to 160 channels = 5 k-steps of conv1 fragments per wave; s4.b1 of RegNetY-200MF, 152 -> 368: 4072 vs
+            # 4002 clips/s with it on the same box)
             c1g = bool(C1_GCONV and not one_launch and dt == torch.bfloat16 and bw.w2frag is not None and blk.cin <= C1_GCONV_MAX_CIN
                        and ops.c1_gconv_fits(h, w, blk.cin, blk.cout, blk.stride))
             if c1g and bw.c1g_w1f is None:
