@@ -23,7 +23,7 @@ TRAIN_FAMILY = [("bn_bwd_apply", "bn_bwd"), ("colstats", "bn_bwd"), ("wgrad", "w
                 ("bn_apply", "bn_apply"), ("pool_mean", "se_train"), ("scale_rows", "se_train"), ("se_train", "se_train"),
                 ("adamw", "adamw"), ("multi_fold", "grad_writeout"), ("gather_cast", "repack"), ("stem_mfma", "stem"),
                 ("stem_wgrad", "stem")]
-FAMILY = [("sgp_fold", "sgp_fold"), ("bneck_kernel", "bneck"), ("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_big", "gemm_big"), ("gemm_kernel", "gemm"),
+FAMILY = [("sgp_fold", "sgp_fold"), ("bneck_kernel", "bneck"), ("c1_gconv", "c1_gconv"), ("gemm_ws_kernel", "gemm_ws"), ("gemm_splitk", "gemm_splitk"), ("gemm_big", "gemm_big"), ("gemm_kernel", "gemm"),
           ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"), ("gsf_", "gate_shift"), ("se_gate", "se_gate"),
           ("stem_kernel", "stem"), ("sgp_mlp", "sgp_mlp"), ("sgp_front", "sgp_front"), ("mixer_front", "mixer_front"), ("mixer_branch", "mixer_branch"),
           ("sgp_branch", "sgp_branch"), ("layernorm", "layernorm"), ("groupnorm", "groupnorm"), ("maxpool", "maxpool"),
