@@ -202,7 +202,9 @@ static long gc_cap() {
   static long cap = -1;
   if (cap < 0) {
     const char* e = getenv("TDEED_GCONV_LDS_KB");
-    cap = e ? atol(e) * 1024 : 64 * 1024;
+    // 48 KB: three workgroups per CU.  Measured best since three batches share the chip (same-box A/B, cfg2: 4110 -> 4196
+    // clips/s together with the fused front's budget; 64 KB = two per CU was best with two sub-batches per batch)
+    cap = e ? atol(e) * 1024 : 48 * 1024;
     if (cap > 64 * 1024) cap = 64 * 1024;
   }
   return cap;

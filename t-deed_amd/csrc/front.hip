@@ -304,7 +304,8 @@ static long front_cap() {
   static long cap = -1;
   if (cap < 0) {
     const char* e = getenv("TDEED_FRONT_LDS_KB");
-    cap = e ? atol(e) * 1024 : 64 * 1024;      // 64 KB: two workgroups per CU, measured best with two batches in flight
+    cap = e ? atol(e) * 1024 : 48 * 1024;      // 48 KB: three workgroups per CU, measured best with three batches in flight
+                                               // (64 KB / two per CU was best with two: DESIGN section 4)
     if (cap > FRONT_LDS_CAP) cap = FRONT_LDS_CAP;
   }
   return cap;
