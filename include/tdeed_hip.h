@@ -149,6 +149,15 @@ int tdeed_se_gate_mfma_fits(int C, int R);
 int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R, const void* w1f,
                            const float* b1, const void* w2f, const float* b2, float* gate, void* stream);
 
+/* Register-stationary form of the same contraction for K = N = 320 over many rows (conv1 / conv3 of the s3 blocks of
+ * RegNetY-800MF): the whole weight matrix lives in the registers of a 10-wave workgroup, the activations cross the chip once
+ * (64-row tiles through LDS).  Arguments as tdeed_gemm_ws_fwd (Wfrag from pack_ws_weights, bf16) without the row gather;
+ * a_scale_rows >= 64.  tdeed_gemm_rs_fits(M, K, N) != 0 tells whether the shape is covered. */
+int tdeed_gemm_rs_fits(int M, int K, int N);
+int tdeed_gemm_rs_fwd(const void* A, long lda, const void* A0, long lda0, int k0, const float* a_scale, int a_scale_rows,
+                      int M, int K, int N, const void* Wfrag, const float* scale, const float* shift, const void* R, long ldr,
+                      int act, void* C, long ldc, void* C2, long ldc2, int n2, void* stream);
+
 /* conv1 (1x1 + BN + ReLU, with the gate-shift splice of shift.py:89-93) IN FRONT of the grouped 3x3 of the same timm
  * Bottleneck, one launch: the y1 band the grouped conv reads is computed in LDS from the block input, the y1 map (the
  * largest intermediate of a stride-2 block) never exists.  bf16.  x [N][Hi][Wi][Cin]; G optional [N*Hi*Wi][Fp]; w1f: conv1

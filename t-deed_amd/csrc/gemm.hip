@@ -793,6 +793,219 @@ extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long l
 }
 
 // =============================================================================================
+// Register-stationary contraction for the 320-wide layers of RegNetY-800MF (conv1 / conv3 of the eight s3 blocks: M =
+// 156 800 .. 313 600 rows, K = N = 320).  The tiled kernel re-reads A once per 64-column tile (five times, from L2: 355 -
+// 440 TFLOP/s), the sliced weight-stationary one twice from memory; here W (200 KB in bf16) lives in REGISTERS -- ten waves,
+// each holding the 20 A-operand fragments of its two 16-channel tiles -- and the activations cross the chip once: 64-row
+// tiles of A go global -> registers -> LDS (double buffered, row stride = 96 mod 128 bytes: conflict-free fragment reads),
+// every wave reads the whole tile as B fragments (one read feeds two MFMAs) and owns 32 output channels of its 64 rows.
+// SE gates of the (at most two) frames of a tile sit in a small LDS table that is filled one tile ahead; the gate-shift
+// splice, BatchNorm, residual, ReLU and the compact second output are those of gemm_ws_kernel (same weight packing).
+constexpr int RS_KS = 10, RS_NW = 10, RS_THR = RS_NW * 64, RS_ROWS = 64, RS_LD = RS_KS * 64 + 96;   // 736 B per row
+constexpr int RS_TILE = RS_ROWS * RS_LD;
+constexpr int RS_CPT = RS_ROWS * RS_KS * 4 / RS_THR;          // 16-byte chunks per thread per tile (4)
+constexpr int RS_KSR = 8;                                     // k-steps of W held in registers; the last RS_KS - RS_KSR come
+                                                              // from a wave-private LDS copy (16 registers for 40 % more LDS
+                                                              // reads: the loop stays bound by the MFMA pipe, and the
+                                                              // residual pieces of a tile fit without spilling)
+constexpr int RS_WTAIL = RS_NW * 2 * (RS_KS - RS_KSR) * 64 * 16;      // 40 KB
+
+// SE / RES / OUT2 are compile-time: a run-time branch inside the tile loop makes the wait-count pass drain every
+// outstanding load at its join, i.e. wait for the NEXT tile's rows in the middle of this tile's MFMAs.
+template <bool SE, bool RES, bool OUT2>
+__global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles = smem;                                        // [2][64][RS_LD]
+  bf16x8* wtail = reinterpret_cast<bf16x8*>(smem + 2 * RS_TILE);      // [NW][2][KS - KSR][64] fragments, wave-private
+  float* gt = reinterpret_cast<float*>(smem + 2 * RS_TILE + RS_WTAIL);    // [2][2][K] SE gates of the tile's two frames
+  float* bnt = gt + 4 * RS_KS * 32;                                   // [2][N] scale, shift
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, q = lane >> 4;
+  const int KP = RS_KS * 32;
+  // this wave's weights: tile pair (2 wv, 2 wv + 1) = logical channels [32 wv, 32 wv + 32)
+  bf16x8 wf[2][RS_KSR];
+  bf16x8* wt = wtail + wv * 2 * (RS_KS - RS_KSR) * 64 + lane;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ks = 0; ks < RS_KS; ++ks) {
+      const bf16x8 f = reinterpret_cast<const bf16x8*>(p.Wf)[((long)(2 * wv + h) * RS_KS + ks) * 64 + lane];
+      if (ks < RS_KSR) wf[h][ks] = f;
+      else wt[(h * (RS_KS - RS_KSR) + ks - RS_KSR) * 64] = f;
+    }
+  for (int i = tid; i < 2 * p.N; i += RS_THR) {
+    const int n = i % p.N;
+    bnt[i] = i < p.N ? (p.scale ? p.scale[n] : 1.0f) : (p.shift ? p.shift[n] : 0.0f);
+  }
+  const long ntiles = ((long)p.M + RS_ROWS - 1) / RS_ROWS;
+  // staging: RS_THR = 16 rows x 40 pieces, so a thread serves ONE 16-byte piece (ck) of rows r0, r0 + 16, r0 + 32, r0 + 48
+  const int r0 = tid / (RS_KS * 4), ck = tid - r0 * (RS_KS * 4);
+  const int kk = ck * 8;
+  const bool kok = kk < p.K;
+  const bool spl = p.A0 && kk < p.k0;
+  const T* abase = spl ? reinterpret_cast<const T*>(p.A0) + kk : reinterpret_cast<const T*>(p.A) + (kok ? kk : 0);
+  const long ald = spl ? p.lda0 : p.lda;
+  u32x4 sv[RS_CPT];
+  float gv = 0.f;                                                     // one gate of the next tile's table per thread
+  const int gf = tid / KP, gk = tid - gf * KP;                        // (frame slot, k) of that gate: 2 KP = RS_THR threads
+  auto gload = [&](long t) {
+    const long m0 = t * RS_ROWS + r0;
+#pragma unroll
+    for (int j = 0; j < RS_CPT; ++j) {
+      const long m = m0 + 16 * j;
+      const bool ok = kok && m < p.M;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(abase + (ok ? m : 0) * ald);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      sv[j] = ok ? v : z;
+    }
+    if constexpr (SE) {
+      const long f0 = (t * RS_ROWS) / p.a_scale_rows;
+      const long flast = ((long)p.M - 1) / p.a_scale_rows;
+      gv = p.a_scale[min(f0 + gf, flast) * (long)p.K + min(gk, p.K - 1)];
+    }
+  };
+  auto lstore = [&](int buf, long t) {
+    unsigned char* base = tiles + buf * RS_TILE + r0 * RS_LD + ck * 16;
+    if constexpr (SE) {
+      float* g = gt + buf * 2 * KP;
+      g[tid] = gv;                                                    // table of tile t (both frames), then scale the chunks
+      __syncthreads();
+      const long f0 = (t * RS_ROWS) / p.a_scale_rows;
+#pragma unroll
+      for (int j = 0; j < RS_CPT; ++j) {
+        const long m = min(t * RS_ROWS + r0 + 16 * j, (long)p.M - 1);
+        const float* gr = g + (int)(m / p.a_scale_rows - f0) * KP + kk;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr), g1 = *reinterpret_cast<const f32x4*>(gr + 4);
+        bf16x8 x8 = *reinterpret_cast<const bf16x8*>(&sv[j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x8[e] = (bf16_t)((float)x8[e] * g0[e]);
+          x8[4 + e] = (bf16_t)((float)x8[4 + e] * g1[e]);
+        }
+        sv[j] = *reinterpret_cast<const u32x4*>(&x8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RS_CPT; ++j) *reinterpret_cast<u32x4*>(base + j * 16 * RS_LD) = sv[j];
+  };
+  const int ch = 32 * wv + 8 * q;                                     // this lane's 8 logical output channels
+  long t = blockIdx.x;
+  if (t < ntiles) {
+    gload(t);
+    lstore(0, t);
+  }
+  __syncthreads();
+  int buf = 0;
+  const float lo = p.act == TDEED_ACT_RELU ? 0.f : -3.0e38f;           // ReLU (or nothing) without a branch
+  const int chc = min(ch, p.N - 8);
+  for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+    const long tn = t + gridDim.x;
+    // residual pieces of this tile first, THEN the next tile's rows: vmcnt counts in order, so a wait for a residual piece
+    // never has to drain the prefetch behind it
+    u32x4 rpre[RES ? 4 : 1];
+    if constexpr (RES) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const long m = min(t * RS_ROWS + mt * 16 + px, (long)p.M - 1);
+        rpre[mt] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + m * p.ldr + chc);
+      }
+    }
+    if (tn < ntiles) gload(tn);                                       // next tile travels while this one is multiplied
+    const unsigned char* base = tiles + buf * RS_TILE;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(bnt + chc), s1 = *reinterpret_cast<const f32x4*>(bnt + chc + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(bnt + p.N + chc), h1 = *reinterpret_cast<const f32x4*>(bnt + p.N + chc + 4);
+    // one 16-row tile at a time: two accumulators (the wave's two channel tiles) alternate on the MFMA pipe
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const long m = t * RS_ROWS + mt * 16 + px;
+      const unsigned char* ar = base + (mt * 16 + px) * RS_LD + 16 * q;
+#pragma unroll
+      for (int ks = 0; ks < RS_KS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + 64 * ks);
+        const bf16x8 w0 = ks < RS_KSR ? wf[0][ks < RS_KSR ? ks : 0] : wt[(ks - RS_KSR) * 64];
+        const bf16x8 w1 = ks < RS_KSR ? wf[1][ks < RS_KSR ? ks : 0] : wt[((RS_KS - RS_KSR) + ks - RS_KSR) * 64];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a, acc1, 0, 0, 0);
+      }
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc0[r] * s0[r] + h0[r];
+        v[4 + r] = acc1[r] * s1[r] + h1[r];
+      }
+      if constexpr (RES) {
+        float rv[8];
+        Chunk<T>::load(reinterpret_cast<const T*>(&rpre[mt]), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo);
+      if (ch < p.N && m < p.M) {
+        Chunk<T>::store(reinterpret_cast<T*>(p.C) + m * p.ldc + ch, v);
+        if constexpr (OUT2) {
+          if (ch < p.n2) Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + ch, v);
+        }
+      }
+    }
+    if (tn < ntiles) lstore(buf ^ 1, tn);     // (every wave is past its reads of buffer buf ^ 1: they ended before the last barrier)
+    __syncthreads();
+  }
+}
+
+extern "C" int tdeed_gemm_rs_fits(int M, int K, int N) { return (K == 320 && N == 320 && M > 0) ? 1 : 0; }
+
+// same contract as tdeed_gemm_ws_fwd (weights from engine.pack_ws_weights, bf16) without the stride-2 row gather
+extern "C" int tdeed_gemm_rs_fwd(const void* A, long lda, const void* A0, long lda0, int k0, const float* a_scale,
+                                 int a_scale_rows, int M, int K, int N, const void* Wfrag, const float* scale,
+                                 const float* shift, const void* R, long ldr, int act, void* C, long ldc, void* C2, long ldc2,
+                                 int n2, void* stream) {
+  TD_CHECK(A && Wfrag && C, "gemm_rs: null pointer");
+  TD_CHECK(tdeed_gemm_rs_fits(M, K, N), "gemm_rs: M=%d K=%d N=%d unsupported (K = N = 320)", M, K, N);
+  TD_CHECK(lda % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0), "gemm_rs: row strides must be multiples of 8");
+  TD_CHECK(!A0 || (k0 % 8 == 0 && lda0 % 8 == 0 && k0 <= K), "gemm_rs: bad splice");
+  TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm_rs: bad second output");
+  TD_CHECK(!a_scale || (a_scale_rows >= RS_ROWS), "gemm_rs: a tile of %d rows must span at most two frames (rows per frame %d)",
+           RS_ROWS, a_scale_rows);
+  GemmWsP p;
+  p.A = A; p.lda = lda; p.A0 = A0; p.lda0 = lda0; p.k0 = A0 ? k0 : 0;
+  p.a_scale = a_scale; p.a_scale_rows = a_scale_rows > 0 ? a_scale_rows : 1;
+  p.M = M; p.K = K; p.N = N; p.Wf = Wfrag; p.scale = scale; p.shift = shift;
+  p.R = R; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
+  p.g_stride = 1; p.g_hi = p.g_wi = p.g_ho = p.g_wo = 0;
+  p.NT = 2 * RS_NW; p.NTS = p.NT;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0;
+  const size_t smem = (size_t)2 * RS_TILE + RS_WTAIL + (size_t)4 * RS_KS * 32 * sizeof(float) + (size_t)2 * N * sizeof(float);
+  TD_CHECK(act == TDEED_ACT_NONE || act == TDEED_ACT_RELU, "gemm_rs: ReLU or no activation only");
+  long grid = ((long)M + RS_ROWS - 1) / RS_ROWS;
+  if (grid > 256) grid = 256;
+  static bool attr[8] = {false};
+#define TD_RS(Sv, Rv, Ov)                                                                                              \
+  do {                                                                                                                 \
+    const int ix = (Sv ? 4 : 0) + (Rv ? 2 : 0) + (Ov ? 1 : 0);                                                         \
+    if (!attr[ix]) {                                                                                                   \
+      if (hipFuncSetAttribute((const void*)gemm_rs_kernel<Sv, Rv, Ov>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              160 * 1024) != hipSuccess) {                                                             \
+        tdeed_set_error("gemm_rs: hipFuncSetAttribute failed");                                                        \
+        return TDEED_ERR_RUNTIME;                                                                                      \
+      }                                                                                                                \
+      attr[ix] = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gemm_rs_kernel<Sv, Rv, Ov>), dim3((unsigned)grid), dim3(RS_THR), smem, (hipStream_t)stream, p); \
+  } while (0)
+  const bool se = a_scale != nullptr, rs = R != nullptr, o2 = C2 != nullptr;
+  if (se) { if (rs) { if (o2) TD_RS(true, true, true); else TD_RS(true, true, false); }
+            else { if (o2) TD_RS(true, false, true); else TD_RS(true, false, false); } }
+  else { if (rs) { if (o2) TD_RS(false, true, true); else TD_RS(false, true, false); }
+         else { if (o2) TD_RS(false, false, true); else TD_RS(false, false, false); } }
+#undef TD_RS
+  TD_LAUNCH_CHECK("gemm_rs");
+  return TDEED_OK;
+}
+
+// =============================================================================================
 // Split-K contraction for the short sequences of the SGP encoder-decoder (M = B*T of a few hundred rows, K up to
 // 6C): with so few rows a tiled kernel has ~40 workgroups that each walk K in 20+ dependent global->LDS round
 // trips (30-43 us for 0.9 GFLOP).  Here K is cut into chunks of <=192: a workgroup issues ALL loads of its

@@ -196,6 +196,7 @@ def pack_se_mfma(fc1_w, fc2_w, device):
 GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
 WS_NARROW_ONLY = os.environ.get("TDEED_WS_NARROW_ONLY", "1") == "1"
 WS_WIDE_MIN_ROWS = int(os.environ.get("TDEED_WS_WIDE_MIN_ROWS", "250000"))     # 0: never the sliced form
+RS_MIN_ROWS = int(os.environ.get("TDEED_RS_MIN_ROWS", "60000"))                # 0: never the register-stationary kernel
 
 
 class DenseW:
@@ -227,6 +228,14 @@ class DenseW:
     def _use_wide(self, M):
         return self.wide and M is not None and M >= WS_WIDE_MIN_ROWS
 
+    def _use_rs(self, M, kw):
+        """register-stationary kernel (K = N = 320, W in the registers of a 10-wave workgroup): conv1-shaped calls only -- with
+        the SE re-scale and the residual of a conv3 its 168 registers spill and it is no faster than the tiled kernel
+        (tools/bench_ws_wide.py: plain 106 vs 183 us at M = 313 600, conv3 232 vs 249)"""
+        return (RS_MIN_ROWS > 0 and self.wide and M is not None and M >= RS_MIN_ROWS and kw.get("residual") is None
+                and kw.get("a_scale") is None and kw.get("gather") is None and kw.get("lda") is None and kw.get("ldc") is None
+                and ops.gemm_rs_fits(M, self.K, self.N))
+
     def kern(self, M):
         """kernel family that serves this layer at M rows"""
         return "gemm_ws" if (self.ws or self._use_wide(M)) else "gemm"
@@ -234,6 +243,9 @@ class DenseW:
     def run(self, A, scale, shift, act, **kw):
         if self.ws:
             return ops.gemm_ws(A, self.w, self.K, self.N, scale, shift, act, **kw)
+        if act in (ops.ACT_NONE, ops.ACT_RELU) and self._use_rs(kw.get("M"), kw):
+            return ops.gemm_rs(A, self.w_wide, self.K, self.N, scale, shift, act,
+                               **{k: v for k, v in kw.items() if k in ("A0", "k0", "out", "M", "out2")})
         if self._use_wide(kw.get("M")):
             return ops.gemm_ws(A, self.w_wide, self.K, self.N, scale, shift, act, **kw)
         return ops.gemm(A, self.w, scale, shift, act, **kw)

@@ -228,6 +228,24 @@ def gemm_ws(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None,
     return out
 
 
+def gemm_rs_fits(M, K, N):
+    return _lib.load().tdeed_gemm_rs_fits(M, K, N) != 0
+
+
+def gemm_rs(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None, a_scale=None, a_scale_rows=0, A0=None, k0=0,
+            out=None, M=None, out2=None):
+    """Register-stationary form of gemm_ws() for K = N = 320 (tdeed_gemm_rs_fwd); Wfrag from engine.pack_ws_weights."""
+    _chk(A, "A", torch.bfloat16)
+    if M is None:
+        M = A.numel() // A.shape[-1]
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    call("tdeed_gemm_rs_fwd", ptr(A), A.shape[-1], ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0, ptr(a_scale),
+         a_scale_rows, M, K, N, ptr(Wfrag), ptr(scale), ptr(shift), ptr(residual),
+         (residual.shape[-1] if residual is not None else 0), act, ptr(out), N, *_out2(out2, A), stream_ptr())
+    return out
+
+
 def gemm_splitk_splits(K):
     return _lib.load().tdeed_gemm_splitk_splits(K)
 

@@ -503,3 +503,30 @@ def test_conv1_in_front_of_the_grouped_conv_equals_the_two_launches(H, W, Cin, C
     torch.cuda.synchronize()
     assert torch.equal(out2, ref) and torch.equal(pooled2, pref)
     assert torch.equal(sc.view(-1, C), sref.view(-1, C)), float((sc.view(-1, C).float() - sref.view(-1, C).float()).abs().max())
+
+
+@pytest.mark.parametrize("M", [196 * 7, 196 * 40 + 0, 64 * 3 + 17])
+def test_register_stationary_contraction_equals_the_tiled_one(M):
+    """tdeed_gemm_rs_fwd (K = N = 320: the whole W in the registers of a 10-wave workgroup, 64-row activation tiles through
+    LDS) against tdeed_gemm_fwd on the same operands, bitwise: plain, with the gate-shift splice, and as conv3 (SE re-scale,
+    residual, ReLU, second compact output)."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_ws_weights
+    K = N = 320
+    hw = 196
+    assert ops.gemm_rs_fits(M, K, N)
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    A0 = torch.randn(M, 80, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    sc, sh = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    gate = torch.rand((M + hw - 1) // hw, K, generator=g).to(DEV)
+    Wd, Wf = W.to(DEV), pack_ws_weights(W.float().numpy(), torch.bfloat16, DEV)
+    for kw in (dict(), dict(A0=A0, k0=80), dict(residual=res, a_scale=gate, a_scale_rows=hw)):
+        o2a = torch.empty((M, 80), dtype=torch.bfloat16, device=DEV)
+        o2b = torch.empty_like(o2a)
+        ref = ops.gemm(A, Wd, sc, sh, ops.ACT_RELU, out2=o2a, **kw)
+        got = ops.gemm_rs(A, Wf, K, N, sc, sh, ops.ACT_RELU, out2=o2b, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and torch.equal(o2a, o2b), (list(kw), float((got.float() - ref.float()).abs().max()))

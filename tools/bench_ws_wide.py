@@ -40,4 +40,19 @@ for (M, K, N) in [(313600, 320, 320), (156800, 320, 320), (313600, 128, 320), (3
         line += f"   ws(mode {mode}) {t1:7.1f} us ({2.0 * M * K * N / t1 / 1e6:6.1f} TF)  max diff {err:.3g}"
     else:
         line += "   ws: does not fit"
+    if ops.gemm_rs_fits(M, K, N):
+        Wf = pack_ws_weights(W.float().cpu().numpy(), torch.bfloat16, "cuda")
+        ops.gemm(A, W, sc, sh, 1, out=out)
+        ref = out.clone()
+        t2 = timeit(lambda: ops.gemm_rs(A, Wf, K, N, sc, sh, 1, out=out))
+        line += f"   rs {t2:7.1f} us ({2.0 * M * K * N / t2 / 1e6:6.1f} TF)  max diff {float((out.float() - ref.float()).abs().max()):.3g}"
+        R = torch.randn(M, N, device="cuda").bfloat16()
+        gate = torch.rand(M // 196, K, device="cuda")
+        t3 = timeit(lambda: ops.gemm(A, W, sc, sh, 1, residual=R, a_scale=gate, a_scale_rows=196, out=out))
+        ref = out.clone()
+        t4 = timeit(lambda: ops.gemm_rs(A, Wf, K, N, sc, sh, 1, residual=R, a_scale=gate, a_scale_rows=196, out=out))
+        line += f" | conv3: tiled {t3:7.1f} us  rs {t4:7.1f} us  max diff {float((out.float() - ref.float()).abs().max()):.3g}"
+        t5 = timeit(lambda: ops.gemm_rs(A, Wf, K, N, sc, sh, 1, residual=R, out=out))
+        t6 = timeit(lambda: ops.gemm_rs(A, Wf, K, N, sc, sh, 1, a_scale=gate, a_scale_rows=196, out=out))
+        line += f" (rs residual only {t5:.1f}, gate only {t6:.1f})"
     print(line, flush=True)
