@@ -442,6 +442,7 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
     hipError_t e = hipFuncSetAttribute((const void*)bneck_kernel<12, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 1, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<12, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { tdeed_set_error("bneck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
     attr_set = true;
   }
@@ -449,6 +450,7 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
   if (KS == 12 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<12, 2, 7>), dim3(grid), dim3(BNK_THR), smem, st, p);
   else if (KS == 5 && fpw == 1) hipLaunchKernelGGL((bneck_kernel<5, 1, 13>), dim3(grid), dim3(BNK_THR), smem, st, p);
   else if (KS == 5 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<5, 2, 8>), dim3(grid), dim3(BNK_THR), smem, st, p);
+  else if (KS == 12 && fpw == 1) hipLaunchKernelGGL((bneck_kernel<12, 1, 7>), dim3(grid), dim3(BNK_THR), smem, st, p);   // e.g. 13 x 7 maps
   else { tdeed_set_error("bneck: KS=%d with %d frames per workgroup", KS, fpw); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("bneck");
   return TDEED_OK;

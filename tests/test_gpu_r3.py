@@ -366,7 +366,8 @@ def test_sliced_weight_stationary_contraction_of_the_wide_layers(M, K, N, hw):
 
 # ------------------------------------------------------------------------------------ whole bottleneck in one launch
 @pytest.mark.parametrize("h,w,C,gw,R,Fp,N", [(7, 7, 368, 8, 92, 96, 37), (14, 14, 152, 8, 38, 40, 5), (7, 7, 152, 8, 38, 0, 6),
-                                              (7, 7, 368, 16, 38, 0, 4), (5, 5, 368, 8, 92, 96, 3)])
+                                              (7, 7, 368, 16, 38, 0, 4), (5, 5, 368, 8, 92, 96, 3), (13, 7, 368, 8, 92, 96, 3),
+                                              (10, 10, 152, 8, 38, 40, 2)])
 def test_one_launch_bottleneck_equals_the_launch_per_layer_chain(h, w, C, gw, R, Fp, N):
     """tdeed_bneck_fwd (conv1 + gate-shift splice -> grouped 3x3 -> SE -> conv3 + shortcut, a workgroup's frames resident in
     LDS) against the four launches it replaces on the same operands -- bitwise, including the compact second output -- and
