@@ -182,6 +182,10 @@ int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int 
  *   (tdeed_amd.engine.pack_mfma_frags); w2f as for tdeed_gconv3x3_fwd (pack_gconv_frags, group width 8 or 16); se_w1f /
  *   se_w2f / R as for tdeed_se_gate_mfma_fwd; s*, h*: folded BatchNorm scale / shift; out [N][h][w][C]; out2 optional
  *   [N*h*w][n2] compact copy of channels [0, n2) (the next block's gate-shift slice).
+ *   gs_gate != NULL (then G must be NULL; Fp = the splice width): the APPLY step of the gate-shift-fuse module
+ *   (impl/gsf.py:66-93, what tdeed_gsf_apply_fused_fwd computes into G) runs inside the load phase -- gs_x: the raw channel
+ *   slice the module reads ([N*h*w][gs_ldx], the block input or its compact copy), gs_gate / gs_ysum / gs_xsum: what
+ *   tdeed_gsf_gate_fwd left, gs_cw1 .. gs_cb2: the fusion conv, gs_T the clip length, gs_F the fold.
  * Bit-identical to tdeed_gemm_fwd -> tdeed_gconv3x3_fwd -> tdeed_se_gate_mfma_fwd -> tdeed_gemm_fwd on the same operands.
  * tdeed_bneck_fits: 7x7x368 (two frames per workgroup) and 14x14x152 are the shapes it was built for.
  * tdeed_bneck_set_debug(buf): diagnostic, int64 [workgroups][16] phase time stamps (null switches it off). */
@@ -190,7 +194,9 @@ int tdeed_bneck_set_debug(void* buf);
 int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f, const float* s1,
                     const float* h1, const void* w2f, const float* s2, const float* h2, const void* se_w1f,
                     const float* se_b1, const void* se_w2f, const float* se_b2, int R, const void* w3f, const float* s3,
-                    const float* h3, void* out, void* out2, int n2, void* stream);
+                    const float* h3, void* out, void* out2, int n2, const void* gs_x, int gs_ldx, const float* gs_gate,
+                    const float* gs_ysum, const float* gs_xsum, const float* gs_cw1, const float* gs_cb1, const float* gs_cw2,
+                    const float* gs_cb2, int gs_T, int gs_F, void* stream);
 
 /* conv3 of a RegNetY bottleneck WITH its SE excitation (timm Bottleneck.forward: x = conv3(se(conv2(x)))):
  * the contraction of tdeed_gemm_fwd whose operand rows are re-scaled per (frame, k) by gates that every workgroup derives

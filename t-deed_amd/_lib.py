@@ -62,7 +62,7 @@ _SIGS = {
     "tdeed_bneck_fits": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_bneck_set_debug": ([P], c_int),
     "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int,
-                         P], c_int),
+                         P, c_int, P, P, P, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_gemm_se_fits": ([c_int, c_int, c_int], c_int),
     "tdeed_gemm_se_fwd": ([P, c_long, c_int, P, c_int, c_float, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_long, P, P,
                            P, c_long, c_int, P, c_long, P, c_long, c_int, P], c_int),

@@ -817,10 +817,12 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
         const int col = co - g * Fh;
         const int ci = g * Fh + (col & 1) * Fq + (col >> 1);
         const float xv = (float)xr[ci];
-        const float r = xv - gc[2 * pl_ + g] * xv;
+        // (explicit fused multiply-adds: bneck.hip computes the same expression while it loads a block's frames, and
+        //  -ffp-contract=fast would otherwise be free to contract the two copies differently)
+        const float r = fmaf(-gc[2 * pl_ + g], xv, xv);
         const float ysh = gs[2 * pl_ + g] * (float)sr[ci];
         const float wv = fwl[ci];
-        o[e] = (bf16_t)(ysh * wv + r * (1.0f - wv));
+        o[e] = (bf16_t)fmaf(ysh, wv, r * (1.0f - wv));
       }
       *reinterpret_cast<bf16x4*>(out + (f * hw + p0 + pl_) * Fp + qd * 4) = o;
     }

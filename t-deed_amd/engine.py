@@ -451,6 +451,10 @@ def _se(pooled, inv_cnt, bw, gate):
 
 SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
+# the gate-shift's apply step inside that launch: opt-in.  Dropping the eleven apply launches outright is worth +9 % (timing
+# experiment), but computed by the bottleneck's one workgroup per CU the step costs 14-18 us per launch against the 15-20 us
+# of the launch it removes (which runs 800 small workgroups at full occupancy): 4130-4184 vs 4156-4176 clips/s, a tie
+GS_APPLY_IN_BNECK = os.environ.get("TDEED_GS_APPLY_IN_BNECK", "0") == "1"
 C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
 C1_GCONV_MAX_CIN = int(os.environ.get("TDEED_C1_GCONV_MAX_CIN", "160"))
 # ... and the downsample shortcut out of the same launch: opt-in (bit-identical, measured slower on the same box: cfg2 3890 vs
@@ -878,14 +882,23 @@ class ForwardEngine:
                 # the gate-shift launches read only channels [0, Fp): from the compact slice the previous block's conv3 wrote
                 # beside its output when there is one (a slice of the channels-last map drags whole cache lines)
                 xg = xs if (xs is not None and xs.shape[-1] == Fp) else x
+                # (opt-in) the module's apply step (fusion weights, gated shifts, blend) inside the one-launch bottleneck's load
+                # phase: the launch and the G tensor disappear
+                apply_in = bool(one_launch and GS_APPLY_IN_BNECK and bw.gs_cw1 is not None
+                                and ("_features." + blk.name + ".gs_out") not in taps)
                 gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
                           ysum=pool.take((N, F), torch.float32),
-                          xsum=pool.take((N, F), torch.float32), out=pool.take((M, Fp), dt))
-                if bw.gs_cw1 is not None:
-                    gb["fw"] = pool.take((B, F, T), torch.float32)
-                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
+                          xsum=pool.take((N, F), torch.float32))
+                if not apply_in:
+                    gb["out"] = pool.take((M, Fp), dt)
+                    if bw.gs_cw1 is not None:
+                        gb["fw"] = pool.take((B, F, T), torch.float32)
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp, ai=apply_in: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf), M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, gates_only=ai),
+                    (M * (2 * F + Fp) * es + M * 16) if not apply_in else (M * F * es + M * 16), 2 * M * F * 27))
+                gs_in = (dict(x=xg, Fp=Fp, F=F, T=T, gate=gb["gate"], ysum=gb["ysum"], xsum=gb["xsum"], cw1=bw.gs_cw1,
+                              cb1=bw.gs_cb1, cw2=bw.gs_cw2, cb2=bw.gs_cb2) if apply_in else None)
                 if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
@@ -904,12 +917,14 @@ class ForwardEngine:
                 nxt = blocks[bi + 1].spec if bi + 1 < len(blocks) else None
                 xs_next = (pool.take((N, h, w, (nxt.gsf_fold + 7) // 8 * 8), dt)
                            if (nxt is not None and nxt.gsf_fold and GS_SLICE) else None)
-                G = gb["out"] if blk.gsf_fold else None
-                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, out=out, xs_next=xs_next: ops.bneck(
+                gsd = gs_in if blk.gsf_fold else None
+                G = gb["out"] if (blk.gsf_fold and gsd is None) else None
+                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, gsd=gsd, out=out, xs_next=xs_next: ops.bneck(
                     x, bw.fused.w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
-                    bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out,
+                    bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, gs=gsd, out=out,
                     out2=(xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None)),
-                    2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
+                    2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es
+                    + (3 * M * blk.gsf_fold * es if gsd is not None else 0),
                     2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
                 for t_ in gs_bufs:
                     pool.give(t_)

@@ -11,6 +11,10 @@ from . import _lib
 from ._lib import call, ptr, stream_ptr, dtype_code, ACT_NONE, ACT_RELU, ACT_GELU  # noqa: F401
 
 
+# timing experiment only (results are wrong with it): what the gate-shift apply launches cost in the overlapped forward
+_EXPERIMENT_SKIP_APPLY = __import__("os").environ.get("TDEED_EXPERIMENT_SKIP_APPLY", "0") == "1"
+
+
 def _chk(t, name, dtype=None):
     if t is None:
         return
@@ -165,16 +169,25 @@ def bneck_fits(h, w, C, R):
     return _lib.load().tdeed_bneck_fits(h, w, C, R) != 0
 
 
-def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, G=None, out=None, out2=None):
+def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, G=None, out=None, out2=None, gs=None):
     """Whole stride-1 bottleneck in one launch (tdeed_bneck_fwd): x (N,h,w,C) bf16 -> (N,h,w,C); G (N*h*w, Fp): gate-shift
-    output spliced into conv1's operand; out2 (N*h*w, n2): compact copy of the first n2 output channels."""
+    output spliced into conv1's operand; out2 (N*h*w, n2): compact copy of the first n2 output channels.
+    gs = dict(x=slice source (N,h,w,ldx), Fp, F, T, gate, ysum, xsum, cw1, cb1, cw2, cb2): the gate-shift APPLY step runs
+    inside the launch instead of producing G (gate / ysum / xsum from gate_shift_gates())."""
     _chk(x, "x", torch.bfloat16); _chk(G, "G", torch.bfloat16); _chk(out2, "out2", torch.bfloat16)
     N, h, w, C = x.shape
     if out is None:
         out = torch.empty_like(x)
-    call("tdeed_bneck_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else 0), N, h, w, C, ptr(w1f), ptr(s1), ptr(h1),
-         ptr(w2f), ptr(s2), ptr(h2), ptr(se_w1f), ptr(se_b1), ptr(se_w2f), ptr(se_b2), R, ptr(w3f), ptr(s3), ptr(h3),
-         ptr(out), ptr(out2), (out2.shape[-1] if out2 is not None else 0), stream_ptr())
+    g = gs or {}
+    if gs is not None:
+        _chk(g["x"], "gs.x", torch.bfloat16)
+        if G is not None:
+            raise ValueError("bneck: either G or gs")
+    call("tdeed_bneck_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else g.get("Fp", 0)), N, h, w, C, ptr(w1f), ptr(s1),
+         ptr(h1), ptr(w2f), ptr(s2), ptr(h2), ptr(se_w1f), ptr(se_b1), ptr(se_w2f), ptr(se_b2), R, ptr(w3f), ptr(s3), ptr(h3),
+         ptr(out), ptr(out2), (out2.shape[-1] if out2 is not None else 0),
+         ptr(g.get("x")), (g["x"].shape[-1] if gs is not None else 0), ptr(g.get("gate")), ptr(g.get("ysum")), ptr(g.get("xsum")),
+         ptr(g.get("cw1")), ptr(g.get("cb1")), ptr(g.get("cw2")), ptr(g.get("cb2")), g.get("T", 0), g.get("F", 0), stream_ptr())
     return out
 
 
@@ -349,7 +362,7 @@ def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
 
 
 def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
-               bufs=None, wqf=None, separate_weight=False):
+               bufs=None, wqf=None, separate_weight=False, gates_only=False):
     """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
     GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out."""
     _chk(x, "x")
@@ -366,7 +379,7 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     if xsum is None:
         xsum = torch.empty((N, F), dtype=torch.float32, device=dev)
     out = bufs.get("out")
-    if out is None:
+    if out is None and not gates_only:
         out = torch.empty((N * h * w, Fp), dtype=x.dtype, device=dev)
     q = bufs.get("q")
     if q is None:
@@ -374,7 +387,11 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     dc = dtype_code(x.dtype)
     call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
          ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+    if gates_only:          # the apply step runs elsewhere (inside tdeed_bneck_fwd): gate / ysum / xsum are the result
+        return None
     if cw1 is not None and not separate_weight:
+        if _EXPERIMENT_SKIP_APPLY:           # timing experiment only (stale G): upper bound of folding this launch away
+            return out
         call("tdeed_gsf_apply_fused_fwd", ptr(x), ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
              B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
         return out
