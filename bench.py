@@ -564,25 +564,27 @@ def main():
     feed = None
     if world == 1 and depth >= 2 and not a.no_feed:       # single-process side measurement (its timed regions hold barriers)
         hosts = [torch.randint(0, 256, (B, T, 3, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
-        # H2D lands in a ring of device staging buffers on two copy streams (the link carries 50 GB/s with one stream, 56
-        # with two); the forward's first act is a device-to-device copy (1 TB/s, 0.12 ms) staging -> the plan's input
+        # H2D lands in a ring of device staging buffers on a copy stream; the forward's first act is a device-to-device copy (1 TB/s, 0.12 ms) staging -> the plan's input
         # buffers, after which the staging slot is free again: the upload of batch i+2 never waits for a forward to END,
         # only for the head of the forward that last used its slot.
-        NST = 3
+        NST = int(os.environ.get("TDEED_FEED_AHEAD", "2")) + 1
         stage = [torch.empty((B, T, 3, H, W), dtype=torch.uint8, device=dev) for _ in range(NST)]
-        copy_sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+        # copy streams the batch is cut over: ONE.  Alone, two streams carry 56 GB/s against 50; next to three forwards in
+        # flight one stream sustains 48 GB/s and two fall to 39 (tools/_feed_ab.sh: 3190 vs 2630 clips/s)
+        n_cs = int(os.environ.get("TDEED_FEED_STREAMS", "1"))
+        copy_sts = [torch.cuda.Stream() for _ in range(n_cs)]
+        ahead = int(os.environ.get("TDEED_FEED_AHEAD", "2"))           # batches uploaded ahead of the forward (<= NST - 1)
         freed = [None] * NST              # event: the D2D copy out of staging slot j has run
         arrived = [None] * NST
 
         def upload(step):
             j = step % NST
-            half = B // 2
             evs = []
             for k_, cs in enumerate(copy_sts):
                 with torch.cuda.stream(cs):
                     if freed[j] is not None:
                         cs.wait_event(freed[j])
-                    lo, hi = (0, half) if k_ == 0 else (half, B)
+                    lo, hi = B * k_ // n_cs, B * (k_ + 1) // n_cs
                     stage[j][lo:hi].copy_(hosts[step % 3][lo:hi], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(cs)
@@ -590,9 +592,8 @@ def main():
             arrived[j] = evs
 
         def run_fed(n):
-            upload(0)
-            if n > 1:
-                upload(1)
+            for k0_ in range(min(ahead, n)):
+                upload(k0_)
             for i in range(n):
                 p_, j = i % depth, i % NST
                 pl = plans[p_]
@@ -606,15 +607,15 @@ def main():
                     ev.record(streams[p_])
                     freed[j] = ev
                     eng.run_plan(pl)
-                if i + 2 < n:
-                    upload(i + 2)
+                if i + ahead < n:
+                    upload(i + ahead)
 
         run_fed(6)
         walls_f, _ = timed_regions(run_fed, a.steps, 3, dev, streams + copy_sts)
         el_f = statistics.median(walls_f)
         feed = dict(value=round(B * a.steps / el_f, 2), unit="clips/s", ms_per_step=round(el_f / a.steps * 1e3, 4),
                     h2d_GBps=round(B * T * 3 * H * W / (el_f / a.steps) / 1e9, 2),
-                    note="uint8 clips in pinned host memory -> async H2D on two copy streams into a ring of 3 device staging "
+                    note="uint8 clips in pinned host memory -> async H2D on a copy stream into a ring of 3 device staging "
                          "buffers, two batches ahead of the forward that consumes them (its first act: a device-to-device copy "
                          "into the plan's input buffers); 15 MB per clip over PCIe",
                     frac_of_resident=round((B * a.steps / el_f) / (world * B * a.steps / el), 3))
