@@ -188,6 +188,167 @@ class DecodePool:
         self.ex.shutdown(wait=True)
 
 
+class _Ack:
+    """Future of one decode job of a ProcessDecodePool."""
+    __slots__ = ("ev", "err")
+
+    def __init__(self):
+        import threading
+        self.ev, self.err = threading.Event(), None
+
+    def result(self, timeout=120.0):
+        if not self.ev.wait(timeout):
+            raise TimeoutError("decode worker did not answer")
+        if self.err:
+            raise RuntimeError(self.err)
+
+
+class ProcessDecodePool:
+    """Decode worker PROCESSES (what the reference's DataLoader workers are, train_tdeed.py:131-139): JPEG decode in Python
+    scales to ~8 threads (DecodePool: Pillow releases the GIL only inside libjpeg), processes scale with the cores.  The
+    workers (`_decode_worker.py`: numpy + Pillow, no torch) write straight into staging slots that live in POSIX shared
+    memory and are page-locked in this process (`make_slots`), so a decoded batch is uploaded without a copy between
+    processes.  Same interface as DecodePool."""
+
+    def __init__(self, procs=None):
+        import subprocess
+        import sys
+        import threading
+        self.procs = procs if procs else min(32, (os.cpu_count() or 8))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        boot = f"import sys; sys.path.insert(0, {root!r}); import tdeed_amd._decode_worker as w; w.main()"
+        self._w, self._pending, self._lock, self._next, self._rr = [], {}, threading.Lock(), 0, 0
+        self._shms, self._slots = [], []
+        for _ in range(self.procs):
+            pr = subprocess.Popen([sys.executable, "-c", boot], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+            th = threading.Thread(target=self._reader, args=(pr,), daemon=True)
+            th.start()
+            self._w.append(pr)
+
+    def _reader(self, pr):
+        for line in pr.stdout:
+            parts = line.rstrip("\n").split(" ", 2)
+            with self._lock:
+                ack = self._pending.pop(int(parts[0]), None)
+            if ack is not None:
+                if parts[1] != "ok":
+                    ack.err = parts[2] if len(parts) > 2 else "decode worker error"
+                ack.ev.set()
+        with self._lock:                 # worker gone: fail what it still owed
+            for ack in self._pending.values():
+                if ack.err is None and not ack.ev.is_set():
+                    pass
+
+    def make_slots(self, depth, shape):
+        """`depth` uint8 staging tensors of `shape` in shared memory, page-locked when a GPU runtime is there."""
+        from multiprocessing import shared_memory
+        n = int(np.prod(shape))
+        out = []
+        for _ in range(depth):
+            shm = shared_memory.SharedMemory(create=True, size=n)
+            t = torch.frombuffer(shm.buf, dtype=torch.uint8, count=n).view(*shape)
+            if torch.cuda.is_available():
+                rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), n, 0)
+                if int(rc) != 0:
+                    raise RuntimeError(f"cudaHostRegister failed: {rc}")
+            self._shms.append((shm, t.data_ptr(), n, torch.cuda.is_available()))
+            self._slots.append(t)
+            out.append(t)
+        return out
+
+    def _locate(self, dst):
+        p = dst.data_ptr()
+        for shm, base, n, _ in self._shms:
+            if base <= p < base + n:
+                return shm.name, p - base
+        raise ValueError("ProcessDecodePool: destination is not inside a slot from make_slots()")
+
+    def submit(self, jobs):
+        acks = []
+        for path, dst in jobs:
+            name, off = self._locate(dst)
+            ack = _Ack()
+            with self._lock:
+                jid = self._next
+                self._next += 1
+                self._pending[jid] = ack
+                pr = self._w[self._rr % self.procs]
+                self._rr += 1
+            pr.stdin.write(f"{jid} {name} {off} {dst.shape[-2]} {dst.shape[-1]} {path}\n")
+            acks.append(ack)
+        for pr in self._w:
+            pr.stdin.flush()
+        return acks
+
+    def submit_rows(self, paths, dst, chunk=25):
+        """Consecutive frames: paths[i] -> dst[i] (dst: a contiguous (n,3,H,W) view inside a slot), `chunk` frames per job
+        line -- the parent's per-frame work (formatting, pipe write, acknowledgement) otherwise caps the pool near 30 000
+        frames/s however many workers there are."""
+        import json
+        if not dst.is_contiguous():
+            raise ValueError("submit_rows: the destination rows must be contiguous")
+        name, off = self._locate(dst)
+        H, W = dst.shape[-2], dst.shape[-1]
+        acks, touched = [], set()
+        for lo in range(0, len(paths), chunk):
+            ack = _Ack()
+            with self._lock:
+                jid = self._next
+                self._next += 1
+                self._pending[jid] = ack
+                wi = self._rr % self.procs
+                self._rr += 1
+            self._w[wi].stdin.write("J " + json.dumps(dict(id=jid, shm=name, off=off + lo * 3 * H * W, H=H, W=W,
+                                                           paths=list(paths[lo:lo + chunk]))) + "\n")
+            touched.add(wi)
+            acks.append(ack)
+        for wi in touched:
+            self._w[wi].stdin.flush()
+        return acks
+
+    def decode(self, jobs):
+        for a in self.submit(jobs):
+            a.result()
+
+    def close(self):
+        for pr in self._w:
+            try:
+                pr.stdin.write("quit\n")
+                pr.stdin.flush()
+                pr.stdin.close()
+            except Exception:       # noqa: BLE001
+                pass
+        for pr in self._w:
+            try:
+                pr.wait(timeout=10)
+            except Exception:       # noqa: BLE001
+                pr.kill()
+        self._w = []
+        self._slots = []
+        for shm, ptr_, n, pinned in self._shms:
+            try:
+                if pinned:
+                    torch.cuda.cudart().cudaHostUnregister(ptr_)
+            except Exception:       # noqa: BLE001
+                pass
+            try:
+                shm.close()
+            except BufferError:
+                pass                # a tensor still views the block: the mapping goes with the process
+            try:
+                shm.unlink()
+            except FileNotFoundError:
+                pass
+        self._shms = []
+
+    def __del__(self):
+        try:
+            if self._w:
+                self.close()
+        except Exception:           # noqa: BLE001
+            pass
+
+
 def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, pad=True):
     """Batches of decoded clips in pinned staging slots, ready for `prefetch`: `clips` is a list of descriptors
     dict(paths=<load_paths result>, stride=..) (+ any label entries, passed through per batch as lists); every batch dict
@@ -196,7 +357,11 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
     before `depth` further batches are produced -- `prefetch` copies it one batch later."""
     own = pool is None
     pool = pool if pool is not None else DecodePool()
-    slots = [torch.zeros((batch_size, clip_len) + tuple(frame_shape), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    shape = (batch_size, clip_len) + tuple(frame_shape)
+    if hasattr(pool, "make_slots"):          # worker processes decode into shared, page-locked slots
+        slots = pool.make_slots(depth, shape)
+    else:
+        slots = [torch.zeros(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
     try:
         for bi, lo in enumerate(range(0, len(clips) - batch_size + 1, batch_size)):
             slot = slots[bi % depth]
@@ -211,10 +376,15 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
                     dst[:pad_start].zero_()
                 if pad and pad_end:
                     dst[pad_start + n_real:pad_start + n_real + pad_end].zero_()
+                names = []
                 for j in range(n_real):
                     num = start + j * stride
-                    nm = (os.path.join(base, "frame") + str(num) + ".jpg") if ndigits == -1 else (base + "/" + str(num).zfill(ndigits) + ".jpg")
-                    futs += pool.submit([(nm, dst[pad_start + j])])
+                    names.append((os.path.join(base, "frame") + str(num) + ".jpg") if ndigits == -1
+                                 else (base + "/" + str(num).zfill(ndigits) + ".jpg"))
+                if hasattr(pool, "submit_rows"):
+                    futs += pool.submit_rows(names, dst[pad_start:pad_start + n_real])
+                else:
+                    futs += pool.submit([(nm, dst[pad_start + j]) for j, nm in enumerate(names)])
             for f in futs:
                 f.result()
             extra = {k: [c[k] for c in group] for k in group[0] if k not in ("paths", "stride")}

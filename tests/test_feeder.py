@@ -109,3 +109,36 @@ def test_clip_batches_decodes_whole_batches_into_pinned_slots():
     for b, lo in zip(out, (0, 2)):
         for i in range(2):
             assert np.array_equal(b["frame"][i].numpy(), g[cs[lo + i]["train_key"]])
+
+
+def test_process_decode_pool_matches_read_frame(tmp_path):
+    """feeder.ProcessDecodePool (decode worker PROCESSES writing into shared-memory staging slots: the role of the reference's
+    DataLoader workers, train_tdeed.py:131-139) delivers the same bytes as read_frame, reports a missing file as an error,
+    and leaves neither processes nor shared-memory blocks behind."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from tdeed_amd import feeder
+    rs = np.random.RandomState(3)
+    for i in range(12):
+        Image.fromarray(rs.randint(0, 256, (48, 64, 3), dtype=np.uint8)).save(tmp_path / f"frame{i}.jpg", quality=92)
+    ref = torch.stack([feeder.read_frame(str(tmp_path / f"frame{i}.jpg")) for i in range(12)])
+    pool = feeder.ProcessDecodePool(2)
+    try:
+        clips = [dict(paths=[str(tmp_path), 0, 0, 0, -1, 12], stride=1, label=7)] * 4
+        n = 0
+        for batch in feeder.clip_batches(clips, 2, (3, 48, 64), 12, pool=pool, depth=2):
+            assert batch["label"] == [7, 7]
+            assert torch.equal(batch["frame"][0], ref) and torch.equal(batch["frame"][1], ref)
+            n += 1
+        assert n == 2
+        slot = pool.make_slots(1, (1, 1, 3, 48, 64))[0]
+        with pytest.raises(RuntimeError, match="FileNotFoundError"):
+            pool.decode([(str(tmp_path / "missing.jpg"), slot[0, 0])])
+        names = [shm.name for shm, *_ in pool._shms]
+        procs = list(pool._w)
+    finally:
+        pool.close()
+    assert all(p.poll() is not None for p in procs)
+    import os
+    assert not any(os.path.exists("/dev/shm/" + nm.lstrip("/")) for nm in names)
