@@ -11,10 +11,6 @@ from . import _lib
 from ._lib import call, ptr, stream_ptr, dtype_code, ACT_NONE, ACT_RELU, ACT_GELU  # noqa: F401
 
 
-# timing experiment only (results are wrong with it): what the gate-shift apply launches cost in the overlapped forward
-_EXPERIMENT_SKIP_APPLY = __import__("os").environ.get("TDEED_EXPERIMENT_SKIP_APPLY", "0") == "1"
-
-
 def _chk(t, name, dtype=None):
     if t is None:
         return
@@ -390,8 +386,6 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     if gates_only:          # the apply step runs elsewhere (inside tdeed_bneck_fwd): gate / ysum / xsum are the result
         return None
     if cw1 is not None and not separate_weight:
-        if _EXPERIMENT_SKIP_APPLY:           # timing experiment only (stale G): upper bound of folding this launch away
-            return out
         call("tdeed_gsf_apply_fused_fwd", ptr(x), ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
              B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
         return out
