@@ -300,6 +300,624 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
 }
 
 #define FRONT_LDS_CAP (80 * 1024)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Rolling form of the same launch.  s1_front_kernel above gives every conv2 output row band its own workgroup, which with
+// one-row bands (what 48 KB of LDS = three workgroups per CU allows) recomputes half of the conv1 rows and three of every
+// seven input rows.  Here a workgroup walks a STRIP of S consecutive output rows: the conv1 rows live in a ring of three
+// LDS rows and the normalised input rows in a ring of eight, so a step adds four input rows and two conv1 rows to what the
+// previous step left (S = 8: 35 input / 17 conv1 rows per strip instead of 56 / 24).  Same arithmetic, same order per
+// output element; the squeeze sums come as one partial row per strip.
+template <int NT1>
+__global__ __launch_bounds__(256) void s1_front_roll_kernel(const FrontP p, int S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[4][16];
+  __shared__ __attribute__((aligned(16))) bf16_t zero16[8];           // operand of the two unused k-slots of the stem patch
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int nstrips = (p.Ho + S - 1) / S;
+  const int bnd = (int)(lid % nstrips), n = (int)(lid / nstrips);
+  const int oy0 = bnd * S;
+  const int nrows_out = min(S, p.Ho - oy0);
+  const int INW = p.cw + 2, Y1W = p.Ws + 2;
+  bf16_t* inp = reinterpret_cast<bf16_t*>(smem);                       // [8][INW][4] ring of normalised input rows
+  const int in_bytes = (8 * INW * 8 + 15) & ~15;
+  unsigned char* y1t = smem + in_bytes;                                 // [3][Y1W][PS] ring of conv1 rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, q = lane >> 4;
+  const int cpp = p.PS >> 4;
+  // ---- once: halo columns of both rings
+  {
+    const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (tid < 8) zero16[tid] = (bf16_t)0.f;
+    for (int i = tid; i < 16; i += 256)
+      *reinterpret_cast<bf16x4*>(inp + ((long)(i >> 1) * INW + ((i & 1) ? (p.cw + 1) : 0)) * 4) = z4;
+    for (int i = tid; i < 3 * 2 * cpp; i += 256) {
+      const int j = i % cpp, rc = i / cpp;
+      const int rr = rc >> 1, col = (rc & 1) ? (p.Ws + 1) : 0;
+      *reinterpret_cast<u32x4*>(y1t + ((long)rr * Y1W + col) * p.PS + j * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  // ---- weights and BatchNorm affines (as in s1_front_kernel)
+  bf16x8 swf[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swf[t][ks] = p.stem_wf[(t * 2 + ks) * 64 + lane];
+  float ssc[8], ssh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = (e < 4) ? (4 * q + e) : (16 + 4 * q + e - 4);
+    ssc[e] = p.stem_sc[c];
+    ssh[e] = p.stem_sh[c];
+  }
+  bf16x8 w1r[NT1], wdr[NT1];
+  float c1s[NT1][4], c1h[NT1][4], cds[NT1][4], cdh[NT1][4];
+#pragma unroll
+  for (int t = 0; t < NT1; ++t) {
+    w1r[t] = p.w1f[t * 64 + lane];
+    wdr[t] = p.wdf[t * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int chn = t * 16 + 4 * q + e;
+      const bool ok = chn < p.C1;
+      c1s[t][e] = ok ? p.sc1[chn] : 0.f; c1h[t][e] = ok ? p.sh1[chn] : 0.f;
+      cds[t][e] = ok ? p.scd[chn] : 0.f; cdh[t][e] = ok ? p.shd[chn] : 0.f;
+    }
+  }
+  const int units = p.CSP >> 4;
+  const int unit = wv % units;
+  const int mstep = 4 / units;
+  bf16x8 wf[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) wf[ks] = p.w2f[(unit * 5 + ks) * 64 + lane];
+  int tdy[5], toff[5];                      // per k-slot: tap row (0..2) and the offset of the tap inside a conv1 row
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) {
+    const int sidx = 4 * ks + q;
+    const int half = sidx / 9, tap = sidx - half * 9;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    tdy[ks] = sidx < 18 ? dy : 0;
+    toff[ks] = sidx < 18 ? dx * p.PS + half * 16 + unit * 32 : unit * 32;
+  }
+  const int ch0 = unit * 16 + q * 4;
+  float sc2[4], sh2[4], psum[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = ch0 + r < p.C1;
+    sc2[r] = ok ? p.sc2[ch0 + r] : 0.f;
+    sh2[r] = ok ? p.sh2[ch0 + r] : 0.f;
+    psum[r] = 0.f;
+  }
+  const float na[3] = {1.0f / (255.0f * 0.229f), 1.0f / (255.0f * 0.224f), 1.0f / (255.0f * 0.225f)};
+  const float nb[3] = {-0.485f / 0.229f, -0.456f / 0.224f, -0.406f / 0.225f};
+  const uint8_t* src = p.frames + (long)n * 3 * p.H * p.W;
+  const long plane = (long)p.H * p.W;
+  const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  const int tiles_per_row = (p.Ws + 15) >> 4;
+  const IDiv dtpr(tiles_per_row);
+  const int nch = p.cw >> 4;
+  const IDiv dnch(max(nch, 1)), dcw(p.cw);
+  __syncthreads();
+
+  for (int k = 0; k < nrows_out; ++k) {
+    const int oy = oy0 + k;
+    // ---- A. new input rows -> ring (slot = (row + 8) & 7); rows outside the crop are zeros
+    {
+      const int ir0 = k == 0 ? 4 * oy - 3 : 4 * oy;
+      const int nir = k == 0 ? 7 : 4;
+      if (p.vec16) {
+        for (int i = tid; i < nir * nch; i += 256) {
+          int kq, r;
+          dnch.divmod(i, r, kq);
+          const int iy = ir0 + r;
+          bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)((iy + 8) & 7) * INW + 16 * kq + 1) * 4);
+          if (iy >= 0 && iy < p.ch) {
+            const int scol = p.flip ? (p.cw - 16 - 16 * kq) : 16 * kq;
+            const uint8_t* s0 = src + (long)(p.top + iy) * p.W + p.left + scol;
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(s0);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(s0 + plane);
+            const u32x4 v2 = *reinterpret_cast<const u32x4*>(s0 + 2 * plane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const unsigned int sh8 = 8 * (e & 3);
+              bf16x4 o;
+              o[0] = (bf16_t)fmaf((float)((v0[e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
+              o[1] = (bf16_t)fmaf((float)((v1[e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
+              o[2] = (bf16_t)fmaf((float)((v2[e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
+              o[3] = (bf16_t)0.f;
+              dst[p.flip ? (15 - e) : e] = o;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[e] = z4;
+          }
+        }
+      } else {
+        for (int i = tid; i < nir * p.cw; i += 256) {
+          int r, ix;
+          dcw.divmod(i, r, ix);
+          const int iy = ir0 + r;
+          bf16x4 v4 = z4;
+          if (iy >= 0 && iy < p.ch) {
+            const int sx = p.flip ? (p.cw - 1 - ix) : ix;
+            const long o = (long)(p.top + iy) * p.W + (p.left + sx);
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) v4[c3] = (bf16_t)fmaf((float)src[c3 * plane + o], na[c3], nb[c3]);
+          }
+          *reinterpret_cast<bf16x4*>(inp + ((long)((iy + 8) & 7) * INW + ix + 1) * 4) = v4;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B. new conv1 rows (stem -> conv1 -> ring slot (r + 3) % 3) and the downsample of the even one
+    {
+      const int r_first = k == 0 ? 2 * oy - 1 : 2 * oy;
+      const int nr = k == 0 ? 3 : 2;
+      // rows outside the stem map are the grouped conv's zero padding
+      for (int j = 0; j < nr; ++j) {
+        const int r = r_first + j;
+        if (r >= 0 && r < p.Hs) continue;
+        unsigned char* rowp = y1t + (long)((r + 3) % 3) * Y1W * p.PS;
+        for (int i = tid; i < Y1W * cpp; i += 256) *reinterpret_cast<u32x4*>(rowp + (long)i * 16) = (u32x4){0u, 0u, 0u, 0u};
+      }
+      const int r_lo = max(r_first, 0), r_hi = min(r_first + nr, p.Hs);
+      const int ntiles = max(r_hi - r_lo, 0) * tiles_per_row;
+      for (int tI = wv; tI < ntiles; tI += 4) {
+        int rq, rm;
+        dtpr.divmod(tI, rq, rm);
+        const int r = r_lo + rq;
+        const int c = rm * 16 + px;
+        const bool cok = c < p.Ws;
+        const int cc = cok ? c : (p.Ws - 1);
+        f32x4 sa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int s = 4 * ks + q;
+          const int ky = s >> 1, half = s & 1;
+          const bf16_t* xp = (s < 6) ? inp + (((2 * r - 1 + ky + 8) & 7) * INW + 2 * cc + 2 * half) * 4 : zero16;
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp);
+          sa[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][ks], xf, sa[0], 0, 0, 0);
+          sa[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][ks], xf, sa[1], 0, 0, 0);
+        }
+        bf16x8 sf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sf[e] = (bf16_t)(sa[0][e] * ssc[e] + ssh[e]);
+          sf[4 + e] = (bf16_t)(sa[1][e] * ssc[4 + e] + ssh[4 + e]);
+        }
+        sf = relu_bf16x8(sf);
+        unsigned char* y1p = y1t + (((r + 3) % 3) * Y1W + (cc + 1)) * p.PS;
+        const bool do_ds = (r & 1) == 0 && (r >> 1) == oy;
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+          const int c0 = t * 16 + 4 * q;
+          f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t], sf, a1, 0, 0, 0);
+          if (cok) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(a1[e] * c1s[t][e] + c1h[t][e]);
+            *reinterpret_cast<bf16x4*>(y1p + c0 * 2) = relu_bf16x4(o);
+          }
+          if (do_ds) {
+            f32x4 ad = {0.f, 0.f, 0.f, 0.f};
+            ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdr[t], sf, ad, 0, 0, 0);
+            if (cok && (c & 1) == 0 && c0 < p.C1) {
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(ad[e] * cds[t][e] + cdh[t][e]);
+              *reinterpret_cast<bf16x4*>(p.shortcut + (((long)n * p.Ho + oy) * p.Wo + (c >> 1)) * p.C1 + c0) = o;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- C. grouped 3x3 stride 2 for output row oy from the ring (conv1 rows 2 oy - 1 .. 2 oy + 1)
+    {
+      int off[5];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) off[ks] = ((2 * oy - 1 + tdy[ks] + 3) % 3) * Y1W * p.PS + toff[ks];
+      const int ntl = (p.Wo + 15) >> 4;
+      bf16_t* yout = p.y2 + ((long)n * p.Ho + oy) * p.Wo * p.C1;
+      for (int mt = wv / units; mt < ntl; mt += mstep) {
+        const int ox = mt * 16 + px;
+        const bool pok = ox < p.Wo;
+        const unsigned char* base = y1t + (long)((pok ? ox : 0) * 2) * p.PS;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + off[ks]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc, 0, 0, 0);
+        }
+        if (pok && ch0 < p.C1) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[r] * sc2[r] + sh2[r]);
+          o = relu_bf16x4(o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) psum[r] += (float)o[r];
+          *reinterpret_cast<bf16x4*>(yout + (long)ox * p.C1 + ch0) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- squeeze sums of the strip
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = psum[r];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (px == 0) red[wv][q * 4 + r] = v;
+  }
+  __syncthreads();
+  if (tid < units * 16) {
+    const int u = tid >> 4, cc = tid & 15;
+    float sres = 0.f;
+    for (int w2 = u; w2 < 4; w2 += units) sres += red[w2][cc];
+    const int chn = u * 16 + cc;
+    if (chn < p.C1) p.pooled[((long)n * nstrips + bnd) * p.C1 + chn] = sres;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pipelined form of the strip walk: the three phases of a step depend on each other but not on the SAME step of the other
+// phases, so eight waves split into roles and run skewed by one step each - wave 0 fetches and normalises the input rows of
+// step j (its global loads for step j + 1 stay in flight across the barrier: the barrier fences LDS only), waves 1-5 turn
+// the rows of step j - 1 into conv1 rows, waves 6-7 contract the conv1 rows of step j - 2 into an output row - with ONE
+// barrier per step.  Each role holds only its own weights in registers (119 VGPRs: two workgroups per CU).  Rings: 16 input
+// rows, 5 conv1 rows.  CSP <= 32 and 16-byte-aligned crops; the rolling kernel above takes everything else.
+// Measured (800 frames 224 x 224, regnety_002 widths): band form 434 us, rolling 389 us, this 247 us; the role split
+// 2 / 4 / 2 gives 252 us, ten waves (2 / 6 / 2) do not fit twice on a CU and give 315 us.
+#define LDS_BARRIER()                                                  \
+  do {                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");    \
+    __builtin_amdgcn_s_barrier();                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");    \
+  } while (0)
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PIPE_NWA = 1, PIPE_NWB = 5;                                // waves of roles A and B (C: 2)
+constexpr int PIPE_NT = 64 * (PIPE_NWA + PIPE_NWB + 2);
+template <int NT1>
+__global__ __launch_bounds__(PIPE_NT, 4) void s1_front_pipe_kernel(const FrontP p, int S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[2][16];
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int nstrips = (p.Ho + S - 1) / S;
+  const int bnd = (int)(lid % nstrips), n = (int)(lid / nstrips);
+  const int oy0 = bnd * S;
+  const int nrows_out = min(S, p.Ho - oy0);
+  const int NS = nrows_out + 2;                                         // super-steps: the roles run skewed by one each
+  const int INW = p.cw + 2, Y1W = p.Ws + 2;
+  // smem[0..16) stays zero: the operand of the two unused k-slots of the 3 x 3 x 2 stem patch
+  bf16_t* inp = reinterpret_cast<bf16_t*>(smem + 16);                  // [16][INW][4] ring of normalised input rows
+  const int in_bytes = (16 * INW * 8 + 15) & ~15;
+  unsigned char* y1t = smem + 16 + in_bytes;                                 // [5][Y1W][PS] ring of conv1 rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, q = lane >> 4;
+  const int cpp = p.PS >> 4;
+  {
+    const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (tid < 2) reinterpret_cast<bf16x4*>(smem)[tid] = z4;
+    for (int i = tid; i < 32; i += PIPE_NT)
+      *reinterpret_cast<bf16x4*>(inp + ((long)(i >> 1) * INW + ((i & 1) ? (p.cw + 1) : 0)) * 4) = z4;
+    for (int i = tid; i < 5 * 2 * cpp; i += PIPE_NT) {
+      const int j = i % cpp, rc = i / cpp;
+      const int rr = rc >> 1, col = (rc & 1) ? (p.Ws + 1) : 0;
+      *reinterpret_cast<u32x4*>(y1t + ((long)rr * Y1W + col) * p.PS + j * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  __syncthreads();
+
+  if (wv < PIPE_NWA) {
+    // =============================== role A: uint8 planes -> normalised bf16 pixels in the ring (slot = (row + 16) & 15)
+    const float na[3] = {1.0f / (255.0f * 0.229f), 1.0f / (255.0f * 0.224f), 1.0f / (255.0f * 0.225f)};
+    const float nb[3] = {-0.485f / 0.229f, -0.456f / 0.224f, -0.406f / 0.225f};
+    const uint8_t* src = p.frames + (long)n * 3 * p.H * p.W;
+    const long plane = (long)p.H * p.W;
+    const bf16x4 z4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    const int nch8 = p.cw >> 3;
+    const IDiv dn8(nch8);
+    constexpr int NTA = PIPE_NWA * 64, MAXP = 256 / NTA;               // 4 rows x (cw / 8) chunks <= MAXP x NTA lanes: cw <= 512
+    auto fetch = [&](int iy, int c8, u32x2* v) {
+      const int scol = p.flip ? (p.cw - 8 - 8 * c8) : 8 * c8;
+      const uint8_t* s0 = src + (long)(p.top + iy) * p.W + p.left + scol;
+      v[0] = *reinterpret_cast<const u32x2*>(s0);
+      v[1] = *reinterpret_cast<const u32x2*>(s0 + plane);
+      v[2] = *reinterpret_cast<const u32x2*>(s0 + 2 * plane);
+    };
+    auto put = [&](int iy, int c8, bool ok, const u32x2* v) {
+      bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)((iy + 16) & 15) * INW + 8 * c8 + 1) * 4);
+      if (ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned int sh8 = 8 * (e & 3);
+          bf16x4 o;
+          o[0] = (bf16_t)fmaf((float)((v[0][e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
+          o[1] = (bf16_t)fmaf((float)((v[1][e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
+          o[2] = (bf16_t)fmaf((float)((v[2][e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
+          o[3] = (bf16_t)0.f;
+          dst[p.flip ? (7 - e) : e] = o;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = z4;
+      }
+    };
+    // steady state: the four rows of step k are fetched one super-step ahead into `pre`
+    u32x2 preA[MAXP][3], preB[MAXP][3];
+    // (loads are unconditional - clamped lanes and rows re-read a valid chunk - so that the compiler can count them: a load
+    // under a branch makes every later wait a vmcnt(0), which would drain the fetch-ahead)
+    auto issue = [&](int k, u32x2 (*pre)[3]) {
+      const int ir0 = 4 * (oy0 + k);
+#pragma unroll
+      for (int ps = 0; ps < MAXP; ++ps) {
+        const int i = min(tid + ps * NTA, 4 * nch8 - 1);
+        int r, c8;
+        dn8.divmod(i, r, c8);
+        fetch(min(ir0 + r, p.ch - 1), c8, pre[ps]);
+      }
+    };
+    auto drain = [&](int k, u32x2 (*pre)[3]) {
+      const int ir0 = 4 * (oy0 + k);
+#pragma unroll
+      for (int ps = 0; ps < MAXP; ++ps) {
+        const int i = tid + ps * NTA;
+        int r, c8;
+        dn8.divmod(i, r, c8);
+        const int iy = ir0 + r;
+        if (i < 4 * nch8) put(iy, c8, iy < p.ch, pre[ps]);
+      }
+    };
+    auto stepA = [&](int j, u32x2 (*cur)[3], u32x2 (*nxt)[3]) {
+      if (j < nrows_out) {
+        issue(min(j + 1, nrows_out - 1), nxt);
+        if (j == 0) {
+          const int ir0 = 4 * oy0 - 3;
+          for (int i = tid; i < 7 * nch8; i += NTA) {
+            int r, c8;
+            dn8.divmod(i, r, c8);
+            const int iy = ir0 + r;
+            const bool ok = iy >= 0 && iy < p.ch;
+            u32x2 v[3];
+            if (ok) fetch(iy, c8, v);
+            put(iy, c8, ok, v);
+          }
+        } else {
+          drain(j, cur);
+        }
+      }
+      LDS_BARRIER();
+    };
+    for (int j = 0; j < NS; j += 2) {
+      stepA(j, preA, preB);
+      if (j + 1 < NS) stepA(j + 1, preB, preA);
+    }
+  } else if (wv < PIPE_NWA + PIPE_NWB) {
+    // =============================== role B: stem -> conv1 rows into the ring (slot = (r + 5) % 5), downsample of the even row
+    // The SIMDs' instruction issue is what this role is short of: everything that depends only on the step (ring slots) is
+    // scalar, a tile's per-lane addressing is a handful of adds and selects, and lanes past the map's edge duplicate the edge
+    // column (same value to the same address) instead of being masked.
+    constexpr int NWB = PIPE_NWB;
+    const int bw = wv - PIPE_NWA, btid = tid - PIPE_NWA * 64;
+    bf16x8 swf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) swf[t][ks] = p.stem_wf[(t * 2 + ks) * 64 + lane];
+    float ssc[8], ssh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (e < 4) ? (4 * q + e) : (16 + 4 * q + e - 4);
+      ssc[e] = p.stem_sc[c];
+      ssh[e] = p.stem_sh[c];
+    }
+    bf16x8 w1r[NT1], wdr[NT1];
+    float c1s[NT1][4], c1h[NT1][4], cds[NT1][4], cdh[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      w1r[t] = p.w1f[t * 64 + lane];
+      wdr[t] = p.wdf[t * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int chn = t * 16 + 4 * q + e;
+        const bool ok = chn < p.C1;
+        c1s[t][e] = ok ? p.sc1[chn] : 0.f; c1h[t][e] = ok ? p.sh1[chn] : 0.f;
+        cds[t][e] = ok ? p.scd[chn] : 0.f; cdh[t][e] = ok ? p.shd[chn] : 0.f;
+      }
+    }
+    const int tiles_per_row = (p.Ws + 15) >> 4;
+    const int inv_tpr = 65536 / tiles_per_row + 1;                       // item / tiles_per_row for item < 64 (scalar)
+    const int pitch_in = INW * 8, pitch_y1 = Y1W * p.PS;
+    const bool q_hi = (q & 2) != 0, q_lt2 = q < 2;
+    const int qcol = 16 * (q & 1);                                        // second pixel pair of the 3-wide patch
+    const int st_lane = 8 * q;                                            // this lane's 4 channels inside a pixel of the ring
+    for (int j = 0; j < NS; ++j) {
+      const int k = j - 1;
+      if (k >= 0 && k < nrows_out) {
+        const int oy = oy0 + k;
+        const int r_first = k == 0 ? 2 * oy - 1 : 2 * oy;
+        const int nr = k == 0 ? 3 : 2;
+        for (int jr = 0; jr < nr; ++jr) {                                // rows outside the stem map: the 3x3's zero padding
+          const int r = r_first + jr;
+          if (r >= 0 && r < p.Hs) continue;
+          unsigned char* rowp = y1t + (long)((r + 5) % 5) * pitch_y1;
+          for (int i = btid; i < Y1W * cpp; i += NWB * 64) *reinterpret_cast<u32x4*>(rowp + (long)i * 16) = (u32x4){0u, 0u, 0u, 0u};
+        }
+        const int r_lo = max(r_first, 0), r_hi = min(r_first + nr, p.Hs);
+        const int ntiles = max(r_hi - r_lo, 0) * tiles_per_row;
+        bf16_t* sc_row = p.shortcut + ((long)n * p.Ho + oy) * p.Wo * p.C1;
+        for (int tI = bw; tI < ntiles; tI += NWB) {
+          const int rq = (tI * inv_tpr) >> 16, ct = tI - rq * tiles_per_row;
+          const int r = r_lo + rq;
+          const int ro0 = ((2 * r + 15) & 15) * pitch_in, ro1 = ((2 * r + 16) & 15) * pitch_in, ro2 = ((2 * r + 17) & 15) * pitch_in;
+          const int y1row = ((r + 5) % 5) * pitch_y1;
+          const bool do_ds = (r & 1) == 0 && (r >> 1) == oy;
+          const int cc = min(ct * 16 + px, p.Ws - 1);
+          const int colb = cc * 16 + qcol;
+          const int a0 = 16 + colb + (q_hi ? ro1 : ro0);
+          const int a1 = q_lt2 ? 16 + colb + ro2 : 0;                     // k-slots 6, 7 of the patch: the zero block
+          const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(smem + a0);
+          const bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(smem + a1);
+          f32x4 sa0 = {0.f, 0.f, 0.f, 0.f}, sa1 = {0.f, 0.f, 0.f, 0.f};
+          sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][0], xf0, sa0, 0, 0, 0);
+          sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][0], xf0, sa1, 0, 0, 0);
+          sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][1], xf1, sa0, 0, 0, 0);
+          sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][1], xf1, sa1, 0, 0, 0);
+          bf16x8 sf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sf[e] = (bf16_t)(sa0[e] * ssc[e] + ssh[e]);
+            sf[4 + e] = (bf16_t)(sa1[e] * ssc[4 + e] + ssh[4 + e]);
+          }
+          sf = relu_bf16x8(sf);
+          unsigned char* y1p = y1t + y1row + __mul24(cc + 1, p.PS) + st_lane;
+          f32x4 a1v[NT1], adv[NT1];
+#pragma unroll
+          for (int t = 0; t < NT1; ++t) {
+            a1v[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            a1v[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t], sf, a1v[t], 0, 0, 0);
+          }
+          if (do_ds) {
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) {
+              adv[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              adv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdr[t], sf, adv[t], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < NT1; ++t) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(a1v[t][e] * c1s[t][e] + c1h[t][e]);
+            *reinterpret_cast<bf16x4*>(y1p + t * 32) = relu_bf16x4(o);
+          }
+          if (do_ds) {
+            bf16_t* scp = sc_row + __mul24(cc >> 1, p.C1) + 4 * q;
+            const bool even = (cc & 1) == 0;
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) {
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(adv[t][e] * cds[t][e] + cdh[t][e]);
+              if (even && t * 16 + 4 * q < p.C1) *reinterpret_cast<bf16x4*>(scp + t * 16) = o;
+            }
+          }
+        }
+      }
+      LDS_BARRIER();
+    }
+  } else {
+    // =============================== role C: grouped 3x3 stride 2 for one output row from the conv1 ring + squeeze sums
+    const int cwv = wv - PIPE_NWA - PIPE_NWB;
+    const int unit = NT1 == 2 ? cwv : 0;
+    const int mt0 = NT1 == 2 ? 0 : cwv, mstep = NT1 == 2 ? 1 : 2;
+    bf16x8 wf[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) wf[ks] = p.w2f[(unit * 5 + ks) * 64 + lane];
+    const int pitch_y1 = Y1W * p.PS;
+    int tdy[5], toff[5];                                                  // per k-slot: tap row (0..2) and the tap's offset in a row
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int sidx = 4 * ks + q;
+      const int half = sidx / 9, tap = sidx - half * 9;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      tdy[ks] = sidx < 18 ? dy : 0;
+      toff[ks] = (sidx < 18 ? dx * p.PS + half * 16 : 0) + unit * 32;
+    }
+    const int ch0 = unit * 16 + q * 4;
+    float sc2[4], sh2[4], psum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = ch0 + r < p.C1;
+      sc2[r] = ok ? p.sc2[ch0 + r] : 0.f;
+      sh2[r] = ok ? p.sh2[ch0 + r] : 0.f;
+      psum[r] = 0.f;
+    }
+    const int ntl = (p.Wo + 15) >> 4;
+    const bool chok = ch0 < p.C1;
+    for (int j = 0; j < NS; ++j) {
+      const int k = j - 2;
+      if (k >= 0) {
+        const int oy = oy0 + k;
+        const int rs0 = ((2 * oy + 4) % 5) * pitch_y1, rs1 = ((2 * oy + 5) % 5) * pitch_y1, rs2 = ((2 * oy + 6) % 5) * pitch_y1;
+        int off[5];
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) off[ks] = toff[ks] + (tdy[ks] == 0 ? rs0 : (tdy[ks] == 1 ? rs1 : rs2));
+        bf16_t* yout = p.y2 + ((long)n * p.Ho + oy) * p.Wo * p.C1 + ch0;
+        for (int mt = mt0; mt < ntl; mt += mstep) {
+          const int ox = mt * 16 + px;
+          const bool pok = ox < p.Wo;
+          const unsigned char* base = y1t + __mul24(min(ox, p.Wo - 1), 2 * p.PS);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 5; ++ks) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + off[ks]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf, acc, 0, 0, 0);
+          }
+          if (pok && chok) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[r] * sc2[r] + sh2[r]);
+            o = relu_bf16x4(o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) psum[r] += (float)o[r];
+            *reinterpret_cast<bf16x4*>(yout + __mul24(ox, p.C1)) = o;
+          }
+        }
+      }
+      LDS_BARRIER();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = psum[r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (px == 0) red[cwv][q * 4 + r] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < NT1 * 16) {
+    const int u = tid >> 4, cc = tid & 15;
+    const float sres = NT1 == 2 ? red[u][cc] : red[0][cc] + red[1][cc];
+    const int chn = u * 16 + cc;
+    if (chn < p.C1) p.pooled[((long)n * nstrips + bnd) * p.C1 + chn] = sres;
+  }
+}
+
+// the pipelined form is the default where it applies; TDEED_FRONT_PIPE=0 -> the rolling kernel
+static bool front_pipe() {
+  static int s = -1;
+  if (s < 0) { const char* e = getenv("TDEED_FRONT_PIPE"); s = e ? (atoi(e) != 0) : 1; }
+  return s != 0;
+}
+static size_t front_pipe_smem(int crop_w, int Ws, int PS) {
+  return 16 + (((size_t)16 * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)5 * (Ws + 2) * PS;
+}
+static bool front_pipe_shape(int crop_w, int Ws, int CSP) {
+  return front_pipe() && CSP <= 32 && crop_w <= 512 && crop_w % 16 == 0 && front_pipe_smem(crop_w, Ws, CSP * 2 + 16) <= FRONT_LDS_CAP;
+}
+
+// rows per strip of the strip-walking forms (0: the band form at the top); TDEED_FRONT_ROLL overrides.  A function of the
+// SHAPE only - tdeed_s1_front_parts must agree with the launch whatever the alignment of the frames turns out to be.
+static bool front_pipe_shape(int crop_w, int Ws, int CSP);
+static int front_roll(int crop_w, int Ws, int CSP) {
+  static int s = -2;
+  if (s == -2) { const char* e = getenv("TDEED_FRONT_ROLL"); s = e ? atoi(e) : -1; if (e && s < 0) s = 0; }
+  if (s >= 0) return s;
+  return front_pipe_shape(crop_w, Ws, CSP) ? 28 : 8;
+}
+static size_t front_roll_smem(int crop_w, int Ws, int PS) {
+  return (((size_t)8 * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)3 * (Ws + 2) * PS;
+}
+
 static long front_cap() {
   static long cap = -1;
   if (cap < 0) {
@@ -331,6 +949,7 @@ extern "C" int tdeed_s1_front_parts(int crop_h, int crop_w, int C1) {
   const int Hs = (crop_h + 1) / 2, Ws = (crop_w + 1) / 2, Ho = (Hs + 1) / 2;
   if (C1 % 8 != 0 || C1 < 8 || C1 > 64) return 0;
   const int CSP = C1 > 32 ? 64 : (C1 > 16 ? 32 : 16);
+  if (const int S = front_roll(crop_w, Ws, CSP); S > 0 && front_roll_smem(crop_w, Ws, CSP * 2 + 16) <= FRONT_LDS_CAP) return (Ho + S - 1) / S;
   const int band = front_band(crop_w, Ws, CSP * 2 + 16, Ho);
   if (band <= 0 || front_smem(crop_w, Ws, CSP * 2 + 16, band) > FRONT_LDS_CAP) return 0;
   return (Ho + band - 1) / band;
@@ -359,6 +978,41 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
   p.PS = p.CSP * 2 + 16;
   p.Hs = (crop_h + 1) / 2; p.Ws = (crop_w + 1) / 2;
   p.Ho = (p.Hs + 1) / 2; p.Wo = (p.Ws + 1) / 2;
+  p.vec16 = (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
+            (((uintptr_t)frames & 15) == 0);
+  if (const int S = front_roll(crop_w, p.Ws, p.CSP); S > 0 && front_roll_smem(crop_w, p.Ws, p.PS) <= FRONT_LDS_CAP) {
+    const int nstrips = (p.Ho + S - 1) / S;
+    const size_t smr = front_roll_smem(crop_w, p.Ws, p.PS);
+    p.band = S; p.nbands = nstrips;
+    static bool attr_r = false;
+    if (!attr_r) {
+      hipError_t e = hipFuncSetAttribute((const void*)s1_front_roll_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_roll_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_roll_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+      if (e != hipSuccess) { tdeed_set_error("s1_front: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+      attr_r = true;
+    }
+    const int nt1r = p.CSP >> 4;
+    if (p.vec16 && front_pipe_shape(crop_w, p.Ws, p.CSP)) {
+      static bool attr_p = false;
+      if (!attr_p) {
+        hipError_t e = hipFuncSetAttribute((const void*)s1_front_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
+        if (e != hipSuccess) { tdeed_set_error("s1_front: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+        attr_p = true;
+      }
+      const size_t smp = front_pipe_smem(crop_w, p.Ws, p.PS);
+      if (nt1r == 1) hipLaunchKernelGGL(s1_front_pipe_kernel<1>, dim3(nstrips * N), dim3(PIPE_NT), smp, (hipStream_t)stream, p, S);
+      else hipLaunchKernelGGL(s1_front_pipe_kernel<2>, dim3(nstrips * N), dim3(PIPE_NT), smp, (hipStream_t)stream, p, S);
+      TD_LAUNCH_CHECK("s1_front_pipe");
+      return TDEED_OK;
+    }
+    if (nt1r == 1) hipLaunchKernelGGL(s1_front_roll_kernel<1>, dim3(nstrips * N), dim3(256), smr, (hipStream_t)stream, p, S);
+    else if (nt1r == 2) hipLaunchKernelGGL(s1_front_roll_kernel<2>, dim3(nstrips * N), dim3(256), smr, (hipStream_t)stream, p, S);
+    else hipLaunchKernelGGL(s1_front_roll_kernel<4>, dim3(nstrips * N), dim3(256), smr, (hipStream_t)stream, p, S);
+    TD_LAUNCH_CHECK("s1_front_roll");
+    return TDEED_OK;
+  }
   p.band = front_band(crop_w, p.Ws, p.PS, p.Ho);
   TD_CHECK(p.band > 0 && front_smem(crop_w, p.Ws, p.PS, p.band) <= FRONT_LDS_CAP,
            "s1_front: a row band of %d px does not fit LDS (use the unfused kernels)", crop_w);

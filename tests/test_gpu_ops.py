@@ -280,7 +280,11 @@ def test_avgpool_posenc(ops, dtype):
 
 
 @pytest.mark.parametrize("geom", [(2, 64, 64, None, False, 24, 8), (1, 72, 80, (4, 8, 64, 64), True, 24, 8),
-                                  (1, 224, 224, None, False, 24, 8), (1, 96, 64, None, False, 64, 16)])
+                                  (1, 224, 224, None, False, 24, 8), (1, 96, 64, None, False, 64, 16),
+                                  # pipelined strip kernel: aligned crop + flip, one-tile width (C1 = 16), ragged last strip,
+                                  # odd crop (-> rolling kernel)
+                                  (1, 96, 112, (16, 16, 64, 96), True, 24, 8), (2, 64, 64, None, True, 16, 8),
+                                  (1, 240, 224, None, False, 24, 8), (1, 70, 90, (3, 5, 61, 77), True, 24, 8)])
 def test_s1_front_fused_vs_unfused_reference(ops, geom):
     """stem -> conv1 -> conv2 (+ squeeze) and the stride-2 shortcut in one kernel == the same chain in torch fp32."""
     from tdeed_amd.engine import pack_front_weights

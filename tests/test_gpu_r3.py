@@ -2,6 +2,9 @@
 SoccerNetBall long-clip train step (BASELINE configs[4]: 800MF, T=250) against autograd on the oracle, the bf16 train step
 of BASELINE configs[2] at its real batch (B=16) eager vs captured, and captured training graphs that share an engine
 with eager steps and with each other.  -m gpu only."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -575,3 +578,16 @@ def test_gate_shift_apply_inside_the_one_launch_bottleneck(h, w, C, F, B, T, com
     torch.cuda.synchronize()
     assert torch.isfinite(got.float()).all()
     assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+
+
+@pytest.mark.parametrize("env", [{"TDEED_FRONT_ROLL": "5"}, {"TDEED_FRONT_PIPE": "0"}, {"TDEED_FRONT_PIPE": "0", "TDEED_FRONT_ROLL": "3"},
+                                 {"TDEED_FRONT_ROLL": "0"}])
+def test_s1_front_forms_agree(env):
+    """The three forms of the stage-1 front launch (row bands, rolling strips, pipelined strips) are selected per process:
+    each passes the same fused-vs-unfused comparison, at strip heights that leave ragged last strips."""
+    import subprocess
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(os.path.dirname(__file__), "test_gpu_ops.py"), "-q", "-m", "gpu",
+                        "-k", "s1_front", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "8 passed" in r.stdout, r.stdout[-500:]
