@@ -912,7 +912,7 @@ static int front_roll(int crop_w, int Ws, int CSP) {
   static int s = -2;
   if (s == -2) { const char* e = getenv("TDEED_FRONT_ROLL"); s = e ? atoi(e) : -1; if (e && s < 0) s = 0; }
   if (s >= 0) return s;
-  return front_pipe_shape(crop_w, Ws, CSP) ? 28 : 8;
+  return (front_pipe_shape(crop_w, Ws, CSP) || CSP > 32) ? 28 : 8;        // measured: A/B lines in profiles/r03_front_strips.txt
 }
 static size_t front_roll_smem(int crop_w, int Ws, int PS) {
   return (((size_t)8 * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)3 * (Ws + 2) * PS;
