@@ -48,6 +48,30 @@ TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r03_train_hbm_traffic.json")
 TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
 
 
+def _masked_streams(depth, mode):
+    """`depth` HIP streams, each confined to its own 1/depth of the CUs: every `depth`-th CU ("interleave") or a contiguous
+    block of the CU numbering ("block").  An experiment: kernels of different batches then never queue for the
+    same CUs."""
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ncu + 31) // 32
+    out = []
+    for s_ in range(depth):
+        bits = [0] * words
+        for i in range(ncu):
+            own = (i % depth == s_) if mode == "interleave" else (i * depth // ncu == s_)
+            if own:
+                bits[i // 32] |= 1 << (i % 32)
+        arr = (ctypes.c_uint32 * words)(*bits)
+        h = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), arr)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out
+
+
 def git_head():
     from tdeed_amd import buildinfo
     return buildinfo.head()
@@ -533,6 +557,8 @@ def main():
     ap.add_argument("--split", type=int, default=1,
                     help="sub-batches of whole clips per batch, each on its own stream inside the batch's HIP graph (1: none; "
                          "2 gives the shortest single-batch latency, 1 with three batches in flight the highest throughput)")
+    ap.add_argument("--cu-mask", default="none", choices=["none", "interleave", "block"],
+                    help="experiment: give each in-flight batch's stream its own share of the CUs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight: consecutive steps alternate between this many independent buffer sets / HIP "
                          "graphs on their own streams, so the latency-bound tail of one batch overlaps the next one's "
@@ -550,7 +576,7 @@ def main():
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     sd = synth.make_state(state_layout.model_state_shapes(cfg), 0)       # random-init weights of the architecture
     depth = max(1, a.inflight)
-    streams = [torch.cuda.Stream() for _ in range(depth)]
+    streams = _masked_streams(depth, a.cu_mask) if a.cu_mask != "none" else [torch.cuda.Stream() for _ in range(depth)]
     stream = streams[0]
     with torch.cuda.stream(stream):
         eng = ForwardEngine(cfg, sd, dt, dev, use_graph=not a.no_graph, n_split=a.split)
