@@ -591,3 +591,28 @@ def test_s1_front_forms_agree(env):
                         "-k", "s1_front", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "8 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("flags", [[], ["--cu-mask", "interleave", "--inflight", "4"]])
+def test_bench_line_contract(flags):
+    """`bench.py` prints ONE JSON line with the contract's fields (short run, side measurements off); the same with every
+    in-flight batch's stream confined to its own XCDs (`--cu-mask`)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--repeats", "1", "--no-train",
+                        "--no-feed", "--no-cpu-baseline", *flags], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["config"]["workload"].startswith("rny002_b8") and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(d["value"] - d["config"]["clips_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
