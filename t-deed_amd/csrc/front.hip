@@ -1019,8 +1019,6 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
   p.nbands = (p.Ho + p.band - 1) / p.band;
   const int ny1 = 2 * (p.band - 1) + 3, nin = 2 * (ny1 - 1) + 3;
   const size_t smem = (((size_t)nin * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)ny1 * (p.Ws + 2) * p.PS;
-  p.vec16 = (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
-            (((uintptr_t)frames & 15) == 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)s1_front_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
