@@ -462,52 +462,59 @@ __global__ __launch_bounds__(256) void s1_front_roll_kernel(const FrontP p, int 
       }
       const int r_lo = max(r_first, 0), r_hi = min(r_first + nr, p.Hs);
       const int ntiles = max(r_hi - r_lo, 0) * tiles_per_row;
+      // (addressing as in the pipelined kernel below: ring slots and row bases are scalars of the step, lanes past the map's
+      // edge duplicate the edge column - the same value to the same address - instead of being masked)
+      const int inv_tpr = 65536 / tiles_per_row + 1;                     // tile / tiles_per_row for tile < 64
+      const int pitch_in = INW * 8, pitch_y1 = Y1W * p.PS;
+      const bool q_hi = (q & 2) != 0, q_lt2 = q < 2;
+      const int qcol = 16 * (q & 1);
+      bf16_t* sc_row = p.shortcut + ((long)n * p.Ho + oy) * p.Wo * p.C1;
+      const unsigned char* inb = reinterpret_cast<const unsigned char*>(inp);
       for (int tI = wv; tI < ntiles; tI += 4) {
-        int rq, rm;
-        dtpr.divmod(tI, rq, rm);
+        const int rq = (tI * inv_tpr) >> 16, ct = tI - rq * tiles_per_row;
         const int r = r_lo + rq;
-        const int c = rm * 16 + px;
-        const bool cok = c < p.Ws;
-        const int cc = cok ? c : (p.Ws - 1);
-        f32x4 sa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int s = 4 * ks + q;
-          const int ky = s >> 1, half = s & 1;
-          const bf16_t* xp = (s < 6) ? inp + (((2 * r - 1 + ky + 8) & 7) * INW + 2 * cc + 2 * half) * 4 : zero16;
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp);
-          sa[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][ks], xf, sa[0], 0, 0, 0);
-          sa[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][ks], xf, sa[1], 0, 0, 0);
-        }
+        const int ro0 = ((2 * r + 7) & 7) * pitch_in, ro1 = ((2 * r + 8) & 7) * pitch_in, ro2 = ((2 * r + 9) & 7) * pitch_in;
+        const int y1row = ((r + 3) % 3) * pitch_y1;
+        const bool do_ds = (r & 1) == 0 && (r >> 1) == oy;
+        const int cc = min(ct * 16 + px, p.Ws - 1);
+        const int colb = cc * 16 + qcol;
+        const unsigned char* xp0 = inb + colb + (q_hi ? ro1 : ro0);
+        const unsigned char* xp1 = q_lt2 ? inb + colb + ro2 : reinterpret_cast<const unsigned char*>(zero16);
+        const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(xp0);
+        const bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(xp1);
+        f32x4 sa0 = {0.f, 0.f, 0.f, 0.f}, sa1 = {0.f, 0.f, 0.f, 0.f};
+        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][0], xf0, sa0, 0, 0, 0);
+        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][0], xf0, sa1, 0, 0, 0);
+        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[0][1], xf1, sa0, 0, 0, 0);
+        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(swf[1][1], xf1, sa1, 0, 0, 0);
         bf16x8 sf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          sf[e] = (bf16_t)(sa[0][e] * ssc[e] + ssh[e]);
-          sf[4 + e] = (bf16_t)(sa[1][e] * ssc[4 + e] + ssh[4 + e]);
+          sf[e] = (bf16_t)(sa0[e] * ssc[e] + ssh[e]);
+          sf[4 + e] = (bf16_t)(sa1[e] * ssc[4 + e] + ssh[4 + e]);
         }
         sf = relu_bf16x8(sf);
-        unsigned char* y1p = y1t + (((r + 3) % 3) * Y1W + (cc + 1)) * p.PS;
-        const bool do_ds = (r & 1) == 0 && (r >> 1) == oy;
+        unsigned char* y1p = y1t + y1row + __mul24(cc + 1, p.PS) + 8 * q;
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {
-          const int c0 = t * 16 + 4 * q;
           f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
           a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t], sf, a1, 0, 0, 0);
-          if (cok) {
-            bf16x4 o;
+          bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(a1[e] * c1s[t][e] + c1h[t][e]);
-            *reinterpret_cast<bf16x4*>(y1p + c0 * 2) = relu_bf16x4(o);
-          }
-          if (do_ds) {
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(a1[e] * c1s[t][e] + c1h[t][e]);
+          *reinterpret_cast<bf16x4*>(y1p + t * 32) = relu_bf16x4(o);
+        }
+        if (do_ds) {
+          bf16_t* scp = sc_row + __mul24(cc >> 1, p.C1) + 4 * q;
+          const bool even = (cc & 1) == 0;
+#pragma unroll
+          for (int t = 0; t < NT1; ++t) {
             f32x4 ad = {0.f, 0.f, 0.f, 0.f};
             ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdr[t], sf, ad, 0, 0, 0);
-            if (cok && (c & 1) == 0 && c0 < p.C1) {
-              bf16x4 o;
+            bf16x4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(ad[e] * cds[t][e] + cdh[t][e]);
-              *reinterpret_cast<bf16x4*>(p.shortcut + (((long)n * p.Ho + oy) * p.Wo + (c >> 1)) * p.C1 + c0) = o;
-            }
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(ad[e] * cds[t][e] + cdh[t][e]);
+            if (even && t * 16 + 4 * q < p.C1) *reinterpret_cast<bf16x4*>(scp + t * 16) = o;
           }
         }
       }
