@@ -406,30 +406,35 @@ __global__ __launch_bounds__(256) void s1_front_roll_kernel(const FrontP p, int 
       const int ir0 = k == 0 ? 4 * oy - 3 : 4 * oy;
       const int nir = k == 0 ? 7 : 4;
       if (p.vec16) {
-        for (int i = tid; i < nir * nch; i += 256) {
+        // four pixels per lane: a step's 4 rows x (cw / 4) quads spread over all four waves (16 pixels per lane left the
+        // conversion to one wave: 354 -> 332 us).  Requesting the next step's quads one step ahead as the pipelined kernel
+        // does was measured too: 325 us and 16 more VGPRs, no change at the 800MF widths; not kept.
+        const int nq4 = p.cw >> 2;
+        const IDiv dq4(nq4);
+        for (int i = tid; i < nir * nq4; i += 256) {
           int kq, r;
-          dnch.divmod(i, r, kq);
+          dq4.divmod(i, r, kq);
           const int iy = ir0 + r;
-          bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)((iy + 8) & 7) * INW + 16 * kq + 1) * 4);
+          bf16x4* dst = reinterpret_cast<bf16x4*>(inp + ((long)((iy + 8) & 7) * INW + 4 * kq + 1) * 4);
           if (iy >= 0 && iy < p.ch) {
-            const int scol = p.flip ? (p.cw - 16 - 16 * kq) : 16 * kq;
+            const int scol = p.flip ? (p.cw - 4 - 4 * kq) : 4 * kq;
             const uint8_t* s0 = src + (long)(p.top + iy) * p.W + p.left + scol;
-            const u32x4 v0 = *reinterpret_cast<const u32x4*>(s0);
-            const u32x4 v1 = *reinterpret_cast<const u32x4*>(s0 + plane);
-            const u32x4 v2 = *reinterpret_cast<const u32x4*>(s0 + 2 * plane);
+            const unsigned int v0 = *reinterpret_cast<const unsigned int*>(s0);
+            const unsigned int v1 = *reinterpret_cast<const unsigned int*>(s0 + plane);
+            const unsigned int v2 = *reinterpret_cast<const unsigned int*>(s0 + 2 * plane);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const unsigned int sh8 = 8 * (e & 3);
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int sh8 = 8 * e;
               bf16x4 o;
-              o[0] = (bf16_t)fmaf((float)((v0[e >> 2] >> sh8) & 0xffu), na[0], nb[0]);
-              o[1] = (bf16_t)fmaf((float)((v1[e >> 2] >> sh8) & 0xffu), na[1], nb[1]);
-              o[2] = (bf16_t)fmaf((float)((v2[e >> 2] >> sh8) & 0xffu), na[2], nb[2]);
+              o[0] = (bf16_t)fmaf((float)((v0 >> sh8) & 0xffu), na[0], nb[0]);
+              o[1] = (bf16_t)fmaf((float)((v1 >> sh8) & 0xffu), na[1], nb[1]);
+              o[2] = (bf16_t)fmaf((float)((v2 >> sh8) & 0xffu), na[2], nb[2]);
               o[3] = (bf16_t)0.f;
-              dst[p.flip ? (15 - e) : e] = o;
+              dst[p.flip ? (3 - e) : e] = o;
             }
           } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dst[e] = z4;
+            for (int e = 0; e < 4; ++e) dst[e] = z4;
           }
         }
       } else {
