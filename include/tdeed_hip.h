@@ -58,7 +58,9 @@ int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, int H, int W,
 /* ---- fused trunk front (bf16 only): pre-proc + stem + s1.b1.conv1 + s1.b1.conv2 (+SE squeeze) + s1.b1.downsample
  * uint8 frames [N][3][H][W] -> y2 [N][Ho][Wo][C1] (conv2 output), shortcut [N][Ho][Wo][C1], pooled fp32
  * [N][parts][C1] partial sums of y2 (parts = tdeed_s1_front_parts(crop_h, crop_w, C1)).  The 112^2 stem and conv1
- * maps stay in LDS / MFMA accumulators (front.hip).  Weight fragments are pre-packed by
+ * maps stay in LDS / MFMA accumulators (front.hip: a workgroup walks a strip of output rows over rings of input and
+ * conv1 rows; parts = strips per frame, a function of the shape and of TDEED_FRONT_ROLL / TDEED_FRONT_PIPE only, never of
+ * the frames' alignment).  Weight fragments are pre-packed by
  * tdeed_amd.engine.pack_front_weights; scale/shift are the folded eval BatchNorms (fp32). */
 int tdeed_s1_front_parts(int crop_h, int crop_w, int C1);
 int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, int crop_top, int crop_left, int crop_h,
