@@ -417,23 +417,24 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     if ((ps16 & 1) == 0) ++ps16;
     const int PSQ = ps16 * 16, KSq = (9 * nch + 3) / 4;
     const long wbytes = (long)KSq * 64 * 16;
-    int bq = (int)((60 * 1024 - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
-    long q_cap = 60 * 1024;
+    static const long q_kb = getenv("TDEED_GSF_Q_KB") ? atol(getenv("TDEED_GSF_Q_KB")) : 52;   // three workgroups per CU (measured: DESIGN §9)
+    long q_cap = q_kb * 1024;
+    int bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     if (bq < 1) {
       // wide slices (F = 196 of RegNetY-800MF s4: 58 KB of tap-weight fragments alone): up to 150 KB of LDS, one
       // workgroup per CU, instead of falling back to the vector-ALU tap kernel (118 vs ~35 us per site)
       q_cap = 150 * 1024;
       bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
-      if (bq >= 1) {
-        static bool attr_q = false;
-        if (!attr_q) {
-          if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
-              hipSuccess) {
-            tdeed_set_error("gsf_gate: hipFuncSetAttribute failed");
-            return TDEED_ERR_RUNTIME;
-          }
-          attr_q = true;
+    }
+    if (bq >= 1 && q_cap > 48 * 1024) {
+      static bool attr_q = false;
+      if (!attr_q) {
+        if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+            hipSuccess) {
+          tdeed_set_error("gsf_gate: hipFuncSetAttribute failed");
+          return TDEED_ERR_RUNTIME;
         }
+        attr_q = true;
       }
     }
     const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F + 4 * KSq) * sizeof(float);
@@ -845,9 +846,12 @@ extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const
   else if (dtype == TDEED_BF16) {
     // pixels per LDS chunk: (2 gate pairs fp32 + 2 x Fp bf16) per pixel next to the fixed tables, within 60 KB
     const long fixed = (long)(11 * F + 40) * sizeof(float);
-    long pchunk = (60 * 1024 - fixed) / (16 + 4L * Fp);
+    static const long a_kb = getenv("TDEED_GSF_APPLY_KB") ? atol(getenv("TDEED_GSF_APPLY_KB")) : 26;   // six workgroups per CU
+    long pchunk = (a_kb * 1024 - fixed) / (16 + 4L * Fp);
+    if (pchunk < 1) pchunk = (60 * 1024 - fixed) / (16 + 4L * Fp);
     TD_CHECK(pchunk >= 1 && F <= 256, "gsf_apply_fused: fold %d too wide", F);
     if (pchunk > hw) pchunk = hw;
+    pchunk = (hw + (hw + pchunk - 1) / pchunk - 1) / ((hw + pchunk - 1) / pchunk);      // equal chunks
     const size_t smb = (size_t)fixed + (size_t)pchunk * (16 + 4 * Fp);
     hipLaunchKernelGGL(gsf_apply_fused_bf16_kernel, dim3(B * T), dim3(256), smb, st, (const bf16_t*)x, gate, ysum, xsum,
                        1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (int)pchunk, (bf16_t*)out);
