@@ -1,3 +1,4 @@
+# kernel trace + stats of the 800MF B=16 inference forward, one batch in flight (GPU box): bash tools/_kt_b16.sh
 set -eu
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/kt_b16; rm -rf $O; mkdir -p $O
