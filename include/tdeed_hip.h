@@ -487,6 +487,21 @@ int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid,
  * relu(in_a[c] * x + in_b[c]) (x a raw conv output: BatchNorm + ReLU applied on load) */
 int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C,
                      const float* in_a, const float* in_b, void* y, int dtype, void* stream);
+/* SE + conv2-BatchNorm backward of a bottleneck without the d_y2 map (csrc/trunk_bwd2.hip; timm SEModule / BatchNorm2d under
+ * autograd, /root/reference/model/model.py:265-324).  d = d(y2 * gate) [N][hw][C] (conv3's input gradient), z = conv2's raw
+ * output, y2 = relu(fa * z + fb):
+ *   tdeed_se_bn_bwd_sums:     sums fp32 [5][N][C] = per (frame, channel) sum over the pixels of
+ *                             d*y2 | d*m | d*m*(z-mean) | m | m*(z-mean),  m = [fa z + fb > 0];  sums[0] is d(gate)
+ *   tdeed_se_bn_bwd_finalize: out fp32 [2][C] = (sum g, sum g * xhat) with g = m * (d * gate + d_p / hw): the conv2
+ *                             BatchNorm's (d bias, d weight), from the frame sums, gate [N][C] and d_p [N][C] = d(squeeze)
+ *   tdeed_se_bn_bwd_apply:    dz [N][hw][C] = k1 * g + k2 * z + k3 (the BatchNorm input gradient), g formed on the fly */
+int tdeed_se_bn_bwd_sums(const void* d, const void* z, int N, int hw, int C, const float* fa, const float* fb,
+                         const float* mean, float* sums, int dtype, void* stream);
+int tdeed_se_bn_bwd_finalize(const float* sums, const float* gate, const float* d_p, int N, int hw, int C, const float* rstd,
+                             float* out, void* stream);
+int tdeed_se_bn_bwd_apply(const void* d, const void* z, const float* gate, const float* d_p, int N, int hw, int C,
+                          const float* fa, const float* fb, const float* mean, const float* rstd, const float* w,
+                          const float* sums, void* dz, int dtype, void* stream);
 /* grouped 3x3 backward: dx (may be NULL: a stride-1 input gradient is itself a grouped 3x3 conv of dy with the flipped,
  * transposed weights and can run on tdeed_gconv3x3_fwd's MFMA kernel) and dw (fp32, the forward's packed [G][9][gw][gw]).
  * part fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw] */

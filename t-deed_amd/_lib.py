@@ -76,6 +76,9 @@ _SIGS = {
     "tdeed_se_train_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P, P], c_int),
     "tdeed_se_train_bwd": ([P, P, P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_scale_rows": ([P, P, P, c_float, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_se_bn_bwd_sums": ([P, P, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
+    "tdeed_se_bn_bwd_finalize": ([P, P, P, c_int, c_int, c_int, P, P, P], c_int),
+    "tdeed_se_bn_bwd_apply": ([P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_gconv_wgrad_slabs": ([c_long], c_int),
     "tdeed_gconv3x3_bwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_stride2_rows": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P], c_int),
@@ -179,6 +182,7 @@ def load():
 
 
 _PROFILE = None      # list of (entry name, start event, end event, args) while a `profile()` block is open
+SCOPE = ""           # label the training engine sets per stage / block ("s3.b2.bwd"): recorded with every profiled call
 
 
 class profile:
@@ -199,11 +203,20 @@ class profile:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, a, b, args in self.rec:
+        for name, a, b, args, *_ in self.rec:
             d = out.setdefault(name, dict(ms=0.0, calls=0, args=[]))
             d["ms"] += a.elapsed_time(b)
             d["calls"] += 1
             d["args"].append(args)
+        return out
+
+    def by_scope(self):
+        """{scope: {entry: ms}} (scope = _lib.SCOPE when the call was issued)"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, args, scope in self.rec:
+            d = out.setdefault(scope, {})
+            d[name] = d.get(name, 0.0) + a.elapsed_time(b)
         return out
 
 
@@ -215,7 +228,7 @@ def call(name, *args):
         a.record(st)
         rc = getattr(lib, name)(*args)
         b.record(st)
-        _PROFILE.append((name, a, b, args))
+        _PROFILE.append((name, a, b, args, SCOPE))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

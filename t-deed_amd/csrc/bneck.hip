@@ -617,14 +617,14 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
   const int hw = h * w, fpw = bneck_fpw(hw), KS = (C + 31) / 32;
   const size_t smem = bneck_smem(fpw, hw, C);
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)bneck_kernel<12, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 1, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<12, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { tdeed_set_error("bneck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   const int grid = (N + fpw - 1) / fpw;
   if (KS == 12 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<12, 2, 7>), dim3(grid), dim3(BNK_THR), smem, st, p);

@@ -33,6 +33,15 @@ void tdeed_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// Once-per-DEVICE guard of the launchers' hipFuncSetAttribute(MaxDynamicSharedMemorySize) calls: the attribute belongs
+// to the (function, device) pair, so a process that drives a second GPU sets it there again.
+struct TdDevOnce {
+  bool done[32] = {};
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 31; }
+  bool get() const { return done[dev()]; }
+  void set() { done[dev()] = true; }
+};
+
 // --------------------------------------------------------------------------- debug flavour (python t-deed_amd/build.py --debug)
 // TD_DEV_ASSERT / TD_LDS_CHECK compile to nothing in the release library.  The debug library (-O1 -g -DTDEED_DEBUG=1,
 // csrc/libtdeed_hip_dbg.so, loaded with TDEED_LIB_FLAVOUR=debug) traps the wave at the first violated condition: LDS

@@ -996,22 +996,22 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
     const int nstrips = (p.Ho + S - 1) / S;
     const size_t smr = front_roll_smem(crop_w, p.Ws, p.PS);
     p.band = S; p.nbands = nstrips;
-    static bool attr_r = false;
-    if (!attr_r) {
+    static TdDevOnce attr_r;
+    if (!attr_r.get()) {
       hipError_t e = hipFuncSetAttribute((const void*)s1_front_roll_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_roll_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_roll_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
       if (e != hipSuccess) { tdeed_set_error("s1_front: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-      attr_r = true;
+      attr_r.set();
     }
     const int nt1r = p.CSP >> 4;
     if (p.vec16 && front_pipe_shape(crop_w, p.Ws, p.CSP)) {
-      static bool attr_p = false;
-      if (!attr_p) {
+      static TdDevOnce attr_p;
+      if (!attr_p.get()) {
         hipError_t e = hipFuncSetAttribute((const void*)s1_front_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
         if (e != hipSuccess) { tdeed_set_error("s1_front: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-        attr_p = true;
+        attr_p.set();
       }
       const size_t smp = front_pipe_smem(crop_w, p.Ws, p.PS);
       if (nt1r == 1) hipLaunchKernelGGL(s1_front_pipe_kernel<1>, dim3(nstrips * N), dim3(PIPE_NT), smp, (hipStream_t)stream, p, S);
@@ -1031,13 +1031,13 @@ extern "C" int tdeed_s1_front_fwd(const uint8_t* frames, int N, int H, int W, in
   p.nbands = (p.Ho + p.band - 1) / p.band;
   const int ny1 = 2 * (p.band - 1) + 3, nin = 2 * (ny1 - 1) + 3;
   const size_t smem = (((size_t)nin * (crop_w + 2) * 8 + 15) & ~(size_t)15) + (size_t)ny1 * (p.Ws + 2) * p.PS;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)s1_front_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s1_front_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e != hipSuccess) { tdeed_set_error("s1_front: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   const int nt1 = p.CSP >> 4;
   if (nt1 == 1) hipLaunchKernelGGL(s1_front_kernel<1>, dim3(p.nbands * N), dim3(256), smem, (hipStream_t)stream, p);
@@ -1294,12 +1294,12 @@ extern "C" int tdeed_stem_mfma_fwd(const void* frames, int frames_f32, int N, in
   TD_CHECK(grid <= 0x7fffffffL, "stem_mfma: grid too large");
   p.g.vec16 = !frames_f32 && (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
               (((uintptr_t)frames & 15) == 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e != hipSuccess) { tdeed_set_error("stem_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   if (frames_f32) hipLaunchKernelGGL(stem_mfma_kernel<float>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(stem_mfma_kernel<uint8_t>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
@@ -1424,12 +1424,12 @@ int td_stem_wgrad_tr_launch(const void* frames, int frames_f32, int N, int H, in
   if (smem > FRONT_LDS_CAP || ((size_t)8 * (crop_w + 2) + 2 * (size_t)p.WoP + 4) * 8 > patch_b + (size_t)4 * p.WoP * 64) return 0;
   p.g.vec16 = !frames_f32 && (W % 16 == 0) && (crop_w % 16 == 0) && (crop_left % 16 == 0) && (((long)H * W) % 16 == 0) &&
               (((uintptr_t)frames & 15) == 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)stem_wgrad_tr_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_wgrad_tr_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_LDS_CAP);
     if (e != hipSuccess) return 0;
-    attr_set = true;
+    attr_set.set();
   }
   const long grid = (long)N * p.groups;
   if (grid > 0x7fffffffL) return 0;

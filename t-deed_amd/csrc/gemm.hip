@@ -716,22 +716,22 @@ static int launch_gemm_ws(GemmWsP& p, hipStream_t st) {
   long gx = smem > 64 * 1024 ? 256 / nsl : 1024 / nsl;     // persistent blocks; wide slices: one block per CU, all resident
   if (gx > nchunks) gx = nchunks;
   if (gx < 1) gx = 1;
-  static bool attr_set[16] = {false};
+  static TdDevOnce attr_set[16];
 #define WS_CASE(k)                                                                                              \
   case k:                                                                                                       \
-    if (smem > 64 * 1024 && !attr_set[k]) {                                                                     \
+    if (smem > 64 * 1024 && !attr_set[k].get()) {                                                                     \
       if (hipFuncSetAttribute((const void*)gemm_ws_kernel<T, k, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               WS_LDS_CAP) != hipSuccess) {                                                      \
         tdeed_set_error("gemm_ws: hipFuncSetAttribute failed");                                                 \
         return TDEED_ERR_RUNTIME;                                                                               \
       }                                                                                                         \
-      attr_set[k] = true;                                                                                       \
+      attr_set[k].set();                                                                                        \
     }                                                                                                           \
     if (wide8) {                                                                                                \
       if constexpr (sizeof(T) == 2 && (k == 10 || k == 12)) {                                                   \
-        static bool a8 = false;                                                                                 \
-        if (!a8) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, k, true, 8>,                        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_CAP); a8 = true; } \
+        static TdDevOnce a8;                                                                                 \
+        if (!a8.get()) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, k, true, 8>,                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_CAP); a8.set(); } \
         hipLaunchKernelGGL((gemm_ws_kernel<T, k, true, 8>), dim3((unsigned)gx, nsl), dim3(512), smem, st, p);   \
         break;                                                                                                  \
       }                                                                                                         \
@@ -981,17 +981,17 @@ extern "C" int tdeed_gemm_rs_fwd(const void* A, long lda, const void* A0, long l
   TD_CHECK(act == TDEED_ACT_NONE || act == TDEED_ACT_RELU, "gemm_rs: ReLU or no activation only");
   long grid = ((long)M + RS_ROWS - 1) / RS_ROWS;
   if (grid > 256) grid = 256;
-  static bool attr[8] = {false};
+  static TdDevOnce attr[8];
 #define TD_RS(Sv, Rv, Ov)                                                                                              \
   do {                                                                                                                 \
     const int ix = (Sv ? 4 : 0) + (Rv ? 2 : 0) + (Ov ? 1 : 0);                                                         \
-    if (!attr[ix]) {                                                                                                   \
+    if (!attr[ix].get()) {                                                                                               \
       if (hipFuncSetAttribute((const void*)gemm_rs_kernel<Sv, Rv, Ov>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               160 * 1024) != hipSuccess) {                                                             \
         tdeed_set_error("gemm_rs: hipFuncSetAttribute failed");                                                        \
         return TDEED_ERR_RUNTIME;                                                                                      \
       }                                                                                                                \
-      attr[ix] = true;                                                                                                 \
+      attr[ix].set();                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((gemm_rs_kernel<Sv, Rv, Ov>), dim3((unsigned)grid), dim3(RS_THR), smem, (hipStream_t)stream, p); \
   } while (0)

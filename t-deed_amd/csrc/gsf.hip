@@ -427,14 +427,14 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
       bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     }
     if (bq >= 1 && q_cap > 48 * 1024) {
-      static bool attr_q = false;
-      if (!attr_q) {
+      static TdDevOnce attr_q;
+      if (!attr_q.get()) {
         if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
             hipSuccess) {
           tdeed_set_error("gsf_gate: hipFuncSetAttribute failed");
           return TDEED_ERR_RUNTIME;
         }
-        attr_q = true;
+        attr_q.set();
       }
     }
     const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F + 4 * KSq) * sizeof(float);

@@ -244,12 +244,12 @@ extern "C" int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo,
   TD_CHECK(T_hi <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80, "mixer_branch: T=%d / ks=%d up=%d beyond the staging registers", T_hi, ks, up);
   size_t smem = sgp_smem(T_hi, ks, up, 2, 2);
   TD_CHECK(smem <= 128 * 1024, "mixer_branch: T=%d too long for the LDS window", T_hi);
-  static bool attr_set = false;
-  if (!attr_set) {        // long clips (T=250) need more than the default 64 KB of dynamic LDS
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {        // long clips (T=250) need more than the default 64 KB of dynamic LDS
     hipError_t e = hipFuncSetAttribute((const void*)mixer_branch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mixer_branch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) { tdeed_set_error("mixer_branch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   dim3 grid(B, cdiv(C, SGP_CH));
   hipStream_t st = (hipStream_t)stream;

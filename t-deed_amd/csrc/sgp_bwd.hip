@@ -875,12 +875,12 @@ extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, 
   TD_CHECK(B > 0 && T > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad sizes");
   const size_t smem = ((size_t)2 * T * (C / G) + 2 * (C / G) + 8) * sizeof(float);
   TD_CHECK(smem <= 150 * 1024, "groupnorm_bwd: slab too large");
-  static bool attr_set = false;
-  if (!attr_set) {      // long clips with wide groups (T=250, 48 channels per group: 96 KB) exceed the default 64 KB
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {      // long clips with wide groups (T=250, 48 channels per group: 96 KB) exceed the default 64 KB
     hipError_t e = hipFuncSetAttribute((const void*)groupnorm_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)groupnorm_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) { tdeed_set_error("groupnorm_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   dim3 grid(B, G);
   hipStream_t st = (hipStream_t)stream;
@@ -1072,12 +1072,12 @@ extern "C" int tdeed_sgp_branch_bwd(const void* o, long ldo, const void* g_conv,
   const size_t smem = (size_t)(3 * (T + 2 * halo) * SGP_CH + 4 * T * SGP_CH + wlen * SGP_CH + 17 * SGP_CH + 80 * SGP_CH) *
                       sizeof(float);
   TD_CHECK(smem <= 144 * 1024, "sgp_branch_bwd: T=%d too long for the LDS window", T);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_branch_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     if (e != hipSuccess) { tdeed_set_error("sgp_branch_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   dim3 grid(B, cdiv(C, SGP_CH));
   hipStream_t st = (hipStream_t)stream;

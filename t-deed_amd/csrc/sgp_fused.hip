@@ -663,12 +663,12 @@ extern "C" int tdeed_sgp_mlp_fwd(const void* y, int R, int T, int C, int G, cons
   const int S = (force_s == 1 || force_s == 2 || force_s == 4) ? force_s : tdeed_sgp_mlp_splits(R, C);
   TD_CHECK(S == 1 || partial, "sgp_mlp: split %d needs the partial buffer", S);
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)sgp_mlp_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_mlp_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { tdeed_set_error("sgp_mlp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   if (rows == 64)
     hipLaunchKernelGGL((sgp_mlp_kernel<4, 3>), dim3(cdiv(R, 64), S), dim3(MLP_NW * 64), smem, st, (const bf16_t*)y, R, T, C, G,

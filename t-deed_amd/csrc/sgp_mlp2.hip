@@ -560,13 +560,13 @@ extern "C" int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, con
   TD_CHECK(tdeed_sgp_mlp2_fits(R, T, C, G), "sgp_mlp2: geometry R=%d T=%d C=%d G=%d not served", R, T, C, G);
   const int S = tdeed_sgp_mlp2_slices(C);
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sgp_mlp2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { tdeed_set_error("sgp_mlp2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set = true;
+    attr_set.set();
   }
   // 64-row tiles while they fill the chip (R / 64 x S workgroups); 32-row tiles for the short pyramid levels
   const int rows = mlp2_rows(R, T, S);

@@ -1283,14 +1283,14 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   const size_t sm_s2 = (size_t)100 * (C + (dtype == TDEED_F32 ? 4 : 8)) * (dtype == TDEED_F32 ? 4 : 2) + (size_t)4 * 9 * gw * gw * 4;
   const bool dg_tiled = dx && stride == 2 && !dg_old && sm_s2 <= 120 * 1024 && Hi % 2 == 0 && Wi % 2 == 0 && N <= 65535;
   if (dg_tiled && sm_s2 > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static TdDevOnce attr_set;
+    if (!attr_set.get()) {
       hipError_t e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
       if (e != hipSuccess) { tdeed_set_error("gconv3x3_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-      attr_set = true;
+      attr_set.set();
     }
   }
   const dim3 gts2(cdiv(Wi, 16), cdiv(Hi, 16), N);

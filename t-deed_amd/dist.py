@@ -134,7 +134,8 @@ class GradReducer:
         self.rank = dist.get_rank()
         self.scale = 1.0 / self.world
         self.rs_ag_min_bytes = self.RS_AG_MIN_BYTES if rs_ag_min_bytes is None else int(rs_ag_min_bytes)
-        self.launched = []                                          # collectives actually enqueued, per call (describe())
+        from collections import deque
+        self.launched = deque(maxlen=4 * max(1, len(self.buckets)))  # the last collectives enqueued (describe(), tests): bounded
         if backend is None:
             backend = "rccl" if (flat.is_cuda and dist.get_backend() == "nccl") else "torch"
         self.backend = backend

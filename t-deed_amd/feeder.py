@@ -19,6 +19,7 @@ Only plumbing lives here (host memory, streams, events); nothing in this file co
 import os
 
 import numpy as np
+from types import SimpleNamespace
 import torch
 
 
@@ -190,11 +191,11 @@ class DecodePool:
 
 class _Ack:
     """Future of one decode job of a ProcessDecodePool."""
-    __slots__ = ("ev", "err")
+    __slots__ = ("ev", "err", "worker")
 
-    def __init__(self):
+    def __init__(self, worker=-1):
         import threading
-        self.ev, self.err = threading.Event(), None
+        self.ev, self.err, self.worker = threading.Event(), None, worker
 
     def result(self, timeout=120.0):
         if not self.ev.wait(timeout):
@@ -218,14 +219,17 @@ class ProcessDecodePool:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         boot = f"import sys; sys.path.insert(0, {root!r}); import tdeed_amd._decode_worker as w; w.main()"
         self._w, self._pending, self._lock, self._next, self._rr = [], {}, threading.Lock(), 0, 0
-        self._shms, self._slots = [], []
-        for _ in range(self.procs):
+        self._shms, self._slots, self._slot_cache = [], [], {}
+        self._alive = []
+        self._closing = False
+        for wi in range(self.procs):
             pr = subprocess.Popen([sys.executable, "-c", boot], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
-            th = threading.Thread(target=self._reader, args=(pr,), daemon=True)
-            th.start()
             self._w.append(pr)
+            self._alive.append(True)
+            th = threading.Thread(target=self._reader, args=(pr, wi), daemon=True)
+            th.start()
 
-    def _reader(self, pr):
+    def _reader(self, pr, wi):
         for line in pr.stdout:
             parts = line.rstrip("\n").split(" ", 2)
             with self._lock:
@@ -234,14 +238,43 @@ class ProcessDecodePool:
                 if parts[1] != "ok":
                     ack.err = parts[2] if len(parts) > 2 else "decode worker error"
                 ack.ev.set()
-        with self._lock:                 # worker gone: fail what it still owed
-            for ack in self._pending.values():
-                if ack.err is None and not ack.ev.is_set():
-                    pass
+        # EOF on the worker's pipe: it exited (crash, OOM kill, or close()).  Fail the jobs it still owed right away instead
+        # of letting every result() run into its timeout, and take it out of the rotation.
+        rc = pr.poll()
+        with self._lock:
+            self._alive[wi] = False
+            owed = [j for j, a in self._pending.items() if a.worker == wi]
+            for j in owed:
+                ack = self._pending.pop(j)
+                ack.err = f"decode worker {wi} exited (rc={rc}) with the job outstanding"
+                ack.ev.set()
+
+    def _pick_worker(self):
+        """next live worker of the rotation (caller holds the lock)"""
+        for _ in range(self.procs):
+            wi = self._rr % self.procs
+            self._rr += 1
+            if self._alive[wi]:
+                return wi
+        raise RuntimeError("ProcessDecodePool: no live decode worker left")
+
+    def _send(self, wi, line, ack, jid):
+        try:
+            self._w[wi].stdin.write(line)
+        except (BrokenPipeError, ValueError, OSError) as e:
+            with self._lock:
+                self._alive[wi] = False
+                self._pending.pop(jid, None)
+            ack.err = f"decode worker {wi} is gone ({type(e).__name__})"
+            ack.ev.set()
 
     def make_slots(self, depth, shape):
-        """`depth` uint8 staging tensors of `shape` in shared memory, page-locked when a GPU runtime is there."""
+        """`depth` uint8 staging tensors of `shape` in shared memory, page-locked when a GPU runtime is there.  Cached per
+        (depth, shape): a second loader over the same pool reuses the blocks instead of piling up shared memory."""
         from multiprocessing import shared_memory
+        key = (int(depth), tuple(int(v) for v in shape))
+        if key in self._slot_cache:
+            return self._slot_cache[key]
         n = int(np.prod(shape))
         out = []
         for _ in range(depth):
@@ -254,6 +287,7 @@ class ProcessDecodePool:
             self._shms.append((shm, t.data_ptr(), n, torch.cuda.is_available()))
             self._slots.append(t)
             out.append(t)
+        self._slot_cache[key] = out
         return out
 
     def _locate(self, dst):
@@ -267,18 +301,24 @@ class ProcessDecodePool:
         acks = []
         for path, dst in jobs:
             name, off = self._locate(dst)
-            ack = _Ack()
             with self._lock:
+                wi = self._pick_worker()
+                ack = _Ack(wi)
                 jid = self._next
                 self._next += 1
                 self._pending[jid] = ack
-                pr = self._w[self._rr % self.procs]
-                self._rr += 1
-            pr.stdin.write(f"{jid} {name} {off} {dst.shape[-2]} {dst.shape[-1]} {path}\n")
+            self._send(wi, f"{jid} {name} {off} {dst.shape[-2]} {dst.shape[-1]} {path}\n", ack, jid)
             acks.append(ack)
-        for pr in self._w:
-            pr.stdin.flush()
+        self._flush(range(self.procs))
         return acks
+
+    def _flush(self, workers):
+        for wi in workers:
+            if self._alive[wi]:
+                try:
+                    self._w[wi].stdin.flush()
+                except (BrokenPipeError, ValueError, OSError):
+                    pass                # the reader thread fails the worker's jobs at EOF
 
     def submit_rows(self, paths, dst, chunk=25):
         """Consecutive frames: paths[i] -> dst[i] (dst: a contiguous (n,3,H,W) view inside a slot), `chunk` frames per job
@@ -291,19 +331,17 @@ class ProcessDecodePool:
         H, W = dst.shape[-2], dst.shape[-1]
         acks, touched = [], set()
         for lo in range(0, len(paths), chunk):
-            ack = _Ack()
             with self._lock:
+                wi = self._pick_worker()
+                ack = _Ack(wi)
                 jid = self._next
                 self._next += 1
                 self._pending[jid] = ack
-                wi = self._rr % self.procs
-                self._rr += 1
-            self._w[wi].stdin.write("J " + json.dumps(dict(id=jid, shm=name, off=off + lo * 3 * H * W, H=H, W=W,
-                                                           paths=list(paths[lo:lo + chunk]))) + "\n")
+            self._send(wi, "J " + json.dumps(dict(id=jid, shm=name, off=off + lo * 3 * H * W, H=H, W=W,
+                                                  paths=list(paths[lo:lo + chunk]))) + "\n", ack, jid)
             touched.add(wi)
             acks.append(ack)
-        for wi in touched:
-            self._w[wi].stdin.flush()
+        self._flush(touched)
         return acks
 
     def decode(self, jobs):
@@ -325,6 +363,7 @@ class ProcessDecodePool:
                 pr.kill()
         self._w = []
         self._slots = []
+        self._slot_cache = {}
         for shm, ptr_, n, pinned in self._shms:
             try:
                 if pinned:
@@ -354,7 +393,11 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
     dict(paths=<load_paths result>, stride=..) (+ any label entries, passed through per batch as lists); every batch dict
     holds 'frame' = a PINNED uint8 (B,T,3,H,W) tensor filled by `pool` (all frames of the batch are decode jobs of one
     pool call, so B * T JPEGs decode concurrently).  The slots rotate: a batch must be consumed (copied to the device)
-    before `depth` further batches are produced -- `prefetch` copies it one batch later."""
+    before `depth` further batches are produced.  `prefetch` uploads a pinned batch straight from its slot, asynchronously:
+    it leaves the arrival event in the batch's `_src` holder, and a slot is not decoded into again before that event has
+    completed (a consumer that never syncs -- graph replays -- would otherwise see frames overwritten mid-copy).  Rows of
+    a clip behind its real frames are always zeroed (pad=False only drops the END padding from the clip's length in the
+    reference, dataset/frame.py:355-382; a fixed-length slot must not show an earlier batch's frames there)."""
     own = pool is None
     pool = pool if pool is not None else DecodePool()
     shape = (batch_size, clip_len) + tuple(frame_shape)
@@ -362,9 +405,14 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
         slots = pool.make_slots(depth, shape)
     else:
         slots = [torch.zeros(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    holders = [SimpleNamespace(event=None) for _ in range(depth)]
     try:
         for bi, lo in enumerate(range(0, len(clips) - batch_size + 1, batch_size)):
             slot = slots[bi % depth]
+            hold = holders[bi % depth]
+            if hold.event is not None:       # the upload that last read this slot (prefetch) must have left it
+                hold.event.synchronize()
+                hold.event = None
             group = clips[lo:lo + batch_size]
             futs = []
             for i, c in enumerate(group):
@@ -374,8 +422,8 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
                 dst = slot[i]
                 if pad_start:
                     dst[:pad_start].zero_()
-                if pad and pad_end:
-                    dst[pad_start + n_real:pad_start + n_real + pad_end].zero_()
+                if pad_start + n_real < clip_len:
+                    dst[pad_start + n_real:].zero_()
                 names = []
                 for j in range(n_real):
                     num = start + j * stride
@@ -388,7 +436,7 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
             for f in futs:
                 f.result()
             extra = {k: [c[k] for c in group] for k in group[0] if k not in ("paths", "stride")}
-            yield dict(frame=slot, **extra)
+            yield dict(frame=slot, _src=hold, **extra)
     finally:
         if own:
             pool.close()
@@ -473,10 +521,14 @@ def prefetch(loader, device="cuda", key="frame", depth=3, auto=True):
         j = ring.next_slot()
         if fr.is_pinned():
             dev, ev = ring.upload(j, src=fr.contiguous())
+            src = batch.get("_src")
+            if src is not None:              # the producer's staging slot is busy until this copy has left it
+                src.event = ev
         else:
             ring.host[j].copy_(fr)
             dev, ev = ring.upload(j)
         out = dict(batch)
+        out.pop("_src", None)
         out[key] = dev
         out["_slot"] = (ring, j, ev)
         return out

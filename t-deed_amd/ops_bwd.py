@@ -252,6 +252,27 @@ def scale_rows(x, s, add=None, add_scale=1.0, out=None, affine=None):
     return out
 
 
+def se_bn_bwd(d, z, bn, w, gate, hid, se_w1, se_w2):
+    """The passes between conv3's input gradient d = d(y2 * gate) (N,h,w,C) and conv2's BatchNorm input gradient without
+    the d_y2 map (csrc/trunk_bwd2.hip): z = conv2's raw output, bn = (mean, rstd, a, b) of its BatchNorm (y2 = relu(a z + b)),
+    w its weight, gate (N,C) / hid (N,R) the SE forward's values, se_w1 (R,C) / se_w2 (C,R) the SE weights.
+    -> dz (like z), dw, db (BatchNorm weight / bias gradients), d_pre2 (N,C), d_hid (N,R) (operands of the SE weight gradients)."""
+    N, C = z.shape[0], z.shape[-1]
+    hw = z.numel() // (N * C)
+    dev = z.device
+    mean, rstd, fa, fb = bn
+    sums = _f32((5, N, C), dev)
+    call("tdeed_se_bn_bwd_sums", ptr(d), ptr(z), N, hw, C, ptr(fa), ptr(fb), ptr(mean), ptr(sums), dtype_code(z.dtype),
+         stream_ptr())
+    d_pre2, d_hid, d_p = se_train_bwd(sums[0], gate, hid, se_w1, se_w2)
+    st = _f32((2, C), dev)
+    call("tdeed_se_bn_bwd_finalize", ptr(sums), ptr(gate), ptr(d_p), N, hw, C, ptr(rstd), ptr(st), stream_ptr())
+    dz = torch.empty_like(z)
+    call("tdeed_se_bn_bwd_apply", ptr(d), ptr(z), ptr(gate), ptr(d_p), N, hw, C, ptr(fa), ptr(fb), ptr(mean), ptr(rstd),
+         ptr(w), ptr(st), ptr(dz), dtype_code(z.dtype), stream_ptr())
+    return dz, st[1], st[0], d_pre2, d_hid
+
+
 def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True, in_affine=None):
     """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x (None if not want_dx), dw fp32 [G][9][gw][gw].
     in_affine = (a, b) (bf16): x is a raw conv output, relu(a*x + b) is applied on load for the weight gradient."""

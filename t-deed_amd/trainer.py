@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from . import ops, ops_bwd as B_
+from . import ops, ops_bwd as B_, _lib
 from .streams import new_stream
 from .optim import FlatParams, FusedAdamW, warmup_cosine_lr, is_late_bucket_key
 from .regnet_spec import regnet_spec
@@ -104,6 +104,7 @@ class TrainEngine:
         crop = (top, left, h, w) shared by all clips (model.py:115); flip: bool or per-clip flags (B,) (model.py:83).
         Returns (head_out (B*T, n_out) fp32, ctx for backward_train)."""
         sd, dt = self.state, self.dt
+        _lib.SCOPE = "stem.fwd"
         Bn, T = frames_u8.shape[:2]
         fr = frames_u8.reshape(Bn * T, *frames_u8.shape[2:])
         fl = self._frame_flip(flip, Bn, T)
@@ -122,7 +123,9 @@ class TrainEngine:
                                   sd["_features.stem.bn.running_mean"], sd["_features.stem.bn.running_var"], relu=True)
         x = y0
         for blk in self.blocks:
+            _lib.SCOPE = blk.blk.name + ".fwd"
             x = blk.forward(x)
+        _lib.SCOPE = "temporal.fwd"
         hw = x.shape[1] * x.shape[2]
         feat = ops.avgpool_posenc(x, Bn, T, sd["temp_enc"])
         head_out, tctx = self.temporal.forward_heads(feat, drop_masks)
@@ -134,6 +137,7 @@ class TrainEngine:
     def backward_train(self, ctx, dhead):
         """Backward of forward_train from d(loss)/d(head_out): returns grads dict name -> fp32 tensor."""
         grads = {}
+        _lib.SCOPE = "temporal.bwd"
         d_feat = self.temporal.backward_heads(ctx.tctx, dhead, grads)
         grads.update(self.backward_trunk(ctx, d_feat))
         return {k: B_.materialize(g) for k, g in grads.items()}
@@ -146,7 +150,9 @@ class TrainEngine:
         grads["temp_enc"] = d_enc
         dx = dx.view(ctx.x_shape)
         for blk in reversed(self.blocks):
+            _lib.SCOPE = blk.blk.name + ".bwd"
             dx = blk.backward(dx, grads)
+        _lib.SCOPE = "stem.bwd"
         from .trunk_train import ZMASK
         dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, None if ZMASK else ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
         grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
@@ -221,11 +227,13 @@ class TrainEngine:
         # weight gradients stay in their per-workgroup partials until the bucket's write-out launch folds them
         lazy = os.environ.get("TDEED_LAZY_WGRAD", "1") == "1"
         B_.LAZY_WGRAD = lazy
+        _lib.SCOPE = "temporal.bwd"
         try:
             d_feat = self.temporal.backward_heads(ctx.tctx, dhead, g_t)
         finally:
             B_.LAZY_WGRAD = False
         self._check_bucket_keys(g_t, 0)
+        _lib.SCOPE = "write_grads"
         self.write_grads(g_t, scale, first, partial=True, role=0)
         if red is not None:
             red.reduce_bucket(0)
@@ -238,6 +246,7 @@ class TrainEngine:
         if missing:
             raise RuntimeError(f"no gradient produced for {sorted(missing)[:4]} ...")
         self._check_bucket_keys(g_b, 1)
+        _lib.SCOPE = "write_grads"
         self.write_grads(g_b, scale, first, partial=True, role=1)
         if red is not None:
             red.reduce_bucket(1)
@@ -248,6 +257,7 @@ class TrainEngine:
         attached the current stream first waits for the bucket all-reduces and the 1/world of the mean rides on AdamW's
         grad_scale; `all_reduce` is the older blocking form (callable(flat_grad))."""
         gs = 1.0
+        _lib.SCOPE = "optim"
         if all_reduce is not None:
             all_reduce(self.params.grad)
         elif self.reducer is not None:

@@ -17,6 +17,9 @@ import os as _os
 
 FUSE_RES = _os.environ.get("TDEED_TRAIN_FUSE_RES", "1") == "1"
 ZMASK = _os.environ.get("TDEED_TRAIN_ZMASK", "1") == "1"
+# SE gate gradient, SE scale backward and conv2's BatchNorm backward from five per-frame sums (trunk_bwd2.hip): 5 passes over
+# the block's output-resolution maps instead of 9; TDEED_TRAIN_SE_BN_FUSED=0 restores pool_rows / scale_rows / bn_train_bwd
+SE_BN_FUSED = ZMASK and _os.environ.get("TDEED_TRAIN_SE_BN_FUSED", "1") == "1"
 
 
 def _dense(w, dt):
@@ -254,13 +257,21 @@ class BottleneckTrain:
         d_y2s = ops.gemm(dz3, self.w3.wt, None, None, ops.ACT_NONE).view(N, h2, w2, C)
         grads[pre + ".conv3.conv.weight"] = B_.wgrad(dz3, c.y2s, with_bias=False, M=N * hw2)[0].reshape(
             sd[pre + ".conv3.conv.weight"].shape)
-        # SE
-        if c.onload:
-            d_gate = B_.pool_rows(d_y2s, c.z2, affine=(c.bn2[2], c.bn2[3]), affine_on=2)
+        # SE + conv2's BatchNorm
+        if SE_BN_FUSED and len(c.bn2) >= 4:
+            # one pass over (d_y2s, z2) for every per-frame sum the SE gate gradient and the BatchNorm statistics need, one
+            # pass that writes dz2: d_y2 = d_y2s * gate + d_pool / hw is never materialised (trunk_bwd2.hip)
+            dz2, dw_bn2, db_bn2, d_pre2, d_hid = B_.se_bn_bwd(d_y2s, c.z2, c.bn2, sd[pre + ".conv2.bn.weight"], c.gate, c.hid,
+                                                             self.se_w1, self.se_w2)
         else:
-            d_gate = B_.pool_rows(d_y2s, c.y2)
-        d_pre2, d_hid, d_p = B_.se_train_bwd(d_gate, c.gate, c.hid, self.se_w1, self.se_w2)
-        d_y2 = B_.scale_rows(d_y2s, c.gate, add=d_p, add_scale=1.0 / hw2)
+            if c.onload:
+                d_gate = B_.pool_rows(d_y2s, c.z2, affine=(c.bn2[2], c.bn2[3]), affine_on=2)
+            else:
+                d_gate = B_.pool_rows(d_y2s, c.y2)
+            d_pre2, d_hid, d_p = B_.se_train_bwd(d_gate, c.gate, c.hid, self.se_w1, self.se_w2)
+            d_y2 = B_.scale_rows(d_y2s, c.gate, add=d_p, add_scale=1.0 / hw2)
+            dz2, _, dw_bn2, db_bn2 = B_.bn_train_bwd(c.z2, d_y2, None if ZMASK else c.y2, c.bn2, sd[pre + ".conv2.bn.weight"],
+                                                     relu=True)
         dW2, db2 = B_.wgrad(d_pre2, c.hid)
         dW1, db1 = B_.wgrad(d_hid, c.p)
         grads[pre + ".se.fc1.weight"] = dW1.reshape(sd[pre + ".se.fc1.weight"].shape)
@@ -268,8 +279,7 @@ class BottleneckTrain:
         grads[pre + ".se.fc2.weight"] = dW2.reshape(sd[pre + ".se.fc2.weight"].shape)
         grads[pre + ".se.fc2.bias"] = db2
         # conv2
-        dz2, _, dw, db = B_.bn_train_bwd(c.z2, d_y2, None if ZMASK else c.y2, c.bn2, sd[pre + ".conv2.bn.weight"], relu=True)
-        bn_names("conv2", dw, db)
+        bn_names("conv2", dw_bn2, db_bn2)
         xin, aff1 = (c.z1, (c.bn1[2], c.bn1[3])) if c.onload else (c.y1, None)
         if self.w2frag_t is not None:
             d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)

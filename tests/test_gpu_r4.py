@@ -1,0 +1,117 @@
+"""Round-4 parity tests on the MI355X (through the C ABI).  -m gpu only.
+
+* the execution shape bench.py times (one sub-batch, three plans = three buffer sets / HIP graphs rotated over three
+  streams) gives, per slot, the logits of the per-clip B=1 forwards and the reference's golden logits;
+* the restructured training backward (SE + BatchNorm backward from per-frame sums; ReLU mask and BatchNorm statistics in
+  the producing contraction's epilogue) against the launch-per-op chain it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, model_state, t, max_abs
+from tdeed_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_three_rotated_slots_of_the_timed_shape_equal_single_clip_forwards():
+    """BASELINE configs[1] as bench.py runs it (bench.py main(): n_split=1, plan(B, H, W, slot=i) for i < 3, replayed
+    rotated on three streams): after 7 rotated steps every slot still holds the logits of ITS OWN clips -- equal to the
+    B=1 forward of each clip (bf16 <= 2e-2) and, for the golden clip in slot 0, within the bf16 bound of the reference's
+    logits (model/model.py:105-149)."""
+    from tdeed_amd.engine import ForwardEngine
+    meta, g = load_golden("finediving_small")
+    cfg = meta["cfg"]
+    sd = model_state(cfg, meta["seed_w"])
+    T, H, W = cfg["clip_len"], meta["H"], meta["W"]
+    B, depth = 8, 3
+    K1 = cfg["num_classes"] + 1
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    clips = [np.concatenate([synth.uint8_clip(meta["seed_x"] + 100 * s + i, (1, T, 3, H, W)) for i in range(B)], 0)
+             for s in range(depth)]
+    with torch.cuda.stream(streams[0]):
+        eng = ForwardEngine(cfg, sd, torch.bfloat16, DEV, n_split=1)
+        plans = [eng.plan(B, H, W, slot=i) for i in range(depth)]
+        assert all(len(p.subs) == 1 for p in plans)
+        assert len({p.head_out.data_ptr() for p in plans}) == depth
+        for p, c in zip(plans, clips):
+            eng.set_frames(p, t(c).to(DEV))
+    torch.cuda.synchronize()
+    for i in range(7 * depth):                                       # the loop of bench.py's run(n)
+        with torch.cuda.stream(streams[i % depth]):
+            eng.run_plan(plans[i % depth])
+    torch.cuda.synchronize()
+    assert all(p.graph is not None for p in plans)
+    heads = [p.head_out.float().cpu().view(B, T, -1).clone() for p in plans]
+    for s in range(depth):
+        assert torch.isfinite(heads[s]).all()
+        for o in range(s):
+            assert max_abs(heads[s], heads[o]) > 1e-2                 # different clips: different logits (no aliasing)
+    # per-clip B=1 forwards on a fresh engine (its own buffers)
+    eng1 = ForwardEngine(cfg, sd, torch.bfloat16, DEV, n_split=1)
+    st = torch.cuda.Stream()
+    for s in range(depth):
+        for i in (0, 3, 7):
+            with torch.cuda.stream(st):
+                h1, _ = eng1.forward(t(clips[s][i:i + 1]).to(DEV))
+                st.synchronize()
+            assert max_abs(h1.float().cpu().view(T, -1), heads[s][i]) <= 2e-2, (s, i)
+    err = max_abs(heads[0][0, :, :K1], g["logits"][0])
+    assert err < 0.08 * max(1.0, float(np.abs(g["logits"]).max()))
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,h,w,C,R", [(6, 7, 7, 48, 12), (5, 14, 14, 152, 38), (3, 9, 5, 768, 192), (2, 56, 56, 64, 8)])
+def test_se_and_conv2_batchnorm_backward_from_frame_sums_equals_the_pass_per_op_chain(dtype, N, h, w, C, R):
+    """tdeed_se_bn_bwd_{sums,finalize,apply} (five per-frame sums, no d_y2 map) against the chain it replaces
+    (tdeed_pool_rows -> tdeed_se_train_bwd -> tdeed_scale_rows -> tdeed_bn_train_bwd) and, in fp32, against autograd on
+    the plain torch expression of timm's SEModule + BatchNorm2d + ReLU."""
+    from tdeed_amd import ops_bwd as B_
+    z = _rand((N, h, w, C), 1).to(DEV).to(dtype)
+    d = _rand((N, h, w, C), 2, 0.5).to(DEV).to(dtype)
+    bw = (_rand((C,), 3, 0.3) + 1.0).to(DEV)
+    bb = _rand((C,), 4, 0.3).to(DEV)
+    w1, b1 = _rand((R, C), 5, 0.2).to(DEV), _rand((R,), 6, 0.1).to(DEV)
+    w2, b2 = _rand((C, R), 7, 0.2).to(DEV), _rand((C,), 8, 0.1).to(DEV)
+    mean, rstd, fa, fb = B_.bn_stats(z, bw, bb)
+    bn = (mean, rstd, fa, fb)
+    p = B_.pool_rows(z, affine=(fa, fb))
+    hid, gate = B_.se_train_fwd(p, w1.t().contiguous(), b1, w2.t().contiguous(), b2)
+    # the chain
+    d_gate = B_.pool_rows(d, z, affine=(fa, fb), affine_on=2)
+    d_pre2, d_hid, d_p = B_.se_train_bwd(d_gate, gate, hid, w1, w2)
+    d_y2 = B_.scale_rows(d, gate, add=d_p, add_scale=1.0 / (h * w))
+    dz_ref, _, dw_ref, db_ref = B_.bn_train_bwd(z, d_y2, None, bn, bw, relu=True)
+    # the fused form
+    dz, dw, db, d_pre2_f, d_hid_f = B_.se_bn_bwd(d, z, bn, bw, gate, hid, w1, w2)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+
+    def close(a, b, name, t_=tol):
+        a, b = a.float().cpu(), b.float().cpu()
+        sc = max(1e-6, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= t_ * sc, (name, float((a - b).abs().max()), sc)
+
+    close(d_pre2_f, d_pre2, "d_pre2", 2e-5 if dtype == torch.float32 else 1e-4)
+    close(d_hid_f, d_hid, "d_hid", 2e-5 if dtype == torch.float32 else 1e-4)
+    close(dz, dz_ref, "dz")
+    close(dw, dw_ref, "dw", tol if dtype == torch.float32 else 5e-3)
+    close(db, db_ref, "db", tol if dtype == torch.float32 else 5e-3)
+    if dtype == torch.float32:
+        zc = z.cpu().double().requires_grad_(True)
+        wc, bc = bw.cpu().double().requires_grad_(True), bb.cpu().double().requires_grad_(True)
+        mu = zc.mean((0, 1, 2))
+        var = zc.var((0, 1, 2), unbiased=False)
+        y = torch.relu((zc - mu) / torch.sqrt(var + 1e-5) * wc + bc)
+        pp = y.mean((1, 2))
+        gt = torch.sigmoid(torch.relu(pp @ w1.cpu().double().t() + b1.cpu().double()) @ w2.cpu().double().t() + b2.cpu().double())
+        (y * gt[:, None, None, :] * d.cpu().double()).sum().backward()
+        close(dz, zc.grad, "dz vs autograd", 1e-4)
+        close(dw, wc.grad, "dw vs autograd", 1e-4)
+        close(db, bc.grad, "db vs autograd", 1e-4)

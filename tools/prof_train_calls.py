@@ -33,6 +33,12 @@ tot = sum(d["ms"] for d in s.values())
 print(f"{wname} B={B}: {tot:.2f} ms of device time inside C-ABI calls (one eager step)")
 for k, d in sorted(s.items(), key=lambda kv: -kv[1]["ms"]):
     print(f"  {k:34s} {d['ms']:8.3f} ms {d['calls']:5d} calls {d['ms'] / tot * 100:5.1f} %")
+sc = pr.by_scope()
+print("per scope (stage / block, forward and backward), ms of device time and the three largest entry points:")
+for k, d in sc.items():
+    tt = sum(d.values())
+    top = sorted(d.items(), key=lambda kv: -kv[1])[:3]
+    print(f"  {k or '-':16s} {tt:8.3f} ms   " + "  ".join(f"{n.replace('tdeed_', '')} {v:.2f}" for n, v in top))
 for entry, idx in (("tdeed_gemm_fwd", (7, 8, 9)), ("tdeed_wgrad", None)):
     g = s.get(entry)
     if g is None or idx is None:
@@ -42,7 +48,7 @@ for entry, idx in (("tdeed_gemm_fwd", (7, 8, 9)), ("tdeed_wgrad", None)):
     with _lib.profile() as pr2:
         eng.step(frames, lab, labD, drop_masks=masks)
     torch.cuda.synchronize()
-    for name, a, b, args in pr2.rec:
+    for name, a, b, args, *_ in pr2.rec:
         if name != entry:
             continue
         key = tuple(args[i] for i in idx) + (bool(args[14]), bool(args[25]))      # residual, colpart
