@@ -502,6 +502,29 @@ int tdeed_se_bn_bwd_finalize(const float* sums, const float* gate, const float* 
 int tdeed_se_bn_bwd_apply(const void* d, const void* z, const float* gate, const float* d_p, int N, int hw, int C,
                           const float* fa, const float* fb, const float* mean, const float* rstd, const float* w,
                           const float* sums, void* dz, int dtype, void* stream);
+/* "Gradient sink" (csrc/trunk_bwd2.hip, gemm.hip): the ReLU backward at a block's output and the statistics pass of the
+ * BatchNorm backward behind it, applied by the kernels that PRODUCE the gradient (timm Bottleneck under autograd,
+ * /root/reference/model/model.py:265-324).
+ * tdeed_gemm_dgrad: C [M][N] = ((A [M][K] @ W [N][K]^T) + R) * [mask > 0]; with r_hi > 0 the residual R has rows only for the
+ *   even pixels of an r_hi x r_wi frame (stride-2 shortcut); C2 (optional, [M][n2]) takes columns [0, n2) BEFORE the residual
+ *   and C keeps only the residual there (gate-shift blocks); bpart (optional) fp32 [ceil(M/128)][3][N]: per-tile column sums of
+ *   the stored v, v * (bz - bmean) and (bzd given) v * (bzd - bmean_d).
+ * tdeed_gsf_add_cols_sink: dx[m][c] += (a + b)[m][c] * [mask > 0] for c < Fp, with the sums of what was ADDED in
+ *   part fp32 [tdeed_gsf_add_cols_sink_parts(M, Fp, dtype)][3][Fp] (mask / part may be NULL).
+ * tdeed_bn_bwd_from_parts: BatchNorm backward of z [M][C] for an already masked gradient g whose column sums lie in producer
+ *   partials: partA PA rows of [3][C] (+ partB PB rows of [3][nB] for columns [0, nB)); q = 1 / 2 selects the product row;
+ *   sums fp32 [2][C] = (d bias, d weight); dz (may be NULL) = the input gradient; tmp fp32 [2 * 64 * 3 * C]. */
+int tdeed_gemm_dgrad(const void* A, long lda, int M, int K, int N, const void* W, long ldw, const void* R, long ldr, int r_hi,
+                     int r_wi, void* C, long ldc, void* C2, long ldc2, int n2, const void* mask, long ldmask, const void* bz,
+                     long ldbz, const float* bmean, const void* bzd, long ldbzd, const float* bmean_d, float* bpart, int dtype,
+                     void* stream);
+int tdeed_gsf_add_cols_sink_parts(long M, int Fp, int dtype);
+int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask, long ldmask,
+                            const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd, const float* bmean_d,
+                            float* part, int dtype, void* stream);
+int tdeed_bn_bwd_from_parts(const void* z, const void* g, long M, int C, const float* mean, const float* rstd, const float* w,
+                            const float* partA, int PA, const float* partB, int PB, int nB, int q, float* tmp, float* sums,
+                            void* dz, int dtype, void* stream);
 /* grouped 3x3 backward: dx (may be NULL: a stride-1 input gradient is itself a grouped 3x3 conv of dy with the flipped,
  * transposed weights and can run on tdeed_gconv3x3_fwd's MFMA kernel) and dw (fp32, the forward's packed [G][9][gw][gw]).
  * part fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw] */

@@ -32,6 +32,13 @@ struct GemmP {
   void* C2; long ldc2; int n2;   // optional second, compact copy of columns [0, n2) of C (the next block's gate-shift slice)
   int c2_pre;                    // C2 takes the value BEFORE residual / activation and C keeps only the residual in those columns
   SeP se;                        // SE == 3: the gates are computed in the prologue from conv2's squeeze sums (se_excite.h)
+  // BWD epilogue (tdeed_gemm_dgrad: the input-gradient contraction of a training bottleneck's conv1, whose output rows are
+  // the gradient arriving at the PREVIOUS block's output ReLU):
+  const void* mask; long ldmask;                      // v = mask[m][n] > 0 ? v : 0 after the residual (that ReLU's backward)
+  const void* bz; long ldbz; const float* bmean;      // per-tile column sums of v and v * (bz - bmean): the statistics of the
+  const void* bzd; long ldbzd; const float* bmean_d;  // BatchNorm backward that consumes v; optionally also v * (bzd - bmean_d)
+  float* bpart;                                       // [M tiles][3][N]
+  int r_hi, r_wi;                                     // > 0: the residual holds rows only for the even (y, x) pixels of an r_hi x r_wi frame
 };
 
 template <typename T> struct Frag;
@@ -59,7 +66,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // register stage (two K slabs in flight) was measured: it needs > 256 VGPRs, spills, and loses (43 vs 32 us at
 // M=39200, K=N=368).  SE = 3 is SE = 2 with the table COMPUTED here (fc1 / ReLU / fc2 / sigmoid on the MFMA pipe from the
 // squeeze sums of the tile's frames, se_excite.h) instead of read from a gate tensor: no se_gate launch in front of conv3.
-template <typename T, int BN, int SE>
+template <typename T, int BN, int SE, bool BWD = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int EPC = Chunk<T>::N;        // elements per 16-B chunk
   constexpr int KT = 8 * EPC;             // elements of K per slab
@@ -276,6 +283,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr bool RPRE = sizeof(T) == 2;
   constexpr int NPT = (64 * CPR + 255) / 256;
   u32x4 rres[RPRE ? 2 : 1][RPRE ? NPT : 1];
+  // BWD with a stride-2 residual (the shortcut conv's input gradient lives on the even pixels only): row m = (f, y, x) of an
+  // r_hi x r_wi frame reads residual row (f, y / 2, x / 2) when y and x are even, nothing otherwise
+  [[maybe_unused]] unsigned rskip = 0u;                         // bit (half * NPT + it): no residual for that chunk
+  auto rrow = [&](long m, bool& has) -> long {
+    if constexpr (BWD) {
+      if (p.r_hi > 0) {
+        const long per = (long)p.r_hi * p.r_wi;
+        const long f = m / per;
+        const int rem = (int)(m - f * per);
+        const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
+        has = !((yy | xx) & 1);
+        const int ho = (p.r_hi + 1) >> 1, wo = (p.r_wi + 1) >> 1;
+        return has ? (f * ho + (yy >> 1)) * wo + (xx >> 1) : 0;
+      }
+    }
+    has = true;
+    return m;
+  };
   if constexpr (RPRE) {
     if (p.R) {
 #pragma unroll
@@ -286,8 +311,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
           const int row = idx / CPR, cj = idx - row * CPR;
           const long m = min(m0 + half * 64 + row, (long)p.M - 1);
           const int n = min(n0 + cj * EPC, p.N - EPC);
-          rres[half][it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + m * p.ldr + n);
+          bool has;
+          const long rm = rrow(m, has);
+          if (!has) rskip |= 1u << (half * NPT + it);
+          rres[half][it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + rm * p.ldr + n);
         }
+    }
+  }
+  // BWD statistics: a thread serves one column chunk in every iteration (CPR divides 256): its means live in registers
+  [[maybe_unused]] float bm[BWD ? EPC : 1], bmd[BWD ? EPC : 1], cs3[BWD ? EPC : 1];
+  if constexpr (BWD) {
+    const int nb0 = min(n0 + (tid % CPR) * EPC, p.N - EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      bm[e] = p.bpart ? p.bmean[nb0 + e] : 0.f;
+      bmd[e] = (p.bpart && p.bzd) ? p.bmean_d[nb0 + e] : 0.f;
+      cs3[e] = 0.f;
     }
   }
   for (int half = 0; half < 2; ++half) {
@@ -320,12 +359,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) v[e] = 0.f;
         }
+        [[maybe_unused]] u32x4 mk4, bz4, bzd4;
+        if constexpr (BWD) {                              // this chunk's mask / statistics operands: requested before the residual math
+          if (p.mask) mk4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.mask) + m * p.ldmask + n);
+          if (p.bpart) {
+            bz4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bz) + m * p.ldbz + n);
+            if (p.bzd) bzd4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bzd) + m * p.ldbzd + n);
+          }
+        }
         if (p.R) {
           float rv[EPC];
-          if constexpr (RPRE) Chunk<T>::load(reinterpret_cast<const T*>(&rres[half][it]), rv);
-          else Chunk<T>::load(reinterpret_cast<const T*>(p.R) + m * p.ldr + n, rv);
+          bool has = true;
+          if constexpr (RPRE) {
+            Chunk<T>::load(reinterpret_cast<const T*>(&rres[half][it]), rv);
+            if constexpr (BWD) has = !((rskip >> (half * NPT + it)) & 1u);
+          } else {
+            const long rm = rrow(m, has);
+            Chunk<T>::load(reinterpret_cast<const T*>(p.R) + rm * p.ldr + n, rv);
+          }
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] += rv[e];
+          for (int e = 0; e < EPC; ++e) v[e] += has ? rv[e] : 0.f;
+        }
+        if constexpr (BWD) {
+          if (p.mask) {
+            float mv[EPC];
+            Chunk<T>::load(reinterpret_cast<const T*>(&mk4), mv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+          }
         }
         if (p.act == TDEED_ACT_RELU) {
 #pragma unroll
@@ -344,9 +405,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
             cs2[e] = fmaf(r, r, cs2[e]);
           }
         }
+        if constexpr (BWD) {
+          if (p.bpart) {
+            float zv[EPC];
+            Chunk<T>::load(reinterpret_cast<const T*>(&bz4), zv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const float r = round_to<T>(v[e]);
+              cs1[e] += r;
+              cs2[e] = fmaf(r, zv[e] - bm[e], cs2[e]);
+            }
+            if (p.bzd) {
+              Chunk<T>::load(reinterpret_cast<const T*>(&bzd4), zv);
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) cs3[e] = fmaf(round_to<T>(v[e]), zv[e] - bmd[e], cs3[e]);
+            }
+          }
+        }
       }
     }
     __syncthreads();
+  }
+  if constexpr (BWD) {
+    if (p.bpart) {                                 // one row of sums at a time through [RLN][BN] floats (fits every tile shape)
+      constexpr int RLN = 256 / CPR;
+      float* red = reinterpret_cast<float*>(lds);
+      const int cj = tid % CPR, rl = tid / CPR;
+      const int nrow = p.bzd ? 3 : 2;
+      for (int which = 0; which < nrow; ++which) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[rl * BN + cj * EPC + e] = which == 0 ? cs1[e] : (which == 1 ? cs2[e] : cs3[e]);
+        __syncthreads();
+        for (int col = tid; col < BN; col += 256) {
+          if (n0 + col < p.N) {
+            float a = 0.f;
+            for (int i = 0; i < RLN; ++i) a += red[i * BN + col];
+            p.bpart[((long)tile_m * 3 + which) * p.N + n0 + col] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
   if (p.colpart) {
     constexpr int RLN = 256 / CPR;          // row lanes per column chunk
@@ -370,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 }
 
 template <typename T>
-static int launch_gemm(const GemmP& p, hipStream_t st) {
+static int launch_gemm(const GemmP& p, hipStream_t st, bool bwd = false) {
   const long mb = (p.M + 127) / 128;
   // column tile: least padded MFMA work, narrower tiles charged for their extra A re-reads /
   // LDS traffic; then shrink while the grid would leave most of the 256 CUs idle.
@@ -406,6 +505,10 @@ static int launch_gemm(const GemmP& p, hipStream_t st) {
   }
 #define TD_GEMM(BNv)                                                                                                   \
   do {                                                                                                                 \
+    if (bwd) {                                                                                                         \
+      hipLaunchKernelGGL((gemm_kernel<T, BNv, 0, true>), dim3((unsigned)grid), dim3(256), 0, st, p);                   \
+      break;                                                                                                           \
+    }                                                                                                                  \
     if constexpr (sizeof(T) == 2) {                                                                                    \
       if (se == 3) hipLaunchKernelGGL((gemm_kernel<T, BNv, 3>), dim3((unsigned)grid), dim3(256), se3_bytes, st, p);    \
     }                                                                                                                  \
@@ -443,7 +546,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   if (gather_stride > 1)
     TD_CHECK(gather_hi > 0 && gather_wi > 0 && gather_ho > 0 && gather_wo > 0 && M % (gather_ho * gather_wo) == 0,
              "gemm: bad gather geometry");
-  GemmP p;
+  GemmP p{};
   p.A = A; p.lda = lda; p.A0 = A0; p.lda0 = lda0; p.k0 = A0 ? k0 : 0;
   p.a_scale = a_scale; p.a_scale_rows = a_scale_rows > 0 ? a_scale_rows : 1;
   p.M = M; p.K = K; p.N = N; p.W = W; p.ldw = ldw; p.scale = scale; p.shift = shift;
@@ -454,6 +557,43 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   p.se = SeP{};
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st) : launch_gemm<bf16_t>(p, st);
+}
+
+// Input-gradient contraction of a training bottleneck's conv1 (dx = dz1 @ W1, W given as [N = Cin][K = Cout]) whose output IS the
+// gradient at the previous block's output ReLU (timm Bottleneck.forward: x = act3(bn3(conv3) + shortcut), under autograd;
+// /root/reference/model/model.py:265-324): instead of leaving that ReLU's backward and the statistics pass of the BatchNorm
+// backward behind it to passes of their own over the map, the epilogue
+//   * adds the residual R (the block's own shortcut gradient; with r_hi > 0 R holds rows for the even pixels of an
+//     r_hi x r_wi frame only: the stride-2 shortcut conv's input gradient, no scatter-add pass),
+//   * sends columns [0, n2) to C2 before the residual (gate-shift blocks, as tdeed_gemm_fwd's c2_pre),
+//   * masks with mask[m][n] > 0 (the previous block's output = this block's input),
+//   * leaves per-tile column sums of the stored values v: sum v, sum v * (bz - bmean) and (bzd given: the previous block's
+//     shortcut BatchNorm) sum v * (bzd - bmean_d) in bpart [ceil(M / 128)][3][N].
+extern "C" int tdeed_gemm_dgrad(const void* A, long lda, int M, int K, int N, const void* W, long ldw, const void* R, long ldr,
+                                int r_hi, int r_wi, void* C, long ldc, void* C2, long ldc2, int n2, const void* mask,
+                                long ldmask, const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd,
+                                const float* bmean_d, float* bpart, int dtype, void* stream) {
+  TD_CHECK(A && W && C, "gemm_dgrad: null pointer");
+  TD_CHECK(M > 0 && K > 0 && N > 0, "gemm_dgrad: bad sizes M=%d K=%d N=%d", M, K, N);
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gemm_dgrad: bad dtype %d", dtype);
+  TD_CHECK(K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0, "gemm_dgrad: sizes must be multiples of 8");
+  TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm_dgrad: bad second output");
+  TD_CHECK(!R || ldr % 8 == 0, "gemm_dgrad: bad residual stride");
+  TD_CHECK(r_hi == 0 || (R && r_hi > 0 && r_wi > 0 && M % (r_hi * r_wi) == 0), "gemm_dgrad: bad stride-2 residual geometry");
+  TD_CHECK(!mask || ldmask % 8 == 0, "gemm_dgrad: bad mask stride");
+  TD_CHECK(!bpart || (bz && bmean && ldbz % 8 == 0 && (!bzd || (bmean_d && ldbzd % 8 == 0))), "gemm_dgrad: bad statistics operands");
+  GemmP p{};
+  p.A = A; p.lda = lda; p.a_scale_rows = 1;
+  p.M = M; p.K = K; p.N = N; p.W = W; p.ldw = ldw;
+  p.R = R; p.ldr = ldr; p.act = TDEED_ACT_NONE; p.C = C; p.ldc = ldc;
+  p.g_stride = 1;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0; p.c2_pre = C2 ? 1 : 0;
+  p.mask = mask; p.ldmask = ldmask;
+  p.bz = bz; p.ldbz = ldbz; p.bmean = bmean; p.bzd = bpart ? bzd : nullptr; p.ldbzd = ldbzd; p.bmean_d = bmean_d;
+  p.bpart = bpart;
+  p.r_hi = r_hi; p.r_wi = r_wi;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TDEED_F32 ? launch_gemm<float>(p, st, true) : launch_gemm<bf16_t>(p, st, true);
 }
 
 // conv3 of a bottleneck with the SE excitation inside: the operand re-scale gate[frame][k] is computed by every workgroup
@@ -478,7 +618,7 @@ extern "C" int tdeed_gemm_se_fwd(const void* A, long lda, int rows_per_frame, co
   TD_CHECK(!R_ || ldr % 8 == 0, "gemm_se: ldr=%ld must be a multiple of 8", ldr);
   TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm_se: bad second output");
   TD_CHECK(act >= 0 && act <= 2, "gemm_se: bad act %d", act);
-  GemmP p;
+  GemmP p{};
   p.A = A; p.lda = lda; p.A0 = nullptr; p.lda0 = 0; p.k0 = 0;
   p.a_scale = pooled;            // non-null marks a gated operand; the SE = 3 kernel never reads it as gates
   p.a_scale_rows = rows_per_frame;

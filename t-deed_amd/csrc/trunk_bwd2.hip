@@ -230,3 +230,236 @@ extern "C" int tdeed_se_bn_bwd_apply(const void* d, const void* z, const float* 
   TD_LAUNCH_CHECK("se_bn_bwd_apply");
   return TDEED_OK;
 }
+
+// =========================================================================== "gradient sink": ReLU mask + BatchNorm statistics
+// at the PRODUCERS of a block-input gradient
+// The gradient dx of a bottleneck's input is the gradient `dout` at the previous block's output ReLU.  The previous block's
+// backward starts with g = dout * [out > 0] and the column sums (sum g, sum g * xhat) of its conv3 (and shortcut) BatchNorm.
+// Both are linear in dout's contributions, so every kernel that writes or adds into dx applies the mask and leaves the sums of
+// what it contributed (tdeed_gemm_dgrad's epilogue; here: the gate-shift module's input gradient joining columns [0, Fp)).
+// The previous block then runs only the apply pass of its BatchNorm backward (tdeed_bn_bwd_from_parts): the masked-gradient
+// map `d_res`, the separate statistics pass and the ReLU pass disappear.
+
+// dx[m][c] (c < Fp, row stride C) = round(dx + (a[m][c] + b[m][c]) * [mask[m][c] > 0]);  part[wg][k][c] (k < 3, c < Fp) =
+// sums over the workgroup's rows of delta = new - old, delta * (bz - bmean), delta * (bzd - bmean_d)  (mask / bz / bzd NULL: skipped)
+template <typename T>
+__global__ __launch_bounds__(256) void gsf_add_cols_sink_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
+                                                                int Fp, T* __restrict__ dx, const T* __restrict__ mask,
+                                                                long ldmask, const T* __restrict__ bz, long ldbz,
+                                                                const float* __restrict__ bmean, const T* __restrict__ bzd,
+                                                                long ldbzd, const float* __restrict__ bmean_d,
+                                                                float* __restrict__ part, int nch, long rpw) {
+  constexpr int EPC = Chunk<T>::N;
+  extern __shared__ float red[];                                 // [RL][3][Fp]
+  const int RL = 256 / nch, rl = threadIdx.x / nch, ck = threadIdx.x - rl * nch;
+  const int c0 = ck * EPC;
+  float s1[EPC], s2[EPC], s3[EPC], bm[EPC], bmd[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    s1[e] = s2[e] = s3[e] = 0.f;
+    bm[e] = (part && rl < RL) ? bmean[c0 + e] : 0.f;
+    bmd[e] = (part && bzd && rl < RL) ? bmean_d[c0 + e] : 0.f;
+  }
+  const long m0 = (long)blockIdx.x * rpw, m1 = min(M, m0 + rpw);
+  if (rl < RL) {
+    for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * 2) {
+      float av[2][EPC], bv[2][EPC], xv[2][EPC], mv[2][EPC], zv[2][EPC], zd[2][EPC];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long r = min(r0 + (long)u * RL, m1 - 1);
+        Chunk<T>::load(a + r * Fp + c0, av[u]);
+        Chunk<T>::load(b + r * Fp + c0, bv[u]);
+        Chunk<T>::load(dx + r * C + c0, xv[u]);
+        if (mask) Chunk<T>::load(mask + r * ldmask + c0, mv[u]);
+        if (part) Chunk<T>::load(bz + r * ldbz + c0, zv[u]);
+        if (part && bzd) Chunk<T>::load(bzd + r * ldbzd + c0, zd[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long r = r0 + (long)u * RL;
+        if (r < m1) {
+          float o[EPC];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float add = (mask && !(mv[u][e] > 0.f)) ? 0.f : av[u][e] + bv[u][e];
+            o[e] = round_to<T>(xv[u][e] + add);
+            const float dl = o[e] - xv[u][e];
+            if (part) {
+              s1[e] += dl;
+              s2[e] = fmaf(dl, zv[u][e] - bm[e], s2[e]);
+              if (bzd) s3[e] = fmaf(dl, zd[u][e] - bmd[e], s3[e]);
+            }
+          }
+          Chunk<T>::store(dx + r * C + c0, o);
+        }
+      }
+    }
+  }
+  if (!part) return;
+  if (rl < RL) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red[(rl * 3 + 0) * Fp + c0 + e] = s1[e];
+      red[(rl * 3 + 1) * Fp + c0 + e] = s2[e];
+      red[(rl * 3 + 2) * Fp + c0 + e] = s3[e];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 3 * Fp; j += 256) {
+    float v = 0.f;
+    for (int i = 0; i < RL; ++i) v += red[i * 3 * Fp + j];
+    part[(long)blockIdx.x * 3 * Fp + j] = v;
+  }
+}
+
+static long add_cols_rpw(long M, int nch) {
+  const long RL = 256 / nch;
+  long rpw = RL * 2 * 4;
+  if ((M + rpw - 1) / rpw > 2048) rpw = ((M + 2047) / 2048 + RL * 2 - 1) / (RL * 2) * (RL * 2);
+  return rpw;
+}
+extern "C" int tdeed_gsf_add_cols_sink_parts(long M, int Fp, int dtype) {
+  const int nch = Fp / (dtype == TDEED_F32 ? 4 : 8);
+  if (nch <= 0 || nch > 256) return 0;
+  const long rpw = add_cols_rpw(M, nch);
+  return (int)((M + rpw - 1) / rpw);
+}
+
+extern "C" int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask,
+                                       long ldmask, const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd,
+                                       const float* bmean_d, float* part, int dtype, void* stream) {
+  TD_CHECK(a && b && dx && M > 0 && Fp > 0 && Fp <= C && Fp % 8 == 0 && C % 8 == 0, "gsf_add_cols_sink: bad arguments");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_add_cols_sink: bad dtype %d", dtype);
+  TD_CHECK(!part || (bz && bmean && (!bzd || bmean_d)), "gsf_add_cols_sink: statistics operands missing");
+  TD_CHECK((!mask || ldmask % 8 == 0) && (!bz || ldbz % 8 == 0) && (!bzd || ldbzd % 8 == 0), "gsf_add_cols_sink: bad row strides");
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = Fp / (dtype == TDEED_F32 ? 4 : 8);
+  TD_CHECK(nch <= 256, "gsf_add_cols_sink: Fp=%d too wide", Fp);
+  const long rpw = add_cols_rpw(M, nch);
+  const long nwg = (M + rpw - 1) / rpw;
+  const size_t smem = (size_t)(256 / nch) * 3 * Fp * sizeof(float);
+  TD_CHECK(smem <= 64 * 1024, "gsf_add_cols_sink: Fp=%d beyond the LDS budget", Fp);
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(gsf_add_cols_sink_kernel<float>, dim3((unsigned)nwg), dim3(256), smem, st, (const float*)a, (const float*)b,
+                       M, C, Fp, (float*)dx, (const float*)mask, ldmask, (const float*)bz, ldbz, bmean, (const float*)bzd, ldbzd,
+                       bmean_d, part, nch, rpw);
+  else
+    hipLaunchKernelGGL(gsf_add_cols_sink_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), smem, st, (const bf16_t*)a,
+                       (const bf16_t*)b, M, C, Fp, (bf16_t*)dx, (const bf16_t*)mask, ldmask, (const bf16_t*)bz, ldbz, bmean,
+                       (const bf16_t*)bzd, ldbzd, bmean_d, part, nch, rpw);
+  TD_LAUNCH_CHECK("gsf_add_cols_sink");
+  return TDEED_OK;
+}
+
+// --------------------------------------------------------------------------- BatchNorm backward from producer partials
+// sums[0][c] = sum_p A[p][0][c] + sum_p B[p][0][c] (c < nB),  sums[1][c] = rstd[c] * (the same over row `q` of the partials):
+// tmpA [SA][3][C], tmpB [SB][3][nB] are the partial rows already folded to <= 64 slices.  One thread per channel.
+__global__ __launch_bounds__(256) void bn_parts_finalize_kernel(const float* __restrict__ tmpA, int SA, const float* __restrict__ tmpB,
+                                                                int SB, int nB, int q, int C, const float* __restrict__ rstd,
+                                                                float* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < SA; ++s) {
+    s1 += (double)tmpA[((long)s * 3 + 0) * C + c];
+    s2 += (double)tmpA[((long)s * 3 + q) * C + c];
+  }
+  if (tmpB && c < nB)
+    for (int s = 0; s < SB; ++s) {
+      s1 += (double)tmpB[((long)s * 3 + 0) * nB + c];
+      s2 += (double)tmpB[((long)s * 3 + q) * nB + c];
+    }
+  sums[c] = (float)s1;
+  sums[C + c] = (float)(s2 * (double)rstd[c]);
+}
+
+// dz = k1 * g + k2 * z + k3 with g already masked (k1..k3 as in tdeed_bn_train_bwd)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_g_kernel(const T* __restrict__ z, const T* __restrict__ g,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ w, const float* __restrict__ sums,
+                                                             float inv_M, T* __restrict__ dz, long M, int nch, int rpw) {
+  constexpr int EPC = Chunk<T>::N;
+  const int RL = 256 / nch, rl = threadIdx.x / nch, ck = threadIdx.x - rl * nch;
+  if (rl >= RL) return;
+  const int C = nch * EPC, c0 = ck * EPC;
+  float k1[EPC], k2[EPC], k3[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int c = c0 + e;
+    const float rs = rstd[c], mu = mean[c], s1 = sums[c] * inv_M, s2 = sums[C + c] * inv_M;
+    k1[e] = w[c] * rs;
+    k2[e] = -k1[e] * rs * s2;
+    k3[e] = k1[e] * (mu * rs * s2 - s1);
+  }
+  const long m0 = (long)blockIdx.x * rpw, m1 = min(M, m0 + rpw);
+  for (long r0 = m0 + rl; r0 < m1; r0 += (long)RL * SB_U) {
+    float zv[SB_U][EPC], gv[SB_U][EPC];
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+      const long r = min(r0 + (long)u * RL, m1 - 1);
+      Chunk<T>::load(z + r * C + c0, zv[u]);
+      Chunk<T>::load(g + r * C + c0, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+      const long r = r0 + (long)u * RL;
+      if (r < m1) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) zv[u][e] = fmaf(k1[e], gv[u][e], fmaf(k2[e], zv[u][e], k3[e]));
+        Chunk<T>::store(dz + r * C + c0, zv[u]);
+      }
+    }
+  }
+}
+
+// partA: PA rows of [3][C] floats (tdeed_gemm_dgrad's bpart), partB (optional): PB rows of [3][nB] (tdeed_gsf_add_cols_sink's
+// part); q = 1 / 2: which product row holds this BatchNorm's sum g * (z - mean).  tmp: fp32 [2 * 64 * 3 * C] scratch;
+// sums: fp32 [2][C] (out: d bias, d weight).  dz may be NULL (statistics only).
+extern "C" int tdeed_bn_bwd_from_parts(const void* z, const void* g, long M, int C, const float* mean, const float* rstd,
+                                       const float* w, const float* partA, int PA, const float* partB, int PB, int nB, int q,
+                                       float* tmp, float* sums, void* dz, int dtype, void* stream) {
+  TD_CHECK(z && g && mean && rstd && w && partA && tmp && sums, "bn_bwd_from_parts: null pointer");
+  TD_CHECK(M > 0 && C > 0 && C % 8 == 0 && PA > 0 && (q == 1 || q == 2), "bn_bwd_from_parts: bad sizes");
+  TD_CHECK(!partB || (PB > 0 && nB > 0 && nB <= C), "bn_bwd_from_parts: bad second partial set");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "bn_bwd_from_parts: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const float* tA = partA;
+  int SA = PA;
+  if (PA > 64) {
+    int rc = tdeed_fold_rows(partA, 3L * C, PA, 3 * C, 64, tmp, 3L * C, stream);
+    if (rc != TDEED_OK) return rc;
+    tA = tmp;
+    SA = 64;                                                     // (slices behind the last row hold zeros)
+  }
+  const float* tB = nullptr;
+  int SB = 0;
+  if (partB) {
+    tB = partB;
+    SB = PB;
+    if (PB > 64) {
+      float* t2 = tmp + 64L * 3 * C;
+      int rc = tdeed_fold_rows(partB, 3L * nB, PB, 3 * nB, 64, t2, 3L * nB, stream);
+      if (rc != TDEED_OK) return rc;
+      tB = t2;
+      SB = 64;
+    }
+  }
+  hipLaunchKernelGGL(bn_parts_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, tA, SA, tB, SB, nB, q, C, rstd, sums);
+  TD_LAUNCH_CHECK("bn_parts_finalize");
+  if (!dz) return TDEED_OK;
+  const int nch = C / (dtype == TDEED_F32 ? 4 : 8);
+  TD_CHECK(nch <= 256, "bn_bwd_from_parts: C=%d too wide", C);
+  const int rpw = (256 / nch) * SB_U * 4;
+  const long nwg = (M + rpw - 1) / rpw;
+  TD_CHECK(nwg < 0x7fffffffL, "bn_bwd_from_parts: too many rows");
+  const float inv_M = 1.0f / (float)M;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_g_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)z, (const float*)g, mean,
+                       rstd, w, sums, inv_M, (float*)dz, M, nch, rpw);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_g_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)g,
+                       mean, rstd, w, sums, inv_M, (bf16_t*)dz, M, nch, rpw);
+  TD_LAUNCH_CHECK("bn_bwd_apply_g");
+  return TDEED_OK;
+}

@@ -273,6 +273,68 @@ def se_bn_bwd(d, z, bn, w, gate, hid, se_w1, se_w2):
     return dz, st[1], st[0], d_pre2, d_hid
 
 
+class GradSink:
+    """The ReLU backward at a block's output and the statistics of the BatchNorm backward behind it, delegated to whichever
+    kernels produce the gradient arriving there (csrc/trunk_bwd2.hip "gradient sink"): mask = the block's output (ReLU
+    backward: out > 0), z / mean = raw output and batch mean of its conv3 BatchNorm, zd / mean_d the same for its shortcut
+    BatchNorm (blocks with a downsample conv).  The producers leave their partial column sums in partA (tdeed_gemm_dgrad:
+    one row per 128-row tile) and partB (the gate-shift module's input gradient joining columns [0, nB))."""
+
+    def __init__(self, mask, z, mean, zd=None, mean_d=None):
+        C = z.shape[-1]
+        self.mask, self.z, self.mean, self.zd, self.mean_d, self.C = mask.view(-1, C), z.view(-1, C), mean, zd, mean_d, C
+        if zd is not None:
+            self.zd = zd.view(-1, C)
+        self.partA = self.partB = None
+        self.nB = 0
+
+
+def gemm_dgrad(dz, wt, sink=None, residual=None, r_hw=None, out2=None):
+    """dx (M, N) = ((dz (M,K) @ wt (N,K)^T) + residual) masked / summed for `sink` (tdeed_gemm_dgrad).  r_hw = (hi, wi): the
+    residual has rows for the even pixels of every hi x wi frame only; out2 (M, n2): columns [0, n2) before the residual."""
+    N, K = wt.shape
+    M = dz.numel() // K
+    dev = dz.device
+    dx = torch.empty((M, N), dtype=dz.dtype, device=dev)
+    bpart = None
+    if sink is not None:
+        bpart = _f32(((M + 127) // 128, 3, N), dev)
+        sink.partA = bpart
+    rh, rw = r_hw if r_hw is not None else (0, 0)
+    call("tdeed_gemm_dgrad", ptr(dz), K, M, K, N, ptr(wt), K, ptr(residual), (residual.shape[-1] if residual is not None else 0),
+         rh, rw, ptr(dx), N, ptr(out2), (out2.shape[-1] if out2 is not None else 0), (out2.shape[-1] if out2 is not None else 0),
+         ptr(sink.mask if sink else None), N, ptr(sink.z if sink else None), N, ptr(sink.mean if sink else None),
+         ptr(sink.zd if sink else None), N, ptr(sink.mean_d if sink else None), ptr(bpart), dtype_code(dz.dtype), stream_ptr())
+    return dx
+
+
+def gsf_add_cols_sink(a, b, dx, Fp, sink):
+    """dx[:, :Fp] += (a + b) masked / summed for `sink` (tdeed_gsf_add_cols_sink)"""
+    C = dx.shape[-1]
+    M = dx.numel() // C
+    P = _lib.load().tdeed_gsf_add_cols_sink_parts(M, Fp, dtype_code(dx.dtype))
+    part = _f32((P, 3, Fp), dx.device)
+    sink.partB, sink.nB = part, Fp
+    call("tdeed_gsf_add_cols_sink", ptr(a), ptr(b), M, C, Fp, ptr(dx), ptr(sink.mask), C, ptr(sink.z), C, ptr(sink.mean),
+         ptr(sink.zd), C, ptr(sink.mean_d), ptr(part), dtype_code(dx.dtype), stream_ptr())
+    return dx
+
+
+def bn_bwd_from_parts(z, g, ctx, w, sink, q=1, want_dz=True):
+    """BatchNorm backward of z for the already masked gradient g whose statistics the producers left in `sink`
+    (q = 1: against sink.z, q = 2: against sink.zd).  -> dz (or None), dw, db."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    tmp, sums = _f32((2 * 64 * 3 * C,), dev), _f32((2, C), dev)
+    dz = torch.empty_like(z) if want_dz else None
+    pb = sink.partB
+    call("tdeed_bn_bwd_from_parts", ptr(z), ptr(g), M, C, ptr(ctx[0]), ptr(ctx[1]), ptr(w), ptr(sink.partA), sink.partA.shape[0],
+         ptr(pb), (pb.shape[0] if pb is not None else 0), sink.nB, q, ptr(tmp), ptr(sums), ptr(dz), dtype_code(z.dtype),
+         stream_ptr())
+    return dz, sums[1], sums[0]
+
+
 def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True, in_affine=None):
     """x (N,Hi,Wi,C), dy (N,Ho,Wo,C) -> dx like x (None if not want_dx), dw fp32 [G][9][gw][gw].
     in_affine = (a, b) (bf16): x is a raw conv output, relu(a*x + b) is applied on load for the weight gradient."""

@@ -149,12 +149,25 @@ class TrainEngine:
         dx, d_enc = B_.avgpool_posenc_bwd(d_feat, ctx.hw)
         grads["temp_enc"] = d_enc
         dx = dx.view(ctx.x_shape)
-        for blk in reversed(self.blocks):
+        from .trunk_train import ZMASK, SINK
+        nb = len(self.blocks)
+        sinks = [blk.make_sink() for blk in self.blocks[:-1]] if SINK else []
+        stem_sink = B_.GradSink(ctx.y0, ctx.z0, ctx.bn0[0]) if SINK else None
+        for i in reversed(range(nb)):
+            blk = self.blocks[i]
             _lib.SCOPE = blk.blk.name + ".bwd"
-            dx = blk.backward(dx, grads)
+            if SINK:
+                # block i's input gradient is produced masked by the ReLU in front of it, with the column sums the BatchNorm
+                # backward of block i-1 (or of the stem) needs
+                dx = blk.backward(dx, grads, sink_in=(sinks[i] if i + 1 < nb else None),
+                                  sink_out=(sinks[i - 1] if i > 0 else stem_sink))
+            else:
+                dx = blk.backward(dx, grads)
         _lib.SCOPE = "stem.bwd"
-        from .trunk_train import ZMASK
-        dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, None if ZMASK else ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
+        if SINK:
+            dz0, dw, db = B_.bn_bwd_from_parts(ctx.z0, dx, ctx.bn0, sd["_features.stem.bn.weight"], stem_sink, q=1)
+        else:
+            dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, None if ZMASK else ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
         grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
         grads["_features.stem.conv.weight"] = B_.stem_wgrad(ctx.fr, dz0, crop=ctx.crop, flip=ctx.flip)
         return grads

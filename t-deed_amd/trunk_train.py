@@ -20,6 +20,9 @@ ZMASK = _os.environ.get("TDEED_TRAIN_ZMASK", "1") == "1"
 # SE gate gradient, SE scale backward and conv2's BatchNorm backward from five per-frame sums (trunk_bwd2.hip): 5 passes over
 # the block's output-resolution maps instead of 9; TDEED_TRAIN_SE_BN_FUSED=0 restores pool_rows / scale_rows / bn_train_bwd
 SE_BN_FUSED = ZMASK and _os.environ.get("TDEED_TRAIN_SE_BN_FUSED", "1") == "1"
+# output-ReLU backward and BatchNorm-backward statistics applied by the producers of each block-input gradient
+# (ops_bwd.GradSink); TDEED_TRAIN_SINK=0 restores the masked statistics pass + d_res map per block
+SINK = _os.environ.get("TDEED_TRAIN_SINK", "1") == "1"
 
 
 def _dense(w, dt):
@@ -242,8 +245,17 @@ class BottleneckTrain:
         self.ctx = c
         return c.out
 
-    def backward(self, dout, grads):
-        """dout: gradient of forward()'s output; fills grads[name] for this block's parameters, returns d x."""
+    def make_sink(self):
+        """The sink the producers of this block's OUTPUT gradient fill (the next block's backward): output ReLU mask and
+        the statistics of the conv3 / shortcut BatchNorm backward (ops_bwd.GradSink)."""
+        c, ds = self.ctx, self.blk.has_downsample
+        return B_.GradSink(c.out, c.z3, c.bn3[0], zd=(c.zd if ds else None), mean_d=(c.bnd[0] if ds else None))
+
+    def backward(self, dout, grads, sink_in=None, sink_out=None):
+        """dout: gradient of forward()'s output; fills grads[name] for this block's parameters, returns d x.
+        sink_in: dout is ALREADY masked by this block's output ReLU and its BatchNorm column sums lie in sink_in (whoever
+        produced dout filled the sink make_sink() returned); sink_out: the sink of the block in front, applied by the kernels
+        that write d x here (then d x comes back masked, too)."""
         blk, sd, pre, c = self.blk, self.sd, self.pre, self.ctx
         N, h2, w2, C = c.out.shape
         hw2 = h2 * w2
@@ -252,7 +264,12 @@ class BottleneckTrain:
             p = (self.c1 if name == "conv1" else f"{pre}.{name}") + ".bn"
             grads[p + ".weight"], grads[p + ".bias"] = dw, db
 
-        dz3, d_sc, dw, db = B_.bn_train_bwd(c.z3, dout, c.out, c.bn3, sd[pre + ".conv3.bn.weight"], relu=True, want_res=True)
+        if sink_in is not None:
+            # only the apply pass is left of this BatchNorm backward, and dout itself is the shortcut's gradient
+            dz3, dw, db = B_.bn_bwd_from_parts(c.z3, dout, c.bn3, sd[pre + ".conv3.bn.weight"], sink_in, q=1)
+            d_sc = dout
+        else:
+            dz3, d_sc, dw, db = B_.bn_train_bwd(c.z3, dout, c.out, c.bn3, sd[pre + ".conv3.bn.weight"], relu=True, want_res=True)
         bn_names("conv3", dw, db)
         d_y2s = ops.gemm(dz3, self.w3.wt, None, None, ops.ACT_NONE).view(N, h2, w2, C)
         grads[pre + ".conv3.conv.weight"] = B_.wgrad(dz3, c.y2s, with_bias=False, M=N * hw2)[0].reshape(
@@ -296,6 +313,31 @@ class BottleneckTrain:
         # identity shortcut: its gradient joins dx in the contraction's epilogue (no separate add pass); behind a gate-shift the
         # first Fp columns of the contraction belong to the module's backward alone: they leave as a compact tensor and dx keeps
         # only the shortcut gradient there (no slice copy / zero fill)
+        if sink_out is not None:
+            # the contraction's epilogue takes every other contribution to d x as its residual (identity shortcut: d_sc; shortcut
+            # conv: its input gradient, on the even pixels of a stride-2 block -- no scatter-add pass), applies the ReLU mask of
+            # the block in front and leaves that block's BatchNorm column sums (tdeed_gemm_dgrad)
+            res, r_hw = d_sc.view(-1, Cin) if not blk.has_downsample else None, None
+            if blk.has_downsample:
+                wdn = sd[pre + ".downsample.bn.weight"]
+                if sink_in is not None:
+                    dzd, dw, db = B_.bn_bwd_from_parts(c.zd, dout, c.bnd, wdn, sink_in, q=2)
+                else:
+                    dzd, _, dw, db = B_.bn_train_bwd(c.zd, d_sc, None, c.bnd, wdn, relu=False)
+                bn_names("downsample", dw, db)
+                res = ops.gemm(dzd, self.wd.wt, None, None, ops.ACT_NONE)
+                grads[pre + ".downsample.conv.weight"] = B_.wgrad(dzd, c.xs, with_bias=False, M=N * hw2)[0].reshape(
+                    sd[pre + ".downsample.conv.weight"].shape)
+                r_hw = (h, w) if blk.stride == 2 else None
+            dA = (torch.empty((Nf * h * w, self.gs.Fp), dtype=dz1.dtype, device=dz1.device) if self.gs is not None else None)
+            dx = B_.gemm_dgrad(dz1, self.w1.wt, sink=sink_out, residual=res, r_hw=r_hw, out2=dA).view(Nf, h, w, Cin)
+            grads[self.c1 + ".conv.weight"] = B_.wgrad(dz1, c.a1, with_bias=False, M=Nf * h * w, X0=c.G,
+                                                       k0=(self.gs.Fp if c.G is not None else 0))[0].reshape(
+                sd[self.c1 + ".conv.weight"].shape)
+            if self.gs is not None:
+                d_xs, dz_bn = self.gs.backward(dA, grads)
+                B_.gsf_add_cols_sink(d_xs, dz_bn, dx, self.gs.Fp, sink_out)
+            return dx
         fuse = FUSE_RES and not blk.has_downsample
         dA = (torch.empty((Nf * h * w, self.gs.Fp), dtype=dz1.dtype, device=dz1.device)
               if (self.gs is not None and FUSE_RES) else None)

@@ -101,8 +101,9 @@ def test_se_and_conv2_batchnorm_backward_from_frame_sums_equals_the_pass_per_op_
     close(d_pre2_f, d_pre2, "d_pre2", 2e-5 if dtype == torch.float32 else 1e-4)
     close(d_hid_f, d_hid, "d_hid", 2e-5 if dtype == torch.float32 else 1e-4)
     close(dz, dz_ref, "dz")
-    close(dw, dw_ref, "dw", tol if dtype == torch.float32 else 5e-3)
-    close(db, db_ref, "db", tol if dtype == torch.float32 else 5e-3)
+    # (bf16: the chain rounds d_y2 to bf16 before the sums, the fused form keeps it in fp32)
+    close(dw, dw_ref, "dw", tol if dtype == torch.float32 else 1.5e-2)
+    close(db, db_ref, "db", tol if dtype == torch.float32 else 1.5e-2)
     if dtype == torch.float32:
         zc = z.cpu().double().requires_grad_(True)
         wc, bc = bw.cpu().double().requires_grad_(True), bb.cpu().double().requires_grad_(True)
@@ -115,3 +116,73 @@ def test_se_and_conv2_batchnorm_backward_from_frame_sums_equals_the_pass_per_op_
         close(dz, zc.grad, "dz vs autograd", 1e-4)
         close(dw, wc.grad, "dw vs autograd", 1e-4)
         close(db, bc.grad, "db vs autograd", 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("frames,hi,wi,K,N,n2,res", [(9, 7, 5, 64, 32, 0, "s2"), (4, 14, 14, 152, 152, 40, "full"),
+                                                     (3, 9, 9, 320, 128, 0, "s2"), (2, 28, 28, 128, 128, 0, "full"),
+                                                     (5, 6, 6, 48, 56, 16, "none")])
+def test_input_gradient_contraction_with_the_gradient_sink_epilogue(dtype, frames, hi, wi, K, N, n2, res):
+    """tdeed_gemm_dgrad: residual (full / on the even pixels of a stride-2 block), compact second output before the residual,
+    ReLU mask of the block in front and the per-tile column sums of the BatchNorm backward behind it, against torch; then
+    tdeed_gsf_add_cols_sink on top and tdeed_bn_bwd_from_parts against the masked-statistics pass (tdeed_bn_train_bwd)."""
+    from tdeed_amd import ops_bwd as B_
+    M = frames * hi * wi
+    f32 = dtype == torch.float32
+    dz = _rand((M, K), 11, 0.5).to(DEV).to(dtype)
+    wt = _rand((N, K), 12, 0.2).to(DEV).to(dtype)
+    mask = _rand((M, N), 13).to(DEV).to(dtype)
+    z = _rand((M, N), 14).to(DEV).to(dtype)
+    zd = _rand((M, N), 15).to(DEV).to(dtype)
+    mean, mean_d = _rand((N,), 16, 0.2).to(DEV), _rand((N,), 17, 0.2).to(DEV)
+    ho, wo = (hi + 1) // 2, (wi + 1) // 2
+    R = r_hw = None
+    if res == "full":
+        R = _rand((M, N), 18, 0.5).to(DEV).to(dtype)
+    elif res == "s2":
+        R = _rand((frames * ho * wo, N), 18, 0.5).to(DEV).to(dtype)
+        r_hw = (hi, wi)
+    out2 = torch.empty((M, n2), dtype=dtype, device=DEV) if n2 else None
+    sink = B_.GradSink(mask, z, mean, zd=zd, mean_d=mean_d)
+    dx = B_.gemm_dgrad(dz, wt, sink=sink, residual=R, r_hw=r_hw, out2=out2)
+    torch.cuda.synchronize()
+    acc = dz.double() @ wt.double().t()
+    if n2:
+        ref2 = acc[:, :n2].clone()
+        acc[:, :n2] = 0
+        assert max_abs(out2, ref2.to(dtype)) <= (1e-4 if f32 else 3e-2) * max(1.0, float(ref2.abs().max()))
+    if res == "full":
+        acc = acc + R.double()
+    elif res == "s2":
+        full = torch.zeros((frames, hi, wi, N), dtype=torch.float64, device=DEV)
+        full[:, ::2, ::2] = R.double().view(frames, ho, wo, N)
+        acc = acc + full.view(M, N)
+    ref = torch.where(mask.double() > 0, acc, torch.zeros_like(acc))
+    tol = (1e-4 if f32 else 3e-2) * max(1.0, float(ref.abs().max()))
+    assert max_abs(dx, ref) <= tol
+    # column sums of what was stored
+    st = dx.double()
+    sums = sink.partA.double().sum(0)
+    want = torch.stack([st.sum(0), (st * (z.double() - mean.double())).sum(0), (st * (zd.double() - mean_d.double())).sum(0)])
+    assert max_abs(sums, want) <= 1e-3 * max(1.0, float(want.abs().max()))
+    # the gate-shift columns joining afterwards
+    C, Fp = N, 16
+    a = _rand((M, Fp), 19, 0.3).to(DEV).to(dtype)
+    b = _rand((M, Fp), 20, 0.3).to(DEV).to(dtype)
+    dx0 = dx.clone()
+    B_.gsf_add_cols_sink(a, b, dx, Fp, sink)
+    torch.cuda.synchronize()
+    add = torch.where(mask[:, :Fp].double() > 0, a.double() + b.double(), torch.zeros((M, Fp), dtype=torch.float64, device=DEV))
+    ref_cols = (dx0[:, :Fp].double() + add).to(dtype)
+    assert max_abs(dx[:, :Fp], ref_cols) <= (1e-6 if f32 else 2e-2) * max(1.0, float(ref_cols.abs().max()))
+    assert max_abs(dx[:, Fp:], dx0[:, Fp:]) == 0.0
+    # BatchNorm backward from the two partial sets == the statistics pass over the finished map
+    bw = (_rand((C,), 21, 0.3) + 1.0).to(DEV)
+    rstd = (_rand((C,), 22, 0.1).abs() + 0.5).to(DEV)
+    for q, zz, mm in ((1, z, mean), (2, zd, mean_d)):
+        dz_f, dw_f, db_f = B_.bn_bwd_from_parts(zz, dx, (mm, rstd), bw, sink, q=q)
+        dz_r, _, dw_r, db_r = B_.bn_train_bwd(zz, dx, None, (mm, rstd), bw, relu=False)
+        torch.cuda.synchronize()
+        sc = max(1.0, float(dw_r.abs().max()), float(db_r.abs().max()))
+        assert max_abs(dw_f, dw_r) <= 2e-4 * sc and max_abs(db_f, db_r) <= 2e-4 * sc, q
+        assert max_abs(dz_f, dz_r) <= (1e-4 if f32 else 2e-2) * max(1.0, float(dz_r.float().abs().max())), q

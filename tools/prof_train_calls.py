@@ -37,7 +37,7 @@ sc = pr.by_scope()
 print("per scope (stage / block, forward and backward), ms of device time and the three largest entry points:")
 for k, d in sc.items():
     tt = sum(d.values())
-    top = sorted(d.items(), key=lambda kv: -kv[1])[:3]
+    top = sorted(d.items(), key=lambda kv: -kv[1])[:(99 if os.environ.get("PROF_ALL") else 3)]
     print(f"  {k or '-':16s} {tt:8.3f} ms   " + "  ".join(f"{n.replace('tdeed_', '')} {v:.2f}" for n, v in top))
 for entry, idx in (("tdeed_gemm_fwd", (7, 8, 9)), ("tdeed_wgrad", None)):
     g = s.get(entry)
