@@ -466,6 +466,10 @@ int tdeed_fold_rows(const float* part, long pstride, int P, int n, int slices, f
 /* y = act(z * a[c] + b[c] + res) */
 int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu, void* y,
                    int dtype, void* stream);
+/* y = act(z * a + b + (res * ra + rb)): the same with the residual a raw conv output under its own BatchNorm affine (the
+ * shortcut conv of a downsampling bottleneck: its normalised map is never written) */
+int tdeed_bn_apply2(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
+                    const float* rb, int relu, void* y, int dtype, void* stream);
 /* BatchNorm (training) backward; when relu != 0 the ReLU mask comes from y (the block's output) or, with y NULL (no
  * residual in front of the ReLU), from z through the forward affine fa, fb (y > 0 <=> fa*z + fb > 0: one map less to
  * read); d_res (optional) receives the masked gradient = gradient of the residual summed in before the ReLU.  sums fp32

@@ -44,12 +44,26 @@ __global__ __launch_bounds__(256) void gsf_bwd_dw_kernel(const T* __restrict__ x
     const bool has = ts >= 0 && ts < T_len;
     const long fs = has ? f + (ts - t) : f;
     float a = 0.f;
-    for (int p = s; p < hw; p += S) {
-      const long pix = f * hw + p, pixs = fs * hw + p;
-      const float xv = (float)x[pix * C + ci];
-      const float r = xv - gate[pix * 2 + g] * xv;
-      const float ys = has ? gate[pixs * 2 + g] * (float)x[pixs * C + ci] : 0.f;
-      a = fmaf((float)dA[pix * Fp + co], ys - r, a);
+    // four pixels per trip with every load issued first (one dependent round trip per pixel before: 72 us per site)
+    for (int p0 = s; p0 < hw; p0 += 4 * S) {
+      float xv[4], gv[4], xs[4], gs[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = min(p0 + u * S, hw - 1);
+        const long pix = f * hw + p, pixs = fs * hw + p;
+        xv[u] = (float)x[pix * C + ci];
+        gv[u] = gate[pix * 2 + g];
+        xs[u] = (float)x[pixs * C + ci];
+        gs[u] = gate[pixs * 2 + g];
+        dv[u] = (float)dA[pix * Fp + co];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + u * S < hw) {
+          const float r = xv[u] - gv[u] * xv[u];
+          const float ys = has ? gs[u] * xs[u] : 0.f;
+          a = fmaf(dv[u], ys - r, a);
+        }
     }
     red[s * F + ci] = a;
   }
@@ -116,7 +130,9 @@ __global__ __launch_bounds__(256) void gsf_bwd_cw_kernel(const float* __restrict
   float acc[19];
 #pragma unroll
   for (int k = 0; k < 19; ++k) acc[k] = 0.f;
-  for (int i = threadIdx.x; i < Fh * T_len; i += 256) {
+  // the (channel, time) plane of one (clip, group) is dealt over gridDim.z workgroups (B x 2 workgroups alone left the chip
+  // idle: 61 us for 16 clips); partial rows [b * gridDim.z + z][g][19]
+  for (int i = blockIdx.z * 256 + threadIdx.x; i < Fh * T_len; i += 256 * gridDim.z) {
     const int cl = i / T_len, t = i - cl * T_len;
     const float v = dpw[((long)b * F + g * Fh + cl) * T_len + t];
     acc[18] += v;
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void gsf_bwd_cw_kernel(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 19; ++k) {
     const float s = block_sum<4>(acc[k], scratch);
-    if (threadIdx.x == 0) part[((long)b * 2 + g) * 19 + k] = s;
+    if (threadIdx.x == 0) part[(((long)b * gridDim.z + blockIdx.z) * 2 + g) * 19 + k] = s;
   }
 }
 
@@ -366,8 +382,8 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __rest
                                                                  T* __restrict__ d_bn) {
   constexpr int EPC = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  float* sw = reinterpret_cast<float*>(smraw);                 // [F][27]
-  float* dp = sw + F * 27;                                     // [PT][2][27] (+1 pad per row)
+  float* sw = reinterpret_cast<float*>(smraw);                 // [27][Fp]
+  float* dp = sw + Fp * 27;                                    // [PT][2][27] (+1 pad per row)
   float* aff = dp + PT * 55;                                   // [2][F]
   const int NCH = Fp / EPC;
   const long f = blockIdx.y;
@@ -377,7 +393,12 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __rest
   const int t = (int)(f % T_len);
   const int Fh = F >> 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < F * 27; i += 256) sw[i] = w3[i];
+  // weights tap-major [27][Fp] (zero in the pad columns): a lane's 8 channels of one tap are two 16-byte reads instead of
+  // eight 4-byte ones (the kernel is bound by its LDS reads: 2 per FMA before, 3/8 now)
+  for (int i = tid; i < Fp * 27; i += 256) {
+    const int kq = i / Fp, c = i - kq * Fp;
+    sw[i] = c < F ? w3[c * 27 + kq] : 0.f;
+  }
   for (int i = tid; i < F; i += 256) { aff[i] = sa[i]; aff[F + i] = sb[i]; }
   for (int i = tid; i < np * 27; i += 256) {
     const int pp = i / 27, kq = i - pp * 27;
@@ -397,17 +418,35 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __rest
   float xv[EPC], o[EPC];
   ld8<T>(x + pix * C + k * EPC, xv);
 #pragma unroll
+  for (int e = 0; e < EPC; ++e) o[e] = 0.f;
+  // a chunk lies in one gate group unless it straddles F/2 (F/2 not a multiple of 8): per-element group then
+  const bool one_g = (k * EPC + EPC <= Fh) || (k * EPC >= Fh);
+  const float* d0 = dp + pl * 55;
+  if (one_g) {
+    const float* d = d0 + (k * EPC >= Fh ? 27 : 0);
+#pragma unroll
+    for (int kq = 0; kq < 27; ++kq) {
+      const float dv = d[kq];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + kq * Fp + k * EPC);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(sw + kq * Fp + k * EPC + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = fmaf(w0[e], dv, o[e]);
+        o[4 + e] = fmaf(w1[e], dv, o[4 + e]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int kq = 0; kq < 27; ++kq) {
+      const float da = d0[kq], db = d0[27 + kq];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o[e] = fmaf(sw[kq * Fp + k * EPC + e], (k * EPC + e >= Fh) ? db : da, o[e]);
+    }
+  }
+#pragma unroll
   for (int e = 0; e < EPC; ++e) {
     const int c = k * EPC + e;
-    float a = 0.f;
-    if (c < F) {
-      const float* d = dp + pl * 55 + (c >= Fh ? 27 : 0);
-      const float* wc = sw + c * 27;
-#pragma unroll
-      for (int kq = 0; kq < 27; ++kq) a = fmaf(wc[kq], d[kq], a);
-      if (!(fmaf(xv[e], aff[c], aff[F + c]) > 0.f)) a = 0.f;
-    }
-    o[e] = a;
+    if (c >= F || !(fmaf(xv[e], aff[c], aff[F + c]) > 0.f)) o[e] = 0.f;
   }
   st8<T>(d_bn + pix * Fp + k * EPC, o);
 }
@@ -642,10 +681,11 @@ extern "C" int tdeed_gsf_slice(const void* x, long M, int C, int F, int Fp, void
   return TDEED_OK;
 }
 
+constexpr int GSF_CW_Z = 8;       // workgroups per (clip, gate group) of the fusion-conv weight gradient
 extern "C" long tdeed_gsf_bwd_scratch_floats(int B, int T, int hw, int F) {
   const long N = (long)B * T;
   // d_wgt [N][F], dpw [B][F][T], d_ym [N][F], d_rm [N][F], d_pre [N][hw][2], part_cw [B][2][19], part_w3 [N][F*27+2]
-  return 4 * N * F + N * hw * 2 + (long)B * 38 + N * ((long)F * 27 + 2);
+  return 4 * N * F + N * hw * 2 + (long)B * GSF_CW_Z * 38 + N * ((long)F * 27 + 2);
 }
 
 template <typename T>
@@ -665,7 +705,7 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
   float* d_rm = d_ym + N * F;
   float* d_pre = d_rm + N * F;
   float* part_cw = d_pre + N * hw * 2;
-  float* part_w3 = part_cw + (long)B * 38;
+  float* part_w3 = part_cw + (long)B * GSF_CW_Z * 38;
   const int S = 256 / F > 0 ? 256 / F : 1;
   if (fw) {          // the fusion-weight path exists in gate-shift-FUSE only
     hipLaunchKernelGGL(gsf_bwd_dw_kernel<T>, dim3((unsigned)N), dim3(256), (size_t)S * F * sizeof(float), st, x, gate, dA,
@@ -676,7 +716,7 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
                        dpw);
     hipLaunchKernelGGL(gsf_bwd_planes_kernel, dim3((unsigned)((nft + 255) / 256)), dim3(256), 0, st, dpw, T_len, F, cw1,
                        cw2, nft, d_ym, d_rm);
-    hipLaunchKernelGGL(gsf_bwd_cw_kernel, dim3(B, 2), dim3(256), 0, st, dpw, ysum, xsum, T_len, F, 1.0f / (float)hw,
+    hipLaunchKernelGGL(gsf_bwd_cw_kernel, dim3(B, 2, GSF_CW_Z), dim3(256), 0, st, dpw, ysum, xsum, T_len, F, 1.0f / (float)hw,
                        part_cw);
     TD_LAUNCH_CHECK("gsf_bwd fuse");
   }
@@ -691,7 +731,7 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
     hipLaunchKernelGGL(gsf_bwd_gate2_kernel<T>, g2, dim3(256), sm_g, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, PT,
                        d_xs, d_pre);
     TD_LAUNCH_CHECK("gsf_bwd_gate2");
-    const size_t sm_d = (size_t)(F * 27 + PT * 55 + 2 * F) * sizeof(float);
+    const size_t sm_d = (size_t)(Fp * 27 + PT * 55 + 2 * F) * sizeof(float);
     hipLaunchKernelGGL(gsf_bwd_conv3d_dx2_kernel<T>, g2, dim3(256), sm_d, st, x, d_pre, w3, sa, sb, T_len, h, w, C, F, Fp,
                        PT, d_bn);
     TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx2");
@@ -753,16 +793,16 @@ extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, 
   if (rc != TDEED_OK) return rc;
   const long N = (long)B * T;
   float* part_cw = scratch + 4 * N * F + N * h * w * 2;
-  float* part_w3 = part_cw + (long)B * 38;
+  float* part_w3 = part_cw + (long)B * GSF_CW_Z * 38;
   // fold the per-frame / per-clip partials (rows hold several parameter groups side by side)
   const long row = (long)F * 27 + 2;
   rc = tdeed_reduce_strided(part_w3, (int)N, row, (long)F * 27, d_w3, stream);
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_w3 + (long)F * 27, (int)N, row, 2, d_b3, stream);
   if (!fw) return rc;
-  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw, B, 38, 18, d_cw, stream);                 // channel_conv1 taps
-  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 19, B, 38, 18, d_cw + 18, stream);       // channel_conv2 taps
-  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 18, B, 38, 1, d_cb, stream);
-  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 37, B, 38, 1, d_cb + 1, stream);
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw, B * GSF_CW_Z, 38, 18, d_cw, stream);                 // channel_conv1 taps
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 19, B * GSF_CW_Z, 38, 18, d_cw + 18, stream);       // channel_conv2 taps
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 18, B * GSF_CW_Z, 38, 1, d_cb, stream);
+  if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 37, B * GSF_CW_Z, 38, 1, d_cb + 1, stream);
   return rc;
 }
 

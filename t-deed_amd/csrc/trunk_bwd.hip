@@ -256,17 +256,25 @@ static inline int rows_per_wg(int nch) { return (256 / nch) * RW_U * 4; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, const float* __restrict__ a,
-                                                     const float* __restrict__ b, const T* __restrict__ res, int relu,
+                                                     const float* __restrict__ b, const T* __restrict__ res,
+                                                     const float* __restrict__ ra, const float* __restrict__ rb, int relu,
                                                      T* __restrict__ y, long M, int nch, int rpw) {
   constexpr int EPC = Chunk<T>::N;
   const RowMap mp(nch);
   if (!mp.on) return;
   const int C = nch * EPC, c0 = mp.ck * EPC;
-  float av[EPC], bv[EPC];
+  // ra / rb: the residual is itself a raw conv output (the shortcut conv) whose BatchNorm affine is applied here: the
+  // normalised shortcut map is not materialised (rounded to T like the map would be: same values as the two-pass form)
+  const bool raff = ra != nullptr;
+  const float* pra = raff ? ra : a;
+  const float* prb = raff ? rb : a;
+  float av[EPC], bv[EPC], rav[EPC], rbv[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     av[e] = a[c0 + e];
     bv[e] = b[c0 + e];
+    rav[e] = pra[c0 + e];
+    rbv[e] = prb[c0 + e];
   }
   const long m0 = (long)blockIdx.x * rpw, m1 = min(M, m0 + rpw);
   for (long r0 = m0 + mp.rl; r0 < m1; r0 += (long)mp.RL * RW_U) {
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, co
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
           float o = fmaf(v[u][e], av[e], bv[e]);
-          if (res) o += rv[u][e];
+          if (res) o += raff ? round_to<T>(fmaf(rv[u][e], rav[e], rbv[e])) : rv[u][e];
           v[u][e] = relu ? fmaxf(o, 0.f) : o;
         }
         Chunk<T>::store(y + r * C + c0, v[u]);
@@ -293,8 +301,21 @@ __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, co
   }
 }
 
+static int bn_apply_launch(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
+                           const float* rb, int relu, void* y, int dtype, void* stream);
 extern "C" int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu,
                               void* y, int dtype, void* stream) {
+  return bn_apply_launch(z, M, C, a, b, res, nullptr, nullptr, relu, y, dtype, stream);
+}
+// y = act(z * a + b + (res * ra + rb)): conv3's BatchNorm + the shortcut conv's BatchNorm + ReLU of a downsampling bottleneck in
+// one pass (timm Bottleneck.forward: x = act3(bn3(conv3(x)) + downsample(shortcut)))
+extern "C" int tdeed_bn_apply2(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
+                               const float* rb, int relu, void* y, int dtype, void* stream) {
+  TD_CHECK(res && ra && rb, "bn_apply2: the residual and its affine are required");
+  return bn_apply_launch(z, M, C, a, b, res, ra, rb, relu, y, dtype, stream);
+}
+static int bn_apply_launch(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
+                           const float* rb, int relu, void* y, int dtype, void* stream) {
   TD_CHECK(z && a && b && y && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "bn_apply: bad dtype %d", dtype);
@@ -305,10 +326,10 @@ extern "C" int tdeed_bn_apply(const void* z, long M, int C, const float* a, cons
   TD_CHECK(nwg < 0x7fffffffL, "bn_apply: too many rows");
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(affine_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)z, a, b, (const float*)res,
-                       relu, (float*)y, M, nch, rpw);
+                       ra, rb, relu, (float*)y, M, nch, rpw);
   else
     hipLaunchKernelGGL(affine_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), 0, st, (const bf16_t*)z, a, b,
-                       (const bf16_t*)res, relu, (bf16_t*)y, M, nch, rpw);
+                       (const bf16_t*)res, ra, rb, relu, (bf16_t*)y, M, nch, rpw);
   TD_LAUNCH_CHECK("bn_apply");
   return TDEED_OK;
 }

@@ -169,7 +169,7 @@ class BottleneckTrain:
         self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, R).contiguous()
         self.se_w1t, self.se_w2t = self.se_w1.t().contiguous(), self.se_w2.t().contiguous()
 
-    def _bn(self, z, name, res=None, relu=True, part=None, apply=True):
+    def _bn(self, z, name, res=None, relu=True, part=None, apply=True, res_affine=None):
         """BatchNorm(batch statistics) + residual + ReLU of a raw conv output.  part = (sums, sums of squares, row stride,
         rows): the per-channel partial sums the conv's own epilogue wrote (no second pass over z for the statistics).
         apply=False (with part): statistics and affine only, the map is applied by its consumers."""
@@ -177,7 +177,8 @@ class BottleneckTrain:
         if part is not None:
             ps, pq, stride, P = part
             return B_.bn_finalize_apply(z, ps, pq, stride, P, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1,
-                                        sd[p + ".running_mean"], sd[p + ".running_var"], res=res, relu=relu, apply=apply)
+                                        sd[p + ".running_mean"], sd[p + ".running_var"], res=res, relu=relu, apply=apply,
+                                        res_affine=res_affine)
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
 
@@ -238,10 +239,17 @@ class BottleneckTrain:
             c.xs = B_.stride2_gather(x) if blk.stride == 2 else x
             zd, partd = self._conv1x1(c.xs, self.wd.w, N * h2 * w2, C)
             c.zd = zd.view(N, h2, w2, C)
-            c.sc, c.bnd = self._bn(c.zd, "downsample", relu=False, part=partd)
+            # with both statistics from the contractions' epilogues the shortcut's BatchNorm is applied inside conv3's apply pass
+            # (tdeed_bn_apply2): the normalised shortcut map is not written and read back
+            fuse_sc = partd is not None and part3 is not None and _os.environ.get("TDEED_TRAIN_SC_FUSED", "1") == "1"
+            c.sc, c.bnd = self._bn(c.zd, "downsample", relu=False, part=partd, apply=not fuse_sc)
         else:
             c.sc = x
-        c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.sc, relu=True, part=part3)
+            fuse_sc = False
+        if fuse_sc:
+            c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.zd, relu=True, part=part3, res_affine=(c.bnd[2], c.bnd[3]))
+        else:
+            c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.sc, relu=True, part=part3)
         self.ctx = c
         return c.out
 

@@ -67,6 +67,6 @@ def t(x):
 
 
 def max_abs(a, b):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0

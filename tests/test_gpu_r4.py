@@ -186,3 +186,19 @@ def test_input_gradient_contraction_with_the_gradient_sink_epilogue(dtype, frame
         sc = max(1.0, float(dw_r.abs().max()), float(db_r.abs().max()))
         assert max_abs(dw_f, dw_r) <= 2e-4 * sc and max_abs(db_f, db_r) <= 2e-4 * sc, q
         assert max_abs(dz_f, dz_r) <= (1e-4 if f32 else 2e-2) * max(1.0, float(dz_r.float().abs().max())), q
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shortcut_batchnorm_inside_conv3s_apply_pass_equals_two_passes(dtype):
+    """tdeed_bn_apply2 (y = relu(z a + b + (zd ra + rb))) == tdeed_bn_apply(zd) followed by tdeed_bn_apply(z, res), bitwise."""
+    from tdeed_amd import ops_bwd as B_
+    from tdeed_amd._lib import call, ptr, stream_ptr, dtype_code
+    M, C = 1000, 152
+    z, zd = _rand((M, C), 31).to(DEV).to(dtype), _rand((M, C), 32).to(DEV).to(dtype)
+    a, b, ra, rb = (_rand((C,), 33 + i, 0.5).to(DEV) for i in range(4))
+    sc = B_.bn_apply(zd, ra, rb, relu=False)
+    ref = B_.bn_apply(z, a, b, res=sc, relu=True)
+    out = torch.empty_like(z)
+    call("tdeed_bn_apply2", ptr(z), M, C, ptr(a), ptr(b), ptr(zd), ptr(ra), ptr(rb), 1, ptr(out), dtype_code(dtype), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
