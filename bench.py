@@ -42,8 +42,9 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {torch.bfloat16: 2500.0, torch.float32: 157.3}
-TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
-TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r03_train_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE_800MF = os.path.join("profiles", "r04_hbm_traffic_800mf_b16.json")
+TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r04_train_hbm_traffic.json")
 # C-ABI entry -> kernel family of tools/summarize_pmc.py (what the counter passes are keyed by)
 TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
 
@@ -103,6 +104,30 @@ def timed_regions(run, steps, repeats, dev, streams):
         t_beg = min(starts[0].elapsed_time(s) for s in starts)
         evs.append(t_end - t_beg)
     return walls, evs
+
+
+def check_timed_outputs(eng, plans, B, T, H, W, rank, dev):
+    """What the timed plans left in their output buffers: every slot's logits finite, different slots (different clips)
+    different, and slot 0 equal to a fresh forward of the same clips through a plan of its own (bf16: <= 2e-2; the same
+    kernels in the same order -- in practice bit-identical).  Raises instead of printing a line whose logits are garbage."""
+    torch.cuda.synchronize()
+    heads = [p.head_out.float().clone() for p in plans]
+    for i, h in enumerate(heads):
+        if not bool(torch.isfinite(h).all()):
+            raise RuntimeError(f"bench: non-finite logits in the timed plan of slot {i}")
+    for i in range(1, len(heads)):
+        if float((heads[i] - heads[0]).abs().max()) < 1e-3:
+            raise RuntimeError(f"bench: slots 0 and {i} hold the same logits (buffer aliasing between in-flight batches?)")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ref_plan = eng.plan(B, H, W, slot=len(plans))                       # a buffer set none of the timed plans touches
+        eng.set_frames(ref_plan, ops.fill_u8_hash((B, T, 3, H, W), 1000 + rank, dev))
+        eng.run_plan(ref_plan)
+        st.synchronize()
+        err = float((ref_plan.head_out.float() - heads[0]).abs().max())
+    if err > 2e-2:
+        raise RuntimeError(f"bench: slot 0's logits differ from a fresh forward of the same clips by {err}")
+    return dict(slots=len(plans), finite=True, slots_differ=True, slot0_vs_fresh_plan_max_abs=round(err, 6))
 
 
 def kernel_profile(eng, plan, reps=3):
@@ -172,6 +197,126 @@ def sgp_stage_time(plan, reps=30):
         out.append((a.elapsed_time(b) / reps, len(steps)))
         _lib.call("tdeed_graph_destroy", h)
     return out
+
+
+def dominant_roofline(prof, dt, traffic_file):
+    """`roofline` of the kernel family with the largest share of the serial kernel time (kernel_profile): algorithmic bytes
+    (or flops) per launch over the live-measured average launch duration; `traffic` only from a committed counter file."""
+    name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_s = d["ms"] / max(d["launches"], 1) * 1e-3
+    gbs = d["bytes"] / max(d["launches"], 1) / per_launch_s / 1e9
+    tfs = d["flops"] / max(d["launches"], 1) / per_launch_s / 1e12
+    # bound: whichever roof the kernel's algorithmic intensity puts it under
+    mfma_bound = name.startswith(("gemm", "bneck")) and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
+    roof = dict(kernel=name, bound="mfma" if mfma_bound else "hbm",
+                achieved=round(tfs if mfma_bound else gbs, 2), peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS,
+                unit="TFLOP/s" if mfma_bound else "GB/s",
+                frac=round((tfs / MFMA_PEAK_TF[dt]) if mfma_bound else (gbs / HBM_PEAK_GBS), 4), traffic=None,
+                traffic_source=None, algorithmic_bytes_per_launch=int(d["bytes"] / max(d["launches"], 1)),
+                avg_launch_us=round(per_launch_s * 1e6, 2),
+                launches_per_step=d["launches"], ms_per_step=round(d["ms"], 4),
+                share_of_step=round(d["ms"] / sum(x["ms"] for x in prof.values()), 3))
+    # HBM bytes per launch of that kernel family: NOT measured by this run.  It comes from separate rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE passes over this same command (MI355X_MICROARCH.md corrections; tools/summarize_pmc.py);
+    # the file names the passes, their time stamps and the git HEAD they were taken at.
+    if traffic_file is not None:
+        try:
+            with open(os.path.join(ROOT, traffic_file)) as fh:
+                tj = json.load(fh)
+            tr = tj["kernels"].get(name)
+            if tr is not None:
+                # per launch of THIS line's launch unit (an engine step; a gate-shift site is three kernels)
+                roof["traffic"] = (int(tr["hbm_bytes_per_forward"] / max(d["launches"], 1)) if "hbm_bytes_per_forward" in tr
+                                   else tr["hbm_bytes_per_launch"])
+                roof["traffic_source"] = (f"{traffic_file}: separate rocprofv3 --pmc passes at git {tj.get('git_head')} "
+                                          f"({tj.get('fetch_pass', {}).get('mtime')}); not measured by this run")
+        except (OSError, KeyError, ValueError):
+            pass
+    return roof
+
+
+def sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt):
+    """SGP encoder-decoder against the HBM roof with the ALGORITHMIC byte count of SURVEY.md section 8d:
+    es * [B*C*Sigma_T + W]: every block/mixer reads its inputs once and writes its output once, weights once."""
+    from tdeed_amd.regnet_spec import pyramid_lengths, sgp_up_size
+    sgp_steps = [s for s in plan.steps if s.name.startswith("_temp_fine.")]
+    n_l, Cc = cfg["n_layers"], eng.pw.spec.feat_dim
+    lens = pyramid_lengths(T, n_l)
+    sig = sum(2 * lens[i] + lens[i + 1] for i in range(n_l)) + 2 * lens[n_l] \
+        + sum((2 * lens[l] + lens[l + 1]) + 2 * lens[l] for l in range(n_l))
+    ks_, up_ = cfg["sgp_ks"], sgp_up_size(cfg["sgp_ks"], cfg["sgp_r"])
+    Wsgp = (2 * n_l + 1) * (8 * Cc * Cc + (2 * ks_ + up_ + 16) * Cc) + n_l * (14 * Cc * Cc + (4 * ks_ + 2 * up_ + 26) * Cc)
+    es_ = 2 if dt == torch.bfloat16 else 4
+    sgp_bytes = es_ * (B * Cc * sig + Wsgp)
+    sgp_flops = sum(s.flops for s in sgp_steps)
+    # stage time: the sub-batches' stage chains timed back to back on one stream (they overlap other work inside the
+    # graph; this is the stage's own device time)
+    sgp_ms = sum(x[0] for x in sgp_direct)
+    return dict(bound="hbm", algorithmic_bytes=int(sgp_bytes), sigma_T=int(sig), weights=int(Wsgp),
+                ms=round(sgp_ms, 4), ms_event_sum=round(sgp_stage_ms, 4),
+                achieved=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9, 2),
+                peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                launches=len(sgp_steps), launches_per_chain=[x[1] for x in sgp_direct],
+                us_per_chain=[round(x[0] * 1e3, 1) for x in sgp_direct],
+                chains=("one for the whole batch (behind the sub-batch join)"
+                        if getattr(plan, "tail", None) is not None else "one per sub-batch"),
+                mfma_tflops=round(sgp_flops / (sgp_ms * 1e-3) / 1e12, 2),
+                mfma_frac=round(sgp_flops / (sgp_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dt], 4))
+
+
+def kernels_table(prof):
+    return {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
+                    GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0,
+                    TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0)
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def infer_sub_record(workload, steps, repeats, depth, rank, dev, traffic_file):
+    """A driver-visible (d) record of the inference forward of another BASELINE configuration on this GPU (rank 0, N = 1):
+    the same execution shape as the headline (one sub-batch, `depth` batches in flight as single-chain HIP graphs on their
+    own streams), clips/s, the dominant family's roofline with `traffic` from the committed counter passes, the SGP stage."""
+    wl = CONFIGS[workload]
+    cfg, B, H, W = wl["cfg"], wl["B"], wl["H"], wl["W"]
+    dt = torch.bfloat16
+    T = cfg["clip_len"]
+    sd = synth.make_state(state_layout.model_state_shapes(cfg), 0)
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    with torch.cuda.stream(streams[0]):
+        eng = ForwardEngine(cfg, sd, dt, dev, use_graph=True, n_split=1)
+        plans = [eng.plan(B, H, W, slot=i) for i in range(depth)]
+        for i, pl in enumerate(plans):
+            eng.set_frames(pl, ops.fill_u8_hash((B, T, 3, H, W), 1000 + rank + 97 * i, dev))
+    torch.cuda.synchronize()
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % depth]):
+                eng.run_plan(plans[i % depth])
+
+    run(2 * depth)
+    walls, evs = timed_regions(run, steps, repeats, dev, streams)
+    el = statistics.median(walls)
+    chk = check_timed_outputs(eng, plans, B, T, H, W, rank, dev)
+    with torch.cuda.stream(streams[0]):
+        prof, sgp_stage_ms = kernel_profile(eng, plans[0])
+        sgp_direct = sgp_stage_time(plans[0])
+    ms = el / steps * 1e3
+    step_bytes, _ = forward_layer_bytes(cfg, B, H, W, dt, dev)
+    rec = dict(workload=f"{workload}: {cfg['feature_arch']} + ed_sgp_mixer n_layers={cfg['n_layers']} ks={cfg['sgp_ks']}, "
+                        f"L={T}, {H}x{W}, batch {B}/GPU, inference forward, random-init weights",
+               value=round(B * steps / el, 2), unit="clips/s", ms_per_step=round(ms, 4), steps=steps, repeats=repeats,
+               ms_per_step_repeats=[round(w / steps * 1e3, 4) for w in walls], dtype="bf16", batches_in_flight=depth,
+               hip_graph=True, timed_output_check=chk,
+               roofline=dominant_roofline(prof, dt, traffic_file),
+               roofline_step=dict(bound="hbm", algorithmic_bytes=int(step_bytes),
+                                  achieved=round(step_bytes / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+               roofline_sgp=sgp_roofline(cfg, B, T, eng, plans[0], sgp_direct, sgp_stage_ms, dt),
+               kernels=kernels_table(prof))
+    del plans, eng
+    torch.cuda.empty_cache()
+    return rec
 
 
 def _cpu_model():
@@ -482,8 +627,9 @@ def decode_rate(B, T, H, W, seconds=3.0):
 
 
 def cpu_train_baseline():
-    """The oracle's training step (train-mode forward + CE/MSE + autograd backward) on the host cores: FineDiving_small
-    hyper-parameters, ONE synthetic clip of 100 frames at 224x224, fp32; bounded to one warm-up-free pass (~10-30 s)."""
+    """The oracle's training step (train-mode forward + CE/MSE + autograd backward) on the host cores: the model of BASELINE
+    configs[2] (FineDiving_big hyper-parameters: RegNetY-800MF, n_layers 3), ONE synthetic clip of 100 frames at 224x224,
+    fp32; bounded to one warm-up-free pass (~10-30 s)."""
     from oracle import tdeed_oracle as O
     from tdeed_amd.regnet_spec import regnet_spec
     have = torch.get_num_threads()
@@ -495,7 +641,7 @@ def cpu_train_baseline():
 
 
 def _cpu_train_baseline(O, regnet_spec):
-    c = CONFIGS["rny002_b8"]["cfg"]
+    c = CONFIGS["rny008_b16"]["cfg"]          # the model of the record this stands beside (FineDiving_big: 800MF, n_layers 3)
     sd0 = O.as_torch_state(synth.make_state(state_layout.model_state_shapes(c), 0))
     par = [k for k in sd0 if state_layout.is_parameter(k)]
     sd = {k: (v.clone().requires_grad_(True) if k in par else v.clone()) for k, v in sd0.items()}
@@ -512,8 +658,9 @@ def _cpu_train_baseline(O, regnet_spec):
     el = time.perf_counter() - t0
     return dict(value=round(1.0 / el, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
                 host_cores=os.cpu_count(), cpu_model=_cpu_model(),
-                sample="FineDiving_small training step (train-mode forward + loss + autograd backward, no optimizer), "
-                       "1 synthetic clip (100x3x224x224), fp32, one pass", sec_per_clip=round(el, 3))
+                sample="FineDiving_big (RegNetY-800MF + SGP n_layers 3: the model of this record) training step (train-mode "
+                       "forward + loss + autograd backward, no optimizer), 1 synthetic clip (100x3x224x224), fp32, one pass",
+                sec_per_clip=round(el, 3))
 
 
 def main_train(a):
@@ -596,6 +743,7 @@ def main():
     run(max(a.warmup, depth))
     walls, evs = timed_regions(run, a.steps, a.repeats, dev, streams)
     el = statistics.median(walls)
+    out_check = check_timed_outputs(eng, plans, B, T, H, W, rank, dev)
     if a.pmc_pass:
         if rank == 0:
             print(json.dumps({"pmc_pass": True, "workload": a.workload, "steps": a.steps, "ms_per_step": round(el / a.steps * 1e3, 4),
@@ -684,56 +832,9 @@ def main():
     if rank == 0:
         ms = el / a.steps * 1e3
         value = world * B * a.steps / el
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
-        per_launch_s = d["ms"] / max(d["launches"], 1) * 1e-3
-        gbs = d["bytes"] / max(d["launches"], 1) / per_launch_s / 1e9
-        tfs = d["flops"] / max(d["launches"], 1) / per_launch_s / 1e12
-        # bound: whichever roof the kernel's algorithmic intensity puts it under
-        mfma_bound = name.startswith(("gemm", "bneck")) and (d["flops"] / max(d["bytes"], 1)) > (MFMA_PEAK_TF[dt] * 1e12 / (HBM_PEAK_GBS * 1e9))
-        roof = dict(kernel=name, bound="mfma" if mfma_bound else "hbm",
-                    achieved=round(tfs if mfma_bound else gbs, 2), peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS,
-                    unit="TFLOP/s" if mfma_bound else "GB/s",
-                    frac=round((tfs / MFMA_PEAK_TF[dt]) if mfma_bound else (gbs / HBM_PEAK_GBS), 4), traffic=None,
-                    traffic_source=None, algorithmic_bytes_per_launch=int(d["bytes"] / max(d["launches"], 1)),
-                    avg_launch_us=round(per_launch_s * 1e6, 2),
-                    launches_per_step=d["launches"], ms_per_step=round(d["ms"], 4),
-                    share_of_step=round(d["ms"] / sum(x["ms"] for x in prof.values()), 3))
-        # HBM bytes per launch of that kernel family: NOT measured by this run.  It comes from separate rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE passes over this same command (MI355X_MICROARCH.md corrections; tools/summarize_pmc.py);
-        # the file names the passes, their time stamps and the git HEAD they were taken at.
-        try:
-            with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
-                tj = json.load(fh)
-            tr = tj["kernels"].get(name)
-            if tr is not None and a.workload == "rny002_b8" and a.dtype == "bf16":
-                # per launch of THIS line's launch unit (an engine step; a gate-shift site is three kernels)
-                roof["traffic"] = (int(tr["hbm_bytes_per_forward"] / max(d["launches"], 1)) if "hbm_bytes_per_forward" in tr
-                                   else tr["hbm_bytes_per_launch"])
-                roof["traffic_source"] = (f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes at git {tj.get('git_head')} "
-                                          f"({tj.get('fetch_pass', {}).get('mtime')}); not measured by this run")
-        except (OSError, KeyError, ValueError):
-            pass
-        sgp_steps = [s for s in plan.steps if s.name.startswith("_temp_fine.")]
-        # SGP encoder-decoder against the HBM roof with the ALGORITHMIC byte count of SURVEY.md section 8d:
-        # es * [B*C*Sigma_T + W]: every block/mixer reads its inputs once and writes its output once, weights once
-        from tdeed_amd.regnet_spec import pyramid_lengths, sgp_up_size
-        n_l, Cc = cfg["n_layers"], eng.pw.spec.feat_dim
-        lens = pyramid_lengths(T, n_l)
-        sig = sum(2 * lens[i] + lens[i + 1] for i in range(n_l)) + 2 * lens[n_l] \
-            + sum((2 * lens[l] + lens[l + 1]) + 2 * lens[l] for l in range(n_l))
-        ks_, up_ = cfg["sgp_ks"], sgp_up_size(cfg["sgp_ks"], cfg["sgp_r"])
-        Wsgp = (2 * n_l + 1) * (8 * Cc * Cc + (2 * ks_ + up_ + 16) * Cc) + n_l * (14 * Cc * Cc + (4 * ks_ + 2 * up_ + 26) * Cc)
-        es_ = 2 if dt == torch.bfloat16 else 4
-        sgp_bytes = es_ * (B * Cc * sig + Wsgp)
-        sgp_flops = sum(s.flops for s in sgp_steps)
-        # stage time: the sub-batches' stage chains timed back to back on one stream (they overlap other work inside the
-        # graph; this is the stage's own device time)
-        sgp_ms = sum(x[0] for x in sgp_direct)
-        kernels = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
-                           GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0,
-                           TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0)
-                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        roof = dominant_roofline(prof, dt, TRAFFIC_FILE if (a.workload == "rny002_b8" and a.dtype == "bf16") else None)
+        sgp_roof = sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt)
+        kernels = kernels_table(prof)
         step_bytes, _ = forward_layer_bytes(cfg, B, H, W, dt, dev)     # layer-granular (fusion-independent), as in round 1 / 2
         step_flops = sum(s.flops for s in plan.steps)
         out = dict(metric=f"clips/sec (L={T}, 224^2, {a.dtype}) forward, per-frame logits", value=round(value, 2),
@@ -754,17 +855,7 @@ def main():
                                       peak=HBM_PEAK_GBS, unit="GB/s", frac=round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       tflops=round(step_flops / (ms * 1e-3) / 1e12, 1)),
                    kernels=kernels,
-                   roofline_sgp=dict(bound="hbm", algorithmic_bytes=int(sgp_bytes), sigma_T=int(sig), weights=int(Wsgp),
-                                     ms=round(sgp_ms, 4), ms_event_sum=round(sgp_stage_ms, 4),
-                                     achieved=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9, 2),
-                                     peak=HBM_PEAK_GBS, unit="GB/s",
-                                     frac=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     launches=len(sgp_steps), launches_per_chain=[x[1] for x in sgp_direct],
-                                     us_per_chain=[round(x[0] * 1e3, 1) for x in sgp_direct],
-                                     chains=("one for the whole batch (behind the sub-batch join)"
-                                             if getattr(plan, "tail", None) is not None else "one per sub-batch"),
-                                     mfma_tflops=round(sgp_flops / (sgp_ms * 1e-3) / 1e12, 2),
-                                     mfma_frac=round(sgp_flops / (sgp_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dt], 4)),
+                   roofline_sgp=sgp_roof, timed_output_check=out_check,
                    fed_from_host=feed, cpu_baseline=None, git_head=git_head())
     del plans, plan, eng
     torch.cuda.empty_cache()
@@ -777,6 +868,11 @@ def main():
             out["logit_rms_err_fp32"] = round(errs["fp32_rms"], 8)
             out["logit_rms_err_bf16"] = round(errs["bf16_rms"], 5)
     if world == 1 and not a.no_train and a.workload == "rny002_b8" and a.dtype == "bf16":
+        # driver-visible forward of the 800MF model (BASELINE configs[2..4] run on it): B = 16 as in configs[2]
+        try:
+            out["infer_800mf"] = infer_sub_record("rny008_b16", 10, 3, depth, rank, dev, TRAFFIC_FILE_800MF)
+        except Exception as e:           # noqa: BLE001  (the headline line must still be printed)
+            out["infer_800mf"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         # driver-visible training-step records: BASELINE configs[2] (800MF, B=16) and the 200MF geometry of the headline
         tr = {}
         for wk, st_ in (("rny008_b16", 6), ("rny002_b8", 10)):

@@ -18,7 +18,8 @@ import time
 from collections import defaultdict
 
 # training-step kernels (trunk_bwd.hip, sgp_bwd.hip, gsf_bwd.hip, train.hip) first: their names contain inference names
-TRAIN_FAMILY = [("bn_bwd_apply", "bn_bwd"), ("colstats", "bn_bwd"), ("wgrad", "wgrad"), ("gconv_dgrad", "gconv_bwd"),
+TRAIN_FAMILY = [("se_bn_", "se_bn_bwd"), ("bn_parts_finalize", "bn_bwd"), ("gsf_add_cols", "gate_shift_bwd"),
+                ("bn_bwd_apply", "bn_bwd"), ("colstats", "bn_bwd"), ("wgrad", "wgrad"), ("gconv_dgrad", "gconv_bwd"),
                 ("gconv_wgrad", "gconv_bwd"), ("gsf_bwd", "gate_shift_bwd"), ("affine_kernel", "bn_apply"),
                 ("bn_apply", "bn_apply"), ("pool_mean", "se_train"), ("scale_rows", "se_train"), ("se_train", "se_train"),
                 ("adamw", "adamw"), ("multi_fold", "grad_writeout"), ("gather_cast", "repack"), ("stem_mfma", "stem"),
@@ -110,6 +111,13 @@ def main():
                               cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
     except OSError:
         head = None
+    if not head:                                 # the GPU box has the tree without .git: the revision build() recorded
+        try:
+            bi = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "t-deed_amd", "csrc",
+                                             "build_info.json")))
+            head = bi.get("git_head") + ("+dirty" if bi.get("dirty") else "")
+        except (OSError, ValueError, TypeError):
+            head = None
     json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled (gfx950); "
                         "averages over every launch of the kernel family",
                    command=cmd, forwards_profiled=steps, git_head=head, fetch_pass=stamp(ff), write_pass=stamp(wf), kernels=res,
