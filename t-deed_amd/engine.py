@@ -1169,95 +1169,6 @@ class ForwardEngine:
         self._plans[key] = plan
         return plan
 
-    # ------------------------------------------------------------------ batches in flight with ONE temporal stage per group
-    def plan_group(self, B, H, W, depth=3, flip=False):
-        """`depth` batches of B clips in flight (each its own buffer set and single-chain HIP graph, replayed on the caller's
-        stream of that slot) whose temporal stage -- SGP encoder-decoder + heads, a chain of ~16 latency-bound launches whose
-        cost is dominated by its 19 MB of weights and its launch boundaries, not by the row count -- runs ONCE per group over
-        all depth * B clips on a stream of its own (model/modules.py:69-87 is batch-independent per clip).  Batch i's trunk
-        writes its pooled features into rows [i*B, (i+1)*B) of a shared feature buffer; when the group's last trunk has been
-        issued the tail stream waits for the `depth` trunks, stages the features into the tail's own copy (so the next
-        group's trunks may overwrite the shared buffer while the stage runs) and replays the tail graph.  Every batch still
-        gets the complete forward; its logits are rows [i*B*T, (i+1)*B*T) of `head_out` once `tail_done` has passed."""
-        key = ("group", B, H, W, bool(flip), depth)
-        if key in self._plans:
-            return self._plans[key]
-        pw = self.pw
-        T, C, dev = pw.clip_len, pw.spec.feat_dim, self.device
-        N = depth * B
-        feat = torch.empty((N, T, C), dtype=self.act_dtype, device=dev)
-        frs = torch.empty((N * T, 2), dtype=torch.float32, device=dev)
-        subs = [self._build(B, H, W, bool(flip), set(), feat_out=feat[i * B:(i + 1) * B], feat_rs=frs[i * B * T:(i + 1) * B * T])
-                for i in range(depth)]
-        feat_t, frs_t = torch.empty_like(feat), torch.empty_like(frs)
-        feat_t._td_rowstat = frs_t
-        head_out = torch.empty((N * T, pw.n_out), dtype=torch.float32, device=dev)
-        tail = self._build_tail(N, feat_t, head_out)
-        grp = SimpleNamespace(subs=subs, tail=tail, depth=depth, B=B, T=T, feat=feat, frs=frs, feat_t=feat_t, frs_t=frs_t,
-                              head_out=head_out, graphs=None, tail_graph=None, tail_stream=new_stream(dev),
-                              trunk_ev=[torch.cuda.Event() for _ in range(depth)], staged=None,
-                              tail_done=torch.cuda.Event(), pending=0, graph=None,
-                              steps=[st for sb in subs for st in sb.steps] + tail.steps,
-                              pool_bytes=sum(sb.pool_bytes for sb in subs) + tail.pool_bytes)
-        self._plans[key] = grp
-        return grp
-
-    def set_group_frames(self, grp, i, frames_u8):
-        """Copy a (B,T,3,H,W) uint8 batch into slot i's input buffer."""
-        grp.subs[i].frames.copy_(frames_u8.reshape(-1, *frames_u8.shape[2:]), non_blocking=True)
-
-    def run_group_slot(self, grp, i):
-        """Issue slot i's trunk on the CURRENT stream (HIP-graph replay; eager launches with use_graph=False); behind the
-        group's last slot, the temporal stage on the group's tail stream."""
-        st = torch.cuda.current_stream()
-        if self.use_graph and st.cuda_stream == 0:
-            raise RuntimeError("graph replay needs a non-default stream: wrap the call in torch.cuda.stream(s)")
-        if self.use_graph and grp.graphs is None:
-            _drain_dead_graphs()
-            for sb in grp.subs:                                   # warm-up launches (module load, argument validation)
-                for s_ in sb.steps:
-                    s_.fn()
-            for s_ in grp.tail.steps:
-                s_.fn()
-            st.synchronize()
-            grp.graphs = [self._capture(st, lambda sb=sb: [x.fn() for x in sb.steps]) for sb in grp.subs]
-            grp.tail_graph = self._capture(st, lambda: [x.fn() for x in grp.tail.steps])
-            grp.graph = SimpleNamespace(subs=list(grp.graphs), tail=grp.tail_graph)     # (what __del__ parks for destruction)
-            st.synchronize()
-        if grp.staged is not None:
-            st.wait_event(grp.staged)                             # the previous group's features have left the shared buffer
-        if self.use_graph:
-            _lib.call("tdeed_graph_launch", grp.graphs[i], st.cuda_stream)
-        else:
-            for s_ in grp.subs[i].steps:
-                s_.fn()
-        grp.trunk_ev[i].record(st)
-        grp.pending = max(grp.pending, i + 1)
-        if i == grp.depth - 1:
-            self.flush_group(grp)
-
-    def flush_group(self, grp):
-        """Run the temporal stage over the slots issued since the last one (all `depth` rows are computed; rows of slots
-        that were not issued hold their previous content).  Called by run_group_slot behind the last slot, and by the
-        caller when it stops in the middle of a group."""
-        if grp.pending == 0:
-            return
-        ts = grp.tail_stream
-        for ev in grp.trunk_ev[:grp.pending]:
-            ts.wait_event(ev)
-        with torch.cuda.stream(ts):
-            grp.feat_t.copy_(grp.feat, non_blocking=True)
-            grp.frs_t.copy_(grp.frs, non_blocking=True)
-            grp.staged = torch.cuda.Event()
-            grp.staged.record(ts)
-            if self.use_graph:
-                _lib.call("tdeed_graph_launch", grp.tail_graph, ts.cuda_stream)
-            else:
-                for s_ in grp.tail.steps:
-                    s_.fn()
-            grp.tail_done.record(ts)
-        grp.pending = 0
-
     def set_frames(self, plan, frames_u8):
         """Copy a (B,T,3,H,W) uint8 batch into the plan's input buffers (one per sub-batch)."""
         B, T = frames_u8.shape[:2]
