@@ -160,6 +160,12 @@ int tdeed_gemm_rs_fwd(const void* A, long lda, const void* A0, long lda0, int k0
                       int M, int K, int N, const void* Wfrag, const float* scale, const float* shift, const void* R, long ldr,
                       int act, void* C, long ldc, void* C2, long ldc2, int n2, void* stream);
 
+/* the same contraction as the training forward runs it: raw output + the BatchNorm statistics of that output, one partial
+ * row per persistent workgroup: colpart fp32 [tdeed_gemm_rs_grid(M)][2][N] (column sums | sums of squares) */
+int tdeed_gemm_rs_grid(int M);
+int tdeed_gemm_rs_stats_fwd(const void* A, long lda, const void* A0, long lda0, int k0, int M, int K, int N, const void* Wfrag,
+                            void* C, long ldc, float* colpart, void* stream);
+
 /* conv1 (1x1 + BN + ReLU, with the gate-shift splice of shift.py:89-93) IN FRONT of the grouped 3x3 of the same timm
  * Bottleneck, one launch: the y1 band the grouped conv reads is computed in LDS from the block input, the y1 map (the
  * largest intermediate of a stride-2 block) never exists.  bf16.  x [N][Hi][Wi][Cin]; G optional [N*Hi*Wi][Fp]; w1f: conv1

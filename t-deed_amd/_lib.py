@@ -53,6 +53,8 @@ _SIGS = {
     "tdeed_se_gate_mfma_fits": ([c_int, c_int], c_int),
     "tdeed_se_gate_mfma_fwd": ([P, c_int, c_float, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gemm_rs_fits": ([c_int, c_int, c_int], c_int),
+    "tdeed_gemm_rs_grid": ([c_int], c_int),
+    "tdeed_gemm_rs_stats_fwd": ([P, c_long, P, c_long, c_int, c_int, c_int, c_int, P, P, c_long, P, P], c_int),
     "tdeed_gemm_rs_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, c_long, c_int, P, c_long, P,
                            c_long, c_int, P], c_int),
     "tdeed_c1_gconv_fits": ([c_int, c_int, c_int, c_int, c_int], c_int),

@@ -659,6 +659,7 @@ struct GemmWsP {
   int NT;                         // n-tiles of the whole matrix
   int NTS;                        // n-tiles per block slice (blockIdx.y selects the slice; == NT when W fits LDS)
   void* C2; long ldc2; int n2;    // optional second, compact copy of columns [0, n2) of C
+  float* colpart;                 // gemm_rs STATS: [gridDim.x][2][N] per-workgroup column sums / sums of squares of the stored C
 };
 
 // WLDS = false: the weights do not fit LDS (K = N = 368): fragments are read straight from global memory
@@ -919,7 +920,7 @@ extern "C" int tdeed_gemm_ws_fwd(const void* A, long lda, const void* A0, long l
   if (gather_stride > 1)
     TD_CHECK(gather_hi > 0 && gather_wi > 0 && gather_ho > 0 && gather_wo > 0 && M % (gather_ho * gather_wo) == 0,
              "gemm_ws: bad gather geometry");
-  GemmWsP p;
+  GemmWsP p{};
   p.A = A; p.lda = lda; p.A0 = A0; p.lda0 = lda0; p.k0 = A0 ? k0 : 0;
   p.a_scale = a_scale; p.a_scale_rows = a_scale_rows > 0 ? a_scale_rows : 1;
   p.M = M; p.K = K; p.N = N; p.Wf = Wfrag; p.scale = scale; p.shift = shift;
@@ -952,7 +953,10 @@ constexpr int RS_WTAIL = RS_NW * 2 * (RS_KS - RS_KSR) * 64 * 16;      // 40 KB
 
 // SE / RES / OUT2 are compile-time: a run-time branch inside the tile loop makes the wait-count pass drain every
 // outstanding load at its join, i.e. wait for the NEXT tile's rows in the middle of this tile's MFMAs.
-template <bool SE, bool RES, bool OUT2>
+// STATS (training forward: the raw conv output's BatchNorm statistics): every lane sums the rounded values it stores and their
+// squares per channel over ALL tiles of its workgroup; one fold over the 16 pixel lanes at the end leaves one partial row
+// colpart[blockIdx.x][2][N] per workgroup -- the kernel is persistent, so the statistics cost 16 FMAs per 16-row tile per lane.
+template <bool SE, bool RES, bool OUT2, bool STATS = false>
 __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1039,6 +1043,11 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
   int buf = 0;
   const float lo = p.act == TDEED_ACT_RELU ? 0.f : -3.0e38f;           // ReLU (or nothing) without a branch
   const int chc = min(ch, p.N - 8);
+  [[maybe_unused]] float st1[STATS ? 8 : 1], st2[STATS ? 8 : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st1[e] = st2[e] = 0.f;
+  }
   for (; t < ntiles; t += gridDim.x, buf ^= 1) {
     const long tn = t + gridDim.x;
     // residual pieces of this tile first, THEN the next tile's rows: vmcnt counts in order, so a wait for a residual piece
@@ -1053,8 +1062,10 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
     }
     if (tn < ntiles) gload(tn);                                       // next tile travels while this one is multiplied
     const unsigned char* base = tiles + buf * RS_TILE;
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(bnt + chc), s1 = *reinterpret_cast<const f32x4*>(bnt + chc + 4);
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(bnt + p.N + chc), h1 = *reinterpret_cast<const f32x4*>(bnt + p.N + chc + 4);
+    // (the STATS form stores the raw contraction: no BatchNorm fold, and 16 registers for the column sums instead)
+    const float* bq = STATS ? bnt : bnt + chc;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(bq), s1 = *reinterpret_cast<const f32x4*>(bq + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(bq + p.N), h1 = *reinterpret_cast<const f32x4*>(bq + p.N + 4);
     // one 16-row tile at a time: two accumulators (the wave's two channel tiles) alternate on the MFMA pipe
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -1072,8 +1083,8 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc0[r] * s0[r] + h0[r];
-        v[4 + r] = acc1[r] * s1[r] + h1[r];
+        v[r] = STATS ? acc0[r] : acc0[r] * s0[r] + h0[r];
+        v[4 + r] = STATS ? acc1[r] : acc1[r] * s1[r] + h1[r];
       }
       if constexpr (RES) {
         float rv[8];
@@ -1088,10 +1099,36 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
         if constexpr (OUT2) {
           if (ch < p.n2) Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + ch, v);
         }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float r = round_to<T>(v[e]);
+            st1[e] += r;
+            st2[e] = fmaf(r, r, st2[e]);
+          }
+        }
       }
     }
     if (tn < ntiles) lstore(buf ^ 1, tn);     // (every wave is past its reads of buffer buf ^ 1: they ended before the last barrier)
     __syncthreads();
+  }
+  if constexpr (STATS) {
+    // fold over the 16 pixel lanes of each quarter (lanes l, l ^ 1, l ^ 2, l ^ 4, l ^ 8 share q), fixed order
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        st1[e] += __shfl_xor(st1[e], o, 64);
+        st2[e] += __shfl_xor(st2[e], o, 64);
+      }
+    }
+    if (px == 0 && ch < p.N) {
+      float* dst = p.colpart + (long)blockIdx.x * 2 * p.N + ch;
+      *reinterpret_cast<f32x4*>(dst) = (f32x4){st1[0], st1[1], st1[2], st1[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){st1[4], st1[5], st1[6], st1[7]};
+      *reinterpret_cast<f32x4*>(dst + p.N) = (f32x4){st2[0], st2[1], st2[2], st2[3]};
+      *reinterpret_cast<f32x4*>(dst + p.N + 4) = (f32x4){st2[4], st2[5], st2[6], st2[7]};
+    }
   }
 }
 
@@ -1109,7 +1146,7 @@ extern "C" int tdeed_gemm_rs_fwd(const void* A, long lda, const void* A0, long l
   TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm_rs: bad second output");
   TD_CHECK(!a_scale || (a_scale_rows >= RS_ROWS), "gemm_rs: a tile of %d rows must span at most two frames (rows per frame %d)",
            RS_ROWS, a_scale_rows);
-  GemmWsP p;
+  GemmWsP p{};
   p.A = A; p.lda = lda; p.A0 = A0; p.lda0 = lda0; p.k0 = A0 ? k0 : 0;
   p.a_scale = a_scale; p.a_scale_rows = a_scale_rows > 0 ? a_scale_rows : 1;
   p.M = M; p.K = K; p.N = N; p.Wf = Wfrag; p.scale = scale; p.shift = shift;
@@ -1142,6 +1179,43 @@ extern "C" int tdeed_gemm_rs_fwd(const void* A, long lda, const void* A0, long l
          else { if (o2) TD_RS(false, false, true); else TD_RS(false, false, false); } }
 #undef TD_RS
   TD_LAUNCH_CHECK("gemm_rs");
+  return TDEED_OK;
+}
+
+// Training forward of the same shape: raw output (no BatchNorm fold, no activation) + its column statistics, one partial row
+// per workgroup: colpart fp32 [tdeed_gemm_rs_grid(M)][2][N] (sums | sums of squares of the stored, rounded values) -- what
+// tdeed_gemm_fwd(colpart) leaves per 128-row tile, here per persistent workgroup.
+extern "C" int tdeed_gemm_rs_grid(int M) {
+  long grid = ((long)M + RS_ROWS - 1) / RS_ROWS;
+  return (int)(grid > 256 ? 256 : grid);
+}
+extern "C" int tdeed_gemm_rs_stats_fwd(const void* A, long lda, const void* A0, long lda0, int k0, int M, int K, int N,
+                                       const void* Wfrag, void* C, long ldc, float* colpart, void* stream) {
+  TD_CHECK(A && Wfrag && C && colpart, "gemm_rs_stats: null pointer");
+  TD_CHECK(tdeed_gemm_rs_fits(M, K, N), "gemm_rs_stats: M=%d K=%d N=%d unsupported (K = N = 320)", M, K, N);
+  TD_CHECK(lda % 8 == 0 && ldc % 8 == 0, "gemm_rs_stats: row strides must be multiples of 8");
+  TD_CHECK(!A0 || (k0 % 8 == 0 && lda0 % 8 == 0 && k0 <= K), "gemm_rs_stats: bad splice");
+  GemmWsP p{};
+  p.A = A; p.lda = lda; p.A0 = A0; p.lda0 = lda0; p.k0 = A0 ? k0 : 0;
+  p.a_scale_rows = 1;
+  p.M = M; p.K = K; p.N = N; p.Wf = Wfrag;
+  p.act = TDEED_ACT_NONE; p.C = C; p.ldc = ldc;
+  p.g_stride = 1;
+  p.NT = 2 * RS_NW; p.NTS = p.NT;
+  p.colpart = colpart;
+  const size_t smem = (size_t)2 * RS_TILE + RS_WTAIL + (size_t)4 * RS_KS * 32 * sizeof(float) + (size_t)2 * N * sizeof(float);
+  static TdDevOnce attr;
+  if (!attr.get()) {
+    if (hipFuncSetAttribute((const void*)gemm_rs_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      tdeed_set_error("gemm_rs_stats: hipFuncSetAttribute failed");
+      return TDEED_ERR_RUNTIME;
+    }
+    attr.set();
+  }
+  hipLaunchKernelGGL((gemm_rs_kernel<false, false, false, true>), dim3((unsigned)tdeed_gemm_rs_grid(M)), dim3(RS_THR), smem,
+                     (hipStream_t)stream, p);
+  TD_LAUNCH_CHECK("gemm_rs_stats");
   return TDEED_OK;
 }
 

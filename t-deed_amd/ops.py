@@ -255,6 +255,21 @@ def gemm_rs(A, Wfrag, K, N, scale=None, shift=None, act=ACT_NONE, residual=None,
     return out
 
 
+def gemm_rs_stats(A, Wfrag, K, N, M=None, A0=None, k0=0):
+    """Training forward of a K = N = 320 layer on the register-stationary kernel: raw output + the (sums, sums of squares,
+    row stride, rows) partials of its BatchNorm statistics (tdeed_gemm_rs_stats_fwd), like gemm(colpart=...)."""
+    _chk(A, "A", torch.bfloat16)
+    if M is None:
+        M = A.numel() // A.shape[-1]
+    out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    P = _lib.load().tdeed_gemm_rs_grid(M)
+    cp = torch.empty((P, 2, N), dtype=torch.float32, device=A.device)
+    call("tdeed_gemm_rs_stats_fwd", ptr(A), A.shape[-1], ptr(A0), (A0.shape[-1] if A0 is not None else 0), k0, M, K, N,
+         ptr(Wfrag), ptr(out), N, ptr(cp), stream_ptr())
+    flat = cp.view(-1)
+    return out, (flat, flat[N:], 2 * N, P)
+
+
 def gemm_splitk_splits(K):
     return _lib.load().tdeed_gemm_splitk_splits(K)
 

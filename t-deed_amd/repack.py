@@ -87,6 +87,20 @@ def transpose(w):
     return B_.transpose(w)
 
 
+def pack_ws(w):
+    """[N][K] dense weight (N, K multiples of 32) -> the fragment order of the weight-/register-stationary contractions
+    ([N/16][K/32][64][8], engine.pack_ws_weights): a pure permutation, so it records like any other copy (apply it to the
+    fp32 master view and cast afterwards: `to_bf16(pack_ws(w))`)."""
+    N, K = w.shape
+    if N % 32 or K % 32:
+        raise ValueError(f"pack_ws: N={N}, K={K} must be multiples of 32")
+    NT, KS = N // 16, K // 32
+    n = torch.arange(16)
+    rows = torch.cat([32 * (nt // 2) + 8 * (n // 4) + 4 * (nt % 2) + (n % 4) for nt in range(NT)]).to(w.device)
+    fr = w[rows].reshape(NT, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+    return fr.reshape(NT, KS, 64, 8)
+
+
 def pad1d(v, n):
     """v (F,) -> (n,) with zeros behind."""
     if v.numel() == n:

@@ -23,6 +23,10 @@ SE_BN_FUSED = ZMASK and _os.environ.get("TDEED_TRAIN_SE_BN_FUSED", "1") == "1"
 # output-ReLU backward and BatchNorm-backward statistics applied by the producers of each block-input gradient
 # (ops_bwd.GradSink); TDEED_TRAIN_SINK=0 restores the masked statistics pass + d_res map per block
 SINK = _os.environ.get("TDEED_TRAIN_SINK", "1") == "1"
+# K = N = 320 contractions over >= RS_MIN_ROWS rows on the register-stationary kernel (forward with the statistics epilogue,
+# conv3's input gradient); TDEED_TRAIN_RS=0: the tiled kernel everywhere
+RS_TRAIN = _os.environ.get("TDEED_TRAIN_RS", "1") == "1"
+RS_MIN_ROWS = 60000
 
 
 def _dense(w, dt):
@@ -150,6 +154,15 @@ class BottleneckTrain:
             self.gs.repack()
         self.w1 = _dense(sd[self.c1 + ".conv.weight"], dt)
         self.w3 = _dense(sd[pre + ".conv3.conv.weight"], dt)
+        # 320-wide layers over many rows (the s3 blocks of RegNetY-800MF): fragment-ordered copies for the register-stationary
+        # contraction (W in registers, activations cross the chip once: 106 vs 171 us per call at M = 313 600)
+        self.w1.ws = self.w3.ws = self.w3.wst_ws = None
+        if dt == torch.bfloat16 and RS_TRAIN and blk.cin == blk.cout and ops.gemm_rs_fits(1 << 20, blk.cin, blk.cout):
+            W1 = sd[self.c1 + ".conv.weight"].reshape(blk.cout, blk.cin)
+            W3 = sd[pre + ".conv3.conv.weight"].reshape(blk.cout, blk.cout)
+            self.w1.ws = R.to_bf16(R.pack_ws(W1))
+            self.w3.ws = R.to_bf16(R.pack_ws(W3))
+            self.w3.wst_ws = R.to_bf16(R.pack_ws(W3.t()))
         self.wd = _dense(sd[pre + ".downsample.conv.weight"], dt) if blk.has_downsample else None
         G, gw = blk.groups, blk.gw
         self.w2p = (sd[pre + ".conv2.conv.weight"].reshape(G, gw, gw, 3, 3).permute(0, 3, 4, 2, 1)
@@ -182,8 +195,10 @@ class BottleneckTrain:
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
 
-    def _conv1x1(self, a, w, M, N, A0=None, k0=0):
+    def _conv1x1(self, a, w, M, N, A0=None, k0=0, ws=None):
         """raw 1x1 conv; with the column statistics of its output from the epilogue -> (z, part | None)"""
+        if ws is not None and self.epi_stats and M >= RS_MIN_ROWS:
+            return ops.gemm_rs_stats(a, ws, a.shape[-1], N, M=M, A0=A0, k0=k0)
         if not self.epi_stats:
             return ops.gemm(a, w, None, None, ops.ACT_NONE, M=M, A0=A0, k0=k0), None
         P = ops.gemm_colpart_rows(M)
@@ -211,7 +226,8 @@ class BottleneckTrain:
                 c.a1.view(-1, Cin)[:, :Fp] = G
         else:
             c.a1 = x
-        z1, part = self._conv1x1(c.a1, self.w1.w, N * h * w, C, A0=c.G, k0=(self.gs.Fp if c.G is not None else 0))
+        z1, part = self._conv1x1(c.a1, self.w1.w, N * h * w, C, A0=c.G, k0=(self.gs.Fp if c.G is not None else 0),
+                                 ws=self.w1.ws)
         c.z1 = z1.view(N, h, w, C)
         onload = (self.onload and part is not None and self.w2frag is not None
                   and ops.gconv3x3_mfma_fits(h, w, C, blk.stride))
@@ -233,7 +249,7 @@ class BottleneckTrain:
         c.p = B_.pool_rows(c.z2 if onload else c.y2, affine=aff2)
         c.hid, c.gate = B_.se_train_fwd(c.p, self.se_w1t, sd[pre + ".se.fc1.bias"], self.se_w2t, sd[pre + ".se.fc2.bias"])
         c.y2s = B_.scale_rows(c.z2 if onload else c.y2, c.gate, affine=aff2)
-        z3, part3 = self._conv1x1(c.y2s, self.w3.w, N * h2 * w2, C)
+        z3, part3 = self._conv1x1(c.y2s, self.w3.w, N * h2 * w2, C, ws=self.w3.ws)
         c.z3 = z3.view(N, h2, w2, C)
         if blk.has_downsample:
             c.xs = B_.stride2_gather(x) if blk.stride == 2 else x
@@ -279,7 +295,10 @@ class BottleneckTrain:
         else:
             dz3, d_sc, dw, db = B_.bn_train_bwd(c.z3, dout, c.out, c.bn3, sd[pre + ".conv3.bn.weight"], relu=True, want_res=True)
         bn_names("conv3", dw, db)
-        d_y2s = ops.gemm(dz3, self.w3.wt, None, None, ops.ACT_NONE).view(N, h2, w2, C)
+        if self.w3.wst_ws is not None and N * hw2 >= RS_MIN_ROWS:
+            d_y2s = ops.gemm_rs(dz3, self.w3.wst_ws, C, C, M=N * hw2).view(N, h2, w2, C)
+        else:
+            d_y2s = ops.gemm(dz3, self.w3.wt, None, None, ops.ACT_NONE).view(N, h2, w2, C)
         grads[pre + ".conv3.conv.weight"] = B_.wgrad(dz3, c.y2s, with_bias=False, M=N * hw2)[0].reshape(
             sd[pre + ".conv3.conv.weight"].shape)
         # SE + conv2's BatchNorm

@@ -202,3 +202,33 @@ def test_shortcut_batchnorm_inside_conv3s_apply_pass_equals_two_passes(dtype):
     call("tdeed_bn_apply2", ptr(z), M, C, ptr(a), ptr(b), ptr(zd), ptr(ra), ptr(rb), 1, ptr(out), dtype_code(dtype), stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_register_stationary_contraction_with_the_statistics_epilogue_equals_the_tiled_kernel():
+    """tdeed_gemm_rs_stats_fwd (K = N = 320, W in registers, per-workgroup column sums) against tdeed_gemm_fwd(colpart): the
+    same rounded outputs (same k order per MFMA chain is not guaranteed: <= 1 bf16 ulp) and the same BatchNorm statistics;
+    weights packed by repack.pack_ws == engine.pack_ws_weights."""
+    from tdeed_amd import ops, repack as R
+    from tdeed_amd.engine import pack_ws_weights
+    M, K = 70000 + 37, 320
+    A = _rand((M, K), 41).to(DEV).to(torch.bfloat16)
+    G = _rand((M, 80), 42).to(DEV).to(torch.bfloat16)
+    W = _rand((K, K), 43, 0.05).to(DEV)
+    wf = R.pack_ws(W).to(torch.bfloat16)
+    assert torch.equal(wf.cpu(), pack_ws_weights(W.cpu().numpy(), torch.bfloat16, "cpu"))
+    Wb = W.to(torch.bfloat16)
+    for A0, k0 in ((None, 0), (G, 80)):
+        z, (ps, pq, stride, P) = ops.gemm_rs_stats(A, wf, K, K, M=M, A0=A0, k0=k0)
+        cp = torch.empty((ops.gemm_colpart_rows(M), 2, K), dtype=torch.float32, device=DEV)
+        zr = ops.gemm(A, Wb, None, None, ops.ACT_NONE, M=M, colpart=cp, A0=A0, k0=k0)
+        torch.cuda.synchronize()
+        assert max_abs(z, zr) <= 2e-2 * max(1.0, float(zr.float().abs().max()))
+        s1 = ps.view(P, 2 * K)[:, :K].double().sum(0)
+        s2 = ps.view(P, 2 * K)[:, K:].double().sum(0)
+        zf = z.double()
+        assert max_abs(s1, zf.sum(0)) <= 1e-3 * max(1.0, float(zf.sum(0).abs().max()))
+        assert max_abs(s2, (zf * zf).sum(0)) <= 1e-3 * float((zf * zf).sum(0).abs().max())
+    # the plain form serves conv3's input gradient
+    d = ops.gemm_rs(A, wf, K, K, M=M)
+    torch.cuda.synchronize()
+    assert max_abs(d, ops.gemm(A, Wb, None, None, ops.ACT_NONE, M=M)) <= 2e-2 * max(1.0, float(d.float().abs().max()))
