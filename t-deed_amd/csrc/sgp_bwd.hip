@@ -613,6 +613,89 @@ __global__ __launch_bounds__(256) void wgrad_tr128_kernel(const bf16_t* __restri
   }
 }
 
+// 160 x 160 output tile for N = K = 320 (the s3 layers of RegNetY-800MF: 16 launches per step over 313 600 rows): two exact
+// tiles per dimension instead of three 128-wide ones padded to 384 -- the operands are re-read 2 x instead of 3 x and no MFMA
+// runs on padding.  Waves 2 x 2, each 80 x 80 (25 accumulator tiles); otherwise wgrad_tr128_kernel.
+constexpr int WT_RS3 = 176;                                     // LDS row stride in elements: 160 columns + 32 bytes
+__global__ __launch_bounds__(256) void wgrad_tr160_kernel(const bf16_t* __restrict__ dY, long ldy, const bf16_t* __restrict__ X,
+                                                          long ldx, const bf16_t* __restrict__ X0, long ldx0, int k0s, int M, int N,
+                                                          int K, float* __restrict__ part_w) {
+  __shared__ __attribute__((aligned(16))) bf16_t sY[64 * WT_RS3];
+  __shared__ __attribute__((aligned(16))) bf16_t sX[64 * WT_RS3];
+  const int n0 = blockIdx.x * 160, k0 = blockIdx.y * 160, z = blockIdx.z, Z = gridDim.z;
+  const int mper = ((M + Z - 1) / Z + 63) / 64 * 64;
+  const int m_begin = z * mper, m_end = min(M, m_begin + mper);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), pl = lane & 15;
+  const int wn = wv >> 1, wk = wv & 1;
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  // staging: 64 rows x 20 16-byte chunks per operand = 1280 pieces = 5 per thread: piece i = tid + 256 j -> row i / 20, chunk i % 20
+  // (no bias partial here: conv layers have none, and its 40 registers would cost the second wave per SIMD)
+  f32x4 acc[5][5];
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int prow[5], pcol[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int i = tid + 256 * j;
+    prow[j] = i / 20;
+    pcol[j] = (i - prow[j] * 20) * 8;
+  }
+  u32x4 vy[5], vx[5];
+  auto issue = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const long row = min(m0 + prow[j], M - 1);
+      const long yc = n0 + pcol[j], xc = k0 + pcol[j];
+      vy[j] = *reinterpret_cast<const u32x4*>(dY + row * ldy + yc);
+      vx[j] = *reinterpret_cast<const u32x4*>(xc < k0s ? X0 + row * ldx0 + xc : X + row * ldx + xc);
+    }
+  };
+  if (m_begin < m_end) issue(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bool rok = m0 + prow[j] < m_end;
+      *reinterpret_cast<u32x4*>(sY + prow[j] * WT_RS3 + pcol[j]) = rok ? vy[j] : (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(sX + prow[j] * WT_RS3 + pcol[j]) = rok ? vx[j] : (u32x4){0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    if (m0 + 64 < m_end) issue(m0 + 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = ks * 32 + g4 * 8 + q4;
+      bf16x8 af[5], bfr[5];
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const bf16_t* a = sY + row * WT_RS3 + wn * 80 + nt * 16 + p4 * 4;
+        af[nt] = td_tr_read8(a, a + 4 * WT_RS3);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt) {
+        const bf16_t* b = sX + row * WT_RS3 + wk * 80 + kt * 16 + p4 * 4;
+        bfr[kt] = td_tr_read8(b, b + 4 * WT_RS3);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) {
+      const int k = k0 + wk * 80 + kt * 16 + pl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 80 + nt * 16 + 4 * g4 + e;
+        if (n < N && k < K) part_w[((long)z * N + n) * K + k] = acc[nt][kt][e];
+      }
+    }
+}
+
 static bool wgrad_wide(int M, int N, int K) {
   static const bool off = getenv("TDEED_WGRAD_TILE64") && atoi(getenv("TDEED_WGRAD_TILE64")) == 1;
   return !off && N >= 96 && K >= 96 && M >= 4096;
@@ -620,10 +703,15 @@ static bool wgrad_wide(int M, int N, int K) {
 
 // number of M slices: enough workgroups that every CU holds several (each one is a chain of dependent 32-row steps:
 // latency hidden by its neighbours), without slices shorter than 256 rows or more than 32 MB of partials
+static bool wgrad_160(int M, int N, int K) {
+  static const bool off = getenv("TDEED_WGRAD_TILE160") && atoi(getenv("TDEED_WGRAD_TILE160")) == 0;
+  return !off && N == 320 && K == 320 && M >= 4096;
+}
+
 extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
-  const int tw = wgrad_wide(M, N, K) ? 128 : 64;
+  const int tw = wgrad_160(M, N, K) ? 160 : (wgrad_wide(M, N, K) ? 128 : 64);
   const long tiles = (long)((N + tw - 1) / tw) * ((K + tw - 1) / tw);
-  long z = ((tw == 128 ? 1024 : 2048) + tiles - 1) / tiles;
+  long z = ((tw >= 128 ? 1024 : 2048) + tiles - 1) / tiles;
   const long zmax = M >= 8192 ? (M + 255) / 256 : (M + 63) / 64;       // few rows (SE / head layers): 64-row slices
   if (z > zmax) z = zmax;
   const long zbytes = (32L << 20) / ((long)N * K * 4);
@@ -651,7 +739,10 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, co
     static const bool scatter = getenv("TDEED_WGRAD_SCATTER") && atoi(getenv("TDEED_WGRAD_SCATTER")) == 1;
     const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
     TD_CHECK(!X0 || (!valu && vec_ok && !scatter), "wgrad: the spliced X operand needs the transposing-read kernel");
-    if (!valu && vec_ok && !scatter && wgrad_wide(M, N, K))     // wide layers: 128 x 128 output tiles
+    if (!valu && vec_ok && !scatter && wgrad_160(M, N, K) && !part_b)      // N = K = 320 (no bias): two exact 160-wide tiles per dimension
+      hipLaunchKernelGGL(wgrad_tr160_kernel, dim3(2, 2, Z), dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx,
+                         (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w);
+    else if (!valu && vec_ok && !scatter && wgrad_wide(M, N, K))     // wide layers: 128 x 128 output tiles
       hipLaunchKernelGGL(wgrad_tr128_kernel, dim3(cdiv(N, 128), cdiv(K, 128), Z), dim3(256), 0, st, (const bf16_t*)dY, ldy,
                          (const bf16_t*)X, ldx, (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w,
                          (db || accumulate < 0) ? part_b : nullptr);

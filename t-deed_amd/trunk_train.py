@@ -177,9 +177,9 @@ class BottleneckTrain:
             if blk.stride == 1:
                 wt = w2.reshape(G, gw, gw, 3, 3).transpose(1, 2).flip(3, 4).reshape(blk.cout, gw, 3, 3)
                 self.w2frag_t = gconv_frags_on_device(wt, gw)
-        R, C = blk.se_rd, blk.cout
-        self.se_w1 = sd[pre + ".se.fc1.weight"].reshape(R, C).contiguous()
-        self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, R).contiguous()
+        Rd, C = blk.se_rd, blk.cout
+        self.se_w1 = sd[pre + ".se.fc1.weight"].reshape(Rd, C).contiguous()
+        self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, Rd).contiguous()
         self.se_w1t, self.se_w2t = self.se_w1.t().contiguous(), self.se_w2.t().contiguous()
 
     def _bn(self, z, name, res=None, relu=True, part=None, apply=True, res_affine=None):

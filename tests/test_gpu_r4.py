@@ -232,3 +232,21 @@ def test_register_stationary_contraction_with_the_statistics_epilogue_equals_the
     d = ops.gemm_rs(A, wf, K, K, M=M)
     torch.cuda.synchronize()
     assert max_abs(d, ops.gemm(A, Wb, None, None, ops.ACT_NONE, M=M)) <= 2e-2 * max(1.0, float(d.float().abs().max()))
+
+
+def test_weight_gradient_on_exact_160_wide_tiles_for_the_320_wide_layers():
+    """tdeed_wgrad at N = K = 320 (wgrad_tr160_kernel: 2 x 2 exact tiles) against the fp64 product, with and without the
+    gate-shift splice of the X operand, on a row count that is not a multiple of the 64-row chunk."""
+    from tdeed_amd import ops_bwd as B_
+    M, N = 9000 + 13, 320
+    dY = _rand((M, N), 51, 0.5).to(DEV).to(torch.bfloat16)
+    X = _rand((M, N), 52).to(DEV).to(torch.bfloat16)
+    X0 = _rand((M, 80), 53).to(DEV).to(torch.bfloat16)
+    for x0, k0 in ((None, 0), (X0, 80)):
+        dW, _ = B_.wgrad(dY, X, with_bias=False, M=M, X0=x0, k0=k0)
+        torch.cuda.synchronize()
+        Xe = X.double().clone()
+        if x0 is not None:
+            Xe[:, :k0] = x0.double()
+        ref = dY.double().t() @ Xe
+        assert max_abs(dW, ref) <= 2e-4 * float(ref.abs().max())
