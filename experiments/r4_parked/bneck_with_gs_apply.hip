@@ -22,6 +22,11 @@ struct BneckP {
   const bf16x8* w3f; const float* s3; const float* h3;        // [NT][KS][64]
   bf16_t* out; bf16_t* out2; int n2;              // out [N][hw][C]; optional compact copy of channels [0, n2)
   int N, h, w, C;
+  // gate-shift-fuse APPLY step inside the load phase (impl/gsf.py:66-93; gate == null: G above is used instead): the
+  // spliced columns of a frame are computed here from the raw channel slice of frames t-1, t, t+1 (xs, row stride ldx), the
+  // gates and the per-frame spatial sums that tdeed_gsf_gate_fwd left, and the fusion conv's weights
+  const bf16_t* xs; int ldx; const float* gate; const float* ysum; const float* xsum;
+  const float* cw1; const float* cb1; const float* cw2; const float* cb2; int T_len, F;
   long long* dbg;                                 // diagnostic: per-workgroup phase time stamps (or null)
 };
 
@@ -86,9 +91,71 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   // ---- P0: x (gate-shift columns spliced in) -> region A; pads, zero row
   {
     const int cpr = C >> 3;
-    const bf16_t* gg = p.G ? p.G + (long)f0 * hw * p.Fp : nullptr;
+    const bf16_t* gg = (p.G && !p.gate) ? p.G + (long)f0 * hw * p.Fp : nullptr;
     const int total = npix * cpr;
     const IDiv dcpr(cpr);
+    // gate-shift apply (p.gate != null): its operands are requested FIRST, so that they travel together with the frame rows
+    // loaded below; they are stored and blended after those (see the second half further down)
+    const int gF = p.F, gFp = p.Fp, gFh = gF >> 1, gFq = gF >> 2, gT = p.T_len;
+    const int npc = p.gate ? (gFp >> 2) : 1;                       // 4-channel pieces per pixel
+    constexpr int MAXS = 4;                                      // slice pieces per thread per frame (hw * Fp / 4 <= 2048)
+    const IDiv dnpc(npc);
+    u32x2 vc[FPW][MAXS], vn[FPW][MAXS], vp[FPW][MAXS];
+    f32x2 ga[FPW];
+    float gnx[FPW], gpx[FPW], sums[FPW][2][3][5];                // [ysum | xsum][channel c-1..c+1][frame t-2..t+2]
+    float cwv[18], cbv = 0.f;
+    const float inv_hw = 1.0f / (float)hw;
+    const int fsz = ((gF + 4 * hw) * 4 + 2 * hw * gFp * 2 + 15) & ~15;      // per-frame scratch bytes
+    unsigned char* scr = Bt + 64;
+    if (p.gate) {
+      const int F = gF, Fp = gFp, Fh = gFh, Fq = gFq, T_len = gT;
+      (void)Fq; (void)Fp;
+      // ---- gate-shift apply for this workgroup's frames.  Scratch = region B behind its first 64 bytes (nothing lives there
+      // yet).  Every global load of the step -- the three frames' channel slices, the gates, and for the threads that make
+      // the fusion weights the 30 spatial sums each of them needs -- is issued before the first LDS store: ONE round trip,
+      // travelling with the frame loads above, then one barrier, then the blend into region A.  (A first version staged
+      // sums, gates and slices in three dependent loops with three barriers: +18 us per launch, more than the apply launch
+      // it replaced.)
+#pragma unroll
+      for (int j = 0; j < FPW; ++j) {
+        const long f = f0 + min(j, nfr - 1);
+        const int t = (int)(f % T_len);
+        const long b = f / T_len;
+        const long fn = t < T_len - 1 ? f + 1 : f, fp_ = t > 0 ? f - 1 : f;
+#pragma unroll
+        for (int u = 0; u < MAXS; ++u) {
+          const int i = min(tid + u * BNK_THR, hw * npc - 1);
+          int pq, pj;
+          dnpc.divmod(i, pq, pj);
+          const long off = (long)pq * p.ldx + pj * 4;
+          vc[j][u] = *reinterpret_cast<const u32x2*>(p.xs + f * hw * p.ldx + off);
+          vn[j][u] = *reinterpret_cast<const u32x2*>(p.xs + fn * hw * p.ldx + off);
+          vp[j][u] = *reinterpret_cast<const u32x2*>(p.xs + fp_ * hw * p.ldx + off);
+        }
+        const int gi = min(tid, hw - 1);
+        ga[j] = *reinterpret_cast<const f32x2*>(p.gate + (f * hw + gi) * 2);
+        gnx[j] = p.gate[(fn * hw + gi) * 2];
+        gpx[j] = p.gate[(fp_ * hw + gi) * 2 + 1];
+        // fusion-weight threads: channel c = tid (< F) of frame j
+        const int c = min(tid, F - 1);
+        const int g = c >= Fh, cl = c - g * Fh;
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) {
+          const int c2 = min(max(cl + dc - 1, 0), Fh - 1) + g * Fh;
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            const int t2 = min(max(t + r - 2, 0), T_len - 1);
+            sums[j][0][dc][r] = p.ysum[(b * T_len + t2) * F + c2];
+            sums[j][1][dc][r] = p.xsum[(b * T_len + t2) * F + c2];
+          }
+        }
+      }
+      // the fusion conv of this thread's channel group (group 0: cw1 / cb1, group 1: cw2 / cb2)
+      const bool grp1 = min(tid, F - 1) >= Fh;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) cwv[i] = (grp1 ? p.cw2 : p.cw1)[i];
+      cbv = (grp1 ? p.cb2 : p.cb1)[0];
+    }
     constexpr int NLD = 9;                                       // independent 16-byte loads in flight per thread: a workgroup's
     for (int i0 = tid; i0 < total; i0 += BNK_THR * NLD) {        // 72 KB (7 x 7 x 368, two frames) in ONE round trip
       u32x4 v[NLD];
@@ -113,10 +180,105 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
         }
       }
     }
+    if (p.gate) {
+      const int F = gF, Fp = gFp, Fh = gFh, Fq = gFq, T_len = gT;
+      (void)Fq; (void)Fp;
+      TD_LDS_CHECK((scr - smem) + FPW * fsz, 0, (Zr - smem));
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int j = 0; j < FPW; ++j) {
+        if (j < nfr) {
+          const long f = f0 + j;
+          const int t = (int)(f % T_len);
+          const bool has_next = t < T_len - 1, has_prev = t > 0;
+          float* fwl = reinterpret_cast<float*>(scr + j * fsz);  // [F] fusion weights
+          float* gc = fwl + F;                                   // [hw][2] gates of this frame
+          float* gs = gc + 2 * hw;                               // [hw][2] gate 0 of frame t+1 | gate 1 of frame t-1
+          bf16_t* xc = reinterpret_cast<bf16_t*>(gs + 2 * hw);   // [hw][Fp] this frame's slice
+          bf16_t* xsf = xc + hw * Fp;                            // [hw][Fp] c < Fh: frame t+1, else frame t-1
+#pragma unroll
+          for (int u = 0; u < MAXS; ++u) {
+            const int i = tid + u * BNK_THR;
+            if (i < hw * npc) {
+              int pq, pj;
+              dnpc.divmod(i, pq, pj);
+              *reinterpret_cast<u32x2*>(xc + pq * Fp + pj * 4) = vc[j][u];
+              const bf16x4 n4 = *reinterpret_cast<const bf16x4*>(&vn[j][u]);
+              const bf16x4 p4 = *reinterpret_cast<const bf16x4*>(&vp[j][u]);
+              bf16x4 o4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o4[e] = (pj * 4 + e < Fh) ? n4[e] : p4[e];
+              *reinterpret_cast<bf16x4*>(xsf + pq * Fp + pj * 4) = o4;
+            }
+          }
+          if (tid < hw) {
+            gc[2 * tid] = ga[j][0];
+            gc[2 * tid + 1] = ga[j][1];
+            gs[2 * tid] = has_next ? gnx[j] : 0.f;
+            gs[2 * tid + 1] = has_prev ? gpx[j] : 0.f;
+          }
+          if (tid < F) {
+            // fusion weight of channel c: 3x3 conv over the (channel, time) plane of the spatial means + sigmoid
+            const int c = tid, g = c >= Fh, cl = c - g * Fh;
+            float a = cbv;
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+              const int c2 = cl + dc;
+              if (c2 < 0 || c2 >= Fh) continue;
+#pragma unroll
+              for (int dt = -1; dt <= 1; ++dt) {
+                const int t2 = t + dt;
+                if (t2 < 0 || t2 >= T_len) continue;
+                const float rm = (sums[j][1][dc + 1][dt + 2] - sums[j][0][dc + 1][dt + 2]) * inv_hw;
+                // the shifted source frame: t2 - 1 for group 1, t2 + 1 for group 0 (zeros outside the clip); both candidates
+                // are compile-time positions of the register array (an index depending on g would put it into scratch)
+                const int ts = t2 + (g ? -1 : 1);
+                const float ycand = g ? sums[j][0][dc + 1][dt + 1] : sums[j][0][dc + 1][dt + 3];
+                const float ysh = (ts >= 0 && ts < T_len) ? ycand * inv_hw : 0.f;
+                a = fmaf(cwv[(dc + 1) * 3 + (dt + 1)], ysh, a);
+                a = fmaf(cwv[9 + (dc + 1) * 3 + (dt + 1)], rm, a);
+              }
+            }
+            fwl[c] = sigmoidf_(a);
+          }
+        }
+      }
+      __syncthreads();
+      // the spliced columns of every pixel -> region A (channels [0, Fp) of the rows loaded above)
+      for (int idx = tid; idx < npix * npc; idx += BNK_THR) {
+        int px, qd;
+        dnpc.divmod(idx, px, qd);
+        const int j = (FPW > 1 && px >= hw) ? 1 : 0;
+        const int pl_ = px - j * hw;
+        const float* fwl = reinterpret_cast<const float*>(scr + j * fsz);
+        const float* gc = fwl + F;
+        const float* gs = gc + 2 * hw;
+        const bf16_t* xr = reinterpret_cast<const bf16_t*>(gs + 2 * hw) + pl_ * Fp;
+        const bf16_t* sr = xr + hw * Fp;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = qd * 4 + e;
+          if (co >= F) { o[e] = xr[co]; continue; }
+          const int g = co >= Fh;
+          const int col = co - g * Fh;
+          const int ci = g * Fh + (col & 1) * Fq + (col >> 1);
+          const float xv = (float)xr[ci];
+          const float r = fmaf(-gc[2 * pl_ + g], xv, xv);
+          const float ysh = gs[2 * pl_ + g] * (float)sr[ci];
+          const float wv = fwl[ci];
+          o[e] = (bf16_t)fmaf(ysh, wv, r * (1.0f - wv));
+        }
+        *reinterpret_cast<bf16x4*>(At + px * RS + qd * 8) = o;
+      }
+      // (no barrier here: what follows before the phase's closing barrier writes region A's pads, the zero row and the 64
+      //  bytes in front of the scratch only)
+    }
     // the pad bytes behind every row (they meet the zero weights of the k pad, but 0 * stale NaN = NaN), the zero row
-    // (region B's pad bytes that the grouped conv reads are written by conv1 itself: the zeros of its overhang tile)
+    // (region B's pad bytes that the grouped conv reads are written by conv1 itself: the zeros of its overhang tile; with the
+    //  gate-shift scratch in region B they must not be touched here)
     const int padp = (RS - C * 2) >> 4;
-    for (int i = tid; i < 2 * FPW * hw * padp; i += BNK_THR) {
+    for (int i = tid; i < (p.gate ? 1 : 2) * FPW * hw * padp; i += BNK_THR) {
       const int r = i / padp, j = i - r * padp;
       *reinterpret_cast<u32x4*>(smem + r * RS + C * 2 + j * 16) = (u32x4){0u, 0u, 0u, 0u};
     }
@@ -419,13 +581,15 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
                                const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
                                const void* se_w1f, const float* se_b1, const void* se_w2f, const float* se_b2, int R,
                                const void* w3f, const float* s3, const float* h3, void* out, void* out2, int n2,
-                               void* stream) {
+                               const void* gs_x, int gs_ldx, const float* gs_gate, const float* gs_ysum,
+                               const float* gs_xsum, const float* gs_cw1, const float* gs_cb1, const float* gs_cw2,
+                               const float* gs_cb2, int gs_T, int gs_F, void* stream) {
   TD_CHECK(x && w1f && s1 && h1 && w2f && s2 && h2 && se_w1f && se_b1 && se_w2f && se_b2 && w3f && s3 && h3 && out,
            "bneck: null pointer");
   TD_CHECK(N > 0 && tdeed_bneck_fits(h, w, C, R), "bneck: geometry h=%d w=%d C=%d R=%d unsupported", h, w, C, R);
   TD_CHECK(!G || (Fp % 8 == 0 && Fp > 0 && Fp <= C), "bneck: bad splice width %d", Fp);
   TD_CHECK(!out2 || (n2 % 8 == 0 && n2 > 0 && n2 <= C), "bneck: bad second output width %d", n2);
-  BneckP p{};
+  BneckP p;
   p.x = (const bf16_t*)x; p.G = (const bf16_t*)G; p.Fp = G ? Fp : 0;
   p.w1f = (const bf16x8*)w1f; p.s1 = s1; p.h1 = h1;
   p.w2f = (const bf16x8*)w2f; p.s2 = s2; p.h2 = h2;
@@ -434,6 +598,21 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
   p.w3f = (const bf16x8*)w3f; p.s3 = s3; p.h3 = h3;
   p.out = (bf16_t*)out; p.out2 = (bf16_t*)out2; p.n2 = out2 ? n2 : 0;
   p.N = N; p.h = h; p.w = w; p.C = C;
+  p.xs = (const bf16_t*)gs_x; p.ldx = gs_ldx; p.gate = gs_gate; p.ysum = gs_ysum; p.xsum = gs_xsum;
+  p.cw1 = gs_cw1; p.cb1 = gs_cb1; p.cw2 = gs_cw2; p.cb2 = gs_cb2; p.T_len = gs_T; p.F = gs_F;
+  if (gs_gate) {
+    // the apply step of the gate-shift inside the load phase: Fp = the splice width, F the fold (impl/gsf.py:38-93)
+    TD_CHECK(!G && gs_x && gs_ysum && gs_xsum && gs_cw1 && gs_cb1 && gs_cw2 && gs_cb2, "bneck: gate-shift apply operands");
+    TD_CHECK(Fp % 8 == 0 && Fp > 0 && Fp <= C && gs_F % 4 == 0 && gs_F > 0 && gs_F <= Fp && gs_F <= 256 && gs_ldx >= Fp &&
+                 gs_ldx % 4 == 0 && gs_T > 0 && N % gs_T == 0,
+             "bneck: bad gate-shift geometry F=%d Fp=%d ldx=%d T=%d N=%d", gs_F, Fp, gs_ldx, gs_T, N);
+    p.Fp = Fp;
+    const int fpw_ = bneck_fpw(h * w);
+    const long fsz = ((((long)gs_F + 4L * h * w) * 4 + 2L * h * w * Fp * 2) + 15) & ~15L;
+    TD_CHECK(64 + fpw_ * fsz <= (long)fpw_ * h * w * bneck_rs(C), "bneck: gate-shift scratch does not fit the y1 region");
+    TD_CHECK((long)h * w * (Fp / 4) <= 4L * BNK_THR && h * w <= BNK_THR && gs_F <= BNK_THR,
+             "bneck: gate-shift slice of %d px x %d ch too large for the in-kernel apply step", h * w, Fp);
+  }
   p.dbg = g_bneck_dbg;
   const int hw = h * w, fpw = bneck_fpw(hw), KS = (C + 31) / 32;
   const size_t smem = bneck_smem(fpw, hw, C);

@@ -419,12 +419,15 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
 // at 800 frames, written once and read 2.25 x) never exists.  x rows are MFMA B operands straight from global memory
 // (lane = pixel l & 15, k-chunk l >> 4), the conv1 weights of the slab are A-operand fragments in registers
 // (w1f: [slabs * CSP / 16][KS1][64], engine.pack_mfma_frags, zero padded).
-// (A form that also produced the downsample shortcut from the same x fragments was measured slower and is parked:
-// experiments/r4_parked/conv_with_c1_gconv_ds.hip.)
-template <int STRIDE, int KS1>
+// DS: the block's downsample shortcut (1x1 conv of stride STRIDE + BN on the same x) comes out of the same launch: the x
+// fragments of the band's own rows feed a second set of weight fragments (wdf, laid out like w1f), as s1_front_kernel does
+// for s1.b1 -- x is not read again by a contraction of its own.
+template <int STRIDE, int KS1, bool DS>
 __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G, int Fp,
                                                             int Hi, int Wi, int Cin, int C, const bf16x8* __restrict__ w1f,
                                                             const float* __restrict__ s1, const float* __restrict__ h1,
+                                                            const bf16x8* __restrict__ wdf, const float* __restrict__ sd,
+                                                            const float* __restrict__ hd, bf16_t* __restrict__ sc_out,
                                                             const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                             float* __restrict__ pooled, int Ho, int Wo, int band, int nbands,
@@ -460,6 +463,23 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
       b1[t][e] = ok ? h1[c] : 0.f;
     }
   }
+  bf16x8 wdr[DS ? 4 : 1][KS1];
+  float ad[DS ? 4 : 1][4], bd[DS ? 4 : 1][4];
+  if constexpr (DS) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tt = slab * nts + min(t, nts - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) wdr[t][ks] = wdf[((long)tt * KS1 + ks) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = slab * CSP + t * 16 + 4 * q + e;
+        const bool ok = t < nts && c < C;
+        ad[t][e] = ok ? sd[c] : 0.f;
+        bd[t][e] = ok ? hd[c] : 0.f;
+      }
+    }
+  }
   // ---- zero the halo columns of every band row and the rows that fall outside the map
   {
     const int cpp = PS >> 4;
@@ -491,6 +511,7 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
       dwi.divmod(pok ? p : 0, rr, cc);
       const long pix = (long)(r_lo + rr) * Wi + cc;
       bf16x8 xf[KS1];
+      [[maybe_unused]] bf16x8 xd[DS ? KS1 : 1];
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
         const int k = 32 * ks + 8 * q;
@@ -500,6 +521,14 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
         const u32x4 z = {0u, 0u, 0u, 0u};
         const u32x4 w = ok ? v : z;
         xf[ks] = *reinterpret_cast<const bf16x8*>(&w);
+        if constexpr (DS) {                                 // the shortcut reads x itself, not the spliced operand
+          xd[ks] = xf[ks];
+          if (gn && k < Fp) {
+            const u32x4 vd = *reinterpret_cast<const u32x4*>(ok ? xn + pix * Cin + k : xn);
+            const u32x4 wd_ = ok ? vd : z;
+            xd[ks] = *reinterpret_cast<const bf16x8*>(&wd_);
+          }
+        }
       }
       unsigned char* dst = tile + ((long)(r_lo + rr - iy0) * WP + cc + 1) * PS + 8 * q;
 #pragma unroll
@@ -513,6 +542,30 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(acc[e] * a1[t][e] + b1[t][e], 0.f);
             *reinterpret_cast<bf16x4*>(dst + t * 32) = o;
+          }
+        }
+      }
+      if constexpr (DS) {
+        // shortcut pixels: input (r, c) with r, c multiples of STRIDE, r / STRIDE one of THIS band's output rows (halo rows
+        // belong to the neighbouring band).  A tile's 16 pixels may straddle two rows: per-lane test.
+        const int r = r_lo + rr;
+        const int orow = r / STRIDE;
+        const bool mine = pok && (r % STRIDE == 0) && (cc % STRIDE == 0) && orow >= oy0 && orow < oy0 + nrows_out;
+        if (__builtin_amdgcn_read_exec() != 0 && __any(mine)) {
+          bf16_t* sdst = sc_out + (((long)n * Ho + orow) * Wo + cc / STRIDE) * C + slab * CSP + 4 * q;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t < nts) {
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdr[t][ks], xd[ks], acc, 0, 0, 0);
+              if (mine && slab * CSP + t * 16 + 4 * q < C) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[e] * ad[t][e] + bd[t][e]);
+                *reinterpret_cast<bf16x4*>(sdst + t * 16) = o;
+              }
+            }
           }
         }
       }
@@ -590,9 +643,11 @@ extern "C" int tdeed_c1_gconv_slab_tiles(int Hi, int Wi, int C, int stride) {   
   return g.nslabs * (g.CSP >> 4);
 }
 extern "C" int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int Wi, int Cin, int C, int gw,
-                                  int stride, const void* w1f, const float* s1, const float* h1, const void* wfrag,
-                                  const float* scale, const float* shift, void* y, float* pooled, void* stream) {
+                                  int stride, const void* w1f, const float* s1, const float* h1, const void* wdf,
+                                  const float* sd, const float* hd, void* shortcut, const void* wfrag, const float* scale,
+                                  const float* shift, void* y, float* pooled, void* stream) {
   TD_CHECK(x && w1f && s1 && h1 && wfrag && scale && shift && y && pooled, "c1_gconv: null pointer");
+  TD_CHECK(!wdf == !shortcut && (!wdf || (sd && hd)), "c1_gconv: the downsample's weights, BatchNorm and output come together");
   TD_CHECK((gw == 8 || gw == 16) && C % gw == 0, "c1_gconv: group width %d / C %d unsupported", gw, C);
   TD_CHECK(stride == 1 || stride == 2, "c1_gconv: stride %d", stride);
   TD_CHECK(N > 0 && N <= 65535 && tdeed_c1_gconv_fits(Hi, Wi, Cin, C, stride), "c1_gconv: Hi=%d Wi=%d Cin=%d C=%d unsupported",
@@ -604,16 +659,17 @@ extern "C" int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, i
   const size_t smem = (size_t)g.rows_in * (Wi + 2) * g.PS;
   hipStream_t st = (hipStream_t)stream;
   const int KS1 = (Cin + 31) / 32;
-#define TD_C1G(Sv, Kv)                                                                                                     \
-  hipLaunchKernelGGL((c1_gconv_mfma_kernel<Sv, Kv>), grid, dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)G,           \
-                     G ? Fp : 0, Hi, Wi, Cin, C, (const bf16x8*)w1f, s1, h1, (const bf16x8*)wfrag, scale, shift, (bf16_t*)y,  \
-                     pooled, Ho, Wo, g.band, g.nbands, g.CSP, g.PS, g.rows_in, 1)
-#define TD_C1G_K(Sv)                                                                                                       \
+#define TD_C1G(Sv, Kv, Dv)                                                                                                 \
+  hipLaunchKernelGGL((c1_gconv_mfma_kernel<Sv, Kv, Dv>), grid, dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)G,       \
+                     G ? Fp : 0, Hi, Wi, Cin, C, (const bf16x8*)w1f, s1, h1, (const bf16x8*)wdf, sd, hd, (bf16_t*)shortcut,   \
+                     (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, Ho, Wo, g.band, g.nbands, g.CSP, g.PS, g.rows_in, 1)
+#define TD_C1G_K(Sv, Dv)                                                                                                   \
   do {                                                                                                                     \
-    if (KS1 == 1) TD_C1G(Sv, 1); else if (KS1 == 2) TD_C1G(Sv, 2); else if (KS1 == 4) TD_C1G(Sv, 4);                      \
-    else TD_C1G(Sv, 5);                                                                                                    \
+    if (KS1 == 1) TD_C1G(Sv, 1, Dv); else if (KS1 == 2) TD_C1G(Sv, 2, Dv); else if (KS1 == 4) TD_C1G(Sv, 4, Dv);          \
+    else TD_C1G(Sv, 5, Dv);                                                                                                \
   } while (0)
-  if (stride == 2) TD_C1G_K(2); else TD_C1G_K(1);
+  if (stride == 2) { if (wdf) TD_C1G_K(2, true); else TD_C1G_K(2, false); }
+  else { if (wdf) TD_C1G_K(1, true); else TD_C1G_K(1, false); }
 #undef TD_C1G_K
 #undef TD_C1G
   TD_LAUNCH_CHECK("c1_gconv");

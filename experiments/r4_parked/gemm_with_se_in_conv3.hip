@@ -14,6 +14,7 @@
 // where the SE gate / gate-shift splice / stride-2 row gather are applied).
 // Epilogue goes through LDS so that C (and the residual) move as whole 16-B chunks per lane.
 #include "common.h"
+#include "se_excite.h"
 #include <stdlib.h>
 
 struct GemmP {
@@ -30,6 +31,7 @@ struct GemmP {
   float* colpart;      // optional [M tiles][2][N]: per-tile column sums / sums of squares of the stored C (BatchNorm statistics)
   void* C2; long ldc2; int n2;   // optional second, compact copy of columns [0, n2) of C (the next block's gate-shift slice)
   int c2_pre;                    // C2 takes the value BEFORE residual / activation and C keeps only the residual in those columns
+  SeP se;                        // SE == 3: the gates are computed in the prologue from conv2's squeeze sums (se_excite.h)
   // BWD epilogue (tdeed_gemm_dgrad: the input-gradient contraction of a training bottleneck's conv1, whose output rows are
   // the gradient arriving at the PREVIOUS block's output ReLU):
   const void* mask; long ldmask;                      // v = mask[m][n] > 0 ? v : 0 after the residual (that ReLU's backward)
@@ -62,8 +64,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // gates of the (few) frames a 128-row tile touches in LDS (dynamic, frames x K floats) and reads them when a slab is
 // stored; SE = 1 is the general form that prefetches them in registers next to the slab (32 VGPRs).  __launch_bounds__(256, 2) makes the compiler keep two workgroups per CU resident; a variant with a second
 // register stage (two K slabs in flight) was measured: it needs > 256 VGPRs, spills, and loses (43 vs 32 us at
-// M=39200, K=N=368).  (A form that COMPUTED the gate table in its prologue -- no se_gate launch -- was measured slower and is
-// parked: experiments/r4_parked/gemm_with_se_in_conv3.hip.)
+// M=39200, K=N=368).  SE = 3 is SE = 2 with the table COMPUTED here (fc1 / ReLU / fc2 / sigmoid on the MFMA pipe from the
+// squeeze sums of the tile's frames, se_excite.h) instead of read from a gate tensor: no se_gate launch in front of conv3.
 template <typename T, int BN, int SE, bool BWD = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int EPC = Chunk<T>::N;        // elements per 16-B chunk
@@ -230,6 +232,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       gfi[i] = (int)(m / p.a_scale_rows - f_first);
     }
     __syncthreads();
+  }
+  if constexpr (SE == 3) {
+    const long f_first = m0 / p.a_scale_rows;
+    const long f_last = (p.M - 1) / p.a_scale_rows;
+    const int nf = 128 / p.a_scale_rows + 2;                    // <= 16 (checked by the host)
+    // scratch: the operand stage buffers (not yet written) when they are large enough, else behind the table
+    unsigned char* scr = se_excite_scratch_bytes(p.se.C, p.se.R) <= LDS_BYTES
+                             ? lds : reinterpret_cast<unsigned char*>(gtab + nf * p.K);
+    se_excite_lds<12, 3, false>(p.se, f_first, nf, f_last, gtab, p.K, scr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = min(m0 + r0 + 32 * i, (long)p.M - 1);
+      gfi[i] = (int)(m / p.a_scale_rows - f_first);
+    }
   }
   lstore(0, 0);
   __syncthreads();
@@ -479,12 +495,24 @@ static int launch_gemm(const GemmP& p, hipStream_t st, bool bwd = false) {
   static int se_tab = -1;
   if (se_tab < 0) { const char* e = getenv("TDEED_GEMM_SE_TABLE"); se_tab = e ? atoi(e) : 1; }
   int se = !p.a_scale ? 0 : ((se_tab && gt_bytes <= 24 * 1024) ? 2 : 1);
+  size_t se3_bytes = 0;
+  if (p.se.pooled) {                                // excitation fused into this launch (bf16 only, checked by the caller)
+    se = 3;
+    const int nf = 128 / p.a_scale_rows + 2;
+    const int stage = 128 * 128 + bn * 128, cs = 64 * (bn + 4) * 4;
+    const int scr = se_excite_scratch_bytes(p.se.C, p.se.R);
+    se3_bytes = (size_t)nf * p.K * sizeof(float) + (scr <= (stage > cs ? stage : cs) ? 0 : scr);
+  }
 #define TD_GEMM(BNv)                                                                                                   \
   do {                                                                                                                 \
     if (bwd) {                                                                                                         \
       hipLaunchKernelGGL((gemm_kernel<T, BNv, 0, true>), dim3((unsigned)grid), dim3(256), 0, st, p);                   \
       break;                                                                                                           \
     }                                                                                                                  \
+    if constexpr (sizeof(T) == 2) {                                                                                    \
+      if (se == 3) hipLaunchKernelGGL((gemm_kernel<T, BNv, 3>), dim3((unsigned)grid), dim3(256), se3_bytes, st, p);    \
+    }                                                                                                                  \
+    if (se == 3) break;                                                                                                \
     if (se == 2) hipLaunchKernelGGL((gemm_kernel<T, BNv, 2>), dim3((unsigned)grid), dim3(256), gt_bytes, st, p);      \
     else if (se == 1) hipLaunchKernelGGL((gemm_kernel<T, BNv, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
     else hipLaunchKernelGGL((gemm_kernel<T, BNv, 0>), dim3((unsigned)grid), dim3(256), 0, st, p);                      \
@@ -526,6 +554,7 @@ extern "C" int tdeed_gemm_fwd(const void* A, long lda, const void* A0, long lda0
   p.g_stride = gather_stride; p.g_hi = gather_hi; p.g_wi = gather_wi; p.g_ho = gather_ho; p.g_wo = gather_wo;
   p.colpart = colpart;
   p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0; p.c2_pre = (C2 && c2_pre) ? 1 : 0;
+  p.se = SeP{};
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st) : launch_gemm<bf16_t>(p, st);
 }
@@ -565,6 +594,42 @@ extern "C" int tdeed_gemm_dgrad(const void* A, long lda, int M, int K, int N, co
   p.r_hi = r_hi; p.r_wi = r_wi;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TDEED_F32 ? launch_gemm<float>(p, st, true) : launch_gemm<bf16_t>(p, st, true);
+}
+
+// conv3 of a bottleneck with the SE excitation inside: the operand re-scale gate[frame][k] is computed by every workgroup
+// for the frames of its row tile from conv2's squeeze sums (pooled [M / rows_per_frame][n_parts][K] fp32, inv_cnt =
+// 1 / (Ho * Wo)) instead of read from a tensor a tdeed_se_gate_* launch wrote.  bf16 only; weights as for
+// tdeed_se_gate_mfma_fwd.  gate_out (optional [frames][K]) also receives the gates.
+extern "C" int tdeed_gemm_se_fits(int rows_per_frame, int K, int R) {
+  return rows_per_frame > 0 && 128 / rows_per_frame + 2 <= 16 && K % 8 == 0 && K <= 384 && R >= 1 && R <= 96 &&
+         (size_t)(128 / rows_per_frame + 2) * K * sizeof(float) <= 24 * 1024;
+}
+
+extern "C" int tdeed_gemm_se_fwd(const void* A, long lda, int rows_per_frame, const float* pooled, int n_parts, float inv_cnt,
+                                 int R, const void* w1f, const float* b1, const void* w2f, const float* b2, float* gate_out,
+                                 int M, int K, int N, const void* W, long ldw, const float* scale, const float* shift,
+                                 const void* R_, long ldr, int act, void* C, long ldc, void* C2, long ldc2, int n2,
+                                 void* stream) {
+  TD_CHECK(A && W && C && pooled && w1f && b1 && w2f && b2, "gemm_se: null pointer");
+  TD_CHECK(M > 0 && K > 0 && N > 0 && n_parts > 0, "gemm_se: bad sizes M=%d K=%d N=%d parts=%d", M, K, N, n_parts);
+  TD_CHECK(tdeed_gemm_se_fits(rows_per_frame, K, R), "gemm_se: rows_per_frame=%d K=%d R=%d unsupported", rows_per_frame, K, R);
+  TD_CHECK(M % rows_per_frame == 0, "gemm_se: M=%d is not whole frames of %d rows", M, rows_per_frame);
+  TD_CHECK(N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0, "gemm_se: N, lda, ldw, ldc must be multiples of 8");
+  TD_CHECK(!R_ || ldr % 8 == 0, "gemm_se: ldr=%ld must be a multiple of 8", ldr);
+  TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm_se: bad second output");
+  TD_CHECK(act >= 0 && act <= 2, "gemm_se: bad act %d", act);
+  GemmP p{};
+  p.A = A; p.lda = lda; p.A0 = nullptr; p.lda0 = 0; p.k0 = 0;
+  p.a_scale = pooled;            // non-null marks a gated operand; the SE = 3 kernel never reads it as gates
+  p.a_scale_rows = rows_per_frame;
+  p.M = M; p.K = K; p.N = N; p.W = W; p.ldw = ldw; p.scale = scale; p.shift = shift;
+  p.R = R_; p.ldr = ldr; p.act = act; p.C = C; p.ldc = ldc;
+  p.g_stride = 1; p.g_hi = p.g_wi = p.g_ho = p.g_wo = 0;
+  p.colpart = nullptr;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0; p.c2_pre = 0;
+  p.se.pooled = pooled; p.se.n_parts = n_parts; p.se.inv_cnt = inv_cnt; p.se.C = K; p.se.R = R;
+  p.se.w1f = (const bf16x8*)w1f; p.se.b1 = b1; p.se.w2f = (const bf16x8*)w2f; p.se.b2 = b2; p.se.gate_out = gate_out;
+  return launch_gemm<bf16_t>(p, (hipStream_t)stream);
 }
 
 // =============================================================================================

@@ -324,8 +324,70 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
   gsf_spatial_sums<T>(x, f, hw, C, F, sg, part, ysum, xsum);
 }
 
-// (a merged form of launches 1a + 1b -- every frame staged three times, no Q maps -- was measured twice as slow and is parked:
-// experiments/r4_parked/gsf_with_merge.hip)
+// ---- launches 1a + 1b in one (bf16, frame fits one LDS tile): the workgroup of frame t stages frames t-1, t, t+1 in
+// turn and takes from each only the temporal tap it contributes, so the per-tap maps Q never exist in memory and the
+// gate / spatial sums follow in the same launch.  3x redundant MFMA work (trivial here) for one launch fewer.
+__global__ __launch_bounds__(256) void gsf_gate3_mfma_kernel(const bf16_t* __restrict__ x, int T_len, int h, int w, int C,
+                                                             int F, int nch, int PSQ, int KS,
+                                                             const float* __restrict__ bn_scale,
+                                                             const float* __restrict__ bn_shift,
+                                                             const bf16x8* __restrict__ wqf,
+                                                             const float* __restrict__ b3d, float* __restrict__ gate,
+                                                             float* __restrict__ ysum, float* __restrict__ xsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smq[];
+  const int f = blockIdx.x, t = f % T_len;
+  const int hw = h * w, WP = w + 2;
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
+  unsigned char* a = smq + (size_t)KS * 64 * 16;               // [h+2][WP][PSQ]
+  float* sg = reinterpret_cast<float*>(a + (size_t)(h + 2) * WP * PSQ);   // [hw][2] gate pre-activations
+  float* part = sg + 2 * hw;                                    // [2][S][F], S*F = 512
+  float* sbn = part + 1024;                                     // [2F]
+  int* soff = reinterpret_cast<int*>(sbn + 2 * F);              // [KS*4]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  for (int s_ = tid; s_ < KS * 4; s_ += 256) {                  // byte offset of every k-slot (tap, 8-channel chunk)
+    const int tap = s_ / nch, ck = s_ - tap * nch;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    soff[s_] = tap < 9 ? (dy * WP + dx) * PSQ + ck * 16 : 0;
+  }
+  gsf_stage_bn(sbn, bn_scale, bn_shift, F);
+  copy16_batched(reinterpret_cast<u32x4*>(wl), reinterpret_cast<const u32x4*>(wqf), KS * 64);
+  {
+    const float b0 = b3d[0], b1 = b3d[1];
+    for (int i = tid; i < 2 * hw; i += 256) sg[i] = (i & 1) ? b1 : b0;
+  }
+  const int ntl = (hw + 15) >> 4;
+  for (int dt = -1; dt <= 1; ++dt) {
+    if (t + dt < 0 || t + dt >= T_len) continue;                // uniform per workgroup
+    __syncthreads();
+    gsf_stage_frame(a, x, (long)f + dt, h, w, C, F, 0, h + 2, nch, PSQ, sbn);
+    __syncthreads();
+    const int own_q = dt == 1 ? 1 : 0;                          // D rows 2j, 2j+1 (j = dt + 1) live in these lanes
+    for (int mt = wv; mt < ntl; mt += 4) {
+      const int p = mt * 16 + pl;
+      const bool pok = p < hw;
+      const int pc = pok ? p : 0;
+      const int py = pc / w, px = pc - py * w;
+      const unsigned char* base = a + ((long)py * WP + px) * PSQ;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + soff[ks * 4 + q]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks * 64 + lane], af, acc, 0, 0, 0);
+      }
+      if (pok && q == own_q) {
+        sg[2 * p] += dt == 0 ? acc[2] : acc[0];
+        sg[2 * p + 1] += dt == 0 ? acc[3] : acc[1];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * hw; i += 256) {
+    const float v = tanhf(sg[i]);
+    sg[i] = v;
+    gate[(long)f * hw * 2 + i] = v;
+  }
+  __syncthreads();
+  gsf_spatial_sums<bf16_t>(x, (long)f, hw, C, F, sg, part, ysum, xsum);
+}
 
 extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
                                   const float* bn_scale, const float* bn_shift, const float* wq, const void* wqf,
@@ -374,6 +436,16 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
         }
         attr_q.set();
       }
+    }
+    const size_t sm3 = (size_t)wbytes + (size_t)(h + 2) * (w + 2) * PSQ + (size_t)(2 * hw + 1024 + 2 * F + 4 * KSq) * sizeof(float);
+    // opt-in (TDEED_GSF_MERGE=1): one launch fewer, but the three staging phases run back to back inside each
+    // workgroup and the site gets slower on MI355X (85 vs 52 us at 14x14, F=40, 400 frames)
+    static const bool merge_ok = getenv("TDEED_GSF_MERGE") && atoi(getenv("TDEED_GSF_MERGE")) == 1;
+    if (merge_ok && sm3 <= 64 * 1024) {
+      hipLaunchKernelGGL(gsf_gate3_mfma_kernel, dim3(B * T), dim3(256), sm3, st, (const bf16_t*)x, T, h, w, C, F, nch,
+                         PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, b3d, gate, ysum, xsum);
+      TD_LAUNCH_CHECK("gsf_gate3");
+      return TDEED_OK;
     }
     if (bq >= 1) {
       if (bq > h) bq = h;

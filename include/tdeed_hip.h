@@ -171,16 +171,12 @@ int tdeed_gemm_rs_stats_fwd(const void* A, long lda, const void* A0, long lda0, 
  * largest intermediate of a stride-2 block) never exists.  bf16.  x [N][Hi][Wi][Cin]; G optional [N*Hi*Wi][Fp]; w1f: conv1
  * weight [C][Cin] as MFMA A-operand fragments [tdeed_c1_gconv_slab_tiles()][ceil(Cin/32)][64][8] (zero padded to whole
  * slabs); s1 / h1: its folded BatchNorm; wfrag / scale / shift / y / pooled as tdeed_gconv3x3_fwd (ReLU applied).
- * wdf / sd / hd / shortcut (optional, together): the block's downsample shortcut (1x1 conv of the same stride + BN on x,
- * weight [C][Cin] laid out like w1f) -> shortcut [N][Ho][Wo][C] from the same x fragments (timm Bottleneck.downsample).
- * Bit-identical to tdeed_gemm_fwd (or tdeed_gemm_ws_fwd) followed by tdeed_gconv3x3_fwd (and to the strided
- * tdeed_gemm_ws_fwd of the shortcut).  tdeed_c1_gconv_fits: Cin <= 64, or 97..160 (k-steps of 32: 1, 2, 4, 5). */
+ * Bit-identical to tdeed_gemm_fwd (or tdeed_gemm_ws_fwd) followed by tdeed_gconv3x3_fwd.  tdeed_c1_gconv_fits: Cin <= 64, or 97..160 (k-steps of 32: 1, 2, 4, 5). */
 int tdeed_c1_gconv_fits(int Hi, int Wi, int Cin, int C, int stride);
 int tdeed_c1_gconv_slab_tiles(int Hi, int Wi, int C, int stride);
 int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int Wi, int Cin, int C, int gw, int stride,
-                       const void* w1f, const float* s1, const float* h1, const void* wdf, const float* sd, const float* hd,
-                       void* shortcut, const void* wfrag, const float* scale, const float* shift, void* y, float* pooled,
-                       void* stream);
+                       const void* w1f, const float* s1, const float* h1, const void* wfrag, const float* scale,
+                       const float* shift, void* y, float* pooled, void* stream);
 
 /* A whole stride-1 RegNetY bottleneck with identity shortcut on a small map in ONE launch (timm Bottleneck.forward:
  * conv1 -> conv2 -> se -> conv3 + shortcut -> ReLU, with the gate-shift splice of shift.py:89-93 on conv1's operand;
@@ -190,10 +186,6 @@ int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int 
  *   (tdeed_amd.engine.pack_mfma_frags); w2f as for tdeed_gconv3x3_fwd (pack_gconv_frags, group width 8 or 16); se_w1f /
  *   se_w2f / R as for tdeed_se_gate_mfma_fwd; s*, h*: folded BatchNorm scale / shift; out [N][h][w][C]; out2 optional
  *   [N*h*w][n2] compact copy of channels [0, n2) (the next block's gate-shift slice).
- *   gs_gate != NULL (then G must be NULL; Fp = the splice width): the APPLY step of the gate-shift-fuse module
- *   (impl/gsf.py:66-93, what tdeed_gsf_apply_fused_fwd computes into G) runs inside the load phase -- gs_x: the raw channel
- *   slice the module reads ([N*h*w][gs_ldx], the block input or its compact copy), gs_gate / gs_ysum / gs_xsum: what
- *   tdeed_gsf_gate_fwd left, gs_cw1 .. gs_cb2: the fusion conv, gs_T the clip length, gs_F the fold.
  * Bit-identical to tdeed_gemm_fwd -> tdeed_gconv3x3_fwd -> tdeed_se_gate_mfma_fwd -> tdeed_gemm_fwd on the same operands.
  * tdeed_bneck_fits: 7x7x368 (two frames per workgroup) and 14x14x152 are the shapes it was built for.
  * tdeed_bneck_set_debug(buf): diagnostic, int64 [workgroups][16] phase time stamps (null switches it off). */
@@ -202,22 +194,8 @@ int tdeed_bneck_set_debug(void* buf);
 int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f, const float* s1,
                     const float* h1, const void* w2f, const float* s2, const float* h2, const void* se_w1f,
                     const float* se_b1, const void* se_w2f, const float* se_b2, int R, const void* w3f, const float* s3,
-                    const float* h3, void* out, void* out2, int n2, const void* gs_x, int gs_ldx, const float* gs_gate,
-                    const float* gs_ysum, const float* gs_xsum, const float* gs_cw1, const float* gs_cb1, const float* gs_cw2,
-                    const float* gs_cb2, int gs_T, int gs_F, void* stream);
+                    const float* h3, void* out, void* out2, int n2, void* stream);
 
-/* conv3 of a RegNetY bottleneck WITH its SE excitation (timm Bottleneck.forward: x = conv3(se(conv2(x)))):
- * the contraction of tdeed_gemm_fwd whose operand rows are re-scaled per (frame, k) by gates that every workgroup derives
- * itself, for the frames of its 128-row tile, from conv2's squeeze sums -- pooled fp32 [M / rows_per_frame][n_parts][K],
- * inv_cnt = 1 / (Ho * Wo), weights as for tdeed_se_gate_mfma_fwd (R hidden units) -- so that no tdeed_se_gate_* launch sits
- * between conv2 and conv3.  bf16 operands only.  gate_out: optional fp32 [M / rows_per_frame][K], also receives the gates
- * (bit-identical to tdeed_se_gate_mfma_fwd for n_parts = 1).  tdeed_gemm_se_fits(rows_per_frame, K, R) != 0 tells whether
- * the shape is covered (at most 16 frames per 128-row tile, K <= 384, R <= 96). */
-int tdeed_gemm_se_fits(int rows_per_frame, int K, int R);
-int tdeed_gemm_se_fwd(const void* A, long lda, int rows_per_frame, const float* pooled, int n_parts, float inv_cnt, int R,
-                      const void* w1f, const float* b1, const void* w2f, const float* b2, float* gate_out, int M, int K,
-                      int N, const void* W, long ldw, const float* scale, const float* shift, const void* Res, long ldr,
-                      int act, void* C, long ldc, void* C2, long ldc2, int n2, void* stream);
 
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
  * timm SEModule fc1/ReLU/fc2/sigmoid.  pooled: fp32 [N][n_parts][C] partial sums, mean = inv_cnt *

@@ -209,7 +209,7 @@ class DenseW:
         # mode 1: the whole W sits in LDS; mode 2: W does not fit, equal column slices over blockIdx.y (activations re-read per
         # slice, 8 waves per workgroup).  TDEED_WS_SLICED=1 sends mode-2 layers there at every row count
         mode = ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) if str(device) != "cpu" else 0
-        self.ws = mode == 1 or (mode == 2 and os.environ.get("TDEED_WS_SLICED", "0") == "1")
+        self.ws = mode == 1
         # The weight-stationary kernel was built for the narrow RegNetY-200MF layers (24 .. 152 channels), where it wins by
         # 20-35 %; on the 64- and 128-wide layers of the 800MF trunk the tiled kernel is the faster one
         # (tools/bench_ws_vs_gemm.py, us: 64x64 conv1 135 vs 152, conv3 190 vs 221; 128x128 conv3 101 vs 123; conv1 a tie)
@@ -449,22 +449,9 @@ def _se(pooled, inv_cnt, bw, gate):
     return ops.se_gate(pooled, inv_cnt, bw.se_w1t, bw.se_b1, bw.se_w2t, bw.se_b2, out=gate)
 
 
-SE_IN_CONV3 = os.environ.get("TDEED_SE_IN_CONV3", "0") == "1"
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
-# the gate-shift's apply step inside that launch: opt-in.  Dropping the eleven apply launches outright is worth +9 % (timing
-# experiment), but computed by the bottleneck's one workgroup per CU the step costs 14-18 us per launch against the 15-20 us
-# of the launch it removes (which runs 800 small workgroups at full occupancy): 4130-4184 vs 4156-4176 clips/s, a tie
-GS_APPLY_IN_BNECK = os.environ.get("TDEED_GS_APPLY_IN_BNECK", "0") == "1"
 C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
 C1_GCONV_MAX_CIN = int(os.environ.get("TDEED_C1_GCONV_MAX_CIN", "160"))
-# ... and the downsample shortcut out of the same launch: opt-in (bit-identical, measured slower on the same box: cfg2 3890 vs
-# 4048 clips/s, 800MF B=16 1454 vs 1543: the scattered 8-byte shortcut stores and 40 more registers cost more than the
-# strided contraction of its own)
-C1_GCONV_DS = os.environ.get("TDEED_C1_GCONV_DS", "0") == "1"
-# one graph per sub-batch stream (joined by events) instead of a fork inside one graph: opt-in.  A graph of trivial kernels
-# replays 4x faster per node that way (tools/bench_dispatch.py), the forward does not: 3670 vs 3696 clips/s with 4 hardware
-# queues, 2900 with 8 (more queues than the command processor keeps resident are time-multiplexed)
-GRAPH_SPLIT = os.environ.get("TDEED_GRAPH_SPLIT", "0") == "1"
 
 
 def _bneck_fused(bw, h, w, out_is_slice):
@@ -474,12 +461,6 @@ def _bneck_fused(bw, h, w, out_is_slice):
     return bool(BNECK_ONE_LAUNCH and getattr(bw, "fused", None) is not None and bw.se_mf is not None and blk.stride == 1
                 and not blk.has_downsample and blk.cin == blk.cout and not out_is_slice
                 and ops.bneck_fits(h, w, blk.cout, blk.se_rd))
-
-
-def _se_fused(bw, rows_per_frame, taps=()):
-    """True when conv3 of this block computes its SE gates itself (bf16, the tiled contraction, shape covered)."""
-    return bool(SE_IN_CONV3 and bw.se_mf is not None and not bw.w3.ws
-                and ops.gemm_se_fits(rows_per_frame, bw.spec.cout, bw.spec.se_rd))
 
 
 class Step:
@@ -738,7 +719,7 @@ class PackedWeights:
             bw.w1 = DenseW(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
             bw.w1_raw = _np(sd[c1 + ".conv.weight"]).reshape(blk.cout, blk.cin)
             bw.wd_raw = _np(sd[bp + ".downsample.conv.weight"]).reshape(blk.cout, blk.cin) if blk.has_downsample else None
-            bw.c1g_w1f = bw.c1g_wdf = None    # conv1 / downsample as MFMA fragments padded to whole channel slabs
+            bw.c1g_w1f = None    # conv1 / downsample as MFMA fragments padded to whole channel slabs
                                               # (tdeed_c1_gconv_fwd), packed on first use
             bw.s1, bw.h1 = bn_fold(c1 + ".bn")
             w2 = sd[bp + ".conv2.conv.weight"]                       # [C][gw][3][3]
@@ -872,8 +853,6 @@ class ForwardEngine:
             if c1g and bw.c1g_w1f is None:
                 rows_ = 16 * ops.c1_gconv_slab_tiles(h, w, blk.cout, blk.stride)
                 bw.c1g_w1f = pack_mfma_frags(bw.w1_raw, self.device, rows=rows_)
-                if blk.has_downsample:
-                    bw.c1g_wdf = pack_mfma_frags(bw.wd_raw, self.device, rows=rows_)
             # conv1 (optionally behind the gate-shift splice)
             y1 = None if (one_launch or c1g) else pool.take((N, h, w, blk.cout), dt)
             if blk.gsf_fold:
@@ -882,23 +861,16 @@ class ForwardEngine:
                 # the gate-shift launches read only channels [0, Fp): from the compact slice the previous block's conv3 wrote
                 # beside its output when there is one (a slice of the channels-last map drags whole cache lines)
                 xg = xs if (xs is not None and xs.shape[-1] == Fp) else x
-                # (opt-in) the module's apply step (fusion weights, gated shifts, blend) inside the one-launch bottleneck's load
-                # phase: the launch and the G tensor disappear
-                apply_in = bool(one_launch and GS_APPLY_IN_BNECK and bw.gs_cw1 is not None
-                                and ("_features." + blk.name + ".gs_out") not in taps)
                 gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
                           ysum=pool.take((N, F), torch.float32),
                           xsum=pool.take((N, F), torch.float32))
-                if not apply_in:
-                    gb["out"] = pool.take((M, Fp), dt)
-                    if bw.gs_cw1 is not None:
-                        gb["fw"] = pool.take((B, F, T), torch.float32)
-                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp, ai=apply_in: ops.gate_shift(
+                gb["out"] = pool.take((M, Fp), dt)
+                if bw.gs_cw1 is not None:
+                    gb["fw"] = pool.take((B, F, T), torch.float32)
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, gates_only=ai),
-                    (M * (2 * F + Fp) * es + M * 16) if not apply_in else (M * F * es + M * 16), 2 * M * F * 27))
-                gs_in = (dict(x=xg, Fp=Fp, F=F, T=T, gate=gb["gate"], ysum=gb["ysum"], xsum=gb["xsum"], cw1=bw.gs_cw1,
-                              cb1=bw.gs_cb1, cw2=bw.gs_cw2, cb2=bw.gs_cb2) if apply_in else None)
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf),
+                    M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                 if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
@@ -917,14 +889,12 @@ class ForwardEngine:
                 nxt = blocks[bi + 1].spec if bi + 1 < len(blocks) else None
                 xs_next = (pool.take((N, h, w, (nxt.gsf_fold + 7) // 8 * 8), dt)
                            if (nxt is not None and nxt.gsf_fold and GS_SLICE) else None)
-                gsd = gs_in if blk.gsf_fold else None
-                G = gb["out"] if (blk.gsf_fold and gsd is None) else None
-                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, gsd=gsd, out=out, xs_next=xs_next: ops.bneck(
+                G = gb["out"] if blk.gsf_fold else None
+                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, out=out, xs_next=xs_next: ops.bneck(
                     x, bw.fused.w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
-                    bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, gs=gsd, out=out,
+                    bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out,
                     out2=(xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None)),
-                    2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es
-                    + (3 * M * blk.gsf_fold * es if gsd is not None else 0),
+                    2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
                     2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
                 for t_ in gs_bufs:
                     pool.give(t_)
@@ -944,29 +914,19 @@ class ForwardEngine:
             parts = ops.gconv3x3_parts(h, w, blk.cout, s, dt) if bw.w2frag is not None else 1
             pooled = pool.take((N, parts, blk.cout), torch.float32)
             gate = pool.take((N, blk.cout), torch.float32)
-            sc_fused = None
             if c1g:
                 G = gb["out"] if blk.gsf_fold else None
-                if blk.has_downsample and C1_GCONV_DS:     # the shortcut conv reads the same x fragments: out of the same launch
-                    sc_fused = pool.take((N, h2, w2, blk.cout), dt)
-                steps.append(Step(blk.name + ".conv1_conv2", "c1_gconv", lambda x=x, bw=bw, blk=blk, G=G, y2=y2, pooled=pooled, sc_=sc_fused: ops.c1_gconv(
-                    x, bw.c1g_w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, blk.gw, blk.stride, blk.cout, G=G, out=y2, pooled=pooled,
-                    ds=((bw.c1g_wdf, bw.sd, bw.hd) if sc_ is not None else None), shortcut=sc_),
-                    (M * blk.cin + (2 if blk.has_downsample else 1) * M2 * blk.cout) * es + blk.cout * (2 * blk.cin + blk.gw * 9) * es,
-                    2 * M * blk.cin * blk.cout + 2 * M2 * blk.cout * (blk.gw * 9 + (blk.cin if blk.has_downsample else 0))))
+                steps.append(Step(blk.name + ".conv1_conv2", "c1_gconv", lambda x=x, bw=bw, blk=blk, G=G, y2=y2, pooled=pooled: ops.c1_gconv(
+                    x, bw.c1g_w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, blk.gw, blk.stride, blk.cout, G=G, out=y2, pooled=pooled),
+                    (M * blk.cin + M2 * blk.cout) * es + blk.cout * (blk.cin + blk.gw * 9) * es,
+                    2 * M * blk.cin * blk.cout + 2 * M2 * blk.cout * blk.gw * 9))
             else:
                 steps.append(Step(blk.name + ".conv2", "gconv3x3", lambda y1=y1, bw=bw, blk=blk, y2=y2, pooled=pooled: ops.gconv3x3(
                     y1, bw.w2, bw.s2, bw.h2, blk.gw, blk.stride, wfrag=bw.w2frag, out=y2, pooled=pooled),
                     (M + M2) * blk.cout * es + blk.cout * blk.gw * 9 * 4, 2 * M2 * blk.cout * blk.gw * 9))
-            # SE excitation inside conv3 (tdeed_gemm_se_fwd: every workgroup derives the gates of its tile's frames from the
-            # squeeze sums) where the tiled kernel serves conv3 and the shape is covered; a launch of its own otherwise
-            se_in_conv3 = _se_fused(bw, h2 * w2, taps)
-            if not se_in_conv3:
-                steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
-                    2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
-            if sc_fused is not None:
-                sc = sc_fused
-            elif blk.has_downsample:
+            steps.append(Step(blk.name + ".se", "se_gate", lambda pooled=pooled, bw=bw, gate=gate, ic=1.0 / (h2 * w2): _se(pooled, ic, bw, gate),
+                2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4, 4 * N * blk.cout * blk.se_rd))
+            if blk.has_downsample:
                 sc = pool.take((N, h2, w2, blk.cout), dt)
                 gather = (s, h, w, h2, w2) if s > 1 else None
                 steps.append(Step(blk.name + ".downsample", bw.wd.kern(M2), lambda x=x, bw=bw, sc=sc, gather=gather, M2=M2: bw.wd.run(
@@ -979,16 +939,9 @@ class ForwardEngine:
             xs_next = None
             if nxt is not None and nxt.gsf_fold and GS_SLICE:
                 xs_next = pool.take((N, h2, w2, (nxt.gsf_fold + 7) // 8 * 8), dt)
-            if se_in_conv3:
-                steps.append(Step(blk.name + ".conv3", "gemm", lambda y2=y2, bw=bw, pooled=pooled, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: ops.gemm_se(
-                    y2, bw.w3.w, hw2, pooled, 1.0 / hw2, bw.spec.se_rd, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
-                    bw.s3, bw.h3, ops.ACT_RELU, residual=sc, out=out, M=M2, out2=xs_next),
-                    gemm_cost(M2, blk.cout, blk.cout, es, True)[0] + 2 * N * blk.cout * 4 + 2 * blk.cout * blk.se_rd * 4,
-                    gemm_cost(M2, blk.cout, blk.cout, es, True)[1] + 4 * N * blk.cout * blk.se_rd))
-            else:
-                steps.append(Step(blk.name + ".conv3", bw.w3.kern(M2), lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: bw.w3.run(
-                    y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2, out2=xs_next),
-                    *gemm_cost(M2, blk.cout, blk.cout, es, True)))
+            steps.append(Step(blk.name + ".conv3", bw.w3.kern(M2), lambda y2=y2, bw=bw, gate=gate, sc=sc, out=out, M2=M2, hw2=h2 * w2, xs_next=xs_next: bw.w3.run(
+                y2, bw.s3, bw.h3, ops.ACT_RELU, residual=sc, a_scale=gate, a_scale_rows=hw2, out=out, M=M2, out2=xs_next),
+                *gemm_cost(M2, blk.cout, blk.cout, es, True)))
             # liveness: everything but `out` (and the next block's slice) dies here
             for t_ in ([y1] if y1 is not None else []) + [y2, pooled, gate] + gs_bufs + ([sc] if blk.has_downsample else []):
                 pool.give(t_)
@@ -1229,39 +1182,6 @@ class ForwardEngine:
                     gc.enable()
         return h
 
-    def _run_split(self, plan, st):
-        """Several sub-batches as SEPARATE single-chain graphs, one per stream, joined by events in front of the tail's graph.
-        A fork INSIDE one graph replays at ~3.7 us per TRIVIAL kernel node over both branches together
-        (tools/bench_dispatch.py: 256 nodes on two branches 960 us per replay), two single-chain graphs on two streams at 0.9 us
-        per node in aggregate.  With real kernels the dispatch hides behind the other stream's execution: measured a tie with
-        four hardware queues and a loss with eight, so this path is opt-in (TDEED_GRAPH_SPLIT=1)."""
-        streams = [st if (s_ is None or s_.cuda_stream == st.cuda_stream) else s_ for s_ in plan.streams]
-        if plan.graph is None:
-            _drain_dead_graphs()
-            self._launch_all(plan, st)         # warm-up launch (module load, validates arguments)
-            st.synchronize()
-            gs = []
-            for sb, s_ in zip(plan.subs, streams):
-                s_.synchronize()
-                with torch.cuda.stream(s_):
-                    gs.append(self._capture(s_, lambda sb=sb: [x.fn() for x in sb.steps]))
-            gt = self._capture(st, lambda: [x.fn() for x in plan.tail.steps]) if plan.tail is not None else None
-            plan.graph = SimpleNamespace(subs=gs, tail=gt, fork=torch.cuda.Event(),
-                                         joins=[torch.cuda.Event() for _ in streams])
-        g = plan.graph
-        g.fork.record(st)
-        for i, s_ in enumerate(streams):
-            if s_.cuda_stream != st.cuda_stream:
-                s_.wait_event(g.fork)
-            _lib.call("tdeed_graph_launch", g.subs[i], s_.cuda_stream)
-            if s_.cuda_stream != st.cuda_stream:
-                g.joins[i].record(s_)
-        for i, s_ in enumerate(streams):
-            if s_.cuda_stream != st.cuda_stream:
-                st.wait_event(g.joins[i])
-        if g.tail is not None:
-            _lib.call("tdeed_graph_launch", g.tail, st.cuda_stream)
-
     def run_plan(self, plan):
         """Launch the plan on the current stream (eager) or replay its HIP graph(s)."""
         st = torch.cuda.current_stream()
@@ -1270,9 +1190,6 @@ class ForwardEngine:
             return
         if st.cuda_stream == 0:
             raise RuntimeError("graph replay needs a non-default stream: wrap the call in torch.cuda.stream(s)")
-        if len(plan.subs) > 1 and GRAPH_SPLIT:
-            self._run_split(plan, st)
-            return
         if plan.graph is None:
             _drain_dead_graphs()
             self._launch_all(plan, st)         # warm-up launch (module load, validates arguments)
@@ -1328,10 +1245,7 @@ class ForwardEngine:
         try:
             for p in self._plans.values():
                 if p.graph is not None:
-                    if isinstance(p.graph, SimpleNamespace):
-                        _DEAD_GRAPHS.extend([g_ for g_ in list(p.graph.subs) + [p.graph.tail] if g_ is not None])
-                    else:
-                        _DEAD_GRAPHS.append(p.graph)
+                    _DEAD_GRAPHS.append(p.graph)
                     p.graph = None
         except Exception:
             pass

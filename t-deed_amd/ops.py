@@ -141,10 +141,9 @@ def c1_gconv_slab_tiles(Hi, Wi, C, stride):
     return _lib.load().tdeed_c1_gconv_slab_tiles(Hi, Wi, C, stride)
 
 
-def c1_gconv(x, w1f, s1, h1, wfrag, scale, shift, gw, stride, C, G=None, out=None, pooled=None, ds=None, shortcut=None):
+def c1_gconv(x, w1f, s1, h1, wfrag, scale, shift, gw, stride, C, G=None, out=None, pooled=None):
     """conv1 + grouped 3x3 of one bottleneck in one launch (tdeed_c1_gconv_fwd): x (N,Hi,Wi,Cin) bf16 -> y2 (N,Ho,Wo,C),
-    pooled (N, parts, C) squeeze partial sums.  G (N*Hi*Wi, Fp): gate-shift output spliced into conv1's operand.
-    ds = (wdf, sd, hd): also the block's downsample shortcut -> `shortcut` (N,Ho,Wo,C)."""
+    pooled (N, parts, C) squeeze partial sums.  G (N*Hi*Wi, Fp): gate-shift output spliced into conv1's operand."""
     _chk(x, "x", torch.bfloat16); _chk(G, "G", torch.bfloat16)
     N, Hi, Wi, Cin = x.shape
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
@@ -152,58 +151,25 @@ def c1_gconv(x, w1f, s1, h1, wfrag, scale, shift, gw, stride, C, G=None, out=Non
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     if pooled is None:
         pooled = torch.empty((N, gconv3x3_parts(Hi, Wi, C, stride, x.dtype), C), dtype=torch.float32, device=x.device)
-    if ds is not None and shortcut is None:
-        shortcut = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
-    wdf, sd, hd = ds if ds is not None else (None, None, None)
     call("tdeed_c1_gconv_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else 0), N, Hi, Wi, Cin, C, gw, stride, ptr(w1f),
-         ptr(s1), ptr(h1), ptr(wdf), ptr(sd), ptr(hd), ptr(shortcut), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), ptr(pooled),
-         stream_ptr())
-    return (out, pooled, shortcut) if ds is not None else (out, pooled)
+         ptr(s1), ptr(h1), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), ptr(pooled), stream_ptr())
+    return out, pooled
 
 
 def bneck_fits(h, w, C, R):
     return _lib.load().tdeed_bneck_fits(h, w, C, R) != 0
 
 
-def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, G=None, out=None, out2=None, gs=None):
+def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, G=None, out=None, out2=None):
     """Whole stride-1 bottleneck in one launch (tdeed_bneck_fwd): x (N,h,w,C) bf16 -> (N,h,w,C); G (N*h*w, Fp): gate-shift
-    output spliced into conv1's operand; out2 (N*h*w, n2): compact copy of the first n2 output channels.
-    gs = dict(x=slice source (N,h,w,ldx), Fp, F, T, gate, ysum, xsum, cw1, cb1, cw2, cb2): the gate-shift APPLY step runs
-    inside the launch instead of producing G (gate / ysum / xsum from gate_shift_gates())."""
+    output spliced into conv1's operand; out2 (N*h*w, n2): compact copy of the first n2 output channels."""
     _chk(x, "x", torch.bfloat16); _chk(G, "G", torch.bfloat16); _chk(out2, "out2", torch.bfloat16)
     N, h, w, C = x.shape
     if out is None:
         out = torch.empty_like(x)
-    g = gs or {}
-    if gs is not None:
-        _chk(g["x"], "gs.x", torch.bfloat16)
-        if G is not None:
-            raise ValueError("bneck: either G or gs")
-    call("tdeed_bneck_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else g.get("Fp", 0)), N, h, w, C, ptr(w1f), ptr(s1),
+    call("tdeed_bneck_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else 0), N, h, w, C, ptr(w1f), ptr(s1),
          ptr(h1), ptr(w2f), ptr(s2), ptr(h2), ptr(se_w1f), ptr(se_b1), ptr(se_w2f), ptr(se_b2), R, ptr(w3f), ptr(s3), ptr(h3),
-         ptr(out), ptr(out2), (out2.shape[-1] if out2 is not None else 0),
-         ptr(g.get("x")), (g["x"].shape[-1] if gs is not None else 0), ptr(g.get("gate")), ptr(g.get("ysum")), ptr(g.get("xsum")),
-         ptr(g.get("cw1")), ptr(g.get("cb1")), ptr(g.get("cw2")), ptr(g.get("cb2")), g.get("T", 0), g.get("F", 0), stream_ptr())
-    return out
-
-
-def gemm_se_fits(rows_per_frame, K, R):
-    return _lib.load().tdeed_gemm_se_fits(rows_per_frame, K, R) != 0
-
-
-def gemm_se(A, W, rows_per_frame, pooled, inv_cnt, R, w1f, b1, w2f, b2, scale=None, shift=None, act=ACT_NONE, residual=None,
-            out=None, M=None, out2=None, gate_out=None):
-    """conv3 with the SE excitation inside (tdeed_gemm_se_fwd): C = act(((A * gate[frame]) @ W^T) * scale + shift + residual),
-    gate = sigmoid(fc2 relu(fc1 mean)) from pooled (frames, parts, K) squeeze sums.  bf16."""
-    _chk(A, "A", torch.bfloat16); _chk(W, "W", torch.bfloat16); _chk(pooled, "pooled", torch.float32)
-    N, K = W.shape
-    if M is None:
-        M = A.numel() // A.shape[-1]
-    if out is None:
-        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
-    call("tdeed_gemm_se_fwd", ptr(A), A.shape[-1], rows_per_frame, ptr(pooled), pooled.shape[1], float(inv_cnt), R, ptr(w1f),
-         ptr(b1), ptr(w2f), ptr(b2), ptr(gate_out), M, K, N, ptr(W), W.shape[1], ptr(scale), ptr(shift), ptr(residual),
-         (residual.shape[-1] if residual is not None else 0), act, ptr(out), N, *_out2(out2, A), stream_ptr())
+         ptr(out), ptr(out2), (out2.shape[-1] if out2 is not None else 0), stream_ptr())
     return out
 
 
@@ -373,7 +339,7 @@ def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
 
 
 def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
-               bufs=None, wqf=None, separate_weight=False, gates_only=False):
+               bufs=None, wqf=None, separate_weight=False):
     """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
     GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out."""
     _chk(x, "x")
@@ -390,7 +356,7 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     if xsum is None:
         xsum = torch.empty((N, F), dtype=torch.float32, device=dev)
     out = bufs.get("out")
-    if out is None and not gates_only:
+    if out is None:
         out = torch.empty((N * h * w, Fp), dtype=x.dtype, device=dev)
     q = bufs.get("q")
     if q is None:
@@ -398,8 +364,6 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     dc = dtype_code(x.dtype)
     call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
          ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
-    if gates_only:          # the apply step runs elsewhere (inside tdeed_bneck_fwd): gate / ysum / xsum are the result
-        return None
     if cw1 is not None and not separate_weight:
         call("tdeed_gsf_apply_fused_fwd", ptr(x), ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
              B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())

@@ -88,7 +88,9 @@ def test_forward_bf16_close_to_reference(name):
     ref = t(g["logits"])
     err = (head[..., :K1] - ref).abs().max().item()
     scale = ref.abs().max().item()
-    assert err < 0.08 * max(1.0, scale), (err, scale)
+    # measured 7.6e-2 on the FineDiving_small golden clip (logit range +-4.5): tools/diag_bf16_split.py attributes 4.6e-2 to
+    # the trunk alone and 5.1e-2 to the temporal stage alone; the reference's own CPU bf16 autocast is 4.5e-2 off
+    assert err < 0.1, (err, scale)
     assert (head[..., :K1].argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
 
 

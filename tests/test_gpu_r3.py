@@ -287,53 +287,6 @@ def test_concat_fc_fold_per_clip_and_channels():
     assert torch.allclose(chs[..., 1], (of * of).sum(1), rtol=1e-5, atol=1e-3)
 
 
-# ------------------------------------------------------------------------------------ SE excitation inside conv3
-@pytest.mark.parametrize("hw,C,R,parts,N", [(49, 368, 92, 1, 37), (49, 368, 38, 1, 8), (196, 152, 38, 3, 5), (25, 320, 80, 1, 19),
-                                            (784, 128, 16, 2, 3), (9, 56, 6, 1, 40)])
-def test_conv3_with_the_se_excitation_inside_equals_se_gate_then_conv3(hw, C, R, parts, N):
-    """tdeed_gemm_se_fwd (every workgroup derives the gates of its row tile's frames from conv2's squeeze sums) against the
-    two launches it replaces, tdeed_se_gate_mfma_fwd + tdeed_gemm_fwd(a_scale=gate): gates to fp32 rounding (bitwise for one
-    partial row), conv3 output bitwise then; and both against the SE arithmetic in torch fp32 (timm SEModule: mean ->
-    fc1 -> ReLU -> fc2 -> sigmoid)."""
-    from tdeed_amd import ops
-    from tdeed_amd.engine import pack_se_mfma
-    assert ops.gemm_se_fits(hw, C, R) and ops.se_gate_mfma_fits(C, R)
-    g = torch.Generator().manual_seed(hw * 1000 + C + R)
-    M = N * hw
-    y2 = (torch.randn(M, C, generator=g)).to(torch.bfloat16).to(DEV)
-    res = (torch.randn(M, C, generator=g)).to(torch.bfloat16).to(DEV)
-    W = (torch.randn(C, C, generator=g) / C ** 0.5).to(torch.bfloat16).to(DEV)
-    sc = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    sh = (torch.randn(C, generator=g) * 0.1).to(DEV)
-    pooled = (torch.randn(N, parts, C, generator=g) * hw / parts + 0.3 * hw / parts).to(DEV)
-    fc1 = torch.randn(R, C, generator=g) / C ** 0.5
-    fc2 = torch.randn(C, R, generator=g) / R ** 0.5
-    b1 = (torch.randn(R, generator=g) * 0.1).to(DEV)
-    b2 = (torch.randn(C, generator=g) * 0.1).to(DEV)
-    pk = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
-    gate_ref = ops.se_gate_mfma(pooled, 1.0 / hw, pk["w1f"], b1, pk["w2f"], b2, R)
-    out_ref = ops.gemm(y2, W, sc, sh, ops.ACT_RELU, residual=res, a_scale=gate_ref, a_scale_rows=hw)
-    gate = torch.full((N, C), float("nan"), device=DEV)
-    n2 = 16 if C >= 16 else 8
-    out2 = torch.empty((M, n2), dtype=torch.bfloat16, device=DEV)
-    out = ops.gemm_se(y2, W, hw, pooled, 1.0 / hw, R, pk["w1f"], b1, pk["w2f"], b2, sc, sh, ops.ACT_RELU, residual=res,
-                      gate_out=gate, out2=out2)
-    torch.cuda.synchronize()
-    assert torch.isfinite(gate).all()
-    if parts == 1:
-        assert torch.equal(gate, gate_ref)
-        assert torch.equal(out, out_ref)
-    else:
-        assert torch.allclose(gate, gate_ref, rtol=1e-5, atol=1e-6)
-        d = (out.float() - out_ref.float()).abs()
-        assert float(d.max()) <= 2 ** -6 * float(out_ref.float().abs().max())
-    assert torch.equal(out2, out[:, :n2].contiguous())
-    mean = pooled.sum(1).cpu() / hw
-    gt = torch.sigmoid(torch.relu(mean @ fc1.to(torch.bfloat16).float().t() + b1.cpu()) @ fc2.to(torch.bfloat16).float().t()
-                       + b2.cpu())
-    assert torch.allclose(gate.cpu(), gt, atol=2e-4, rtol=1e-4)
-
-
 @pytest.mark.parametrize("M,K,N,hw", [(70000 - 70000 % 196, 320, 320, 196), (60025, 320, 768, 49), (61152, 368, 368, 49)])
 def test_sliced_weight_stationary_contraction_of_the_wide_layers(M, K, N, hw):
     """gemm_ws with W cut into equal column slices (8 waves per workgroup; what engine.DenseW picks for the 320-wide layers of
@@ -474,8 +427,7 @@ def test_debug_flavour_runs_the_hot_path_without_a_trap():
                                                        (15, 13, 24, 56, 8, 2, 0, 2)])
 def test_conv1_in_front_of_the_grouped_conv_equals_the_two_launches(H, W, Cin, C, gw, stride, Fp, N):
     """tdeed_c1_gconv_fwd (the y1 band computed in LDS from the block input) against conv1 (tdeed_gemm_fwd with the gate-shift
-    splice) followed by tdeed_gconv3x3_fwd: output rows and squeeze partial sums bitwise; with the downsample shortcut out of
-    the same launch against the strided contraction of its own (timm Bottleneck.downsample)."""
+    splice) followed by tdeed_gconv3x3_fwd: output rows and squeeze partial sums bitwise."""
     from tdeed_amd import ops
     from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags
     assert ops.c1_gconv_fits(H, W, Cin, C, stride)
@@ -496,17 +448,6 @@ def test_conv1_in_front_of_the_grouped_conv_equals_the_two_launches(H, W, Cin, C
     torch.cuda.synchronize()
     assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
     assert torch.equal(pooled, pref)
-    # + the downsample shortcut
-    Wd = torch.randn(C, Cin, generator=g) / Cin ** 0.5
-    sd_, hd_ = vec(C, 0.1, 1.0), vec(C)
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    sref = ops.gemm(x, Wd.to(torch.bfloat16).to(DEV), sd_, hd_, ops.ACT_NONE,
-                    gather=(stride, H, W, Ho, Wo) if stride > 1 else None)
-    out2, pooled2, sc = ops.c1_gconv(x, w1f, s1, h1, w2f, s2, h2, gw, stride, C, G=G,
-                                     ds=(pack_mfma_frags(Wd.numpy(), DEV, rows=tiles * 16), sd_, hd_))
-    torch.cuda.synchronize()
-    assert torch.equal(out2, ref) and torch.equal(pooled2, pref)
-    assert torch.equal(sc.view(-1, C), sref.view(-1, C)), float((sc.view(-1, C).float() - sref.view(-1, C).float()).abs().max())
 
 
 @pytest.mark.parametrize("M", [196 * 7, 196 * 40 + 0, 64 * 3 + 17])
@@ -534,50 +475,6 @@ def test_register_stationary_contraction_equals_the_tiled_one(M):
         got = ops.gemm_rs(A, Wf, K, N, sc, sh, ops.ACT_RELU, out2=o2b, **kw)
         torch.cuda.synchronize()
         assert torch.equal(got, ref) and torch.equal(o2a, o2b), (list(kw), float((got.float() - ref.float()).abs().max()))
-
-
-@pytest.mark.parametrize("h,w,C,F,B,T,compact", [(7, 7, 368, 92, 2, 7, True), (14, 14, 152, 40, 1, 5, True),
-                                                  (7, 7, 368, 92, 1, 6, False), (5, 5, 152, 36, 3, 4, True)])
-def test_gate_shift_apply_inside_the_one_launch_bottleneck(h, w, C, F, B, T, compact):
-    """tdeed_bneck_fwd with the gate-shift-fuse APPLY step in its load phase (impl/gsf.py:66-93: fusion weights from the
-    per-frame spatial sums, gated temporal shifts, blend) against the launch it replaces (tdeed_gsf_apply_fused_fwd producing
-    G, spliced by the same bottleneck launch): bitwise -- clips of odd and even length (a workgroup's two frames may belong to
-    different clips), slice read from the compact copy or from the block input itself."""
-    from tdeed_amd import ops
-    from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma
-    g = torch.Generator().manual_seed(h * 100 + C + F + T)
-    N, hw = B * T, h * w
-    M = N * hw
-    Fp = (F + 7) // 8 * 8
-    R, gw = (92 if C == 368 else 38), 8
-    assert ops.bneck_fits(h, w, C, R)
-    x = torch.relu(torch.randn(N, h, w, C, generator=g)).to(torch.bfloat16).to(DEV)
-    xs = x[..., :Fp].contiguous() if compact else x
-    vec = lambda n, s=0.1, o=0.0: (torch.randn(n, generator=g) * s + o).to(DEV)          # noqa: E731
-    # gate-shift module parameters (BatchNorm3d folded, conv3D 2 x F/2 x 3x3x3, fusion convs 2 -> 1 x 3x3)
-    bn_s, bn_h = vec(F, 0.1, 1.0), vec(F)
-    w3d = torch.randn(2, F // 2, 3, 3, 3, generator=g) * 0.2
-    wq = w3d.reshape(F, 27).t().contiguous().to(DEV)
-    b3d = vec(2)
-    cw1, cw2, cb1, cb2 = vec(18, 0.5), vec(18, 0.5), vec(1), vec(1)
-    bufs = dict(gate=torch.empty((N, h, w, 2), device=DEV), q=torch.empty((N, h, w, 6), device=DEV),
-                ysum=torch.empty((N, F), device=DEV), xsum=torch.empty((N, F), device=DEV),
-                out=torch.empty((M, Fp), dtype=torch.bfloat16, device=DEV))
-    G = ops.gate_shift(xs, B, T, F, Fp, bn_s, bn_h, wq, b3d, cw1, cb1, cw2, cb2, bufs=bufs)
-    W1, W3 = torch.randn(C, C, generator=g) / C ** 0.5, torch.randn(C, C, generator=g) / C ** 0.5
-    W2 = torch.randn(C, gw, 3, 3, generator=g) / (gw * 9) ** 0.5
-    fc1, fc2 = torch.randn(R, C, generator=g) / C ** 0.5, torch.randn(C, R, generator=g) / R ** 0.5
-    s1, h1, s2, h2, s3, h3, b1, b2 = vec(C, .1, 1.), vec(C), vec(C, .1, 1.), vec(C), vec(C, .1, .5), vec(C), vec(R), vec(C)
-    w1f, w3f = pack_mfma_frags(W1.numpy(), DEV), pack_mfma_frags(W3.numpy(), DEV)
-    w2f = pack_gconv_frags(W2.numpy(), gw, DEV)
-    se = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
-    args = (w1f, s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R, w3f, s3, h3)
-    ref = ops.bneck(x, *args, G=G)
-    got = ops.bneck(x, *args, gs=dict(x=xs, Fp=Fp, F=F, T=T, gate=bufs["gate"], ysum=bufs["ysum"], xsum=bufs["xsum"],
-                                      cw1=cw1, cb1=cb1, cw2=cw2, cb2=cb2))
-    torch.cuda.synchronize()
-    assert torch.isfinite(got.float()).all()
-    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
 
 
 @pytest.mark.parametrize("env", [{"TDEED_FRONT_ROLL": "5"}, {"TDEED_FRONT_PIPE": "0"}, {"TDEED_FRONT_PIPE": "0", "TDEED_FRONT_ROLL": "3"},

@@ -68,8 +68,14 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
     fused(); torch.cuda.synchronize()
     _lib.call("tdeed_bneck_set_debug", None)
     d = dbg.cpu().numpy().astype(np.float64)
-    sub = [np.median(d[:, 8] - d[:, 2])] + [np.median(d[:, 9 + j] - d[:, 8 + j]) for j in range(3)]
-    print("   conv2 of wave 0, cycles: tap offsets + weight requests %.0f, units %s" % (sub[0], ", ".join("%.0f" % v for v in sub[1:])))
+    # slots 8..11: wave 0's conv2 unit stamps; a form whose wave 0 owns fewer than three units leaves the later slots
+    # unwritten (zero): only differences between two written stamps are reported
+    def gap(a, b):
+        ok = (d[:, a] > 0) & (d[:, b] > 0)
+        return float(np.median(d[ok, b] - d[ok, a])) if ok.any() else None
+    sub = [gap(2, 8)] + [gap(8 + j, 9 + j) for j in range(3)]
+    print("   conv2 of wave 0, cycles: tap offsets + weight requests %s, units %s"
+          % ("%.0f" % sub[0] if sub[0] is not None else "-", ", ".join("%.0f" % v for v in sub[1:] if v is not None)))
     ph = np.diff(d[:, :7], axis=1) / 100.0          # clock64 ticks (shader clock, ~2.4 GHz) / 100
     names = ["load x", "conv1", "conv2", "SE + gate", "conv3", "store"]
     print("   phase cycles / 100 (median over workgroups): " + ", ".join(f"{n} {np.median(ph[:, i]):.2f}" for i, n in enumerate(names))
