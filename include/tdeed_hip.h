@@ -475,6 +475,19 @@ int tdeed_se_train_bwd(const float* d_gate, const float* gate, const float* hid,
  * relu(in_a[c] * x + in_b[c]) (x a raw conv output: BatchNorm + ReLU applied on load) */
 int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_scale, int N, int hw, int C,
                      const float* in_a, const float* in_b, void* y, int dtype, void* stream);
+/* conv1's BatchNorm backward with the statistics from conv2's input-gradient launch (stride-1 bottlenecks, bf16):
+ *   tdeed_gconv3x3_dgrad_stats: dx [N][Hi][Wi][C] = grouped 3x3 conv of dy with the flipped / transposed weights (wfrag_t,
+ *     packed like tdeed_gconv3x3_fwd's wfrag; one / zero: fp32 [C] ones / zeros), and part_s / part_q fp32
+ *     [N][tdeed_gconv3x3_parts(Hi, Wi, C, 1)][C]: per (frame, band) sums of g and g * (bz - bmean), g = dx * [bfa bz + bfb > 0]
+ *     (bz: conv1's raw output, bfa / bfb its BatchNorm affine, bmean its batch mean);
+ *   tdeed_bn_bwd_masked_from_parts: folds such partial rows (P rows, pstride floats apart) into sums fp32 [2][C]
+ *     (d bias, d weight) and runs the apply pass dz = k1 g + k2 z + k3 with the ReLU mask recomputed from z. */
+int tdeed_gconv3x3_dgrad_stats(const void* dy, int N, int Hi, int Wi, int C, int gw, const void* wfrag_t, const float* one,
+                               const float* zero, void* dx, const void* bz, const float* bfa, const float* bfb,
+                               const float* bmean, float* part_s, float* part_q, void* stream);
+int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C, const float* mean, const float* rstd,
+                                   const float* w, const float* fa, const float* fb, const float* part_s, const float* part_q,
+                                   long pstride, int P, float* sums, void* dz, int dtype, void* stream);
 /* SE + conv2-BatchNorm backward of a bottleneck without the d_y2 map (csrc/trunk_bwd2.hip; timm SEModule / BatchNorm2d under
  * autograd, /root/reference/model/model.py:265-324).  d = d(y2 * gate) [N][hw][C] (conv3's input gradient), z = conv2's raw
  * output, y2 = relu(fa * z + fb):

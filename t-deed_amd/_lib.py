@@ -76,6 +76,8 @@ _SIGS = {
     "tdeed_se_train_fwd": ([P, c_int, c_int, c_int, P, P, P, P, P, P, P], c_int),
     "tdeed_se_train_bwd": ([P, P, P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_scale_rows": ([P, P, P, c_float, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
+    "tdeed_gconv3x3_dgrad_stats": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P], c_int),
+    "tdeed_bn_bwd_masked_from_parts": ([P, P, c_long, c_int, P, P, P, P, P, P, P, c_long, c_int, P, P, c_int, P], c_int),
     "tdeed_se_bn_bwd_sums": ([P, P, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_se_bn_bwd_finalize": ([P, P, P, c_int, c_int, c_int, P, P, P], c_int),
     "tdeed_se_bn_bwd_apply": ([P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),

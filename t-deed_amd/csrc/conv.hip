@@ -234,13 +234,20 @@ static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
 // The grouped 3x3 itself, from a zero-haloed band of the (post-BN-ReLU) input in LDS: implicit GEMM per 16-channel unit,
 // BatchNorm (+ ReLU), output rows, SE squeeze partial sums (and sums of squares in training).  Shared by the kernel that
 // stages the band from a stored map and by the one that computes it (conv1 in front, c1_gconv_mfma_kernel).
+// Training backward (the stride-1 input gradient of conv2 is this kernel with flipped / transposed weights): when the output
+// d_y1 arrives at conv1's BatchNorm + ReLU, that BatchNorm's backward needs sum g and sum g * (z1 - mean) with g = d_y1 masked by
+// [fa z1 + fb > 0].  With `bz` given the per-(frame, band) partial rows `pooled` / `pooled_sq` hold exactly those sums (the
+// stored output stays unmasked): the statistics pass over (d_y1, z1) disappears, z1 is read here once, 8 bytes per lane and tile.
+struct GcStat {
+  const bf16_t* z; const float* fa; const float* fb; const float* mean;
+};
 template <int STRIDE>
 __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float (*red)[16], float (*redq)[16], int Wi, int C,
                                                const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
                                                const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                float* __restrict__ pooled, float* __restrict__ pooled_sq, int Ho, int Wo,
                                                int nbands, int CSP, int PS, int relu, int n, int bnd, int slab, int oy0,
-                                               int nrows_out) {
+                                               int nrows_out, const GcStat bst = GcStat{nullptr, nullptr, nullptr, nullptr}) {
   const int WP = Wi + 2;
   const int cs0 = slab * CSP;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -271,9 +278,20 @@ __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float 
     psum[r] = 0.f;
     psq[r] = 0.f;
   }
+  float bfa[4], bfb[4], bmu[4];
+  if (bst.z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = min(ch0 + r, C - 1);
+      bfa[r] = bst.fa[c];
+      bfb[r] = bst.fb[c];
+      bmu[r] = bst.mean[c];
+    }
+  }
   const int npix = nrows_out * Wo;
   const int ntiles = (npix + 15) >> 4;
   bf16_t* yout = y + ((long)n * Ho + oy0) * Wo * C;
+  const bf16_t* zin = bst.z ? bst.z + ((long)n * Ho + oy0) * Wo * C : nullptr;
   const IDiv dwo(Wo);
   for (int mt = wv / units; mt < ntiles; mt += mstep) {
     const int p = mt * 16 + pl;
@@ -282,6 +300,8 @@ __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float 
     int oyl, ox;
     dwo.divmod(pc, oyl, ox);
     const unsigned char* base = tile + ((long)(oyl * STRIDE) * WP + ox * STRIDE) * PS;
+    bf16x4 z4 = {};
+    if (zin) z4 = *reinterpret_cast<const bf16x4*>(zin + (long)pc * C + min(ch0, C - 4));   // travels under the MFMA chain
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
@@ -294,8 +314,15 @@ __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float 
       for (int r = 0; r < 4; ++r) {
         const float v = relu ? fmaxf(acc[r] * sc[r] + sh[r], 0.f) : acc[r] * sc[r] + sh[r];
         o[r] = (bf16_t)v;
-        psum[r] += (float)o[r];
-        psq[r] = fmaf((float)o[r], (float)o[r], psq[r]);
+        if (zin) {
+          const float zv = (float)z4[r];
+          const float g = fmaf(zv, bfa[r], bfb[r]) > 0.f ? (float)o[r] : 0.f;
+          psum[r] += g;
+          psq[r] = fmaf(g, zv - bmu[r], psq[r]);
+        } else {
+          psum[r] += (float)o[r];
+          psq[r] = fmaf((float)o[r], (float)o[r], psq[r]);
+        }
       }
       *reinterpret_cast<bf16x4*>(yout + (long)pc * C + ch0) = o;
     }
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ y, float* __restrict__ pooled,
                                                             float* __restrict__ pooled_sq,
                                                             int Ho, int Wo, int band, int nbands, int CSP, int PS,
-                                                            int rows_in, int relu) {
+                                                            int rows_in, int relu, const GcStat bst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   __shared__ float red[4][16];
   __shared__ float redq[4][16];
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   }
   __syncthreads();
   gconv_band_mma<STRIDE>(tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, pooled_sq, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
-                         slab, oy0, nrows_out);
+                         slab, oy0, nrows_out, bst);
 }
 
 // conv1 (1x1 + BN + ReLU, optionally behind the gate-shift splice) IN FRONT of the grouped 3x3 of the same bottleneck, one
@@ -534,10 +561,30 @@ extern "C" int tdeed_gconv3x3_parts(int Hi, int Wi, int C, int stride, int dtype
   return g.band > 0 ? g.nbands : 1;
 }
 
+static int gconv3x3_launch(const void* x, int N, int Hi, int Wi, int C, int gw, int stride, const float* w, const void* wfrag,
+                           const float* scale, const float* shift, void* y, float* pooled, float* pooled_sq, const float* in_a,
+                           const float* in_b, int relu, int dtype, void* stream, const GcStat bst);
 extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, int gw, int stride,
                                   const float* w, const void* wfrag, const float* scale, const float* shift,
                                   void* y, float* pooled, float* pooled_sq, const float* in_a, const float* in_b, int relu,
                                   int dtype, void* stream) {
+  return gconv3x3_launch(x, N, Hi, Wi, C, gw, stride, w, wfrag, scale, shift, y, pooled, pooled_sq, in_a, in_b, relu, dtype,
+                         stream, GcStat{nullptr, nullptr, nullptr, nullptr});
+}
+// Stride-1 input gradient of a training bottleneck's conv2 (a grouped conv of dy with the flipped / transposed weights, wfrag_t)
+// that also leaves the statistics of conv1's BatchNorm backward: part_s / part_q fp32 [N][tdeed_gconv3x3_parts()][C] = per
+// (frame, band) sums of g and g * (bz - bmean), g = dx masked by [bfa * bz + bfb > 0]  (bz: conv1's raw output, like dx).  bf16.
+extern "C" int tdeed_gconv3x3_dgrad_stats(const void* dy, int N, int Hi, int Wi, int C, int gw, const void* wfrag_t,
+                                          const float* one, const float* zero, void* dx, const void* bz, const float* bfa,
+                                          const float* bfb, const float* bmean, float* part_s, float* part_q, void* stream) {
+  TD_CHECK(bz && bfa && bfb && bmean && part_s && part_q && wfrag_t && one && zero, "gconv3x3_dgrad_stats: null pointer");
+  TD_CHECK(tdeed_gconv3x3_mfma_fits(Hi, Wi, C, 1), "gconv3x3_dgrad_stats: %dx%dx%d is not served by the MFMA kernel", Hi, Wi, C);
+  return gconv3x3_launch(dy, N, Hi, Wi, C, gw, 1, nullptr, wfrag_t, one, zero, dx, part_s, part_q, nullptr, nullptr, 0,
+                         TDEED_BF16, stream, GcStat{(const bf16_t*)bz, bfa, bfb, bmean});
+}
+static int gconv3x3_launch(const void* x, int N, int Hi, int Wi, int C, int gw, int stride, const float* w, const void* wfrag,
+                           const float* scale, const float* shift, void* y, float* pooled, float* pooled_sq, const float* in_a,
+                           const float* in_b, int relu, int dtype, void* stream, const GcStat bst) {
   TD_CHECK(x && scale && shift && y && pooled, "gconv3x3: null pointer");
   TD_CHECK(!in_a == !in_b, "gconv3x3: in_a and in_b come together");
   TD_CHECK(!in_a || (dtype == TDEED_BF16 && wfrag), "gconv3x3: the on-load input affine exists in the bf16 MFMA kernel only");
@@ -565,7 +612,7 @@ extern "C" int tdeed_gconv3x3_fwd(const void* x, int N, int Hi, int Wi, int C, i
 #define TD_GCF(Sv, Av)                                                                                                   \
   hipLaunchKernelGGL((gconv3x3_mfma_kernel<Sv, Av>), grid, dim3(256), smem, st, (const bf16_t*)x, Hi, Wi, C, in_a, in_b,      \
                      (const bf16x8*)wfrag, scale, shift, (bf16_t*)y, pooled, pooled_sq, Ho, Wo, g.band, g.nbands, g.CSP, g.PS, \
-                     g.rows_in, relu)
+                     g.rows_in, relu, bst)
     if (stride == 1) { if (in_a) TD_GCF(1, true); else TD_GCF(1, false); }
     else { if (in_a) TD_GCF(2, true); else TD_GCF(2, false); }
 #undef TD_GCF

@@ -435,6 +435,71 @@ extern "C" int tdeed_bn_train_bwd(const void* z, const void* dy, const void* y, 
   return TDEED_OK;
 }
 
+// The same backward when the PRODUCER of dy has already left the masked column sums (tdeed_gconv3x3_dgrad_stats: conv2's
+// input gradient arriving at conv1's BatchNorm + ReLU): part_s / part_q hold P rows (pstride floats apart) of per-channel
+// sum g and sum g * (z - mean); they are folded here (x rstd for the second), then only the apply pass runs.
+__global__ __launch_bounds__(256) void bn_sums_from_parts_kernel(const float* __restrict__ part_s, const float* __restrict__ part_q,
+                                                                long pstride, int P, int C, const float* __restrict__ rstd,
+                                                                float* __restrict__ sums) {
+  __shared__ double r1[32][9], r2[32][9];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p0 = pl; p0 < P; p0 += 8 * 32) {
+    float v1[8], v2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long p = min(p0 + u * 32, P - 1);
+      v1[u] = part_s[p * pstride + c];
+      v2[u] = part_q[p * pstride + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u * 32 < P) {
+        s1 += (double)v1[u];
+        s2 += (double)v2[u];
+      }
+  }
+  r1[pl][cl] = s1;
+  r2[pl][cl] = s2;
+  __syncthreads();
+  if (pl != 0) return;
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int i = 0; i < 32; ++i) {
+    s1 += r1[i][cl];
+    s2 += r2[i][cl];
+  }
+  sums[c] = (float)s1;
+  sums[C + c] = (float)(s2 * (double)rstd[c]);
+}
+
+extern "C" int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C, const float* mean, const float* rstd,
+                                              const float* w, const float* fa, const float* fb, const float* part_s,
+                                              const float* part_q, long pstride, int P, float* sums, void* dz, int dtype,
+                                              void* stream) {
+  TD_CHECK(z && dy && mean && rstd && w && fa && fb && part_s && part_q && sums && dz, "bn_bwd_masked_from_parts: null pointer");
+  TD_CHECK(M > 0 && C > 0 && C % 8 == 0 && P > 0 && pstride >= C, "bn_bwd_masked_from_parts: bad sizes");
+  TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "bn_bwd_masked_from_parts: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_sums_from_parts_kernel, dim3(C / 8), dim3(256), 0, st, part_s, part_q, pstride, P, C, rstd, sums);
+  TD_LAUNCH_CHECK("bn_sums_from_parts");
+  const float inv_M = 1.0f / (float)M;
+  const int nch = C / (dtype == TDEED_F32 ? 4 : 8);
+  TD_CHECK(nch <= 256, "bn_bwd_masked_from_parts: C=%d too wide", C);
+  const int rpw = rows_per_wg(nch);
+  const long nwg = (M + rpw - 1) / rpw;
+  TD_CHECK(nwg < 0x7fffffffL, "bn_bwd_masked_from_parts: too many rows");
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)z, (const float*)dy,
+                       (const float*)nullptr, 1, mean, rstd, w, sums, fa, fb, inv_M, (float*)dz, (float*)nullptr, M, nch, rpw);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dy,
+                       (const bf16_t*)nullptr, 1, mean, rstd, w, sums, fa, fb, inv_M, (bf16_t*)dz, (bf16_t*)nullptr, M, nch, rpw);
+  TD_LAUNCH_CHECK("bn_bwd_apply");
+  return TDEED_OK;
+}
+
 // =========================================================================== SE (training): squeeze, excitation, scale
 // mean over the hw pixels of a frame: x [N][hw][C] -> p [N][C] fp32 (lanes = (pixel slice, channel chunk), batched loads)
 // aff_on = 1 / 2: x / x2 is a raw conv output and relu(in_a[c] * . + in_b[c]) is applied on load (the post-BN map is not

@@ -277,6 +277,33 @@ def se_bn_bwd(d, z, bn, w, gate, hid, se_w1, se_w2):
     return dz, st[1], st[0], d_pre2, d_hid
 
 
+def gconv3x3_dgrad_stats(dy, wfrag_t, one, zero, gw, z1, bn1):
+    """Stride-1 input gradient of conv2 (MFMA kernel, flipped / transposed weights) that also leaves the column sums of
+    conv1's BatchNorm backward (tdeed_gconv3x3_dgrad_stats).  z1: conv1's raw output, bn1 = (mean, rstd, a, b).
+    -> (d_y1, (part_s, part_q, row stride, rows))"""
+    from . import ops
+    N, Hi, Wi, C = dy.shape
+    parts = ops.gconv3x3_parts(Hi, Wi, C, 1, dy.dtype)
+    dx = torch.empty_like(dy)
+    ps, pq = _f32((N, parts, C), dy.device), _f32((N, parts, C), dy.device)
+    call("tdeed_gconv3x3_dgrad_stats", ptr(dy), N, Hi, Wi, C, gw, ptr(wfrag_t), ptr(one), ptr(zero), ptr(dx), ptr(z1), ptr(bn1[2]),
+         ptr(bn1[3]), ptr(bn1[0]), ptr(ps), ptr(pq), stream_ptr())
+    return dx, (ps, pq, C, N * parts)
+
+
+def bn_bwd_masked_from_parts(z, dy, ctx, w, part):
+    """BatchNorm + ReLU backward of z whose masked column sums the producer of dy left in `part` = (part_s, part_q, row
+    stride, rows).  -> dz, dw, db"""
+    C = z.shape[-1]
+    M = z.numel() // C
+    sums = _f32((2, C), z.device)
+    dz = torch.empty_like(z)
+    ps, pq, stride, P = part
+    call("tdeed_bn_bwd_masked_from_parts", ptr(z), ptr(dy), M, C, ptr(ctx[0]), ptr(ctx[1]), ptr(w), ptr(ctx[2]), ptr(ctx[3]),
+         ptr(ps), ptr(pq), stride, P, ptr(sums), ptr(dz), dtype_code(z.dtype), stream_ptr())
+    return dz, sums[1], sums[0]
+
+
 class GradSink:
     """The ReLU backward at a block's output and the statistics of the BatchNorm backward behind it, delegated to whichever
     kernels produce the gradient arriving there (csrc/trunk_bwd2.hip "gradient sink"): mask = the block's output (ReLU

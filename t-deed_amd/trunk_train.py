@@ -26,6 +26,8 @@ SINK = _os.environ.get("TDEED_TRAIN_SINK", "1") == "1"
 # K = N = 320 contractions over >= RS_MIN_ROWS rows on the register-stationary kernel (forward with the statistics epilogue,
 # conv3's input gradient); TDEED_TRAIN_RS=0: the tiled kernel everywhere
 RS_TRAIN = _os.environ.get("TDEED_TRAIN_RS", "1") == "1"
+# statistics of conv1's BatchNorm backward from the epilogue of conv2's (stride-1) input-gradient launch
+DGRAD_STATS = _os.environ.get("TDEED_TRAIN_DGRAD_STATS", "1") == "1"
 RS_MIN_ROWS = 60000
 
 
@@ -325,8 +327,14 @@ class BottleneckTrain:
         # conv2
         bn_names("conv2", dw_bn2, db_bn2)
         xin, aff1 = (c.z1, (c.bn1[2], c.bn1[3])) if c.onload else (c.y1, None)
+        part1 = None
         if self.w2frag_t is not None:
-            d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)
+            if (DGRAD_STATS and ZMASK and len(c.bn1) >= 4 and dz2.dtype == torch.bfloat16
+                    and ops.gconv3x3_mfma_fits(h2, w2, C, 1)):
+                # ... and the statistics of conv1's BatchNorm backward out of the same launch: no pass over (d_y1, z1) for them
+                d_y1, part1 = B_.gconv3x3_dgrad_stats(dz2, self.w2frag_t, self.one, self.zero, blk.gw, c.z1, c.bn1)
+            else:
+                d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)
             _, dw2p = B_.gconv3x3_bwd(xin, dz2, self.w2p, blk.gw, blk.stride, want_dx=False, in_affine=aff1)
         else:
             d_y1, dw2p = B_.gconv3x3_bwd(xin, dz2, self.w2p, blk.gw, blk.stride, in_affine=aff1)
@@ -334,7 +342,10 @@ class BottleneckTrain:
         grads[pre + ".conv2.conv.weight"] = (dw2p.reshape(G, 3, 3, gw, gw).permute(0, 4, 3, 1, 2)
                                              .reshape(sd[pre + ".conv2.conv.weight"].shape).contiguous())
         # conv1
-        dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, None if ZMASK else c.y1, c.bn1, sd[self.c1 + ".bn.weight"], relu=True)
+        if part1 is not None:
+            dz1, dw, db = B_.bn_bwd_masked_from_parts(c.z1, d_y1, c.bn1, sd[self.c1 + ".bn.weight"], part1)
+        else:
+            dz1, _, dw, db = B_.bn_train_bwd(c.z1, d_y1, None if ZMASK else c.y1, c.bn1, sd[self.c1 + ".bn.weight"], relu=True)
         bn_names("conv1", dw, db)
         Nf, h, w, Cin = c.x.shape
         # identity shortcut: its gradient joins dx in the contraction's epilogue (no separate add pass); behind a gate-shift the

@@ -250,3 +250,30 @@ def test_weight_gradient_on_exact_160_wide_tiles_for_the_320_wide_layers():
             Xe[:, :k0] = x0.double()
         ref = dY.double().t() @ Xe
         assert max_abs(dW, ref) <= 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("N,h,w,C,gw", [(5, 14, 14, 320, 16), (3, 28, 28, 128, 16), (4, 7, 7, 368, 8), (2, 14, 14, 152, 8)])
+def test_conv1_batchnorm_backward_statistics_from_conv2s_input_gradient_launch(N, h, w, C, gw):
+    """tdeed_gconv3x3_dgrad_stats + tdeed_bn_bwd_masked_from_parts against the separate launches they replace (the grouped conv
+    of dz2 with the flipped weights, then tdeed_bn_train_bwd's masked statistics pass + apply pass over (d_y1, z1))."""
+    from tdeed_amd import ops, ops_bwd as B_
+    from tdeed_amd.engine import gconv_frags_on_device
+    G = C // gw
+    w2 = _rand((C, gw, 3, 3), 61, 0.2).to(DEV)
+    wt = w2.reshape(G, gw, gw, 3, 3).transpose(1, 2).flip(3, 4).reshape(C, gw, 3, 3).contiguous()
+    wfrag_t = gconv_frags_on_device(wt, gw)
+    one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    dz2 = _rand((N, h, w, C), 62, 0.5).to(DEV).to(torch.bfloat16)
+    z1 = _rand((N, h, w, C), 63).to(DEV).to(torch.bfloat16)
+    bw = (_rand((C,), 64, 0.3) + 1.0).to(DEV)
+    bb = _rand((C,), 65, 0.3).to(DEV)
+    bn1 = B_.bn_stats(z1, bw, bb)
+    d_ref, _ = ops.gconv3x3(dz2, None, one, zero, gw, 1, wfrag=wfrag_t, relu=False)
+    dz_ref, _, dw_ref, db_ref = B_.bn_train_bwd(z1, d_ref, None, bn1, bw, relu=True)
+    d_y1, part = B_.gconv3x3_dgrad_stats(dz2, wfrag_t, one, zero, gw, z1, bn1)
+    dz, dw, db = B_.bn_bwd_masked_from_parts(z1, d_y1, bn1, bw, part)
+    torch.cuda.synchronize()
+    assert torch.equal(d_y1, d_ref)
+    sc = max(1.0, float(dw_ref.abs().max()), float(db_ref.abs().max()))
+    assert max_abs(dw, dw_ref) <= 2e-4 * sc and max_abs(db, db_ref) <= 2e-4 * sc
+    assert max_abs(dz, dz_ref) <= 1e-2 * max(1.0, float(dz_ref.float().abs().max()))
