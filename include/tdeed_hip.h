@@ -485,6 +485,13 @@ int tdeed_scale_rows(const void* x, const float* s, const float* add, float add_
 int tdeed_gconv3x3_dgrad_stats(const void* dy, int N, int Hi, int Wi, int C, int gw, const void* wfrag_t, const float* one,
                                const float* zero, void* dx, const void* bz, const float* bfa, const float* bfb,
                                const float* bmean, float* part_s, float* part_q, void* stream);
+/* stride-2 blocks: tdeed_gconv3x3_bwd (stride 2, bf16) whose input-gradient launch leaves the same partial rows:
+ * part_s / part_q fp32 [N * tdeed_gconv3x3_bwd_stats_bands(Hi)][C] */
+int tdeed_gconv3x3_bwd_stats_bands(int Hi);
+int tdeed_gconv3x3_bwd_stats_fits(int N, int Hi, int Wi, int C, int gw);
+int tdeed_gconv3x3_bwd_stats(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, const float* w,
+                             const float* in_a, const float* in_b, void* dx, float* part, float* dw, const void* bz,
+                             const float* bfa, const float* bfb, const float* bmean, float* part_s, float* part_q, void* stream);
 int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C, const float* mean, const float* rstd,
                                    const float* w, const float* fa, const float* fb, const float* part_s, const float* part_q,
                                    long pstride, int P, float* sums, void* dz, int dtype, void* stream);

@@ -77,6 +77,9 @@ _SIGS = {
     "tdeed_se_train_bwd": ([P, P, P, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_scale_rows": ([P, P, P, c_float, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_gconv3x3_dgrad_stats": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P], c_int),
+    "tdeed_gconv3x3_bwd_stats_bands": ([c_int], c_int),
+    "tdeed_gconv3x3_bwd_stats_fits": ([c_int, c_int, c_int, c_int, c_int], c_int),
+    "tdeed_gconv3x3_bwd_stats": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P], c_int),
     "tdeed_bn_bwd_masked_from_parts": ([P, P, c_long, c_int, P, P, P, P, P, P, P, c_long, c_int, P, P, c_int, P], c_int),
     "tdeed_se_bn_bwd_sums": ([P, P, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
     "tdeed_se_bn_bwd_finalize": ([P, P, P, c_int, c_int, c_int, P, P, P], c_int),

@@ -980,9 +980,15 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_pack_kernel(const float* _
 // workgroup = (band of 16 input rows, frame, chunk of 64 channels), walking the 16-pixel-wide tiles of the band; wave =
 // one 16-channel unit of the chunk with its 5 weight fragments in registers; the 10 x 10 output pixels that reach a tile
 // are staged in LDS (zero outside the map).
+// bz given (training): dx arrives at conv1's BatchNorm + ReLU, whose backward needs sum g and sum g * (z1 - mean), g = dx masked
+// by [fa z1 + fb > 0]: every lane sums them over what it stores (z1 read here once, 8 bytes beside each store), one fold over
+// the 16 pixel lanes at the end leaves the partial row part_s / part_q [frame * bands + band][C] of this workgroup's 64 channels.
+struct S2Stat {
+  const bf16_t* z; const float* fa; const float* fb; const float* mean; float* part_s; float* part_q;
+};
 __global__ __launch_bounds__(256) void gconv_dgrad_s2_mfma_kernel(const bf16_t* __restrict__ dy, int Hi, int Wi, int Ho,
                                                                   int Wo, int C, const bf16x8* __restrict__ wfrag,
-                                                                  bf16_t* __restrict__ dx) {
+                                                                  bf16_t* __restrict__ dx, const S2Stat bst) {
   constexpr int TO = 10, CP = 64 + 8;                           // pixel stride 144 B: odd number of 16-byte slots
   __shared__ __attribute__((aligned(16))) bf16_t dyt[TO * TO * CP];
   const int n = blockIdx.y, iy0 = blockIdx.x * 16, c0 = blockIdx.z * 64;
@@ -997,6 +1003,16 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_mfma_kernel(const bf16_t* 
   const int oyb = iy0 >> 1;
   const IDiv dck(nck);
   const int ntx = (Wi + 15) >> 4;
+  float sfa[4], sfb[4], smu[4], ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bst.z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = min(u * 16 + kq * 4 + r, C - 1);
+      sfa[r] = bst.fa[c];
+      sfb[r] = bst.fb[c];
+      smu[r] = bst.mean[c];
+    }
+  }
   for (int tx = 0; tx < ntx; ++tx) {
     const int ix0 = tx * 16, oxb = ix0 >> 1;
     __syncthreads();
@@ -1046,11 +1062,39 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_mfma_kernel(const bf16_t* 
         }
         const int iy = iy0 + 2 * ly + pyc, ix = ix0 + 2 * lx + pxc;
         if (iy < Hi && ix < Wi && u * 16 + kq * 4 < C) {
-          bf16_t* dst = dx + (((long)n * Hi + iy) * Wi + ix) * C + u * 16 + kq * 4;
+          const long off = (((long)n * Hi + iy) * Wi + ix) * C + u * 16 + kq * 4;
           typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
           bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-          *reinterpret_cast<bf16x4*>(dst) = o;
+          *reinterpret_cast<bf16x4*>(dx + off) = o;
+          if (bst.z) {
+            const bf16x4 z4 = *reinterpret_cast<const bf16x4*>(bst.z + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float zv = (float)z4[r];
+              const float g = fmaf(zv, sfa[r], sfb[r]) > 0.f ? (float)o[r] : 0.f;
+              ps1[r] += g;
+              ps2[r] = fmaf(g, zv - smu[r], ps2[r]);
+            }
+          }
         }
+      }
+    }
+  }
+  if (bst.z) {                                                  // (inactive waves hold zeros and write nothing)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        ps1[r] += __shfl_xor(ps1[r], o, 64);
+        ps2[r] += __shfl_xor(ps2[r], o, 64);
+      }
+    }
+    if (active && pl == 0 && u * 16 + kq * 4 < C) {
+      const long row = ((long)n * gridDim.x + blockIdx.x) * C + u * 16 + kq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bst.part_s[row + r] = ps1[r];
+        bst.part_q[row + r] = ps2[r];
       }
     }
   }
@@ -1345,6 +1389,8 @@ extern "C" int tdeed_gconv_wgrad_slabs(long npix_out) {
   return (int)(s < 2 ? 2 : (s > 2048 ? 2048 : s));             // gradient's weight fragments (80 C floats)
 }
 
+static thread_local S2Stat g_s2_stat = S2Stat{};      // set by tdeed_gconv3x3_bwd_stats for the call it makes, cleared by that call
+
 // dx [N][Hi][Wi][C] (activation dtype), dw fp32 [G][9][gw][gw] (the forward's packed layout);
 // part: fp32 [tdeed_gconv_wgrad_slabs(N*Ho*Wo)][G*9*gw*gw]
 extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, int stride,
@@ -1390,8 +1436,13 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
     hipLaunchKernelGGL(gconv_dgrad_s2_pack_kernel, dim3((unsigned)cdiv((C + 15) / 16 * 320, 256)), dim3(256), 0, st, w, C, gw,
                        (bf16x8*)part);
     hipLaunchKernelGGL(gconv_dgrad_s2_mfma_kernel, dim3(cdiv(Hi, 16), N, cdiv(C, 64)), dim3(256), 0, st, (const bf16_t*)dy, Hi,
-                       Wi, Ho, Wo, C, (const bf16x8*)part, (bf16_t*)dx);
+                       Wi, Ho, Wo, C, (const bf16x8*)part, (bf16_t*)dx, g_s2_stat);
+  } else if (g_s2_stat.z) {
+    g_s2_stat = S2Stat{};
+    tdeed_set_error("gconv3x3_bwd_stats: the geometry is not served by the stride-2 MFMA input-gradient kernel");
+    return TDEED_ERR_ARG;
   }
+  g_s2_stat = S2Stat{};
 #define TD_GC_LAUNCH(TT, GWv)                                                                                           \
   do {                                                                                                                  \
     if (dg_mfma) {                                                                                                      \
@@ -1440,6 +1491,31 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   TD_LAUNCH_CHECK("gconv3x3_bwd");
   TD_CHECK(!in_a, "gconv3x3_bwd: the on-load input affine needs the bf16 transposing-read weight-gradient kernel");
   return tdeed_reduce_partials(part, nrows, (long)G * 9 * gw * gw, dw, 0, stream);
+}
+
+// The same (stride 2, bf16) with the statistics of conv1's BatchNorm backward out of the input-gradient launch: part_s / part_q
+// fp32 [N * tdeed_gconv3x3_bwd_stats_bands(Hi)][C] = sums of g and g * (bz - bmean), g = dx masked by [bfa bz + bfb > 0].
+extern "C" int tdeed_gconv3x3_bwd_stats_bands(int Hi) { return cdiv(Hi, 16); }
+// 1 when tdeed_gconv3x3_bwd would run the stride-2 MFMA input-gradient kernel for this geometry (the only one with the epilogue)
+extern "C" int tdeed_gconv3x3_bwd_stats_fits(int N, int Hi, int Wi, int C, int gw) {
+  static const bool dg_old = getenv("TDEED_GCONV_DGRAD_ROWS") && atoi(getenv("TDEED_GCONV_DGRAD_ROWS")) == 1;
+  static const bool dg_valu = getenv("TDEED_GCONV_DGRAD_VALU") && atoi(getenv("TDEED_GCONV_DGRAD_VALU")) == 1;
+  if (dg_old || dg_valu || !(gw == 8 || gw == 16) || C % gw != 0 || C % 8 != 0 || Hi % 2 != 0 || Wi % 2 != 0 || N <= 0 || N > 65535)
+    return 0;
+  const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1, G = C / gw;
+  const int slabs = tdeed_gconv_wgrad_slabs((long)N * Ho * Wo);
+  const long frag_bytes = (long)((C + 15) / 16) * 5 * 64 * 16;
+  return frag_bytes <= (long)slabs * G * 9 * gw * gw * 4 ? 1 : 0;
+}
+extern "C" int tdeed_gconv3x3_bwd_stats(const void* x, const void* dy, int N, int Hi, int Wi, int C, int gw, const float* w,
+                                        const float* in_a, const float* in_b, void* dx, float* part, float* dw, const void* bz,
+                                        const float* bfa, const float* bfb, const float* bmean, float* part_s, float* part_q,
+                                        void* stream) {
+  TD_CHECK(dx && bz && bfa && bfb && bmean && part_s && part_q, "gconv3x3_bwd_stats: null pointer");
+  g_s2_stat = S2Stat{(const bf16_t*)bz, bfa, bfb, bmean, part_s, part_q};
+  const int rc = tdeed_gconv3x3_bwd(x, dy, N, Hi, Wi, C, gw, 2, w, in_a, in_b, dx, part, dw, TDEED_BF16, stream);
+  g_s2_stat = S2Stat{};
+  return rc;
 }
 
 // =========================================================================== row gather / scatter for stride-2 1x1 convs

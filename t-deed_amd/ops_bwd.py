@@ -291,6 +291,26 @@ def gconv3x3_dgrad_stats(dy, wfrag_t, one, zero, gw, z1, bn1):
     return dx, (ps, pq, C, N * parts)
 
 
+def gconv3x3_bwd_stats_fits(N, Hi, Wi, C, gw):
+    return _lib.load().tdeed_gconv3x3_bwd_stats_fits(N, Hi, Wi, C, gw) != 0
+
+
+def gconv3x3_bwd_stats(x, dy, w_packed, gw, z1, bn1, in_affine=None):
+    """gconv3x3_bwd (stride 2, bf16) whose input-gradient launch also leaves the column sums of conv1's BatchNorm backward
+    (tdeed_gconv3x3_bwd_stats).  -> dx, dw, (part_s, part_q, row stride, rows)"""
+    N, Hi, Wi, C = x.shape
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    G = C // gw
+    part = _f32((_lib.load().tdeed_gconv_wgrad_slabs(N * Ho * Wo), G * 9 * gw * gw), x.device)
+    dx, dw = torch.empty_like(x), _f32((G, 9, gw, gw), x.device)
+    nb = _lib.load().tdeed_gconv3x3_bwd_stats_bands(Hi)
+    ps, pq = _f32((N * nb, C), x.device), _f32((N * nb, C), x.device)
+    call("tdeed_gconv3x3_bwd_stats", ptr(x), ptr(dy), N, Hi, Wi, C, gw, ptr(w_packed), ptr(in_affine[0] if in_affine else None),
+         ptr(in_affine[1] if in_affine else None), ptr(dx), ptr(part), ptr(dw), ptr(z1), ptr(bn1[2]), ptr(bn1[3]), ptr(bn1[0]),
+         ptr(ps), ptr(pq), stream_ptr())
+    return dx, dw, (ps, pq, C, N * nb)
+
+
 def bn_bwd_masked_from_parts(z, dy, ctx, w, part):
     """BatchNorm + ReLU backward of z whose masked column sums the producer of dy left in `part` = (part_s, part_q, row
     stride, rows).  -> dz, dw, db"""

@@ -336,6 +336,9 @@ class BottleneckTrain:
             else:
                 d_y1, _ = ops.gconv3x3(dz2, self.w2p, self.one, self.zero, blk.gw, 1, wfrag=self.w2frag_t, relu=False)
             _, dw2p = B_.gconv3x3_bwd(xin, dz2, self.w2p, blk.gw, blk.stride, want_dx=False, in_affine=aff1)
+        elif (DGRAD_STATS and ZMASK and len(c.bn1) >= 4 and blk.stride == 2 and dz2.dtype == torch.bfloat16
+              and B_.gconv3x3_bwd_stats_fits(xin.shape[0], xin.shape[1], xin.shape[2], C, blk.gw)):
+            d_y1, dw2p, part1 = B_.gconv3x3_bwd_stats(xin, dz2, self.w2p, blk.gw, c.z1, c.bn1, in_affine=aff1)
         else:
             d_y1, dw2p = B_.gconv3x3_bwd(xin, dz2, self.w2p, blk.gw, blk.stride, in_affine=aff1)
         G, gw = blk.groups, blk.gw

@@ -277,3 +277,29 @@ def test_conv1_batchnorm_backward_statistics_from_conv2s_input_gradient_launch(N
     sc = max(1.0, float(dw_ref.abs().max()), float(db_ref.abs().max()))
     assert max_abs(dw, dw_ref) <= 2e-4 * sc and max_abs(db, db_ref) <= 2e-4 * sc
     assert max_abs(dz, dz_ref) <= 1e-2 * max(1.0, float(dz_ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("N,Hi,Wi,C,gw", [(3, 28, 28, 128, 16), (2, 56, 56, 64, 16), (4, 14, 14, 368, 8), (2, 30, 18, 56, 8)])
+def test_stride2_input_gradient_launch_leaves_conv1_batchnorm_backward_statistics(N, Hi, Wi, C, gw):
+    """tdeed_gconv3x3_bwd_stats (stride 2): dx and dw equal tdeed_gconv3x3_bwd's, and the partial rows fold to the sums of
+    tdeed_bn_train_bwd's masked statistics pass over (dx, z1)."""
+    from tdeed_amd import ops_bwd as B_
+    assert B_.gconv3x3_bwd_stats_fits(N, Hi, Wi, C, gw)
+    G = C // gw
+    Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    w2p = _rand((G, 9, gw, gw), 71, 0.2).to(DEV)
+    x = torch.relu(_rand((N, Hi, Wi, C), 72)).to(DEV).to(torch.bfloat16)
+    dy = _rand((N, Ho, Wo, C), 73, 0.5).to(DEV).to(torch.bfloat16)
+    z1 = _rand((N, Hi, Wi, C), 74).to(DEV).to(torch.bfloat16)
+    bw = (_rand((C,), 75, 0.3) + 1.0).to(DEV)
+    bb = _rand((C,), 76, 0.3).to(DEV)
+    bn1 = B_.bn_stats(z1, bw, bb)
+    dx_ref, dw_ref = B_.gconv3x3_bwd(x, dy, w2p, gw, 2)
+    dz_ref, _, dwb_ref, dbb_ref = B_.bn_train_bwd(z1, dx_ref, None, bn1, bw, relu=True)
+    dx, dw, part = B_.gconv3x3_bwd_stats(x, dy, w2p, gw, z1, bn1)
+    dz, dwb, dbb = B_.bn_bwd_masked_from_parts(z1, dx, bn1, bw, part)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref)
+    sc = max(1.0, float(dwb_ref.abs().max()), float(dbb_ref.abs().max()))
+    assert max_abs(dwb, dwb_ref) <= 2e-4 * sc and max_abs(dbb, dbb_ref) <= 2e-4 * sc
+    assert max_abs(dz, dz_ref) <= 1e-2 * max(1.0, float(dz_ref.float().abs().max()))
