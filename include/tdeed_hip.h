@@ -495,6 +495,23 @@ int tdeed_gconv3x3_bwd_stats(const void* x, const void* dy, int N, int Hi, int W
 int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C, const float* mean, const float* rstd,
                                    const float* w, const float* fa, const float* fb, const float* part_s, const float* part_q,
                                    long pstride, int P, float* sums, void* dz, int dtype, void* stream);
+/* conv1 backward of a NARROW training bottleneck in one launch (csrc/trunk_bwd3.hip; bf16; (Co, Ci) = (64, 32), (128, 64),
+ * (128, 128): RegNetY-800MF s1 / s2): from conv2's input gradient dY and conv1's raw output Z ([M][Co]) the BatchNorm + ReLU
+ * backward dz1 (never stored), the input gradient dX [M][Ci] = dz1 @ W1 + shortcut gradient, masked by [X > 0] with the
+ * gradient sink's column sums (as tdeed_gemm_dgrad), and the partial weight gradients dz1^T @ X.
+ * fa / fb / mean / rstd / w: conv1's BatchNorm; sums fp32 [2][Co] = (sum g, sum g xhat) of its backward; Wt [Ci][Co] = W1^T;
+ * R: shortcut gradient [M][Ci] (r_hi > 0: rows of the even pixels of an r_hi x r_wi frame) or NULL; bpart fp32
+ * [grid][3][Ci] (or NULL), wpart fp32 [grid][Co][Ci], grid = tdeed_narrow_conv1_bwd_grid(M). */
+int tdeed_narrow_conv1_bwd_fits(int Co, int Ci);
+int tdeed_narrow_conv1_bwd_grid(long M);
+int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int Co, int Ci, const float* fa, const float* fb,
+                           const float* mean, const float* rstd, const float* w, const float* sums, const void* X, const void* Wt,
+                           const void* R, long ldr, int r_hi, int r_wi, void* dX, int use_mask, const void* bz,
+                           const float* bmean, const void* bzd, const float* bmean_d, float* bpart, float* wpart, void* stream);
+/* sums fp32 [2][C] = (sum_p part_s, rstd * sum_p part_q) over P partial rows pstride floats apart (what
+ * tdeed_gconv3x3_dgrad_stats / tdeed_gconv3x3_bwd_stats leave) */
+int tdeed_bn_sums_from_parts(const float* part_s, const float* part_q, long pstride, int P, int C, const float* rstd,
+                             float* sums, void* stream);
 /* SE + conv2-BatchNorm backward of a bottleneck without the d_y2 map (csrc/trunk_bwd2.hip; timm SEModule / BatchNorm2d under
  * autograd, /root/reference/model/model.py:265-324).  d = d(y2 * gate) [N][hw][C] (conv3's input gradient), z = conv2's raw
  * output, y2 = relu(fa * z + fb):

@@ -474,6 +474,15 @@ __global__ __launch_bounds__(256) void bn_sums_from_parts_kernel(const float* __
   sums[C + c] = (float)(s2 * (double)rstd[c]);
 }
 
+extern "C" int tdeed_bn_sums_from_parts(const float* part_s, const float* part_q, long pstride, int P, int C, const float* rstd,
+                                        float* sums, void* stream) {
+  TD_CHECK(part_s && part_q && rstd && sums && P > 0 && C > 0 && C % 8 == 0 && pstride >= C, "bn_sums_from_parts: bad arguments");
+  hipLaunchKernelGGL(bn_sums_from_parts_kernel, dim3(C / 8), dim3(256), 0, (hipStream_t)stream, part_s, part_q, pstride, P, C,
+                     rstd, sums);
+  TD_LAUNCH_CHECK("bn_sums_from_parts");
+  return TDEED_OK;
+}
+
 extern "C" int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C, const float* mean, const float* rstd,
                                               const float* w, const float* fa, const float* fb, const float* part_s,
                                               const float* part_q, long pstride, int P, float* sums, void* dz, int dtype,

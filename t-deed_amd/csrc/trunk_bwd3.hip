@@ -1,0 +1,304 @@
+// conv1 backward of a NARROW training bottleneck in ONE launch (bf16; RegNetY-800MF s1.b1 64 <- 32, s2.b1 128 <- 64,
+// s2.b2/b3 128 <- 128 channels; timm Bottleneck.conv1 = ConvNormAct under autograd, /root/reference/model/model.py:265-324):
+//
+//   d_y1 (conv2's input gradient), z1 (conv1's raw output)            -- read ONCE
+//     -> dz1 = k1 * g + k2 * z1 + k3,  g = d_y1 * [fa z1 + fb > 0]     (BatchNorm + ReLU backward, statistics given)
+//     -> dx  = dz1 @ W1  (+ shortcut gradient)  masked by [x > 0], with the column sums the BatchNorm backward of the block in
+//             front needs ("gradient sink", trunk_bwd2.hip / tdeed_gemm_dgrad)
+//     -> dW1 = dz1^T @ x                                               (per-workgroup partials, folded by the write-out)
+//
+// The pass-per-op chain writes dz1 (a map at the block's INPUT resolution: 2.6 GB at s1.b1 of cfg3) and reads it twice more
+// (input-gradient contraction, weight-gradient contraction); here it lives in LDS for one 64-row tile.  W1 (<= 32 KB) sits in
+// LDS, read as MFMA A-operand fragments, the weight gradient (<= 128 x 128) in the accumulators of a persistent workgroup.  Both contractions read the same two LDS tiles: the input gradient with plain 16-byte fragment reads
+// (k = output channel), the weight gradient with transposing reads (k = row), like wgrad_tr128_kernel.
+#include "common.h"
+
+struct NbwP {
+  const bf16_t* dY; const bf16_t* Z;                  // [M][CO]
+  const float* fa; const float* fb;                   // ReLU mask of conv1's BatchNorm: fa z + fb > 0
+  const float* mean; const float* rstd; const float* w; const float* sums;   // its statistics: sums[0][c] = sum g, sums[1][c] = sum g xhat
+  const bf16_t* X;                                    // [M][CI] conv1's input (the ReLU output of the block in front: also the sink's mask)
+  const bf16_t* Wt;                                   // conv1's weight transposed, [CI][CO] row-major
+  const bf16_t* R; long ldr; int r_hi, r_wi;          // shortcut gradient: [M][CI], or rows for the even pixels of an r_hi x r_wi frame
+  bf16_t* dX;                                         // [M][CI]
+  int use_mask;
+  const bf16_t* bz; const float* bmean; const bf16_t* bzd; const float* bmean_d;   // sink statistics operands, [M][CI]
+  float* bpart;                                       // [gridDim.x][3][CI]
+  float* wpart;                                       // [gridDim.x][CO][CI]
+  long M; float inv_M;
+};
+
+// waves WN x WK over (output channels, input channels) of the weight gradient; each wave NTW x KTW accumulator tiles
+template <int CO, int CI> struct NbwGeom;
+template <> struct NbwGeom<64, 32> { static constexpr int WN = 4, WK = 1; };
+template <> struct NbwGeom<128, 64> { static constexpr int WN = 2, WK = 2; };
+template <> struct NbwGeom<128, 128> { static constexpr int WN = 2, WK = 2; };
+
+template <int CO, int CI>
+__global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) {
+  typedef NbwGeom<CO, CI> G;
+  constexpr int WN = G::WN, WK = G::WK;
+  constexpr int NTW = CO / WN / 16, KTW = CI / WK / 16;
+  constexpr int RSY = CO + 16, RSX = CI + 16;                     // LDS row strides (elements): + 32 bytes
+  constexpr int KS = CO / 32;                                     // k-steps of the input-gradient contraction
+  constexpr int TCI = CI / 16;                                    // its output (input-channel) tiles
+  constexpr int TPW = (TCI + 3) / 4;                              // ... per wave (tiles w, w + 4)
+  constexpr int CPY = CO / 8, CPX = CI / 8;                       // 16-byte pieces per row
+  constexpr int NPY = 64 * CPY / 256, NPX = (64 * CPX + 255) / 256;      // pieces per thread per tile
+  __shared__ __attribute__((aligned(16))) bf16_t sY[64 * RSY];    // dz1 tile [row][output channel]
+  __shared__ __attribute__((aligned(16))) bf16_t sX[64 * RSX];    // x tile   [row][input channel]
+  __shared__ __attribute__((aligned(16))) float kt_[5 * CO];      // k1 | k2 | k3 | fa | fb per output channel
+  __shared__ __attribute__((aligned(16))) float bt_[2 * CI];      // sink means per input channel
+  __shared__ __attribute__((aligned(16))) bf16_t sW[CI * (CO + 8)];      // Wt [ci][co] (row stride + 16 bytes)
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), pl = lane & 15, q = lane >> 4;
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int wn = wv / WK, wk = wv % WK;
+
+  // ---- per-thread constants of the staging pass: a thread serves ONE 8-channel chunk of dY / Z (CPY divides 256)
+  const int cy = (tid % CPY) * 8, ry = tid / CPY;                 // rows ry + (256 / CPY) * j
+  // per-channel constants and the weight live in LDS (as registers they cost the second wave per SIMD at 128 channels)
+  for (int c = tid; c < CO; c += 256) {
+    const float rs = p.rstd[c], mu = p.mean[c], s1 = p.sums[c] * p.inv_M, s2 = p.sums[CO + c] * p.inv_M;
+    const float k1 = p.w[c] * rs;
+    kt_[c] = k1;
+    kt_[CO + c] = -k1 * rs * s2;
+    kt_[2 * CO + c] = k1 * (mu * rs * s2 - s1);
+    kt_[3 * CO + c] = p.fa[c];
+    kt_[4 * CO + c] = p.fb[c];
+  }
+  for (int c = tid; c < CI; c += 256) {
+    bt_[c] = p.bpart ? p.bmean[c] : 0.f;
+    bt_[CI + c] = (p.bpart && p.bzd) ? p.bmean_d[c] : 0.f;
+  }
+  for (int i = tid; i < CI * CO / 8; i += 256) {
+    const int r = i / CPY, ck = i - r * CPY;
+    *reinterpret_cast<u32x4*>(sW + r * (CO + 8) + ck * 8) = *reinterpret_cast<const u32x4*>(p.Wt + (long)r * CO + ck * 8);
+  }
+  float ss1[TPW][4], ss2[TPW][4], ss3[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss1[t][r] = ss2[t][r] = ss3[t][r] = 0.f;
+  f32x4 acc[NTW][KTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long ntiles = (p.M + 63) / 64;
+  u32x4 vy[NPY], vz[NPY], vx[NPX];
+  auto issue = [&](long t) {
+    const long m0 = t * 64;
+#pragma unroll
+    for (int j = 0; j < NPY; ++j) {
+      const long row = min(m0 + ry + (256 / CPY) * j, p.M - 1);
+      vy[j] = *reinterpret_cast<const u32x4*>(p.dY + row * CO + cy);
+      vz[j] = *reinterpret_cast<const u32x4*>(p.Z + row * CO + cy);
+    }
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int i = min(tid + 256 * j, 64 * CPX - 1);
+      const long row = min(m0 + i / CPX, p.M - 1);
+      vx[j] = *reinterpret_cast<const u32x4*>(p.X + row * CI + (i % CPX) * 8);
+    }
+  };
+  long t = blockIdx.x;
+  if (t < ntiles) issue(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const long m0 = t * 64;
+    __syncthreads();                                              // the previous tile's LDS reads are over
+    // ---- dz1 = k1 g + k2 z + k3 -> sY (rows beyond M: zeros, they then add nothing to either contraction)
+#pragma unroll
+    for (int j = 0; j < NPY; ++j) {
+      const int r = ry + (256 / CPY) * j;
+      const bool rok = m0 + r < p.M;
+      const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&vy[j]);
+      const bf16x8 z8 = *reinterpret_cast<const bf16x8*>(&vz[j]);
+      bf16x8 o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(kt_ + cy + 4 * h), k2 = *reinterpret_cast<const f32x4*>(kt_ + CO + cy + 4 * h);
+        const f32x4 k3 = *reinterpret_cast<const f32x4*>(kt_ + 2 * CO + cy + 4 * h);
+        const f32x4 ma = *reinterpret_cast<const f32x4*>(kt_ + 3 * CO + cy + 4 * h), mb = *reinterpret_cast<const f32x4*>(kt_ + 4 * CO + cy + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zv = (float)z8[4 * h + e];
+          const float g = fmaf(zv, ma[e], mb[e]) > 0.f ? (float)d8[4 * h + e] : 0.f;
+          o[4 * h + e] = rok ? (bf16_t)fmaf(k1[e], g, fmaf(k2[e], zv, k3[e])) : (bf16_t)0.f;
+        }
+      }
+      *reinterpret_cast<bf16x8*>(sY + r * RSY + cy) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 64 * CPX) {
+        const int r = i / CPX;
+        const bool rok = m0 + r < p.M;
+        *reinterpret_cast<u32x4*>(sX + r * RSX + (i % CPX) * 8) = rok ? vx[j] : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    __syncthreads();
+    if (t + gridDim.x < ntiles) issue(t + gridDim.x);             // the next tile travels under this tile's contractions
+
+    // ---- input gradient: dx[m][ci] = sum_co dz1[m][co] * Wt[ci][co]; A = Wt fragments, B = dz1 rows
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int ct = wv + 4 * tt;
+      if (ct < TCI) {                                             // (wave-uniform)
+        const int c0 = ct * 16 + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int rl = mt * 16 + pl;
+          const long m = m0 + rl;
+          const bool mok = m < p.M;
+          const long mc = mok ? m : p.M - 1;
+          // epilogue operands of this (row, 4 channels): requested before the MFMA chain
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          bf16x4_t r4 = {}, z4 = {}, zd4 = {};
+          bool has_r = p.R != nullptr;
+          if (p.R) {
+            long rm = mc;
+            if (p.r_hi > 0) {
+              const long per = (long)p.r_hi * p.r_wi;
+              const long f = mc / per;
+              const int rem = (int)(mc - f * per);
+              const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
+              has_r = !((yy | xx) & 1);
+              rm = has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
+            }
+            r4 = *reinterpret_cast<const bf16x4_t*>(p.R + rm * p.ldr + c0);
+          }
+          if (p.bpart) {
+            z4 = *reinterpret_cast<const bf16x4_t*>(p.bz + mc * CI + c0);
+            if (p.bzd) zd4 = *reinterpret_cast<const bf16x4_t*>(p.bzd + mc * CI + c0);
+          }
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          const bf16_t* br = sY + rl * RSY + 8 * q;
+          const bf16_t* wr = sW + (ct * 16 + pl) * (CO + 8) + 8 * q;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wr + 32 * ks),
+                                                        *reinterpret_cast<const bf16x8*>(br + 32 * ks), a, 0, 0, 0);
+          const bf16x4_t x4 = *reinterpret_cast<const bf16x4_t*>(sX + rl * RSX + c0);
+          bf16x4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = a[r] + (has_r ? (float)r4[r] : 0.f);
+            if (p.use_mask && !((float)x4[r] > 0.f)) v = 0.f;
+            o[r] = (bf16_t)v;
+          }
+          if (mok) {
+            *reinterpret_cast<bf16x4_t*>(p.dX + m * CI + c0) = o;
+            if (p.bpart) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float vr = (float)o[r];
+                ss1[tt][r] += vr;
+                ss2[tt][r] = fmaf(vr, (float)z4[r] - bt_[c0 + r], ss2[tt][r]);
+                if (p.bzd) ss3[tt][r] = fmaf(vr, (float)zd4[r] - bt_[CI + c0 + r], ss3[tt][r]);
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- weight gradient: dW[co][ci] += sum_m dz1[m][co] * x[m][ci]: both operands through transposing reads (k = row)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = ks * 32 + g4 * 8 + q4;
+      bf16x8 af[NTW], bfr[KTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const bf16_t* a = sY + row * RSY + wn * (NTW * 16) + nt * 16 + p4 * 4;
+        af[nt] = td_tr_read8(a, a + 4 * RSY);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) {
+        const bf16_t* b = sX + row * RSX + wk * (KTW * 16) + kt * 16 + p4 * 4;
+        bfr[kt] = td_tr_read8(b, b + 4 * RSX);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+    }
+  }
+  // ---- partials of this workgroup
+  float* wp = p.wpart + (long)blockIdx.x * CO * CI;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) {
+      const int k = wk * (KTW * 16) + kt * 16 + pl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = wn * (NTW * 16) + nt * 16 + 4 * g4 + e;
+        wp[(long)n * CI + k] = acc[nt][kt][e];
+      }
+    }
+  if (p.bpart) {
+    float* bp = p.bpart + (long)blockIdx.x * 3 * CI;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          ss1[tt][r] += __shfl_xor(ss1[tt][r], o, 64);
+          ss2[tt][r] += __shfl_xor(ss2[tt][r], o, 64);
+          ss3[tt][r] += __shfl_xor(ss3[tt][r], o, 64);
+        }
+      }
+      const int ct = wv + 4 * tt;
+      if (ct < TCI && pl == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = ct * 16 + 4 * q + r;
+          bp[c] = ss1[tt][r];
+          bp[CI + c] = ss2[tt][r];
+          bp[2 * CI + c] = ss3[tt][r];
+        }
+      }
+    }
+  }
+}
+
+extern "C" int tdeed_narrow_conv1_bwd_fits(int Co, int Ci) {
+  return ((Co == 64 && Ci == 32) || (Co == 128 && Ci == 64) || (Co == 128 && Ci == 128)) ? 1 : 0;
+}
+// persistent workgroups (two per CU); also the row count of wpart / bpart
+extern "C" int tdeed_narrow_conv1_bwd_grid(long M) {
+  const long tiles = (M + 63) / 64;
+  return (int)(tiles < 512 ? tiles : 512);
+}
+
+// dY, Z [M][Co] bf16; fa / fb / mean / rstd / w: conv1's BatchNorm (forward affine, batch statistics, weight); sums fp32 [2][Co]
+// = (sum g, sum g * xhat) of its backward (tdeed_bn_bwd_masked_from_parts leaves them); X [M][Ci]; Wt [Ci][Co] (the weight
+// transposed); R: shortcut gradient ([M][Ci], or with r_hi > 0 the rows of the even pixels of an r_hi x r_wi frame) or NULL;
+// dX [M][Ci]; use_mask: dX *= [X > 0]; bz / bmean (/ bzd / bmean_d) + bpart fp32 [grid][3][Ci]: the gradient sink's statistics
+// (NULL: none); wpart fp32 [grid][Co][Ci]: partial weight gradients, grid = tdeed_narrow_conv1_bwd_grid(M).
+extern "C" int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int Co, int Ci, const float* fa, const float* fb,
+                                      const float* mean, const float* rstd, const float* w, const float* sums, const void* X,
+                                      const void* Wt, const void* R, long ldr, int r_hi, int r_wi, void* dX, int use_mask,
+                                      const void* bz, const float* bmean, const void* bzd, const float* bmean_d, float* bpart,
+                                      float* wpart, void* stream) {
+  TD_CHECK(dY && Z && fa && fb && mean && rstd && w && sums && X && Wt && dX && wpart, "narrow_conv1_bwd: null pointer");
+  TD_CHECK(M > 0 && tdeed_narrow_conv1_bwd_fits(Co, Ci), "narrow_conv1_bwd: %d <- %d channels not served", Co, Ci);
+  TD_CHECK(!R || ldr % 4 == 0, "narrow_conv1_bwd: bad residual stride");
+  TD_CHECK(r_hi == 0 || (R && r_hi > 0 && r_wi > 0 && M % ((long)r_hi * r_wi) == 0), "narrow_conv1_bwd: bad stride-2 residual geometry");
+  TD_CHECK(!bpart || (bz && bmean && (!bzd || bmean_d)), "narrow_conv1_bwd: statistics operands missing");
+  NbwP p{};
+  p.dY = (const bf16_t*)dY; p.Z = (const bf16_t*)Z; p.fa = fa; p.fb = fb; p.mean = mean; p.rstd = rstd; p.w = w; p.sums = sums;
+  p.X = (const bf16_t*)X; p.Wt = (const bf16_t*)Wt; p.R = (const bf16_t*)R; p.ldr = ldr; p.r_hi = r_hi; p.r_wi = r_wi;
+  p.dX = (bf16_t*)dX; p.use_mask = use_mask;
+  p.bz = (const bf16_t*)bz; p.bmean = bmean; p.bzd = bpart ? (const bf16_t*)bzd : nullptr; p.bmean_d = bmean_d; p.bpart = bpart;
+  p.wpart = wpart; p.M = M; p.inv_M = 1.0f / (float)M;
+  const int grid = tdeed_narrow_conv1_bwd_grid(M);
+  hipStream_t st = (hipStream_t)stream;
+  if (Co == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, st, p);
+  else if (Ci == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 64>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 128>), dim3(grid), dim3(256), 0, st, p);
+  TD_LAUNCH_CHECK("narrow_conv1_bwd");
+  return TDEED_OK;
+}

@@ -324,6 +324,37 @@ def bn_bwd_masked_from_parts(z, dy, ctx, w, part):
     return dz, sums[1], sums[0]
 
 
+def narrow_conv1_bwd_fits(Co, Ci, dtype):
+    return dtype == torch.bfloat16 and _lib.load().tdeed_narrow_conv1_bwd_fits(Co, Ci) != 0
+
+
+def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_hw=None):
+    """conv1 backward of a narrow bottleneck in one launch (tdeed_narrow_conv1_bwd): d_y1 / z1 (.., Co), bn1 = (mean, rstd, a, b),
+    w its weight, part = the masked column-sum partials conv2's input-gradient launch left, x (.., Ci) conv1's input (= the
+    sink's mask), wt (Ci, Co) the transposed weight, residual: shortcut gradient (r_hw = (hi, wi): on the even pixels only).
+    -> dx (M, Ci) (masked / summed for `sink`), dW (Co, Ci) as a LazyFold, BatchNorm dw, db."""
+    Co, Ci = z1.shape[-1], x.shape[-1]
+    M = z1.numel() // Co
+    dev = z1.device
+    ps, pq, stride, P = part
+    sums = _f32((2, Co), dev)
+    call("tdeed_bn_sums_from_parts", ptr(ps), ptr(pq), stride, P, Co, ptr(bn1[1]), ptr(sums), stream_ptr())
+    grid = _lib.load().tdeed_narrow_conv1_bwd_grid(M)
+    dx = torch.empty((M, Ci), dtype=z1.dtype, device=dev)
+    wpart = _f32((grid, Co, Ci), dev)
+    bpart = None
+    if sink is not None:
+        bpart = _f32((grid, 3, Ci), dev)
+        sink.partA = bpart
+    rh, rw = r_hw if r_hw is not None else (0, 0)
+    call("tdeed_narrow_conv1_bwd", ptr(d_y1), ptr(z1), M, Co, Ci, ptr(bn1[2]), ptr(bn1[3]), ptr(bn1[0]), ptr(bn1[1]), ptr(w),
+         ptr(sums), ptr(x), ptr(wt), ptr(residual), (residual.shape[-1] if residual is not None else 0), rh, rw, ptr(dx),
+         int(sink is not None), ptr(sink.z if sink else None), ptr(sink.mean if sink else None), ptr(sink.zd if sink else None),
+         ptr(sink.mean_d if sink else None), ptr(bpart), ptr(wpart), stream_ptr())
+    dW = LazyFold(wpart, grid, Co * Ci, (Co, Ci)) if LAZY_WGRAD else LazyFold(wpart, grid, Co * Ci, (Co, Ci)).materialize()
+    return dx, dW, sums[1], sums[0]
+
+
 class GradSink:
     """The ReLU backward at a block's output and the statistics of the BatchNorm backward behind it, delegated to whichever
     kernels produce the gradient arriving there (csrc/trunk_bwd2.hip "gradient sink"): mask = the block's output (ReLU

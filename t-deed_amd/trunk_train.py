@@ -28,6 +28,8 @@ SINK = _os.environ.get("TDEED_TRAIN_SINK", "1") == "1"
 RS_TRAIN = _os.environ.get("TDEED_TRAIN_RS", "1") == "1"
 # statistics of conv1's BatchNorm backward from the epilogue of conv2's (stride-1) input-gradient launch
 DGRAD_STATS = _os.environ.get("TDEED_TRAIN_DGRAD_STATS", "1") == "1"
+# conv1's whole backward (BatchNorm apply + input gradient + weight gradient) of the narrow 800MF s1 / s2 layers in one launch
+NARROW_BWD = _os.environ.get("TDEED_TRAIN_NARROW_BWD", "1") == "1"
 RS_MIN_ROWS = 60000
 
 
@@ -345,6 +347,28 @@ class BottleneckTrain:
         grads[pre + ".conv2.conv.weight"] = (dw2p.reshape(G, 3, 3, gw, gw).permute(0, 4, 3, 1, 2)
                                              .reshape(sd[pre + ".conv2.conv.weight"].shape).contiguous())
         # conv1
+        Nf, h, w, Cin = c.x.shape
+        if (part1 is not None and NARROW_BWD and sink_out is not None and self.gs is None and c.G is None
+                and B_.narrow_conv1_bwd_fits(C, Cin, d_y1.dtype) and sink_out.mask.data_ptr() == c.x.data_ptr()):
+            # narrow layers (RegNetY-800MF s1 / s2): BatchNorm + ReLU backward, input gradient (+ shortcut gradient, the sink of
+            # the block in front) and weight gradient in ONE launch; dz1 lives in LDS only (trunk_bwd3.hip)
+            res, r_hw = d_sc.view(-1, Cin) if not blk.has_downsample else None, None
+            if blk.has_downsample:
+                wdn = sd[pre + ".downsample.bn.weight"]
+                if sink_in is not None:
+                    dzd, dw, db = B_.bn_bwd_from_parts(c.zd, dout, c.bnd, wdn, sink_in, q=2)
+                else:
+                    dzd, _, dw, db = B_.bn_train_bwd(c.zd, d_sc, None, c.bnd, wdn, relu=False)
+                bn_names("downsample", dw, db)
+                res = ops.gemm(dzd, self.wd.wt, None, None, ops.ACT_NONE)
+                grads[pre + ".downsample.conv.weight"] = B_.wgrad(dzd, c.xs, with_bias=False, M=N * hw2)[0].reshape(
+                    sd[pre + ".downsample.conv.weight"].shape)
+                r_hw = (h, w) if blk.stride == 2 else None
+            dx, dW1, dw, db = B_.narrow_conv1_bwd(d_y1, c.z1, c.bn1, sd[self.c1 + ".bn.weight"], part1, c.x, self.w1.wt,
+                                                  sink=sink_out, residual=res, r_hw=r_hw)
+            bn_names("conv1", dw, db)
+            grads[self.c1 + ".conv.weight"] = dW1.reshape(sd[self.c1 + ".conv.weight"].shape)
+            return dx.view(Nf, h, w, Cin)
         if part1 is not None:
             dz1, dw, db = B_.bn_bwd_masked_from_parts(c.z1, d_y1, c.bn1, sd[self.c1 + ".bn.weight"], part1)
         else:

@@ -303,3 +303,51 @@ def test_stride2_input_gradient_launch_leaves_conv1_batchnorm_backward_statistic
     sc = max(1.0, float(dwb_ref.abs().max()), float(dbb_ref.abs().max()))
     assert max_abs(dwb, dwb_ref) <= 2e-4 * sc and max_abs(dbb, dbb_ref) <= 2e-4 * sc
     assert max_abs(dz, dz_ref) <= 1e-2 * max(1.0, float(dz_ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("Co,Ci,frames,hi,wi,res", [(64, 32, 3, 10, 10, "s2"), (128, 64, 2, 12, 8, "s2"), (128, 128, 5, 7, 9, "full"),
+                                                     (128, 128, 2, 16, 16, "full"), (64, 32, 1, 8, 8, "none")])
+def test_narrow_conv1_backward_in_one_launch_equals_the_three_launch_chain(Co, Ci, frames, hi, wi, res):
+    """tdeed_narrow_conv1_bwd (BatchNorm + ReLU backward, input gradient with the gradient-sink epilogue, weight gradient; dz1
+    never stored) against tdeed_bn_bwd_masked_from_parts -> tdeed_gemm_dgrad -> tdeed_wgrad on the same operands."""
+    from tdeed_amd import ops_bwd as B_
+    assert B_.narrow_conv1_bwd_fits(Co, Ci, torch.bfloat16)
+    M = frames * hi * wi
+    bf = torch.bfloat16
+    d_y1 = _rand((M, Co), 81, 0.5).to(DEV).to(bf)
+    z1 = _rand((M, Co), 82).to(DEV).to(bf)
+    x = torch.relu(_rand((M, Ci), 83)).to(DEV).to(bf)
+    W1 = _rand((Co, Ci), 84, 0.2).to(DEV).to(bf)
+    wt = W1.t().contiguous()
+    bw = (_rand((Co,), 85, 0.3) + 1.0).to(DEV)
+    bb = _rand((Co,), 86, 0.3).to(DEV)
+    bn1 = B_.bn_stats(z1, bw, bb)
+    zp, zdp = _rand((M, Ci), 87).to(DEV).to(bf), _rand((M, Ci), 88).to(DEV).to(bf)
+    mp, mdp = _rand((Ci,), 89, 0.2).to(DEV), _rand((Ci,), 90, 0.2).to(DEV)
+    ho, wo = (hi + 1) // 2, (wi + 1) // 2
+    R = r_hw = None
+    if res == "full":
+        R = _rand((M, Ci), 91, 0.5).to(DEV).to(bf)
+    elif res == "s2":
+        R, r_hw = _rand((frames * ho * wo, Ci), 91, 0.5).to(DEV).to(bf), (hi, wi)
+    # the chain
+    dz_ref, _, dwb_ref, dbb_ref = B_.bn_train_bwd(z1, d_y1, None, bn1, bw, relu=True)
+    s_ref = B_.GradSink(x, zp, mp, zd=zdp, mean_d=mdp)
+    dx_ref = B_.gemm_dgrad(dz_ref, wt, sink=s_ref, residual=R, r_hw=r_hw)
+    dW_ref, _ = B_.wgrad(dz_ref, x, with_bias=False, M=M)
+    # one launch; the statistics partials as conv2's input-gradient launch would leave them (one row here)
+    part = (dbb_ref.view(1, Co).contiguous(), (dwb_ref / bn1[1]).view(1, Co).contiguous(), Co, 1)
+    s_new = B_.GradSink(x, zp, mp, zd=zdp, mean_d=mdp)
+    dx, dW, dwb, dbb = B_.narrow_conv1_bwd(d_y1, z1, bn1, bw, part, x, wt, sink=s_new, residual=R, r_hw=r_hw)
+    dW = B_.materialize(dW)
+    torch.cuda.synchronize()
+    assert max_abs(dwb, dwb_ref) <= 1e-4 * max(1.0, float(dwb_ref.abs().max()))
+    assert max_abs(dbb, dbb_ref) <= 1e-4 * max(1.0, float(dbb_ref.abs().max()))
+    assert max_abs(dx, dx_ref) <= 2e-2 * max(1.0, float(dx_ref.float().abs().max()))
+    assert max_abs(dW, dW_ref) <= 5e-3 * max(1.0, float(dW_ref.abs().max()))
+    a, b = s_new.partA.double().sum(0), s_ref.partA.double().sum(0)
+    assert max_abs(a, b) <= 5e-3 * max(1.0, float(b.abs().max()))
+    # the sums are those of what was stored
+    st = dx.double()
+    want = torch.stack([st.sum(0), (st * (zp.double() - mp.double())).sum(0), (st * (zdp.double() - mdp.double())).sum(0)])
+    assert max_abs(a, want) <= 1e-3 * max(1.0, float(want.abs().max()))
