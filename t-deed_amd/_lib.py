@@ -82,7 +82,7 @@ _SIGS = {
     "tdeed_gconv3x3_bwd_stats": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P], c_int),
     "tdeed_bn_bwd_masked_from_parts": ([P, P, c_long, c_int, P, P, P, P, P, P, P, c_long, c_int, P, P, c_int, P], c_int),
     "tdeed_narrow_conv1_bwd_fits": ([c_int, c_int], c_int),
-    "tdeed_narrow_conv1_bwd_grid": ([c_long], c_int),
+    "tdeed_narrow_conv1_bwd_grid": ([c_long, c_int, c_int], c_int),
     "tdeed_narrow_conv1_bwd": ([P, P, c_long, c_int, c_int, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P, c_int, P, P, P, P,
                                 P, P, P], c_int),
     "tdeed_bn_sums_from_parts": ([P, P, c_long, c_int, c_int, P, P, P], c_int),

@@ -102,8 +102,47 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
       vx[j] = *reinterpret_cast<const u32x4*>(p.X + row * CI + (i % CPX) * 8);
     }
   };
+  // the input gradient's epilogue operands (shortcut gradient, sink statistics maps: 8 bytes per lane and 16-row tile) of a
+  // tile are requested while the tile BEFORE it runs its weight-gradient phase: asked for inside the epilogue itself they cost
+  // one exposed memory round trip per 16-row tile (3.1 ms instead of ~2 at s1.b1 of cfg3)
+  // (not at 128 x 128: the 48 registers of the prefetch would cost the second workgroup per CU, measured slower)
+  constexpr bool PRE = !(CO == 128 && CI == 128);
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  bf16x4_t er[PRE ? TPW : 1][4], ez[PRE ? TPW : 1][4], ezd[PRE ? TPW : 1][4];
+  unsigned rmask = 0u;                                            // bit mt: the row has a shortcut-gradient row
+  auto issue_epi = [&](long tq) {
+    if constexpr (!PRE) return;
+    rmask = 0u;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const long mc = min(tq * 64 + mt * 16 + pl, p.M - 1);
+      long rm = mc;
+      bool has_r = p.R != nullptr;
+      if (p.R && p.r_hi > 0) {
+        const long per = (long)p.r_hi * p.r_wi;
+        const long f = mc / per;
+        const int rem = (int)(mc - f * per);
+        const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
+        has_r = !((yy | xx) & 1);
+        rm = has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
+      }
+      if (has_r) rmask |= 1u << mt;
+#pragma unroll
+      for (int tt = 0; tt < (PRE ? TPW : 1); ++tt) {
+        const int c0 = min(wv + 4 * tt, TCI - 1) * 16 + 4 * q;
+        if (p.R) er[tt][mt] = *reinterpret_cast<const bf16x4_t*>(p.R + rm * p.ldr + c0);
+        if (p.bpart) {
+          ez[tt][mt] = *reinterpret_cast<const bf16x4_t*>(p.bz + mc * CI + c0);
+          if (p.bzd) ezd[tt][mt] = *reinterpret_cast<const bf16x4_t*>(p.bzd + mc * CI + c0);
+        }
+      }
+    }
+  };
   long t = blockIdx.x;
-  if (t < ntiles) issue(t);
+  if (t < ntiles) {
+    issue(t);
+    issue_epi(t);
+  }
   for (; t < ntiles; t += gridDim.x) {
     const long m0 = t * 64;
     __syncthreads();                                              // the previous tile's LDS reads are over
@@ -153,25 +192,28 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
           const long m = m0 + rl;
           const bool mok = m < p.M;
           const long mc = mok ? m : p.M - 1;
-          // epilogue operands of this (row, 4 channels): requested before the MFMA chain
-          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
           bf16x4_t r4 = {}, z4 = {}, zd4 = {};
           bool has_r = p.R != nullptr;
-          if (p.R) {
-            long rm = mc;
-            if (p.r_hi > 0) {
-              const long per = (long)p.r_hi * p.r_wi;
-              const long f = mc / per;
-              const int rem = (int)(mc - f * per);
-              const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
-              has_r = !((yy | xx) & 1);
-              rm = has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
+          if constexpr (PRE) {
+            r4 = er[tt][mt]; z4 = ez[tt][mt]; zd4 = ezd[tt][mt];
+            has_r = (rmask >> mt) & 1u;
+          } else {
+            if (p.R) {
+              long rm = mc;
+              if (p.r_hi > 0) {
+                const long per = (long)p.r_hi * p.r_wi;
+                const long f = mc / per;
+                const int rem = (int)(mc - f * per);
+                const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
+                has_r = !((yy | xx) & 1);
+                rm = has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
+              }
+              r4 = *reinterpret_cast<const bf16x4_t*>(p.R + rm * p.ldr + c0);
             }
-            r4 = *reinterpret_cast<const bf16x4_t*>(p.R + rm * p.ldr + c0);
-          }
-          if (p.bpart) {
-            z4 = *reinterpret_cast<const bf16x4_t*>(p.bz + mc * CI + c0);
-            if (p.bzd) zd4 = *reinterpret_cast<const bf16x4_t*>(p.bzd + mc * CI + c0);
+            if (p.bpart) {
+              z4 = *reinterpret_cast<const bf16x4_t*>(p.bz + mc * CI + c0);
+              if (p.bzd) zd4 = *reinterpret_cast<const bf16x4_t*>(p.bzd + mc * CI + c0);
+            }
           }
           f32x4 a = {0.f, 0.f, 0.f, 0.f};
           const bf16_t* br = sY + rl * RSY + 8 * q;
@@ -203,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
         }
       }
     }
+    if (t + gridDim.x < ntiles) issue_epi(t + gridDim.x);         // (this tile's epilogue values are consumed)
     // ---- weight gradient: dW[co][ci] += sum_m dz1[m][co] * x[m][ci]: both operands through transposing reads (k = row)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -267,17 +310,18 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
 extern "C" int tdeed_narrow_conv1_bwd_fits(int Co, int Ci) {
   return ((Co == 64 && Ci == 32) || (Co == 128 && Ci == 64) || (Co == 128 && Ci == 128)) ? 1 : 0;
 }
-// persistent workgroups (two per CU); also the row count of wpart / bpart
-extern "C" int tdeed_narrow_conv1_bwd_grid(long M) {
+// persistent workgroups; also the row count of wpart / bpart
+extern "C" int tdeed_narrow_conv1_bwd_grid(long M, int Co, int Ci) {
   const long tiles = (M + 63) / 64;
-  return (int)(tiles < 512 ? tiles : 512);
+  const long cap = (Co == 64) ? 768 : 512;                       // resident workgroups: three per CU at 64 <- 32, two otherwise
+  return (int)(tiles < cap ? tiles : cap);
 }
 
 // dY, Z [M][Co] bf16; fa / fb / mean / rstd / w: conv1's BatchNorm (forward affine, batch statistics, weight); sums fp32 [2][Co]
 // = (sum g, sum g * xhat) of its backward (tdeed_bn_bwd_masked_from_parts leaves them); X [M][Ci]; Wt [Ci][Co] (the weight
 // transposed); R: shortcut gradient ([M][Ci], or with r_hi > 0 the rows of the even pixels of an r_hi x r_wi frame) or NULL;
 // dX [M][Ci]; use_mask: dX *= [X > 0]; bz / bmean (/ bzd / bmean_d) + bpart fp32 [grid][3][Ci]: the gradient sink's statistics
-// (NULL: none); wpart fp32 [grid][Co][Ci]: partial weight gradients, grid = tdeed_narrow_conv1_bwd_grid(M).
+// (NULL: none); wpart fp32 [grid][Co][Ci]: partial weight gradients, grid = tdeed_narrow_conv1_bwd_grid(M, Co, Ci).
 extern "C" int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int Co, int Ci, const float* fa, const float* fb,
                                       const float* mean, const float* rstd, const float* w, const float* sums, const void* X,
                                       const void* Wt, const void* R, long ldr, int r_hi, int r_wi, void* dX, int use_mask,
@@ -294,7 +338,7 @@ extern "C" int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int
   p.dX = (bf16_t*)dX; p.use_mask = use_mask;
   p.bz = (const bf16_t*)bz; p.bmean = bmean; p.bzd = bpart ? (const bf16_t*)bzd : nullptr; p.bmean_d = bmean_d; p.bpart = bpart;
   p.wpart = wpart; p.M = M; p.inv_M = 1.0f / (float)M;
-  const int grid = tdeed_narrow_conv1_bwd_grid(M);
+  const int grid = tdeed_narrow_conv1_bwd_grid(M, Co, Ci);
   hipStream_t st = (hipStream_t)stream;
   if (Co == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, st, p);
   else if (Ci == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 64>), dim3(grid), dim3(256), 0, st, p);

@@ -339,7 +339,7 @@ def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_
     ps, pq, stride, P = part
     sums = _f32((2, Co), dev)
     call("tdeed_bn_sums_from_parts", ptr(ps), ptr(pq), stride, P, Co, ptr(bn1[1]), ptr(sums), stream_ptr())
-    grid = _lib.load().tdeed_narrow_conv1_bwd_grid(M)
+    grid = _lib.load().tdeed_narrow_conv1_bwd_grid(M, Co, Ci)
     dx = torch.empty((M, Ci), dtype=z1.dtype, device=dev)
     wpart = _f32((grid, Co, Ci), dev)
     bpart = None
