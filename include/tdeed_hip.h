@@ -454,6 +454,10 @@ int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b,
  * shortcut conv of a downsampling bottleneck: its normalised map is never written) */
 int tdeed_bn_apply2(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
                     const float* rb, int relu, void* y, int dtype, void* stream);
+/* ... and y2 [M][Fp2]: a compact copy of output channels [0, F2) (zeros in [F2, Fp2)) -- the dense slice the next block's
+ * gate-shift module reads (what tdeed_gsf_slice would make with a pass of its own); ra / rb may be NULL */
+int tdeed_bn_apply_slice(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
+                         const float* rb, int relu, void* y, void* y2, int F2, int Fp2, int dtype, void* stream);
 /* BatchNorm (training) backward; when relu != 0 the ReLU mask comes from y (the block's output) or, with y NULL (no
  * residual in front of the ReLU), from z through the forward affine fa, fb (y > 0 <=> fa*z + fb > 0: one map less to
  * read); d_res (optional) receives the masked gradient = gradient of the residual summed in before the ReLU.  sums fp32

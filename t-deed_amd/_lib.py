@@ -68,6 +68,7 @@ _SIGS = {
     "tdeed_bn_slabs": ([c_long], c_int),
     "tdeed_bn_train_stats": ([P, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_bn_apply": ([P, c_long, c_int, P, P, P, c_int, P, c_int, P], c_int),
+    "tdeed_bn_apply_slice": ([P, c_long, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, P], c_int),
     "tdeed_bn_apply2": ([P, c_long, c_int, P, P, P, P, P, c_int, P, c_int, P], c_int),
     "tdeed_bn_train_bwd": ([P, P, P, c_int, c_long, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_fold_rows": ([P, c_long, c_int, c_int, c_int, P, c_long, P], c_int),

@@ -258,7 +258,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, const float* __restrict__ a,
                                                      const float* __restrict__ b, const T* __restrict__ res,
                                                      const float* __restrict__ ra, const float* __restrict__ rb, int relu,
-                                                     T* __restrict__ y, long M, int nch, int rpw) {
+                                                     T* __restrict__ y, long M, int nch, int rpw, T* __restrict__ y2 = nullptr,
+                                                     int F2 = 0, int Fp2 = 0) {
   constexpr int EPC = Chunk<T>::N;
   const RowMap mp(nch);
   if (!mp.on) return;
@@ -296,13 +297,26 @@ __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ z, co
           v[u][e] = relu ? fmaxf(o, 0.f) : o;
         }
         Chunk<T>::store(y + r * C + c0, v[u]);
+        if (y2 && c0 < Fp2) {               // compact copy of channels [0, F2) (zeros up to Fp2): the next block's gate-shift slice
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            if (c0 + e >= F2) v[u][e] = 0.f;
+          Chunk<T>::store(y2 + r * Fp2 + c0, v[u]);
+        }
       }
     }
   }
 }
 
 static int bn_apply_launch(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
-                           const float* rb, int relu, void* y, int dtype, void* stream);
+                           const float* rb, int relu, void* y, int dtype, void* stream, void* y2 = nullptr, int F2 = 0, int Fp2 = 0);
+// the same (ra / rb may be NULL) + y2 [M][Fp2]: a compact copy of output channels [0, F2), zeros in [F2, Fp2): the dense slice
+// the NEXT block's gate-shift module normalises and shifts (tdeed_gsf_slice's result, without its pass over the map)
+extern "C" int tdeed_bn_apply_slice(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
+                                    const float* rb, int relu, void* y, void* y2, int F2, int Fp2, int dtype, void* stream) {
+  TD_CHECK(y2 && F2 > 0 && Fp2 >= F2 && Fp2 % 8 == 0 && Fp2 <= C && !ra == !rb, "bn_apply_slice: bad slice arguments");
+  return bn_apply_launch(z, M, C, a, b, res, ra, rb, relu, y, dtype, stream, y2, F2, Fp2);
+}
 extern "C" int tdeed_bn_apply(const void* z, long M, int C, const float* a, const float* b, const void* res, int relu,
                               void* y, int dtype, void* stream) {
   return bn_apply_launch(z, M, C, a, b, res, nullptr, nullptr, relu, y, dtype, stream);
@@ -315,7 +329,7 @@ extern "C" int tdeed_bn_apply2(const void* z, long M, int C, const float* a, con
   return bn_apply_launch(z, M, C, a, b, res, ra, rb, relu, y, dtype, stream);
 }
 static int bn_apply_launch(const void* z, long M, int C, const float* a, const float* b, const void* res, const float* ra,
-                           const float* rb, int relu, void* y, int dtype, void* stream) {
+                           const float* rb, int relu, void* y, int dtype, void* stream, void* y2, int F2, int Fp2) {
   TD_CHECK(z && a && b && y && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "bn_apply: bad dtype %d", dtype);
@@ -326,10 +340,10 @@ static int bn_apply_launch(const void* z, long M, int C, const float* a, const f
   TD_CHECK(nwg < 0x7fffffffL, "bn_apply: too many rows");
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(affine_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)z, a, b, (const float*)res,
-                       ra, rb, relu, (float*)y, M, nch, rpw);
+                       ra, rb, relu, (float*)y, M, nch, rpw, (float*)y2, F2, Fp2);
   else
     hipLaunchKernelGGL(affine_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), 0, st, (const bf16_t*)z, a, b,
-                       (const bf16_t*)res, ra, rb, relu, (bf16_t*)y, M, nch, rpw);
+                       (const bf16_t*)res, ra, rb, relu, (bf16_t*)y, M, nch, rpw, (bf16_t*)y2, F2, Fp2);
   TD_LAUNCH_CHECK("bn_apply");
   return TDEED_OK;
 }

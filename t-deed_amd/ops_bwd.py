@@ -173,7 +173,7 @@ def bn_apply(z, a, b, res=None, relu=True, out=None):
 
 
 def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, res=None,
-                      relu=True, out=None, apply=True, res_affine=None):
+                      relu=True, out=None, apply=True, res_affine=None, slice_out=None):
     """BatchNorm(batch statistics) of z from per-channel partial sums a producer's epilogue wrote (gemm(colpart=...),
     gconv3x3(pooled_sq=...)) + the apply pass.  Returns (y, (mean, rstd, a, b))."""
     C = z.shape[-1]
@@ -191,7 +191,12 @@ def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.
         return None, (mean, rstd, a, bb)
     if out is None:
         out = torch.empty_like(z)
-    if res_affine is not None:                  # res is a raw conv output under its own BatchNorm affine (shortcut conv)
+    if slice_out is not None:                   # (F, xs): also the compact gate-shift slice of the next block
+        F2, xs = slice_out
+        ra, rb = res_affine if res_affine is not None else (None, None)
+        call("tdeed_bn_apply_slice", ptr(z), M, C, ptr(a), ptr(bb), ptr(res), ptr(ra), ptr(rb), int(relu), ptr(out), ptr(xs), F2,
+             xs.shape[-1], dtype_code(z.dtype), stream_ptr())
+    elif res_affine is not None:                # res is a raw conv output under its own BatchNorm affine (shortcut conv)
         call("tdeed_bn_apply2", ptr(z), M, C, ptr(a), ptr(bb), ptr(res), ptr(res_affine[0]), ptr(res_affine[1]), int(relu),
              ptr(out), dtype_code(z.dtype), stream_ptr())
     else:

@@ -122,9 +122,12 @@ class TrainEngine:
             y0, bn0 = B_.bn_train(z0, sd["_features.stem.bn.weight"], sd["_features.stem.bn.bias"], BN_EPS, 0.1,
                                   sd["_features.stem.bn.running_mean"], sd["_features.stem.bn.running_var"], relu=True)
         x = y0
-        for blk in self.blocks:
+        xs = None
+        for i, blk in enumerate(self.blocks):
             _lib.SCOPE = blk.blk.name + ".fwd"
-            x = blk.forward(x)
+            nxt = self.blocks[i + 1] if i + 1 < len(self.blocks) else None
+            x = blk.forward(x, xs=xs, next_fold=(nxt.blk.gsf_fold if nxt is not None and nxt.gs is not None else 0))
+            xs = blk.ctx.out_slice
         _lib.SCOPE = "temporal.fwd"
         hw = x.shape[1] * x.shape[2]
         feat = ops.avgpool_posenc(x, Bn, T, sd["temp_enc"])

@@ -30,6 +30,8 @@ RS_TRAIN = _os.environ.get("TDEED_TRAIN_RS", "1") == "1"
 DGRAD_STATS = _os.environ.get("TDEED_TRAIN_DGRAD_STATS", "1") == "1"
 # conv1's whole backward (BatchNorm apply + input gradient + weight gradient) of the narrow 800MF s1 / s2 layers in one launch
 NARROW_BWD = _os.environ.get("TDEED_TRAIN_NARROW_BWD", "1") == "1"
+# the next block's gate-shift slice written by this block's last BatchNorm-apply pass
+SLICE_OUT = _os.environ.get("TDEED_TRAIN_SLICE_OUT", "1") == "1"
 RS_MIN_ROWS = 60000
 
 
@@ -74,12 +76,13 @@ class GateShiftTrain:
         else:
             self.cw1 = self.cb1 = self.cw2 = self.cb2 = None
 
-    def forward(self, x):
-        """x (N,h,w,C) -> G (N*h*w, Fp): the module output in conv1's operand layout (pad columns = copies of x)."""
+    def forward(self, x, xs=None):
+        """x (N,h,w,C) -> G (N*h*w, Fp): the module output in conv1's operand layout (pad columns = copies of x).
+        xs: the dense slice x[..., :F] (zeros up to Fp) when the producer of x wrote it along (tdeed_bn_apply_slice)."""
         sd, pre, F, Fp, T = self.sd, self.pre, self.F, self.Fp, self.T
         N = x.shape[0]
         c = SimpleNamespace(x=x, B=N // T)
-        c.xs = B_.gsf_slice(x, F, Fp)
+        c.xs = xs if xs is not None else B_.gsf_slice(x, F, Fp)
         c.w_pad = self.w_pad
         c.mean, c.rstd, c.sa, c.sb = B_.bn_stats(c.xs, self.w_pad, self.b_pad, BN_EPS, 0.1, self.rm_pad, self.rv_pad)
         bufs = {}
@@ -186,7 +189,7 @@ class BottleneckTrain:
         self.se_w2 = sd[pre + ".se.fc2.weight"].reshape(C, Rd).contiguous()
         self.se_w1t, self.se_w2t = self.se_w1.t().contiguous(), self.se_w2.t().contiguous()
 
-    def _bn(self, z, name, res=None, relu=True, part=None, apply=True, res_affine=None):
+    def _bn(self, z, name, res=None, relu=True, part=None, apply=True, res_affine=None, slice_out=None):
         """BatchNorm(batch statistics) + residual + ReLU of a raw conv output.  part = (sums, sums of squares, row stride,
         rows): the per-channel partial sums the conv's own epilogue wrote (no second pass over z for the statistics).
         apply=False (with part): statistics and affine only, the map is applied by its consumers."""
@@ -195,7 +198,7 @@ class BottleneckTrain:
             ps, pq, stride, P = part
             return B_.bn_finalize_apply(z, ps, pq, stride, P, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1,
                                         sd[p + ".running_mean"], sd[p + ".running_var"], res=res, relu=relu, apply=apply,
-                                        res_affine=res_affine)
+                                        res_affine=res_affine, slice_out=slice_out)
         return B_.bn_train(z, sd[p + ".weight"], sd[p + ".bias"], BN_EPS, 0.1, sd[p + ".running_mean"],
                            sd[p + ".running_var"], res=res, relu=relu)
 
@@ -211,16 +214,19 @@ class BottleneckTrain:
         flat = cp.view(-1)
         return z, (flat, flat[N:], 2 * N, P)
 
-    def forward(self, x):
-        """x (N,h,w,Cin) activation dtype -> (N,h2,w2,Cout); ctx kept on self."""
+    def forward(self, x, xs=None, next_fold=0):
+        """x (N,h,w,Cin) activation dtype -> (N,h2,w2,Cout); ctx kept on self.  xs: the compact gate-shift slice of x when its
+        producer wrote one; next_fold: fold F of the NEXT block's gate-shift module -- this block's last pass then writes that
+        block's slice along (ctx.out_slice) instead of a tdeed_gsf_slice pass over the map."""
         blk, sd, pre = self.blk, self.sd, self.pre
         N, h, w, Cin = x.shape
         C = blk.cout
         c = SimpleNamespace(x=x)
         c.G = None
+        c.out_slice = None
         if self.gs is not None:
             Fp = self.gs.Fp
-            G = self.gs.forward(x)
+            G = self.gs.forward(x, xs=xs)
             if B_.wgrad_splice_ok(self.dt, N * h * w) and _os.environ.get("TDEED_TRAIN_SPLICE", "1") == "1":
                 # conv1 operand [G | x[..., Fp:]] is never built: the contraction and its weight gradient read the first Fp
                 # columns from G and the rest from x (shift.py:89-93 as an operand splice, like the inference path)
@@ -266,10 +272,15 @@ class BottleneckTrain:
         else:
             c.sc = x
             fuse_sc = False
+        so = None
+        if next_fold and part3 is not None and SLICE_OUT:
+            Fp2 = (next_fold + 7) // 8 * 8
+            c.out_slice = torch.empty((N * h2 * w2, Fp2), dtype=c.z3.dtype, device=c.z3.device)
+            so = (next_fold, c.out_slice)
         if fuse_sc:
-            c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.zd, relu=True, part=part3, res_affine=(c.bnd[2], c.bnd[3]))
+            c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.zd, relu=True, part=part3, res_affine=(c.bnd[2], c.bnd[3]), slice_out=so)
         else:
-            c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.sc, relu=True, part=part3)
+            c.out, c.bn3 = self._bn(c.z3, "conv3", res=c.sc, relu=True, part=part3, slice_out=so)
         self.ctx = c
         return c.out
 
