@@ -500,7 +500,7 @@ int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C,
                                    const float* w, const float* fa, const float* fb, const float* part_s, const float* part_q,
                                    long pstride, int P, float* sums, void* dz, int dtype, void* stream);
 /* conv1 backward of a NARROW training bottleneck in one launch (csrc/trunk_bwd3.hip; bf16; (Co, Ci) = (64, 32), (128, 64),
- * (128, 128): RegNetY-800MF s1 / s2): from conv2's input gradient dY and conv1's raw output Z ([M][Co]) the BatchNorm + ReLU
+ * (128, 128), (64, 64): RegNetY-800MF s1 / s2; with fa = 0, fb = 1 and no R / sink also conv3's backward there): from conv2's input gradient dY and conv1's raw output Z ([M][Co]) the BatchNorm + ReLU
  * backward dz1 (never stored), the input gradient dX [M][Ci] = dz1 @ W1 + shortcut gradient, masked by [X > 0] with the
  * gradient sink's column sums (as tdeed_gemm_dgrad), and the partial weight gradients dz1^T @ X.
  * fa / fb / mean / rstd / w: conv1's BatchNorm; sums fp32 [2][Co] = (sum g, sum g xhat) of its backward; Wt [Ci][Co] = W1^T;

@@ -1,5 +1,6 @@
 // conv1 backward of a NARROW training bottleneck in ONE launch (bf16; RegNetY-800MF s1.b1 64 <- 32, s2.b1 128 <- 64,
-// s2.b2/b3 128 <- 128 channels; timm Bottleneck.conv1 = ConvNormAct under autograd, /root/reference/model/model.py:265-324):
+// s2.b2/b3 128 <- 128 channels; with fa = 0, fb = 1 (no ReLU between the BatchNorm and the conv), no shortcut gradient and no
+// sink the same launch is conv3's backward of those blocks: 64 <- 64, 128 <- 128; timm Bottleneck.conv1 = ConvNormAct under autograd, /root/reference/model/model.py:265-324):
 //
 //   d_y1 (conv2's input gradient), z1 (conv1's raw output)            -- read ONCE
 //     -> dz1 = k1 * g + k2 * z1 + k3,  g = d_y1 * [fa z1 + fb > 0]     (BatchNorm + ReLU backward, statistics given)
@@ -31,6 +32,7 @@ struct NbwP {
 // waves WN x WK over (output channels, input channels) of the weight gradient; each wave NTW x KTW accumulator tiles
 template <int CO, int CI> struct NbwGeom;
 template <> struct NbwGeom<64, 32> { static constexpr int WN = 4, WK = 1; };
+template <> struct NbwGeom<64, 64> { static constexpr int WN = 2, WK = 2; };
 template <> struct NbwGeom<128, 64> { static constexpr int WN = 2, WK = 2; };
 template <> struct NbwGeom<128, 128> { static constexpr int WN = 2, WK = 2; };
 
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
 }
 
 extern "C" int tdeed_narrow_conv1_bwd_fits(int Co, int Ci) {
-  return ((Co == 64 && Ci == 32) || (Co == 128 && Ci == 64) || (Co == 128 && Ci == 128)) ? 1 : 0;
+  return ((Co == 64 && (Ci == 32 || Ci == 64)) || (Co == 128 && Ci == 64) || (Co == 128 && Ci == 128)) ? 1 : 0;
 }
 // persistent workgroups; also the row count of wpart / bpart
 extern "C" int tdeed_narrow_conv1_bwd_grid(long M, int Co, int Ci) {
@@ -340,7 +342,8 @@ extern "C" int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int
   p.wpart = wpart; p.M = M; p.inv_M = 1.0f / (float)M;
   const int grid = tdeed_narrow_conv1_bwd_grid(M, Co, Ci);
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, st, p);
+  if (Co == 64 && Ci == 32) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, st, p);
+  else if (Co == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 64>), dim3(grid), dim3(256), 0, st, p);
   else if (Ci == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 64>), dim3(grid), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 128>), dim3(grid), dim3(256), 0, st, p);
   TD_LAUNCH_CHECK("narrow_conv1_bwd");

@@ -333,7 +333,7 @@ def narrow_conv1_bwd_fits(Co, Ci, dtype):
     return dtype == torch.bfloat16 and _lib.load().tdeed_narrow_conv1_bwd_fits(Co, Ci) != 0
 
 
-def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_hw=None):
+def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_hw=None, sums=None):
     """conv1 backward of a narrow bottleneck in one launch (tdeed_narrow_conv1_bwd): d_y1 / z1 (.., Co), bn1 = (mean, rstd, a, b),
     w its weight, part = the masked column-sum partials conv2's input-gradient launch left, x (.., Ci) conv1's input (= the
     sink's mask), wt (Ci, Co) the transposed weight, residual: shortcut gradient (r_hw = (hi, wi): on the even pixels only).
@@ -341,9 +341,10 @@ def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_
     Co, Ci = z1.shape[-1], x.shape[-1]
     M = z1.numel() // Co
     dev = z1.device
-    ps, pq, stride, P = part
-    sums = _f32((2, Co), dev)
-    call("tdeed_bn_sums_from_parts", ptr(ps), ptr(pq), stride, P, Co, ptr(bn1[1]), ptr(sums), stream_ptr())
+    if sums is None:
+        ps, pq, stride, P = part
+        sums = _f32((2, Co), dev)
+        call("tdeed_bn_sums_from_parts", ptr(ps), ptr(pq), stride, P, Co, ptr(bn1[1]), ptr(sums), stream_ptr())
     grid = _lib.load().tdeed_narrow_conv1_bwd_grid(M, Co, Ci)
     dx = torch.empty((M, Ci), dtype=z1.dtype, device=dev)
     wpart = _f32((grid, Co, Ci), dev)
@@ -420,6 +421,12 @@ def bn_bwd_from_parts(z, g, ctx, w, sink, q=1, want_dz=True):
          ptr(pb), (pb.shape[0] if pb is not None else 0), sink.nB, q, ptr(tmp), ptr(sums), ptr(dz), dtype_code(z.dtype),
          stream_ptr())
     return dz, sums[1], sums[0]
+
+
+def bn_sums_from_sink(z, g, ctx, w, sink, q=1):
+    """(sums fp32 [2][C]) of the BatchNorm backward whose column-sum partials lie in `sink` (no apply pass)"""
+    _, dw, _ = bn_bwd_from_parts(z, g, ctx, w, sink, q=q, want_dz=False)
+    return dw._base if dw._base is not None else dw
 
 
 def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True, in_affine=None):

@@ -303,19 +303,30 @@ class BottleneckTrain:
             p = (self.c1 if name == "conv1" else f"{pre}.{name}") + ".bn"
             grads[p + ".weight"], grads[p + ".bias"] = dw, db
 
-        if sink_in is not None:
-            # only the apply pass is left of this BatchNorm backward, and dout itself is the shortcut's gradient
-            dz3, dw, db = B_.bn_bwd_from_parts(c.z3, dout, c.bn3, sd[pre + ".conv3.bn.weight"], sink_in, q=1)
+        if sink_in is not None and NARROW_BWD and B_.narrow_conv1_bwd_fits(C, C, dout.dtype):
+            # narrow layers: conv3's BatchNorm apply pass, its input gradient and its weight gradient in one launch (the conv1
+            # kernel with no ReLU between BatchNorm and conv: fa = 0, fb = 1; dz3 lives in LDS only)
+            sums3 = B_.bn_sums_from_sink(c.z3, dout, c.bn3, sd[pre + ".conv3.bn.weight"], sink_in, q=1)
+            d_y2s, dW3, dw, db = B_.narrow_conv1_bwd(dout, c.z3, (c.bn3[0], c.bn3[1], self.zero, self.one),
+                                                     sd[pre + ".conv3.bn.weight"], None, c.y2s, self.w3.wt, sums=sums3)
+            d_y2s = d_y2s.view(N, h2, w2, C)
             d_sc = dout
+            bn_names("conv3", dw, db)
+            grads[pre + ".conv3.conv.weight"] = dW3.reshape(sd[pre + ".conv3.conv.weight"].shape)
         else:
-            dz3, d_sc, dw, db = B_.bn_train_bwd(c.z3, dout, c.out, c.bn3, sd[pre + ".conv3.bn.weight"], relu=True, want_res=True)
-        bn_names("conv3", dw, db)
-        if self.w3.wst_ws is not None and N * hw2 >= RS_MIN_ROWS:
-            d_y2s = ops.gemm_rs(dz3, self.w3.wst_ws, C, C, M=N * hw2).view(N, h2, w2, C)
-        else:
-            d_y2s = ops.gemm(dz3, self.w3.wt, None, None, ops.ACT_NONE).view(N, h2, w2, C)
-        grads[pre + ".conv3.conv.weight"] = B_.wgrad(dz3, c.y2s, with_bias=False, M=N * hw2)[0].reshape(
-            sd[pre + ".conv3.conv.weight"].shape)
+            if sink_in is not None:
+                # only the apply pass is left of this BatchNorm backward, and dout itself is the shortcut's gradient
+                dz3, dw, db = B_.bn_bwd_from_parts(c.z3, dout, c.bn3, sd[pre + ".conv3.bn.weight"], sink_in, q=1)
+                d_sc = dout
+            else:
+                dz3, d_sc, dw, db = B_.bn_train_bwd(c.z3, dout, c.out, c.bn3, sd[pre + ".conv3.bn.weight"], relu=True, want_res=True)
+            bn_names("conv3", dw, db)
+            if self.w3.wst_ws is not None and N * hw2 >= RS_MIN_ROWS:
+                d_y2s = ops.gemm_rs(dz3, self.w3.wst_ws, C, C, M=N * hw2).view(N, h2, w2, C)
+            else:
+                d_y2s = ops.gemm(dz3, self.w3.wt, None, None, ops.ACT_NONE).view(N, h2, w2, C)
+            grads[pre + ".conv3.conv.weight"] = B_.wgrad(dz3, c.y2s, with_bias=False, M=N * hw2)[0].reshape(
+                sd[pre + ".conv3.conv.weight"].shape)
         # SE + conv2's BatchNorm
         if SE_BN_FUSED and len(c.bn2) >= 4:
             # one pass over (d_y2s, z2) for every per-frame sum the SE gate gradient and the BatchNorm statistics need, one
