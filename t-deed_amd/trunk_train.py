@@ -377,14 +377,22 @@ class BottleneckTrain:
             res, r_hw = d_sc.view(-1, Cin) if not blk.has_downsample else None, None
             if blk.has_downsample:
                 wdn = sd[pre + ".downsample.bn.weight"]
-                if sink_in is not None:
-                    dzd, dw, db = B_.bn_bwd_from_parts(c.zd, dout, c.bnd, wdn, sink_in, q=2)
+                if sink_in is not None and B_.narrow_conv1_bwd_fits(C, Cin, dout.dtype):
+                    # the shortcut conv's backward through the same one-launch kernel (no ReLU, no sink)
+                    sums_d = B_.bn_sums_from_sink(c.zd, dout, c.bnd, wdn, sink_in, q=2)
+                    res, dWd, dw, db = B_.narrow_conv1_bwd(dout, c.zd, (c.bnd[0], c.bnd[1], self.zero, self.one), wdn, None,
+                                                           c.xs, self.wd.wt, sums=sums_d)
+                    bn_names("downsample", dw, db)
+                    grads[pre + ".downsample.conv.weight"] = dWd.reshape(sd[pre + ".downsample.conv.weight"].shape)
                 else:
-                    dzd, _, dw, db = B_.bn_train_bwd(c.zd, d_sc, None, c.bnd, wdn, relu=False)
-                bn_names("downsample", dw, db)
-                res = ops.gemm(dzd, self.wd.wt, None, None, ops.ACT_NONE)
-                grads[pre + ".downsample.conv.weight"] = B_.wgrad(dzd, c.xs, with_bias=False, M=N * hw2)[0].reshape(
-                    sd[pre + ".downsample.conv.weight"].shape)
+                    if sink_in is not None:
+                        dzd, dw, db = B_.bn_bwd_from_parts(c.zd, dout, c.bnd, wdn, sink_in, q=2)
+                    else:
+                        dzd, _, dw, db = B_.bn_train_bwd(c.zd, d_sc, None, c.bnd, wdn, relu=False)
+                    bn_names("downsample", dw, db)
+                    res = ops.gemm(dzd, self.wd.wt, None, None, ops.ACT_NONE)
+                    grads[pre + ".downsample.conv.weight"] = B_.wgrad(dzd, c.xs, with_bias=False, M=N * hw2)[0].reshape(
+                        sd[pre + ".downsample.conv.weight"].shape)
                 r_hw = (h, w) if blk.stride == 2 else None
             dx, dW1, dw, db = B_.narrow_conv1_bwd(d_y1, c.z1, c.bn1, sd[self.c1 + ".bn.weight"], part1, c.x, self.w1.wt,
                                                   sink=sink_out, residual=res, r_hw=r_hw)
