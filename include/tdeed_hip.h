@@ -370,6 +370,10 @@ int tdeed_process_prediction(const float* head_out, int B, int T, int ld, int K1
 
 /* ---- utility ------------------------------------------------------------------------------- */
 int tdeed_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+/* the large dense weights' kernel copies in one launch: tab = device array of n entries of six 8-byte fields {const float* src
+ * (an fp32 [R][C] matrix), long R, long C, void* dst ([R][C] in `dtype`, or NULL), void* dstT ([C][R] in `dtype`, or NULL),
+ * long first_tile}; tiles = sum over the entries of ceil(R/32) * ceil(C/32), first_tile its running prefix */
+int tdeed_multi_cast_transpose(const void* tab, int n, long tiles, int dtype, void* stream);
 /* out[i] = idx[i] ? src[idx[i] - 1] : 0 for i < n (n a multiple of 8), out fp32 or bf16: all kernel-layout copies of the
  * master parameters (casts, transposes, MFMA fragment orders, zero pads) refreshed in one launch from a recorded index
  * table; replaces the per-tensor `.to(bf16)` / `.t().contiguous()` of a framework step. */

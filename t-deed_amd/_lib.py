@@ -154,6 +154,7 @@ _SIGS = {
     "tdeed_process_prediction": ([P, c_int, c_int, c_int, c_int, c_int, P, P, P], c_int),
     "tdeed_gather_cast": ([P, P, c_long, P, c_int, P], c_int),
     "tdeed_cast_f32_to_bf16": ([P, P, c_long, P], c_int),
+    "tdeed_multi_cast_transpose": ([P, c_int, c_long, c_int, P], c_int),
     "tdeed_fill_u8_hash": ([P, c_long, c_uint64, P], c_int),
     "tdeed_comm_unique_id": ([P], c_int),
     "tdeed_comm_init": ([POINTER(c_void_p), P, c_int, c_int], c_int),

@@ -34,6 +34,9 @@ def recording():
 # element (measured 6.8 ms for the 140 M packed elements of the 800MF model), an LDS-tiled transpose streams.  Below this
 # size the gather is cheaper than a launch.
 DIRECT_MIN = 65536
+import os as _os
+# the large weights' casts / transposes as one table-driven launch (TDEED_REPACK_MULTI=0: one cast + one transpose launch each)
+MULTI_DIRECT = _os.environ.get("TDEED_REPACK_MULTI", "1") == "1"
 _plan = None                                                     # the PackPlan being recorded
 
 
@@ -234,11 +237,53 @@ class PackPlan:
         return self
 
     # ------------------------------------------------------------------ steady state
+    def _direct_table(self):
+        """The recorded large-weight casts / transposes as ONE table for tdeed_multi_cast_transpose: every op must be a cast of a
+        master run (bf16 mode) optionally followed by transposes of its output, or a transpose of a master view (fp32 mode);
+        anything else keeps its own launch.  Returns (device table, entries, tiles, dtype code, leftover ops)."""
+        ents, left = {}, []
+        flat = self.params.flat
+        for op in self.direct:
+            if op[0] == "cast":
+                _, off, n, out = op
+                C = out.shape[-1]
+                ents[id(out)] = dict(src=flat.data_ptr() + 4 * off, R=n // C, C=C, dst=out.data_ptr(), dstT=0, dt=out.dtype)
+        for op in self.direct:
+            if op[0] != "transpose":
+                continue
+            _, src, out = op
+            e = ents.get(id(src))
+            if e is not None and e["dstT"] == 0 and src.dim() == 2:
+                e["dstT"] = out.data_ptr()
+            elif (src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous()
+                  and flat.data_ptr() <= src.data_ptr() < flat.data_ptr() + 4 * flat.numel()):
+                ents[id(out)] = dict(src=src.data_ptr(), R=src.shape[0], C=src.shape[1], dst=0, dstT=out.data_ptr(), dt=out.dtype)
+            else:
+                left.append(op)
+        rows, tiles = [], 0
+        dts = {e["dt"] for e in ents.values()}
+        if len(dts) != 1:
+            return None, 0, 0, 0, list(self.direct)
+        for e in ents.values():
+            rows.append((e["src"], e["R"], e["C"], e["dst"], e["dstT"], tiles))
+            tiles += ((e["R"] + 31) // 32) * ((e["C"] + 31) // 32)
+        tab = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        return tab, len(rows), tiles, dtype_code(dts.pop()), left
+
     def run(self):
         for dt, tab in self.tables.items():
             call("tdeed_gather_cast", ptr(self.params.flat), ptr(tab), tab.numel(), ptr(self.bufs[dt]), dtype_code(dt),
                  stream_ptr())
-        for op in self.direct:
+        if self.direct and MULTI_DIRECT:
+            if getattr(self, "_dt", None) is None:
+                self._dt = self._direct_table()
+            tab, n, tiles, dc, left = self._dt
+            if n:
+                call("tdeed_multi_cast_transpose", ptr(tab), n, tiles, dc, stream_ptr())
+            ops_ = left
+        else:
+            ops_ = self.direct
+        for op in ops_:
             if op[0] == "cast":
                 _, off, n, out = op
                 call("tdeed_cast_f32_to_bf16", ptr(self.params.flat[off:off + n]), ptr(out), n, stream_ptr())
