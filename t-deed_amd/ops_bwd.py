@@ -182,8 +182,12 @@ def bn_finalize_apply(z, part_s, part_q, pstride, P, w, b, eps=1e-5, momentum=0.
     mean, rstd, a, bb = (_f32((C,), dev) for _ in range(4))
     if P > 2048:                                 # one partial row per (frame, band): fold to 64 rows first, chip-wide
         tmp = _f32((64, 2, C), dev)
-        call("tdeed_fold_rows", ptr(part_s), pstride, P, C, 64, ptr(tmp), 2 * C, stream_ptr())
-        call("tdeed_fold_rows", ptr(part_q), pstride, P, C, 64, ptr(tmp.view(-1)[C:]), 2 * C, stream_ptr())
+        if pstride == 2 * C and part_q.data_ptr() == part_s.data_ptr() + 4 * C:
+            # a contraction's [P][2][C] partials: sums and sums of squares are one row of 2C floats, folded by one launch
+            call("tdeed_fold_rows", ptr(part_s), pstride, P, 2 * C, 64, ptr(tmp), 2 * C, stream_ptr())
+        else:
+            call("tdeed_fold_rows", ptr(part_s), pstride, P, C, 64, ptr(tmp), 2 * C, stream_ptr())
+            call("tdeed_fold_rows", ptr(part_q), pstride, P, C, 64, ptr(tmp.view(-1)[C:]), 2 * C, stream_ptr())
         part_s, part_q, pstride, P = tmp.view(-1), tmp.view(-1)[C:], 2 * C, 64
     call("tdeed_bn_finalize", ptr(part_s), ptr(part_q), pstride, P, M, C, ptr(w), ptr(b), eps, momentum, ptr(mean),
          ptr(rstd), ptr(a), ptr(bb), ptr(run_mean), ptr(run_var), stream_ptr())
