@@ -18,7 +18,8 @@ import time
 from collections import defaultdict
 
 # training-step kernels (trunk_bwd.hip, sgp_bwd.hip, gsf_bwd.hip, train.hip) first: their names contain inference names
-TRAIN_FAMILY = [("se_bn_", "se_bn_bwd"), ("bn_parts_finalize", "bn_bwd"), ("gsf_add_cols", "gate_shift_bwd"),
+TRAIN_FAMILY = [("narrow_conv1_bwd", "narrow_conv_bwd"), ("multi_cast_transpose", "repack"), ("bn_sums_from_parts", "bn_bwd"),
+                ("se_bn_", "se_bn_bwd"), ("bn_parts_finalize", "bn_bwd"), ("gsf_add_cols", "gate_shift_bwd"),
                 ("bn_bwd_apply", "bn_bwd"), ("colstats", "bn_bwd"), ("wgrad", "wgrad"), ("gconv_dgrad", "gconv_bwd"),
                 ("gconv_wgrad", "gconv_bwd"), ("gsf_bwd", "gate_shift_bwd"), ("affine_kernel", "bn_apply"),
                 ("bn_apply", "bn_apply"), ("pool_mean", "se_train"), ("scale_rows", "se_train"), ("se_train", "se_train"),
