@@ -404,7 +404,10 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
     if hasattr(pool, "make_slots"):          # worker processes decode into shared, page-locked slots
         slots = pool.make_slots(depth, shape)
     else:
-        slots = [torch.zeros(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        # (page-locked when a GPU runtime is there, like make_slots: the decode logic itself also runs on a GPU-less host)
+        slots = [torch.zeros(shape, dtype=torch.uint8) for _ in range(depth)]
+        if torch.cuda.is_available():
+            slots = [t_.pin_memory() for t_ in slots]
     holders = [SimpleNamespace(event=None) for _ in range(depth)]
     try:
         for bi, lo in enumerate(range(0, len(clips) - batch_size + 1, batch_size)):

@@ -142,3 +142,77 @@ def test_process_decode_pool_matches_read_frame(tmp_path):
     assert all(p.poll() is not None for p in procs)
     import os
     assert not any(os.path.exists("/dev/shm/" + nm.lstrip("/")) for nm in names)
+
+
+def test_a_dead_decode_worker_fails_its_jobs_at_once_and_leaves_the_rotation(tmp_path):
+    """when a worker process dies, the jobs it still owed fail immediately with a clear error (no 120 s timeout per
+    result), the worker leaves the round-robin, the remaining workers keep serving, and with none left submit raises."""
+    import time
+    from PIL import Image
+    rs = np.random.RandomState(5)
+    for i in range(4):
+        Image.fromarray(rs.randint(0, 256, (16, 16, 3), dtype=np.uint8)).save(tmp_path / f"frame{i}.jpg", quality=92)
+    pool = feeder.ProcessDecodePool(2)
+    try:
+        slot = pool.make_slots(1, (4, 3, 16, 16))[0]
+        pool.decode([(str(tmp_path / f"frame{i}.jpg"), slot[i]) for i in range(4)])          # both workers alive
+        pool._w[0].kill()
+        pool._w[0].wait(timeout=10)
+        t0 = time.time()
+        while pool._alive[0] and time.time() - t0 < 10:                                      # the reader thread sees EOF
+            time.sleep(0.05)
+        assert not pool._alive[0] and pool._alive[1]
+        ref = torch.stack([feeder.read_frame(str(tmp_path / f"frame{i}.jpg")) for i in range(4)])
+        slot.zero_()
+        t0 = time.time()
+        pool.decode([(str(tmp_path / f"frame{i}.jpg"), slot[i]) for i in range(4)])          # all four go to worker 1
+        assert time.time() - t0 < 30 and torch.equal(slot, ref)
+        # a job outstanding on a worker that dies is failed by the reader thread, at once
+        pool._w[1].stdin.write("")                                                          # (pipe still open)
+        acks = pool.submit([(str(tmp_path / "frame0.jpg"), slot[0])])
+        pool._w[1].kill()
+        t0 = time.time()
+        try:
+            acks[0].result(timeout=30)
+            finished = True                                                                  # it had answered before the kill
+        except RuntimeError as e:
+            finished = False
+            assert "exited" in str(e) or "gone" in str(e)
+        assert time.time() - t0 < 20, finished
+        t0 = time.time()
+        while pool._alive[1] and time.time() - t0 < 10:
+            time.sleep(0.05)
+        with pytest.raises(RuntimeError, match="no live decode worker"):
+            pool.submit([(str(tmp_path / "frame0.jpg"), slot[0])])
+    finally:
+        pool.close()
+
+
+def test_clip_batches_waits_for_the_upload_that_last_read_a_slot(tmp_path):
+    """a staging slot is decoded into again only after the event the consumer (prefetch) left in the batch's `_src`
+    holder has completed; rows behind a clip's real frames are zeroed even with pad=False."""
+    from PIL import Image
+    rs = np.random.RandomState(6)
+    for i in range(3):
+        Image.fromarray(rs.randint(1, 256, (16, 16, 3), dtype=np.uint8)).save(tmp_path / f"frame{i}.jpg", quality=92)
+
+    class Ev:
+        def __init__(self):
+            self.waited = 0
+
+        def synchronize(self):
+            self.waited += 1
+
+    # every clip: 3 real frames + 1 missing at the end (pad_end = 1), clip_len 4
+    clips = [dict(paths=[str(tmp_path), 0, 0, 1, -1, 4], stride=1)] * 6
+    evs = []
+    gen = feeder.clip_batches(clips, 1, (3, 16, 16), 4, pool=feeder.DecodePool(2), depth=2, pad=False)
+    for bi, b in enumerate(gen):
+        assert int(b["frame"][0, 3].sum()) == 0 and int(b["frame"][0, 2].sum()) > 0         # tail row zeroed, real rows decoded
+        b["frame"][0, 3].fill_(9)                                                           # stale content a later batch must not show
+        ev = Ev()
+        b["_src"].event = ev                                                                # what prefetch does after ring.upload
+        evs.append(ev)
+    assert len(evs) == 6
+    # slots rotate with depth 2: the events of batches 0..3 were waited for exactly once (before batches 2..5 decoded)
+    assert [e.waited for e in evs] == [1, 1, 1, 1, 0, 0]
