@@ -242,7 +242,7 @@ struct GcStat {
   const bf16_t* z; const float* fa; const float* fb; const float* mean;
 };
 template <int STRIDE>
-__device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float (*red)[16], float (*redq)[16], int Wi, int C,
+__device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float (*red)[32], float (*redq)[32], int Wi, int C,
                                                const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
                                                const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                float* __restrict__ pooled, float* __restrict__ pooled_sq, int Ho, int Wo,
@@ -253,6 +253,153 @@ __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int q = lane >> 4, pl = lane & 15;
   const int units = CSP >> 4;
+  if (units >= 2) {
+    // ---- pair form: a wave serves TWO adjacent 16-channel units on the same 16 pixels, then swaps accumulator rows between
+    // the two tiles (v_permlane16_swap) so that a lane holds 8 consecutive channels: one 16-byte store per lane, 64 contiguous
+    // bytes per pixel and wave instruction.  With one unit per wave the stores (and the statistics loads) are 16 pixels x 32
+    // bytes, a shape that moves the same bytes ~1.5x slower (tools/ubench/access_shape.hip: 4.3 vs 6.2 TB/s).  Two independent
+    // accumulator chains per tile also keep the MFMA pipe busier than five dependent MFMAs.
+    const int pairs = units >> 1, pr = wv % pairs, mstep = 4 / pairs;
+    bf16x8 wfA[5], wfB[5];
+    const long ubase = ((long)(slab * 4 + 2 * pr) * 5) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      wfA[ks] = wfrag[ubase + ks * 64];
+      wfB[ks] = wfrag[ubase + (5 + ks) * 64];
+    }
+    int off[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int sidx = 4 * ks + q;
+      const int half = sidx / 9, tap = sidx - half * 9;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      off[ks] = sidx < 18 ? (dy * WP + dx) * PS + half * 16 + pr * 64 : pr * 64;
+    }
+    const int chA = cs0 + pr * 32 + q * 4, chB = chA + 16;        // accumulator rows: 4 channels of unit A, 4 of unit B
+    const int chS = cs0 + pr * 32 + (q & 1) * 16 + (q >> 1) * 8;  // after the swap: this lane's 8 consecutive channels
+    float scA[4], shA[4], scB[4], shB[4], psA[4], psB[4], pqA[4], pqB[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool oka = chA + r < C, okb = chB + r < C;
+      scA[r] = oka ? scale[chA + r] : 0.f;
+      shA[r] = oka ? shift[chA + r] : 0.f;
+      scB[r] = okb ? scale[chB + r] : 0.f;
+      shB[r] = okb ? shift[chB + r] : 0.f;
+      psA[r] = psB[r] = pqA[r] = pqB[r] = 0.f;
+    }
+    float faA[4], fbA[4], muA[4], faB[4], fbB[4], muB[4];
+    if (bst.z) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ca = min(chA + r, C - 1), cb = min(chB + r, C - 1);
+        faA[r] = bst.fa[ca]; fbA[r] = bst.fb[ca]; muA[r] = bst.mean[ca];
+        faB[r] = bst.fa[cb]; fbB[r] = bst.fb[cb]; muB[r] = bst.mean[cb];
+      }
+    }
+    const int npix = nrows_out * Wo;
+    const int ntiles = (npix + 15) >> 4;
+    bf16_t* yout = y + ((long)n * Ho + oy0) * Wo * C;
+    const bf16_t* zin = bst.z ? bst.z + ((long)n * Ho + oy0) * Wo * C : nullptr;
+    const IDiv dwo(Wo);
+    const bool sok = chS < C;                                     // (C is a multiple of 8: a chunk is inside or outside)
+    for (int mt = wv / pairs; mt < ntiles; mt += mstep) {
+      const int p = mt * 16 + pl;
+      const bool pok = p < npix;
+      const int pc = pok ? p : 0;
+      int oyl, ox;
+      dwo.divmod(pc, oyl, ox);
+      const unsigned char* base = tile + ((long)(oyl * STRIDE) * WP + ox * STRIDE) * PS;
+      u32x4 zs = {0u, 0u, 0u, 0u};
+      if (zin) zs = *reinterpret_cast<const u32x4*>(zin + (long)pc * C + (sok ? chS : 0));   // travels under the MFMA chains
+      f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const bf16x8 xa = *reinterpret_cast<const bf16x8*>(base + off[ks]);
+        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(base + off[ks] + 32);
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], xa, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], xb, accB, 0, 0, 0);
+      }
+      bf16x4 oA, oB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float va = accA[r] * scA[r] + shA[r], vb = accB[r] * scB[r] + shB[r];
+        oA[r] = (bf16_t)(relu ? fmaxf(va, 0.f) : va);
+        oB[r] = (bf16_t)(relu ? fmaxf(vb, 0.f) : vb);
+      }
+      if (zin) {
+        // the statistics map arrives in the stored (swapped) layout: the same swap takes it back to accumulator rows
+        const auto z0 = __builtin_amdgcn_permlane16_swap(zs[0], zs[2], false, false);
+        const auto z1 = __builtin_amdgcn_permlane16_swap(zs[1], zs[3], false, false);
+        const u32x2 za2 = {z0[0], z1[0]}, zb2 = {z0[1], z1[1]};
+        const bf16x4 zA = *reinterpret_cast<const bf16x4*>(&za2), zB = *reinterpret_cast<const bf16x4*>(&zb2);
+        if (pok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float za = (float)zA[r], zb = (float)zB[r];
+            const float ga = (chA + r < C && fmaf(za, faA[r], fbA[r]) > 0.f) ? (float)oA[r] : 0.f;
+            const float gb = (chB + r < C && fmaf(zb, faB[r], fbB[r]) > 0.f) ? (float)oB[r] : 0.f;
+            psA[r] += ga;
+            pqA[r] = fmaf(ga, za - muA[r], pqA[r]);
+            psB[r] += gb;
+            pqB[r] = fmaf(gb, zb - muB[r], pqB[r]);
+          }
+        }
+      } else if (pok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          psA[r] += (float)oA[r];
+          pqA[r] = fmaf((float)oA[r], (float)oA[r], pqA[r]);
+          psB[r] += (float)oB[r];
+          pqB[r] = fmaf((float)oB[r], (float)oB[r], pqB[r]);
+        }
+      }
+      const u32x2 a2 = *reinterpret_cast<const u32x2*>(&oA), b2 = *reinterpret_cast<const u32x2*>(&oB);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(a2[0], b2[0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(a2[1], b2[1], false, false);
+      if (pok && sok) *reinterpret_cast<u32x4*>(yout + (long)pc * C + chS) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+    }
+    // ---- squeeze partial sums: lanes sharing q, then the waves sharing the pair (fixed order)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float va = psA[r], vb = psB[r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        va += __shfl_xor(va, o, 64);
+        vb += __shfl_xor(vb, o, 64);
+      }
+      if (pl == 0) {
+        red[wv][q * 4 + r] = va;
+        red[wv][16 + q * 4 + r] = vb;
+      }
+      if (pooled_sq) {
+        float wa = pqA[r], wb = pqB[r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          wa += __shfl_xor(wa, o, 64);
+          wb += __shfl_xor(wb, o, 64);
+        }
+        if (pl == 0) {
+          redq[wv][q * 4 + r] = wa;
+          redq[wv][16 + q * 4 + r] = wb;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < units * 16) {
+      const int u = threadIdx.x >> 4, cc = threadIdx.x & 15;
+      float sres = 0.f, qres = 0.f;
+      for (int w2 = u >> 1; w2 < 4; w2 += pairs) {
+        sres += red[w2][(u & 1) * 16 + cc];
+        if (pooled_sq) qres += redq[w2][(u & 1) * 16 + cc];
+      }
+      const int ch = cs0 + u * 16 + cc;
+      if (ch < C) {
+        pooled[((long)n * nbands + bnd) * C + ch] = sres;
+        if (pooled_sq) pooled_sq[((long)n * nbands + bnd) * C + ch] = qres;
+      }
+    }
+    return;
+  }
   const int unit = wv % units;
   const int mstep = 4 / units;
   // weights of this unit: 5 k-steps
@@ -372,8 +519,8 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
                                                             int Ho, int Wo, int band, int nbands, int CSP, int PS,
                                                             int rows_in, int relu, const GcStat bst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
-  __shared__ float red[4][16];
-  __shared__ float redq[4][16];
+  __shared__ float red[4][32];
+  __shared__ float redq[4][32];
   // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
   const int nslabs_ = (C + CSP - 1) / CSP;
@@ -457,8 +604,8 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
                                                             float* __restrict__ pooled, int Ho, int Wo, int band, int nbands,
                                                             int CSP, int PS, int rows_in, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
-  __shared__ float red[4][16];
-  __shared__ float redq[4][16];
+  __shared__ float red[4][32];
+  __shared__ float redq[4][32];
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
   const int nslabs_ = (C + CSP - 1) / CSP;
   const int slab = (int)(lid % nslabs_);

@@ -1018,22 +1018,34 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_mfma_kernel(const bf16_t* 
   const int CH = min(64, C - c0), nck = ((CH + 15) >> 4) * 2;   // 16-byte chunks staged (an odd 8-channel tail is zero-padded)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4, ts = kq >> 1, pl = lane & 15;
-  const bool active = c0 + wv * 16 < C;
-  const int u = (c0 >> 4) + wv;
-  bf16x8 af[5];
+  // a wave serves a PAIR of adjacent 16-channel units (pr) on two of the four 16-pixel tiles (mh, mh + 2): after a row swap
+  // between the two accumulators (v_permlane16_swap) a lane holds 8 consecutive channels -- 16-byte stores and statistics
+  // loads, 64 bytes per pixel and wave instruction instead of 32 (tools/ubench/access_shape.hip: 32-byte segments move the
+  // same bytes ~1.5x slower)
+  const int pr = wv & 1, mh = wv >> 1;
+  const int uA = (c0 >> 4) + 2 * pr, uB = uA + 1;
+  const int U = (C + 15) >> 4;
+  const bool active = uA < U;
+  bf16x8 afA[5], afB[5];
 #pragma unroll
-  for (int f = 0; f < 5; ++f) af[f] = wfrag[((long)(active ? u : 0) * 5 + f) * 64 + lane];
+  for (int f = 0; f < 5; ++f) {
+    afA[f] = wfrag[((long)min(uA, U - 1) * 5 + f) * 64 + lane];
+    afB[f] = wfrag[((long)min(uB, U - 1) * 5 + f) * 64 + lane];
+  }
+  const int chA = uA * 16 + kq * 4, chB = chA + 16;              // accumulator rows
+  const int chS = uA * 16 + (kq & 1) * 16 + (kq >> 1) * 8;       // after the swap: this lane's 8 consecutive channels
+  const bool sok = chS < C;
   const int oyb = iy0 >> 1;
   const IDiv dck(nck);
   const int ntx = (Wi + 15) >> 4;
-  float sfa[4], sfb[4], smu[4], ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+  float faA[4], fbA[4], muA[4], faB[4], fbB[4], muB[4];
+  float ps1A[4] = {0.f, 0.f, 0.f, 0.f}, ps2A[4] = {0.f, 0.f, 0.f, 0.f}, ps1B[4] = {0.f, 0.f, 0.f, 0.f}, ps2B[4] = {0.f, 0.f, 0.f, 0.f};
   if (bst.z) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = min(u * 16 + kq * 4 + r, C - 1);
-      sfa[r] = bst.fa[c];
-      sfb[r] = bst.fb[c];
-      smu[r] = bst.mean[c];
+      const int ca = min(chA + r, C - 1), cb = min(chB + r, C - 1);
+      faA[r] = bst.fa[ca]; fbA[r] = bst.fb[ca]; muA[r] = bst.mean[ca];
+      faB[r] = bst.fa[cb]; fbB[r] = bst.fb[cb]; muB[r] = bst.mean[cb];
     }
   }
   for (int tx = 0; tx < ntx; ++tx) {
@@ -1065,59 +1077,90 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_mfma_kernel(const bf16_t* 
     }
     __syncthreads();
     if (!active) continue;
-    const bf16_t* colb = dyt + wv * 16 + (kq & 1) * 8;
+    const bf16_t* colA = dyt + 2 * pr * 16 + (kq & 1) * 8;
+    const bf16_t* colB = colA + 16;
 #pragma unroll
     for (int cls = 0; cls < 4; ++cls) {
       const int pyc = cls >> 1, pxc = cls & 1;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int j = 0; j < 2; ++j) {
+        const int mt = mh + 2 * j;
         const int p = mt * 16 + pl, ly = p >> 3, lx = p & 7;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (cls == 0) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], *reinterpret_cast<const bf16x8*>(colb + (ly * TO + lx) * CP), acc, 0, 0, 0);
-        } else if (cls == 1) {                                  // ky = 1 (ry = ly); kx = 0 -> rx = lx + 1, kx = 2 -> rx = lx
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], *reinterpret_cast<const bf16x8*>(colb + (ly * TO + lx + 1 - ts) * CP), acc, 0, 0, 0);
-        } else if (cls == 2) {                                  // kx = 1 (rx = lx); ky = 0 -> ry = ly + 1, ky = 2 -> ry = ly
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], *reinterpret_cast<const bf16x8*>(colb + ((ly + 1 - ts) * TO + lx) * CP), acc, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3], *reinterpret_cast<const bf16x8*>(colb + ((ly + 1) * TO + lx + 1 - ts) * CP), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4], *reinterpret_cast<const bf16x8*>(colb + (ly * TO + lx + 1 - ts) * CP), acc, 0, 0, 0);
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        int o0, o1 = 0;                                          // pixel offsets of the one or two K slabs of the class
+        if (cls == 0) o0 = ly * TO + lx;
+        else if (cls == 1) o0 = ly * TO + lx + 1 - ts;           // ky = 1 (ry = ly); kx = 0 -> rx = lx + 1, kx = 2 -> rx = lx
+        else if (cls == 2) o0 = (ly + 1 - ts) * TO + lx;         // kx = 1 (rx = lx); ky = 0 -> ry = ly + 1, ky = 2 -> ry = ly
+        else { o0 = (ly + 1) * TO + lx + 1 - ts; o1 = ly * TO + lx + 1 - ts; }
+        const int f0 = cls;                                      // fragments 0, 1, 2, 3 (+ 4 for the (odd, odd) class)
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afA[f0], *reinterpret_cast<const bf16x8*>(colA + o0 * CP), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afB[f0], *reinterpret_cast<const bf16x8*>(colB + o0 * CP), accB, 0, 0, 0);
+        if (cls == 3) {
+          accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afA[4], *reinterpret_cast<const bf16x8*>(colA + o1 * CP), accA, 0, 0, 0);
+          accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afB[4], *reinterpret_cast<const bf16x8*>(colB + o1 * CP), accB, 0, 0, 0);
         }
         const int iy = iy0 + 2 * ly + pyc, ix = ix0 + 2 * lx + pxc;
-        if (iy < Hi && ix < Wi && u * 16 + kq * 4 < C) {
-          const long off = (((long)n * Hi + iy) * Wi + ix) * C + u * 16 + kq * 4;
-          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-          bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-          *reinterpret_cast<bf16x4*>(dx + off) = o;
-          if (bst.z) {
-            const bf16x4 z4 = *reinterpret_cast<const bf16x4*>(bst.z + off);
+        const bool pok = iy < Hi && ix < Wi;
+        const long off = (((long)n * Hi + (pok ? iy : 0)) * Wi + (pok ? ix : 0)) * C + (sok ? chS : 0);
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 oA = {(__bf16)accA[0], (__bf16)accA[1], (__bf16)accA[2], (__bf16)accA[3]};
+        const bf16x4 oB = {(__bf16)accB[0], (__bf16)accB[1], (__bf16)accB[2], (__bf16)accB[3]};
+        if (bst.z) {
+          // the statistics map arrives in the stored (swapped) layout: the same swap takes it back to accumulator rows
+          const u32x4 zs = *reinterpret_cast<const u32x4*>(bst.z + off);
+          const auto z0 = __builtin_amdgcn_permlane16_swap(zs[0], zs[2], false, false);
+          const auto z1 = __builtin_amdgcn_permlane16_swap(zs[1], zs[3], false, false);
+          const u32x2 za2 = {z0[0], z1[0]}, zb2 = {z0[1], z1[1]};
+          const bf16x4 zA = *reinterpret_cast<const bf16x4*>(&za2), zB = *reinterpret_cast<const bf16x4*>(&zb2);
+          if (pok) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float zv = (float)z4[r];
-              const float g = fmaf(zv, sfa[r], sfb[r]) > 0.f ? (float)o[r] : 0.f;
-              ps1[r] += g;
-              ps2[r] = fmaf(g, zv - smu[r], ps2[r]);
+              const float za = (float)zA[r], zb = (float)zB[r];
+              const float ga = (chA + r < C && fmaf(za, faA[r], fbA[r]) > 0.f) ? (float)oA[r] : 0.f;
+              const float gb = (chB + r < C && fmaf(zb, faB[r], fbB[r]) > 0.f) ? (float)oB[r] : 0.f;
+              ps1A[r] += ga;
+              ps2A[r] = fmaf(ga, za - muA[r], ps2A[r]);
+              ps1B[r] += gb;
+              ps2B[r] = fmaf(gb, zb - muB[r], ps2B[r]);
             }
           }
         }
+        const u32x2 a2 = *reinterpret_cast<const u32x2*>(&oA), b2 = *reinterpret_cast<const u32x2*>(&oB);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(a2[0], b2[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(a2[1], b2[1], false, false);
+        if (pok && sok) *reinterpret_cast<u32x4*>(dx + off) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
       }
     }
   }
-  if (bst.z) {                                                  // (inactive waves hold zeros and write nothing)
+  if (bst.z) {
+    // lanes sharing kq (the 16 pixels of a tile), then the two waves sharing the pair, in a fixed order
+    __shared__ float red[4][2][32];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
-        ps1[r] += __shfl_xor(ps1[r], o, 64);
-        ps2[r] += __shfl_xor(ps2[r], o, 64);
+        ps1A[r] += __shfl_xor(ps1A[r], o, 64);
+        ps2A[r] += __shfl_xor(ps2A[r], o, 64);
+        ps1B[r] += __shfl_xor(ps1B[r], o, 64);
+        ps2B[r] += __shfl_xor(ps2B[r], o, 64);
       }
     }
-    if (active && pl == 0 && u * 16 + kq * 4 < C) {
-      const long row = ((long)n * gridDim.x + blockIdx.x) * C + u * 16 + kq * 4;
+    if (pl == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        bst.part_s[row + r] = ps1[r];
-        bst.part_q[row + r] = ps2[r];
+        red[wv][0][kq * 4 + r] = ps1A[r];
+        red[wv][0][16 + kq * 4 + r] = ps1B[r];
+        red[wv][1][kq * 4 + r] = ps2A[r];
+        red[wv][1][16 + kq * 4 + r] = ps2B[r];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63, pp = c >> 5, cl = c & 31;
+      if (c0 + c < C) {
+        const float a = red[pp][which][cl] + red[pp + 2][which][cl];
+        const long row = ((long)n * gridDim.x + blockIdx.x) * C + c0 + c;
+        (which ? bst.part_q : bst.part_s)[row] = a;
       }
     }
   }

@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
   constexpr int NTW = CO / WN / 16, KTW = CI / WK / 16;
   constexpr int RSY = CO + 16, RSX = CI + 16;                     // LDS row strides (elements): + 32 bytes
   constexpr int KS = CO / 32;                                     // k-steps of the input-gradient contraction
-  constexpr int TCI = CI / 16;                                    // its output (input-channel) tiles
-  constexpr int TPW = (TCI + 3) / 4;                              // ... per wave (tiles w, w + 4)
+  // its output goes in PAIRS of 16-channel tiles: a lane holds 8 consecutive input channels of one row (16-byte epilogue
+  // accesses, 64 bytes per row and wave instruction -- with 32-byte row segments the same bytes move 1.5x slower,
+  // tools/ubench/access_shape.hip); wave w serves pair w % PAIRS on the 16-row tiles w / PAIRS + WPP * j
+  constexpr int PAIRS = CI / 32, WPP = 4 / PAIRS, MPW = PAIRS;
   constexpr int CPY = CO / 8, CPX = CI / 8;                       // 16-byte pieces per row
   constexpr int NPY = 64 * CPY / 256, NPX = (64 * CPX + 255) / 256;      // pieces per thread per tile
   __shared__ __attribute__((aligned(16))) bf16_t sY[64 * RSY];    // dz1 tile [row][output channel]
@@ -76,11 +78,11 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
     const int r = i / CPY, ck = i - r * CPY;
     *reinterpret_cast<u32x4*>(sW + r * (CO + 8) + ck * 8) = *reinterpret_cast<const u32x4*>(p.Wt + (long)r * CO + ck * 8);
   }
-  float ss1[TPW][4], ss2[TPW][4], ss3[TPW][4];
+  float ss1[8], ss2[8], ss3[8];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ss1[t][r] = ss2[t][r] = ss3[t][r] = 0.f;
+  for (int r = 0; r < 8; ++r) ss1[r] = ss2[r] = ss3[r] = 0.f;
+  const int pr = wv % PAIRS, mt0 = wv / PAIRS;                    // this wave's channel pair and first 16-row tile
+  const int c0 = pr * 32 + 8 * q;                                 // this lane's 8 input channels
   f32x4 acc[NTW][KTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
@@ -109,34 +111,33 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
   // one exposed memory round trip per 16-row tile (3.1 ms instead of ~2 at s1.b1 of cfg3)
   // (not at 128 x 128: the 48 registers of the prefetch would cost the second workgroup per CU, measured slower)
   constexpr bool PRE = !(CO == 128 && CI == 128);
-  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-  bf16x4_t er[PRE ? TPW : 1][4], ez[PRE ? TPW : 1][4], ezd[PRE ? TPW : 1][4];
-  unsigned rmask = 0u;                                            // bit mt: the row has a shortcut-gradient row
+  u32x4 er[PRE ? MPW : 1], ez[PRE ? MPW : 1], ezd[PRE ? MPW : 1];
+  unsigned rmask = 0u;                                            // bit j: the row of tile j has a shortcut-gradient row
+  auto res_row = [&](long mc, bool& has_r) -> long {
+    has_r = p.R != nullptr;
+    if (p.R && p.r_hi > 0) {
+      const long per = (long)p.r_hi * p.r_wi;
+      const long f = mc / per;
+      const int rem = (int)(mc - f * per);
+      const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
+      has_r = !((yy | xx) & 1);
+      return has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
+    }
+    return mc;
+  };
   auto issue_epi = [&](long tq) {
     if constexpr (!PRE) return;
     rmask = 0u;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const long mc = min(tq * 64 + mt * 16 + pl, p.M - 1);
-      long rm = mc;
-      bool has_r = p.R != nullptr;
-      if (p.R && p.r_hi > 0) {
-        const long per = (long)p.r_hi * p.r_wi;
-        const long f = mc / per;
-        const int rem = (int)(mc - f * per);
-        const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
-        has_r = !((yy | xx) & 1);
-        rm = has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
-      }
-      if (has_r) rmask |= 1u << mt;
-#pragma unroll
-      for (int tt = 0; tt < (PRE ? TPW : 1); ++tt) {
-        const int c0 = min(wv + 4 * tt, TCI - 1) * 16 + 4 * q;
-        if (p.R) er[tt][mt] = *reinterpret_cast<const bf16x4_t*>(p.R + rm * p.ldr + c0);
-        if (p.bpart) {
-          ez[tt][mt] = *reinterpret_cast<const bf16x4_t*>(p.bz + mc * CI + c0);
-          if (p.bzd) ezd[tt][mt] = *reinterpret_cast<const bf16x4_t*>(p.bzd + mc * CI + c0);
-        }
+    for (int j = 0; j < (PRE ? MPW : 1); ++j) {
+      const long mc = min(tq * 64 + (mt0 + WPP * j) * 16 + pl, p.M - 1);
+      bool has_r;
+      const long rm = res_row(mc, has_r);
+      if (has_r) rmask |= 1u << j;
+      if (p.R) er[j] = *reinterpret_cast<const u32x4*>(p.R + rm * p.ldr + c0);
+      if (p.bpart) {
+        ez[j] = *reinterpret_cast<const u32x4*>(p.bz + mc * CI + c0);
+        if (p.bzd) ezd[j] = *reinterpret_cast<const u32x4*>(p.bzd + mc * CI + c0);
       }
     }
   };
@@ -182,67 +183,56 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
     __syncthreads();
     if (t + gridDim.x < ntiles) issue(t + gridDim.x);             // the next tile travels under this tile's contractions
 
-    // ---- input gradient: dx[m][ci] = sum_co dz1[m][co] * Wt[ci][co]; A = Wt fragments, B = dz1 rows
+    // ---- input gradient: dx[m][ci] = sum_co dz1[m][co] * Wt[ci][co]; A = Wt fragments, B = dz1 rows.  The two tiles of a
+    // pair take the rows of Wt permuted (A row i of tile h <-> channel 8 (i / 4) + 4 h + i % 4 of the pair) so that
+    // accumulator h of lane (pl, q) holds channels 8 q + 4 h + (0..3): 8 consecutive channels per lane
+#pragma unroll(PRE ? MPW : 1)
+    for (int j = 0; j < MPW; ++j) {
+      const int rl = (mt0 + WPP * j) * 16 + pl;
+      const long m = m0 + rl;
+      const bool mok = m < p.M;
+      const long mc = mok ? m : p.M - 1;
+      u32x4 r4 = {0u, 0u, 0u, 0u}, z4 = {0u, 0u, 0u, 0u}, zd4 = {0u, 0u, 0u, 0u};
+      bool has_r;
+      if constexpr (PRE) {
+        r4 = er[j]; z4 = ez[j]; zd4 = ezd[j];
+        has_r = (rmask >> j) & 1u;
+      } else {
+        const long rm = res_row(mc, has_r);
+        if (p.R) r4 = *reinterpret_cast<const u32x4*>(p.R + rm * p.ldr + c0);
+        if (p.bpart) {
+          z4 = *reinterpret_cast<const u32x4*>(p.bz + mc * CI + c0);
+          if (p.bzd) zd4 = *reinterpret_cast<const u32x4*>(p.bzd + mc * CI + c0);
+        }
+      }
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      const bf16_t* br = sY + rl * RSY + 8 * q;
+      const bf16_t* wr = sW + (pr * 32 + 8 * (pl >> 2) + (pl & 3)) * (CO + 8) + 8 * q;
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
-      const int ct = wv + 4 * tt;
-      if (ct < TCI) {                                             // (wave-uniform)
-        const int c0 = ct * 16 + 4 * q;
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(br + 32 * ks);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wr + 32 * ks), b, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wr + 4 * (CO + 8) + 32 * ks), b, a1, 0, 0, 0);
+      }
+      const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(sX + rl * RSX + c0);
+      const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(&r4);
+      bf16x8 o;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int rl = mt * 16 + pl;
-          const long m = m0 + rl;
-          const bool mok = m < p.M;
-          const long mc = mok ? m : p.M - 1;
-          bf16x4_t r4 = {}, z4 = {}, zd4 = {};
-          bool has_r = p.R != nullptr;
-          if constexpr (PRE) {
-            r4 = er[tt][mt]; z4 = ez[tt][mt]; zd4 = ezd[tt][mt];
-            has_r = (rmask >> mt) & 1u;
-          } else {
-            if (p.R) {
-              long rm = mc;
-              if (p.r_hi > 0) {
-                const long per = (long)p.r_hi * p.r_wi;
-                const long f = mc / per;
-                const int rem = (int)(mc - f * per);
-                const int yy = rem / p.r_wi, xx = rem - yy * p.r_wi;
-                has_r = !((yy | xx) & 1);
-                rm = has_r ? (f * ((p.r_hi + 1) >> 1) + (yy >> 1)) * ((p.r_wi + 1) >> 1) + (xx >> 1) : 0;
-              }
-              r4 = *reinterpret_cast<const bf16x4_t*>(p.R + rm * p.ldr + c0);
-            }
-            if (p.bpart) {
-              z4 = *reinterpret_cast<const bf16x4_t*>(p.bz + mc * CI + c0);
-              if (p.bzd) zd4 = *reinterpret_cast<const bf16x4_t*>(p.bzd + mc * CI + c0);
-            }
-          }
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          const bf16_t* br = sY + rl * RSY + 8 * q;
-          const bf16_t* wr = sW + (ct * 16 + pl) * (CO + 8) + 8 * q;
+      for (int e = 0; e < 8; ++e) {
+        float v = (e < 4 ? a0[e & 3] : a1[e & 3]) + (has_r ? (float)r8[e] : 0.f);
+        if (p.use_mask && !((float)x8[e] > 0.f)) v = 0.f;
+        o[e] = (bf16_t)v;
+      }
+      if (mok) {
+        *reinterpret_cast<bf16x8*>(p.dX + m * CI + c0) = o;
+        if (p.bpart) {
+          const bf16x8 z8 = *reinterpret_cast<const bf16x8*>(&z4), zd8 = *reinterpret_cast<const bf16x8*>(&zd4);
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wr + 32 * ks),
-                                                        *reinterpret_cast<const bf16x8*>(br + 32 * ks), a, 0, 0, 0);
-          const bf16x4_t x4 = *reinterpret_cast<const bf16x4_t*>(sX + rl * RSX + c0);
-          bf16x4_t o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = a[r] + (has_r ? (float)r4[r] : 0.f);
-            if (p.use_mask && !((float)x4[r] > 0.f)) v = 0.f;
-            o[r] = (bf16_t)v;
-          }
-          if (mok) {
-            *reinterpret_cast<bf16x4_t*>(p.dX + m * CI + c0) = o;
-            if (p.bpart) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float vr = (float)o[r];
-                ss1[tt][r] += vr;
-                ss2[tt][r] = fmaf(vr, (float)z4[r] - bt_[c0 + r], ss2[tt][r]);
-                if (p.bzd) ss3[tt][r] = fmaf(vr, (float)zd4[r] - bt_[CI + c0 + r], ss3[tt][r]);
-              }
-            }
+          for (int e = 0; e < 8; ++e) {
+            const float vr = (float)o[e];
+            ss1[e] += vr;
+            ss2[e] = fmaf(vr, (float)z8[e] - bt_[c0 + e], ss2[e]);
+            if (p.bzd) ss3[e] = fmaf(vr, (float)zd8[e] - bt_[CI + c0 + e], ss3[e]);
           }
         }
       }
@@ -283,28 +273,35 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
       }
     }
   if (p.bpart) {
+    // lanes sharing q (the 16 rows of a tile), then the WPP waves sharing the pair, in a fixed order
     float* bp = p.bpart + (long)blockIdx.x * 3 * CI;
+    float* red = reinterpret_cast<float*>(sY);                    // [4 waves][3][32]
+    __syncthreads();                                              // (the last tile's LDS reads are over)
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
+    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          ss1[tt][r] += __shfl_xor(ss1[tt][r], o, 64);
-          ss2[tt][r] += __shfl_xor(ss2[tt][r], o, 64);
-          ss3[tt][r] += __shfl_xor(ss3[tt][r], o, 64);
-        }
+      for (int o = 1; o < 16; o <<= 1) {
+        ss1[e] += __shfl_xor(ss1[e], o, 64);
+        ss2[e] += __shfl_xor(ss2[e], o, 64);
+        ss3[e] += __shfl_xor(ss3[e], o, 64);
       }
-      const int ct = wv + 4 * tt;
-      if (ct < TCI && pl == 0) {
+    }
+    if (pl == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = ct * 16 + 4 * q + r;
-          bp[c] = ss1[tt][r];
-          bp[CI + c] = ss2[tt][r];
-          bp[2 * CI + c] = ss3[tt][r];
-        }
+      for (int e = 0; e < 8; ++e) {
+        red[(wv * 3 + 0) * 32 + 8 * q + e] = ss1[e];
+        red[(wv * 3 + 1) * 32 + 8 * q + e] = ss2[e];
+        red[(wv * 3 + 2) * 32 + 8 * q + e] = ss3[e];
       }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * CI; i += 256) {
+      const int which = i / CI, c = i - which * CI;
+      const int pp = c >> 5, cl = c & 31;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < WPP; ++k) a += red[((pp + PAIRS * k) * 3 + which) * 32 + cl];
+      bp[i] = a;
     }
   }
 }
