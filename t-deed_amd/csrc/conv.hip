@@ -658,6 +658,8 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
     const IDiv dwi(Wi);
     const bf16_t* xn = x + (long)n * Hi * Wi * Cin;
     const bf16_t* gn = G ? G + (long)n * Hi * Wi * Fp : nullptr;
+    // (requesting the NEXT tile's x fragments before this tile's MFMAs, with the BatchNorm fold moved to LDS to keep three
+    // workgroups per CU, was measured slower: c1_gconv 1.59 -> 1.89 ms per 800MF batch, 0.31 -> 0.34 at cfg2)
     for (int t0 = wv; t0 < ntl; t0 += 4) {
       const int p = t0 * 16 + pl;
       const bool pok = p < npx;

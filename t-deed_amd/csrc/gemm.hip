@@ -987,20 +987,21 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
     const long tn = t + gridDim.x;
     // residual pieces of this tile first, THEN the next tile's rows: vmcnt counts in order, so a wait for a residual piece
     // never has to drain the prefetch behind it
-    u32x4 rpre[RES ? 4 : 1];
+    // residual pieces of the tile in flight per lane: all four, or two where the compact second output needs the registers
+    constexpr int RS_RPRE = (SE && RES && OUT2) ? 2 : 4;
+    u32x4 rpre[RES ? RS_RPRE : 1];
+    auto rload = [&](int mt) {
+      const long m = min(t * RS_ROWS + mt * 16 + px, (long)p.M - 1);
+      rpre[mt % RS_RPRE] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + m * p.ldr + chc);
+    };
     if constexpr (RES) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const long m = min(t * RS_ROWS + mt * 16 + px, (long)p.M - 1);
-        rpre[mt] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + m * p.ldr + chc);
-      }
+      for (int mt = 0; mt < RS_RPRE; ++mt) rload(mt);
     }
     if (tn < ntiles) gload(tn);                                       // next tile travels while this one is multiplied
     const unsigned char* base = tiles + buf * RS_TILE;
     // (the STATS form stores the raw contraction: no BatchNorm fold, and 16 registers for the column sums instead)
-    const float* bq = STATS ? bnt : bnt + chc;
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(bq), s1 = *reinterpret_cast<const f32x4*>(bq + 4);
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(bq + p.N), h1 = *reinterpret_cast<const f32x4*>(bq + p.N + 4);
+    const float* bq0 = STATS ? bnt : bnt + chc;
     // one 16-row tile at a time: two accumulators (the wave's two channel tiles) alternate on the MFMA pipe
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -1015,6 +1016,12 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a, acc1, 0, 0, 0);
       }
+      // the BatchNorm fold of the lane's 8 channels comes from LDS again for every 16-row tile (an opaque pointer keeps the
+      // compiler from holding its 16 registers across the MFMA loops, where the budget of 168 is needed for W and the prefetches)
+      const float* bq = bq0;
+      if constexpr (SE || RES) asm volatile("" : "+v"(bq));
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(bq), s1 = *reinterpret_cast<const f32x4*>(bq + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(bq + p.N), h1 = *reinterpret_cast<const f32x4*>(bq + p.N + 4);
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1023,9 +1030,10 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
       }
       if constexpr (RES) {
         float rv[8];
-        Chunk<T>::load(reinterpret_cast<const T*>(&rpre[mt]), rv);
+        Chunk<T>::load(reinterpret_cast<const T*>(&rpre[mt % RS_RPRE]), rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        if (mt + RS_RPRE < 4) rload(mt + RS_RPRE);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo);

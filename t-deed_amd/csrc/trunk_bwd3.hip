@@ -36,7 +36,10 @@ template <> struct NbwGeom<64, 64> { static constexpr int WN = 2, WK = 2; };
 template <> struct NbwGeom<128, 64> { static constexpr int WN = 2, WK = 2; };
 template <> struct NbwGeom<128, 128> { static constexpr int WN = 2, WK = 2; };
 
-template <int CO, int CI>
+// RC (Z == NULL at the C ABI): the raw conv output z is not read but RECOMPUTED from the x tile and the weight that are in LDS
+// anyway (z = x @ W^T, CI / 32 MFMA k-steps per 16 x 16 tile, rounded to bf16 like the stored map): a quarter of the bytes
+// of a launch (2.6 GB at s1.b1 of cfg3) for CO * CI / 64 MFMAs per 64-row tile.  Not at 128 x 128 (MFMA-bound there).
+template <int CO, int CI, bool RC = false>
 __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) {
   typedef NbwGeom<CO, CI> G;
   constexpr int WN = G::WN, WK = G::WK;
@@ -89,15 +92,28 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // RC: A-operand fragments of W (rows = output channels, k = input channels) for the z contraction, gathered once from the
+  // transposed copy in LDS: lane (i = pl, k-chunk q) of tile T, k-step ks holds W[T * 16 + pl][32 ks + 8 q + (0..7)]
+  constexpr int NZT = CO / 64, KS1 = CI / 32;
+  bf16x8 zf[RC ? NZT : 1][RC ? KS1 : 1];
+  if constexpr (RC) {
+    __syncthreads();
+#pragma unroll
+    for (int zt = 0; zt < NZT; ++zt)
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zf[zt][ks][e] = sW[(32 * ks + 8 * q + e) * (CO + 8) + (wv + 4 * zt) * 16 + pl];
+  }
   const long ntiles = (p.M + 63) / 64;
-  u32x4 vy[NPY], vz[NPY], vx[NPX];
+  u32x4 vy[NPY], vz[RC ? 1 : NPY], vx[NPX];
   auto issue = [&](long t) {
     const long m0 = t * 64;
 #pragma unroll
     for (int j = 0; j < NPY; ++j) {
       const long row = min(m0 + ry + (256 / CPY) * j, p.M - 1);
       vy[j] = *reinterpret_cast<const u32x4*>(p.dY + row * CO + cy);
-      vz[j] = *reinterpret_cast<const u32x4*>(p.Z + row * CO + cy);
+      if constexpr (!RC) vz[j] = *reinterpret_cast<const u32x4*>(p.Z + row * CO + cy);
     }
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -149,13 +165,46 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
   for (; t < ntiles; t += gridDim.x) {
     const long m0 = t * 64;
     __syncthreads();                                              // the previous tile's LDS reads are over
+    auto store_x = [&]() {
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        const int i = tid + 256 * j;
+        if (i < 64 * CPX) {
+          const int r = i / CPX;
+          const bool rok = m0 + r < p.M;
+          *reinterpret_cast<u32x4*>(sX + r * RSX + (i % CPX) * 8) = rok ? vx[j] : (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+    };
+    if constexpr (RC) {
+      // ---- z = x @ W^T of this tile -> sY (bf16, like the stored map); wave w: output-channel tiles w, w + 4, ...
+      store_x();
+      __syncthreads();
+#pragma unroll
+      for (int zt = 0; zt < NZT; ++zt) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          const bf16_t* xr = sX + (mt * 16 + pl) * RSX + 8 * q;
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks)
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[zt][ks], *reinterpret_cast<const bf16x8*>(xr + 32 * ks), a, 0, 0, 0);
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          const bf16x4_t o4 = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+          *reinterpret_cast<bf16x4_t*>(sY + (mt * 16 + pl) * RSY + (wv + 4 * zt) * 16 + 4 * q) = o4;
+        }
+      }
+      __syncthreads();
+    }
     // ---- dz1 = k1 g + k2 z + k3 -> sY (rows beyond M: zeros, they then add nothing to either contraction)
 #pragma unroll
     for (int j = 0; j < NPY; ++j) {
       const int r = ry + (256 / CPY) * j;
       const bool rok = m0 + r < p.M;
       const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&vy[j]);
-      const bf16x8 z8 = *reinterpret_cast<const bf16x8*>(&vz[j]);
+      bf16x8 z8;
+      if constexpr (RC) z8 = *reinterpret_cast<const bf16x8*>(sY + r * RSY + cy);      // (this thread overwrites the same chunk)
+      else z8 = *reinterpret_cast<const bf16x8*>(&vz[j]);
       bf16x8 o;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -171,15 +220,7 @@ __global__ __launch_bounds__(256, 2) void narrow_conv1_bwd_kernel(const NbwP p) 
       }
       *reinterpret_cast<bf16x8*>(sY + r * RSY + cy) = o;
     }
-#pragma unroll
-    for (int j = 0; j < NPX; ++j) {
-      const int i = tid + 256 * j;
-      if (i < 64 * CPX) {
-        const int r = i / CPX;
-        const bool rok = m0 + r < p.M;
-        *reinterpret_cast<u32x4*>(sX + r * RSX + (i % CPX) * 8) = rok ? vx[j] : (u32x4){0u, 0u, 0u, 0u};
-      }
-    }
+    if constexpr (!RC) store_x();
     __syncthreads();
     if (t + gridDim.x < ntiles) issue(t + gridDim.x);             // the next tile travels under this tile's contractions
 
@@ -316,7 +357,7 @@ extern "C" int tdeed_narrow_conv1_bwd_grid(long M, int Co, int Ci) {
   return (int)(tiles < cap ? tiles : cap);
 }
 
-// dY, Z [M][Co] bf16; fa / fb / mean / rstd / w: conv1's BatchNorm (forward affine, batch statistics, weight); sums fp32 [2][Co]
+// dY, Z [M][Co] bf16 (Z NULL: recomputed as X @ W^T in the launch -- Z must be exactly that product, not at 128 <- 128); fa / fb / mean / rstd / w: conv1's BatchNorm (forward affine, batch statistics, weight); sums fp32 [2][Co]
 // = (sum g, sum g * xhat) of its backward (tdeed_bn_bwd_masked_from_parts leaves them); X [M][Ci]; Wt [Ci][Co] (the weight
 // transposed); R: shortcut gradient ([M][Ci], or with r_hi > 0 the rows of the even pixels of an r_hi x r_wi frame) or NULL;
 // dX [M][Ci]; use_mask: dX *= [X > 0]; bz / bmean (/ bzd / bmean_d) + bpart fp32 [grid][3][Ci]: the gradient sink's statistics
@@ -326,7 +367,8 @@ extern "C" int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int
                                       const void* Wt, const void* R, long ldr, int r_hi, int r_wi, void* dX, int use_mask,
                                       const void* bz, const float* bmean, const void* bzd, const float* bmean_d, float* bpart,
                                       float* wpart, void* stream) {
-  TD_CHECK(dY && Z && fa && fb && mean && rstd && w && sums && X && Wt && dX && wpart, "narrow_conv1_bwd: null pointer");
+  TD_CHECK(dY && fa && fb && mean && rstd && w && sums && X && Wt && dX && wpart, "narrow_conv1_bwd: null pointer");
+  TD_CHECK(Z || !(Co == 128 && Ci == 128), "narrow_conv1_bwd: the 128 <- 128 form reads Z (no recompute)");
   TD_CHECK(M > 0 && tdeed_narrow_conv1_bwd_fits(Co, Ci), "narrow_conv1_bwd: %d <- %d channels not served", Co, Ci);
   TD_CHECK(!R || ldr % 4 == 0, "narrow_conv1_bwd: bad residual stride");
   TD_CHECK(r_hi == 0 || (R && r_hi > 0 && r_wi > 0 && M % ((long)r_hi * r_wi) == 0), "narrow_conv1_bwd: bad stride-2 residual geometry");
@@ -339,7 +381,11 @@ extern "C" int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int
   p.wpart = wpart; p.M = M; p.inv_M = 1.0f / (float)M;
   const int grid = tdeed_narrow_conv1_bwd_grid(M, Co, Ci);
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 64 && Ci == 32) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, st, p);
+  if (!Z) {
+    if (Co == 64 && Ci == 32) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32, true>), dim3(grid), dim3(256), 0, st, p);
+    else if (Co == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 64, true>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 64, true>), dim3(grid), dim3(256), 0, st, p);
+  } else if (Co == 64 && Ci == 32) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, st, p);
   else if (Co == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<64, 64>), dim3(grid), dim3(256), 0, st, p);
   else if (Ci == 64) hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 64>), dim3(grid), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((narrow_conv1_bwd_kernel<128, 128>), dim3(grid), dim3(256), 0, st, p);

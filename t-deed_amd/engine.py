@@ -229,11 +229,13 @@ class DenseW:
         return self.wide and M is not None and M >= WS_WIDE_MIN_ROWS
 
     def _use_rs(self, M, kw):
-        """register-stationary kernel (K = N = 320, W in the registers of a 10-wave workgroup): conv1-shaped calls only -- with
-        the SE re-scale and the residual of a conv3 its 168 registers spill and it is no faster than the tiled kernel
-        (tools/bench_ws_wide.py: plain 106 vs 183 us at M = 313 600, conv3 232 vs 249)"""
-        return (RS_MIN_ROWS > 0 and self.wide and M is not None and M >= RS_MIN_ROWS and kw.get("residual") is None
-                and kw.get("a_scale") is None and kw.get("gather") is None and kw.get("lda") is None and kw.get("ldc") is None
+        """register-stationary kernel (K = N = 320, W in the registers of a 10-wave workgroup) -- conv1-shaped calls and, since
+        the kernel re-reads its BatchNorm fold from LDS per 16-row tile instead of holding it across the MFMA loops (no spills
+        left at its 168-register budget), conv3 with the SE re-scale and the residual too (tools/bench_ws_wide.py at
+        M = 313 600: plain 114 vs 181 us tiled, conv3 172 vs 247; the a_scale tile must span at most two frames)"""
+        return (RS_MIN_ROWS > 0 and self.wide and M is not None and M >= RS_MIN_ROWS
+                and (kw.get("a_scale") is None or kw.get("a_scale_rows", 0) >= 64)
+                and kw.get("gather") is None and kw.get("lda") is None and kw.get("ldc") is None
                 and ops.gemm_rs_fits(M, self.K, self.N))
 
     def kern(self, M):
@@ -245,7 +247,8 @@ class DenseW:
             return ops.gemm_ws(A, self.w, self.K, self.N, scale, shift, act, **kw)
         if act in (ops.ACT_NONE, ops.ACT_RELU) and self._use_rs(kw.get("M"), kw):
             return ops.gemm_rs(A, self.w_wide, self.K, self.N, scale, shift, act,
-                               **{k: v for k, v in kw.items() if k in ("A0", "k0", "out", "M", "out2")})
+                               **{k: v for k, v in kw.items() if k in ("A0", "k0", "out", "M", "out2", "residual", "a_scale",
+                                                                       "a_scale_rows")})
         if self._use_wide(kw.get("M")):
             return ops.gemm_ws(A, self.w_wide, self.K, self.N, scale, shift, act, **kw)
         return ops.gemm(A, self.w, scale, shift, act, **kw)

@@ -1,6 +1,8 @@
 """Torch-tensor wrappers of the backward entry points (training path).  Same conventions as ops.py: tensors are
 device memory handed over as raw pointers on the current stream; scratch (`part*`) is allocated here when the caller
 does not pass it (a training engine passes preallocated buffers)."""
+import os
+
 import torch
 
 from . import _lib
@@ -337,12 +339,18 @@ def narrow_conv1_bwd_fits(Co, Ci, dtype):
     return dtype == torch.bfloat16 and _lib.load().tdeed_narrow_conv1_bwd_fits(Co, Ci) != 0
 
 
-def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_hw=None, sums=None):
+NARROW_RECOMPUTE = os.environ.get("TDEED_TRAIN_NARROW_RECOMPUTE", "1") == "1"
+
+
+def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_hw=None, sums=None, recompute=False):
     """conv1 backward of a narrow bottleneck in one launch (tdeed_narrow_conv1_bwd): d_y1 / z1 (.., Co), bn1 = (mean, rstd, a, b),
     w its weight, part = the masked column-sum partials conv2's input-gradient launch left, x (.., Ci) conv1's input (= the
     sink's mask), wt (Ci, Co) the transposed weight, residual: shortcut gradient (r_hw = (hi, wi): on the even pixels only).
+    recompute: z1 IS x @ wt (the raw conv output of exactly these operands): the launch recomputes it from the x tile it holds
+    instead of reading the map (not at 128 <- 128).
     -> dx (M, Ci) (masked / summed for `sink`), dW (Co, Ci) as a LazyFold, BatchNorm dw, db."""
     Co, Ci = z1.shape[-1], x.shape[-1]
+    rc = recompute and NARROW_RECOMPUTE and not (Co == 128 and Ci == 128)
     M = z1.numel() // Co
     dev = z1.device
     if sums is None:
@@ -357,7 +365,7 @@ def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_
         bpart = _f32((grid, 3, Ci), dev)
         sink.partA = bpart
     rh, rw = r_hw if r_hw is not None else (0, 0)
-    call("tdeed_narrow_conv1_bwd", ptr(d_y1), ptr(z1), M, Co, Ci, ptr(bn1[2]), ptr(bn1[3]), ptr(bn1[0]), ptr(bn1[1]), ptr(w),
+    call("tdeed_narrow_conv1_bwd", ptr(d_y1), ptr(None if rc else z1), M, Co, Ci, ptr(bn1[2]), ptr(bn1[3]), ptr(bn1[0]), ptr(bn1[1]), ptr(w),
          ptr(sums), ptr(x), ptr(wt), ptr(residual), (residual.shape[-1] if residual is not None else 0), rh, rw, ptr(dx),
          int(sink is not None), ptr(sink.z if sink else None), ptr(sink.mean if sink else None), ptr(sink.zd if sink else None),
          ptr(sink.mean_d if sink else None), ptr(bpart), ptr(wpart), stream_ptr())

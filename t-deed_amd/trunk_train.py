@@ -308,7 +308,8 @@ class BottleneckTrain:
             # kernel with no ReLU between BatchNorm and conv: fa = 0, fb = 1; dz3 lives in LDS only)
             sums3 = B_.bn_sums_from_sink(c.z3, dout, c.bn3, sd[pre + ".conv3.bn.weight"], sink_in, q=1)
             d_y2s, dW3, dw, db = B_.narrow_conv1_bwd(dout, c.z3, (c.bn3[0], c.bn3[1], self.zero, self.one),
-                                                     sd[pre + ".conv3.bn.weight"], None, c.y2s, self.w3.wt, sums=sums3)
+                                                     sd[pre + ".conv3.bn.weight"], None, c.y2s, self.w3.wt, sums=sums3,
+                                                     recompute=True)
             d_y2s = d_y2s.view(N, h2, w2, C)
             d_sc = dout
             bn_names("conv3", dw, db)
@@ -381,7 +382,7 @@ class BottleneckTrain:
                     # the shortcut conv's backward through the same one-launch kernel (no ReLU, no sink)
                     sums_d = B_.bn_sums_from_sink(c.zd, dout, c.bnd, wdn, sink_in, q=2)
                     res, dWd, dw, db = B_.narrow_conv1_bwd(dout, c.zd, (c.bnd[0], c.bnd[1], self.zero, self.one), wdn, None,
-                                                           c.xs, self.wd.wt, sums=sums_d)
+                                                           c.xs, self.wd.wt, sums=sums_d, recompute=True)
                     bn_names("downsample", dw, db)
                     grads[pre + ".downsample.conv.weight"] = dWd.reshape(sd[pre + ".downsample.conv.weight"].shape)
                 else:
@@ -394,8 +395,9 @@ class BottleneckTrain:
                     grads[pre + ".downsample.conv.weight"] = B_.wgrad(dzd, c.xs, with_bias=False, M=N * hw2)[0].reshape(
                         sd[pre + ".downsample.conv.weight"].shape)
                 r_hw = (h, w) if blk.stride == 2 else None
+            # (z3 / zd / z1 of these layers are the raw products of exactly the operands the launch holds: recomputed, not read)
             dx, dW1, dw, db = B_.narrow_conv1_bwd(d_y1, c.z1, c.bn1, sd[self.c1 + ".bn.weight"], part1, c.x, self.w1.wt,
-                                                  sink=sink_out, residual=res, r_hw=r_hw)
+                                                  sink=sink_out, residual=res, r_hw=r_hw, recompute=True)
             bn_names("conv1", dw, db)
             grads[self.c1 + ".conv.weight"] = dW1.reshape(sd[self.c1 + ".conv.weight"].shape)
             return dx.view(Nf, h, w, Cin)

@@ -351,3 +351,19 @@ def test_narrow_conv1_backward_in_one_launch_equals_the_three_launch_chain(Co, C
     st = dx.double()
     want = torch.stack([st.sum(0), (st * (zp.double() - mp.double())).sum(0), (st * (zdp.double() - mdp.double())).sum(0)])
     assert max_abs(a, want) <= 1e-3 * max(1.0, float(want.abs().max()))
+    # z1 recomputed inside the launch (Z = NULL) when it is the raw product of the operands the launch holds: the same results
+    # as reading that map
+    if not (Co == 128 and Ci == 128):
+        from tdeed_amd import ops
+        z_raw = ops.gemm(x, W1, None, None, ops.ACT_NONE)
+        bn_r = B_.bn_stats(z_raw, bw, bb)
+        _, _, dwb_r, dbb_r = B_.bn_train_bwd(z_raw, d_y1, None, bn_r, bw, relu=True)
+        part_r = (dbb_r.view(1, Co).contiguous(), (dwb_r / bn_r[1]).view(1, Co).contiguous(), Co, 1)
+        outs = []
+        for rc in (False, True):
+            sk = B_.GradSink(x, zp, mp, zd=zdp, mean_d=mdp)
+            dx_r, dW_r, _, _ = B_.narrow_conv1_bwd(d_y1, z_raw, bn_r, bw, part_r, x, wt, sink=sk, residual=R, r_hw=r_hw,
+                                                   recompute=rc)
+            outs.append((dx_r, B_.materialize(dW_r), sk.partA.clone()))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
