@@ -658,37 +658,51 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
     const IDiv dwi(Wi);
     const bf16_t* xn = x + (long)n * Hi * Wi * Cin;
     const bf16_t* gn = G ? G + (long)n * Hi * Wi * Fp : nullptr;
-    // (requesting the NEXT tile's x fragments before this tile's MFMAs, with the BatchNorm fold moved to LDS to keep three
-    // workgroups per CU, was measured slower: c1_gconv 1.59 -> 1.89 ms per 800MF batch, 0.31 -> 0.34 at cfg2)
-    for (int t0 = wv; t0 < ntl; t0 += 4) {
-      const int p = t0 * 16 + pl;
-      const bool pok = p < npx;
-      int rr, cc;
-      dwi.divmod(pok ? p : 0, rr, cc);
-      const long pix = (long)(r_lo + rr) * Wi + cc;
-      bf16x8 xf[KS1];
+    // A wave's tiles go in groups of NPF: the x fragments of the whole group are requested before the first MFMA, so a group
+    // costs ONE exposed memory round trip instead of one per tile (narrow inputs: s2.b1 of RegNetY-800MF is 44 800 workgroups
+    // of ~0.4 us of MFMA work whose four to five dependent load -> MFMA -> LDS-store rounds per wave were the launch's time).
+    // At KS1 >= 4 a second set of fragments costs the third workgroup per CU (measured slower, also with the BatchNorm fold
+    // moved to LDS): those stay one tile at a time.
+    constexpr int NPF = KS1 <= 2 ? 4 : 1;
+    for (int tb = wv; tb < ntl; tb += 4 * NPF) {
+      bf16x8 xf[NPF][KS1];
+      int rrs[NPF], ccs[NPF];
+      bool poks[NPF];
 #pragma unroll
-      for (int ks = 0; ks < KS1; ++ks) {
-        const int k = 32 * ks + 8 * q;
-        const bool ok = pok && k < Cin;
-        const bf16_t* src = (gn && k < Fp) ? gn + pix * Fp + k : xn + pix * Cin + k;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? src : xn);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        const u32x4 w = ok ? v : z;
-        xf[ks] = *reinterpret_cast<const bf16x8*>(&w);
+      for (int g = 0; g < NPF; ++g) {
+        const int t0 = tb + 4 * g;
+        const int p = t0 * 16 + pl;
+        poks[g] = t0 < ntl && p < npx;
+        dwi.divmod(poks[g] ? p : 0, rrs[g], ccs[g]);
+        const long pix = (long)(r_lo + rrs[g]) * Wi + ccs[g];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const int k = 32 * ks + 8 * q;
+          const bool ok = poks[g] && k < Cin;
+          const bf16_t* src = (gn && k < Fp) ? gn + pix * Fp + k : xn + pix * Cin + k;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? src : xn);
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          const u32x4 w = ok ? v : z;
+          xf[g][ks] = *reinterpret_cast<const bf16x8*>(&w);
+        }
       }
-      unsigned char* dst = tile + ((long)(r_lo + rr - iy0) * WP + cc + 1) * PS + 8 * q;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < nts) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < NPF; ++g) {
+        if (tb + 4 * g >= ntl) break;                             // (wave-uniform)
+        const bool pok = poks[g];
+        unsigned char* dst = tile + ((long)(r_lo + rrs[g] - iy0) * WP + ccs[g] + 1) * PS + 8 * q;
 #pragma unroll
-          for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t][ks], xf[ks], acc, 0, 0, 0);
-          if (pok) {
-            bf16x4 o;
+        for (int t = 0; t < 4; ++t) {
+          if (t < nts) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(acc[e] * a1[t][e] + b1[t][e], 0.f);
-            *reinterpret_cast<bf16x4*>(dst + t * 32) = o;
+            for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t][ks], xf[g][ks], acc, 0, 0, 0);
+            if (pok) {
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(acc[e] * a1[t][e] + b1[t][e], 0.f);
+              *reinterpret_cast<bf16x4*>(dst + t * 32) = o;
+            }
           }
         }
       }
