@@ -7,6 +7,7 @@ keeps the activations the backward needs and maps the kernels' packed gradient l
 state_dict names.  Inputs: trunk features (B, T, C) *after* the positional encoding; outputs: the loss, the gradient of
 every `_temp_fine.*`, `_pred_fine.*`, `_pred_displ.*` parameter and the gradient w.r.t. the features, which
 `trainer.TrainEngine` hands on to the trunk backward (trunk_train.py)."""
+import os
 from types import SimpleNamespace
 
 import torch
@@ -15,6 +16,7 @@ from . import ops, ops_bwd as B_, repack as R
 from .regnet_spec import pyramid_lengths
 
 _BR = ["psi", "convw", "convkw", "fc", "global_fc"]
+SPLITK_TRAIN = os.environ.get("TDEED_TRAIN_SPLITK", "1") == "1"
 
 
 def _flat(v):
@@ -89,6 +91,14 @@ class TemporalStack:
             o.fc2, o.b2 = _Dense(sd[pre + ".mlp.2.weight"], dt), sd[pre + ".mlp.2.bias"]
             self.mixers.append(o)
 
+    def _long_k(self, A, W, bias, R, residual=None):
+        """A (R, K) @ W (N, K)^T + bias (+ residual) for the long contractions over few rows (fc2, concat_fc, fc1's input
+        gradient: K = 4C .. 6C over B*T = 400 .. 1600 rows).  The tiled kernel walks K in ~100 dependent slabs on a few dozen
+        workgroups (50 us whatever the row count); the split-K form of the inference path spreads K over the chip."""
+        if self.dt == torch.bfloat16 and SPLITK_TRAIN and R <= 4096 and W.shape[1] >= 1024:
+            return ops.gemm_splitk(A, W, None, bias, ops.ACT_NONE, residual=residual, M=R)
+        return ops.gemm(A, W, None, bias, ops.ACT_NONE, residual=residual, M=R)
+
     # ------------------------------------------------------------------ mlp (shared by blocks and mixers)
     def _mlp_fwd(self, y, o, ctx):
         Bn, T, C = y.shape
@@ -96,7 +106,7 @@ class TemporalStack:
         gn = ops.groupnorm(y, 16, o.gn_w, o.gn_b)
         hpre = ops.gemm(gn, o.fc1.w, None, o.b1, ops.ACT_NONE, M=R).view(Bn, T, 4 * C)
         hid = B_.eltwise(hpre, None, B_.GELU_FWD)
-        out = ops.gemm(hid, o.fc2.w, None, o.b2, ops.ACT_NONE, residual=y, M=R).view(Bn, T, C)
+        out = self._long_k(hid, o.fc2.w, o.b2, R, residual=y).view(Bn, T, C)
         ctx.gn, ctx.hpre, ctx.hid = gn, hpre, hid
         return out
 
@@ -107,7 +117,7 @@ class TemporalStack:
         d_hid = ops.gemm(dout, o.fc2.wt, None, None, ops.ACT_NONE, M=R).view(Bn, T, 4 * C)
         dW2, db2 = B_.wgrad(dout, ctx.hid, M=R)
         d_hpre = B_.eltwise(ctx.hpre, d_hid, B_.GELU_BWD)
-        d_gn = ops.gemm(d_hpre, o.fc1.wt, None, None, ops.ACT_NONE, M=R).view(Bn, T, C)
+        d_gn = self._long_k(d_hpre, o.fc1.wt, None, R).view(Bn, T, C)
         dW1, db1 = B_.wgrad(d_hpre, ctx.gn, M=R)
         d_y = dout.clone()
         _, dgw, dgb = B_.groupnorm_bwd(y, d_gn, 16, o.gn_w, dx=d_y, accumulate=True)
@@ -146,7 +156,7 @@ class TemporalStack:
         ops.layernorm(z, o.ln1_w, o.ln1_b, out=cat.view(-1)[4 * C:], ldy=6 * C, rows=R, C=C)
         xn = ops.layernorm(xlo, o.ln2_w, o.ln2_b)
         ops.mixer_branch(xn, cat, T_hi, o.ks, o.up, o.dw1, o.db1, o.dw2, o.db2)
-        cpre = ops.gemm(cat, o.cat.w, None, o.bcat, ops.ACT_NONE, M=R).view(Bn, T_hi, C)
+        cpre = self._long_k(cat, o.cat.w, o.bcat, R).view(Bn, T_hi, C)
         mo = B_.eltwise(cpre, None, B_.GELU_FWD)
         ctx.cat, ctx.cpre, ctx.mo, ctx.T_lo = cat, cpre, mo, T_lo
         return self._mlp_fwd(mo, o, ctx), ctx
