@@ -765,9 +765,9 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, co
 }
 
 // =========================================================================== channel LayerNorm backward
-// one wave per row, 32 rows per workgroup; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;
+// one wave per row, LNB_ROWS rows per workgroup; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;
 // part[blk][0][c] = sum_rows dy * xhat (d weight), part[blk][1][c] = sum_rows dy (d bias)
-constexpr int LNB_ROWS = 32;
+constexpr int LNB_ROWS = 8;      // (32 until round 4: 1600 rows were 50 workgroups of 8 dependent row rounds per wave)
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                             long ldy, int rows, int C, const float* __restrict__ w,
@@ -868,7 +868,8 @@ extern "C" int tdeed_layernorm_bwd_blocks(int rows) { return (rows + LNB_ROWS - 
 extern "C" int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long ldy, int rows, int C, const float* w,
                                    float eps, void* dx, int accumulate, float* part, float* dw, float* db, int dtype,
                                    void* stream) {
-  TD_CHECK(x && dy && w && dx && part && dw && db, "layernorm_bwd: null pointer");
+  // dw == db == NULL: partials only (part [blocks][2][C]; the caller folds them, e.g. with the gradient write-out)
+  TD_CHECK(x && dy && w && dx && part && (!dw == !db), "layernorm_bwd: null pointer");
   TD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm_bwd: bad sizes");
   const int nb = tdeed_layernorm_bwd_blocks(rows);
   const size_t smem = (size_t)8 * C * sizeof(float);
@@ -883,6 +884,7 @@ extern "C" int tdeed_layernorm_bwd(const void* x, long ldx, const void* dy, long
                        (const bf16_t*)dy, ldy, rows, C, w, eps, (bf16_t*)dx, accumulate, part);
   } else { tdeed_set_error("layernorm_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("layernorm_bwd");
+  if (!dw) return TDEED_OK;
   // part viewed as [nb][2C]: the first C columns of a row are d weight, the next C are d bias
   launch_reduce(part, nb, 2L * C, (long)C, dw, 0, st);
   launch_reduce(part + C, nb, 2L * C, (long)C, db, 0, st);
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const T* __restrict_
 extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, int C, int G, const float* w, float eps,
                                    void* dx, int accumulate, float* part, float* dw, float* db, int dtype,
                                    void* stream) {
-  TD_CHECK(x && dy && w && dx && part && dw && db, "groupnorm_bwd: null pointer");
+  TD_CHECK(x && dy && w && dx && part && (!dw == !db), "groupnorm_bwd: null pointer");
   TD_CHECK(B > 0 && T > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad sizes");
   const size_t smem = ((size_t)2 * T * (C / G) + 2 * (C / G) + 8) * sizeof(float);
   TD_CHECK(smem <= 150 * 1024, "groupnorm_bwd: slab too large");
@@ -983,6 +985,7 @@ extern "C" int tdeed_groupnorm_bwd(const void* x, const void* dy, int B, int T, 
                        G, w, eps, (bf16_t*)dx, accumulate, part);
   else { tdeed_set_error("groupnorm_bwd: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("groupnorm_bwd");
+  if (!dw) return TDEED_OK;                                      // partials only (see tdeed_layernorm_bwd)
   // part viewed as [B][2C]: the first C columns of each row are d weight, the next C are d bias
   launch_reduce(part, B, 2L * C, (long)C, dw, 0, st);
   launch_reduce(part + C, B, 2L * C, (long)C, db, 0, st);

@@ -35,8 +35,10 @@ class LazyFold:
     (`multi_copy` -> tdeed_multi_fold) folds it on its way into the flat gradient buffer, instead of one fold launch per
     tensor (~280 per step).  Quacks like the tensor it stands for as far as the write-out needs (numel / dtype / reshape)."""
 
-    def __init__(self, part, P, n, shape=None):
+    def __init__(self, part, P, n, shape=None, pstride=None):
+        """part: fp32 tensor whose storage from data_ptr() on holds P rows of n values, pstride (default n) floats apart"""
         self.part, self.P, self.n = part, int(P), int(n)
+        self.pstride = self.n if pstride is None else int(pstride)
         self.shape = tuple(shape) if shape is not None else (self.n,)
         self.dtype, self.device = torch.float32, part.device
 
@@ -45,11 +47,14 @@ class LazyFold:
 
     def reshape(self, *shape):
         shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
-        return LazyFold(self.part, self.P, self.n, shape)
+        return LazyFold(self.part, self.P, self.n, shape, self.pstride)
 
     view = reshape
 
     def materialize(self):
+        if self.pstride != self.n:
+            rows = torch.as_strided(self.part, (self.P, self.n), (self.pstride, 1), self.part.storage_offset())
+            return rows.sum(0).view(self.shape)
         out = _f32((self.n,), self.device)
         call("tdeed_reduce_partials", ptr(self.part), self.P, self.n, ptr(out), 0, stream_ptr())
         return out.view(self.shape)
@@ -97,7 +102,14 @@ def layernorm_bwd(x, dy, w, eps=1e-5, dx=None, accumulate=False, ldx=None, ldy=N
     if dx is None:
         dx = torch.empty_like(x)
     nb = _lib.load().tdeed_layernorm_bwd_blocks(rows)
-    part, dw, db = _f32((nb, 2, C), dev), _f32((C,), dev), _f32((C,), dev)
+    part = _f32((nb, 2, C), dev)
+    if LAZY_WGRAD:
+        # the parameter gradients stay per-workgroup partials: the gradient write-out folds them (no reduce launches here)
+        call("tdeed_layernorm_bwd", ptr(x), (C if ldx is None else ldx), ptr(dy), (C if ldy is None else ldy), rows, C, ptr(w),
+             eps, ptr(dx), int(accumulate), ptr(part), None, None, dtype_code(x.dtype), stream_ptr())
+        flat = part.view(-1)
+        return dx, LazyFold(flat, nb, C, pstride=2 * C), LazyFold(flat[C:], nb, C, pstride=2 * C)
+    dw, db = _f32((C,), dev), _f32((C,), dev)
     call("tdeed_layernorm_bwd", ptr(x), (C if ldx is None else ldx), ptr(dy), (C if ldy is None else ldy), rows, C, ptr(w),
          eps, ptr(dx), int(accumulate), ptr(part), ptr(dw), ptr(db), dtype_code(x.dtype), stream_ptr())
     return dx, dw, db
@@ -108,7 +120,13 @@ def groupnorm_bwd(x, dy, G, w, eps=1e-5, dx=None, accumulate=False):
     dev = x.device
     if dx is None:
         dx = torch.empty_like(x)
-    part, dw, db = _f32((B, 2, C), dev), _f32((C,), dev), _f32((C,), dev)
+    part = _f32((B, 2, C), dev)
+    if LAZY_WGRAD:
+        call("tdeed_groupnorm_bwd", ptr(x), ptr(dy), B, T, C, G, ptr(w), eps, ptr(dx), int(accumulate), ptr(part), None, None,
+             dtype_code(x.dtype), stream_ptr())
+        flat = part.view(-1)
+        return dx, LazyFold(flat, B, C, pstride=2 * C), LazyFold(flat[C:], B, C, pstride=2 * C)
+    dw, db = _f32((C,), dev), _f32((C,), dev)
     call("tdeed_groupnorm_bwd", ptr(x), ptr(dy), B, T, C, G, ptr(w), eps, ptr(dx), int(accumulate), ptr(part), ptr(dw),
          ptr(db), dtype_code(x.dtype), stream_ptr())
     return dx, dw, db
@@ -589,7 +607,7 @@ def multi_copy(srcs, offsets, dst_flat, scale=1.0, accumulate=False, tables=None
     for t_, off in zip(srcs, offsets):
         if isinstance(t_, LazyFold):
             cw = cwf(t_.P, t_.n)
-            rows.append((t_.part.data_ptr(), off, t_.n, wg, t_.P | (cw << 32), t_.n, t_.n, t_.n))
+            rows.append((t_.part.data_ptr(), off, t_.n, wg, t_.P | (cw << 32), t_.pstride, t_.n, t_.n))
             wg += (t_.n + cw - 1) // cw if t_.P > 1 else (t_.n + 4095) // 4096
             keep.append(t_.part)
             continue
