@@ -555,6 +555,14 @@ int tdeed_gsf_add_cols_sink_parts(long M, int Fp, int dtype);
 int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask, long ldmask,
                             const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd, const float* bmean_d,
                             float* part, int dtype, void* stream);
+/* tdeed_gsf_add_cols_sink with the backward of the module's BatchNorm3d applied to b on load: b = the gradient at the
+ * BatchNorm's output (d_bn of tdeed_gsf_bwd), bnx [M][Fp] its input (the dense slice), bn_sums fp32 [2][Fp] = (sum g,
+ * sum g xhat) as tdeed_bn_bwd_from_parts leaves them, bn_mean / bn_rstd / bn_w [Fp]: batch statistics and weight
+ * (torch.nn.BatchNorm3d under autograd, /root/reference/model/impl/gsf.py:38-93). */
+int tdeed_gsf_add_cols_sink_bn(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask, long ldmask,
+                               const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd,
+                               const float* bmean_d, float* part, const void* bnx, const float* bn_sums, const float* bn_mean,
+                               const float* bn_rstd, const float* bn_w, int dtype, void* stream);
 int tdeed_bn_bwd_from_parts(const void* z, const void* g, long M, int C, const float* mean, const float* rstd, const float* w,
                             const float* partA, int PA, const float* partB, int PB, int nB, int q, float* tmp, float* sums,
                             void* dz, int dtype, void* stream);
@@ -606,6 +614,16 @@ int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float
                   const float* sb, const float* cw1, const float* cw2, float* scratch, void* d_xs, void* d_bn,
                   float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype, void* stream);
 int tdeed_gsf_add_cols(const void* a, const void* b, long M, int C, int Fp, void* dx, int dtype, void* stream);
+/* tdeed_gsf_bwd that also leaves the statistics of the module's BatchNorm3d backward: bn_part fp32
+ * [tdeed_gsf_bwd_bn_parts(B,T,h,w,C,Fp)][3][Fp], rows 0 / 1 = per-workgroup sums of d_bn and d_bn * (x - bn_mean) (the layout
+ * tdeed_bn_bwd_from_parts folds with q = 1); tdeed_gsf_bwd_bn_parts == 0: not served at this geometry.  In both entries
+ * d_w3 == NULL leaves the parameter gradients as partials inside scratch (layout in gsf_bwd.hip) for the caller's fold. */
+int tdeed_gsf_bwd_bn_parts(int B, int T, int h, int w, int C, int Fp);
+int tdeed_gsf_bwd_stats(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                        const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3, const float* sa,
+                        const float* sb, const float* cw1, const float* cw2, float* scratch, void* d_xs, void* d_bn,
+                        float* d_w3, float* d_b3, float* d_cw, float* d_cb, const float* bn_mean, float* bn_part, int dtype,
+                        void* stream);
 
 /* ---- data-parallel gradient reduction over RCCL / xGMI (comm.hip) ---------------------------------------------------
  * New functionality (the reference is single-GPU: model/model.py:184-190): one process per GPU, one

@@ -105,6 +105,11 @@ _SIGS = {
     "tdeed_gsf_bwd": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                        c_int, P], c_int),
     "tdeed_gsf_add_cols": ([P, P, c_long, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_gsf_bwd_bn_parts": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int),
+    "tdeed_gsf_bwd_stats": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                             P, P, c_int, P], c_int),
+    "tdeed_gsf_add_cols_sink_bn": ([P, P, c_long, c_int, c_int, P, P, c_long, P, c_long, P, P, c_long, P, P, P, P, P, P, P, c_int,
+                                    P], c_int),
     "tdeed_multi_fold_cw": ([c_int, c_long], c_int),
     "tdeed_multi_fold": ([P, c_int, c_long, P, c_float, c_int, P], c_int),
     "tdeed_multi_copy": ([P, c_int, c_long, P, c_float, c_int, P], c_int),

@@ -379,12 +379,17 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __rest
                                                                  const float* __restrict__ w3,
                                                                  const float* __restrict__ sa, const float* __restrict__ sb,
                                                                  int T_len, int h, int w, int C, int F, int Fp, int PT,
-                                                                 T* __restrict__ d_bn) {
+                                                                 T* __restrict__ d_bn, const float* __restrict__ bn_mean,
+                                                                 float* __restrict__ bn_part) {
+  // bn_part (training): d_bn enters the BatchNorm3d of the module, whose backward needs sum g and sum g * (x - mean) over all
+  // pixels: this workgroup's partial row bn_part[(f * gridDim.x + blockIdx.x)][3][Fp] (rows 0 and 1; of the STORED values)
+  // replaces the column-statistics pass over (d_bn, x) -- tdeed_bn_bwd_from_parts folds the rows.
   constexpr int EPC = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   float* sw = reinterpret_cast<float*>(smraw);                 // [27][Fp]
   float* dp = sw + Fp * 27;                                    // [PT][2][27] (+1 pad per row)
   float* aff = dp + PT * 55;                                   // [2][F]
+  float* bred = aff + 2 * F;                                   // [PT][2][Fp] (bn_part only)
   const int NCH = Fp / EPC;
   const long f = blockIdx.y;
   const int hw = h * w;
@@ -413,42 +418,61 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __rest
   }
   __syncthreads();
   const int pl = tid / NCH, k = tid - pl * NCH;
-  if (pl >= np) return;
-  const long pix = f * hw + p0 + pl;
+  const bool act = pl < np;
+  if (!act && !bn_part) return;
   float xv[EPC], o[EPC];
-  ld8<T>(x + pix * C + k * EPC, xv);
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) o[e] = 0.f;
-  // a chunk lies in one gate group unless it straddles F/2 (F/2 not a multiple of 8): per-element group then
-  const bool one_g = (k * EPC + EPC <= Fh) || (k * EPC >= Fh);
-  const float* d0 = dp + pl * 55;
-  if (one_g) {
-    const float* d = d0 + (k * EPC >= Fh ? 27 : 0);
+  for (int e = 0; e < EPC; ++e) { xv[e] = 0.f; o[e] = 0.f; }
+  if (act) {
+    const long pix = f * hw + p0 + pl;
+    ld8<T>(x + pix * C + k * EPC, xv);
+    // a chunk lies in one gate group unless it straddles F/2 (F/2 not a multiple of 8): per-element group then
+    const bool one_g = (k * EPC + EPC <= Fh) || (k * EPC >= Fh);
+    const float* d0 = dp + pl * 55;
+    if (one_g) {
+      const float* d = d0 + (k * EPC >= Fh ? 27 : 0);
 #pragma unroll
-    for (int kq = 0; kq < 27; ++kq) {
-      const float dv = d[kq];
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + kq * Fp + k * EPC);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(sw + kq * Fp + k * EPC + 4);
+      for (int kq = 0; kq < 27; ++kq) {
+        const float dv = d[kq];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + kq * Fp + k * EPC);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sw + kq * Fp + k * EPC + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = fmaf(w0[e], dv, o[e]);
-        o[4 + e] = fmaf(w1[e], dv, o[4 + e]);
+        for (int e = 0; e < 4; ++e) {
+          o[e] = fmaf(w0[e], dv, o[e]);
+          o[4 + e] = fmaf(w1[e], dv, o[4 + e]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < 27; ++kq) {
+        const float da = d0[kq], db = d0[27 + kq];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = fmaf(sw[kq * Fp + k * EPC + e], (k * EPC + e >= Fh) ? db : da, o[e]);
       }
     }
-  } else {
 #pragma unroll
-    for (int kq = 0; kq < 27; ++kq) {
-      const float da = d0[kq], db = d0[27 + kq];
+    for (int e = 0; e < EPC; ++e) {
+      const int c = k * EPC + e;
+      if (c >= F || !(fmaf(xv[e], aff[c], aff[F + c]) > 0.f)) o[e] = 0.f;
+    }
+    st8<T>(d_bn + pix * Fp + k * EPC, o);
+  }
+  if (!bn_part) return;
+  if (pl < PT) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) o[e] = fmaf(sw[kq * Fp + k * EPC + e], (k * EPC + e >= Fh) ? db : da, o[e]);
+    for (int e = 0; e < EPC; ++e) {
+      const int c = k * EPC + e;
+      const float r = act ? round_to<T>(o[e]) : 0.f;
+      bred[(pl * 2 + 0) * Fp + c] = r;
+      bred[(pl * 2 + 1) * Fp + c] = (act && c < F) ? r * (xv[e] - bn_mean[c]) : 0.f;
     }
   }
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    const int c = k * EPC + e;
-    if (c >= F || !(fmaf(xv[e], aff[c], aff[F + c]) > 0.f)) o[e] = 0.f;
+  __syncthreads();
+  for (int j = tid; j < 2 * Fp; j += 256) {
+    float a = 0.f;
+    for (int i = 0; i < PT; ++i) a += bred[i * 2 * Fp + j];
+    bn_part[((f * gridDim.x + blockIdx.x) * 3) * Fp + j] = a;
   }
-  st8<T>(d_bn + pix * Fp + k * EPC, o);
 }
 
 // ---- conv3d weight gradient: workgroup = frame f'; a[f'] (relu(bn(x))) tile in LDS, d_pre of frames f'-1..f'+1 with a
@@ -692,7 +716,7 @@ template <typename T>
 static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, const float* ysum, const float* xsum,
                           const void* dA_, int B, int T_len, int h, int w, int C, int F, int Fp, const float* w3,
                           const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
-                          void* d_xs_, void* d_bn_, hipStream_t st) {
+                          void* d_xs_, void* d_bn_, const float* bn_mean, float* bn_part, hipStream_t st) {
   const T* x = (const T*)x_;
   const T* dA = (const T*)dA_;
   T* d_xs = (T*)d_xs_;
@@ -731,11 +755,12 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
     hipLaunchKernelGGL(gsf_bwd_gate2_kernel<T>, g2, dim3(256), sm_g, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, PT,
                        d_xs, d_pre);
     TD_LAUNCH_CHECK("gsf_bwd_gate2");
-    const size_t sm_d = (size_t)(Fp * 27 + PT * 55 + 2 * F) * sizeof(float);
+    const size_t sm_d = (size_t)(Fp * 27 + PT * 55 + 2 * F + (bn_part ? 2 * PT * Fp : 0)) * sizeof(float);
     hipLaunchKernelGGL(gsf_bwd_conv3d_dx2_kernel<T>, g2, dim3(256), sm_d, st, x, d_pre, w3, sa, sb, T_len, h, w, C, F, Fp,
-                       PT, d_bn);
+                       PT, d_bn, bn_mean, bn_part);
     TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx2");
   } else {
+    TD_CHECK(!bn_part, "gsf_bwd: the BatchNorm3d statistics partials come from the coalesced kernels only (tdeed_gsf_bwd_bn_parts)");
     hipLaunchKernelGGL(gsf_bwd_gate_kernel<T>, gpix, dim3(256), 0, st, x, gate, fw, dA, d_ym, d_rm, T_len, hw, C, F, Fp, d_xs,
                        d_pre);
     TD_LAUNCH_CHECK("gsf_bwd_gate");
@@ -773,24 +798,26 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
 // gradient entering the BatchNorm3d output after the ReLU mask (d_bn, dense [M][Fp]); parameter gradients:
 // d_w3 [F][27] (= conv3D.weight (2, F/2, 3,3,3) flattened), d_b3 [2], d_cw [2][18] + d_cb [2] (channel_conv1 | 2).
 // sa/sb: the BatchNorm3d affine used by the forward of this step.  scratch: tdeed_gsf_bwd_scratch_floats() fp32.
-extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
-                             const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3,
-                             const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
-                             void* d_xs, void* d_bn, float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype,
-                             void* stream) {
+static int gsf_bwd_entry(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                         const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3,
+                         const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
+                         void* d_xs, void* d_bn, float* d_w3, float* d_b3, float* d_cw, float* d_cb, const float* bn_mean,
+                         float* bn_part, int dtype, void* stream) {
   // fw == NULL selects the plain gate-shift module (_GSM, impl/gsm.py:89-116: out = shift(gate*x) + (x - gate*x), no
   // fusion conv): ysum / xsum / cw1 / cw2 / d_cw / d_cb are then unused and may be NULL
-  TD_CHECK(x && gate && dA && w3 && sa && sb && scratch && d_xs && d_bn && d_w3 && d_b3, "gsf_bwd: null pointer");
-  TD_CHECK(!fw || (ysum && xsum && cw1 && cw2 && d_cw && d_cb), "gsf_bwd: the fuse path needs ysum, xsum, cw1, cw2, d_cw, d_cb");
+  // d_w3 == NULL: the parameter gradients stay partials in `scratch` (part_cw [B * 8][38] at float offset 4 N F + 2 N hw, then
+  // part_w3 [N][27 F + 2]; column layout in the fold calls below) for a caller that folds them itself (gradient write-out)
+  TD_CHECK(x && gate && dA && w3 && sa && sb && scratch && d_xs && d_bn && (!d_w3 == !d_b3), "gsf_bwd: null pointer");
+  TD_CHECK(!fw || (ysum && xsum && cw1 && cw2 && (!d_w3 || (d_cw && d_cb))), "gsf_bwd: the fuse path needs ysum, xsum, cw1, cw2, d_cw, d_cb");
   TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && F > 0 && F % 4 == 0 && Fp >= F && Fp <= C && F <= 256, "gsf_bwd: bad sizes");
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   int rc = dtype == TDEED_F32
                ? gsf_bwd_launch<float>(x, gate, fw, ysum, xsum, dA, B, T, h, w, C, F, Fp, w3, sa, sb, cw1, cw2, scratch, d_xs,
-                                       d_bn, st)
+                                       d_bn, bn_mean, bn_part, st)
                : gsf_bwd_launch<bf16_t>(x, gate, fw, ysum, xsum, dA, B, T, h, w, C, F, Fp, w3, sa, sb, cw1, cw2, scratch,
-                                        d_xs, d_bn, st);
-  if (rc != TDEED_OK) return rc;
+                                        d_xs, d_bn, bn_mean, bn_part, st);
+  if (rc != TDEED_OK || !d_w3) return rc;
   const long N = (long)B * T;
   float* part_cw = scratch + 4 * N * F + N * h * w * 2;
   float* part_w3 = part_cw + (long)B * GSF_CW_Z * 38;
@@ -804,6 +831,34 @@ extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, 
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 18, B * GSF_CW_Z, 38, 1, d_cb, stream);
   if (rc == TDEED_OK) rc = tdeed_reduce_strided(part_cw + 37, B * GSF_CW_Z, 38, 1, d_cb + 1, stream);
   return rc;
+}
+
+extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                             const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3,
+                             const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
+                             void* d_xs, void* d_bn, float* d_w3, float* d_b3, float* d_cw, float* d_cb, int dtype,
+                             void* stream) {
+  return gsf_bwd_entry(x, gate, fw, ysum, xsum, dA, B, T, h, w, C, F, Fp, w3, sa, sb, cw1, cw2, scratch, d_xs, d_bn, d_w3, d_b3,
+                       d_cw, d_cb, nullptr, nullptr, dtype, stream);
+}
+// rows of bn_part (fp32 [rows][3][Fp]) tdeed_gsf_bwd_stats writes; 0: this geometry has no statistics epilogue
+extern "C" int tdeed_gsf_bwd_bn_parts(int B, int T, int h, int w, int C, int Fp) {
+  const bool old_pix = getenv("TDEED_GSF_BWD_PIXEL") && atoi(getenv("TDEED_GSF_BWD_PIXEL")) == 1;
+  if (old_pix || Fp % 8 != 0 || Fp > C || Fp / 8 > 64) return 0;
+  const int PT = 256 / (Fp / 8);
+  return cdiv(h * w, PT) * B * T;
+}
+// tdeed_gsf_bwd that also leaves the statistics of the module's BatchNorm3d backward (bn_mean: its batch means, fp32 [>= F]):
+// bn_part[p][0][c] = sum d_bn, bn_part[p][1][c] = sum d_bn * (x - mean) over the pixels of workgroup p (row 2 unused), the
+// layout tdeed_bn_bwd_from_parts folds (q = 1): no column-statistics pass over (d_bn, x)
+extern "C" int tdeed_gsf_bwd_stats(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
+                                   const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3,
+                                   const float* sa, const float* sb, const float* cw1, const float* cw2, float* scratch,
+                                   void* d_xs, void* d_bn, float* d_w3, float* d_b3, float* d_cw, float* d_cb,
+                                   const float* bn_mean, float* bn_part, int dtype, void* stream) {
+  TD_CHECK(bn_mean && bn_part && tdeed_gsf_bwd_bn_parts(B, T, h, w, C, Fp) > 0, "gsf_bwd_stats: no statistics epilogue here");
+  return gsf_bwd_entry(x, gate, fw, ysum, xsum, dA, B, T, h, w, C, F, Fp, w3, sa, sb, cw1, cw2, scratch, d_xs, d_bn, d_w3, d_b3,
+                       d_cw, d_cb, bn_mean, bn_part, dtype, stream);
 }
 
 // dx[m][0:Fp] += a + b (dx row stride C): the module's input gradient joins conv1's pass-through gradient

@@ -248,17 +248,32 @@ __global__ __launch_bounds__(256) void gsf_add_cols_sink_kernel(const T* __restr
                                                                 long ldmask, const T* __restrict__ bz, long ldbz,
                                                                 const float* __restrict__ bmean, const T* __restrict__ bzd,
                                                                 long ldbzd, const float* __restrict__ bmean_d,
-                                                                float* __restrict__ part, int nch, long rpw) {
+                                                                float* __restrict__ part, int nch, long rpw,
+                                                                const T* __restrict__ bnx, const float* __restrict__ bn_sums,
+                                                                const float* __restrict__ bn_mean,
+                                                                const float* __restrict__ bn_rstd, const float* __restrict__ bn_w,
+                                                                float inv_M) {
+  // bnx: b is the gradient at the OUTPUT of the module's BatchNorm3d and the BatchNorm backward is applied right here,
+  // b' = round(k1 b + k2 bnx + k3) from the statistics bn_sums = (sum g, sum g xhat): the dz map is not written and read back
   constexpr int EPC = Chunk<T>::N;
   extern __shared__ float red[];                                 // [RL][3][Fp]
   const int RL = 256 / nch, rl = threadIdx.x / nch, ck = threadIdx.x - rl * nch;
   const int c0 = ck * EPC;
   float s1[EPC], s2[EPC], s3[EPC], bm[EPC], bmd[EPC];
+  float k1[EPC], k2[EPC], k3[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     s1[e] = s2[e] = s3[e] = 0.f;
     bm[e] = (part && rl < RL) ? bmean[c0 + e] : 0.f;
     bmd[e] = (part && bzd && rl < RL) ? bmean_d[c0 + e] : 0.f;
+    k1[e] = k2[e] = k3[e] = 0.f;
+    if (bnx && rl < RL) {
+      const int c = c0 + e;
+      const float rs = bn_rstd[c], mu = bn_mean[c], m1 = bn_sums[c] * inv_M, m2 = bn_sums[Fp + c] * inv_M;
+      k1[e] = bn_w[c] * rs;
+      k2[e] = -k1[e] * rs * m2;
+      k3[e] = k1[e] * (mu * rs * m2 - m1);
+    }
   }
   const long m0 = (long)blockIdx.x * rpw, m1 = min(M, m0 + rpw);
   if (rl < RL) {
@@ -269,6 +284,12 @@ __global__ __launch_bounds__(256) void gsf_add_cols_sink_kernel(const T* __restr
         const long r = min(r0 + (long)u * RL, m1 - 1);
         Chunk<T>::load(a + r * Fp + c0, av[u]);
         Chunk<T>::load(b + r * Fp + c0, bv[u]);
+        if (bnx) {
+          float bx[EPC];
+          Chunk<T>::load(bnx + r * Fp + c0, bx);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) bv[u][e] = round_to<T>(fmaf(k1[e], bv[u][e], fmaf(k2[e], bx[e], k3[e])));
+        }
         Chunk<T>::load(dx + r * C + c0, xv[u]);
         if (mask) Chunk<T>::load(mask + r * ldmask + c0, mv[u]);
         if (part) Chunk<T>::load(bz + r * ldbz + c0, zv[u]);
@@ -325,9 +346,10 @@ extern "C" int tdeed_gsf_add_cols_sink_parts(long M, int Fp, int dtype) {
   return (int)((M + rpw - 1) / rpw);
 }
 
-extern "C" int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask,
-                                       long ldmask, const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd,
-                                       const float* bmean_d, float* part, int dtype, void* stream) {
+static int add_cols_sink_launch(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask,
+                                long ldmask, const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd,
+                                const float* bmean_d, float* part, const void* bnx, const float* bn_sums, const float* bn_mean,
+                                const float* bn_rstd, const float* bn_w, int dtype, void* stream) {
   TD_CHECK(a && b && dx && M > 0 && Fp > 0 && Fp <= C && Fp % 8 == 0 && C % 8 == 0, "gsf_add_cols_sink: bad arguments");
   TD_CHECK(dtype == TDEED_F32 || dtype == TDEED_BF16, "gsf_add_cols_sink: bad dtype %d", dtype);
   TD_CHECK(!part || (bz && bmean && (!bzd || bmean_d)), "gsf_add_cols_sink: statistics operands missing");
@@ -342,13 +364,32 @@ extern "C" int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(gsf_add_cols_sink_kernel<float>, dim3((unsigned)nwg), dim3(256), smem, st, (const float*)a, (const float*)b,
                        M, C, Fp, (float*)dx, (const float*)mask, ldmask, (const float*)bz, ldbz, bmean, (const float*)bzd, ldbzd,
-                       bmean_d, part, nch, rpw);
+                       bmean_d, part, nch, rpw, (const float*)bnx, bn_sums, bn_mean, bn_rstd, bn_w, 1.0f / (float)M);
   else
     hipLaunchKernelGGL(gsf_add_cols_sink_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), smem, st, (const bf16_t*)a,
                        (const bf16_t*)b, M, C, Fp, (bf16_t*)dx, (const bf16_t*)mask, ldmask, (const bf16_t*)bz, ldbz, bmean,
-                       (const bf16_t*)bzd, ldbzd, bmean_d, part, nch, rpw);
+                       (const bf16_t*)bzd, ldbzd, bmean_d, part, nch, rpw, (const bf16_t*)bnx, bn_sums, bn_mean, bn_rstd, bn_w,
+                       1.0f / (float)M);
   TD_LAUNCH_CHECK("gsf_add_cols_sink");
   return TDEED_OK;
+}
+extern "C" int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask,
+                                       long ldmask, const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd,
+                                       const float* bmean_d, float* part, int dtype, void* stream) {
+  return add_cols_sink_launch(a, b, M, C, Fp, dx, mask, ldmask, bz, ldbz, bmean, bzd, ldbzd, bmean_d, part, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, dtype, stream);
+}
+// ... with the backward of the module's BatchNorm3d applied to b on load: b [M][Fp] = the gradient at the BatchNorm's output
+// (d_bn of tdeed_gsf_bwd), bnx [M][Fp] its input (the dense slice), bn_sums fp32 [2][Fp] = (sum g, sum g xhat) as
+// tdeed_bn_bwd_from_parts leaves them, bn_mean / bn_rstd / bn_w [Fp]: its batch statistics and weight
+extern "C" int tdeed_gsf_add_cols_sink_bn(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask,
+                                          long ldmask, const void* bz, long ldbz, const float* bmean, const void* bzd,
+                                          long ldbzd, const float* bmean_d, float* part, const void* bnx, const float* bn_sums,
+                                          const float* bn_mean, const float* bn_rstd, const float* bn_w, int dtype,
+                                          void* stream) {
+  TD_CHECK(bnx && bn_sums && bn_mean && bn_rstd && bn_w, "gsf_add_cols_sink_bn: null pointer");
+  return add_cols_sink_launch(a, b, M, C, Fp, dx, mask, ldmask, bz, ldbz, bmean, bzd, ldbzd, bmean_d, part, bnx, bn_sums, bn_mean,
+                              bn_rstd, bn_w, dtype, stream);
 }
 
 // --------------------------------------------------------------------------- BatchNorm backward from producer partials

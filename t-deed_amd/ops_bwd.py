@@ -426,13 +426,20 @@ def gemm_dgrad(dz, wt, sink=None, residual=None, r_hw=None, out2=None):
     return dx
 
 
-def gsf_add_cols_sink(a, b, dx, Fp, sink):
-    """dx[:, :Fp] += (a + b) masked / summed for `sink` (tdeed_gsf_add_cols_sink)"""
+def gsf_add_cols_sink(a, b, dx, Fp, sink, bn=None):
+    """dx[:, :Fp] += (a + b) masked / summed for `sink` (tdeed_gsf_add_cols_sink).  bn = (xs, sums, mean, rstd, w): b is the
+    gradient at the output of the module's BatchNorm3d, whose backward is applied on load (tdeed_gsf_add_cols_sink_bn)."""
     C = dx.shape[-1]
     M = dx.numel() // C
     P = _lib.load().tdeed_gsf_add_cols_sink_parts(M, Fp, dtype_code(dx.dtype))
     part = _f32((P, 3, Fp), dx.device)
     sink.partB, sink.nB = part, Fp
+    if bn is not None:
+        xs, sums, mean, rstd, w = bn
+        call("tdeed_gsf_add_cols_sink_bn", ptr(a), ptr(b), M, C, Fp, ptr(dx), ptr(sink.mask), C, ptr(sink.z), C, ptr(sink.mean),
+             ptr(sink.zd), C, ptr(sink.mean_d), ptr(part), ptr(xs), ptr(sums), ptr(mean), ptr(rstd), ptr(w),
+             dtype_code(dx.dtype), stream_ptr())
+        return dx
     call("tdeed_gsf_add_cols_sink", ptr(a), ptr(b), M, C, Fp, ptr(dx), ptr(sink.mask), C, ptr(sink.z), C, ptr(sink.mean),
          ptr(sink.zd), C, ptr(sink.mean_d), ptr(part), dtype_code(dx.dtype), stream_ptr())
     return dx
@@ -507,22 +514,49 @@ def gsf_slice(x, F, Fp):
     return xs
 
 
-def gsf_bwd(x, gate, fw, ysum, xsum, dA, B, T, F, Fp, w3, sa, sb, cw1, cw2):
+def gsf_bwd_bn_parts(B, T, h, w, C, Fp):
+    return _lib.load().tdeed_gsf_bwd_bn_parts(B, T, h, w, C, Fp)
+
+
+def gsf_bwd(x, gate, fw, ysum, xsum, dA, B, T, F, Fp, w3, sa, sb, cw1, cw2, bn_mean=None):
     """-> d_xs (M,Fp), d_bn (M,Fp), d_w3 (F,27), d_b3 (2,), d_cw (2,18), d_cb (2,).  fw None: the plain gate-shift module
-    (_GSM): no fusion conv, d_cw / d_cb come back None."""
+    (_GSM): no fusion conv, d_cw / d_cb come back None.  bn_mean (the BatchNorm3d's batch means): a seventh result, the
+    statistics partials fp32 [P][3][Fp] of that BatchNorm's backward (tdeed_gsf_bwd_stats)."""
     N, h, w, C = x.shape
     dev = x.device
+    entry, extra = "tdeed_gsf_bwd", ()
+    bn_part = None
+    if bn_mean is not None:
+        bn_part = _f32((gsf_bwd_bn_parts(B, T, h, w, C, Fp), 3, Fp), dev)
+        entry, extra = "tdeed_gsf_bwd_stats", (ptr(bn_mean), ptr(bn_part))
+    ret = (lambda *r: r + (bn_part,)) if bn_mean is not None else (lambda *r: r)
     scratch = _f32((_lib.load().tdeed_gsf_bwd_scratch_floats(B, T, h * w, F),), dev)
     M = N * h * w
     d_xs = torch.empty((M, Fp), dtype=x.dtype, device=dev)
     d_bn = torch.empty((M, Fp), dtype=x.dtype, device=dev)
-    d_w3, d_b3 = _f32((F, 27), dev), _f32((2,), dev)
     fuse = fw is not None
+    if LAZY_WGRAD:
+        # parameter gradients stay the launch's per-frame / per-clip partials inside `scratch`; the gradient write-out folds
+        # them (six reduce launches per module otherwise).  d_cw / d_cb come back as pairs (channel_conv1, channel_conv2)
+        call(entry, ptr(x), ptr(gate), ptr(fw), ptr(ysum), ptr(xsum), ptr(dA), B, T, h, w, C, F, Fp, ptr(w3), ptr(sa),
+             ptr(sb), ptr(cw1), ptr(cw2), ptr(scratch), ptr(d_xs), ptr(d_bn), None, None, None, None, *extra,
+             dtype_code(x.dtype), stream_ptr())
+        row = F * 27 + 2
+        off_cw = 4 * N * F + N * h * w * 2
+        off_w3 = scratch.numel() - N * row
+        PZ = (off_w3 - off_cw) // 38                                # B * GSF_CW_Z rows of 38
+        d_w3 = LazyFold(scratch[off_w3:], N, F * 27, (F, 27), pstride=row)
+        d_b3 = LazyFold(scratch[off_w3 + F * 27:], N, 2, pstride=row)
+        if not fuse:
+            return ret(d_xs, d_bn, d_w3, d_b3, None, None)
+        cw = lambda c0, n: LazyFold(scratch[off_cw + c0:], PZ, n, pstride=38)       # noqa: E731
+        return ret(d_xs, d_bn, d_w3, d_b3, (cw(0, 18), cw(19, 18)), (cw(18, 1), cw(37, 1)))
+    d_w3, d_b3 = _f32((F, 27), dev), _f32((2,), dev)
     d_cw, d_cb = (_f32((2, 18), dev), _f32((2,), dev)) if fuse else (None, None)
-    call("tdeed_gsf_bwd", ptr(x), ptr(gate), ptr(fw), ptr(ysum), ptr(xsum), ptr(dA), B, T, h, w, C, F, Fp, ptr(w3), ptr(sa),
-         ptr(sb), ptr(cw1), ptr(cw2), ptr(scratch), ptr(d_xs), ptr(d_bn), ptr(d_w3), ptr(d_b3), ptr(d_cw), ptr(d_cb),
+    call(entry, ptr(x), ptr(gate), ptr(fw), ptr(ysum), ptr(xsum), ptr(dA), B, T, h, w, C, F, Fp, ptr(w3), ptr(sa),
+         ptr(sb), ptr(cw1), ptr(cw2), ptr(scratch), ptr(d_xs), ptr(d_bn), ptr(d_w3), ptr(d_b3), ptr(d_cw), ptr(d_cb), *extra,
          dtype_code(x.dtype), stream_ptr())
-    return d_xs, d_bn, d_w3, d_b3, d_cw, d_cb
+    return ret(d_xs, d_bn, d_w3, d_b3, d_cw, d_cb)
 
 
 def gsf_add_cols(a, b, dx, Fp):
@@ -607,6 +641,8 @@ def multi_copy(srcs, offsets, dst_flat, scale=1.0, accumulate=False, tables=None
     for t_, off in zip(srcs, offsets):
         if isinstance(t_, LazyFold):
             cw = cwf(t_.P, t_.n)
+            if cw == 1024 and (t_.pstride % 4 or t_.part.data_ptr() % 16):
+                cw = 256                                          # the 4-wide sequential fold wants 16-byte aligned rows
             rows.append((t_.part.data_ptr(), off, t_.n, wg, t_.P | (cw << 32), t_.pstride, t_.n, t_.n))
             wg += (t_.n + cw - 1) // cw if t_.P > 1 else (t_.n + 4095) // 4096
             keep.append(t_.part)

@@ -23,6 +23,9 @@ SE_BN_FUSED = ZMASK and _os.environ.get("TDEED_TRAIN_SE_BN_FUSED", "1") == "1"
 # output-ReLU backward and BatchNorm-backward statistics applied by the producers of each block-input gradient
 # (ops_bwd.GradSink); TDEED_TRAIN_SINK=0 restores the masked statistics pass + d_res map per block
 SINK = _os.environ.get("TDEED_TRAIN_SINK", "1") == "1"
+# the gate-shift module's BatchNorm3d backward: statistics out of the conv3d input-gradient launch, apply inside the kernel that
+# adds the module's input gradient into d x (no column-statistics pass, no dz map)
+GSF_BN_FUSED = _os.environ.get("TDEED_TRAIN_GSF_BN_FUSED", "1") == "1"
 # K = N = 320 contractions over >= RS_MIN_ROWS rows on the register-stationary kernel (forward with the statistics epilogue,
 # conv3's input gradient); TDEED_TRAIN_RS=0: the tiled kernel everywhere
 RS_TRAIN = _os.environ.get("TDEED_TRAIN_RS", "1") == "1"
@@ -99,24 +102,39 @@ class GateShiftTrain:
         self.ctx = c
         return G
 
-    def backward(self, dA, grads):
-        """dA (N*h*w, Fp): gradient of forward()'s output.  Returns (d_xs, dz_bn): the two dense (M,Fp) parts of the
-        gradient w.r.t. x[..., :Fp] (to be added into the block-input gradient)."""
+    def backward(self, dA, grads, fused_bn=False):
+        """dA (N*h*w, Fp): gradient of forward()'s output.  Returns (d_xs, dz_bn, None): the two dense (M,Fp) parts of the
+        gradient w.r.t. x[..., :Fp] (to be added into the block-input gradient).  fused_bn (and the geometry served): the
+        BatchNorm3d backward is left to the kernel that adds the parts into d x -- returns (d_xs, d_bn, bn) with d_bn the
+        gradient at the BatchNorm's OUTPUT and bn = (xs, sums, mean, rstd, w) for ops_bwd.gsf_add_cols_sink(bn=...): its
+        statistics come from the conv3d input-gradient launch (no pass over (d_bn, xs)), its apply pass does not exist."""
         sd, pre, F, Fp, T, c = self.sd, self.pre, self.F, self.Fp, self.T, self.ctx
         b = c.bufs
-        d_xs, d_bn, d_w3, d_b3, d_cw, d_cb = B_.gsf_bwd(c.x, b["gate"], b.get("fw"), b["ysum"], b["xsum"], dA, c.B, T, F, Fp,
-                                                       self.w3, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.cw1,
-                                                       self.cw2)
-        dz, _, dw, db = B_.bn_train_bwd(c.xs, d_bn, None, (c.mean, c.rstd), c.w_pad, relu=False)
+        N, h, w, C = c.x.shape
+        fused_bn = (fused_bn and GSF_BN_FUSED and dA.dtype == torch.bfloat16
+                    and B_.gsf_bwd_bn_parts(c.B, T, h, w, C, Fp) > 0)
+        r = B_.gsf_bwd(c.x, b["gate"], b.get("fw"), b["ysum"], b["xsum"], dA, c.B, T, F, Fp, self.w3, c.sa[:F].contiguous(),
+                       c.sb[:F].contiguous(), self.cw1, self.cw2, bn_mean=(c.mean if fused_bn else None))
+        d_xs, d_bn, d_w3, d_b3, d_cw, d_cb = r[:6]
+        bn = None
+        if fused_bn:
+            sink = SimpleNamespace(partA=r[6], partB=None, nB=0)
+            sums = B_.bn_sums_from_sink(c.xs, d_bn, (c.mean, c.rstd), c.w_pad, sink, q=1)       # [2][Fp]: d bias | d weight
+            dw, db = sums[1], sums[0]
+            bn = (c.xs, sums, c.mean, c.rstd, c.w_pad)
+            dz = d_bn
+        else:
+            dz, _, dw, db = B_.bn_train_bwd(c.xs, d_bn, None, (c.mean, c.rstd), c.w_pad, relu=False)
         grads[pre + ".conv3D.weight"] = d_w3.reshape(sd[pre + ".conv3D.weight"].shape)
         grads[pre + ".conv3D.bias"] = d_b3
         grads[pre + ".bn.weight"], grads[pre + ".bn.bias"] = dw[:F].contiguous(), db[:F].contiguous()
         if self.fuse:
             grads[pre + ".channel_conv1.weight"] = d_cw[0].reshape(sd[pre + ".channel_conv1.weight"].shape)
             grads[pre + ".channel_conv2.weight"] = d_cw[1].reshape(sd[pre + ".channel_conv2.weight"].shape)
-            grads[pre + ".channel_conv1.bias"] = d_cb[0:1].contiguous()
-            grads[pre + ".channel_conv2.bias"] = d_cb[1:2].contiguous()
-        return d_xs, dz
+            lazy = isinstance(d_cb, tuple)                                  # (partials folded by the gradient write-out)
+            grads[pre + ".channel_conv1.bias"] = d_cb[0] if lazy else d_cb[0:1].contiguous()
+            grads[pre + ".channel_conv2.bias"] = d_cb[1] if lazy else d_cb[1:2].contiguous()
+        return d_xs, dz, bn
 
 
 class StemTrain:
@@ -432,8 +450,8 @@ class BottleneckTrain:
                                                        k0=(self.gs.Fp if c.G is not None else 0))[0].reshape(
                 sd[self.c1 + ".conv.weight"].shape)
             if self.gs is not None:
-                d_xs, dz_bn = self.gs.backward(dA, grads)
-                B_.gsf_add_cols_sink(d_xs, dz_bn, dx, self.gs.Fp, sink_out)
+                d_xs, dz_bn, bn = self.gs.backward(dA, grads, fused_bn=True)
+                B_.gsf_add_cols_sink(d_xs, dz_bn, dx, self.gs.Fp, sink_out, bn=bn)
             return dx
         fuse = FUSE_RES and not blk.has_downsample
         dA = (torch.empty((Nf * h * w, self.gs.Fp), dtype=dz1.dtype, device=dz1.device)
@@ -448,7 +466,7 @@ class BottleneckTrain:
             if dA is None:
                 dA = dx.view(-1, Cin)[:, :Fp].contiguous()                      # gradient of the gate-shift output
                 dx.view(-1, Cin)[:, :Fp] = 0
-            d_xs, dz_bn = self.gs.backward(dA, grads)
+            d_xs, dz_bn, _ = self.gs.backward(dA, grads)
             B_.gsf_add_cols(d_xs, dz_bn, dx, Fp)
         # shortcut
         if blk.has_downsample:

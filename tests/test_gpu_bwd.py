@@ -411,7 +411,7 @@ def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
     dA = torch.zeros((N * h * w, Fp), dtype=dtype)
     dA[:, :F] = dy.permute(0, 2, 3, 1).reshape(-1, F)
     grads = {}
-    d_xs, dz = gs.backward(dA.to(DEV), grads)
+    d_xs, dz, _ = gs.backward(dA.to(DEV), grads)
     dx = (d_xs.float() + dz.float())[:, :F].view(N, h, w, F).permute(0, 3, 1, 2)
     want = {k for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k}
     assert set(grads) == want, set(grads) ^ want
@@ -425,6 +425,26 @@ def test_gate_shift_train_fwd_bwd_matches_autograd(dtype, geom):
         ga = torch.cat([grads[k].detach().cpu().double().reshape(-1) for k in sorted(want)])
         gr = torch.cat([sdr[k].grad.double().reshape(-1) for k in sorted(want)])
         assert float((ga - gr).norm() / gr.norm()) < 0.1
+        # the BatchNorm3d backward left to the kernel that adds the module's input gradient into d x (statistics from the
+        # conv3d input-gradient launch, apply on load): the same d x columns and BatchNorm parameter gradients
+        from tdeed_amd import ops_bwd as B2
+        if B2.gsf_bwd_bn_parts(B, T, h, w, C, Fp) > 0:
+            grads2 = {}
+            d_xs2, d_bn2, bn = gs.backward(dA.to(DEV), grads2, fused_bn=True)
+            assert bn is not None
+            M = N * h * w
+            dxa = torch.zeros((M, C), dtype=dtype, device=DEV)
+            sink = B2.GradSink(torch.ones((M, C), dtype=dtype, device=DEV), torch.zeros((M, C), dtype=dtype, device=DEV),
+                               torch.zeros(C, device=DEV))
+            B2.gsf_add_cols_sink(d_xs2, d_bn2, dxa, Fp, sink, bn=bn)
+            dxb = torch.zeros((M, C), dtype=dtype, device=DEV)
+            B2.gsf_add_cols(d_xs, dz, dxb, Fp)
+            torch.cuda.synchronize()
+            scale = float(dxb.float().abs().max())
+            assert float((dxa.float() - dxb.float()).abs().max()) <= 2e-2 * scale
+            for k in ("gs.bn.weight", "gs.bn.bias"):
+                a, b_ = B2.materialize(grads2[k]).float(), B2.materialize(grads[k]).float()
+                assert float((a - b_).abs().max()) <= 5e-3 * max(1.0, float(b_.abs().max())), k
 
 
 def _oracle_train_loss(frames, sd, cfg, spec, lab, labD, masks, crop, flip):
