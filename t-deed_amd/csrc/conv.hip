@@ -241,8 +241,34 @@ static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
 struct GcStat {
   const bf16_t* z; const float* fa; const float* fb; const float* mean;
 };
+// the weight fragments of a wave (pair form: units 2 pr, 2 pr + 1 of the slab; single-unit form: a only).  Requested by the
+// kernels BEFORE they stage the band, so that the L2 round trip of the weights runs under the band's loads instead of behind
+// the barrier that ends the staging (a workgroup lives ~5 us; this was ~1 us of it).
+struct GcW { bf16x8 a[5], b[5]; };
+__device__ __forceinline__ GcW gconv_load_w(const bf16x8* __restrict__ wfrag, int slab, int CSP) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int units = CSP >> 4;
+  GcW w;
+  if (units >= 2) {
+    const int pairs = units >> 1, pr = wv % pairs;
+    const long ubase = ((long)(slab * 4 + 2 * pr) * 5) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      w.a[ks] = wfrag[ubase + ks * 64];
+      w.b[ks] = wfrag[ubase + (5 + ks) * 64];
+    }
+  } else {
+    const long ubase = ((long)(slab * 4) * 5) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      w.a[ks] = wfrag[ubase + ks * 64];
+      w.b[ks] = w.a[ks];
+    }
+  }
+  return w;
+}
 template <int STRIDE>
-__device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float (*red)[32], float (*redq)[32], int Wi, int C,
+__device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned char* tile, float (*red)[32], float (*redq)[32], int Wi, int C,
                                                const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
                                                const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                float* __restrict__ pooled, float* __restrict__ pooled_sq, int Ho, int Wo,
@@ -260,13 +286,8 @@ __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float 
     // bytes, a shape that moves the same bytes ~1.5x slower (tools/ubench/access_shape.hip: 4.3 vs 6.2 TB/s).  Two independent
     // accumulator chains per tile also keep the MFMA pipe busier than five dependent MFMAs.
     const int pairs = units >> 1, pr = wv % pairs, mstep = 4 / pairs;
-    bf16x8 wfA[5], wfB[5];
-    const long ubase = ((long)(slab * 4 + 2 * pr) * 5) * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-      wfA[ks] = wfrag[ubase + ks * 64];
-      wfB[ks] = wfrag[ubase + (5 + ks) * 64];
-    }
+    const bf16x8 (&wfA)[5] = gw_.a;
+    const bf16x8 (&wfB)[5] = gw_.b;
     int off[5];
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
@@ -402,11 +423,8 @@ __device__ __forceinline__ void gconv_band_mma(const unsigned char* tile, float 
   }
   const int unit = wv % units;
   const int mstep = 4 / units;
-  // weights of this unit: 5 k-steps
-  bf16x8 wf[5];
-  const long ubase = ((long)(slab * 4 + unit) * 5) * 64 + lane;   // wfrag laid out [slab*4+unit][ks][lane]
-#pragma unroll
-  for (int ks = 0; ks < 5; ++ks) wf[ks] = wfrag[ubase + ks * 64];
+  // weights of this unit (units == 1 here: unit 0 of the slab): 5 k-steps, wfrag laid out [slab*4+unit][ks][lane]
+  const bf16x8 (&wf)[5] = gw_.a;
   int off[5];
 #pragma unroll
   for (int ks = 0; ks < 5; ++ks) {
@@ -527,6 +545,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   const int slab = (int)(lid % nslabs_);
   const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
   const int cs0 = slab * CSP;
+  const GcW gw_ = gconv_load_w(wfrag, slab, CSP);                // (travels under the staging below)
   const int oy0 = bnd * band;
   const int nrows_out = min(band, Ho - oy0);
   const int WP = Wi + 2;
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
     }
   }
   __syncthreads();
-  gconv_band_mma<STRIDE>(tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, pooled_sq, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
+  gconv_band_mma<STRIDE>(gw_, tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, pooled_sq, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
                          slab, oy0, nrows_out, bst);
 }
 
@@ -618,6 +637,8 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pl = lane & 15, q = lane >> 4;
   const int nts = CSP >> 4;                                // conv1 output tiles of this slab (<= 4)
+  GcW gw_;                                                 // the grouped conv's weights travel under conv1 -- where the
+  if constexpr (KS1 <= 2) gw_ = gconv_load_w(wfrag, slab, CSP);   // registers allow (at KS1 >= 4 they cost the third workgroup per CU)
   // conv1 weights of the slab, BN affine of this lane's 4 channels per tile
   bf16x8 w1r[4][KS1];
   float a1[4][4], b1[4][4];
@@ -708,8 +729,9 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
       }
     }
   }
+  if constexpr (KS1 > 2) gw_ = gconv_load_w(wfrag, slab, CSP);
   __syncthreads();
-  gconv_band_mma<STRIDE>(tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, nullptr, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
+  gconv_band_mma<STRIDE>(gw_, tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, nullptr, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
                          slab, oy0, nrows_out);
 }
 
