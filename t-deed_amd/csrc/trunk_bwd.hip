@@ -1331,14 +1331,18 @@ constexpr int GWT_RS = 80;                                      // LDS row strid
 // AFF: x is the RAW output z of the conv in front and relu(in_a[c] * z + in_b[c]) -- the BatchNorm + ReLU between the two
 // convs -- is applied while the patch is staged (zero padding stays zero): the post-BN map is never materialised.
 template <int S, int GW, bool AFF>
-__global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256, S == 1 ? 4 : 3) void gconv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                              const float* __restrict__ in_a, const float* __restrict__ in_b,
                                                              int N, int Hi, int Wi, int Ho, int Wo, int C, int tiles_per_wg,
                                                              float* __restrict__ part) {
   constexpr int PW = 8 * S + (S == 1 ? 2 : 1);                  // patch width / height in input pixels: 10 or 17
   constexpr int NPIX = PW * PW;
-  __shared__ __attribute__((aligned(16))) bf16_t patch[NPIX * GWT_RS];
-  __shared__ __attribute__((aligned(16))) bf16_t dyt[64 * GWT_RS];
+  // LDS row stride (elements).  Stride 2: 64 channels + 16 bytes, 51 KB per workgroup = THREE per CU (with + 32 bytes: 57 KB, two);
+  // these kernels are chains of dependent stage -> barrier -> MFMA rounds and live on resident workgroups (a form that put a
+  // whole tile's loads in flight at the cost of one workgroup per CU was 30 % slower)
+  constexpr int RSW = S == 2 ? 72 : GWT_RS;
+  __shared__ __attribute__((aligned(16))) bf16_t patch[NPIX * RSW];
+  __shared__ __attribute__((aligned(16))) bf16_t dyt[64 * RSW];
   __shared__ __attribute__((aligned(16))) float saff[2][64];
   const int c0 = blockIdx.y * 64, CH = min(64, C - c0), nck = CH >> 3;
   if constexpr (AFF) {
@@ -1356,8 +1360,8 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
 #pragma unroll
   for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // the pad columns of both images are read by the unit that holds an 8-channel tail: keep them finite
-  for (int i = tid; i < (NPIX + 64) * (GWT_RS / 8); i += 256) {
-    bf16_t* base = i < NPIX * (GWT_RS / 8) ? patch + (long)i * 8 : dyt + (long)(i - NPIX * (GWT_RS / 8)) * 8;
+  for (int i = tid; i < (NPIX + 64) * (RSW / 8); i += 256) {
+    bf16_t* base = i < NPIX * (RSW / 8) ? patch + (long)i * 8 : dyt + (long)(i - NPIX * (RSW / 8)) * 8;
     *reinterpret_cast<u32x4*>(base) = (u32x4){0u, 0u, 0u, 0u};
   }
   const IDiv dck(nck), dpw(PW), dtx(txN), dty(tyN);
@@ -1387,13 +1391,13 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
           const int iy = oy0 * S - 1 + py, ix = ox0 * S - 1 + pxx;
           ok[b] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
           src = x + (((long)n * Hi + (ok[b] ? iy : 0)) * Wi + (ok[b] ? ix : 0)) * C + c0 + ck * 8;
-          dst[b] = px * GWT_RS + ck * 8;
+          dst[b] = px * RSW + ck * 8;
         } else {
           dck.divmod(i - n_patch, px, ck);
           const int oy = oy0 + (px >> 3), ox = ox0 + (px & 7);
           ok[b] = oy < Ho && ox < Wo;
           src = dy + (((long)n * Ho + (ok[b] ? oy : 0)) * Wo + (ok[b] ? ox : 0)) * C + c0 + ck * 8;
-          dst[b] = NPIX * GWT_RS + px * GWT_RS + ck * 8;        // dyt follows patch in the shared segment? no: flagged below
+          dst[b] = NPIX * RSW + px * RSW + ck * 8;        // dyt follows patch in the shared segment? no: flagged below
         }
         v[b] = *reinterpret_cast<const u32x4*>(src);
       }
@@ -1401,7 +1405,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         if (i0 + b * 256 < n_all) {
-          bf16_t* d = dst[b] < NPIX * GWT_RS ? patch + dst[b] : dyt + (dst[b] - NPIX * GWT_RS);
+          bf16_t* d = dst[b] < NPIX * RSW ? patch + dst[b] : dyt + (dst[b] - NPIX * RSW);
           if constexpr (AFF) {
             if (cko[b] >= 0) {                                  // an input piece: BatchNorm affine + ReLU of the layer in front
               const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&v[b]);
@@ -1422,12 +1426,12 @@ __global__ __launch_bounds__(256) void gconv_wgrad_tr_kernel(const bf16_t* __res
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ty = ks * 4 + g4;
-      const bf16x8 bfr = td_tr_read8(dyt + (ty * 8 + q4) * GWT_RS + colo, dyt + (ty * 8 + q4 + 4) * GWT_RS + colo);
+      const bf16x8 bfr = td_tr_read8(dyt + (ty * 8 + q4) * RSW + colo, dyt + (ty * 8 + q4 + 4) * RSW + colo);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int r0 = (ty * S + ky) * PW + q4 * S + kx;
-        const bf16x8 afr = td_tr_read8(patch + r0 * GWT_RS + colo, patch + (r0 + 4 * S) * GWT_RS + colo);
+        const bf16x8 afr = td_tr_read8(patch + r0 * RSW + colo, patch + (r0 + 4 * S) * RSW + colo);
         acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[tap], 0, 0, 0);
       }
     }
