@@ -85,6 +85,17 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   BN_STAMP(0);
   // ---- P0: x (gate-shift columns spliced in) -> region A; pads, zero row
   {
+    // the folded BatchNorm tables are requested FIRST and stored after the frames: behind the frames' LDS stores (where they
+    // used to be read) they were a second, exposed memory round trip per workgroup
+    constexpr int NBV = (6 * 16 * ((KS * 32 + 15) / 16) + BNK_THR - 1) / BNK_THR;
+    float bv[NBV];
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int i = tid + j * BNK_THR;
+      const int v = min(i / CP, 5), c = i - (i / CP) * CP;
+      const float* src = v == 0 ? p.s1 : v == 1 ? p.h1 : v == 2 ? p.s2 : v == 3 ? p.h2 : v == 4 ? p.s3 : p.h3;
+      bv[j] = src[min(c, C - 1)];
+    }
     const int cpr = C >> 3;
     const bf16_t* gg = p.G ? p.G + (long)f0 * hw * p.Fp : nullptr;
     const int total = npix * cpr;
@@ -124,10 +135,10 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     // the k pad of the last loaded row reads on into the next row (KS * 32 > C + pad / 2): region B's head, or the first
     // unused row of region A when the workgroup has fewer frames -- finite before anything has been written there
     if (tid < 4) *reinterpret_cast<u32x4*>(At + npix * RS + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-    for (int i = tid; i < 6 * CP; i += BNK_THR) {
-      const int v = i / CP, c = i - v * CP;
-      const float* src = v == 0 ? p.s1 : v == 1 ? p.h1 : v == 2 ? p.s2 : v == 3 ? p.h2 : v == 4 ? p.s3 : p.h3;
-      bnv[i] = c < C ? src[c] : 0.f;                     // channels >= C: exact zeros out of every epilogue
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+      const int i = tid + j * BNK_THR;
+      if (i < 6 * CP) bnv[i] = (i - (i / CP) * CP) < C ? bv[j] : 0.f;      // channels >= C: exact zeros out of every epilogue
     }
   }
   __syncthreads();

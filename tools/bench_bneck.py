@@ -61,7 +61,10 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
 
     t0, t1 = timeit(chain), timeit(fused)
     chain(); ref = out.clone(); fused(); torch.cuda.synchronize()
-    print(f"{h}x{w}x{C} N={N}: chain {t0:7.1f} us   one launch {t1:7.1f} us   equal {torch.equal(ref, outb.view(M, C))}", flush=True)
+    ob = outb.view(M, C)
+    ndiff = int((ref != ob).sum())
+    print(f"{h}x{w}x{C} N={N}: chain {t0:7.1f} us   one launch {t1:7.1f} us   equal {torch.equal(ref, ob)}"
+          f"   ({ndiff} of {ref.numel()} elements differ, max abs {float((ref.float() - ob.float()).abs().max()):.3g})", flush=True)
     nwg = (N + (1 if hw > 64 else 2) - 1) // (1 if hw > 64 else 2)
     dbg = torch.zeros((nwg, 16), dtype=torch.int64, device=DEV)
     _lib.call("tdeed_bneck_set_debug", dbg.data_ptr())
