@@ -526,7 +526,12 @@ __global__ __launch_bounds__(256) void wgrad_tr128_kernel(const bf16_t* __restri
                                                           int K, float* __restrict__ part_w, float* __restrict__ part_b) {
   __shared__ __attribute__((aligned(16))) bf16_t sY[64 * WT_RS2];
   __shared__ __attribute__((aligned(16))) bf16_t sX[64 * WT_RS2];
-  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, z = blockIdx.z, Z = gridDim.z;
+  // 1-D grid, renumbered: the tiles of one row slice sit on one XCD and share its L2 (see wgrad_tr160_kernel)
+  const int ntx_ = (N + 127) >> 7, nty_ = (K + 127) >> 7, ntl_ = ntx_ * nty_;
+  const long lid_ = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile_ = (int)(lid_ % ntl_), z = (int)(lid_ / ntl_), Z = (int)(gridDim.x / ntl_);
+  const int bx_ = tile_ % ntx_, by_ = tile_ / ntx_;
+  const int n0 = bx_ * 128, k0 = by_ * 128;
   const int mper = ((M + Z - 1) / Z + 63) / 64 * 64;
   const int m_begin = z * mper, m_end = min(M, m_begin + mper);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), pl = lane & 15;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256) void wgrad_tr128_kernel(const bf16_t* __restri
   const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
   const int r = tid >> 4, c8 = (tid & 15) * 8;                  // staging: rows r + 16 h, 16-byte chunk c8
   const bool nok = n0 + c8 < N, kok = k0 + c8 < K;
-  const bool want_b = part_b && blockIdx.y == 0;
+  const bool want_b = part_b && by_ == 0;
   f32x4 acc[4][4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -622,7 +627,12 @@ __global__ __launch_bounds__(256) void wgrad_tr160_kernel(const bf16_t* __restri
                                                           int K, float* __restrict__ part_w) {
   __shared__ __attribute__((aligned(16))) bf16_t sY[64 * WT_RS3];
   __shared__ __attribute__((aligned(16))) bf16_t sX[64 * WT_RS3];
-  const int n0 = blockIdx.x * 160, k0 = blockIdx.y * 160, z = blockIdx.z, Z = gridDim.z;
+  // 1-D grid of 4 Z workgroups, renumbered so that the four output tiles of one row slice run on ONE XCD next to each other:
+  // each half of dY / X is read by two of them, the second time from that XCD's L2 (as a (2, 2, Z) grid the hardware dealt the
+  // four over four XCDs and every operand byte crossed from HBM twice: 800 MB per call instead of 400)
+  const long lid_ = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile_ = (int)(lid_ & 3), z = (int)(lid_ >> 2), Z = (int)(gridDim.x >> 2);
+  const int n0 = (tile_ & 1) * 160, k0 = (tile_ >> 1) * 160;
   const int mper = ((M + Z - 1) / Z + 63) / 64 * 64;
   const int m_begin = z * mper, m_end = min(M, m_begin + mper);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), pl = lane & 15;
@@ -740,10 +750,10 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, co
     const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
     TD_CHECK(!X0 || (!valu && vec_ok && !scatter), "wgrad: the spliced X operand needs the transposing-read kernel");
     if (!valu && vec_ok && !scatter && wgrad_160(M, N, K) && !part_b)      // N = K = 320 (no bias): two exact 160-wide tiles per dimension
-      hipLaunchKernelGGL(wgrad_tr160_kernel, dim3(2, 2, Z), dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx,
+      hipLaunchKernelGGL(wgrad_tr160_kernel, dim3(4 * Z), dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx,
                          (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w);
     else if (!valu && vec_ok && !scatter && wgrad_wide(M, N, K))     // wide layers: 128 x 128 output tiles
-      hipLaunchKernelGGL(wgrad_tr128_kernel, dim3(cdiv(N, 128), cdiv(K, 128), Z), dim3(256), 0, st, (const bf16_t*)dY, ldy,
+      hipLaunchKernelGGL(wgrad_tr128_kernel, dim3((unsigned)(cdiv(N, 128) * cdiv(K, 128) * Z)), dim3(256), 0, st, (const bf16_t*)dY, ldy,
                          (const bf16_t*)X, ldx, (const bf16_t*)X0, ldx0, X0 ? k0 : 0, M, N, K, part_w,
                          (db || accumulate < 0) ? part_b : nullptr);
     else if (!valu && vec_ok && !scatter && M >= 4096)          // long contractions: transposing LDS reads, 64-row chunks
