@@ -509,7 +509,8 @@ int tdeed_bn_bwd_masked_from_parts(const void* z, const void* dy, long M, int C,
  * gradient sink's column sums (as tdeed_gemm_dgrad), and the partial weight gradients dz1^T @ X.
  * fa / fb / mean / rstd / w: conv1's BatchNorm; sums fp32 [2][Co] = (sum g, sum g xhat) of its backward; Wt [Ci][Co] = W1^T;
  * R: shortcut gradient [M][Ci] (r_hi > 0: rows of the even pixels of an r_hi x r_wi frame) or NULL; bpart fp32
- * [grid][3][Ci] (or NULL), wpart fp32 [grid][Co][Ci], grid = tdeed_narrow_conv1_bwd_grid(M, Co, Ci). */
+ * [grid][3][Ci] (or NULL), wpart fp32 [grid][Co][Ci], grid = tdeed_narrow_conv1_bwd_grid(M, Co, Ci).
+ * Z == NULL (not at 128 <- 128): Z is X @ W1^T of exactly these operands and is recomputed in the launch instead of read. */
 int tdeed_narrow_conv1_bwd_fits(int Co, int Ci);
 int tdeed_narrow_conv1_bwd_grid(long M, int Co, int Ci);
 int tdeed_narrow_conv1_bwd(const void* dY, const void* Z, long M, int Co, int Ci, const float* fa, const float* fb,
