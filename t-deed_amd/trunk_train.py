@@ -26,6 +26,7 @@ SINK = _os.environ.get("TDEED_TRAIN_SINK", "1") == "1"
 # the gate-shift module's BatchNorm3d backward: statistics out of the conv3d input-gradient launch, apply inside the kernel that
 # adds the module's input gradient into d x (no column-statistics pass, no dz map)
 GSF_BN_FUSED = _os.environ.get("TDEED_TRAIN_GSF_BN_FUSED", "1") == "1"
+GSF_DENSE_IN = _os.environ.get("TDEED_TRAIN_GSF_DENSE_IN", "1") == "1"
 # K = N = 320 contractions over >= RS_MIN_ROWS rows on the register-stationary kernel (forward with the statistics epilogue,
 # conv3's input gradient); TDEED_TRAIN_RS=0: the tiled kernel everywhere
 RS_TRAIN = _os.environ.get("TDEED_TRAIN_RS", "1") == "1"
@@ -96,7 +97,10 @@ class GateShiftTrain:
         bufs["xsum"] = torch.empty((N, F), dtype=torch.float32, device=dev)
         if self.fuse:
             bufs["fw"] = torch.empty((c.B, F, T), dtype=torch.float32, device=dev)
-        G = ops.gate_shift(x, c.B, T, F, Fp, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.wq, self.b3, self.cw1,
+        # the module's kernels read the DENSE slice where it holds everything they need (F == Fp: no pass-through pad columns;
+        # the backward always -- it reads channels < F only): rows of 2 Fp bytes instead of 2 Fp bytes out of every 2 C
+        c.xin = c.xs.view(N, h, w, Fp) if (F == Fp and GSF_DENSE_IN) else x
+        G = ops.gate_shift(c.xin, c.B, T, F, Fp, c.sa[:F].contiguous(), c.sb[:F].contiguous(), self.wq, self.b3, self.cw1,
                            self.cb1, self.cw2, self.cb2, bufs=bufs, wqf=self.wqf, separate_weight=True)
         c.bufs = bufs
         self.ctx = c
@@ -112,8 +116,9 @@ class GateShiftTrain:
         b = c.bufs
         N, h, w, C = c.x.shape
         fused_bn = (fused_bn and GSF_BN_FUSED and dA.dtype == torch.bfloat16
-                    and B_.gsf_bwd_bn_parts(c.B, T, h, w, C, Fp) > 0)
-        r = B_.gsf_bwd(c.x, b["gate"], b.get("fw"), b["ysum"], b["xsum"], dA, c.B, T, F, Fp, self.w3, c.sa[:F].contiguous(),
+                    and B_.gsf_bwd_bn_parts(c.B, T, h, w, (Fp if GSF_DENSE_IN else C), Fp) > 0)
+        xb = c.xs.view(N, h, w, Fp) if GSF_DENSE_IN else c.x
+        r = B_.gsf_bwd(xb, b["gate"], b.get("fw"), b["ysum"], b["xsum"], dA, c.B, T, F, Fp, self.w3, c.sa[:F].contiguous(),
                        c.sb[:F].contiguous(), self.cw1, self.cw2, bn_mean=(c.mean if fused_bn else None))
         d_xs, d_bn, d_w3, d_b3, d_cw, d_cb = r[:6]
         bn = None
