@@ -874,7 +874,7 @@ def main():
     if world == 1 and not a.no_train and a.workload == "rny002_b8" and a.dtype == "bf16":
         # driver-visible forward of the 800MF model (BASELINE configs[2..4] run on it): B = 16 as in configs[2]
         try:
-            out["infer_800mf"] = infer_sub_record("rny008_b16", 20, 3, depth, rank, dev, TRAFFIC_FILE_800MF)
+            out["infer_800mf"] = infer_sub_record("rny008_b16", 50, 3, depth, rank, dev, TRAFFIC_FILE_800MF)
         except Exception as e:           # noqa: BLE001  (the headline line must still be printed)
             out["infer_800mf"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         # driver-visible training-step records: BASELINE configs[2] (800MF, B=16) and the 200MF geometry of the headline
