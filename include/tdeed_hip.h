@@ -586,6 +586,14 @@ int tdeed_avgpool_posenc_bwd(const void* d_feat, int B, int T, int hw, int C, vo
 int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h, int crop_w,
                      int flip, const unsigned char* flip_mask /* NULL or [N], as tdeed_stem_fwd */, const void* dz,
                      float* part, float* dw, int dtype, void* stream);
+/* tdeed_stem_wgrad with the stem BatchNorm's backward (torch.nn.BatchNorm2d of timm's stem ConvNormAct under autograd) applied
+ * while the gradient rows are staged: g = the masked gradient at the BatchNorm's output, z = the raw stem output, sums fp32
+ * [2][32] = (sum g, sum g xhat) as tdeed_bn_bwd_from_parts leaves them, mean / rstd / w [32].  bf16; geometry per
+ * tdeed_stem_wgrad_bn_fits. */
+int tdeed_stem_wgrad_bn_fits(int H, int W, int crop_h, int crop_w);
+int tdeed_stem_wgrad_bn(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h,
+                        int crop_w, int flip, const unsigned char* flip_mask, const void* g, const void* z, const float* sums,
+                        const float* mean, const float* rstd, const float* w, float* part, float* dw, void* stream);
 
 /* train-time augmentation inside Impl.forward (model.py:76-83, 154-157): per clip ColorJitter(hue), (saturation),
  * (brightness), (contrast), GaussianBlur(5) on the cropped frames (torchvision 0.18.1 float-tensor arithmetic restated in

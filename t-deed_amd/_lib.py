@@ -37,6 +37,8 @@ _SIGS = {
     "tdeed_stem_mfma_parts": ([c_int, c_int], c_int),
     "tdeed_stem_mfma_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P], c_int),
     "tdeed_stem_wgrad": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P], c_int),
+    "tdeed_stem_wgrad_bn_fits": ([c_int, c_int, c_int, c_int], c_int),
+    "tdeed_stem_wgrad_bn": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P], c_int),
     "tdeed_s1_front_parts": ([c_int, c_int, c_int], c_int),
     "tdeed_s1_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, P,
                             P, P, P, P, P, P, P], c_int),

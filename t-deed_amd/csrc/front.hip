@@ -1326,6 +1326,10 @@ struct StemWgP {
   const unsigned char* flip_mask;
   const bf16_t* dz; float* part;
   int Ho, Wo, WoP, groups;
+  // bz given: `dz` is the (masked) gradient g at the OUTPUT of the stem's BatchNorm and the BatchNorm backward
+  // dz = k1 g + k2 z + k3 is applied while the rows are staged (bz = the raw stem output z, bsums = (sum g, sum g xhat), the
+  // statistics and weight of that BatchNorm): the dz map (1.3 GB at cfg3) is neither written nor read back
+  const bf16_t* bz; const float* bsums; const float* bmean; const float* brstd; const float* bw; float inv_M;
 };
 
 template <typename IN>
@@ -1347,6 +1351,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_tr_kernel(const StemWgP p) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) acc[t][ky] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int cpr = p.WoP * 4;                                              // 16-byte chunks per dz image row
+  // (cpr is a multiple of 4 and 256 too: a thread stages the same 8 channels in every iteration -> its constants in registers)
+  float k1[8], k2[8], k3[8];
+  const bf16_t* zf = p.bz ? p.bz + (long)n * p.Ho * p.Wo * 32 : nullptr;
+  if (p.bz) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (tid & 3) * 8 + e;
+      const float rs = p.brstd[c], mu = p.bmean[c], m1 = p.bsums[c] * p.inv_M, m2 = p.bsums[32 + c] * p.inv_M;
+      k1[e] = p.bw[c] * rs;
+      k2[e] = -k1[e] * rs * m2;
+      k3[e] = k1[e] * (mu * rs * m2 - m1);
+    }
+  }
   for (int sb = 0; sb < 4; ++sb) {
     const int oy0 = grp * 16 + sb * 4;
     if (oy0 >= p.Ho) break;
@@ -1356,7 +1373,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_tr_kernel(const StemWgP p) {
       const int ry = i / cpr, cx = i - ry * cpr;
       const int oy = oy0 + ry;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (oy < p.Ho && cx < p.Wo * 4) v = *reinterpret_cast<const u32x4*>(dzf + ((long)oy * p.Wo) * 32 + (long)cx * 8);
+      if (oy < p.Ho && cx < p.Wo * 4) {
+        v = *reinterpret_cast<const u32x4*>(dzf + ((long)oy * p.Wo) * 32 + (long)cx * 8);
+        if (zf) {
+          const u32x4 zv = *reinterpret_cast<const u32x4*>(zf + ((long)oy * p.Wo) * 32 + (long)cx * 8);
+          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&v), z8 = *reinterpret_cast<const bf16x8*>(&zv);
+          bf16x8 o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)fmaf(k1[e], (float)g8[e], fmaf(k2[e], (float)z8[e], k3[e]));
+          v = *reinterpret_cast<const u32x4*>(&o8);
+        }
+      }
       *reinterpret_cast<u32x4*>(dzs + (long)i * 8) = v;
     }
     __syncthreads();
@@ -1410,8 +1437,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_tr_kernel(const StemWgP p) {
 // launcher used by tdeed_stem_wgrad (trunk_bwd.hip); returns 0 when the geometry does not fit (the caller falls back)
 int td_stem_wgrad_tr_launch(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h,
                             int crop_w, int flip, const unsigned char* flip_mask, const void* dz, float* part,
-                            hipStream_t st) {
+                            hipStream_t st, const void* bz, const float* bsums, const float* bmean, const float* brstd,
+                            const float* bw) {
   StemWgP p;
+  p.bz = (const bf16_t*)bz; p.bsums = bsums; p.bmean = bmean; p.brstd = brstd; p.bw = bw;
+  p.inv_M = 1.0f / ((float)N * (float)((crop_h + 1) / 2) * (float)((crop_w + 1) / 2));
   p.frames = frames; p.g.H = H; p.g.W = W; p.g.top = crop_top; p.g.left = crop_left; p.g.ch = crop_h; p.g.cw = crop_w;
   p.flip = flip; p.flip_mask = flip_mask; p.dz = (const bf16_t*)dz; p.part = part;
   p.Ho = (crop_h + 1) / 2; p.Wo = (crop_w + 1) / 2;

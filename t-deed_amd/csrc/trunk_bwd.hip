@@ -1830,7 +1830,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const IN* __restri
 // dz [N][Ho][Wo][32] (gradient of the raw stem conv output) -> dw [32][3][3][3] fp32; part fp32 [N*ceil(Ho/16)][864]
 int td_stem_wgrad_tr_launch(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left, int crop_h,
                             int crop_w, int flip, const unsigned char* flip_mask, const void* dz, float* part,
-                            hipStream_t st);
+                            hipStream_t st, const void* bz, const float* bsums, const float* bmean, const float* brstd,
+                            const float* bw);
 
 extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
                                 int crop_h, int crop_w, int flip, const unsigned char* flip_mask, const void* dz,
@@ -1849,7 +1850,7 @@ extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H
     static const bool old_mfma = getenv("TDEED_STEM_WGRAD_IM2COL") && atoi(getenv("TDEED_STEM_WGRAD_IM2COL")) == 1;
     if (valu) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
     else if (!old_mfma && td_stem_wgrad_tr_launch(frames, frames_f32, N, H, W, crop_top, crop_left, crop_h, crop_w, flip, flip_mask,
-                                                  dz, part, st)) {
+                                                  dz, part, st, nullptr, nullptr, nullptr, nullptr, nullptr)) {
       // transposing-read form (front.hip): same partial layout
     }
     else if (frames_f32)
@@ -1862,6 +1863,31 @@ extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H
 #undef TD_SWG
   else { tdeed_set_error("stem_wgrad: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("stem_wgrad");
+  return tdeed_reduce_partials(part, N * cdiv(Ho, 16), 864, dw, 0, stream);
+}
+
+// tdeed_stem_wgrad with the stem BatchNorm's backward applied while the gradient rows are staged (bf16, the transposing-read
+// kernel): g = the masked gradient at the BatchNorm's OUTPUT, z = the raw stem output, sums fp32 [2][32] = (sum g, sum g xhat)
+// as tdeed_bn_bwd_from_parts leaves them, mean / rstd / w [32].  Returns TDEED_ERR_ARG when the geometry is not served
+// (tdeed_stem_wgrad_bn_fits): the caller then applies the BatchNorm backward itself and calls tdeed_stem_wgrad.
+extern "C" int tdeed_stem_wgrad_bn_fits(int H, int W, int crop_h, int crop_w) {
+  const int WoP = ((crop_w + 1) / 2 + 31) / 32 * 32;
+  const size_t patch_b = (size_t)((((9 * (crop_w + 2) + 2) * 4 + 7) & ~7)) * 2;
+  const size_t smem = patch_b + (size_t)4 * WoP * 64;
+  return (smem <= 80 * 1024 && ((size_t)8 * (crop_w + 2) + 2 * (size_t)WoP + 4) * 8 <= smem) ? 1 : 0;      // (front.hip: FRONT_LDS_CAP)
+}
+extern "C" int tdeed_stem_wgrad_bn(const void* frames, int frames_f32, int N, int H, int W, int crop_top, int crop_left,
+                                   int crop_h, int crop_w, int flip, const unsigned char* flip_mask, const void* g,
+                                   const void* z, const float* sums, const float* mean, const float* rstd, const float* w,
+                                   float* part, float* dw, void* stream) {
+  TD_CHECK(frames && g && z && sums && mean && rstd && w && part && dw, "stem_wgrad_bn: null pointer");
+  TD_CHECK(N > 0 && crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= H &&
+               crop_left + crop_w <= W, "stem_wgrad_bn: bad geometry");
+  const int Ho = (crop_h + 1) / 2;
+  TD_CHECK(td_stem_wgrad_tr_launch(frames, frames_f32, N, H, W, crop_top, crop_left, crop_h, crop_w, flip, flip_mask, g, part,
+                                   (hipStream_t)stream, z, sums, mean, rstd, w),
+           "stem_wgrad_bn: geometry not served (tdeed_stem_wgrad_bn_fits)");
+  TD_LAUNCH_CHECK("stem_wgrad_bn");
   return tdeed_reduce_partials(part, N * cdiv(Ho, 16), 864, dw, 0, stream);
 }
 

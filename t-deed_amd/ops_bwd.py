@@ -575,13 +575,25 @@ def avgpool_posenc_bwd(d_feat, hw):
     return dx, d_enc
 
 
-def stem_wgrad(frames_u8, dz, crop=None, flip=False):
-    """frames (N,3,H,W) uint8, dz (N,Ho,Wo,32) -> dw (32,3,3,3) fp32"""
+def stem_wgrad_bn_fits(frames, crop, dtype):
+    H, W = frames.shape[-2], frames.shape[-1]
+    top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
+    return dtype == torch.bfloat16 and _lib.load().tdeed_stem_wgrad_bn_fits(H, W, ch, cw) != 0
+
+
+def stem_wgrad(frames_u8, dz, crop=None, flip=False, bn=None):
+    """frames (N,3,H,W) uint8, dz (N,Ho,Wo,32) -> dw (32,3,3,3) fp32.  bn = (z, sums, mean, rstd, w): `dz` is the masked gradient
+    at the OUTPUT of the stem's BatchNorm, whose backward is applied while the rows are staged (tdeed_stem_wgrad_bn)."""
     N, _, H, W = frames_u8.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, H, W)
     part, dw = _f32((N * ((dz.shape[1] + 15) // 16), 864), dz.device), _f32((32, 3, 3, 3), dz.device)
     from .ops import _flip_args
     fl, fmask = _flip_args(flip, N)
+    if bn is not None:
+        z, sums, mean, rstd, w = bn
+        call("tdeed_stem_wgrad_bn", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, fl,
+             ptr(fmask), ptr(dz), ptr(z), ptr(sums), ptr(mean), ptr(rstd), ptr(w), ptr(part), ptr(dw), stream_ptr())
+        return dw
     call("tdeed_stem_wgrad", ptr(frames_u8), int(frames_u8.dtype == torch.float32), N, H, W, top, left, ch, cw, fl,
          ptr(fmask), ptr(dz), ptr(part), ptr(dw),
          dtype_code(dz.dtype), stream_ptr())

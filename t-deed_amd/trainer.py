@@ -24,6 +24,7 @@ from .temporal_train import TemporalStack
 from .trunk_train import BottleneckTrain, StemTrain, BN_EPS
 
 STEM_MFMA = os.environ.get("TDEED_TRAIN_STEM_MFMA", "1") == "1"
+STEM_BN_FUSED = os.environ.get("TDEED_TRAIN_STEM_BN_FUSED", "1") == "1"
 
 
 class TrainEngine:
@@ -167,10 +168,20 @@ class TrainEngine:
             else:
                 dx = blk.backward(dx, grads)
         _lib.SCOPE = "stem.bwd"
+        wbn = sd["_features.stem.bn.weight"]
+        fr4 = ctx.fr.view(-1, *ctx.fr.shape[-3:])
+        if SINK and STEM_BN_FUSED and B_.stem_wgrad_bn_fits(fr4, ctx.crop, dx.dtype):
+            # the stem BatchNorm's backward is applied inside the weight-gradient launch while it stages the gradient rows:
+            # dz0 (the largest map of the step) is neither written nor read back
+            sums = B_.bn_sums_from_sink(ctx.z0, dx, ctx.bn0, wbn, stem_sink, q=1)
+            grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = sums[1], sums[0]
+            grads["_features.stem.conv.weight"] = B_.stem_wgrad(ctx.fr, dx, crop=ctx.crop, flip=ctx.flip,
+                                                                bn=(ctx.z0, sums, ctx.bn0[0], ctx.bn0[1], wbn))
+            return grads
         if SINK:
-            dz0, dw, db = B_.bn_bwd_from_parts(ctx.z0, dx, ctx.bn0, sd["_features.stem.bn.weight"], stem_sink, q=1)
+            dz0, dw, db = B_.bn_bwd_from_parts(ctx.z0, dx, ctx.bn0, wbn, stem_sink, q=1)
         else:
-            dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, None if ZMASK else ctx.y0, ctx.bn0, sd["_features.stem.bn.weight"], relu=True)
+            dz0, _, dw, db = B_.bn_train_bwd(ctx.z0, dx, None if ZMASK else ctx.y0, ctx.bn0, wbn, relu=True)
         grads["_features.stem.bn.weight"], grads["_features.stem.bn.bias"] = dw, db
         grads["_features.stem.conv.weight"] = B_.stem_wgrad(ctx.fr, dz0, crop=ctx.crop, flip=ctx.flip)
         return grads

@@ -720,3 +720,15 @@ def test_stem_weight_gradient_on_transposing_reads(geom, f32_frames, monkeypatch
     got = ops_bwd.stem_wgrad(fr, dz, crop=crop, flip=flip)
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < 1e-2, err                        # the input is rounded to bf16 for the MFMA (2^-9 per element, averaged out)
+    # the stem BatchNorm's backward applied while the gradient rows are staged (tdeed_stem_wgrad_bn) against apply-then-wgrad
+    if ops_bwd.stem_wgrad_bn_fits(fr, crop, torch.bfloat16):
+        z = rnd(913, "z", tuple(dz.shape)).to(torch.bfloat16).to(DEV)
+        wbn = (rnd(914, "w", (32,)) * 0.3 + 1.0).to(DEV)
+        bbn = (rnd(915, "b", (32,)) * 0.3).to(DEV)
+        ctx = ops_bwd.bn_stats(z, wbn, bbn)
+        dz_ref, _, dwb, dbb = ops_bwd.bn_train_bwd(z, dz, None, ctx, wbn, relu=False)
+        sums = torch.stack([dbb, dwb]).contiguous()
+        want = ops_bwd.stem_wgrad(fr, dz_ref, crop=crop, flip=flip)
+        fused = ops_bwd.stem_wgrad(fr, dz, crop=crop, flip=flip, bn=(z, sums, ctx[0], ctx[1], wbn))
+        torch.cuda.synchronize()
+        assert float((fused - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))
