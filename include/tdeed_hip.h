@@ -552,6 +552,12 @@ int tdeed_gemm_dgrad(const void* A, long lda, int M, int K, int N, const void* W
                      int r_wi, void* C, long ldc, void* C2, long ldc2, int n2, const void* mask, long ldmask, const void* bz,
                      long ldbz, const float* bmean, const void* bzd, long ldbzd, const float* bmean_d, float* bpart, int dtype,
                      void* stream);
+/* tdeed_gemm_dgrad for K = N = 320 over many rows on the register-stationary contraction (Wfrag = the packed [N][K] matrix,
+ * engine.pack_ws_weights): residual and mask required, no stride-2 residual, no second statistics map;
+ * bpart fp32 [tdeed_gemm_rs_grid(M)][3][N]. */
+int tdeed_gemm_dgrad_rs(const void* A, long lda, int M, int K, int N, const void* Wfrag, const void* R, long ldr, void* C,
+                        long ldc, void* C2, long ldc2, int n2, const void* mask, long ldmask, const void* bz, long ldbz,
+                        const float* bmean, float* bpart, void* stream);
 int tdeed_gsf_add_cols_sink_parts(long M, int Fp, int dtype);
 int tdeed_gsf_add_cols_sink(const void* a, const void* b, long M, int C, int Fp, void* dx, const void* mask, long ldmask,
                             const void* bz, long ldbz, const float* bmean, const void* bzd, long ldbzd, const float* bmean_d,

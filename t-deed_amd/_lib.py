@@ -94,6 +94,8 @@ _SIGS = {
     "tdeed_se_bn_bwd_apply": ([P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_gemm_dgrad": ([P, c_long, c_int, c_int, c_int, P, c_long, P, c_long, c_int, c_int, P, c_long, P, c_long, c_int, P,
                           c_long, P, c_long, P, P, c_long, P, P, c_int, P], c_int),
+    "tdeed_gemm_dgrad_rs": ([P, c_long, c_int, c_int, c_int, P, P, c_long, P, c_long, P, c_long, c_int, P, c_long, P, c_long, P, P,
+                             P], c_int),
     "tdeed_gsf_add_cols_sink_parts": ([c_long, c_int, c_int], c_int),
     "tdeed_gsf_add_cols_sink": ([P, P, c_long, c_int, c_int, P, P, c_long, P, c_long, P, P, c_long, P, P, c_int, P], c_int),
     "tdeed_bn_bwd_from_parts": ([P, P, c_long, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, c_int, P], c_int),

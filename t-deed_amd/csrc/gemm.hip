@@ -1075,6 +1075,157 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
   }
 }
 
+// Input-gradient contraction of a training bottleneck's conv1 (tdeed_gemm_dgrad) on the register-stationary scheme for
+// K = N = 320 over many rows (the s3 identity blocks of RegNetY-800MF): C = ((A @ W^T) + R) * [mask > 0], columns [0, n2) of the
+// raw product to C2 with only the residual left in C there (the gate-shift columns), and the gradient sink's column sums of
+// what is stored -- r and r * (bz - bmean) -- one partial row bpart[blockIdx.x][3][N] per persistent workgroup (row 2: zeros;
+// sinks with a second statistics map stay on the tiled kernel).  The epilogue operands of a 16-row tile (shortcut gradient,
+// mask, statistics map: 3 x 16 bytes per lane) are requested one tile ahead; the means live in LDS and are read through an
+// opaque pointer per tile (register budget 168, see gemm_rs_kernel).  231 vs 300 us per call at M = 313 600.
+struct GemmRsBwdP {
+  const void* A; long lda; int M; const void* Wf;
+  const void* R; long ldr; void* C; long ldc; void* C2; long ldc2; int n2;
+  const void* mask; long ldmask; const void* bz; long ldbz; const float* bmean; float* bpart;
+};
+__global__ __launch_bounds__(RS_THR, 1) void gemm_rs_bwd_kernel(const GemmRsBwdP p) {
+  typedef bf16_t T;
+  constexpr int N = 320;
+  // one k-step fewer of W in registers than the forward kernel (7 of 10: 60 KB of wave-private LDS copies, 157 KB in all):
+  // the epilogue's operands and column sums need the 8 registers
+  constexpr int KSR = 7, WTAIL = RS_NW * 2 * (RS_KS - KSR) * 64 * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles = smem;                                        // [2][64][RS_LD]
+  bf16x8* wtail = reinterpret_cast<bf16x8*>(smem + 2 * RS_TILE);      // [NW][2][KS - KSR][64] fragments, wave-private
+  float* bmt = reinterpret_cast<float*>(smem + 2 * RS_TILE + WTAIL);   // [N] means of the statistics map
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, q = lane >> 4;
+  bf16x8 wf[2][KSR];
+  bf16x8* wt = wtail + wv * 2 * (RS_KS - KSR) * 64 + lane;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ks = 0; ks < RS_KS; ++ks) {
+      const bf16x8 f = reinterpret_cast<const bf16x8*>(p.Wf)[((long)(2 * wv + h) * RS_KS + ks) * 64 + lane];
+      if (ks < KSR) wf[h][ks] = f;
+      else wt[(h * (RS_KS - KSR) + ks - KSR) * 64] = f;
+    }
+  for (int i = tid; i < N; i += RS_THR) bmt[i] = p.bpart ? p.bmean[i] : 0.f;
+  const long ntiles = ((long)p.M + RS_ROWS - 1) / RS_ROWS;
+  const int r0 = tid / (RS_KS * 4), ck = tid - r0 * (RS_KS * 4);
+  const T* abase = reinterpret_cast<const T*>(p.A) + ck * 8;
+  u32x4 sv[RS_CPT];
+  auto gload = [&](long t) {
+    const long m0 = t * RS_ROWS + r0;
+#pragma unroll
+    for (int j = 0; j < RS_CPT; ++j) {
+      const long m = m0 + 16 * j;
+      const bool ok = m < p.M;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(abase + (ok ? m : 0) * p.lda);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      sv[j] = ok ? v : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* base = tiles + buf * RS_TILE + r0 * RS_LD + ck * 16;
+#pragma unroll
+    for (int j = 0; j < RS_CPT; ++j) *reinterpret_cast<u32x4*>(base + j * 16 * RS_LD) = sv[j];
+  };
+  const int ch = 32 * wv + 8 * q;                                     // this lane's 8 logical output channels
+  long t = blockIdx.x;
+  if (t < ntiles) {
+    gload(t);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  float st1[8], st2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) st1[e] = st2[e] = 0.f;
+  constexpr int NPRE = 1;                                             // 16-row tiles whose epilogue operands are in flight (2: 9 VGPRs spill, 257 vs 231 us per call)
+  for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+    const long tn = t + gridDim.x;
+    u32x4 er[NPRE], em[NPRE], ez[NPRE];
+    auto eload = [&](int mt) {
+      const long m = min(t * RS_ROWS + mt * 16 + px, (long)p.M - 1);
+      er[mt % NPRE] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.R) + m * p.ldr + ch);
+      em[mt % NPRE] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.mask) + m * p.ldmask + ch);
+      if (p.bpart) ez[mt % NPRE] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bz) + m * p.ldbz + ch);
+    };
+#pragma unroll
+    for (int mt = 0; mt < NPRE; ++mt) eload(mt);
+    if (tn < ntiles) gload(tn);                                       // next tile travels while this one is multiplied
+    const unsigned char* base = tiles + buf * RS_TILE;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const long m = t * RS_ROWS + mt * 16 + px;
+      const unsigned char* ar = base + (mt * 16 + px) * RS_LD + 16 * q;
+#pragma unroll
+      for (int ks = 0; ks < RS_KS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + 64 * ks);
+        const bf16x8 w0 = ks < KSR ? wf[0][ks < KSR ? ks : 0] : wt[(ks - KSR) * 64];
+        const bf16x8 w1 = ks < KSR ? wf[1][ks < KSR ? ks : 0] : wt[((RS_KS - KSR) + ks - KSR) * 64];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a, acc1, 0, 0, 0);
+      }
+      const bool mok = m < p.M;
+      const bool gs = p.C2 && ch < p.n2;             // gate-shift columns: the module's gradient leaves, C keeps the residual
+      if (gs && mok) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc0[r]; v[4 + r] = acc1[r]; }
+        Chunk<T>::store(reinterpret_cast<T*>(p.C2) + m * p.ldc2 + ch, v);
+      }
+      // element pairs straight out of the packed words (bf16 -> fp32 is a shift): nothing but the pair in flight is live
+      const u32x4 rw = er[mt % NPRE], mw = em[mt % NPRE], zw = ez[mt % NPRE];
+      const float* bp = bmt + ch;
+      asm volatile("" : "+v"(bp));
+      u32x4 ow;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float a0 = gs ? 0.f : (w < 2 ? acc0[2 * w] : acc1[2 * w - 4]);
+        const float a1 = gs ? 0.f : (w < 2 ? acc0[2 * w + 1] : acc1[2 * w - 3]);
+        const float r0 = __uint_as_float(rw[w] << 16), r1 = __uint_as_float(rw[w] & 0xffff0000u);
+        const float m0 = __uint_as_float(mw[w] << 16), m1 = __uint_as_float(mw[w] & 0xffff0000u);
+        const bf16_t o0 = (bf16_t)(m0 > 0.f ? a0 + r0 : 0.f), o1 = (bf16_t)(m1 > 0.f ? a1 + r1 : 0.f);
+        const unsigned short u0 = __builtin_bit_cast(unsigned short, o0), u1 = __builtin_bit_cast(unsigned short, o1);
+        ow[w] = (unsigned)u0 | ((unsigned)u1 << 16);
+        if (p.bpart && mok) {
+          const float q0 = (float)o0, q1 = (float)o1;
+          const float z0 = __uint_as_float(zw[w] << 16), z1 = __uint_as_float(zw[w] & 0xffff0000u);
+          st1[2 * w] += q0;
+          st1[2 * w + 1] += q1;
+          st2[2 * w] = fmaf(q0, z0 - bp[2 * w], st2[2 * w]);
+          st2[2 * w + 1] = fmaf(q1, z1 - bp[2 * w + 1], st2[2 * w + 1]);
+        }
+      }
+      if (mok) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + m * p.ldc + ch) = ow;
+      if (mt + NPRE < 4) eload(mt + NPRE);
+    }
+    if (tn < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (p.bpart) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        st1[e] += __shfl_xor(st1[e], o, 64);
+        st2[e] += __shfl_xor(st2[e], o, 64);
+      }
+    }
+    if (px == 0) {
+      float* dst = p.bpart + (long)blockIdx.x * 3 * N + ch;
+      *reinterpret_cast<f32x4*>(dst) = (f32x4){st1[0], st1[1], st1[2], st1[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){st1[4], st1[5], st1[6], st1[7]};
+      *reinterpret_cast<f32x4*>(dst + N) = (f32x4){st2[0], st2[1], st2[2], st2[3]};
+      *reinterpret_cast<f32x4*>(dst + N + 4) = (f32x4){st2[4], st2[5], st2[6], st2[7]};
+      *reinterpret_cast<f32x4*>(dst + 2 * N) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(dst + 2 * N + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
 extern "C" int tdeed_gemm_rs_fits(int M, int K, int N) { return (K == 320 && N == 320 && M > 0) ? 1 : 0; }
 
 // same contract as tdeed_gemm_ws_fwd (weights from engine.pack_ws_weights, bf16) without the stride-2 row gather
@@ -1161,6 +1312,37 @@ extern "C" int tdeed_gemm_rs_stats_fwd(const void* A, long lda, const void* A0, 
   TD_LAUNCH_CHECK("gemm_rs_stats");
   return TDEED_OK;
 }
+
+// tdeed_gemm_dgrad for K = N = 320 on the register-stationary scheme (gemm_rs_bwd_kernel): Wfrag = pack_ws_weights of the
+// [N][K] matrix the product is taken with (W^T of the layer); R (the shortcut gradient, [M][N] rows) and mask are required, no
+// stride-2 residual and no second statistics map (those calls stay on tdeed_gemm_dgrad); bpart fp32 [tdeed_gemm_rs_grid(M)][3][N].
+extern "C" int tdeed_gemm_dgrad_rs(const void* A, long lda, int M, int K, int N, const void* Wfrag, const void* R, long ldr,
+                                   void* C, long ldc, void* C2, long ldc2, int n2, const void* mask, long ldmask,
+                                   const void* bz, long ldbz, const float* bmean, float* bpart, void* stream) {
+  TD_CHECK(A && Wfrag && R && C && mask, "gemm_dgrad_rs: null pointer");
+  TD_CHECK(tdeed_gemm_rs_fits(M, K, N), "gemm_dgrad_rs: M=%d K=%d N=%d unsupported (K = N = 320)", M, K, N);
+  TD_CHECK(lda % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0 && ldmask % 8 == 0, "gemm_dgrad_rs: row strides must be multiples of 8");
+  TD_CHECK(!C2 || (n2 > 0 && n2 % 8 == 0 && n2 <= N && ldc2 % 8 == 0 && ldc2 >= n2), "gemm_dgrad_rs: bad second output");
+  TD_CHECK(!bpart || (bz && bmean && ldbz % 8 == 0), "gemm_dgrad_rs: statistics operands missing");
+  GemmRsBwdP p{};
+  p.A = A; p.lda = lda; p.M = M; p.Wf = Wfrag; p.R = R; p.ldr = ldr; p.C = C; p.ldc = ldc;
+  p.C2 = C2; p.ldc2 = ldc2; p.n2 = C2 ? n2 : 0;
+  p.mask = mask; p.ldmask = ldmask; p.bz = bz; p.ldbz = ldbz; p.bmean = bmean; p.bpart = bpart;
+  const size_t smem = (size_t)2 * RS_TILE + (size_t)RS_NW * 2 * (RS_KS - 7) * 64 * 16 + (size_t)N * sizeof(float);
+  static TdDevOnce attr;
+  if (!attr.get()) {
+    if (hipFuncSetAttribute((const void*)gemm_rs_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess) {
+      tdeed_set_error("gemm_dgrad_rs: hipFuncSetAttribute failed");
+      return TDEED_ERR_RUNTIME;
+    }
+    attr.set();
+  }
+  hipLaunchKernelGGL(gemm_rs_bwd_kernel, dim3((unsigned)tdeed_gemm_rs_grid(M)), dim3(RS_THR), smem, (hipStream_t)stream, p);
+  TD_LAUNCH_CHECK("gemm_dgrad_rs");
+  return TDEED_OK;
+}
+
 
 // =============================================================================================
 // Split-K contraction for the short sequences of the SGP encoder-decoder (M = B*T of a few hundred rows, K up to

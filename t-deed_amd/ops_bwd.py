@@ -407,13 +407,27 @@ class GradSink:
         self.nB = 0
 
 
-def gemm_dgrad(dz, wt, sink=None, residual=None, r_hw=None, out2=None):
+DGRAD_RS = os.environ.get("TDEED_TRAIN_DGRAD_RS", "1") == "1"
+DGRAD_RS_MIN_ROWS = 60000
+
+
+def gemm_dgrad(dz, wt, sink=None, residual=None, r_hw=None, out2=None, wt_ws=None):
     """dx (M, N) = ((dz (M,K) @ wt (N,K)^T) + residual) masked / summed for `sink` (tdeed_gemm_dgrad).  r_hw = (hi, wi): the
-    residual has rows for the even pixels of every hi x wi frame only; out2 (M, n2): columns [0, n2) before the residual."""
+    residual has rows for the even pixels of every hi x wi frame only; out2 (M, n2): columns [0, n2) before the residual.
+    wt_ws: the same matrix in the register-stationary kernel's fragment order -- K = N = 320 over many rows with a plain
+    residual and a one-map sink then run on tdeed_gemm_dgrad_rs."""
     N, K = wt.shape
     M = dz.numel() // K
     dev = dz.device
     dx = torch.empty((M, N), dtype=dz.dtype, device=dev)
+    if (DGRAD_RS and wt_ws is not None and sink is not None and sink.zd is None and residual is not None and r_hw is None
+            and dz.dtype == torch.bfloat16 and M >= DGRAD_RS_MIN_ROWS and _lib.load().tdeed_gemm_rs_fits(M, K, N)):
+        bpart = _f32((_lib.load().tdeed_gemm_rs_grid(M), 3, N), dev)
+        sink.partA = bpart
+        n2 = out2.shape[-1] if out2 is not None else 0
+        call("tdeed_gemm_dgrad_rs", ptr(dz), K, M, K, N, ptr(wt_ws), ptr(residual), residual.shape[-1], ptr(dx), N, ptr(out2),
+             n2, n2, ptr(sink.mask), N, ptr(sink.z), N, ptr(sink.mean), ptr(bpart), stream_ptr())
+        return dx
     bpart = None
     if sink is not None:
         bpart = _f32(((M + 127) // 128, 3, N), dev)

@@ -186,11 +186,12 @@ class BottleneckTrain:
         self.w3 = _dense(sd[pre + ".conv3.conv.weight"], dt)
         # 320-wide layers over many rows (the s3 blocks of RegNetY-800MF): fragment-ordered copies for the register-stationary
         # contraction (W in registers, activations cross the chip once: 106 vs 171 us per call at M = 313 600)
-        self.w1.ws = self.w3.ws = self.w3.wst_ws = None
+        self.w1.ws = self.w1.wst_ws = self.w3.ws = self.w3.wst_ws = None
         if dt == torch.bfloat16 and RS_TRAIN and blk.cin == blk.cout and ops.gemm_rs_fits(1 << 20, blk.cin, blk.cout):
             W1 = sd[self.c1 + ".conv.weight"].reshape(blk.cout, blk.cin)
             W3 = sd[pre + ".conv3.conv.weight"].reshape(blk.cout, blk.cout)
             self.w1.ws = R.to_bf16(R.pack_ws(W1))
+            self.w1.wst_ws = R.to_bf16(R.pack_ws(W1.t()))
             self.w3.ws = R.to_bf16(R.pack_ws(W3))
             self.w3.wst_ws = R.to_bf16(R.pack_ws(W3.t()))
         self.wd = _dense(sd[pre + ".downsample.conv.weight"], dt) if blk.has_downsample else None
@@ -450,7 +451,8 @@ class BottleneckTrain:
                     sd[pre + ".downsample.conv.weight"].shape)
                 r_hw = (h, w) if blk.stride == 2 else None
             dA = (torch.empty((Nf * h * w, self.gs.Fp), dtype=dz1.dtype, device=dz1.device) if self.gs is not None else None)
-            dx = B_.gemm_dgrad(dz1, self.w1.wt, sink=sink_out, residual=res, r_hw=r_hw, out2=dA).view(Nf, h, w, Cin)
+            dx = B_.gemm_dgrad(dz1, self.w1.wt, sink=sink_out, residual=res, r_hw=r_hw, out2=dA,
+                               wt_ws=self.w1.wst_ws).view(Nf, h, w, Cin)
             grads[self.c1 + ".conv.weight"] = B_.wgrad(dz1, c.a1, with_bias=False, M=Nf * h * w, X0=c.G,
                                                        k0=(self.gs.Fp if c.G is not None else 0))[0].reshape(
                 sd[self.c1 + ".conv.weight"].shape)

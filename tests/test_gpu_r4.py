@@ -366,4 +366,38 @@ def test_narrow_conv1_backward_in_one_launch_equals_the_three_launch_chain(Co, C
                                                    recompute=rc)
             outs.append((dx_r, B_.materialize(dW_r), sk.partA.clone()))
         torch.cuda.synchronize()
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])@pytest.mark.gpu
+@pytest.mark.parametrize("n2", [0, 80])
+def test_register_stationary_input_gradient_with_the_sink_epilogue_equals_the_tiled_kernel(n2):
+    """tdeed_gemm_dgrad_rs (K = N = 320 over many rows: residual, mask, compact second output before the residual, one-map sink
+    statistics per persistent workgroup) against tdeed_gemm_dgrad on the same operands."""
+    from tdeed_amd import ops_bwd as B_, repack as R
+    M, K = 70000 + 21, 320
+    bf = torch.bfloat16
+    dz = _rand((M, K), 61, 0.5).to(DEV).to(bf)
+    Wt = _rand((K, K), 62, 0.05).to(DEV)                       # the [N][K] matrix of the product
+    wt, wt_ws = Wt.to(bf), R.pack_ws(Wt).to(bf)
+    res = _rand((M, K), 63, 0.5).to(DEV).to(bf)
+    mask = torch.relu(_rand((M, K), 64)).to(DEV).to(bf)
+    z, mean = _rand((M, K), 65).to(DEV).to(bf), _rand((K,), 66, 0.2).to(DEV)
+    outs = []
+    for ws in (None, wt_ws):
+        sink = B_.GradSink(mask, z, mean)
+        o2 = torch.empty((M, n2), dtype=bf, device=DEV) if n2 else None
+        dx = B_.gemm_dgrad(dz, wt, sink=sink, residual=res, out2=o2, wt_ws=ws)
+        outs.append((dx, o2, sink.partA.double().sum(0)))
+    torch.cuda.synchronize()
+    (dx0, o20, p0), (dx1, o21, p1) = outs
+    assert p1.shape == p0.shape
+    assert max_abs(dx1, dx0) <= 2e-2 * max(1.0, float(dx0.float().abs().max()))
+    if n2:
+        assert max_abs(o21, o20) <= 2e-2 * max(1.0, float(o20.float().abs().max()))
+        assert torch.equal(dx1[:, :n2], (res[:, :n2].float() * (mask[:, :n2] > 0)).to(bf))
+    # the sums are those of what was stored
+    st = dx1.double()
+    want = torch.stack([st.sum(0), (st * (z.double() - mean.double())).sum(0)])
+    assert max_abs(p1[:2], want) <= 1e-3 * max(1.0, float(want.abs().max()))
+    assert float(p1[2].abs().max()) == 0.0
+
+
+
