@@ -400,9 +400,15 @@ __global__ __launch_bounds__(256) void gsf_bwd_conv3d_dx2_kernel(const T* __rest
   const int tid = threadIdx.x;
   // weights tap-major [27][Fp] (zero in the pad columns): a lane's 8 channels of one tap are two 16-byte reads instead of
   // eight 4-byte ones (the kernel is bound by its LDS reads: 2 per FMA before, 3/8 now)
-  for (int i = tid; i < Fp * 27; i += 256) {
-    const int kq = i / Fp, c = i - kq * Fp;
-    sw[i] = c < F ? w3[c * 27 + kq] : 0.f;
+  // (the global reads walk w3 [F][27] in memory order -- 8.6 KB = 68 lines per workgroup, scattered into the tap-major LDS image;
+  // walking the LDS image instead made every one of the 27 F scalar loads a different cache line, 12 800 workgroups over)
+  for (int i = tid; i < F * 27; i += 256) {
+    const int c = i / 27, kq = i - c * 27;
+    sw[kq * Fp + c] = w3[i];
+  }
+  for (int i = tid; i < (Fp - F) * 27; i += 256) {
+    const int kq = i / (Fp - F), c = F + i - kq * (Fp - F);
+    sw[kq * Fp + c] = 0.f;
   }
   for (int i = tid; i < F; i += 256) { aff[i] = sa[i]; aff[F + i] = sb[i]; }
   for (int i = tid; i < np * 27; i += 256) {
