@@ -27,6 +27,7 @@ import torch.nn.functional as F
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 BN_EPS = 1e-5
+BN_UPDATES = "__bn_updates__"     # optional dict in a state: train-mode forwards leave the new BatchNorm buffers there
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -42,6 +43,18 @@ def _bn(x, sd, pre, training, dims_per_channel=None):
     """BatchNorm (2d/3d share the formula); eval: running stats, train: biased batch stats."""
     w, b = sd[pre + ".weight"], sd[pre + ".bias"]
     if training:
+        upd = sd.get(BN_UPDATES)
+        if upd is not None:
+            # what nn.BatchNorm2d/3d leaves in its buffers after a train-mode forward (torch defaults, as constructed by
+            # timm / model/impl/gsf.py:26): momentum 0.1, UNBIASED batch variance, num_batches_tracked += 1
+            with torch.no_grad():
+                red = [d for d in range(x.dim()) if d != 1]
+                n = x.numel() // x.shape[1]
+                m = x.detach().mean(dim=red)
+                v = x.detach().var(dim=red, unbiased=False) * (n / max(n - 1, 1))
+                upd[pre + ".running_mean"] = 0.9 * sd[pre + ".running_mean"] + 0.1 * m
+                upd[pre + ".running_var"] = 0.9 * sd[pre + ".running_var"] + 0.1 * v
+                upd[pre + ".num_batches_tracked"] = sd[pre + ".num_batches_tracked"] + 1
         return F.batch_norm(x, None, None, w, b, True, 0.0, BN_EPS)
     return F.batch_norm(x, sd[pre + ".running_mean"], sd[pre + ".running_var"], w, b, False, 0.0, BN_EPS)
 

@@ -67,6 +67,8 @@ class TDEEDModel:
             #   augment_fn(frames (B,T,3,H,W) uint8|fp32 0..255 on the device, crop (top,left,h,w)|None) -> frames of the
             #   crop window (B,T,3,h,w), uint8 or fp32 0..255, on the device (flips included, if wanted)
             self.augment_generator = None           # torch.Generator for the augmentation draws (None: the global CPU one)
+            self.dropout_mask_fn = None             # optional hook replaying a recorded dropout draw of the heads:
+            #   dropout_mask_fn(B, T, C, n_heads) -> n_heads tensors (B,T,C) of 0 / 2 (class head(s) first, displacement last)
 
         # ---- nn.Module-like surface the reference's callers touch
         @staticmethod
@@ -223,7 +225,12 @@ class TDEEDModel:
                 flip = bool(augment_inference)
             C = self._feat_dim
             n_heads = (2 if self._double_head else 1) + (1 if self._radi_displacement > 0 else 0)
-            masks = [((torch.rand((B, T, C), device=self._device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
+            if self.dropout_mask_fn is not None:
+                # replay of a recorded nn.Dropout draw (parity tests against reference fixtures): n_heads tensors (B,T,C)
+                # holding 0 / 2, class head(s) first, displacement head last
+                masks = [m.to(self._device).to(eng.dt).contiguous() for m in self.dropout_mask_fn(B, T, C, n_heads)]
+            else:
+                masks = [((torch.rand((B, T, C), device=self._device) >= 0.5).to(eng.dt) * 2.0) for _ in range(n_heads)]
             head, ctx = eng.forward_train(x, crop=crop, flip=flip, drop_masks=masks)
             self._train_ctx = ctx
             n_cls, dcol, _ = eng.temporal.head_layout()

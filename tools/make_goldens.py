@@ -436,6 +436,170 @@ def frame_reader(name="frame_reader"):
                     layouts={k: [v[0], v[1]] for k, v in layouts.items()}), **arrays)
 
 
+# ----------------------------------------------------------------------------- training
+TRAIN_KEYS = [
+    "_features.stem.conv.weight", "_features.stem.bn.weight", "_features.s1.b1.downsample.conv.weight",
+    "_features.s2.b1.se.fc1.weight", "_features.s3.b1.conv1.gs.conv3D.weight", "_features.s3.b1.conv1.gs.bn.weight",
+    "_features.s3.b1.conv1.gs.channel_conv1.weight", "_features.s3.b2.conv2.conv.weight",
+    "_features.s4.b2.conv1.gs.channel_conv2.bias", "_features.s4.b1.se.fc2.bias", "_features.s4.b3.conv3.bn.bias",
+    "_features.s4.b7.conv1.net.conv.weight", "temp_enc",
+    "_temp_fine._sgp.0.ln.weight", "_temp_fine._sgp.1.convkw.weight", "_temp_fine._sgp.2.mlp.0.weight",
+    "_temp_fine._sgp.4.gn.bias", "_temp_fine._sgp.3.mlp.2.bias", "_temp_fine._sgpMixer.0.concat_fc.weight",
+    "_temp_fine._sgpMixer.1.psi2.weight", "_temp_fine._sgpMixer.0.global_fc1.weight",
+    "_pred_fine._fc_out.weight", "_pred_fine._fc_out.bias", "_pred_displ._fc_out.weight",
+]
+
+
+def sample_flat(a, cap=8192):
+    """what a fixture keeps of a tensor: all of it up to `cap` values, else every stride-th value"""
+    a = np.asarray(a).reshape(-1)
+    stride = 1 if a.size <= cap else a.size // 4096 + 1
+    return a[::stride].copy()
+
+
+class _MaskDrop(torch.nn.Module):
+    """nn.Dropout() of FCLayers (modules.py:372) with its random keep-mask replaced by a recorded one: x * mask, mask in
+    {0, 1/(1-p)} = {0, 2} -- exactly what F.dropout(p=0.5, training=True) computes for that draw."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask
+
+
+def drop_masks(seed, B, T, C, n):
+    return [((synth.normalish(seed + i, "dropmask", B * T * C) > 0).astype(np.float32) * 2.0).reshape(B, T, C)
+            for i in range(n)]
+
+
+def _train_model(cfg, seed_w, mask_seed, B):
+    args = types.SimpleNamespace(modality="rgb", temporal_arch="ed_sgp_mixer", pretrain=None, **cfg)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = rmodel.TDEEDModel(device="cpu", args=args)
+    fill(m._model, seed_w)
+    C = m._model._feat_dim
+    mk = drop_masks(mask_seed, B, cfg["clip_len"], C, 2)
+    m._model._pred_fine.dropout = _MaskDrop(torch.from_numpy(mk[0]))       # class head
+    m._model._pred_displ.dropout = _MaskDrop(torch.from_numpy(mk[1]))      # displacement head
+    return m, args
+
+
+def _chained(opt, warm_steps, cos_steps):
+    """train_tdeed.py:79-87 get_lr_scheduler: LinearLR(0.01 -> 1) chained with CosineAnnealingLR"""
+    from torch.optim.lr_scheduler import ChainedScheduler, LinearLR, CosineAnnealingLR
+    return ChainedScheduler([LinearLR(opt, start_factor=0.01, end_factor=1.0, total_iters=warm_steps),
+                             CosineAnnealingLR(opt, cos_steps)])
+
+
+def train_step(name, arch="rny002_gsf", seed_w=21, seed_x=2100, n_steps=3, lr=5e-5):
+    """Reference TDEEDModel in .train(): Impl.forward(x, inference=True) (center-crop branch: no random augmentation,
+    model.py:119-129) with BatchNorm batch statistics and the heads' dropout on a recorded mask, the loss of epoch()
+    (model.py:208-211, 308-319), modules.step() (390-404) with AdamW from get_optimizer (37-39) and the chained
+    LinearLR + CosineAnnealingLR of train_tdeed.py:79-87 -- `n_steps` steps on the same batch."""
+    import torch.nn.functional as Fn
+    cfg = tiny(arch, T=16)
+    B, H, W = 2, 64, 64
+    t0 = time.time()
+    m, args = _train_model(cfg, seed_w, seed_x + 7, B)
+    net = m._model
+    net.train()
+    clip = synth.uint8_clip(seed_x, (B, cfg["clip_len"], 3, H, W))
+    lab, labD = synth.labels(seed_x + 1, B, cfg["clip_len"], cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
+    K1 = cfg["num_classes"] + 1
+    wgt = torch.FloatTensor([1] + [5] * (K1 - 1))
+    opt, scaler = m.get_optimizer({"lr": lr})
+    assert scaler is None
+    sched = _chained(opt, 2, 4)
+    names = [k for k, _ in net.named_parameters()]
+    proj = {k: synth.normalish(77, "proj:" + k, p.numel()).astype(np.float64) for k, p in net.named_parameters()}
+    arrays = {}
+    losses, lrs = [], [opt.param_groups[0]["lr"]]
+    grabbed = {}
+
+    def grab(optimizer, a_, kw_):                       # the gradients modules.step() hands to AdamW, first step only
+        if not grabbed:
+            grabbed.update({k: p.grad.detach().double().numpy().reshape(-1).copy() for k, p in net.named_parameters()})
+    opt.register_step_pre_hook(grab)
+    with torch.enable_grad():
+        for s_ in range(n_steps):
+            pred, _ = net(torch.from_numpy(clip).float(), inference=True)
+            loss = Fn.cross_entropy(pred["im_feat"].reshape(-1, K1), torch.from_numpy(lab).flatten(), weight=wgt)
+            loss = loss + Fn.mse_loss(pred["displ_feat"], torch.from_numpy(labD).float(), reduction="none").mean()
+            losses.append(float(loss.detach()))
+            if s_ == 0:
+                arrays["logits0"] = pred["im_feat"].detach().numpy().copy()
+                arrays["displ0"] = pred["displ_feat"].detach().numpy().copy()
+            rmod.step(opt, scaler, loss, lr_scheduler=sched)
+            lrs.append(opt.param_groups[0]["lr"])
+            if s_ == 0:
+                sd1 = net.state_dict()
+                for k in TRAIN_KEYS:
+                    arrays["param1:" + k] = sample_flat(sd1[k].detach().numpy())
+    g = grabbed
+    arrays["grad_norm"] = np.array([np.linalg.norm(g[k]) for k in names])
+    arrays["grad_proj"] = np.array([float(g[k] @ proj[k]) for k in names])
+    for k in TRAIN_KEYS:
+        arrays["grad:" + k] = sample_flat(g[k].astype(np.float32))
+    sd = net.state_dict()
+    for k in TRAIN_KEYS:
+        arrays["param:" + k] = sample_flat(sd[k].detach().numpy())
+    bn_keys = [k for k in sd if k.endswith(("running_mean", "running_var"))]
+    arrays["bn_running"] = np.concatenate([sd[k].numpy().reshape(-1) for k in bn_keys])
+    arrays["bn_tracked"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")], np.int64)
+    arrays["losses"] = np.array(losses, np.float64)
+    arrays["lrs"] = np.array(lrs, np.float64)
+    meta = dict(kind="train_step", cfg=cfg, B=B, H=H, W=W, seed_w=seed_w, seed_x=seed_x, mask_seed=seed_x + 7,
+                label_seed=seed_x + 1, n_steps=n_steps, lr=lr, warm_steps=2, cos_steps=4, fg_frac=0.3, proj_seed=77,
+                param_names=names, bn_keys=bn_keys, keys=TRAIN_KEYS, sample_cap=8192, secs=round(time.time() - t0, 1))
+    save(name, meta, **arrays)
+
+
+def train_epoch(name, arch="rny002_gsf", seed_w=23, seed_x=2300, lr=2e-3):
+    """The reference's own TDEEDModel.epoch() training branch (model.py:193-332) on a two-batch loader -- a plain batch
+    and a mixup batch ('frame2' / 'label2' / 'labelD2', Beta(0.2, 0.2) weights from `random`) -- with acc_grad_iter=2,
+    AdamW and the chained scheduler.  crop_dim None and the augmentation Compose emptied (the draw in which no
+    RandomApply fires and no flip happens), dropout on recorded masks."""
+    import random
+    cfg = tiny(arch, T=16)
+    B, H, W, T_ = 2, 64, 64, 16
+    t0 = time.time()
+    m, args = _train_model(cfg, seed_w, seed_x + 7, B)
+    net = m._model
+    net.augmentation = sys.modules["torchvision.transforms"].Compose([])
+    batches = []
+    for i in range(2):
+        fr = synth.uint8_clip(seed_x + 10 * i, (B, T_, 3, H, W))
+        lab, labD = synth.labels(seed_x + 10 * i + 1, B, T_, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
+        bt = {"frame": torch.from_numpy(fr), "label": torch.from_numpy(lab), "labelD": torch.from_numpy(labD)}
+        if i == 1:
+            fr2 = synth.uint8_clip(seed_x + 10 * i + 5, (B, T_, 3, H, W))
+            lab2, labD2 = synth.labels(seed_x + 10 * i + 6, B, T_, cfg["num_classes"], cfg["radi_displacement"], fg_frac=0.3)
+            bt.update(frame2=torch.from_numpy(fr2), label2=torch.from_numpy(lab2), labelD2=torch.from_numpy(labD2))
+        batches.append(bt)
+    opt, scaler = m.get_optimizer({"lr": lr})
+    sched = _chained(opt, 2, 4)
+    random.seed(5)
+    rmodel.tqdm = lambda it: it
+    with torch.enable_grad():
+        avg = m.epoch(batches, optimizer=opt, scaler=scaler, lr_scheduler=sched, acc_grad_iter=2)
+    random.seed(5)
+    lam = [random.betavariate(0.2, 0.2) for _ in range(B)]
+    sd = net.state_dict()
+    arrays = {"loss": np.float64(avg), "lam": np.array(lam, np.float64), "lr_after": np.float64(opt.param_groups[0]["lr"])}
+    for k in TRAIN_KEYS:
+        arrays["param:" + k] = sample_flat(sd[k].detach().numpy())
+    bn_keys = [k for k in sd if k.endswith(("running_mean", "running_var"))]
+    arrays["bn_running"] = np.concatenate([sd[k].numpy().reshape(-1) for k in bn_keys])
+    arrays["bn_tracked"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")], np.int64)
+    meta = dict(kind="train_epoch", cfg=cfg, B=B, H=H, W=W, seed_w=seed_w, seed_x=seed_x, mask_seed=seed_x + 7, lr=lr,
+                warm_steps=2, cos_steps=4, acc_grad_iter=2, random_seed=5, fg_frac=0.3, keys=TRAIN_KEYS, bn_keys=bn_keys,
+                sample_cap=8192, secs=round(time.time() - t0, 1))
+    save(name, meta, **arrays)
+
+
 CASES = {
     "init_stats": lambda: init_stats(),
     "timm_keymap": lambda: timm_keymap(),
@@ -466,6 +630,8 @@ CASES = {
     "finediving_small": lambda: full_model("finediving_small", CFG_SMALL, 1, 224, 224),
     "finediving_big": lambda: full_model("finediving_big", CFG_BIG, 1, 224, 224),
     "snb_t250": lambda: full_model("snb_t250", CFG_SNB, 1, 160, 160),
+    "train_step_tiny_rny002": lambda: train_step("train_step_tiny_rny002"),
+    "train_epoch_tiny_rny002": lambda: train_epoch("train_epoch_tiny_rny002"),
 }
 
 
