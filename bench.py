@@ -326,6 +326,87 @@ def infer_sub_record(workload, steps, repeats, depth, rank, dev, traffic_file, s
     return rec
 
 
+
+# ---------------------------------------------------------------------------------------------- the printed line
+# The driver keeps 8 KB of head and 2 KB of tail of a line: the default line is therefore COMPACT (< 7 KB) with the numbers
+# a reader looks for hoisted as scalars right behind the contract's fields; `--full` prints every table (what
+# tools/prof_r05.sh stores under profiles/), and the full record is also left in gpurun_out/bench_full.json.
+_DROP_KEYS = {"note", "kernels", "ms_per_step_repeats", "by_processes", "by_threads", "families_ms", "traffic_source",
+              "cpu_model", "measured", "workload", "thread_sweep", "sweep", "repeats", "hip_graph", "steps", "unit_note",
+              "bn_bwd_family", "gemm_family", "kernel_name", "slots", "algorithmic_bytes_per_launch", "host_cores"}
+
+
+def _trim(o, drop=_DROP_KEYS, maxstr=110):
+    if isinstance(o, dict):
+        return {k: _trim(v, drop, maxstr) for k, v in o.items() if k not in drop}
+    if isinstance(o, list):
+        return [_trim(v, drop, maxstr) for v in o[:8]]
+    if isinstance(o, str) and len(o) > maxstr:
+        return o[:maxstr - 3] + "..."
+    return o
+
+
+def _g(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+
+
+def compact_line(out):
+    c = {k: out[k] for k in CONTRACT if k in out}
+    tr = out.get("train") or {}
+    hoist = dict(
+        train_rny008_b16_ms_per_step=_g(tr, "rny008_b16", "ms_per_step"),
+        train_rny008_b16_clips_per_s=_g(tr, "rny008_b16", "value"),
+        train_rny008_b16_step_hbm_GB=(None if _g(tr, "rny008_b16", "roofline_family", "step_hbm_bytes_measured") is None
+                                      else round(_g(tr, "rny008_b16", "roofline_family", "step_hbm_bytes_measured") / 1e9, 1)),
+        train_rny002_b8_ms_per_step=_g(tr, "rny002_b8", "ms_per_step"),
+        infer_800mf_clips_per_s=_g(out, "infer_800mf", "value"),
+        infer_800mf_sgp_stage_us=(None if _g(out, "infer_800mf", "roofline_sgp", "ms") is None
+                                  else round(_g(out, "infer_800mf", "roofline_sgp", "ms") * 1e3, 1)),
+        infer_snb_t250_clips_per_s=_g(out, "infer_snb_t250", "value"),
+        sgp_stage_us=(None if _g(out, "roofline_sgp", "ms") is None else round(_g(out, "roofline_sgp", "ms") * 1e3, 1)),
+        logit_max_abs_err_fp32=out.get("logit_max_abs_err_fp32"), logit_max_abs_err_bf16=out.get("logit_max_abs_err_bf16"),
+        logit_abs_max=out.get("logit_abs_max"), latency_ms_inflight1=out.get("latency_ms_inflight1"),
+        fed_from_host_clips_per_s=_g(out, "fed_from_host", "value"),
+        timed_output_check_ok=_g(out, "timed_output_check", "ok"))
+    c.update({k: v for k, v in hoist.items() if v is not None})
+    c["roofline"] = _trim(out.get("roofline"))
+    c["cpu_baseline"] = _trim(out.get("cpu_baseline"))
+    for k in ("roofline_step", "roofline_sgp", "timed_output_check", "fed_from_host", "infer_800mf", "infer_snb_t250", "train",
+              "dp_diag"):
+        if out.get(k) is not None:
+            c[k] = _trim(out[k])
+    c["git_head"] = out.get("git_head")
+    c["full_record"] = out.get("full_record")
+    # never beyond the driver's 8 KB head: shed the optional sub-tables, least important first
+    for k in ("fed_from_host", "roofline_step", "timed_output_check"):
+        if len(json.dumps(c)) <= 7000:
+            break
+        c.pop(k, None)
+    if len(json.dumps(c)) > 7000:
+        c = _trim(c, _DROP_KEYS | {"roofline_step", "config", "sample"}, 60)
+    return c
+
+
+def emit(out, full):
+    """rank 0: leave the full record in gpurun_out/ (when writable) and print ONE line"""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        path = os.path.join("gpurun_out", "bench_full.json")
+        with open(os.path.join(ROOT, path), "w") as f:
+            json.dump(out, f)
+        out["full_record"] = path
+    except OSError:
+        out["full_record"] = None
+    print(json.dumps(out if full else compact_line(out)))
+
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -706,6 +787,9 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-records of the default line")
     ap.add_argument("--no-feed", action="store_true", help="skip the fed-from-pinned-host-memory measurement")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--full", action="store_true",
+                    help="print every table (per-kernel tables, sweeps, notes); the default line is compact (< 7 KB: the driver "
+                         "keeps 8 KB of a line's head) with the sub-records' headline numbers hoisted as scalars")
     ap.add_argument("--pmc-pass", action="store_true",
                     help="only the timed steps (for rocprofv3 --pmc counter passes: eager launches, no side measurements)")
     ap.add_argument("--split", type=int, default=1,
@@ -892,7 +976,7 @@ def main():
                 tr[wk] = dict(error=f"{type(e).__name__}: {e}"[:300])
         out["train"] = tr
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, a.full)
     if world > 1:
         import torch.distributed as dist
         tdist.barrier()                                          # rank 0's side measurements are over: leave together

@@ -624,6 +624,11 @@ int tdeed_mix_frames(const uint8_t* a, const uint8_t* b, const float* lam, int B
  * tdeed_gsf_add_cols: dx[m][0:Fp] += a[m][:] + b[m][:] (dx row stride C). */
 int tdeed_gsf_slice(const void* x, long M, int C, int F, int Fp, void* xs, int dtype, void* stream);
 long tdeed_gsf_bwd_scratch_floats(int B, int T, int hw, int F);
+/* tdeed_gsf_bwd_part_layout: where tdeed_gsf_bwd(d_w3 == NULL) leaves its parameter-gradient partials inside `scratch`
+ *   (float offsets): out[6] = {off_cw, rows_cw, stride_cw, off_w3, rows_w3, stride_w3}; part_cw row columns 0..17
+ *   channel_conv1 taps, 18 its bias, 19..36 channel_conv2 taps, 37 its bias; part_w3 row = conv3D.weight [F][27], 2 biases
+ *   (replaces nothing in the reference: autograd accumulates these in model/impl/gsf.py:38-93's backward). */
+int tdeed_gsf_bwd_part_layout(int B, int T, int hw, int F, long* out);
 int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, const float* ysum, const float* xsum,
                   const void* dA, int B, int T, int h, int w, int C, int F, int Fp, const float* w3, const float* sa,
                   const float* sb, const float* cw1, const float* cw2, float* scratch, void* d_xs, void* d_bn,

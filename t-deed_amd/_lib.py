@@ -106,6 +106,7 @@ _SIGS = {
     "tdeed_reduce_strided": ([P, c_int, c_long, c_long, P, P], c_int),
     "tdeed_gsf_slice": ([P, c_long, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gsf_bwd_scratch_floats": ([c_int, c_int, c_int, c_int], c_long),
+    "tdeed_gsf_bwd_part_layout": ([c_int, c_int, c_int, c_int, P], c_int),
     "tdeed_gsf_bwd": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                        c_int, P], c_int),
     "tdeed_gsf_add_cols": ([P, P, c_long, c_int, c_int, P, c_int, P], c_int),

@@ -718,6 +718,22 @@ extern "C" long tdeed_gsf_bwd_scratch_floats(int B, int T, int hw, int F) {
   return 4 * N * F + N * hw * 2 + (long)B * GSF_CW_Z * 38 + N * ((long)F * 27 + 2);
 }
 
+// Where the parameter-gradient partials of tdeed_gsf_bwd(d_w3 == NULL) lie inside `scratch` (float offsets), for a caller
+// that folds them itself: out = {off_cw, rows_cw, stride_cw, off_w3, rows_w3, stride_w3}.  part_cw rows [rows_cw][38]:
+// columns 0..17 channel_conv1 taps, 18 its bias, 19..36 channel_conv2 taps, 37 its bias; part_w3 rows [rows_w3][27 F + 2]:
+// conv3D.weight as [F][27], then the two biases.
+extern "C" int tdeed_gsf_bwd_part_layout(int B, int T, int hw, int F, long* out) {
+  TD_CHECK(out && B > 0 && T > 0 && hw > 0 && F > 0, "gsf_bwd_part_layout: bad arguments");
+  const long N = (long)B * T;
+  out[0] = 4 * N * F + N * hw * 2;
+  out[1] = (long)B * GSF_CW_Z;
+  out[2] = 38;
+  out[3] = out[0] + out[1] * 38;
+  out[4] = N;
+  out[5] = (long)F * 27 + 2;
+  return TDEED_OK;
+}
+
 template <typename T>
 static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, const float* ysum, const float* xsum,
                           const void* dA_, int B, int T_len, int h, int w, int C, int F, int Fp, const float* w3,

@@ -230,24 +230,35 @@ class ProcessDecodePool:
             th.start()
 
     def _reader(self, pr, wi):
-        for line in pr.stdout:
-            parts = line.rstrip("\n").split(" ", 2)
+        try:
+            for line in pr.stdout:
+                parts = line.rstrip("\n").split(" ", 2)
+                try:
+                    jid = int(parts[0])
+                    status = parts[1]
+                except (ValueError, IndexError):
+                    continue                    # not a protocol line (a library's warning on the worker's stdout): skip it
+                with self._lock:
+                    ack = self._pending.pop(jid, None)
+                if ack is not None:
+                    if status != "ok":
+                        ack.err = parts[2] if len(parts) > 2 else "decode worker error"
+                    ack.ev.set()
+        finally:
+            # EOF on the worker's pipe (or this thread dying): the worker exited (crash, OOM kill, or close()).  Fail the
+            # jobs it still owed right away instead of letting every result() run into its timeout, and take it out of
+            # the rotation.
+            try:
+                rc = pr.wait(timeout=2.0)
+            except Exception:           # noqa: BLE001  (still running: the pipe closed first)
+                rc = pr.poll()
             with self._lock:
-                ack = self._pending.pop(int(parts[0]), None)
-            if ack is not None:
-                if parts[1] != "ok":
-                    ack.err = parts[2] if len(parts) > 2 else "decode worker error"
-                ack.ev.set()
-        # EOF on the worker's pipe: it exited (crash, OOM kill, or close()).  Fail the jobs it still owed right away instead
-        # of letting every result() run into its timeout, and take it out of the rotation.
-        rc = pr.poll()
-        with self._lock:
-            self._alive[wi] = False
-            owed = [j for j, a in self._pending.items() if a.worker == wi]
-            for j in owed:
-                ack = self._pending.pop(j)
-                ack.err = f"decode worker {wi} exited (rc={rc}) with the job outstanding"
-                ack.ev.set()
+                self._alive[wi] = False
+                owed = [j for j, a in self._pending.items() if a.worker == wi]
+                for j in owed:
+                    ack = self._pending.pop(j)
+                    ack.err = f"decode worker {wi} exited (rc={rc}) with the job outstanding"
+                    ack.ev.set()
 
     def _pick_worker(self):
         """next live worker of the rotation (caller holds the lock)"""
@@ -274,7 +285,7 @@ class ProcessDecodePool:
         from multiprocessing import shared_memory
         key = (int(depth), tuple(int(v) for v in shape))
         if key in self._slot_cache:
-            return self._slot_cache[key]
+            return self._slot_cache[key][0]
         n = int(np.prod(shape))
         out = []
         for _ in range(depth):
@@ -287,8 +298,17 @@ class ProcessDecodePool:
             self._shms.append((shm, t.data_ptr(), n, torch.cuda.is_available()))
             self._slots.append(t)
             out.append(t)
-        self._slot_cache[key] = out
+        # the upload-event holders that guard a slot's reuse live WITH the slots: a second loader over the same pool and
+        # shape (train + val, or a new epoch while an upload from the old generator is still in flight) waits on the same
+        # events before it decodes into a slot
+        from types import SimpleNamespace
+        self._slot_cache[key] = (out, [SimpleNamespace(event=None) for _ in range(depth)])
         return out
+
+    def slot_holders(self, depth, shape):
+        """the per-slot upload-event holders of make_slots(depth, shape) (shared by every loader that uses those slots)"""
+        self.make_slots(depth, shape)
+        return self._slot_cache[(int(depth), tuple(int(v) for v in shape))][1]
 
     def _locate(self, dst):
         p = dst.data_ptr()
@@ -403,12 +423,15 @@ def clip_batches(clips, batch_size, frame_shape, clip_len, pool=None, depth=3, p
     shape = (batch_size, clip_len) + tuple(frame_shape)
     if hasattr(pool, "make_slots"):          # worker processes decode into shared, page-locked slots
         slots = pool.make_slots(depth, shape)
+        holders = pool.slot_holders(depth, shape) if hasattr(pool, "slot_holders") else None
     else:
+        holders = None
         # (page-locked when a GPU runtime is there, like make_slots: the decode logic itself also runs on a GPU-less host)
         slots = [torch.zeros(shape, dtype=torch.uint8) for _ in range(depth)]
         if torch.cuda.is_available():
             slots = [t_.pin_memory() for t_ in slots]
-    holders = [SimpleNamespace(event=None) for _ in range(depth)]
+    if holders is None:
+        holders = [SimpleNamespace(event=None) for _ in range(depth)]
     try:
         for bi, lo in enumerate(range(0, len(clips) - batch_size + 1, batch_size)):
             slot = slots[bi % depth]

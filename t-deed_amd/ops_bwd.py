@@ -3,6 +3,8 @@ device memory handed over as raw pointers on the current stream; scratch (`part*
 does not pass it (a training engine passes preallocated buffers)."""
 import os
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -459,9 +461,10 @@ def gsf_add_cols_sink(a, b, dx, Fp, sink, bn=None):
     return dx
 
 
-def bn_bwd_from_parts(z, g, ctx, w, sink, q=1, want_dz=True):
+def bn_bwd_from_parts(z, g, ctx, w, sink, q=1, want_dz=True, want_sums=False):
     """BatchNorm backward of z for the already masked gradient g whose statistics the producers left in `sink`
-    (q = 1: against sink.z, q = 2: against sink.zd).  -> dz (or None), dw, db."""
+    (q = 1: against sink.z, q = 2: against sink.zd).  -> dz (or None), dw, db; with want_sums -> dz, sums fp32 [2][C]
+    (row 0 = db, row 1 = dw: the buffer stem_wgrad_bn / narrow_conv1_bwd read as a whole)."""
     C = z.shape[-1]
     M = z.numel() // C
     dev = z.device
@@ -471,13 +474,14 @@ def bn_bwd_from_parts(z, g, ctx, w, sink, q=1, want_dz=True):
     call("tdeed_bn_bwd_from_parts", ptr(z), ptr(g), M, C, ptr(ctx[0]), ptr(ctx[1]), ptr(w), ptr(sink.partA), sink.partA.shape[0],
          ptr(pb), (pb.shape[0] if pb is not None else 0), sink.nB, q, ptr(tmp), ptr(sums), ptr(dz), dtype_code(z.dtype),
          stream_ptr())
-    return dz, sums[1], sums[0]
+    return (dz, sums[1], sums[0]) if not want_sums else (dz, sums)
 
 
 def bn_sums_from_sink(z, g, ctx, w, sink, q=1):
-    """(sums fp32 [2][C]) of the BatchNorm backward whose column-sum partials lie in `sink` (no apply pass)"""
-    _, dw, _ = bn_bwd_from_parts(z, g, ctx, w, sink, q=q, want_dz=False)
-    return dw._base if dw._base is not None else dw
+    """(sums fp32 [2][C]: row 0 = d bias, row 1 = d weight) of the BatchNorm backward whose column-sum partials lie in
+    `sink` (no apply pass)"""
+    _, sums = bn_bwd_from_parts(z, g, ctx, w, sink, q=q, want_dz=False, want_sums=True)
+    return sums
 
 
 def gconv3x3_bwd(x, dy, w_packed, gw, stride, want_dx=True, in_affine=None):
@@ -555,15 +559,16 @@ def gsf_bwd(x, gate, fw, ysum, xsum, dA, B, T, F, Fp, w3, sa, sb, cw1, cw2, bn_m
         call(entry, ptr(x), ptr(gate), ptr(fw), ptr(ysum), ptr(xsum), ptr(dA), B, T, h, w, C, F, Fp, ptr(w3), ptr(sa),
              ptr(sb), ptr(cw1), ptr(cw2), ptr(scratch), ptr(d_xs), ptr(d_bn), None, None, None, None, *extra,
              dtype_code(x.dtype), stream_ptr())
-        row = F * 27 + 2
-        off_cw = 4 * N * F + N * h * w * 2
-        off_w3 = scratch.numel() - N * row
-        PZ = (off_w3 - off_cw) // 38                                # B * GSF_CW_Z rows of 38
+        # the partials' place inside `scratch` comes from the library (the layout is the .hip file's to change)
+        lay = (ctypes.c_long * 6)()
+        call("tdeed_gsf_bwd_part_layout", B, T, h * w, F, lay)
+        off_cw, PZ, cw_stride, off_w3, n_w3, row = (int(v) for v in lay)
+        assert n_w3 == N and row == F * 27 + 2 and cw_stride == 38 and off_w3 + n_w3 * row == scratch.numel(), tuple(lay)
         d_w3 = LazyFold(scratch[off_w3:], N, F * 27, (F, 27), pstride=row)
         d_b3 = LazyFold(scratch[off_w3 + F * 27:], N, 2, pstride=row)
         if not fuse:
             return ret(d_xs, d_bn, d_w3, d_b3, None, None)
-        cw = lambda c0, n: LazyFold(scratch[off_cw + c0:], PZ, n, pstride=38)       # noqa: E731
+        cw = lambda c0, n: LazyFold(scratch[off_cw + c0:], PZ, n, pstride=cw_stride)       # noqa: E731
         return ret(d_xs, d_bn, d_w3, d_b3, (cw(0, 18), cw(19, 18)), (cw(18, 1), cw(37, 1)))
     d_w3, d_b3 = _f32((F, 27), dev), _f32((2,), dev)
     d_cw, d_cb = (_f32((2, 18), dev), _f32((2,), dev)) if fuse else (None, None)

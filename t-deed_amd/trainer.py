@@ -212,6 +212,8 @@ class TrainEngine:
             self.pack = PackPlan(self.params, self.device).build(list(self.blocks) + [self.temporal, self.stem])
         else:
             self.pack.run()
+            for blk in self.blocks:          # the gather refreshed every block's packed copies in place (blk.repack() bumps
+                blk.pack_gen += 1            # its own counter): a backward of an older forward must not recompute from them
 
     # ------------------------------------------------------------------ one optimiser step
     def write_grads(self, grads, scale=1.0, first=True, partial=False, role=0):

@@ -163,6 +163,7 @@ class BottleneckTrain:
 
     def __init__(self, sd, pre, blk, act_dtype=torch.float32, clip_len=None):
         self.sd, self.pre, self.blk, self.dt = sd, pre, blk, act_dtype
+        self.pack_gen = 0                     # bumped by whoever refreshes the packed weights (TrainEngine.repack)
         self.c1 = pre + (".conv1.net" if blk.gsf_fold else ".conv1")          # GatedShift keeps the conv as .net
         self.gs = GateShiftTrain(sd, pre + ".conv1.gs", blk.gsf_fold, clip_len, act_dtype) if blk.gsf_fold else None
         # BatchNorm statistics out of the producing conv's epilogue (bf16 MFMA kernels); TDEED_TRAIN_EPI_STATS=0 restores the
@@ -177,7 +178,17 @@ class BottleneckTrain:
         self.onload = (self.epi_stats and ZMASK and os.environ.get("TDEED_TRAIN_ONLOAD", "1") == "1")
         self.repack()
 
+    def _check_recompute(self, c):
+        """The narrow one-launch backward is called with recompute=True: it re-derives z = x @ W^T from the packed transposed
+        weights instead of reading the saved map.  That equals the forward's z only while those are the weights the forward
+        multiplied with (same packing, same k order and rounding: the forward's own kernel layout) -- so no repack / optimizer
+        step may lie between a forward and its backward."""
+        if c.pack_gen != self.pack_gen:
+            raise RuntimeError(f"{self.pre}: the packed weights changed (repack generation {c.pack_gen} -> {self.pack_gen}) "
+                               "between forward and backward; the narrow backward recomputes z from them")
+
     def repack(self):
+        self.pack_gen += 1
         sd, pre, blk, dt = self.sd, self.pre, self.blk, self.dt
         dev = sd[self.c1 + ".conv.weight"].device
         if self.gs is not None:
@@ -248,6 +259,7 @@ class BottleneckTrain:
         c = SimpleNamespace(x=x)
         c.G = None
         c.out_slice = None
+        c.pack_gen = self.pack_gen           # which packing of the weights this forward multiplied with (checked in backward)
         if self.gs is not None:
             Fp = self.gs.Fp
             G = self.gs.forward(x, xs=xs)
@@ -330,6 +342,7 @@ class BottleneckTrain:
         if sink_in is not None and NARROW_BWD and B_.narrow_conv1_bwd_fits(C, C, dout.dtype):
             # narrow layers: conv3's BatchNorm apply pass, its input gradient and its weight gradient in one launch (the conv1
             # kernel with no ReLU between BatchNorm and conv: fa = 0, fb = 1; dz3 lives in LDS only)
+            self._check_recompute(c)
             sums3 = B_.bn_sums_from_sink(c.z3, dout, c.bn3, sd[pre + ".conv3.bn.weight"], sink_in, q=1)
             d_y2s, dW3, dw, db = B_.narrow_conv1_bwd(dout, c.z3, (c.bn3[0], c.bn3[1], self.zero, self.one),
                                                      sd[pre + ".conv3.bn.weight"], None, c.y2s, self.w3.wt, sums=sums3,
@@ -399,6 +412,7 @@ class BottleneckTrain:
                 and B_.narrow_conv1_bwd_fits(C, Cin, d_y1.dtype) and sink_out.mask.data_ptr() == c.x.data_ptr()):
             # narrow layers (RegNetY-800MF s1 / s2): BatchNorm + ReLU backward, input gradient (+ shortcut gradient, the sink of
             # the block in front) and weight gradient in ONE launch; dz1 lives in LDS only (trunk_bwd3.hip)
+            self._check_recompute(c)
             res, r_hw = d_sc.view(-1, Cin) if not blk.has_downsample else None, None
             if blk.has_downsample:
                 wdn = sd[pre + ".downsample.bn.weight"]

@@ -79,8 +79,11 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
     sub = [gap(2, 8)] + [gap(8 + j, 9 + j) for j in range(3)]
     print("   conv2 of wave 0, cycles: tap offsets + weight requests %s, units %s"
           % ("%.0f" % sub[0] if sub[0] is not None else "-", ", ".join("%.0f" % v for v in sub[1:] if v is not None)))
+    d = d[(d[:, 0] > 0) & (d[:, 6] > 0)]            # rows of workgroups that ran (the row count above is an upper bound)
     ph = np.diff(d[:, :7], axis=1) / 100.0          # clock64 ticks (shader clock, ~2.4 GHz) / 100
+    # clock64 is a per-XCD counter: a span across workgroups means something only while the eight counters agree
+    sp = (d[:, 6].max() - d[:, 0].min()) / 100.0
+    span = f"{sp:.2f}" if sp < 100 * np.median(d[:, 6] - d[:, 0]) / 100.0 else "n/a (the XCDs' counters are not aligned)"
     names = ["load x", "conv1", "conv2", "SE + gate", "conv3", "store"]
     print("   phase cycles / 100 (median over workgroups): " + ", ".join(f"{n} {np.median(ph[:, i]):.2f}" for i, n in enumerate(names))
-          + f"; workgroup total {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}; first start -> last end "
-          f"{(d[:, 6].max() - d[:, 0].min()) / 100.0:.2f}", flush=True)
+          + f"; workgroup total {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}; first start -> last end {span}", flush=True)
