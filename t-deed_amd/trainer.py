@@ -213,7 +213,7 @@ class TrainEngine:
         else:
             self.pack.run()
             for blk in self.blocks:          # the gather refreshed every block's packed copies in place (blk.repack() bumps
-                blk.pack_gen += 1            # its own counter): a backward of an older forward must not recompute from them
+                blk.pack_gen = getattr(blk, "pack_gen", 0) + 1   # its own counter): a backward of an older forward must not recompute from them
 
     # ------------------------------------------------------------------ one optimiser step
     def write_grads(self, grads, scale=1.0, first=True, partial=False, role=0):

@@ -188,7 +188,7 @@ class BottleneckTrain:
                                "between forward and backward; the narrow backward recomputes z from them")
 
     def repack(self):
-        self.pack_gen += 1
+        self.pack_gen = getattr(self, "pack_gen", 0) + 1
         sd, pre, blk, dt = self.sd, self.pre, self.blk, self.dt
         dev = sd[self.c1 + ".conv.weight"].device
         if self.gs is not None:
