@@ -275,13 +275,17 @@ int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int
  * tdeed_sgp_mlp_fwd takes instead of re-reading the clip for its GroupNorm statistics */
 /* rowstat* (optional, fp32 [rows][2] = LayerNorm mean, rstd of every input row, as tdeed_sgp_mlp2_fwd leaves them for the
  * rows it writes): taken instead of re-deriving the statistics from the clip's (T x C) slab */
+/* rowstat*_parts: 0 = the (mean, rstd) form above; n > 0 = [n][rows][2] partial (sum, sum of squares) of each row over the n
+ * column tiles of the tdeed_sgp_gemm_residual launch that stored the rows (summed in order; mean / rstd derived here).
+ * dtype_cat (mixer): the six slabs may be stored as bf16 while z / x_lo are fp32 (fp32 residual stream, bf16 contraction). */
 int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w, const float* ln_b, float eps,
-                        const float* dw, const float* db, void* y, float* chsum, const float* rowstat, int dtype,
-                        void* stream);
+                        const float* dw, const float* db, void* y, float* chsum, const float* rowstat, int rowstat_parts,
+                        int dtype, void* stream);
 int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T_lo, int C, int ks, int up,
                           const float* ln1_w, const float* ln1_b, const float* ln2_w, const float* ln2_b, float eps,
                           const float* dw1, const float* db1, const float* dw2, const float* db2, void* cat,
-                          const float* rowstat_z, const float* rowstat_x, int dtype, void* stream);
+                          const float* rowstat_z, int rowstat_z_parts, const float* rowstat_x, int rowstat_x_parts,
+                          int dtype, int dtype_cat, void* stream);
 int tdeed_sgp_mlp_fits(int R, int T, int C, int G);
 /* hidden-chunk split S of the launch (1, 2 or 4); for S > 1 `partial` must hold S*R*C floats (fp32 partials, folded in a
  * fixed order by a second launch) */
@@ -669,6 +673,33 @@ int tdeed_graph_begin(void* stream);
 int tdeed_graph_end(void* stream, void** graph_exec);
 int tdeed_graph_launch(void* graph_exec, void* stream);
 int tdeed_graph_destroy(void* graph_exec);
+
+/* ---- dense contractions of the SGP encoder-decoder with their prologue / epilogue (csrc/sgp_gemm.hip; round 5).
+ * Replaces, per SGPBlock / SGPMixer of /root/reference/model/modules.py: self.gn + self.mlp[0] + GELU (134-138, 186, 316),
+ * self.mlp[2] + the residual add (186, 316) with the AdaptiveMaxPool1d of the encoder (64, 75-77) and the row sums the next
+ * LayerNorm needs (320-363), concat_fc + GELU (245-246, 307-308) with the channel sums the next GroupNorm needs.
+ * Weights: MFMA fragments [N/16][tdeed_sgp_gemm_ksteps(K)][64][8] bf16 (zero padded).  Row tiles never straddle clips.
+ *   form = 16 * MT + NT (tile = 16 MT rows x 64 NT features) from tdeed_sgp_gemm_form; tdeed_sgp_gemm_row_tiles(T, MT) row
+ *   tiles per clip (NJ), tdeed_sgp_gemm_col_tiles(N, NT) column tiles (nct).
+ * tdeed_sgp_gemm_gn_gelu:   H[B*T][N] bf16 = GELU(GroupNorm_G(y) . W^T + b); y [B*T][K] in dtype_a; chsum [parts][B][K][2]
+ *   (sum, sum of squares over the clip's rows per channel, summed over `parts` in order).
+ * tdeed_sgp_gemm_residual:  out = resid + H . W^T + b (H bf16 [B*T][K]; out, resid, pooled in dtype_o); rowstat_part
+ *   [nct][B*T][2] = (sum, sum of squares) of each stored row over the column tile; pooled != NULL (needs T == 2 T_out):
+ *   the max of each row pair [B*T_out][N] and rowstat_pool_part [nct][B*T_out][2].
+ * tdeed_sgp_gemm_gelu_chsum: out = GELU(A . W^T + b) (A bf16 [B*T][K], out in dtype_o); chs_out [NJ][B][N][2] per-channel
+ *   (sum, sum of squares) of the stored rows of each row tile. */
+int tdeed_sgp_gemm_ksteps(int K);
+int tdeed_sgp_gemm_row_tiles(int T, int MT);
+int tdeed_sgp_gemm_col_tiles(int N, int NT);
+int tdeed_sgp_gemm_form(int mode, int B, int T, int N, int K);
+int tdeed_sgp_gemm_gn_gelu(const void* y, int B, int T, int K, const float* chsum, int chs_parts, const float* gn_w,
+                           const float* gn_b, int G, float eps, const void* Wp, const float* bias, int N, void* H, int form,
+                           int dtype_a, void* stream);
+int tdeed_sgp_gemm_residual(const void* H, int B, int T, int K, const void* Wp, const float* bias, int N, const void* resid,
+                            void* out, float* rowstat_part, void* pooled, float* rowstat_pool_part, int T_out, int form,
+                            int dtype_o, void* stream);
+int tdeed_sgp_gemm_gelu_chsum(const void* A, int B, int T, int K, const void* Wp, const float* bias, int N, void* out,
+                              float* chs_out, int form, int dtype_o, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,13 @@ _SIGS = {
     "tdeed_gsf_slice": ([P, c_long, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gsf_bwd_scratch_floats": ([c_int, c_int, c_int, c_int], c_long),
     "tdeed_gsf_bwd_part_layout": ([c_int, c_int, c_int, c_int, P], c_int),
+    "tdeed_sgp_gemm_ksteps": ([c_int], c_int),
+    "tdeed_sgp_gemm_row_tiles": ([c_int, c_int], c_int),
+    "tdeed_sgp_gemm_col_tiles": ([c_int, c_int], c_int),
+    "tdeed_sgp_gemm_form": ([c_int, c_int, c_int, c_int, c_int], c_int),
+    "tdeed_sgp_gemm_gn_gelu": ([P, c_int, c_int, c_int, P, c_int, P, P, c_int, c_float, P, P, c_int, P, c_int, c_int, P], c_int),
+    "tdeed_sgp_gemm_residual": ([P, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, P], c_int),
+    "tdeed_sgp_gemm_gelu_chsum": ([P, c_int, c_int, c_int, P, P, c_int, P, P, c_int, c_int, P], c_int),
     "tdeed_gsf_bwd": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                        c_int, P], c_int),
     "tdeed_gsf_add_cols": ([P, P, c_long, c_int, c_int, P, c_int, P], c_int),
@@ -140,9 +147,9 @@ _SIGS = {
     "tdeed_layernorm_fwd": ([P, c_long, c_int, c_int, P, P, c_float, P, c_long, c_int, P], c_int),
     "tdeed_sgp_branch_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_mixer_branch_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
-    "tdeed_sgp_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int, P], c_int),
-    "tdeed_mixer_front_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P, P, c_int,
-                               P], c_int),
+    "tdeed_sgp_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_mixer_front_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int, P,
+                               c_int, c_int, c_int, P], c_int),
     "tdeed_sgp_mlp2_slices": ([c_int], c_int),
     "tdeed_sgp_mlp2_stamped": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_sgp_fold_cols": ([P, c_int, c_int, c_int, c_int, P, c_int, P, P, P], c_int),

@@ -55,12 +55,27 @@ __device__ __forceinline__ void ln_row_stats(const T* __restrict__ slab, long ld
   }
 }
 
-// the same statistics handed over by the producer of the rows (sgp_fold_rows_kernel: rowstat [rows][2] = mean, rstd)
-__device__ __forceinline__ void ln_row_stats_load(const float* __restrict__ rowstat, int T_len, float* mu, float* rs) {
+// the same statistics handed over by the producer of the rows: parts == 0: rowstat [rows][2] = (mean, rstd)
+// (sgp_fold_rows_kernel, avgpool_posenc); parts > 0: [parts][rows][2] = (sum, sum of squares) of the row over each column
+// tile of the contraction that stored it (sgp_gemm.hip MODE 1), summed here in order; pstride = floats per part
+__device__ __forceinline__ void ln_row_stats_load(const float* __restrict__ rowstat, int parts, long pstride, int T_len,
+                                                  int C, float eps, float* mu, float* rs) {
   for (int t = threadIdx.x; t < T_len; t += blockDim.x) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(rowstat + (long)t * 2);
-    mu[t] = v[0];
-    rs[t] = v[1];
+    if (parts == 0) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(rowstat + (long)t * 2);
+      mu[t] = v[0];
+      rs[t] = v[1];
+    } else {
+      float s = 0.f, q = 0.f;
+      for (int pt = 0; pt < parts; ++pt) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(rowstat + pt * pstride + (long)t * 2);
+        s += v[0];
+        q += v[1];
+      }
+      const float m = s / (float)C;
+      mu[t] = m;
+      rs[t] = 1.0f / sqrtf(fmaxf(q / (float)C - m * m, 0.f) + eps);
+    }
   }
 }
 
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
                                                         float eps, const float* __restrict__ dw,
                                                         const float* __restrict__ db, T* __restrict__ y,
                                                         float* __restrict__ chsum,
-                                                        const float* __restrict__ rowstat) {
+                                                        const float* __restrict__ rowstat, int rs_parts) {
   extern __shared__ float sm[];
   const int halo = up >> 1;
   const int wlen = 2 * ks + up + 2;
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
   dw_issue(dw, wlen, c0, C, wv);
   const Bias5 bb = bias_issue(db, C, c0 + c, C);
   const float lw = ln_w[min(c0 + c, C - 1)], lb = ln_b[min(c0 + c, C - 1)];
-  if (rowstat) ln_row_stats_load(rowstat + (long)b * T_len * 2, T_len, mu, rs);
+  if (rowstat) ln_row_stats_load(rowstat + (long)b * T_len * 2, rs_parts, (long)gridDim.x * T_len * 2, T_len, C, eps, mu, rs);
   else ln_row_stats<T>(x + base, C, T_len, C, eps, mu, rs);
   tile_commit<T>(tv, T_len, c0, C, tile, halo);
   dw_commit(wv, wlen, c0, C, wl);
@@ -161,8 +176,9 @@ static size_t front_smem(int T_len, int ks, int up, int ntiles, int nres, int ns
 
 extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w,
                                    const float* ln_b, float eps, const float* dw, const float* db, void* y,
-                                   float* chsum, const float* rowstat, int dtype, void* stream) {
+                                   float* chsum, const float* rowstat, int rowstat_parts, int dtype, void* stream) {
   TD_CHECK(x && ln_w && ln_b && dw && db && y, "sgp_front: null pointer");
+  TD_CHECK(rowstat_parts >= 0 && rowstat_parts <= 64, "sgp_front: rowstat_parts");
   TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_front: bad sizes");
   TD_CHECK(T <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80,
            "sgp_front: T=%d / ks=%d up=%d beyond the staging registers", T, ks, up);
@@ -173,10 +189,10 @@ extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(sgp_front_kernel<float>, grid, dim3(256), smem, st, (const float*)x, T, C, ks, up, ln_w, ln_b, eps,
-                       dw, db, (float*)y, chsum, rowstat);
+                       dw, db, (float*)y, chsum, rowstat, rowstat_parts);
   else if (dtype == TDEED_BF16)
     hipLaunchKernelGGL(sgp_front_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)x, T, C, ks, up, ln_w, ln_b,
-                       eps, dw, db, (bf16_t*)y, chsum, rowstat);
+                       eps, dw, db, (bf16_t*)y, chsum, rowstat, rowstat_parts);
   else { tdeed_set_error("sgp_front: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("sgp_front");
   return TDEED_OK;
@@ -185,16 +201,16 @@ extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, i
 // =========================================================================== SGPMixer front half (LN1, LN2 fused)
 // cat row = [out1 | out2 | out3 | out4 | zn | xu], each C wide (modules.py:302-308).  The two sources are independent until
 // the concat: blockIdx.z = 0 handles z (LN1, slabs 4, 0, 2), blockIdx.z = 1 handles x_lo (LN2, up-sampling, slabs 5, 1, 3).
-template <typename T>
+template <typename T, typename TC>
 __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ z, const T* __restrict__ xlo, int T_hi,
                                                           int T_lo, int C, int ks, int up,
                                                           const float* __restrict__ ln1_w, const float* __restrict__ ln1_b,
                                                           const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
                                                           float eps, const float* __restrict__ dw1,
                                                           const float* __restrict__ db1, const float* __restrict__ dw2,
-                                                          const float* __restrict__ db2, T* __restrict__ cat,
-                                                          const float* __restrict__ rowstat_z,
-                                                          const float* __restrict__ rowstat_x) {
+                                                          const float* __restrict__ db2, TC* __restrict__ cat,
+                                                          const float* __restrict__ rowstat_z, int parts_z,
+                                                          const float* __restrict__ rowstat_x, int parts_x) {
   extern __shared__ float sm[];
   const int halo = up >> 1;
   const int wlen = 2 * ks + up + 2;
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
   float* rs = mu + T_hi;
   const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH, src = blockIdx.z;
   const long ldc = 6L * C;
-  T* crow = cat + (long)b * T_hi * ldc;
+  TC* crow = cat + (long)b * T_hi * ldc;
   const int T_src = src == 0 ? T_hi : T_lo;
   const T* sb = src == 0 ? z + (long)b * T_hi * C : xlo + (long)b * T_lo * C;
   const float* dw = src == 0 ? dw1 : dw2;
@@ -222,7 +238,8 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
     tile_issue<T>(sb, C, T_src, c0, C, sv);
     dw_issue(dw, wlen, c0, C, wv);
     const float* rst = src == 0 ? rowstat_z : rowstat_x;
-    if (rst) ln_row_stats_load(rst + (long)b * T_src * 2, T_src, mu, rs);
+    if (rst) ln_row_stats_load(rst + (long)b * T_src * 2, src == 0 ? parts_z : parts_x, (long)gridDim.x * T_src * 2, T_src, C,
+                               eps, mu, rs);
     else ln_row_stats<T>(sb, C, T_src, C, eps, mu, rs);
     if (src == 0) tile_commit<T>(sv, T_hi, c0, C, tile, halo);
     else tile_commit<T>(sv, T_lo, c0, C, res, 0);          // x_lo at T_lo -> res (no halo)
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
   }
   __syncthreads();
   // slab 4 = zn, slab 5 = xu
-  store_tile<T>(tile + halo * SGP_CH, crow + (long)(4 + src) * C, ldc, 0, T_hi, c0, C, (const T*)nullptr, 0);
+  store_tile<TC>(tile + halo * SGP_CH, crow + (long)(4 + src) * C, ldc, 0, T_hi, c0, C, (const TC*)nullptr, 0);
   tile_mean(tile, T_hi, halo, red);
   const float mean_c = red[16 * SGP_CH + c];
 #define MIX_FAST(KS_, UP_)                                                                                     \
@@ -282,15 +299,17 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
 #undef MIX_FAST
 #undef MIX_GENERIC
   __syncthreads();
-  store_tile<T>(res, crow + (long)src * C, ldc, 0, T_hi, c0, C, (const T*)nullptr, 0);
-  store_tile<T>(res2, crow + (long)(2 + src) * C, ldc, 0, T_hi, c0, C, (const T*)nullptr, 0);
+  store_tile<TC>(res, crow + (long)src * C, ldc, 0, T_hi, c0, C, (const TC*)nullptr, 0);
+  store_tile<TC>(res2, crow + (long)(2 + src) * C, ldc, 0, T_hi, c0, C, (const TC*)nullptr, 0);
 }
 
 extern "C" int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T_lo, int C, int ks, int up,
                                      const float* ln1_w, const float* ln1_b, const float* ln2_w, const float* ln2_b,
                                      float eps, const float* dw1, const float* db1, const float* dw2, const float* db2,
-                                     void* cat, const float* rowstat_z, const float* rowstat_x, int dtype, void* stream) {
+                                     void* cat, const float* rowstat_z, int parts_z, const float* rowstat_x, int parts_x,
+                                     int dtype, int dtype_cat, void* stream) {
   TD_CHECK(z && xlo && ln1_w && ln1_b && ln2_w && ln2_b && dw1 && db1 && dw2 && db2 && cat, "mixer_front: null pointer");
+  TD_CHECK(parts_z >= 0 && parts_z <= 64 && parts_x >= 0 && parts_x <= 64, "mixer_front: rowstat parts");
   TD_CHECK(B > 0 && T_hi >= T_lo && T_lo > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks,
            "mixer_front: bad sizes");
   TD_CHECK(T_hi <= (dtype == TDEED_BF16 ? 512 : 256) && 2 * ks + up + 2 <= 80,
@@ -300,13 +319,20 @@ extern "C" int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int 
   TD_CHECK(smem <= 64 * 1024, "mixer_front: T=%d too long for the LDS window", T_hi);
   dim3 grid(B, cdiv(C, SGP_CH), 2);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDEED_F32)
-    hipLaunchKernelGGL(mixer_front_kernel<float>, grid, dim3(256), smem, st, (const float*)z, (const float*)xlo, T_hi, T_lo,
-                       C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (float*)cat, rowstat_z, rowstat_x);
-  else if (dtype == TDEED_BF16)
-    hipLaunchKernelGGL(mixer_front_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)z, (const bf16_t*)xlo, T_hi,
-                       T_lo, C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (bf16_t*)cat, rowstat_z, rowstat_x);
-  else { tdeed_set_error("mixer_front: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  if (dtype == TDEED_F32 && dtype_cat == TDEED_F32)
+    hipLaunchKernelGGL((mixer_front_kernel<float, float>), grid, dim3(256), smem, st, (const float*)z, (const float*)xlo, T_hi,
+                       T_lo, C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (float*)cat, rowstat_z, parts_z,
+                       rowstat_x, parts_x);
+  else if (dtype == TDEED_F32 && dtype_cat == TDEED_BF16)
+    // fp32 residual stream, bf16 contraction operand (the throughput mode of round 5): the six slabs are rounded once, at the store
+    hipLaunchKernelGGL((mixer_front_kernel<float, bf16_t>), grid, dim3(256), smem, st, (const float*)z, (const float*)xlo, T_hi,
+                       T_lo, C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (bf16_t*)cat, rowstat_z, parts_z,
+                       rowstat_x, parts_x);
+  else if (dtype == TDEED_BF16 && dtype_cat == TDEED_BF16)
+    hipLaunchKernelGGL((mixer_front_kernel<bf16_t, bf16_t>), grid, dim3(256), smem, st, (const bf16_t*)z, (const bf16_t*)xlo,
+                       T_hi, T_lo, C, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, eps, dw1, db1, dw2, db2, (bf16_t*)cat, rowstat_z,
+                       parts_z, rowstat_x, parts_x);
+  else { tdeed_set_error("mixer_front: bad dtypes %d / %d", dtype, dtype_cat); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("mixer_front");
   return TDEED_OK;
 }

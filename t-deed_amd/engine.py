@@ -174,13 +174,15 @@ def pack_se_bf16(fc1_w, fc2_w, device):
     return dict(se_w1p=bf(p1), se_w2p=bf(w2.T))
 
 
-def pack_mfma_frags(W, device, rows=None):
+def pack_mfma_frags(W, device, rows=None, ks_mult=1):
     """A dense [N][K] weight as MFMA A-operand fragments [ceil(N/16)][ceil(K/32)][64][8] (bf16, zero padded; lane l holds row
-    l&15, k = 8*(l>>4)+j of the 16 x 32 tile).  rows: pad N up to this many rows (whole channel slabs)."""
+    l&15, k = 8*(l>>4)+j of the 16 x 32 tile).  rows: pad N up to this many rows (whole channel slabs); ks_mult: pad the
+    k-steps to a multiple of this (sgp_gemm: whole super-iterations of its chunk ring, 12)."""
     W = _np(W).astype(np.float32)
     W = W.reshape(W.shape[0], -1)
     N, K = W.shape
     NT, KS = (max(N, rows or 0) + 15) // 16, (K + 31) // 32
+    KS = (KS + ks_mult - 1) // ks_mult * ks_mult
     Wp = np.zeros((NT * 16, KS * 32), np.float32)
     Wp[:N, :K] = W
     fr = Wp.reshape(NT, 16, KS, 4, 8).transpose(0, 2, 3, 1, 4)

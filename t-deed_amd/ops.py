@@ -415,6 +415,11 @@ def mixer_branch(xn, cat, T_hi, ks, up, dw1, db1, dw2, db2):
     return cat
 
 
+def _rs_parts(rowstat):
+    """rowstat (rows, 2) = (mean, rstd) -> 0; (n, rows, 2) = partial (sum, sum of squares) per column tile -> n"""
+    return 0 if rowstat is None or rowstat.dim() == 2 else int(rowstat.shape[0])
+
+
 def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None, rowstat=None):
     """SGPBlock front half with the LayerNorm computed in-kernel: y = x + LN(x) + fc*phi + (convw+convkw)*psi.
     chsum: optional fp32 (B, C, 2) output, per-channel sum / sum of squares over T of y (for sgp_mlp's GroupNorm);
@@ -423,7 +428,7 @@ def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None, row
     if out is None:
         out = torch.empty_like(x)
     call("tdeed_sgp_front_fwd", ptr(x), B, T, C, ks, up, ptr(ln_w), ptr(ln_b), eps, ptr(dw), ptr(db), ptr(out),
-         ptr(chsum), ptr(rowstat), dtype_code(x.dtype), stream_ptr())
+         ptr(chsum), ptr(rowstat), _rs_parts(rowstat), dtype_code(x.dtype), stream_ptr())
     return out
 
 
@@ -433,8 +438,8 @@ def mixer_front(z, xlo, cat, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, dw1, db1, dw2, 
     B, T_hi, C = z.shape
     T_lo = xlo.shape[1]
     call("tdeed_mixer_front_fwd", ptr(z), ptr(xlo), B, T_hi, T_lo, C, ks, up, ptr(ln1_w), ptr(ln1_b), ptr(ln2_w),
-         ptr(ln2_b), eps, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(cat), ptr(rowstat_z), ptr(rowstat_x),
-         dtype_code(z.dtype), stream_ptr())
+         ptr(ln2_b), eps, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(cat), ptr(rowstat_z), _rs_parts(rowstat_z),
+         ptr(rowstat_x), _rs_parts(rowstat_x), dtype_code(z.dtype), dtype_code(cat.dtype), stream_ptr())
     return cat
 
 
@@ -623,3 +628,59 @@ def fill_u8_hash(shape, seed, device="cuda"):
     base = ((seed * 0x9E3779B97F4A7C15) ^ fnv1a64("clip")) & 0xFFFFFFFFFFFFFFFF
     call("tdeed_fill_u8_hash", ptr(out), n, base, stream_ptr())
     return out[:n].view(*shape)
+
+
+# ---------------------------------------------------------------------------------------------- SGP contractions (sgp_gemm.hip)
+def sgp_gemm_ksteps(K):
+    return int(_lib.load().tdeed_sgp_gemm_ksteps(K))
+
+
+def sgp_gemm_form(mode, B, T, N, K):
+    """(MT, NT) of the tile the launcher wants for this contraction: 16 MT rows of one clip x 64 NT features per workgroup.
+    mode 0 / 3: GroupNorm + fc1 + GELU on bf16 / fp32 rows, 1: fc2 + residual, 2: concat_fc + GELU"""
+    f = int(_lib.load().tdeed_sgp_gemm_form(mode, B, T, N, K))
+    return f >> 4, f & 15
+
+
+def sgp_gemm_tiles(T, N, form):
+    """(row tiles per clip, column tiles) of a form: the leading dimensions of chs_out / rowstat_part"""
+    L = _lib.load()
+    return int(L.tdeed_sgp_gemm_row_tiles(T, form[0])), int(L.tdeed_sgp_gemm_col_tiles(N, form[1]))
+
+
+def sgp_gemm_gn_gelu(y, chsum, gn_w, gn_b, Wp, bias, N, out=None, form=None, G=16, eps=1e-5):
+    """H (B,T,N) bf16 = GELU(GroupNorm(y) @ W^T + b).  y (B,T,K) bf16 | fp32; chsum fp32 (parts,B,K,2) or (B,K,2): per-channel
+    (sum, sum of squares) of y over each clip's rows; Wp: engine.pack_mfma_frags(W, ks_mult=12)."""
+    B, T, K = y.shape
+    parts = 1 if chsum.dim() == 3 else chsum.shape[0]
+    form = form or sgp_gemm_form(0 if y.dtype == torch.bfloat16 else 3, B, T, N, K)
+    if out is None:
+        out = torch.empty((B, T, N), dtype=torch.bfloat16, device=y.device)
+    call("tdeed_sgp_gemm_gn_gelu", ptr(y), B, T, K, ptr(chsum), parts, ptr(gn_w), ptr(gn_b), G, eps, ptr(Wp), ptr(bias), N,
+         ptr(out), form[0] * 16 + form[1], dtype_code(y.dtype), stream_ptr())
+    return out
+
+
+def sgp_gemm_residual(H, Wp, bias, resid, out=None, rowstat_part=None, pooled=None, rowstat_pool_part=None, form=None):
+    """out (B,T,N) = resid + H @ W^T + b (H bf16 (B,T,K); out / resid / pooled bf16 | fp32).  rowstat_part fp32 (nct, B*T, 2):
+    (sum, sum of squares) of every stored row over each column tile; pooled (B,T/2,N): AdaptiveMaxPool1d(T/2) of out and its
+    rowstat_pool_part (nct, B*T/2, 2).  -> (out, form)"""
+    B, T, K = H.shape
+    N = resid.shape[-1]
+    form = form or sgp_gemm_form(1, B, T, N, K)
+    if out is None:
+        out = torch.empty_like(resid)
+    call("tdeed_sgp_gemm_residual", ptr(H), B, T, K, ptr(Wp), ptr(bias), N, ptr(resid), ptr(out), ptr(rowstat_part),
+         ptr(pooled), ptr(rowstat_pool_part), 0 if pooled is None else pooled.shape[1], form[0] * 16 + form[1],
+         dtype_code(out.dtype), stream_ptr())
+    return out
+
+
+def sgp_gemm_gelu_chsum(A, Wp, bias, N, out, chs_out, form=None):
+    """out (B,T,N) bf16 | fp32 = GELU(A @ W^T + b), A bf16 (B,T,K); chs_out fp32 (NJ,B,N,2): per-channel (sum, sum of squares)
+    of the stored rows per row tile"""
+    B, T, K = A.shape
+    form = form or sgp_gemm_form(2, B, T, N, K)
+    call("tdeed_sgp_gemm_gelu_chsum", ptr(A), B, T, K, ptr(Wp), ptr(bias), N, ptr(out), ptr(chs_out), form[0] * 16 + form[1],
+         dtype_code(out.dtype), stream_ptr())
+    return out

@@ -31,3 +31,104 @@ def test_backward_after_a_repack_is_refused_where_it_would_recompute_from_the_ne
     _, dhead = eng.temporal.loss_fwd_bwd(head, B, T, lab.reshape(-1).contiguous())
     eng.backward_train(ctx, dhead)
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ sgp_gemm.hip
+def _rnd(seed, name, shape, scale=1.0):
+    return t((synth.normalish(seed, name, int(np.prod(shape))) * scale).reshape(shape).astype(np.float32))
+
+
+FORMS = [(4, 2), (4, 1), (2, 2), (2, 1), (1, 2), (1, 1), None]
+
+
+@pytest.mark.parametrize("adt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,C", [(8, 100, 368), (3, 50, 368), (2, 25, 48), (2, 13, 768), (1, 250, 96)])
+def test_sgp_gemm_groupnorm_fc1_gelu(B, T, C, adt):
+    """MODE 0 of sgp_gemm.hip against torch: H = GELU(GroupNorm16(y) @ W1^T + b1) (modules.py:134-136, 186), every tile form,
+    bf16 and fp32 rows, the GroupNorm statistics from per-channel sums handed in as 1 or 3 partials."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_mfma_frags
+    N = 4 * C
+    y = _rnd(1, "y", (B, T, C), 1.5).to(DEV).to(adt)
+    W = _rnd(2, "w", (N, C), 0.08).to(DEV)
+    b1 = _rnd(3, "b", (N,), 0.1).to(DEV)
+    gw, gb = (1.0 + _rnd(4, "gw", (C,), 0.2)).to(DEV), _rnd(5, "gb", (C,), 0.2).to(DEV)
+    Wp = pack_mfma_frags(W.cpu().numpy(), DEV, ks_mult=12)
+    yf = y.float()
+    chs = torch.stack([yf.sum(1), (yf * yf).sum(1)], -1).contiguous()                 # (B, C, 2)
+    parts3 = torch.stack([chs * 0.5, chs * 0.25, chs * 0.25]).contiguous()
+    gn = torch.nn.functional.group_norm(yf.transpose(1, 2), 16, gw, gb, 1e-5).transpose(1, 2)
+    ref = torch.nn.functional.gelu(gn.to(torch.bfloat16).float() @ W.to(torch.bfloat16).float().t() + b1)
+    forms = FORMS if adt == torch.bfloat16 else [f for f in FORMS if f != (4, 2)]
+    for form in forms:
+        for cs in (chs, parts3):
+            H = ops.sgp_gemm_gn_gelu(y, cs, gw, gb, Wp, b1, N, form=form)
+            torch.cuda.synchronize()
+            err = float((H.float() - ref).abs().max())
+            assert err < 2e-2 * max(1.0, float(ref.abs().max())), (form, err)
+
+
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,C,pool", [(8, 100, 368, True), (3, 50, 368, True), (2, 25, 48, False), (2, 13, 768, False),
+                                        (1, 250, 96, True)])
+def test_sgp_gemm_fc2_residual_rowsums_pool(B, T, C, pool, odt):
+    """MODE 1: out = y + H @ W2^T + b2 (modules.py:137, 186), the per-row sums the next LayerNorm is derived from (exactly
+    the sums of the stored values) and the fused AdaptiveMaxPool1d(T/2) (modules.py:64, 77) with its row sums."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_mfma_frags
+    K = 4 * C
+    H = _rnd(11, "h", (B, T, K), 0.7).to(DEV).to(torch.bfloat16)
+    W = _rnd(12, "w", (C, K), 0.05).to(DEV)
+    b2 = _rnd(13, "b", (C,), 0.1).to(DEV)
+    y = _rnd(14, "y", (B, T, C), 1.0).to(DEV).to(odt)
+    Wp = pack_mfma_frags(W.cpu().numpy(), DEV, ks_mult=12)
+    ref = (y.float() + H.float() @ W.to(torch.bfloat16).float().t() + b2)
+    for form in FORMS:
+        f = form or ops.sgp_gemm_form(1, B, T, C, K)
+        NJ, nct = ops.sgp_gemm_tiles(T, C, f)
+        rsp = torch.full((nct, B * T, 2), float("nan"), device=DEV)
+        pooled = torch.full((B, T // 2, C), float("nan"), device=DEV, dtype=odt) if pool else None
+        rpp = torch.full((nct, B * (T // 2), 2), float("nan"), device=DEV) if pool else None
+        out = ops.sgp_gemm_residual(H, Wp, b2, y, rowstat_part=rsp, pooled=pooled, rowstat_pool_part=rpp, form=f)
+        torch.cuda.synchronize()
+        tol = (2e-2 if odt == torch.bfloat16 else 2e-3) * max(1.0, float(ref.abs().max()))
+        assert float((out.float() - ref).abs().max()) < tol, form
+        of = out.float().reshape(B * T, C)
+        s = rsp.sum(0)
+        assert float((s[:, 0] - of.sum(1)).abs().max()) < 1e-3 * C ** 0.5 * max(1.0, float(of.abs().max())), form
+        assert float((s[:, 1] - (of * of).sum(1)).abs().max()) < 1e-3 * float((of * of).sum(1).max()), form
+        if pool:
+            pr = torch.nn.functional.adaptive_max_pool1d(out.float().transpose(1, 2), T // 2).transpose(1, 2)
+            assert torch.equal(pooled.float(), pr), form
+            pf = pooled.float().reshape(B * (T // 2), C)
+            sp = rpp.sum(0)
+            assert float((sp[:, 0] - pf.sum(1)).abs().max()) < 1e-3 * C ** 0.5 * max(1.0, float(pf.abs().max())), form
+            assert float((sp[:, 1] - (pf * pf).sum(1)).abs().max()) < 1e-3 * float((pf * pf).sum(1).max()), form
+
+
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,C", [(8, 100, 368), (3, 50, 368), (2, 25, 48), (2, 13, 768)])
+def test_sgp_gemm_concat_gelu_channel_sums(B, T, C, odt):
+    """MODE 2: mo = GELU(cat @ Wc^T + bc) (modules.py:307-308) and the per-channel sums of the stored rows per row tile
+    (what the mixer's GroupNorm statistics are derived from)."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_mfma_frags
+    K = 6 * C
+    A = _rnd(21, "a", (B, T, K), 0.8).to(DEV).to(torch.bfloat16)
+    W = _rnd(22, "w", (C, K), 0.04).to(DEV)
+    bc = _rnd(23, "b", (C,), 0.1).to(DEV)
+    Wp = pack_mfma_frags(W.cpu().numpy(), DEV, ks_mult=12)
+    ref = torch.nn.functional.gelu(A.float() @ W.to(torch.bfloat16).float().t() + bc)
+    for form in FORMS:
+        f = form or ops.sgp_gemm_form(2, B, T, C, K)
+        NJ, nct = ops.sgp_gemm_tiles(T, C, f)
+        out = torch.full((B, T, C), float("nan"), device=DEV, dtype=odt)
+        chs = torch.full((NJ, B, C, 2), float("nan"), device=DEV)
+        ops.sgp_gemm_gelu_chsum(A, Wp, bc, C, out, chs, form=f)
+        torch.cuda.synchronize()
+        tol = (2e-2 if odt == torch.bfloat16 else 2e-3) * max(1.0, float(ref.abs().max()))
+        assert float((out.float() - ref).abs().max()) < tol, form
+        of = out.float()
+        s = chs.sum(0)
+        assert float((s[..., 0] - of.sum(1)).abs().max()) < 1e-3 * T ** 0.5 * max(1.0, float(of.abs().max())), form
+        assert float((s[..., 1] - (of * of).sum(1)).abs().max()) < 1e-3 * max(1.0, float((of * of).sum(1).max())), form
