@@ -242,7 +242,7 @@ int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysu
  * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]).  rowstat (optional, fp32
  * [B*T][2]): LayerNorm mean / rstd over C of every stored feature row, for tdeed_sgp_front_fwd of the first SGP block. */
 int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
-                             void* feat, float* rowstat, int dtype, void* stream);
+                             void* feat, float* rowstat, int dtype, int dtype_out /* feat: dtype, or TDEED_F32 */, void* stream);
 
 /* ---- SGP pyramid pieces (model/modules.py:58-363), NTC layout ------------------------------- */
 /* channel LayerNorm of every row (modules.py:320-363): y[r][c] = (x-mu)/sqrt(var+eps)*w[c]+b[c];

@@ -1087,10 +1087,10 @@ extern "C" int tdeed_se_gate_bf16_fwd(const float* pooled, int n_parts, float in
 // =========================================================================== avg-pool + pos-enc
 // One workgroup per frame, 256 lanes = (pixel slice, channel chunk); every lane fetches its pixels in batches of 8
 // independent loads (a plain accumulate loop costs one memory round trip per pixel), then an ordered reduce in LDS.
-template <typename T>
+template <typename T, typename TO>
 __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict__ x, int T_len, int hw, int C,
                                                              const float* __restrict__ temp_enc,
-                                                             T* __restrict__ feat, float* __restrict__ rowstat,
+                                                             TO* __restrict__ feat, float* __restrict__ rowstat,
                                                              float ln_eps) {
   constexpr int EPC = Chunk<T>::N;
   extern __shared__ float red[];       // [S][C]
@@ -1129,10 +1129,18 @@ __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict
       for (int s = 0; s < S; ++s) v += red[s * C + c0 + e];
       a[e] = v / (float)hw + temp_enc[(long)t * C + c0 + e];
     }
-    Chunk<T>::store(feat + (long)f * C + c0, a);
+    // (TO = float under a bf16 trunk: the temporal stage keeps its residual stream in fp32, round 5)
+    constexpr int EPO = Chunk<TO>::N;
+#pragma unroll
+    for (int g = 0; g < EPC / EPO; ++g) {
+      float o[EPO];
+#pragma unroll
+      for (int e = 0; e < EPO; ++e) o[e] = a[g * EPO + e];
+      Chunk<TO>::store(feat + (long)f * C + c0 + g * EPO, o);
+    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      const float v = round_to<T>(a[e]);
+      const float v = round_to<TO>(a[e]);
       rs1 += v;
       rs2 = fmaf(v, v, rs2);
     }
@@ -1151,18 +1159,23 @@ __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict
 }
 
 extern "C" int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int C, const float* temp_enc,
-                                        void* feat, float* rowstat, int dtype, void* stream) {
+                                        void* feat, float* rowstat, int dtype, int dtype_out, void* stream) {
   TD_CHECK(x && temp_enc && feat, "avgpool: null pointer");
+  TD_CHECK(dtype_out == dtype || dtype_out == TDEED_F32, "avgpool: feat is stored in the input's type or in fp32");
   TD_CHECK(B > 0 && T > 0 && hw > 0 && C > 0 && C % 8 == 0 && C <= 2048, "avgpool: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32) {
     const int nch = C / 4, S = 256 / nch > 0 ? 256 / nch : 1;
-    hipLaunchKernelGGL(avgpool_posenc_kernel<float>, dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
+    hipLaunchKernelGGL((avgpool_posenc_kernel<float, float>), dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
                        (const float*)x, T, hw, C, temp_enc, (float*)feat, rowstat, 1e-5f);
   } else if (dtype == TDEED_BF16) {
     const int nch = C / 8, S = 256 / nch > 0 ? 256 / nch : 1;
-    hipLaunchKernelGGL(avgpool_posenc_kernel<bf16_t>, dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
-                       (const bf16_t*)x, T, hw, C, temp_enc, (bf16_t*)feat, rowstat, 1e-5f);
+    if (dtype_out == TDEED_F32)
+      hipLaunchKernelGGL((avgpool_posenc_kernel<bf16_t, float>), dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
+                         (const bf16_t*)x, T, hw, C, temp_enc, (float*)feat, rowstat, 1e-5f);
+    else
+      hipLaunchKernelGGL((avgpool_posenc_kernel<bf16_t, bf16_t>), dim3(B * T), dim3(256), (size_t)S * C * sizeof(float), st,
+                         (const bf16_t*)x, T, hw, C, temp_enc, (bf16_t*)feat, rowstat, 1e-5f);
   } else { tdeed_set_error("avgpool: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("avgpool_posenc");
   return TDEED_OK;

@@ -80,6 +80,18 @@ def _sgp_mlp2_on():
     return os.environ.get("TDEED_SGP_MLP2", "1") == "1"
 
 
+SGP_GEMM = os.environ.get("TDEED_SGP_GEMM", "1") == "1"             # the SGP contractions on sgp_gemm.hip (round 5)
+# its residual stream (block / mixer inputs and outputs, the stash) in fp32 under a bf16 trunk, like the reference's autocast
+SGP_F32_STREAM = os.environ.get("TDEED_SGP_F32_STREAM", "1") == "1"
+
+
+def sgp_stream_dtype(act_dtype, device):
+    """type of the temporal stage's residual stream (feat, block / mixer outputs, the stash) for a trunk in act_dtype"""
+    if SGP_GEMM and SGP_F32_STREAM and act_dtype == torch.bfloat16 and str(device) != "cpu":
+        return torch.float32
+    return act_dtype
+
+
 def _pack_mlp(sd, pre, C, o, act_dtype, device):
     o.w_fc1 = _dense(_np(sd[pre + ".mlp.0.weight"]).reshape(4 * C, C), act_dtype, device)
     o.b_fc1 = _f32(_np(sd[pre + ".mlp.0.bias"]), device)
@@ -88,6 +100,11 @@ def _pack_mlp(sd, pre, C, o, act_dtype, device):
     o.gn_w, o.gn_b = _f32(_np(sd[pre + ".gn.weight"]), device), _f32(_np(sd[pre + ".gn.bias"]), device)
     o.w1f = o.w2f = None
     o.w1p = o.b1p = o.w2p = None
+    o.w1g = o.w2g = None
+    if act_dtype == torch.bfloat16 and str(device) != "cpu" and C % 16 == 0 and SGP_GEMM:
+        # sgp_gemm.hip: plain MFMA fragments of the whole weight, k-steps padded to its chunk ring
+        o.w1g = pack_mfma_frags(_np(sd[pre + ".mlp.0.weight"]).reshape(4 * C, C), device, ks_mult=12)
+        o.w2g = pack_mfma_frags(_np(sd[pre + ".mlp.2.weight"]).reshape(C, 4 * C), device, ks_mult=12)
     if act_dtype == torch.bfloat16 and str(device) != "cpu" and C % 16 == 0 and 64 <= C <= 768:
         o.w1f, o.w2f = pack_mlp_frags(sd[pre + ".mlp.0.weight"], sd[pre + ".mlp.2.weight"], device)
         if C <= 384 and _sgp_mlp2_on():
@@ -441,6 +458,8 @@ def pack_sgp_mixer(sd, pre, C, act_dtype, device):
     o.up = _np(sd[pre + ".convkw1.weight"]).shape[-1]
     o.w_cat = _dense(_np(sd[pre + ".concat_fc.weight"]).reshape(C, 6 * C), act_dtype, device)
     o.b_cat = _f32(_np(sd[pre + ".concat_fc.bias"]), device)
+    o.wcg = (pack_mfma_frags(_np(sd[pre + ".concat_fc.weight"]).reshape(C, 6 * C), device, ks_mult=12)
+             if act_dtype == torch.bfloat16 and str(device) != "cpu" and C % 16 == 0 and SGP_GEMM else None)
     _pack_mlp(sd, pre, C, o, act_dtype, device)
     return o
 
@@ -496,6 +515,39 @@ class SgpBuilder:
         # widest feature dimension served by the fused MLP launch: covers RegNetY-800MF (C = 768: 46 -> 26 launches for the
         # stage, 1421 -> 1465 clips/s at B = 16)
         self.mlp_maxc = int(os.environ.get("TDEED_SGP_MLP_MAXC", "800"))
+        # round 5: the contractions on sgp_gemm.hip (full K per workgroup, no fp32 partials, no fold launches); `adt` is the
+        # type of the stage's residual stream -- fp32 under a bf16 trunk unless TDEED_SGP_F32_STREAM=0
+        self.gemm = SGP_GEMM and act_dtype == torch.bfloat16
+        # (the residual stream's type is the type of what the stage is handed: sgp_stream_dtype() for the model's plans)
+
+    def _mlp_gemm(self, name, y, o, Tn, chsum, pool_to=None):
+        """out = y + mlp(GN(y)) as two sgp_gemm launches; leaves the output's partial row sums on it (`_td_rowstat`) and, when
+        the following AdaptiveMaxPool1d halves the length, the pooled rows in `self.last_pooled`."""
+        pool, steps, B, C = self.pool, self.steps, self.B, o.C
+        R, adt = B * Tn, y.dtype
+        es = _esz(adt)
+        f1 = ops.sgp_gemm_form(0 if adt == torch.bfloat16 else 3, B, Tn, 4 * C, C)
+        f2 = ops.sgp_gemm_form(1, B, Tn, C, 4 * C)
+        nct = ops.sgp_gemm_tiles(Tn, C, f2)[1]
+        H = pool.take((B, Tn, 4 * C), torch.bfloat16)
+        outb = pool.take((B, Tn, C), adt)
+        rsp = torch.empty((nct, R, 2), dtype=torch.float32, device=y.device)          # lives as long as the plan (tiny)
+        pooled = rpp = None
+        if pool_to is not None and 2 * pool_to == Tn:
+            pooled = pool.take((B, pool_to, C), adt)
+            rpp = torch.empty((nct, B * pool_to, 2), dtype=torch.float32, device=y.device)
+            pooled._td_rowstat = rpp
+        self.last_pooled = pooled
+        steps.append(Step(name + ".fc1", "sgp_gemm", lambda: ops.sgp_gemm_gn_gelu(y, chsum, o.gn_w, o.gn_b, o.w1g, o.b_fc1, 4 * C,
+                                                                                out=H, form=f1),
+                          R * C * es + 4 * C * C * 2 + R * 4 * C * 2, 2 * R * 4 * C * C))
+        steps.append(Step(name + ".fc2", "sgp_gemm", lambda: ops.sgp_gemm_residual(H, o.w2g, o.b_fc2, y, out=outb, rowstat_part=rsp,
+                                                                                 pooled=pooled, rowstat_pool_part=rpp, form=f2),
+                          R * 4 * C * 2 + 4 * C * C * 2 + 2 * R * C * es + (0 if pooled is None else B * pool_to * C * es),
+                          2 * R * 4 * C * C))
+        pool.give(H)
+        outb._td_rowstat = rsp
+        return outb
 
     def dense(self, name, A, Wt, bias, act, out, R, residual=None):
         """One Conv1d(k=1) of the mlp / concat_fc.  Short sequences (bf16, <= splitk_rows rows) go through the split-K
@@ -563,6 +615,22 @@ class SgpBuilder:
         carry it, `self.last_pooled` holds the pooled tensor afterwards (else None: the caller adds a max-pool launch)."""
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
         self.last_pooled = None
+        if self.gemm and self.fused and str(xin.device) != "cpu" and getattr(o, "w1g", None) is not None:
+            adt = xin.dtype
+            es, R = _esz(adt), B * Tn
+            wl = 2 * o.ks + o.up + 2
+            y = pool.take((B, Tn, C), adt)
+            chs = pool.take((B, C, 2), torch.float32)
+            rs_in = getattr(xin, "_td_rowstat", None)
+            steps.append(Step(name + ".front", "sgp_front", lambda: ops.sgp_front(xin, o.ks, o.up, o.ln_w, o.ln_b, o.dw, o.db,
+                                                                                 out=y, chsum=chs, rowstat=rs_in),
+                              2 * R * C * es + C * (wl + 7) * 4, 2 * R * C * (wl + 3)))
+            outb = self._mlp_gemm(name, y, o, Tn, chs, pool_to=pool_to)
+            pool.give(y)
+            pool.give(chs)
+            if name in self.taps:
+                self.keep[name] = outb
+            return outb
         if self.fused and str(xin.device) != "cpu":
             y = pool.take((B, Tn, C), dt)
             outb = pool.take((B, Tn, C), dt)
@@ -603,6 +671,31 @@ class SgpBuilder:
 
     def mixer(self, xlo, T_lo, z, T_hi, o, name):
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
+        if self.gemm and self.fused and str(z.device) != "cpu" and getattr(o, "wcg", None) is not None:
+            adt = z.dtype
+            if xlo.dtype != adt:
+                raise TypeError("SgpBuilder.mixer: z and x_lo must share the residual stream's type")
+            es, R, Rl = _esz(adt), B * T_hi, B * T_lo
+            wl = 2 * o.ks + o.up + 2
+            cat = pool.take((B, T_hi, 6 * C), torch.bfloat16)
+            rs_z, rs_x = getattr(z, "_td_rowstat", None), getattr(xlo, "_td_rowstat", None)
+            steps.append(Step(name + ".front", "mixer_front",
+                              lambda: ops.mixer_front(z, xlo, cat, o.ks, o.up, o.ln1_w, o.ln1_b, o.ln2_w, o.ln2_b, o.dw1,
+                                                      o.db1, o.dw2, o.db2, rowstat_z=rs_z, rowstat_x=rs_x),
+                              (R + Rl) * C * es + 6 * R * C * 2 + 2 * C * (wl + 7) * 4, 4 * R * C * (wl + 3)))
+            fc = ops.sgp_gemm_form(2, B, T_hi, C, 6 * C)
+            NJ = ops.sgp_gemm_tiles(T_hi, C, fc)[0]
+            mo = pool.take((B, T_hi, C), adt)
+            chs = pool.take((NJ, B, C, 2), torch.float32)
+            steps.append(Step(name + ".cat", "sgp_gemm", lambda: ops.sgp_gemm_gelu_chsum(cat, o.wcg, o.b_cat, C, mo, chs, form=fc),
+                              R * 6 * C * 2 + 6 * C * C * 2 + R * C * es, 2 * R * 6 * C * C))
+            pool.give(cat)
+            outb = self._mlp_gemm(name, mo, o, T_hi, chs)
+            pool.give(mo)
+            pool.give(chs)
+            if name in self.taps:
+                self.keep[name] = outb
+            return outb
         if self.fused and str(z.device) != "cpu":
             cat = pool.take((B, T_hi, 6 * C), dt)
             mo = pool.take((B, T_hi, C), dt)
@@ -674,9 +767,9 @@ class SgpBuilder:
             stash.append(cur)
             pooled = self.last_pooled
             if pooled is None:
-                pooled = pool.take((B, lens[i + 1], C), dt)
+                pooled = pool.take((B, lens[i + 1], C), cur.dtype)
                 steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1]: ops.maxpool(a, L, out=b),
-                                  B * (lens[i] + lens[i + 1]) * C * _esz(dt)))
+                                  B * (lens[i] + lens[i + 1]) * C * _esz(cur.dtype)))
             cur = pooled
         cur = self.block(cur, lens[n], sgp[n], f"{pre}_sgp.{n}")
         for i in range(n):
@@ -1050,7 +1143,7 @@ class ForwardEngine:
             return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=None, pool_bytes=pool.total_bytes(), B=B, T=T,
                                    h=h, w=w)
         C = pw.spec.feat_dim
-        feat = pool.take((B, T, C), dt) if feat_out is None else feat_out
+        feat = pool.take((B, T, C), sgp_stream_dtype(dt, dev)) if feat_out is None else feat_out
         # LayerNorm statistics of the feature rows for the first SGP block's front kernel (the caller's slice of the shared
         # buffer when the temporal stage runs once for all sub-batches)
         frs = feat_rs if feat_rs is not None else torch.empty((N, 2), dtype=torch.float32, device=dev)
@@ -1093,7 +1186,8 @@ class ForwardEngine:
             head_out = torch.empty((B * T, self.pw.n_out), dtype=torch.float32, device=self.device)
             tail = None
             if self.merge_tail:
-                feat = torch.empty((B, T, self.pw.spec.feat_dim), dtype=self.act_dtype, device=self.device)
+                feat = torch.empty((B, T, self.pw.spec.feat_dim), dtype=sgp_stream_dtype(self.act_dtype, self.device),
+                                   device=self.device)
                 k = self.join_at
                 if k is not None and 0 < k < len(self.pw.W.blocks):
                     # the sub-batches split only the bandwidth-bound head of the trunk (blocks [0, k)); the latency-bound

@@ -385,7 +385,7 @@ def avgpool_posenc(x, B, T, temp_enc, out=None, rowstat=None):
     if out is None:
         out = torch.empty((B, T, C), dtype=x.dtype, device=x.device)
     call("tdeed_avgpool_posenc_fwd", ptr(x), B, T, h * w, C, ptr(temp_enc), ptr(out), ptr(rowstat), dtype_code(x.dtype),
-         stream_ptr())
+         dtype_code(out.dtype), stream_ptr())
     return out
 
 

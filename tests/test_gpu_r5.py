@@ -132,3 +132,76 @@ def test_sgp_gemm_concat_gelu_channel_sums(B, T, C, odt):
         s = chs.sum(0)
         assert float((s[..., 0] - of.sum(1)).abs().max()) < 1e-3 * T ** 0.5 * max(1.0, float(of.abs().max())), form
         assert float((s[..., 1] - (of * of).sum(1)).abs().max()) < 1e-3 * max(1.0, float((of * of).sum(1).max())), form
+
+
+# ------------------------------------------------------------------------------------------------ the stage on sgp_gemm
+def _run(steps):
+    for s_ in steps:
+        s_.fn()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("stream", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name", ["sgp_block_c32_t25", "sgp_block_c368_t100", "sgp_block_c48_t13"])
+def test_sgp_block_on_sgp_gemm_matches_the_reference(name, stream):
+    """SGPBlock.forward (modules.py:159-188) with bf16 contractions on sgp_gemm.hip, residual stream bf16 or fp32 (the
+    throughput mode), against the reference's output."""
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, _Pool
+    from helpers import module_state, act
+    meta, g = load_golden(name)
+    B, C, T = meta["B"], meta["C"], meta["T"]
+    sd = module_state("sgp_block", "blk", meta["seed"], **meta)
+    x = t(act(meta["seed"], name + ":x", (B, C, T)).transpose(0, 2, 1).copy()).to(stream).to(DEV)
+    steps, keep = [], {}
+    sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, torch.bfloat16)
+    assert sb.gemm
+    out = sb.block(x, T, pack_sgp_block(sd, "blk", C, torch.bfloat16, DEV), "blk")
+    assert any(s_.kernel == "sgp_gemm" for s_ in steps) and out.dtype == stream
+    _run(steps)
+    ref = t(g["y"]).permute(0, 2, 1)
+    tol = 4e-2 if stream == torch.bfloat16 else 2e-2
+    assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("stream", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name", ["sgp_mixer_c32_t25", "sgp_mixer_c368_t100"])
+def test_sgp_mixer_on_sgp_gemm_matches_the_reference(name, stream):
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_mixer, _Pool
+    from helpers import module_state, act
+    meta, g = load_golden(name)
+    B, C, Th, Tl = meta["B"], meta["C"], meta["T_hi"], meta["T_lo"]
+    sd = module_state("sgp_mixer", "mix", meta["seed"], **meta)
+    z = t(act(meta["seed"], name + ":z", (B, C, Th)).transpose(0, 2, 1).copy()).to(stream).to(DEV)
+    x = t(act(meta["seed"], name + ":x", (B, C, Tl)).transpose(0, 2, 1).copy()).to(stream).to(DEV)
+    steps, keep = [], {}
+    sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, torch.bfloat16)
+    out = sb.mixer(x, Tl, z, Th, pack_sgp_mixer(sd, "mix", C, torch.bfloat16, DEV), "mix")
+    assert sum(s_.kernel == "sgp_gemm" for s_ in steps) == 3 and out.dtype == stream
+    _run(steps)
+    ref = t(g["y"]).permute(0, 2, 1)
+    tol = 4e-2 if stream == torch.bfloat16 else 2e-2
+    assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("stream", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name", ["pyramid_c32_l25_n2", "pyramid_c64_l100_n3", "pyramid_c48_l250_n2"])
+def test_pyramid_on_sgp_gemm_matches_the_reference(name, stream):
+    """EDSGPMIXERLayers.forward (modules.py:69-87): even levels pool inside the fc2 launch, odd ones (25 -> 13, 125 -> 63)
+    through the max-pool launch + in-kernel LayerNorm statistics."""
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, pack_sgp_mixer, _Pool
+    from helpers import module_state, act
+    meta, g = load_golden(name)
+    B, C, L, n = meta["B"], meta["C"], meta["L"], meta["n"]
+    sd = module_state("pyramid", "_temp_fine", meta["seed"], **meta)
+    x = t(act(meta["seed"], name + ":x", (B, L, C))).to(stream).to(DEV)
+    sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, torch.bfloat16, DEV) for i in range(2 * n + 1)]
+    mix = [pack_sgp_mixer(sd, f"_temp_fine._sgpMixer.{i}", C, torch.bfloat16, DEV) for i in range(n)]
+    steps, keep = [], {}
+    sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, torch.bfloat16)
+    out = sb.pyramid(x, L, n, sgp, mix)
+    kinds = [s_.kernel for s_ in steps]
+    assert "sgp_mlp2" not in kinds and "gemm_splitk" not in kinds and kinds.count("sgp_gemm") == 2 * (2 * n + 1) + 3 * n
+    _run(steps)
+    ref = t(g["y"])
+    tol = 6e-2 if stream == torch.bfloat16 else 3e-2
+    assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))

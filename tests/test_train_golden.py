@@ -46,8 +46,9 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def _check_grads(grad_of, g, meta, tol_sel, tol_norm):
-    """selected tensors element-wise (sampled), every tensor through its norm and a fixed random projection"""
+def _check_grads(grad_of, g, meta, tol_sel, tol_norm, floor=1e-6):
+    """selected tensors element-wise (sampled), every tensor through its norm and a fixed random projection; floor: the
+    part of the WHOLE gradient's norm allowed on top (single-scalar biases are sums with heavy cancellation)"""
     names = meta["param_names"]
     gn = float(np.linalg.norm(g["grad_norm"]))
     for k in meta["keys"]:
@@ -55,13 +56,13 @@ def _check_grads(grad_of, g, meta, tol_sel, tol_norm):
         want = g["grad:" + k]
         assert got.shape == want.shape, k
         d = float(np.linalg.norm(got.astype(np.float64) - want))
-        assert d <= tol_sel * float(np.linalg.norm(want)) + 1e-6 * gn, (k, d, float(np.linalg.norm(want)))
+        assert d <= tol_sel * float(np.linalg.norm(want)) + floor * gn, (k, d, float(np.linalg.norm(want)))
     for i, k in enumerate(names):
         gk = grad_of(k).detach().cpu().double().numpy().reshape(-1)
-        assert abs(np.linalg.norm(gk) - g["grad_norm"][i]) <= tol_norm * g["grad_norm"][i] + 1e-6 * gn, k
+        assert abs(np.linalg.norm(gk) - g["grad_norm"][i]) <= tol_norm * g["grad_norm"][i] + floor * gn, k
         proj = synth.normalish(meta["proj_seed"], "proj:" + k, gk.size).astype(np.float64)
         # the projection of an n-vector has magnitude ~ |g| (unit-variance weights): compare on that scale
-        assert abs(float(gk @ proj) - g["grad_proj"][i]) <= tol_norm * g["grad_norm"][i] + 1e-6 * gn, k
+        assert abs(float(gk @ proj) - g["grad_proj"][i]) <= tol_norm * g["grad_norm"][i] + floor * gn, k
 
 
 def _check_bn(state, g, meta, tol):
@@ -195,7 +196,7 @@ def test_hip_train_steps_match_the_reference():
             assert float((pred["displ_feat"].cpu() - t(g["displ0"])).abs().max()) < 1e-3
             # per tensor within 2 % of its own norm (the bound tests/test_gpu_bwd.py holds the same engine to against autograd:
             # BatchNorm layers that see B*T*h*w = 32..8k samples at this size amplify fp32 summation-order differences)
-            _check_grads(lambda k: eng.params.grad_view(k), g, meta, tol_sel=2e-2, tol_norm=2e-2)
+            _check_grads(lambda k: eng.params.grad_view(k), g, meta, tol_sel=2e-2, tol_norm=2e-2, floor=2e-5)
         opt.step()
         sched.step()
         opt.zero_grad()
