@@ -80,13 +80,19 @@ __device__ __forceinline__ void ln_row_stats_load(const float* __restrict__ rows
 }
 
 // LayerNorm applied to the interior rows of a staged tile: tile[halo + t][c] = (x - mu[t]) / den[t] * w[c] + b[c]
-__device__ __forceinline__ void ln_apply_tile(float* tile, int T_len, int halo, const float* mu, const float* rs, float w,
-                                              float b, bool cok) {
+// -> the sum of the values this thread stored (rows tl, tl + 16, ...), rounded like a stored activation of type R
+template <typename R = float>
+__device__ __forceinline__ float ln_apply_tile(float* tile, int T_len, int halo, const float* mu, const float* rs, float w,
+                                               float b, bool cok) {
   const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  float s = 0.f;
   for (int t = tl; t < T_len; t += 16) {
     const float x = tile[(halo + t) * SGP_CH + c];
-    tile[(halo + t) * SGP_CH + c] = cok ? ((x - mu[t]) * rs[t] * w + b) : 0.f;
+    const float v = cok ? round_to<R>((x - mu[t]) * rs[t] * w + b) : 0.f;
+    tile[(halo + t) * SGP_CH + c] = v;
+    s += v;
   }
+  return s;
 }
 
 }  // namespace
@@ -119,48 +125,45 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
   const float lw = ln_w[min(c0 + c, C - 1)], lb = ln_b[min(c0 + c, C - 1)];
   if (rowstat) ln_row_stats_load(rowstat + (long)b * T_len * 2, rs_parts, (long)gridDim.x * T_len * 2, T_len, C, eps, mu, rs);
   else ln_row_stats<T>(x + base, C, T_len, C, eps, mu, rs);
-  tile_commit<T>(tv, T_len, c0, C, tile, halo);
+  tile_commit<T>(tv, T_len, c0, C, tile, halo, res);          // res starts as the raw rows: y = x + (branches) grows in place
   dw_commit(wv, wlen, c0, C, wl);
   __syncthreads();
-  ln_apply_tile(tile, T_len, halo, mu, rs, lw, lb, cok);
+  red[tl * SGP_CH + c] = ln_apply_tile(tile, T_len, halo, mu, rs, lw, lb, cok);      // + this thread's share of mean_T
   __syncthreads();
-  tile_mean(tile, T_len, halo, red);
-  const float mean_c = red[16 * SGP_CH + c];
+  const float mean_c = tile_mean_fold(red, c, T_len);
 #define FRONT_FAST(KS_, UP_)                                                                                   \
   branch_runs<KS_, UP_>(tile, wl, bb, cok, c, tl, T_len, halo, mean_c,                                         \
-                        [&](int t, const BranchOut& r, float o) { res[t * SGP_CH + c] = r.inst + r.conv_gate + o; });
+                        [&](int t, const BranchOut& r, float o) { res[t * SGP_CH + c] += r.inst + r.conv_gate + o; });
 #define FRONT_GENERIC                                                                                          \
   for (int t = tl; t < T_len; t += 16) {                                                                       \
     BranchOut r = branch_eval(tile, wl, bb, cok, t, c, halo, ks, up, mean_c);                                  \
-    res[t * SGP_CH + c] = r.inst + r.conv_gate + tile[(halo + t) * SGP_CH + c];                                \
+    res[t * SGP_CH + c] += r.inst + r.conv_gate + tile[(halo + t) * SGP_CH + c];                               \
   }
   SGP_BRANCH_DISPATCH(ks, up, FRONT_FAST, FRONT_GENERIC)
 #undef FRONT_FAST
 #undef FRONT_GENERIC
   __syncthreads();
-  store_tile<T>(res, y + base, C, 0, T_len, c0, C, x + base, C);
+  store_tile<T>(res, y + base, C, 0, T_len, c0, C, (const T*)nullptr, 0);
   if (chsum) {
     // per-channel sum and sum of squares over T of the stored y (what GroupNorm of the MLP half reads): the consumer
-    // then only folds 16 groups instead of re-reading the clip.  y = res + x, rounded like the store.
-    constexpr int EPC = Chunk<T>::N;
+    // then only folds 16 groups instead of re-reading the clip.  Rounded like the store.
     float s = 0.f, q = 0.f;
     if (cok)
       for (int t = tl; t < T_len; t += 16) {
-        const float v = round_to<T>(res[t * SGP_CH + c] + (float)x[base + (long)t * C + c0 + c]);
+        const float v = round_to<T>(res[t * SGP_CH + c]);
         s += v;
         q = fmaf(v, v, q);
       }
-    (void)EPC;
-    __syncthreads();
+    float* redq = tile;                 // [16][16] second scratch: the LayerNorm tile is dead behind the barrier above
     red[tl * SGP_CH + c] = s;
-    tile[tl * SGP_CH + c] = q;
+    redq[tl * SGP_CH + c] = q;
     __syncthreads();
     if (threadIdx.x < SGP_CH && c0 + (int)threadIdx.x < C) {
       float a = 0.f, bq = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         a += red[i * SGP_CH + threadIdx.x];
-        bq += tile[i * SGP_CH + threadIdx.x];
+        bq += redq[i * SGP_CH + threadIdx.x];
       }
       chsum[((long)b * C + c0 + threadIdx.x) * 2] = a;
       chsum[((long)b * C + c0 + threadIdx.x) * 2 + 1] = bq;
@@ -253,17 +256,15 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
       tile[row * SGP_CH + c_] = 0.f;
     }
   __syncthreads();
-  // the normalised sequences are tensors in the reference: round them like stored activations
+  // the normalised sequences are tensors in the reference: rounded like stored activations of the stream's type; each thread
+  // keeps the sum of the rows it produced (its share of mean_T, folded by every thread behind the next barrier)
   if (src == 0) {
-    ln_apply_tile(tile, T_hi, halo, mu, rs, lw, lb, cok);        // zn = LN1(z)
-    __syncthreads();
-    for (int t = tl; t < T_hi; t += 16) tile[(halo + t) * SGP_CH + c] = round_to<T>(tile[(halo + t) * SGP_CH + c]);
+    red[tl * SGP_CH + c] = ln_apply_tile<T>(tile, T_hi, halo, mu, rs, lw, lb, cok);        // zn = LN1(z)
   } else {
-    ln_apply_tile(res, T_lo, 0, mu, rs, lw, lb, cok);            // xn = LN2(x_lo), before the up-sampling (modules.py:287-288)
-    __syncthreads();
-    for (int t = tl; t < T_lo; t += 16) res[t * SGP_CH + c] = round_to<T>(res[t * SGP_CH + c]);
+    ln_apply_tile<T>(res, T_lo, 0, mu, rs, lw, lb, cok);         // xn = LN2(x_lo), before the up-sampling (modules.py:287-288)
     __syncthreads();
     const float scale = (T_hi > 1) ? (float)(T_lo - 1) / (float)(T_hi - 1) : 0.f;
+    float sacc = 0.f;
     for (int t = tl; t < T_hi; t += 16) {
       float v;
       if (T_hi == T_lo) {
@@ -276,14 +277,16 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
         const float l0 = 1.f - l1;
         v = l0 * res[i0 * SGP_CH + c] + l1 * res[i1 * SGP_CH + c];
       }
-      tile[(halo + t) * SGP_CH + c] = round_to<T>(v);
+      v = round_to<T>(v);
+      tile[(halo + t) * SGP_CH + c] = v;
+      sacc += v;
     }
+    red[tl * SGP_CH + c] = sacc;
   }
   __syncthreads();
   // slab 4 = zn, slab 5 = xu
   store_tile<TC>(tile + halo * SGP_CH, crow + (long)(4 + src) * C, ldc, 0, T_hi, c0, C, (const TC*)nullptr, 0);
-  tile_mean(tile, T_hi, halo, red);
-  const float mean_c = red[16 * SGP_CH + c];
+  const float mean_c = tile_mean_fold(red, c, T_hi);
 #define MIX_FAST(KS_, UP_)                                                                                     \
   branch_runs<KS_, UP_>(tile, wl, bb, cok, c, tl, T_hi, halo, mean_c, [&](int t, const BranchOut& r, float) {  \
     res[t * SGP_CH + c] = r.conv_gate;                                                                         \

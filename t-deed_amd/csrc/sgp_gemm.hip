@@ -25,6 +25,8 @@
 //     to whole super-iterations of 3 chunks (zero weights), so the steady state has no conditional load; K = C (12 k-steps at
 //     C = 368) is exactly one super-iteration: every load of the launch is issued before the first MFMA.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -165,45 +167,66 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bias + min(ft0 + nt, NFT - 1) * 16 + lq * 4);
 
-  // ---- MODE 0: GroupNorm scale / shift of this clip per input channel (fixed-order sums over the channel partials)
+  // ---- MODE 0: GroupNorm scale / shift of this clip per input channel (fixed-order sums over the channel partials).  Every
+  // global load of the prologue (the channel sums AND the affine) is requested before the first barrier: one round trip.
   if constexpr (MODE == 0) {
     const int Kp = p.KSP * 32;
     float* gs = red;                                      // [G][2] group (mean, rstd); red is re-used later
     float* cs = red + 64;                                 // [Kp][2]
-    for (int c = tid; c < p.K; c += 256) {
+    constexpr int CPT = 4;                                // channels per thread: K <= 1024
+    float gw_[CPT], gb_[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int c = min(tid + u * 256, p.K - 1);
       float s = 0.f, q = 0.f;
       for (int pt = 0; pt < p.chs_parts; ++pt) {
         const f32x2 v = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + c) * 2);
         s += v[0];
         q += v[1];
       }
-      cs[2 * c] = s;
-      cs[2 * c + 1] = q;
+      gw_[u] = p.gn_w[c];
+      gb_[u] = p.gn_b[c];
+      if (tid + u * 256 < p.K) {
+        cs[2 * c] = s;
+        cs[2 * c + 1] = q;
+      }
     }
     __syncthreads();
     const int cg = p.K / p.G;
-    if (tid < p.G) {
-      float s = 0.f, q = 0.f;
-      for (int c = 0; c < cg; ++c) {
-        s += cs[2 * (tid * cg + c)];
-        q += cs[2 * (tid * cg + c) + 1];
+    {
+      // 16 lanes per group walk its channels (G <= 16 groups per pass of 256 threads), one shuffle tree joins them
+      for (int g0 = 0; g0 < p.G; g0 += 16) {
+        const int g = min(g0 + (tid >> 4), p.G - 1), jj = tid & 15;
+        float s = 0.f, q = 0.f;
+        for (int c = jj; c < cg; c += 16) {
+          s += cs[2 * (g * cg + c)];
+          q += cs[2 * (g * cg + c) + 1];
+        }
+        s = sg_sum_r(s);
+        q = sg_sum_r(q);
+        if (jj == 0 && g0 + (tid >> 4) < p.G) {
+          const float n = (float)cg * (float)p.T;
+          const float mean = s / n;
+          const float var = fmaxf(q / n - mean * mean, 0.f);
+          gs[2 * g] = mean;
+          gs[2 * g + 1] = 1.0f / sqrtf(var + p.eps);
+        }
       }
-      const float n = (float)cg * (float)p.T;
-      const float mean = s / n;
-      const float var = fmaxf(q / n - mean * mean, 0.f);
-      gs[2 * tid] = mean;
-      gs[2 * tid + 1] = 1.0f / sqrtf(var + p.eps);
     }
     __syncthreads();
-    for (int c = tid; c < Kp; c += 256) {
-      float sc = 0.f, sh = 0.f;
-      if (c < p.K) {
-        const int g = c / cg;
-        sc = gs[2 * g + 1] * p.gn_w[c];
-        sh = fmaf(-gs[2 * g], sc, p.gn_b[c]);
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int c = tid + u * 256;
+      if (c < Kp) {
+        float sc = 0.f, sh = 0.f;
+        if (c < p.K) {
+          const int g = c / cg;
+          sc = gs[2 * g + 1] * gw_[u];
+          sh = fmaf(-gs[2 * g], sc, gb_[u]);
+        }
+        gtab[c] = sc;
+        gtab[Kp + c] = sh;
       }
-      gtab[c] = sc;
-      gtab[Kp + c] = sh;
     }
     __syncthreads();
   }
@@ -445,24 +468,38 @@ extern "C" int tdeed_sgp_gemm_ksteps(int K) { return ((K + 31) / 32 + 11) / 12 *
 extern "C" int tdeed_sgp_gemm_row_tiles(int T, int MT) { return (T + 16 * MT - 1) / (16 * MT); }
 extern "C" int tdeed_sgp_gemm_col_tiles(int N, int NT) { return (N + 64 * NT - 1) / (64 * NT); }
 
-// The tile form the launcher picks for (mode, B, T, N, K): enough workgroups for the 256 CUs (two resident per CU) at the fewest
-// bytes per CU.  mode 3 = mode 0 on fp32 rows.  Returns MT * 16 + NT.
+// The tile form the launcher picks for (mode, B, T, N, K): mode 0 / 3 = GroupNorm + fc1 + GELU on bf16 / fp32 rows, 1 = fc2 +
+// residual, 2 = concat_fc.  Returns MT * 16 + NT.  Rules from tools/bench_sgp_gemm.py on MI355X (kernel-trace durations):
+// small tiles win wherever the launch is latency bound (cfg2: every launch), because three or four resident workgroups per CU
+// hide each other's round trips; the wide models' T = 100 levels are bound by bytes per CU and take the tile with the fewest.
+// TDEED_SGP_FORM_<mode> = "MT,NT" overrides (experiments).
 extern "C" int tdeed_sgp_gemm_form(int mode, int B, int T, int N, int K) {
-  static const int forms[6][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
-  int best = -1;
-  double best_cost = 0;
-  for (int i = 0; i < 6; ++i) {
-    const int MT = forms[i][0], NT = forms[i][1];
-    if (mode == 3 && MT == 4 && NT == 2) continue;       // fp32 rows: the 64 x 128 tile's staging registers spill
-    const long nrt = (long)B * ((T + 16 * MT - 1) / (16 * MT)), nct = (N + 64 * NT - 1) / (64 * NT);
-    const long nwg = nrt * nct;
-    const double per_wg = (double)(16 * MT + 64 * NT) * K * 2.0;          // bytes one workgroup pulls through its CU
-    const double waves = (double)((nwg + 255) / 256);                     // rounds of workgroups over the CUs (1 per CU and round)
-    // time ~ bytes per CU (per-CU load path) + a fixed cost per round of workgroups (prologue + epilogue round trips)
-    const double cost = waves * (per_wg + 60e3);
-    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  static int ov[4] = {-1, -1, -1, -1};
+  static bool init = false;
+  if (!init) {
+    for (int m = 0; m < 4; ++m) {
+      char nm[32];
+      snprintf(nm, sizeof nm, "TDEED_SGP_FORM_%d", m);
+      const char* e = getenv(nm);
+      int a = 0, b = 0;
+      if (e && sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2)) ov[m] = a * 16 + b;
+    }
+    init = true;
   }
-  return forms[best][0] * 16 + forms[best][1];
+  if (mode >= 0 && mode < 4 && ov[mode] >= 0 && !(mode == 3 && ov[mode] == 4 * 16 + 2)) return ov[mode];
+  const long R = (long)B * T;
+  const bool wide = (mode == 0 || mode == 3 ? K : N) > 384;
+  int MT = 2, NT = 1;
+  if (mode == 0 || mode == 3) {
+    if (wide) { MT = (mode == 0 && T >= 50) ? 4 : 2; NT = 2; }
+    else { MT = 2; NT = 1; }
+  } else if (mode == 1) {
+    MT = (!wide && T < 64) ? 1 : 2; NT = 1;
+  } else {
+    if (wide) { MT = R >= 1200 ? 4 : 2; NT = 1; }
+    else { MT = T < 64 ? 1 : 2; NT = 1; }
+  }
+  return MT * 16 + NT;
 }
 
 // MODE 0: H = GELU(GroupNorm(y) . W^T + b); y [B*T][K] (dtype_a), chsum [parts][B][K][2], H bf16 [B*T][N]
@@ -470,7 +507,7 @@ extern "C" int tdeed_sgp_gemm_gn_gelu(const void* y, int B, int T, int K, const 
                                       const float* gn_b, int G, float eps, const void* Wp, const float* bias, int N, void* H,
                                       int form, int dtype_a, void* stream) {
   TD_CHECK(y && chsum && gn_w && gn_b && Wp && bias && H, "sgp_gemm_gn_gelu: null pointer");
-  TD_CHECK(B > 0 && T > 0 && K % 8 == 0 && N % 16 == 0 && G > 0 && K % G == 0 && G <= 32 && chs_parts > 0,
+  TD_CHECK(B > 0 && T > 0 && K % 8 == 0 && K <= 1024 && N % 16 == 0 && G > 0 && K % G == 0 && G <= 32 && chs_parts > 0,
            "sgp_gemm_gn_gelu: bad sizes");
   SgpGemmP p = {};
   const int MT = form >> 4, NT = form & 15;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void tile_issue(const T* __restrict__ src, long ld, i
 
 template <typename T>
 __device__ __forceinline__ void tile_commit(const float (&v)[SGP_TI][Chunk<T>::N], int T_len, int c0, int C,
-                                            float* tile, int halo) {
+                                            float* tile, int halo, float* raw = nullptr) {
   constexpr int EPC = Chunk<T>::N;
   constexpr int CPR = SGP_CH / EPC;
   const int n = T_len * CPR;
@@ -101,8 +101,21 @@ __device__ __forceinline__ void tile_commit(const float (&v)[SGP_TI][Chunk<T>::N
       const bool ok = c0 + ck * EPC < C;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) tile[(halo + t) * SGP_CH + ck * EPC + e] = ok ? v[u][e] : 0.f;
+      if (raw) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) raw[t * SGP_CH + ck * EPC + e] = ok ? v[u][e] : 0.f;
+      }
     }
   }
+}
+
+// mean over T of the tile per channel from the per-row-lane partial sums red[tl][c] (16 lanes): every thread folds the 16
+// partials of its channel itself, in a fixed order (no designated threads, no second barrier)
+__device__ __forceinline__ float tile_mean_fold(const float* red, int c, int T_len) {
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a += red[i * SGP_CH + c];
+  return a / (float)T_len;
 }
 
 __device__ __forceinline__ void dw_issue(const float* __restrict__ dw, int wlen, int c0, int C, float (&w)[SGP_WI]) {

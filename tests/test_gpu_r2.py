@@ -516,7 +516,7 @@ def test_fused_sgp_launches_match_the_launch_per_op_chain(C, T, B, n, monkeypatc
         a, b = outs["1"][0], outs["0"][0]
         assert outs["1"][1] < outs["0"][1]
         if dtype == torch.bfloat16:
-            assert any(k.startswith("sgp_mlp") for k in outs["1"][2])
+            assert any(k.startswith(("sgp_mlp", "sgp_gemm")) for k in outs["1"][2])
         tol = 1e-5 if dtype == torch.float32 else 4e-2
         assert max_abs(a, b) < tol * max(1.0, float(b.abs().max())), (dtype, max_abs(a, b), float(b.abs().max()))
 
