@@ -634,6 +634,25 @@ def train_measure(workload, dtype, steps, warmup, repeats, rank, world, dev, use
             rec["roofline_family"] = train_family_roofline(eng, workload, frames, lab, labD, masks, dt)
         except Exception as e:       # noqa: BLE001  (a side measurement must not take the line down)
             rec["roofline_family"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    if eng.reducer is not None and world > 1:
+        # ---- self-diagnosis of the data-parallel step (every rank takes part): the same step with the reduction replaced by
+        # a no-op gives the communication the backward does NOT hide; each bucket's collective alone gives what there is to hide
+        step_nr = eng.make_step(B, H, W, frames, lab, labD, masks, use_graph=use_graph, world=world, all_reduce=lambda g: None)
+        for _ in range(2):
+            step_nr()
+
+        def run_nr(n):
+            for _ in range(n):
+                step_nr()
+        walls_nr, _ = timed_regions(run_nr, steps, max(2, repeats - 1), dev, [st])
+        ms_nr = statistics.median(walls_nr) / steps * 1e3
+        buckets = eng.reducer.measure()
+        comm = sum(b_["ms"] for b_ in buckets)
+        rec["dp_diag"] = dict(step_ms=round(ms, 3), step_ms_no_reduce=round(ms_nr, 3), exposed_comm_ms=round(ms - ms_nr, 3),
+                              comm_alone_ms=round(comm, 3), hidden_frac=(round(1.0 - max(ms - ms_nr, 0.0) / comm, 3) if comm > 0 else None),
+                              buckets=buckets,
+                              note="exposed = step with the bucketed reduction - the same step with a no-op reduction; "
+                                   "comm_alone = each bucket's collective on an idle device (GradReducer.measure)")
     if eng.reducer is not None:                                  # N > 1: which transport reduced the gradients, ranks RCCL saw
         rec["reducer"] = eng.reducer.describe()
         rec["reducer"]["rccl_ranks_expected"] = world
@@ -768,6 +787,8 @@ def main_train(a):
                    roofline=rec["roofline"], cpu_baseline=rec["cpu_baseline"], git_head=git_head())
         if "reducer" in rec:
             out["config"]["reducer"] = rec["reducer"]
+        if "dp_diag" in rec:
+            out["dp_diag"] = rec["dp_diag"]
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
@@ -964,6 +985,11 @@ def main():
             out["infer_800mf"] = infer_sub_record("rny008_b16", 50, 3, depth, rank, dev, TRAFFIC_FILE_800MF, streams=streams)
         except Exception as e:           # noqa: BLE001  (the headline line must still be printed)
             out["infer_800mf"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+        # ... and of the long-clip configuration (BASELINE configs[4] per-GPU share: 800MF, T = 250, B = 4)
+        try:
+            out["infer_snb_t250"] = infer_sub_record("snb_t250_b4", 40, 3, depth, rank, dev, None, streams=streams)
+        except Exception as e:           # noqa: BLE001
+            out["infer_snb_t250"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         # driver-visible training-step records: BASELINE configs[2] (800MF, B=16) and the 200MF geometry of the headline
         tr = {}
         for wk, st_ in (("rny008_b16", 6), ("rny002_b8", 10)):

@@ -214,6 +214,33 @@ class GradReducer:
         for i in range(len(self.buckets)):
             self.reduce_bucket(i)
 
+    def measure(self, reps=3):
+        """Self-diagnosis of a data-parallel run (bench.py --mode train, N > 1): each bucket's collective ALONE on an
+        otherwise idle device / process group -- median wall ms over `reps` (sync, enqueue, join, sync), the bus bandwidth it
+        implies for a ring (2 (N-1)/N x bytes / time) -- so that an 8-GPU line shows at once whether a bucket runs at xGMI
+        rates and how much of it the backward has to hide.  The buffer's VALUES are summed `reps` times over the ranks: call it
+        on gradients nobody needs any more (the bench does, after its timed regions).  All ranks must call it together."""
+        import statistics
+        import time
+        sync = torch.cuda.synchronize if self.flat.is_cuda else (lambda: None)
+        out = []
+        for i, (lo, hi) in enumerate(self.buckets):
+            pl = self.plan(i) if self.world > 1 else dict(collective="none")
+            ts = []
+            for _ in range(reps):
+                sync()
+                barrier()
+                t0 = time.perf_counter()
+                self.reduce_bucket(i)
+                self.join()
+                sync()
+                ts.append(time.perf_counter() - t0)
+            ms = statistics.median(ts) * 1e3
+            nbytes = (hi - lo) * self.flat.element_size()
+            out.append(dict(bucket=i, collective=pl["collective"], mb=round(nbytes / 2 ** 20, 2), ms=round(ms, 4),
+                            busbw_GBps=round(2 * (self.world - 1) / max(self.world, 1) * nbytes / max(ms, 1e-9) / 1e6, 2)))
+        return out
+
     def join(self):
         if self._comm is not None:
             self._comm.join()

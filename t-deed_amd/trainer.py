@@ -486,15 +486,19 @@ class TrainEngine:
         self.opt.step(lr_factor=lr_factor, grad_scale=gs)       # the next replay starts with repack(): no refresh needed here
         return h.loss
 
-    def make_step(self, B, H, W, frames, label, labelD=None, drop_masks=None, use_graph=True, world=1):
+    def make_step(self, B, H, W, frames, label, labelD=None, drop_masks=None, use_graph=True, world=1, all_reduce=None):
         """A zero-argument callable running one optimisation step on the given (static) batch: through the captured HIP graph
-        or eagerly; for world > 1 the flat gradient buffer is all-reduced (RCCL) before AdamW."""
-        ar = None
+        or eagerly; for world > 1 the flat gradient buffer is all-reduced (RCCL) before AdamW.  all_reduce: a callable
+        (flat_grad) replacing the bucketed reduction (the bench's "no communication" arm passes a no-op)."""
+        ar = all_reduce
         if world > 1 and self.reducer is None:
             self.set_reducer("auto")
         if not use_graph:
             return lambda: self.step(frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
-        hnd = self.build_graph(B, H, W)
+        hnd = getattr(self, "last_graph", None)
+        if hnd is None or getattr(hnd, "geom", None) != (B, H, W):
+            hnd = self.build_graph(B, H, W)
+            hnd.geom = (B, H, W)
         self.last_graph = hnd                                    # (tests / the bench line read .mode)
         return lambda: self.step_graph(hnd, frames, label, labelD, drop_masks=drop_masks, all_reduce=ar)
 

@@ -79,6 +79,38 @@ def _reducer_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _measure_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    tdist.init(backend="gloo")
+    flat = torch.ones(4096, dtype=torch.float32)
+    red = tdist.GradReducer(flat, [(1024, 4096), (0, 1024)], rs_ag_min_bytes=8192)
+    m = red.measure(reps=2)
+    q.put((rank, m, float(flat[0]), float(flat[-1])))
+    tdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_self_diagnosis_times_every_bucket_on_two_ranks():
+    """GradReducer.measure (what `bench.py --mode train --gpus N` prints as dp_diag.buckets): per bucket the collective it
+    goes out as, its size, a positive time and the bus bandwidth that implies; every rank runs the same collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_measure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, m, first, last in res:
+        assert [b["bucket"] for b in m] == [0, 1]
+        assert m[0]["collective"] == "rs_ag" and m[1]["collective"] == "all_reduce"      # 12 KB >= 8 KB, 4 KB below
+        assert m[0]["mb"] == round(3072 * 4 / 2 ** 20, 2) and all(b["ms"] > 0 and b["busbw_GBps"] > 0 for b in m)
+        assert first == 4.0 and last == 4.0          # two repetitions of a sum over two ranks: 1 -> 2 -> 4 in both buckets
+
+
 def test_bucketed_grad_reducer_sums_every_bucket_over_two_ranks():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

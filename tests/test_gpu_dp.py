@@ -155,3 +155,6 @@ def test_bench_runs_as_two_ranks_on_one_gpu(mode):
     if mode == "train":
         red = rec["config"]["reducer"]
         assert red["world"] == 2 and len(red["buckets_mb"]) == 2 and "between the two captured halves" in red["collectives"]
+        dg = rec["dp_diag"]          # the self-diagnosis of an N > 1 training line
+        assert len(dg["buckets"]) == 2 and all(b["ms"] > 0 for b in dg["buckets"]) and dg["step_ms_no_reduce"] > 0
+        assert abs(dg["exposed_comm_ms"] - (dg["step_ms"] - dg["step_ms_no_reduce"])) < 1e-2
