@@ -262,19 +262,14 @@ int tdeed_sgp_branch_fwd(const void* o, const void* x, int B, int T, int C, int 
 int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int ks, int up,
                            const float* dw1, const float* db1, const float* dw2,
                            const float* db2, void* cat, int dtype, void* stream);
-/* ---- fused SGP launches (sgp_fused.hip): a block = sgp_front + sgp_mlp, a mixer = mixer_front + concat_fc + sgp_mlp.
+/* ---- fused SGP launches (sgp_fused.hip): a block = sgp_front + two contractions, a mixer = mixer_front + three.
  * sgp_front:   y = x + LN(x) + fc*phi + (convw+convkw)*psi   (modules.py:159-184; LayerNorm 320-363 computed in-kernel)
  * mixer_front: cat [B][T_hi][6C] = (out1,out2,out3,out4,LN1(z),up(LN2(x_lo)))   (modules.py:286-308)
- * sgp_mlp (bf16): out = y + mlp(GroupNorm16(y)), mlp = Conv1d(C,4C,1) -> GELU(erf) -> Conv1d(4C,C,1)   (modules.py:186,316);
- *              W1 / W2 bf16 in MFMA fragment order, each [4][C/16][ceil(C/32)][64][8]: chunk c (C hidden units), 16-row tile
- *              t, k-step s, lane l, element j  =  W1[c*C + 16t + (l&15)][32s + 8(l>>4) + j]  resp.
- *              W2[16t + (l&15)][c*C + 32s + 8(l>>4) + j], zero where the k index passes C (tdeed_amd.engine.pack_mlp_frags);
- *              biases / GroupNorm affine fp32.  tdeed_sgp_mlp_fits tells whether the geometry (R = B*T rows) is served;
- *              callers otherwise use groupnorm + two tdeed_gemm_fwd. */
+ * (out = y + mlp(GroupNorm16(y)) and concat_fc: tdeed_sgp_gemm_* below, csrc/sgp_gemm.hip) */
 /* chsum (optional, fp32 [B][C][2]): per clip and channel the sum and sum of squares over T of the stored y, which
- * tdeed_sgp_mlp_fwd takes instead of re-reading the clip for its GroupNorm statistics */
-/* rowstat* (optional, fp32 [rows][2] = LayerNorm mean, rstd of every input row, as tdeed_sgp_mlp2_fwd leaves them for the
- * rows it writes): taken instead of re-deriving the statistics from the clip's (T x C) slab */
+ * tdeed_sgp_gemm_gn_gelu takes for its GroupNorm statistics */
+/* rowstat* (optional, fp32 [rows][2] = LayerNorm mean, rstd of every input row, as tdeed_avgpool_posenc_fwd leaves them):
+ * taken instead of re-deriving the statistics from the clip's (T x C) slab */
 /* rowstat*_parts: 0 = the (mean, rstd) form above; n > 0 = [n][rows][2] partial (sum, sum of squares) of each row over the n
  * column tiles of the tdeed_sgp_gemm_residual launch that stored the rows (summed in order; mean / rstd derived here).
  * dtype_cat (mixer): the six slabs may be stored as bf16 while z / x_lo are fp32 (fp32 residual stream, bf16 contraction). */
@@ -286,40 +281,6 @@ int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T
                           const float* dw1, const float* db1, const float* dw2, const float* db2, void* cat,
                           const float* rowstat_z, int rowstat_z_parts, const float* rowstat_x, int rowstat_x_parts,
                           int dtype, int dtype_cat, void* stream);
-int tdeed_sgp_mlp_fits(int R, int T, int C, int G);
-/* hidden-chunk split S of the launch (1, 2 or 4); for S > 1 `partial` must hold S*R*C floats (fp32 partials, folded in a
- * fixed order by a second launch) */
-int tdeed_sgp_mlp_splits(int R, int C);
-int tdeed_sgp_mlp_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
-                      const void* W1, const float* b1, const void* W2, const float* b2, void* out, float* partial,
-                      const float* chsum /* optional, see tdeed_sgp_front_fwd */, void* stream);
-/* sgp_mlp2 (sgp_mlp2.hip, bf16, C <= 384): the same out = y + mlp(GroupNorm16(y)) (modules.py:186, 316) cut into
- * R/64 row tiles x S = ceil(4C/128) slices of 128 hidden units, so that a few hundred rows still spread the weight stream
- * over ~150 workgroups; every workgroup issues all its loads up front.  W1p bf16 [S*8][12][64][8]: hidden tile h, k-step
- * s, lane l, element j = W1[16h + (l&15)][32s + 8(l>>4) + j]; W2p bf16 [S][C/16][4][64][8]: slice q, output tile t, k-step
- * s = W2[16t + (l&15)][128q + 32s + 8(l>>4) + j]; zeros past C resp. 4C; b1p fp32 [S*128] zero padded
- * (tdeed_amd.engine.pack_mlp2_frags).  partial: fp32 scratch [S][R][C]; chsum REQUIRED (tdeed_sgp_front_fwd's);
- * rowstat (optional output, fp32 [R][2]): LayerNorm mean / rstd (eps ln_eps) over C of every stored output row.
- * T_pool > 0 (T/2 <= T_pool <= T): the fold also applies the AdaptiveMaxPool1d(T_pool) that follows an encoder block
- * (modules.py:64, 75-77): pooled (R/T, T_pool, C) bf16 and rowstat_pool [R/T*T_pool][2] (optional) come out of the same
- * launch. */
-int tdeed_sgp_mlp2_slices(int C);
-/* fold of a split-K contraction organised by (clip, 16 channels): out = bf16(act(sum_s partial[s] + bias)) and chsum
- * [B][C][2] = per-channel (sum, sum of squares) over T of the stored values -- the mixer's concat_fc + GELU
- * (modules.py:308-309) feeding tdeed_sgp_mlp2_fwd.  partial: [S][B*T][C] fp32 from tdeed_gemm_splitk_partials. */
-int tdeed_sgp_fold_cols(const float* partial, int S, int B, int T, int C, const float* bias, int act, void* out,
-                        float* chsum, void* stream);
-int tdeed_sgp_mlp2_fits(int R, int T, int C, int G);
-/* diagnostic build of the sgp_mlp2 main kernel with in-kernel phase stamps (tools/stamp_sgp_mlp2.py): stamps
- * [R/rows * S][8] u64 = s_memtime at start / loads issued / statistics / A tile staged / fc1 done / first partial store /
- * stores landed, [7] = s_memrealtime at start.  Not part of the product path. */
-int tdeed_sgp_mlp2_stamped(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
-                           const void* W1p, const float* b1p, const void* W2p, float* partial, const float* chsum,
-                           unsigned long long* stamps, int rows, int dbg, void* stream);
-int tdeed_sgp_mlp2_fwd(const void* y, int R, int T, int C, int G, const float* gn_w, const float* gn_b, float eps,
-                       const void* W1p, const float* b1p, const void* W2p, const float* b2, void* out, float* partial,
-                       const float* chsum, float* rowstat, float ln_eps, int T_pool, void* pooled, float* rowstat_pool,
-                       void* stream);
 /* nn.GroupNorm(G, C) over (C/G x T) per clip (modules.py:115,186): x,y [B][T][C]. */
 int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* w, const float* b,
                         float eps, void* y, int dtype, void* stream);

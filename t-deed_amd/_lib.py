@@ -150,16 +150,7 @@ _SIGS = {
     "tdeed_sgp_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int, c_int, P], c_int),
     "tdeed_mixer_front_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int, P,
                                c_int, c_int, c_int, P], c_int),
-    "tdeed_sgp_mlp2_slices": ([c_int], c_int),
-    "tdeed_sgp_mlp2_stamped": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, c_int, c_int, P], c_int),
-    "tdeed_sgp_fold_cols": ([P, c_int, c_int, c_int, c_int, P, c_int, P, P, P], c_int),
     "tdeed_gemm_splitk_partials": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P], c_int),
-    "tdeed_sgp_mlp2_fits": ([c_int, c_int, c_int, c_int], c_int),
-    "tdeed_sgp_mlp2_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, P, P, c_float, c_int, P, P, P],
-                           c_int),
-    "tdeed_sgp_mlp_fits": ([c_int, c_int, c_int, c_int], c_int),
-    "tdeed_sgp_mlp_splits": ([c_int, c_int], c_int),
-    "tdeed_sgp_mlp_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P, P, P], c_int),
     "tdeed_groupnorm_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, c_int, P], c_int),
     "tdeed_maxpool_fwd": ([P, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_heads_fwd": ([P, c_int, c_int, P, P, c_int, P, c_int, P], c_int),

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libtdeed_hip.so")
-SOURCES = ["gemm.hip", "conv.hip", "front.hip", "gsf.hip", "sgp.hip", "sgp_fused.hip", "sgp_mlp2.hip", "sgp_gemm.hip", "bneck.hip", "sgp_bwd.hip", "trunk_bwd.hip", "trunk_bwd2.hip", "trunk_bwd3.hip", "gsf_bwd.hip", "train.hip", "misc.hip", "augment.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "conv.hip", "front.hip", "gsf.hip", "sgp.hip", "sgp_fused.hip", "sgp_gemm.hip", "bneck.hip", "sgp_bwd.hip", "trunk_bwd.hip", "trunk_bwd2.hip", "trunk_bwd3.hip", "gsf_bwd.hip", "train.hip", "misc.hip", "augment.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall",
          "-Wno-unused-function"]
 # MFMA accumulators in VGPRs instead of AGPRs for the files whose epilogues are VALU-bound: every accumulator element

@@ -75,11 +75,6 @@ def _dwpack(sd, pre, names, C, device):
     return _f32(np.concatenate(ws, axis=1), device), _f32(np.stack(bs, axis=0), device)
 
 
-# narrow-C form of the fused GroupNorm + MLP launch (sgp_mlp2.hip): row tiles x 128-unit hidden slices
-def _sgp_mlp2_on():
-    return os.environ.get("TDEED_SGP_MLP2", "1") == "1"
-
-
 SGP_GEMM = os.environ.get("TDEED_SGP_GEMM", "1") == "1"             # the SGP contractions on sgp_gemm.hip (round 5)
 # its residual stream (block / mixer inputs and outputs, the stash) in fp32 under a bf16 trunk, like the reference's autocast
 SGP_F32_STREAM = os.environ.get("TDEED_SGP_F32_STREAM", "1") == "1"
@@ -98,18 +93,11 @@ def _pack_mlp(sd, pre, C, o, act_dtype, device):
     o.w_fc2 = _dense(_np(sd[pre + ".mlp.2.weight"]).reshape(C, 4 * C), act_dtype, device)
     o.b_fc2 = _f32(_np(sd[pre + ".mlp.2.bias"]), device)
     o.gn_w, o.gn_b = _f32(_np(sd[pre + ".gn.weight"]), device), _f32(_np(sd[pre + ".gn.bias"]), device)
-    o.w1f = o.w2f = None
-    o.w1p = o.b1p = o.w2p = None
     o.w1g = o.w2g = None
     if act_dtype == torch.bfloat16 and str(device) != "cpu" and C % 16 == 0 and SGP_GEMM:
         # sgp_gemm.hip: plain MFMA fragments of the whole weight, k-steps padded to its chunk ring
         o.w1g = pack_mfma_frags(_np(sd[pre + ".mlp.0.weight"]).reshape(4 * C, C), device, ks_mult=12)
         o.w2g = pack_mfma_frags(_np(sd[pre + ".mlp.2.weight"]).reshape(C, 4 * C), device, ks_mult=12)
-    if act_dtype == torch.bfloat16 and str(device) != "cpu" and C % 16 == 0 and 64 <= C <= 768:
-        o.w1f, o.w2f = pack_mlp_frags(sd[pre + ".mlp.0.weight"], sd[pre + ".mlp.2.weight"], device)
-        if C <= 384 and _sgp_mlp2_on():
-            o.w1p, o.b1p, o.w2p = pack_mlp2_frags(sd[pre + ".mlp.0.weight"], sd[pre + ".mlp.0.bias"],
-                                                  sd[pre + ".mlp.2.weight"], device)
 
 
 def pack_ws_weights(W, act_dtype, device):
@@ -131,49 +119,6 @@ def pack_ws_weights(W, act_dtype, device):
     fr = Wp.reshape(NT, 16, KS, 4, epc).transpose(0, 2, 3, 1, 4)          # [NT][KS][q][n][epc]
     fr = np.ascontiguousarray(fr).reshape(NT, KS, 64, epc)
     return torch.from_numpy(fr).to(device).to(act_dtype).contiguous()
-
-
-def pack_mlp_frags(w1, w2, device):
-    """mlp.0.weight (4C,C) and mlp.2.weight (C,4C) -> bf16 MFMA A-operand fragments for sgp_mlp_kernel, each
-    [4][C/16][ceil(C/32)][64][8]: chunk c of C hidden units, 16-row tile t, k-step s, lane l holds row l&15 and
-    k = 32s + 8(l>>4) + j (zero past C), so that a wave's fragment load is 1 KB of consecutive bytes."""
-    w1, w2 = _np(w1).astype(np.float32), _np(w2).astype(np.float32)
-    C = w1.shape[1]
-    w1, w2 = w1.reshape(4 * C, C), w2.reshape(C, 4 * C)
-    nt, KS = C // 16, (C + 31) // 32
-    KP = KS * 32
-    a = np.zeros((4, C, KP), np.float32)
-    a[:, :, :C] = w1.reshape(4, C, C)                                   # [chunk][hidden unit][k]
-    b = np.zeros((4, C, KP), np.float32)
-    b[:, :, :C] = w2.reshape(C, 4, C).transpose(1, 0, 2)                # [chunk][out feature][k within chunk]
-
-    def frag(x):
-        fr = x.reshape(4, nt, 16, KS, 4, 8).transpose(0, 1, 3, 4, 2, 5)     # [c][t][s][q][n][j]
-        return torch.from_numpy(np.ascontiguousarray(fr).reshape(4, nt, KS, 64, 8)).to(device).to(torch.bfloat16).contiguous()
-    return frag(a), frag(b)
-
-
-def pack_mlp2_frags(w1, b1, w2, device):
-    """mlp.0.weight (4C,C), mlp.0.bias (4C), mlp.2.weight (C,4C) -> operands of sgp_mlp2_kernel (C <= 384): the hidden
-    dimension is cut into S = ceil(4C/128) slices of 8 tiles of 16 units.  W1p bf16 [S*8][12][64][8]: hidden tile h,
-    k-step s, lane l, element j = W1[16h + (l&15)][32s + 8(l>>4) + j]; b1p fp32 [S*128]; W2p bf16 [S][C/16][4][64][8]: slice
-    q, output tile t, k-step s = W2[16t + (l&15)][128q + 32s + 8(l>>4) + j]; zero where an index passes C resp. 4C."""
-    w1, b1, w2 = _np(w1).astype(np.float32), _np(b1).astype(np.float32), _np(w2).astype(np.float32)
-    C = w1.shape[1]
-    H = 4 * C
-    w1, w2 = w1.reshape(H, C), w2.reshape(C, H)
-    S = (H + 127) // 128
-    HP, KP, nto = S * 128, 384, C // 16
-    a = np.zeros((HP, KP), np.float32)
-    a[:H, :C] = w1
-    fr1 = a.reshape(S * 8, 16, 12, 4, 8).transpose(0, 2, 3, 1, 4)            # [h][s][q][n][j]
-    b = np.zeros((C, HP), np.float32)
-    b[:, :H] = w2
-    fr2 = b.reshape(nto, 16, S, 4, 4, 8).transpose(2, 0, 3, 4, 1, 5)         # [slice][t][s][q][n][j]
-    bp = np.zeros(HP, np.float32)
-    bp[:H] = b1
-    t_ = lambda x, shp: torch.from_numpy(np.ascontiguousarray(x).reshape(shp)).to(device).to(torch.bfloat16).contiguous()  # noqa: E731
-    return t_(fr1, (S * 8, 12, 64, 8)), torch.from_numpy(bp).to(device), t_(fr2, (S, nto, 4, 64, 8))
 
 
 def pack_se_bf16(fc1_w, fc2_w, device):
@@ -512,9 +457,6 @@ class SgpBuilder:
         # fused launches (sgp_fused.hip): LayerNorm inside the branch kernels (both dtypes), GroupNorm + fc1 + GELU + fc2 +
         # residual in one MFMA launch (bf16).  TDEED_SGP_FUSED=0 restores the launch-per-op chain (A/B measurements).
         self.fused = os.environ.get("TDEED_SGP_FUSED", "1") == "1"
-        # widest feature dimension served by the fused MLP launch: covers RegNetY-800MF (C = 768: 46 -> 26 launches for the
-        # stage, 1421 -> 1465 clips/s at B = 16)
-        self.mlp_maxc = int(os.environ.get("TDEED_SGP_MLP_MAXC", "800"))
         # round 5: the contractions on sgp_gemm.hip (full K per workgroup, no fp32 partials, no fold launches); `adt` is the
         # type of the stage's residual stream -- fp32 under a bf16 trunk unless TDEED_SGP_F32_STREAM=0
         self.gemm = SGP_GEMM and act_dtype == torch.bfloat16
@@ -565,43 +507,11 @@ class SgpBuilder:
             self.steps.append(Step(name, "gemm", lambda: ops.gemm(A, Wt, None, bias, act, residual=residual, out=out, M=R),
                                    *gemm_cost(R, K, N, es, residual is not None)))
 
-    def _mlp(self, name, y, o, outb, Tn, chsum=None, pool_to=None):
-        """out = y + mlp(GN(y)): one launch where sgp_mlp serves the geometry, else groupnorm + two contractions."""
+    def _mlp(self, name, y, o, outb, Tn):
+        """out = y + mlp(GN(y)) as groupnorm + two contractions (fp32 mode and TDEED_SGP_GEMM=0; the bf16 path is _mlp_gemm)."""
         pool, steps, B, C, dt = self.pool, self.steps, self.B, o.C, self.dt
         es, R = _esz(dt), B * Tn
-        self.last_rowstat = None
         self.last_pooled = None
-        # narrow feature dimension (C <= 384) with the producer's per-channel sums at hand: row tiles x hidden slices, and
-        # the fold leaves the LayerNorm statistics of the output rows for whichever front kernel reads them next
-        if (self.fused and dt == torch.bfloat16 and str(y.device) != "cpu" and chsum is not None
-                and getattr(o, "w1p", None) is not None and ops.sgp_mlp2_fits(R, Tn, C)):
-            ws = pool.take((ops.sgp_mlp2_slices(C), R, C), torch.float32)
-            rst = torch.empty((R, 2), dtype=torch.float32, device=y.device)       # lives as long as the plan (tiny)
-            pooled = rsp = None
-            if pool_to is not None and 2 * pool_to >= Tn:
-                # the AdaptiveMaxPool1d behind an encoder block rides on the fold launch
-                pooled = pool.take((B, pool_to, C), dt)
-                rsp = torch.empty((B * pool_to, 2), dtype=torch.float32, device=y.device)
-                pooled._td_rowstat = rsp
-                self.last_pooled = pooled
-            steps.append(Step(name + ".mlp", "sgp_mlp2", lambda: ops.sgp_mlp2(y, o.gn_w, o.gn_b, o.w1p, o.b1p, o.w2p, o.b_fc2,
-                                                                            chsum, out=outb, partial=ws, rowstat=rst,
-                                                                            pooled=pooled, rowstat_pool=rsp),
-                              2 * R * C * es + 8 * C * C * es + (0 if pooled is None else B * pool_to * C * es),
-                              2 * R * 8 * C * C))
-            pool.give(ws)
-            self.last_rowstat = rst
-            return
-        # every workgroup of the fused launch streams all 16*C*C bytes of W1 and W2 through its CU (~16 us at C=368, ~70 us
-        # at C=768): beyond mlp_maxc the tiled contractions, which spread the weights over many CUs, win
-        if (self.fused and dt == torch.bfloat16 and str(y.device) != "cpu" and C <= self.mlp_maxc and o.w1f is not None
-                and ops.sgp_mlp_fits(R, Tn, C)):
-            ws = pool.take((4, R, C), torch.float32)          # partials of the hidden-split form (S <= 4)
-            steps.append(Step(name + ".mlp", "sgp_mlp", lambda: ops.sgp_mlp(y, o.gn_w, o.gn_b, o.w1f, o.b_fc1, o.w2f,
-                                                                          o.b_fc2, out=outb, partial=ws, chsum=chsum),
-                              2 * R * C * es + 8 * C * C * es, 2 * R * 8 * C * C))
-            pool.give(ws)
-            return
         gn = pool.take((B, Tn, C), dt)
         hid = pool.take((B, Tn, 4 * C), dt)
         steps.append(Step(name + ".gn", "groupnorm", lambda: ops.groupnorm(y, 16, o.gn_w, o.gn_b, out=gn), 2 * R * C * es))
@@ -636,17 +546,12 @@ class SgpBuilder:
             outb = pool.take((B, Tn, C), dt)
             es, R = _esz(dt), B * Tn
             wl = 2 * o.ks + o.up + 2
-            chs = pool.take((B, C, 2), torch.float32) if dt == torch.bfloat16 else None
-            rs_in = getattr(xin, "_td_rowstat", None)          # LayerNorm statistics left by the producer of xin (sgp_mlp2)
+            rs_in = getattr(xin, "_td_rowstat", None)          # LayerNorm statistics left by the producer of xin (avgpool_posenc)
             steps.append(Step(name + ".front", "sgp_front", lambda: ops.sgp_front(xin, o.ks, o.up, o.ln_w, o.ln_b, o.dw, o.db,
-                                                                                 out=y, chsum=chs, rowstat=rs_in),
+                                                                                 out=y, rowstat=rs_in),
                               2 * R * C * es + C * (wl + 7) * 4, 2 * R * C * (wl + 3)))
-            self._mlp(name, y, o, outb, Tn, chsum=chs, pool_to=pool_to)
-            if self.last_rowstat is not None:
-                outb._td_rowstat = self.last_rowstat
+            self._mlp(name, y, o, outb, Tn)
             pool.give(y)
-            if chs is not None:
-                pool.give(chs)
             if name in self.taps:
                 self.keep[name] = outb
             return outb
@@ -707,24 +612,8 @@ class SgpBuilder:
                               lambda: ops.mixer_front(z, xlo, cat, o.ks, o.up, o.ln1_w, o.ln1_b, o.ln2_w, o.ln2_b, o.dw1,
                                                       o.db1, o.dw2, o.db2, rowstat_z=rs_z, rowstat_x=rs_x),
                               (7 * R + Rl) * C * es + 2 * C * (wl + 7) * 4, 4 * R * C * (wl + 3)))
-            K6 = 6 * C
-            if (dt == torch.bfloat16 and getattr(o, "w1p", None) is not None and ops.sgp_mlp2_fits(R, T_hi, C)
-                    and R <= self.splitk_rows and ops.gemm_splitk_splits(K6) >= 4):
-                # concat_fc as split-K partials folded per (clip, 16 channels): GELU, the bf16 rows and the per-channel
-                # sums that let the narrow MLP form (sgp_mlp2) take the GroupNorm statistics without a pass of its own
-                ws = pool.take((ops.gemm_splitk_splits(K6), R, C), torch.float32)
-                chs = pool.take((B, C, 2), torch.float32)
-                steps.append(Step(name + ".cat", "gemm_splitk",
-                                  lambda: ops.gemm_splitk_fold_cols(cat, o.w_cat, o.b_cat, ops.ACT_GELU, B, T_hi, mo, chs,
-                                                                    workspace=ws), *gemm_cost(R, K6, C, es)))
-                pool.give(ws)
-                self._mlp(name, mo, o, outb, T_hi, chsum=chs)
-                pool.give(chs)
-            else:
-                self.dense(name + ".cat", cat, o.w_cat, o.b_cat, ops.ACT_GELU, mo, R)
-                self._mlp(name, mo, o, outb, T_hi)
-            if self.last_rowstat is not None:
-                outb._td_rowstat = self.last_rowstat
+            self.dense(name + ".cat", cat, o.w_cat, o.b_cat, ops.ACT_GELU, mo, R)
+            self._mlp(name, mo, o, outb, T_hi)
             pool.give(cat)
             pool.give(mo)
             if name in self.taps:

@@ -261,21 +261,6 @@ def gemm_splitk(A, W, scale, shift, act=ACT_NONE, residual=None, out=None, M=Non
     return out
 
 
-def gemm_splitk_fold_cols(A, W, bias, act, B, T, out, chsum, workspace=None):
-    """The same split-K contraction with the fold organised by (clip, 16 channels): out (B,T,N) = act(A . W^T + bias) and
-    chsum (B, N, 2) = per-channel sum / sum of squares over T of the stored out (for the GroupNorm of sgp_mlp2)."""
-    _chk(A, "A", torch.bfloat16)
-    _chk(W, "W", torch.bfloat16)
-    N, K = W.shape
-    M = B * T
-    if workspace is None:
-        workspace = gemm_splitk_workspace(M, K, N, A.device)
-    call("tdeed_gemm_splitk_partials", ptr(A), K, M, K, N, ptr(W), K, ptr(workspace), stream_ptr())
-    call("tdeed_sgp_fold_cols", ptr(workspace), gemm_splitk_splits(K), B, T, N, ptr(bias), act, ptr(out), ptr(chsum),
-         stream_ptr())
-    return out
-
-
 def se_gate_mfma_fits(C, R):
     return _lib.load().tdeed_se_gate_mfma_fits(C, R) != 0
 
@@ -422,8 +407,9 @@ def _rs_parts(rowstat):
 
 def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None, rowstat=None):
     """SGPBlock front half with the LayerNorm computed in-kernel: y = x + LN(x) + fc*phi + (convw+convkw)*psi.
-    chsum: optional fp32 (B, C, 2) output, per-channel sum / sum of squares over T of y (for sgp_mlp's GroupNorm);
-    rowstat: optional fp32 (B*T, 2) input, LayerNorm mean / rstd of every row of x (left by sgp_mlp2 for its output)."""
+    chsum: optional fp32 (B, C, 2) output, per-channel sum / sum of squares over T of y (for sgp_gemm_gn_gelu's GroupNorm);
+    rowstat: optional fp32 (B*T, 2) input, LayerNorm statistics of every row of x: (mean, rstd) as avgpool_posenc leaves them, or (n, B*T, 2) partial (sum, sum of
+    squares) per column tile as sgp_gemm_residual does."""
     B, T, C = x.shape
     if out is None:
         out = torch.empty_like(x)
@@ -441,56 +427,6 @@ def mixer_front(z, xlo, cat, ks, up, ln1_w, ln1_b, ln2_w, ln2_b, dw1, db1, dw2, 
          ptr(ln2_b), eps, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(cat), ptr(rowstat_z), _rs_parts(rowstat_z),
          ptr(rowstat_x), _rs_parts(rowstat_x), dtype_code(z.dtype), dtype_code(cat.dtype), stream_ptr())
     return cat
-
-
-def sgp_mlp2_fits(R, T, C, G=16):
-    return bool(_lib.load().tdeed_sgp_mlp2_fits(R, T, C, G))
-
-
-def sgp_mlp2_slices(C):
-    return int(_lib.load().tdeed_sgp_mlp2_slices(C))
-
-
-def sgp_mlp2(y, gn_w, gn_b, W1p, b1p, W2p, b2, chsum, G=16, eps=1e-5, out=None, partial=None, rowstat=None, ln_eps=1e-5,
-             pooled=None, rowstat_pool=None):
-    """out = y + fc2(GELU(fc1(GroupNorm(y)))) for C <= 384 (bf16), row tiles x 128-unit hidden slices + a row-wise fold
-    that also leaves the LayerNorm statistics of the output rows in `rowstat` (fp32 (B*T, 2), optional).  W1p / b1p / W2p:
-    engine.pack_mlp2_frags; chsum: sgp_front's per-channel sums of y; partial: fp32 scratch (sgp_mlp2_slices(C), B*T, C).
-    pooled (B, T_pool, C): also the AdaptiveMaxPool1d(T_pool) of the output (+ its LayerNorm statistics in rowstat_pool)."""
-    _chk(y, "y", torch.bfloat16); _chk(W1p, "W1p", torch.bfloat16); _chk(W2p, "W2p", torch.bfloat16)
-    B, T, C = y.shape
-    if out is None:
-        out = torch.empty_like(y)
-    if partial is None:
-        partial = torch.empty((sgp_mlp2_slices(C), B * T, C), dtype=torch.float32, device=y.device)
-    call("tdeed_sgp_mlp2_fwd", ptr(y), B * T, T, C, G, ptr(gn_w), ptr(gn_b), eps, ptr(W1p), ptr(b1p), ptr(W2p), ptr(b2),
-         ptr(out), ptr(partial), ptr(chsum), ptr(rowstat), ln_eps, 0 if pooled is None else pooled.shape[1], ptr(pooled),
-         ptr(rowstat_pool), stream_ptr())
-    return out
-
-
-def sgp_mlp_fits(R, T, C, G=16):
-    return bool(_lib.load().tdeed_sgp_mlp_fits(R, T, C, G))
-
-
-def sgp_mlp_partial_shape(R, C):
-    """fp32 scratch (S, R, C) of the hidden-split form of sgp_mlp (S = 1: none needed)."""
-    return (_lib.load().tdeed_sgp_mlp_splits(R, C), R, C)
-
-
-def sgp_mlp(y, gn_w, gn_b, W1, b1, W2, b2, G=16, eps=1e-5, out=None, partial=None, chsum=None):
-    """out = y + fc2(GELU(fc1(GroupNorm(y)))) (bf16): one launch, or hidden-split partials + a fold launch at small row
-    counts.  y (B,T,C); W1 / W2: engine.pack_mlp_frags(...) fragments; partial: fp32 scratch of sgp_mlp_partial_shape
-    (allocated if None)."""
-    _chk(y, "y", torch.bfloat16); _chk(W1, "W1", torch.bfloat16); _chk(W2, "W2", torch.bfloat16)
-    B, T, C = y.shape
-    if out is None:
-        out = torch.empty_like(y)
-    if partial is None:
-        partial = torch.empty((4, B * T, C), dtype=torch.float32, device=y.device)
-    call("tdeed_sgp_mlp_fwd", ptr(y), B * T, T, C, G, ptr(gn_w), ptr(gn_b), eps, ptr(W1), ptr(b1), ptr(W2), ptr(b2),
-         ptr(out), ptr(partial), ptr(chsum), stream_ptr())
-    return out
 
 
 def groupnorm(x, G, w, b, eps=1e-5, out=None):

@@ -206,87 +206,6 @@ def test_apply_reduces_gradients_that_were_accumulated_without_reduce():
         assert b.reducer.calls == [0, 1, "join"]                    # reduced inside the backward, not a second time
 
 
-# ------------------------------------------------------------------------------------ SGP stage, round-3 kernels
-@pytest.mark.parametrize("B,T,C,pool", [(8, 100, 368, 50), (3, 25, 368, 13), (2, 125, 128, 63), (4, 50, 368, None), (5, 13, 256, 7)])
-def test_sgp_mlp2_with_carrying_folds_matches_the_reference_arithmetic(B, T, C, pool):
-    """sgp_mlp2 (row tiles x hidden slices) + its fold against plain torch on the SAME bf16 operands:
-    out = y + fc2(GELU(fc1(GroupNorm16(y)))) (modules.py:186), the AdaptiveMaxPool1d of the output (modules.py:64, 75-77; odd
-    lengths = overlapping windows), and the LayerNorm statistics (modules.py:353-357) the fold hands to the next front kernel,
-    for full-resolution and pooled rows."""
-    from tdeed_amd import ops
-    from tdeed_amd.engine import pack_mlp2_frags
-    torch.manual_seed(B * 1000 + T)
-    y = (torch.randn(B, T, C) * 1.5).to(torch.bfloat16)
-    w1 = torch.randn(4 * C, C) / C ** 0.5
-    b1 = torch.randn(4 * C) * 0.1
-    w2 = torch.randn(C, 4 * C) / (4 * C) ** 0.5
-    b2 = torch.randn(C) * 0.1
-    gw, gb = torch.rand(C) + 0.5, torch.randn(C) * 0.1
-    assert ops.sgp_mlp2_fits(B * T, T, C)
-    w1p, b1p, w2p = pack_mlp2_frags(w1.numpy(), b1.numpy(), w2.numpy(), DEV)
-    yd = y.to(DEV)
-    yf = yd.float()
-    chs = torch.stack([yf.sum(1), (yf * yf).sum(1)], -1).contiguous()
-    out = torch.empty_like(yd)
-    rst = torch.empty((B * T, 2), device=DEV)
-    pooled = torch.empty((B, pool, C), dtype=torch.bfloat16, device=DEV) if pool else None
-    rsp = torch.empty((B * pool, 2), device=DEV) if pool else None
-    ops.sgp_mlp2(yd, gw.to(DEV), gb.to(DEV), w1p, b1p, w2p, b2.to(DEV), chs, out=out, rowstat=rst, pooled=pooled,
-                 rowstat_pool=rsp)
-    torch.cuda.synchronize()
-    # reference in fp32 on the bf16-rounded operands, rounding where the kernel rounds (GN output, hidden tile)
-    yr = y.float()
-    gn = torch.nn.functional.group_norm(yr.transpose(1, 2), 16, gw, gb, 1e-5).transpose(1, 2)
-    gn = gn.to(torch.bfloat16).float()
-    hid = torch.nn.functional.gelu(gn @ w1.to(torch.bfloat16).float().t() + b1).to(torch.bfloat16).float()
-    ref = yr + hid @ w2.to(torch.bfloat16).float().t() + b2
-    got = out.float().cpu()
-    scale = float(ref.abs().max())
-    assert float((got - ref).abs().max()) < 2e-2 * scale                       # bf16 output rounding + GELU approximation
-    assert float((got - ref).pow(2).mean().sqrt()) < 3e-3 * scale
-    # LayerNorm statistics of the STORED rows
-    g2 = got.view(B * T, C)
-    mean, var = g2.mean(1), g2.var(1, unbiased=False)
-    assert torch.allclose(rst[:, 0].cpu(), mean, atol=2e-5 * max(1.0, scale), rtol=1e-4)
-    assert torch.allclose(rst[:, 1].cpu(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-4)
-    if pool:
-        pref = torch.nn.functional.adaptive_max_pool1d(got.transpose(1, 2), pool).transpose(1, 2)
-        assert torch.equal(pooled.float().cpu(), pref)                          # max of the stored values: exact
-        p2 = pref.reshape(B * pool, C)
-        assert torch.allclose(rsp[:, 0].cpu(), p2.mean(1), atol=2e-5 * max(1.0, scale), rtol=1e-4)
-        assert torch.allclose(rsp[:, 1].cpu(), 1.0 / torch.sqrt(p2.var(1, unbiased=False) + 1e-5), rtol=2e-4)
-    # bit-reproducible (fixed-order folds, no atomics)
-    out2 = torch.empty_like(yd)
-    ops.sgp_mlp2(yd, gw.to(DEV), gb.to(DEV), w1p, b1p, w2p, b2.to(DEV), chs, out=out2)
-    torch.cuda.synchronize()
-    assert torch.equal(out, out2)
-
-
-def test_concat_fc_fold_per_clip_and_channels():
-    """gemm_splitk_partials + sgp_fold_cols (the mixer's concat_fc + GELU, modules.py:308-309) = the ordinary split-K
-    contraction to bf16 rounding (the two choose their own number of K slices, so the fp32 sums associate differently),
-    plus the per-channel sums of the stored output that the next GroupNorm takes."""
-    from tdeed_amd import ops
-    B, T, C = 4, 50, 368
-    torch.manual_seed(7)
-    cat = (torch.randn(B, T, 6 * C) * 0.7).to(torch.bfloat16).to(DEV)
-    w = (torch.randn(C, 6 * C) / (6 * C) ** 0.5).to(torch.bfloat16).to(DEV)
-    bias = (torch.randn(C) * 0.1).to(DEV)
-    ref = ops.gemm_splitk(cat, w, None, bias, ops.ACT_GELU, M=B * T)
-    out = torch.empty((B, T, C), dtype=torch.bfloat16, device=DEV)
-    chs = torch.empty((B, C, 2), device=DEV)
-    ops.gemm_splitk_fold_cols(cat, w, bias, ops.ACT_GELU, B, T, out, chs)
-    torch.cuda.synchronize()
-    d = (out.view(B * T, C).float() - ref.view(B * T, C).float()).abs()
-    assert float(d.max()) <= 2 ** -7 * float(ref.float().abs().max())          # one bf16 ulp at the largest magnitude
-    assert float((d > 0).float().mean()) < 0.05                                 # and only where a rounding boundary is crossed
-    exact = torch.nn.functional.gelu(cat.float().view(B * T, -1) @ w.float().t() + bias)
-    assert float((out.view(B * T, C).float() - exact).abs().max()) < 2e-2 * float(exact.abs().max())
-    of = out.float()
-    assert torch.allclose(chs[..., 0], of.sum(1), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(chs[..., 1], (of * of).sum(1), rtol=1e-5, atol=1e-3)
-
-
 @pytest.mark.parametrize("M,K,N,hw", [(70000 - 70000 % 196, 320, 320, 196), (60025, 320, 768, 49), (61152, 368, 368, 49)])
 def test_sliced_weight_stationary_contraction_of_the_wide_layers(M, K, N, hw):
     """gemm_ws with W cut into equal column slices (8 waves per workgroup; what engine.DenseW picks for the 320-wide layers of
