@@ -218,6 +218,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   __syncthreads();
   BN_STAMP(2);
 
+  bf16x8 sew1[KS];                                       // SE fc1 fragments of this wave's first hidden tile (requested inside P2)
   // ---- P2: conv2 grouped 3x3 from y1 (taps outside the map read the zero row) -> y2 in region A; squeeze sums per frame
   {
     const int NU = NT;
@@ -255,8 +256,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     }
     // the weights of ALL of this wave's units are requested up front (the first came with conv1): a unit is ~1.3 k cycles of
     // work, far less than an L2 round trip, so a one-ahead prefetch would expose one round trip per unit
-    constexpr int MAXU = 3;
-    bf16x8 (&wf)[5] = wf2;
+    constexpr int MAXU = KS <= 8 ? 2 : 3;          // units per wave: C <= 256 has at most 16 units over the 8 waves
     bf16x8 wfx[MAXU - 1][5];
 #pragma unroll
     for (int j = 1; j < MAXU; ++j) {
@@ -264,9 +264,11 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) wfx[j - 1][ks] = p.w2f[((long)U * 5 + ks) * 64 + lane];
     }
-    int ju = 0;
     BN_STAMP(8);
-    for (int U = wv; U < NU; U += BNK_NW, ++ju) {
+    // one unit: this wave's ju-th 16-channel group with the weights wfu (all requested above / with conv1)
+    auto unit = [&](int ju, const bf16x8 (&wfu)[5]) {
+      const int U = wv + ju * BNK_NW;
+      if (U >= NU) return;
       const int ch0 = U * 16 + 4 * q;
       const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 2 * CP + ch0), sh = *reinterpret_cast<const f32x4*>(bnv + 3 * CP + ch0);
       float psum[FPW][4];
@@ -288,14 +290,14 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
 #pragma unroll
           for (int pt = HA; pt < NPTM; ++pt) yf[pt] = *reinterpret_cast<const bf16x8*>(bu + toff[pt][ks]);
 #pragma unroll
-          for (int pt = 0; pt < HA; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yf[pt], acc[pt], 0, 0, 0);
+          for (int pt = 0; pt < HA; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfu[ks], yf[pt], acc[pt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (ks + 1 < 5) {
 #pragma unroll
             for (int pt = 0; pt < HA; ++pt) yf[pt] = *reinterpret_cast<const bf16x8*>(bu + toff[pt][ks + 1]);
           }
 #pragma unroll
-          for (int pt = HA; pt < NPTM; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yf[pt], acc[pt], 0, 0, 0);
+          for (int pt = HA; pt < NPTM; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfu[ks], yf[pt], acc[pt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -322,9 +324,25 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
           const float v = bnk_row16_sum(psum[f][r]);
           if (pl == 0 && ch0 + r < C) pooled[f * C + ch0 + r] = v;
         }
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) wf[ks] = ju == 0 ? wfx[0][ks] : wfx[MAXU - 2][ks];
       BN_STAMP(9 + ju);
+    };
+    // The SE excitation's first fc1 tile (KS fragments) is requested in front of the wave's LAST unit slot: by then the other
+    // units' weights are dead registers, and the L2 round trip that used to open the SE phase (7.4 k of its 18.7 k cycles at
+    // 7 x 7 x 368, tools/bench_bneck.py) travels under a unit's MFMAs instead.
+    auto se_prefetch = [&]() {
+      const int KS1 = (C + 31) >> 5, RT = (p.se.R + 15) >> 4;
+      const int tc = min(wv, RT - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) sew1[ks] = p.se.w1f[((long)tc * KS1 + min(ks, KS1 - 1)) * 64 + lane];
+    };
+    unit(0, wf2);
+    if constexpr (MAXU == 2) {
+      se_prefetch();
+      unit(1, wfx[0]);
+    } else {
+      unit(1, wfx[0]);
+      se_prefetch();
+      unit(2, wfx[MAXU - 2]);
     }
   }
   __syncthreads();
@@ -339,7 +357,8 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   {
     SeP se = p.se;
     se.pooled = pooled; se.n_parts = 1; se.inv_cnt = 1.0f / (float)hw; se.C = C; se.gate_out = nullptr;
-    se_excite_lds<KS, 3, true, BNK_NW>(se, 0, nfr, nfr - 1, gtab, C, Bt);
+    se_excite_lds<KS, 3, true, BNK_NW, true>(se, 0, nfr, nfr - 1, gtab, C, Bt, p.dbg ? p.dbg + (long)blockIdx.x * 16 + 12 : nullptr,
+                                             &sew1);
     const int cpr = C >> 3;
     const IDiv dcpr(cpr);
     for (int i = tid; i < npix * cpr; i += BNK_THR) {

@@ -28,9 +28,20 @@ __host__ __device__ inline int se_excite_scratch_bytes(int C, int R) {
 // gates of frames [f_first, f_first + nf) (nf <= 16, frames beyond f_last clamp to it) -> gtab[f][ldg] (LDS, fp32).
 // All NW * 64 threads of the workgroup call it; it ends with a barrier (gtab and scratch are then free to read / reuse).
 // se.pooled may point into LDS (generic address).
-template <int KS1M, int KS2M, bool EARLY = true, int NW = 4>
+// stamps (diagnostic, tools/bench_bneck.py): thread 0 leaves clock64() behind the means / hidden / gate stages in stamps[0..2]
+// PRE: the fc1 fragments of this wave's first hidden tile were requested by the caller (*w1pre), earlier than this call.
+// The barriers fence LDS only: the weight fragments requested here stay in flight across them (a __syncthreads() drains
+// vmcnt, i.e. waited for the fc2 fragments two stages before they are used).
+#define SE_LDS_BARRIER()                                               \
+  do {                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");    \
+    __builtin_amdgcn_s_barrier();                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");    \
+  } while (0)
+template <int KS1M, int KS2M, bool EARLY = true, int NW = 4, bool PRE = false>
 __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int nf, long f_last, float* gtab, int ldg,
-                                              unsigned char* scratch) {
+                                              unsigned char* scratch, long long* stamps = nullptr,
+                                              const bf16x8 (*w1pre)[KS1M] = nullptr) {
   const int C = se.C, R = se.R;
   const int KS1 = (C + 31) >> 5, RT = (R + 15) >> 4, CT = (C + 15) >> 4, KS2 = (R + 31) >> 5;
   const int PS1 = KS1 * 32 + 8, PS2 = KS2 * 32 + 8;
@@ -41,7 +52,10 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
   // fc1 fragments of this wave's first hidden tile: requested before anything else
   bf16x8 w1r[KS1M];
-  if constexpr (EARLY) {
+  if constexpr (PRE) {
+#pragma unroll
+    for (int ks = 0; ks < KS1M; ++ks) w1r[ks] = (*w1pre)[ks];
+  } else if constexpr (EARLY) {
     const int tc = min(wv, RT - 1);
 #pragma unroll
     for (int ks = 0; ks < KS1M; ++ks) w1r[ks] = se.w1f[((long)tc * KS1 + min(ks, KS1 - 1)) * 64 + lane];
@@ -93,13 +107,14 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
     *reinterpret_cast<bf16x4*>(Plo + f * PS1 + c) = lo;
   }
   for (int i = tid; i < 2 * 16 * PS2 / 8; i += NW * 64) reinterpret_cast<u32x4*>(Hhi)[i] = (u32x4){0u, 0u, 0u, 0u};
-  __syncthreads();
+  SE_LDS_BARRIER();
+  if (stamps && tid == 0) stamps[0] = clock64();
   // ---- hidden units: tiles wv, wv + NW, ...
 #pragma unroll
   for (int j1 = 0; j1 < MAXT1; ++j1) {
     const int tile = wv + j1 * NW;
     if (tile >= RT) break;
-    if (!EARLY || tile != wv) {
+    if (!(EARLY || PRE) || tile != wv) {
 #pragma unroll
       for (int ks = 0; ks < KS1M; ++ks) w1r[ks] = se.w1f[((long)tile * KS1 + min(ks, KS1 - 1)) * 64 + lane];
     }
@@ -121,7 +136,8 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
       Hlo[pl * PS2 + r] = (bf16_t)(hv - (float)hi);
     }
   }
-  __syncthreads();
+  SE_LDS_BARRIER();
+  if (stamps && tid == 0) stamps[1] = clock64();
   // ---- gates: channel tiles wv, wv + NW, ...
 #pragma unroll
   for (int j = 0; j < MAXT2; ++j) {
@@ -152,5 +168,6 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
       if (se.gate_out && f_first + pl <= f_last) *reinterpret_cast<f32x4*>(se.gate_out + (f_first + pl) * (long)C + c0) = g;
     }
   }
-  __syncthreads();
+  SE_LDS_BARRIER();
+  if (stamps && tid == 0) stamps[2] = clock64();
 }

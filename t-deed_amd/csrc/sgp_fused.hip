@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
   float* res = tile + (T_len + 2 * halo) * SGP_CH;    // [T][16]
   float* wl = res + T_len * SGP_CH;                   // [wlen][16]
   float* red = wl + wlen * SGP_CH;                    // [17][16]
-  float* mu = red + 17 * SGP_CH;                      // [T]
+  float* redq = red + 17 * SGP_CH;                    // [16][16] (a region of its own: the tile is only T + 2 halo rows)
+  float* mu = redq + 16 * SGP_CH;                     // [T]
   float* rs = mu + T_len;                             // [T]
   const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH;
   const long base = (long)b * T_len * C;
@@ -155,7 +156,6 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
         s += v;
         q = fmaf(v, v, q);
       }
-    float* redq = tile;                 // [16][16] second scratch: the LayerNorm tile is dead behind the barrier above
     red[tl * SGP_CH + c] = s;
     redq[tl * SGP_CH + c] = q;
     __syncthreads();
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
 
 static size_t front_smem(int T_len, int ks, int up, int ntiles, int nres, int nstat) {
   const int halo = up / 2, wlen = 2 * ks + up + 2;
-  return (size_t)(ntiles * (T_len + 2 * halo) * SGP_CH + nres * T_len * SGP_CH + ntiles * wlen * SGP_CH + 17 * SGP_CH +
+  return (size_t)(ntiles * (T_len + 2 * halo) * SGP_CH + nres * T_len * SGP_CH + ntiles * wlen * SGP_CH + 33 * SGP_CH +
                   nstat * 2 * T_len) * sizeof(float);
 }
 
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void mixer_front_kernel(const T* __restrict__ 
   float* res = tile + trows * SGP_CH;          // [T_hi][16] (holds xn [T_lo][16] during the up-sampling)
   float* res2 = res + T_hi * SGP_CH;           // [T_hi][16]
   float* wl = res2 + T_hi * SGP_CH;
-  float* red = wl + wlen * SGP_CH;             // [17][16]
-  float* mu = red + 17 * SGP_CH;               // [T_hi]
+  float* red = wl + wlen * SGP_CH;             // [17][16] (+ [16][16] the block kernel uses: one layout, front_smem)
+  float* mu = red + 33 * SGP_CH;               // [T_hi]
   float* rs = mu + T_hi;
   const int b = blockIdx.x, c0 = blockIdx.y * SGP_CH, src = blockIdx.z;
   const long ldc = 6L * C;

@@ -205,3 +205,26 @@ def test_pyramid_on_sgp_gemm_matches_the_reference(name, stream):
     ref = t(g["y"])
     tol = 6e-2 if stream == torch.bfloat16 else 3e-2
     assert max_abs(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("T", [4, 2, 6])
+def test_tiny_clips_through_the_stage(T):
+    """clip_len 4 / 2 / 6: levels of 2 and 1 rows (tiles far below 16 rows, T + 2 halo < 16 rows of LDS tile): the bf16 stage
+    with the fp32 stream tracks the fp32 launch-per-op chain (regression: the front kernels' second reduction scratch
+    overlapped their result tile for T + 2 halo < 16)."""
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, pack_sgp_mixer, _Pool
+    from helpers import module_state, act
+    B, C, n = 2, 368, 2 if T >= 4 else 1
+    sd = module_state("pyramid", "_temp_fine", 5, C=C, ks=5, r=2, n=n)
+    x = t(act(9, "x", (B, T, C)))
+    outs = []
+    for wdt, sdt in ((torch.float32, torch.float32), (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)):
+        sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, wdt, DEV) for i in range(2 * n + 1)]
+        mix = [pack_sgp_mixer(sd, f"_temp_fine._sgpMixer.{i}", C, wdt, DEV) for i in range(n)]
+        steps, keep = [], {}
+        sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, wdt)
+        out = sb.pyramid(x.to(sdt).to(DEV), T, n, sgp, mix)
+        _run(steps)
+        outs.append(out.float().cpu())
+    scale = max(1.0, float(outs[0].abs().max()))
+    assert max_abs(outs[1], outs[0]) < 3e-2 * scale and max_abs(outs[2], outs[0]) < 6e-2 * scale

@@ -80,6 +80,9 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
     print("   conv2 of wave 0, cycles: tap offsets + weight requests %s, units %s"
           % ("%.0f" % sub[0] if sub[0] is not None else "-", ", ".join("%.0f" % v for v in sub[1:] if v is not None)))
     d = d[(d[:, 0] > 0) & (d[:, 6] > 0)]            # rows of workgroups that ran (the row count above is an upper bound)
+    # slots 12..14: inside the SE phase (stamp 3 = its start, 4 = its end): means staged, hidden units done, gates done
+    se = [np.median(d[:, 12] - d[:, 3]), np.median(d[:, 13] - d[:, 12]), np.median(d[:, 14] - d[:, 13]), np.median(d[:, 4] - d[:, 14])]
+    print("   SE phase, cycles: weights requested + means staged %.0f, hidden units %.0f, gates %.0f, y2 *= gate pass %.0f" % tuple(se))
     ph = np.diff(d[:, :7], axis=1) / 100.0          # clock64 ticks (shader clock, ~2.4 GHz) / 100
     # clock64 is a per-XCD counter: a span across workgroups means something only while the eight counters agree
     sp = (d[:, 6].max() - d[:, 0].min()) / 100.0
