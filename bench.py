@@ -43,9 +43,9 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {torch.bfloat16: 2500.0, torch.float32: 157.3}
-TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
-TRAFFIC_FILE_800MF = os.path.join("profiles", "r04_hbm_traffic_800mf_b16.json")
-TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r04_train_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
+TRAFFIC_FILE_800MF = os.path.join("profiles", "r05_hbm_traffic_800mf_b16.json")
+TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r05_train_hbm_traffic.json")
 # C-ABI entry -> kernel family of tools/summarize_pmc.py (what the counter passes are keyed by)
 TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
 
@@ -239,7 +239,10 @@ def dominant_roofline(prof, dt, traffic_file):
     return roof
 
 
-def sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt):
+SGP_FAMILIES = ("sgp_gemm", "sgp_front", "mixer_front", "maxpool", "sgp_fold", "sgp_mlp", "gemm_splitk")
+
+
+def sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt, traffic_file=None):
     """SGP encoder-decoder against the HBM roof with the ALGORITHMIC byte count of SURVEY.md section 8d:
     es * [B*C*Sigma_T + W]: every block/mixer reads its inputs once and writes its output once, weights once."""
     from tdeed_amd.regnet_spec import pyramid_lengths, sgp_up_size
@@ -256,7 +259,17 @@ def sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt):
     # stage time: the sub-batches' stage chains timed back to back on one stream (they overlap other work inside the
     # graph; this is the stage's own device time)
     sgp_ms = sum(x[0] for x in sgp_direct)
+    # HBM-side traffic of the stage's kernel families per forward, from the committed counter passes (not measured here)
+    traffic = None
+    if traffic_file is not None:
+        try:
+            with open(os.path.join(ROOT, traffic_file)) as fh:
+                tk = json.load(fh)["kernels"]
+            traffic = int(sum(tk[f]["hbm_bytes_per_forward"] for f in SGP_FAMILIES if f in tk and "hbm_bytes_per_forward" in tk[f]))
+        except (OSError, KeyError, ValueError):
+            traffic = None
     return dict(bound="hbm", algorithmic_bytes=int(sgp_bytes), sigma_T=int(sig), weights=int(Wsgp),
+                traffic=traffic, traffic_over_algorithmic=(round(traffic / sgp_bytes, 2) if traffic else None),
                 ms=round(sgp_ms, 4), ms_event_sum=round(sgp_stage_ms, 4),
                 achieved=round(sgp_bytes / (sgp_ms * 1e-3) / 1e9, 2),
                 peak=HBM_PEAK_GBS, unit="GB/s",
@@ -319,7 +332,7 @@ def infer_sub_record(workload, steps, repeats, depth, rank, dev, traffic_file, s
                roofline_step=dict(bound="hbm", algorithmic_bytes=int(step_bytes),
                                   achieved=round(step_bytes / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
-               roofline_sgp=sgp_roofline(cfg, B, T, eng, plans[0], sgp_direct, sgp_stage_ms, dt),
+               roofline_sgp=sgp_roofline(cfg, B, T, eng, plans[0], sgp_direct, sgp_stage_ms, dt, traffic_file),
                kernels=kernels_table(prof))
     del plans, eng
     torch.cuda.empty_cache()
@@ -945,7 +958,8 @@ def main():
         ms = el / a.steps * 1e3
         value = world * B * a.steps / el
         roof = dominant_roofline(prof, dt, TRAFFIC_FILE if (a.workload == "rny002_b8" and a.dtype == "bf16") else None)
-        sgp_roof = sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt)
+        sgp_roof = sgp_roofline(cfg, B, T, eng, plan, sgp_direct, sgp_stage_ms, dt,
+                                TRAFFIC_FILE if (a.workload == "rny002_b8" and a.dtype == "bf16") else None)
         kernels = kernels_table(prof)
         step_bytes, _ = forward_layer_bytes(cfg, B, H, W, dt, dev)     # layer-granular (fusion-independent), as in round 1 / 2
         step_flops = sum(s.flops for s in plan.steps)

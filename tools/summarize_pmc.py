@@ -25,7 +25,7 @@ TRAIN_FAMILY = [("narrow_conv1_bwd", "narrow_conv_bwd"), ("gemm_rs", "gemm"), ("
                 ("bn_apply", "bn_apply"), ("pool_mean", "se_train"), ("scale_rows", "se_train"), ("se_train", "se_train"),
                 ("adamw", "adamw"), ("multi_fold", "grad_writeout"), ("gather_cast", "repack"), ("stem_mfma", "stem"),
                 ("stem_wgrad", "stem")]
-FAMILY = [("sgp_fold", "sgp_fold"), ("bneck_kernel", "bneck"), ("c1_gconv", "c1_gconv"), ("gemm_ws_kernel", "gemm_ws"),
+FAMILY = [("sgp_gemm", "sgp_gemm"), ("sgp_fold", "sgp_fold"), ("bneck_kernel", "bneck"), ("c1_gconv", "c1_gconv"), ("gemm_ws_kernel", "gemm_ws"),
           ("gemm_rs", "gemm_ws"),                  # the register-stationary forms: the family bench.py's kernels table counts them in
           ("gemm_splitk", "gemm_splitk"), ("gemm_big", "gemm_big"), ("gemm_kernel", "gemm"),
           ("gconv3x3", "gconv3x3"), ("s1_front", "s1_front"), ("gsf_", "gate_shift"), ("se_gate", "se_gate"),
