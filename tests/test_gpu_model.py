@@ -88,9 +88,10 @@ def test_forward_bf16_close_to_reference(name):
     ref = t(g["logits"])
     err = (head[..., :K1] - ref).abs().max().item()
     scale = ref.abs().max().item()
-    # measured 7.6e-2 on the FineDiving_small golden clip (logit range +-4.5): tools/diag_bf16_split.py attributes 4.6e-2 to
-    # the trunk alone and 5.1e-2 to the temporal stage alone; the reference's own CPU bf16 autocast is 4.5e-2 off
-    assert err < 0.1, (err, scale)
+    # measured 4.4e-2 .. 4.7e-2 on the FineDiving_small golden clip (logit range +-4.5) since the temporal stage keeps its
+    # residual stream in fp32 (round 5; 7.6e-2 before: tools/diag_bf16_split.py attributed 4.6e-2 to the bf16 trunk alone);
+    # the reference's own CPU bf16 autocast is 4.5e-2 off
+    assert err < 0.06, (err, scale)
     assert (head[..., :K1].argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
 
 

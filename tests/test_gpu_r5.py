@@ -228,3 +228,74 @@ def test_tiny_clips_through_the_stage(T):
         outs.append(out.float().cpu())
     scale = max(1.0, float(outs[0].abs().max()))
     assert max_abs(outs[1], outs[0]) < 3e-2 * scale and max_abs(outs[2], outs[0]) < 6e-2 * scale
+
+
+# ------------------------------------------------------------------------------------------------ the timed sizes
+@pytest.mark.parametrize("h,w,C,gw,R,Fp", [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)])
+def test_one_launch_bottleneck_at_the_timed_size_is_within_one_ulp_of_the_chain(h, w, C, gw, R, Fp):
+    """tdeed_bneck_fwd against gemm -> gconv3x3 -> se_gate_mfma -> gemm at N = 800 frames (B = 8 clips
+    of 100: what bench.py times).  The squeeze sums of a workgroup's frames are folded in another order than the chain's,
+    so the SE gate may differ in its last fp32 bit and a handful of outputs by ONE bf16 ulp: at most 1e-5 of the elements,
+    none by more than one ulp of its own magnitude."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma
+    N = 800
+    g = torch.Generator().manual_seed(h * 100 + C)
+    hw = h * w
+    M = N * hw
+    x = torch.relu(torch.randn(N, h, w, C, generator=g)).to(torch.bfloat16)
+    G = torch.randn(M, Fp, generator=g).to(torch.bfloat16)
+    W1 = torch.randn(C, C, generator=g) / C ** 0.5
+    W3 = torch.randn(C, C, generator=g) / C ** 0.5
+    W2 = torch.randn(C, gw, 3, 3, generator=g) / (gw * 9) ** 0.5
+    fc1 = torch.randn(R, C, generator=g) / C ** 0.5
+    fc2 = torch.randn(C, R, generator=g) / R ** 0.5
+    vec = lambda n, s_=0.1, o=0.0: (torch.randn(n, generator=g) * s_ + o).to(DEV)          # noqa: E731
+    s1, h1, s2, h2, s3, h3 = vec(C, 0.1, 1.0), vec(C), vec(C, 0.1, 1.0), vec(C), vec(C, 0.1, 0.5), vec(C)
+    b1, b2 = vec(R), vec(C)
+    W1d, W3d = W1.to(torch.bfloat16).to(DEV), W3.to(torch.bfloat16).to(DEV)
+    w2f = pack_gconv_frags(W2.numpy(), gw, DEV)
+    se = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
+    xd, Gd = x.to(DEV), G.to(DEV)
+    y1 = ops.gemm(xd.view(M, C), W1d, s1, h1, ops.ACT_RELU, A0=Gd, k0=Fp)
+    y2, pooled = ops.gconv3x3(y1.view(N, h, w, C), None, s2, h2, gw, 1, wfrag=w2f)
+    gate = ops.se_gate_mfma(pooled, 1.0 / hw, se["w1f"], b1, se["w2f"], b2, R)
+    ref = ops.gemm(y2.view(M, C), W3d, s3, h3, ops.ACT_RELU, residual=xd.view(M, C), a_scale=gate, a_scale_rows=hw)
+    out = ops.bneck(xd, pack_mfma_frags(W1.numpy(), DEV), s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R,
+                    pack_mfma_frags(W3.numpy(), DEV), s3, h3, G=Gd).view(M, C)
+    torch.cuda.synchronize()
+    a, b = out.float(), ref.float()
+    diff = (a - b).abs()
+    nd = int((diff > 0).sum())
+    assert nd <= 1e-5 * a.numel(), nd
+    ulp = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7          # one bf16 ulp is at most 2^-7 of the magnitude
+    assert bool((diff <= ulp + 1e-30).all()), float((diff - ulp).max())
+
+
+def test_cfg5_geometry_at_its_real_size_tracks_the_fp32_engine():
+    """BASELINE configs[4] per-GPU share as bench.py runs it (RegNetY-800MF, T = 250, 224 x 224, B = 4): the bf16 forward of
+    the whole batch against the fp32 engine on the same clips (the fp32 engine is the one held to the reference's goldens,
+    incl. snb_t250 at 160 x 160), finite everywhere, the arg-max of nearly every frame equal."""
+    from tdeed_amd.engine import ForwardEngine
+    cfg = dict(feature_arch="rny008_gsf", clip_len=250, crop_dim=None, n_layers=2, sgp_ks=9, sgp_r=4, num_classes=12,
+               radi_displacement=4)
+    B, T, H, W = 4, 250, 224, 224
+    sd = model_state(cfg, 0)
+    clip = t(synth.uint8_clip(4242, (B, T, 3, H, W))).to(DEV)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            eng = ForwardEngine(cfg, sd, dt, DEV, use_graph=(dt == torch.bfloat16), n_split=1)
+            plan = eng.plan(B, H, W)
+            eng.set_frames(plan, clip)
+            eng.run_plan(plan)
+        torch.cuda.synchronize()
+        outs[dt] = plan.head_out.float().cpu().view(B, T, -1)
+        del eng, plan
+        torch.cuda.empty_cache()
+    K1 = cfg["num_classes"] + 1
+    a, b = outs[torch.bfloat16], outs[torch.float32]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = float(b[..., :K1].abs().max())
+    assert float((a[..., :K1] - b[..., :K1]).abs().max()) < 0.08 * max(1.0, scale)
+    assert float((a[..., :K1].argmax(-1) == b[..., :K1].argmax(-1)).float().mean()) > 0.9
