@@ -275,6 +275,7 @@ int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int
  * dtype_cat (mixer): the six slabs may be stored as bf16 while z / x_lo are fp32 (fp32 residual stream, bf16 contraction). */
 int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w, const float* ln_b, float eps,
                         const float* dw, const float* db, void* y, float* chsum, const float* rowstat, int rowstat_parts,
+                        void* y16 /* optional, dtype fp32 only: a bf16 copy of y (the fc1 operand of wide models) */,
                         int dtype, void* stream);
 int tdeed_mixer_front_fwd(const void* z, const void* xlo, int B, int T_hi, int T_lo, int C, int ks, int up,
                           const float* ln1_w, const float* ln1_b, const float* ln2_w, const float* ln2_b, float eps,
@@ -287,6 +288,10 @@ int tdeed_groupnorm_fwd(const void* x, int B, int T, int C, int G, const float* 
 /* nn.AdaptiveMaxPool1d over T (modules.py:64,76): [B][T_in][C] -> [B][T_out][C]. */
 int tdeed_maxpool_fwd(const void* x, int B, int T_in, int T_out, int C, void* y, int dtype,
                       void* stream);
+/* the same pooling with the LayerNorm statistics (mean, rstd over C, eps inside the sqrt; modules.py:353-357) of every pooled
+ * row in rowstat [B*T_out][2] -- what tdeed_sgp_front_fwd of the next block takes instead of re-deriving them */
+int tdeed_maxpool_rowstat_fwd(const void* x, int B, int T_in, int T_out, int C, void* y, float* rowstat, float eps, int dtype,
+                              void* stream);
 
 /* ---- heads (modules.py:366-387, model.py:141-146), eval (no dropout) ------------------------
  * x [rows][C]; w fp32 [n_out][C], b [n_out]; out fp32 [rows][n_out] (class logits and the
@@ -660,7 +665,8 @@ int tdeed_sgp_gemm_residual(const void* H, int B, int T, int K, const void* Wp, 
                             void* out, float* rowstat_part, void* pooled, float* rowstat_pool_part, int T_out, int form,
                             int dtype_o, void* stream);
 int tdeed_sgp_gemm_gelu_chsum(const void* A, int B, int T, int K, const void* Wp, const float* bias, int N, void* out,
-                              float* chs_out, int form, int dtype_o, void* stream);
+                              float* chs_out, void* out16 /* optional bf16 copy of out */, int form, int dtype_o,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,7 @@ _SIGS = {
     "tdeed_sgp_gemm_form": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "tdeed_sgp_gemm_gn_gelu": ([P, c_int, c_int, c_int, P, c_int, P, P, c_int, c_float, P, P, c_int, P, c_int, c_int, P], c_int),
     "tdeed_sgp_gemm_residual": ([P, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, P], c_int),
-    "tdeed_sgp_gemm_gelu_chsum": ([P, c_int, c_int, c_int, P, P, c_int, P, P, c_int, c_int, P], c_int),
+    "tdeed_sgp_gemm_gelu_chsum": ([P, c_int, c_int, c_int, P, P, c_int, P, P, P, c_int, c_int, P], c_int),
     "tdeed_gsf_bwd": ([P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                        c_int, P], c_int),
     "tdeed_gsf_add_cols": ([P, P, c_long, c_int, c_int, P, c_int, P], c_int),
@@ -147,12 +147,13 @@ _SIGS = {
     "tdeed_layernorm_fwd": ([P, c_long, c_int, c_int, P, P, c_float, P, c_long, c_int, P], c_int),
     "tdeed_sgp_branch_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_mixer_branch_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
-    "tdeed_sgp_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int, c_int, P], c_int),
+    "tdeed_sgp_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int, P, c_int, P], c_int),
     "tdeed_mixer_front_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int, P,
                                c_int, c_int, c_int, P], c_int),
     "tdeed_gemm_splitk_partials": ([P, c_long, c_int, c_int, c_int, P, c_long, P, P], c_int),
     "tdeed_groupnorm_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, P, c_int, P], c_int),
     "tdeed_maxpool_fwd": ([P, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_maxpool_rowstat_fwd": ([P, c_int, c_int, c_int, c_int, P, P, c_float, c_int, P], c_int),
     "tdeed_heads_fwd": ([P, c_int, c_int, P, P, c_int, P, c_int, P], c_int),
     "tdeed_loss_fwd": ([P, c_int, c_int, c_int, P, P, P, c_int, P, P, P], c_int),
     "tdeed_loss_bwd": ([P, c_int, c_int, c_int, P, P, P, c_int, P, c_float, P, P], c_int),

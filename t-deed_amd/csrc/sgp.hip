@@ -344,6 +344,66 @@ __global__ void maxpool_kernel(const T* __restrict__ x, int T_in, int T_out, int
   }
 }
 
+// The same pooling by one wave per POOLED row, which therefore also holds the whole row: it leaves the LayerNorm statistics
+// (mean, rstd over C of the stored values; modules.py:353-357) of every pooled row for the next block's front kernel.  Used
+// behind encoder blocks whose length does not halve (25 -> 13, 125 -> 63): those cannot pool inside the fc2 launch, and without
+// the statistics the front kernel re-derives them from the clip's slab (16 vs 9 us at C = 768).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_rowstat_kernel(const T* __restrict__ x, int T_in, int T_out, int C,
+                                                              T* __restrict__ y, float* __restrict__ rowstat, float eps,
+                                                              long rows) {
+  constexpr int EPC = Chunk<T>::N;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wid;
+  if (r >= rows) return;
+  const int i = (int)(r % T_out);
+  const long b = r / T_out;
+  const int lo = (int)(((long)i * T_in) / T_out);
+  const int hi = (int)((((long)(i + 1)) * T_in + T_out - 1) / T_out);
+  const int cpr = C / EPC;
+  float s1 = 0.f, s2 = 0.f;
+  for (int ck = lane; ck < cpr; ck += 64) {
+    float m[EPC];
+    Chunk<T>::load(x + ((long)b * T_in + lo) * C + ck * EPC, m);
+    for (int t = lo + 1; t < hi; ++t) {
+      float v[EPC];
+      Chunk<T>::load(x + ((long)b * T_in + t) * C + ck * EPC, v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+    Chunk<T>::store(y + r * C + ck * EPC, m);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      s1 += m[e];                       // (a maximum of stored values is a stored value: no rounding to repeat)
+      s2 = fmaf(m[e], m[e], s2);
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    const float mu = s1 / (float)C;
+    rowstat[r * 2] = mu;
+    rowstat[r * 2 + 1] = 1.0f / sqrtf(fmaxf(s2 / (float)C - mu * mu, 0.f) + eps);
+  }
+}
+
+extern "C" int tdeed_maxpool_rowstat_fwd(const void* x, int B, int T_in, int T_out, int C, void* y, float* rowstat, float eps,
+                                         int dtype, void* stream) {
+  TD_CHECK(x && y && rowstat, "maxpool_rowstat: null pointer");
+  TD_CHECK(B > 0 && T_in > 0 && T_out > 0 && T_out <= T_in && C % 8 == 0, "maxpool_rowstat: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)B * T_out;
+  if (dtype == TDEED_F32)
+    hipLaunchKernelGGL(maxpool_rowstat_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, T_in, T_out, C,
+                       (float*)y, rowstat, eps, rows);
+  else if (dtype == TDEED_BF16)
+    hipLaunchKernelGGL(maxpool_rowstat_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, T_in, T_out,
+                       C, (bf16_t*)y, rowstat, eps, rows);
+  else { tdeed_set_error("maxpool_rowstat: bad dtype %d", dtype); return TDEED_ERR_ARG; }
+  TD_LAUNCH_CHECK("maxpool_rowstat");
+  return TDEED_OK;
+}
+
 extern "C" int tdeed_maxpool_fwd(const void* x, int B, int T_in, int T_out, int C, void* y, int dtype,
                                  void* stream) {
   TD_CHECK(x && y, "maxpool: null pointer");

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
                                                         float eps, const float* __restrict__ dw,
                                                         const float* __restrict__ db, T* __restrict__ y,
                                                         float* __restrict__ chsum,
-                                                        const float* __restrict__ rowstat, int rs_parts) {
+                                                        const float* __restrict__ rowstat, int rs_parts,
+                                                        bf16_t* __restrict__ y16) {
   extern __shared__ float sm[];
   const int halo = up >> 1;
   const int wlen = 2 * ks + up + 2;
@@ -146,6 +147,9 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
 #undef FRONT_GENERIC
   __syncthreads();
   store_tile<T>(res, y + base, C, 0, T_len, c0, C, (const T*)nullptr, 0);
+  // fp32 residual stream over a WIDE feature dimension: a bf16 copy of y as the fc1 contraction's operand (its fp32 rows would
+  // double the bytes every column tile of that launch pulls through its CU: 34.9 vs 28.1 us at C = 768, 1600 rows)
+  if (y16) store_tile<bf16_t>(res, y16 + base, C, 0, T_len, c0, C, (const bf16_t*)nullptr, 0);
   if (chsum) {
     // per-channel sum and sum of squares over T of the stored y (what GroupNorm of the MLP half reads): the consumer
     // then only folds 16 groups instead of re-reading the clip.  Rounded like the store.
@@ -180,7 +184,8 @@ static size_t front_smem(int T_len, int ks, int up, int ntiles, int nres, int ns
 
 extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w,
                                    const float* ln_b, float eps, const float* dw, const float* db, void* y,
-                                   float* chsum, const float* rowstat, int rowstat_parts, int dtype, void* stream) {
+                                   float* chsum, const float* rowstat, int rowstat_parts, void* y16, int dtype,
+                                   void* stream) {
   TD_CHECK(x && ln_w && ln_b && dw && db && y, "sgp_front: null pointer");
   TD_CHECK(rowstat_parts >= 0 && rowstat_parts <= 64, "sgp_front: rowstat_parts");
   TD_CHECK(B > 0 && T > 0 && C % 8 == 0 && ks % 2 == 1 && up % 2 == 1 && up >= ks, "sgp_front: bad sizes");
@@ -193,10 +198,10 @@ extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(sgp_front_kernel<float>, grid, dim3(256), smem, st, (const float*)x, T, C, ks, up, ln_w, ln_b, eps,
-                       dw, db, (float*)y, chsum, rowstat, rowstat_parts);
+                       dw, db, (float*)y, chsum, rowstat, rowstat_parts, (bf16_t*)y16);
   else if (dtype == TDEED_BF16)
     hipLaunchKernelGGL(sgp_front_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)x, T, C, ks, up, ln_w, ln_b,
-                       eps, dw, db, (bf16_t*)y, chsum, rowstat, rowstat_parts);
+                       eps, dw, db, (bf16_t*)y, chsum, rowstat, rowstat_parts, (bf16_t*)nullptr);
   else { tdeed_set_error("sgp_front: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("sgp_front");
   return TDEED_OK;

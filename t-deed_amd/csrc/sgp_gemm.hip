@@ -48,6 +48,7 @@ struct SgpGemmP {
   float* rowstat_part;                // MODE 1: [nct][B*T][2] (sum, sum of squares) of the stored row over this tile's features
   void* pooled; float* rowstat_pool_part; int T_out;      // MODE 1 with T == 2 T_out: pooled rows [B*T_out][N] + their sums
   float* chs_out;                     // MODE 2: [NJ][B][N][2] per-channel sums of the stored rows of this row tile
+  bf16_t* out16;                      // MODE 2 (optional): a bf16 copy of out, the next contraction's operand in wide models
 };
 
 #define SG_LDS_BARRIER()                                               \
@@ -332,6 +333,9 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
       if (rok && fok) {
         if constexpr (MODE == 0) SgOut<bf16_t>::store(reinterpret_cast<bf16_t*>(p.out) + (row0 + tr) * p.ldo + f, v);
         else SgOut<TO>::store(O + (row0 + tr) * p.ldo + f, v);
+        if constexpr (MODE == 2) {
+          if (p.out16) SgOut<bf16_t>::store(p.out16 + (row0 + tr) * p.ldo + f, v);
+        }
       }
       if constexpr (MODE == 1) {
         if (rok && fok) {
@@ -544,9 +548,9 @@ extern "C" int tdeed_sgp_gemm_residual(const void* H, int B, int T, int K, const
   return TDEED_ERR_ARG;
 }
 
-// MODE 2: out = GELU(A . W^T + b); A bf16 [B*T][K]; out in dtype_o; chs_out [NJ][B][N][2]
+// MODE 2: out = GELU(A . W^T + b); A bf16 [B*T][K]; out in dtype_o; chs_out [NJ][B][N][2]; out16: optional bf16 copy of out
 extern "C" int tdeed_sgp_gemm_gelu_chsum(const void* A, int B, int T, int K, const void* Wp, const float* bias, int N,
-                                         void* out, float* chs_out, int form, int dtype_o, void* stream) {
+                                         void* out, float* chs_out, void* out16, int form, int dtype_o, void* stream) {
   TD_CHECK(A && Wp && bias && out && chs_out, "sgp_gemm_gelu_chsum: null pointer");
   TD_CHECK(B > 0 && T > 0 && K % 8 == 0 && N % 16 == 0, "sgp_gemm_gelu_chsum: bad sizes");
   SgpGemmP p = {};
@@ -555,6 +559,7 @@ extern "C" int tdeed_sgp_gemm_gelu_chsum(const void* A, int B, int T, int K, con
   p.B = B; p.T = T; p.N = N; p.K = K; p.NJ = tdeed_sgp_gemm_row_tiles(T, MT); p.nct = tdeed_sgp_gemm_col_tiles(N, NT);
   p.ct_major = 0;
   p.chs_out = chs_out;
+  p.out16 = (bf16_t*)out16;
   hipStream_t st = (hipStream_t)stream;
   if (dtype_o == TDEED_BF16) return sg_dispatch<2, bf16_t, bf16_t>(p, MT, NT, st);
   if (dtype_o == TDEED_F32) return sg_dispatch<2, bf16_t, float>(p, MT, NT, st);

@@ -78,6 +78,9 @@ def _dwpack(sd, pre, names, C, device):
 SGP_GEMM = os.environ.get("TDEED_SGP_GEMM", "1") == "1"             # the SGP contractions on sgp_gemm.hip (round 5)
 # its residual stream (block / mixer inputs and outputs, the stash) in fp32 under a bf16 trunk, like the reference's autocast
 SGP_F32_STREAM = os.environ.get("TDEED_SGP_F32_STREAM", "1") == "1"
+# feature dimensions above this get a bf16 copy of the fc1 operand beside the fp32 rows (a wide fc1 launch is bound by the
+# bytes per CU; narrow ones are latency bound and take the fp32 rows directly)
+SGP_BF16_OPERAND_MIN_C = int(os.environ.get("TDEED_SGP_BF16_OPERAND_MIN_C", "384"))
 
 
 def sgp_stream_dtype(act_dtype, device):
@@ -462,13 +465,14 @@ class SgpBuilder:
         self.gemm = SGP_GEMM and act_dtype == torch.bfloat16
         # (the residual stream's type is the type of what the stage is handed: sgp_stream_dtype() for the model's plans)
 
-    def _mlp_gemm(self, name, y, o, Tn, chsum, pool_to=None):
+    def _mlp_gemm(self, name, y, o, Tn, chsum, pool_to=None, y16=None):
         """out = y + mlp(GN(y)) as two sgp_gemm launches; leaves the output's partial row sums on it (`_td_rowstat`) and, when
         the following AdaptiveMaxPool1d halves the length, the pooled rows in `self.last_pooled`."""
         pool, steps, B, C = self.pool, self.steps, self.B, o.C
         R, adt = B * Tn, y.dtype
         es = _esz(adt)
-        f1 = ops.sgp_gemm_form(0 if adt == torch.bfloat16 else 3, B, Tn, 4 * C, C)
+        ya = y if y16 is None else y16           # fc1's operand: the rows themselves, or their bf16 copy (wide models, fp32 stream)
+        f1 = ops.sgp_gemm_form(0 if ya.dtype == torch.bfloat16 else 3, B, Tn, 4 * C, C)
         f2 = ops.sgp_gemm_form(1, B, Tn, C, 4 * C)
         nct = ops.sgp_gemm_tiles(Tn, C, f2)[1]
         H = pool.take((B, Tn, 4 * C), torch.bfloat16)
@@ -480,9 +484,9 @@ class SgpBuilder:
             rpp = torch.empty((nct, B * pool_to, 2), dtype=torch.float32, device=y.device)
             pooled._td_rowstat = rpp
         self.last_pooled = pooled
-        steps.append(Step(name + ".fc1", "sgp_gemm", lambda: ops.sgp_gemm_gn_gelu(y, chsum, o.gn_w, o.gn_b, o.w1g, o.b_fc1, 4 * C,
+        steps.append(Step(name + ".fc1", "sgp_gemm", lambda: ops.sgp_gemm_gn_gelu(ya, chsum, o.gn_w, o.gn_b, o.w1g, o.b_fc1, 4 * C,
                                                                                 out=H, form=f1),
-                          R * C * es + 4 * C * C * 2 + R * 4 * C * 2, 2 * R * 4 * C * C))
+                          R * C * _esz(ya.dtype) + 4 * C * C * 2 + R * 4 * C * 2, 2 * R * 4 * C * C))
         steps.append(Step(name + ".fc2", "sgp_gemm", lambda: ops.sgp_gemm_residual(H, o.w2g, o.b_fc2, y, out=outb, rowstat_part=rsp,
                                                                                  pooled=pooled, rowstat_pool_part=rpp, form=f2),
                           R * 4 * C * 2 + 4 * C * C * 2 + 2 * R * C * es + (0 if pooled is None else B * pool_to * C * es),
@@ -530,13 +534,16 @@ class SgpBuilder:
             es, R = _esz(adt), B * Tn
             wl = 2 * o.ks + o.up + 2
             y = pool.take((B, Tn, C), adt)
+            y16 = pool.take((B, Tn, C), torch.bfloat16) if (adt == torch.float32 and C > SGP_BF16_OPERAND_MIN_C) else None
             chs = pool.take((B, C, 2), torch.float32)
             rs_in = getattr(xin, "_td_rowstat", None)
             steps.append(Step(name + ".front", "sgp_front", lambda: ops.sgp_front(xin, o.ks, o.up, o.ln_w, o.ln_b, o.dw, o.db,
-                                                                                 out=y, chsum=chs, rowstat=rs_in),
-                              2 * R * C * es + C * (wl + 7) * 4, 2 * R * C * (wl + 3)))
-            outb = self._mlp_gemm(name, y, o, Tn, chs, pool_to=pool_to)
+                                                                                 out=y, chsum=chs, rowstat=rs_in, out16=y16),
+                              2 * R * C * es + C * (wl + 7) * 4 + (0 if y16 is None else R * C * 2), 2 * R * C * (wl + 3)))
+            outb = self._mlp_gemm(name, y, o, Tn, chs, pool_to=pool_to, y16=y16)
             pool.give(y)
+            if y16 is not None:
+                pool.give(y16)
             pool.give(chs)
             if name in self.taps:
                 self.keep[name] = outb
@@ -591,12 +598,16 @@ class SgpBuilder:
             fc = ops.sgp_gemm_form(2, B, T_hi, C, 6 * C)
             NJ = ops.sgp_gemm_tiles(T_hi, C, fc)[0]
             mo = pool.take((B, T_hi, C), adt)
+            mo16 = pool.take((B, T_hi, C), torch.bfloat16) if (adt == torch.float32 and C > SGP_BF16_OPERAND_MIN_C) else None
             chs = pool.take((NJ, B, C, 2), torch.float32)
-            steps.append(Step(name + ".cat", "sgp_gemm", lambda: ops.sgp_gemm_gelu_chsum(cat, o.wcg, o.b_cat, C, mo, chs, form=fc),
-                              R * 6 * C * 2 + 6 * C * C * 2 + R * C * es, 2 * R * 6 * C * C))
+            steps.append(Step(name + ".cat", "sgp_gemm", lambda: ops.sgp_gemm_gelu_chsum(cat, o.wcg, o.b_cat, C, mo, chs, form=fc,
+                                                                                       out16=mo16),
+                              R * 6 * C * 2 + 6 * C * C * 2 + R * C * es + (0 if mo16 is None else R * C * 2), 2 * R * 6 * C * C))
             pool.give(cat)
-            outb = self._mlp_gemm(name, mo, o, T_hi, chs)
+            outb = self._mlp_gemm(name, mo, o, T_hi, chs, y16=mo16)
             pool.give(mo)
+            if mo16 is not None:
+                pool.give(mo16)
             pool.give(chs)
             if name in self.taps:
                 self.keep[name] = outb
@@ -657,8 +668,15 @@ class SgpBuilder:
             pooled = self.last_pooled
             if pooled is None:
                 pooled = pool.take((B, lens[i + 1], C), cur.dtype)
-                steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1]: ops.maxpool(a, L, out=b),
-                                  B * (lens[i] + lens[i + 1]) * C * _esz(cur.dtype)))
+                if self.gemm and self.fused and str(cur.device) != "cpu":
+                    # lengths that do not halve: a pooling launch that also leaves the pooled rows' LayerNorm statistics
+                    prs = torch.empty((B * lens[i + 1], 2), dtype=torch.float32, device=cur.device)
+                    pooled._td_rowstat = prs
+                    steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1], r=prs:
+                                      ops.maxpool_rowstat(a, L, out=b, rowstat=r), B * (lens[i] + lens[i + 1]) * C * _esz(cur.dtype)))
+                else:
+                    steps.append(Step(f"{pre}pool{i}", "maxpool", lambda a=cur, b=pooled, L=lens[i + 1]: ops.maxpool(a, L, out=b),
+                                      B * (lens[i] + lens[i + 1]) * C * _esz(cur.dtype)))
             cur = pooled
         cur = self.block(cur, lens[n], sgp[n], f"{pre}_sgp.{n}")
         for i in range(n):

@@ -405,7 +405,7 @@ def _rs_parts(rowstat):
     return 0 if rowstat is None or rowstat.dim() == 2 else int(rowstat.shape[0])
 
 
-def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None, rowstat=None):
+def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None, rowstat=None, out16=None):
     """SGPBlock front half with the LayerNorm computed in-kernel: y = x + LN(x) + fc*phi + (convw+convkw)*psi.
     chsum: optional fp32 (B, C, 2) output, per-channel sum / sum of squares over T of y (for sgp_gemm_gn_gelu's GroupNorm);
     rowstat: optional fp32 (B*T, 2) input, LayerNorm statistics of every row of x: (mean, rstd) as avgpool_posenc leaves them, or (n, B*T, 2) partial (sum, sum of
@@ -414,7 +414,7 @@ def sgp_front(x, ks, up, ln_w, ln_b, dw, db, eps=1e-5, out=None, chsum=None, row
     if out is None:
         out = torch.empty_like(x)
     call("tdeed_sgp_front_fwd", ptr(x), B, T, C, ks, up, ptr(ln_w), ptr(ln_b), eps, ptr(dw), ptr(db), ptr(out),
-         ptr(chsum), ptr(rowstat), _rs_parts(rowstat), dtype_code(x.dtype), stream_ptr())
+         ptr(chsum), ptr(rowstat), _rs_parts(rowstat), ptr(out16), dtype_code(x.dtype), stream_ptr())
     return out
 
 
@@ -443,6 +443,17 @@ def maxpool(x, T_out, out=None):
         out = torch.empty((B, T_out, C), dtype=x.dtype, device=x.device)
     call("tdeed_maxpool_fwd", ptr(x), B, T_in, T_out, C, ptr(out), dtype_code(x.dtype), stream_ptr())
     return out
+
+
+def maxpool_rowstat(x, T_out, out=None, rowstat=None, eps=1e-5):
+    """AdaptiveMaxPool1d(T_out) along T of (B,T,C) + the LayerNorm (mean, rstd) of every pooled row in rowstat (B*T_out, 2)"""
+    B, T_in, C = x.shape
+    if out is None:
+        out = torch.empty((B, T_out, C), dtype=x.dtype, device=x.device)
+    if rowstat is None:
+        rowstat = torch.empty((B * T_out, 2), dtype=torch.float32, device=x.device)
+    call("tdeed_maxpool_rowstat_fwd", ptr(x), B, T_in, T_out, C, ptr(out), ptr(rowstat), eps, dtype_code(x.dtype), stream_ptr())
+    return out, rowstat
 
 
 def heads(x, w, b, out=None):
@@ -612,11 +623,11 @@ def sgp_gemm_residual(H, Wp, bias, resid, out=None, rowstat_part=None, pooled=No
     return out
 
 
-def sgp_gemm_gelu_chsum(A, Wp, bias, N, out, chs_out, form=None):
+def sgp_gemm_gelu_chsum(A, Wp, bias, N, out, chs_out, form=None, out16=None):
     """out (B,T,N) bf16 | fp32 = GELU(A @ W^T + b), A bf16 (B,T,K); chs_out fp32 (NJ,B,N,2): per-channel (sum, sum of squares)
     of the stored rows per row tile"""
     B, T, K = A.shape
     form = form or sgp_gemm_form(2, B, T, N, K)
-    call("tdeed_sgp_gemm_gelu_chsum", ptr(A), B, T, K, ptr(Wp), ptr(bias), N, ptr(out), ptr(chs_out), form[0] * 16 + form[1],
-         dtype_code(out.dtype), stream_ptr())
+    call("tdeed_sgp_gemm_gelu_chsum", ptr(A), B, T, K, ptr(Wp), ptr(bias), N, ptr(out), ptr(chs_out), ptr(out16),
+         form[0] * 16 + form[1], dtype_code(out.dtype), stream_ptr())
     return out

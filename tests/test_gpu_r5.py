@@ -124,8 +124,10 @@ def test_sgp_gemm_concat_gelu_channel_sums(B, T, C, odt):
         NJ, nct = ops.sgp_gemm_tiles(T, C, f)
         out = torch.full((B, T, C), float("nan"), device=DEV, dtype=odt)
         chs = torch.full((NJ, B, C, 2), float("nan"), device=DEV)
-        ops.sgp_gemm_gelu_chsum(A, Wp, bc, C, out, chs, form=f)
+        o16 = torch.full((B, T, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ops.sgp_gemm_gelu_chsum(A, Wp, bc, C, out, chs, form=f, out16=o16)
         torch.cuda.synchronize()
+        assert torch.equal(o16, out.to(torch.bfloat16)), form
         tol = (2e-2 if odt == torch.bfloat16 else 2e-3) * max(1.0, float(ref.abs().max()))
         assert float((out.float() - ref).abs().max()) < tol, form
         of = out.float()
@@ -299,3 +301,27 @@ def test_cfg5_geometry_at_its_real_size_tracks_the_fp32_engine():
     scale = float(b[..., :K1].abs().max())
     assert float((a[..., :K1] - b[..., :K1]).abs().max()) < 0.08 * max(1.0, scale)
     assert float((a[..., :K1].argmax(-1) == b[..., :K1].argmax(-1)).float().mean()) > 0.9
+
+
+@pytest.mark.parametrize("T,n", [(50, 2), (26, 2)])
+def test_wide_stage_with_bf16_operand_copies_and_odd_levels(T, n):
+    """C = 768 (RegNetY-800MF): the fp32-stream stage hands fc1 a bf16 copy of its rows (sgp_front / the concat launch write
+    it beside the fp32 tensor) and pools odd lengths (25 -> 13, 13 -> 7) through tdeed_maxpool_rowstat_fwd; against the fp32
+    launch-per-op chain on the same weights."""
+    from tdeed_amd.engine import SgpBuilder, pack_sgp_block, pack_sgp_mixer, _Pool
+    from helpers import module_state, act
+    B, C = 2, 768
+    sd = module_state("pyramid", "_temp_fine", 5, C=C, ks=7, r=4, n=n)
+    x = t(act(9, "x", (B, T, C)))
+    outs, kinds = [], None
+    for wdt in (torch.float32, torch.bfloat16):
+        sgp = [pack_sgp_block(sd, f"_temp_fine._sgp.{i}", C, wdt, DEV) for i in range(2 * n + 1)]
+        mix = [pack_sgp_mixer(sd, f"_temp_fine._sgpMixer.{i}", C, wdt, DEV) for i in range(n)]
+        steps, keep = [], {}
+        sb = SgpBuilder(_Pool(DEV), steps, keep, set(), B, wdt)
+        out = sb.pyramid(x.to(DEV), T, n, sgp, mix)
+        _run(steps)
+        outs.append(out.float().cpu())
+        kinds = [s_.kernel for s_ in steps]
+    assert "maxpool" in kinds and kinds.count("sgp_gemm") == 2 * (2 * n + 1) + 3 * n
+    assert max_abs(outs[1], outs[0]) < 3e-2 * max(1.0, float(outs[0].abs().max()))
