@@ -205,7 +205,11 @@ def test_hip_train_steps_match_the_reference():
             sd = m.state_dict()
             for k in meta["keys"]:
                 got = sample_flat(sd[k].detach().cpu().numpy(), meta["sample_cap"])
-                assert float(np.abs(got - g["param1:" + k]).max()) < 0.1 * lrs[0] + 1e-7, k
+                # the first Adam step moves every entry by lr * sign(g): an entry whose gradient sits in the fp32 noise may go
+                # the other way (2 lr apart), the bulk must agree to a fraction of the step
+                d = np.abs(got - g["param1:" + k])
+                assert float(d.max()) <= 2.2 * lrs[0] + 1e-7 and float(np.median(d)) < 0.1 * lrs[0] + 1e-7, k
+                assert float((d > 0.5 * lrs[0]).mean()) < 0.02, k
     assert np.allclose(lrs, g["lrs"], rtol=1e-9, atol=0)
     sd = m.state_dict()
     _check_bn(sd, g, meta, 2e-3)
