@@ -77,8 +77,24 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   // The first channel tile's weights of each contraction are requested one phase early (conv1's before the frames are
   // loaded, conv2's before conv1 runs, conv3's before the SE phase): a phase otherwise opens with a bare L2 round trip.
   const int NT_ = (C + 15) >> 4;
+  // PAIR (the 368-wide form, >= 16 channel tiles): a wave multiplies TWO of its channel tiles (wv, wv + 8) against each pixel
+  // fragment it reads, in two half-K blocks of 2 x KS/2 weight fragments -- the activation reads of conv1 / conv3, which bound
+  // those phases (a fragment read per MFMA: 7.9 k LDS cycles per contraction against 4.0 k of MFMA issue), fall by a third
+  // (the wave's third tile runs alone).  Same k order per output: bit-identical results.  Register cost: 7 more accumulators.
+  constexpr bool PAIR = KS >= 8 && KS % 2 == 0;
+  constexpr int KH = KS / 2;
   bf16x8 wc1[KS], wf2[5];
-  if (wv < NT_) {
+  auto load_block = [&](bf16x8 (&dst)[KS], const bf16x8* __restrict__ wsrc, int ta, int tb, int ks0) {
+    // dst[0 .. KH) = tile ta, k-steps ks0 .. ks0 + KH; dst[KH .. KS) = tile tb, the same k-steps
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      dst[k] = wsrc[((long)ta * KS + ks0 + k) * 64 + lane];
+      dst[KH + k] = wsrc[((long)tb * KS + ks0 + k) * 64 + lane];
+    }
+  };
+  if constexpr (PAIR) {
+    load_block(wc1, p.w1f, wv, wv + BNK_NW, 0);
+  } else if (wv < NT_) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wc1[ks] = p.w1f[((long)wv * KS + ks) * 64 + lane];
   }
@@ -184,8 +200,76 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     }
   };
 
+  // half a contraction of TWO channel tiles: k-steps ks0 .. ks0 + KH of both, one activation fragment read per pair of MFMAs
+  auto contract_half = [&](const bf16x8 (&wb)[KS], int ks0, const unsigned char* act, f32x4 (&acc0)[NPTM], f32x4 (&acc1)[NPTM]) {
+    bf16x8 a[NPTM];
+    const int kq = 16 * q;
+#pragma unroll
+    for (int pt = 0; pt < HA; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + 64 * ks0 + kq);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int kb = 64 * (ks0 + k) + kq;
+#pragma unroll
+      for (int pt = HA; pt < NPTM; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb);
+#pragma unroll
+      for (int pt = 0; pt < HA; ++pt) {
+        acc0[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k], a[pt], acc0[pt], 0, 0, 0);
+        acc1[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[KH + k], a[pt], acc1[pt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < KH) {
+#pragma unroll
+        for (int pt = 0; pt < HA; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb + 64);
+      }
+#pragma unroll
+      for (int pt = HA; pt < NPTM; ++pt) {
+        acc0[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k], a[pt], acc0[pt], 0, 0, 0);
+        acc1[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[KH + k], a[pt], acc1[pt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // epilogue of conv1 for one channel tile: BN + ReLU -> y1 rows in region B (channels >= C get exact zeros: row pad)
+  auto epi1 = [&](int T, const f32x4 (&acc)[NPTM]) {
+    const int ch0 = T * 16 + 4 * q;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + ch0), sh = *reinterpret_cast<const f32x4*>(bnv + CP + ch0);
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[pt][r] * sc[r] + sh[r], 0.f);
+      unsigned char* dst = At + srowA[pt];
+      TD_LDS_CHECK(((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) - smem, 8, (Tr + RS) - smem);
+      *reinterpret_cast<bf16x4*>((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) = o;
+    }
+  };
+
   // ---- P1: conv1: y1 = relu(bn(W1 x'))  (wave = channel tiles wv, wv + 8, ...)
-  {
+  if constexpr (PAIR) {
+    bf16x8 wn[KS];
+    if (wv < NT) {
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) wf2[ks] = p.w2f[((long)wv * 5 + ks) * 64 + lane];       // conv2's first unit
+    }
+    const int TA = wv, TB = wv + BNK_NW, TC = wv + 2 * BNK_NW;
+    load_block(wn, p.w1f, TA, TB, KH);                       // second half-K block of the pair
+    f32x4 acc0[NPTM], acc1[NPTM];
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) acc0[pt] = acc1[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    contract_half(wc1, 0, At, acc0, acc1);
+    if (TC < NT) {                                           // the third tile's weights travel under the second half
+      // (made unconditional with a clamped tile the kernel spills 158 VGPRs: measured 114 us; the branch stays)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wc1[ks] = p.w1f[((long)TC * KS + ks) * 64 + lane];
+    }
+    contract_half(wn, KH, At, acc0, acc1);
+    epi1(TA, acc0);
+    epi1(TB, acc1);
+    if (TC < NT) {
+      contract(wc1, At, acc0);
+      epi1(TC, acc0);
+    }
+  } else {
     bf16x8 (&wc)[KS] = wc1;
     bf16x8 wn[KS];
     if (wv < NT) {
@@ -349,7 +433,9 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   BN_STAMP(3);
 
   bf16x8 wc3[KS];
-  if (wv < NT) {
+  if constexpr (PAIR) {
+    load_block(wc3, p.w3f, wv, wv + BNK_NW, 0);
+  } else if (wv < NT) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wc3[ks] = p.w3f[((long)wv * KS + ks) * 64 + lane];
   }
@@ -380,7 +466,52 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   BN_STAMP(4);
 
   // ---- P4: conv3 on the gated y2, + residual x, ReLU -> output rows in region B
-  {
+  // residual of one channel tile: 4 channels of this lane's pixel per pixel tile, L2-hot
+  auto load_res = [&](int T, bf16x4 (&rres)[NPTM]) {
+    const int ch0 = T * 16 + 4 * q;
+    const bool cok = ch0 < C;
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) {
+      const int px = pt * 16 + pl;
+      rres[pt] = *reinterpret_cast<const bf16x4*>(xg + (long)((px < npix && cok) ? px : 0) * C + (cok ? ch0 : 0));
+    }
+  };
+  auto epi3 = [&](int T, const f32x4 (&acc)[NPTM], const bf16x4 (&rres)[NPTM]) {
+    const int ch0 = T * 16 + 4 * q;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 4 * CP + ch0), sh = *reinterpret_cast<const f32x4*>(bnv + 5 * CP + ch0);
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[pt][r] * sc[r] + sh[r] + (float)rres[pt][r], 0.f);
+      unsigned char* dst = At + srowA[pt];
+      *reinterpret_cast<bf16x4*>((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) = o;
+    }
+  };
+  if constexpr (PAIR) {
+    bf16x8 wn[KS];
+    const int TA = wv, TB = wv + BNK_NW, TC = wv + 2 * BNK_NW;
+    load_block(wn, p.w3f, TA, TB, KH);
+    bf16x4 rA[NPTM], rB[NPTM];
+    load_res(TA, rA);
+    f32x4 acc0[NPTM], acc1[NPTM];
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) acc0[pt] = acc1[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    contract_half(wc3, 0, At, acc0, acc1);
+    load_res(TB, rB);
+    if (TC < NT) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wc3[ks] = p.w3f[((long)TC * KS + ks) * 64 + lane];
+    }
+    contract_half(wn, KH, At, acc0, acc1);
+    epi3(TA, acc0, rA);
+    if (TC < NT) load_res(TC, rA);
+    epi3(TB, acc1, rB);
+    if (TC < NT) {
+      contract(wc3, At, acc0);
+      epi3(TC, acc0, rA);
+    }
+  } else {
     bf16x8 (&wc)[KS] = wc3;
     bf16x8 wn[KS];
     for (int T = wv; T < NT; T += BNK_NW) {
