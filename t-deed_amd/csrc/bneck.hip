@@ -54,7 +54,9 @@ template <int KS, int FPW, int NPTM>
 __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int hw = p.h * p.w, C = p.C;
-  const int f0 = blockIdx.x * FPW;
+  // frames in contiguous chunks per XCD, the numbering of the gate-shift launches in front of this one: the spliced columns
+  // (and most of x) arrive through the L2 they were written through
+  const int f0 = (int)xcd_logical_id(blockIdx.x, gridDim.x) * FPW;
   const int nfr = min(FPW, p.N - f0);                    // frames of this workgroup
   const int npix = nfr * hw;
   const int RS = bneck_rs(C);                            // activation row stride (bytes)

@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(256) void avgpool_posenc_kernel(const T* __restrict
                                                              float ln_eps) {
   constexpr int EPC = Chunk<T>::N;
   extern __shared__ float red[];       // [S][C]
-  const int f = blockIdx.x;            // frame = b*T + t
+  const int f = (int)xcd_logical_id(blockIdx.x, gridDim.x);    // frame = b*T + t, in the per-XCD chunks of the last block's launch
   const int t = f % T_len;
   const int nch = C / EPC;
   const int S = 256 / nch > 0 ? 256 / nch : 1;

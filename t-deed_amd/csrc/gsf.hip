@@ -196,10 +196,14 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
                                                          int band, int nch, int PSQ, int KS,
                                                          const float* __restrict__ bn_scale,
                                                          const float* __restrict__ bn_shift,
-                                                         const bf16x8* __restrict__ wqf, float* __restrict__ Q) {
+                                                         const bf16x8* __restrict__ wqf, float* __restrict__ Q,
+                                                         int nbq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smq[];
-  const int f = blockIdx.x;
-  const int y0 = blockIdx.y * band;
+  // frames in contiguous chunks per XCD (all three launches of a site use the same numbering): the maps of frames t-1 / t+1
+  // that the next launch reads were written through, and are read through, the same L2
+  const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int f = (int)(lid / nbq);
+  const int y0 = (int)(lid % nbq) * band;
   const int y1 = min(h, y0 + band);
   const int rows = y1 - y0 + 2, WP = w + 2;
   bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
                                                             float* __restrict__ gate, float* __restrict__ ysum,
                                                             float* __restrict__ xsum) {
   extern __shared__ float sm[];        // gates [hw][2], then partial sums [2][S][F]
-  const long f = blockIdx.x;
+  const long f = xcd_logical_id(blockIdx.x, gridDim.x);
   const int t = (int)(f % T_len);
   float* sg = sm;
   float* part = sm + 2 * hw;
@@ -379,8 +383,8 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
       if (bq > h) bq = h;
       const int nbq = cdiv(h, bq);
       const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ + (size_t)8 * F + (size_t)16 * KSq;
-      hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(B * T, nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
-                         nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q);
+      hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(B * T * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
+                         nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q, nbq);
       mfma_done = true;
     }
   }
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
                                                                    int C, int F, int Fp, int pchunk,
                                                                    bf16_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sma[];
-  const long f = blockIdx.x;
+  const long f = xcd_logical_id(blockIdx.x, gridDim.x);
   const int t = (int)(f % T_len);
   const long b = f / T_len;
   const int Fh = F >> 1, Fq = F >> 2, tid = threadIdx.x;
@@ -697,8 +701,12 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
       dnpc.divmod(i, pq, pj);
       const long off = (long)(p0 + pq) * C + pj * 4;
       vc[u] = *reinterpret_cast<const u32x2*>(x + f * hw * C + off);
-      vn[u] = *reinterpret_cast<const u32x2*>(x + fn * hw * C + off);
-      vp[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
+      // a piece's channels below Fh are shifted in from frame t+1, the others from frame t-1: only the piece that straddles
+      // Fh (F / 2 not a multiple of 4) needs both neighbours
+      vn[u] = (u32x2){0u, 0u};
+      vp[u] = (u32x2){0u, 0u};
+      if (pj * 4 < Fh) vn[u] = *reinterpret_cast<const u32x2*>(x + fn * hw * C + off);
+      if (pj * 4 + 3 >= Fh && pj * 4 < F) vp[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
     }
   };
   auto commit = [&](int pn, int total, int it) {
