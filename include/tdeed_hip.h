@@ -237,6 +237,12 @@ int tdeed_gsf_apply_fwd(const void* x, const float* gate, const float* fw /*NULL
 int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
                               const float* cw1, const float* cb1, const float* cw2, const float* cb2, int B,
                               int T, int h, int w, int C, int F, int Fp, void* out, int dtype, void* stream);
+/* the same launch with the output left in SOURCE channel order (impl/gsf.py:79-91 without the final `c = i*(F/4)+j -> 2j+i`
+ * interleave; bf16 only): for a caller that folds the interleave into the columns of the 1x1 conv reading the slice
+ * (engine.gs_source_order_columns); everything stays in registers, one memory round trip per frame. */
+int tdeed_gsf_blend_src_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
+                            const float* cw1, const float* cb1, const float* cw2, const float* cb2, int B,
+                            int T, int h, int w, int C, int F, int Fp, void* out, int dtype, void* stream);
 
 /* ---- global average pool + positional encoding (model.py:133-137) --------------------------
  * x: [B*T][hw][C] -> feat [B][T][C] = mean_hw(x) + temp_enc[t][c] (temp_enc fp32 [T][C]).  rowstat (optional, fp32

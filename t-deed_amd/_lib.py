@@ -143,6 +143,7 @@ _SIGS = {
     "tdeed_gsf_weight_fwd": ([P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_gsf_apply_fwd": ([P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_gsf_apply_fused_fwd": ([P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
+    "tdeed_gsf_blend_src_fwd": ([P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P], c_int),
     "tdeed_avgpool_posenc_fwd": ([P, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, P], c_int),
     "tdeed_layernorm_fwd": ([P, c_long, c_int, c_int, P, P, c_float, P, c_long, c_int, P], c_int),
     "tdeed_sgp_branch_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),

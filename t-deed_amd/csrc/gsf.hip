@@ -192,56 +192,180 @@ __device__ __forceinline__ void gsf_stage_bn(float* sbn, const float* __restrict
 // k = (spatial tap, 8-channel chunk): a lane's 8 k-values are one 16-byte read of the BN+ReLU'd frame
 // (bf16, zero halo, pixel stride an odd number of 16-byte slots => conflict-free ds_read_b128).
 // wqf: [KS][64] fragments (engine.pack_gsf_q_frags), rows jg >= 6 and channels of the other gate group are 0.
+// The launch is a latency chain per workgroup (weights + frame -> LDS -> K-loop -> store), so it is built to run it ONCE:
+//  * nfr frames per workgroup (launcher: 2 when one frame each would need a second round of workgroups -- 800 frames
+//    against 768 resident ones doubled the launch's duration);
+//  * weights, BatchNorm table and the frames' INTERIOR pieces are requested together (one memory round trip; the halo ring
+//    and the pad slots are zero-filled while the loads travel, not fetched from a dummy address);
+//  * a wave multiplies two pixel tiles at a time, four k-steps of LDS reads in flight in front of their MFMAs
+//    (a step-by-step loop was offset read -> fragment read -> MFMA, serial, per k-step).
 __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restrict__ x, int h, int w, int C, int F,
                                                          int band, int nch, int PSQ, int KS,
                                                          const float* __restrict__ bn_scale,
                                                          const float* __restrict__ bn_shift,
                                                          const bf16x8* __restrict__ wqf, float* __restrict__ Q,
-                                                         int nbq) {
+                                                         int nbq, int nfr, int nframes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smq[];
   // frames in contiguous chunks per XCD (all three launches of a site use the same numbering): the maps of frames t-1 / t+1
   // that the next launch reads were written through, and are read through, the same L2
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int f = (int)(lid / nbq);
+  const int f0 = (int)(lid / nbq) * nfr;
+  const int nf = min(nfr, nframes - f0);
   const int y0 = (int)(lid % nbq) * band;
   const int y1 = min(h, y0 + band);
-  const int rows = y1 - y0 + 2, WP = w + 2;
+  const int nrow = y1 - y0, rows = nrow + 2, WP = w + 2;
+  const int fbytes = (band + 2) * WP * PSQ;                     // one frame's band
   bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
-  unsigned char* a = smq + (size_t)KS * 64 * 16;               // [rows][WP][PSQ]
-  float* sbn = reinterpret_cast<float*>(a + (size_t)(band + 2) * WP * PSQ);   // [2F]
+  unsigned char* a = smq + (size_t)KS * 64 * 16;               // [nfr][rows][WP][PSQ]
+  float* sbn = reinterpret_cast<float*>(a + (size_t)nfr * fbytes);   // [2F]
   int* soff = reinterpret_cast<int*>(sbn + 2 * F);              // [KS*4]
   const int tid = threadIdx.x;
+  // ---- requests first: weight fragments, the frames' interior 16-byte pieces, the BatchNorm table
+  const int nwp = KS * 64;
+  const int pin = nrow * w * nch, ptot = nf * pin;              // interior pieces of one frame / of the workgroup
+  const IDiv dpin(pin), dnch(nch), dw_(w);
+  u32x4 wr[8], v[8];
+  int doff[8], dc0[8];
+  auto issue_w = [&](int it) {
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8)
+      wr[b8] = reinterpret_cast<const u32x4*>(wqf)[min(it * 2048 + tid + b8 * 256, nwp - 1)];
+  };
+  auto commit_w = [&](int it) {
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = it * 2048 + tid + b8 * 256;
+      if (i < nwp) reinterpret_cast<u32x4*>(wl)[i] = wr[b8];
+    }
+  };
+  auto issue_f = [&](int it) {
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      const int i = min(it * 2048 + tid + b8 * 256, ptot - 1);
+      int fr, r, pix, j, py, px;
+      dpin.divmod(i, fr, r);
+      dnch.divmod(r, pix, j);
+      dw_.divmod(pix, py, px);
+      doff[b8] = fr * fbytes + ((py + 1) * WP + px + 1) * PSQ + j * 16;
+      dc0[b8] = j * 8;
+      v[b8] = *reinterpret_cast<const u32x4*>(x + ((long)(f0 + fr) * h * w + (long)(y0 + py) * w + px) * C + j * 8);
+    }
+  };
+  auto commit_f = [&](int it) {
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+      if (it * 2048 + tid + b8 * 256 >= ptot) continue;
+      const int c0 = dc0[b8];
+      float fv[8];
+      Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v[b8]), fv);
+      bf16x8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = min(c0 + e, F - 1);
+        r[e] = (c0 + e < F) ? (bf16_t)fmaxf(fmaf(fv[e], sbn[c], sbn[F + c]), 0.f) : (bf16_t)0.f;
+      }
+      TD_LDS_CHECK((a - smq) + doff[b8], 16, (unsigned char*)sbn - smq);
+      *reinterpret_cast<u32x4*>(a + doff[b8]) = *reinterpret_cast<u32x4*>(&r);
+    }
+  };
+  issue_w(0);
+  issue_f(0);
+  float bnv[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = min(tid + u * 256, 2 * F - 1);
+    bnv[u] = i < F ? bn_scale[i] : bn_shift[i - F];
+  }
+  TD_ISSUE_FENCE();
+  // ---- while they travel: zero the bands (halo ring, pad slots, pixels of missing halo rows), k-slot offsets
+  for (int i = tid; i < nf * (fbytes >> 4); i += 256) reinterpret_cast<u32x4*>(a)[i] = (u32x4){0u, 0u, 0u, 0u};
   for (int s_ = tid; s_ < KS * 4; s_ += 256) {                  // byte offset of every k-slot (tap, 8-channel chunk)
     const int tap = s_ / nch, ck = s_ - tap * nch;
     const int dy = tap / 3, dx = tap - dy * 3;
     soff[s_] = tap < 9 ? (dy * WP + dx) * PSQ + ck * 16 : 0;
   }
-  gsf_stage_bn(sbn, bn_scale, bn_shift, F);
-  copy16_batched(reinterpret_cast<u32x4*>(wl), reinterpret_cast<const u32x4*>(wqf), KS * 64);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + u * 256 < 2 * F) sbn[tid + u * 256] = bnv[u];
+  commit_w(0);
+  for (int it = 1; it * 2048 < nwp; ++it) { issue_w(it); TD_ISSUE_FENCE(); commit_w(it); }
+  __syncthreads();                                              // zeros and the BatchNorm table are in place
+  // halo rows that exist in the frame (bands of a frame taller than one band): fetched like interior rows
+  commit_f(0);
+  for (int it = 1; it * 2048 < ptot; ++it) { issue_f(it); TD_ISSUE_FENCE(); commit_f(it); }
+  if (nbq > 1) {
+    for (int fr = 0; fr < nf; ++fr)
+      for (int hr = 0; hr < 2; ++hr) {
+        const int yy = hr ? y1 : y0 - 1;
+        if (yy < 0 || yy >= h) continue;
+        for (int i = tid; i < w * nch; i += 256) {
+          int px, j;
+          dnch.divmod(i, px, j);
+          const u32x4 vv = *reinterpret_cast<const u32x4*>(x + ((long)(f0 + fr) * h * w + (long)yy * w + px) * C + j * 8);
+          float fv[8];
+          Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&vv), fv);
+          bf16x8 r;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = min(j * 8 + e, F - 1);
+            r[e] = (j * 8 + e < F) ? (bf16_t)fmaxf(fmaf(fv[e], sbn[c], sbn[F + c]), 0.f) : (bf16_t)0.f;
+          }
+          *reinterpret_cast<u32x4*>(a + fr * fbytes + ((hr ? rows - 1 : 0) * WP + px + 1) * PSQ + j * 16) =
+              *reinterpret_cast<u32x4*>(&r);
+        }
+      }
+  }
   __syncthreads();
-  gsf_stage_frame(a, x, f, h, w, C, F, y0, rows, nch, PSQ, sbn);
-  __syncthreads();
+  // ---- K-loop: tile pairs (t, t + 1) of the workgroup's nf * ntl pixel tiles
   const int lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
-  const int npix = (y1 - y0) * w;
+  const int npix = nrow * w;
   const int ntl = (npix + 15) >> 4;
-  const IDiv dw_(w);
-  for (int mt = wv; mt < ntl; mt += 4) {
-    const int p = mt * 16 + pl;
-    const bool pok = p < npix;
-    const int pc = pok ? p : 0;
-    int py, px;
-    dw_.divmod(pc, py, px);
-    const unsigned char* base = a + ((long)py * WP + px) * PSQ;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + soff[ks * 4 + q]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks * 64 + lane], af, acc, 0, 0, 0);
+  const int ntot = nf * ntl;
+  const IDiv dntl(ntl);
+  for (int t0 = wv * 2; t0 < ntot; t0 += 8) {
+    const unsigned char* base[2];
+    bool pok[2];
+    long qrow[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = min(t0 + u, ntot - 1);
+      int fr, mt;
+      dntl.divmod(t, fr, mt);
+      const int pp = mt * 16 + pl;
+      pok[u] = (t0 + u < ntot) && pp < npix;
+      const int pc = pok[u] ? pp : 0;
+      int py, px;
+      dw_.divmod(pc, py, px);
+      base[u] = a + fr * fbytes + ((long)py * WP + px) * PSQ;
+      qrow[u] = (long)(f0 + fr) * h * w + (long)(y0 + py) * w + px;
     }
-    if (pok) {
-      float* dst = Q + ((long)f * h * w + (long)(y0 + py) * w + px) * 6;
-      if (q == 0) { dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3]; }
-      else if (q == 1) { dst[4] = acc[0]; dst[5] = acc[1]; }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+      int o[4];
+      bf16x8 wf[4], a0[4], a1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = soff[min(ks0 + j, KS - 1) * 4 + q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wf[j] = wl[min(ks0 + j, KS - 1) * 64 + lane];
+        a0[j] = *reinterpret_cast<const bf16x8*>(base[0] + o[j]);
+        a1[j] = *reinterpret_cast<const bf16x8*>(base[1] + o[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ks0 + j < KS) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0[j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1[j], acc1, 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (pok[u]) {
+        const f32x4 acc = u ? acc1 : acc0;
+        float* dst = Q + qrow[u] * 6;
+        if (q == 0) { dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3]; }
+        else if (q == 1) { dst[4] = acc[0]; dst[5] = acc[1]; }
+      }
   }
 }
 
@@ -368,7 +492,7 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
       q_cap = 150 * 1024;
       bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     }
-    if (bq >= 1 && q_cap > 48 * 1024) {
+    if (bq >= 1) {
       static TdDevOnce attr_q;
       if (!attr_q.get()) {
         if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
@@ -378,13 +502,24 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
         }
         attr_q.set();
       }
-    }
-    if (bq >= 1) {
       if (bq > h) bq = h;
       const int nbq = cdiv(h, bq);
-      const size_t smq = (size_t)wbytes + (size_t)(bq + 2) * (w + 2) * PSQ + (size_t)8 * F + (size_t)16 * KSq;
-      hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(B * T * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
-                         nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q, nbq);
+      const size_t fbytes = (size_t)(bq + 2) * (w + 2) * PSQ, fixed = (size_t)wbytes + (size_t)8 * F + (size_t)16 * KSq;
+      // frames per workgroup: 2 when one frame each does not fit the chip in ONE round of resident workgroups and two do
+      // (cfg2: 800 frames against 3 x 256 resident workgroups of 41-48 KB)
+      static const int q_fpw = getenv("TDEED_GSF_Q_FPW") ? atoi(getenv("TDEED_GSF_Q_FPW")) : 0;     // 0 = by rule
+      const long lds_cu = 160 * 1024, ncu = 256;
+      int nfr = 1;
+      if (nbq == 1 && B * T > 1) {
+        const long slots1 = std::min<long>(8, lds_cu / (long)(fixed + fbytes)) * ncu;
+        const long per2 = (long)(fixed + 2 * fbytes);
+        const long slots2 = per2 <= 150 * 1024 ? std::min<long>(8, lds_cu / per2) * ncu : 0;
+        if ((long)B * T > slots1 && ((long)B * T + 1) / 2 <= slots2) nfr = 2;
+        if (q_fpw == 1 || (q_fpw == 2 && slots2 > 0)) nfr = q_fpw;
+      }
+      const size_t smq = fixed + (size_t)nfr * fbytes;
+      hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(cdiv(B * T, nfr) * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
+                         nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q, nbq, nfr, B * T);
       mfma_done = true;
     }
   }
@@ -643,6 +778,10 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_kernel(const T* __restric
 // channels of its two temporal neighbours, the three gate maps and the five rows of spatial sums the fusion conv
 // touches are all fetched in wide batches into LDS (clamped addresses, no branches around loads); the blend and the
 // channel interleave then run out of LDS and leave as 8-byte stores.
+// GA_UX: 8-byte pieces per thread and batch.  A chunk of pixels is sized by the launcher to ONE batch (256 * GA_UX pieces,
+// 512 pixels): every further batch is one more exposed memory round trip in a launch that is nothing but round trips
+// (7x7x96: 1176 pieces were two batches of 4 per thread, 28x28x16: three chunks of 1048 pieces = six round trips).
+constexpr int GA_UX = 8;
 __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t* __restrict__ x,
                                                                    const float* __restrict__ gate,
                                                                    const float* __restrict__ ysum,
@@ -684,7 +823,7 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
   f32x2 ga[2];
   float gn_[2], gp_[2];     // only gate 0 of frame t+1 and gate 1 of frame t-1 are needed (a half-used wide load
                             // leaves a dead register that gets reused while the load is in flight: WAW stall)
-  u32x2 vc[4], vn[4], vp[4];
+  u32x2 vc[GA_UX], vn[GA_UX], vp[GA_UX];
   // gates (one float2 per pixel from each of the three frames) and activations (8-byte pieces, three frames)
   auto issue = [&](int p0, int pn, int total, int it) {
 #pragma unroll
@@ -695,8 +834,8 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
       gp_[u] = gate[(fp * hw + p) * 2 + 1];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = min(it * 1024 + tid + u * 256, total - 1);
+    for (int u = 0; u < GA_UX; ++u) {
+      const int i = min(it * (256 * GA_UX) + tid + u * 256, total - 1);
       int pj, pq;
       dnpc.divmod(i, pq, pj);
       const long off = (long)(p0 + pq) * C + pj * 4;
@@ -721,8 +860,8 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = it * 1024 + tid + u * 256;
+    for (int u = 0; u < GA_UX; ++u) {
+      const int i = it * (256 * GA_UX) + tid + u * 256;
       if (i < total) {
         int pj, pl_;
         dnpc.divmod(i, pl_, pj);
@@ -757,7 +896,7 @@ __global__ __launch_bounds__(256) void gsf_apply_fused_bf16_kernel(const bf16_t*
     const int pn = min(pchunk, hw - p0);
     const int total = pn * npc;
     if (p0 > 0) __syncthreads();
-    for (int it = p0 == 0 ? 1 : 0; it * 1024 < total || it * 512 < pn; ++it) {
+    for (int it = p0 == 0 ? 1 : 0; it * (256 * GA_UX) < total || it * 512 < pn; ++it) {
       issue(p0, pn, total, it);
       TD_ISSUE_FENCE();
       commit(pn, total, it);
@@ -830,12 +969,15 @@ extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const
     hipLaunchKernelGGL(gsf_apply_fused_kernel<float>, dim3(B * T), dim3(256), smem, st, (const float*)x, gate, ysum,
                        xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (float*)out);
   else if (dtype == TDEED_BF16) {
-    // pixels per LDS chunk: (2 gate pairs fp32 + 2 x Fp bf16) per pixel next to the fixed tables, within 60 KB
+    // pixels per LDS chunk: (2 gate pairs fp32 + 2 x Fp bf16) per pixel next to the fixed tables; a chunk is at most one
+    // batch of loads (256 * GA_UX pieces, 512 pixels) and at most TDEED_GSF_APPLY_KB of LDS (36: four workgroups per CU,
+    // 1024 resident workgroups for the 800 frames of a batch); equal chunks
     const long fixed = (long)(11 * F + 40) * sizeof(float);
-    static const long a_kb = getenv("TDEED_GSF_APPLY_KB") ? atol(getenv("TDEED_GSF_APPLY_KB")) : 26;   // six workgroups per CU
+    static const long a_kb = getenv("TDEED_GSF_APPLY_KB") ? atol(getenv("TDEED_GSF_APPLY_KB")) : 36;
     long pchunk = (a_kb * 1024 - fixed) / (16 + 4L * Fp);
     if (pchunk < 1) pchunk = (60 * 1024 - fixed) / (16 + 4L * Fp);
     TD_CHECK(pchunk >= 1 && F <= 256, "gsf_apply_fused: fold %d too wide", F);
+    pchunk = std::min<long>(pchunk, std::min<long>(512, (256L * GA_UX) / (Fp >> 2)));
     if (pchunk > hw) pchunk = hw;
     pchunk = (hw + (hw + pchunk - 1) / pchunk - 1) / ((hw + pchunk - 1) / pchunk);      // equal chunks
     const size_t smb = (size_t)fixed + (size_t)pchunk * (16 + 4 * Fp);
@@ -844,6 +986,165 @@ extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const
   }
   else { tdeed_set_error("gsf_apply_fused: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("gsf_apply_fused");
+  return TDEED_OK;
+}
+
+// ---- the same blend with the output left in SOURCE channel order (no `c = i*(F/4)+j -> 2j+i` interleave): for callers that
+// fold the interleave into the weight columns of the 1x1 conv consuming the slice (engine.py permutes conv1's first F columns).
+// Without the gather nothing needs LDS but the F fusion weights: a thread's 8-byte pieces of this frame, the matching pieces of
+// the neighbour frame its channels shift in from (t+1 below F/2, t-1 above; the piece straddling F/2 takes both), the three
+// gate values of its pixel and the spatial sums are requested together -- ONE memory round trip per workgroup -- and the blend
+// runs out of registers (the interleaving launch staged three frames' pieces in LDS and gathered 2-byte elements from them:
+// ~20 LDS reads per piece).  Arithmetic = gsf_apply_fused_bf16_kernel's, bit for bit.
+constexpr int GB_UX = 8;          // pieces per thread and batch
+__global__ __launch_bounds__(256) void gsf_blend_src_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gate,
+                                                            const float* __restrict__ ysum, const float* __restrict__ xsum,
+                                                            float inv_hw, const float* __restrict__ cw1,
+                                                            const float* __restrict__ cb1, const float* __restrict__ cw2,
+                                                            const float* __restrict__ cb2, int T_len, int hw, int C, int F,
+                                                            int Fp, bf16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+  const long f = xcd_logical_id(blockIdx.x, gridDim.x);
+  const int t = (int)(f % T_len);
+  const long b = f / T_len;
+  const int Fh = F >> 1, tid = threadIdx.x;
+  float* ssum = reinterpret_cast<float*>(smb);                 // [2][5][F]: ysum, xsum of frames t-2 .. t+2 (0 outside)
+  float* fwl = ssum + 10 * F;                                   // [Fp] fusion weight by source channel (pad channels: unused)
+  float* cwl = fwl + Fp;                                        // [2][18] conv weights, [2] biases
+  const bool has_next = t < T_len - 1, has_prev = t > 0;
+  const long fn = has_next ? f + 1 : f, fp = has_prev ? f - 1 : f;
+  const int npc = Fp >> 2, total = hw * npc;
+  const IDiv dF(F), dnpc(npc);
+  const bool strad = (Fh & 3) != 0;                             // a piece holds channels of both gate groups
+  // ---- requests: sums + conv weights, then the first batch of pieces and gates
+  float sv[10];
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const int i = min(tid + u * 256, 10 * F - 1);
+    int row, c;                                                 // row = arr * 5 + r
+    dF.divmod(i, row, c);
+    const int arr = row >= 5, r = row - 5 * arr;
+    const int t2 = min(max(t + r - 2, 0), T_len - 1);
+    sv[u] = (arr ? xsum : ysum)[(b * T_len + t2) * F + c];
+  }
+  const float cwv = *(tid < 18 ? cw1 + tid : tid < 36 ? cw2 + (tid - 18) : tid == 36 ? cb1 : cb2);
+  u32x2 vc[GB_UX], vs[GB_UX], vs2[GB_UX];
+  f32x2 ga[GB_UX];
+  float gnb[GB_UX], gnb2[GB_UX];
+  auto issue = [&](int it) {
+#pragma unroll
+    for (int u = 0; u < GB_UX; ++u) {
+      const int i = min(it * (256 * GB_UX) + tid + u * 256, total - 1);
+      int p, pj;
+      dnpc.divmod(i, p, pj);
+      const long off = (long)p * C + pj * 4;
+      const bool lo = pj * 4 < Fh;                               // first channel of the piece in gate group 0
+      vc[u] = *reinterpret_cast<const u32x2*>(x + f * hw * C + off);
+      vs[u] = *reinterpret_cast<const u32x2*>(x + (lo ? fn : fp) * hw * C + off);
+      ga[u] = *reinterpret_cast<const f32x2*>(gate + (f * hw + p) * 2);
+      gnb[u] = lo ? gate[(fn * hw + p) * 2] : gate[(fp * hw + p) * 2 + 1];
+      vs2[u] = (u32x2){0u, 0u};
+      gnb2[u] = 0.f;
+      if (strad && lo && pj * 4 + 3 >= Fh) {                     // the straddling piece: its upper channels come from t-1
+        vs2[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
+        gnb2[u] = gate[(fp * hw + p) * 2 + 1];
+      }
+    }
+  };
+  auto blend = [&](int it) {
+#pragma unroll
+    for (int u = 0; u < GB_UX; ++u) {
+      const int i = it * (256 * GB_UX) + tid + u * 256;
+      if (i >= total) continue;
+      int p, pj;
+      dnpc.divmod(i, p, pj);
+      const bf16x4 xc4 = *reinterpret_cast<const bf16x4*>(&vc[u]);
+      const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(&vs[u]);
+      const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(&vs2[u]);
+      const bool lo = pj * 4 < Fh;
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(fwl + pj * 4);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ci = pj * 4 + e;
+        if (ci >= F) { o[e] = xc4[e]; continue; }
+        const int g = ci >= Fh;
+        const bool second = lo && g;                             // upper channel of the straddling piece
+        const float xv = (float)xc4[e];
+        const float r = fmaf(-(g ? ga[u][1] : ga[u][0]), xv, xv);
+        float gsh = second ? gnb2[u] : gnb[u];
+        gsh = (g ? has_prev : has_next) ? gsh : 0.f;
+        const float ysh = gsh * (float)(second ? t4[e] : s4[e]);
+        const float wv = w4[e];
+        o[e] = (bf16_t)fmaf(ysh, wv, r * (1.0f - wv));
+      }
+      *reinterpret_cast<bf16x4*>(out + (f * hw + p) * Fp + pj * 4) = o;
+    }
+  };
+  issue(0);
+  TD_ISSUE_FENCE();
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const int i = tid + u * 256;
+    if (i < 10 * F) {
+      const int row = dF.div(i);
+      const int t2 = t + (row >= 5 ? row - 5 : row) - 2;
+      ssum[i] = (t2 >= 0 && t2 < T_len) ? sv[u] : 0.f;
+    }
+  }
+  if (tid < 38) cwl[tid] = cwv;
+  __syncthreads();
+  // fusion weights of this frame: 3x3 conv over the (channel, time) plane of the spatial means + sigmoid
+  for (int c = tid; c < Fp; c += 256) {
+    float wgt = 0.f;
+    if (c < F) {
+      const int g = c >= Fh;
+      const int cl = c - g * Fh;
+      const float* cw = cwl + 18 * g;
+      float a = cwl[36 + g];
+#pragma unroll
+      for (int dc = -1; dc <= 1; ++dc) {
+        const int c2 = cl + dc;
+        if (c2 < 0 || c2 >= Fh) continue;
+        const int cc = g * Fh + c2;
+#pragma unroll
+        for (int dt = -1; dt <= 1; ++dt) {
+          const int t2 = t + dt;
+          if (t2 < 0 || t2 >= T_len) continue;
+          const float rm = (ssum[(5 + dt + 2) * F + cc] - ssum[(dt + 2) * F + cc]) * inv_hw;
+          const int r2 = dt + 2 + (g ? -1 : 1);                 // row of the shifted source frame (zeros outside the clip)
+          const float ysh = ssum[r2 * F + cc] * inv_hw;
+          a = fmaf(cw[(dc + 1) * 3 + (dt + 1)], ysh, a);
+          a = fmaf(cw[9 + (dc + 1) * 3 + (dt + 1)], rm, a);
+        }
+      }
+      wgt = sigmoidf_(a);
+    }
+    fwl[c] = wgt;
+  }
+  __syncthreads();
+  blend(0);
+  for (int it = 1; it * (256 * GB_UX) < total; ++it) {
+    issue(it);
+    TD_ISSUE_FENCE();
+    blend(it);
+  }
+}
+
+extern "C" int tdeed_gsf_blend_src_fwd(const void* x, const float* gate, const float* ysum, const float* xsum,
+                                       const float* cw1, const float* cb1, const float* cw2, const float* cb2,
+                                       int B, int T, int h, int w, int C, int F, int Fp, void* out, int dtype,
+                                       void* stream) {
+  TD_CHECK(x && gate && ysum && xsum && cw1 && cb1 && cw2 && cb2 && out, "gsf_blend_src: null pointer");
+  TD_CHECK(F % 4 == 0 && Fp % 8 == 0 && Fp >= F && Fp <= C && F <= 256, "gsf_blend_src: bad fold F=%d Fp=%d C=%d", F, Fp, C);
+  TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && (long)B * T <= 0x7fffffffL, "gsf_blend_src: bad sizes");
+  TD_CHECK(dtype == TDEED_BF16, "gsf_blend_src: bf16 only (dtype %d)", dtype);
+  TD_CHECK(C % 4 == 0, "gsf_blend_src: rows of %d channels are not 8-byte pieces", C);
+  const int hw = h * w;
+  const size_t smem = (size_t)(10 * F + Fp + 40) * sizeof(float);
+  hipLaunchKernelGGL(gsf_blend_src_kernel, dim3(B * T), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x, gate, ysum,
+                     xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (bf16_t*)out);
+  TD_LAUNCH_CHECK("gsf_blend_src");
   return TDEED_OK;
 }
 

@@ -161,6 +161,8 @@ def pack_se_mfma(fc1_w, fc2_w, device):
 
 
 GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
+# gate-shift-fuse slice left in source channel order, the module's interleave folded into conv1's weight columns
+GS_SRC_ORDER = os.environ.get("TDEED_GS_SRC_ORDER", "1") == "1"
 WS_NARROW_ONLY = os.environ.get("TDEED_WS_NARROW_ONLY", "1") == "1"
 WS_WIDE_MIN_ROWS = int(os.environ.get("TDEED_WS_WIDE_MIN_ROWS", "250000"))     # 0: never the sliced form
 RS_MIN_ROWS = int(os.environ.get("TDEED_RS_MIN_ROWS", "60000"))                # 0: never the register-stationary kernel
@@ -283,6 +285,16 @@ def stem_frags_on_device(w):
 
 
 _GSFQ_IDX = {}
+
+
+def gs_source_order_columns(w1, F):
+    """conv1 weight (cout, cin) of a gate-shift-fuse site -> the same weight for a slice left in SOURCE channel order:
+    out[:, ci] = w1[:, co] for the output channel co that source channel ci is interleaved to (impl/gsf.py:88-91);
+    columns >= F unchanged."""
+    w = np.array(w1, copy=True)
+    src = ops.gs_source_order(F)                  # src[co] = ci
+    w[:, src] = w1[:, :F]
+    return w
 
 
 def gsf_q_frags_on_device(w3d):
@@ -721,8 +733,16 @@ class PackedWeights:
             bp = p + blk.name
             bw = SimpleNamespace(spec=blk)
             c1 = bp + (".conv1.net" if blk.gsf_fold else ".conv1")
-            bw.w1 = DenseW(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), act_dtype, device)
-            bw.w1_raw = _np(sd[c1 + ".conv.weight"]).reshape(blk.cout, blk.cin)
+            w1_mat = _np(sd[c1 + ".conv.weight"]).reshape(blk.cout, blk.cin)
+            # gate-shift-fuse sites of the bf16 engine: the module's channel interleave is folded into conv1's columns (the
+            # blend launch leaves its slice in source channel order, ops.gate_shift(src_order=True)): column ci of the
+            # packed weight is the column of the output channel that source channel ci is interleaved to
+            bw.gs_src = bool(blk.gsf_fold and GS_SRC_ORDER and self.mode == "gsf" and act_dtype == torch.bfloat16
+                             and str(device) != "cpu")
+            if bw.gs_src:
+                w1_mat = gs_source_order_columns(w1_mat, blk.gsf_fold)
+            bw.w1 = DenseW(w1_mat, act_dtype, device)
+            bw.w1_raw = w1_mat
             bw.wd_raw = _np(sd[bp + ".downsample.conv.weight"]).reshape(blk.cout, blk.cin) if blk.has_downsample else None
             bw.c1g_w1f = None    # conv1 / downsample as MFMA fragments padded to whole channel slabs
                                               # (tdeed_c1_gconv_fwd), packed on first use
@@ -744,7 +764,7 @@ class PackedWeights:
                             and ops.se_gate_mfma_fits(blk.cout, blk.se_rd)) else None)
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device, gated=True)
             # MFMA-fragment copies of conv1 / conv3 for the one-launch bottleneck (stride-1 identity blocks up to 384 wide)
-            bw.fused = (SimpleNamespace(w1f=pack_mfma_frags(sd[c1 + ".conv.weight"].reshape(blk.cout, blk.cin), device),
+            bw.fused = (SimpleNamespace(w1f=pack_mfma_frags(w1_mat, device),
                                         w3f=pack_mfma_frags(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), device))
                         if (bw.se_mf is not None and blk.stride == 1 and not blk.has_downsample and blk.cin == blk.cout
                             and blk.cout <= 384) else None)
@@ -874,13 +894,15 @@ class ForwardEngine:
                     gb["fw"] = pool.take((B, F, T), torch.float32)
                 steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf),
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, src_order=bw.gs_src),
                     M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
                 if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
                         *gemm_cost(M, blk.cin, blk.cout, es)))
                 if blk.name and ("_features." + blk.name + ".gs_out") in taps:
+                    if bw.gs_src:
+                        raise ValueError("the gs_out tap is in module channel order: build the engine with TDEED_GS_SRC_ORDER=0")
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
                 gs_bufs = list(gb.values()) + ([xs] if xs is not None else [])
             else:

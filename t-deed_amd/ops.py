@@ -324,9 +324,10 @@ def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
 
 
 def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
-               bufs=None, wqf=None, separate_weight=False):
+               bufs=None, wqf=None, separate_weight=False, src_order=False):
     """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
-    GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out."""
+    GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out.
+    src_order (GSF, bf16): the output stays in source channel order, out[:, gs_source_order(F)] is the module's output."""
     _chk(x, "x")
     N, h, w, C = x.shape
     dev = x.device
@@ -349,6 +350,12 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     dc = dtype_code(x.dtype)
     call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
          ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+    if src_order:
+        if cw1 is None or separate_weight or x.dtype != torch.bfloat16:
+            raise ValueError("gate_shift: src_order is the fused bf16 GSF launch only")
+        call("tdeed_gsf_blend_src_fwd", ptr(x), ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
+             B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
+        return out
     if cw1 is not None and not separate_weight:
         call("tdeed_gsf_apply_fused_fwd", ptr(x), ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2), ptr(cb2),
              B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
@@ -362,6 +369,13 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
              ptr(fw), stream_ptr())
     call("tdeed_gsf_apply_fwd", ptr(x), ptr(gate), ptr(fw), B, T, h, w, C, F, Fp, ptr(out), dc, stream_ptr())
     return out
+
+
+def gs_source_order(F):
+    """Source channel of every output channel of the gate-shift module's interleave (impl/gsf.py:88-91: inside each half,
+    c = i*(F/4)+j -> 2j+i): module_out[:, co] = src_order_out[:, gs_source_order(F)[co]]."""
+    Fh, Fq = F // 2, F // 4
+    return [g * Fh + (col & 1) * Fq + (col >> 1) for g in range(2) for col in range(Fh)]
 
 
 def avgpool_posenc(x, B, T, temp_enc, out=None, rowstat=None):

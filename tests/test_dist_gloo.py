@@ -107,7 +107,7 @@ def test_reducer_self_diagnosis_times_every_bucket_on_two_ranks():
     for rank, m, first, last in res:
         assert [b["bucket"] for b in m] == [0, 1]
         assert m[0]["collective"] == "rs_ag" and m[1]["collective"] == "all_reduce"      # 12 KB >= 8 KB, 4 KB below
-        assert m[0]["mb"] == round(3072 * 4 / 2 ** 20, 2) and all(b["ms"] > 0 and b["busbw_GBps"] > 0 for b in m)
+        assert m[0]["mb"] == round(3072 * 4 / 2 ** 20, 2) and all(b["ms"] > 0 and b["busbw_GBps"] >= 0 for b in m)   # (KB-sized buckets over gloo: the bandwidth can round to 0.00)
         assert first == 4.0 and last == 4.0          # two repetitions of a sum over two ranks: 1 -> 2 -> 4 in both buckets
 
 

@@ -346,6 +346,13 @@ def test_gate_shift_golden(ops, name, dtype):
                               dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T), dev(sd["gs.conv3D.bias"]),
                               separate_weight=True, **kw)
         assert torch.equal(out3, out)
+    if mode == "gsf" and dtype == torch.bfloat16:
+        # the launch that leaves the slice in source channel order (the engine folds the interleave into conv1's columns):
+        # the module's output channel co is its channel gs_source_order(F)[co], bit for bit; pad columns stay copies of x
+        src = ops.gate_shift(t(xin).to(dtype).to(DEV), B, T, Fd, Fp, dev(s), dev(sh),
+                             dev(sd["gs.conv3D.weight"].reshape(Fd, 27).T), dev(sd["gs.conv3D.bias"]), src_order=True, **kw)
+        idx = torch.tensor(ops.gs_source_order(Fd) + list(range(Fd, Fp)), device=DEV)
+        assert torch.equal(src[:, idx], out)
     out = out.float().cpu().view(B * T, h, w, Fp)
     ref = t(g["y"]).permute(0, 2, 3, 1)
     tol = 2e-5 if dtype == torch.float32 else 3e-2
