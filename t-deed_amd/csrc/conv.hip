@@ -1188,8 +1188,11 @@ extern "C" int tdeed_avgpool_posenc_fwd(const void* x, int B, int T, int hw, int
 // round trip + ~50 MFMAs per wave instead of the VALU kernel's three dependent round trips and ~2000 FMAs per lane.
 // The fp32 operands (pooled means, hidden units) are split hi + lo into two bf16 MFMAs: bf16 weights, fp32-accurate
 // activations, the numerics of se_gate_bf16_kernel.
-template <int KS1M, int NT1M, int NT2M, int KS2M>
-__global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restrict__ pooled, int n_parts, float inv_cnt,
+// NW waves; LATE2: the fc2 fragments are requested behind the fc1 MFMAs instead of up front (the wide form -- C <= 768,
+// R <= 192: 48 + 36 fragments per lane do not fit the register file together; their round trip then overlaps the barrier and
+// the hidden units' LDS writes).
+template <int KS1M, int NT1M, int NT2M, int KS2M, int NW = 4, bool LATE2 = false>
+__global__ __launch_bounds__(NW * 64) void se_gate_mfma_kernel(const float* __restrict__ pooled, int n_parts, float inv_cnt,
                                                            int N, int C, int R, const bf16x8* __restrict__ w1f,
                                                            const float* __restrict__ b1,
                                                            const bf16x8* __restrict__ w2f,
@@ -1207,45 +1210,59 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
   // ---- issue: weights, biases (clamped indices: never a branch around a load)
   bf16x8 w1r[NT1M][KS1M], w2r[NT2M][KS2M];
   float b1v[NT1M][4], b2v[NT2M][4];
+  auto load_w1 = [&]() {
+#pragma unroll
+    for (int a = 0; a < NT1M; ++a) {
+      const int tc = min(wv + NW * a, RT - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS1M; ++ks) w1r[a][ks] = w1f[((long)tc * KS1 + min(ks, KS1 - 1)) * 64 + lane];
+    }
+  };
+  if constexpr (!LATE2) load_w1();        // (wide form: behind the staging of the means, whose batches need the registers)
 #pragma unroll
   for (int a = 0; a < NT1M; ++a) {
-    const int tc = min(wv + 4 * a, RT - 1);
-#pragma unroll
-    for (int ks = 0; ks < KS1M; ++ks) w1r[a][ks] = w1f[((long)tc * KS1 + min(ks, KS1 - 1)) * 64 + lane];
+    const int tc = min(wv + NW * a, RT - 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) b1v[a][e] = b1[min(tc * 16 + 4 * q + e, R - 1)];
   }
+  auto load_w2 = [&]() {
+#pragma unroll
+    for (int a = 0; a < NT2M; ++a) {
+      const int tc = min(wv + NW * a, CT - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS2M; ++ks) w2r[a][ks] = w2f[((long)tc * KS2 + min(ks, KS2 - 1)) * 64 + lane];
+    }
+  };
+  if constexpr (!LATE2) load_w2();
 #pragma unroll
   for (int a = 0; a < NT2M; ++a) {
-    const int tc = min(wv + 4 * a, CT - 1);
-#pragma unroll
-    for (int ks = 0; ks < KS2M; ++ks) w2r[a][ks] = w2f[((long)tc * KS2 + min(ks, KS2 - 1)) * 64 + lane];
+    const int tc = min(wv + NW * a, CT - 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) b2v[a][e] = b2[min(tc * 16 + 4 * q + e, C - 1)];
   }
   // ---- pooled sums -> means -> hi/lo bf16 in LDS
   const int c4n = C >> 2, nitems = 16 * c4n;
-  const int NS = nitems >= 256 ? 1 : min(256 / nitems, n_parts);        // part slices summed in parallel
+  const int NS = nitems >= NW * 64 ? 1 : min(NW * 64 / nitems, n_parts);   // part slices summed in parallel
   const IDiv dit(nitems), dc4(c4n);
-  for (int i = tid; i < 16 * PS1 / 8; i += 256) {                        // zero both P arrays (pad columns must be 0)
+  for (int i = tid; i < 16 * PS1 / 8; i += NW * 64) {                        // zero both P arrays (pad columns must be 0)
     reinterpret_cast<u32x4*>(Phi)[i] = (u32x4){0u, 0u, 0u, 0u};
     reinterpret_cast<u32x4*>(Plo)[i] = (u32x4){0u, 0u, 0u, 0u};
   }
-  for (int i = tid; i < 16 * PS2 / 8; i += 256) {
+  for (int i = tid; i < 16 * PS2 / 8; i += NW * 64) {
     reinterpret_cast<u32x4*>(Hhi)[i] = (u32x4){0u, 0u, 0u, 0u};
     reinterpret_cast<u32x4*>(Hlo)[i] = (u32x4){0u, 0u, 0u, 0u};
   }
   __syncthreads();
   if (NS == 1) {
-    // wide layers (>= 256 float4 items, few partial rows): 8 items per lane per batch, all loads of a batch in flight
-    for (int i0 = tid; i0 < nitems; i0 += 256 * 8) {
+    // wide layers (>= one float4 item per thread, few partial rows): 8 items per lane per batch, all loads of a batch in flight
+    for (int i0 = tid; i0 < nitems; i0 += NW * 64 * 8) {
       f32x4 acc[8];
       int fo[8];
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int f, c4;
-        dc4.divmod(min(i0 + b * 256, nitems - 1), f, c4);
+        dc4.divmod(min(i0 + b * NW * 64, nitems - 1), f, c4);
         fo[b] = f * PS1 + c4 * 4;
       }
       for (int p = 0; p < n_parts; ++p) {
@@ -1253,7 +1270,7 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
           int f, c4;
-          dc4.divmod(min(i0 + b * 256, nitems - 1), f, c4);
+          dc4.divmod(min(i0 + b * NW * 64, nitems - 1), f, c4);
           v[b] = *reinterpret_cast<const f32x4*>(pooled + ((long)min(f0 + f, N - 1) * n_parts + p) * C + c4 * 4);
         }
 #pragma unroll
@@ -1261,7 +1278,7 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
       }
 #pragma unroll
       for (int b = 0; b < 8; ++b)
-        if (i0 + b * 256 < nitems) {
+        if (i0 + b * NW * 64 < nitems) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float m = acc[b][e] * inv_cnt;
@@ -1273,7 +1290,7 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
     }
   } else {
     // narrow layers with many partial rows (s1: 56 per frame): slices of the partial rows summed in parallel
-    for (int i = tid; i < nitems * NS; i += 256) {
+    for (int i = tid; i < nitems * NS; i += NW * 64) {
       int slice, item, f, c4;
       dit.divmod(i, slice, item);
       dc4.divmod(item, f, c4);
@@ -1292,7 +1309,7 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
   }
   if (NS > 1) {
     __syncthreads();
-    for (int item = tid; item < nitems; item += 256) {
+    for (int item = tid; item < nitems; item += NW * 64) {
       int f, c4;
       dc4.divmod(item, f, c4);
       f32x4 acc = red[item];
@@ -1309,11 +1326,12 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
       }
     }
   }
+  if constexpr (LATE2) load_w1();
   __syncthreads();
   // ---- phase 1: hidden units
 #pragma unroll
   for (int a = 0; a < NT1M; ++a) {
-    const int tile = wv + 4 * a;
+    const int tile = wv + NW * a;
     if (tile < RT) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1334,11 +1352,12 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
       }
     }
   }
+  if constexpr (LATE2) load_w2();
   __syncthreads();
   // ---- phase 2: gates
 #pragma unroll
   for (int a = 0; a < NT2M; ++a) {
-    const int tile = wv + 4 * a;
+    const int tile = wv + NW * a;
     if (tile < CT) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1360,7 +1379,8 @@ __global__ __launch_bounds__(256) void se_gate_mfma_kernel(const float* __restri
   }
 }
 
-extern "C" int tdeed_se_gate_mfma_fits(int C, int R) { return C % 8 == 0 && C <= 384 && R >= 1 && R <= 96; }
+// C <= 384, R <= 96: everything in registers up front, 4 waves; up to C = 768, R = 192 (RegNetY-800MF s4): 8 waves, LATE2
+extern "C" int tdeed_se_gate_mfma_fits(int C, int R) { return C % 8 == 0 && C <= 768 && R >= 1 && R <= 192; }
 
 extern "C" int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float inv_cnt, int N, int C, int R,
                                       const void* w1f, const float* b1, const void* w2f, const float* b2, float* gate,
@@ -1368,12 +1388,29 @@ extern "C" int tdeed_se_gate_mfma_fwd(const float* pooled, int n_parts, float in
   TD_CHECK(pooled && w1f && b1 && w2f && b2 && gate, "se_gate_mfma: null pointer");
   TD_CHECK(N > 0 && n_parts > 0 && tdeed_se_gate_mfma_fits(C, R), "se_gate_mfma: C=%d R=%d unsupported", C, R);
   const int KS1 = (C + 31) / 32, KS2 = (R + 31) / 32;
+  const bool wide = C > 384 || R > 96;
+  const int thr = wide ? 512 : 256;
   const int nitems = 16 * (C / 4);
-  const int NS = nitems >= 256 ? 1 : (256 / nitems < n_parts ? 256 / nitems : n_parts);
+  const int NS = nitems >= thr ? 1 : (thr / nitems < n_parts ? thr / nitems : n_parts);
   const size_t smem = (size_t)2 * 16 * (KS1 * 32 + 8) * 2 + (size_t)2 * 16 * (KS2 * 32 + 8) * 2 +
                       (NS > 1 ? (size_t)NS * nitems * 16 : 0);
-  hipLaunchKernelGGL((se_gate_mfma_kernel<12, 2, 6, 3>), dim3(cdiv(N, 16)), dim3(256), smem, (hipStream_t)stream, pooled,
-                     n_parts, inv_cnt, N, C, R, (const bf16x8*)w1f, b1, (const bf16x8*)w2f, b2, gate);
+  if (wide) {
+    static TdDevOnce attr_w;
+    if (!attr_w.get()) {
+      if (hipFuncSetAttribute((const void*)se_gate_mfma_kernel<24, 2, 6, 6, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024) != hipSuccess) {
+        tdeed_set_error("se_gate_mfma: hipFuncSetAttribute failed");
+        return TDEED_ERR_RUNTIME;
+      }
+      attr_w.set();
+    }
+    TD_CHECK(smem <= 96 * 1024, "se_gate_mfma: C=%d R=%d n_parts=%d need %zu B of LDS", C, R, n_parts, smem);
+    hipLaunchKernelGGL((se_gate_mfma_kernel<24, 2, 6, 6, 8, true>), dim3(cdiv(N, 16)), dim3(512), smem, (hipStream_t)stream,
+                       pooled, n_parts, inv_cnt, N, C, R, (const bf16x8*)w1f, b1, (const bf16x8*)w2f, b2, gate);
+  } else {
+    hipLaunchKernelGGL((se_gate_mfma_kernel<12, 2, 6, 3>), dim3(cdiv(N, 16)), dim3(256), smem, (hipStream_t)stream, pooled,
+                       n_parts, inv_cnt, N, C, R, (const bf16x8*)w1f, b1, (const bf16x8*)w2f, b2, gate);
+  }
   TD_LAUNCH_CHECK("se_gate_mfma");
   return TDEED_OK;
 }

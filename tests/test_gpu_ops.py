@@ -256,10 +256,12 @@ def test_se_gate_bf16(ops, N, C, R):
 
 
 @pytest.mark.parametrize("N,C,R,parts", [(11, 152, 38, 1), (400, 368, 92, 1), (35, 24, 8, 56), (7, 56, 6, 10), (9, 152, 14, 2),
-                                          (16, 368, 38, 1)])
+                                          (16, 368, 38, 1),
+                                          # the 8-wave form of the wide layers (RegNetY-800MF s4: 768 channels, 80 / 192 hidden)
+                                          (37, 768, 192, 1), (400, 768, 80, 1), (5, 520, 130, 3), (33, 384, 100, 1)])
 def test_se_gate_mfma(ops, N, C, R, parts):
     from tdeed_amd.engine import pack_se_mfma
-    assert ops.se_gate_mfma_fits(C, R) and not ops.se_gate_mfma_fits(768, 192)
+    assert ops.se_gate_mfma_fits(C, R) and not ops.se_gate_mfma_fits(776, 192) and not ops.se_gate_mfma_fits(768, 200)
     p = rnd(146, "p", (N, parts, C)).abs()
     w1, b1 = rnd(147, "w1", (R, C), 0.1).to(torch.bfloat16).float(), rnd(148, "b1", (R,), 0.1)
     w2, b2 = rnd(149, "w2", (C, R), 0.2).to(torch.bfloat16).float(), rnd(150, "b2", (C,), 0.1)
