@@ -195,8 +195,8 @@ __device__ __forceinline__ void gsf_stage_bn(float* sbn, const float* __restrict
 // The launch is a latency chain per workgroup (weights + frame -> LDS -> K-loop -> store), so it is built to run it ONCE:
 //  * nfr frames per workgroup (launcher: 2 when one frame each would need a second round of workgroups -- 800 frames
 //    against 768 resident ones doubled the launch's duration);
-//  * weights, BatchNorm table and the frames' INTERIOR pieces are requested together (one memory round trip; the halo ring
-//    and the pad slots are zero-filled while the loads travel, not fetched from a dummy address);
+//  * weights, BatchNorm table and the frames' pieces are requested together (one memory round trip; the halo ring outside the
+//    frame and the pad slots are zero-filled while the loads travel, not fetched from a dummy address);
 //  * a wave multiplies two pixel tiles at a time, four k-steps of LDS reads in flight in front of their MFMAs
 //    (a step-by-step loop was offset read -> fragment read -> MFMA, serial, per k-step).
 __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restrict__ x, int h, int w, int C, int F,
@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   const int tid = threadIdx.x;
   // ---- requests first: weight fragments, the frames' interior 16-byte pieces, the BatchNorm table
   const int nwp = KS * 64;
-  const int pin = nrow * w * nch, ptot = nf * pin;              // interior pieces of one frame / of the workgroup
+  // rows fetched: the band's own rows and the halo rows that exist in the frame (bands of a frame taller than one band)
+  const int ylo = max(y0 - 1, 0), yhi = min(y1 + 1, h);
+  const int pin = (yhi - ylo) * w * nch, ptot = nf * pin;       // fetched pieces of one frame / of the workgroup
   const IDiv dpin(pin), dnch(nch), dw_(w);
   u32x4 wr[8], v[8];
   int doff[8], dc0[8];
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
       dpin.divmod(i, fr, r);
       dnch.divmod(r, pix, j);
       dw_.divmod(pix, py, px);
-      doff[b8] = fr * fbytes + ((py + 1) * WP + px + 1) * PSQ + j * 16;
+      doff[b8] = fr * fbytes + ((ylo + py - (y0 - 1)) * WP + px + 1) * PSQ + j * 16;
       dc0[b8] = j * 8;
-      v[b8] = *reinterpret_cast<const u32x4*>(x + ((long)(f0 + fr) * h * w + (long)(y0 + py) * w + px) * C + j * 8);
+      v[b8] = *reinterpret_cast<const u32x4*>(x + ((long)(f0 + fr) * h * w + (long)(ylo + py) * w + px) * C + j * 8);
     }
   };
   auto commit_f = [&](int it) {
@@ -290,31 +292,8 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   commit_w(0);
   for (int it = 1; it * 2048 < nwp; ++it) { issue_w(it); TD_ISSUE_FENCE(); commit_w(it); }
   __syncthreads();                                              // zeros and the BatchNorm table are in place
-  // halo rows that exist in the frame (bands of a frame taller than one band): fetched like interior rows
   commit_f(0);
   for (int it = 1; it * 2048 < ptot; ++it) { issue_f(it); TD_ISSUE_FENCE(); commit_f(it); }
-  if (nbq > 1) {
-    for (int fr = 0; fr < nf; ++fr)
-      for (int hr = 0; hr < 2; ++hr) {
-        const int yy = hr ? y1 : y0 - 1;
-        if (yy < 0 || yy >= h) continue;
-        for (int i = tid; i < w * nch; i += 256) {
-          int px, j;
-          dnch.divmod(i, px, j);
-          const u32x4 vv = *reinterpret_cast<const u32x4*>(x + ((long)(f0 + fr) * h * w + (long)yy * w + px) * C + j * 8);
-          float fv[8];
-          Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&vv), fv);
-          bf16x8 r;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int c = min(j * 8 + e, F - 1);
-            r[e] = (j * 8 + e < F) ? (bf16_t)fmaxf(fmaf(fv[e], sbn[c], sbn[F + c]), 0.f) : (bf16_t)0.f;
-          }
-          *reinterpret_cast<u32x4*>(a + fr * fbytes + ((hr ? rows - 1 : 0) * WP + px + 1) * PSQ + j * 16) =
-              *reinterpret_cast<u32x4*>(&r);
-        }
-      }
-  }
   __syncthreads();
   // ---- K-loop: tile pairs (t, t + 1) of the workgroup's nf * ntl pixel tiles
   const int lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
