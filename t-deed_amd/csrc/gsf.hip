@@ -486,7 +486,6 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
       const size_t fbytes = (size_t)(bq + 2) * (w + 2) * PSQ, fixed = (size_t)wbytes + (size_t)8 * F + (size_t)16 * KSq;
       // frames per workgroup: 2 when one frame each does not fit the chip in ONE round of resident workgroups and two do
       // (cfg2: 800 frames against 3 x 256 resident workgroups of 41-48 KB)
-      static const int q_fpw = getenv("TDEED_GSF_Q_FPW") ? atoi(getenv("TDEED_GSF_Q_FPW")) : 0;     // 0 = by rule
       const long lds_cu = 160 * 1024, ncu = 256;
       int nfr = 1;
       if (nbq == 1 && B * T > 1) {
@@ -494,7 +493,6 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
         const long per2 = (long)(fixed + 2 * fbytes);
         const long slots2 = per2 <= 150 * 1024 ? std::min<long>(8, lds_cu / per2) * ncu : 0;
         if ((long)B * T > slots1 && ((long)B * T + 1) / 2 <= slots2) nfr = 2;
-        if (q_fpw == 1 || (q_fpw == 2 && slots2 > 0)) nfr = q_fpw;
       }
       const size_t smq = fixed + (size_t)nfr * fbytes;
       hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(cdiv(B * T, nfr) * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
