@@ -325,3 +325,28 @@ def test_wide_stage_with_bf16_operand_copies_and_odd_levels(T, n):
         kinds = [s_.kernel for s_ in steps]
     assert "maxpool" in kinds and kinds.count("sgp_gemm") == 2 * (2 * n + 1) + 3 * n
     assert max_abs(outs[1], outs[0]) < 3e-2 * max(1.0, float(outs[0].abs().max()))
+
+
+# ------------------------------------------------------------------------------------ gate-shift at the timed frame counts
+@pytest.mark.parametrize("h,C,F,B,T", [(7, 96, 92, 9, 89), (14, 40, 40, 5, 161), (7, 368, 92, 8, 100)])
+def test_gate_shift_two_frames_per_workgroup_equals_clip_by_clip(h, C, F, B, T):
+    """Above 768 frames (3 resident workgroups per CU) tdeed_gsf_gate_fwd gives a workgroup of the tap-map launch TWO frames
+    (the cfg2 batch is 800); the module is independent per clip, so the batch in one call must equal the clips one by one
+    (each below the threshold: one frame per workgroup) bit for bit -- odd frame counts (a last workgroup with one frame),
+    pairs that span two clips, both blends (module order and source order)."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_gsf_q_frags
+    g = torch.Generator().manual_seed(h * 1000 + F + B)
+    N, Fp = B * T, (F + 7) // 8 * 8
+    x = (torch.randn((N, h, h, C), generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    w3d = torch.randn(2, F // 2, 3, 3, 3, generator=g) * 0.1
+    f32 = lambda *s: (torch.randn(s, generator=g) * 0.3).to(DEV)      # noqa: E731
+    bn_s, bn_b, b3d = f32(F).abs() + 0.5, f32(F), f32(2)
+    cw = [f32(18), f32(1), f32(18), f32(1)]
+    wq, wqf = w3d.reshape(F, 27).t().contiguous().to(DEV), pack_gsf_q_frags(w3d.numpy(), DEV)
+    assert N > 768
+    for src in (False, True):
+        whole = ops.gate_shift(x, B, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf, src_order=src).view(B, T * h * h, Fp)
+        for b in range(B):
+            one = ops.gate_shift(x[b * T:(b + 1) * T], 1, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf, src_order=src)
+            assert torch.equal(one, whole[b]), (src, b)
