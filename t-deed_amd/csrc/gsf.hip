@@ -217,8 +217,9 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   const int fbytes = (band + 2) * WP * PSQ;                     // one frame's band
   bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
   unsigned char* a = smq + (size_t)KS * 64 * 16;               // [nfr][rows][WP][PSQ]
-  float* sbn = reinterpret_cast<float*>(a + (size_t)nfr * fbytes);   // [2F]
-  int* soff = reinterpret_cast<int*>(sbn + 2 * F);              // [KS*4]
+  const int FP8 = nch * 8;                                      // BatchNorm table padded to whole chunks (zeros: relu(0 * x + 0) = 0)
+  float* sbn = reinterpret_cast<float*>(a + (size_t)nfr * fbytes);   // [2][FP8]
+  int* soff = reinterpret_cast<int*>(sbn + 2 * FP8);            // [KS*4]
   const int tid = threadIdx.x;
   // ---- requests first: weight fragments, the frames' interior 16-byte pieces, the BatchNorm table
   const int nwp = KS * 64;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
       if (i < nwp) reinterpret_cast<u32x4*>(wl)[i] = wr[b8];
     }
   };
+  const bf16_t* __restrict__ xb = x + (long)f0 * h * w * C;      // uniform base; lane offsets are unsigned 32-bit elements
   auto issue_f = [&](int it) {
 #pragma unroll
     for (int b8 = 0; b8 < 8; ++b8) {
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
       dw_.divmod(pix, py, px);
       doff[b8] = fr * fbytes + ((ylo + py - (y0 - 1)) * WP + px + 1) * PSQ + j * 16;
       dc0[b8] = j * 8;
-      v[b8] = *reinterpret_cast<const u32x4*>(x + ((long)(f0 + fr) * h * w + (long)(ylo + py) * w + px) * C + j * 8);
+      v[b8] = *reinterpret_cast<const u32x4*>(xb + ((unsigned)((fr * h + ylo + py) * w + px) * (unsigned)C + (unsigned)j * 8u));
     }
   };
   auto commit_f = [&](int it) {
@@ -260,11 +262,13 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
       const int c0 = dc0[b8];
       float fv[8];
       Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v[b8]), fv);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbn + c0), s1 = *reinterpret_cast<const f32x4*>(sbn + c0 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(sbn + FP8 + c0), h1 = *reinterpret_cast<const f32x4*>(sbn + FP8 + c0 + 4);
       bf16x8 r;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = min(c0 + e, F - 1);
-        r[e] = (c0 + e < F) ? (bf16_t)fmaxf(fmaf(fv[e], sbn[c], sbn[F + c]), 0.f) : (bf16_t)0.f;
+      for (int e = 0; e < 4; ++e) {
+        r[e] = (bf16_t)fmaxf(fmaf(fv[e], s0[e], h0[e]), 0.f);
+        r[4 + e] = (bf16_t)fmaxf(fmaf(fv[4 + e], s1[e], h1[e]), 0.f);
       }
       TD_LDS_CHECK((a - smq) + doff[b8], 16, (unsigned char*)sbn - smq);
       *reinterpret_cast<u32x4*>(a + doff[b8]) = *reinterpret_cast<u32x4*>(&r);
@@ -274,21 +278,24 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   issue_f(0);
   float bnv[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int i = min(tid + u * 256, 2 * F - 1);
-    bnv[u] = i < F ? bn_scale[i] : bn_shift[i - F];
+  for (int u = 0; u < 2; ++u) {                                 // entry i of [2][FP8]: scale | shift, zeros behind channel F
+    const int i = tid + u * 256;
+    const int c = i < FP8 ? i : i - FP8;
+    bnv[u] = (i < FP8 ? bn_scale : bn_shift)[min(c, F - 1)];
+    if (c >= F || i >= 2 * FP8) bnv[u] = 0.f;
   }
   TD_ISSUE_FENCE();
   // ---- while they travel: zero the bands (halo ring, pad slots, pixels of missing halo rows), k-slot offsets
   for (int i = tid; i < nf * (fbytes >> 4); i += 256) reinterpret_cast<u32x4*>(a)[i] = (u32x4){0u, 0u, 0u, 0u};
   for (int s_ = tid; s_ < KS * 4; s_ += 256) {                  // byte offset of every k-slot (tap, 8-channel chunk)
-    const int tap = s_ / nch, ck = s_ - tap * nch;
-    const int dy = tap / 3, dx = tap - dy * 3;
+    int tap, ck;
+    dnch.divmod(s_, tap, ck);
+    const int dy = (tap * 11) >> 5, dx = tap - dy * 3;          // tap / 3 for tap < 12
     soff[s_] = tap < 9 ? (dy * WP + dx) * PSQ + ck * 16 : 0;
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u)
-    if (tid + u * 256 < 2 * F) sbn[tid + u * 256] = bnv[u];
+    if (tid + u * 256 < 2 * FP8) sbn[tid + u * 256] = bnv[u];
   commit_w(0);
   for (int it = 1; it * 2048 < nwp; ++it) { issue_w(it); TD_ISSUE_FENCE(); commit_w(it); }
   __syncthreads();                                              // zeros and the BatchNorm table are in place
@@ -355,16 +362,17 @@ __device__ __forceinline__ void gsf_spatial_sums(const T* __restrict__ x, long f
                                                  float* part, float* __restrict__ ysum, float* __restrict__ xsum) {
   const int Fh = F >> 1, nq = F >> 1;
   const int S = 256 / nq;
-  const int cp = threadIdx.x % nq;
-  const int s = threadIdx.x / nq;
+  int s, cp;
+  IDiv(nq).divmod((int)threadIdx.x, s, cp);
   if (s < S) {
     float y0 = 0.f, y1 = 0.f, x0 = 0.f, x1 = 0.f;
-    const T* xf = x + f * hw * C + 2 * cp;
+    const T* __restrict__ xf = x + f * hw * C;                  // uniform base, unsigned 32-bit lane offsets
+    const unsigned c2 = 2u * (unsigned)cp;
     const int g = (2 * cp) >= Fh;
     for (int p0 = s; p0 < hw; p0 += S * 8) {
       float v0[8], v1[8];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) Pair<T>::load(xf + (long)min(p0 + b * S, hw - 1) * C, v0[b], v1[b]);
+      for (int b = 0; b < 8; ++b) Pair<T>::load(xf + ((unsigned)min(p0 + b * S, hw - 1) * (unsigned)C + c2), v0[b], v1[b]);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         const int p = p0 + b * S;
@@ -407,15 +415,19 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
   const float has_prev = t > 0 ? 1.f : 0.f, has_next = t < T_len - 1 ? 1.f : 0.f;
   const long fp = t > 0 ? f - 1 : f, fn = t < T_len - 1 ? f + 1 : f;      // clamped: loads stay branch-free
   const float b0 = b3d[0], b1 = b3d[1];
+  const float* __restrict__ Qc = Q + f * hw * 6;                // uniform bases of the three frames' tap maps
+  const float* __restrict__ Qp = Q + fp * hw * 6;
+  const float* __restrict__ Qn = Q + fn * hw * 6;
+  float* __restrict__ gout = gate + f * hw * 2;
   for (int i0 = threadIdx.x; i0 < 2 * hw; i0 += 256 * 4) {
     float qc[4], qp[4], qn[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int i = min(i0 + b * 256, 2 * hw - 1);
-      const int p = i >> 1, g = i & 1;
-      qc[b] = Q[(f * hw + p) * 6 + 2 + g];
-      qp[b] = Q[(fp * hw + p) * 6 + g];
-      qn[b] = Q[(fn * hw + p) * 6 + 4 + g];
+      const unsigned i = (unsigned)min(i0 + b * 256, 2 * hw - 1);
+      const unsigned o = (i >> 1) * 6u + (i & 1u);
+      qc[b] = Qc[o + 2u];
+      qp[b] = Qp[o];
+      qn[b] = Qn[o + 4u];
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
       if (i < 2 * hw) {
         const float v = tanhf(((i & 1) ? b1 : b0) + qc[b] + has_prev * qp[b] + has_next * qn[b]);
         sg[i] = v;
-        gate[f * hw * 2 + i] = v;
+        gout[i] = v;
       }
     }
   }
@@ -464,12 +476,12 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     const long wbytes = (long)KSq * 64 * 16;
     static const long q_kb = getenv("TDEED_GSF_Q_KB") ? atol(getenv("TDEED_GSF_Q_KB")) : 52;   // three workgroups per CU (measured: DESIGN §9)
     long q_cap = q_kb * 1024;
-    int bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
+    int bq = (int)((q_cap - wbytes - 64L * nch - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     if (bq < 1) {
       // wide slices (F = 196 of RegNetY-800MF s4: 58 KB of tap-weight fragments alone): up to 150 KB of LDS, one
       // workgroup per CU, instead of falling back to the vector-ALU tap kernel (118 vs ~35 us per site)
       q_cap = 150 * 1024;
-      bq = (int)((q_cap - wbytes - 8L * F - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
+      bq = (int)((q_cap - wbytes - 64L * nch - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     }
     if (bq >= 1) {
       static TdDevOnce attr_q;
@@ -483,7 +495,7 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
       }
       if (bq > h) bq = h;
       const int nbq = cdiv(h, bq);
-      const size_t fbytes = (size_t)(bq + 2) * (w + 2) * PSQ, fixed = (size_t)wbytes + (size_t)8 * F + (size_t)16 * KSq;
+      const size_t fbytes = (size_t)(bq + 2) * (w + 2) * PSQ, fixed = (size_t)wbytes + (size_t)8 * (nch * 8) + (size_t)16 * KSq;
       // frames per workgroup: 2 when one frame each does not fit the chip in ONE round of resident workgroups and two do
       // (cfg2: 800 frames against 3 x 256 resident workgroups of 41-48 KB)
       const long lds_cu = 160 * 1024, ncu = 256;
@@ -973,6 +985,11 @@ extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const
 // gate values of its pixel and the spatial sums are requested together -- ONE memory round trip per workgroup -- and the blend
 // runs out of registers (the interleaving launch staged three frames' pieces in LDS and gathered 2-byte elements from them:
 // ~20 LDS reads per piece).  Arithmetic = gsf_apply_fused_bf16_kernel's, bit for bit.
+// Instruction count matters as much as the round trip here: time stamps showed 3.9 us of a workgroup's 7.9 us between its start
+// and the END OF ISSUING its loads -- a divmod per piece and per sum, 64-bit address arithmetic per load.  Hence: every
+// address is a workgroup-uniform base (frame t-1 of the slice / the gate map: scalar registers) plus an unsigned 32-bit lane
+// offset, a thread's pieces step by 256 through (pixel, piece-of-pixel) with adds instead of divisions, the spatial sums are
+// read row by row by thread c < F.
 constexpr int GB_UX = 8;          // pieces per thread and batch
 __global__ __launch_bounds__(256) void gsf_blend_src_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gate,
                                                             const float* __restrict__ ysum, const float* __restrict__ xsum,
@@ -989,52 +1006,61 @@ __global__ __launch_bounds__(256) void gsf_blend_src_kernel(const bf16_t* __rest
   float* fwl = ssum + 10 * F;                                   // [Fp] fusion weight by source channel (pad channels: unused)
   float* cwl = fwl + Fp;                                        // [2][18] conv weights, [2] biases
   const bool has_next = t < T_len - 1, has_prev = t > 0;
-  const long fn = has_next ? f + 1 : f, fp = has_prev ? f - 1 : f;
+  const long fp = has_prev ? f - 1 : f;
   const int npc = Fp >> 2, total = hw * npc;
-  const IDiv dF(F), dnpc(npc);
   const bool strad = (Fh & 3) != 0;                             // a piece holds channels of both gate groups
+  // uniform bases (frame t-1, or t at a clip's first frame) and the element offsets of frames t / t+1 from them
+  const bf16_t* __restrict__ xb = x + fp * hw * C;
+  const float* __restrict__ gb = gate + fp * hw * 2;
+  bf16_t* __restrict__ ob = out + f * hw * Fp;
+  const unsigned oc = has_prev ? (unsigned)hw : 0u;            // this frame, in pixels from the base
+  const unsigned on = oc + (has_next ? (unsigned)hw : 0u);     // frame t+1 (clamped to t at a clip's last frame)
   // ---- requests: sums + conv weights, then the first batch of pieces and gates
   float sv[10];
 #pragma unroll
-  for (int u = 0; u < 10; ++u) {
-    const int i = min(tid + u * 256, 10 * F - 1);
-    int row, c;                                                 // row = arr * 5 + r
-    dF.divmod(i, row, c);
+  for (int row = 0; row < 10; ++row) {                          // row = arr * 5 + r: thread c < F reads channel c of every row
     const int arr = row >= 5, r = row - 5 * arr;
     const int t2 = min(max(t + r - 2, 0), T_len - 1);
-    sv[u] = (arr ? xsum : ysum)[(b * T_len + t2) * F + c];
+    sv[row] = 0.f;
+    if (tid < F) sv[row] = (arr ? xsum : ysum)[(b * T_len + t2) * F + tid];
   }
   const float cwv = *(tid < 18 ? cw1 + tid : tid < 36 ? cw2 + (tid - 18) : tid == 36 ? cb1 : cb2);
   u32x2 vc[GB_UX], vs[GB_UX], vs2[GB_UX];
   f32x2 ga[GB_UX];
   float gnb[GB_UX], gnb2[GB_UX];
+  int pa[GB_UX], pja[GB_UX];                                    // (pixel, piece of the pixel) of each of the thread's pieces
+  const IDiv dnpc(npc);
+  const int q256 = 256 / npc, r256 = 256 - q256 * npc;          // a step of 256 pieces in (pixel, piece) terms
   auto issue = [&](int it) {
+    int p, pj;
+    dnpc.divmod(it * (256 * GB_UX) + tid, p, pj);
 #pragma unroll
     for (int u = 0; u < GB_UX; ++u) {
-      const int i = min(it * (256 * GB_UX) + tid + u * 256, total - 1);
-      int p, pj;
-      dnpc.divmod(i, p, pj);
-      const long off = (long)p * C + pj * 4;
+      pa[u] = p;
+      pja[u] = pj;
+      const unsigned pp = (unsigned)min(p, hw - 1);            // (pieces beyond the frame: clamped addresses, never blended)
+      const unsigned off = pp * (unsigned)C + (unsigned)pj * 4u;
       const bool lo = pj * 4 < Fh;                               // first channel of the piece in gate group 0
-      vc[u] = *reinterpret_cast<const u32x2*>(x + f * hw * C + off);
-      vs[u] = *reinterpret_cast<const u32x2*>(x + (lo ? fn : fp) * hw * C + off);
-      ga[u] = *reinterpret_cast<const f32x2*>(gate + (f * hw + p) * 2);
-      gnb[u] = lo ? gate[(fn * hw + p) * 2] : gate[(fp * hw + p) * 2 + 1];
+      vc[u] = *reinterpret_cast<const u32x2*>(xb + (oc * (unsigned)C + off));
+      vs[u] = *reinterpret_cast<const u32x2*>(xb + ((lo ? on : 0u) * (unsigned)C + off));
+      ga[u] = *reinterpret_cast<const f32x2*>(gb + ((oc + pp) * 2u));
+      gnb[u] = gb[(lo ? on + pp : pp) * 2u + (lo ? 0u : 1u)];
       vs2[u] = (u32x2){0u, 0u};
       gnb2[u] = 0.f;
       if (strad && lo && pj * 4 + 3 >= Fh) {                     // the straddling piece: its upper channels come from t-1
-        vs2[u] = *reinterpret_cast<const u32x2*>(x + fp * hw * C + off);
-        gnb2[u] = gate[(fp * hw + p) * 2 + 1];
+        vs2[u] = *reinterpret_cast<const u32x2*>(xb + off);
+        gnb2[u] = gb[pp * 2u + 1u];
       }
+      pj += r256;
+      p += q256;
+      if (pj >= npc) { pj -= npc; ++p; }
     }
   };
   auto blend = [&](int it) {
 #pragma unroll
     for (int u = 0; u < GB_UX; ++u) {
-      const int i = it * (256 * GB_UX) + tid + u * 256;
-      if (i >= total) continue;
-      int p, pj;
-      dnpc.divmod(i, p, pj);
+      const int p = pa[u], pj = pja[u];
+      if (p >= hw) continue;
       const bf16x4 xc4 = *reinterpret_cast<const bf16x4*>(&vc[u]);
       const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(&vs[u]);
       const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(&vs2[u]);
@@ -1055,18 +1081,16 @@ __global__ __launch_bounds__(256) void gsf_blend_src_kernel(const bf16_t* __rest
         const float wv = w4[e];
         o[e] = (bf16_t)fmaf(ysh, wv, r * (1.0f - wv));
       }
-      *reinterpret_cast<bf16x4*>(out + (f * hw + p) * Fp + pj * 4) = o;
+      *reinterpret_cast<bf16x4*>(ob + ((unsigned)p * (unsigned)Fp + (unsigned)pj * 4u)) = o;
     }
   };
   issue(0);
   TD_ISSUE_FENCE();
+  if (tid < F) {
 #pragma unroll
-  for (int u = 0; u < 10; ++u) {
-    const int i = tid + u * 256;
-    if (i < 10 * F) {
-      const int row = dF.div(i);
+    for (int row = 0; row < 10; ++row) {
       const int t2 = t + (row >= 5 ? row - 5 : row) - 2;
-      ssum[i] = (t2 >= 0 && t2 < T_len) ? sv[u] : 0.f;
+      ssum[row * F + tid] = (t2 >= 0 && t2 < T_len) ? sv[row] : 0.f;
     }
   }
   if (tid < 38) cwl[tid] = cwv;
