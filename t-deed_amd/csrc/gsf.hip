@@ -199,6 +199,12 @@ __device__ __forceinline__ void gsf_stage_bn(float* sbn, const float* __restrict
 //    frame and the pad slots are zero-filled while the loads travel, not fetched from a dummy address);
 //  * a wave multiplies two pixel tiles at a time, four k-steps of LDS reads in flight in front of their MFMAs
 //    (a step-by-step loop was offset read -> fragment read -> MFMA, serial, per k-step).
+//  * WREG (KS <= 28, i.e. F <= 96): a wave copies the weight fragments from LDS into REGISTERS once, ahead of its tiles.  The
+//    K-loop was bound by the LDS pipe, which all waves of a CU share: a 16x16x32 MFMA fed with both operands from LDS costs
+//    2 x 1 KB = 16 LDS cycles against the 4 cycles per MFMA the CU's four SIMDs sustain; time stamps gave ~1000 cycles per
+//    four k-steps.  With the weights in registers only the activation fragment is read.  (Fetching them from global memory
+//    per wave instead -- no LDS copy at all -- cost 4 x the weight bytes per workgroup and was slower at the cfg2 sizes.)
+template <bool WREG>
 __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restrict__ x, int h, int w, int C, int F,
                                                          int band, int nch, int PSQ, int KS,
                                                          const float* __restrict__ bn_scale,
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   const int fbytes = (band + 2) * WP * PSQ;                     // one frame's band
   bf16x8* wl = reinterpret_cast<bf16x8*>(smq);                  // [KS][64]
   unsigned char* a = smq + (size_t)KS * 64 * 16;               // [nfr][rows][WP][PSQ]
+  constexpr int KSR = 28;
   const int FP8 = nch * 8;                                      // BatchNorm table padded to whole chunks (zeros: relu(0 * x + 0) = 0)
   float* sbn = reinterpret_cast<float*>(a + (size_t)nfr * fbytes);   // [2][FP8]
   int* soff = reinterpret_cast<int*>(sbn + 2 * FP8);            // [KS*4]
@@ -304,6 +311,12 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   __syncthreads();
   // ---- K-loop: tile pairs (t, t + 1) of the workgroup's nf * ntl pixel tiles
   const int lane = tid & 63, wv = tid >> 6, pl = lane & 15, q = lane >> 4;
+  bf16x8 wreg[WREG ? KSR : 1];
+  if constexpr (WREG) {                                         // this wave's copy of the fragments: LDS -> registers, once
+#pragma unroll
+    for (int ks = 0; ks < KSR; ++ks)
+      if (ks < KS) wreg[ks] = wl[ks * 64 + lane];
+  }
   const int npix = nrow * w;
   const int ntl = (npix + 15) >> 4;
   const int ntot = nf * ntl;
@@ -326,23 +339,46 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
       qrow[u] = (long)(f0 + fr) * h * w + (long)(y0 + py) * w + px;
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
-      int o[4];
-      bf16x8 wf[4], a0[4], a1[4];
+    if constexpr (WREG) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = soff[min(ks0 + j, KS - 1) * 4 + q];
+      for (int g = 0; g < KSR / 4; ++g) {
+        if (g * 4 < KS) {                                        // (uniform)
+          int o[4];
+          bf16x8 a0[4], a1[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        wf[j] = wl[min(ks0 + j, KS - 1) * 64 + lane];
-        a0[j] = *reinterpret_cast<const bf16x8*>(base[0] + o[j]);
-        a1[j] = *reinterpret_cast<const bf16x8*>(base[1] + o[j]);
-      }
+          for (int j = 0; j < 4; ++j) o[j] = soff[min(g * 4 + j, KS - 1) * 4 + q];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (ks0 + j < KS) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1[j], acc1, 0, 0, 0);
+          for (int j = 0; j < 4; ++j) {
+            a0[j] = *reinterpret_cast<const bf16x8*>(base[0] + o[j]);
+            a1[j] = *reinterpret_cast<const bf16x8*>(base[1] + o[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (g * 4 + j < KS) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[g * 4 + j], a0[j], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[g * 4 + j], a1[j], acc1, 0, 0, 0);
+            }
         }
+      }
+    } else {
+      for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+        int o[4];
+        bf16x8 wf[4], a0[4], a1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = soff[min(ks0 + j, KS - 1) * 4 + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wf[j] = wl[min(ks0 + j, KS - 1) * 64 + lane];
+          a0[j] = *reinterpret_cast<const bf16x8*>(base[0] + o[j]);
+          a1[j] = *reinterpret_cast<const bf16x8*>(base[1] + o[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ks0 + j < KS) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1[j], acc1, 0, 0, 0);
+          }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -473,9 +509,13 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     int ps16 = nch + 1;
     if ((ps16 & 1) == 0) ++ps16;
     const int PSQ = ps16 * 16, KSq = (9 * nch + 3) / 4;
+    const bool wreg = KSq <= 28;                                  // weight fragments copied to registers per wave (F <= 96)
     const long wbytes = (long)KSq * 64 * 16;
-    static const long q_kb = getenv("TDEED_GSF_Q_KB") ? atol(getenv("TDEED_GSF_Q_KB")) : 52;   // three workgroups per CU (measured: DESIGN §9)
-    long q_cap = q_kb * 1024;
+    // LDS budget per workgroup: 52 KB = three workgroups per CU (measured: DESIGN §9); the register-weight form may take
+    // 78 KB = two per CU when a frame does not fit 52 (800MF s3, F = 80: a whole 14 x 14 frame instead of two bands with
+    // the weights staged twice)
+    static const long q_kb = getenv("TDEED_GSF_Q_KB") ? atol(getenv("TDEED_GSF_Q_KB")) : 0;
+    long q_cap = (q_kb > 0 ? q_kb : (wreg ? 78 : 52)) * 1024;
     int bq = (int)((q_cap - wbytes - 64L * nch - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     if (bq < 1) {
       // wide slices (F = 196 of RegNetY-800MF s4: 58 KB of tap-weight fragments alone): up to 150 KB of LDS, one
@@ -486,8 +526,10 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     if (bq >= 1) {
       static TdDevOnce attr_q;
       if (!attr_q.get()) {
-        if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
-            hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gsf_q_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void*)gsf_q_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+                hipSuccess) {
           tdeed_set_error("gsf_gate: hipFuncSetAttribute failed");
           return TDEED_ERR_RUNTIME;
         }
@@ -497,18 +539,22 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
       const int nbq = cdiv(h, bq);
       const size_t fbytes = (size_t)(bq + 2) * (w + 2) * PSQ, fixed = (size_t)wbytes + (size_t)8 * (nch * 8) + (size_t)16 * KSq;
       // frames per workgroup: 2 when one frame each does not fit the chip in ONE round of resident workgroups and two do
-      // (cfg2: 800 frames against 3 x 256 resident workgroups of 41-48 KB)
-      const long lds_cu = 160 * 1024, ncu = 256;
+      // (cfg2: 800 frames against 3 x 256 resident workgroups).  Resident workgroups per CU: by LDS, and three by registers
+      const long lds_cu = 160 * 1024, ncu = 256, reg_cap = 3;
       int nfr = 1;
       if (nbq == 1 && B * T > 1) {
-        const long slots1 = std::min<long>(8, lds_cu / (long)(fixed + fbytes)) * ncu;
+        const long slots1 = std::min<long>(reg_cap, lds_cu / (long)(fixed + fbytes)) * ncu;
         const long per2 = (long)(fixed + 2 * fbytes);
-        const long slots2 = per2 <= 150 * 1024 ? std::min<long>(8, lds_cu / per2) * ncu : 0;
+        const long slots2 = per2 <= 150 * 1024 ? std::min<long>(reg_cap, lds_cu / per2) * ncu : 0;
         if ((long)B * T > slots1 && ((long)B * T + 1) / 2 <= slots2) nfr = 2;
       }
       const size_t smq = fixed + (size_t)nfr * fbytes;
-      hipLaunchKernelGGL(gsf_q_mfma_kernel, dim3(cdiv(B * T, nfr) * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C, F, bq,
-                         nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q, nbq, nfr, B * T);
+      if (wreg)
+        hipLaunchKernelGGL(gsf_q_mfma_kernel<true>, dim3(cdiv(B * T, nfr) * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C,
+                           F, bq, nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q, nbq, nfr, B * T);
+      else
+        hipLaunchKernelGGL(gsf_q_mfma_kernel<false>, dim3(cdiv(B * T, nfr) * nbq), dim3(256), smq, st, (const bf16_t*)x, h, w, C,
+                           F, bq, nch, PSQ, KSq, bn_scale, bn_shift, (const bf16x8*)wqf, Q, nbq, nfr, B * T);
       mfma_done = true;
     }
   }
