@@ -350,3 +350,29 @@ def test_gate_shift_two_frames_per_workgroup_equals_clip_by_clip(h, C, F, B, T):
         for b in range(B):
             one = ops.gate_shift(x[b * T:(b + 1) * T], 1, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf, src_order=src)
             assert torch.equal(one, whole[b]), (src, b)
+
+
+@pytest.mark.parametrize("h,w,C,F,B,T", [(5, 9, 24, 20, 2, 3), (3, 3, 16, 8, 1, 1), (9, 5, 48, 44, 3, 2), (14, 14, 88, 80, 2, 7),
+                                         (7, 7, 200, 196, 2, 5), (6, 6, 40, 36, 4, 2), (11, 13, 64, 60, 2, 2),
+                                         (7, 7, 104, 100, 1, 9), (4, 4, 32, 28, 5, 1)])
+def test_gate_shift_odd_geometries(h, w, C, F, B, T):
+    """The bf16 gate-shift launches on geometries no model config has: non-square maps, folds that are not multiples of 8
+    (a chunk and a piece straddling F/2), clips of one frame, folds on both sides of the register-weight limit (F = 100, 196:
+    tap weights read from LDS).  Source-order blend == module-order blend under the interleave, bit for bit; both within the
+    bf16 tolerance of the fp32 kernels on the same (bf16-rounded) input."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_gsf_q_frags
+    g = torch.Generator().manual_seed(h * 131 + w * 7 + F)
+    Fp = (F + 7) // 8 * 8
+    x = (torch.randn((B * T, h, w, C), generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    w3d = torch.randn(2, F // 2, 3, 3, 3, generator=g) * 0.1
+    f32 = lambda *s: (torch.randn(s, generator=g) * 0.3).to(DEV)      # noqa: E731
+    bn_s, bn_b, b3d = f32(F).abs() + 0.5, f32(F), f32(2)
+    cw = [f32(18), f32(1), f32(18), f32(1)]
+    wq, wqf = w3d.reshape(F, 27).t().contiguous().to(DEV), pack_gsf_q_frags(w3d.numpy(), DEV)
+    mod = ops.gate_shift(x, B, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf)
+    src = ops.gate_shift(x, B, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf, src_order=True)
+    idx = torch.tensor(ops.gs_source_order(F) + list(range(F, Fp)), device=DEV)
+    assert torch.equal(src[:, idx], mod)
+    ref = ops.gate_shift(x.float(), B, T, F, Fp, bn_s, bn_b, wq, b3d, *cw)
+    assert float((mod.float() - ref).abs().max()) < 3e-2 * float(ref.abs().max())
