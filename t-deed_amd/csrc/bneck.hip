@@ -85,7 +85,24 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   // (the wave's third tile runs alone).  Same k order per output: bit-identical results.  Register cost: 7 more accumulators.
   constexpr bool PAIR = KS >= 8 && KS % 2 == 0;
   constexpr int KH = KS / 2;
+  // TRIPLE (KS = 12): ALL THREE of a wave's channel tiles (wv, wv + 8, wv + 16) against each activation fragment, in three
+  // third-K blocks of 3 x KS/3 weight fragments (the same 2 x KS fragment registers as PAIR, 7 more accumulators): one LDS
+  // fragment read per three MFMAs.  conv1 / conv3 at the pair form were bound by exactly those reads (8 waves x 168 reads x
+  // 8 LDS cycles = 10.7 k cycles of a 14.2 k-cycle phase against 8 k cycles of MFMA issue).  A wave without a third tile
+  // (wv = 7 at 23 tiles) multiplies a clamped one and drops it.  Same k order per output: bit-identical results.
+  constexpr bool TRIPLE = PAIR && KS % 3 == 0;
+  constexpr int KT = KS / 3;
   bf16x8 wc1[KS], wf2[5];
+  auto load_block3 = [&](bf16x8 (&dst)[KS], const bf16x8* __restrict__ wsrc, int ta, int tb, int tc, int ks0) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      dst[k] = wsrc[((long)ta * KS + ks0 + k) * 64 + lane];
+      dst[KT + k] = wsrc[((long)tb * KS + ks0 + k) * 64 + lane];
+      dst[2 * KT + k] = wsrc[((long)tc * KS + ks0 + k) * 64 + lane];
+    }
+  };
+  const int T3A = wv, T3B = wv + BNK_NW, T3C = min(wv + 2 * BNK_NW, NT_ - 1);
+  const bool t3c_ok = wv + 2 * BNK_NW < NT_;
   auto load_block = [&](bf16x8 (&dst)[KS], const bf16x8* __restrict__ wsrc, int ta, int tb, int ks0) {
     // dst[0 .. KH) = tile ta, k-steps ks0 .. ks0 + KH; dst[KH .. KS) = tile tb, the same k-steps
 #pragma unroll
@@ -94,7 +111,12 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       dst[KH + k] = wsrc[((long)tb * KS + ks0 + k) * 64 + lane];
     }
   };
-  if constexpr (PAIR) {
+  bf16x8 wn1[TRIPLE ? KS : 1];                           // TRIPLE: conv1's second block, requested here as well (a block is
+                                                         // ~1.3 k cycles of MFMAs: one block ahead is less than an L2 round trip)
+  if constexpr (TRIPLE) {
+    load_block3(wc1, p.w1f, T3A, T3B, T3C, 0);
+    load_block3(wn1, p.w1f, T3A, T3B, T3C, KT);
+  } else if constexpr (PAIR) {
     load_block(wc1, p.w1f, wv, wv + BNK_NW, 0);
   } else if (wv < NT_) {
 #pragma unroll
@@ -231,6 +253,38 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // a third of a contraction of THREE channel tiles: k-steps ks0 .. ks0 + KT, one activation fragment read per three MFMAs
+  auto contract_third = [&](const bf16x8 (&wb)[KS], int ks0, const unsigned char* act, f32x4 (&acc0)[NPTM], f32x4 (&acc1)[NPTM],
+                            f32x4 (&acc2)[NPTM]) {
+    bf16x8 a[NPTM];
+    const int kq = 16 * q;
+#pragma unroll
+    for (int pt = 0; pt < HA; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + 64 * ks0 + kq);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int kb = 64 * (ks0 + k) + kq;
+#pragma unroll
+      for (int pt = HA; pt < NPTM; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb);
+#pragma unroll
+      for (int pt = 0; pt < HA; ++pt) {
+        acc0[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k], a[pt], acc0[pt], 0, 0, 0);
+        acc1[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[KT + k], a[pt], acc1[pt], 0, 0, 0);
+        acc2[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2 * KT + k], a[pt], acc2[pt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < KT) {
+#pragma unroll
+        for (int pt = 0; pt < HA; ++pt) a[pt] = *reinterpret_cast<const bf16x8*>(act + prow[pt] + kb + 64);
+      }
+#pragma unroll
+      for (int pt = HA; pt < NPTM; ++pt) {
+        acc0[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k], a[pt], acc0[pt], 0, 0, 0);
+        acc1[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[KT + k], a[pt], acc1[pt], 0, 0, 0);
+        acc2[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2 * KT + k], a[pt], acc2[pt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   // epilogue of conv1 for one channel tile: BN + ReLU -> y1 rows in region B (channels >= C get exact zeros: row pad)
   auto epi1 = [&](int T, const f32x4 (&acc)[NPTM]) {
     const int ch0 = T * 16 + 4 * q;
@@ -247,7 +301,23 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   };
 
   // ---- P1: conv1: y1 = relu(bn(W1 x'))  (wave = channel tiles wv, wv + 8, ...)
-  if constexpr (PAIR) {
+  if constexpr (TRIPLE) {
+    bf16x8 (&wn)[KS] = wn1;
+    f32x4 acc0[NPTM], acc1[NPTM], acc2[NPTM];
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) acc0[pt] = acc1[pt] = acc2[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    contract_third(wc1, 0, At, acc0, acc1, acc2);
+    load_block3(wc1, p.w1f, T3A, T3B, T3C, 2 * KT);          // the last block travels under the second
+    contract_third(wn, KT, At, acc0, acc1, acc2);
+    if (wv < NT) {                                           // conv2's first unit: into the registers the second block left
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) wf2[ks] = p.w2f[((long)wv * 5 + ks) * 64 + lane];
+    }
+    contract_third(wc1, 2 * KT, At, acc0, acc1, acc2);
+    epi1(T3A, acc0);
+    epi1(T3B, acc1);
+    if (t3c_ok) epi1(wv + 2 * BNK_NW, acc2);
+  } else if constexpr (PAIR) {
     bf16x8 wn[KS];
     if (wv < NT) {
 #pragma unroll
@@ -435,7 +505,9 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   BN_STAMP(3);
 
   bf16x8 wc3[KS];
-  if constexpr (PAIR) {
+  if constexpr (TRIPLE) {
+    load_block3(wc3, p.w3f, T3A, T3B, T3C, 0);
+  } else if constexpr (PAIR) {
     load_block(wc3, p.w3f, wv, wv + BNK_NW, 0);
   } else if (wv < NT) {
 #pragma unroll
@@ -490,7 +562,25 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       *reinterpret_cast<bf16x4*>((srowA[pt] < dAB ? dst + dAB : dst) + ch0 * 2) = o;
     }
   };
-  if constexpr (PAIR) {
+  if constexpr (TRIPLE) {
+    bf16x8 wn[KS];
+    load_block3(wn, p.w3f, T3A, T3B, T3C, KT);
+    f32x4 acc0[NPTM], acc1[NPTM], acc2[NPTM];
+#pragma unroll
+    for (int pt = 0; pt < NPTM; ++pt) acc0[pt] = acc1[pt] = acc2[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    contract_third(wc3, 0, At, acc0, acc1, acc2);
+    load_block3(wc3, p.w3f, T3A, T3B, T3C, 2 * KT);
+    contract_third(wn, KT, At, acc0, acc1, acc2);
+    // the residual rows of the three tiles: requested into the registers the second block left, they travel under the third
+    bf16x4 rA[NPTM], rB[NPTM], rC[NPTM];
+    load_res(T3A, rA);
+    load_res(T3B, rB);
+    load_res(T3C, rC);
+    contract_third(wc3, 2 * KT, At, acc0, acc1, acc2);
+    epi3(T3A, acc0, rA);
+    epi3(T3B, acc1, rB);
+    if (t3c_ok) epi3(wv + 2 * BNK_NW, acc2, rC);
+  } else if constexpr (PAIR) {
     bf16x8 wn[KS];
     const int TA = wv, TB = wv + BNK_NW, TC = wv + 2 * BNK_NW;
     load_block(wn, p.w3f, TA, TB, KH);
