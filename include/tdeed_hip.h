@@ -194,7 +194,10 @@ int tdeed_bneck_set_debug(void* buf);
 int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f, const float* s1,
                     const float* h1, const void* w2f, const float* s2, const float* h2, const void* se_w1f,
                     const float* se_b1, const void* se_w2f, const float* se_b2, int R, const void* w3f, const float* s3,
-                    const float* h3, void* out, void* out2, int n2, void* stream);
+                    const float* h3, void* out, void* out2, int n2,
+                    int w2_tap_major /* k-slot order of w2f: 1 = engine.pack_gconv_frags(tap_major=True), the conflict-free
+                                        order of this launch (group width 8); 0 = the order tdeed_gconv3x3_fwd reads */,
+                    void* stream);
 
 
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------

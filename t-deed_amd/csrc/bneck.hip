@@ -22,6 +22,7 @@ struct BneckP {
   const bf16x8* w3f; const float* s3; const float* h3;        // [NT][KS][64]
   bf16_t* out; bf16_t* out2; int n2;              // out [N][hw][C]; optional compact copy of channels [0, n2)
   int N, h, w, C;
+  int w2_tap_major;                               // k-slot order of w2f: 0 = half * 9 + tap (gconv3x3_mfma_kernel's), 1 = 2 * tap + half
   long long* dbg;                                 // diagnostic: per-workgroup phase time stamps (or null)
 };
 
@@ -386,9 +387,15 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       int dyv[5], dxv[5], doff[5];
       bool sok[5];
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) {                   // k-slot -> (half, dy, dx) with compares only
+      for (int ks = 0; ks < 5; ++ks) {                   // k-slot -> (tap, half): tap-major fragments (engine.pack_gconv_frags(tap_major))
+        // the two k-slots of a ds_read_b128 lane group (q = 0 / 1: slots 4 ks, 4 ks + 1) are the two 16-byte halves of ONE tap
+        // pixel: at this kernel's even row stride (14 or 6 slots mod 16) the group's 16 lanes fall on 16 distinct bank slots;
+        // the half-major order of gconv3x3_mfma_kernel (slots of adjacent taps, same half) gave two-way conflicts on every read
+        // (for group width 8 an output's sum is bit-identical under either order in every test; for 16-wide groups -- both
+        //  halves of a k-slot pair carry weights of the same output -- it is not, and the caller keeps the half-major order)
         const int sidx = 4 * ks + q;
-        const int half = sidx >= 9 ? 1 : 0, tap = sidx - 9 * half;
+        const int half = p.w2_tap_major ? (sidx & 1) : (sidx >= 9 ? 1 : 0);
+        const int tap = p.w2_tap_major ? (sidx >> 1) : sidx - 9 * half;
         const int ty = (tap >= 3 ? 1 : 0) + (tap >= 6 ? 1 : 0);
         dyv[ks] = ty - 1;
         dxv[ks] = tap - 3 * ty - 1;
@@ -672,7 +679,7 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
                                const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
                                const void* se_w1f, const float* se_b1, const void* se_w2f, const float* se_b2, int R,
                                const void* w3f, const float* s3, const float* h3, void* out, void* out2, int n2,
-                               void* stream) {
+                               int w2_tap_major, void* stream) {
   TD_CHECK(x && w1f && s1 && h1 && w2f && s2 && h2 && se_w1f && se_b1 && se_w2f && se_b2 && w3f && s3 && h3 && out,
            "bneck: null pointer");
   TD_CHECK(N > 0 && tdeed_bneck_fits(h, w, C, R), "bneck: geometry h=%d w=%d C=%d R=%d unsupported", h, w, C, R);
@@ -687,6 +694,7 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
   p.w3f = (const bf16x8*)w3f; p.s3 = s3; p.h3 = h3;
   p.out = (bf16_t*)out; p.out2 = (bf16_t*)out2; p.n2 = out2 ? n2 : 0;
   p.N = N; p.h = h; p.w = w; p.C = C;
+  p.w2_tap_major = w2_tap_major ? 1 : 0;
   p.dbg = g_bneck_dbg;
   const int hw = h * w, fpw = bneck_fpw(hw), KS = (C + 31) / 32;
   const size_t smem = bneck_smem(fpw, hw, C);

@@ -339,15 +339,17 @@ def pack_gsf_q_frags(w3d, device):
     return torch.from_numpy(_gsf_q_frags_np(_np(w3d).astype(np.float32))).to(device).to(torch.bfloat16).contiguous()
 
 
-def pack_gconv_frags(w, gw, device):
+def pack_gconv_frags(w, gw, device, tap_major=False):
     """Conv2d.weight [C][gw][3][3] -> bf16 MFMA A-operand fragments [ceil4(C/16)][5][64][8] for
     gconv3x3_mfma_kernel: unit u = output channels [16u,16u+16); lane l holds Wt[n=l&15][k=8(l>>4)+j];
     k-slot s = 4*ks + (l>>4) = half*9 + tap; for gw=8 'half' selects which of the unit's two groups
-    the 8 input channels belong to (block-diagonal), for gw=16 which half of the group's 16 inputs."""
-    return torch.from_numpy(_gconv_frags_np(_np(w).astype(np.float32), gw)).to(device).to(torch.bfloat16).contiguous()
+    the 8 input channels belong to (block-diagonal), for gw=16 which half of the group's 16 inputs.
+    tap_major (tdeed_bneck_fwd): s = 2*tap + half -- the two k-slots of a ds_read_b128 lane group then differ by 16 bytes
+    at the SAME tap pixel, which is conflict-free at the one-launch bottleneck's even row stride (bneck.hip)."""
+    return torch.from_numpy(_gconv_frags_np(_np(w).astype(np.float32), gw, tap_major)).to(device).to(torch.bfloat16).contiguous()
 
 
-def _gconv_frags_np(w, gw):
+def _gconv_frags_np(w, gw, tap_major=False):
     C = w.shape[0]
     nu = (C + 15) // 16
     nu4 = (nu + 3) // 4 * 4
@@ -358,7 +360,7 @@ def _gconv_frags_np(w, gw):
                 s_ = 4 * ks + q
                 if s_ >= 18:
                     continue
-                half, tap = divmod(s_, 9)
+                half, tap = (s_ & 1, s_ >> 1) if tap_major else divmod(s_, 9)
                 ky, kx = divmod(tap, 3)
                 for n in range(16):
                     co = u * 16 + n
@@ -765,6 +767,8 @@ class PackedWeights:
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device, gated=True)
             # MFMA-fragment copies of conv1 / conv3 for the one-launch bottleneck (stride-1 identity blocks up to 384 wide)
             bw.fused = (SimpleNamespace(w1f=pack_mfma_frags(w1_mat, device),
+                                        w2f=pack_gconv_frags(sd[bp + ".conv2.conv.weight"], gw, device, tap_major=(gw == 8)),
+                                        w2_tap_major=(gw == 8),
                                         w3f=pack_mfma_frags(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), device))
                         if (bw.se_mf is not None and blk.stride == 1 and not blk.has_downsample and blk.cin == blk.cout
                             and blk.cout <= 384) else None)
@@ -918,9 +922,10 @@ class ForwardEngine:
                            if (nxt is not None and nxt.gsf_fold and GS_SLICE) else None)
                 G = gb["out"] if blk.gsf_fold else None
                 steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, out=out, xs_next=xs_next: ops.bneck(
-                    x, bw.fused.w1f, bw.s1, bw.h1, bw.w2frag, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
+                    x, bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
                     bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out,
-                    out2=(xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None)),
+                    out2=(xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None),
+                    w2_tap_major=bw.fused.w2_tap_major),
                     2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
                     2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
                 for t_ in gs_bufs:

@@ -160,16 +160,19 @@ def bneck_fits(h, w, C, R):
     return _lib.load().tdeed_bneck_fits(h, w, C, R) != 0
 
 
-def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, G=None, out=None, out2=None):
+def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, G=None, out=None, out2=None,
+          w2_tap_major=True):
     """Whole stride-1 bottleneck in one launch (tdeed_bneck_fwd): x (N,h,w,C) bf16 -> (N,h,w,C); G (N*h*w, Fp): gate-shift
-    output spliced into conv1's operand; out2 (N*h*w, n2): compact copy of the first n2 output channels."""
+    output spliced into conv1's operand; out2 (N*h*w, n2): compact copy of the first n2 output channels.
+    w2f: engine.pack_gconv_frags(..., tap_major=w2_tap_major) -- tap-major k-slots are the conflict-free order of this launch
+    (group width 8: bit-identical to the chain either way); False: the order tdeed_gconv3x3_fwd reads (16-wide groups)."""
     _chk(x, "x", torch.bfloat16); _chk(G, "G", torch.bfloat16); _chk(out2, "out2", torch.bfloat16)
     N, h, w, C = x.shape
     if out is None:
         out = torch.empty_like(x)
     call("tdeed_bneck_fwd", ptr(x), ptr(G), (G.shape[-1] if G is not None else 0), N, h, w, C, ptr(w1f), ptr(s1),
          ptr(h1), ptr(w2f), ptr(s2), ptr(h2), ptr(se_w1f), ptr(se_b1), ptr(se_w2f), ptr(se_b2), R, ptr(w3f), ptr(s3), ptr(h3),
-         ptr(out), ptr(out2), (out2.shape[-1] if out2 is not None else 0), stream_ptr())
+         ptr(out), ptr(out2), (out2.shape[-1] if out2 is not None else 0), int(bool(w2_tap_major)), stream_ptr())
     return out
 
 

@@ -278,8 +278,9 @@ def test_one_launch_bottleneck_equals_the_launch_per_layer_chain(h, w, C, gw, R,
     ref = ops.gemm(y2.view(M, C), W3d, s3, h3, ops.ACT_RELU, residual=xd.view(M, C), a_scale=gate, a_scale_rows=hw, out2=ref2)
     # one launch
     out2 = torch.empty_like(ref2)
-    out = ops.bneck(xd, pack_mfma_frags(W1.numpy(), DEV), s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R,
-                    pack_mfma_frags(W3.numpy(), DEV), s3, h3, G=Gd, out2=out2)
+    out = ops.bneck(xd, pack_mfma_frags(W1.numpy(), DEV), s1, h1, pack_gconv_frags(W2.numpy(), gw, DEV, tap_major=(gw == 8)), s2, h2,
+                    se["w1f"], b1, se["w2f"], b2, R,
+                    pack_mfma_frags(W3.numpy(), DEV), s3, h3, G=Gd, out2=out2, w2_tap_major=(gw == 8))
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     assert torch.equal(out.view(M, C), ref), float((out.view(M, C).float() - ref.float()).abs().max())

@@ -263,8 +263,9 @@ def test_one_launch_bottleneck_at_the_timed_size_is_within_one_ulp_of_the_chain(
     y2, pooled = ops.gconv3x3(y1.view(N, h, w, C), None, s2, h2, gw, 1, wfrag=w2f)
     gate = ops.se_gate_mfma(pooled, 1.0 / hw, se["w1f"], b1, se["w2f"], b2, R)
     ref = ops.gemm(y2.view(M, C), W3d, s3, h3, ops.ACT_RELU, residual=xd.view(M, C), a_scale=gate, a_scale_rows=hw)
-    out = ops.bneck(xd, pack_mfma_frags(W1.numpy(), DEV), s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R,
-                    pack_mfma_frags(W3.numpy(), DEV), s3, h3, G=Gd).view(M, C)
+    out = ops.bneck(xd, pack_mfma_frags(W1.numpy(), DEV), s1, h1, pack_gconv_frags(W2.numpy(), gw, DEV, tap_major=(gw == 8)), s2, h2,
+                    se["w1f"], b1, se["w2f"], b2, R,
+                    pack_mfma_frags(W3.numpy(), DEV), s3, h3, G=Gd, w2_tap_major=(gw == 8)).view(M, C)
     torch.cuda.synchronize()
     a, b = out.float(), ref.float()
     diff = (a - b).abs()

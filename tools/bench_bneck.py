@@ -39,6 +39,7 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
     W1d, W3d = W1.to(torch.bfloat16).to(DEV), W3.to(torch.bfloat16).to(DEV)
     w1f, w3f = pack_mfma_frags(W1.numpy(), DEV), pack_mfma_frags(W3.numpy(), DEV)
     w2f = pack_gconv_frags(W2.numpy(), gw, DEV)
+    w2f_tm = pack_gconv_frags(W2.numpy(), gw, DEV, tap_major=True)      # the one-launch form's k-slot order
     se = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
     y1 = torch.empty((M, C), dtype=torch.bfloat16, device=DEV)
     y2 = torch.empty((N, h, w, C), dtype=torch.bfloat16, device=DEV)
@@ -57,7 +58,7 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
                  out2=out2)
 
     def fused():
-        ops.bneck(x, w1f, s1, h1, w2f, s2, h2, se["w1f"], b1, se["w2f"], b2, R, w3f, s3, h3, G=G, out=outb, out2=out2)
+        ops.bneck(x, w1f, s1, h1, w2f_tm, s2, h2, se["w1f"], b1, se["w2f"], b2, R, w3f, s3, h3, G=G, out=outb, out2=out2)
 
     t0, t1 = timeit(chain), timeit(fused)
     chain(); ref = out.clone(); fused(); torch.cuda.synchronize()
