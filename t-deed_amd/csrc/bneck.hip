@@ -51,7 +51,9 @@ __device__ __forceinline__ float bnk_row16_sum(float v) {
 }
 
 // FPW frames per workgroup, NPTM >= ceil(FPW * hw / 16) pixel tiles
-template <int KS, int FPW, int NPTM>
+// TAPM: conv2's k-slot order (BneckP::w2_tap_major) as a compile-time constant -- as a run-time select the same addresses
+// cost the conv2 phase its whole gain (186 vs 175 stamp units: measured)
+template <int KS, int FPW, int NPTM, bool TAPM>
 __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int hw = p.h * p.w, C = p.C;
@@ -394,8 +396,8 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
         // (for group width 8 an output's sum is bit-identical under either order in every test; for 16-wide groups -- both
         //  halves of a k-slot pair carry weights of the same output -- it is not, and the caller keeps the half-major order)
         const int sidx = 4 * ks + q;
-        const int half = p.w2_tap_major ? (sidx & 1) : (sidx >= 9 ? 1 : 0);
-        const int tap = p.w2_tap_major ? (sidx >> 1) : sidx - 9 * half;
+        const int half = TAPM ? (sidx & 1) : (sidx >= 9 ? 1 : 0);
+        const int tap = TAPM ? (sidx >> 1) : sidx - 9 * half;
         const int ty = (tap >= 3 ? 1 : 0) + (tap >= 6 ? 1 : 0);
         dyv[ks] = ty - 1;
         dxv[ks] = tap - 3 * ty - 1;
@@ -701,19 +703,24 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
   hipStream_t st = (hipStream_t)stream;
   static TdDevOnce attr_set;
   if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)bneck_kernel<12, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 1, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<5, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<12, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipSuccess;
+#define BNK_ATTR(...) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    BNK_ATTR(12, 2, 7, true); BNK_ATTR(12, 2, 7, false); BNK_ATTR(5, 1, 13, true); BNK_ATTR(5, 1, 13, false);
+    BNK_ATTR(5, 2, 8, true); BNK_ATTR(5, 2, 8, false); BNK_ATTR(12, 1, 7, true); BNK_ATTR(12, 1, 7, false);
+#undef BNK_ATTR
     if (e != hipSuccess) { tdeed_set_error("bneck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
     attr_set.set();
   }
   const int grid = (N + fpw - 1) / fpw;
-  if (KS == 12 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<12, 2, 7>), dim3(grid), dim3(BNK_THR), smem, st, p);
-  else if (KS == 5 && fpw == 1) hipLaunchKernelGGL((bneck_kernel<5, 1, 13>), dim3(grid), dim3(BNK_THR), smem, st, p);
-  else if (KS == 5 && fpw == 2) hipLaunchKernelGGL((bneck_kernel<5, 2, 8>), dim3(grid), dim3(BNK_THR), smem, st, p);
-  else if (KS == 12 && fpw == 1) hipLaunchKernelGGL((bneck_kernel<12, 1, 7>), dim3(grid), dim3(BNK_THR), smem, st, p);   // e.g. 13 x 7 maps
+  const bool tm = p.w2_tap_major != 0;
+#define BNK_GO(...) do { if (tm) hipLaunchKernelGGL((bneck_kernel<__VA_ARGS__, true>), dim3(grid), dim3(BNK_THR), smem, st, p); \
+                         else hipLaunchKernelGGL((bneck_kernel<__VA_ARGS__, false>), dim3(grid), dim3(BNK_THR), smem, st, p); } while (0)
+  if (KS == 12 && fpw == 2) BNK_GO(12, 2, 7);
+  else if (KS == 5 && fpw == 1) BNK_GO(5, 1, 13);
+  else if (KS == 5 && fpw == 2) BNK_GO(5, 2, 8);
+  else if (KS == 12 && fpw == 1) BNK_GO(12, 1, 7);   // e.g. 13 x 7 maps
   else { tdeed_set_error("bneck: KS=%d with %d frames per workgroup", KS, fpw); return TDEED_ERR_ARG; }
+#undef BNK_GO
   TD_LAUNCH_CHECK("bneck");
   return TDEED_OK;
 }
