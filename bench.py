@@ -23,6 +23,64 @@ from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _requested_gpus(argv):
+    """--gpus N as given on the command line (1 if absent), read without argparse so that it is known before torch is
+    imported and before anything touches the GPU."""
+    n = 1
+    for i, tok in enumerate(argv):
+        if tok == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif tok.startswith("--gpus="):
+            n = int(tok.split("=", 1)[1])
+    return n
+
+
+def _self_launch(n, argv):
+    """`python bench.py --gpus N` with no torchrun environment around it: start N CHILD ranks of this same script (one
+    process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relay rank 0's JSON line and
+    leave with the worst child's return code.  The parent never imports torch and never initialises the GPU; nothing is
+    re-exec'd (a child is a fresh interpreter started before any HIP call of its own)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   TDEED_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=os.getcwd(),
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), text=True))
+    import threading
+    got = []
+    rd = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    # a rank that dies before the rendezvous would leave the others waiting for it: end them (exact PIDs) and report
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        time.sleep(0.2)
+    rd.join(timeout=10)
+    sys.stdout.write("".join(got))
+    sys.stdout.flush()
+    bad = [p.returncode for p in procs if p.returncode != 0]
+    return (bad[0] if bad else 0)
+
+
+if __name__ == "__main__":
+    _n = _requested_gpus(sys.argv[1:])
+    _w = os.environ.get("WORLD_SIZE")
+    if _w is None and _n > 1:
+        sys.exit(_self_launch(_n, sys.argv[1:]))
+    if _w is not None and int(_w) != _n:
+        sys.stderr.write(f"bench.py: --gpus {_n} disagrees with WORLD_SIZE={_w} of the launching environment\n")
+        sys.exit(2)
+
 import torch  # noqa: E402
 import tdeed_amd  # noqa: E402,F401
 from tdeed_amd import synth, state_layout, ops, dist as tdist  # noqa: E402
@@ -47,6 +105,7 @@ TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
 TRAFFIC_FILE_800MF = os.path.join("profiles", "r05_hbm_traffic_800mf_b16.json")
 TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r05_train_hbm_traffic.json")
 # C-ABI entry -> kernel family of tools/summarize_pmc.py (what the counter passes are keyed by)
+DIST_INFO = dict(backend="none", ranks=1)      # _dist_setup(): what the process group itself counted
 TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
 
 
@@ -392,6 +451,10 @@ def compact_line(out):
     c.update({k: v for k, v in hoist.items() if v is not None})
     c["roofline"] = _trim(out.get("roofline"))
     c["cpu_baseline"] = _trim(out.get("cpu_baseline"))
+    if isinstance(c["cpu_baseline"], dict):          # north_star: "core count stated" -- the host's, beside the threads used
+        for k in ("host_cores", "cpu_model"):
+            if _g(out, "cpu_baseline", k) is not None:
+                c["cpu_baseline"][k] = out["cpu_baseline"][k]
     for k in ("roofline_step", "roofline_sgp", "timed_output_check", "fed_from_host", "infer_800mf", "infer_snb_t250", "train",
               "dp_diag"):
         if out.get(k) is not None:
@@ -499,7 +562,21 @@ def _dist_setup():
     local_dev = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local_dev)
     tdist.init(backend=backend, device=torch.device("cuda", local_dev))   # no-op for a single process
+    global DIST_INFO
+    DIST_INFO = tdist.count_ranks(torch.device("cuda", local_dev))
+    if DIST_INFO["ranks"] != world:
+        raise RuntimeError(f"the process group counts {DIST_INFO['ranks']} ranks, WORLD_SIZE is {world}")
     return rank, local, world, f"cuda:{local_dev}"
+
+
+def _dist_fields():
+    """config fields that show how many ranks the launch really had: counted by a one-element all-reduce on the process
+    group (`rccl_ranks` when that group is RCCL, i.e. backend "nccl"; `dist_ranks` always)."""
+    d = dict(dist_backend=DIST_INFO["backend"], dist_ranks=DIST_INFO["ranks"],
+             self_launched=os.environ.get("TDEED_BENCH_SELF_LAUNCHED") == "1")
+    if DIST_INFO["backend"] == "nccl":
+        d["rccl_ranks"] = DIST_INFO["ranks"]
+    return d
 
 
 # ----------------------------------------------------------------------------------------------------- training step
@@ -583,8 +660,11 @@ def train_family_roofline(eng, workload, frames, lab, labD, masks, dt):
         if tj.get("workload") == workload:
             tr = tj["kernels"].get(TRAIN_FAMILY.get(name, ""))
             if tr is not None:
-                rec["traffic"] = int(tr["hbm_bytes_per_step"] / max(d["calls"], 1)) if "hbm_bytes_per_step" in tr \
-                    else tr["hbm_bytes_per_launch"]
+                # per launch of the KERNEL family the counters are keyed by (its own launch count, register-stationary and
+                # input-gradient forms included) -- not the family's bytes over this C-ABI entry's calls
+                rec["traffic"] = int(tr["hbm_bytes_per_launch"])
+                rec["traffic_kernel_family"] = dict(name=TRAIN_FAMILY.get(name), launches_per_step=tr.get("kernel_launches_per_step"),
+                                                    hbm_bytes_per_step=tr.get("hbm_bytes_per_step"))
                 rec["traffic_source"] = (f"{TRAIN_TRAFFIC_FILE}: separate rocprofv3 --pmc passes at git {tj.get('git_head')} "
                                          f"({tj.get('fetch_pass', {}).get('mtime')}); not measured by this run")
             rec["step_hbm_bytes_measured"] = tj.get("step_hbm_bytes")
@@ -795,7 +875,8 @@ def main_train(a):
                    ms_per_step=rec["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=a.dtype, data="synthetic",
                    config=dict(workload=rec["workload"], clips_per_gpu=wl["B"], parallelism=rec["parallelism"],
-                               grad_buffer_mb=rec["grad_buffer_mb"], final_loss=rec["final_loss"], hip_graph=rec["hip_graph"]),
+                               grad_buffer_mb=rec["grad_buffer_mb"], final_loss=rec["final_loss"], hip_graph=rec["hip_graph"],
+                               **_dist_fields()),
                    repeats=a.repeats, ms_per_step_repeats=rec["ms_per_step_repeats"],
                    roofline=rec["roofline"], cpu_baseline=rec["cpu_baseline"], git_head=git_head())
         if "reducer" in rec:
@@ -970,7 +1051,7 @@ def main():
                                         f"ks={cfg['sgp_ks']}, L={T}, {H}x{W}, batch {B}/GPU, inference forward, "
                                         "random-init weights", clips_per_gpu=B, parallelism=f"dp{world} (clip-sharded, no collective)",
                                hip_graph=not a.no_graph, batches_in_flight=depth,
-                               sub_batches_per_batch=len(plan.subs)),
+                               sub_batches_per_batch=len(plan.subs), **_dist_fields()),
                    repeats=a.repeats, ms_per_step_repeats=[round(w / a.steps * 1e3, 4) for w in walls],
                    ms_per_step_hip_events=round(statistics.median(evs) / a.steps, 4),
                    latency_ms_inflight1=round(statistics.median(lat), 4),
@@ -1023,5 +1104,24 @@ def main():
         dist.destroy_process_group()
 
 
+def launch_probe():
+    """TDEED_BENCH_LAUNCH_PROBE=1: only the launch path -- rendezvous (gloo, CPU), count the ranks with a collective, rank 0
+    prints {"n_gpus": ranks, ...} -- so that `python bench.py --gpus N` (self-launch) and the torchrun form can be tested
+    on a box without a GPU.  Not a measurement."""
+    rank, local, world = tdist.init(backend="gloo")
+    info = tdist.count_ranks()
+    tdist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(launch_probe=True, n_gpus=info["ranks"], world_env=world, dist_backend=info["backend"],
+                              requested_gpus=_requested_gpus(sys.argv[1:]),
+                              self_launched=os.environ.get("TDEED_BENCH_SELF_LAUNCHED") == "1")))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("TDEED_BENCH_LAUNCH_PROBE") == "1":
+        launch_probe()
+    else:
+        main()

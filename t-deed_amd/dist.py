@@ -32,6 +32,17 @@ def init(backend=None, device=None):
     return rank, local, world
 
 
+def count_ranks(device=None):
+    """How many ranks the default process group REALLY has: a one-element SUM all-reduce of ones (on `device` when the group
+    is RCCL).  {"backend": "none" | "nccl" | "gloo", "ranks": n}; a single process reports ("none", 1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return dict(backend="none", ranks=1)
+    backend = dist.get_backend()
+    one = torch.ones(1, dtype=torch.float32, device=(device if backend == "nccl" else "cpu"))
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return dict(backend=backend, ranks=int(round(float(one.item()))))
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced split of n_items clips: the first n_items % world ranks get one extra."""
     base, rem = divmod(n_items, world)

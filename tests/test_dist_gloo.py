@@ -215,3 +215,45 @@ def test_eight_rank_reducer_takes_rs_ag_on_the_real_bucket_layout():
         assert d["bucket_collectives"][0] == "rs_ag" and d["world"] == 8 and d["rs_ag_tail_elems"] == [0, 0]
         assert launched[0] == (0, "rs_ag")
         assert p_odd["collective"] == "rs_ag" and p_odd["tail"] == 4 and p_odd["rs_ag_numel"] == 8 * 37
+
+
+def _bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_bench_gpus_flag_starts_that_many_ranks_by_itself(n):
+    """`python bench.py --gpus N` without torchrun around it (the flag was parsed and never used): the
+    launch path alone (TDEED_BENCH_LAUNCH_PROBE: rendezvous + a counting all-reduce, no GPU) must come up as N ranks and
+    print one line from rank 0."""
+    import json
+    r = _bench(["--gpus", str(n), "--steps", "3"], dict(TDEED_BENCH_LAUNCH_PROBE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["world_env"] == n and rec["self_launched"] == (n > 1)
+
+
+def test_bench_gpus_flag_under_torchrun_and_mismatch_is_refused():
+    """The driver's launch line keeps working (WORLD_SIZE from torchrun == --gpus), and a --gpus that disagrees with the
+    launching environment's WORLD_SIZE exits non-zero before anything is measured."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, TDEED_BENCH_LAUNCH_PROBE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["self_launched"] is False
+    r = _bench(["--gpus", "2"], dict(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode == 2 and "disagrees with WORLD_SIZE" in r.stderr

@@ -130,19 +130,27 @@ def test_two_rank_dp_step_equals_adamw_on_the_mean_of_per_rank_gradients(graph):
 
 
 
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
 @pytest.mark.parametrize("mode", ["infer", "train"])
-def test_bench_runs_as_two_ranks_on_one_gpu(mode):
-    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with
-    two ranks sharing this box's GPU over gloo: every rank must reach every collective (barriers, max over ranks, gradient
-    buckets) and rank 0 must print one JSON line for the whole job."""
+def test_bench_runs_as_two_ranks_on_one_gpu(mode, launcher):
+    """Both launch forms of a 2-rank job, two ranks sharing this box's GPU over gloo: "self" = plain `python bench.py --gpus 2`
+    (bench.py starts its own child ranks before anything touches the GPU), "torchrun" = the driver's
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.  Every rank must reach every collective
+    (barriers, max over ranks, gradient buckets), rank 0 must print ONE JSON line for the whole job, and the line must show
+    the rank count the process group itself counted."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TDEED_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--repeats", "2", "--no-cpu-baseline"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
     if mode == "train":
         cmd += ["--mode", "train", "--workload", "rny002_b8"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
@@ -152,6 +160,8 @@ def test_bench_runs_as_two_ranks_on_one_gpu(mode):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["clips_per_gpu"] == 8
+    assert rec["config"]["dist_ranks"] == 2 and rec["config"]["dist_backend"] == "gloo"
+    assert rec["config"]["self_launched"] == (launcher == "self")
     if mode == "train":
         red = rec["config"]["reducer"]
         assert red["world"] == 2 and len(red["buckets_mb"]) == 2 and "between the two captured halves" in red["collectives"]
