@@ -219,10 +219,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     const long f_first = m0 / p.a_scale_rows;
     const long f_last = (p.M - 1) / p.a_scale_rows;
     const int nf = 128 / p.a_scale_rows + 2;
-    for (int i = tid * 4; i < nf * p.K; i += 1024) {
-      const int f = i / p.K, k = i - f * p.K;
-      *reinterpret_cast<f32x4*>(gtab + i) =
-          *reinterpret_cast<const f32x4*>(p.a_scale + min(f_first + f, f_last) * (long)p.K + k);
+    const int ng = nf * p.K;
+    for (int i0 = tid * 4; i0 < ng; i0 += 4 * 1024) {           // four pieces per thread in flight (not a round trip per piece)
+      f32x4 gv[4];
+#pragma unroll
+      for (int b_ = 0; b_ < 4; ++b_) {
+        const int i = min(i0 + b_ * 1024, ng - 4);
+        const int f = i / p.K, k = i - f * p.K;
+        gv[b_] = *reinterpret_cast<const f32x4*>(p.a_scale + min(f_first + f, f_last) * (long)p.K + k);
+      }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int b_ = 0; b_ < 4; ++b_)
+        if (i0 + b_ * 1024 < ng) *reinterpret_cast<f32x4*>(gtab + i0 + b_ * 1024) = gv[b_];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -620,7 +629,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ws_kernel(const
       frag_t* wdst = reinterpret_cast<frag_t*>(smem);
       const frag_t* src = reinterpret_cast<const frag_t*>(p.Wf) + (size_t)nt0 * KS * 64;
       TD_DEV_ASSERT(nts <= p.NTS && nt0 + nts <= p.NT);
-      for (int i = tid; i < nts * KS * 64; i += NTHR) wdst[i] = src[i];
+      // 8 fragments per thread in flight (round 6: `wdst[i] = src[i]` per trip was one `global_load; s_waitcnt vmcnt(0)` per
+      // 16 bytes -- a 152 x 152 weight cost every workgroup 13 dependent L2 round trips before its first row)
+      const int nfr = nts * KS * 64;
+      constexpr int WB = 8;
+      for (int i0 = tid; i0 < nfr; i0 += NTHR * WB) {
+        frag_t v[WB];
+#pragma unroll
+        for (int b_ = 0; b_ < WB; ++b_) v[b_] = src[min(i0 + b_ * NTHR, nfr - 1)];
+        TD_ISSUE_FENCE();
+#pragma unroll
+        for (int b_ = 0; b_ < WB; ++b_)
+          if (i0 + b_ * NTHR < nfr) wdst[i0 + b_ * NTHR] = v[b_];
+      }
     }
     for (int i = tid; i < nts * 16; i += NTHR) {
       const int n = nt0 * 16 + i;
@@ -1415,9 +1436,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   if (i >= (long)M * n4) return;
   const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
   f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)m * N + n);
-  for (int s_ = 1; s_ < S; ++s_) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(part + ((long)s_ * M + m) * N + n);
-    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  // eight partials in flight per thread (round 6: one `load; s_waitcnt vmcnt(0); add` per split was 16 - 24 dependent round
+  // trips at K = 4C .. 6C); the additions keep their order
+  for (int s0 = 1; s0 < S; s0 += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(part + ((long)min(s0 + k, S - 1) * M + m) * N + n);
+    TD_ISSUE_FENCE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (s0 + k < S) { v[0] += t[k][0]; v[1] += t[k][1]; v[2] += t[k][2]; v[3] += t[k][3]; }
   }
   bf16x4 rr;
   if (R) rr = *reinterpret_cast<const bf16x4*>(R + (long)m * ldr + n);

@@ -61,6 +61,10 @@ __device__ __forceinline__ void ln_row_stats(const T* __restrict__ slab, long ld
 // tile of the contraction that stored it (sgp_gemm.hip MODE 1), summed here in order; pstride = floats per part
 __device__ __forceinline__ void ln_row_stats_load(const float* __restrict__ rowstat, int parts, long pstride, int T_len,
                                                   int C, float eps, float* mu, float* rs) {
+  // a row's parts are requested TOGETHER, in batches of PB (round 6: as `for (pt) { load; add; }` hipcc emitted
+  // `global_load; s_waitcnt vmcnt(0)` per part -- 3 to 12 dependent L2 round trips in front of every front launch, and the
+  // vmcnt(0) also drained the tile / weight loads issued before); the additions keep their order
+  constexpr int PB = 6;
   for (int t = threadIdx.x; t < T_len; t += blockDim.x) {
     if (parts == 0) {
       const f32x2 v = *reinterpret_cast<const f32x2*>(rowstat + (long)t * 2);
@@ -68,10 +72,17 @@ __device__ __forceinline__ void ln_row_stats_load(const float* __restrict__ rows
       rs[t] = v[1];
     } else {
       float s = 0.f, q = 0.f;
-      for (int pt = 0; pt < parts; ++pt) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(rowstat + pt * pstride + (long)t * 2);
-        s += v[0];
-        q += v[1];
+      for (int p0 = 0; p0 < parts; p0 += PB) {
+        f32x2 v[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) v[k] = *reinterpret_cast<const f32x2*>(rowstat + min(p0 + k, parts - 1) * pstride + (long)t * 2);
+        TD_ISSUE_FENCE();
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+          if (p0 + k < parts) {
+            s += v[k][0];
+            q += v[k][1];
+          }
       }
       const float m = s / (float)C;
       mu[t] = m;

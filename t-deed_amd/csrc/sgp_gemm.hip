@@ -175,21 +175,45 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
     float* gs = red;                                      // [G][2] group (mean, rstd); red is re-used later
     float* cs = red + 64;                                 // [Kp][2]
     constexpr int CPT = 4;                                // channels per thread: K <= 1024
-    float gw_[CPT], gb_[CPT];
+    // ALL of this thread's partial sums are requested before any is added (round 6: as `for (u) for (pt) load; add` hipcc
+    // emitted one `global_load; s_waitcnt vmcnt(0)` loop per channel slot -- four dependent L2 round trips in a row, which also
+    // drained the two chunks in flight: the 2.7 us the round-5 stamps found in this prologue).  Same order of additions.
+    constexpr int PB = 4;                                 // parts per batch
+    float gw_[CPT], gb_[CPT], s_[CPT], q_[CPT];
+    const int nu = min(CPT, (p.K + 255) >> 8);            // channel slots that hold a channel at all (uniform)
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
       const int c = min(tid + u * 256, p.K - 1);
-      float s = 0.f, q = 0.f;
-      for (int pt = 0; pt < p.chs_parts; ++pt) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + c) * 2);
-        s += v[0];
-        q += v[1];
-      }
-      gw_[u] = p.gn_w[c];
-      gb_[u] = p.gn_b[c];
-      if (tid + u * 256 < p.K) {
-        cs[2 * c] = s;
-        cs[2 * c + 1] = q;
+      gw_[u] = u < nu ? p.gn_w[c] : 0.f;
+      gb_[u] = u < nu ? p.gn_b[c] : 0.f;
+      s_[u] = q_[u] = 0.f;
+    }
+    for (int p0 = 0; p0 < p.chs_parts; p0 += PB) {
+      f32x2 v[CPT][PB];
+#pragma unroll
+      for (int u = 0; u < CPT; ++u)
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+          const int c = min(tid + u * 256, p.K - 1), pt = min(p0 + k, p.chs_parts - 1);
+          if (u < nu) v[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + c) * 2);
+          else v[u][k] = f32x2{0.f, 0.f};
+        }
+      TD_ISSUE_FENCE();
+#pragma unroll
+      for (int u = 0; u < CPT; ++u)
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+          if (p0 + k < p.chs_parts) {
+            s_[u] += v[u][k][0];
+            q_[u] += v[u][k][1];
+          }
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int c = tid + u * 256;
+      if (c < p.K) {
+        cs[2 * c] = s_[u];
+        cs[2 * c + 1] = q_[u];
       }
     }
     __syncthreads();

@@ -620,8 +620,8 @@ __device__ __forceinline__ void se_contract(const float* in /*LDS [SEF][I]*/, in
     if (j < J) {
       const int per = (I + nsl - 1) / nsl;
       const int i_lo = sl * per, i_hi = min(I, i_lo + per);
-#pragma unroll 8
-      for (int i = i_lo; i < i_hi; ++i) {
+#pragma unroll 16
+      for (int i = i_lo; i < i_hi; ++i) {       // 16 weight loads in flight per trip (a trip is one exposed L2 round trip)
         const float wv = wt[(long)i * J + j];
 #pragma unroll
         for (int f = 0; f < SEF; ++f) a[f] = fmaf(in[f * I + i], wv, a[f]);
