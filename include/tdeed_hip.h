@@ -282,6 +282,9 @@ int tdeed_mixer_branch_fwd(const void* xn, int B, int T_hi, int T_lo, int C, int
 /* rowstat*_parts: 0 = the (mean, rstd) form above; n > 0 = [n][rows][2] partial (sum, sum of squares) of each row over the n
  * column tiles of the tdeed_sgp_gemm_residual launch that stored the rows (summed in order; mean / rstd derived here).
  * dtype_cat (mixer): the six slabs may be stored as bf16 while z / x_lo are fp32 (fp32 residual stream, bf16 contraction). */
+/* diagnostic: int64 [workgroups][16] phase time stamps of tdeed_sgp_front_fwd (wall_clock64, 10 ns ticks; slots 0..5 = start,
+ * loads issued + row statistics, tile in LDS, LayerNorm applied, branches done, stored); null switches it off */
+int tdeed_sgp_front_set_debug(void* buf);
 int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, int up, const float* ln_w, const float* ln_b, float eps,
                         const float* dw, const float* db, void* y, float* chsum, const float* rowstat, int rowstat_parts,
                         void* y16 /* optional, dtype fp32 only: a bf16 copy of y (the fc1 operand of wide models) */,

@@ -148,6 +148,7 @@ _SIGS = {
     "tdeed_layernorm_fwd": ([P, c_long, c_int, c_int, P, P, c_float, P, c_long, c_int, P], c_int),
     "tdeed_sgp_branch_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P], c_int),
     "tdeed_mixer_branch_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P], c_int),
+    "tdeed_sgp_front_set_debug": ([P], c_int),
     "tdeed_sgp_front_fwd": ([P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int, P, c_int, P], c_int),
     "tdeed_mixer_front_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int, P,
                                c_int, c_int, c_int, P], c_int),

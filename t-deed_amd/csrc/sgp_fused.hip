@@ -16,6 +16,10 @@
 #include "sgp_tile.h"
 #include <stdlib.h>
 
+static long long* g_sgp_front_dbg = nullptr;           // diagnostic: per-workgroup phase time stamps (wall_clock64, 10 ns ticks)
+extern "C" int tdeed_sgp_front_set_debug(void* buf) { g_sgp_front_dbg = (long long*)buf; return TDEED_OK; }
+#define SF_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------ LayerNorm row statistics
@@ -117,8 +121,9 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ db, T* __restrict__ y,
                                                         float* __restrict__ chsum,
                                                         const float* __restrict__ rowstat, int rs_parts,
-                                                        bf16_t* __restrict__ y16) {
+                                                        bf16_t* __restrict__ y16, long long* __restrict__ dbg) {
   extern __shared__ float sm[];
+  SF_STAMP(0);
   const int halo = up >> 1;
   const int wlen = 2 * ks + up + 2;
   float* tile = sm;                                   // [(T+2h)][16]
@@ -139,11 +144,14 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
   const float lw = ln_w[min(c0 + c, C - 1)], lb = ln_b[min(c0 + c, C - 1)];
   if (rowstat) ln_row_stats_load(rowstat + (long)b * T_len * 2, rs_parts, (long)gridDim.x * T_len * 2, T_len, C, eps, mu, rs);
   else ln_row_stats<T>(x + base, C, T_len, C, eps, mu, rs);
+  SF_STAMP(1);
   tile_commit<T>(tv, T_len, c0, C, tile, halo, res);          // res starts as the raw rows: y = x + (branches) grows in place
   dw_commit(wv, wlen, c0, C, wl);
   __syncthreads();
+  SF_STAMP(2);
   red[tl * SGP_CH + c] = ln_apply_tile(tile, T_len, halo, mu, rs, lw, lb, cok);      // + this thread's share of mean_T
   __syncthreads();
+  SF_STAMP(3);
   const float mean_c = tile_mean_fold(red, c, T_len);
 #define FRONT_FAST(KS_, UP_)                                                                                   \
   branch_runs<KS_, UP_>(tile, wl, bb, cok, c, tl, T_len, halo, mean_c,                                         \
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
 #undef FRONT_FAST
 #undef FRONT_GENERIC
   __syncthreads();
+  SF_STAMP(4);
   store_tile<T>(res, y + base, C, 0, T_len, c0, C, (const T*)nullptr, 0);
   // fp32 residual stream over a WIDE feature dimension: a bf16 copy of y as the fc1 contraction's operand (its fp32 rows would
   // double the bytes every column tile of that launch pulls through its CU: 34.9 vs 28.1 us at C = 768, 1600 rows)
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(256) void sgp_front_kernel(const T* __restrict__ x,
       chsum[((long)b * C + c0 + threadIdx.x) * 2 + 1] = bq;
     }
   }
+  SF_STAMP(5);
 }
 
 static size_t front_smem(int T_len, int ks, int up, int ntiles, int nres, int nstat) {
@@ -209,10 +219,10 @@ extern "C" int tdeed_sgp_front_fwd(const void* x, int B, int T, int C, int ks, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDEED_F32)
     hipLaunchKernelGGL(sgp_front_kernel<float>, grid, dim3(256), smem, st, (const float*)x, T, C, ks, up, ln_w, ln_b, eps,
-                       dw, db, (float*)y, chsum, rowstat, rowstat_parts, (bf16_t*)y16);
+                       dw, db, (float*)y, chsum, rowstat, rowstat_parts, (bf16_t*)y16, g_sgp_front_dbg);
   else if (dtype == TDEED_BF16)
     hipLaunchKernelGGL(sgp_front_kernel<bf16_t>, grid, dim3(256), smem, st, (const bf16_t*)x, T, C, ks, up, ln_w, ln_b,
-                       eps, dw, db, (bf16_t*)y, chsum, rowstat, rowstat_parts, (bf16_t*)nullptr);
+                       eps, dw, db, (bf16_t*)y, chsum, rowstat, rowstat_parts, (bf16_t*)nullptr, g_sgp_front_dbg);
   else { tdeed_set_error("sgp_front: bad dtype %d", dtype); return TDEED_ERR_ARG; }
   TD_LAUNCH_CHECK("sgp_front");
   return TDEED_OK;

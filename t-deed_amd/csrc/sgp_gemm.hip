@@ -114,6 +114,16 @@ __device__ __forceinline__ float sg_sum_r(float v) {
   return v;
 }
 
+// the same sum by DPP moves (lane ^ 1, lane ^ 2, the other quad of the half row, the other half row): the pairing of the
+// xor butterfly above, so the same bits, without its LDS crossbar round trips
+__device__ __forceinline__ float sg_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 template <int MT, int NT, int MODE, typename TA, typename TO>
 __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
   constexpr int BM = 16 * MT;
@@ -162,95 +172,104 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
       for (int ks = 0; ks < SG_KC; ++ks) wreg[slot][ks][nt] = wp[ks * 64];
     }
   };
+  // MODE 0: the first batch of GroupNorm channel sums (group pass 0, this lane's first channels, the first parts) and the
+  // affine are requested AHEAD of the chunks, so the prologue's wait leaves the chunk loads in flight (vmcnt counts in order)
+  constexpr int GN_NCL = 4, GN_PB = 4;                    // channels per lane and parts per batch of loads
+  [[maybe_unused]] f32x2 gn_v0[MODE == 0 ? GN_NCL : 1][MODE == 0 ? GN_PB : 1];
+  [[maybe_unused]] float gn_w0[MODE == 0 ? GN_NCL : 1], gn_b0[MODE == 0 ? GN_NCL : 1];
+  if constexpr (MODE == 0) {
+    const int cg = p.K / p.G, g = min(tid >> 4, p.G - 1), jj = tid & 15;
+#pragma unroll
+    for (int u = 0; u < GN_NCL; ++u) {
+      const int ch = g * cg + min(jj + 16 * u, cg - 1);
+#pragma unroll
+      for (int k = 0; k < GN_PB; ++k)
+        gn_v0[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)min(k, p.chs_parts - 1) * p.B + b) * p.K + ch) * 2);
+      gn_w0[u] = p.gn_w[ch];
+      gn_b0[u] = p.gn_b[ch];
+    }
+  }
   issue(0, 0);
   issue(1, 1);
   f32x4 bias[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bias + min(ft0 + nt, NFT - 1) * 16 + lq * 4);
 
-  // ---- MODE 0: GroupNorm scale / shift of this clip per input channel (fixed-order sums over the channel partials).  Every
-  // global load of the prologue (the channel sums AND the affine) is requested before the first barrier: one round trip.
+  // ---- MODE 0: GroupNorm scale / shift of this clip per input channel, in ONE barrier (round 6).  Sixteen lanes per group
+  // (sixteen groups per pass of the 256 threads): a lane requests the per-part sums of ITS channels of the group (jj, jj + 16,
+  // ...) and their affine straight from global memory -- everything in one round trip, beside the first two chunks -- adds
+  // them in the order the round-5 prologue did (a channel's parts in order, the lane's channels in order, then the 16-lane
+  // tree: DPP moves with the pairing of the xor butterfly, i.e. the same bits), derives the group's mean / rstd in registers
+  // and writes the table entries of its own channels.  The round-5 form went channel sums -> LDS -> barrier -> group
+  // reduce -> LDS -> barrier -> table -> barrier and its loads were four dependent loops (2.7 us of a 6.6 us workgroup).
   if constexpr (MODE == 0) {
     const int Kp = p.KSP * 32;
-    float* gs = red;                                      // [G][2] group (mean, rstd); red is re-used later
-    float* cs = red + 64;                                 // [Kp][2]
-    constexpr int CPT = 4;                                // channels per thread: K <= 1024
-    // ALL of this thread's partial sums are requested before any is added (round 6: as `for (u) for (pt) load; add` hipcc
-    // emitted one `global_load; s_waitcnt vmcnt(0)` loop per channel slot -- four dependent L2 round trips in a row, which also
-    // drained the two chunks in flight: the 2.7 us the round-5 stamps found in this prologue).  Same order of additions.
-    constexpr int PB = 4;                                 // parts per batch
-    float gw_[CPT], gb_[CPT], s_[CPT], q_[CPT];
-    const int nu = min(CPT, (p.K + 255) >> 8);            // channel slots that hold a channel at all (uniform)
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      const int c = min(tid + u * 256, p.K - 1);
-      gw_[u] = u < nu ? p.gn_w[c] : 0.f;
-      gb_[u] = u < nu ? p.gn_b[c] : 0.f;
-      s_[u] = q_[u] = 0.f;
-    }
-    for (int p0 = 0; p0 < p.chs_parts; p0 += PB) {
-      f32x2 v[CPT][PB];
-#pragma unroll
-      for (int u = 0; u < CPT; ++u)
-#pragma unroll
-        for (int k = 0; k < PB; ++k) {
-          const int c = min(tid + u * 256, p.K - 1), pt = min(p0 + k, p.chs_parts - 1);
-          if (u < nu) v[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + c) * 2);
-          else v[u][k] = f32x2{0.f, 0.f};
-        }
-      TD_ISSUE_FENCE();
-#pragma unroll
-      for (int u = 0; u < CPT; ++u)
-#pragma unroll
-        for (int k = 0; k < PB; ++k)
-          if (p0 + k < p.chs_parts) {
-            s_[u] += v[u][k][0];
-            q_[u] += v[u][k][1];
-          }
-    }
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      const int c = tid + u * 256;
-      if (c < p.K) {
-        cs[2 * c] = s_[u];
-        cs[2 * c + 1] = q_[u];
-      }
-    }
-    __syncthreads();
     const int cg = p.K / p.G;
-    {
-      // 16 lanes per group walk its channels (G <= 16 groups per pass of 256 threads), one shuffle tree joins them
-      for (int g0 = 0; g0 < p.G; g0 += 16) {
-        const int g = min(g0 + (tid >> 4), p.G - 1), jj = tid & 15;
-        float s = 0.f, q = 0.f;
-        for (int c = jj; c < cg; c += 16) {
-          s += cs[2 * (g * cg + c)];
-          q += cs[2 * (g * cg + c) + 1];
-        }
-        s = sg_sum_r(s);
-        q = sg_sum_r(q);
-        if (jj == 0 && g0 + (tid >> 4) < p.G) {
-          const float n = (float)cg * (float)p.T;
-          const float mean = s / n;
-          const float var = fmaxf(q / n - mean * mean, 0.f);
-          gs[2 * g] = mean;
-          gs[2 * g + 1] = 1.0f / sqrtf(var + p.eps);
-        }
-      }
+    const int gl = tid >> 4, jj = tid & 15;
+    constexpr int NCL = GN_NCL, PB = GN_PB;
+    for (int c = p.K + tid; c < Kp; c += 256) {           // the k pad: 0 * x + 0
+      gtab[c] = 0.f;
+      gtab[Kp + c] = 0.f;
     }
-    __syncthreads();
+    for (int g0 = 0; g0 < p.G; g0 += 16) {
+      const int g = min(g0 + gl, p.G - 1);
+      const bool gok = g0 + gl < p.G;
+      float s = 0.f, q = 0.f, gw_[NCL], gb_[NCL];
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      const int c = tid + u * 256;
-      if (c < Kp) {
-        float sc = 0.f, sh = 0.f;
-        if (c < p.K) {
-          const int g = c / cg;
-          sc = gs[2 * g + 1] * gw_[u];
-          sh = fmaf(-gs[2 * g], sc, gb_[u]);
+      for (int u = 0; u < NCL; ++u) {
+        const int ch = g * cg + min(jj + 16 * u, cg - 1);
+        gw_[u] = g0 == 0 ? gn_w0[u] : p.gn_w[ch];
+        gb_[u] = g0 == 0 ? gn_b0[u] : p.gn_b[ch];
+      }
+      for (int c0 = 0; c0 < cg; c0 += 16 * NCL) {
+        float s_[NCL], q_[NCL];
+#pragma unroll
+        for (int u = 0; u < NCL; ++u) s_[u] = q_[u] = 0.f;
+        for (int p0 = 0; p0 < p.chs_parts; p0 += PB) {
+          f32x2 v[NCL][PB];
+#pragma unroll
+          for (int u = 0; u < NCL; ++u)
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+              const int ch = g * cg + min(c0 + jj + 16 * u, cg - 1), pt = min(p0 + k, p.chs_parts - 1);
+              if (g0 == 0 && c0 == 0 && p0 == 0) v[u][k] = gn_v0[u][k];
+              else v[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + ch) * 2);
+            }
+          TD_ISSUE_FENCE();
+#pragma unroll
+          for (int u = 0; u < NCL; ++u)
+#pragma unroll
+            for (int k = 0; k < PB; ++k)
+              if (p0 + k < p.chs_parts) {
+                s_[u] += v[u][k][0];
+                q_[u] += v[u][k][1];
+              }
         }
-        gtab[c] = sc;
-        gtab[Kp + c] = sh;
+#pragma unroll
+        for (int u = 0; u < NCL; ++u)
+          if (c0 + jj + 16 * u < cg) {
+            s += s_[u];
+            q += q_[u];
+          }
+      }
+      s = sg_row16_sum(s);
+      q = sg_row16_sum(q);
+      const float n = (float)cg * (float)p.T;
+      const float mean = s / n;
+      const float var = fmaxf(q / n - mean * mean, 0.f);
+      const float rstd = 1.0f / sqrtf(var + p.eps);
+      for (int c0 = 0; c0 < cg; c0 += 16 * NCL) {
+#pragma unroll
+        for (int u = 0; u < NCL; ++u) {
+          const int c = c0 + jj + 16 * u;
+          if (c < cg && gok) {
+            const int ch = g * cg + c;
+            const float w_ = c0 == 0 ? gw_[u] : p.gn_w[ch], b_ = c0 == 0 ? gb_[u] : p.gn_b[ch];
+            const float sc = rstd * w_;
+            gtab[ch] = sc;
+            gtab[Kp + ch] = fmaf(-mean, sc, b_);
+          }
+        }
       }
     }
     __syncthreads();
