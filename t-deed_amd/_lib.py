@@ -190,9 +190,14 @@ def load():
     if _lib is not None:
         return _lib
     path = LIB_PATH
-    if os.environ.get("TDEED_LIB_FLAVOUR", "release") == "debug":
+    flavour = os.environ.get("TDEED_LIB_FLAVOUR", "release")
+    if flavour == "debug":
         # the asserting build (csrc/common.h TD_DEV_ASSERT): `python t-deed_amd/build.py --debug`
         path = LIB_PATH.replace("libtdeed_hip.so", "libtdeed_hip_dbg.so")
+    elif flavour != "release":
+        # an A/B build of the same ABI with some sources taken from another revision (tools/build_ab.py): lets one gpurun
+        # call time two forms of a kernel on the SAME box (boxes differ by 2-3 %)
+        path = LIB_PATH.replace("libtdeed_hip.so", f"libtdeed_hip_{flavour}.so")
     if not os.path.exists(path):
         raise HipLibraryMissing(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -200,6 +205,8 @@ def load():
             "tdeed_amd has no CPU fallback.")
     lib = ctypes.CDLL(path)
     for name, (args, res) in _SIGS.items():
+        if flavour not in ("release", "debug") and not hasattr(lib, name):
+            continue                                 # an A/B flavour built from an older revision may lack a newer entry point
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res

@@ -178,15 +178,20 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
   [[maybe_unused]] f32x2 gn_v0[MODE == 0 ? GN_NCL : 1][MODE == 0 ? GN_PB : 1];
   [[maybe_unused]] float gn_w0[MODE == 0 ? GN_NCL : 1], gn_b0[MODE == 0 ? GN_NCL : 1];
   if constexpr (MODE == 0) {
+    // (only the slots that exist -- 16 u < cg, k < parts, both workgroup-uniform -- are requested: as 24 clamped loads per
+    //  thread the prologue cost the T = 100 launches 3 us, 96 eight-byte wave loads per workgroup in front of its chunks)
     const int cg = p.K / p.G, g = min(tid >> 4, p.G - 1), jj = tid & 15;
 #pragma unroll
     for (int u = 0; u < GN_NCL; ++u) {
       const int ch = g * cg + min(jj + 16 * u, cg - 1);
+      const bool uok = 16 * u < cg;
 #pragma unroll
-      for (int k = 0; k < GN_PB; ++k)
-        gn_v0[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)min(k, p.chs_parts - 1) * p.B + b) * p.K + ch) * 2);
-      gn_w0[u] = p.gn_w[ch];
-      gn_b0[u] = p.gn_b[ch];
+      for (int k = 0; k < GN_PB; ++k) {
+        if (uok && k < p.chs_parts) gn_v0[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)k * p.B + b) * p.K + ch) * 2);
+        else gn_v0[u][k] = f32x2{0.f, 0.f};
+      }
+      gn_w0[u] = uok ? p.gn_w[ch] : 0.f;
+      gn_b0[u] = uok ? p.gn_b[ch] : 0.f;
     }
   }
   issue(0, 0);
@@ -233,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
             for (int k = 0; k < PB; ++k) {
               const int ch = g * cg + min(c0 + jj + 16 * u, cg - 1), pt = min(p0 + k, p.chs_parts - 1);
               if (g0 == 0 && c0 == 0 && p0 == 0) v[u][k] = gn_v0[u][k];
-              else v[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + ch) * 2);
+              else if (c0 + 16 * u < cg && p0 + k < p.chs_parts)
+                v[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + ch) * 2);
+              else v[u][k] = f32x2{0.f, 0.f};
             }
           TD_ISSUE_FENCE();
 #pragma unroll
