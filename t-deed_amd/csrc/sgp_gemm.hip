@@ -172,28 +172,6 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
       for (int ks = 0; ks < SG_KC; ++ks) wreg[slot][ks][nt] = wp[ks * 64];
     }
   };
-  // MODE 0: the first batch of GroupNorm channel sums (group pass 0, this lane's first channels, the first parts) and the
-  // affine are requested AHEAD of the chunks, so the prologue's wait leaves the chunk loads in flight (vmcnt counts in order)
-  constexpr int GN_NCL = 4, GN_PB = 4;                    // channels per lane and parts per batch of loads
-  [[maybe_unused]] f32x2 gn_v0[MODE == 0 ? GN_NCL : 1][MODE == 0 ? GN_PB : 1];
-  [[maybe_unused]] float gn_w0[MODE == 0 ? GN_NCL : 1], gn_b0[MODE == 0 ? GN_NCL : 1];
-  if constexpr (MODE == 0) {
-    // (only the slots that exist -- 16 u < cg, k < parts, both workgroup-uniform -- are requested: as 24 clamped loads per
-    //  thread the prologue cost the T = 100 launches 3 us, 96 eight-byte wave loads per workgroup in front of its chunks)
-    const int cg = p.K / p.G, g = min(tid >> 4, p.G - 1), jj = tid & 15;
-#pragma unroll
-    for (int u = 0; u < GN_NCL; ++u) {
-      const int ch = g * cg + min(jj + 16 * u, cg - 1);
-      const bool uok = 16 * u < cg;
-#pragma unroll
-      for (int k = 0; k < GN_PB; ++k) {
-        if (uok && k < p.chs_parts) gn_v0[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)k * p.B + b) * p.K + ch) * 2);
-        else gn_v0[u][k] = f32x2{0.f, 0.f};
-      }
-      gn_w0[u] = uok ? p.gn_w[ch] : 0.f;
-      gn_b0[u] = uok ? p.gn_b[ch] : 0.f;
-    }
-  }
   issue(0, 0);
   issue(1, 1);
   f32x4 bias[NT];
@@ -211,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
     const int Kp = p.KSP * 32;
     const int cg = p.K / p.G;
     const int gl = tid >> 4, jj = tid & 15;
-    constexpr int NCL = GN_NCL, PB = GN_PB;
+    // (3 channels per lane cover groups of up to 48 channels in one pass, 2 parts per batch: the registers of a deeper batch
+    //  -- and of requesting the first batch ahead of the chunks -- took the (2, 1) form from 151 to 199 VGPRs, i.e. from three
+    //  workgroups per CU to two: 736 workgroups then ran in two rounds and the launch lost 3 us at T = 100, measured)
+    constexpr int NCL = 3, PB = 2;
     for (int c = p.K + tid; c < Kp; c += 256) {           // the k pad: 0 * x + 0
       gtab[c] = 0.f;
       gtab[Kp + c] = 0.f;
@@ -223,8 +204,9 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
 #pragma unroll
       for (int u = 0; u < NCL; ++u) {
         const int ch = g * cg + min(jj + 16 * u, cg - 1);
-        gw_[u] = g0 == 0 ? gn_w0[u] : p.gn_w[ch];
-        gb_[u] = g0 == 0 ? gn_b0[u] : p.gn_b[ch];
+        const bool uok = 16 * u < cg;
+        gw_[u] = uok ? p.gn_w[ch] : 0.f;
+        gb_[u] = uok ? p.gn_b[ch] : 0.f;
       }
       for (int c0 = 0; c0 < cg; c0 += 16 * NCL) {
         float s_[NCL], q_[NCL];
@@ -237,8 +219,7 @@ __global__ __launch_bounds__(256, 2) void sgp_gemm_kernel(const SgpGemmP p) {
 #pragma unroll
             for (int k = 0; k < PB; ++k) {
               const int ch = g * cg + min(c0 + jj + 16 * u, cg - 1), pt = min(p0 + k, p.chs_parts - 1);
-              if (g0 == 0 && c0 == 0 && p0 == 0) v[u][k] = gn_v0[u][k];
-              else if (c0 + 16 * u < cg && p0 + k < p.chs_parts)
+              if (c0 + 16 * u < cg && p0 + k < p.chs_parts)
                 v[u][k] = *reinterpret_cast<const f32x2*>(p.chsum + (((long)pt * p.B + b) * p.K + ch) * 2);
               else v[u][k] = f32x2{0.f, 0.f};
             }
