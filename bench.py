@@ -445,6 +445,7 @@ def compact_line(out):
         infer_snb_t250_clips_per_s=_g(out, "infer_snb_t250", "value"),
         sgp_stage_us=(None if _g(out, "roofline_sgp", "ms") is None else round(_g(out, "roofline_sgp", "ms") * 1e3, 1)),
         logit_max_abs_err_fp32=out.get("logit_max_abs_err_fp32"), logit_max_abs_err_bf16=out.get("logit_max_abs_err_bf16"),
+        logit_rms_err_bf16=out.get("logit_rms_err_bf16"),
         logit_abs_max=out.get("logit_abs_max"), latency_ms_inflight1=out.get("latency_ms_inflight1"),
         fed_from_host_clips_per_s=_g(out, "fed_from_host", "value"),
         timed_output_check_ok=_g(out, "timed_output_check", "ok"))
