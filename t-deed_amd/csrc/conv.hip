@@ -198,17 +198,9 @@ static int launch_gconv(const void* x, int N, int Hi, int Wi, int C, int stride,
 // and stay in registers.  The weights are the MFMA A operand so that each lane ends up with 4
 // consecutive channels of one pixel (8-byte stores) rather than 4 pixels of one channel.
 #include <stdlib.h>
-static long gc_cap() {
-  static long cap = -1;
-  if (cap < 0) {
-    const char* e = getenv("TDEED_GCONV_LDS_KB");
-    // 48 KB: three workgroups per CU.  Measured best since three batches share the chip (same-box A/B, cfg2: 4110 -> 4196
-    // clips/s together with the fused front's budget; 64 KB = two per CU was best with two sub-batches per batch)
-    cap = e ? atol(e) * 1024 : 48 * 1024;
-    if (cap > 64 * 1024) cap = 64 * 1024;
-  }
-  return cap;
-}
+// 48 KB: three workgroups per CU.  Measured best since three batches share the chip (same-box A/B, cfg2: 4110 -> 4196
+// clips/s together with the fused front's budget; 64 KB = two per CU was best with two sub-batches per batch)
+static long gc_cap() { return 48 * 1024; }
 struct GcGeom { int band, nbands, CSP, nslabs, PS, rows_in; };
 static GcGeom gc_geom(int Hi, int Wi, int C, int stride) {
   GcGeom g;

@@ -933,8 +933,7 @@ static size_t front_roll_smem(int crop_w, int Ws, int PS) {
 static long front_cap() {
   static long cap = -1;
   if (cap < 0) {
-    const char* e = getenv("TDEED_FRONT_LDS_KB");
-    cap = e ? atol(e) * 1024 : 48 * 1024;      // 48 KB: three workgroups per CU, measured best with three batches in flight
+    cap = 48 * 1024;      // 48 KB: three workgroups per CU, measured best with three batches in flight
                                                // (64 KB / two per CU was best with two: DESIGN section 4)
     if (cap > FRONT_LDS_CAP) cap = FRONT_LDS_CAP;
   }
@@ -1260,7 +1259,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemP p) {
 static int stem_band(int cw, int Hs) {
   const long rowb = (long)(cw + 2) * 16;                 // head + tail planes
   static long cap = -1;                                  // 48 KB: three workgroups per CU
-  if (cap < 0) { const char* e = getenv("TDEED_STEM_LDS_KB"); cap = e ? atol(e) * 1024 : 48 * 1024; }
+  if (cap < 0) cap = 48 * 1024;
   int band = (int)((cap / rowb - 1) / 2);
   if (band > 16) band = 16;
   if (band < 1) band = 1;

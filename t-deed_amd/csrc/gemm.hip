@@ -485,9 +485,7 @@ static int launch_gemm(const GemmP& p, hipStream_t st, bool bwd = false) {
   if (grid > 0x7fffffffL) { tdeed_set_error("gemm: grid too large"); return TDEED_ERR_ARG; }
   // SE gate table in LDS when the frames of one 128-row tile fit 24 KB (K % 4 == 0 holds: K is a multiple of 8)
   const size_t gt_bytes = p.a_scale ? (size_t)(128 / p.a_scale_rows + 2) * p.K * sizeof(float) : 0;
-  static int se_tab = -1;
-  if (se_tab < 0) { const char* e = getenv("TDEED_GEMM_SE_TABLE"); se_tab = e ? atoi(e) : 1; }
-  int se = !p.a_scale ? 0 : ((se_tab && gt_bytes <= 24 * 1024) ? 2 : 1);
+  int se = !p.a_scale ? 0 : (gt_bytes <= 24 * 1024 ? 2 : 1);
 #define TD_GEMM(BNv)                                                                                                   \
   do {                                                                                                                 \
     if (bwd) {                                                                                                         \
@@ -807,8 +805,7 @@ static int launch_gemm_ws(GemmWsP& p, hipStream_t st) {
   if (p.NTS < 2) { tdeed_set_error("gemm_ws: K=%d too deep for an LDS-resident weight slice", p.K); return TDEED_ERR_ARG; }
   const int nsl = (p.NT + p.NTS - 1) / p.NTS;
   const size_t smem = (size_t)p.NTS * KS * 64 * 16 + (size_t)p.NTS * 16 * 2 * sizeof(float);
-  static const int nw8 = [] { const char* e = getenv("TDEED_WS_NW"); return e && atoi(e) == 4 ? 0 : 1; }();
-  const bool wide8 = nw8 && smem > 64 * 1024 && sizeof(T) == 2;
+  const bool wide8 = smem > 64 * 1024 && sizeof(T) == 2;
   const long nchunks = ((long)p.M + (wide8 ? 255 : 127)) / (wide8 ? 256 : 128);
   long gx = smem > 64 * 1024 ? 256 / nsl : 1024 / nsl;     // persistent blocks; wide slices: one block per CU, all resident
   if (gx > nchunks) gx = nchunks;

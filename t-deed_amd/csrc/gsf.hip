@@ -514,8 +514,7 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
     // LDS budget per workgroup: 52 KB = three workgroups per CU (measured: DESIGN §9); the register-weight form may take
     // 78 KB = two per CU when a frame does not fit 52 (800MF s3, F = 80: a whole 14 x 14 frame instead of two bands with
     // the weights staged twice)
-    static const long q_kb = getenv("TDEED_GSF_Q_KB") ? atol(getenv("TDEED_GSF_Q_KB")) : 0;
-    long q_cap = (q_kb > 0 ? q_kb : (wreg ? 78 : 52)) * 1024;
+    long q_cap = (wreg ? 78 : 52) * 1024;
     int bq = (int)((q_cap - wbytes - 64L * nch - 16L * KSq) / ((long)(w + 2) * PSQ)) - 2;
     if (bq < 1) {
       // wide slices (F = 196 of RegNetY-800MF s4: 58 KB of tap-weight fragments alone): up to 150 KB of LDS, one
@@ -1005,10 +1004,10 @@ extern "C" int tdeed_gsf_apply_fused_fwd(const void* x, const float* gate, const
                        xsum, 1.0f / (float)hw, cw1, cb1, cw2, cb2, T, hw, C, F, Fp, (float*)out);
   else if (dtype == TDEED_BF16) {
     // pixels per LDS chunk: (2 gate pairs fp32 + 2 x Fp bf16) per pixel next to the fixed tables; a chunk is at most one
-    // batch of loads (256 * GA_UX pieces, 512 pixels) and at most TDEED_GSF_APPLY_KB of LDS (36: four workgroups per CU,
+    // batch of loads (256 * GA_UX pieces, 512 pixels) and at most 36 KB of LDS ( four workgroups per CU,
     // 1024 resident workgroups for the 800 frames of a batch); equal chunks
     const long fixed = (long)(11 * F + 40) * sizeof(float);
-    static const long a_kb = getenv("TDEED_GSF_APPLY_KB") ? atol(getenv("TDEED_GSF_APPLY_KB")) : 36;
+    constexpr long a_kb = 36;
     long pchunk = (a_kb * 1024 - fixed) / (16 + 4L * Fp);
     if (pchunk < 1) pchunk = (60 * 1024 - fixed) / (16 + 4L * Fp);
     TD_CHECK(pchunk >= 1 && F <= 256, "gsf_apply_fused: fold %d too wide", F);

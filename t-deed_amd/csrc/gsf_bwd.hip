@@ -767,8 +767,7 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
     TD_LAUNCH_CHECK("gsf_bwd fuse");
   }
   const dim3 gpix(cdiv(hw, 256), (unsigned)N);
-  static const bool old_pix = getenv("TDEED_GSF_BWD_PIXEL") && atoi(getenv("TDEED_GSF_BWD_PIXEL")) == 1;
-  if (!old_pix && Fp % 8 == 0 && Fp <= C && Fp / 8 <= 64) {
+  if (Fp % 8 == 0 && Fp <= C && Fp / 8 <= 64) {
     // coalesced forms: PT pixels x (Fp / 8) channel chunks per workgroup
     const int NCH = Fp / 8;
     const int PT = 256 / NCH;
@@ -791,11 +790,10 @@ static int gsf_bwd_launch(const void* x_, const float* gate, const float* fw, co
     TD_LAUNCH_CHECK("gsf_bwd_conv3d_dx");
   }
   if constexpr (sizeof(T) == 2) {
-    static const bool dw_valu = getenv("TDEED_GSF_DW_VALU") && atoi(getenv("TDEED_GSF_DW_VALU")) == 1;
     const int KST = (hw + 31) / 32, MTn = (F + 15) / 16;
     const int RS = MTn * 16 + 16;                               // row stride (elements): whole channel tiles + 32 bytes
     const size_t smm = (size_t)KST * 32 * RS * 2 + (size_t)3 * (h + 2) * (w + 2) * 2 * 4 + (size_t)KST * 32 * 4;
-    if (!dw_valu && smm <= 150 * 1024 && ((F + 7) / 8) * 8 <= C) {
+    if (smm <= 150 * 1024 && ((F + 7) / 8) * 8 <= C) {
       hipError_t e2 = hipFuncSetAttribute((const void*)gsf_bwd_conv3d_dw_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           150 * 1024);
       if (e2 != hipSuccess) { tdeed_set_error("gsf_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e2)); return TDEED_ERR_RUNTIME; }
@@ -865,8 +863,7 @@ extern "C" int tdeed_gsf_bwd(const void* x, const float* gate, const float* fw, 
 }
 // rows of bn_part (fp32 [rows][3][Fp]) tdeed_gsf_bwd_stats writes; 0: this geometry has no statistics epilogue
 extern "C" int tdeed_gsf_bwd_bn_parts(int B, int T, int h, int w, int C, int Fp) {
-  const bool old_pix = getenv("TDEED_GSF_BWD_PIXEL") && atoi(getenv("TDEED_GSF_BWD_PIXEL")) == 1;
-  if (old_pix || Fp % 8 != 0 || Fp > C || Fp / 8 > 64) return 0;
+  if (Fp % 8 != 0 || Fp > C || Fp / 8 > 64) return 0;
   const int PT = 256 / (Fp / 8);
   return cdiv(h * w, PT) * B * T;
 }

@@ -707,15 +707,13 @@ __global__ __launch_bounds__(256) void wgrad_tr160_kernel(const bf16_t* __restri
 }
 
 static bool wgrad_wide(int M, int N, int K) {
-  static const bool off = getenv("TDEED_WGRAD_TILE64") && atoi(getenv("TDEED_WGRAD_TILE64")) == 1;
-  return !off && N >= 96 && K >= 96 && M >= 4096;
+  return N >= 96 && K >= 96 && M >= 4096;
 }
 
 // number of M slices: enough workgroups that every CU holds several (each one is a chain of dependent 32-row steps:
 // latency hidden by its neighbours), without slices shorter than 256 rows or more than 32 MB of partials
 static bool wgrad_160(int M, int N, int K) {
-  static const bool off = getenv("TDEED_WGRAD_TILE160") && atoi(getenv("TDEED_WGRAD_TILE160")) == 0;
-  return !off && N == 320 && K == 320 && M >= 4096;
+  return N == 320 && K == 320 && M >= 4096;
 }
 
 extern "C" int tdeed_wgrad_slices(int M, int N, int K) {
@@ -745,8 +743,7 @@ extern "C" int tdeed_wgrad(const void* dY, long ldy, const void* X, long ldx, co
     hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, M, N, K,
                        part_w, (db || accumulate < 0) ? part_b : nullptr);
   else if (dtype == TDEED_BF16) {
-    static const bool valu = getenv("TDEED_WGRAD_VALU") && atoi(getenv("TDEED_WGRAD_VALU")) == 1;
-    static const bool scatter = getenv("TDEED_WGRAD_SCATTER") && atoi(getenv("TDEED_WGRAD_SCATTER")) == 1;
+    constexpr bool valu = false, scatter = false;      // (A/B switches of rounds 2 - 4, retired in round 6: the forms below won)
     const bool vec_ok = N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && ldy % 8 == 0 && ldx % 8 == 0;
     TD_CHECK(!X0 || (!valu && vec_ok && !scatter), "wgrad: the spliced X operand needs the transposing-read kernel");
     if (!valu && vec_ok && !scatter && wgrad_160(M, N, K) && !part_b)      // N = K = 320 (no bias): two exact 160-wide tiles per dimension

@@ -1478,10 +1478,10 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   const int nsl = (int)((npix_out + pps - 1) / pps);
   hipStream_t st = (hipStream_t)stream;
   dim3 gd((unsigned)((npix_in + 255) / 256), G), gwg(nsl, G);
-  static const bool wg_valu = getenv("TDEED_GCONV_WGRAD_VALU") && atoi(getenv("TDEED_GCONV_WGRAD_VALU")) == 1;
+  constexpr bool wg_valu = false;      // (A/B switches of rounds 2 - 4 retired in round 6; the forms they forced stay as the fp32 / fallback paths)
   const bool mfma_w = dtype == TDEED_BF16 && !wg_valu && C % 8 == 0;
   const dim3 gwm(nsl, (C + 15) / 16);
-  static const bool dg_old = getenv("TDEED_GCONV_DGRAD_ROWS") && atoi(getenv("TDEED_GCONV_DGRAD_ROWS")) == 1;
+  constexpr bool dg_old = false;
   const size_t sm_s2 = (size_t)100 * (C + (dtype == TDEED_F32 ? 4 : 8)) * (dtype == TDEED_F32 ? 4 : 2) + (size_t)4 * 9 * gw * gw * 4;
   const bool dg_tiled = dx && stride == 2 && !dg_old && sm_s2 <= 120 * 1024 && Hi % 2 == 0 && Wi % 2 == 0 && N <= 65535;
   if (dg_tiled && sm_s2 > 64 * 1024) {
@@ -1498,7 +1498,7 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
   const dim3 gts2(cdiv(Wi, 16), cdiv(Hi, 16), N);
   // bf16: the MFMA form; its weight fragments are packed into the head of `part` (the weight-gradient launch that follows
   // on the same stream overwrites them only after this kernel has finished)
-  static const bool dg_valu = getenv("TDEED_GCONV_DGRAD_VALU") && atoi(getenv("TDEED_GCONV_DGRAD_VALU")) == 1;
+  constexpr bool dg_valu = false;
   const long frag_bytes = (long)((C + 15) / 16) * 5 * 64 * 16;
   const bool dg_mfma = dx && stride == 2 && dtype == TDEED_BF16 && !dg_old && !dg_valu && C % 8 == 0 && Hi % 2 == 0 && Wi % 2 == 0 &&
                        N <= 65535 && frag_bytes <= (long)slabs * G * 9 * gw * gw * 4;
@@ -1531,7 +1531,7 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
 #undef TD_GC_LAUNCH
   int nrows = nsl;                                              // partial rows the launches below leave in `part`
   if (mfma_w) {
-    static const bool wg_scatter = getenv("TDEED_GCONV_WGRAD_SCATTER") && atoi(getenv("TDEED_GCONV_WGRAD_SCATTER")) == 1;
+    constexpr bool wg_scatter = false;
     const long tiles = (long)N * cdiv(Ho, 8) * cdiv(Wo, 8);
     if (!wg_scatter && tiles < (1L << 22)) {                    // transposing LDS reads, one fetch per input pixel
       const int tpw = (int)((tiles + slabs - 1) / slabs);
@@ -1568,9 +1568,7 @@ extern "C" int tdeed_gconv3x3_bwd(const void* x, const void* dy, int N, int Hi, 
 extern "C" int tdeed_gconv3x3_bwd_stats_bands(int Hi) { return cdiv(Hi, 16); }
 // 1 when tdeed_gconv3x3_bwd would run the stride-2 MFMA input-gradient kernel for this geometry (the only one with the epilogue)
 extern "C" int tdeed_gconv3x3_bwd_stats_fits(int N, int Hi, int Wi, int C, int gw) {
-  static const bool dg_old = getenv("TDEED_GCONV_DGRAD_ROWS") && atoi(getenv("TDEED_GCONV_DGRAD_ROWS")) == 1;
-  static const bool dg_valu = getenv("TDEED_GCONV_DGRAD_VALU") && atoi(getenv("TDEED_GCONV_DGRAD_VALU")) == 1;
-  if (dg_old || dg_valu || !(gw == 8 || gw == 16) || C % gw != 0 || C % 8 != 0 || Hi % 2 != 0 || Wi % 2 != 0 || N <= 0 || N > 65535)
+  if (!(gw == 8 || gw == 16) || C % gw != 0 || C % 8 != 0 || Hi % 2 != 0 || Wi % 2 != 0 || N <= 0 || N > 65535)
     return 0;
   const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1, G = C / gw;
   const int slabs = tdeed_gconv_wgrad_slabs((long)N * Ho * Wo);
@@ -1846,10 +1844,7 @@ extern "C" int tdeed_stem_wgrad(const void* frames, int frames_f32, int N, int H
                      crop_left, crop_h, crop_w, flip, flip_mask, (const TT*)dz, Ho, Wo, part)
   if (dtype == TDEED_F32) { if (frames_f32) TD_SWG(float, float); else TD_SWG(float, uint8_t); }
   else if (dtype == TDEED_BF16) {
-    static const bool valu = getenv("TDEED_STEM_WGRAD_VALU") && atoi(getenv("TDEED_STEM_WGRAD_VALU")) == 1;
-    static const bool old_mfma = getenv("TDEED_STEM_WGRAD_IM2COL") && atoi(getenv("TDEED_STEM_WGRAD_IM2COL")) == 1;
-    if (valu) { if (frames_f32) TD_SWG(bf16_t, float); else TD_SWG(bf16_t, uint8_t); }
-    else if (!old_mfma && td_stem_wgrad_tr_launch(frames, frames_f32, N, H, W, crop_top, crop_left, crop_h, crop_w, flip, flip_mask,
+    if (td_stem_wgrad_tr_launch(frames, frames_f32, N, H, W, crop_top, crop_left, crop_h, crop_w, flip, flip_mask,
                                                   dz, part, st, nullptr, nullptr, nullptr, nullptr, nullptr)) {
       // transposing-read form (front.hip): same partial layout
     }

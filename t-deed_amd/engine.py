@@ -160,11 +160,11 @@ def pack_se_mfma(fc1_w, fc2_w, device):
     return dict(w1f=pack_mfma_frags(fc1_w, device), w2f=pack_mfma_frags(fc2_w, device))
 
 
-GS_SLICE = os.environ.get("TDEED_GS_SLICE", "1") == "1"
+GS_SLICE = True
 # gate-shift-fuse slice left in source channel order, the module's interleave folded into conv1's weight columns
 GS_SRC_ORDER = os.environ.get("TDEED_GS_SRC_ORDER", "1") == "1"
-WS_NARROW_ONLY = os.environ.get("TDEED_WS_NARROW_ONLY", "1") == "1"
-WS_WIDE_MIN_ROWS = int(os.environ.get("TDEED_WS_WIDE_MIN_ROWS", "250000"))     # 0: never the sliced form
+WS_NARROW_ONLY = True
+WS_WIDE_MIN_ROWS = 250000     # 0: never the sliced form
 RS_MIN_ROWS = int(os.environ.get("TDEED_RS_MIN_ROWS", "60000"))                # 0: never the register-stationary kernel
 
 
@@ -176,7 +176,7 @@ class DenseW:
         W = _np(W)
         self.N, self.K = W.shape
         # mode 1: the whole W sits in LDS; mode 2: W does not fit, equal column slices over blockIdx.y (activations re-read per
-        # slice, 8 waves per workgroup).  TDEED_WS_SLICED=1 sends mode-2 layers there at every row count
+        # slice, 8 waves per workgroup).
         mode = ops.gemm_ws_fits_mode(self.K, self.N, act_dtype) if str(device) != "cpu" else 0
         self.ws = mode == 1
         # The weight-stationary kernel was built for the narrow RegNetY-200MF layers (24 .. 152 channels), where it wins by
@@ -437,7 +437,7 @@ def _se(pooled, inv_cnt, bw, gate):
 
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
 C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
-C1_GCONV_MAX_CIN = int(os.environ.get("TDEED_C1_GCONV_MAX_CIN", "160"))
+C1_GCONV_MAX_CIN = 160
 
 
 def _bneck_fused(bw, h, w, out_is_slice):
@@ -470,7 +470,7 @@ class SgpBuilder:
 
     def __init__(self, pool, steps, keep, taps, B, act_dtype):
         self.pool, self.steps, self.keep, self.taps, self.B, self.dt = pool, steps, keep, taps, B, act_dtype
-        self.splitk_rows = int(os.environ.get("TDEED_SPLITK_ROWS", "4096"))
+        self.splitk_rows = 4096
         # fused launches (sgp_fused.hip): LayerNorm inside the branch kernels (both dtypes), GroupNorm + fc1 + GELU + fc2 +
         # residual in one MFMA launch (bf16).  TDEED_SGP_FUSED=0 restores the launch-per-op chain (A/B measurements).
         self.fused = os.environ.get("TDEED_SGP_FUSED", "1") == "1"
@@ -762,7 +762,7 @@ class PackedWeights:
             bw.se_bf = (SimpleNamespace(**pack_se_bf16(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
                         if act_dtype == torch.bfloat16 and str(device) != "cpu" else None)
             bw.se_mf = (SimpleNamespace(**pack_se_mfma(sd[bp + ".se.fc1.weight"], sd[bp + ".se.fc2.weight"], device))
-                        if (bw.se_bf is not None and os.environ.get("TDEED_SE_MFMA", "1") == "1"
+                        if (bw.se_bf is not None and True
                             and ops.se_gate_mfma_fits(blk.cout, blk.se_rd)) else None)
             bw.w3 = DenseW(sd[bp + ".conv3.conv.weight"].reshape(blk.cout, blk.cout), act_dtype, device, gated=True)
             # MFMA-fragment copies of conv1 / conv3 for the one-launch bottleneck (stride-1 identity blocks up to 384 wide)
@@ -853,10 +853,9 @@ class ForwardEngine:
         self.n_split = int(os.environ.get("TDEED_SPLIT", n_split))
         # the temporal stage (SGP encoder-decoder + heads) of a split batch runs ONCE over all clips behind the join of the
         # sub-batch trunks: its launches are latency bound and their cost does not depend on the row count at these sizes
-        self.merge_tail = os.environ.get("TDEED_SGP_MERGE", "1") == "1"
+        self.merge_tail = True
         # where the sub-batch pipelines join inside the trunk (index into the block list; None = behind the last block)
-        ja = os.environ.get("TDEED_JOIN_AT", "")
-        self.join_at = int(ja) if ja not in ("", "none") else None
+        self.join_at = None
         self._plans = {}
 
     # ------------------------------------------------------------------ plan construction
@@ -1071,7 +1070,7 @@ class ForwardEngine:
         if stop_at is not None:
             blocks = blocks[:max(0, stop_at - (1 if fused_front else 0))]
         if trunk_out is not None and not blocks:
-            raise ValueError("TDEED_JOIN_AT must leave at least one un-fused bottleneck in the sub-batch plans")
+            raise ValueError("join_at must leave at least one un-fused bottleneck in the sub-batch plans")
         x, h, w, x_kept = self._blocks(pool, steps, keep, taps, B, x, h, w, blocks, x_kept, out_last=trunk_out)
         if stop_at is not None:          # trunk head only: the rest of the trunk runs once for all sub-batches (plan.tail)
             return SimpleNamespace(frames=frames, steps=steps, keep=keep, head_out=None, pool_bytes=pool.total_bytes(), B=B, T=T,

@@ -359,7 +359,7 @@ def narrow_conv1_bwd_fits(Co, Ci, dtype):
     return dtype == torch.bfloat16 and _lib.load().tdeed_narrow_conv1_bwd_fits(Co, Ci) != 0
 
 
-NARROW_RECOMPUTE = os.environ.get("TDEED_TRAIN_NARROW_RECOMPUTE", "1") == "1"
+NARROW_RECOMPUTE = True
 
 
 def narrow_conv1_bwd(d_y1, z1, bn1, w, part, x, wt, sink=None, residual=None, r_hw=None, sums=None, recompute=False):
@@ -409,7 +409,7 @@ class GradSink:
         self.nB = 0
 
 
-DGRAD_RS = os.environ.get("TDEED_TRAIN_DGRAD_RS", "1") == "1"
+DGRAD_RS = True
 DGRAD_RS_MIN_ROWS = 60000
 
 

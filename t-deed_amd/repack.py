@@ -35,8 +35,8 @@ def recording():
 # size the gather is cheaper than a launch.
 DIRECT_MIN = 65536
 import os as _os
-# the large weights' casts / transposes as one table-driven launch (TDEED_REPACK_MULTI=0: one cast + one transpose launch each)
-MULTI_DIRECT = _os.environ.get("TDEED_REPACK_MULTI", "1") == "1"
+# the large weights' casts / transposes as one table-driven launch (MULTI_DIRECT = False: one cast + one transpose launch each)
+MULTI_DIRECT = True
 _plan = None                                                     # the PackPlan being recorded
 
 

@@ -16,7 +16,7 @@ from . import ops, ops_bwd as B_, repack as R
 from .regnet_spec import pyramid_lengths
 
 _BR = ["psi", "convw", "convkw", "fc", "global_fc"]
-SPLITK_TRAIN = os.environ.get("TDEED_TRAIN_SPLITK", "1") == "1"
+SPLITK_TRAIN = True
 
 
 def _flat(v):

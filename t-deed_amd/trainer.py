@@ -23,8 +23,8 @@ from .regnet_spec import regnet_spec
 from .temporal_train import TemporalStack
 from .trunk_train import BottleneckTrain, StemTrain, BN_EPS
 
-STEM_MFMA = os.environ.get("TDEED_TRAIN_STEM_MFMA", "1") == "1"
-STEM_BN_FUSED = os.environ.get("TDEED_TRAIN_STEM_BN_FUSED", "1") == "1"
+STEM_MFMA = True
+STEM_BN_FUSED = True
 
 
 class TrainEngine:
