@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include "common.h"
 
+void tdeed_set_error(const char* fmt, ...) { (void)fmt; }        // (lives in misc.hip of the product library)
+
 struct TdVDim { unsigned x, y, z; };
 __shared__ TdVDim td_vblock, td_vgrid;
 
