@@ -101,9 +101,10 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {torch.bfloat16: 2500.0, torch.float32: 157.3}
-TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
-TRAFFIC_FILE_800MF = os.path.join("profiles", "r05_hbm_traffic_800mf_b16.json")
-TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r05_train_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_hbm_traffic.json")
+TRAFFIC_FILE_800MF = os.path.join("profiles", "r06_hbm_traffic_800mf_b16.json")
+TRAFFIC_FILE_SNB = os.path.join("profiles", "r06_hbm_traffic_snb_t250_b4.json")
+TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r06_train_hbm_traffic.json")
 # C-ABI entry -> kernel family of tools/summarize_pmc.py (what the counter passes are keyed by)
 DIST_INFO = dict(backend="none", ranks=1)      # _dist_setup(): what the process group itself counted
 TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
@@ -1083,7 +1084,7 @@ def main():
             out["infer_800mf"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         # ... and of the long-clip configuration (BASELINE configs[4] per-GPU share: 800MF, T = 250, B = 4)
         try:
-            out["infer_snb_t250"] = infer_sub_record("snb_t250_b4", 40, 3, depth, rank, dev, None, streams=streams)
+            out["infer_snb_t250"] = infer_sub_record("snb_t250_b4", 40, 3, depth, rank, dev, TRAFFIC_FILE_SNB, streams=streams)
         except Exception as e:           # noqa: BLE001
             out["infer_snb_t250"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         # driver-visible training-step records: BASELINE configs[2] (800MF, B=16) and the 200MF geometry of the headline
