@@ -107,7 +107,8 @@ TRAFFIC_FILE_SNB = os.path.join("profiles", "r06_hbm_traffic_snb_t250_b4.json")
 TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r06_train_hbm_traffic.json")
 # C-ABI entry -> kernel family of tools/summarize_pmc.py (what the counter passes are keyed by)
 DIST_INFO = dict(backend="none", ranks=1)      # _dist_setup(): what the process group itself counted
-TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad"}
+TRAIN_FAMILY = {"tdeed_gemm_fwd": "gemm", "tdeed_bn_train_bwd": "bn_bwd", "tdeed_wgrad": "wgrad",
+                "tdeed_narrow_conv1_bwd": "narrow_conv_bwd"}
 
 
 def _masked_streams(depth, mode):
@@ -406,7 +407,7 @@ def infer_sub_record(workload, steps, repeats, depth, rank, dev, traffic_file, s
 # tools/prof_r05.sh stores under profiles/), and the full record is also left in gpurun_out/bench_full.json.
 _DROP_KEYS = {"note", "kernels", "ms_per_step_repeats", "by_processes", "by_threads", "families_ms", "traffic_source",
               "cpu_model", "measured", "workload", "thread_sweep", "sweep", "repeats", "hip_graph", "steps", "unit_note",
-              "bn_bwd_family", "gemm_family", "kernel_name", "slots", "algorithmic_bytes_per_launch", "host_cores"}
+              "bn_bwd_family", "gemm_family", "narrow_bwd_family", "kernel_name", "slots", "algorithmic_bytes_per_launch", "host_cores"}
 
 
 def _trim(o, drop=_DROP_KEYS, maxstr=110):
@@ -642,6 +643,28 @@ def train_family_roofline(eng, workload, frames, lab, labD, masks, dt):
                        achieved=gemm["TFLOPs"] if mfma_bound else gemm["GBps"],
                        peak=MFMA_PEAK_TF[dt] if mfma_bound else HBM_PEAK_GBS, unit="TFLOP/s" if mfma_bound else "GB/s",
                        frac=gemm["frac_mfma"] if mfma_bound else gemm["frac_hbm"])
+    nb = summ.get("tdeed_narrow_conv1_bwd")
+    if nb is not None:
+        # tdeed_narrow_conv1_bwd(dY [0], Z [1], M [2], Co [3], Ci [4], ..., X [11], Wt [12], R [13], ldr, r_hi [15], r_wi, dX [17],
+        # use_mask, bz [19], bmean, bzd [21], ...): conv1's whole backward of a narrow layer in one launch.  Algorithmic bytes =
+        # dY and (where it is not recomputed) Z read once, X read once (operand of the weight gradient, of the recomputed z and
+        # the sink's mask), the shortcut gradient R (a quarter of the rows behind a stride-2 block), the sink's raw maps bz / bzd,
+        # dX written once; the weights and the per-workgroup partials are KBs.
+        def nb_bytes(a):
+            M, Co, Ci = a[2], a[3], a[4]
+            b = M * Co * (1 + (1 if a[1] else 0)) + M * Ci * 2
+            if a[13]:
+                b += (M // 4 if a[15] else M) * Ci
+            b += M * Ci * ((1 if a[19] else 0) + (1 if a[21] else 0))
+            return b * es
+        nbb = sum(nb_bytes(a) for a in nb["args"])
+        nsec = nb["ms"] * 1e-3
+        rec["narrow_bwd_family"] = dict(ms_per_step=round(nb["ms"], 3), launches_per_step=nb["calls"], algorithmic_bytes=int(nbb),
+                                        GBps=round(nbb / nsec / 1e9, 1), frac_hbm=round(nbb / nsec / 1e9 / HBM_PEAK_GBS, 4))
+        if name == "tdeed_narrow_conv1_bwd":
+            rec.update(bound="hbm", algorithmic_bytes_per_launch=int(nbb / nb["calls"]),
+                       avg_launch_us=round(nb["ms"] / nb["calls"] * 1e3, 2), achieved=round(nbb / nsec / 1e9, 1),
+                       peak=HBM_PEAK_GBS, unit="GB/s", frac=round(nbb / nsec / 1e9 / HBM_PEAK_GBS, 4))
     bn = summ.get("tdeed_bn_train_bwd")
     if bn is not None:
         # tdeed_bn_train_bwd(z, dy, y, relu, M, C, ..., dz [13], d_res [14], ...): BatchNorm (batch statistics) backward.

@@ -807,7 +807,13 @@ static int launch_gemm_ws(GemmWsP& p, hipStream_t st) {
   const size_t smem = (size_t)p.NTS * KS * 64 * 16 + (size_t)p.NTS * 16 * 2 * sizeof(float);
   const bool wide8 = smem > 64 * 1024 && sizeof(T) == 2;
   const long nchunks = ((long)p.M + (wide8 ? 255 : 127)) / (wide8 ? 256 : 128);
-  long gx = smem > 64 * 1024 ? 256 / nsl : 1024 / nsl;     // persistent blocks; wide slices: one block per CU, all resident
+  // persistent blocks, ALL resident: wide slices one per CU; otherwise as many per CU as LDS allows (at most 4).  Round 6: the
+  // grid used to be 1024 whatever the weight's size -- a 152 x 152 weight (52.5 KB) leaves three workgroups per CU = 768
+  // slots, and the 256 workgroups that did not fit started their share only when a first-round workgroup had finished its own
+  long per_cu = smem > 64 * 1024 ? 1 : (long)((160 * 1024) / (smem ? smem : 1));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  long gx = 256 * per_cu / nsl;
   if (gx > nchunks) gx = nchunks;
   if (gx < 1) gx = 1;
   static TdDevOnce attr_set[16];
