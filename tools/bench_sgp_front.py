@@ -38,8 +38,9 @@ for (B, T, C, ks, parts) in [(8, 100, 368, 7, 0), (8, 100, 368, 7, 6), (8, 50, 3
     if parts == 0:
         rowstat = torch.stack([x.mean(-1), 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)], -1).reshape(B * T, 2).contiguous()
     else:
-        xs = x.reshape(B * T, parts, C // parts)
-        rowstat = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()       # (parts, B*T, 2)
+        xf = x.reshape(B * T, C)                     # (sum, sum of squares) per 64-column tile, as sgp_gemm MODE 1 leaves them
+        tiles = [xf[:, 64 * i:min(64 * (i + 1), C)] for i in range(parts)]
+        rowstat = torch.stack([torch.stack([tl.sum(-1), (tl * tl).sum(-1)], -1) for tl in tiles], 0).contiguous()   # (parts, B*T, 2)
 
     def run():
         ops.sgp_front(x, ks, up, ln_w, ln_b, dw, db, out=y, chsum=chs, rowstat=rowstat)
