@@ -562,7 +562,11 @@ def _dist_setup():
     ranks share one GPU to exercise the multi-process path on a single-GPU box (functional check, not a measurement)."""
     rank, local, world = tdist.env_world()
     backend = os.environ.get("TDEED_DIST_BACKEND", "nccl")
-    local_dev = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+    ndev = torch.cuda.device_count()
+    local_dev = local % max(ndev, 1) if backend != "nccl" else local
+    if local_dev >= ndev:
+        raise RuntimeError(f"bench.py: rank {rank} of {world} needs GPU {local_dev}, this node shows {ndev} "
+                           f"(one process per GPU; TDEED_DIST_BACKEND=gloo lets ranks share a GPU for a functional check)")
     torch.cuda.set_device(local_dev)
     tdist.init(backend=backend, device=torch.device("cuda", local_dev))   # no-op for a single process
     global DIST_INFO
