@@ -228,7 +228,7 @@ def _bench(args, env_extra, timeout=300):
                           text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
 def test_bench_gpus_flag_starts_that_many_ranks_by_itself(n):
     """`python bench.py --gpus N` without torchrun around it (the flag was parsed and never used): the
     launch path alone (TDEED_BENCH_LAUNCH_PROBE: rendezvous + a counting all-reduce, no GPU) must come up as N ranks and
