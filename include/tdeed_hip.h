@@ -172,6 +172,10 @@ int tdeed_gemm_rs_stats_fwd(const void* A, long lda, const void* A0, long lda0, 
  * weight [C][Cin] as MFMA A-operand fragments [tdeed_c1_gconv_slab_tiles()][ceil(Cin/32)][64][8] (zero padded to whole
  * slabs); s1 / h1: its folded BatchNorm; wfrag / scale / shift / y / pooled as tdeed_gconv3x3_fwd (ReLU applied).
  * Bit-identical to tdeed_gemm_fwd (or tdeed_gemm_ws_fwd) followed by tdeed_gconv3x3_fwd.  tdeed_c1_gconv_fits: Cin <= 64, or 97..160 (k-steps of 32: 1, 2, 4, 5). */
+/* diagnostic: int64 [workgroups][8] phase time stamps of tdeed_c1_gconv_fwd (wall_clock64, 10 ns ticks; 0 start, 1 weights
+ * requested + halo zeroed, 2 wave 0's conv1 tiles done, 3 barrier, 4 grouped conv set up, 5 its tiles multiplied and stored,
+ * 6 squeeze sums stored); null switches it off */
+int tdeed_c1_gconv_set_debug(void* buf);
 int tdeed_c1_gconv_fits(int Hi, int Wi, int Cin, int C, int stride);
 int tdeed_c1_gconv_slab_tiles(int Hi, int Wi, int C, int stride);
 int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, int Hi, int Wi, int Cin, int C, int gw, int stride,

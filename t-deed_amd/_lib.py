@@ -59,6 +59,7 @@ _SIGS = {
     "tdeed_gemm_rs_stats_fwd": ([P, c_long, P, c_long, c_int, c_int, c_int, c_int, P, P, c_long, P, P], c_int),
     "tdeed_gemm_rs_fwd": ([P, c_long, P, c_long, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, c_long, c_int, P, c_long, P,
                            c_long, c_int, P], c_int),
+    "tdeed_c1_gconv_set_debug": ([P], c_int),
     "tdeed_c1_gconv_fits": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "tdeed_c1_gconv_slab_tiles": ([c_int, c_int, c_int, c_int], c_int),
     "tdeed_c1_gconv_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,

@@ -144,6 +144,16 @@ __device__ __forceinline__ long xcd_logical_id(long bid, long nwg) {
   return (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + bid / 8;
 }
 
+// q = lid / d, r = lid % d for a workgroup index (< 2^31) in ONE unsigned 32-bit division.  `long % int` and `long / int` are
+// ~120 vector instructions EACH on this target (no hardware divide: a float-reciprocal sequence in 64-bit arithmetic, executed by
+// every wave even for a uniform value); round 6: four of them opened every c1_gconv / grouped-conv workgroup, a third of the
+// 2.6 us its time stamps showed in front of the first load.
+__device__ __forceinline__ void td_split(long lid, int d, int& q, int& r) {
+  const unsigned u = (unsigned)lid, dd = (unsigned)d, qq = u / dd;
+  q = (int)qq;
+  r = (int)(u - qq * dd);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Division by a run-time constant without the ~25-instruction integer-divide sequence (index arithmetic of the

@@ -265,7 +265,9 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
                                                const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                float* __restrict__ pooled, float* __restrict__ pooled_sq, int Ho, int Wo,
                                                int nbands, int CSP, int PS, int relu, int n, int bnd, int slab, int oy0,
-                                               int nrows_out, const GcStat bst = GcStat{nullptr, nullptr, nullptr, nullptr}) {
+                                               int nrows_out, const GcStat bst = GcStat{nullptr, nullptr, nullptr, nullptr},
+                                               long long* dbg = nullptr) {
+#define GC_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[(long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
   const int WP = Wi + 2;
   const int cs0 = slab * CSP;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -291,22 +293,32 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
     const int chA = cs0 + pr * 32 + q * 4, chB = chA + 16;        // accumulator rows: 4 channels of unit A, 4 of unit B
     const int chS = cs0 + pr * 32 + (q & 1) * 16 + (q >> 1) * 8;  // after the swap: this lane's 8 consecutive channels
     float scA[4], shA[4], scB[4], shB[4], psA[4], psB[4], pqA[4], pqB[4];
+    {
+      // 16-byte loads (chA, chB are multiples of 4 and C of 8: a group of 4 channels is inside or outside)
+      const bool oka = chA < C, okb = chB < C;
+      const int ca = min(chA, C - 4), cb = min(chB, C - 4);
+      const f32x4 vsa = *reinterpret_cast<const f32x4*>(scale + ca), vha = *reinterpret_cast<const f32x4*>(shift + ca);
+      const f32x4 vsb = *reinterpret_cast<const f32x4*>(scale + cb), vhb = *reinterpret_cast<const f32x4*>(shift + cb);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool oka = chA + r < C, okb = chB + r < C;
-      scA[r] = oka ? scale[chA + r] : 0.f;
-      shA[r] = oka ? shift[chA + r] : 0.f;
-      scB[r] = okb ? scale[chB + r] : 0.f;
-      shB[r] = okb ? shift[chB + r] : 0.f;
-      psA[r] = psB[r] = pqA[r] = pqB[r] = 0.f;
+      for (int r = 0; r < 4; ++r) {
+        scA[r] = oka ? vsa[r] : 0.f;
+        shA[r] = oka ? vha[r] : 0.f;
+        scB[r] = okb ? vsb[r] : 0.f;
+        shB[r] = okb ? vhb[r] : 0.f;
+        psA[r] = psB[r] = pqA[r] = pqB[r] = 0.f;
+      }
     }
     float faA[4], fbA[4], muA[4], faB[4], fbB[4], muB[4];
     if (bst.z) {
+      const int ca = min(chA, C - 4), cb = min(chB, C - 4);       // (groups beyond C are never used: their sums are gated)
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(bst.fa + ca), a1_ = *reinterpret_cast<const f32x4*>(bst.fb + ca),
+                  a2 = *reinterpret_cast<const f32x4*>(bst.mean + ca);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bst.fa + cb), b1_ = *reinterpret_cast<const f32x4*>(bst.fb + cb),
+                  b2_ = *reinterpret_cast<const f32x4*>(bst.mean + cb);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ca = min(chA + r, C - 1), cb = min(chB + r, C - 1);
-        faA[r] = bst.fa[ca]; fbA[r] = bst.fb[ca]; muA[r] = bst.mean[ca];
-        faB[r] = bst.fa[cb]; fbB[r] = bst.fb[cb]; muB[r] = bst.mean[cb];
+        faA[r] = a0[r]; fbA[r] = a1_[r]; muA[r] = a2[r];
+        faB[r] = b0[r]; fbB[r] = b1_[r]; muB[r] = b2_[r];
       }
     }
     const int npix = nrows_out * Wo;
@@ -315,6 +327,7 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
     const bf16_t* zin = bst.z ? bst.z + ((long)n * Ho + oy0) * Wo * C : nullptr;
     const IDiv dwo(Wo);
     const bool sok = chS < C;                                     // (C is a multiple of 8: a chunk is inside or outside)
+    GC_STAMP(4);
     for (int mt = wv / pairs; mt < ntiles; mt += mstep) {
       const int p = mt * 16 + pl;
       const bool pok = p < npix;
@@ -371,6 +384,7 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
       const auto s1 = __builtin_amdgcn_permlane16_swap(a2[1], b2[1], false, false);
       if (pok && sok) *reinterpret_cast<u32x4*>(yout + (long)pc * C + chS) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
     }
+    GC_STAMP(5);
     // ---- squeeze partial sums: lanes sharing q, then the waves sharing the pair (fixed order)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -411,6 +425,7 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
         if (pooled_sq) pooled_sq[((long)n * nbands + bnd) * C + ch] = qres;
       }
     }
+    GC_STAMP(6);
     return;
   }
   const int unit = wv % units;
@@ -427,22 +442,28 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
   }
   const int ch0 = cs0 + unit * 16 + q * 4;      // this lane's 4 output channels
   float sc[4], sh[4], psum[4], psq[4];
+  {
+    const bool ok = ch0 < C;                      // (ch0 is a multiple of 4, C of 8)
+    const int c_ = min(ch0, C - 4);
+    const f32x4 vs = *reinterpret_cast<const f32x4*>(scale + c_), vh = *reinterpret_cast<const f32x4*>(shift + c_);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const bool ok = ch0 + r < C;
-    sc[r] = ok ? scale[ch0 + r] : 0.f;
-    sh[r] = ok ? shift[ch0 + r] : 0.f;
-    psum[r] = 0.f;
-    psq[r] = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      sc[r] = ok ? vs[r] : 0.f;
+      sh[r] = ok ? vh[r] : 0.f;
+      psum[r] = 0.f;
+      psq[r] = 0.f;
+    }
   }
   float bfa[4], bfb[4], bmu[4];
   if (bst.z) {
+    const int c_ = min(ch0, C - 4);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(bst.fa + c_), v1 = *reinterpret_cast<const f32x4*>(bst.fb + c_),
+                v2 = *reinterpret_cast<const f32x4*>(bst.mean + c_);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = min(ch0 + r, C - 1);
-      bfa[r] = bst.fa[c];
-      bfb[r] = bst.fb[c];
-      bmu[r] = bst.mean[c];
+      bfa[r] = v0[r];
+      bfb[r] = v1[r];
+      bmu[r] = v2[r];
     }
   }
   const int npix = nrows_out * Wo;
@@ -533,9 +554,10 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
   __shared__ float redq[4][32];
   // slabs and bands of one frame read the same pixel rows (different channel slices / halo rows): one XCD
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int nslabs_ = (C + CSP - 1) / CSP;
-  const int slab = (int)(lid % nslabs_);
-  const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
+  const int nslabs_ = (C + CSP - 1) >> (CSP == 64 ? 6 : (CSP == 32 ? 5 : 4));        // CSP is 16, 32 or 64
+  int slab, bnd, n, t_;
+  td_split(lid, nslabs_, t_, slab);
+  td_split(t_, nbands, n, bnd);
   const int cs0 = slab * CSP;
   const GcW gw_ = gconv_load_w(wfrag, slab, CSP);                // (travels under the staging below)
   const int oy0 = bnd * band;
@@ -613,14 +635,16 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
                                                             const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                             float* __restrict__ pooled, int Ho, int Wo, int band, int nbands,
-                                                            int CSP, int PS, int rows_in, int relu) {
+                                                            int CSP, int PS, int rows_in, int relu, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   __shared__ float red[4][32];
   __shared__ float redq[4][32];
+  GC_STAMP(0);
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int nslabs_ = (C + CSP - 1) / CSP;
-  const int slab = (int)(lid % nslabs_);
-  const int bnd = (int)((lid / nslabs_) % nbands), n = (int)(lid / ((long)nslabs_ * nbands));
+  const int nslabs_ = (C + CSP - 1) >> (CSP == 64 ? 6 : (CSP == 32 ? 5 : 4));        // CSP is 16, 32 or 64
+  int slab, bnd, n, t_;
+  td_split(lid, nslabs_, t_, slab);
+  td_split(t_, nbands, n, bnd);
   const int oy0 = bnd * band;
   const int nrows_out = min(band, Ho - oy0);
   const int WP = Wi + 2;
@@ -639,12 +663,17 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
     const int tt = slab * nts + min(t, nts - 1);
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) w1r[t][ks] = w1f[((long)tt * KS1 + ks) * 64 + lane];
+    // this lane's 4 channels of the tile as ONE 16-byte load each (round 6: as 8 dword loads per tile the prologue was 32
+    // vector-memory instructions per wave -- time stamps put 2.6 us of a ~9 us workgroup in front of its first x load, and a
+    // CU's memory front end serves three such workgroups at a time); C is a multiple of 8: a group of 4 is inside or outside
+    const int c4 = slab * CSP + t * 16 + 4 * q;
+    const bool ok = t < nts && c4 < C;
+    const int cc4 = min(c4, C - 4);
+    const f32x4 av = *reinterpret_cast<const f32x4*>(s1 + cc4), bv = *reinterpret_cast<const f32x4*>(h1 + cc4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int c = slab * CSP + t * 16 + 4 * q + e;
-      const bool ok = t < nts && c < C;
-      a1[t][e] = ok ? s1[c] : 0.f;                          // channels beyond C: exact zeros
-      b1[t][e] = ok ? h1[c] : 0.f;
+      a1[t][e] = ok ? av[e] : 0.f;                          // channels beyond C: exact zeros
+      b1[t][e] = ok ? bv[e] : 0.f;
     }
   }
   // ---- zero the halo columns of every band row and the rows that fall outside the map
@@ -663,6 +692,7 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
     }
     // the 16 pad bytes behind the channels of every interior pixel are never read (k-slot offsets stay below CSP * 2)
   }
+  GC_STAMP(1);
   // ---- conv1 over the band's pixels (rows inside the map), 16 pixels per MFMA tile, tiles dealt over the four waves
   {
     const int r_lo = max(iy0, 0), r_hi = min(iy0 + nrow_used, Hi);
@@ -721,11 +751,16 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
       }
     }
   }
+  GC_STAMP(2);
   if constexpr (KS1 > 2) gw_ = gconv_load_w(wfrag, slab, CSP);
   __syncthreads();
+  GC_STAMP(3);
   gconv_band_mma<STRIDE>(gw_, tile, red, redq, Wi, C, wfrag, scale, shift, y, pooled, nullptr, Ho, Wo, nbands, CSP, PS, relu, n, bnd,
-                         slab, oy0, nrows_out);
+                         slab, oy0, nrows_out, GcStat{nullptr, nullptr, nullptr, nullptr}, dbg);
 }
+
+static long long* g_c1g_dbg = nullptr;
+extern "C" int tdeed_c1_gconv_set_debug(void* buf) { g_c1g_dbg = (long long*)buf; return TDEED_OK; }
 
 // 1 if the bf16 MFMA kernel serves this geometry (a band of input rows fits LDS), i.e. if wfrag / in_a are usable
 extern "C" int tdeed_gconv3x3_mfma_fits(int Hi, int Wi, int C, int stride) {
@@ -831,7 +866,7 @@ extern "C" int tdeed_c1_gconv_fwd(const void* x, const void* G, int Fp, int N, i
 #define TD_C1G(Sv, Kv)                                                                                                     \
   hipLaunchKernelGGL((c1_gconv_mfma_kernel<Sv, Kv>), grid, dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)G,           \
                      G ? Fp : 0, Hi, Wi, Cin, C, (const bf16x8*)w1f, s1, h1, (const bf16x8*)wfrag, scale, shift, (bf16_t*)y,  \
-                     pooled, Ho, Wo, g.band, g.nbands, g.CSP, g.PS, g.rows_in, 1)
+                     pooled, Ho, Wo, g.band, g.nbands, g.CSP, g.PS, g.rows_in, 1, g_c1g_dbg)
 #define TD_C1G_K(Sv)                                                                                                       \
   do {                                                                                                                     \
     if (KS1 == 1) TD_C1G(Sv, 1); else if (KS1 == 2) TD_C1G(Sv, 2); else if (KS1 == 4) TD_C1G(Sv, 4);                      \

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void s1_front_kernel(const FrontP p) {
   __shared__ float red[4][16];
   // bands of one frame share halo rows: keep them on one XCD (one L2)
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int bnd = (int)(lid % p.nbands), n = (int)(lid / p.nbands);
+  int bnd, n;
+  td_split(lid, p.nbands, n, bnd);
   const int oy0 = bnd * p.band;
   const int nrows_out = min(p.band, p.Ho - oy0);
   const int y1r0 = 2 * oy0 - 1;                         // first conv1-map row held (may be -1)
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(256) void s1_front_roll_kernel(const FrontP p, int 
   __shared__ __attribute__((aligned(16))) bf16_t zero16[8];           // operand of the two unused k-slots of the stem patch
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
   const int nstrips = (p.Ho + S - 1) / S;
-  const int bnd = (int)(lid % nstrips), n = (int)(lid / nstrips);
+  int bnd, n;
+  td_split(lid, nstrips, n, bnd);
   const int oy0 = bnd * S;
   const int nrows_out = min(S, p.Ho - oy0);
   const int INW = p.cw + 2, Y1W = p.Ws + 2;
@@ -601,7 +603,8 @@ __global__ __launch_bounds__(PIPE_NT, 4) void s1_front_pipe_kernel(const FrontP 
   __shared__ float red[2][16];
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
   const int nstrips = (p.Ho + S - 1) / S;
-  const int bnd = (int)(lid % nstrips), n = (int)(lid / nstrips);
+  int bnd, n;
+  td_split(lid, nstrips, n, bnd);
   const int oy0 = bnd * S;
   const int nrows_out = min(S, p.Ho - oy0);
   const int NS = nrows_out + 2;                                         // super-steps: the roles run skewed by one each
@@ -1163,7 +1166,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[4][64];
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int bnd = (int)(lid % p.nbands), n = (int)(lid / p.nbands);
+  int bnd, n;
+  td_split(lid, p.nbands, n, bnd);
   const int r0 = bnd * p.band;
   const int nrows = min(p.band, p.Hs - r0);
   const int in_r0 = 2 * r0 - 1, nin = 2 * nrows + 1;

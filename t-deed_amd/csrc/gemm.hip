@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   // logical tiles are renumbered such that consecutive ones (the N tiles of one M tile, which re-read the same
   // A rows) share an XCD and therefore its L2, instead of fetching A from HBM / Infinity Cache once per XCD.
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int tile_n = (int)(lid % nb);
-  const long tile_m = lid / nb;
+  int tile_n, tile_m_;
+  td_split(lid, nb, tile_m_, tile_n);
+  const long tile_m = tile_m_;
   const long m0 = tile_m * 128;
   const int n0 = tile_n * BN;
 
@@ -103,16 +104,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     aok[i] = m < p.M;
     long mm = aok[i] ? m : 0;
     long src = mm;
-    if (p.g_stride > 1) {
-      long per = (long)p.g_ho * p.g_wo;
-      long f = mm / per;
-      int rem = (int)(mm - f * per);
-      int yo = rem / p.g_wo, xo = rem - yo * p.g_wo;
-      src = (f * p.g_hi + (long)yo * p.g_stride) * p.g_wi + (long)xo * p.g_stride;
+    const unsigned mu = (unsigned)mm;            // rows are < 2^31 (M is an int): unsigned 32-bit divisions, not the 64-bit
+    if (p.g_stride > 1) {                        // sequences (~120 vector instructions each: common.h td_split)
+      const unsigned per = (unsigned)(p.g_ho * p.g_wo);
+      const unsigned f = mu / per, rem = mu - f * per;
+      const unsigned yo = rem / (unsigned)p.g_wo, xo = rem - yo * (unsigned)p.g_wo;
+      src = ((long)f * p.g_hi + (long)yo * p.g_stride) * p.g_wi + (long)xo * p.g_stride;
     }
     arow[i] = reinterpret_cast<const T*>(p.A) + src * p.lda;
     a0row[i] = p.A0 ? reinterpret_cast<const T*>(p.A0) + src * p.lda0 : nullptr;
-    srow[i] = p.a_scale ? p.a_scale + (mm / p.a_scale_rows) * (long)p.K : nullptr;
+    srow[i] = p.a_scale ? p.a_scale + (long)(mu / (unsigned)p.a_scale_rows) * (long)p.K : nullptr;
   }
   const T* brow[BROWS];
   bool bok[BROWS];
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   gload(0);
   if constexpr (SE == 2) {
     // gates of the frames this tile touches -> LDS (rows of one tile span at most 128 / a_scale_rows + 2 frames)
-    const long f_first = m0 / p.a_scale_rows;
-    const long f_last = (p.M - 1) / p.a_scale_rows;
+    const long f_first = (long)((unsigned)m0 / (unsigned)p.a_scale_rows);
+    const long f_last = (long)((unsigned)(p.M - 1) / (unsigned)p.a_scale_rows);
     const int nf = 128 / p.a_scale_rows + 2;
     const int ng = nf * p.K;
     for (int i0 = tid * 4; i0 < ng; i0 += 4 * 1024) {           // four pieces per thread in flight (not a round trip per piece)
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long m = min(m0 + r0 + 32 * i, (long)p.M - 1);
-      gfi[i] = (int)(m / p.a_scale_rows - f_first);
+      gfi[i] = (int)((long)((unsigned)m / (unsigned)p.a_scale_rows) - f_first);
     }
     __syncthreads();
   }
@@ -662,16 +663,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ws_kernel(const
       const long mm = mok[mt] ? m : 0;
       mrow[mt] = mm;
       long src = mm;
+      const unsigned mu = (unsigned)mm;          // (rows < 2^31: 32-bit divisions, common.h td_split)
       if (p.g_stride > 1) {
-        const long per = (long)p.g_ho * p.g_wo;
-        const long f = mm / per;
-        const int rem = (int)(mm - f * per);
-        const int yo = rem / p.g_wo, xo = rem - yo * p.g_wo;
-        src = (f * p.g_hi + (long)yo * p.g_stride) * p.g_wi + (long)xo * p.g_stride;
+        const unsigned per = (unsigned)(p.g_ho * p.g_wo);
+        const unsigned f = mu / per, rem = mu - f * per;
+        const unsigned yo = rem / (unsigned)p.g_wo, xo = rem - yo * (unsigned)p.g_wo;
+        src = ((long)f * p.g_hi + (long)yo * p.g_stride) * p.g_wi + (long)xo * p.g_stride;
       }
       const T* arow = reinterpret_cast<const T*>(p.A) + src * p.lda;
       const T* a0row = p.A0 ? reinterpret_cast<const T*>(p.A0) + src * p.lda0 : nullptr;
-      const float* srow = p.a_scale ? p.a_scale + (mm / p.a_scale_rows) * (long)p.K : nullptr;
+      const float* srow = p.a_scale ? p.a_scale + (long)(mu / (unsigned)p.a_scale_rows) * (long)p.K : nullptr;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int k = (ks * 4 + q) * EPC;
@@ -963,8 +964,8 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
       sv[j] = ok ? v : z;
     }
     if constexpr (SE) {
-      const long f0 = (t * RS_ROWS) / p.a_scale_rows;
-      const long flast = ((long)p.M - 1) / p.a_scale_rows;
+      const long f0 = (long)((unsigned)(t * RS_ROWS) / (unsigned)p.a_scale_rows);       // (rows < 2^31: 32-bit divisions)
+      const long flast = (long)((unsigned)(p.M - 1) / (unsigned)p.a_scale_rows);
       gv = p.a_scale[min(f0 + gf, flast) * (long)p.K + min(gk, p.K - 1)];
     }
   };
@@ -974,11 +975,11 @@ __global__ __launch_bounds__(RS_THR, 1) void gemm_rs_kernel(const GemmWsP p) {
       float* g = gt + buf * 2 * KP;
       g[tid] = gv;                                                    // table of tile t (both frames), then scale the chunks
       __syncthreads();
-      const long f0 = (t * RS_ROWS) / p.a_scale_rows;
+      const long f0 = (long)((unsigned)(t * RS_ROWS) / (unsigned)p.a_scale_rows);
 #pragma unroll
       for (int j = 0; j < RS_CPT; ++j) {
         const long m = min(t * RS_ROWS + r0 + 16 * j, (long)p.M - 1);
-        const float* gr = g + (int)(m / p.a_scale_rows - f0) * KP + kk;
+        const float* gr = g + (int)((long)((unsigned)m / (unsigned)p.a_scale_rows) - f0) * KP + kk;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr), g1 = *reinterpret_cast<const f32x4*>(gr + 4);
         bf16x8 x8 = *reinterpret_cast<const bf16x8*>(&sv[j]);
 #pragma unroll

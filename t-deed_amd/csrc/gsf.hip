@@ -215,9 +215,11 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
   // frames in contiguous chunks per XCD (all three launches of a site use the same numbering): the maps of frames t-1 / t+1
   // that the next launch reads were written through, and are read through, the same L2
   const long lid = xcd_logical_id(blockIdx.x, gridDim.x);
-  const int f0 = (int)(lid / nbq) * nfr;
+  int fq_, bq_;
+  td_split(lid, nbq, fq_, bq_);
+  const int f0 = fq_ * nfr;
   const int nf = min(nfr, nframes - f0);
-  const int y0 = (int)(lid % nbq) * band;
+  const int y0 = bq_ * band;
   const int y1 = min(h, y0 + band);
   const int nrow = y1 - y0, rows = nrow + 2, WP = w + 2;
   const int fbytes = (band + 2) * WP * PSQ;                     // one frame's band
