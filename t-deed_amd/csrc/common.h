@@ -154,6 +154,17 @@ __device__ __forceinline__ void td_split(long lid, int d, int& q, int& r) {
   r = (int)(u - qq * dd);
 }
 
+// sum over each row of 16 lanes (lanes sharing lane >> 4), every lane gets it: four DPP moves (lane ^ 1, lane ^ 2, the other quad
+// of the half row, the other half row) -- the pairing of the xor butterfly `v += __shfl_xor(v, 1 / 2 / 4 / 8)`, i.e. the same
+// bits, without its four ds_bpermute round trips through the LDS crossbar (hipcc emits one per step: ~40 in c1_gconv's tail)
+__device__ __forceinline__ float td_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Division by a run-time constant without the ~25-instruction integer-divide sequence (index arithmetic of the

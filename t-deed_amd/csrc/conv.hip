@@ -388,23 +388,13 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
     // ---- squeeze partial sums: lanes sharing q, then the waves sharing the pair (fixed order)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float va = psA[r], vb = psB[r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        va += __shfl_xor(va, o, 64);
-        vb += __shfl_xor(vb, o, 64);
-      }
+      const float va = td_row16_sum(psA[r]), vb = td_row16_sum(psB[r]);
       if (pl == 0) {
         red[wv][q * 4 + r] = va;
         red[wv][16 + q * 4 + r] = vb;
       }
       if (pooled_sq) {
-        float wa = pqA[r], wb = pqB[r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          wa += __shfl_xor(wa, o, 64);
-          wb += __shfl_xor(wb, o, 64);
-        }
+        const float wa = td_row16_sum(pqA[r]), wb = td_row16_sum(pqB[r]);
         if (pl == 0) {
           redq[wv][q * 4 + r] = wa;
           redq[wv][16 + q * 4 + r] = wb;
@@ -508,18 +498,10 @@ __device__ __forceinline__ void gconv_band_mma(const GcW& gw_, const unsigned ch
   // ---- SE squeeze partial sums: lanes sharing q, then waves sharing the unit
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float v = psum[r];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    const float v = td_row16_sum(psum[r]);
     if (pl == 0) red[wv][q * 4 + r] = v;
     if (pooled_sq) {            // training: sums of squares too (BatchNorm statistics of the raw conv output)
-      float w = psq[r];
-      w += __shfl_xor(w, 1, 64);
-      w += __shfl_xor(w, 2, 64);
-      w += __shfl_xor(w, 4, 64);
-      w += __shfl_xor(w, 8, 64);
+      const float w = td_row16_sum(psq[r]);
       if (pl == 0) redq[wv][q * 4 + r] = w;
     }
   }

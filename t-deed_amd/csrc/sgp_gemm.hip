@@ -106,13 +106,7 @@ __device__ __forceinline__ float sg_sum_q(float v) {
   return v;
 }
 // sum over the 16 lanes of a row (lanes sharing l >> 4)
-__device__ __forceinline__ float sg_sum_r(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
-}
+__device__ __forceinline__ float sg_sum_r(float v) { return td_row16_sum(v); }      // (DPP: the xor butterfly's pairing, same bits)
 
 // the same sum by DPP moves (lane ^ 1, lane ^ 2, the other quad of the half row, the other half row): the pairing of the
 // xor butterfly above, so the same bits, without its LDS crossbar round trips
