@@ -16,6 +16,13 @@ def main():
     name, rev, files = sys.argv[1], sys.argv[2], sys.argv[3:]
     objs = []
     with tempfile.TemporaryDirectory() as td:
+        # the headers of REV beside the files taken from it (an #include "common.h" resolves to the including file's directory
+        # first): a change to a shared header is then part of the A/B too
+        for h in ("common.h", "sgp_tile.h", "se_excite.h"):
+            r = subprocess.run(["git", "-C", ROOT, "show", f"{rev}:t-deed_amd/csrc/{h}"], capture_output=True, text=True)
+            if r.returncode == 0:
+                with open(os.path.join(td, h), "w") as f:
+                    f.write(r.stdout)
         for s in B.SOURCES:
             obj = os.path.join(B.CSRC, s.replace(".hip", ".o"))
             if s in files:
