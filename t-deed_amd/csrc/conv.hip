@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma_kernel(const bf16_t* __rest
 // (A form that also produced the downsample shortcut from the same x fragments was measured slower and is parked:
 // experiments/r4_parked/conv_with_c1_gconv_ds.hip.)
 template <int STRIDE, int KS1>
-__global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G, int Fp,
+__global__ __launch_bounds__(256, KS1 == 4 ? 3 : 1) void c1_gconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G, int Fp,
                                                             int Hi, int Wi, int Cin, int C, const bf16x8* __restrict__ w1f,
                                                             const float* __restrict__ s1, const float* __restrict__ h1,
                                                             const bf16x8* __restrict__ wfrag, const float* __restrict__ scale,
@@ -689,6 +689,57 @@ __global__ __launch_bounds__(256) void c1_gconv_mfma_kernel(const bf16_t* __rest
     // At KS1 >= 4 a second set of fragments costs the third workgroup per CU (measured slower, also with the BatchNorm fold
     // moved to LDS): those stay one tile at a time.
     constexpr int NPF = KS1 <= 2 ? 4 : 1;
+    if constexpr (KS1 == 4) {
+      // Cin = 128: one tile's fragments are 16 registers and a wave has ~5 tiles, i.e. five dependent load -> MFMA -> LDS-store
+      // rounds (time stamps: 6.7 - 8 us of a 12 - 17 us workgroup).  The NEXT tile's fragments are requested before the current
+      // tile is multiplied, UNCONDITIONALLY (the tile index is clamped: the last request is a repeat nobody uses) -- behind a
+      // branch the compiler cannot count the loads in flight and waits for all of them (vmcnt(0)), which is what made the first
+      // attempt slower.  Two alternating register sets, no copies.
+      auto tile_px = [&](int t0, int& rr, int& cc) {
+        const int p = min(t0, ntl - 1) * 16 + pl;
+        const bool ok = t0 < ntl && p < npx;
+        dwi.divmod(p < npx ? p : 0, rr, cc);
+        return ok;
+      };
+      auto tile_load = [&](int rr, int cc, bf16x8 (&xfo)[KS1]) {
+        const long pix = (long)(r_lo + rr) * Wi + cc;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const int k = 32 * ks + 8 * q;
+          const bf16_t* src = (gn && k < Fp) ? gn + pix * Fp + k : xn + pix * Cin + k;
+          xfo[ks] = *reinterpret_cast<const bf16x8*>(src);           // Cin = 128: every k-step is inside the row
+        }
+      };
+      auto tile_mma = [&](bool pok_, int rr, int cc, const bf16x8 (&xfi)[KS1]) {
+        unsigned char* dst = tile + ((long)(r_lo + rr - iy0) * WP + cc + 1) * PS + 8 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t < nts) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[t][ks], xfi[ks], acc, 0, 0, 0);
+            if (pok_) {
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)fmaxf(acc[e] * a1[t][e] + b1[t][e], 0.f);
+              *reinterpret_cast<bf16x4*>(dst + t * 32) = o;
+            }
+          }
+        }
+      };
+      bf16x8 xa[KS1], xb[KS1];
+      int ra, ca, rb, cb;
+      bool pa = tile_px(wv, ra, ca), pb;
+      tile_load(ra, ca, xa);
+      for (int tb = wv; tb < ntl; tb += 8) {
+        pb = tile_px(tb + 4, rb, cb);
+        tile_load(rb, cb, xb);                                      // (always: see above)
+        tile_mma(pa, ra, ca, xa);
+        pa = tile_px(tb + 8, ra, ca);
+        tile_load(ra, ca, xa);
+        tile_mma(pb, rb, cb, xb);
+      }
+    } else
     for (int tb = wv; tb < ntl; tb += 4 * NPF) {
       bf16x8 xf[NPF][KS1];
       int rrs[NPF], ccs[NPF];
