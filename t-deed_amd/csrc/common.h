@@ -135,6 +135,13 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// the same on the hardware's exp2 / reciprocal (1 ulp each; saturates to exactly 0 / 1): ~4 instructions against ~40 for libm's
+// expf + IEEE division.  For the bf16 throughput path's SE gates, where both forms of the excitation (se_gate_mfma_kernel and
+// the one inside the one-launch bottleneck) use it, so they stay bit-identical to each other; the fp32 parity path keeps
+// sigmoidf_.  (Round 6: 12 gates per lane were ~1.9 k of the bottleneck workgroup's 76 k cycles.)
+__device__ __forceinline__ float sigmoid_fast_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
 
 // XCD-aware workgroup renumbering (bijective): hardware deals workgroups round-robin over the 8 XCDs; this maps
 // blockIdx -> logical id so that consecutive logical ids sit on ONE XCD (one L2) and run close in time.  Used

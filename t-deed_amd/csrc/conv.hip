@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(NW * 64) void se_gate_mfma_kernel(const float* __re
       if (c0 < C && f0 + pl < N) {
         f32x4 g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + b2v[a][e]);
+        for (int e = 0; e < 4; ++e) g[e] = sigmoid_fast_(acc[e] + b2v[a][e]);
         *reinterpret_cast<f32x4*>(gate + (long)(f0 + pl) * C + c0) = g;
       }
     }

@@ -162,7 +162,7 @@ __device__ __forceinline__ void se_excite_lds(const SeP& se, long f_first, int n
     if (c0 < C && pl < nf) {
       f32x4 g;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + b2v[j][e]);
+      for (int e = 0; e < 4; ++e) g[e] = sigmoid_fast_(acc[e] + b2v[j][e]);
       TD_DEV_ASSERT(pl < 16 && c0 + 4 <= ldg);
       *reinterpret_cast<f32x4*>(gtab + pl * ldg + c0) = g;
       if (se.gate_out && f_first + pl <= f_last) *reinterpret_cast<f32x4*>(se.gate_out + (f_first + pl) * (long)C + c0) = g;
