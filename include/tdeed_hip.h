@@ -202,6 +202,16 @@ int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, i
                     int w2_tap_major /* k-slot order of w2f: 1 = engine.pack_gconv_frags(tap_major=True), the conflict-free
                                         order of this launch (group width 8); 0 = the order tdeed_gconv3x3_fwd reads */,
                     void* stream);
+/* The same block behind a gate-shift-fuse site (impl/gsf.py:74-93) with the site's last launch -- fusion weights + blend,
+ * tdeed_gsf_blend_src_fwd -- done inside the frame load: gx [N][h*w][ldx] is the slice's source (the block input, or the
+ * compact copy of its first Fp channels), gate / ysum / xsum are tdeed_gsf_gate_fwd's outputs for the N = B * T frames, cw* / cb*
+ * the two fusion convs.  out == tdeed_bneck_fwd(x, G = tdeed_gsf_blend_src_fwd(gx, ...)), bit for bit. */
+int tdeed_bneck_gs_fwd(const void* x, const void* gx, int ldx, const float* gate, const float* ysum, const float* xsum,
+                       const float* cw1, const float* cb1, const float* cw2, const float* cb2, int T, int F, int Fp, int N,
+                       int h, int w, int C, const void* w1f, const float* s1, const float* h1, const void* w2f,
+                       const float* s2, const float* h2, const void* se_w1f, const float* se_b1, const void* se_w2f,
+                       const float* se_b2, int R, const void* w3f, const float* s3, const float* h3, void* out, void* out2,
+                       int n2, int w2_tap_major, void* stream);
 
 
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------

@@ -24,6 +24,15 @@ struct BneckP {
   int N, h, w, C;
   int w2_tap_major;                               // k-slot order of w2f: 0 = half * 9 + tap (gconv3x3_mfma_kernel's), 1 = 2 * tap + half
   long long* dbg;                                 // diagnostic: per-workgroup phase time stamps (or null)
+  // gate-shift-fuse blend inside the frame load (gs.gate != null; G unused): what tdeed_gsf_blend_src_fwd would have written
+  // into G is made here from the gate maps and spatial sums of tdeed_gsf_gate_fwd -- one launch and one round trip of the
+  // slice through memory less per block
+  struct Gs {
+    const bf16_t* x; int ldx;                     // the slice's source: block input or its compact copy, row stride in elements
+    const float* gate; const float* ysum; const float* xsum;   // [N][hw][2], [N][F], [N][F]
+    const float* cw1; const float* cb1; const float* cw2; const float* cb2;
+    int T_len, F;
+  } gs;
 };
 
 #define BN_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 16 + (i)] = clock64(); } while (0)
@@ -53,7 +62,9 @@ __device__ __forceinline__ float bnk_row16_sum(float v) {
 // FPW frames per workgroup, NPTM >= ceil(FPW * hw / 16) pixel tiles
 // TAPM: conv2's k-slot order (BneckP::w2_tap_major) as a compile-time constant -- as a run-time select the same addresses
 // cost the conv2 phase its whole gain (186 vs 175 stamp units: measured)
-template <int KS, int FPW, int NPTM, bool TAPM>
+// BLEND: the gate-shift-fuse blend inside the frame load (p.gs) -- a template parameter so that either form of the load phase is
+// straight-line code (as a run-time branch the requests of the two forms met at joins, and waits there are conservative)
+template <int KS, int FPW, int NPTM, bool TAPM, bool BLEND>
 __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int hw = p.h * p.w, C = p.C;
@@ -141,31 +152,173 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     }
     const int cpr = C >> 3;
     const bf16_t* gg = p.G ? p.G + (long)f0 * hw * p.Fp : nullptr;
-    const int total = npix * cpr;
-    const IDiv dcpr(cpr);
+    // ---- gate-shift-fuse blend (gsf.hip: gsf_blend_src_kernel's arithmetic, bit for bit): requests first.  Scratch in region B,
+    // which nothing else touches before conv1: rows 1 + 12 fs + (0..9) = the spatial sums of frames t-2 .. t+2 (y, then x) of
+    // the workgroup's frame fs, row + 10 its fusion weights, row 1 + 12 FPW the conv weights (row 0's head is the k pad's slack)
+    constexpr bool blend = BLEND;
+    const int gF = p.gs.F, gFh = gF >> 1, gT = p.gs.T_len;
+    const int npc8 = p.Fp >> 3;                                  // 16-byte pieces of the slice per pixel
+    const int ck0 = blend ? npc8 : 0;                            // the plain pass below skips the slice's pieces: the blend makes them
+    const int cprx = cpr - ck0, total = npix * cprx;
+    const IDiv dcpr(cprx);
+    auto srow = [&](int r) { return reinterpret_cast<float*>(Bt + r * RS); };
+    float sv[10], cwv = 0.f;
+    u32x4 bxc[3], bxn[3], bxp[3];
+    f32x2 bga[3];
+    float bgn[3], bgp[3];
+    const int sfs = (FPW > 1 && tid >= gF) ? 1 : 0, sc_ = tid - sfs * gF;          // sums: thread = (frame slot, channel)
+    const IDiv dgt(blend ? gT : 1);
+    if (blend) {
+      {
+        const int f = f0 + min(sfs, nfr - 1);
+        int b, t;
+        dgt.divmod(f, b, t);
+        const int cc = min(sc_, gF - 1);
+#pragma unroll
+        for (int row = 0; row < 10; ++row) {
+          const int r = row >= 5 ? row - 5 : row;
+          const int t2 = min(max(t + r - 2, 0), gT - 1);
+          sv[row] = (row >= 5 ? p.gs.xsum : p.gs.ysum)[((long)b * gT + t2) * gF + cc];
+        }
+        const int ci = min(max(tid - 256, 0), 37);
+        cwv = *(ci < 18 ? p.gs.cw1 + ci : ci < 36 ? p.gs.cw2 + (ci - 18) : ci == 36 ? p.gs.cb1 : p.gs.cb2);
+      }
+      const IDiv dnpc(npc8);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int i = min(tid + j * BNK_THR, npix * npc8 - 1);
+        int px, ck;
+        dnpc.divmod(i, px, ck);
+        const int fs = (FPW > 1 && px >= hw) ? 1 : 0, pix = px - fs * hw;
+        const int f = f0 + fs;
+        const int t = f - dgt.div(f) * gT;
+        const long fn = t < gT - 1 ? f + 1 : f, fpv = t > 0 ? f - 1 : f;
+        const bf16_t* xs0 = p.gs.x + (long)pix * p.gs.ldx + ck * 8;
+        const long fstride = (long)hw * p.gs.ldx;
+        // a piece's neighbour: frame t+1 while its channels are in gate group 0, t-1 in group 1; the one piece that straddles
+        // F/2 needs both (the others repeat the first address: no branch around a load, and no second line either)
+        const bool lo = ck * 8 < gFh, strad = lo && ck * 8 + 7 >= gFh;
+        bxc[j] = *reinterpret_cast<const u32x4*>(xs0 + f * fstride);
+        bxn[j] = *reinterpret_cast<const u32x4*>(xs0 + (lo ? fn : fpv) * fstride);
+        bxp[j] = *reinterpret_cast<const u32x4*>(xs0 + ((lo && !strad) ? fn : fpv) * fstride);
+        bga[j] = *reinterpret_cast<const f32x2*>(p.gs.gate + ((long)f * hw + pix) * 2);
+        bgn[j] = p.gs.gate[(fn * hw + pix) * 2];
+        bgp[j] = p.gs.gate[(fpv * hw + pix) * 2 + 1];
+      }
+    }
     constexpr int NLD = 9;                                       // independent 16-byte loads in flight per thread: a workgroup's
-    for (int i0 = tid; i0 < total; i0 += BNK_THR * NLD) {        // 72 KB (7 x 7 x 368, two frames) in ONE round trip
-      u32x4 v[NLD];
+    u32x4 v[NLD];                                                // 72 KB (7 x 7 x 368, two frames) in ONE round trip
+    auto x_issue = [&](int i0) {
 #pragma unroll
       for (int b = 0; b < NLD; ++b) {
         const int i = min(i0 + b * BNK_THR, total - 1);
         int px, ck;
         dcpr.divmod(i, px, ck);
-        const int k = ck * 8;
+        const int k = (ck + ck0) * 8;
         const bf16_t* src = (gg && k < p.Fp) ? gg + (long)px * p.Fp + k : xg + (long)px * C + k;
         v[b] = *reinterpret_cast<const u32x4*>(src);
       }
-      TD_ISSUE_FENCE();
+    };
+    auto x_store = [&](int i0) {
 #pragma unroll
       for (int b = 0; b < NLD; ++b) {
         const int i = i0 + b * BNK_THR;
         if (i < total) {
           int px, ck;
           dcpr.divmod(i, px, ck);
+          ck += ck0;
           TD_LDS_CHECK(px * RS + ck * 16, 16, FPW * hw * RS);
           *reinterpret_cast<u32x4*>(At + px * RS + ck * 16) = v[b];
         }
       }
+    };
+    x_issue(tid);
+    TD_ISSUE_FENCE();
+    // (the blend runs on requests that were made before the frames': it is done while those travel)
+    if (blend) {
+      // sums (zeros outside the clip) and conv weights -> scratch; fusion weights of the workgroup's frames: the 3x3 conv over
+      // the (channel, time) plane of the spatial means + sigmoid; then the blend of this thread's pieces into region A
+      if (sfs < nfr && sc_ < gF) {
+        const int f = f0 + sfs, t = f - dgt.div(f) * gT;
+#pragma unroll
+        for (int row = 0; row < 10; ++row) {
+          const int t2 = t + (row >= 5 ? row - 5 : row) - 2;
+          srow(1 + 12 * sfs + row)[sc_] = (t2 >= 0 && t2 < gT) ? sv[row] : 0.f;
+        }
+      }
+      float* cwl = srow(1 + 12 * FPW);
+      if (tid >= 256 && tid < 256 + 38) cwl[tid - 256] = cwv;
+      __syncthreads();
+      {
+        const int fs = (FPW > 1 && tid >= p.Fp) ? 1 : 0, c = tid - fs * p.Fp;
+        if (fs < nfr && c < p.Fp) {
+          const int t = (f0 + fs) - dgt.div(f0 + fs) * gT;
+          const int rb = 1 + 12 * fs;
+          const float inv_hw = 1.0f / (float)hw;
+          float wgt = 0.f;
+          if (c < gF) {
+            const int g = c >= gFh;
+            const int cl = c - g * gFh;
+            const float* cw = cwl + 18 * g;
+            float a = cwl[36 + g];
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+              const int c2 = cl + dc;
+              if (c2 < 0 || c2 >= gFh) continue;
+              const int cc = g * gFh + c2;
+#pragma unroll
+              for (int dt = -1; dt <= 1; ++dt) {
+                const int t2 = t + dt;
+                if (t2 < 0 || t2 >= gT) continue;
+                const float rm = (srow(rb + 5 + dt + 2)[cc] - srow(rb + dt + 2)[cc]) * inv_hw;
+                const int r2 = dt + 2 + (g ? -1 : 1);
+                const float ysh = srow(rb + r2)[cc] * inv_hw;
+                a = fmaf(cw[(dc + 1) * 3 + (dt + 1)], ysh, a);
+                a = fmaf(cw[9 + (dc + 1) * 3 + (dt + 1)], rm, a);
+              }
+            }
+            wgt = sigmoidf_(a);
+          }
+          srow(rb + 10)[c] = wgt;
+        }
+      }
+      __syncthreads();
+      const IDiv dnpc(npc8);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int i = tid + j * BNK_THR;
+        if (i < npix * npc8) {
+          int px, ck;
+          dnpc.divmod(i, px, ck);
+          const int fs = (FPW > 1 && px >= hw) ? 1 : 0;
+          const int t = (f0 + fs) - dgt.div(f0 + fs) * gT;
+          const bool has_next = t < gT - 1, has_prev = t > 0;
+          const float* fwl = srow(1 + 12 * fs + 10) + ck * 8;
+          const bf16x8 xc8 = *reinterpret_cast<const bf16x8*>(&bxc[j]);
+          const bf16x8 xn8 = *reinterpret_cast<const bf16x8*>(&bxn[j]);
+          const bf16x8 xp8 = *reinterpret_cast<const bf16x8*>(&bxp[j]);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ci = ck * 8 + e;
+            if (ci >= gF) { o[e] = xc8[e]; continue; }
+            const bool g = ci >= gFh;
+            const float xv = (float)xc8[e];
+            const float r = fmaf(-(g ? bga[j][1] : bga[j][0]), xv, xv);
+            const float gsh = g ? (has_prev ? bgp[j] : 0.f) : (has_next ? bgn[j] : 0.f);
+            const float ysh = gsh * (float)((g && ck * 8 < gFh) ? xp8[e] : xn8[e]);      // g in a "lo" piece: the straddler's upper part
+            const float wv = fwl[e];
+            o[e] = (bf16_t)fmaf(ysh, wv, r * (1.0f - wv));
+          }
+          *reinterpret_cast<bf16x8*>(At + px * RS + ck * 16) = o;
+        }
+      }
+    }
+    x_store(tid);
+    for (int i0 = tid + BNK_THR * NLD; i0 < total; i0 += BNK_THR * NLD) {
+      x_issue(i0);
+      TD_ISSUE_FENCE();
+      x_store(i0);
     }
     // the pad bytes behind every row (they meet the zero weights of the k pad, but 0 * stale NaN = NaN), the zero row
     // (region B's pad bytes that the grouped conv reads are written by conv1 itself: the zeros of its overhang tile)
@@ -677,18 +830,50 @@ extern "C" int tdeed_bneck_fits(int h, int w, int C, int R) {
   return bneck_smem(fpw, hw, C) <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f,
-                               const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
-                               const void* se_w1f, const float* se_b1, const void* se_w2f, const float* se_b2, int R,
-                               const void* w3f, const float* s3, const float* h3, void* out, void* out2, int n2,
-                               int w2_tap_major, void* stream) {
+static int bneck_launch(BneckP& p, hipStream_t st) {
+  const int h = p.h, w = p.w, C = p.C, N = p.N;
+  p.dbg = g_bneck_dbg;
+  const int hw = h * w, fpw = bneck_fpw(hw), KS = (C + 31) / 32;
+  const size_t smem = bneck_smem(fpw, hw, C);
+  static TdDevOnce attr_set;
+  if (!attr_set.get()) {
+    hipError_t e = hipSuccess;
+#define BNK_ATTR(...) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define BNK_ATTR4(...) BNK_ATTR(__VA_ARGS__, true, true); BNK_ATTR(__VA_ARGS__, true, false); BNK_ATTR(__VA_ARGS__, false, true); \
+                       BNK_ATTR(__VA_ARGS__, false, false)
+    BNK_ATTR4(12, 2, 7); BNK_ATTR4(5, 1, 13); BNK_ATTR4(5, 2, 8); BNK_ATTR4(12, 1, 7);
+#undef BNK_ATTR4
+#undef BNK_ATTR
+    if (e != hipSuccess) { tdeed_set_error("bneck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
+    attr_set.set();
+  }
+  const int grid = (N + fpw - 1) / fpw;
+  const bool tm = p.w2_tap_major != 0;
+  const bool bl = p.gs.gate != nullptr;
+#define BNK_GO1(...) hipLaunchKernelGGL((bneck_kernel<__VA_ARGS__>), dim3(grid), dim3(BNK_THR), smem, st, p)
+#define BNK_GO(...) do { if (tm && bl) BNK_GO1(__VA_ARGS__, true, true); else if (tm) BNK_GO1(__VA_ARGS__, true, false); \
+                         else if (bl) BNK_GO1(__VA_ARGS__, false, true); else BNK_GO1(__VA_ARGS__, false, false); } while (0)
+  if (KS == 12 && fpw == 2) BNK_GO(12, 2, 7);
+  else if (KS == 5 && fpw == 1) BNK_GO(5, 1, 13);
+  else if (KS == 5 && fpw == 2) BNK_GO(5, 2, 8);
+  else if (KS == 12 && fpw == 1) BNK_GO(12, 1, 7);   // e.g. 13 x 7 maps
+  else { tdeed_set_error("bneck: KS=%d with %d frames per workgroup", KS, fpw); return TDEED_ERR_ARG; }
+#undef BNK_GO
+#undef BNK_GO1
+  TD_LAUNCH_CHECK("bneck");
+  return TDEED_OK;
+}
+
+static int bneck_fill(BneckP& p, const void* x, int N, int h, int w, int C, const void* w1f, const float* s1, const float* h1,
+                      const void* w2f, const float* s2, const float* h2, const void* se_w1f, const float* se_b1,
+                      const void* se_w2f, const float* se_b2, int R, const void* w3f, const float* s3, const float* h3, void* out,
+                      void* out2, int n2, int w2_tap_major) {
   TD_CHECK(x && w1f && s1 && h1 && w2f && s2 && h2 && se_w1f && se_b1 && se_w2f && se_b2 && w3f && s3 && h3 && out,
            "bneck: null pointer");
   TD_CHECK(N > 0 && tdeed_bneck_fits(h, w, C, R), "bneck: geometry h=%d w=%d C=%d R=%d unsupported", h, w, C, R);
-  TD_CHECK(!G || (Fp % 8 == 0 && Fp > 0 && Fp <= C), "bneck: bad splice width %d", Fp);
   TD_CHECK(!out2 || (n2 % 8 == 0 && n2 > 0 && n2 <= C), "bneck: bad second output width %d", n2);
-  BneckP p{};
-  p.x = (const bf16_t*)x; p.G = (const bf16_t*)G; p.Fp = G ? Fp : 0;
+  p = BneckP{};
+  p.x = (const bf16_t*)x;
   p.w1f = (const bf16x8*)w1f; p.s1 = s1; p.h1 = h1;
   p.w2f = (const bf16x8*)w2f; p.s2 = s2; p.h2 = h2;
   p.se = SeP{};
@@ -697,30 +882,46 @@ extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int 
   p.out = (bf16_t*)out; p.out2 = (bf16_t*)out2; p.n2 = out2 ? n2 : 0;
   p.N = N; p.h = h; p.w = w; p.C = C;
   p.w2_tap_major = w2_tap_major ? 1 : 0;
-  p.dbg = g_bneck_dbg;
-  const int hw = h * w, fpw = bneck_fpw(hw), KS = (C + 31) / 32;
-  const size_t smem = bneck_smem(fpw, hw, C);
-  hipStream_t st = (hipStream_t)stream;
-  static TdDevOnce attr_set;
-  if (!attr_set.get()) {
-    hipError_t e = hipSuccess;
-#define BNK_ATTR(...) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)bneck_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    BNK_ATTR(12, 2, 7, true); BNK_ATTR(12, 2, 7, false); BNK_ATTR(5, 1, 13, true); BNK_ATTR(5, 1, 13, false);
-    BNK_ATTR(5, 2, 8, true); BNK_ATTR(5, 2, 8, false); BNK_ATTR(12, 1, 7, true); BNK_ATTR(12, 1, 7, false);
-#undef BNK_ATTR
-    if (e != hipSuccess) { tdeed_set_error("bneck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return TDEED_ERR_RUNTIME; }
-    attr_set.set();
-  }
-  const int grid = (N + fpw - 1) / fpw;
-  const bool tm = p.w2_tap_major != 0;
-#define BNK_GO(...) do { if (tm) hipLaunchKernelGGL((bneck_kernel<__VA_ARGS__, true>), dim3(grid), dim3(BNK_THR), smem, st, p); \
-                         else hipLaunchKernelGGL((bneck_kernel<__VA_ARGS__, false>), dim3(grid), dim3(BNK_THR), smem, st, p); } while (0)
-  if (KS == 12 && fpw == 2) BNK_GO(12, 2, 7);
-  else if (KS == 5 && fpw == 1) BNK_GO(5, 1, 13);
-  else if (KS == 5 && fpw == 2) BNK_GO(5, 2, 8);
-  else if (KS == 12 && fpw == 1) BNK_GO(12, 1, 7);   // e.g. 13 x 7 maps
-  else { tdeed_set_error("bneck: KS=%d with %d frames per workgroup", KS, fpw); return TDEED_ERR_ARG; }
-#undef BNK_GO
-  TD_LAUNCH_CHECK("bneck");
   return TDEED_OK;
+}
+
+extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f,
+                               const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
+                               const void* se_w1f, const float* se_b1, const void* se_w2f, const float* se_b2, int R,
+                               const void* w3f, const float* s3, const float* h3, void* out, void* out2, int n2,
+                               int w2_tap_major, void* stream) {
+  BneckP p;
+  const int rc = bneck_fill(p, x, N, h, w, C, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, out, out2, n2,
+                            w2_tap_major);
+  if (rc != TDEED_OK) return rc;
+  TD_CHECK(!G || (Fp % 8 == 0 && Fp > 0 && Fp <= C), "bneck: bad splice width %d", Fp);
+  p.G = (const bf16_t*)G; p.Fp = G ? Fp : 0;
+  return bneck_launch(p, (hipStream_t)stream);
+}
+
+// The same block behind a gate-shift-fuse site, with the site's LAST launch (tdeed_gsf_blend_src_fwd: fusion weights + blend,
+// source channel order) done inside the frame load: gx [N][h*w][ldx] is what that launch would read (the block input, or the
+// compact copy of its first Fp channels), gate / ysum / xsum are tdeed_gsf_gate_fwd's outputs for the N = B * T frames, T frames
+// per clip.  out == tdeed_bneck_fwd(x, G = tdeed_gsf_blend_src_fwd(...)), bit for bit.
+extern "C" int tdeed_bneck_gs_fwd(const void* x, const void* gx, int ldx, const float* gate, const float* ysum, const float* xsum,
+                                  const float* cw1, const float* cb1, const float* cw2, const float* cb2, int T, int F, int Fp,
+                                  int N, int h, int w, int C, const void* w1f, const float* s1, const float* h1, const void* w2f,
+                                  const float* s2, const float* h2, const void* se_w1f, const float* se_b1, const void* se_w2f,
+                                  const float* se_b2, int R, const void* w3f, const float* s3, const float* h3, void* out,
+                                  void* out2, int n2, int w2_tap_major, void* stream) {
+  BneckP p;
+  const int rc = bneck_fill(p, x, N, h, w, C, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, out, out2, n2,
+                            w2_tap_major);
+  if (rc != TDEED_OK) return rc;
+  TD_CHECK(gx && gate && ysum && xsum && cw1 && cb1 && cw2 && cb2, "bneck_gs: null pointer");
+  TD_CHECK(F % 4 == 0 && F > 0 && Fp % 8 == 0 && Fp >= F && Fp < F + 8 && 2 * Fp <= C && ldx >= Fp && ldx % 8 == 0,
+           "bneck_gs: bad fold F=%d Fp=%d ldx=%d C=%d", F, Fp, ldx, C);
+  TD_CHECK(T > 0 && N % T == 0 && N < (1 << 22), "bneck_gs: %d frames are not whole clips of %d", N, T);
+  const int hw = h * w, fpw = bneck_fpw(hw);
+  TD_CHECK(hw >= 14 && fpw * hw * (Fp / 8) <= 3 * BNK_THR && fpw * Fp <= BNK_THR,
+           "bneck_gs: a %d x %d map with a %d-channel slice does not fit the blend's scratch / piece slots", h, w, Fp);
+  p.Fp = Fp;
+  p.gs.x = (const bf16_t*)gx; p.gs.ldx = ldx; p.gs.gate = gate; p.gs.ysum = ysum; p.gs.xsum = xsum;
+  p.gs.cw1 = cw1; p.gs.cb1 = cb1; p.gs.cw2 = cw2; p.gs.cb2 = cb2; p.gs.T_len = T; p.gs.F = F;
+  return bneck_launch(p, (hipStream_t)stream);
 }

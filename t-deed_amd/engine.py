@@ -436,6 +436,9 @@ def _se(pooled, inv_cnt, bw, gate):
 
 
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
+# the gate-shift-fuse blend inside the one-launch bottleneck's frame load (tdeed_bneck_gs_fwd): the site's third launch and the
+# round trip of its output slice are gone
+BNECK_BLEND = os.environ.get("TDEED_BNECK_BLEND", "1") == "1"
 C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
 C1_GCONV_MAX_CIN = 160
 
@@ -892,13 +895,17 @@ class ForwardEngine:
                 gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
                           ysum=pool.take((N, F), torch.float32),
                           xsum=pool.take((N, F), torch.float32))
-                gb["out"] = pool.take((M, Fp), dt)
-                if bw.gs_cw1 is not None:
+                # the blend itself runs inside the one-launch bottleneck's frame load when it can (tdeed_bneck_gs_fwd)
+                blend_in = bool(one_launch and BNECK_BLEND and bw.gs_src and bw.gs_cw1 is not None and h * w >= 14
+                                and 2 * Fp <= blk.cin and ("_features." + blk.name + ".gs_out") not in taps)
+                if not blend_in:
+                    gb["out"] = pool.take((M, Fp), dt)
+                if bw.gs_cw1 is not None and not blend_in:
                     gb["fw"] = pool.take((B, F, T), torch.float32)
-                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp: ops.gate_shift(
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp, go=blend_in: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, src_order=bw.gs_src),
-                    M * (2 * F + Fp) * es + M * 16, 2 * M * F * 27))
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, src_order=bw.gs_src, gates_only=go),
+                    M * ((1 if blend_in else 2) * F + (0 if blend_in else Fp)) * es + M * 16, 2 * M * F * 27))
                 if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, A0=gb["out"], k0=Fp, out=y1, M=M),
@@ -909,6 +916,7 @@ class ForwardEngine:
                     keep["_features." + blk.name + ".gs_out"] = gb["out"]
                 gs_bufs = list(gb.values()) + ([xs] if xs is not None else [])
             else:
+                blend_in = False
                 if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, y1=y1, M=M: bw.w1.run(
                         x, bw.s1, bw.h1, ops.ACT_RELU, out=y1, M=M), *gemm_cost(M, blk.cin, blk.cout, es)))
@@ -919,14 +927,21 @@ class ForwardEngine:
                 nxt = blocks[bi + 1].spec if bi + 1 < len(blocks) else None
                 xs_next = (pool.take((N, h, w, (nxt.gsf_fold + 7) // 8 * 8), dt)
                            if (nxt is not None and nxt.gsf_fold and GS_SLICE) else None)
-                G = gb["out"] if blk.gsf_fold else None
-                steps.append(Step(blk.name + ".bneck", "bneck", lambda x=x, bw=bw, G=G, out=out, xs_next=xs_next: ops.bneck(
-                    x, bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
-                    bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out,
-                    out2=(xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None),
-                    w2_tap_major=bw.fused.w2_tap_major),
-                    2 * M * blk.cout * es + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
-                    2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
+                G = gb["out"] if (blk.gsf_fold and not blend_in) else None
+                o2 = xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None
+                if blend_in:
+                    run = lambda x=x, xg=xg, bw=bw, gb=gb, out=out, o2=o2, F=F, Fp=Fp: ops.bneck_gs(           # noqa: E731
+                        x, xg, gb["gate"], gb["ysum"], gb["xsum"], bw.gs_cw1, bw.gs_cb1, bw.gs_cw2, bw.gs_cb2, T, F, Fp,
+                        bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
+                        bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, out=out, out2=o2, w2_tap_major=bw.fused.w2_tap_major)
+                else:
+                    run = lambda x=x, bw=bw, G=G, out=out, o2=o2: ops.bneck(                                    # noqa: E731
+                        x, bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
+                        bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out, out2=o2, w2_tap_major=bw.fused.w2_tap_major)
+                steps.append(Step(blk.name + ".bneck", "bneck", run,
+                                  (2 * M * blk.cout + (3 * M * Fp if blend_in else 0)) * es
+                                  + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
+                                  2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
                 for t_ in gs_bufs:
                     pool.give(t_)
                 xs = xs_next

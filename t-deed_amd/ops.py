@@ -176,6 +176,22 @@ def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3,
     return out
 
 
+def bneck_gs(x, gx, gate, ysum, xsum, cw1, cb1, cw2, cb2, T, F, Fp, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R,
+             w3f, s3, h3, out=None, out2=None, w2_tap_major=True):
+    """The one-launch bottleneck behind a gate-shift-fuse site with the site's blend inside its frame load
+    (tdeed_bneck_gs_fwd): gx (N,h,w,ldx >= Fp) the slice's source, gate / ysum / xsum from gate_shift_gates.
+    == bneck(x, G=gate_shift(gx, ..., src_order=True)), bit for bit."""
+    _chk(x, "x", torch.bfloat16); _chk(gx, "gx", torch.bfloat16); _chk(out2, "out2", torch.bfloat16)
+    N, h, w, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("tdeed_bneck_gs_fwd", ptr(x), ptr(gx), gx.shape[-1], ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2),
+         ptr(cb2), T, F, Fp, N, h, w, C, ptr(w1f), ptr(s1), ptr(h1), ptr(w2f), ptr(s2), ptr(h2), ptr(se_w1f), ptr(se_b1),
+         ptr(se_w2f), ptr(se_b2), R, ptr(w3f), ptr(s3), ptr(h3), ptr(out), ptr(out2),
+         (out2.shape[-1] if out2 is not None else 0), int(bool(w2_tap_major)), stream_ptr())
+    return out
+
+
 def gemm_ws_fits_mode(K, N, act_dtype):
     """0: no; 1: weights fit LDS (preferred kernel for narrow layers); 2: weights streamed from L2 (wide layers)."""
     return _lib.load().tdeed_gemm_ws_fits(K, N, dtype_code(act_dtype))
@@ -327,10 +343,11 @@ def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
 
 
 def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
-               bufs=None, wqf=None, separate_weight=False, src_order=False):
+               bufs=None, wqf=None, separate_weight=False, src_order=False, gates_only=False):
     """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
     GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out.
-    src_order (GSF, bf16): the output stays in source channel order, out[:, gs_source_order(F)] is the module's output."""
+    src_order (GSF, bf16): the output stays in source channel order, out[:, gs_source_order(F)] is the module's output.
+    gates_only: stop behind the gate launches and return (gate, ysum, xsum) -- the caller's next launch does the blend (bneck_gs)."""
     _chk(x, "x")
     N, h, w, C = x.shape
     dev = x.device
@@ -345,7 +362,7 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     if xsum is None:
         xsum = torch.empty((N, F), dtype=torch.float32, device=dev)
     out = bufs.get("out")
-    if out is None:
+    if out is None and not gates_only:
         out = torch.empty((N * h * w, Fp), dtype=x.dtype, device=dev)
     q = bufs.get("q")
     if q is None:
@@ -353,6 +370,8 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     dc = dtype_code(x.dtype)
     call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
          ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+    if gates_only:
+        return gate, ysum, xsum
     if src_order:
         if cw1 is None or separate_weight or x.dtype != torch.bfloat16:
             raise ValueError("gate_shift: src_order is the fused bf16 GSF launch only")

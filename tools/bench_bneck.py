@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from tdeed_amd import ops, _lib
-from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma
+from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma, pack_gsf_q_frags
+from tdeed_amd.regnet_spec import gsf_fold_dim
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 DEV = "cuda"
@@ -91,3 +92,39 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
     names = ["load x", "conv1", "conv2", "SE + gate", "conv3", "store"]
     print("   phase cycles / 100 (median over workgroups): " + ", ".join(f"{n} {np.median(ph[:, i]):.2f}" for i, n in enumerate(names))
           + f"; workgroup total {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}; first start -> last end {span}", flush=True)
+
+    # ---- behind a gate-shift-fuse site: blend launch + bottleneck against the bottleneck that blends in its frame load
+    T = 100 if N % 100 == 0 else N
+    B, F = N // T, gsf_fold_dim(C)
+    xs = x[..., :Fp].contiguous()
+    w3d = torch.randn(2, F // 2, 3, 3, 3, generator=g) * 0.1
+    f32 = lambda *s_: (torch.randn(s_, generator=g) * 0.3).to(DEV)      # noqa: E731
+    bn_s, bn_b, b3d = f32(F).abs() + 0.5, f32(F), f32(2)
+    cw = [f32(18), f32(1), f32(18), f32(1)]
+    wq, wqf = w3d.reshape(F, 27).t().contiguous().to(DEV), pack_gsf_q_frags(w3d.numpy(), DEV)
+    bufs = dict(gate=torch.empty((N, h, w, 2), device=DEV), q=torch.empty((N, h, w, 6), device=DEV), ysum=torch.empty((N, F), device=DEV),
+                xsum=torch.empty((N, F), device=DEV), out=G)
+    gates = lambda: ops.gate_shift(xs, B, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf, bufs=bufs, gates_only=True)      # noqa: E731
+    gates()
+
+    def two():
+        _lib.call("tdeed_gsf_blend_src_fwd", xs.data_ptr(), bufs["gate"].data_ptr(), bufs["ysum"].data_ptr(), bufs["xsum"].data_ptr(),
+                      *[c.data_ptr() for c in cw], B, T, h, w, Fp, F, Fp, G.data_ptr(), ops.dtype_code(torch.bfloat16), ops.stream_ptr())
+        fused()
+
+    def one():
+        ops.bneck_gs(x, xs, bufs["gate"], bufs["ysum"], bufs["xsum"], *cw, T, F, Fp, w1f, s1, h1, w2f_tm, s2, h2, se["w1f"], b1,
+                     se["w2f"], b2, R, w3f, s3, h3, out=outb, out2=out2)
+
+    se = pack_se_mfma(fc1.numpy(), fc2.numpy(), DEV)
+    tg, t2, t1 = timeit(gates), timeit(two), timeit(one)
+    two(); r2 = outb.clone(); one(); torch.cuda.synchronize()
+    dbg.zero_()
+    _lib.call("tdeed_bneck_set_debug", dbg.data_ptr())
+    one(); torch.cuda.synchronize()
+    _lib.call("tdeed_bneck_set_debug", None)
+    d = dbg.cpu().numpy().astype(np.float64)
+    d = d[(d[:, 0] > 0) & (d[:, 6] > 0)]
+    print(f"   gate-shift-fuse site: gate launches {tg:.1f} us; blend + bottleneck {t2:.1f} us; bottleneck with the blend inside {t1:.1f} us"
+          f" (equal {torch.equal(r2, outb)}); its load phase {np.median(d[:, 1] - d[:, 0]) / 100.0:.2f}, workgroup total"
+          f" {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}", flush=True)
