@@ -205,13 +205,20 @@ int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, i
 /* The same block behind a gate-shift-fuse site (impl/gsf.py:74-93) with the site's last launch -- fusion weights + blend,
  * tdeed_gsf_blend_src_fwd -- done inside the frame load: gx [N][h*w][ldx] is the slice's source (the block input, or the
  * compact copy of its first Fp channels), gate / ysum / xsum are tdeed_gsf_gate_fwd's outputs for the N = B * T frames, cw* / cb*
- * the two fusion convs.  out == tdeed_bneck_fwd(x, G = tdeed_gsf_blend_src_fwd(gx, ...)), bit for bit. */
+ * the two fusion convs.  out == tdeed_bneck_fwd(x, G = tdeed_gsf_blend_src_fwd(gx, ...)), bit for bit.
+ * Q (optional, tdeed_bneck_qtail_fits): the tap maps [N][h*w][6] of the NEXT block's gate-shift site (impl/gsf.py:49-52, the
+ * conv3d as three 2-D convs per frame), made from this block's output rows while they are in LDS -- what the first launch of
+ * tdeed_gsf_gate_fwd computes from `out`, as a 1x1 contraction to per-tap sums plus nine fp32 adds (same products, another
+ * summation order: equal to fp32 rounding); the site then runs tdeed_gsf_gate_sums_fwd only.  q_wqf: the site's weights as
+ * engine.pack_gsf_p_frags lays them out; q_bn [2][8 * ceil(q_F / 8)]: its folded BatchNorm3d scale | shift, zeros behind
+ * channel q_F. */
+int tdeed_bneck_qtail_fits(int h, int w, int C, int F);
 int tdeed_bneck_gs_fwd(const void* x, const void* gx, int ldx, const float* gate, const float* ysum, const float* xsum,
                        const float* cw1, const float* cb1, const float* cw2, const float* cb2, int T, int F, int Fp, int N,
                        int h, int w, int C, const void* w1f, const float* s1, const float* h1, const void* w2f,
                        const float* s2, const float* h2, const void* se_w1f, const float* se_b1, const void* se_w2f,
                        const float* se_b2, int R, const void* w3f, const float* s3, const float* h3, void* out, void* out2,
-                       int n2, int w2_tap_major, void* stream);
+                       int n2, int w2_tap_major, const void* q_wqf, const float* q_bn, int q_F, float* Q, void* stream);
 
 
 /* ---- SE excitation: gate = sigmoid(W2 relu(W1 mean + b1) + b2) -----------------------------
@@ -243,6 +250,10 @@ int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int C, int F,
                        const float* b3d /*[2]*/,
                        float* Q /*scratch fp32 [B*T][h][w][6]*/, float* gate, float* ysum, float* xsum,
                        int dtype, void* stream);
+/* The second launch of tdeed_gsf_gate_fwd alone (gates + spatial sums), for a site whose tap maps Q were made by the launch in
+ * front of it (tdeed_bneck_gs_fwd's Q).  bf16. */
+int tdeed_gsf_gate_sums_fwd(const void* x, int B, int T, int h, int w, int C, int F, const float* b3d, const float* Q,
+                            float* gate, float* ysum, float* xsum, void* stream);
 int tdeed_gsf_weight_fwd(const float* ysum, const float* xsum, int B, int T, int F, int hw,
                          const float* cw1 /*[2][3][3]*/, const float* cb1, const float* cw2,
                          const float* cb2, float* fw /*[B][F][T]*/, void* stream);

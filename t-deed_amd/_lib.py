@@ -69,7 +69,9 @@ _SIGS = {
     "tdeed_bneck_fwd": ([P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int,
                          c_int, P], c_int),
     "tdeed_bneck_gs_fwd": ([P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P,
-                            P, P, P, c_int, P, P, P, P, P, c_int, c_int, P], c_int),
+                            P, P, P, c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, P, P], c_int),
+    "tdeed_bneck_qtail_fits": ([c_int, c_int, c_int, c_int], c_int),
+    "tdeed_gsf_gate_sums_fwd": ([P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P], c_int),
     "tdeed_bn_slabs": ([c_long], c_int),
     "tdeed_bn_train_stats": ([P, c_long, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, P], c_int),
     "tdeed_bn_apply": ([P, c_long, c_int, P, P, P, c_int, P, c_int, P], c_int),

@@ -33,6 +33,14 @@ struct BneckP {
     const float* cw1; const float* cb1; const float* cw2; const float* cb2;
     int T_len, F;
   } gs;
+  // tap maps of the NEXT block's gate-shift site (qt.Q != null): what tdeed_gsf_gate_fwd's first launch (gsf_q_mfma_kernel) would
+  // compute from this block's output, made from the output rows while they are still in LDS -- that launch is gone
+  struct Qt {
+    const bf16x8* wqf;                            // [4][ceil(nch / 4)][64] fragments (engine.pack_gsf_p_frags), nch = ceil(F / 8)
+    const float* bn;                              // [2][8 * nch]: folded BatchNorm3d scale | shift of the site, zeros behind channel F
+    float* Q;                                     // [N][hw][6]
+    int F;
+  } qt;
 };
 
 #define BN_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 16 + (i)] = clock64(); } while (0)
@@ -701,6 +709,37 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
   __syncthreads();
   BN_STAMP(4);
 
+  // the optional tail P6 (tap maps of the next gate-shift site): its requests -- weight fragments, BatchNorm entries -- go out
+  // behind conv3's last contraction block / behind the epilogues, into the registers those leave (behind the output stores of P5
+  // they would wait for the stores' acknowledgements: the tail runs in front of P5)
+  const bool qtail = p.qt.Q != nullptr;
+  const int qF = p.qt.F, nch = (qF + 7) >> 3, KSc = (nch + 3) >> 2, PSQ = (nch | 1) * 16;
+  constexpr int QRSP = 224;                                    // bytes per pixel of the per-tap sums: 54 floats + 2
+  unsigned char* qa = At;                                      // [npix][PSQ]  relu(bn(out[:, :8 nch])) in bf16
+  unsigned char* wl = qa + FPW * hw * PSQ;                     // [4][KSc][64] 16-byte fragments
+  unsigned char* Pl = wl + 4 * KSc * 1024;                     // [npix][QRSP] per-tap sums
+  u32x4 wr[2];
+  f32x4 bs[3][2], bh[3][2];
+  int ipx[3], ick[3];
+  const IDiv dnch(qtail ? nch : 1), dw_(p.w), dhw_(hw);
+  auto q_request = [&]() {                                     // the fragments
+    if (!qtail) return;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) wr[b] = reinterpret_cast<const u32x4*>(p.qt.wqf)[min(tid + b * BNK_THR, 4 * KSc * 64 - 1)];
+  };
+  auto q_request_bn = [&]() {                                  // behind the epilogues (48 registers)
+    if (!qtail) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = min(tid + j * BNK_THR, npix * nch - 1);
+      dnch.divmod(i, ipx[j], ick[j]);
+      const float* bq = p.qt.bn + ick[j] * 8;
+      bs[j][0] = *reinterpret_cast<const f32x4*>(bq);
+      bs[j][1] = *reinterpret_cast<const f32x4*>(bq + 4);
+      bh[j][0] = *reinterpret_cast<const f32x4*>(bq + nch * 8);
+      bh[j][1] = *reinterpret_cast<const f32x4*>(bq + nch * 8 + 4);
+    }
+  };
   // ---- P4: conv3 on the gated y2, + residual x, ReLU -> output rows in region B
   // residual of one channel tile: 4 channels of this lane's pixel per pixel tile, L2-hot
   auto load_res = [&](int T, bf16x4 (&rres)[NPTM]) {
@@ -739,6 +778,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
     load_res(T3B, rB);
     load_res(T3C, rC);
     contract_third(wc3, 2 * KT, At, acc0, acc1, acc2);
+    q_request();
     epi3(T3A, acc0, rA);
     epi3(T3B, acc1, rB);
     if (t3c_ok) epi3(wv + 2 * BNK_NW, acc2, rC);
@@ -758,11 +798,13 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       for (int ks = 0; ks < KS; ++ks) wc3[ks] = p.w3f[((long)TC * KS + ks) * 64 + lane];
     }
     contract_half(wn, KH, At, acc0, acc1);
+    if (!(TC < NT)) q_request();
     epi3(TA, acc0, rA);
     if (TC < NT) load_res(TC, rA);
     epi3(TB, acc1, rB);
     if (TC < NT) {
       contract(wc3, At, acc0);
+      q_request();
       epi3(TC, acc0, rA);
     }
   } else {
@@ -795,9 +837,81 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) wc[ks] = wn[ks];
     }
+    q_request();
   }
+  q_request_bn();
   __syncthreads();
   BN_STAMP(5);
+  // ---- P6 (optional): Q[f][pixel][jg] = conv2d_3x3(relu(bn(out[f][:, :F])), w3d[g][:, j]) for the three temporal taps j and both
+  // gate groups g of the NEXT site (impl/gsf.py:49-52 with the conv3d as three 2-D convs per frame; gsf.hip launch 1a), as
+  //   P[pixel][tap][jg] = sum_c W[jg][tap][c] * a[pixel][c]      one 1x1 contraction on the MFMA pipe, 54 of 64 output rows, then
+  //   Q[pixel][jg]      = sum_tap P[pixel + tap][tap][jg]        nine fp32 adds in tap order, taps outside the frame skipped
+  // -- a third of the implicit GEMM's MFMAs and none of its nine-fold activation reads (that form, measured here first, was bound
+  // by the LDS pipe: 10.7 k cycles per workgroup against the launch it replaced).  Region A is dead and takes all three arrays.
+  if (qtail) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (tid + j * BNK_THR < npix * nch) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Bt + ipx[j] * RS + ick[j] * 16);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16_t)fmaxf(fmaf((float)v[e], bs[j][0][e], bh[j][0][e]), 0.f);
+          o[4 + e] = (bf16_t)fmaxf(fmaf((float)v[4 + e], bs[j][1][e], bh[j][1][e]), 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(qa + ipx[j] * PSQ + ick[j] * 16) = o;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if (tid + b * BNK_THR < 4 * KSc * 64) *reinterpret_cast<u32x4*>(wl + (tid + b * BNK_THR) * 16) = wr[b];
+    __syncthreads();
+    BN_STAMP(8);
+    constexpr int KSCM = (KS + 3) / 4;                           // nch <= KS
+    for (int pt = wv; pt * 16 < npix; pt += BNK_NW) {
+      const int row = min(pt * 16 + pl, npix - 1);
+      f32x4 acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSCM; ++ks) {
+        if (ks < KSc) {                                          // (uniform)
+          const int chunk = 4 * ks + q;                          // chunks behind the slice meet zero weights: any finite operand
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(qa + row * PSQ + (chunk < nch ? chunk : 0) * 16);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wl + ((rt * KSc + ks) * 64 + lane) * 16),
+                                                              av, acc[rt], 0, 0, 0);
+        }
+      }
+      if (pt * 16 + pl < npix) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          if (rt * 16 + 4 * q < 56) *reinterpret_cast<f32x4*>(Pl + row * QRSP + (rt * 16 + 4 * q) * 4) = acc[rt];
+      }
+    }
+    __syncthreads();
+    BN_STAMP(9);
+    {
+      const IDiv d6(6);
+      for (int i = tid; i < npix * 6; i += BNK_THR) {
+        int px, jg, fr, pix, py, pxx;
+        d6.divmod(i, px, jg);
+        dhw_.divmod(px, fr, pix);
+        dw_.divmod(pix, py, pxx);
+        float sum = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+          const bool ok = (unsigned)(py + dy) < (unsigned)p.h && (unsigned)(pxx + dx) < (unsigned)p.w;
+          const float v = *reinterpret_cast<const float*>(Pl + (ok ? px + dy * p.w + dx : px) * QRSP + (tap * 6 + jg) * 4);
+          sum += ok ? v : 0.f;
+        }
+        p.qt.Q[((long)f0 * hw + px) * 6 + jg] = sum;
+      }
+    }
+    BN_STAMP(7);
+  }
   // ---- P5: the output rows leave as whole 16-byte pieces (the frames of a workgroup are contiguous in memory)
   {
     const int cpr = C >> 3;
@@ -885,6 +999,14 @@ static int bneck_fill(BneckP& p, const void* x, int N, int h, int w, int C, cons
   return TDEED_OK;
 }
 
+// 1 when the tap maps of a following gate-shift site of fold F can be made in the launch's tail (tdeed_bneck_gs_fwd's Q)
+extern "C" int tdeed_bneck_qtail_fits(int h, int w, int C, int F) {
+  if (F <= 0 || F % 4 != 0 || 2 * F > C) return 0;
+  const int hw = h * w, fpw = bneck_fpw(hw), nch = (F + 7) / 8, KSc = (nch + 3) / 4, PSQ = (nch | 1) * 16;
+  if (nch > (C + 31) / 32 || 4 * KSc * 64 > 2 * BNK_THR || fpw * hw * nch > 3 * BNK_THR) return 0;          // request slots per thread
+  return (size_t)fpw * hw * (PSQ + 224) + (size_t)4 * KSc * 1024 <= (size_t)fpw * hw * bneck_rs(C) ? 1 : 0;
+}
+
 extern "C" int tdeed_bneck_fwd(const void* x, const void* G, int Fp, int N, int h, int w, int C, const void* w1f,
                                const float* s1, const float* h1, const void* w2f, const float* s2, const float* h2,
                                const void* se_w1f, const float* se_b1, const void* se_w2f, const float* se_b2, int R,
@@ -908,11 +1030,17 @@ extern "C" int tdeed_bneck_gs_fwd(const void* x, const void* gx, int ldx, const 
                                   int N, int h, int w, int C, const void* w1f, const float* s1, const float* h1, const void* w2f,
                                   const float* s2, const float* h2, const void* se_w1f, const float* se_b1, const void* se_w2f,
                                   const float* se_b2, int R, const void* w3f, const float* s3, const float* h3, void* out,
-                                  void* out2, int n2, int w2_tap_major, void* stream) {
+                                  void* out2, int n2, int w2_tap_major, const void* q_wqf, const float* q_bn, int q_F, float* Q,
+                                  void* stream) {
   BneckP p;
   const int rc = bneck_fill(p, x, N, h, w, C, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3, h3, out, out2, n2,
                             w2_tap_major);
   if (rc != TDEED_OK) return rc;
+  if (Q) {
+    TD_CHECK(q_wqf && q_bn, "bneck_gs: tap maps asked for without fragments / BatchNorm table");
+    TD_CHECK(tdeed_bneck_qtail_fits(h, w, C, q_F), "bneck_gs: the tap-map tail does not fit (h=%d w=%d C=%d F=%d)", h, w, C, q_F);
+    p.qt.wqf = (const bf16x8*)q_wqf; p.qt.bn = q_bn; p.qt.Q = Q; p.qt.F = q_F;
+  }
   TD_CHECK(gx && gate && ysum && xsum && cw1 && cb1 && cw2 && cb2, "bneck_gs: null pointer");
   TD_CHECK(F % 4 == 0 && F > 0 && Fp % 8 == 0 && Fp >= F && Fp < F + 8 && 2 * Fp <= C && ldx >= Fp && ldx % 8 == 0,
            "bneck_gs: bad fold F=%d Fp=%d ldx=%d C=%d", F, Fp, ldx, C);

@@ -394,20 +394,50 @@ __global__ __launch_bounds__(256) void gsf_q_mfma_kernel(const bf16_t* __restric
 }
 
 // deterministic spatial sums of gate*x and x over one frame: channel pairs across lanes (coalesced), S pixel slices
-// per pair, 8 pixels of a slice loaded per batch, ordered reduce over the slices.  sg = gates [hw][2] in LDS.
+// per pair, ordered reduce over the slices.  sg = gates [hw][2] in LDS.
+// The frame's values do not depend on the gates: a thread's first GS_NPRE pixels are REQUESTED (gsf_sums_issue) in front of the
+// gate computation, together with the tap maps the gates are made of -- one memory round trip for the launch instead of two
+// (round 6: the launch is a latency chain, 7-9 us per site; slices longer than GS_NPRE pixels take further batches of 8).
+constexpr int GS_NPRE = 24;
 template <typename T>
-__device__ __forceinline__ void gsf_spatial_sums(const T* __restrict__ x, long f, int hw, int C, int F, const float* sg,
-                                                 float* part, float* __restrict__ ysum, float* __restrict__ xsum) {
-  const int Fh = F >> 1, nq = F >> 1;
-  const int S = 256 / nq;
-  int s, cp;
-  IDiv(nq).divmod((int)threadIdx.x, s, cp);
-  if (s < S) {
+struct GsfSums {
+  float v0[GS_NPRE], v1[GS_NPRE];
+  int s, cp, S;
+  bool act;
+};
+template <typename T>
+__device__ __forceinline__ void gsf_sums_issue(GsfSums<T>& st, const T* __restrict__ x, long f, int hw, int C, int F) {
+  const int nq = F >> 1;
+  st.S = 256 / nq;
+  IDiv(nq).divmod((int)threadIdx.x, st.s, st.cp);
+  st.act = st.s < st.S;
+  const T* __restrict__ xf = x + f * hw * C;                    // uniform base, unsigned 32-bit lane offsets
+  const unsigned c2 = 2u * (unsigned)(st.act ? st.cp : 0);
+  const int s0 = st.act ? st.s : 0;
+#pragma unroll
+  for (int b = 0; b < GS_NPRE; ++b) Pair<T>::load(xf + ((unsigned)min(s0 + b * st.S, hw - 1) * (unsigned)C + c2), st.v0[b], st.v1[b]);
+}
+template <typename T>
+__device__ __forceinline__ void gsf_spatial_sums(const GsfSums<T>& st, const T* __restrict__ x, long f, int hw, int C, int F,
+                                                 const float* sg, float* part, float* __restrict__ ysum,
+                                                 float* __restrict__ xsum) {
+  const int Fh = F >> 1;
+  const int S = st.S, s = st.s, cp = st.cp;
+  if (st.act) {
     float y0 = 0.f, y1 = 0.f, x0 = 0.f, x1 = 0.f;
-    const T* __restrict__ xf = x + f * hw * C;                  // uniform base, unsigned 32-bit lane offsets
+    const T* __restrict__ xf = x + f * hw * C;
     const unsigned c2 = 2u * (unsigned)cp;
     const int g = (2 * cp) >= Fh;
-    for (int p0 = s; p0 < hw; p0 += S * 8) {
+#pragma unroll
+    for (int b = 0; b < GS_NPRE; ++b) {
+      const int p = s + b * S;
+      if (p < hw) {
+        const float gt = sg[2 * p + g];
+        x0 += st.v0[b]; x1 += st.v1[b];
+        y0 += st.v0[b] * gt; y1 += st.v1[b] * gt;
+      }
+    }
+    for (int p0 = s + GS_NPRE * S; p0 < hw; p0 += S * 8) {
       float v0[8], v1[8];
 #pragma unroll
       for (int b = 0; b < 8; ++b) Pair<T>::load(xf + ((unsigned)min(p0 + b * S, hw - 1) * (unsigned)C + c2), v0[b], v1[b]);
@@ -457,8 +487,9 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
   const float* __restrict__ Qp = Q + fp * hw * 6;
   const float* __restrict__ Qn = Q + fn * hw * 6;
   float* __restrict__ gout = gate + f * hw * 2;
-  for (int i0 = threadIdx.x; i0 < 2 * hw; i0 += 256 * 4) {
-    float qc[4], qp[4], qn[4];
+  // requests: the first batch of tap-map values, then the frame's values for the sums (they travel while the gates are made)
+  float qc[4], qp[4], qn[4];
+  auto q_issue = [&](int i0) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const unsigned i = (unsigned)min(i0 + b * 256, 2 * hw - 1);
@@ -467,6 +498,13 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
       qp[b] = Qp[o];
       qn[b] = Qn[o + 4u];
     }
+  };
+  q_issue(threadIdx.x);
+  GsfSums<T> st;
+  gsf_sums_issue<T>(st, x, f, hw, C, F);
+  TD_ISSUE_FENCE();
+  for (int i0 = threadIdx.x; i0 < 2 * hw; i0 += 256 * 4) {
+    if (i0 != (int)threadIdx.x) q_issue(i0);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int i = i0 + b * 256;
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(256) void gsf_gate_sums_kernel(const T* __restrict_
     }
   }
   __syncthreads();
-  gsf_spatial_sums<T>(x, f, hw, C, F, sg, part, ysum, xsum);
+  gsf_spatial_sums<T>(st, x, f, hw, C, F, sg, part, ysum, xsum);
 }
 
 // (a merged form of launches 1a + 1b -- every frame staged three times, no Q maps -- was measured twice as slow and is parked:
@@ -575,6 +613,22 @@ extern "C" int tdeed_gsf_gate_fwd(const void* x, int B, int T, int h, int w, int
                        C, F, b3d, gate, ysum, xsum);
   }
   TD_LAUNCH_CHECK("gsf_gate");
+  return TDEED_OK;
+}
+
+// launch 1b alone: the tap maps Q come from elsewhere (the tail of the one-launch bottleneck in front of the site,
+// tdeed_bneck_gs_fwd).  bf16.
+extern "C" int tdeed_gsf_gate_sums_fwd(const void* x, int B, int T, int h, int w, int C, int F, const float* b3d, const float* Q,
+                                       float* gate, float* ysum, float* xsum, void* stream) {
+  TD_CHECK(x && b3d && Q && gate && ysum && xsum, "gsf_gate_sums: null pointer");
+  TD_CHECK(B > 0 && T > 0 && h > 0 && w > 0 && F > 0 && F % 4 == 0 && F <= C && F <= 256,
+           "gsf_gate_sums: bad sizes B=%d T=%d h=%d w=%d C=%d F=%d", B, T, h, w, C, F);
+  const int hw = h * w, S = 256 / (F / 2);
+  const size_t smem2 = (size_t)(2 * hw + 2 * S * F) * sizeof(float);
+  TD_CHECK(smem2 <= 64 * 1024, "gsf_gate_sums: frame too large for the gate/sum pass (%d px)", hw);
+  hipLaunchKernelGGL(gsf_gate_sums_kernel<bf16_t>, dim3(B * T), dim3(256), smem2, (hipStream_t)stream, (const bf16_t*)x, Q, T, hw,
+                     C, F, b3d, gate, ysum, xsum);
+  TD_LAUNCH_CHECK("gsf_gate_sums");
   return TDEED_OK;
 }
 

@@ -339,6 +339,36 @@ def pack_gsf_q_frags(w3d, device):
     return torch.from_numpy(_gsf_q_frags_np(_np(w3d).astype(np.float32))).to(device).to(torch.bfloat16).contiguous()
 
 
+def _gsf_p_frags_np(w3d):
+    Fh = w3d.shape[1]
+    F = 2 * Fh
+    nch = (F + 7) // 8
+    KSc = (nch + 3) // 4
+    fr = np.zeros((4, KSc, 64, 8), np.float32)
+    for rt in range(4):
+        for n in range(16):
+            r = rt * 16 + n
+            if r >= 54:
+                continue
+            tap, jg = divmod(r, 6)
+            dy, dx = divmod(tap, 3)
+            jt, g = divmod(jg, 2)
+            for ks in range(KSc):
+                for q in range(4):
+                    for e in range(8):
+                        c = (4 * ks + q) * 8 + e
+                        if c < F and c // Fh == g:
+                            fr[rt, ks, q * 16 + n, e] = w3d[g, c - g * Fh, jt, dy, dx]
+    return fr
+
+
+def pack_gsf_p_frags(w3d, device):
+    """conv3D.weight [2][F/2][3][3][3] -> bf16 MFMA A fragments [4][ceil(nch/4)][64][8] for the tap-map tail of
+    tdeed_bneck_gs_fwd: row r = tap*6 + jg (jg = 2*j_t + g as in pack_gsf_q_frags; rows 54..63 zero), k = channel,
+    non-zero only for channels of gate group g -- the 3x3x3 conv as ONE 1x1 contraction to per-tap sums."""
+    return torch.from_numpy(_gsf_p_frags_np(_np(w3d).astype(np.float32))).to(device).to(torch.bfloat16).contiguous()
+
+
 def pack_gconv_frags(w, gw, device, tap_major=False):
     """Conv2d.weight [C][gw][3][3] -> bf16 MFMA A-operand fragments [ceil4(C/16)][5][64][8] for
     gconv3x3_mfma_kernel: unit u = output channels [16u,16u+16); lane l holds Wt[n=l&15][k=8(l>>4)+j];
@@ -438,7 +468,9 @@ def _se(pooled, inv_cnt, bw, gate):
 BNECK_ONE_LAUNCH = os.environ.get("TDEED_BNECK", "1") == "1"
 # the gate-shift-fuse blend inside the one-launch bottleneck's frame load (tdeed_bneck_gs_fwd): the site's third launch and the
 # round trip of its output slice are gone
-BNECK_BLEND = os.environ.get("TDEED_BNECK_BLEND", "1") == "1"
+BNECK_BLEND = True
+# ... and the tap maps of the NEXT block's site in the same launch's tail (tdeed_bneck_gs_fwd's Q): that site's first launch is gone
+BNECK_QTAIL = True
 C1_GCONV = os.environ.get("TDEED_C1_GCONV", "1") == "1"           # conv1 (+ downsample) computed inside the grouped conv's launch
 C1_GCONV_MAX_CIN = 160
 
@@ -787,6 +819,8 @@ class PackedWeights:
                 bw.gs_wq = f32(w3d.reshape(F, 27).T)                  # [27][F], c = g*F/2 + cl
                 bw.gs_b3d = f32(sd[gp + ".conv3D.bias"])
                 bw.gs_wqf = pack_gsf_q_frags(w3d, device) if (act_dtype == torch.bfloat16 and str(device) != "cpu") else None
+                bw.gs_bnq = ops.gsq_bn_table(bw.gs_scale, bw.gs_shift) if bw.gs_wqf is not None else None
+                bw.gs_wpf = pack_gsf_p_frags(w3d, device) if bw.gs_wqf is not None else None
                 if self.mode == "gsf":
                     bw.gs_cw1 = f32(sd[gp + ".channel_conv1.weight"].reshape(18))
                     bw.gs_cb1 = f32(sd[gp + ".channel_conv1.bias"])
@@ -872,6 +906,7 @@ class ForwardEngine:
         dt = self.act_dtype
         es = _esz(dt)
         xs = None           # compact copy of the first Fp channels of x, written by the producer of x (see below)
+        q_carry = None      # tap maps of this block's gate-shift site, made in the tail of the bottleneck launch in front of it
         for bi, bw in enumerate(blocks):
             blk = bw.spec
             M = N * h * w
@@ -892,9 +927,12 @@ class ForwardEngine:
                 # the gate-shift launches read only channels [0, Fp): from the compact slice the previous block's conv3 wrote
                 # beside its output when there is one (a slice of the channels-last map drags whole cache lines)
                 xg = xs if (xs is not None and xs.shape[-1] == Fp) else x
-                gb = dict(gate=pool.take((N, h, w, 2), torch.float32), q=pool.take((N, h, w, 6), torch.float32),
+                q_given = q_carry is not None
+                gb = dict(gate=pool.take((N, h, w, 2), torch.float32),
+                          q=(q_carry if q_given else pool.take((N, h, w, 6), torch.float32)),
                           ysum=pool.take((N, F), torch.float32),
                           xsum=pool.take((N, F), torch.float32))
+                q_carry = None
                 # the blend itself runs inside the one-launch bottleneck's frame load when it can (tdeed_bneck_gs_fwd)
                 blend_in = bool(one_launch and BNECK_BLEND and bw.gs_src and bw.gs_cw1 is not None and h * w >= 14
                                 and 2 * Fp <= blk.cin and ("_features." + blk.name + ".gs_out") not in taps)
@@ -902,9 +940,9 @@ class ForwardEngine:
                     gb["out"] = pool.take((M, Fp), dt)
                 if bw.gs_cw1 is not None and not blend_in:
                     gb["fw"] = pool.take((B, F, T), torch.float32)
-                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp, go=blend_in: ops.gate_shift(
+                steps.append(Step(blk.name + ".gate_shift", "gate_shift", lambda x=xg, bw=bw, gb=gb, F=F, Fp=Fp, go=blend_in, qg=q_given: ops.gate_shift(
                     x, B, T, F, Fp, bw.gs_scale, bw.gs_shift, bw.gs_wq, bw.gs_b3d, bw.gs_cw1, bw.gs_cb1,
-                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, src_order=bw.gs_src, gates_only=go),
+                    bw.gs_cw2, bw.gs_cb2, bufs=gb, wqf=bw.gs_wqf, src_order=bw.gs_src, gates_only=go, q_given=qg),
                     M * ((1 if blend_in else 2) * F + (0 if blend_in else Fp)) * es + M * 16, 2 * M * F * 27))
                 if not (one_launch or c1g):
                     steps.append(Step(blk.name + ".conv1", bw.w1.kern(M), lambda x=x, bw=bw, gb=gb, Fp=Fp, y1=y1, M=M: bw.w1.run(
@@ -930,10 +968,17 @@ class ForwardEngine:
                 G = gb["out"] if (blk.gsf_fold and not blend_in) else None
                 o2 = xs_next.view(-1, xs_next.shape[-1]) if xs_next is not None else None
                 if blend_in:
-                    run = lambda x=x, xg=xg, bw=bw, gb=gb, out=out, o2=o2, F=F, Fp=Fp: ops.bneck_gs(           # noqa: E731
+                    # the next site's tap maps in this launch's tail (its input slice is this block's output rows)
+                    qt = None
+                    nbw = blocks[bi + 1] if bi + 1 < len(blocks) else None
+                    if (BNECK_QTAIL and nbw is not None and nxt.gsf_fold and getattr(nbw, "gs_wqf", None) is not None
+                            and xs_next is not None and ops.bneck_qtail_fits(h, w, blk.cout, nxt.gsf_fold)):
+                        q_carry = pool.take((N, h, w, 6), torch.float32)
+                        qt = (nbw.gs_wpf, nbw.gs_bnq, nxt.gsf_fold, q_carry)
+                    run = lambda x=x, xg=xg, bw=bw, gb=gb, out=out, o2=o2, F=F, Fp=Fp, qt=qt: ops.bneck_gs(           # noqa: E731
                         x, xg, gb["gate"], gb["ysum"], gb["xsum"], bw.gs_cw1, bw.gs_cb1, bw.gs_cw2, bw.gs_cb2, T, F, Fp,
                         bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
-                        bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, out=out, out2=o2, w2_tap_major=bw.fused.w2_tap_major)
+                        bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, out=out, out2=o2, w2_tap_major=bw.fused.w2_tap_major, qtail=qt)
                 else:
                     run = lambda x=x, bw=bw, G=G, out=out, o2=o2: ops.bneck(                                    # noqa: E731
                         x, bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,

@@ -177,10 +177,13 @@ def bneck(x, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R, w3f, s3,
 
 
 def bneck_gs(x, gx, gate, ysum, xsum, cw1, cb1, cw2, cb2, T, F, Fp, w1f, s1, h1, w2f, s2, h2, se_w1f, se_b1, se_w2f, se_b2, R,
-             w3f, s3, h3, out=None, out2=None, w2_tap_major=True):
+             w3f, s3, h3, out=None, out2=None, w2_tap_major=True, qtail=None):
     """The one-launch bottleneck behind a gate-shift-fuse site with the site's blend inside its frame load
-    (tdeed_bneck_gs_fwd): gx (N,h,w,ldx >= Fp) the slice's source, gate / ysum / xsum from gate_shift_gates.
-    == bneck(x, G=gate_shift(gx, ..., src_order=True)), bit for bit."""
+    (tdeed_bneck_gs_fwd): gx (N,h,w,ldx >= Fp) the slice's source, gate / ysum / xsum from gate_shift(gates_only=True).
+    == bneck(x, G=gate_shift(gx, ..., src_order=True)), bit for bit.
+    qtail = (wpf, bn, F, Q): also the tap maps Q (N,h,w,6) of the NEXT block's site (fold F, wpf = engine.pack_gsf_p_frags,
+    bn = gsq_bn_table) -- what gate_shift's first launch computes from `out`, in another fp32 summation order; that site then
+    runs gate_shift(q_given=True)."""
     _chk(x, "x", torch.bfloat16); _chk(gx, "gx", torch.bfloat16); _chk(out2, "out2", torch.bfloat16)
     N, h, w, C = x.shape
     if out is None:
@@ -188,8 +191,23 @@ def bneck_gs(x, gx, gate, ysum, xsum, cw1, cb1, cw2, cb2, T, F, Fp, w1f, s1, h1,
     call("tdeed_bneck_gs_fwd", ptr(x), ptr(gx), gx.shape[-1], ptr(gate), ptr(ysum), ptr(xsum), ptr(cw1), ptr(cb1), ptr(cw2),
          ptr(cb2), T, F, Fp, N, h, w, C, ptr(w1f), ptr(s1), ptr(h1), ptr(w2f), ptr(s2), ptr(h2), ptr(se_w1f), ptr(se_b1),
          ptr(se_w2f), ptr(se_b2), R, ptr(w3f), ptr(s3), ptr(h3), ptr(out), ptr(out2),
-         (out2.shape[-1] if out2 is not None else 0), int(bool(w2_tap_major)), stream_ptr())
+         (out2.shape[-1] if out2 is not None else 0), int(bool(w2_tap_major)),
+         *((ptr(qtail[0]), ptr(qtail[1]), int(qtail[2]), ptr(qtail[3])) if qtail is not None else (None, None, 0, None)),
+         stream_ptr())
     return out
+
+
+def bneck_qtail_fits(h, w, C, F):
+    return _lib.load().tdeed_bneck_qtail_fits(h, w, C, F) != 0
+
+
+def gsq_bn_table(bn_scale, bn_shift):
+    """[2][8 * ceil(F / 8)] fp32: the site's folded BatchNorm3d scale | shift, zeros behind channel F (tdeed_bneck_gs_fwd's q_bn)."""
+    F = bn_scale.numel()
+    t = torch.zeros((2, (F + 7) // 8 * 8), dtype=torch.float32, device=bn_scale.device)
+    t[0, :F] = bn_scale
+    t[1, :F] = bn_shift
+    return t
 
 
 def gemm_ws_fits_mode(K, N, act_dtype):
@@ -343,10 +361,11 @@ def se_gate(pooled, inv_cnt, w1t, b1, w2t, b2, out=None):
 
 
 def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, cw2=None, cb2=None,
-               bufs=None, wqf=None, separate_weight=False, src_order=False, gates_only=False):
+               bufs=None, wqf=None, separate_weight=False, src_order=False, gates_only=False, q_given=False):
     """x (B*T,h,w,C) -> (B*T*h*w, Fp): gated/shifted/fused first F channels (+ pad copy).
     GSM when cw1 is None.  bufs: optional dict of preallocated gate/ysum/xsum/fw/out.
     src_order (GSF, bf16): the output stays in source channel order, out[:, gs_source_order(F)] is the module's output.
+    q_given: bufs["q"] already holds the site's tap maps (bneck_gs's qtail): the first launch is skipped.
     gates_only: stop behind the gate launches and return (gate, ysum, xsum) -- the caller's next launch does the blend (bneck_gs)."""
     _chk(x, "x")
     N, h, w, C = x.shape
@@ -368,8 +387,13 @@ def gate_shift(x, B, T, F, Fp, bn_scale, bn_shift, wq, b3d, cw1=None, cb1=None, 
     if q is None:
         q = torch.empty((N, h, w, 6), dtype=torch.float32, device=dev)
     dc = dtype_code(x.dtype)
-    call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
-         ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
+    if q_given:
+        if x.dtype != torch.bfloat16 or bufs.get("q") is None:
+            raise ValueError("gate_shift: q_given needs bufs['q'] and bf16")
+        call("tdeed_gsf_gate_sums_fwd", ptr(x), B, T, h, w, C, F, ptr(b3d), ptr(q), ptr(gate), ptr(ysum), ptr(xsum), stream_ptr())
+    else:
+        call("tdeed_gsf_gate_fwd", ptr(x), B, T, h, w, C, F, ptr(bn_scale), ptr(bn_shift), ptr(wq), ptr(wqf), ptr(b3d),
+             ptr(q), ptr(gate), ptr(ysum), ptr(xsum), dc, stream_ptr())
     if gates_only:
         return gate, ysum, xsum
     if src_order:

@@ -56,6 +56,50 @@ def test_bottleneck_with_the_blend_inside_equals_blend_then_bottleneck(h, w, C, 
     assert torch.equal(out, ref) and torch.equal(out2, out2_ref)
 
 
+@pytest.mark.parametrize("h,w,C,R,B,T", [(7, 7, 368, 92, 3, 7), (14, 14, 152, 38, 2, 5), (7, 7, 368, 92, 8, 100), (13, 14, 152, 38, 3, 3),
+                                         (13, 7, 368, 92, 2, 3), (14, 14, 152, 38, 8, 100)])
+def test_tap_maps_from_the_bottlenecks_tail_equal_the_gate_launch(h, w, C, R, B, T):
+    """tdeed_bneck_gs_fwd's Q: the tap maps of the NEXT site, made from the output rows in LDS (1x1 contraction to per-tap sums +
+    nine adds), against the first launch of tdeed_gsf_gate_fwd run on the block's output (implicit GEMM over (tap, channel)):
+    the same bf16 products in fp32, another summation order -- equal to 2e-6 of the largest map value; the site's second launch
+    alone (tdeed_gsf_gate_sums_fwd) on the launch's own Q equals the two-launch call bit for bit; the block's own outputs are
+    unchanged by the tail."""
+    from tdeed_amd import ops
+    from tdeed_amd.engine import pack_gsf_q_frags, pack_gsf_p_frags
+    from tdeed_amd.regnet_spec import gsf_fold_dim
+    g = torch.Generator().manual_seed(h * 77 + C + B + T)
+    F = gsf_fold_dim(C)
+    Fp = (F + 7) // 8 * 8
+    N = B * T
+    assert ops.bneck_fits(h, w, C, R) and ops.bneck_qtail_fits(h, w, C, F)
+    x = torch.relu(torch.randn(N, h, w, C, generator=g)).to(torch.bfloat16).to(DEV)
+    f32 = lambda *s: (torch.randn(s, generator=g) * 0.3).to(DEV)      # noqa: E731
+
+    def site():
+        w3d = torch.randn(2, F // 2, 3, 3, 3, generator=g) * 0.1
+        return dict(bn_s=f32(F).abs() + 0.5, bn_b=f32(F), b3d=f32(2), cw=[f32(18), f32(1), f32(18), f32(1)],
+                    wq=w3d.reshape(F, 27).t().contiguous().to(DEV), wqf=pack_gsf_q_frags(w3d.numpy(), DEV),
+                    wpf=pack_gsf_p_frags(w3d.numpy(), DEV))
+    s0, s1 = site(), site()
+    blk = _block(g, h, w, C, 8, R)
+    gate, ysum, xsum = ops.gate_shift(x, B, T, F, Fp, s0["bn_s"], s0["bn_b"], s0["wq"], s0["b3d"], *s0["cw"], wqf=s0["wqf"],
+                                      gates_only=True)
+    o2a, o2b = (torch.empty((N * h * w, Fp), dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    ref = ops.bneck_gs(x, x, gate, ysum, xsum, *s0["cw"], T, F, Fp, *blk, out2=o2a)
+    Q = torch.full((N, h, w, 6), float("nan"), device=DEV)
+    out = ops.bneck_gs(x, x, gate, ysum, xsum, *s0["cw"], T, F, Fp, *blk, out2=o2b,
+                       qtail=(s1["wpf"], ops.gsq_bn_table(s1["bn_s"], s1["bn_b"]), F, Q))
+    assert torch.equal(out, ref) and torch.equal(o2a, o2b)
+    bufs = dict(q=torch.empty((N, h, w, 6), device=DEV))
+    g1, y1, x1 = ops.gate_shift(o2a.view(N, h, w, Fp), B, T, F, Fp, s1["bn_s"], s1["bn_b"], s1["wq"], s1["b3d"], *s1["cw"],
+                                wqf=s1["wqf"], bufs=bufs, gates_only=True)
+    assert bool(torch.isfinite(Q).all())
+    assert float((Q - bufs["q"]).abs().max()) <= 2e-6 * float(bufs["q"].abs().max()), float((Q - bufs["q"]).abs().max())
+    g2, y2, x2 = ops.gate_shift(o2a.view(N, h, w, Fp), B, T, F, Fp, s1["bn_s"], s1["bn_b"], s1["wq"], s1["b3d"], *s1["cw"],
+                                wqf=s1["wqf"], bufs=dict(q=bufs["q"].clone()), gates_only=True, q_given=True)
+    assert torch.equal(g1, g2) and torch.equal(y1, y2) and torch.equal(x1, x2)
+
+
 def test_bottleneck_blend_rejects_what_it_cannot_hold():
     from tdeed_amd import ops
     x = torch.zeros((4, 7, 7, 368), dtype=torch.bfloat16, device=DEV)
@@ -65,5 +109,6 @@ def test_bottleneck_blend_rejects_what_it_cannot_hold():
     cw = [z(18), z(1), z(18), z(1)]
     with pytest.raises(RuntimeError, match="whole clips"):
         ops.bneck_gs(x, x, z(4, 7, 7, 2), z(4, 92), z(4, 92), *cw, 3, 92, 96, *blk)
+    assert not ops.bneck_qtail_fits(5, 7, 152, 40)          # two 35-pixel frames of 152 channels: region A is too small for the tail
     with pytest.raises(RuntimeError, match="bad fold"):
         ops.bneck_gs(x, x, z(4, 7, 7, 2), z(4, 92), z(4, 92), *cw, 2, 90, 96, *blk)

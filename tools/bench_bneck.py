@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from tdeed_amd import ops, _lib
-from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma, pack_gsf_q_frags
+from tdeed_amd.engine import pack_mfma_frags, pack_gconv_frags, pack_se_mfma, pack_gsf_q_frags, pack_gsf_p_frags
 from tdeed_amd.regnet_spec import gsf_fold_dim
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
@@ -128,3 +128,23 @@ for (h, w, C, gw, R, Fp) in [(7, 7, 368, 8, 92, 96), (14, 14, 152, 8, 38, 40)]:
     print(f"   gate-shift-fuse site: gate launches {tg:.1f} us; blend + bottleneck {t2:.1f} us; bottleneck with the blend inside {t1:.1f} us"
           f" (equal {torch.equal(r2, outb)}); its load phase {np.median(d[:, 1] - d[:, 0]) / 100.0:.2f}, workgroup total"
           f" {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}", flush=True)
+    # ... and with the next site's tap maps in the tail (stamp 7), against the gate launch's first kernel it replaces
+    Qb = torch.empty((N, h, w, 6), device=DEV)
+    bnq, wpf = ops.gsq_bn_table(bn_s, bn_b), pack_gsf_p_frags(w3d.numpy(), DEV)
+
+    def one_q():
+        ops.bneck_gs(x, xs, bufs["gate"], bufs["ysum"], bufs["xsum"], *cw, T, F, Fp, w1f, s1, h1, w2f_tm, s2, h2, se["w1f"], b1,
+                     se["w2f"], b2, R, w3f, s3, h3, out=outb, out2=out2, qtail=(wpf, bnq, F, Qb))
+
+    sums = lambda: ops.gate_shift(xs, B, T, F, Fp, bn_s, bn_b, wq, b3d, *cw, wqf=wqf, bufs=bufs, gates_only=True, q_given=True)   # noqa: E731
+    tq, ts = timeit(one_q), timeit(sums)
+    dbg.zero_()
+    _lib.call("tdeed_bneck_set_debug", dbg.data_ptr())
+    one_q(); torch.cuda.synchronize()
+    _lib.call("tdeed_bneck_set_debug", None)
+    d = dbg.cpu().numpy().astype(np.float64)
+    d = d[(d[:, 0] > 0) & (d[:, 6] > 0)]
+    print("   tail stamps (cycles): staging + barrier %.0f, contraction + barrier %.0f, nine-tap sums + stores %.0f" % tuple(
+        np.median(d[:, b_] - d[:, a_]) for a_, b_ in ((5, 8), (8, 9), (9, 7))))
+    print(f"   with the tap-map tail {tq:.1f} us (gate launches without their first kernel {ts:.1f} us); tail {np.median(d[:, 7] - d[:, 5]) / 100.0:.2f},"
+          f" stores behind it {np.median(d[:, 6] - d[:, 7]) / 100.0:.2f}, workgroup total {np.median(d[:, 6] - d[:, 0]) / 100.0:.2f}", flush=True)
