@@ -288,6 +288,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
             wgt = sigmoidf_(a);
           }
           srow(rb + 10)[c] = wgt;
+          srow(rb + 11)[c] = 1.0f - wgt;
         }
       }
       __syncthreads();
@@ -301,24 +302,34 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
           const int fs = (FPW > 1 && px >= hw) ? 1 : 0;
           const int t = (f0 + fs) - dgt.div(f0 + fs) * gT;
           const bool has_next = t < gT - 1, has_prev = t > 0;
+          // a PAIR of channels per step (F / 2 is even: a pair never straddles the gate groups or the fold's end), packed fp32
+          // math -- the blend is bound by instruction issue: ~12 operations per element as scalar code, 3 items per thread
           const float* fwl = srow(1 + 12 * fs + 10) + ck * 8;
-          const bf16x8 xc8 = *reinterpret_cast<const bf16x8*>(&bxc[j]);
-          const bf16x8 xn8 = *reinterpret_cast<const bf16x8*>(&bxn[j]);
-          const bf16x8 xp8 = *reinterpret_cast<const bf16x8*>(&bxp[j]);
-          bf16x8 o;
+          const float* oml = srow(1 + 12 * fs + 11) + ck * 8;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(fwl), w1 = *reinterpret_cast<const f32x4*>(fwl + 4);
+          const f32x4 m0 = *reinterpret_cast<const f32x4*>(oml), m1 = *reinterpret_cast<const f32x4*>(oml + 4);
+          const float gn_ = has_next ? bgn[j] : 0.f, gp_ = has_prev ? bgp[j] : 0.f;
+          const bool lo_piece = ck * 8 < gFh;
+          u32x4 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int ci = ck * 8 + e;
-            if (ci >= gF) { o[e] = xc8[e]; continue; }
+          for (int pr = 0; pr < 4; ++pr) {
+            const int ci = ck * 8 + 2 * pr;
             const bool g = ci >= gFh;
-            const float xv = (float)xc8[e];
-            const float r = fmaf(-(g ? bga[j][1] : bga[j][0]), xv, xv);
-            const float gsh = g ? (has_prev ? bgp[j] : 0.f) : (has_next ? bgn[j] : 0.f);
-            const float ysh = gsh * (float)((g && ck * 8 < gFh) ? xp8[e] : xn8[e]);      // g in a "lo" piece: the straddler's upper part
-            const float wv = fwl[e];
-            o[e] = (bf16_t)fmaf(ysh, wv, r * (1.0f - wv));
+            const unsigned xcw = bxc[j][pr], nbw = (g && lo_piece) ? bxp[j][pr] : bxn[j][pr];      // g in a "lo" piece: the straddler's upper part
+            const f32x2 xv = {__builtin_bit_cast(float, xcw << 16), __builtin_bit_cast(float, xcw & 0xffff0000u)};
+            const f32x2 nb = {__builtin_bit_cast(float, nbw << 16), __builtin_bit_cast(float, nbw & 0xffff0000u)};
+            const float gate = g ? bga[j][1] : bga[j][0], gsh = g ? gp_ : gn_;
+            const f32x2 gate2 = {gate, gate}, gsh2 = {gsh, gsh};
+            const f32x2 wv = pr < 2 ? (f32x2){w0[2 * pr], w0[2 * pr + 1]} : (f32x2){w1[2 * pr - 4], w1[2 * pr - 3]};
+            const f32x2 om = pr < 2 ? (f32x2){m0[2 * pr], m0[2 * pr + 1]} : (f32x2){m1[2 * pr - 4], m1[2 * pr - 3]};
+            const f32x2 r = __builtin_elementwise_fma(-gate2, xv, xv);
+            const f32x2 ysh = gsh2 * nb;
+            const f32x2 t = r * om;
+            const f32x2 ov = __builtin_elementwise_fma(ysh, wv, t);
+            const bf16x2 ob = {(bf16_t)ov[0], (bf16_t)ov[1]};
+            o[pr] = ci < gF ? __builtin_bit_cast(unsigned, ob) : xcw;
           }
-          *reinterpret_cast<bf16x8*>(At + px * RS + ck * 16) = o;
+          *reinterpret_cast<u32x4*>(At + px * RS + ck * 16) = o;
         }
       }
     }
