@@ -984,7 +984,9 @@ class ForwardEngine:
                         x, bw.fused.w1f, bw.s1, bw.h1, bw.fused.w2f, bw.s2, bw.h2, bw.se_mf.w1f, bw.se_b1, bw.se_mf.w2f, bw.se_b2,
                         bw.spec.se_rd, bw.fused.w3f, bw.s3, bw.h3, G=G, out=out, out2=o2, w2_tap_major=bw.fused.w2_tap_major)
                 steps.append(Step(blk.name + ".bneck", "bneck", run,
-                                  (2 * M * blk.cout + (3 * M * Fp if blend_in else 0)) * es
+                                  # x in, out; with the blend: each slice piece's temporal neighbour and the gate maps; the tail's Q
+                                  (2 * M * blk.cout + (M * Fp if blend_in else 0)) * es + (8 * M if blend_in else 0)
+                                  + (24 * M if (blend_in and qt is not None) else 0)
                                   + (2 * blk.cout * blk.cout + blk.cout * blk.gw * 9) * es,
                                   2 * M * blk.cout * (2 * blk.cout + blk.gw * 9)))
                 for t_ in gs_bufs:
