@@ -129,3 +129,55 @@ def test_fp32_mode_keeps_dense_weights_as_views():
     assert m.w1.w.data_ptr() == w1.data_ptr() and m.w1.w.dtype == torch.float32
     assert torch.equal(m.w1.wt, w1.reshape(w1.shape[0], -1).t())
     assert torch.bfloat16 not in plan.tables                     # nothing is cast in the fp32 (parity) mode
+
+
+def test_tap_map_fragments_of_both_forms_restate_the_conv3d():
+    """The two MFMA layouts of a gate-shift site's conv3D weights (engine.pack_gsf_q_frags: implicit GEMM over (tap, channel);
+    engine.pack_gsf_p_frags: one 1x1 contraction to per-tap sums, then nine adds -- the tail of tdeed_bneck_gs_fwd), emulated
+    in numpy as the kernels read them, against the conv itself (impl/gsf.py:49-52 per frame: Q[jg] = conv2d(a, w3d[g][:, j]))."""
+    from tdeed_amd.engine import _gsf_q_frags_np, _gsf_p_frags_np
+    rng = np.random.default_rng(5)
+    for F, h, w in ((92, 7, 7), (40, 5, 6), (16, 4, 3)):
+        Fh, nch = F // 2, (F + 7) // 8
+        w3d = rng.standard_normal((2, Fh, 3, 3, 3)).astype(np.float32)
+        a = np.maximum(rng.standard_normal((h, w, nch * 8)), 0).astype(np.float32)
+        a[..., F:] = 0
+        ap = np.pad(a, ((1, 1), (1, 1), (0, 0)))
+        ref = np.zeros((h, w, 6))
+        for jg in range(6):
+            jt, g = divmod(jg, 2)
+            for dy in range(3):
+                for dx in range(3):
+                    ref[..., jg] += ap[dy:dy + h, dx:dx + w, g * Fh:(g + 1) * Fh].astype(np.float64) @ w3d[g, :, jt, dy, dx]
+        # implicit GEMM: k-slot s = 4 ks + q = tap * nch + chunk, lane = q * 16 + row
+        fq = _gsf_q_frags_np(w3d)
+        q1 = np.zeros((h, w, 6))
+        for ks in range(fq.shape[0]):
+            for q in range(4):
+                tap, ck = divmod(4 * ks + q, nch)
+                if tap >= 9:
+                    assert not fq[ks, q * 16:(q + 1) * 16].any()
+                    continue
+                dy, dx = divmod(tap, 3)
+                q1 += ap[dy:dy + h, dx:dx + w, ck * 8:ck * 8 + 8].astype(np.float64) @ fq[ks, q * 16:q * 16 + 6].T
+        # per-tap sums: row r = tap * 6 + jg of row tile r // 16, k = (4 ks + q) * 8 + e = channel
+        fp = _gsf_p_frags_np(w3d)
+        assert fp.shape == (4, (nch + 3) // 4, 64, 8)
+        P = np.zeros((h, w, 64))
+        for rt in range(4):
+            for ks in range(fp.shape[1]):
+                for q in range(4):
+                    ck = 4 * ks + q
+                    blk = fp[rt, ks, q * 16:(q + 1) * 16]                       # [row][e]
+                    if ck >= nch:
+                        assert not blk.any()
+                        continue
+                    P[..., rt * 16:(rt + 1) * 16] += a[..., ck * 8:ck * 8 + 8].astype(np.float64) @ blk.T
+        assert not P[..., 54:].any()
+        Pp = np.pad(P, ((1, 1), (1, 1), (0, 0)))
+        q2 = np.zeros((h, w, 6))
+        for tap in range(9):
+            dy, dx = divmod(tap, 3)
+            q2 += Pp[dy:dy + h, dx:dx + w, tap * 6:tap * 6 + 6]
+        assert np.allclose(q1, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+        assert np.allclose(q2, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
