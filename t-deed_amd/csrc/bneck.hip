@@ -287,6 +287,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
             }
             wgt = sigmoidf_(a);
           }
+          TD_LDS_CHECK((Bt - smem) + (rb + 11) * RS + c * 4, 4, (Zr - smem));
           srow(rb + 10)[c] = wgt;
           srow(rb + 11)[c] = 1.0f - wgt;
         }
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
             const bf16x2 ob = {(bf16_t)ov[0], (bf16_t)ov[1]};
             o[pr] = ci < gF ? __builtin_bit_cast(unsigned, ob) : xcw;
           }
+          TD_LDS_CHECK(px * RS + ck * 16, 16, FPW * hw * RS);
           *reinterpret_cast<u32x4*>(At + px * RS + ck * 16) = o;
         }
       }
@@ -870,12 +872,16 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
           o[e] = (bf16_t)fmaxf(fmaf((float)v[e], bs[j][0][e], bh[j][0][e]), 0.f);
           o[4 + e] = (bf16_t)fmaxf(fmaf((float)v[4 + e], bs[j][1][e], bh[j][1][e]), 0.f);
         }
+        TD_LDS_CHECK(ipx[j] * PSQ + ick[j] * 16, 16, wl - smem);
         *reinterpret_cast<bf16x8*>(qa + ipx[j] * PSQ + ick[j] * 16) = o;
       }
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
-      if (tid + b * BNK_THR < 4 * KSc * 64) *reinterpret_cast<u32x4*>(wl + (tid + b * BNK_THR) * 16) = wr[b];
+      if (tid + b * BNK_THR < 4 * KSc * 64) {
+        TD_LDS_CHECK((wl - smem) + (tid + b * BNK_THR) * 16, 16, Pl - smem);
+        *reinterpret_cast<u32x4*>(wl + (tid + b * BNK_THR) * 16) = wr[b];
+      }
     __syncthreads();
     BN_STAMP(8);
     constexpr int KSCM = (KS + 3) / 4;                           // nch <= KS
@@ -898,7 +904,10 @@ __global__ __launch_bounds__(BNK_THR, 1) void bneck_kernel(const BneckP p) {
       if (pt * 16 + pl < npix) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
-          if (rt * 16 + 4 * q < 56) *reinterpret_cast<f32x4*>(Pl + row * QRSP + (rt * 16 + 4 * q) * 4) = acc[rt];
+          if (rt * 16 + 4 * q < 56) {
+            TD_LDS_CHECK((Pl - smem) + row * QRSP + (rt * 16 + 4 * q) * 4, 16, Bt - smem);
+            *reinterpret_cast<f32x4*>(Pl + row * QRSP + (rt * 16 + 4 * q) * 4) = acc[rt];
+          }
       }
     }
     __syncthreads();

@@ -112,3 +112,31 @@ def test_bottleneck_blend_rejects_what_it_cannot_hold():
     assert not ops.bneck_qtail_fits(5, 7, 152, 40)          # two 35-pixel frames of 152 channels: region A is too small for the tail
     with pytest.raises(RuntimeError, match="bad fold"):
         ops.bneck_gs(x, x, z(4, 7, 7, 2), z(4, 92), z(4, 92), *cw, 2, 90, 96, *blk)
+
+
+def test_whole_forward_with_the_site_fusions_equals_the_forward_without_them(monkeypatch):
+    """RegNetY-200MF + GSF at 224 x 224 (7 x 7 and 14 x 14 one-launch bottlenecks): the plan with the blend inside the
+    bottleneck's frame load equals the plan with the blend launch bit for bit; with the tap maps in the tail as well (another
+    fp32 summation order for seven sites' gates) the logits stay within the bf16 noise of a single rounding flip."""
+    from tdeed_amd import synth, state_layout, engine
+    from tdeed_amd.engine import ForwardEngine
+    cfg = dict(feature_arch="rny002_gsf", clip_len=6, crop_dim=None, n_layers=2, sgp_ks=5, sgp_r=2, num_classes=3,
+               radi_displacement=2)
+    sd = synth.make_state(state_layout.model_state_shapes(cfg), 3)
+    clip = torch.from_numpy(synth.uint8_clip(11, (3, 6, 3, 224, 224))).to(DEV)
+    outs = {}
+    for name, blend, qtail in (("chain", False, False), ("blend", True, False), ("both", True, True)):
+        monkeypatch.setattr(engine, "BNECK_BLEND", blend)
+        monkeypatch.setattr(engine, "BNECK_QTAIL", qtail)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            eng = ForwardEngine(cfg, sd, torch.bfloat16, DEV, use_graph=False)
+            plan = eng.plan(3, 224, 224)
+            kinds = [s.name for s in plan.steps if s.kernel == "bneck"]
+            assert len(kinds) == 9
+            out, _ = eng.forward(clip)
+        torch.cuda.synchronize()
+        outs[name] = out.float().cpu()
+        del eng, plan
+    assert torch.equal(outs["blend"], outs["chain"])
+    scale = float(outs["chain"].abs().max())
+    assert float((outs["both"] - outs["chain"]).abs().max()) < 2e-2 * scale
